@@ -1,0 +1,164 @@
+"""ctypes loading of the two in-tree shared libraries.
+
+libamgsetup.so  host-side setup phase (include/amgsetup.h)
+libamghip.so    gfx950 solve phase    (include/amghip.h)
+
+The product path fails loudly when libamghip.so is missing or there is no GPU:
+there is no CPU fallback for the solve phase.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SETUP_SO = os.path.join(_HERE, "libamgsetup.so")
+HIP_SO = os.path.join(_HERE, "libamghip.so")
+
+i32p = C.POINTER(C.c_int32)
+f64p = C.POINTER(C.c_double)
+i64 = C.c_int64
+vp = C.c_void_p
+
+
+class AMGError(RuntimeError):
+    pass
+
+
+class amgs_options(C.Structure):
+    _fields_ = [("theta", C.c_double), ("max_levels", C.c_int32), ("max_coarse", C.c_int32),
+                ("hermitian", C.c_int32), ("sa_omega", C.c_double), ("sa_improve_iters", C.c_int32),
+                ("sa_B_is_vector", C.c_int32)]
+
+
+class amgh_smoother_t(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("sweep", C.c_int32), ("iter", C.c_int32), ("pad_", C.c_int32),
+                ("omega", C.c_double)]
+
+
+_setup = None
+_hip = None
+
+
+def setup_lib():
+    global _setup
+    if _setup is not None:
+        return _setup
+    if not os.path.exists(SETUP_SO):
+        raise AMGError(f"{SETUP_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(SETUP_SO)
+    L.amgs_last_error.restype = C.c_char_p
+    L.amgs_set_threads.argtypes = [C.c_int]
+    L.amgs_mat_create.restype = vp
+    L.amgs_mat_create.argtypes = [i64, i64, vp, vp, vp]
+    L.amgs_mat_free.argtypes = [vp]
+    for f in ("amgs_mat_rows", "amgs_mat_cols", "amgs_mat_nnz"):
+        getattr(L, f).restype = i64
+        getattr(L, f).argtypes = [vp]
+    for f in ("amgs_mat_colptr", "amgs_mat_rowval", "amgs_mat_nzval"):
+        getattr(L, f).restype = vp
+        getattr(L, f).argtypes = [vp]
+    L.amgs_mat_transpose.restype = vp
+    L.amgs_mat_transpose.argtypes = [vp]
+    L.amgs_mat_spgemm.restype = vp
+    L.amgs_mat_spgemm.argtypes = [vp, vp]
+    L.amgs_mat_is_symmetric.argtypes = [vp]
+    L.amgs_poisson.restype = vp
+    L.amgs_poisson.argtypes = [C.c_int, C.POINTER(i64)]
+    L.amgs_classical_strength.argtypes = [vp, C.c_double, C.POINTER(vp), C.POINTER(vp)]
+    L.amgs_symmetric_strength.restype = vp
+    L.amgs_symmetric_strength.argtypes = [vp, C.c_double, C.c_int]
+    L.amgs_rs_splitting.argtypes = [vp, vp]
+    L.amgs_direct_interpolation.restype = vp
+    L.amgs_direct_interpolation.argtypes = [vp, vp, vp]
+    L.amgs_standard_aggregation.restype = vp
+    L.amgs_standard_aggregation.argtypes = [vp]
+    L.amgs_fit_candidates.restype = vp
+    L.amgs_fit_candidates.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.POINTER(vp), C.POINTER(i64)]
+    L.amgs_jacobi_prolongation.restype = vp
+    L.amgs_jacobi_prolongation.argtypes = [vp, vp, C.c_double]
+    L.amgs_free.argtypes = [vp]
+    L.amgs_default_options_rs.argtypes = [C.POINTER(amgs_options)]
+    L.amgs_default_options_sa.argtypes = [C.POINTER(amgs_options)]
+    L.amgs_ruge_stuben.restype = vp
+    L.amgs_ruge_stuben.argtypes = [vp, C.POINTER(amgs_options)]
+    L.amgs_smoothed_aggregation.restype = vp
+    L.amgs_smoothed_aggregation.argtypes = [vp, vp, C.c_int, C.POINTER(amgs_options)]
+    L.amgs_hier_free.argtypes = [vp]
+    L.amgs_hier_num_levels.argtypes = [vp]
+    L.amgs_hier_get.restype = vp
+    L.amgs_hier_get.argtypes = [vp, C.c_int, C.c_int]
+    _setup = L
+    return L
+
+
+def hip_lib():
+    """Load libamghip.so.  Raises AMGError if it has not been built."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    if not os.path.exists(HIP_SO):
+        raise AMGError(f"{HIP_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the solve phase has no CPU fallback)")
+    L = C.CDLL(HIP_SO)
+    L.amgh_strerror.restype = C.c_char_p
+    L.amgh_strerror.argtypes = [C.c_int]
+    L.amgh_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    L.amgh_destroy.argtypes = [vp]
+    L.amgh_destroy.restype = None
+    L.amgh_push_level.argtypes = [vp, i64, i64] + [vp] * 12 + [C.POINTER(amgh_smoother_t), C.POINTER(amgh_smoother_t)]
+    L.amgh_set_coarse.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.amgh_finalize.argtypes = [vp]
+    L.amgh_num_levels.argtypes = [vp]
+    L.amgh_level_size.restype = i64
+    L.amgh_level_size.argtypes = [vp, C.c_int]
+    L.amgh_device_bytes.restype = i64
+    L.amgh_device_bytes.argtypes = [vp]
+    L.amgh_gs_num_dependency_levels.argtypes = [vp, C.c_int]
+    solve_args = [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, C.POINTER(C.c_int)]
+    L.amgh_solve.argtypes = solve_args
+    L.amgh_solve_d.argtypes = solve_args
+    L.amgh_precond_apply.argtypes = [vp, vp, vp, C.c_int]
+    L.amgh_precond_apply_d.argtypes = [vp, vp, vp, C.c_int]
+    pcg_args = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.POINTER(C.c_int)]
+    L.amgh_pcg.argtypes = pcg_args
+    L.amgh_pcg_d.argtypes = pcg_args
+    L.amgh_level_spmv.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.amgh_level_spmv_d.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.amgh_level_residual_d.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.amgh_level_smooth.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.amgh_level_smooth_d.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.amgh_csr_create.argtypes = [C.POINTER(vp), C.c_int, i64, i64, vp, vp, vp]
+    L.amgh_csr_destroy.argtypes = [vp]
+    L.amgh_csr_destroy.restype = None
+    L.amgh_csr_spmv_d.argtypes = [vp, vp, vp, vp]
+    L.amgh_csr_residual_d.argtypes = [vp, vp, vp, vp, vp]
+    L.amgh_csr_spmv_add_d.argtypes = [vp, vp, vp, vp]
+    L.amgh_csr_jacobi_d.argtypes = [vp, C.c_double, vp, vp, vp, vp]
+    L.amgh_csr_gs_d.argtypes = [vp, C.c_int, C.c_double, C.c_int, vp, vp, vp]
+    L.amgh_dev_alloc.argtypes = [C.c_int, i64, C.POINTER(vp)]
+    L.amgh_dev_free.argtypes = [C.c_int, vp]
+    L.amgh_dev_upload.argtypes = [C.c_int, vp, vp, i64]
+    L.amgh_dev_download.argtypes = [C.c_int, vp, vp, i64]
+    L.amgh_dev_sync.argtypes = [C.c_int]
+    L.amgh_stream.restype = vp
+    L.amgh_stream.argtypes = [vp]
+    L.amgh_timer_begin.argtypes = [vp]
+    L.amgh_timer_end.argtypes = [vp, C.POINTER(C.c_double)]
+    L.amgh_bench_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.amgh_profile_enable.argtypes = [vp, C.c_int]
+    L.amgh_profile_read.argtypes = [vp, vp, C.c_int]
+    L.amgh_set_use_graph.argtypes = [vp, C.c_int]
+    _hip = L
+    return L
+
+
+def hip_check(rc, what=""):
+    if rc != 0:
+        msg = hip_lib().amgh_strerror(rc).decode()
+        raise AMGError(f"libamghip: {what}: {msg} (rc={rc})")
+
+
+def gpu_available():
+    try:
+        return hip_lib().amgh_device_count() > 0
+    except (AMGError, OSError):
+        return False

@@ -1,0 +1,1097 @@
+// amghip.hip — host logic + C ABI of libamghip (see include/amghip.h).
+//
+// The hierarchy (A, S, P, R per level, CSR, int32/f64) lives in HBM; one HIP
+// stream per handle; the cycle of multilevel.jl:214-239 is a host-driven
+// sequence of kernel launches with no host<->device traffic inside it (only the
+// residual norm of multilevel.jl:190 comes back, once per outer iteration).
+//
+// Gauss-Seidel (smoother.jl:61-90) is executed in EXACT lexicographic order by
+// dependency-level scheduling: rows are grouped by the length of their longest
+// dependency chain in the symmetrised pattern, a level-permuted copy of the
+// matrix keeps each group contiguous, wide groups are one coalesced stream-kernel
+// launch each, runs of narrow groups are chained inside one workgroup.  The
+// backward sweep walks the same groups in reverse.
+#include "amghip_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/amghip.h"
+
+using namespace amgh;
+
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return -(1000 + (int)e_);     \
+  } while (0)
+#define RC_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != AMGH_OK) return rc_; \
+  } while (0)
+
+namespace {
+
+template <class T>
+int dev_alloc(T** p, int64_t count) {
+  *p = nullptr;
+  if (count <= 0) count = 1;
+  hipError_t e = hipMalloc((void**)p, sizeof(T) * (size_t)count);
+  if (e == hipErrorOutOfMemory) return AMGH_ENOMEM;
+  if (e != hipSuccess) return -(1000 + (int)e);
+  return AMGH_OK;
+}
+template <class T>
+int dev_upload(T** p, const T* src, int64_t count) {
+  RC_TRY(dev_alloc(p, count));
+  if (count > 0) HIP_TRY(hipMemcpy(*p, src, sizeof(T) * (size_t)count, hipMemcpyHostToDevice));
+  return AMGH_OK;
+}
+inline int grid_for(int64_t n, int threads = 256) {
+  int64_t g = (n + threads - 1) / threads;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, 256 * 8));
+}
+
+// Gauss-Seidel dependency schedule of one square operator.
+struct GsSchedule {
+  int nlev = 0;
+  std::vector<int32_t> lvl_ptr;  // host, nlev+1
+  int32_t* d_lvl_ptr = nullptr;
+  // level-permuted copy of the smoother's matrix
+  int32_t* rowptr = nullptr;
+  int32_t* col = nullptr;
+  double* val = nullptr;
+  int32_t* perm = nullptr;
+  int32_t* dpos = nullptr;
+  double* diag = nullptr;
+  int64_t bytes = 0;
+  struct Seg { int l0, l1; bool chain; };  // dependency levels [l0, l1)
+  std::vector<Seg> segs;
+  void free_dev() {
+    hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
+    hipFree(perm); hipFree(dpos); hipFree(diag);
+    d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = nullptr;
+  }
+};
+
+}  // namespace
+
+struct amgh_csr {
+  int device = 0;
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* col = nullptr;
+  double* val = nullptr;
+  // smoother metadata in natural row order (Jacobi), built on demand
+  int32_t* dpos = nullptr;
+  double* diag = nullptr;
+  GsSchedule* gs = nullptr;
+  int64_t bytes = 0;
+  bool owns = true;
+};
+
+namespace {
+
+constexpr int kChainWidth = 1024;  // dependency levels at most this wide are chained
+
+__global__ void find_diag_kernel(const int32_t* rowptr, const int32_t* col, const double* val, int n,
+                                 int32_t* dpos, double* diag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int dp = -1;
+  double d = 0.0;
+  // the reference keeps the LAST matching entry (d = ifelse(i == row, val, d))
+  for (int j = rowptr[i]; j < rowptr[i + 1]; ++j)
+    if (col[j] == i) { dp = j; d = val[j]; }
+  dpos[i] = dp;
+  diag[i] = d;
+}
+
+int csr_upload(amgh_csr* op, int device, int64_t nrows, int64_t ncols, const int32_t* rowptr,
+               const int32_t* col, const double* val) {
+  if (nrows < 0 || ncols < 0 || !rowptr) return AMGH_EINVAL;
+  if (nrows >= INT32_MAX || ncols >= INT32_MAX) return AMGH_EUNSUPPORTED;
+  const int64_t nnz = rowptr[nrows];
+  if (rowptr[0] != 0 || nnz < 0) return AMGH_EINVAL;
+  if (nnz > 0 && (!col || !val)) return AMGH_EINVAL;
+  op->device = device;
+  op->nrows = nrows;
+  op->ncols = ncols;
+  op->nnz = nnz;
+  RC_TRY(dev_upload(&op->rowptr, rowptr, nrows + 1));
+  RC_TRY(dev_upload(&op->col, col, nnz));
+  RC_TRY(dev_upload(&op->val, val, nnz));
+  op->bytes = (nrows + 1) * 4 + nnz * 12;
+  return AMGH_OK;
+}
+
+void csr_free(amgh_csr* op) {
+  if (!op) return;
+  if (op->owns) { hipFree(op->rowptr); hipFree(op->col); hipFree(op->val); }
+  hipFree(op->dpos); hipFree(op->diag);
+  if (op->gs) { op->gs->free_dev(); delete op->gs; }
+  op->rowptr = op->col = op->dpos = nullptr; op->val = op->diag = nullptr; op->gs = nullptr;
+}
+
+int csr_ensure_diag(amgh_csr* op, hipStream_t st) {
+  if (op->dpos) return AMGH_OK;
+  const int64_t n = std::min(op->nrows, op->ncols);
+  RC_TRY(dev_alloc(&op->dpos, op->nrows));
+  RC_TRY(dev_alloc(&op->diag, op->nrows));
+  if (n < op->nrows) {
+    HIP_TRY(hipMemsetAsync(op->dpos, 0xff, sizeof(int32_t) * op->nrows, st));
+    HIP_TRY(hipMemsetAsync(op->diag, 0, sizeof(double) * op->nrows, st));
+  }
+  if (n > 0)
+    hipLaunchKernelGGL(find_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op->rowptr, op->col,
+                       op->val, (int)n, op->dpos, op->diag);
+  HIP_TRY(hipGetLastError());
+  op->bytes += op->nrows * 12;
+  return AMGH_OK;
+}
+
+// Build the dependency-level schedule from HOST arrays of the smoother matrix.
+int gs_build(GsSchedule* g, int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val) {
+  const int64_t n = nrows;
+  std::vector<int32_t> lev(n, 0);
+  int32_t maxlev = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t li = lev[i];
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t c = col[j];
+      if (c < i) li = std::max(li, lev[c] + 1);
+    }
+    lev[i] = li;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t c = col[j];
+      if (c > i && c < n) lev[c] = std::max(lev[c], li + 1);
+    }
+    maxlev = std::max(maxlev, li);
+  }
+  g->nlev = (int)(maxlev + 1);
+  g->lvl_ptr.assign(g->nlev + 1, 0);
+  for (int64_t i = 0; i < n; ++i) g->lvl_ptr[lev[i] + 1]++;
+  for (int l = 0; l < g->nlev; ++l) g->lvl_ptr[l + 1] += g->lvl_ptr[l];
+  std::vector<int32_t> perm(n), next(g->lvl_ptr.begin(), g->lvl_ptr.end() - (g->nlev > 0 ? 1 : 0));
+  if (g->nlev == 0) next.clear();
+  for (int64_t i = 0; i < n; ++i) perm[next[lev[i]]++] = (int32_t)i;  // ascending row id inside a level
+  std::vector<int32_t>().swap(lev);
+  const int64_t nnz = rowptr[n];
+  std::vector<int32_t> prow(n + 1), pcol(nnz), pdpos(n);
+  std::vector<double> pval(nnz), pdiag(n);
+  int64_t w = 0;
+  prow[0] = 0;
+  for (int64_t p = 0; p < n; ++p) {
+    const int32_t i = perm[p];
+    int32_t dp = -1;
+    double d = 0.0;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      pcol[w] = col[j];
+      pval[w] = val[j];
+      if (col[j] == i) { dp = (int32_t)w; d = val[j]; }
+      ++w;
+    }
+    prow[p + 1] = (int32_t)w;
+    pdpos[p] = dp;
+    pdiag[p] = d;
+  }
+  RC_TRY(dev_upload(&g->rowptr, prow.data(), n + 1));
+  RC_TRY(dev_upload(&g->col, pcol.data(), nnz));
+  RC_TRY(dev_upload(&g->val, pval.data(), nnz));
+  RC_TRY(dev_upload(&g->perm, perm.data(), n));
+  RC_TRY(dev_upload(&g->dpos, pdpos.data(), n));
+  RC_TRY(dev_upload(&g->diag, pdiag.data(), n));
+  RC_TRY(dev_upload(&g->d_lvl_ptr, g->lvl_ptr.data(), g->nlev + 1));
+  g->bytes = (n + 1) * 4 + nnz * 12 + n * 16 + (g->nlev + 1) * 4;
+  // segments: runs of narrow dependency levels are chained in one workgroup
+  g->segs.clear();
+  int l = 0;
+  while (l < g->nlev) {
+    const int width = g->lvl_ptr[l + 1] - g->lvl_ptr[l];
+    if (width <= kChainWidth) {
+      int e = l + 1;
+      while (e < g->nlev && g->lvl_ptr[e + 1] - g->lvl_ptr[e] <= kChainWidth) ++e;
+      g->segs.push_back({l, e, true});
+      l = e;
+    } else {
+      g->segs.push_back({l, l + 1, false});
+      ++l;
+    }
+  }
+  return AMGH_OK;
+}
+
+int csr_ensure_gs(amgh_csr* op) {
+  if (op->gs) return AMGH_OK;
+  const int64_t n = op->nrows;
+  std::vector<int32_t> rowptr(n + 1), col(op->nnz);
+  std::vector<double> val(op->nnz);
+  HIP_TRY(hipMemcpy(rowptr.data(), op->rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
+  if (op->nnz) {
+    HIP_TRY(hipMemcpy(col.data(), op->col, sizeof(int32_t) * op->nnz, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(val.data(), op->val, sizeof(double) * op->nnz, hipMemcpyDeviceToHost));
+  }
+  GsSchedule* g = new GsSchedule;
+  int rc = gs_build(g, n, rowptr.data(), col.data(), val.data());
+  if (rc != AMGH_OK) { g->free_dev(); delete g; return rc; }
+  op->gs = g;
+  op->bytes += g->bytes;
+  return AMGH_OK;
+}
+
+template <int MODE>
+int launch_stream(const StreamArgs& a, hipStream_t st) {
+  const int nrows = a.row_end - a.row_begin;
+  if (nrows <= 0) return AMGH_OK;
+  const int nb = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int per = (nb + kNumXcd - 1) / kNumXcd;
+  hipLaunchKernelGGL(csr_stream_kernel<MODE>, dim3((unsigned)(per * kNumXcd)), dim3(kThreads), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+
+int csr_apply(const amgh_csr* op, int mode, const double* x, const double* b, double* y, hipStream_t st) {
+  StreamArgs a{};
+  a.rowptr = op->rowptr; a.col = op->col; a.val = op->val;
+  a.x = x; a.y = y; a.b = b;
+  a.row_begin = 0; a.row_end = (int32_t)op->nrows;
+  switch (mode) {
+    case M_SPMV: return launch_stream<M_SPMV>(a, st);
+    case M_RESID: return launch_stream<M_RESID>(a, st);
+    case M_ADD: return launch_stream<M_ADD>(a, st);
+  }
+  return AMGH_EINVAL;
+}
+
+int csr_jacobi(amgh_csr* op, double omega, const double* xin, const double* b, double* xout, hipStream_t st) {
+  RC_TRY(csr_ensure_diag(op, st));
+  StreamArgs a{};
+  a.rowptr = op->rowptr; a.col = op->col; a.val = op->val;
+  a.x = xin; a.y = xout; a.b = b; a.dpos = op->dpos; a.diag = op->diag; a.omega = omega;
+  a.row_begin = 0; a.row_end = (int32_t)op->nrows;
+  return launch_stream<M_JACOBI>(a, st);
+}
+
+// One Gauss-Seidel / SOR sweep, forward or backward, exact lexicographic order.
+int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st) {
+  RC_TRY(csr_ensure_gs(op));
+  GsSchedule* g = op->gs;
+  const int ns = (int)g->segs.size();
+  for (int k = 0; k < ns; ++k) {
+    const GsSchedule::Seg& s = g->segs[backward ? ns - 1 - k : k];
+    if (s.chain) {
+      ChainArgs c{};
+      c.rowptr = g->rowptr; c.col = g->col; c.val = g->val; c.x = x; c.b = b;
+      c.dpos = g->dpos; c.diag = g->diag; c.perm = g->perm; c.lvl_ptr = g->d_lvl_ptr; c.omega = omega;
+      if (!backward) { c.lvl_begin = s.l0; c.lvl_end = s.l1; c.step = 1; }
+      else { c.lvl_begin = s.l1 - 1; c.lvl_end = s.l0 - 1; c.step = -1; }
+      if (sor) hipLaunchKernelGGL(gs_chain_kernel<true>, dim3(1), dim3(kChainThreads), 0, st, c);
+      else hipLaunchKernelGGL(gs_chain_kernel<false>, dim3(1), dim3(kChainThreads), 0, st, c);
+      HIP_TRY(hipGetLastError());
+    } else {
+      StreamArgs a{};
+      a.rowptr = g->rowptr; a.col = g->col; a.val = g->val;
+      a.x = x; a.y = x; a.b = b; a.dpos = g->dpos; a.diag = g->diag; a.perm = g->perm; a.omega = omega;
+      a.row_begin = g->lvl_ptr[s.l0]; a.row_end = g->lvl_ptr[s.l0 + 1];
+      RC_TRY(sor ? launch_stream<M_SOR>(a, st) : launch_stream<M_GS>(a, st));
+    }
+  }
+  return AMGH_OK;
+}
+
+struct Level {
+  int64_t n = 0, nc = 0;
+  amgh_csr A, S, P, R;
+  bool has_S = false;  // S distinct from A
+  amgh_smoother_t pre{}, post{};
+  double *res = nullptr, *cx = nullptr, *cb = nullptr, *tmp = nullptr;
+  amgh_csr* smat() { return has_S ? &S : &A; }
+};
+
+}  // namespace
+
+struct amgh_handle {
+  int device = 0;
+  int nrhs = 1;
+  hipStream_t stream = nullptr;
+  std::vector<Level*> levels;
+  // coarsest
+  int64_t ncoarse = -1;
+  amgh_csr finalA;
+  bool has_finalA = false;
+  double* coarse_op = nullptr;
+  double* res_final = nullptr;  // res_vecs[1] when there are no levels
+  bool finalized = false;
+  // reductions / scalars
+  double* partial = nullptr;   // kRedBlocks
+  double* scal = nullptr;      // device scalars: [0] norm/dot out, [1] rho, [2] rho_prev, [3] alpha, [4] beta, [5] tmp
+  // internal fine-level buffers for host-pointer entry points and PCG
+  double *x0 = nullptr, *b0 = nullptr, *pc_r = nullptr, *pc_c = nullptr, *pc_u = nullptr;
+  int64_t ws_bytes = 0;
+  // profiling
+  bool profile = false;
+  std::vector<double> prof_ms;
+  struct Ev { hipEvent_t a, b; int label, level; };
+  std::vector<Ev> pending;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool use_graph = true;
+};
+
+namespace {
+
+int64_t fine_n(const amgh_t* h) { return h->levels.empty() ? h->ncoarse : h->levels[0]->n; }
+
+struct ProfScope {
+  amgh_t* h; int label, level; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(amgh_t* h_, int label_, int level_) : h(h_), label(label_), level(level_) {
+    if (h->profile) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, h->stream); }
+  }
+  ~ProfScope() {
+    if (h->profile) { hipEventRecord(b, h->stream); h->pending.push_back({a, b, label, level}); }
+  }
+};
+
+int prof_flush(amgh_t* h) {
+  if (h->pending.empty()) return AMGH_OK;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int L1 = (int)h->levels.size() + 1;
+  if ((int)h->prof_ms.size() != AMGH_T_COUNT * L1) h->prof_ms.assign(AMGH_T_COUNT * L1, 0.0);
+  for (auto& e : h->pending) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e.a, e.b);
+    h->prof_ms[e.label * L1 + e.level] += ms;
+    hipEventDestroy(e.a); hipEventDestroy(e.b);
+  }
+  h->pending.clear();
+  return AMGH_OK;
+}
+
+int vec_fill(amgh_t* h, double* x, int64_t n, double v) {
+  if (n <= 0) return AMGH_OK;
+  if (v == 0.0) { HIP_TRY(hipMemsetAsync(x, 0, sizeof(double) * n, h->stream)); return AMGH_OK; }
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, x, n, v);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+int vec_copy(amgh_t* h, double* dst, const double* src, int64_t n) {
+  if (n <= 0 || dst == src) return AMGH_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
+  return AMGH_OK;
+}
+// out_d[0] = sum x*y (op 0) or sqrt(sum x*x) (op 1)
+int vec_dot(amgh_t* h, const double* x, const double* y, int64_t n, double* out_d, int op) {
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kThreads - 1) / kThreads));
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, h->stream, x, y, n, h->partial);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, h->stream, h->partial, nb, out_d, op);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+int vec_norm_host(amgh_t* h, const double* x, int64_t n, double* out) {
+  RC_TRY(vec_dot(h, x, x, n, h->scal, 1));
+  HIP_TRY(hipMemcpyAsync(out, h->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return AMGH_OK;
+}
+
+int coarse_solve(amgh_t* h, double* x, const double* b) {
+  const int n = (int)h->ncoarse;
+  if (n <= 0) return AMGH_OK;
+  hipLaunchKernelGGL(dense_gemv_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->coarse_op, b, x, n);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+
+// smooth!(x, smoother, b).  `xc` is the buffer that currently holds x; Jacobi
+// sweeps ping-pong between xc and xo (swapped in place).
+int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& xo, const double* b) {
+  amgh_csr* M = L->smat();
+  for (int it = 0; it < s.iter; ++it) {
+    switch (s.kind) {
+      case AMGH_SMOOTH_NONE: break;
+      case AMGH_SMOOTH_JACOBI:
+        RC_TRY(csr_jacobi(M, s.omega, xc, b, xo, h->stream));
+        std::swap(xc, xo);
+        break;
+      case AMGH_SMOOTH_GS:
+      case AMGH_SMOOTH_SOR: {
+        const bool sor = s.kind == AMGH_SMOOTH_SOR;
+        if (s.sweep == AMGH_SWEEP_FORWARD || s.sweep == AMGH_SWEEP_SYMMETRIC)
+          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream));
+        if (s.sweep == AMGH_SWEEP_BACKWARD || s.sweep == AMGH_SWEEP_SYMMETRIC)
+          RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream));
+        break;
+      }
+      default: return AMGH_EINVAL;
+    }
+  }
+  return AMGH_OK;
+}
+
+int cycle(amgh_t* h, int l, double* x, const double* b, int cyc);
+
+// __solve_next! (multilevel.jl:200-212)
+int cycle_next(amgh_t* h, int l, double* x, const double* b, int cyc) {
+  switch (cyc) {
+    case AMGH_CYCLE_V: return cycle(h, l, x, b, AMGH_CYCLE_V);
+    case AMGH_CYCLE_W:
+      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_W));
+      return cycle(h, l, x, b, AMGH_CYCLE_W);
+    case AMGH_CYCLE_F:
+      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_F));
+      return cycle(h, l, x, b, AMGH_CYCLE_V);
+  }
+  return AMGH_EINVAL;
+}
+
+// __solve! (multilevel.jl:214-239)
+int cycle(amgh_t* h, int l, double* x, const double* b, int cyc) {
+  Level* L = h->levels[l];
+  double* xc = x;
+  double* xo = L->tmp;
+  {
+    ProfScope p(h, AMGH_T_PRESMOOTH, l);
+    RC_TRY(smooth(h, L, L->pre, xc, xo, b));
+  }
+  {
+    ProfScope p(h, AMGH_T_RESIDUAL, l);
+    RC_TRY(csr_apply(&L->A, M_RESID, xc, b, L->res, h->stream));
+  }
+  {
+    ProfScope p(h, AMGH_T_RESTRICT, l);
+    RC_TRY(csr_apply(&L->R, M_SPMV, L->res, nullptr, L->cb, h->stream));
+  }
+  RC_TRY(vec_fill(h, L->cx, L->nc, 0.0));
+  if (l == (int)h->levels.size() - 1) {
+    ProfScope p(h, AMGH_T_COARSE, l + 1);
+    RC_TRY(coarse_solve(h, L->cx, L->cb));
+  } else {
+    RC_TRY(cycle_next(h, l + 1, L->cx, L->cb, cyc));
+  }
+  {
+    ProfScope p(h, AMGH_T_PROLONG, l);
+    RC_TRY(csr_apply(&L->P, M_ADD, L->cx, nullptr, xc, h->stream));
+  }
+  {
+    ProfScope p(h, AMGH_T_POSTSMOOTH, l);
+    RC_TRY(smooth(h, L, L->post, xc, xo, b));
+  }
+  if (xc != x) RC_TRY(vec_copy(h, x, xc, L->n));
+  return AMGH_OK;
+}
+
+// one application of the hierarchy: a cycle, or the coarse solve if no levels
+int apply_once(amgh_t* h, double* x, const double* b, int cyc) {
+  if (h->levels.empty()) {
+    ProfScope p(h, AMGH_T_COARSE, 0);
+    return coarse_solve(h, x, b);
+  }
+  return cycle(h, 0, x, b, cyc);
+}
+
+int fine_residual(amgh_t* h, const double* x, const double* b, double* r) {
+  if (h->levels.empty()) {
+    if (!h->has_finalA) return AMGH_ESTATE;
+    return csr_apply(&h->finalA, M_RESID, x, b, r, h->stream);
+  }
+  return csr_apply(&h->levels[0]->A, M_RESID, x, b, r, h->stream);
+}
+int fine_spmv(amgh_t* h, const double* x, double* y) {
+  if (h->levels.empty()) {
+    if (!h->has_finalA) return AMGH_ESTATE;
+    return csr_apply(&h->finalA, M_SPMV, x, nullptr, y, h->stream);
+  }
+  return csr_apply(&h->levels[0]->A, M_SPMV, x, nullptr, y, h->stream);
+}
+
+// _solve! (multilevel.jl:158-198) on device pointers
+int solve_dev(amgh_t* h, const double* b, double* x, int cyc, int maxiter, double abstol, double reltol,
+              int calc_res, double* hist, int* iters) {
+  const int64_t n = fine_n(h);
+  double normb = 0.0;
+  RC_TRY(vec_norm_host(h, b, n, &normb));
+  double normres = normb;
+  if (normb != 0.0) abstol = std::max(reltol * normb, abstol);
+  if (hist) hist[0] = normb;
+  double* res = h->levels.empty() ? h->res_final : h->levels[0]->res;
+  int itr = 1;
+  while (itr <= maxiter && (!calc_res || normres > abstol)) {
+    RC_TRY(apply_once(h, x, b, cyc));
+    if (calc_res) {
+      RC_TRY(fine_residual(h, x, b, res));
+      RC_TRY(vec_norm_host(h, res, n, &normres));
+      if (hist) hist[itr] = normres;
+    }
+    ++itr;
+  }
+  if (iters) *iters = itr - 1;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  RC_TRY(prof_flush(h));
+  return AMGH_OK;
+}
+
+int scal_div(amgh_t* h, int out, int a, int b) {
+  hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(1), 0, h->stream, h->scal + out, h->scal + a, h->scal + b, 0);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+int scal_copy(amgh_t* h, int out, int a) {
+  hipLaunchKernelGGL(scalar_kernel, dim3(1), dim3(1), 0, h->stream, h->scal + out, h->scal + a, h->scal + a, 1);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+
+// Preconditioned CG, IterativeSolvers.jl `cg(A, b; Pl)` recurrence (x0 = 0):
+//   c = Pl \ r ; rho_prev = rho ; rho = c.r ; beta = rho/rho_prev ; u = c + beta u
+//   c = A u ; alpha = rho / u.c ; x += alpha u ; r -= alpha c ; residual = |r|
+// stop when residual <= max(reltol*|r0|, abstol) or maxiter reached.
+int pcg_dev(amgh_t* h, const double* b, double* x, int cyc, int use_precond, int maxiter, double abstol,
+            double reltol, double* hist, int* iters) {
+  const int64_t n = fine_n(h);
+  double* r = h->pc_r; double* c = h->pc_c; double* u = h->pc_u;
+  RC_TRY(vec_fill(h, x, n, 0.0));
+  RC_TRY(vec_fill(h, u, n, 0.0));
+  RC_TRY(vec_copy(h, r, b, n));
+  double residual = 0.0;
+  RC_TRY(vec_norm_host(h, r, n, &residual));
+  const double tol = std::max(reltol * residual, abstol);
+  if (hist) hist[0] = residual;
+  const double one = 1.0;
+  HIP_TRY(hipMemcpyAsync(h->scal + 1, &one, sizeof(double), hipMemcpyHostToDevice, h->stream));  // rho = 1
+  int it = 0;
+  while (it < maxiter && residual > tol) {
+    if (use_precond) {
+      RC_TRY(vec_fill(h, c, n, 0.0));
+      RC_TRY(apply_once(h, c, r, cyc));
+    } else {
+      RC_TRY(vec_copy(h, c, r, n));
+    }
+    RC_TRY(scal_copy(h, 2, 1));                 // rho_prev = rho
+    RC_TRY(vec_dot(h, c, r, n, h->scal + 1, 0)); // rho = c.r
+    RC_TRY(scal_div(h, 4, 1, 2));               // beta = rho / rho_prev
+    hipLaunchKernelGGL(xpby_dev_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, u, c, h->scal + 4, n);
+    RC_TRY(fine_spmv(h, u, c));                 // c = A u
+    RC_TRY(vec_dot(h, u, c, n, h->scal + 5, 0));
+    RC_TRY(scal_div(h, 3, 1, 5));               // alpha = rho / u.c
+    hipLaunchKernelGGL(axpy_dev_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, x, u, h->scal + 3, 1.0, n);
+    hipLaunchKernelGGL(axpy_dev_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, r, c, h->scal + 3, -1.0, n);
+    HIP_TRY(hipGetLastError());
+    RC_TRY(vec_norm_host(h, r, n, &residual));
+    ++it;
+    if (hist) hist[it] = residual;
+  }
+  if (iters) *iters = it;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  RC_TRY(prof_flush(h));
+  return AMGH_OK;
+}
+
+int check_ready(const amgh_t* h) {
+  if (!h) return AMGH_EINVAL;
+  if (!h->finalized) return AMGH_ESTATE;
+  return AMGH_OK;
+}
+
+bool smoother_valid(const amgh_smoother_t* s) {
+  if (!s) return false;
+  if (s->kind < AMGH_SMOOTH_NONE || s->kind > AMGH_SMOOTH_SOR) return false;
+  if (s->iter < 0) return false;
+  if ((s->kind == AMGH_SMOOTH_GS || s->kind == AMGH_SMOOTH_SOR) &&
+      (s->sweep < AMGH_SWEEP_FORWARD || s->sweep > AMGH_SWEEP_SYMMETRIC)) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* amgh_strerror(int rc) {
+  static thread_local char buf[160];
+  switch (rc) {
+    case AMGH_OK: return "ok";
+    case AMGH_EINVAL: return "invalid argument";
+    case AMGH_ESTATE: return "invalid state (not finalized, already finalized, or operator missing)";
+    case AMGH_ENOMEM: return "out of device memory";
+    case AMGH_EUNSUPPORTED: return "unsupported configuration";
+  }
+  if (rc <= -1000) {
+    snprintf(buf, sizeof buf, "HIP error %d: %s", -rc - 1000, hipGetErrorString((hipError_t)(-rc - 1000)));
+    return buf;
+  }
+  snprintf(buf, sizeof buf, "unknown error %d", rc);
+  return buf;
+}
+
+int amgh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int amgh_create(amgh_t** hp, int device, int nrhs) {
+  if (!hp) return AMGH_EINVAL;
+  *hp = nullptr;
+  if (nrhs != 1) return AMGH_EUNSUPPORTED;  // bs > 1 (SpMM variants) not built yet
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(device));
+  amgh_t* h = new amgh_t;
+  h->device = device;
+  h->nrhs = nrhs;
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return -(1000 + (int)e); }
+  hipEventCreate(&h->t0);
+  hipEventCreate(&h->t1);
+  *hp = h;
+  return AMGH_OK;
+}
+
+void amgh_destroy(amgh_t* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (Level* L : h->levels) {
+    csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R);
+    hipFree(L->res); hipFree(L->cx); hipFree(L->cb); hipFree(L->tmp);
+    delete L;
+  }
+  csr_free(&h->finalA);
+  hipFree(h->coarse_op); hipFree(h->res_final); hipFree(h->partial); hipFree(h->scal);
+  hipFree(h->x0); hipFree(h->b0); hipFree(h->pc_r); hipFree(h->pc_c); hipFree(h->pc_u);
+  for (auto& e : h->pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  if (h->t0) hipEventDestroy(h->t0);
+  if (h->t1) hipEventDestroy(h->t1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, const int32_t* A_col,
+                    const double* A_val, const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
+                    const int32_t* P_rowptr, const int32_t* P_col, const double* P_val, const int32_t* R_rowptr,
+                    const int32_t* R_col, const double* R_val, const amgh_smoother_t* pre,
+                    const amgh_smoother_t* post) {
+  if (!h || n <= 0 || nc < 0 || !A_rowptr || !P_rowptr || !R_rowptr) return AMGH_EINVAL;
+  if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
+  if (h->finalized) return AMGH_ESTATE;
+  if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
+  if (P_rowptr[n] != R_rowptr[nc]) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  Level* L = new Level;
+  L->n = n; L->nc = nc; L->pre = *pre; L->post = *post;
+  int rc = csr_upload(&L->A, h->device, n, n, A_rowptr, A_col, A_val);
+  if (rc == AMGH_OK && S_rowptr) {
+    L->has_S = true;
+    rc = csr_upload(&L->S, h->device, n, n, S_rowptr, S_col, S_val);
+  }
+  if (rc == AMGH_OK) rc = csr_upload(&L->P, h->device, n, nc, P_rowptr, P_col, P_val);
+  if (rc == AMGH_OK) rc = csr_upload(&L->R, h->device, nc, n, R_rowptr, R_col, R_val);
+  const bool need_gs = pre->kind == AMGH_SMOOTH_GS || pre->kind == AMGH_SMOOTH_SOR ||
+                       post->kind == AMGH_SMOOTH_GS || post->kind == AMGH_SMOOTH_SOR;
+  if (rc == AMGH_OK && need_gs) {
+    // schedule built from the host arrays while we still have them
+    amgh_csr* M = L->smat();
+    GsSchedule* g = new GsSchedule;
+    rc = L->has_S ? gs_build(g, n, S_rowptr, S_col, S_val) : gs_build(g, n, A_rowptr, A_col, A_val);
+    if (rc == AMGH_OK) { M->gs = g; M->bytes += g->bytes; }
+    else { g->free_dev(); delete g; }
+  }
+  if (rc != AMGH_OK) {
+    csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R);
+    delete L;
+    return rc;
+  }
+  h->levels.push_back(L);
+  return AMGH_OK;
+}
+
+int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
+                    const double* dense_op) {
+  if (!h || n < 0 || !dense_op) return AMGH_EINVAL;
+  if (h->finalized || h->ncoarse >= 0) return AMGH_ESTATE;
+  if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
+  if (n > 46000) return AMGH_EUNSUPPORTED;  // dense n*n operator
+  HIP_TRY(hipSetDevice(h->device));
+  RC_TRY(dev_upload(&h->coarse_op, dense_op, n * n));
+  if (A_rowptr) {
+    RC_TRY(csr_upload(&h->finalA, h->device, n, n, A_rowptr, A_col, A_val));
+    h->has_finalA = true;
+  }
+  h->ncoarse = n;
+  return AMGH_OK;
+}
+
+int amgh_finalize(amgh_t* h) {
+  if (!h) return AMGH_EINVAL;
+  if (h->finalized || h->ncoarse < 0) return AMGH_ESTATE;
+  if (h->levels.empty() && !h->has_finalA) return AMGH_ESTATE;
+  HIP_TRY(hipSetDevice(h->device));
+  int64_t ws = 0;
+  for (Level* L : h->levels) {
+    RC_TRY(dev_alloc(&L->res, L->n));
+    RC_TRY(dev_alloc(&L->cx, L->nc));
+    RC_TRY(dev_alloc(&L->cb, L->nc));
+    ws += 8 * (L->n + 2 * L->nc);
+    if (L->pre.kind == AMGH_SMOOTH_JACOBI || L->post.kind == AMGH_SMOOTH_JACOBI) {
+      RC_TRY(dev_alloc(&L->tmp, L->n));
+      ws += 8 * L->n;
+      RC_TRY(csr_ensure_diag(L->smat(), h->stream));
+    }
+  }
+  const int64_t n = fine_n(h);
+  if (h->levels.empty()) { RC_TRY(dev_alloc(&h->res_final, n)); ws += 8 * n; }
+  RC_TRY(dev_alloc(&h->partial, kRedBlocks));
+  RC_TRY(dev_alloc(&h->scal, 8));
+  RC_TRY(dev_alloc(&h->x0, n));
+  RC_TRY(dev_alloc(&h->b0, n));
+  ws += 16 * n;
+  h->ws_bytes = ws;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->finalized = true;
+  return AMGH_OK;
+}
+
+int amgh_num_levels(const amgh_t* h) { return h ? (int)h->levels.size() : 0; }
+int64_t amgh_level_size(const amgh_t* h, int l) {
+  if (!h || l < 0 || l > (int)h->levels.size()) return -1;
+  return l == (int)h->levels.size() ? h->ncoarse : h->levels[l]->n;
+}
+int64_t amgh_device_bytes(const amgh_t* h) {
+  if (!h) return 0;
+  int64_t b = h->ws_bytes + (h->ncoarse > 0 ? h->ncoarse * h->ncoarse * 8 : 0) + h->finalA.bytes;
+  for (Level* L : h->levels) b += L->A.bytes + L->S.bytes + L->P.bytes + L->R.bytes;
+  return b;
+}
+int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
+  if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
+  amgh_csr* M = h->levels[l]->smat();
+  return M->gs ? M->gs->nlev : 0;
+}
+
+static int ensure_pcg_bufs(amgh_t* h) {
+  if (h->pc_r) return AMGH_OK;
+  const int64_t n = fine_n(h);
+  RC_TRY(dev_alloc(&h->pc_r, n));
+  RC_TRY(dev_alloc(&h->pc_c, n));
+  RC_TRY(dev_alloc(&h->pc_u, n));
+  h->ws_bytes += 24 * n;
+  return AMGH_OK;
+}
+
+int amgh_solve_d(amgh_t* h, const double* b_d, double* x_d, int cycle_, int maxiter, double abstol, double reltol,
+                 int calculate_residual, double* resid_hist, int* iters) {
+  RC_TRY(check_ready(h));
+  if (!b_d || !x_d || cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  return solve_dev(h, b_d, x_d, cycle_, maxiter, abstol, reltol, calculate_residual, resid_hist, iters);
+}
+
+int amgh_solve(amgh_t* h, const double* b, double* x, int cycle_, int maxiter, double abstol, double reltol,
+               int calculate_residual, double* resid_hist, int* iters) {
+  RC_TRY(check_ready(h));
+  if (!b || !x || cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  const int64_t n = fine_n(h);
+  HIP_TRY(hipMemcpyAsync(h->b0, b, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->x0, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  RC_TRY(solve_dev(h, h->b0, h->x0, cycle_, maxiter, abstol, reltol, calculate_residual, resid_hist, iters));
+  HIP_TRY(hipMemcpy(x, h->x0, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return AMGH_OK;
+}
+
+int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle_) {
+  RC_TRY(check_ready(h));
+  if (!r_d || !z_d || cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  RC_TRY(vec_fill(h, z_d, fine_n(h), 0.0));
+  return apply_once(h, z_d, r_d, cycle_);
+}
+
+int amgh_precond_apply(amgh_t* h, const double* r, double* z, int cycle_) {
+  RC_TRY(check_ready(h));
+  if (!r || !z) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  const int64_t n = fine_n(h);
+  HIP_TRY(hipMemcpyAsync(h->b0, r, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  RC_TRY(amgh_precond_apply_d(h, h->b0, h->x0, cycle_));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  RC_TRY(prof_flush(h));
+  HIP_TRY(hipMemcpy(z, h->x0, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return AMGH_OK;
+}
+
+int amgh_pcg_d(amgh_t* h, const double* b_d, double* x_d, int cycle_, int use_precond, int maxiter, double abstol,
+               double reltol, double* resid_hist, int* iters) {
+  RC_TRY(check_ready(h));
+  if (!b_d || !x_d || cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  RC_TRY(ensure_pcg_bufs(h));
+  return pcg_dev(h, b_d, x_d, cycle_, use_precond, maxiter, abstol, reltol, resid_hist, iters);
+}
+
+int amgh_pcg(amgh_t* h, const double* b, double* x, int cycle_, int use_precond, int maxiter, double abstol,
+             double reltol, double* resid_hist, int* iters) {
+  RC_TRY(check_ready(h));
+  if (!b || !x) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  const int64_t n = fine_n(h);
+  HIP_TRY(hipMemcpyAsync(h->b0, b, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  RC_TRY(amgh_pcg_d(h, h->b0, h->x0, cycle_, use_precond, maxiter, abstol, reltol, resid_hist, iters));
+  HIP_TRY(hipMemcpy(x, h->x0, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return AMGH_OK;
+}
+
+static amgh_csr* level_op(amgh_t* h, int level, int which) {
+  const int L = (int)h->levels.size();
+  if (level == L && which == AMGH_OP_A && h->has_finalA) return &h->finalA;
+  if (level < 0 || level >= L) return nullptr;
+  switch (which) {
+    case AMGH_OP_A: return &h->levels[level]->A;
+    case AMGH_OP_P: return &h->levels[level]->P;
+    case AMGH_OP_R: return &h->levels[level]->R;
+  }
+  return nullptr;
+}
+
+int amgh_level_spmv_d(amgh_t* h, int level, int which, const double* x_d, double* y_d) {
+  RC_TRY(check_ready(h));
+  amgh_csr* op = level_op(h, level, which);
+  if (!op || !x_d || !y_d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  RC_TRY(csr_apply(op, M_SPMV, x_d, nullptr, y_d, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return AMGH_OK;
+}
+
+int amgh_level_spmv(amgh_t* h, int level, int which, const double* x, double* y) {
+  RC_TRY(check_ready(h));
+  amgh_csr* op = level_op(h, level, which);
+  if (!op || !x || !y) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  double *xd = nullptr, *yd = nullptr;
+  RC_TRY(dev_upload(&xd, x, op->ncols));
+  int rc = dev_alloc(&yd, op->nrows);
+  if (rc == AMGH_OK) rc = csr_apply(op, M_SPMV, xd, nullptr, yd, h->stream);
+  if (rc == AMGH_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = -1000 - (int)hipGetLastError();
+  if (rc == AMGH_OK && hipMemcpy(y, yd, sizeof(double) * op->nrows, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
+  hipFree(xd); hipFree(yd);
+  return rc;
+}
+
+int amgh_level_residual_d(amgh_t* h, int level, const double* x_d, const double* b_d, double* r_d) {
+  RC_TRY(check_ready(h));
+  amgh_csr* op = level_op(h, level, AMGH_OP_A);
+  if (!op || !x_d || !b_d || !r_d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  RC_TRY(csr_apply(op, M_RESID, x_d, b_d, r_d, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return AMGH_OK;
+}
+
+static int level_smooth_enqueue(amgh_t* h, int level, int post, double* x_d, const double* b_d) {
+  Level* L = h->levels[level];
+  const amgh_smoother_t& s = post ? L->post : L->pre;
+  double* xc = x_d;
+  double* xo = L->tmp;
+  if (s.kind == AMGH_SMOOTH_JACOBI && !xo) return AMGH_ESTATE;
+  RC_TRY(smooth(h, L, s, xc, xo, b_d));
+  if (xc != x_d) RC_TRY(vec_copy(h, x_d, xc, L->n));
+  return AMGH_OK;
+}
+
+int amgh_level_smooth_d(amgh_t* h, int level, int post, double* x_d, const double* b_d) {
+  RC_TRY(check_ready(h));
+  if (level < 0 || level >= (int)h->levels.size() || !x_d || !b_d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  RC_TRY(level_smooth_enqueue(h, level, post, x_d, b_d));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return AMGH_OK;
+}
+
+int amgh_level_smooth(amgh_t* h, int level, int post, double* x, const double* b) {
+  RC_TRY(check_ready(h));
+  if (level < 0 || level >= (int)h->levels.size() || !x || !b) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  const int64_t n = h->levels[level]->n;
+  double *xd = nullptr, *bd = nullptr;
+  RC_TRY(dev_upload(&xd, x, n));
+  int rc = dev_upload(&bd, b, n);
+  if (rc == AMGH_OK) rc = level_smooth_enqueue(h, level, post, xd, bd);
+  if (rc == AMGH_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = -1001;
+  if (rc == AMGH_OK && hipMemcpy(x, xd, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
+  hipFree(xd); hipFree(bd);
+  return rc;
+}
+
+// ---- stand-alone operators ------------------------------------------------
+int amgh_csr_create(amgh_csr_t** opp, int device, int64_t nrows, int64_t ncols, const int32_t* rowptr,
+                    const int32_t* col, const double* val) {
+  if (!opp) return AMGH_EINVAL;
+  *opp = nullptr;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(device));
+  amgh_csr* op = new amgh_csr;
+  int rc = csr_upload(op, device, nrows, ncols, rowptr, col, val);
+  if (rc != AMGH_OK) { csr_free(op); delete op; return rc; }
+  *opp = op;
+  return AMGH_OK;
+}
+void amgh_csr_destroy(amgh_csr_t* op) {
+  if (!op) return;
+  hipSetDevice(op->device);
+  csr_free(op);
+  delete op;
+}
+int amgh_csr_spmv_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream) {
+  if (!op || !x_d || !y_d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(op->device));
+  return csr_apply(op, M_SPMV, x_d, nullptr, y_d, (hipStream_t)stream);
+}
+int amgh_csr_residual_d(amgh_csr_t* op, const double* x_d, const double* b_d, double* r_d, void* stream) {
+  if (!op || !x_d || !b_d || !r_d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(op->device));
+  return csr_apply(op, M_RESID, x_d, b_d, r_d, (hipStream_t)stream);
+}
+int amgh_csr_spmv_add_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream) {
+  if (!op || !x_d || !y_d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(op->device));
+  return csr_apply(op, M_ADD, x_d, nullptr, y_d, (hipStream_t)stream);
+}
+int amgh_csr_jacobi_d(amgh_csr_t* op, double omega, const double* xin_d, const double* b_d, double* xout_d,
+                      void* stream) {
+  if (!op || !xin_d || !b_d || !xout_d || xin_d == xout_d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(op->device));
+  return csr_jacobi(op, omega, xin_d, b_d, xout_d, (hipStream_t)stream);
+}
+int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d, const double* b_d,
+                  void* stream) {
+  if (!op || !x_d || !b_d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(op->device));
+  return csr_gs_sweep(op, backward != 0, is_sor != 0, omega, x_d, b_d, (hipStream_t)stream);
+}
+
+// ---- device memory + timing helpers ----------------------------------------
+int amgh_dev_alloc(int device, int64_t bytes, void** ptr_d) {
+  if (!ptr_d || bytes < 0) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(device));
+  char* p = nullptr;
+  RC_TRY(dev_alloc(&p, bytes));
+  *ptr_d = p;
+  return AMGH_OK;
+}
+int amgh_dev_free(int device, void* ptr_d) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipFree(ptr_d));
+  return AMGH_OK;
+}
+int amgh_dev_upload(int device, void* dst_d, const void* src, int64_t bytes) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst_d, src, (size_t)bytes, hipMemcpyHostToDevice));
+  return AMGH_OK;
+}
+int amgh_dev_download(int device, void* dst, const void* src_d, int64_t bytes) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst, src_d, (size_t)bytes, hipMemcpyDeviceToHost));
+  return AMGH_OK;
+}
+int amgh_dev_sync(int device) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipDeviceSynchronize());
+  return AMGH_OK;
+}
+void* amgh_stream(amgh_t* h) { return h ? (void*)h->stream : nullptr; }
+
+int amgh_timer_begin(amgh_t* h) {
+  if (!h) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventRecord(h->t0, h->stream));
+  return AMGH_OK;
+}
+int amgh_timer_end(amgh_t* h, double* ms) {
+  if (!h || !ms) return AMGH_EINVAL;
+  HIP_TRY(hipEventRecord(h->t1, h->stream));
+  HIP_TRY(hipEventSynchronize(h->t1));
+  float f = 0.f;
+  HIP_TRY(hipEventElapsedTime(&f, h->t0, h->t1));
+  *ms = f;
+  return AMGH_OK;
+}
+
+int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double* avg_ms) {
+  RC_TRY(check_ready(h));
+  if (!avg_ms || reps <= 0 || warmup < 0) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  amgh_csr* op = level_op(h, level, which <= AMGH_OP_R ? which : AMGH_OP_A);
+  if (!op) return AMGH_EINVAL;
+  double *x = nullptr, *y = nullptr, *b = nullptr;
+  const int64_t nx = std::max(op->ncols, op->nrows);
+  RC_TRY(dev_alloc(&x, nx));
+  RC_TRY(dev_alloc(&y, nx));
+  RC_TRY(dev_alloc(&b, nx));
+  // deterministic non-trivial contents (a zero fill would flatter DVFS)
+  {
+    std::vector<double> hx(nx);
+    uint64_t s = 0x9E3779B97F4A7C15ull;
+    for (int64_t i = 0; i < nx; ++i) {
+      s += 0x9E3779B97F4A7C15ull;
+      uint64_t z = s;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      hx[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    }
+    hipMemcpy(x, hx.data(), sizeof(double) * nx, hipMemcpyHostToDevice);
+    hipMemcpy(b, hx.data(), sizeof(double) * nx, hipMemcpyHostToDevice);
+    hipMemcpy(y, hx.data(), sizeof(double) * nx, hipMemcpyHostToDevice);
+  }
+  int rc = AMGH_OK;
+  auto run = [&]() -> int {
+    if (which <= AMGH_OP_R) return csr_apply(op, M_SPMV, x, nullptr, y, h->stream);
+    if (which == 3) return csr_apply(op, M_RESID, x, b, y, h->stream);
+    if (which == 4) {
+      if (level >= (int)h->levels.size()) return AMGH_EINVAL;
+      return level_smooth_enqueue(h, level, 0, y, b);
+    }
+    return AMGH_EINVAL;
+  };
+  for (int i = 0; i < warmup && rc == AMGH_OK; ++i) rc = run();
+  if (rc == AMGH_OK) {
+    hipEventRecord(h->t0, h->stream);
+    for (int i = 0; i < reps && rc == AMGH_OK; ++i) rc = run();
+    hipEventRecord(h->t1, h->stream);
+    hipEventSynchronize(h->t1);
+    float f = 0.f;
+    hipEventElapsedTime(&f, h->t0, h->t1);
+    *avg_ms = (double)f / reps;
+  }
+  hipFree(x); hipFree(y); hipFree(b);
+  return rc;
+}
+
+int amgh_profile_enable(amgh_t* h, int on) {
+  if (!h) return AMGH_EINVAL;
+  h->profile = on != 0;
+  return AMGH_OK;
+}
+int amgh_profile_read(amgh_t* h, double* out, int reset) {
+  if (!h || !out) return AMGH_EINVAL;
+  RC_TRY(prof_flush(h));
+  const int L1 = (int)h->levels.size() + 1;
+  if ((int)h->prof_ms.size() != AMGH_T_COUNT * L1) h->prof_ms.assign(AMGH_T_COUNT * L1, 0.0);
+  std::copy(h->prof_ms.begin(), h->prof_ms.end(), out);
+  if (reset) std::fill(h->prof_ms.begin(), h->prof_ms.end(), 0.0);
+  return AMGH_OK;
+}
+int amgh_set_use_graph(amgh_t* h, int on) {
+  if (!h) return AMGH_EINVAL;
+  h->use_graph = on != 0;
+  return AMGH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1014 @@
+// amg_setup.cpp — host-side AMG setup phase (CPU, C++17 + OpenMP).
+//
+// Builds the Multilevel/Level hierarchy (A, P, R per level) that the HIP
+// V-cycle in libamghip consumes.  Behavioural restatement of the reference's
+// setup phase, written against its documented semantics; every routine cites
+// the reference lines it follows (paths relative to /root/reference).  All
+// matrices are compressed sparse COLUMN (colptr/rowval/nzval) exactly as the
+// reference holds them, but 0-based with int32 indices.
+//
+// Not on the GPU hot path (sequential graph
+// algorithms, run once).  See include/amgsetup.h for the C ABI.
+
+#include "../../../include/amgsetup.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+struct amgs_mat {
+  int64_t m = 0, n = 0;  // rows, cols
+  std::vector<int32_t> colptr;  // n+1
+  std::vector<int32_t> rowval;
+  std::vector<double> nzval;
+  int64_t nnz() const { return (int64_t)rowval.size(); }
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+using Mat = amgs_mat;
+using MatP = std::unique_ptr<Mat>;
+
+constexpr int F_NODE = 0, C_NODE = 1, U_NODE = 2;  // splitting.jl:1-3
+
+void check_nnz(int64_t nnz) {
+  if (nnz >= (int64_t)std::numeric_limits<int32_t>::max())
+    throw std::runtime_error("matrix exceeds int32 nnz range");
+}
+
+MatP make(int64_t m, int64_t n) {
+  MatP A(new Mat);
+  A->m = m;
+  A->n = n;
+  A->colptr.assign(n + 1, 0);
+  return A;
+}
+
+// dropzeros!(A): remove stored entries whose value is exactly zero.
+void dropzeros(Mat& A) {
+  int64_t w = 0;
+  int32_t start = 0;
+  for (int64_t j = 0; j < A.n; ++j) {
+    int32_t end = A.colptr[j + 1];
+    for (int32_t k = start; k < end; ++k) {
+      if (A.nzval[k] != 0.0) {
+        A.rowval[w] = A.rowval[k];
+        A.nzval[w] = A.nzval[k];
+        ++w;
+      }
+    }
+    start = end;
+    A.colptr[j + 1] = (int32_t)w;
+  }
+  A.rowval.resize(w);
+  A.nzval.resize(w);
+}
+
+// copy(A') — counting-sort transpose; rows inside each output column ascend.
+MatP transpose(const Mat& A) {
+  MatP T = make(A.n, A.m);
+  const int64_t nnz = A.nnz();
+  T->rowval.resize(nnz);
+  T->nzval.resize(nnz);
+  std::vector<int32_t>& tp = T->colptr;
+  for (int64_t k = 0; k < nnz; ++k) tp[A.rowval[k] + 1]++;
+  for (int64_t i = 0; i < A.m; ++i) tp[i + 1] += tp[i];
+  std::vector<int32_t> next(tp.begin(), tp.end() - 1);
+  for (int64_t j = 0; j < A.n; ++j) {
+    for (int32_t k = A.colptr[j]; k < A.colptr[j + 1]; ++k) {
+      int32_t p = next[A.rowval[k]]++;
+      T->rowval[p] = (int32_t)j;
+      T->nzval[p] = A.nzval[k];
+    }
+  }
+  return T;
+}
+
+// X*Y for CSC operands (SparseArrays spmatmul semantics): column j of the
+// product accumulates, for k ascending over Y[:,j] and i ascending over X[:,k],
+// acc[i] += X[i,k]*Y[k,j].  Structural zeros are kept; rows come out sorted.
+MatP spgemm(const Mat& X, const Mat& Y) {
+  if (X.n != Y.m) throw std::runtime_error("spgemm: dimension mismatch");
+  const int64_t m = X.m, n = Y.n;
+  MatP C = make(m, n);
+  std::vector<int32_t> cnt(n, 0);
+  // pass 1: structural count per column
+#pragma omp parallel
+  {
+    std::vector<int32_t> mark(m, -1);
+#pragma omp for schedule(dynamic, 1024)
+    for (int64_t j = 0; j < n; ++j) {
+      int32_t c = 0;
+      for (int32_t p = Y.colptr[j]; p < Y.colptr[j + 1]; ++p) {
+        int32_t k = Y.rowval[p];
+        for (int32_t q = X.colptr[k]; q < X.colptr[k + 1]; ++q) {
+          int32_t i = X.rowval[q];
+          if (mark[i] != (int32_t)j) {
+            mark[i] = (int32_t)j;
+            ++c;
+          }
+        }
+      }
+      cnt[j] = c;
+    }
+  }
+  int64_t total = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    C->colptr[j] = (int32_t)total;
+    total += cnt[j];
+    check_nnz(total);
+  }
+  C->colptr[n] = (int32_t)total;
+  C->rowval.resize(total);
+  C->nzval.resize(total);
+  // pass 2: numeric
+#pragma omp parallel
+  {
+    std::vector<int32_t> mark(m, -1);
+    std::vector<double> acc(m, 0.0);
+#pragma omp for schedule(dynamic, 1024)
+    for (int64_t j = 0; j < n; ++j) {
+      int32_t base = C->colptr[j], c = 0;
+      for (int32_t p = Y.colptr[j]; p < Y.colptr[j + 1]; ++p) {
+        int32_t k = Y.rowval[p];
+        double ykj = Y.nzval[p];
+        for (int32_t q = X.colptr[k]; q < X.colptr[k + 1]; ++q) {
+          int32_t i = X.rowval[q];
+          if (mark[i] != (int32_t)j) {
+            mark[i] = (int32_t)j;
+            C->rowval[base + c++] = i;
+            acc[i] = X.nzval[q] * ykj;
+          } else {
+            acc[i] += X.nzval[q] * ykj;
+          }
+        }
+      }
+      std::sort(C->rowval.begin() + base, C->rowval.begin() + base + c);
+      for (int32_t t = 0; t < c; ++t) C->nzval[base + t] = acc[C->rowval[base + t]];
+    }
+  }
+  return C;
+}
+
+// ---- gallery.jl:1-63 ---------------------------------------------------
+// poisson((n1,..,nN)): 2N on the diagonal, -1 per axis neighbour, Dirichlet
+// truncation, linear index first-axis-fastest (LinearIndices, gallery.jl:14).
+MatP poisson(int ndim, const int64_t* dims) {
+  if (ndim < 1 || ndim > 8) throw std::runtime_error("poisson: bad ndim");
+  int64_t n = 1;
+  std::vector<int64_t> stride(ndim);
+  for (int d = 0; d < ndim; ++d) {
+    if (dims[d] < 1) throw std::runtime_error("poisson: bad dims");
+    stride[d] = n;
+    n *= dims[d];
+  }
+  check_nnz(n * (2 * ndim + 1));
+  MatP A = make(n, n);
+  // count
+  std::vector<int64_t> idx(ndim, 0);
+  int64_t nnz = 0;
+  // column j: neighbours sorted ascending = [-stride[N-1],...,-stride[0], 0,
+  // +stride[0],...,+stride[N-1]] where in-bounds.
+  A->rowval.reserve(n * (2 * ndim + 1));
+  A->nzval.reserve(n * (2 * ndim + 1));
+  for (int64_t j = 0; j < n; ++j) {
+    for (int d = ndim - 1; d >= 0; --d)
+      if (idx[d] > 0) {
+        A->rowval.push_back((int32_t)(j - stride[d]));
+        A->nzval.push_back(-1.0);
+      }
+    A->rowval.push_back((int32_t)j);
+    A->nzval.push_back(2.0 * ndim);
+    for (int d = 0; d < ndim; ++d)
+      if (idx[d] + 1 < dims[d]) {
+        A->rowval.push_back((int32_t)(j + stride[d]));
+        A->nzval.push_back(-1.0);
+      }
+    nnz = (int64_t)A->rowval.size();
+    A->colptr[j + 1] = (int32_t)nnz;
+    for (int d = 0; d < ndim; ++d) {  // increment first-axis-fastest
+      if (++idx[d] < dims[d]) break;
+      idx[d] = 0;
+    }
+  }
+  // a size-1 axis contributes nothing but the 2 on the diagonal (stencil_grid
+  // bounds check), already handled.
+  return A;
+}
+
+// ---- strength.jl:7-70 : Classical(theta)(At) ---------------------------
+void scale_cols_by_largest_entry(Mat& A) {  // strength.jl:61-70, find_max :50-58
+  for (int64_t i = 0; i < A.m && i < A.n; ++i) {  // n = size(A,1)
+    double mx = 0.0;
+    for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) mx = std::max(mx, A.nzval[j]);
+    for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) A.nzval[j] /= mx;
+  }
+}
+
+void classical_strength(const Mat& At, double theta, MatP& S, MatP& T) {
+  T.reset(new Mat(At));
+  const int64_t n = At.n;
+  for (int64_t i = 0; i < n; ++i) {
+    double mx = 0.0;  // find_max_off_diag, strength.jl:39-48
+    for (int32_t j = T->colptr[i]; j < T->colptr[i + 1]; ++j)
+      if (T->rowval[j] != i) mx = std::max(mx, std::fabs(T->nzval[j]));
+    double thr = theta * mx;
+    for (int32_t j = T->colptr[i]; j < T->colptr[i + 1]; ++j) {
+      if (T->rowval[j] != i) {
+        double v = T->nzval[j];
+        T->nzval[j] = (std::fabs(v) >= thr) ? std::fabs(v) : 0.0;
+      }
+    }
+  }
+  dropzeros(*T);
+  scale_cols_by_largest_entry(*T);
+  S = transpose(*T);
+}
+
+// ---- strength.jl:77-122 : SymmetricStrength(theta)(A, bsr_flag) --------
+MatP symmetric_strength(const Mat& A, double theta, bool bsr_flag) {
+  MatP S(new Mat(A));
+  if (bsr_flag && theta == 0.0) {  // strength.jl:81-84: pattern of A, all ones
+    std::fill(S->nzval.begin(), S->nzval.end(), 1.0);
+    return S;
+  }
+  const int64_t n = A.m;
+  std::vector<double> diags(n, 0.0);
+  for (int64_t i = 0; i < n && i < A.n; ++i) {
+    double d = 0.0;
+    for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j)
+      if (A.rowval[j] == i) d += A.nzval[j];
+    diags[i] = std::fabs(d);
+  }
+  for (int64_t i = 0; i < n && i < A.n; ++i) {
+    double eps_Aii = theta * theta * diags[i];
+    for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) {
+      int32_t row = A.rowval[j];
+      double v = A.nzval[j];
+      if (row != i && v * v < eps_Aii * diags[row]) S->nzval[j] = 0.0;
+    }
+  }
+  dropzeros(*S);
+  for (double& v : S->nzval) v = std::fabs(v);
+  scale_cols_by_largest_entry(*S);
+  return S;
+}
+
+// ---- splitting.jl:8-159 : RS() -----------------------------------------
+void remove_diag(Mat& a) {  // splitting.jl:8-18
+  for (int64_t i = 0; i < a.n; ++i)
+    for (int32_t j = a.colptr[i]; j < a.colptr[i + 1]; ++j)
+      if (a.rowval[j] == i) a.nzval[j] = 0.0;
+  dropzeros(a);
+}
+
+// RS_CF_splitting(S, T = copy(S')).  Index bookkeeping kept 1-based (arrays
+// sized n+2) so the bucket arithmetic mirrors splitting.jl:25-159 literally;
+// tie-breaking depends on it (ref_split_test.txt / thing.jl goldens).
+void rs_cf_splitting(const Mat& S, const Mat& T, int32_t* splitting_out) {
+  const int64_t n = S.m;
+  std::vector<int64_t> lambda(n + 2, 0), interval_ptr(n + 3, 0), interval_count(n + 3, 0);
+  std::vector<int64_t> index_to_node(n + 2, 0), node_to_index(n + 2, 0);
+  std::vector<int8_t> splitting(n + 2, U_NODE);
+  const int32_t* Sp = S.colptr.data();
+  const int32_t* Sj = S.rowval.data();
+  const int32_t* Tp = T.colptr.data();
+  const int32_t* Tj = T.rowval.data();
+
+  for (int64_t i = 1; i <= n; ++i) {
+    lambda[i] = Sp[i] - Sp[i - 1];
+    interval_count[lambda[i] + 1] += 1;
+  }
+  // accumulate!(+, interval_ptr[2:end], interval_count[1:end-1])
+  {
+    int64_t s = 0;
+    for (int64_t k = 1; k <= n; ++k) {
+      s += interval_count[k];
+      interval_ptr[k + 1] = s;
+    }
+  }
+  std::fill(interval_count.begin(), interval_count.end(), 0);
+  for (int64_t i = 1; i <= n; ++i) {
+    int64_t li = lambda[i] + 1;
+    interval_count[li] += 1;
+    int64_t index = interval_ptr[li] + interval_count[li];
+    index_to_node[index] = i;
+    node_to_index[i] = index;
+  }
+  for (int64_t i = 1; i <= n; ++i)
+    if (lambda[i] == 0) splitting[i] = F_NODE;
+
+  for (int64_t top_index = n; top_index >= 1; --top_index) {
+    int64_t i = index_to_node[top_index];
+    int64_t li = lambda[i] + 1;
+    interval_count[li] -= 1;
+    if (splitting[i] == F_NODE) continue;
+    // splitting[i] == U_NODE here (splitting.jl:95)
+    splitting[i] = C_NODE;
+    for (int32_t j = Sp[i - 1]; j < Sp[i]; ++j) {
+      int64_t row = (int64_t)Sj[j] + 1;
+      if (splitting[row] == U_NODE) {
+        splitting[row] = F_NODE;
+        for (int32_t k = Tp[row - 1]; k < Tp[row]; ++k) {
+          int64_t rowk = (int64_t)Tj[k] + 1;
+          if (splitting[rowk] == U_NODE) {
+            if (lambda[rowk] >= n - 1) continue;
+            int64_t lk = lambda[rowk] + 1;
+            int64_t old_pos = node_to_index[rowk];
+            int64_t new_pos = interval_ptr[lk] + interval_count[lk];
+            int64_t swap_node = index_to_node[new_pos];
+            index_to_node[old_pos] = swap_node;
+            index_to_node[new_pos] = rowk;
+            node_to_index[rowk] = new_pos;
+            node_to_index[swap_node] = old_pos;
+            lambda[rowk] += 1;
+            interval_count[lk] -= 1;
+            interval_count[lk + 1] += 1;
+            interval_ptr[lk + 1] = new_pos - 1;
+          }
+        }
+      }
+    }
+    for (int32_t j = Tp[i - 1]; j < Tp[i]; ++j) {
+      int64_t row = (int64_t)Tj[j] + 1;
+      if (splitting[row] == U_NODE) {
+        if (lambda[row] == 0) continue;
+        int64_t lj = lambda[row] + 1;
+        int64_t old_pos = node_to_index[row];
+        int64_t new_pos = interval_ptr[lj] + 1;
+        int64_t swap_node = index_to_node[new_pos];
+        index_to_node[old_pos] = swap_node;
+        index_to_node[new_pos] = row;
+        node_to_index[row] = new_pos;
+        node_to_index[swap_node] = old_pos;
+        lambda[row] -= 1;
+        interval_count[lj] -= 1;
+        interval_count[lj - 1] += 1;
+        interval_ptr[lj] += 1;
+      }
+    }
+  }
+  for (int64_t i = 1; i <= n; ++i) splitting_out[i - 1] = splitting[i];
+}
+
+void rs_splitting(Mat& S, int32_t* splitting) {  // splitting.jl:20-23
+  remove_diag(S);
+  MatP T = transpose(S);
+  rs_cf_splitting(S, *T, splitting);
+}
+
+// ---- classical.jl:57-189 : direct_interpolation ------------------------
+// Returns R (n_c x n, one column per fine node); P = R'.
+MatP direct_interpolation(const Mat& At, const Mat& Tin, const int32_t* splitting) {
+  const int64_t n = At.m;
+  // T .= At .* pattern(T)  (classical.jl:58-60): At's values on T's pattern,
+  // numerically-zero products are not stored.
+  Mat T;
+  T.m = Tin.m;
+  T.n = Tin.n;
+  T.colptr.assign(T.n + 1, 0);
+  T.rowval.reserve(Tin.nnz());
+  T.nzval.reserve(Tin.nnz());
+  for (int64_t i = 0; i < Tin.n; ++i) {
+    int32_t a = At.colptr[i], ae = At.colptr[i + 1];
+    for (int32_t t = Tin.colptr[i]; t < Tin.colptr[i + 1]; ++t) {
+      int32_t row = Tin.rowval[t];
+      while (a < ae && At.rowval[a] < row) ++a;
+      if (a < ae && At.rowval[a] == row) {
+        double v = At.nzval[a] * 1.0;
+        if (v != 0.0) {
+          T.rowval.push_back(row);
+          T.nzval.push_back(v);
+        }
+      }
+    }
+    T.colptr[i + 1] = (int32_t)T.rowval.size();
+  }
+
+  // pass 1 (classical.jl:71-89)
+  std::vector<int32_t> Bp(n + 1, 0);
+  int64_t nnzc = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (splitting[i] == C_NODE) {
+      nnzc += 1;
+    } else {
+      for (int32_t j = T.colptr[i]; j < T.colptr[i + 1]; ++j)
+        if (splitting[T.rowval[j]] == C_NODE) nnzc += 1;
+    }
+    check_nnz(nnzc);
+    Bp[i + 1] = (int32_t)nnzc;
+  }
+  // pass 2 (classical.jl:92-189)
+  std::vector<double> Bx(nnzc, 0.0);
+  std::vector<int32_t> Bj(nnzc, 0);
+  const double eps = std::numeric_limits<double>::epsilon();
+  for (int64_t i = 0; i < n; ++i) {
+    if (splitting[i] == C_NODE) {
+      Bj[Bp[i]] = (int32_t)i;
+      Bx[Bp[i]] = 1.0;
+      continue;
+    }
+    double sum_strong_pos = 0.0, sum_strong_neg = 0.0;
+    for (int32_t j = T.colptr[i]; j < T.colptr[i + 1]; ++j) {
+      int32_t row = T.rowval[j];
+      double sval = T.nzval[j];
+      if (splitting[row] == C_NODE) {
+        if (sval < 0)
+          sum_strong_neg += sval;
+        else
+          sum_strong_pos += sval;
+      }
+    }
+    double sum_all_pos = 0.0, sum_all_neg = 0.0, diag = 0.0;
+    for (int32_t j = At.colptr[i]; j < At.colptr[i + 1]; ++j) {
+      int32_t row = At.rowval[j];
+      double aval = At.nzval[j];
+      if (row == i) {
+        diag += aval;
+      } else if (aval < 0) {
+        sum_all_neg += aval;
+      } else {
+        sum_all_pos += aval;
+      }
+    }
+    double alpha, beta;
+    if (sum_strong_pos == 0) {
+      beta = 0.0;
+      if (diag >= 0) diag += sum_all_pos;
+    } else {
+      beta = sum_all_pos / sum_strong_pos;
+    }
+    if (sum_strong_neg == 0) {
+      alpha = 0.0;
+      if (diag < 0) diag += sum_all_neg;
+    } else {
+      alpha = sum_all_neg / sum_strong_neg;
+    }
+    double neg_coeff, pos_coeff;
+    if (std::fabs(diag) <= eps) {  // isapprox(real(diag), 0, atol=eps)
+      neg_coeff = 0.0;
+      pos_coeff = 0.0;
+    } else {
+      neg_coeff = alpha / diag;
+      pos_coeff = beta / diag;
+    }
+    int32_t nz = Bp[i];
+    for (int32_t j = T.colptr[i]; j < T.colptr[i + 1]; ++j) {
+      int32_t row = T.rowval[j];
+      double sval = T.nzval[j];
+      if (splitting[row] == C_NODE) {
+        Bj[nz] = row;
+        Bx[nz] = (sval < 0) ? std::fabs(neg_coeff * sval) : std::fabs(pos_coeff * sval);
+        ++nz;
+      }
+    }
+  }
+  // coarse index map = exclusive prefix sum of splitting (classical.jl:180-186)
+  std::vector<int32_t> map(n, 0);
+  int32_t sum = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    map[i] = sum;
+    sum += splitting[i];
+  }
+  int32_t nc = 0;
+  for (int64_t k = 0; k < nnzc; ++k) {
+    Bj[k] = map[Bj[k]];
+    nc = std::max(nc, Bj[k] + 1);  // isempty(Pj) ? 0 : maximum(Pj)
+  }
+  MatP R = make(nc, n);
+  R->colptr = std::move(Bp);
+  R->rowval = std::move(Bj);
+  R->nzval = std::move(Bx);
+  return R;
+}
+
+// ---- aggregate.jl:12-134 : StandardAggregation -------------------------
+MatP standard_aggregation(const Mat& S) {
+  const int64_t n = S.m;
+  std::vector<int64_t> x(n, 0);
+  int64_t next_aggregate = 1;
+  // Pass 1
+  for (int64_t i = 0; i < n; ++i) {
+    if (x[i] != 0) continue;
+    bool has_agg_neighbors = false, has_neighbors = false;
+    for (int32_t j = S.colptr[i]; j < S.colptr[i + 1]; ++j) {
+      int32_t row = S.rowval[j];
+      if (row != i) {
+        has_neighbors = true;
+        if (x[row] != 0) {
+          has_agg_neighbors = true;
+          break;
+        }
+      }
+    }
+    if (!has_neighbors) {
+      x[i] = -n;
+    } else if (!has_agg_neighbors) {
+      x[i] = next_aggregate;
+      for (int32_t j = S.colptr[i]; j < S.colptr[i + 1]; ++j) {
+        int32_t row = S.rowval[j];
+        if (row != i) x[row] = next_aggregate;
+      }
+      next_aggregate += 1;
+    }
+  }
+  // Pass 2
+  for (int64_t i = 0; i < n; ++i) {
+    if (x[i] != 0) continue;
+    double s_best = 0.0;
+    int64_t x_best = 0;
+    for (int32_t j = S.colptr[i]; j < S.colptr[i + 1]; ++j) {
+      int64_t x_row = x[S.rowval[j]];
+      double s_candidate = S.nzval[j];
+      if (x_row > 0 && s_candidate > s_best) {
+        s_best = s_candidate;
+        x_best = x_row;
+      }
+    }
+    if (x_best > 0) x[i] = -x_best;
+  }
+  std::vector<uint8_t> unagg(n);
+  for (int64_t i = 0; i < n; ++i) unagg[i] = (x[i] == 0);
+  next_aggregate -= 1;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t xi = x[i];
+    if (xi > 0)
+      x[i] = xi - 1;
+    else if (xi == -n)
+      x[i] = -1;
+    else if (xi < 0)
+      x[i] = -xi - 1;
+  }
+  // Pass 3
+  for (int64_t i = 0; i < n; ++i) {
+    if (!unagg[i]) continue;
+    x[i] = next_aggregate;
+    for (int32_t j = S.colptr[i]; j < S.colptr[i + 1]; ++j) {
+      int32_t row = S.rowval[j];
+      if (unagg[row]) {
+        x[row] = next_aggregate;
+        unagg[row] = 0;
+      }
+    }
+    unagg[i] = 0;
+    next_aggregate += 1;
+  }
+  const int64_t N = next_aggregate;
+  MatP Agg = make(N, n);  // N_agg x n, one column per fine node
+  for (int64_t i = 0; i < n; ++i) {
+    if (x[i] != -1) {  // isolated nodes get an empty column (aggregate.jl:120-126)
+      Agg->rowval.push_back((int32_t)x[i]);
+      Agg->nzval.push_back(1.0);
+    }
+    Agg->colptr[i + 1] = (int32_t)Agg->rowval.size();
+  }
+  return Agg;
+}
+
+// ---- aggregation.jl:161-193 : fit_candidates, B::Vector ----------------
+MatP fit_candidates_vector(const Mat& AggOp, const double* B, double tol,
+                           std::vector<double>& Bc) {
+  MatP A = transpose(AggOp);  // n_fine x n_coarse
+  const int64_t n_col = A->n;
+  Bc.assign(n_col, 0.0);
+  for (int64_t i = 0; i < n_col; ++i)
+    for (int32_t j = A->colptr[i]; j < A->colptr[i + 1]; ++j) A->nzval[j] = B[A->rowval[j]];
+  for (int64_t i = 0; i < n_col; ++i) {
+    double s = 0.0;  // norm_col (aggregation.jl:232-240)
+    for (int32_t j = A->colptr[i]; j < A->colptr[i + 1]; ++j) {
+      double v = B[A->rowval[j]];
+      s += v * v;
+    }
+    double norm_i = std::sqrt(s);
+    double threshold_i = tol * norm_i;
+    double scale;
+    if (norm_i > threshold_i) {
+      scale = 1.0 / norm_i;
+      Bc[i] = norm_i;
+    } else {
+      scale = 0.0;
+      Bc[i] = 0.0;
+    }
+    for (int32_t j = A->colptr[i]; j < A->colptr[i + 1]; ++j) A->nzval[j] *= scale;
+  }
+  return A;
+}
+
+// Dense Householder QR of an r x m block (column-major, ld = r), LAPACK
+// dgeqr2/dlarfg conventions (beta = -sign(alpha)*norm).  On return `a` holds R
+// in its upper triangle; Q (r x min(r,m), thin) is written to q.
+void householder_qr(std::vector<double>& a, int r, int m, std::vector<double>& q) {
+  const int k = std::min(r, m);
+  std::vector<double> tau(k, 0.0);
+  for (int j = 0; j < k; ++j) {
+    double alpha = a[j + (size_t)j * r];
+    double xnorm = 0.0;
+    for (int i = j + 1; i < r; ++i) xnorm += a[i + (size_t)j * r] * a[i + (size_t)j * r];
+    xnorm = std::sqrt(xnorm);
+    if (xnorm == 0.0) {
+      tau[j] = 0.0;
+    } else {
+      double beta = -std::copysign(std::hypot(alpha, xnorm), alpha);
+      tau[j] = (beta - alpha) / beta;
+      double scal = 1.0 / (alpha - beta);
+      for (int i = j + 1; i < r; ++i) a[i + (size_t)j * r] *= scal;
+      a[j + (size_t)j * r] = beta;
+    }
+    // apply H_j to trailing columns
+    for (int c = j + 1; c < m; ++c) {
+      double w = a[j + (size_t)c * r];
+      for (int i = j + 1; i < r; ++i) w += a[i + (size_t)j * r] * a[i + (size_t)c * r];
+      w *= tau[j];
+      a[j + (size_t)c * r] -= w;
+      for (int i = j + 1; i < r; ++i) a[i + (size_t)c * r] -= w * a[i + (size_t)j * r];
+    }
+  }
+  // form thin Q = H_0 H_1 ... H_{k-1} [I_k; 0]
+  q.assign((size_t)r * k, 0.0);
+  for (int c = 0; c < k; ++c) q[c + (size_t)c * r] = 1.0;
+  for (int j = k - 1; j >= 0; --j) {
+    for (int c = 0; c < k; ++c) {
+      double w = q[j + (size_t)c * r];
+      for (int i = j + 1; i < r; ++i) w += a[i + (size_t)j * r] * q[i + (size_t)c * r];
+      w *= tau[j];
+      q[j + (size_t)c * r] -= w;
+      for (int i = j + 1; i < r; ++i) q[i + (size_t)c * r] -= w * a[i + (size_t)j * r];
+    }
+  }
+}
+
+// ---- aggregation.jl:195-230 : fit_candidates, B::Matrix (QR per aggregate)
+MatP fit_candidates_matrix(const Mat& AggOp, const double* B, int m, double tol,
+                           std::vector<double>& Bc) {
+  MatP A = transpose(AggOp);  // n_fine x n_agg
+  const int64_t n_fine = A->m, n_agg = A->n;
+  const int64_t n_coarse = (int64_t)m * n_agg;
+  Bc.assign((size_t)n_coarse * m, 0.0);  // n_coarse x m column-major
+  // collect triplets column by column; columns offset+local_j are produced in
+  // increasing order and rows within an aggregate ascend, so output is CSC-sorted.
+  MatP Qs = make(n_fine, n_coarse);
+  std::vector<double> Mblk, Q;
+  for (int64_t agg = 0; agg < n_agg; ++agg) {
+    const int32_t* rows = A->rowval.data() + A->colptr[agg];
+    const int nr = A->colptr[agg + 1] - A->colptr[agg];
+    const int r = std::min(nr, m);
+    const int64_t offset = agg * m;
+    if (nr > 0) {
+      Mblk.assign((size_t)nr * m, 0.0);
+      for (int c = 0; c < m; ++c)
+        for (int i = 0; i < nr; ++i) Mblk[i + (size_t)c * nr] = B[rows[i] + (size_t)c * n_fine];
+      householder_qr(Mblk, nr, m, Q);
+      for (int lj = 0; lj < r; ++lj) {
+        for (int li = 0; li < nr; ++li) {
+          double v = Q[li + (size_t)lj * nr];
+          if (std::fabs(v) >= tol && v != 0.0) {  // store if >= tol; dropzeros! after
+            Qs->rowval.push_back(rows[li]);
+            Qs->nzval.push_back(v);
+          }
+        }
+        Qs->colptr[offset + lj + 1] = (int32_t)Qs->rowval.size();
+      }
+      for (int c = 0; c < m; ++c)
+        for (int i = 0; i < r; ++i)
+          Bc[(offset + i) + (size_t)c * n_coarse] = (i <= c) ? Mblk[i + (size_t)c * nr] : 0.0;
+    }
+    for (int lj = r; lj < m; ++lj) Qs->colptr[offset + lj + 1] = (int32_t)Qs->rowval.size();
+  }
+  return Qs;
+}
+
+// ---- aggregation.jl:10-59 : JacobiProlongation(omega), LocalWeighting ---
+// P = T - (omega * D^-1 A) * T,  D_ii = sum_j |a_ij|  (uses A, not S).
+MatP sparse_sub(const Mat& X, const Mat& Y) {  // X - Y, exact zeros dropped
+  MatP C = make(X.m, X.n);
+  C->rowval.reserve(X.nnz() + Y.nnz());
+  C->nzval.reserve(X.nnz() + Y.nnz());
+  for (int64_t j = 0; j < X.n; ++j) {
+    int32_t a = X.colptr[j], ae = X.colptr[j + 1];
+    int32_t b = Y.colptr[j], be = Y.colptr[j + 1];
+    while (a < ae || b < be) {
+      int32_t row;
+      double v;
+      if (b >= be || (a < ae && X.rowval[a] < Y.rowval[b])) {
+        row = X.rowval[a];
+        v = X.nzval[a] - 0.0;
+        ++a;
+      } else if (a >= ae || Y.rowval[b] < X.rowval[a]) {
+        row = Y.rowval[b];
+        v = 0.0 - Y.nzval[b];
+        ++b;
+      } else {
+        row = X.rowval[a];
+        v = X.nzval[a] - Y.nzval[b];
+        ++a;
+        ++b;
+      }
+      if (v != 0.0) {
+        C->rowval.push_back(row);
+        C->nzval.push_back(v);
+      }
+    }
+    C->colptr[j + 1] = (int32_t)C->rowval.size();
+  }
+  return C;
+}
+
+MatP jacobi_prolongation(const Mat& A, const Mat& T, double omega) {
+  const int64_t n = A.m;
+  std::vector<double> D(n, 0.0);
+  for (int64_t i = 0; i < A.n; ++i)
+    for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) D[A.rowval[j]] += std::fabs(A.nzval[j]);
+  for (int64_t i = 0; i < n; ++i)
+    if (D[i] != 0) D[i] = 1.0 / D[i];
+  Mat DinvS(A);  // scale_rows (aggregation.jl:49-59) then rmul!(., omega)
+  for (int64_t k = 0; k < DinvS.nnz(); ++k) {
+    DinvS.nzval[k] *= D[DinvS.rowval[k]];
+    DinvS.nzval[k] *= omega;
+  }
+  MatP W = spgemm(DinvS, T);
+  return sparse_sub(T, *W);
+}
+
+// ---- smoother.jl:61-90 : gs!, Hermitian "fast" path (column i read as row i).
+// Host-side copy used ONLY by improve_candidates during SA setup
+// (aggregation.jl:75,135-136); the solve-phase sweeps run on the GPU.
+void gs_sweep_host(const Mat& A, const double* b, double* x, bool forward) {
+  const int64_t n = A.m;
+  for (int64_t t = 0; t < n; ++t) {
+    int64_t i = forward ? t : n - 1 - t;
+    double rsum = 0.0, d = 0.0;
+    for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) {
+      int32_t row = A.rowval[j];
+      double val = A.nzval[j];
+      if (row == i)
+        d = val;
+      else
+        rsum += val * x[row];
+    }
+    if (d != 0.0) x[i] = (b[i] - rsum) / d;
+  }
+}
+
+}  // namespace
+
+struct amgs_hier {
+  std::vector<MatP> A, P, R;
+  MatP final_A;
+};
+
+namespace {
+
+struct Guard {
+  template <class F>
+  static auto ptr(F f) -> decltype(f()) {
+    try {
+      return f();
+    } catch (const std::exception& e) {
+      g_err = e.what();
+      return nullptr;
+    }
+  }
+  template <class F>
+  static int rc(F f) {
+    try {
+      f();
+      return 0;
+    } catch (const std::exception& e) {
+      g_err = e.what();
+      return -1;
+    }
+  }
+};
+
+// classical.jl:6-55
+amgs_hier* ruge_stuben(const Mat& A0, const amgs_options& o) {
+  std::unique_ptr<amgs_hier> h(new amgs_hier);
+  MatP A(new Mat(A0));
+  if (A->m != A->n) throw std::runtime_error("ruge_stuben: matrix must be square");
+  while ((int)h->A.size() + 1 < o.max_levels && A->m > o.max_coarse) {
+    MatP Atown;
+    const Mat* At = A.get();
+    if (!o.hermitian) {
+      Atown = transpose(*A);
+      At = Atown.get();
+    }
+    MatP S, T;
+    classical_strength(*At, o.theta, S, T);
+    std::vector<int32_t> splitting(A->m);
+    rs_splitting(*S, splitting.data());
+    MatP R = direct_interpolation(*At, *T, splitting.data());
+    if (R->m == 0) break;  // size(P,2) == 0
+    MatP P = transpose(*R);
+    MatP RA = spgemm(*R, *A);
+    MatP RAP = spgemm(*RA, *P);
+    h->A.push_back(std::move(A));
+    h->P.push_back(std::move(P));
+    h->R.push_back(std::move(R));
+    A = std::move(RAP);
+  }
+  h->final_A = std::move(A);
+  return h.release();
+}
+
+// aggregation.jl:66-157
+amgs_hier* smoothed_aggregation(const Mat& A0, const double* B0, int nB, const amgs_options& o) {
+  std::unique_ptr<amgs_hier> h(new amgs_hier);
+  MatP A(new Mat(A0));
+  if (A->m != A->n) throw std::runtime_error("smoothed_aggregation: matrix must be square");
+  const int64_t n0 = A->m;
+  bool vector_path = (B0 == nullptr) || (o.sa_B_is_vector && nB == 1);
+  if (B0 == nullptr) nB = 1;
+  std::vector<double> B((size_t)n0 * nB, 1.0);
+  if (B0) std::copy(B0, B0 + (size_t)n0 * nB, B.begin());
+  bool bsr_flag = false;
+  while ((int)h->A.size() + 1 < o.max_levels && A->m > o.max_coarse) {
+    const int64_t n = A->m;
+    MatP S;
+    if (o.hermitian) {
+      S = symmetric_strength(*A, o.theta, bsr_flag);
+    } else {
+      MatP At = transpose(*A);
+      S = symmetric_strength(*At, o.theta, bsr_flag);
+    }
+    MatP AggOp = standard_aggregation(*S);
+    if (AggOp->m == 0) break;
+    // improve_candidates(A, B, 0): always the Hermitian fast path
+    // (aggregation.jl:135-136, smoother.jl:34-38); symmetric sweep x iter.
+    {
+      std::vector<double> zero(n, 0.0);
+      // gs! loops the columns of B inside each directional pass (smoother.jl:77);
+      // columns are independent, so sweeping column-by-column is equivalent.
+      for (int c = 0; c < nB; ++c)
+        for (int it = 0; it < o.sa_improve_iters; ++it) {
+          gs_sweep_host(*A, zero.data(), B.data() + (size_t)c * n, true);
+          gs_sweep_host(*A, zero.data(), B.data() + (size_t)c * n, false);
+        }
+    }
+    std::vector<double> Bc;
+    MatP T = vector_path ? fit_candidates_vector(*AggOp, B.data(), 1e-10, Bc)
+                         : fit_candidates_matrix(*AggOp, B.data(), nB, 1e-10, Bc);
+    MatP P = jacobi_prolongation(*A, *T, o.sa_omega);
+    if (P->n == 0) break;
+    MatP R = transpose(*P);
+    MatP RA = spgemm(*R, *A);
+    MatP RAP = spgemm(*RA, *P);
+    h->A.push_back(std::move(A));
+    h->P.push_back(std::move(P));
+    h->R.push_back(std::move(R));
+    A = std::move(RAP);
+    B = std::move(Bc);
+    bsr_flag = true;
+  }
+  h->final_A = std::move(A);
+  return h.release();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* amgs_last_error(void) { return g_err.c_str(); }
+
+int amgs_set_threads(int nthreads) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  return omp_get_max_threads();
+#else
+  (void)nthreads;
+  return 1;
+#endif
+}
+
+amgs_mat* amgs_mat_create(int64_t m, int64_t n, const int32_t* colptr, const int32_t* rowval,
+                          const double* nzval) {
+  return Guard::ptr([&]() -> amgs_mat* {
+    if (m < 0 || n < 0 || !colptr) throw std::runtime_error("amgs_mat_create: bad argument");
+    MatP A = make(m, n);
+    std::copy(colptr, colptr + n + 1, A->colptr.begin());
+    int64_t nnz = colptr[n];
+    if (colptr[0] != 0 || nnz < 0) throw std::runtime_error("amgs_mat_create: colptr must be 0-based");
+    for (int64_t j = 0; j < n; ++j)
+      if (colptr[j + 1] < colptr[j]) throw std::runtime_error("amgs_mat_create: colptr not monotone");
+    A->rowval.assign(rowval, rowval + nnz);
+    A->nzval.assign(nzval, nzval + nnz);
+    for (int64_t k = 0; k < nnz; ++k)
+      if (rowval[k] < 0 || rowval[k] >= m) throw std::runtime_error("amgs_mat_create: row index out of range");
+    return A.release();
+  });
+}
+void amgs_mat_free(amgs_mat* A) { delete A; }
+int64_t amgs_mat_rows(const amgs_mat* A) { return A->m; }
+int64_t amgs_mat_cols(const amgs_mat* A) { return A->n; }
+int64_t amgs_mat_nnz(const amgs_mat* A) { return A->nnz(); }
+const int32_t* amgs_mat_colptr(const amgs_mat* A) { return A->colptr.data(); }
+const int32_t* amgs_mat_rowval(const amgs_mat* A) { return A->rowval.data(); }
+const double* amgs_mat_nzval(const amgs_mat* A) { return A->nzval.data(); }
+amgs_mat* amgs_mat_transpose(const amgs_mat* A) {
+  return Guard::ptr([&]() -> amgs_mat* { return transpose(*A).release(); });
+}
+amgs_mat* amgs_mat_spgemm(const amgs_mat* X, const amgs_mat* Y) {
+  return Guard::ptr([&]() -> amgs_mat* { return spgemm(*X, *Y).release(); });
+}
+int amgs_mat_is_symmetric(const amgs_mat* A) {
+  if (A->m != A->n) return 0;
+  MatP T = transpose(*A);
+  return T->colptr == A->colptr && T->rowval == A->rowval && T->nzval == A->nzval;
+}
+
+amgs_mat* amgs_poisson(int ndim, const int64_t* dims) {
+  return Guard::ptr([&]() -> amgs_mat* { return poisson(ndim, dims).release(); });
+}
+
+int amgs_classical_strength(const amgs_mat* At, double theta, amgs_mat** S, amgs_mat** T) {
+  return Guard::rc([&]() {
+    MatP s, t;
+    classical_strength(*At, theta, s, t);
+    *S = s.release();
+    *T = t.release();
+  });
+}
+amgs_mat* amgs_symmetric_strength(const amgs_mat* A, double theta, int bsr_flag) {
+  return Guard::ptr([&]() -> amgs_mat* { return symmetric_strength(*A, theta, bsr_flag != 0).release(); });
+}
+int amgs_rs_splitting(amgs_mat* S, int32_t* splitting) {
+  return Guard::rc([&]() {
+    if (S->m != S->n) throw std::runtime_error("rs_splitting: S must be square");
+    rs_splitting(*S, splitting);
+  });
+}
+amgs_mat* amgs_direct_interpolation(const amgs_mat* At, const amgs_mat* T, const int32_t* splitting) {
+  return Guard::ptr([&]() -> amgs_mat* { return direct_interpolation(*At, *T, splitting).release(); });
+}
+amgs_mat* amgs_standard_aggregation(const amgs_mat* S) {
+  return Guard::ptr([&]() -> amgs_mat* { return standard_aggregation(*S).release(); });
+}
+amgs_mat* amgs_fit_candidates(const amgs_mat* AggOp, const double* B, int nB, int vector_path, double tol,
+                              double** Bc, int64_t* n_coarse) {
+  return Guard::ptr([&]() -> amgs_mat* {
+    std::vector<double> bc;
+    MatP Q;
+    if (vector_path) {
+      if (nB != 1) throw std::runtime_error("fit_candidates: vector path needs nB == 1");
+      Q = fit_candidates_vector(*AggOp, B, tol, bc);
+    } else {
+      Q = fit_candidates_matrix(*AggOp, B, nB, tol, bc);
+    }
+    *n_coarse = Q->n;
+    *Bc = (double*)std::malloc(sizeof(double) * std::max<size_t>(bc.size(), 1));
+    std::copy(bc.begin(), bc.end(), *Bc);
+    return Q.release();
+  });
+}
+amgs_mat* amgs_jacobi_prolongation(const amgs_mat* A, const amgs_mat* T, double omega) {
+  return Guard::ptr([&]() -> amgs_mat* { return jacobi_prolongation(*A, *T, omega).release(); });
+}
+void amgs_free(void* p) { std::free(p); }
+
+void amgs_default_options_rs(amgs_options* o) {
+  o->theta = 0.25;  // Classical(0.25), classical.jl:8
+  o->max_levels = 10;
+  o->max_coarse = 10;
+  o->hermitian = 1;
+  o->sa_omega = 4.0 / 3.0;
+  o->sa_improve_iters = 4;
+  o->sa_B_is_vector = 1;
+}
+void amgs_default_options_sa(amgs_options* o) {
+  amgs_default_options_rs(o);
+  o->theta = 0.0;  // SymmetricStrength(), strength.jl:75
+}
+
+amgs_hier* amgs_ruge_stuben(const amgs_mat* A, const amgs_options* o) {
+  return Guard::ptr([&]() -> amgs_hier* { return ruge_stuben(*A, *o); });
+}
+amgs_hier* amgs_smoothed_aggregation(const amgs_mat* A, const double* B, int nB, const amgs_options* o) {
+  return Guard::ptr([&]() -> amgs_hier* { return smoothed_aggregation(*A, B, nB, *o); });
+}
+void amgs_hier_free(amgs_hier* h) { delete h; }
+int amgs_hier_num_levels(const amgs_hier* h) { return (int)h->A.size(); }
+const amgs_mat* amgs_hier_get(const amgs_hier* h, int level, int which) {
+  int L = (int)h->A.size();
+  if (level == L && which == 0) return h->final_A.get();
+  if (level < 0 || level >= L) return nullptr;
+  switch (which) {
+    case 0: return h->A[level].get();
+    case 1: return h->P[level].get();
+    case 2: return h->R[level].get();
+  }
+  return nullptr;
+}
+
+}  // extern "C"

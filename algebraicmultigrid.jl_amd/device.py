@@ -1,0 +1,276 @@
+"""HBM-resident hierarchy: thin ctypes layer over libamghip's C ABI.
+
+No compute happens in Python; every method is one call through include/amghip.h.
+If libamghip.so is missing or no GPU is visible this module raises — the solve
+phase has no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._libs import AMGError, gpu_available, hip_check, hip_lib
+from .smoothers import Smoother
+from .sparse import SparseMatrixCSC
+
+OP_A, OP_P, OP_R = 0, 1, 2
+CYCLE_V, CYCLE_W, CYCLE_F = 0, 1, 2
+T_LABELS = ["Presmoother", "Residual eval", "Restriction", "Coarse solve", "Prolongation", "Postsmoother"]
+
+
+def require_gpu():
+    lib = hip_lib()
+    if lib.amgh_device_count() <= 0:
+        raise AMGError("no HIP device visible: the AMG solve phase runs on MI355X only (no CPU fallback)")
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class DeviceBuffer:
+    """A device allocation of `n` doubles (amgh_dev_alloc / amgh_dev_free)."""
+
+    def __init__(self, n, device=0, host=None):
+        self.lib = require_gpu()
+        self.n = int(n)
+        self.device = device
+        p = C.c_void_p()
+        hip_check(self.lib.amgh_dev_alloc(device, 8 * max(self.n, 1), C.byref(p)), "dev_alloc")
+        self.ptr = p.value
+        if host is not None:
+            self.upload(host)
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        assert host.size == self.n
+        hip_check(self.lib.amgh_dev_upload(self.device, self.ptr, host.ctypes.data, 8 * self.n), "upload")
+
+    def download(self):
+        out = np.empty(self.n, dtype=np.float64)
+        hip_check(self.lib.amgh_dev_download(self.device, out.ctypes.data, self.ptr, 8 * self.n), "download")
+        return out
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.amgh_dev_free(self.device, self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class DeviceCSR:
+    """Stand-alone CSR operator on HBM (amgh_csr_*)."""
+
+    def __init__(self, nrows, ncols, rowptr, col, val, device=0):
+        self.lib = require_gpu()
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        self.nrows, self.ncols, self.device = int(nrows), int(ncols), device
+        h = C.c_void_p()
+        hip_check(self.lib.amgh_csr_create(C.byref(h), device, nrows, ncols, _ptr(rowptr), _ptr(col), _ptr(val)),
+                  "csr_create")
+        self.h = h.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.amgh_csr_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def sync(self):
+        hip_check(self.lib.amgh_dev_sync(self.device), "sync")
+
+    def spmv(self, x):
+        xd = DeviceBuffer(self.ncols, self.device, x)
+        yd = DeviceBuffer(self.nrows, self.device)
+        hip_check(self.lib.amgh_csr_spmv_d(self.h, xd.ptr, yd.ptr, None), "csr_spmv")
+        self.sync()
+        return yd.download()
+
+    def residual(self, x, b):
+        xd = DeviceBuffer(self.ncols, self.device, x)
+        bd = DeviceBuffer(self.nrows, self.device, b)
+        rd = DeviceBuffer(self.nrows, self.device)
+        hip_check(self.lib.amgh_csr_residual_d(self.h, xd.ptr, bd.ptr, rd.ptr, None), "csr_residual")
+        self.sync()
+        return rd.download()
+
+    def spmv_add(self, x, y):
+        xd = DeviceBuffer(self.ncols, self.device, x)
+        yd = DeviceBuffer(self.nrows, self.device, y)
+        hip_check(self.lib.amgh_csr_spmv_add_d(self.h, xd.ptr, yd.ptr, None), "csr_spmv_add")
+        self.sync()
+        return yd.download()
+
+    def smooth(self, config, x, b):
+        """Run `config.iter` sweeps in place on host vector x (returns new x)."""
+        n = self.nrows
+        xd = DeviceBuffer(self.ncols, self.device, x)
+        bd = DeviceBuffer(n, self.device, b)
+        tmp = DeviceBuffer(self.ncols, self.device, x) if config.kind == 2 else None
+        cur, other = xd, tmp
+        for _ in range(config.iter):
+            if config.kind == 2:
+                hip_check(self.lib.amgh_csr_jacobi_d(self.h, config.omega, cur.ptr, bd.ptr, other.ptr, None), "jacobi")
+                cur, other = other, cur
+            elif config.kind in (1, 3):
+                sor = int(config.kind == 3)
+                if config.sweep_code in (0, 2):
+                    hip_check(self.lib.amgh_csr_gs_d(self.h, 0, config.omega, sor, cur.ptr, bd.ptr, None), "gs fwd")
+                if config.sweep_code in (1, 2):
+                    hip_check(self.lib.amgh_csr_gs_d(self.h, 1, config.omega, sor, cur.ptr, bd.ptr, None), "gs bwd")
+        self.sync()
+        return cur.download()[:n]
+
+
+def smoother_matrix_csr(A, symmetry):
+    """CSR arrays of the matrix a smoother sweeps row-wise.
+
+    HermitianSymmetry(): the "fast" smoothers read CSC column i as row i
+    (smoother.jl:81-86,128-134) -> the CSC arrays as they are.
+    NoSymmetry(): sweeps over true rows -> CSR of A = CSC arrays of A'."""
+    from .hierarchy import HermitianSymmetry
+    A = SparseMatrixCSC.coerce(A)
+    if symmetry is None or isinstance(symmetry, HermitianSymmetry):
+        return A.colptr, A.rowval, A.nzval
+    return A.csr_arrays()
+
+
+def smooth_standalone(config, A, x, b, symmetry=None):
+    from .hierarchy import HermitianSymmetry
+    A = SparseMatrixCSC.coerce(A)
+    if symmetry is not None and not isinstance(symmetry, HermitianSymmetry):
+        config.check_no_symmetry(A)
+    rp, ci, va = smoother_matrix_csr(A, symmetry)
+    op = DeviceCSR(A.m, A.n, rp, ci, va)
+    x[...] = op.smooth(config, np.asarray(x, dtype=np.float64), np.asarray(b, dtype=np.float64))
+
+
+class DeviceHierarchy:
+    """MultiLevel on HBM: amgh_create / push_level / set_coarse / finalize."""
+
+    def __init__(self, ml, device=0):
+        from .hierarchy import HermitianSymmetry
+        self.lib = require_gpu()
+        self.device = device
+        self.ml = ml
+        h = C.c_void_p()
+        hip_check(self.lib.amgh_create(C.byref(h), device, 1), "create")
+        self.h = h.value
+        hermitian = isinstance(ml.symmetry, HermitianSymmetry)
+        for lev in ml.levels:
+            A = lev.A
+            n, nc = A.m, lev.P.n
+            Ar, Ac, Av = A.csr_arrays()                  # true A rows
+            if hermitian and not A.is_symmetric():
+                Sr, Sc, Sv = A.colptr, A.rowval, A.nzval  # column i read as row i
+            else:
+                Sr = Sc = Sv = None                      # S == A
+            # CSR of P (n x nc) = CSC arrays of R (nc x n), and vice versa.
+            Pr, Pc, Pv = lev.R.colptr, lev.R.rowval, lev.R.nzval
+            Rr, Rc, Rv = lev.P.colptr, lev.P.rowval, lev.P.nzval
+            if lev.R.shape != (nc, n) or lev.P.shape != (n, nc):
+                raise AMGError("Level: P must be n x nc and R nc x n")
+            for s in (lev.presmoother, lev.postsmoother):
+                if not isinstance(s, Smoother):
+                    raise AMGError(f"unsupported smoother {s!r}")
+            pre, post = lev.presmoother.c_struct(), lev.postsmoother.c_struct()
+            hip_check(self.lib.amgh_push_level(self.h, n, nc, _ptr(Ar), _ptr(Ac), _ptr(Av), _ptr(Sr), _ptr(Sc),
+                                               _ptr(Sv), _ptr(Pr), _ptr(Pc), _ptr(Pv), _ptr(Rr), _ptr(Rc), _ptr(Rv),
+                                               C.byref(pre), C.byref(post)), "push_level")
+        fA = ml.final_A
+        op = np.asfortranarray(ml.coarse_solver.dense_operator(), dtype=np.float64)
+        fr, fc, fv = fA.csr_arrays()
+        hip_check(self.lib.amgh_set_coarse(self.h, fA.m, _ptr(fr), _ptr(fc), _ptr(fv), _ptr(op)), "set_coarse")
+        hip_check(self.lib.amgh_finalize(self.h), "finalize")
+        self.n = ml.levels[0].A.m if ml.levels else fA.m
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.amgh_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- solve phase ---------------------------------------------------------
+    def solve(self, b, x0, cycle, maxiter, abstol, reltol, calculate_residual, log):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.array(x0, dtype=np.float64, copy=True, order="C")
+        hist = np.zeros(maxiter + 1, dtype=np.float64)
+        iters = C.c_int(0)
+        hip_check(self.lib.amgh_solve(self.h, b.ctypes.data, x.ctypes.data, cycle, maxiter, abstol, reltol,
+                                      int(bool(calculate_residual)), hist.ctypes.data, C.byref(iters)), "solve")
+        n_hist = (iters.value + 1) if calculate_residual else 1
+        return x, hist[:n_hist].copy(), iters.value
+
+    def precond_apply(self, r, cycle=CYCLE_V):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.empty_like(r)
+        hip_check(self.lib.amgh_precond_apply(self.h, r.ctypes.data, z.ctypes.data, cycle), "precond_apply")
+        return z
+
+    def pcg(self, b, cycle=CYCLE_V, use_precond=True, maxiter=None, abstol=0.0, reltol=None):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        maxiter = self.n if maxiter is None else int(maxiter)
+        reltol = float(np.sqrt(np.finfo(np.float64).eps)) if reltol is None else float(reltol)
+        x = np.zeros_like(b)
+        hist = np.zeros(maxiter + 1, dtype=np.float64)
+        iters = C.c_int(0)
+        hip_check(self.lib.amgh_pcg(self.h, b.ctypes.data, x.ctypes.data, cycle, int(bool(use_precond)), maxiter,
+                                    abstol, reltol, hist.ctypes.data, C.byref(iters)), "pcg")
+        return x, hist[:iters.value + 1].copy(), iters.value
+
+    # ---- per-level hooks -----------------------------------------------------
+    def spmv(self, level, which, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        nr = self._op_rows(level, which)
+        y = np.empty(nr, dtype=np.float64)
+        hip_check(self.lib.amgh_level_spmv(self.h, level, which, x.ctypes.data, y.ctypes.data), "level_spmv")
+        return y
+
+    def _op_rows(self, level, which):
+        L = len(self.ml.levels)
+        if level == L:
+            return self.ml.final_A.m
+        lev = self.ml.levels[level]
+        return lev.P.n if which == OP_R else lev.A.m
+
+    def smooth(self, level, post, x, b):
+        x = np.array(x, dtype=np.float64, copy=True)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        hip_check(self.lib.amgh_level_smooth(self.h, level, int(post), x.ctypes.data, b.ctypes.data), "level_smooth")
+        return x
+
+    def bench_op(self, level, which, reps=20, warmup=3):
+        ms = C.c_double(0)
+        hip_check(self.lib.amgh_bench_op(self.h, level, which, reps, warmup, C.byref(ms)), "bench_op")
+        return ms.value
+
+    def device_bytes(self):
+        return int(self.lib.amgh_device_bytes(self.h))
+
+    def gs_dependency_levels(self, level):
+        return int(self.lib.amgh_gs_num_dependency_levels(self.h, level))
+
+    def profile(self, on=True):
+        hip_check(self.lib.amgh_profile_enable(self.h, int(on)), "profile_enable")
+
+    def profile_read(self, reset=True):
+        L1 = len(self.ml.levels) + 1
+        out = np.zeros(6 * L1, dtype=np.float64)
+        hip_check(self.lib.amgh_profile_read(self.h, out.ctypes.data, int(reset)), "profile_read")
+        return {lab: out[i * L1:(i + 1) * L1].copy() for i, lab in enumerate(T_LABELS)}
+
+    def timer_begin(self):
+        hip_check(self.lib.amgh_timer_begin(self.h), "timer_begin")
+
+    def timer_end(self):
+        ms = C.c_double(0)
+        hip_check(self.lib.amgh_timer_end(self.h, C.byref(ms)), "timer_end")
+        return ms.value

@@ -1,0 +1,361 @@
+"""Host mirror of the reference's setup-phase interface and hierarchy types.
+
+Names, argument meaning and error behaviour follow the reference
+(/root/reference/src): `ruge_stuben` (classical.jl:6-34), `smoothed_aggregation`
+(aggregation.jl:66-114), `Level`/`MultiLevel` (multilevel.jl:1-21),
+`Classical`/`SymmetricStrength` (strength.jl), `RS` (splitting.jl),
+`StandardAggregation` (aggregate.jl), `JacobiProlongation`, `fit_candidates`
+(aggregation.jl), `Pinv`/`QRSolver` (coarse_solver.jl), `poisson` (gallery.jl).
+The heavy lifting is libamgsetup (C++); the solve phase is libamghip (HIP).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._libs import AMGError, amgs_options, setup_lib
+from .smoothers import GaussSeidel, Smoother
+from .sparse import SparseMatrixCSC
+
+
+# ---- symmetry tags (utils.jl:1-19) ----------------------------------------
+class HermitianSymmetry:
+    pass
+
+
+class NoSymmetry:
+    pass
+
+
+# ---- gallery (gallery.jl) ---------------------------------------------------
+def poisson(sz):
+    """poisson(n) / poisson((n1,...,nN)): gallery.jl:1-63 (first axis fastest)."""
+    dims = (int(sz),) if np.isscalar(sz) else tuple(int(s) for s in sz)
+    arr = (C.c_int64 * len(dims))(*dims)
+    return SparseMatrixCSC(setup_lib().amgs_poisson(len(dims), arr))
+
+
+# ---- strength (strength.jl) -------------------------------------------------
+class Classical:
+    def __init__(self, theta=0.25):
+        self.theta = float(theta)
+
+    def __call__(self, At):
+        At = SparseMatrixCSC.coerce(At)
+        S, T = C.c_void_p(), C.c_void_p()
+        rc = setup_lib().amgs_classical_strength(At._h, self.theta, C.byref(S), C.byref(T))
+        if rc != 0:
+            raise AMGError(setup_lib().amgs_last_error().decode())
+        return SparseMatrixCSC(S.value), SparseMatrixCSC(T.value)
+
+
+class SymmetricStrength:
+    def __init__(self, theta=0.0):
+        self.theta = float(theta)
+
+    def __call__(self, A, bsr_flag=False):
+        if np.iscomplexobj(getattr(A, "data", np.zeros(0))):
+            raise AMGError("Symmetric strength not implemented for complex matrices.")  # strength.jl:124-126
+        A = SparseMatrixCSC.coerce(A)
+        S = SparseMatrixCSC(setup_lib().amgs_symmetric_strength(A._h, self.theta, int(bool(bsr_flag))))
+        return S, S
+
+
+# ---- splitting (splitting.jl) ----------------------------------------------
+F_NODE, C_NODE, U_NODE = 0, 1, 2
+
+
+class RS:
+    def __call__(self, S):
+        """RS()(S): removes the diagonal of S in place, returns the C/F splitting."""
+        S = SparseMatrixCSC.coerce(S)
+        out = np.zeros(S.m, dtype=np.int32)
+        rc = setup_lib().amgs_rs_splitting(S._h, out.ctypes.data)
+        if rc != 0:
+            raise AMGError(setup_lib().amgs_last_error().decode())
+        # S was modified in place: refresh its views
+        S.__init__(S._h, S._owner)
+        return out
+
+
+def direct_interpolation(At, T, splitting):
+    """classical.jl:57-68 -> (P, R) with P = R'."""
+    At = SparseMatrixCSC.coerce(At)
+    T = SparseMatrixCSC.coerce(T)
+    sp = np.ascontiguousarray(splitting, dtype=np.int32)
+    R = SparseMatrixCSC(setup_lib().amgs_direct_interpolation(At._h, T._h, sp.ctypes.data))
+    return R.transpose(), R
+
+
+# ---- aggregation (aggregate.jl, aggregation.jl) ----------------------------
+class StandardAggregation:
+    def __call__(self, S):
+        S = SparseMatrixCSC.coerce(S)
+        return SparseMatrixCSC(setup_lib().amgs_standard_aggregation(S._h))
+
+
+def fit_candidates(AggOp, B, tol=1e-10):
+    """aggregation.jl:161-230.  B 1-D -> Vector method, 2-D -> QR method."""
+    AggOp = SparseMatrixCSC.coerce(AggOp)
+    B = np.asarray(B, dtype=np.float64)
+    vector = B.ndim == 1
+    nB = 1 if vector else B.shape[1]
+    Bf = np.asfortranarray(B.reshape(B.shape[0], nB))
+    bc, nc = C.c_void_p(), C.c_int64()
+    Q = SparseMatrixCSC(setup_lib().amgs_fit_candidates(AggOp._h, Bf.ctypes.data, nB, int(vector), tol,
+                                                        C.byref(bc), C.byref(nc)))
+    n_coarse = nc.value
+    buf = np.ctypeslib.as_array(C.cast(bc, C.POINTER(C.c_double)), shape=(max(n_coarse * nB, 1),))[:n_coarse * nB].copy()
+    setup_lib().amgs_free(bc)
+    R = buf if vector else buf.reshape((n_coarse, nB), order="F")
+    return Q, R
+
+
+class LocalWeighting:
+    pass
+
+
+class JacobiProlongation:
+    def __init__(self, omega):
+        self.omega = float(omega)
+
+    def __call__(self, A, T, S=None, B=None, degree=1, weighting=None):
+        if degree != 1 or (weighting is not None and not isinstance(weighting, LocalWeighting)):
+            raise AMGError("only degree=1 LocalWeighting() is built (the reference default)")
+        A = SparseMatrixCSC.coerce(A)
+        T = SparseMatrixCSC.coerce(T)
+        return SparseMatrixCSC(setup_lib().amgs_jacobi_prolongation(A._h, T._h, self.omega))
+
+
+# ---- coarse solvers (coarse_solver.jl) --------------------------------------
+class CoarseSolver:
+    """coarse_solver(A) -> callable (x, b).  `dense_operator()` is what the GPU applies."""
+
+    def __init__(self, A):
+        self.A = SparseMatrixCSC.coerce(A)
+        self._op = None
+
+    def dense_operator(self):
+        raise NotImplementedError
+
+    def __call__(self, x, b):
+        x[...] = self.dense_operator() @ b
+        return x
+
+
+class Pinv(CoarseSolver):
+    """pinv(Matrix(A)) (coarse_solver.jl:9-16); Julia's default rtol = eps * min(size)."""
+
+    def dense_operator(self):
+        if self._op is None:
+            M = self.A.toarray()
+            if M.size == 0:
+                self._op = np.zeros_like(M)
+            else:
+                self._op = np.linalg.pinv(M, rcond=np.finfo(np.float64).eps * min(M.shape))
+        return self._op
+
+    def __repr__(self):
+        return "Pinv"
+
+
+class QRSolver(CoarseSolver):
+    """qr(A) \\ b (coarse_solver.jl:66-81).  For the full-rank coarse matrices AMG
+    produces this is A^-1 b; the dense operator is formed by a Householder-QR
+    solve against the identity (least-squares for rank-deficient input)."""
+
+    def dense_operator(self):
+        if self._op is None:
+            M = self.A.toarray()
+            n = M.shape[0]
+            if n == 0:
+                self._op = np.zeros_like(M)
+            else:
+                Q, R = np.linalg.qr(M)
+                d = np.abs(np.diag(R))
+                if d.min() <= np.finfo(np.float64).eps * n * max(d.max(), 1e-300):
+                    self._op = np.linalg.lstsq(M, np.eye(n), rcond=None)[0]
+                else:
+                    import scipy.linalg as sla
+                    self._op = sla.solve_triangular(R, Q.T)
+        return self._op
+
+    def __repr__(self):
+        return "QRSolver"
+
+
+_default_coarse_solver = QRSolver  # coarse_solver.jl:84
+
+
+# ---- hierarchy types (multilevel.jl:1-114) ----------------------------------
+class Level:
+    def __init__(self, A, P, R, presmoother, postsmoother):
+        self.A = SparseMatrixCSC.coerce(A)
+        self.P = SparseMatrixCSC.coerce(P)
+        self.R = SparseMatrixCSC.coerce(R)
+        self.presmoother = presmoother
+        self.postsmoother = postsmoother
+
+    def __repr__(self):
+        return f"Level with R {self.R.shape} | A {self.A.shape} | P {self.P.shape}"
+
+
+class MultiLevel:
+    """levels, final_A, coarse_solver, presmoother, postsmoother (multilevel.jl:14-21).
+
+    The workspace of the reference (`MultiLevelWorkspace`) lives in HBM inside
+    the libamghip handle, created lazily by `device()`.
+    """
+
+    def __init__(self, levels, final_A, coarse_solver, presmoother, postsmoother, symmetry=None, _hier=None):
+        self.levels = list(levels)
+        self.final_A = SparseMatrixCSC.coerce(final_A)
+        self.coarse_solver = coarse_solver
+        self.presmoother = presmoother
+        self.postsmoother = postsmoother
+        self.symmetry = symmetry if symmetry is not None else HermitianSymmetry()
+        self._hier = _hier
+        self._dev = None
+
+    def __len__(self):
+        return len(self.levels) + 1
+
+    def device(self, device=0):
+        """The HBM-resident hierarchy (libamghip handle); built on first use."""
+        if self._dev is None:
+            from .device import DeviceHierarchy
+            self._dev = DeviceHierarchy(self, device)
+        return self._dev
+
+    def __repr__(self):
+        total = self.final_A.nnz + sum(l.A.nnz for l in self.levels)
+        rows = []
+        for i, l in enumerate(self.levels):
+            rows.append("   %2d   %10d   %10d [%5.2f%%]" % (i + 1, l.A.m, l.A.nnz, 100.0 * l.A.nnz / total))
+        rows.append("   %2d   %10d   %10d [%5.2f%%]" % (len(self.levels) + 1, self.final_A.m, self.final_A.nnz,
+                                                      100.0 * self.final_A.nnz / max(total, 1)))
+        return ("Multilevel Solver\n-----------------\n"
+                f"Operator Complexity: {round(operator_complexity(self), 3)}\n"
+                f"Grid Complexity: {round(grid_complexity(self), 3)}\n"
+                f"No. of Levels: {len(self)}\n"
+                f"Coarse Solver: {self.coarse_solver}\n"
+                "Level     Unknowns     NonZeros\n-----     --------     --------\n" + "\n".join(rows) + "\n")
+
+
+def operator_complexity(ml):
+    if ml.levels:
+        return (sum(l.A.nnz for l in ml.levels) + ml.final_A.nnz) / ml.levels[0].A.nnz
+    return 1.0
+
+
+def grid_complexity(ml):
+    if ml.levels:
+        return (sum(l.A.m for l in ml.levels) + ml.final_A.m) / ml.levels[0].A.m
+    return 1.0
+
+
+class _Hier:
+    """Owns an amgs_hier*; matrices borrowed from it keep it alive."""
+
+    def __init__(self, h):
+        if not h:
+            raise AMGError("libamgsetup: " + setup_lib().amgs_last_error().decode())
+        self.h = h
+
+    def __del__(self):
+        try:
+            setup_lib().amgs_hier_free(self.h)
+        except Exception:
+            pass
+
+    def get(self, level, which):
+        return SparseMatrixCSC(setup_lib().amgs_hier_get(self.h, level, which), owner=self)
+
+
+def _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry):
+    L = setup_lib().amgs_hier_num_levels(hier.h)
+    levels = [Level(hier.get(l, 0), hier.get(l, 1), hier.get(l, 2), presmoother, postsmoother) for l in range(L)]
+    final_A = hier.get(L, 0)
+    if not isinstance(symmetry, HermitianSymmetry):
+        # NoSymmetry smoothers need a nonzero stored diagonal (smoother.jl:239-241)
+        for lev in levels:
+            for s in (presmoother, postsmoother):
+                s.check_no_symmetry(lev.A)
+    cs = coarse_solver(final_A)
+    return MultiLevel(levels, final_A, cs, presmoother, postsmoother, symmetry, _hier=hier)
+
+
+def _unwrap(A, symmetry):
+    return SparseMatrixCSC.coerce(A), symmetry
+
+
+def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, postsmoother=None,
+                max_levels=10, max_coarse=10, coarse_solver=None, **kwargs):
+    """ruge_stuben(A; strength=Classical(0.25), symmetry=HermitianSymmetry(), CF=RS(),
+    presmoother=GaussSeidel(), postsmoother=GaussSeidel(), max_levels=10, max_coarse=10,
+    coarse_solver=QRSolver)   — classical.jl:6-34."""
+    if kwargs.get("B") is not None:  # classical.jl:18
+        raise AMGError("near null space `B` is only supported for smoothed aggregation AMG, not Ruge-Stüben AMG.")
+    strength = strength if strength is not None else Classical(0.25)
+    symmetry = symmetry if symmetry is not None else HermitianSymmetry()
+    presmoother = presmoother if presmoother is not None else GaussSeidel()
+    postsmoother = postsmoother if postsmoother is not None else GaussSeidel()
+    coarse_solver = coarse_solver if coarse_solver is not None else _default_coarse_solver
+    if not isinstance(strength, Classical) or (CF is not None and not isinstance(CF, RS)):
+        raise AMGError("ruge_stuben: only strength=Classical(θ), CF=RS() are built")
+    A = SparseMatrixCSC.coerce(A)
+    o = amgs_options()
+    setup_lib().amgs_default_options_rs(C.byref(o))
+    o.theta = strength.theta
+    o.max_levels = int(max_levels)
+    o.max_coarse = int(max_coarse)
+    o.hermitian = int(isinstance(symmetry, HermitianSymmetry))
+    hier = _Hier(setup_lib().amgs_ruge_stuben(A._h, C.byref(o)))
+    return _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry)
+
+
+def smoothed_aggregation(A, B=None, symmetry=None, strength=None, aggregate=None, smooth=None,
+                         presmoother=None, postsmoother=None, improve_candidates=None, max_levels=10,
+                         max_coarse=10, diagonal_dominance=False, keep=False, verbose=False,
+                         coarse_solver=None, **kwargs):
+    """smoothed_aggregation(A; B=nothing, symmetry, strength=SymmetricStrength(),
+    aggregate=StandardAggregation(), smooth=JacobiProlongation(4/3), presmoother, postsmoother,
+    improve_candidates=GaussSeidel(iter=4), max_levels, max_coarse, coarse_solver) — aggregation.jl:66-114."""
+    if np.iscomplexobj(getattr(A, "data", np.zeros(0))):
+        raise AMGError("Symmetric strength not implemented for complex matrices.")
+    strength = strength if strength is not None else SymmetricStrength()
+    symmetry = symmetry if symmetry is not None else HermitianSymmetry()
+    smooth = smooth if smooth is not None else JacobiProlongation(4.0 / 3.0)
+    presmoother = presmoother if presmoother is not None else GaussSeidel()
+    postsmoother = postsmoother if postsmoother is not None else GaussSeidel()
+    improve_candidates = improve_candidates if improve_candidates is not None else GaussSeidel(iter=4)
+    coarse_solver = coarse_solver if coarse_solver is not None else _default_coarse_solver
+    if not isinstance(strength, SymmetricStrength) or not isinstance(smooth, JacobiProlongation):
+        raise AMGError("smoothed_aggregation: only SymmetricStrength(θ) / JacobiProlongation(ω) are built")
+    if aggregate is not None and not isinstance(aggregate, StandardAggregation):
+        raise AMGError("smoothed_aggregation: only StandardAggregation() is built")
+    if not isinstance(improve_candidates, GaussSeidel) or improve_candidates.sweep_name != "symmetric":
+        raise AMGError("smoothed_aggregation: improve_candidates must be GaussSeidel(SymmetricSweep(), iter)")
+    A = SparseMatrixCSC.coerce(A)
+    n = A.m
+    o = amgs_options()
+    setup_lib().amgs_default_options_sa(C.byref(o))
+    o.theta = strength.theta
+    o.max_levels = int(max_levels)
+    o.max_coarse = int(max_coarse)
+    o.hermitian = int(isinstance(symmetry, HermitianSymmetry))
+    o.sa_omega = smooth.omega
+    o.sa_improve_iters = int(improve_candidates.iter)
+    Bptr, nB = None, 1
+    if B is not None:
+        B = np.asarray(B, dtype=np.float64)
+        if B.shape[0] != n:  # @assert size(A,1) == size(B,1), aggregation.jl:87
+            raise AssertionError("size(A, 1) == size(B, 1)")
+        o.sa_B_is_vector = int(B.ndim == 1)
+        nB = 1 if B.ndim == 1 else B.shape[1]
+        Bf = np.asfortranarray(B.reshape(n, nB))
+        Bptr = Bf.ctypes.data
+    hier = _Hier(setup_lib().amgs_smoothed_aggregation(A._h, Bptr, nB, C.byref(o)))
+    ml = _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry)
+    if verbose:
+        print(ml)
+    return ml

@@ -1,0 +1,155 @@
+"""Solve-phase entry points — host mirror of multilevel.jl:116-264 and
+preconditioner.jl:1-24.  Every call goes through libamghip (HIP, gfx950)."""
+import numpy as np
+
+from ._libs import AMGError
+from .device import CYCLE_F, CYCLE_V, CYCLE_W
+from .hierarchy import MultiLevel, ruge_stuben, smoothed_aggregation
+from .sparse import SparseMatrixCSC
+
+
+class Cycle:
+    code = None
+
+
+class V(Cycle):
+    code = CYCLE_V
+
+
+class W(Cycle):
+    code = CYCLE_W
+
+
+class F(Cycle):
+    code = CYCLE_F
+
+
+def _cycle_code(cycle):
+    if cycle is None:
+        return CYCLE_V
+    if isinstance(cycle, type) and issubclass(cycle, Cycle):
+        cycle = cycle()
+    if not isinstance(cycle, Cycle):
+        raise AMGError("cycle must be V(), W() or F()")
+    return cycle.code
+
+
+_SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
+
+
+def _solve_inplace(x, ml, b, cycle=None, maxiter=100, abstol=0.0, reltol=_SQRT_EPS, verbose=False, log=False,
+                   calculate_residual=True, **kwargs):
+    """`_solve!(x, ml, b, cycle; maxiter, abstol, reltol, verbose, log, calculate_residual)`
+    (multilevel.jl:158-198).  x is the initial guess and is overwritten."""
+    if not isinstance(ml, MultiLevel):
+        raise AMGError("ml must be a MultiLevel")
+    b = np.asarray(b, dtype=np.float64)
+    if b.ndim != 1:
+        raise AMGError("multiple right-hand sides (bs > 1) are not built yet")
+    n = ml.levels[0].A.m if ml.levels else ml.final_A.m
+    if b.shape[0] != n or x.shape != b.shape:
+        raise AMGError("DimensionMismatch: x, b must have length size(A, 1)")
+    xs, hist, iters = ml.device().solve(b, x, _cycle_code(cycle), int(maxiter), float(abstol), float(reltol),
+                                        calculate_residual, log)
+    x[...] = xs
+    if verbose and calculate_residual:
+        for i in range(iters):
+            print("Norm of residual at iteration %6d is %.4e" % (i + 1, hist[i]))
+    return (x, hist) if log else x
+
+
+def _solve(ml, b, cycle=None, **kwargs):
+    """`_solve(ml, b[, cycle]; kwargs...)`: x = zeros, then `_solve!` (multilevel.jl:152-157)."""
+    b = np.asarray(b, dtype=np.float64)
+    x = np.zeros_like(b)
+    return _solve_inplace(x, ml, b, cycle, **kwargs)
+
+
+# ---- CommonSolve-style adapter (multilevel.jl:241-264) ------------------------
+class AMGAlg:
+    pass
+
+
+class RugeStubenAMG(AMGAlg):
+    pass
+
+
+class SmoothedAggregationAMG(AMGAlg):
+    pass
+
+
+_SOLVE_KW = ("maxiter", "abstol", "reltol", "verbose", "log", "calculate_residual")
+_RS_KW = ("strength", "symmetry", "CF", "presmoother", "postsmoother", "max_levels", "max_coarse", "coarse_solver", "B")
+_SA_KW = ("B", "symmetry", "strength", "aggregate", "smooth", "presmoother", "postsmoother", "improve_candidates",
+          "max_levels", "max_coarse", "diagonal_dominance", "keep", "verbose", "coarse_solver")
+
+
+def solve(A, b, alg, cycle=None, **kwargs):
+    """solve(A, b, RugeStubenAMG() | SmoothedAggregationAMG(); kwargs...): the same kwargs go
+    to the setup and to `_solve`, each side ignoring what it does not know (multilevel.jl:252-264)."""
+    if isinstance(alg, type):
+        alg = alg()
+    if isinstance(alg, RugeStubenAMG):
+        ml = ruge_stuben(A, **{k: v for k, v in kwargs.items() if k in _RS_KW})
+    elif isinstance(alg, SmoothedAggregationAMG):
+        ml = smoothed_aggregation(A, **{k: v for k, v in kwargs.items() if k in _SA_KW})
+    else:
+        raise AMGError("alg must be RugeStubenAMG() or SmoothedAggregationAMG()")
+    return _solve(ml, b, cycle, **{k: v for k, v in kwargs.items() if k in _SOLVE_KW})
+
+
+# ---- preconditioner facade (preconditioner.jl) --------------------------------
+class Preconditioner:
+    def __init__(self, ml, cycle=None, init="zero"):
+        self.ml = ml
+        self.cycle = cycle if cycle is not None else V()
+        self.init = init
+
+    def ldiv(self, b, x=None):
+        """ldiv!(x, p, b): x .= 0 then exactly one cycle without residual (preconditioner.jl:12-19)."""
+        b = np.asarray(b, dtype=np.float64)
+        if self.init == "zero":
+            z = self.ml.device().precond_apply(b, _cycle_code(self.cycle))
+        else:
+            z = b.copy()
+            _solve_inplace(z, self.ml, b, self.cycle, maxiter=1, calculate_residual=False)
+        if x is None:
+            return z
+        x[...] = z
+        return x
+
+    def solve(self, b):
+        """`p \\ b`"""
+        return self.ldiv(b)
+
+    def __rmatmul__(self, other):
+        raise TypeError("use p.ldiv(b) / p.solve(b)")
+
+    def mul(self, x):
+        """mul!(b, p, x) = A₁ x (preconditioner.jl:20), on the GPU."""
+        L = len(self.ml.levels)
+        return self.ml.device().spmv(0 if L else L, 0, x)
+
+
+def aspreconditioner(ml, cycle=None):
+    return Preconditioner(ml, cycle)
+
+
+def cg(A, b, Pl=None, abstol=0.0, reltol=_SQRT_EPS, maxiter=None, log=False):
+    """IterativeSolvers.jl `cg(A, b; Pl, abstol, reltol, maxiter, log)` as the reference's tests use it
+    (cycle_tests.jl:25, runtests.jl:186,204).  Runs entirely on device (amgh_pcg); A must be the
+    fine-level operator of Pl's hierarchy."""
+    if not isinstance(Pl, Preconditioner):
+        raise AMGError("cg: Pl must be aspreconditioner(ml)")
+    ml = Pl.ml
+    A = SparseMatrixCSC.coerce(A)
+    fine = ml.levels[0].A if ml.levels else ml.final_A
+    if A is not fine and not (A.shape == fine.shape and A.nnz == fine.nnz and np.array_equal(A.colptr, fine.colptr)
+                              and np.array_equal(A.rowval, fine.rowval) and np.array_equal(A.nzval, fine.nzval)):
+        raise AMGError("cg: A must be the operator the preconditioner was built from")
+    b = np.asarray(b, dtype=np.float64)
+    maxiter = A.n if maxiter is None else int(maxiter)
+    x, hist, iters = ml.device().pcg(b, _cycle_code(Pl.cycle), True, maxiter, float(abstol), float(reltol))
+    if log:
+        return x, {"iters": iters, "resnorm": hist[1:], "isconverged": bool(hist[-1] <= max(reltol * hist[0], abstol))}
+    return x

@@ -1,0 +1,218 @@
+/*
+ * amghip.h — C ABI of libamghip: the MI355X (gfx950) AMG solve phase.
+ *
+ * Drop-in boundary for ONE hot path of AlgebraicMultigrid.jl: the cycling loop
+ * of src/multilevel.jl and the relaxation sweeps of src/smoother.jl.  The
+ * reference has no FFI of its own (pure Julia, multiple dispatch); these entry
+ * points are what a `ccall` shim binds so that `_solve(ml,b)`,
+ * `aspreconditioner(ml)` / `ldiv!`, `smooth!` and `mul!` keep their signatures
+ * (see INTEGRATION.md and julia/AMGHip.jl).  Each declaration cites the
+ * reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.
+ *   - all index arrays 0-based int32, values IEEE f64 (the path computes in f64).
+ *   - matrices are CSR.  The reference stores CSC; CSC arrays of M are CSR
+ *     arrays of M' — the shim passes whichever view each entry point documents.
+ *   - pointers are HOST pointers unless the function name ends in `_d`
+ *     (DEVICE pointers on the handle's device; work is enqueued on the handle's
+ *     stream and the call returns after the stream has been synchronised unless
+ *     documented otherwise).
+ *   - return 0 on success, <0 on error: -2 bad argument, -3 bad state,
+ *     -4 out of memory, -5 unsupported, -(1000+hipError_t) for HIP failures.
+ *     amgh_strerror(rc) gives text.  No exception crosses the boundary.
+ *   - a handle is single-threaded and NOT re-entrant, like the reference's
+ *     MultiLevel whose workspace is mutated by every solve (multilevel.jl:23-59).
+ */
+#ifndef AMGHIP_H
+#define AMGHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct amgh_handle amgh_t; /* MultiLevel on HBM   (multilevel.jl:14-21) */
+typedef struct amgh_csr amgh_csr_t; /* one CSR operator on HBM                   */
+
+#define AMGH_OK 0
+#define AMGH_EINVAL (-2)
+#define AMGH_ESTATE (-3)
+#define AMGH_ENOMEM (-4)
+#define AMGH_EUNSUPPORTED (-5)
+
+/* smoother configuration: GaussSeidel{Sweep}(sweep, iter) smoother.jl:17-23,
+ * Jacobi(omega; iter) :92-99, SOR(omega, sweep, iter) :173-180                  */
+enum { AMGH_SMOOTH_NONE = 0, AMGH_SMOOTH_GS = 1, AMGH_SMOOTH_JACOBI = 2, AMGH_SMOOTH_SOR = 3 };
+enum { AMGH_SWEEP_FORWARD = 0, AMGH_SWEEP_BACKWARD = 1, AMGH_SWEEP_SYMMETRIC = 2 };
+typedef struct {
+  int32_t kind;  /* AMGH_SMOOTH_*                                               */
+  int32_t sweep; /* AMGH_SWEEP_* (GS, SOR)                                      */
+  int32_t iter;  /* number of sweeps (>= 0)                                     */
+  int32_t pad_;
+  double omega;  /* Jacobi / SOR damping                                        */
+} amgh_smoother_t;
+
+/* cycle types: struct V/W/F <: Cycle, multilevel.jl:116-124                     */
+enum { AMGH_CYCLE_V = 0, AMGH_CYCLE_W = 1, AMGH_CYCLE_F = 2 };
+/* operator selector for amgh_level_spmv                                         */
+enum { AMGH_OP_A = 0, AMGH_OP_P = 1, AMGH_OP_R = 2 };
+/* timer labels = the reference's @timeit_debug labels, multilevel.jl:180,216-236 */
+enum {
+  AMGH_T_PRESMOOTH = 0, AMGH_T_RESIDUAL = 1, AMGH_T_RESTRICT = 2,
+  AMGH_T_COARSE = 3, AMGH_T_PROLONG = 4, AMGH_T_POSTSMOOTH = 5, AMGH_T_COUNT = 6
+};
+
+const char* amgh_strerror(int rc);
+/* number of HIP devices visible (0 when there is no GPU); never fails           */
+int amgh_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* Hierarchy construction  — replaces the in-memory Level/MultiLevel structs    */
+/* (multilevel.jl:1-21) and MultiLevelWorkspace (multilevel.jl:23-59).          */
+/* ------------------------------------------------------------------------- */
+/* nrhs = workspace block size `bs` (multilevel.jl:28-35); only 1 is built.     */
+int amgh_create(amgh_t** h, int device, int nrhs);
+void amgh_destroy(amgh_t* h);
+
+/* push!(levels, Level(A, P, R, pre, post))  (classical.jl:48-52,
+ * aggregation.jl:147-151).  Host arrays are copied to HBM; the caller may free
+ * them on return.
+ *   A : n x n CSR of the true operator — what mul!(res, A, x) applies
+ *       (multilevel.jl:188,219).
+ *   S : n x n CSR of the matrix the SMOOTHER sweeps row-wise.  With
+ *       HermitianSymmetry() the reference's "fast" smoothers read CSC column i
+ *       as row i (smoother.jl:81-86,128-134), i.e. S = CSC arrays of A taken as
+ *       CSR (= A' ; identical to A when A is symmetric).  With NoSymmetry() the
+ *       sweeps act on the true rows, S = A.  Pass S_rowptr = NULL for S == A.
+ *   P : n x nc CSR,  R : nc x n CSR  (multilevel.jl:223,233).                  */
+int amgh_push_level(amgh_t* h, int64_t n, int64_t nc,
+                    const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
+                    const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
+                    const int32_t* P_rowptr, const int32_t* P_col, const double* P_val,
+                    const int32_t* R_rowptr, const int32_t* R_col, const double* R_val,
+                    const amgh_smoother_t* pre, const amgh_smoother_t* post);
+
+/* Coarsest level: final_A and the coarse solver (coarse_solver.jl).  The
+ * callable `(cs)(x, b)` becomes x = dense_op * b with dense_op (n x n,
+ * column-major) computed by the host shim: pinv(Matrix(A)) for Pinv
+ * (coarse_solver.jl:9-16) or inv(Matrix(A)) standing in for the QR solve of
+ * QRSolver (coarse_solver.jl:66-81).  final_A (CSR) is needed only when the
+ * hierarchy has no levels (multilevel.jl:179-180 + residual :188); may be NULL
+ * otherwise.                                                                    */
+int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col,
+                    const double* A_val, const double* dense_op);
+
+/* Allocates the workspace (res_vecs, coarse_xs, coarse_bs), builds the
+ * Gauss-Seidel dependency schedules.  Must be called once before any solve.     */
+int amgh_finalize(amgh_t* h);
+
+int amgh_num_levels(const amgh_t* h);            /* length(ml.levels)            */
+int64_t amgh_level_size(const amgh_t* h, int l); /* size(levels[l].A,1); l==L: final */
+int64_t amgh_device_bytes(const amgh_t* h);      /* HBM held by the handle        */
+/* number of Gauss-Seidel dependency levels of level l (0 if no GS smoother)    */
+int amgh_gs_num_dependency_levels(const amgh_t* h, int l);
+
+/* ------------------------------------------------------------------------- */
+/* Solve phase                                                                  */
+/* ------------------------------------------------------------------------- */
+/* _solve!(x, ml, b, cycle; maxiter, abstol, reltol, log, calculate_residual)
+ * multilevel.jl:158-198.  x holds the initial guess on entry (zeros for
+ * `_solve`, :152-157) and the iterate on return.  abstol/reltol as given by the
+ * caller (the max(reltol*norm(b), abstol) rule of :170-173 is applied inside).
+ * resid_hist: NULL or maxiter+1 doubles; [0] = norm(b), [k] = residual after
+ * cycle k (the `log=true` vector, :169,174,191).  *iters = cycles performed.    */
+int amgh_solve(amgh_t* h, const double* b, double* x, int cycle, int maxiter,
+               double abstol, double reltol, int calculate_residual,
+               double* resid_hist, int* iters);
+int amgh_solve_d(amgh_t* h, const double* b_d, double* x_d, int cycle, int maxiter,
+                 double abstol, double reltol, int calculate_residual,
+                 double* resid_hist /*host*/, int* iters);
+
+/* ldiv!(x, p::Preconditioner, b): x .= 0; exactly one cycle, no residual
+ * (preconditioner.jl:12-19).  The _d form only enqueues on the handle's stream
+ * (no synchronisation) so that a caller-side Krylov loop can stay asynchronous. */
+int amgh_precond_apply(amgh_t* h, const double* r, double* z, int cycle);
+int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle);
+
+/* cg(A, b; Pl = aspreconditioner(ml), abstol, reltol, maxiter) — the caller the
+ * reference's tests and README pair with ldiv! (cycle_tests.jl:23-27,
+ * runtests.jl:186,204, README.md:54-56).  IterativeSolvers.jl's PCG recurrence,
+ * entirely on device; x0 = 0.  use_precond = 0 gives plain CG.
+ * resid_hist: NULL or maxiter+1 doubles ([0] = norm(b)).                         */
+int amgh_pcg(amgh_t* h, const double* b, double* x, int cycle, int use_precond,
+             int maxiter, double abstol, double reltol, double* resid_hist, int* iters);
+int amgh_pcg_d(amgh_t* h, const double* b_d, double* x_d, int cycle, int use_precond,
+               int maxiter, double abstol, double reltol, double* resid_hist, int* iters);
+
+/* ------------------------------------------------------------------------- */
+/* Per-level operators — unit-test and roofline hooks                           */
+/* ------------------------------------------------------------------------- */
+/* mul!(y, M, x) with M = levels[l].A | .P | .R (multilevel.jl:188,219,223,233) */
+int amgh_level_spmv(amgh_t* h, int level, int which, const double* x, double* y);
+int amgh_level_spmv_d(amgh_t* h, int level, int which, const double* x_d, double* y_d);
+/* res = b - A x  (multilevel.jl:219-220)                                        */
+int amgh_level_residual_d(amgh_t* h, int level, const double* x_d, const double* b_d, double* r_d);
+/* smooth!(x, levels[l].presmoother | .postsmoother, b)  (smoother.jl:61-90,
+ * 113-141, 193-221); post = 0 | 1                                               */
+int amgh_level_smooth(amgh_t* h, int level, int post, double* x, const double* b);
+int amgh_level_smooth_d(amgh_t* h, int level, int post, double* x_d, const double* b_d);
+
+/* ------------------------------------------------------------------------- */
+/* Stand-alone CSR operators on HBM (used by the row-sharded multi-GPU driver,  */
+/* where each rank holds n_local x (n_local + n_halo) blocks, and by tests).     */
+/* ------------------------------------------------------------------------- */
+int amgh_csr_create(amgh_csr_t** op, int device, int64_t nrows, int64_t ncols,
+                    const int32_t* rowptr, const int32_t* col, const double* val);
+void amgh_csr_destroy(amgh_csr_t* op);
+/* y = M x ; y = b - M x ; y += M x   (device pointers; stream = hipStream_t or NULL) */
+int amgh_csr_spmv_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream);
+int amgh_csr_residual_d(amgh_csr_t* op, const double* x_d, const double* b_d, double* r_d, void* stream);
+int amgh_csr_spmv_add_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream);
+/* one damped-Jacobi sweep on the leading nrows x nrows block's diagonal:
+ * xout[i] = (1-w) xin[i] + w (b[i] - sum_{j != i} m_ij xin[j]) / m_ii ; rows with
+ * m_ii == 0 keep xin[i] (smoother.jl:113-141).  xin has ncols entries (halo
+ * included), xout nrows.                                                        */
+int amgh_csr_jacobi_d(amgh_csr_t* op, double omega, const double* xin_d, const double* b_d,
+                      double* xout_d, void* stream);
+/* Gauss-Seidel / SOR sweep in exact lexicographic order over the leading
+ * nrows x nrows block (columns >= nrows are halo entries held fixed);
+ * backward != 0 sweeps n..1.  omega = 1 is Gauss-Seidel (smoother.jl:61-90),
+ * otherwise SOR (:193-221).                                                     */
+int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d,
+                  const double* b_d, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Device memory + timing helpers for hosts without a HIP binding of their own  */
+/* ------------------------------------------------------------------------- */
+int amgh_dev_alloc(int device, int64_t bytes, void** ptr_d);
+int amgh_dev_free(int device, void* ptr_d);
+int amgh_dev_upload(int device, void* dst_d, const void* src, int64_t bytes);
+int amgh_dev_download(int device, void* dst, const void* src_d, int64_t bytes);
+int amgh_dev_sync(int device);
+void* amgh_stream(amgh_t* h); /* the handle's hipStream_t                        */
+
+/* hipEvent timing on the handle's stream: begin records an event, end records
+ * a second one, synchronises and returns the elapsed milliseconds.              */
+int amgh_timer_begin(amgh_t* h);
+int amgh_timer_end(amgh_t* h, double* ms);
+/* Time `reps` back-to-back launches of one operator kernel with HIP events on
+ * the launching stream; returns the average milliseconds per launch.
+ * which: AMGH_OP_A/P/R = SpMV; 3 = fused residual with A; 4 = pre-smoother.     */
+int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double* avg_ms);
+
+/* Per-label, per-level accumulated milliseconds since the last reset, mirroring
+ * TimerOutputs' six labels (multilevel.jl:180,216-236).  Enabling inserts HIP
+ * events around every step (small overhead).  out: AMGH_T_COUNT x (num_levels+1)
+ * doubles, label-major.                                                         */
+int amgh_profile_enable(amgh_t* h, int on);
+int amgh_profile_read(amgh_t* h, double* out, int reset);
+
+/* Launch-bound inner loops are captured in hipGraphs (default on).              */
+int amgh_set_use_graph(amgh_t* h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
