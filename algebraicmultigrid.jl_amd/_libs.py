@@ -34,6 +34,8 @@ class amgh_smoother_t(C.Structure):
                 ("omega", C.c_double)]
 
 
+COARSE_FN = C.CFUNCTYPE(C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i64)
+
 _setup = None
 _hip = None
 
@@ -106,6 +108,7 @@ def hip_lib():
     L.amgh_destroy.restype = None
     L.amgh_push_level.argtypes = [vp, i64, i64] + [vp] * 12 + [C.POINTER(amgh_smoother_t), C.POINTER(amgh_smoother_t)]
     L.amgh_set_coarse.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.amgh_set_coarse_host.argtypes = [vp, i64, vp, vp, vp, COARSE_FN, vp]
     L.amgh_finalize.argtypes = [vp]
     L.amgh_num_levels.argtypes = [vp]
     L.amgh_level_size.restype = i64

@@ -325,6 +325,9 @@ struct amgh_handle {
   amgh_csr finalA;
   bool has_finalA = false;
   double* coarse_op = nullptr;
+  amgh_coarse_fn coarse_fn = nullptr;  // host-side pluggable coarse solver
+  void* coarse_user = nullptr;
+  std::vector<double> coarse_hb, coarse_hx;
   double* res_final = nullptr;  // res_vecs[1] when there are no levels
   bool finalized = false;
   // reductions / scalars
@@ -401,6 +404,14 @@ int vec_norm_host(amgh_t* h, const double* x, int64_t n, double* out) {
 int coarse_solve(amgh_t* h, double* x, const double* b) {
   const int n = (int)h->ncoarse;
   if (n <= 0) return AMGH_OK;
+  if (h->coarse_fn) {
+    HIP_TRY(hipMemcpyAsync(h->coarse_hb.data(), b, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->coarse_fn(h->coarse_user, h->coarse_hb.data(), h->coarse_hx.data(), n) != 0) return AMGH_ESTATE;
+    HIP_TRY(hipMemcpyAsync(x, h->coarse_hx.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return AMGH_OK;
+  }
   hipLaunchKernelGGL(dense_gemv_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->coarse_op, b, x, n);
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
@@ -725,6 +736,25 @@ int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t
   return AMGH_OK;
 }
 
+int amgh_set_coarse_host(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
+                         amgh_coarse_fn fn, void* user) {
+  if (!h || n < 0 || !fn) return AMGH_EINVAL;
+  if (h->finalized || h->ncoarse >= 0) return AMGH_ESTATE;
+  if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
+  if (n >= INT32_MAX) return AMGH_EUNSUPPORTED;
+  HIP_TRY(hipSetDevice(h->device));
+  if (A_rowptr) {
+    RC_TRY(csr_upload(&h->finalA, h->device, n, n, A_rowptr, A_col, A_val));
+    h->has_finalA = true;
+  }
+  h->coarse_fn = fn;
+  h->coarse_user = user;
+  h->coarse_hb.assign((size_t)std::max<int64_t>(n, 1), 0.0);
+  h->coarse_hx.assign((size_t)std::max<int64_t>(n, 1), 0.0);
+  h->ncoarse = n;
+  return AMGH_OK;
+}
+
 int amgh_finalize(amgh_t* h) {
   if (!h) return AMGH_EINVAL;
   if (h->finalized || h->ncoarse < 0) return AMGH_ESTATE;
@@ -762,7 +792,7 @@ int64_t amgh_level_size(const amgh_t* h, int l) {
 }
 int64_t amgh_device_bytes(const amgh_t* h) {
   if (!h) return 0;
-  int64_t b = h->ws_bytes + (h->ncoarse > 0 ? h->ncoarse * h->ncoarse * 8 : 0) + h->finalA.bytes;
+  int64_t b = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * 8 : 0) + h->finalA.bytes;
   for (Level* L : h->levels) b += L->A.bytes + L->S.bytes + L->P.bytes + L->R.bytes;
   return b;
 }

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._libs import AMGError, gpu_available, hip_check, hip_lib
+from ._libs import COARSE_FN, AMGError, gpu_available, hip_check, hip_lib
 from .smoothers import Smoother
 from .sparse import SparseMatrixCSC
 
@@ -184,9 +184,24 @@ class DeviceHierarchy:
                                                _ptr(Sv), _ptr(Pr), _ptr(Pc), _ptr(Pv), _ptr(Rr), _ptr(Rc), _ptr(Rv),
                                                C.byref(pre), C.byref(post)), "push_level")
         fA = ml.final_A
-        op = np.asfortranarray(ml.coarse_solver.dense_operator(), dtype=np.float64)
         fr, fc, fv = fA.csr_arrays()
-        hip_check(self.lib.amgh_set_coarse(self.h, fA.m, _ptr(fr), _ptr(fc), _ptr(fv), _ptr(op)), "set_coarse")
+        cs = ml.coarse_solver
+        if getattr(cs, "uses_dense", lambda: True)():
+            op = np.asfortranarray(cs.dense_operator(), dtype=np.float64)
+            hip_check(self.lib.amgh_set_coarse(self.h, fA.m, _ptr(fr), _ptr(fc), _ptr(fv), _ptr(op)), "set_coarse")
+        else:
+            # pluggable host coarse solver: the reference's `(cs)(x, b)` protocol
+            def _cb(user, bp, xp, n):
+                try:
+                    b = np.ctypeslib.as_array(bp, shape=(n,))
+                    x = np.ctypeslib.as_array(xp, shape=(n,))
+                    x[...] = cs.host_solve(b)
+                    return 0
+                except Exception:  # never let an exception cross the C boundary
+                    return 1
+            self._coarse_cb = COARSE_FN(_cb)
+            hip_check(self.lib.amgh_set_coarse_host(self.h, fA.m, _ptr(fr), _ptr(fc), _ptr(fv), self._coarse_cb, None),
+                      "set_coarse_host")
         hip_check(self.lib.amgh_finalize(self.h), "finalize")
         self.n = ml.levels[0].A.m if ml.levels else fA.m
 

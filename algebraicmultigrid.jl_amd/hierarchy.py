@@ -127,18 +127,37 @@ class JacobiProlongation:
 
 
 # ---- coarse solvers (coarse_solver.jl) --------------------------------------
+DENSE_COARSE_MAX = 2048  # above this the coarse solve is a host callback, not a dense HBM operator
+
+
 class CoarseSolver:
-    """coarse_solver(A) -> callable (x, b).  `dense_operator()` is what the GPU applies."""
+    """coarse_solver(A) -> callable (x, b)  (coarse_solver.jl:2).
+
+    `dense_operator()` is what the GPU applies as one GEMV when the coarsest level is small
+    (the normal case, n <= max_coarse); for a large coarsest level it returns None and the
+    device calls back into `host_solve(b)` (amgh_set_coarse_host)."""
 
     def __init__(self, A):
         self.A = SparseMatrixCSC.coerce(A)
         self._op = None
+        self._lu = None
+
+    def uses_dense(self):
+        return self.A.m <= DENSE_COARSE_MAX
 
     def dense_operator(self):
         raise NotImplementedError
 
+    def host_solve(self, b):
+        if self.uses_dense():
+            return self.dense_operator() @ b
+        if self._lu is None:  # sparse direct factorisation for a big coarsest level
+            import scipy.sparse.linalg as spla
+            self._lu = spla.splu(self.A.to_scipy())
+        return self._lu.solve(np.asarray(b, dtype=np.float64))
+
     def __call__(self, x, b):
-        x[...] = self.dense_operator() @ b
+        x[...] = self.host_solve(b)
         return x
 
 
@@ -206,7 +225,9 @@ class MultiLevel:
     the libamghip handle, created lazily by `device()`.
     """
 
-    def __init__(self, levels, final_A, coarse_solver, presmoother, postsmoother, symmetry=None, _hier=None):
+    def __init__(self, levels, final_A, coarse_solver, presmoother, postsmoother, symmetry=None, _hier=None,
+                 method=None):
+        self.method = method  # "rs" | "sa" | None (assembled by the caller)
         self.levels = list(levels)
         self.final_A = SparseMatrixCSC.coerce(final_A)
         self.coarse_solver = coarse_solver
@@ -271,7 +292,7 @@ class _Hier:
         return SparseMatrixCSC(setup_lib().amgs_hier_get(self.h, level, which), owner=self)
 
 
-def _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry):
+def _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, method):
     L = setup_lib().amgs_hier_num_levels(hier.h)
     levels = [Level(hier.get(l, 0), hier.get(l, 1), hier.get(l, 2), presmoother, postsmoother) for l in range(L)]
     final_A = hier.get(L, 0)
@@ -281,7 +302,7 @@ def _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry):
             for s in (presmoother, postsmoother):
                 s.check_no_symmetry(lev.A)
     cs = coarse_solver(final_A)
-    return MultiLevel(levels, final_A, cs, presmoother, postsmoother, symmetry, _hier=hier)
+    return MultiLevel(levels, final_A, cs, presmoother, postsmoother, symmetry, _hier=hier, method=method)
 
 
 def _unwrap(A, symmetry):
@@ -310,7 +331,7 @@ def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, post
     o.max_coarse = int(max_coarse)
     o.hermitian = int(isinstance(symmetry, HermitianSymmetry))
     hier = _Hier(setup_lib().amgs_ruge_stuben(A._h, C.byref(o)))
-    return _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry)
+    return _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, "rs")
 
 
 def smoothed_aggregation(A, B=None, symmetry=None, strength=None, aggregate=None, smooth=None,
@@ -355,7 +376,7 @@ def smoothed_aggregation(A, B=None, symmetry=None, strength=None, aggregate=None
         Bf = np.asfortranarray(B.reshape(n, nB))
         Bptr = Bf.ctypes.data
     hier = _Hier(setup_lib().amgs_smoothed_aggregation(A._h, Bptr, nB, C.byref(o)))
-    ml = _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry)
+    ml = _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, "sa")
     if verbose:
         print(ml)
     return ml

@@ -104,6 +104,16 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc,
 int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col,
                     const double* A_val, const double* dense_op);
 
+/* Pluggable coarse solver run on the HOST — the counterpart of the reference's
+ * coarse-solver protocol `(cs)(x, b)` (coarse_solver.jl:2,35-42,75-81; e.g.
+ * LinearSolveWrapper, or QRSolver on a coarsest level too large for a dense
+ * operator).  Each coarse solve copies b to the host, calls fn(user, b, x), copies
+ * x back (two PCIe hops + a stream sync; meant for large or exotic coarse
+ * problems, not for the default path).  fn returns 0 on success.               */
+typedef int (*amgh_coarse_fn)(void* user, const double* b_host, double* x_host, int64_t n);
+int amgh_set_coarse_host(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col,
+                         const double* A_val, amgh_coarse_fn fn, void* user);
+
 /* Allocates the workspace (res_vecs, coarse_xs, coarse_bs), builds the
  * Gauss-Seidel dependency schedules.  Must be called once before any solve.     */
 int amgh_finalize(amgh_t* h);

@@ -1,0 +1,154 @@
+"""ctypes wrapper of the CPU oracle (oracle/amg_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg — never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+vp, i64 = C.c_void_p, C.c_int64
+
+
+COARSE_FN = C.CFUNCTYPE(C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i64)
+
+
+class orc_smoother_t(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("sweep", C.c_int32), ("iter", C.c_int32), ("pad_", C.c_int32),
+                ("omega", C.c_double)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "amg_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_create.restype = vp
+        L.orc_destroy.argtypes = [vp]
+        L.orc_push_level.argtypes = [vp, i64, i64, vp, vp, vp, C.c_int, vp, vp, vp, C.POINTER(orc_smoother_t),
+                                     C.POINTER(orc_smoother_t), C.c_int]
+        L.orc_set_coarse.argtypes = [vp, i64, vp, vp, vp, vp]
+        L.orc_set_coarse_fn.argtypes = [vp, COARSE_FN, vp]
+        L.orc_solve.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, C.POINTER(C.c_int)]
+        L.orc_precond.argtypes = [vp, vp, vp, C.c_int]
+        L.orc_precond.restype = None
+        L.orc_pcg.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.POINTER(C.c_int)]
+        L.orc_spmv_arrays.argtypes = [i64, i64, vp, vp, vp, vp, vp, C.c_int]
+        L.orc_spmv_arrays.restype = None
+        L.orc_smooth_arrays.argtypes = [i64, vp, vp, vp, C.POINTER(orc_smoother_t), C.c_int, vp, vp]
+        L.orc_smooth_arrays.restype = i64
+        _lib = L
+    return _lib
+
+
+def _sm(s):
+    return orc_smoother_t(s.kind, s.sweep_code, int(s.iter), 0, float(s.omega))
+
+
+def spmv(A, x, adjoint=False):
+    """mul!(y, A, x) / mul!(y, A', x) on a SparseMatrixCSC-like (colptr,rowval,nzval,m,n)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(A.n if adjoint else A.m, dtype=np.float64)
+    lib().orc_spmv_arrays(A.m, A.n, A.colptr.ctypes.data, A.rowval.ctypes.data, A.nzval.ctypes.data,
+                          x.ctypes.data, y.ctypes.data, int(adjoint))
+    return y
+
+
+def smooth(config, A, x, b, hermitian=True):
+    """smooth!(x, setup_smoother(config, A, symmetry), b) -> new x (input untouched)."""
+    x = np.array(x, dtype=np.float64, copy=True)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    s = _sm(config)
+    rc = lib().orc_smooth_arrays(A.m, A.colptr.ctypes.data, A.rowval.ctypes.data, A.nzval.ctypes.data,
+                                 C.byref(s), int(hermitian), x.ctypes.data, b.ctypes.data)
+    if rc != 0:
+        raise ArithmeticError(f"SingularException({rc})")
+    return x
+
+
+class OracleHierarchy:
+    """The reference's MultiLevel, on the CPU.  Built from the host hierarchy object
+    (arrays borrowed).  RS levels hold R as CSC with P = R'; SA levels hold P with R = P'."""
+
+    def __init__(self, ml, kind=None):
+        from amg_amd import HermitianSymmetry
+        L = lib()
+        self.ml = ml
+        self.h = L.orc_create()
+        herm = int(isinstance(ml.symmetry, HermitianSymmetry))
+        self._keep = []
+        for lev in ml.levels:
+            A = lev.A
+            n, nc = A.m, lev.P.n
+            # which of P/R is the stored CSC in the reference: RS stores R (unit rows for C points),
+            # SA stores P.  Either view is mathematically the same operator; keep the reference's.
+            m_is_R = 1 if (kind or getattr(ml, "method", None) or "sa") == "rs" else 0
+            M = lev.R if m_is_R else lev.P
+            pre, post = _sm(lev.presmoother), _sm(lev.postsmoother)
+            L.orc_push_level(self.h, n, nc, A.colptr.ctypes.data, A.rowval.ctypes.data, A.nzval.ctypes.data, m_is_R,
+                             M.colptr.ctypes.data, M.rowval.ctypes.data, M.nzval.ctypes.data, C.byref(pre),
+                             C.byref(post), herm)
+            self._keep.append((A, M))
+        fA = ml.final_A
+        cs = ml.coarse_solver
+        if cs.uses_dense():
+            self.op = np.asfortranarray(cs.dense_operator(), dtype=np.float64)
+            L.orc_set_coarse(self.h, fA.m, fA.colptr.ctypes.data, fA.rowval.ctypes.data, fA.nzval.ctypes.data,
+                             self.op.ctypes.data)
+        else:  # big coarsest level: the pluggable `(cs)(x, b)` callable
+            L.orc_set_coarse(self.h, fA.m, fA.colptr.ctypes.data, fA.rowval.ctypes.data, fA.nzval.ctypes.data, None)
+
+            def _cb(user, bp, xp, n):
+                x = np.ctypeslib.as_array(xp, shape=(n,))
+                x[...] = cs.host_solve(np.ctypeslib.as_array(bp, shape=(n,)))
+                return 0
+            self._cb = COARSE_FN(_cb)
+            L.orc_set_coarse_fn(self.h, self._cb, None)
+        self.n = ml.levels[0].A.m if ml.levels else fA.m
+
+    def __del__(self):
+        try:
+            lib().orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def solve(self, b, x0=None, cycle=0, maxiter=100, abstol=0.0, reltol=None, calculate_residual=True):
+        reltol = float(np.sqrt(np.finfo(np.float64).eps)) if reltol is None else reltol
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64, copy=True)
+        hist = np.zeros(maxiter + 1)
+        it = C.c_int(0)
+        lib().orc_solve(self.h, b.ctypes.data, x.ctypes.data, cycle, maxiter, abstol, reltol,
+                        int(calculate_residual), hist.ctypes.data, C.byref(it))
+        return x, hist[:(it.value + 1) if calculate_residual else 1].copy(), it.value
+
+    def precond(self, r, cycle=0):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.zeros_like(r)
+        lib().orc_precond(self.h, r.ctypes.data, z.ctypes.data, cycle)
+        return z
+
+    def pcg(self, b, cycle=0, use_precond=True, maxiter=None, abstol=0.0, reltol=None):
+        reltol = float(np.sqrt(np.finfo(np.float64).eps)) if reltol is None else reltol
+        maxiter = self.n if maxiter is None else maxiter
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b)
+        hist = np.zeros(maxiter + 1)
+        it = C.c_int(0)
+        lib().orc_pcg(self.h, b.ctypes.data, x.ctypes.data, cycle, int(use_precond), maxiter, abstol, reltol,
+                      hist.ctypes.data, C.byref(it))
+        return x, hist[:it.value + 1].copy(), it.value

@@ -1,0 +1,42 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_native():
+    """Tests never compile in the timed path: make sure the in-tree .so files exist."""
+    import __graft_entry__ as g
+    g.build(only_missing=True)
+
+
+def load_csc(name):
+    import amg_amd as AMG
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return AMG.SparseMatrixCSC.from_arrays(int(d["m"]), int(d["n"]), d["colptr"], d["rowval"], d["nzval"])
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def uniform(n, seed=0):
+    """U[0,1) from a self-contained splitmix64 stream (state_k = seed + k*0x9E3779B97F4A7C15)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
