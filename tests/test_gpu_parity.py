@@ -1,0 +1,341 @@
+"""HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs, plus the reference's
+known-answer vectors evaluated on the GPU.  Tolerance: 1e-10 relative (BASELINE.json north_star);
+kernels that reproduce the oracle's IEEE sequence are additionally held to 1e-13."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import amg_amd as AMG
+from conftest import load_csc, load_npz, uniform
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10     # north_star tolerance
+TIGHT = 1e-13   # same-operation-order kernels
+
+FWD = AMG.GaussSeidel(AMG.ForwardSweep())
+BWD = AMG.GaussSeidel(AMG.BackwardSweep())
+SYM = AMG.GaussSeidel()
+
+
+def rel(x, y):
+    d = np.linalg.norm(np.asarray(x) - np.asarray(y))
+    s = max(np.linalg.norm(y), 1e-300)
+    return d / s
+
+
+def test_libamghip_is_loaded_and_gpu_visible():
+    assert AMG.gpu_available()
+    assert AMG.hip_lib().amgh_device_count() >= 1
+
+
+# ---- SpMV family -------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1000,), (70, 50), (24, 20, 16)])
+def test_spmv_residual_add_vs_oracle(shape):
+    A = AMG.poisson(shape)
+    n = A.m
+    op = AMG.DeviceCSR(n, n, *A.csr_arrays())
+    x, b = uniform(n, 1) - 0.5, uniform(n, 2)
+    y_ref = O.spmv(A, x)
+    assert rel(op.spmv(x), y_ref) <= TIGHT
+    assert rel(op.residual(x, b), b - y_ref) <= TIGHT
+    assert rel(op.spmv_add(x, b), b + y_ref) <= TIGHT
+
+
+def test_spmv_irregular_rows_empty_rows_long_rows():
+    rng = np.random.default_rng(5)
+    n = 5000
+    M = sp.random(n, n, 0.002, random_state=rng, format="lil")
+    M[17, :] = rng.random(n)            # one dense row (longer than the LDS stage)
+    M[100:140, :] = 0                   # empty rows
+    M = sp.csc_matrix(M)
+    A = AMG.SparseMatrixCSC.from_scipy(M)
+    x = uniform(n, 9) - 0.5
+    op = AMG.DeviceCSR(n, n, *A.csr_arrays())
+    ref = O.spmv(A, x)
+    got = op.spmv(x)
+    assert rel(got, ref) <= TIGHT
+    assert np.all(got[100:140] == 0)
+
+
+def test_rectangular_P_and_R():
+    A = AMG.poisson((40, 40))
+    ml = AMG.ruge_stuben(A)
+    dev = ml.device()
+    lev = ml.levels[0]
+    r = uniform(lev.A.m, 3)
+    e = uniform(lev.P.n, 4)
+    assert rel(dev.spmv(0, 2, r), O.spmv(lev.R, r)) <= TIGHT          # restriction b_c = R r
+    assert rel(dev.spmv(0, 1, e), O.spmv(lev.P, e)) <= TIGHT          # prolongation P e
+    assert rel(dev.spmv(0, 0, r), O.spmv(lev.A, r)) <= TIGHT
+    L = len(ml.levels)
+    assert rel(dev.spmv(L, 0, np.ones(ml.final_A.m)), O.spmv(ml.final_A, np.ones(ml.final_A.m))) <= TIGHT
+
+
+# ---- smoothers ---------------------------------------------------------------------------------
+def test_gauss_seidel_hand_values_on_gpu():  # sa_tests.jl:316-379
+    def tri(N):
+        return AMG.SparseMatrixCSC.from_scipy(sp.diags([-np.ones(N - 1), 2 * np.ones(N), -np.ones(N - 1)], [-1, 0, 1]))
+    x = np.array([0.0]); FWD(tri(1), x, np.zeros(1)); assert x[0] == 0
+    x = np.array([0, 1, 2.0]); FWD(tri(3), x, np.zeros(3)); assert np.array_equal(x, [1 / 2, 5 / 4, 5 / 8])
+    x = np.array([0, 1, 2.0]); BWD(tri(3), x, np.zeros(3)); assert np.array_equal(x, [1 / 8, 1 / 4, 1 / 2])
+    x = np.array([0.0]); FWD(tri(1), x, np.array([10.0])); assert x[0] == 5.0
+    x = np.array([0, 1, 2.0]); FWD(tri(3), x, np.array([10, 20, 30.0]))
+    assert np.array_equal(x, [11 / 2, 55 / 4, 175 / 8])
+    x = np.ones(10); AMG.GaussSeidel(AMG.SymmetricSweep(), 4)(AMG.poisson(10), x, np.zeros(10))  # issue #26
+    ref = [0.176765, 0.353529, 0.497517, 0.598914, 0.653311, 0.659104, 0.615597, 0.52275, 0.382787, 0.203251]
+    assert ((x - ref) ** 2).sum() < 1e-6
+
+
+SMOOTHERS = [AMG.Jacobi(2 / 3), AMG.Jacobi(0.5, iter=3), AMG.Jacobi(4 / 5, iter=2), FWD, BWD, SYM,
+             AMG.GaussSeidel(AMG.SymmetricSweep(), 3), AMG.SOR(0.5, iter=2), AMG.SOR(1.2, AMG.ForwardSweep()),
+             AMG.SOR(0.8, AMG.BackwardSweep(), 2)]
+
+
+@pytest.mark.parametrize("shape", [(300,), (48, 40), (20, 18, 16)])
+def test_fast_smoothers_vs_oracle(shape):
+    A = AMG.poisson(shape)
+    n = A.m
+    x0, b = uniform(n, 11) - 0.5, uniform(n, 12)
+    for s in SMOOTHERS:
+        x = x0.copy()
+        s(A, x, b)
+        ref = O.smooth(s, A, x0, b, hermitian=True)
+        assert rel(x, ref) <= TIGHT, repr(s)
+
+
+def test_smoothers_wide_dependency_levels():
+    """3-D grid large enough that dependency levels exceed the chain width (wide stream-kernel path)."""
+    A = AMG.poisson((64, 64, 48))
+    n = A.m
+    x0, b = uniform(n, 21) - 0.5, uniform(n, 22)
+    for s in (SYM, AMG.SOR(0.9)):
+        x = x0.copy()
+        s(A, x, b)
+        assert rel(x, O.smooth(s, A, x0, b)) <= TIGHT
+
+
+def test_smoothers_on_amg_coarse_operator_and_zero_diagonal():
+    ml = AMG.ruge_stuben(AMG.poisson((30, 30, 30)))
+    A2 = ml.levels[1].A                      # irregular Galerkin operator
+    n = A2.m
+    x0, b = uniform(n, 31), uniform(n, 32)
+    for s in (SYM, AMG.Jacobi(2 / 3, iter=2), AMG.SOR(0.7)):
+        x = x0.copy(); s(A2, x, b)
+        assert rel(x, O.smooth(s, A2, x0, b)) <= TIGHT
+    # rows with a zero / missing diagonal are skipped (smoother.jl:87,137,218)
+    M = AMG.poisson(50).to_scipy().tolil()
+    M[7, 7] = 0.0
+    M = sp.csc_matrix(M); M.eliminate_zeros()
+    A = AMG.SparseMatrixCSC.from_scipy(M)
+    x0, b = uniform(50, 33), uniform(50, 34)
+    for s in (SYM, AMG.Jacobi(0.5), AMG.SOR(0.5)):
+        x = x0.copy(); s(A, x, b)
+        ref = O.smooth(s, A, x0, b)
+        assert rel(x, ref) <= TIGHT and x[7] == x0[7]
+
+
+def test_hermitian_flag_on_nonsymmetric_matrix_sweeps_the_transpose():
+    """SURVEY §7 hard part 4: with the default HermitianSymmetry the fast smoothers read CSC columns as rows."""
+    rng = np.random.default_rng(3)
+    n = 400
+    M = sp.random(n, n, 0.02, random_state=rng, format="csc") + 6 * sp.identity(n, format="csc")
+    A = AMG.SparseMatrixCSC.from_scipy(M)
+    x0, b = rng.random(n), np.ones(n)
+    for s in (SYM, AMG.Jacobi(0.6, iter=2), AMG.SOR(0.5, iter=2)):
+        x = x0.copy(); s(A, x, b)                                     # Hermitian default
+        assert rel(x, O.smooth(s, A, x0, b, hermitian=True)) <= TIGHT
+        x = x0.copy(); s(A, x, b, AMG.NoSymmetry())                   # true rows
+        assert rel(x, O.smooth(s, A, x0, b, hermitian=False)) <= 1e-12
+
+
+def test_nosymmetry_singular_exception():
+    M = sp.csc_matrix(np.array([[1.0, 2.0], [3.0, 0.0]]))
+    with pytest.raises(AMG.SingularException):
+        FWD(M, np.ones(2), np.ones(2), AMG.NoSymmetry())
+
+
+# ---- cycles, _solve, ldiv!, cg -------------------------------------------------------------------
+def _check_solve(ml, b, **kw):
+    oh = O.OracleHierarchy(ml)
+    x, hist = AMG._solve(ml, b, log=True, **kw)
+    okw = {k: v for k, v in kw.items() if k in ("maxiter", "abstol", "reltol", "calculate_residual")}
+    cyc = kw.get("cycle")
+    xo, ho, it = oh.solve(b, cycle=cyc.code if cyc is not None else 0, **okw)
+    assert len(hist) == len(ho), (len(hist), len(ho))
+    assert rel(x, xo) <= TOL
+    if len(ho) > 1:
+        assert np.allclose(hist, ho, rtol=1e-7, atol=1e-14 * ho[0])
+    return x
+
+
+def test_solve_poisson1000_c1():  # runtests.jl:115-124
+    A = AMG.poisson(1000)
+    b = A @ np.ones(1000)
+    x = _check_solve(AMG.ruge_stuben(A), b)
+    assert ((x - 1) ** 2).sum() < 1e-8
+    x = _check_solve(AMG.ruge_stuben(A, presmoother=FWD, postsmoother=FWD), b)
+    assert ((x - 1) ** 2).sum() < 1e-8
+
+
+@pytest.mark.parametrize("method", ["ruge_stuben", "smoothed_aggregation"])
+def test_cycles_v_w_f(method):  # cycle_tests.jl:6-30
+    A = AMG.poisson((50, 50))
+    b = A @ np.ones(A.m)
+    nb = np.linalg.norm(b)
+    ml = getattr(AMG, method)(A)
+    oh = O.OracleHierarchy(ml)
+    for cyc in (AMG.V(), AMG.W(), AMG.F()):
+        x = _check_solve(ml, b, cycle=cyc, reltol=1e-8)
+        assert np.linalg.norm(b - A @ x) < 1e-8 * nb
+        p = AMG.aspreconditioner(ml, cyc)
+        x, log = AMG.cg(A, b, Pl=p, reltol=1e-8, log=True)
+        xo, ho, ito = oh.pcg(b, cycle=cyc.code, reltol=1e-8)
+        assert np.linalg.norm(b - A @ x) <= 1e-8 * nb
+        assert log["iters"] == ito and rel(x, xo) <= 1e-9
+        z = p.ldiv(b)
+        assert rel(z, oh.precond(b, cyc.code)) <= TOL
+
+
+def test_thing_known_answer_vectors_on_gpu():  # runtests.jl:143-224
+    A = load_csc("thing")
+    g = load_npz("thing_solutions")
+    n = 46
+    b = np.zeros(n); b[0], b[1] = 1, -1
+    ml = AMG.ruge_stuben(A, presmoother=FWD, postsmoother=FWD, coarse_solver=AMG.Pinv)
+    x = AMG._solve(ml, A @ np.ones(n), maxiter=1, abstol=1e-12)
+    assert ((x - g["solve_Aones_fwd_maxiter1"]) ** 2).sum() < 1e-8
+    x = AMG.solve(A, b, AMG.RugeStubenAMG(), presmoother=FWD, postsmoother=FWD, maxiter=1, abstol=1e-12,
+                  coarse_solver=AMG.Pinv)
+    assert ((x - g["solve_b_fwd_maxiter1"]) ** 2).sum() < 1e-8
+    x = AMG.cg(A, b, Pl=AMG.aspreconditioner(ml))
+    assert ((x - g["cg_fwd"]) ** 2).sum() < 1e-8
+    ml = AMG.ruge_stuben(A, coarse_solver=AMG.Pinv)
+    x = AMG.cg(A, b, Pl=AMG.aspreconditioner(ml), maxiter=100000, reltol=1e-6)
+    assert ((x - g["cg_sym_reltol1e-6"]) ** 2).sum() < 1e-8
+    x = AMG._solve(ml, b, maxiter=1, reltol=1e-12)
+    assert ((x - g["solve_b_sym_maxiter1"]) ** 2).sum() < 1e-8
+
+
+def test_sa_jacobi_config_c2_small():
+    """Config C2 at reduced size: smoothed_aggregation + Jacobi(2/3) pre/post."""
+    A = AMG.poisson((96, 96))
+    jac = AMG.Jacobi(2 / 3)
+    ml = AMG.smoothed_aggregation(A, presmoother=jac, postsmoother=jac)
+    b = A @ np.ones(A.m)
+    x = _check_solve(ml, b, reltol=1e-8, maxiter=200)
+    assert np.linalg.norm(b - A @ x) < 1e-8 * np.linalg.norm(b)
+    b2 = uniform(A.m, 0)
+    _check_solve(ml, b2, reltol=1e-8, maxiter=200)
+
+
+def test_rs_gs_config_c3_small():
+    """Config C3 at reduced size: 3-D Poisson, ruge_stuben defaults (symmetric GS)."""
+    A = AMG.poisson((40, 40, 40))
+    ml = AMG.ruge_stuben(A)
+    b = uniform(A.m, 0)
+    x = _check_solve(ml, b)
+    assert np.linalg.norm(b - A @ x) < 1.5e-8 * np.linalg.norm(b)
+
+
+def test_lin_elastic_c5():  # nns_test.jl:213-226
+    d = load_npz("lin_elastic_2d")
+    A = load_csc("lin_elastic_2d")
+    ml = AMG.smoothed_aggregation(A, B=d["B"])
+    x, hist = AMG.solve(A, d["b"], AMG.SmoothedAggregationAMG(), log=True, reltol=1e-10, B=d["B"])
+    assert len(hist) - 1 == 27
+    assert np.linalg.norm(A @ x - d["b"]) <= 1.5e-8 * np.linalg.norm(d["b"])
+    xo, _, _ = O.OracleHierarchy(ml).solve(d["b"], reltol=1e-10)
+    assert rel(x, xo) <= TOL
+    xp, log = AMG.cg(A, d["b"], Pl=AMG.aspreconditioner(ml), reltol=1e-10, log=True)
+    xpo, _, itp = O.OracleHierarchy(ml).pcg(d["b"], reltol=1e-10)
+    assert log["iters"] == itp == 13 and rel(xp, xpo) <= 1e-9
+
+
+def test_degenerate_hierarchies():
+    # no levels: every "cycle" is the coarse solve (multilevel.jl:179-180)
+    for sz in (10, 5, 2):
+        A = AMG.poisson(sz)
+        ml = AMG.ruge_stuben(A)
+        b = A @ np.ones(sz)
+        x = _check_solve(ml, b)
+        assert np.allclose(x, 1.0)
+    # b = 0: zero iterations, x = 0, residuals == [0]
+    ml = AMG.ruge_stuben(AMG.poisson(100))
+    x, hist = AMG._solve(ml, np.zeros(100), log=True)
+    assert np.all(x == 0) and hist.tolist() == [0.0]
+    # calculate_residual = false: exactly maxiter cycles
+    b = AMG.poisson(100) @ np.ones(100)
+    _check_solve(ml, b, maxiter=3, calculate_residual=False)
+    # big single-level problem through the pluggable host coarse solver (issue #56, SA branch)
+    X = AMG.SparseMatrixCSC.from_scipy(AMG.poisson(27000).to_scipy() + 24.0 * sp.identity(27000, format="csc"))
+    ml = AMG.smoothed_aggregation(X, strength=AMG.SymmetricStrength(0.05))
+    assert len(ml) == 1
+    b = uniform(27000, 56)
+    x = AMG._solve(ml, b, reltol=1e-10)
+    assert np.linalg.norm(X @ x - b) <= 1e-10 * np.linalg.norm(b)
+
+
+def test_issue56_tight_tolerance_rs():  # test_regression.jl:59-66
+    X = AMG.SparseMatrixCSC.from_scipy(AMG.poisson(27000).to_scipy() + 24.0 * sp.identity(27000, format="csc"))
+    b = uniform(27000, 56)
+    ml = AMG.ruge_stuben(X)
+    x = _check_solve(ml, b, reltol=1e-10)
+    import scipy.sparse.linalg as spla
+    ref = spla.spsolve(X.to_scipy(), b)
+    assert rel(x, ref) <= 1e-10
+
+
+def test_issue95_nosymmetry_hierarchy():  # test_regression.jl:71-83
+    rng = np.random.default_rng(95)
+    N = 10000
+    M = sp.random(N, N, 0.001, random_state=rng, format="csc") + 5 * sp.identity(N, format="csc")
+    b = np.ones(N)
+    for f in (AMG.ruge_stuben, AMG.smoothed_aggregation):
+        ml = f(M, symmetry=AMG.NoSymmetry())
+        x = AMG._solve(ml, b)
+        xo, _, _ = O.OracleHierarchy(ml).solve(b)
+        assert np.linalg.norm(M @ x - b) <= 1e-8 * np.linalg.norm(b)
+        assert rel(x, xo) <= TOL
+
+
+def test_user_assembled_geometric_hierarchy():  # test/gmg.jl:1-49 via the public Level/MultiLevel constructors
+    def extend(A):
+        nF = A.m
+        nC = (nF - 1) // 2 + 1 if nF % 2 == 0 else (nF - 1) // 2
+        I, J, V = [], [], []
+        for k in range(1, nC + 1):
+            I.append(2 * k); J.append(k); V.append(1.0)
+        for k in range(1, nC):
+            I += [2 * k + 1, 2 * k + 1]; J += [k, k + 1]; V += [0.5, 0.5]
+        P = sp.csc_matrix((V, (np.array(I) - 1, np.array(J) - 1)), shape=(nF, nC))
+        return P, sp.csc_matrix(P.T)
+    A = AMG.poisson(4000)
+    levels = []
+    while len(levels) + 1 < 10 and A.m > 10:
+        P, R = extend(A)
+        levels.append(AMG.Level(A, P, R, SYM, SYM))
+        A = AMG.SparseMatrixCSC.from_scipy(R @ A.to_scipy() @ P)
+    ml = AMG.MultiLevel(levels, A, AMG.Pinv(A), SYM, SYM)
+    assert len(ml) == 10
+    b = levels[0].A @ np.ones(4000)
+    x, hist = AMG._solve(ml, b, log=True, maxiter=20)
+    xo, ho, _ = O.OracleHierarchy(ml).solve(b, maxiter=20)
+    assert len(hist) == len(ho) and rel(x, xo) <= TOL
+
+
+def test_full_size_properties_spmv_linearity_and_symmetry():
+    """Size-independent properties at a larger size than the oracle comparison: linearity of A x,
+    <Ax,y> = <x,Ay> (symmetric operator), residual(x=0) = b."""
+    A = AMG.poisson((128, 128, 64))
+    n = A.m
+    op = AMG.DeviceCSR(n, n, *A.csr_arrays())
+    x, y = uniform(n, 1), uniform(n, 2)
+    Ax, Ay = op.spmv(x), op.spmv(y)
+    assert rel(op.spmv(2.0 * x - 3.0 * y), 2.0 * Ax - 3.0 * Ay) <= 1e-13
+    assert abs(Ax @ y - x @ Ay) <= 1e-12 * abs(Ax @ y)
+    assert np.array_equal(op.residual(np.zeros(n), y), y)
+    # interior rows of the 7-point stencil annihilate constants
+    r = op.spmv(np.ones(n)).reshape((64, 128, 128))
+    assert np.all(r[1:-1, 1:-1, 1:-1] == 0)
