@@ -130,7 +130,7 @@ def main():
 
     vb = vcycle_bytes(ml, 4)
     out = {
-        "metric": "V-cycle unknowns/sec + fine-level SpMV GB/s (% HBM peak), 3-D Poisson %d^3" % N,
+        "metric": f"V-cycle unknowns/sec + fine-level SpMV GB/s (% HBM peak), 3-D Poisson {N}^3",
         "value": value, "unit": "unknowns/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
