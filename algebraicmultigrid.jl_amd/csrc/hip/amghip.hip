@@ -69,13 +69,17 @@ struct GsSchedule {
   int32_t* perm = nullptr;
   int32_t* dpos = nullptr;
   double* diag = nullptr;
+  i4_t* rowmeta = nullptr;  // per permuted row {start, end, diagonal position, original row}
+  i4_t* desc = nullptr;     // per dependency level {first row, end row, first nnz, end nnz}
+  double* bp = nullptr;     // right-hand side in dependency-level order (scratch)
+  int64_t n = 0;
   int64_t bytes = 0;
-  struct Seg { int l0, l1; bool chain; };  // dependency levels [l0, l1)
+  struct Seg { int l0, l1; bool chain; int rows; };  // dependency levels [l0, l1); rows per workgroup (launch)
   std::vector<Seg> segs;
   void free_dev() {
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
-    hipFree(perm); hipFree(dpos); hipFree(diag);
-    d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = nullptr;
+    hipFree(perm); hipFree(dpos); hipFree(diag); hipFree(rowmeta); hipFree(desc); hipFree(bp);
+    d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = bp = nullptr; rowmeta = desc = nullptr;
   }
 };
 
@@ -207,19 +211,43 @@ int gs_build(GsSchedule* g, int64_t nrows, const int32_t* rowptr, const int32_t*
   RC_TRY(dev_upload(&g->dpos, pdpos.data(), n));
   RC_TRY(dev_upload(&g->diag, pdiag.data(), n));
   RC_TRY(dev_upload(&g->d_lvl_ptr, g->lvl_ptr.data(), g->nlev + 1));
-  g->bytes = (n + 1) * 4 + nnz * 12 + n * 16 + (g->nlev + 1) * 4;
+  {
+    std::vector<i4_t> meta(n), desc(g->nlev);
+    for (int64_t p = 0; p < n; ++p) meta[p] = i4_t{prow[p], prow[p + 1], pdpos[p], perm[p]};
+    for (int l = 0; l < g->nlev; ++l)
+      desc[l] = i4_t{g->lvl_ptr[l], g->lvl_ptr[l + 1], prow[g->lvl_ptr[l]], prow[g->lvl_ptr[l + 1]]};
+    RC_TRY(dev_upload(&g->rowmeta, meta.data(), n));
+    RC_TRY(dev_upload(&g->desc, desc.data(), g->nlev));
+  }
+  RC_TRY(dev_alloc(&g->bp, n));
+  g->n = n;
+  g->bytes = (n + 1) * 4 + nnz * 12 + n * 16 + (g->nlev + 1) * 4 + n * 24 + g->nlev * 16;
   // segments: runs of narrow dependency levels are chained in one workgroup
+  // A dependency level is chained (stays inside one workgroup) when it has at most
+  // one row per thread and its products fit one LDS pass; anything larger is worth
+  // a launch of its own that spreads over the CUs.
+  auto narrow = [&](int lv) {
+    const int width = g->lvl_ptr[lv + 1] - g->lvl_ptr[lv];
+    const int lnnz = prow[g->lvl_ptr[lv + 1]] - prow[g->lvl_ptr[lv]];
+    return width <= kChainWidth && lnnz <= kChainLds;
+  };
   g->segs.clear();
   int l = 0;
   while (l < g->nlev) {
-    const int width = g->lvl_ptr[l + 1] - g->lvl_ptr[l];
-    if (width <= kChainWidth) {
+    if (narrow(l)) {
       int e = l + 1;
-      while (e < g->nlev && g->lvl_ptr[e + 1] - g->lvl_ptr[e] <= kChainWidth) ++e;
-      g->segs.push_back({l, e, true});
+      while (e < g->nlev && narrow(e)) ++e;
+      g->segs.push_back({l, e, true, 0});
       l = e;
     } else {
-      g->segs.push_back({l, l + 1, false});
+      // rows per workgroup for this level's launch: about one LDS pass of products per
+      // workgroup, as many workgroups as the level can feed (the launch is latency-bound)
+      const int width = g->lvl_ptr[l + 1] - g->lvl_ptr[l];
+      const int lnnz = prow[g->lvl_ptr[l + 1]] - prow[g->lvl_ptr[l]];
+      const double avg = std::max(1.0, (double)lnnz / width);
+      int rows = 256;
+      while (rows > 8 && rows * avg > 2048.0) rows >>= 1;
+      g->segs.push_back({l, l + 1, false, rows});
       ++l;
     }
   }
@@ -244,15 +272,30 @@ int csr_ensure_gs(amgh_csr* op) {
   return AMGH_OK;
 }
 
-template <int MODE>
+template <int MODE, class CFG = DefaultCfg>
 int launch_stream(const StreamArgs& a, hipStream_t st) {
   const int nrows = a.row_end - a.row_begin;
   if (nrows <= 0) return AMGH_OK;
-  const int nb = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
-  const int per = (nb + kNumXcd - 1) / kNumXcd;
-  hipLaunchKernelGGL(csr_stream_kernel<MODE>, dim3((unsigned)(per * kNumXcd)), dim3(kThreads), 0, st, a);
+  const int nb = (nrows + CFG::ROWS - 1) / CFG::ROWS;
+  const int grid = CFG::XCD ? ((nb + kNumXcd - 1) / kNumXcd) * kNumXcd : nb;
+  hipLaunchKernelGGL((csr_stream_kernel<MODE, CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), 0, st, a);
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
+}
+
+// One dependency level of a Gauss-Seidel / SOR sweep: a latency-bound launch, so the
+// rows are spread over many small workgroups (rows per workgroup chosen at schedule
+// build time from the level's average row length).
+template <int MODE>
+int launch_gs_level(const StreamArgs& a, int rows, hipStream_t st) {
+  switch (rows) {
+    case 8: return launch_stream<MODE, StreamCfg<256, 8, 2048, 1, false, false>>(a, st);
+    case 16: return launch_stream<MODE, StreamCfg<256, 16, 2048, 1, false, false>>(a, st);
+    case 32: return launch_stream<MODE, StreamCfg<256, 32, 2048, 1, false, false>>(a, st);
+    case 64: return launch_stream<MODE, StreamCfg<256, 64, 2048, 1, false, false>>(a, st);
+    case 128: return launch_stream<MODE, StreamCfg<256, 128, 2048, 1, false, false>>(a, st);
+    default: return launch_stream<MODE, StreamCfg<256, 256, 2048, 2, false, false>>(a, st);
+  }
 }
 
 int csr_apply(const amgh_csr* op, int mode, const double* x, const double* b, double* y, hipStream_t st) {
@@ -278,16 +321,23 @@ int csr_jacobi(amgh_csr* op, double omega, const double* xin, const double* b, d
 }
 
 // One Gauss-Seidel / SOR sweep, forward or backward, exact lexicographic order.
-int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st) {
+// gather_b: (re)build the dependency-level-ordered copy of b (needed once per b).
+int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st,
+                 bool gather_b = true) {
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
+  if (g->n <= 0) return AMGH_OK;
+  if (gather_b) {
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n)), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n);
+    HIP_TRY(hipGetLastError());
+  }
   const int ns = (int)g->segs.size();
   for (int k = 0; k < ns; ++k) {
     const GsSchedule::Seg& s = g->segs[backward ? ns - 1 - k : k];
     if (s.chain) {
       ChainArgs c{};
-      c.rowptr = g->rowptr; c.col = g->col; c.val = g->val; c.x = x; c.b = b;
-      c.dpos = g->dpos; c.diag = g->diag; c.perm = g->perm; c.lvl_ptr = g->d_lvl_ptr; c.omega = omega;
+      c.col = g->col; c.val = g->val; c.x = x; c.bp = g->bp; c.diag = g->diag;
+      c.rowmeta = g->rowmeta; c.desc = g->desc; c.omega = omega;
       if (!backward) { c.lvl_begin = s.l0; c.lvl_end = s.l1; c.step = 1; }
       else { c.lvl_begin = s.l1 - 1; c.lvl_end = s.l0 - 1; c.step = -1; }
       if (sor) hipLaunchKernelGGL(gs_chain_kernel<true>, dim3(1), dim3(kChainThreads), 0, st, c);
@@ -296,9 +346,9 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     } else {
       StreamArgs a{};
       a.rowptr = g->rowptr; a.col = g->col; a.val = g->val;
-      a.x = x; a.y = x; a.b = b; a.dpos = g->dpos; a.diag = g->diag; a.perm = g->perm; a.omega = omega;
+      a.x = x; a.y = x; a.b = g->bp; a.dpos = g->dpos; a.diag = g->diag; a.perm = g->perm; a.omega = omega;
       a.row_begin = g->lvl_ptr[s.l0]; a.row_end = g->lvl_ptr[s.l0 + 1];
-      RC_TRY(sor ? launch_stream<M_SOR>(a, st) : launch_stream<M_GS>(a, st));
+      RC_TRY(sor ? launch_gs_level<M_SOR>(a, s.rows, st) : launch_gs_level<M_GS>(a, s.rows, st));
     }
   }
   return AMGH_OK;
@@ -343,6 +393,9 @@ struct amgh_handle {
   std::vector<Ev> pending;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool use_graph = true;
+  // hipGraph cache of whole cycles, keyed by the (x, b, cycle) they were captured on
+  struct CycleGraph { const double* x; const double* b; int cyc; hipGraphExec_t exec; };
+  std::vector<CycleGraph> graphs;
 };
 
 namespace {
@@ -431,10 +484,13 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& 
       case AMGH_SMOOTH_GS:
       case AMGH_SMOOTH_SOR: {
         const bool sor = s.kind == AMGH_SMOOTH_SOR;
-        if (s.sweep == AMGH_SWEEP_FORWARD || s.sweep == AMGH_SWEEP_SYMMETRIC)
-          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream));
+        bool gather = (it == 0);  // b is the same for every sweep of this smooth! call
+        if (s.sweep == AMGH_SWEEP_FORWARD || s.sweep == AMGH_SWEEP_SYMMETRIC) {
+          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, gather));
+          gather = false;
+        }
         if (s.sweep == AMGH_SWEEP_BACKWARD || s.sweep == AMGH_SWEEP_SYMMETRIC)
-          RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream));
+          RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream, gather));
         break;
       }
       default: return AMGH_EINVAL;
@@ -504,6 +560,48 @@ int apply_once(amgh_t* h, double* x, const double* b, int cyc) {
   return cycle(h, 0, x, b, cyc);
 }
 
+// apply_once through a captured hipGraph: a cycle is thousands of short,
+// launch-bound kernels (one per Gauss-Seidel dependency level), replaying them from a
+// graph takes the host launch cost off the critical path.  Falls back to eager
+// launches when profiling, with a host coarse solver, or if capture fails.
+int apply_cycle(amgh_t* h, double* x, const double* b, int cyc) {
+  if (!h->use_graph || h->profile || h->coarse_fn || h->levels.empty()) return apply_once(h, x, b, cyc);
+  for (auto& g : h->graphs)
+    if (g.x == x && g.b == b && g.cyc == cyc) {
+      HIP_TRY(hipGraphLaunch(g.exec, h->stream));
+      return AMGH_OK;
+    }
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return apply_once(h, x, b, cyc);
+  }
+  const int rc = apply_once(h, x, b, cyc);
+  const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+  if (rc != AMGH_OK || e != hipSuccess || !graph) {
+    if (graph) hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    if (rc != AMGH_OK) return rc;
+    h->use_graph = false;  // capture unsupported here: stay eager
+    return apply_once(h, x, b, cyc);
+  }
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (ei != hipSuccess) {
+    (void)hipGetLastError();
+    h->use_graph = false;
+    return apply_once(h, x, b, cyc);
+  }
+  if (h->graphs.size() >= 6) {
+    hipGraphExecDestroy(h->graphs.front().exec);
+    h->graphs.erase(h->graphs.begin());
+  }
+  h->graphs.push_back({x, b, cyc, exec});
+  HIP_TRY(hipGraphLaunch(exec, h->stream));
+  return AMGH_OK;
+}
+
 int fine_residual(amgh_t* h, const double* x, const double* b, double* r) {
   if (h->levels.empty()) {
     if (!h->has_finalA) return AMGH_ESTATE;
@@ -531,7 +629,7 @@ int solve_dev(amgh_t* h, const double* b, double* x, int cyc, int maxiter, doubl
   double* res = h->levels.empty() ? h->res_final : h->levels[0]->res;
   int itr = 1;
   while (itr <= maxiter && (!calc_res || normres > abstol)) {
-    RC_TRY(apply_once(h, x, b, cyc));
+    RC_TRY(apply_cycle(h, x, b, cyc));
     if (calc_res) {
       RC_TRY(fine_residual(h, x, b, res));
       RC_TRY(vec_norm_host(h, res, n, &normres));
@@ -577,7 +675,7 @@ int pcg_dev(amgh_t* h, const double* b, double* x, int cyc, int use_precond, int
   while (it < maxiter && residual > tol) {
     if (use_precond) {
       RC_TRY(vec_fill(h, c, n, 0.0));
-      RC_TRY(apply_once(h, c, r, cyc));
+      RC_TRY(apply_cycle(h, c, r, cyc));
     } else {
       RC_TRY(vec_copy(h, c, r, n));
     }
@@ -675,6 +773,7 @@ void amgh_destroy(amgh_t* h) {
   hipFree(h->coarse_op); hipFree(h->res_final); hipFree(h->partial); hipFree(h->scal);
   hipFree(h->x0); hipFree(h->b0); hipFree(h->pc_r); hipFree(h->pc_c); hipFree(h->pc_u);
   for (auto& e : h->pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (auto& g : h->graphs) hipGraphExecDestroy(g.exec);
   if (h->t0) hipEventDestroy(h->t0);
   if (h->t1) hipEventDestroy(h->t1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -838,7 +937,7 @@ int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle_) 
   if (!r_d || !z_d || cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   RC_TRY(vec_fill(h, z_d, fine_n(h), 0.0));
-  return apply_once(h, z_d, r_d, cycle_);
+  return apply_cycle(h, z_d, r_d, cycle_);
 }
 
 int amgh_precond_apply(amgh_t* h, const double* r, double* z, int cycle_) {

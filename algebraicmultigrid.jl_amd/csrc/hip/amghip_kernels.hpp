@@ -18,9 +18,6 @@ namespace amgh {
 
 constexpr int kWave = 64;
 constexpr int kThreads = 256;        // 4 waves / workgroup
-constexpr int kRowsPerThread = 2;    // rows per thread in the stream kernel
-constexpr int kRowsPerBlock = kThreads * kRowsPerThread;
-constexpr int kLdsNnz = 4096;        // products staged per pass (32 KiB + skew)
 constexpr int kNumXcd = 8;
 
 enum StreamMode : int {
@@ -55,38 +52,93 @@ __device__ __forceinline__ int skew(int k) { return k + (k >> 5); }
 // XCD-contiguous block mapping (workgroup b is observed to run on XCD b % 8):
 // give each XCD a contiguous eighth of the row blocks so that the +-nx rows'
 // x entries are re-used out of that XCD's own L2.  Speed only, never correctness.
+// The grid must be launched with 8*ceil(nb/8) workgroups.
 __device__ __forceinline__ int xcd_block(int b, int nb) {
   const int per = (nb + kNumXcd - 1) / kNumXcd;
-  const int lb = (b % kNumXcd) * per + b / kNumXcd;
-  return lb;  // may be >= nb for the ragged tail: caller must bounds-check
+  return (b % kNumXcd) * per + b / kNumXcd;  // may be >= nb: caller bounds-checks
 }
 
-// "CSR-stream": a workgroup owns kRowsPerBlock consecutive rows.  Their nonzeros
-// form one contiguous range of col/val, loaded with fully coalesced accesses;
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
+// matrix streams are read once: non-temporal loads keep them from evicting x from L2
+template <bool NT, class T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// Tunables of the stream kernel (chosen by tools/spmv_bench.hip measurements).
+template <int THREADS_, int ROWS_, int LDS_NNZ_, int VEC_, bool NT_, bool XCD_>
+struct StreamCfg {
+  static constexpr int THREADS = THREADS_;  // workgroup size
+  static constexpr int ROWS = ROWS_;        // rows per workgroup (may be < THREADS: latency-bound launches)
+  static constexpr int RPT = (ROWS_ + THREADS_ - 1) / THREADS_;  // rows per summing thread
+  static constexpr int LDS_NNZ = LDS_NNZ_;  // products staged per pass
+  static constexpr int VEC = VEC_;          // nonzeros per thread per load (1, 2, 4)
+  static constexpr bool NT = NT_;           // non-temporal loads of col/val
+  static constexpr bool XCD = XCD_;         // XCD-contiguous block mapping
+};
+
+// In-order sum of the staged products s[lo..hi) (indices relative to c0), skipping
+// position dp when SKIPD.  The LDS reads of 8 products are issued together; the
+// additions stay strictly sequential, so the result is the scalar loop's.
+template <bool SKIPD>
+__device__ __forceinline__ double seq_sum(const double* s_prod, int lo, int hi, int c0, int dp, double acc) {
+  int j = lo;
+  for (; j + 8 <= hi; j += 8) {
+    double p[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p[e] = s_prod[skew(j + e - c0)];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (SKIPD) acc = (j + e != dp) ? acc + p[e] : acc;
+      else acc += p[e];
+    }
+  }
+  for (; j < hi; ++j) {
+    const double p = s_prod[skew(j - c0)];
+    if (SKIPD) acc = (j != dp) ? acc + p : acc;
+    else acc += p;
+  }
+  return acc;
+}
+
+// "CSR-stream": a workgroup owns ROWS consecutive rows.  Their nonzeros form one
+// contiguous range of col/val, loaded with fully coalesced (vector) accesses;
 // products val*x[col] are staged in LDS; each thread then sums its own rows'
 // segments sequentially in index order.  Row ranges with more products than fit
 // in LDS are processed in several passes (any row length is handled).
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void csr_stream_kernel(StreamArgs a) {
-  __shared__ double s_prod[kLdsNnz + (kLdsNnz >> 5) + 2];
+template <int MODE, class CFG>
+__global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) {
+  constexpr int T = CFG::THREADS, RPT = CFG::RPT, LDSN = CFG::LDS_NNZ, VEC = CFG::VEC;
+  constexpr bool NT = CFG::NT;
+  __shared__ double s_prod[LDSN + (LDSN >> 5) + 2];
 
   const int nrows = a.row_end - a.row_begin;
-  const int nb = (nrows + kRowsPerBlock - 1) / kRowsPerBlock;
-  const int lb = xcd_block(blockIdx.x, nb);
+  const int nb = (nrows + CFG::ROWS - 1) / CFG::ROWS;
+  const int lb = CFG::XCD ? xcd_block(blockIdx.x, nb) : (int)blockIdx.x;
   if (lb >= nb) return;
-  const int r0 = a.row_begin + lb * kRowsPerBlock;
-  const int r1 = min(r0 + kRowsPerBlock, a.row_end);
+  const int r0 = a.row_begin + lb * CFG::ROWS;
+  const int r1 = min(r0 + CFG::ROWS, a.row_end);
   const int tid = threadIdx.x;
 
-  int rs[kRowsPerThread], re[kRowsPerThread], dp[kRowsPerThread];
-  double acc[kRowsPerThread];
+  int rs[RPT], re[RPT], dp[RPT], gi[RPT];
+  double acc[RPT], gd[RPT], gb[RPT];
 #pragma unroll
-  for (int q = 0; q < kRowsPerThread; ++q) {
-    const int r = r0 + tid + q * kThreads;
-    if (r < r1) {
+  for (int q = 0; q < RPT; ++q) {
+    const int r = r0 + tid + q * T;
+    gi[q] = 0; gd[q] = 0.0; gb[q] = 0.0;
+    if (tid + q * T < CFG::ROWS && r < r1) {
       rs[q] = a.rowptr[r];
       re[q] = a.rowptr[r + 1];
       dp[q] = (MODE >= M_JACOBI) ? a.dpos[r] : -1;
+      if (MODE >= M_GS) {  // issued up front: independent of the products, off the critical path
+        gi[q] = a.perm[r];
+        gd[q] = a.diag[r];
+        gb[q] = a.b[r];  // b pre-gathered into dependency-level order
+      }
     } else {
       rs[q] = re[q] = 0;
       dp[q] = -1;
@@ -96,33 +148,58 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(StreamArgs a) {
   const int p0 = a.rowptr[r0];
   const int p1 = a.rowptr[r1];
 
-  for (int c0 = p0; c0 < p1; c0 += kLdsNnz) {
-    const int c1 = min(c0 + kLdsNnz, p1);
-    for (int k = c0 + tid; k < c1; k += kThreads) {
-      const double v = a.val[k];
-      const int c = a.col[k];
-      s_prod[skew(k - c0)] = v * a.x[c];
+  for (int c0 = p0; c0 < p1; c0 += LDSN) {
+    const int c1 = min(c0 + LDSN, p1);
+    if (VEC == 1) {
+      for (int k = c0 + tid; k < c1; k += T) {
+        const double v = ld_stream<NT>(a.val + k);
+        const int c = ld_stream<NT>(a.col + k);
+        s_prod[skew(k - c0)] = v * a.x[c];
+      }
+    } else {
+      const int a0 = c0 & ~(VEC - 1);  // hipMalloc'ed arrays: index multiple of VEC => 16 B aligned
+      for (int k = a0 + VEC * tid; k < c1; k += VEC * T) {
+        if (k >= c0 && k + VEC <= c1) {
+          double v[VEC];
+          int c[VEC];
+          if (VEC == 2) {
+            const d2_t vv = ld_stream<NT>((const d2_t*)(a.val + k));
+            const i2_t cc = ld_stream<NT>((const i2_t*)(a.col + k));
+            v[0] = vv.x; v[1] = vv.y; c[0] = cc.x; c[1] = cc.y;
+          } else {
+            const d2_t v0 = ld_stream<NT>((const d2_t*)(a.val + k));
+            const d2_t v1 = ld_stream<NT>((const d2_t*)(a.val + k + 2));
+            const i4_t cc = ld_stream<NT>((const i4_t*)(a.col + k));
+            v[0] = v0.x; v[1] = v0.y; v[VEC - 2] = v1.x; v[VEC - 1] = v1.y;
+            c[0] = cc.x; c[1] = cc.y; c[VEC - 2] = cc.z; c[VEC - 1] = cc.w;
+          }
+          double xv[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) xv[e] = a.x[c[e]];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) s_prod[skew(k + e - c0)] = v[e] * xv[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const int kk = k + e;
+            if (kk >= c0 && kk < c1) s_prod[skew(kk - c0)] = a.val[kk] * a.x[a.col[kk]];
+          }
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < kRowsPerThread; ++q) {
+    for (int q = 0; q < RPT; ++q) {
       const int lo = max(rs[q], c0), hi = min(re[q], c1);
-      for (int j = lo; j < hi; ++j) {
-        const double p = s_prod[skew(j - c0)];
-        if (MODE >= M_JACOBI) {
-          if (j != dp[q]) acc[q] += p;
-        } else {
-          acc[q] += p;
-        }
-      }
+      acc[q] = seq_sum<(MODE >= M_JACOBI)>(s_prod, lo, hi, c0, dp[q], acc[q]);
     }
     if (c1 < p1) __syncthreads();
   }
 
 #pragma unroll
-  for (int q = 0; q < kRowsPerThread; ++q) {
-    const int r = r0 + tid + q * kThreads;
-    if (r >= r1) continue;
+  for (int q = 0; q < RPT; ++q) {
+    const int r = r0 + tid + q * T;
+    if (tid + q * T >= CFG::ROWS || r >= r1) continue;
     if (MODE == M_SPMV) {
       a.y[r] = acc[q];
     } else if (MODE == M_RESID) {
@@ -135,17 +212,28 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(StreamArgs a) {
       const double cand = (1.0 - a.omega) * t + a.omega * ((a.b[r] - acc[q]) / d);
       a.y[r] = (d == 0.0) ? t : cand;
     } else {
-      const int i = a.perm ? a.perm[r] : r;
-      const double d = a.diag[r];
+      const int i = gi[q];
+      const double d = gd[q];
       if (d != 0.0) {
         if (MODE == M_GS) {
-          a.y[i] = (a.b[i] - acc[q]) / d;
+          a.y[i] = (gb[q] - acc[q]) / d;
         } else {
-          a.y[i] = (1.0 - a.omega) * a.y[i] + (a.omega / d) * (a.b[i] - acc[q]);
+          a.y[i] = (1.0 - a.omega) * a.y[i] + (a.omega / d) * (gb[q] - acc[q]);
         }
       }
     }
   }
+}
+
+// default configuration used by the library (tools/spmv_bench.hip, profiles/r01_spmv_variants.log)
+using DefaultCfg = StreamCfg<1024, 1024, 8192, 4, false, false>;
+
+// bp[r] = b[perm[r]]: right-hand side gathered into dependency-level order once per
+// smoother application, so that every level kernel reads it coalesced with no
+// perm -> b dependent hop.
+__global__ void gather_perm_kernel(const double* __restrict__ b, const int32_t* __restrict__ perm,
+                                   double* __restrict__ bp, int n) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) bp[r] = b[perm[r]];
 }
 
 // Single-workgroup chain over consecutive NARROW dependency levels of a
@@ -155,47 +243,109 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(StreamArgs a) {
 // level's wavefront, where a kernel boundary per dependency level (~1.5 us)
 // would dominate.
 struct ChainArgs {
-  const int32_t* rowptr;
-  const int32_t* col;
+  const int32_t* col;      // level-permuted matrix
   const double* val;
   double* x;
-  const double* b;
-  const int32_t* dpos;
-  const double* diag;
-  const int32_t* perm;
-  const int32_t* lvl_ptr;  // device copy of the dependency-level pointer
+  const double* bp;        // b in dependency-level order (gather_perm_kernel)
+  const double* diag;      // per permuted row
+  const i4_t* rowmeta;     // per permuted row: {row start, row end, diagonal position, original row id}
+  const i4_t* desc;        // per dependency level: {first row, last row + 1, first nnz, last nnz + 1}
   double omega;
   int32_t lvl_begin;       // dependency levels [lvl_begin, lvl_end) in sweep order
   int32_t lvl_end;
   int32_t step;            // +1 forward, -1 backward (then lvl_begin > lvl_end)
 };
 
-constexpr int kChainThreads = 1024;
+constexpr int kChainThreads = 1024;  // = max rows of a chained dependency level: one row per thread
+constexpr int kChainLds = 8192;      // products staged per pass (64 KiB + skew)
+constexpr int kChainPf = 4;          // nonzeros per thread prefetched for the NEXT dependency level
+
+struct ChainRow {
+  i4_t m;       // rowmeta
+  double d, b;  // diagonal, right-hand side
+  double pv[kChainPf];
+  int pc[kChainPf];
+};
+
+// Everything a dependency level needs that does NOT depend on x: issued one level
+// ahead so that only the x gather, the LDS pass and the x store are on the
+// critical path between two workgroup barriers.
+__device__ __forceinline__ void chain_prefetch(const ChainArgs& a, const i4_t ds, int tid, ChainRow& o) {
+  const int r = ds.x + tid;
+  if (r < ds.y) {
+    o.m = a.rowmeta[r];
+    o.d = a.diag[r];
+    o.b = a.bp[r];
+  } else {
+    o.m = i4_t{0, 0, -1, -1};
+    o.d = 0.0;
+    o.b = 0.0;
+  }
+#pragma unroll
+  for (int e = 0; e < kChainPf; ++e) {
+    const int k = ds.z + tid + e * kChainThreads;
+    if (k < ds.w) {
+      o.pv[e] = a.val[k];
+      o.pc[e] = a.col[k];
+    } else {
+      o.pv[e] = 0.0;
+      o.pc[e] = 0;
+    }
+  }
+}
 
 template <bool SOR>
 __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a) {
-  for (int lv = a.lvl_begin; lv != a.lvl_end; lv += a.step) {
-    const int s = a.lvl_ptr[lv], e = a.lvl_ptr[lv + 1];
-    for (int r = s + (int)threadIdx.x; r < e; r += kChainThreads) {
-      const int js = a.rowptr[r], je = a.rowptr[r + 1];
-      const int dp = a.dpos[r];
-      double acc = 0.0;
-      for (int j = js; j < je; ++j) {
-        // keep the product un-fused with the running sum
-        const double p = __dmul_rn(a.val[j], a.x[a.col[j]]);
-        if (j != dp) acc = __dadd_rn(acc, p);
+  __shared__ double s_prod[kChainLds + (kChainLds >> 5) + 2];
+  const int tid = threadIdx.x;
+  int lv = a.lvl_begin;
+  if (lv == a.lvl_end) return;
+  i4_t ds = a.desc[lv];
+  i4_t ds_next = (lv + a.step != a.lvl_end) ? a.desc[lv + a.step] : ds;
+  ChainRow cur;
+  chain_prefetch(a, ds, tid, cur);
+  for (;;) {
+    const bool has_next = (lv + a.step != a.lvl_end);
+    // descriptor two levels ahead (scalar load), rows + leading nonzeros one level ahead
+    const bool has_next2 = has_next && (lv + 2 * a.step != a.lvl_end);
+    const i4_t ds_next2 = has_next2 ? a.desc[lv + 2 * a.step] : ds_next;
+    ChainRow nxt;
+    if (has_next) chain_prefetch(a, ds_next, tid, nxt);
+
+    const int p0 = ds.z, p1 = ds.w;
+    double acc = 0.0;
+    for (int c0 = p0; c0 < p1; c0 += kChainLds) {
+      const int c1 = min(c0 + kChainLds, p1);
+      if (c0 == p0) {
+#pragma unroll
+        for (int e = 0; e < kChainPf; ++e) {
+          const int k = p0 + tid + e * kChainThreads;
+          if (k < c1) s_prod[skew(k - c0)] = cur.pv[e] * a.x[cur.pc[e]];
+        }
+        for (int k = p0 + tid + kChainPf * kChainThreads; k < c1; k += kChainThreads)
+          s_prod[skew(k - c0)] = a.val[k] * a.x[a.col[k]];
+      } else {
+        for (int k = c0 + tid; k < c1; k += kChainThreads) s_prod[skew(k - c0)] = a.val[k] * a.x[a.col[k]];
       }
-      const double d = a.diag[r];
-      const int i = a.perm[r];
-      if (d != 0.0) {
-        if (SOR)
-          a.x[i] = (1.0 - a.omega) * a.x[i] + (a.omega / d) * (a.b[i] - acc);
-        else
-          a.x[i] = (a.b[i] - acc) / d;
-      }
+      __syncthreads();
+      const int lo = max(cur.m.x, c0), hi = min(cur.m.y, c1);
+      acc = seq_sum<true>(s_prod, lo, hi, c0, cur.m.z, acc);
+      if (c1 < p1) __syncthreads();
     }
+    if (cur.m.w >= 0 && cur.d != 0.0) {
+      const int i = cur.m.w;
+      if (SOR)
+        a.x[i] = (1.0 - a.omega) * a.x[i] + (a.omega / cur.d) * (cur.b - acc);
+      else
+        a.x[i] = (cur.b - acc) / cur.d;
+    }
+    if (!has_next) break;
     __threadfence_block();
-    __syncthreads();
+    __syncthreads();  // x of this dependency level visible to the whole workgroup (one CU)
+    lv += a.step;
+    ds = ds_next;
+    ds_next = ds_next2;
+    cur = nxt;
   }
 }
 
