@@ -392,7 +392,12 @@ struct amgh_handle {
   struct Ev { hipEvent_t a, b; int label, level; };
   std::vector<Ev> pending;
   hipEvent_t t0 = nullptr, t1 = nullptr;
-  bool use_graph = true;
+  // Measured on MI355X (profiles/r01_vcycle_profile.log): replaying a 256^3 V-cycle (~11k kernel
+  // nodes) from a hipGraph takes 180.1 ms vs 179.6 ms eager — the cycle is bound by the GPU-side
+  // latency of each dependency-level kernel, not by host launches — and rocprofv3's kernel tracing
+  // aborts on the replay (malformed AQL packet).  So graphs are opt-in (amgh_set_use_graph or
+  // AMGH_USE_GRAPH=1).
+  bool use_graph = false;
   // hipGraph cache of whole cycles, keyed by the (x, b, cycle) they were captured on
   struct CycleGraph { const double* x; const double* b; int cyc; hipGraphExec_t exec; };
   std::vector<CycleGraph> graphs;
@@ -756,6 +761,7 @@ int amgh_create(amgh_t** hp, int device, int nrhs) {
   if (e != hipSuccess) { delete h; return -(1000 + (int)e); }
   hipEventCreate(&h->t0);
   hipEventCreate(&h->t1);
+  if (const char* e = getenv("AMGH_USE_GRAPH")) h->use_graph = (e[0] == '1');
   *hp = h;
   return AMGH_OK;
 }

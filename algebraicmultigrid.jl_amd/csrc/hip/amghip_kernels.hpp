@@ -309,10 +309,21 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a) {
     // descriptor two levels ahead (scalar load), rows + leading nonzeros one level ahead
     const bool has_next2 = has_next && (lv + 2 * a.step != a.lvl_end);
     const i4_t ds_next2 = has_next2 ? a.desc[lv + 2 * a.step] : ds_next;
+    const int p0 = ds.z, p1 = ds.w;
+    // critical path first: the x gathers of this level's (already prefetched) leading
+    // nonzeros are issued BEFORE the next level's prefetch loads — vector-memory results
+    // return in order, so anything issued ahead of the gathers would delay them.
+    double xv[kChainPf];
+#pragma unroll
+    for (int e = 0; e < kChainPf; ++e) {
+      const int k = p0 + tid + e * kChainThreads;
+      xv[e] = (k < p1) ? a.x[cur.pc[e]] : 0.0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     ChainRow nxt;
     if (has_next) chain_prefetch(a, ds_next, tid, nxt);
+    __builtin_amdgcn_sched_barrier(0);
 
-    const int p0 = ds.z, p1 = ds.w;
     double acc = 0.0;
     for (int c0 = p0; c0 < p1; c0 += kChainLds) {
       const int c1 = min(c0 + kChainLds, p1);
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int e = 0; e < kChainPf; ++e) {
           const int k = p0 + tid + e * kChainThreads;
-          if (k < c1) s_prod[skew(k - c0)] = cur.pv[e] * a.x[cur.pc[e]];
+          if (k < c1) s_prod[skew(k - c0)] = cur.pv[e] * xv[e];
         }
         for (int k = p0 + tid + kChainPf * kChainThreads; k < c1; k += kChainThreads)
           s_prod[skew(k - c0)] = a.val[k] * a.x[a.col[k]];

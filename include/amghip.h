@@ -219,7 +219,8 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
 int amgh_profile_enable(amgh_t* h, int on);
 int amgh_profile_read(amgh_t* h, double* out, int reset);
 
-/* Launch-bound inner loops are captured in hipGraphs (default on).              */
+/* Replay whole cycles from captured hipGraphs (default off: measured no gain on MI355X,
+ * the cycle is GPU-latency-bound; AMGH_USE_GRAPH=1 in the environment also enables it). */
 int amgh_set_use_graph(amgh_t* h, int on);
 
 #ifdef __cplusplus
