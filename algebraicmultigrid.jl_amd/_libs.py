@@ -137,6 +137,10 @@ def hip_lib():
     L.amgh_csr_spmv_add_d.argtypes = [vp, vp, vp, vp]
     L.amgh_csr_jacobi_d.argtypes = [vp, C.c_double, vp, vp, vp, vp]
     L.amgh_csr_gs_d.argtypes = [vp, C.c_int, C.c_double, C.c_int, vp, vp, vp]
+    L.amgh_gather_d.argtypes = [C.c_int, i64, vp, vp, vp, vp]
+    L.amgh_dot_d.argtypes = [C.c_int, i64, vp, vp, vp, C.POINTER(C.c_double), vp]
+    L.amgh_cycle_d.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.amgh_set_stream.argtypes = [vp, vp]
     L.amgh_dev_alloc.argtypes = [C.c_int, i64, C.POINTER(vp)]
     L.amgh_dev_free.argtypes = [C.c_int, vp]
     L.amgh_dev_upload.argtypes = [C.c_int, vp, vp, i64]

@@ -369,6 +369,8 @@ struct amgh_handle {
   int device = 0;
   int nrhs = 1;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;  // the stream created by amgh_create (when an external one is in use)
+  bool ext_stream = false;
   std::vector<Level*> levels;
   // coarsest
   int64_t ncoarse = -1;
@@ -782,7 +784,8 @@ void amgh_destroy(amgh_t* h) {
   for (auto& g : h->graphs) hipGraphExecDestroy(g.exec);
   if (h->t0) hipEventDestroy(h->t0);
   if (h->t1) hipEventDestroy(h->t1);
-  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  else if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -959,6 +962,22 @@ int amgh_precond_apply(amgh_t* h, const double* r, double* z, int cycle_) {
   return AMGH_OK;
 }
 
+int amgh_cycle_d(amgh_t* h, int level, double* x_d, const double* b_d, int cycle_) {
+  RC_TRY(check_ready(h));
+  if (!x_d || !b_d || cycle_ < 0 || cycle_ > 2 || level < 0 || level > (int)h->levels.size()) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  if (level == (int)h->levels.size()) return coarse_solve(h, x_d, b_d);
+  return cycle(h, level, x_d, b_d, cycle_);
+}
+
+int amgh_set_stream(amgh_t* h, void* stream) {
+  if (!h) return AMGH_EINVAL;
+  h->ext_stream = true;
+  h->own_stream = h->own_stream ? h->own_stream : h->stream;
+  h->stream = stream ? (hipStream_t)stream : h->own_stream;
+  return AMGH_OK;
+}
+
 int amgh_pcg_d(amgh_t* h, const double* b_d, double* x_d, int cycle_, int use_precond, int maxiter, double abstol,
                double reltol, double* resid_hist, int* iters) {
   RC_TRY(check_ready(h));
@@ -1109,6 +1128,30 @@ int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, double
   if (!op || !x_d || !b_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(op->device));
   return csr_gs_sweep(op, backward != 0, is_sor != 0, omega, x_d, b_d, (hipStream_t)stream);
+}
+
+int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const double* src_d, double* dst_d, void* stream) {
+  if (n < 0 || (n > 0 && (!idx_d || !src_d || !dst_d)) || n >= INT32_MAX) return AMGH_EINVAL;
+  if (n == 0) return AMGH_OK;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src_d, idx_d, dst_d,
+                     (int)n);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+
+int amgh_dot_d(int device, int64_t n, const double* x_d, const double* y_d, double* scratch_d, double* out,
+               void* stream) {
+  if (n < 0 || !scratch_d || !out || (n > 0 && (!x_d || !y_d))) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kThreads - 1) / kThreads));
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, st, x_d, y_d, n, scratch_d + 1);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, st, scratch_d + 1, nb, scratch_d, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, scratch_d, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return AMGH_OK;
 }
 
 // ---- device memory + timing helpers ----------------------------------------

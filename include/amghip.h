@@ -146,6 +146,14 @@ int amgh_solve_d(amgh_t* h, const double* b_d, double* x_d, int cycle, int maxit
 int amgh_precond_apply(amgh_t* h, const double* r, double* z, int cycle);
 int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle);
 
+/* One `__solve!(x, ml, cycle, b, lvl)` (multilevel.jl:214-239) starting at level `level` on
+ * caller-provided device vectors of that level's size; x is NOT zeroed (the W/F re-entry of
+ * multilevel.jl:204-212 continues from the current x).  Enqueue only, no synchronisation.
+ * Used by the row-sharded multi-GPU driver for the levels collapsed onto rank 0.        */
+int amgh_cycle_d(amgh_t* h, int level, double* x_d, const double* b_d, int cycle);
+/* Make the handle enqueue on the caller's hipStream_t (e.g. torch's current stream).     */
+int amgh_set_stream(amgh_t* h, void* stream);
+
 /* cg(A, b; Pl = aspreconditioner(ml), abstol, reltol, maxiter) — the caller the
  * reference's tests and README pair with ldiv! (cycle_tests.jl:23-27,
  * runtests.jl:186,204, README.md:54-56).  IterativeSolvers.jl's PCG recurrence,
@@ -192,6 +200,13 @@ int amgh_csr_jacobi_d(amgh_csr_t* op, double omega, const double* xin_d, const d
  * otherwise SOR (:193-221).                                                     */
 int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d,
                   const double* b_d, void* stream);
+
+/* dst[i] = src[idx[i]], i < n  — halo pack / unpack (device pointers).              */
+int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const double* src_d, double* dst_d, void* stream);
+/* *out (HOST) = sum_i x[i]*y[i] over device vectors; deterministic two-pass wavefront
+ * reduction; synchronises `stream`.  scratch_d: >= 1025 doubles of device scratch.  */
+int amgh_dot_d(int device, int64_t n, const double* x_d, const double* y_d, double* scratch_d, double* out,
+               void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Device memory + timing helpers for hosts without a HIP binding of their own  */

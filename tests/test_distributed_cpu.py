@@ -1,0 +1,36 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the row-sharded driver (partitioning, halo
+all-gather, collapse to rank 0) with the test-side CPU backend, checked against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+import amg_amd as AMG
+from conftest import ROOT
+
+
+def test_row_ranges_and_vector_plan():
+    assert AMG.dist.row_ranges(10, 3) == [(0, 3), (3, 6), (6, 10)]
+    A = AMG.poisson((4, 4, 6))
+    rp, ci, va = A.csr_arrays()
+    ranges = AMG.dist.row_ranges(A.m, 2)
+    needs = AMG.dist._needs(rp, ci, ranges, ranges)
+    # z-slab partition of a 7-point stencil: each rank needs exactly the neighbour's boundary plane
+    assert np.array_equal(needs[0], np.arange(48, 64)) and np.array_equal(needs[1], np.arange(32, 48))
+    p0 = AMG.dist.VectorPlan(ranges, 0, needs)
+    p1 = AMG.dist.VectorPlan(ranges, 1, needs)
+    assert p0.max_send == p1.max_send == 16 and p0.total_send == 32
+    assert np.array_equal(p0.send_idx, np.arange(32, 48)) and np.array_equal(p1.send_idx, np.arange(0, 16))
+    assert np.array_equal(p0.unpack_idx, 16 + np.arange(16)) and np.array_equal(p1.unpack_idx, np.arange(16))
+    loc = p1.localize(np.array([48, 95, 32, 47]))
+    assert loc.tolist() == [0, 47, 48, 63]
+
+
+def test_gloo_world_size_2():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "tests", "dist_worker.py")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "DIST_WORKER_OK" in out, out[-3000:]
