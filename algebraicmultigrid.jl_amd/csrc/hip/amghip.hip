@@ -72,14 +72,16 @@ struct GsSchedule {
   i4_t* rowmeta = nullptr;  // per permuted row {start, end, diagonal position, original row}
   i4_t* desc = nullptr;     // per dependency level {first row, end row, first nnz, end nnz}
   double* bp = nullptr;     // right-hand side in dependency-level order (scratch)
-  int64_t n = 0;
+  double* xp = nullptr;     // x in dependency-level order (scratch, ncols entries)
+  int32_t* permx = nullptr; // perm extended by the identity over halo columns
+  int64_t n = 0, ncols = 0;
   int64_t bytes = 0;
   struct Seg { int l0, l1; bool chain; int rows; };  // dependency levels [l0, l1); rows per workgroup (launch)
   std::vector<Seg> segs;
   void free_dev() {
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
-    hipFree(perm); hipFree(dpos); hipFree(diag); hipFree(rowmeta); hipFree(desc); hipFree(bp);
-    d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = bp = nullptr; rowmeta = desc = nullptr;
+    hipFree(perm); hipFree(dpos); hipFree(diag); hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
+    d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = bp = xp = nullptr; rowmeta = desc = nullptr; permx = nullptr;
   }
 };
 
@@ -160,7 +162,8 @@ int csr_ensure_diag(amgh_csr* op, hipStream_t st) {
 }
 
 // Build the dependency-level schedule from HOST arrays of the smoother matrix.
-int gs_build(GsSchedule* g, int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val) {
+int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
+             const double* val) {
   const int64_t n = nrows;
   std::vector<int32_t> lev(n, 0);
   int32_t maxlev = -1;
@@ -185,6 +188,13 @@ int gs_build(GsSchedule* g, int64_t nrows, const int32_t* rowptr, const int32_t*
   if (g->nlev == 0) next.clear();
   for (int64_t i = 0; i < n; ++i) perm[next[lev[i]]++] = (int32_t)i;  // ascending row id inside a level
   std::vector<int32_t>().swap(lev);
+  // x is kept in dependency-level order during the sweeps: position p holds x[perm[p]]; columns
+  // beyond the square block (halo entries of a sharded operator) keep their place.  Each level
+  // then reads and writes contiguous stretches of x (coalesced, TLB-friendly) instead of a
+  // hyperplane scattered over the whole vector.
+  std::vector<int32_t> inv(std::max<int64_t>(ncols, n));
+  for (int64_t c = 0; c < (int64_t)inv.size(); ++c) inv[c] = (int32_t)c;
+  for (int64_t p2 = 0; p2 < n; ++p2) inv[perm[p2]] = (int32_t)p2;
   const int64_t nnz = rowptr[n];
   std::vector<int32_t> prow(n + 1), pcol(nnz), pdpos(n);
   std::vector<double> pval(nnz), pdiag(n);
@@ -195,7 +205,7 @@ int gs_build(GsSchedule* g, int64_t nrows, const int32_t* rowptr, const int32_t*
     int32_t dp = -1;
     double d = 0.0;
     for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-      pcol[w] = col[j];
+      pcol[w] = inv[col[j]];   // entries stay in the row's original column order (sum order)
       pval[w] = val[j];
       if (col[j] == i) { dp = (int32_t)w; d = val[j]; }
       ++w;
@@ -220,8 +230,15 @@ int gs_build(GsSchedule* g, int64_t nrows, const int32_t* rowptr, const int32_t*
     RC_TRY(dev_upload(&g->desc, desc.data(), g->nlev));
   }
   RC_TRY(dev_alloc(&g->bp, n));
+  g->ncols = std::max<int64_t>(ncols, n);
+  RC_TRY(dev_alloc(&g->xp, g->ncols));
+  {
+    std::vector<int32_t> permx(g->ncols);
+    for (int64_t c = 0; c < g->ncols; ++c) permx[c] = c < n ? perm[c] : (int32_t)c;
+    RC_TRY(dev_upload(&g->permx, permx.data(), g->ncols));
+  }
   g->n = n;
-  g->bytes = (n + 1) * 4 + nnz * 12 + n * 16 + (g->nlev + 1) * 4 + n * 24 + g->nlev * 16;
+  g->bytes = (n + 1) * 4 + nnz * 12 + n * 16 + (g->nlev + 1) * 4 + n * 24 + g->nlev * 16 + g->ncols * 12;
   // segments: runs of narrow dependency levels are chained in one workgroup
   // A dependency level is chained (stays inside one workgroup) when it has at most
   // one row per thread and its products fit one LDS pass; anything larger is worth
@@ -265,7 +282,7 @@ int csr_ensure_gs(amgh_csr* op) {
     HIP_TRY(hipMemcpy(val.data(), op->val, sizeof(double) * op->nnz, hipMemcpyDeviceToHost));
   }
   GsSchedule* g = new GsSchedule;
-  int rc = gs_build(g, n, rowptr.data(), col.data(), val.data());
+  int rc = gs_build(g, n, op->ncols, rowptr.data(), col.data(), val.data());
   if (rc != AMGH_OK) { g->free_dev(); delete g; return rc; }
   op->gs = g;
   op->bytes += g->bytes;
@@ -321,35 +338,48 @@ int csr_jacobi(amgh_csr* op, double omega, const double* xin, const double* b, d
 }
 
 // One Gauss-Seidel / SOR sweep, forward or backward, exact lexicographic order.
-// gather_b: (re)build the dependency-level-ordered copy of b (needed once per b).
+// first: gather b and x into dependency-level order (once per smooth! call);
+// last: scatter x back to natural order.  Between the two x lives in g->xp.
 int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st,
-                 bool gather_b = true) {
+                 bool first = true, bool last = true) {
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
   if (g->n <= 0) return AMGH_OK;
-  if (gather_b) {
+  if (first) {
     hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n)), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n);
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols)), dim3(256), 0, st, (const double*)x, g->permx,
+                       g->xp, (int)g->ncols);
     HIP_TRY(hipGetLastError());
   }
+  double* xp = g->xp;
   const int ns = (int)g->segs.size();
   for (int k = 0; k < ns; ++k) {
     const GsSchedule::Seg& s = g->segs[backward ? ns - 1 - k : k];
     if (s.chain) {
       ChainArgs c{};
-      c.col = g->col; c.val = g->val; c.x = x; c.bp = g->bp; c.diag = g->diag;
+      c.col = g->col; c.val = g->val; c.x = xp; c.bp = g->bp; c.diag = g->diag;
       c.rowmeta = g->rowmeta; c.desc = g->desc; c.omega = omega;
       if (!backward) { c.lvl_begin = s.l0; c.lvl_end = s.l1; c.step = 1; }
       else { c.lvl_begin = s.l1 - 1; c.lvl_end = s.l0 - 1; c.step = -1; }
-      if (sor) hipLaunchKernelGGL(gs_chain_kernel<true>, dim3(1), dim3(kChainThreads), 0, st, c);
-      else hipLaunchKernelGGL(gs_chain_kernel<false>, dim3(1), dim3(kChainThreads), 0, st, c);
+      const bool ldsx = g->ncols <= kChainLdsX;  // x (halo included) fits LDS
+      const int nx = (int)g->ncols;
+      if (sor && ldsx) hipLaunchKernelGGL((gs_chain_kernel<true, true>), dim3(1), dim3(kChainThreads), 0, st, c, nx);
+      else if (sor) hipLaunchKernelGGL((gs_chain_kernel<true, false>), dim3(1), dim3(kChainThreads), 0, st, c, nx);
+      else if (ldsx) hipLaunchKernelGGL((gs_chain_kernel<false, true>), dim3(1), dim3(kChainThreads), 0, st, c, nx);
+      else hipLaunchKernelGGL((gs_chain_kernel<false, false>), dim3(1), dim3(kChainThreads), 0, st, c, nx);
       HIP_TRY(hipGetLastError());
     } else {
       StreamArgs a{};
       a.rowptr = g->rowptr; a.col = g->col; a.val = g->val;
-      a.x = x; a.y = x; a.b = g->bp; a.dpos = g->dpos; a.diag = g->diag; a.perm = g->perm; a.omega = omega;
+      a.x = xp; a.y = xp; a.b = g->bp; a.dpos = g->dpos; a.diag = g->diag; a.perm = nullptr; a.omega = omega;
       a.row_begin = g->lvl_ptr[s.l0]; a.row_end = g->lvl_ptr[s.l0 + 1];
       RC_TRY(sor ? launch_gs_level<M_SOR>(a, s.rows, st) : launch_gs_level<M_GS>(a, s.rows, st));
     }
+  }
+  if (last) {
+    hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(g->n)), dim3(256), 0, st, (const double*)xp, g->perm, x,
+                       (int)g->n);
+    HIP_TRY(hipGetLastError());
   }
   return AMGH_OK;
 }
@@ -491,13 +521,14 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& 
       case AMGH_SMOOTH_GS:
       case AMGH_SMOOTH_SOR: {
         const bool sor = s.kind == AMGH_SMOOTH_SOR;
-        bool gather = (it == 0);  // b is the same for every sweep of this smooth! call
-        if (s.sweep == AMGH_SWEEP_FORWARD || s.sweep == AMGH_SWEEP_SYMMETRIC) {
-          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, gather));
-          gather = false;
-        }
-        if (s.sweep == AMGH_SWEEP_BACKWARD || s.sweep == AMGH_SWEEP_SYMMETRIC)
-          RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream, gather));
+        // x and b enter dependency-level order before the first sweep of this smooth! call and x
+        // returns to natural order after the last one
+        const bool sym = s.sweep == AMGH_SWEEP_SYMMETRIC;
+        const bool first_it = (it == 0), last_it = (it == s.iter - 1);
+        if (s.sweep == AMGH_SWEEP_FORWARD || sym)
+          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it && !sym));
+        if (s.sweep == AMGH_SWEEP_BACKWARD || sym)
+          RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream, first_it && !sym, last_it));
         break;
       }
       default: return AMGH_EINVAL;
@@ -815,7 +846,7 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
     // schedule built from the host arrays while we still have them
     amgh_csr* M = L->smat();
     GsSchedule* g = new GsSchedule;
-    rc = L->has_S ? gs_build(g, n, S_rowptr, S_col, S_val) : gs_build(g, n, A_rowptr, A_col, A_val);
+    rc = L->has_S ? gs_build(g, n, n, S_rowptr, S_col, S_val) : gs_build(g, n, n, A_rowptr, A_col, A_val);
     if (rc == AMGH_OK) { M->gs = g; M->bytes += g->bytes; }
     else { g->free_dev(); delete g; }
   }

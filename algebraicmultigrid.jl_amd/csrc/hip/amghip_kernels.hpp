@@ -135,7 +135,7 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
       re[q] = a.rowptr[r + 1];
       dp[q] = (MODE >= M_JACOBI) ? a.dpos[r] : -1;
       if (MODE >= M_GS) {  // issued up front: independent of the products, off the critical path
-        gi[q] = a.perm[r];
+        gi[q] = a.perm ? a.perm[r] : r;  // x in dependency-level order: row r writes position r
         gd[q] = a.diag[r];
         gb[q] = a.b[r];  // b pre-gathered into dependency-level order
       }
@@ -235,6 +235,11 @@ __global__ void gather_perm_kernel(const double* __restrict__ b, const int32_t* 
                                    double* __restrict__ bp, int n) {
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) bp[r] = b[perm[r]];
 }
+// x[perm[r]] = xp[r]: back from dependency-level order to natural order
+__global__ void scatter_perm_kernel(const double* __restrict__ xp, const int32_t* __restrict__ perm,
+                                    double* __restrict__ x, int n) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) x[perm[r]] = xp[r];
+}
 
 // Single-workgroup chain over consecutive NARROW dependency levels of a
 // Gauss-Seidel/SOR sweep: one thread per row, a workgroup barrier between
@@ -294,9 +299,16 @@ __device__ __forceinline__ void chain_prefetch(const ChainArgs& a, const i4_t ds
   }
 }
 
-template <bool SOR>
-__global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a) {
+constexpr int kChainLdsX = 8192;  // operators with at most this many rows keep x itself in LDS
+
+// LDSX: the whole x vector of the operator lives in LDS for the duration of the launch (small
+// hierarchy levels): no global memory access is left on the per-level critical path — gathers
+// and updates are LDS traffic, the prefetches of the next level's matrix rows are the only
+// vector-memory operations in flight and are consumed one level later.
+template <bool SOR, bool LDSX>
+__global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a, int n) {
   __shared__ double s_prod[kChainLds + (kChainLds >> 5) + 2];
+  __shared__ double s_x[LDSX ? kChainLdsX : 1];
   const int tid = threadIdx.x;
   int lv = a.lvl_begin;
   if (lv == a.lvl_end) return;
@@ -304,6 +316,11 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a) {
   i4_t ds_next = (lv + a.step != a.lvl_end) ? a.desc[lv + a.step] : ds;
   ChainRow cur;
   chain_prefetch(a, ds, tid, cur);
+  if (LDSX) {
+    for (int i = tid; i < n; i += kChainThreads) s_x[i] = a.x[i];
+    __syncthreads();
+  }
+  const double* xs = LDSX ? (const double*)s_x : (const double*)a.x;
   for (;;) {
     const bool has_next = (lv + a.step != a.lvl_end);
     // descriptor two levels ahead (scalar load), rows + leading nonzeros one level ahead
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a) {
 #pragma unroll
     for (int e = 0; e < kChainPf; ++e) {
       const int k = p0 + tid + e * kChainThreads;
-      xv[e] = (k < p1) ? a.x[cur.pc[e]] : 0.0;
+      xv[e] = (k < p1) ? xs[cur.pc[e]] : 0.0;
     }
     __builtin_amdgcn_sched_barrier(0);
     ChainRow nxt;
@@ -334,9 +351,9 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a) {
           if (k < c1) s_prod[skew(k - c0)] = cur.pv[e] * xv[e];
         }
         for (int k = p0 + tid + kChainPf * kChainThreads; k < c1; k += kChainThreads)
-          s_prod[skew(k - c0)] = a.val[k] * a.x[a.col[k]];
+          s_prod[skew(k - c0)] = a.val[k] * xs[a.col[k]];
       } else {
-        for (int k = c0 + tid; k < c1; k += kChainThreads) s_prod[skew(k - c0)] = a.val[k] * a.x[a.col[k]];
+        for (int k = c0 + tid; k < c1; k += kChainThreads) s_prod[skew(k - c0)] = a.val[k] * xs[a.col[k]];
       }
       __syncthreads();
       const int lo = max(cur.m.x, c0), hi = min(cur.m.y, c1);
@@ -344,14 +361,13 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a) {
       if (c1 < p1) __syncthreads();
     }
     if (cur.m.w >= 0 && cur.d != 0.0) {
-      const int i = cur.m.w;
-      if (SOR)
-        a.x[i] = (1.0 - a.omega) * a.x[i] + (a.omega / cur.d) * (cur.b - acc);
-      else
-        a.x[i] = (cur.b - acc) / cur.d;
+      const int i = ds.x + tid;  // x is in dependency-level order: this row's own position
+      const double xn = SOR ? (1.0 - a.omega) * xs[i] + (a.omega / cur.d) * (cur.b - acc) : (cur.b - acc) / cur.d;
+      if (LDSX) s_x[i] = xn;
+      a.x[i] = xn;  // LDSX: fire-and-forget copy to HBM, nobody in this launch reads it back
     }
     if (!has_next) break;
-    __threadfence_block();
+    if (!LDSX) __threadfence_block();
     __syncthreads();  // x of this dependency level visible to the whole workgroup (one CU)
     lv += a.step;
     ds = ds_next;

@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--size", type=int, default=256, help="grid points per axis (256 = the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--light", action="store_true", help="profiling runs: skip the extra smoother timing")
     args = ap.parse_args()
 
     if args.gpus > 1:
@@ -126,7 +127,9 @@ def main():
     resid_ms = dev.bench_op(0, 3, reps=50, warmup=5)
     alg = spmv_bytes(A.nnz, n, n)
     achieved = alg / (spmv_ms * 1e-3) / 1e9
-    sweep_ms = dev.bench_op(0, 4, reps=3, warmup=1)   # one presmoother application (fwd+bwd GS)
+    # one presmoother application (fwd+bwd GS) on the fine level; skipped with --light because every
+    # dependency level is a launch and rocprofv3's kernel tracing costs ~10 ms per dispatch
+    sweep_ms = None if args.light else dev.bench_op(0, 4, reps=3, warmup=1)
 
     vb = vcycle_bytes(ml, 4)
     out = {
