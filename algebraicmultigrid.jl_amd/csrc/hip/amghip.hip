@@ -1005,7 +1005,7 @@ int amgh_set_stream(amgh_t* h, void* stream) {
   if (!h) return AMGH_EINVAL;
   h->ext_stream = true;
   h->own_stream = h->own_stream ? h->own_stream : h->stream;
-  h->stream = stream ? (hipStream_t)stream : h->own_stream;
+  h->stream = (hipStream_t)stream;  // NULL = the default (null) stream, e.g. torch's current stream
   return AMGH_OK;
 }
 

@@ -151,7 +151,8 @@ int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle);
  * multilevel.jl:204-212 continues from the current x).  Enqueue only, no synchronisation.
  * Used by the row-sharded multi-GPU driver for the levels collapsed onto rank 0.        */
 int amgh_cycle_d(amgh_t* h, int level, double* x_d, const double* b_d, int cycle);
-/* Make the handle enqueue on the caller's hipStream_t (e.g. torch's current stream).     */
+/* Make the handle enqueue on the caller's hipStream_t (e.g. torch's current stream);
+ * NULL selects the default (null) stream.                                               */
 int amgh_set_stream(amgh_t* h, void* stream);
 
 /* cg(A, b; Pl = aspreconditioner(ml), abstol, reltol, maxiter) — the caller the

@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+# torch bundles its own ROCm runtime (libamdhip64.so.7 / libhsa-runtime64): it has to be the first HIP
+# runtime loaded into a process that will use torch.cuda, otherwise torch's device init fails.  The
+# sharded-driver tests use torch tensors, so load it before libamghip.so pulls in /opt/rocm's copy.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

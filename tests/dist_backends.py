@@ -128,6 +128,16 @@ class ThreadComm:
             self.barrier = threading.Barrier(n)
             self.slots = [None] * n
             self.vals = [0.0] * n
+            # the virtual ranks only emulate SPMD control flow: exactly one of them runs between
+            # two collectives (no concurrent calls into HIP / torch from several Python threads)
+            self.turn = threading.Lock()
+
+        def wait(self):
+            self.turn.release()
+            try:
+                self.barrier.wait()
+            finally:
+                self.turn.acquire()
 
     def __init__(self, shared, rank):
         self.sh, self.rank, self.world_size = shared, rank, shared.n
@@ -136,23 +146,23 @@ class ThreadComm:
         if send.is_cuda:
             torch.cuda.synchronize()
         self.sh.slots[self.rank] = send
-        self.sh.barrier.wait()
+        self.sh.wait()
         m = send.numel()
         for p in range(self.world_size):
             recv[p * m:(p + 1) * m].copy_(self.sh.slots[p])
         if send.is_cuda:
             torch.cuda.synchronize()
-        self.sh.barrier.wait()
+        self.sh.wait()
 
     def all_reduce_sum(self, value):
         self.sh.vals[self.rank] = float(value)
-        self.sh.barrier.wait()
+        self.sh.wait()
         s = sum(self.sh.vals)
-        self.sh.barrier.wait()
+        self.sh.wait()
         return s
 
     def barrier(self):
-        self.sh.barrier.wait()
+        self.sh.wait()
 
 
 def run_virtual_ranks(n, fn):
@@ -161,11 +171,14 @@ def run_virtual_ranks(n, fn):
     out, err = [None] * n, [None] * n
 
     def work(r):
+        shared.turn.acquire()
         try:
             out[r] = fn(ThreadComm(shared, r))
         except BaseException as e:  # noqa: BLE001
             err[r] = e
             shared.barrier.abort()
+        finally:
+            shared.turn.release()
 
     ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
     [t.start() for t in ts]
