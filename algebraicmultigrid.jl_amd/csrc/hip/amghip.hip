@@ -103,6 +103,14 @@ struct amgh_csr {
 
 namespace {
 
+// launch-shape tunables of the per-level Gauss-Seidel launches (amgh_debug_set_tunable)
+int g_gs_block_target = 256;   // aim for at least this many workgroups per wide level
+int g_gs_min_rows = 4;         // but never fewer rows per workgroup than this
+int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (one per thread)
+int g_gs_threads = 256;        // workgroup size of the per-level launches (64 or 256)
+
+unsigned long long* g_chain_tim = nullptr;  // diagnostics buffer (amgh_debug_chain_timing)
+
 constexpr int kChainWidth = 1024;  // dependency levels at most this wide are chained
 
 __global__ void find_diag_kernel(const int32_t* rowptr, const int32_t* col, const double* val, int n,
@@ -248,13 +256,36 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
     const int lnnz = prow[g->lvl_ptr[lv + 1]] - prow[g->lvl_ptr[lv]];
     return width <= kChainWidth && lnnz <= kChainLds;
   };
+  // workgroup size class of a chained level: the smallest of 64 / 256 / 1024 threads with one
+  // thread per row and at most ~4 nonzeros per thread (the per-level loop is instruction-issue bound:
+  // more threads = the level's nonzeros spread over all four SIMDs of the CU)
+  auto chain_class = [&](int lv) {
+    const int width = g->lvl_ptr[lv + 1] - g->lvl_ptr[lv];
+    const int lnnz = prow[g->lvl_ptr[lv + 1]] - prow[g->lvl_ptr[lv]];
+    if (width <= 64 && lnnz <= 64 * 4) return 64;
+    if (width <= 256 && lnnz <= 256 * 4) return 256;
+    return 1024;
+  };
   g->segs.clear();
   int l = 0;
   while (l < g->nlev) {
     if (narrow(l)) {
+      // a segment = run of chained levels of one class; a class change only starts a new launch if
+      // the new run is long enough to pay for it (each launch costs a few microseconds)
       int e = l + 1;
-      while (e < g->nlev && narrow(e)) ++e;
-      g->segs.push_back({l, e, true, 0});
+      int cls = chain_class(l);
+      while (e < g->nlev && narrow(e)) {
+        const int ce = chain_class(e);
+        if (ce != cls) {
+          int run = 1;  // length of the run of class ce starting at e
+          while (e + run < g->nlev && narrow(e + run) && chain_class(e + run) == ce && run < 16) ++run;
+          if (ce < cls && run < 16) { ++e; continue; }   // short dip to a smaller class: absorb it
+          if (ce > cls && e - l < 16) { cls = ce; ++e; continue; }  // short prefix: promote the segment
+          break;
+        }
+        ++e;
+      }
+      g->segs.push_back({l, e, true, cls});
       l = e;
     } else {
       // rows per workgroup for this level's launch: about one LDS pass of products per
@@ -262,9 +293,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       const int width = g->lvl_ptr[l + 1] - g->lvl_ptr[l];
       const int lnnz = prow[g->lvl_ptr[l + 1]] - prow[g->lvl_ptr[l]];
       const double avg = std::max(1.0, (double)lnnz / width);
-      int rows = 256;
-      while (rows > 8 && rows * avg > 2048.0) rows >>= 1;
-      g->segs.push_back({l, l + 1, false, rows});
+      g->segs.push_back({l, l + 1, false, (int)std::min(1e6, avg * 16.0)});  // 16 x mean row length
       ++l;
     }
   }
@@ -305,7 +334,26 @@ int launch_stream(const StreamArgs& a, hipStream_t st) {
 // build time from the level's average row length).
 template <int MODE>
 int launch_gs_level(const StreamArgs& a, int rows, hipStream_t st) {
+  // latency-bound launch: prefer many small workgroups over few full ones — a CU's
+  // texture-address unit serialises the x gathers of all its waves
+  // `avg16` = 16 x the level's mean row length (schedule build time).  Measured on MI355X
+  // (tools/gs_tune.py): about one nonzero per thread is the fastest shape at every level.
+  const int width = a.row_end - a.row_begin;
+  const int avg16 = std::max(16, rows);
+  rows = 256;
+  while (rows > g_gs_min_rows && (int64_t)rows * avg16 > (int64_t)g_gs_nnz_per_wg * 16) rows >>= 1;
+  while (rows > g_gs_min_rows && width / rows < g_gs_block_target && (int64_t)rows * avg16 > 16 * 64) rows >>= 1;
+  if (g_gs_threads == 64) {
+    switch (rows) {
+      case 8: return launch_stream<MODE, StreamCfg<64, 8, 2048, 1, false, false>>(a, st);
+      case 16: return launch_stream<MODE, StreamCfg<64, 16, 2048, 1, false, false>>(a, st);
+      case 32: return launch_stream<MODE, StreamCfg<64, 32, 2048, 1, false, false>>(a, st);
+      case 64: return launch_stream<MODE, StreamCfg<64, 64, 2048, 1, false, false>>(a, st);
+      default: break;
+    }
+  }
   switch (rows) {
+    case 4: return launch_stream<MODE, StreamCfg<256, 4, 2048, 1, false, false>>(a, st);
     case 8: return launch_stream<MODE, StreamCfg<256, 8, 2048, 1, false, false>>(a, st);
     case 16: return launch_stream<MODE, StreamCfg<256, 16, 2048, 1, false, false>>(a, st);
     case 32: return launch_stream<MODE, StreamCfg<256, 32, 2048, 1, false, false>>(a, st);
@@ -337,6 +385,24 @@ int csr_jacobi(amgh_csr* op, double omega, const double* xin, const double* b, d
   return launch_stream<M_JACOBI>(a, st);
 }
 
+template <int T, int PF>
+int launch_chain_t(const ChainArgs& c, bool sor, bool ldsx, int nx, hipStream_t st) {
+  if (sor && ldsx) hipLaunchKernelGGL((gs_chain_kernel<true, true, T, PF>), dim3(1), dim3(T), 0, st, c, nx);
+  else if (sor) hipLaunchKernelGGL((gs_chain_kernel<true, false, T, PF>), dim3(1), dim3(T), 0, st, c, nx);
+  else if (ldsx) hipLaunchKernelGGL((gs_chain_kernel<false, true, T, PF>), dim3(1), dim3(T), 0, st, c, nx);
+  else hipLaunchKernelGGL((gs_chain_kernel<false, false, T, PF>), dim3(1), dim3(T), 0, st, c, nx);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+// threads = workgroup size class of the segment (64 / 256 / 1024), see gs_build
+int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, hipStream_t st) {
+  switch (threads) {
+    case 64: return launch_chain_t<64, 4>(c, sor, ldsx, nx, st);
+    case 256: return launch_chain_t<256, 4>(c, sor, ldsx, nx, st);
+    default: return launch_chain_t<1024, 8>(c, sor, ldsx, nx, st);
+  }
+}
+
 // One Gauss-Seidel / SOR sweep, forward or backward, exact lexicographic order.
 // first: gather b and x into dependency-level order (once per smooth! call);
 // last: scatter x back to natural order.  Between the two x lives in g->xp.
@@ -358,16 +424,11 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     if (s.chain) {
       ChainArgs c{};
       c.col = g->col; c.val = g->val; c.x = xp; c.bp = g->bp; c.diag = g->diag;
-      c.rowmeta = g->rowmeta; c.desc = g->desc; c.omega = omega;
+      c.rowmeta = g->rowmeta; c.desc = g->desc; c.omega = omega; c.tim = g_chain_tim;
       if (!backward) { c.lvl_begin = s.l0; c.lvl_end = s.l1; c.step = 1; }
       else { c.lvl_begin = s.l1 - 1; c.lvl_end = s.l0 - 1; c.step = -1; }
       const bool ldsx = g->ncols <= kChainLdsX;  // x (halo included) fits LDS
-      const int nx = (int)g->ncols;
-      if (sor && ldsx) hipLaunchKernelGGL((gs_chain_kernel<true, true>), dim3(1), dim3(kChainThreads), 0, st, c, nx);
-      else if (sor) hipLaunchKernelGGL((gs_chain_kernel<true, false>), dim3(1), dim3(kChainThreads), 0, st, c, nx);
-      else if (ldsx) hipLaunchKernelGGL((gs_chain_kernel<false, true>), dim3(1), dim3(kChainThreads), 0, st, c, nx);
-      else hipLaunchKernelGGL((gs_chain_kernel<false, false>), dim3(1), dim3(kChainThreads), 0, st, c, nx);
-      HIP_TRY(hipGetLastError());
+      RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)g->ncols, st));
     } else {
       StreamArgs a{};
       a.rowptr = g->rowptr; a.col = g->col; a.val = g->val;
@@ -1281,6 +1342,30 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
   }
   hipFree(x); hipFree(y); hipFree(b);
   return rc;
+}
+
+int amgh_debug_set_tunable(const char* name, int value) {
+  if (!name) return AMGH_EINVAL;
+  if (!strcmp(name, "gs_block_target")) g_gs_block_target = value;
+  else if (!strcmp(name, "gs_min_rows")) g_gs_min_rows = value;
+  else if (!strcmp(name, "gs_nnz_per_wg")) g_gs_nnz_per_wg = value;
+  else if (!strcmp(name, "gs_threads")) g_gs_threads = value;
+  else return AMGH_EINVAL;
+  return AMGH_OK;
+}
+
+int amgh_debug_chain_timing(int enable, unsigned long long* out8) {
+  if (enable && !g_chain_tim) {
+    HIP_TRY(hipMalloc((void**)&g_chain_tim, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(g_chain_tim, 0, 8 * sizeof(unsigned long long)));
+  }
+  if (out8 && g_chain_tim) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out8, g_chain_tim, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(g_chain_tim, 0, 8 * sizeof(unsigned long long)));
+  }
+  if (!enable && g_chain_tim) { hipFree(g_chain_tim); g_chain_tim = nullptr; }
+  return AMGH_OK;
 }
 
 int amgh_profile_enable(amgh_t* h, int on) {

@@ -228,6 +228,41 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
 // default configuration used by the library (tools/spmv_bench.hip, profiles/r01_spmv_variants.log)
 using DefaultCfg = StreamCfg<1024, 1024, 8192, 4, false, false>;
 
+// In-order sum of s[lo..hi) (plain, un-skewed LDS indices): batches of 8 LDS reads with immediate
+// offsets from one base address, the next batch in flight while the current one is added — the
+// additions themselves stay one strictly sequential chain (the reference's order).
+__device__ __forceinline__ double seq_sum_range(const double* s, int lo, int hi, double acc) {
+  int j = lo;
+  if (hi - j >= 8) {
+    double p[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p[e] = s[j + e];
+    j += 8;
+    while (hi - j >= 8) {
+      double q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[e] = s[j + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += p[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p[e] = q[e];
+      j += 8;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += p[e];
+  }
+  for (; j < hi; ++j) acc += s[j];
+  return acc;
+}
+// the same, leaving out position dp (the diagonal) when it falls inside [lo, hi)
+__device__ __forceinline__ double seq_sum_skip(const double* s, int lo, int hi, int dp, double acc) {
+  if (dp >= lo && dp < hi) {
+    acc = seq_sum_range(s, lo, dp, acc);
+    return seq_sum_range(s, dp + 1, hi, acc);
+  }
+  return seq_sum_range(s, lo, hi, acc);
+}
+
 // bp[r] = b[perm[r]]: right-hand side gathered into dependency-level order once per
 // smoother application, so that every level kernel reads it coalesced with no
 // perm -> b dependent hop.
@@ -259,23 +294,30 @@ struct ChainArgs {
   int32_t lvl_begin;       // dependency levels [lvl_begin, lvl_end) in sweep order
   int32_t lvl_end;
   int32_t step;            // +1 forward, -1 backward (then lvl_begin > lvl_end)
+  unsigned long long* tim; // diagnostics (amgh_debug_chain_timing): per-phase shader-cycle sums, or nullptr
 };
 
 constexpr int kChainThreads = 1024;  // = max rows of a chained dependency level: one row per thread
 constexpr int kChainLds = 8192;      // products staged per pass (64 KiB + skew)
-constexpr int kChainPf = 4;          // nonzeros per thread prefetched for the NEXT dependency level
+constexpr int kChainLdsX = 8192;     // operators with at most this many columns keep x itself in LDS
 
+// The chain runs as ONE workgroup of T threads.  Every wave of the workgroup executes the whole
+// per-level loop body, so T is the smallest of 64 / 256 / 1024 that gives one thread per row of the
+// segment's widest level (a 1024-thread workgroup on a 6-row level spends its time issuing
+// instructions for 15 idle waves).  PF = nonzeros per thread prefetched for the NEXT level.
+template <int PF>
 struct ChainRow {
   i4_t m;       // rowmeta
   double d, b;  // diagonal, right-hand side
-  double pv[kChainPf];
-  int pc[kChainPf];
+  double pv[PF];
+  int pc[PF];
 };
 
 // Everything a dependency level needs that does NOT depend on x: issued one level
 // ahead so that only the x gather, the LDS pass and the x store are on the
 // critical path between two workgroup barriers.
-__device__ __forceinline__ void chain_prefetch(const ChainArgs& a, const i4_t ds, int tid, ChainRow& o) {
+template <int T, int PF>
+__device__ __forceinline__ void chain_prefetch(const ChainArgs& a, const i4_t ds, int tid, ChainRow<PF>& o) {
   const int r = ds.x + tid;
   if (r < ds.y) {
     o.m = a.rowmeta[r];
@@ -287,8 +329,8 @@ __device__ __forceinline__ void chain_prefetch(const ChainArgs& a, const i4_t ds
     o.b = 0.0;
   }
 #pragma unroll
-  for (int e = 0; e < kChainPf; ++e) {
-    const int k = ds.z + tid + e * kChainThreads;
+  for (int e = 0; e < PF; ++e) {
+    const int k = ds.z + tid + e * T;
     if (k < ds.w) {
       o.pv[e] = a.val[k];
       o.pc[e] = a.col[k];
@@ -299,29 +341,30 @@ __device__ __forceinline__ void chain_prefetch(const ChainArgs& a, const i4_t ds
   }
 }
 
-constexpr int kChainLdsX = 8192;  // operators with at most this many rows keep x itself in LDS
-
 // LDSX: the whole x vector of the operator lives in LDS for the duration of the launch (small
 // hierarchy levels): no global memory access is left on the per-level critical path — gathers
 // and updates are LDS traffic, the prefetches of the next level's matrix rows are the only
 // vector-memory operations in flight and are consumed one level later.
-template <bool SOR, bool LDSX>
-__global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a, int n) {
-  __shared__ double s_prod[kChainLds + (kChainLds >> 5) + 2];
+template <bool SOR, bool LDSX, int T, int PF>
+__global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
+  static_assert(PF * T <= kChainLds, "prefetched nonzeros must fit the first LDS pass");
+  __shared__ double s_prod[kChainLds];  // un-skewed: few rows per level, bank conflicts are not the issue here
   __shared__ double s_x[LDSX ? kChainLdsX : 1];
   const int tid = threadIdx.x;
   int lv = a.lvl_begin;
   if (lv == a.lvl_end) return;
   i4_t ds = a.desc[lv];
   i4_t ds_next = (lv + a.step != a.lvl_end) ? a.desc[lv + a.step] : ds;
-  ChainRow cur;
-  chain_prefetch(a, ds, tid, cur);
+  ChainRow<PF> cur;
+  chain_prefetch<T, PF>(a, ds, tid, cur);
   if (LDSX) {
-    for (int i = tid; i < n; i += kChainThreads) s_x[i] = a.x[i];
+    for (int i = tid; i < n; i += T) s_x[i] = a.x[i];
     __syncthreads();
   }
   const double* xs = LDSX ? (const double*)s_x : (const double*)a.x;
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, nlv = 0;
   for (;;) {
+    const unsigned long long t0 = a.tim ? clock64() : 0;
     const bool has_next = (lv + a.step != a.lvl_end);
     // descriptor two levels ahead (scalar load), rows + leading nonzeros one level ahead
     const bool has_next2 = has_next && (lv + 2 * a.step != a.lvl_end);
@@ -330,34 +373,38 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a, in
     // critical path first: the x gathers of this level's (already prefetched) leading
     // nonzeros are issued BEFORE the next level's prefetch loads — vector-memory results
     // return in order, so anything issued ahead of the gathers would delay them.
-    double xv[kChainPf];
+    double xv[PF];
 #pragma unroll
-    for (int e = 0; e < kChainPf; ++e) {
-      const int k = p0 + tid + e * kChainThreads;
+    for (int e = 0; e < PF; ++e) {
+      const int k = p0 + tid + e * T;
       xv[e] = (k < p1) ? xs[cur.pc[e]] : 0.0;
     }
     __builtin_amdgcn_sched_barrier(0);
-    ChainRow nxt;
-    if (has_next) chain_prefetch(a, ds_next, tid, nxt);
+    const unsigned long long t0a = a.tim ? clock64() : 0;
+    ChainRow<PF> nxt;
+    if (has_next) chain_prefetch<T, PF>(a, ds_next, tid, nxt);
     __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = a.tim ? clock64() : 0;
+    unsigned long long t2 = 0, t3 = 0;
 
     double acc = 0.0;
     for (int c0 = p0; c0 < p1; c0 += kChainLds) {
       const int c1 = min(c0 + kChainLds, p1);
       if (c0 == p0) {
 #pragma unroll
-        for (int e = 0; e < kChainPf; ++e) {
-          const int k = p0 + tid + e * kChainThreads;
-          if (k < c1) s_prod[skew(k - c0)] = cur.pv[e] * xv[e];
+        for (int e = 0; e < PF; ++e) {
+          const int k = p0 + tid + e * T;
+          if (k < c1) s_prod[k - c0] = cur.pv[e] * xv[e];
         }
-        for (int k = p0 + tid + kChainPf * kChainThreads; k < c1; k += kChainThreads)
-          s_prod[skew(k - c0)] = a.val[k] * xs[a.col[k]];
+        for (int k = p0 + tid + PF * T; k < c1; k += T) s_prod[k - c0] = a.val[k] * xs[a.col[k]];
       } else {
-        for (int k = c0 + tid; k < c1; k += kChainThreads) s_prod[skew(k - c0)] = a.val[k] * xs[a.col[k]];
+        for (int k = c0 + tid; k < c1; k += T) s_prod[k - c0] = a.val[k] * xs[a.col[k]];
       }
+      if (a.tim && c0 == p0) t2 = clock64();
       __syncthreads();
+      if (a.tim && c0 == p0) t3 = clock64();
       const int lo = max(cur.m.x, c0), hi = min(cur.m.y, c1);
-      acc = seq_sum<true>(s_prod, lo, hi, c0, cur.m.z, acc);
+      acc = seq_sum_skip(s_prod, lo - c0, hi - c0, cur.m.z - c0, acc);
       if (c1 < p1) __syncthreads();
     }
     if (cur.m.w >= 0 && cur.d != 0.0) {
@@ -366,13 +413,24 @@ __global__ __launch_bounds__(kChainThreads) void gs_chain_kernel(ChainArgs a, in
       if (LDSX) s_x[i] = xn;
       a.x[i] = xn;  // LDSX: fire-and-forget copy to HBM, nobody in this launch reads it back
     }
+    const unsigned long long t4 = a.tim ? clock64() : 0;
     if (!has_next) break;
     if (!LDSX) __threadfence_block();
     __syncthreads();  // x of this dependency level visible to the whole workgroup (one CU)
+    if (a.tim) {
+      const unsigned long long t5 = clock64();
+      tacc[0] += t1 - t0; tacc[5] += t0a - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += t5 - t4; ++nlv;
+    }
     lv += a.step;
     ds = ds_next;
     ds_next = ds_next2;
     cur = nxt;
+  }
+  if (a.tim && tid == 0) {
+    for (int q = 0; q < 5; ++q) atomicAdd(a.tim + q, tacc[q]);
+    atomicAdd(a.tim + 5, nlv);
+    atomicAdd(a.tim + 6, 1ull);
+    atomicAdd(a.tim + 7, tacc[5]);
   }
 }
 

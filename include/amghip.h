@@ -235,6 +235,14 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
 int amgh_profile_enable(amgh_t* h, int on);
 int amgh_profile_read(amgh_t* h, double* out, int reset);
 
+/* Diagnostics: accumulate shader-cycle counts of the phases of gs_chain_kernel's per-level loop
+ * (issue, gather+stage, barrier, row sums, store+barrier; levels; launches).  enable != 0 starts
+ * accumulating; out8 (8 x uint64, may be NULL) receives and resets the sums.               */
+int amgh_debug_chain_timing(int enable, unsigned long long* out8);
+/* Diagnostics: launch-shape tunables of the per-dependency-level Gauss-Seidel launches
+ * ("gs_block_target", "gs_min_rows", "gs_threads"); used by tools/ to pick the defaults.   */
+int amgh_debug_set_tunable(const char* name, int value);
+
 /* Replay whole cycles from captured hipGraphs (default off: measured no gain on MI355X,
  * the cycle is GPU-latency-bound; AMGH_USE_GRAPH=1 in the environment also enables it). */
 int amgh_set_use_graph(amgh_t* h, int on);

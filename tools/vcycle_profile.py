@@ -57,3 +57,20 @@ print(f"sum of labelled steps: {tot:.2f} ms per V-cycle")
 for l in range(min(L, 4)):
     print(f"level {l}: SpMV {dev.bench_op(l, 0, 20, 3):.4f} ms  residual {dev.bench_op(l, 3, 20, 3):.4f} ms  "
           f"R {dev.bench_op(l, 2, 20, 3):.4f} ms  P {dev.bench_op(l, 1, 20, 3):.4f} ms  presmooth {dev.bench_op(l, 4, 3, 1):.3f} ms")
+
+# chain-kernel phase timing (shader cycles) per hierarchy level
+import ctypes as C
+out = (C.c_ulonglong * 8)()
+lib.amgh_debug_chain_timing(1, None)
+xb = AMG.DeviceBuffer(n, 0, uniform(n, 3))
+print("chain kernel phases, avg shader cycles per dependency level: issue | gather+stage | barrier1 | rowsum+store | fence+barrier2 | levels launches")
+for l in range(L):
+    nl = ml.levels[l].A.m
+    xl = AMG.DeviceBuffer(nl, 0, uniform(nl, 3)); bl = AMG.DeviceBuffer(nl, 0, uniform(nl, 4))
+    lib.amgh_debug_chain_timing(1, out)
+    lib.amgh_level_smooth_d(dev.h, l, 0, xl.ptr, bl.ptr)
+    lib.amgh_debug_chain_timing(1, out)
+    v = list(out)
+    if v[5]:
+        print(f"level {l}: " + " | ".join(f"{v[q] / v[5]:8.0f}" for q in range(5)) + f" | {v[5]} {v[6]} | of issue: wait+gather-issue {v[7] / v[5]:6.0f}")
+lib.amgh_debug_chain_timing(0, None)
