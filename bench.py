@@ -51,6 +51,18 @@ def vcycle_bytes(ml, sweeps_per_level):
     return total
 
 
+def pmc_traffic(N):
+    """HBM bytes per fine-level SpMV launch from the committed rocprofv3 PMC passes (FETCH_SIZE with the
+    gfx950 half-count correction + WRITE_SIZE, separate passes: profiles/r01_pmc_spmv_traffic.json).
+    PMC counters cannot be collected from inside this process, so the figure is the measured one of the
+    same kernel on the same matrix; None for any other size."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_spmv_traffic.json")
+    if N != 256 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["hbm_traffic_bytes_per_launch"]
+
+
 def cpu_baseline(ml, b, budget_s=20.0):
     """The CPU restatement of the reference's `_solve` cycle (oracle/amg_oracle.c), single thread,
     timed on this host on a bounded sample: as many whole V-cycles as fit in ~budget_s (>= 1)."""
@@ -145,9 +157,9 @@ def main():
                    "operator_complexity": round(AMG.operator_complexity(ml), 3),
                    "gs_dependency_levels": [dev.gs_dependency_levels(l) for l in range(len(ml.levels))],
                    "parallelism": "1 GPU"},
-        "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<SPMV> (fine-level A, %d rows, %d nnz)" % (n, A.nnz),
+        "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<SPMV, StreamCfg<1024,1024,8192,4>> (fine-level A, %d rows, %d nnz)" % (n, A.nnz),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes": alg, "avg_launch_ms": spmv_ms,
+                     "traffic": pmc_traffic(N), "algorithmic_bytes": alg, "avg_launch_ms": spmv_ms,
                      "fused_residual_ms": resid_ms,
                      "fused_residual_GBs": (alg + 8 * n) / (resid_ms * 1e-3) / 1e9},
         "vcycle": {"algorithmic_bytes": vb, "achieved_GBs": vb / (ms_per_step * 1e-3) / 1e9,

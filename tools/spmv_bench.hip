@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 256;
   const int reps = argc > 2 ? atoi(argv[2]) : 20;
   const int rounds = argc > 3 ? atoi(argv[3]) : 3;
+  const bool ship_only = argc > 4 && std::string(argv[4]) == "ship";  // PMC runs: shipped config only
   const long n = (long)N * N * N;
   std::vector<int> rowptr(n + 1), col;
   std::vector<double> val;
@@ -135,6 +136,7 @@ int main(int argc, char** argv) {
       V(128, 1, 1024, 4, false, false),
       V(128, 2, 2048, 4, false, false),
   };
+  if (ship_only) vs = {V(1024, 1, 8192, 4, false, false)};
   StreamArgs a{};
   a.rowptr = d_rowptr; a.col = d_col; a.val = d_val; a.x = d_x; a.y = d_y; a.row_begin = 0; a.row_end = (int)n;
   std::vector<std::vector<float>> times(vs.size() + 1);
