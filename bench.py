@@ -91,9 +91,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--light", action="store_true", help="profiling runs: skip the extra smoother timing")
+    ap.add_argument("--force-dist", action="store_true", help="run the row-sharded driver even with one rank")
     args = ap.parse_args()
 
-    if args.gpus > 1:
+    if args.gpus > 1 or args.force_dist:
         from bench_dist import main_distributed  # row-sharded path (torch.distributed over RCCL)
         return main_distributed(args)
 
