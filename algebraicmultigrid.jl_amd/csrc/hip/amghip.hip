@@ -614,39 +614,54 @@ int cycle_next(amgh_t* h, int l, double* x, const double* b, int cyc) {
   return AMGH_EINVAL;
 }
 
-// __solve! (multilevel.jl:214-239)
+// smooth! on one column of an n x bs block (multi-RHS: the reference loops the columns inside
+// every smoother, smoother.jl:77,117): Jacobi goes through the level's temp vector and is copied back.
+int smooth_column(amgh_t* h, Level* L, const amgh_smoother_t& s, double* xcol, const double* bcol) {
+  double* xc = xcol;
+  double* xo = L->tmp;
+  RC_TRY(smooth(h, L, s, xc, xo, bcol));
+  if (xc != xcol) RC_TRY(vec_copy(h, xcol, xc, L->n));
+  return AMGH_OK;
+}
+
+// __solve! (multilevel.jl:214-239).  x, b: n x bs column-major (bs = workspace block size,
+// multilevel.jl:28-59); every operator is applied column by column.
 int cycle(amgh_t* h, int l, double* x, const double* b, int cyc) {
   Level* L = h->levels[l];
+  const int bs = h->nrhs;
+  const int64_t n = L->n, nc = L->nc;
   double* xc = x;
   double* xo = L->tmp;
   {
     ProfScope p(h, AMGH_T_PRESMOOTH, l);
-    RC_TRY(smooth(h, L, L->pre, xc, xo, b));
+    if (bs == 1) RC_TRY(smooth(h, L, L->pre, xc, xo, b));
+    else for (int c = 0; c < bs; ++c) RC_TRY(smooth_column(h, L, L->pre, x + c * n, b + c * n));
   }
   {
     ProfScope p(h, AMGH_T_RESIDUAL, l);
-    RC_TRY(csr_apply(&L->A, M_RESID, xc, b, L->res, h->stream));
+    for (int c = 0; c < bs; ++c) RC_TRY(csr_apply(&L->A, M_RESID, xc + c * n, b + c * n, L->res + c * n, h->stream));
   }
   {
     ProfScope p(h, AMGH_T_RESTRICT, l);
-    RC_TRY(csr_apply(&L->R, M_SPMV, L->res, nullptr, L->cb, h->stream));
+    for (int c = 0; c < bs; ++c) RC_TRY(csr_apply(&L->R, M_SPMV, L->res + c * n, nullptr, L->cb + c * nc, h->stream));
   }
-  RC_TRY(vec_fill(h, L->cx, L->nc, 0.0));
+  RC_TRY(vec_fill(h, L->cx, nc * bs, 0.0));
   if (l == (int)h->levels.size() - 1) {
     ProfScope p(h, AMGH_T_COARSE, l + 1);
-    RC_TRY(coarse_solve(h, L->cx, L->cb));
+    for (int c = 0; c < bs; ++c) RC_TRY(coarse_solve(h, L->cx + c * nc, L->cb + c * nc));
   } else {
     RC_TRY(cycle_next(h, l + 1, L->cx, L->cb, cyc));
   }
   {
     ProfScope p(h, AMGH_T_PROLONG, l);
-    RC_TRY(csr_apply(&L->P, M_ADD, L->cx, nullptr, xc, h->stream));
+    for (int c = 0; c < bs; ++c) RC_TRY(csr_apply(&L->P, M_ADD, L->cx + c * nc, nullptr, xc + c * n, h->stream));
   }
   {
     ProfScope p(h, AMGH_T_POSTSMOOTH, l);
-    RC_TRY(smooth(h, L, L->post, xc, xo, b));
+    if (bs == 1) RC_TRY(smooth(h, L, L->post, xc, xo, b));
+    else for (int c = 0; c < bs; ++c) RC_TRY(smooth_column(h, L, L->post, x + c * n, b + c * n));
   }
-  if (xc != x) RC_TRY(vec_copy(h, x, xc, L->n));
+  if (xc != x) RC_TRY(vec_copy(h, x, xc, n));
   return AMGH_OK;
 }
 
@@ -654,7 +669,8 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc) {
 int apply_once(amgh_t* h, double* x, const double* b, int cyc) {
   if (h->levels.empty()) {
     ProfScope p(h, AMGH_T_COARSE, 0);
-    return coarse_solve(h, x, b);
+    for (int c = 0; c < h->nrhs; ++c) RC_TRY(coarse_solve(h, x + c * h->ncoarse, b + c * h->ncoarse));
+    return AMGH_OK;
   }
   return cycle(h, 0, x, b, cyc);
 }
@@ -702,11 +718,11 @@ int apply_cycle(amgh_t* h, double* x, const double* b, int cyc) {
 }
 
 int fine_residual(amgh_t* h, const double* x, const double* b, double* r) {
-  if (h->levels.empty()) {
-    if (!h->has_finalA) return AMGH_ESTATE;
-    return csr_apply(&h->finalA, M_RESID, x, b, r, h->stream);
-  }
-  return csr_apply(&h->levels[0]->A, M_RESID, x, b, r, h->stream);
+  if (h->levels.empty() && !h->has_finalA) return AMGH_ESTATE;
+  const amgh_csr* A = h->levels.empty() ? &h->finalA : &h->levels[0]->A;
+  const int64_t n = A->nrows;
+  for (int c = 0; c < h->nrhs; ++c) RC_TRY(csr_apply(A, M_RESID, x + c * n, b + c * n, r + c * n, h->stream));
+  return AMGH_OK;
 }
 int fine_spmv(amgh_t* h, const double* x, double* y) {
   if (h->levels.empty()) {
@@ -719,7 +735,7 @@ int fine_spmv(amgh_t* h, const double* x, double* y) {
 // _solve! (multilevel.jl:158-198) on device pointers
 int solve_dev(amgh_t* h, const double* b, double* x, int cyc, int maxiter, double abstol, double reltol,
               int calc_res, double* hist, int* iters) {
-  const int64_t n = fine_n(h);
+  const int64_t n = fine_n(h) * h->nrhs;  // norm(b) of an n x bs matrix is the Frobenius norm
   double normb = 0.0;
   RC_TRY(vec_norm_host(h, b, n, &normb));
   double normres = normb;
@@ -843,7 +859,7 @@ int amgh_device_count(void) {
 int amgh_create(amgh_t** hp, int device, int nrhs) {
   if (!hp) return AMGH_EINVAL;
   *hp = nullptr;
-  if (nrhs != 1) return AMGH_EUNSUPPORTED;  // bs > 1 (SpMM variants) not built yet
+  if (nrhs < 1 || nrhs > 64) return AMGH_EUNSUPPORTED;
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return AMGH_EINVAL;
@@ -962,10 +978,10 @@ int amgh_finalize(amgh_t* h) {
   HIP_TRY(hipSetDevice(h->device));
   int64_t ws = 0;
   for (Level* L : h->levels) {
-    RC_TRY(dev_alloc(&L->res, L->n));
-    RC_TRY(dev_alloc(&L->cx, L->nc));
-    RC_TRY(dev_alloc(&L->cb, L->nc));
-    ws += 8 * (L->n + 2 * L->nc);
+    RC_TRY(dev_alloc(&L->res, L->n * h->nrhs));
+    RC_TRY(dev_alloc(&L->cx, L->nc * h->nrhs));
+    RC_TRY(dev_alloc(&L->cb, L->nc * h->nrhs));
+    ws += 8 * (L->n + 2 * L->nc) * h->nrhs;
     if (L->pre.kind == AMGH_SMOOTH_JACOBI || L->post.kind == AMGH_SMOOTH_JACOBI) {
       RC_TRY(dev_alloc(&L->tmp, L->n));
       ws += 8 * L->n;
@@ -973,12 +989,12 @@ int amgh_finalize(amgh_t* h) {
     }
   }
   const int64_t n = fine_n(h);
-  if (h->levels.empty()) { RC_TRY(dev_alloc(&h->res_final, n)); ws += 8 * n; }
+  if (h->levels.empty()) { RC_TRY(dev_alloc(&h->res_final, n * h->nrhs)); ws += 8 * n * h->nrhs; }
   RC_TRY(dev_alloc(&h->partial, kRedBlocks));
   RC_TRY(dev_alloc(&h->scal, 8));
-  RC_TRY(dev_alloc(&h->x0, n));
-  RC_TRY(dev_alloc(&h->b0, n));
-  ws += 16 * n;
+  RC_TRY(dev_alloc(&h->x0, n * h->nrhs));
+  RC_TRY(dev_alloc(&h->b0, n * h->nrhs));
+  ws += 16 * n * h->nrhs;
   h->ws_bytes = ws;
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->finalized = true;
@@ -1025,7 +1041,7 @@ int amgh_solve(amgh_t* h, const double* b, double* x, int cycle_, int maxiter, d
   RC_TRY(check_ready(h));
   if (!b || !x || cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
-  const int64_t n = fine_n(h);
+  const int64_t n = fine_n(h) * h->nrhs;
   HIP_TRY(hipMemcpyAsync(h->b0, b, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->x0, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   RC_TRY(solve_dev(h, h->b0, h->x0, cycle_, maxiter, abstol, reltol, calculate_residual, resid_hist, iters));
@@ -1037,7 +1053,7 @@ int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle_) 
   RC_TRY(check_ready(h));
   if (!r_d || !z_d || cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
-  RC_TRY(vec_fill(h, z_d, fine_n(h), 0.0));
+  RC_TRY(vec_fill(h, z_d, fine_n(h) * h->nrhs, 0.0));
   return apply_cycle(h, z_d, r_d, cycle_);
 }
 
@@ -1045,7 +1061,7 @@ int amgh_precond_apply(amgh_t* h, const double* r, double* z, int cycle_) {
   RC_TRY(check_ready(h));
   if (!r || !z) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
-  const int64_t n = fine_n(h);
+  const int64_t n = fine_n(h) * h->nrhs;
   HIP_TRY(hipMemcpyAsync(h->b0, r, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
   RC_TRY(amgh_precond_apply_d(h, h->b0, h->x0, cycle_));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1074,6 +1090,7 @@ int amgh_pcg_d(amgh_t* h, const double* b_d, double* x_d, int cycle_, int use_pr
                double reltol, double* resid_hist, int* iters) {
   RC_TRY(check_ready(h));
   if (!b_d || !x_d || cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
+  if (h->nrhs != 1) return AMGH_EUNSUPPORTED;  // IterativeSolvers' cg takes vectors
   HIP_TRY(hipSetDevice(h->device));
   RC_TRY(ensure_pcg_bufs(h));
   return pcg_dev(h, b_d, x_d, cycle_, use_precond, maxiter, abstol, reltol, resid_hist, iters);

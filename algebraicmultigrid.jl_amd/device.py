@@ -154,13 +154,14 @@ def smooth_standalone(config, A, x, b, symmetry=None):
 class DeviceHierarchy:
     """MultiLevel on HBM: amgh_create / push_level / set_coarse / finalize."""
 
-    def __init__(self, ml, device=0):
+    def __init__(self, ml, device=0, nrhs=1):
         from .hierarchy import HermitianSymmetry
         self.lib = require_gpu()
         self.device = device
         self.ml = ml
+        self.nrhs = int(nrhs)
         h = C.c_void_p()
-        hip_check(self.lib.amgh_create(C.byref(h), device, 1), "create")
+        hip_check(self.lib.amgh_create(C.byref(h), device, self.nrhs), "create")
         self.h = h.value
         hermitian = isinstance(ml.symmetry, HermitianSymmetry)
         for lev in ml.levels:
@@ -215,8 +216,9 @@ class DeviceHierarchy:
 
     # ---- solve phase ---------------------------------------------------------
     def solve(self, b, x0, cycle, maxiter, abstol, reltol, calculate_residual, log):
-        b = np.ascontiguousarray(b, dtype=np.float64)
-        x = np.array(x0, dtype=np.float64, copy=True, order="C")
+        # n x bs blocks travel column-major, as Julia holds them
+        b = np.asfortranarray(b, dtype=np.float64)
+        x = np.array(x0, dtype=np.float64, copy=True, order="F")
         hist = np.zeros(maxiter + 1, dtype=np.float64)
         iters = C.c_int(0)
         hip_check(self.lib.amgh_solve(self.h, b.ctypes.data, x.ctypes.data, cycle, maxiter, abstol, reltol,
@@ -225,8 +227,8 @@ class DeviceHierarchy:
         return x, hist[:n_hist].copy(), iters.value
 
     def precond_apply(self, r, cycle=CYCLE_V):
-        r = np.ascontiguousarray(r, dtype=np.float64)
-        z = np.empty_like(r)
+        r = np.asfortranarray(r, dtype=np.float64)
+        z = np.empty_like(r, order="F")
         hip_check(self.lib.amgh_precond_apply(self.h, r.ctypes.data, z.ctypes.data, cycle), "precond_apply")
         return z
 

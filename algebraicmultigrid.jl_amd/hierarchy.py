@@ -235,17 +235,19 @@ class MultiLevel:
         self.postsmoother = postsmoother
         self.symmetry = symmetry if symmetry is not None else HermitianSymmetry()
         self._hier = _hier
-        self._dev = None
+        self._dev = {}
 
     def __len__(self):
         return len(self.levels) + 1
 
-    def device(self, device=0):
-        """The HBM-resident hierarchy (libamghip handle); built on first use."""
-        if self._dev is None:
+    def device(self, device=0, nrhs=1):
+        """The HBM-resident hierarchy (libamghip handle) for workspace block size `nrhs`
+        (the reference's `Val{bs}`, multilevel.jl:28-35); built on first use."""
+        key = (device, int(nrhs))
+        if key not in self._dev:
             from .device import DeviceHierarchy
-            self._dev = DeviceHierarchy(self, device)
-        return self._dev
+            self._dev[key] = DeviceHierarchy(self, device, int(nrhs))
+        return self._dev[key]
 
     def __repr__(self):
         total = self.final_A.nnz + sum(l.A.nnz for l in self.levels)

@@ -44,13 +44,14 @@ def _solve_inplace(x, ml, b, cycle=None, maxiter=100, abstol=0.0, reltol=_SQRT_E
     if not isinstance(ml, MultiLevel):
         raise AMGError("ml must be a MultiLevel")
     b = np.asarray(b, dtype=np.float64)
-    if b.ndim != 1:
-        raise AMGError("multiple right-hand sides (bs > 1) are not built yet")
+    if b.ndim not in (1, 2):
+        raise AMGError("b must be a vector or an n x bs matrix")
     n = ml.levels[0].A.m if ml.levels else ml.final_A.m
     if b.shape[0] != n or x.shape != b.shape:
         raise AMGError("DimensionMismatch: x, b must have length size(A, 1)")
-    xs, hist, iters = ml.device().solve(b, x, _cycle_code(cycle), int(maxiter), float(abstol), float(reltol),
-                                        calculate_residual, log)
+    bs = 1 if b.ndim == 1 else b.shape[1]   # workspace block size (`Val{bs}`, multilevel.jl:28-35)
+    xs, hist, iters = ml.device(nrhs=bs).solve(b, x, _cycle_code(cycle), int(maxiter), float(abstol),
+                                               float(reltol), calculate_residual, log)
     x[...] = xs
     if verbose and calculate_residual:
         for i in range(iters):
@@ -109,7 +110,8 @@ class Preconditioner:
         """ldiv!(x, p, b): x .= 0 then exactly one cycle without residual (preconditioner.jl:12-19)."""
         b = np.asarray(b, dtype=np.float64)
         if self.init == "zero":
-            z = self.ml.device().precond_apply(b, _cycle_code(self.cycle))
+            bs = 1 if b.ndim == 1 else b.shape[1]
+            z = self.ml.device(nrhs=bs).precond_apply(b, _cycle_code(self.cycle))
         else:
             z = b.copy()
             _solve_inplace(z, self.ml, b, self.cycle, maxiter=1, calculate_residual=False)

@@ -72,7 +72,9 @@ int amgh_device_count(void);
 /* Hierarchy construction  — replaces the in-memory Level/MultiLevel structs    */
 /* (multilevel.jl:1-21) and MultiLevelWorkspace (multilevel.jl:23-59).          */
 /* ------------------------------------------------------------------------- */
-/* nrhs = workspace block size `bs` (multilevel.jl:28-35); only 1 is built.     */
+/* nrhs = workspace block size `bs` (multilevel.jl:28-35), 1..64: b and x of the solve entry
+ * points are n x nrhs column-major and every operator is applied column by column, as the
+ * reference's smoothers do (smoother.jl:77,117).                                          */
 int amgh_create(amgh_t** h, int device, int nrhs);
 void amgh_destroy(amgh_t* h);
 

@@ -38,7 +38,8 @@ def test_strerror_and_argument_checks_without_gpu():
     assert lib.amgh_device_count() >= 0
     assert lib.amgh_create(None, 0, 1) == -2           # NULL out-pointer
     h = ctypes.c_void_p()
-    assert lib.amgh_create(ctypes.byref(h), 0, 2) == -5  # nrhs > 1 unsupported
+    assert lib.amgh_create(ctypes.byref(h), 0, 0) == -5    # block size must be 1..64
+    assert lib.amgh_create(ctypes.byref(h), 0, 65) == -5
 
 
 @pytest.mark.skipif(AMG.gpu_available(), reason="only meaningful on a box without a GPU")

@@ -339,3 +339,30 @@ def test_full_size_properties_spmv_linearity_and_symmetry():
     # interior rows of the 7-point stencil annihilate constants
     r = op.spmv(np.ones(n)).reshape((64, 128, 128))
     assert np.all(r[1:-1, 1:-1, 1:-1] == 0)
+
+
+def test_multiple_right_hand_sides_block_workspace():
+    """bs > 1 (`MultiLevelWorkspace{TX,bs}`, multilevel.jl:28-59): b, x are n x bs; the smoothers and
+    operators act column by column, the stopping test uses the norm of the whole block."""
+    A = AMG.poisson((30, 30))
+    n = A.m
+    B = np.stack([uniform(n, 41), A @ np.ones(n), uniform(n, 43) - 0.5], axis=1)
+    for ml in (AMG.ruge_stuben(A), AMG.smoothed_aggregation(A, presmoother=AMG.Jacobi(2 / 3), postsmoother=AMG.Jacobi(2 / 3))):
+        oh = O.OracleHierarchy(ml)
+        # fixed number of cycles: every column equals the single-RHS oracle run
+        X = AMG._solve(ml, B, maxiter=4, calculate_residual=False)
+        assert X.shape == B.shape
+        for c in range(3):
+            xo, _, _ = oh.solve(B[:, c], maxiter=4, calculate_residual=False)
+            assert rel(X[:, c], xo) <= TOL
+        # tolerance-driven: joint Frobenius-norm test, same cycle count for all columns
+        X, hist = AMG._solve(ml, B, reltol=1e-8, log=True, maxiter=100)
+        its = len(hist) - 1
+        Xo = np.stack([oh.solve(B[:, c], maxiter=its, calculate_residual=False)[0] for c in range(3)], axis=1)
+        assert rel(X, Xo) <= TOL
+        R = B - A.to_scipy() @ X
+        assert np.isclose(hist[-1], np.linalg.norm(R), rtol=1e-6) and hist[-1] <= 1e-8 * np.linalg.norm(B)
+        assert hist[-2] > 1e-8 * np.linalg.norm(B)
+        Z = AMG.aspreconditioner(ml).ldiv(B)
+        for c in range(3):
+            assert rel(Z[:, c], oh.precond(B[:, c])) <= TOL
