@@ -399,7 +399,7 @@ int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, h
   switch (threads) {
     case 64: return launch_chain_t<64, 4>(c, sor, ldsx, nx, st);
     case 256: return launch_chain_t<256, 4>(c, sor, ldsx, nx, st);
-    default: return launch_chain_t<1024, 8>(c, sor, ldsx, nx, st);
+    default: return launch_chain_t<1024, 4>(c, sor, ldsx, nx, st);  // PF = 8 spills at 1024 threads (128 VGPRs)
   }
 }
 

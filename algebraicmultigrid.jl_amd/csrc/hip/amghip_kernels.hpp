@@ -48,6 +48,9 @@ struct StreamArgs {
 // (ds_read_b64 banks = (addr/4) mod 64; one pad slot per 32 keeps a 32-lane
 // group conflict-free for row lengths 7, 8, 16, 27).
 __device__ __forceinline__ int skew(int k) { return k + (k >> 5); }
+template <bool SKEWED>
+__device__ __forceinline__ int lidx(int k) { return SKEWED ? skew(k) : k; }
+__device__ __forceinline__ double seq_sum_skip(const double* s, int lo, int hi, int dp, double acc);
 
 // XCD-contiguous block mapping (workgroup b is observed to run on XCD b % 8):
 // give each XCD a contiguous eighth of the row blocks so that the +-nx rows'
@@ -114,6 +117,9 @@ template <int MODE, class CFG>
 __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) {
   constexpr int T = CFG::THREADS, RPT = CFG::RPT, LDSN = CFG::LDS_NNZ, VEC = CFG::VEC;
   constexpr bool NT = CFG::NT;
+  // few rows per workgroup (latency-bound GS launches): plain LDS indices + the pipelined in-order
+  // sum; many rows per workgroup (SpMV): skewed indices keep the row-strided reads conflict-free
+  constexpr bool SK = CFG::ROWS > 64;
   __shared__ double s_prod[LDSN + (LDSN >> 5) + 2];
 
   const int nrows = a.row_end - a.row_begin;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
       for (int k = c0 + tid; k < c1; k += T) {
         const double v = ld_stream<NT>(a.val + k);
         const int c = ld_stream<NT>(a.col + k);
-        s_prod[skew(k - c0)] = v * a.x[c];
+        s_prod[lidx<SK>(k - c0)] = v * a.x[c];
       }
     } else {
       const int a0 = c0 & ~(VEC - 1);  // hipMalloc'ed arrays: index multiple of VEC => 16 B aligned
@@ -177,12 +183,12 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
 #pragma unroll
           for (int e = 0; e < VEC; ++e) xv[e] = a.x[c[e]];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) s_prod[skew(k + e - c0)] = v[e] * xv[e];
+          for (int e = 0; e < VEC; ++e) s_prod[lidx<SK>(k + e - c0)] = v[e] * xv[e];
         } else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const int kk = k + e;
-            if (kk >= c0 && kk < c1) s_prod[skew(kk - c0)] = a.val[kk] * a.x[a.col[kk]];
+            if (kk >= c0 && kk < c1) s_prod[lidx<SK>(kk - c0)] = a.val[kk] * a.x[a.col[kk]];
           }
         }
       }
@@ -191,7 +197,8 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       const int lo = max(rs[q], c0), hi = min(re[q], c1);
-      acc[q] = seq_sum<(MODE >= M_JACOBI)>(s_prod, lo, hi, c0, dp[q], acc[q]);
+      if (SK) acc[q] = seq_sum<(MODE >= M_JACOBI)>(s_prod, lo, hi, c0, dp[q], acc[q]);
+      else acc[q] = seq_sum_skip(s_prod, lo - c0, hi - c0, (MODE >= M_JACOBI) ? dp[q] - c0 : -1, acc[q]);
     }
     if (c1 < p1) __syncthreads();
   }
@@ -234,24 +241,43 @@ using DefaultCfg = StreamCfg<1024, 1024, 8192, 4, false, false>;
 __device__ __forceinline__ double seq_sum_range(const double* s, int lo, int hi, double acc) {
   int j = lo;
   if (hi - j >= 8) {
-    double p[8];
+    double p[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) p[e] = s[j + e];
     j += 8;
-    while (hi - j >= 8) {
-      double q[8];
+    // two register sets ping-pong (no copies): while one batch is being added the other is loading
+    while (hi - j >= 16) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) q[e] = s[j + e];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc += p[e];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) p[e] = q[e];
-      j += 8;
-    }
+      for (int e = 0; e < 8; ++e) p[e] = s[j + 8 + e];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc += p[e];
+      for (int e = 0; e < 8; ++e) acc += q[e];
+      j += 16;
+    }
+    if (hi - j >= 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[e] = s[j + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += p[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += q[e];
+      j += 8;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += p[e];
+    }
   }
-  for (; j < hi; ++j) acc += s[j];
+  if (j < hi) {  // tail of 1..7: the reads go out together, the adds stay ordered and conditional
+    double r[7];
+#pragma unroll
+    for (int e = 0; e < 7; ++e) r[e] = s[min(j + e, hi - 1)];
+#pragma unroll
+    for (int e = 0; e < 7; ++e)
+      if (j + e < hi) acc += r[e];
+  }
   return acc;
 }
 // the same, leaving out position dp (the diagonal) when it falls inside [lo, hi)
