@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -793,6 +794,24 @@ struct Guard {
   }
 };
 
+struct Timer {
+  bool on = std::getenv("AMGS_TIMING") != nullptr;
+  double t0 = now();
+  static double now() {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+  }
+  void lap(const char* label, int64_t n) {
+    if (!on) return;
+    const double t = now();
+    std::fprintf(stderr, "[amgsetup] n=%lld %-14s %.3f s\n", (long long)n, label, t - t0);
+    t0 = t;
+  }
+};
+
 // classical.jl:6-55
 amgs_hier* ruge_stuben(const Mat& A0, const amgs_options& o) {
   std::unique_ptr<amgs_hier> h(new amgs_hier);
@@ -805,15 +824,20 @@ amgs_hier* ruge_stuben(const Mat& A0, const amgs_options& o) {
       Atown = transpose(*A);
       At = Atown.get();
     }
+    Timer tm;  // AMGS_TIMING=1 prints the same labels the reference's @timeit_debug uses (classical.jl:25-48)
     MatP S, T;
     classical_strength(*At, o.theta, S, T);
+    tm.lap("strength", A->m);
     std::vector<int32_t> splitting(A->m);
     rs_splitting(*S, splitting.data());
+    tm.lap("splitting", A->m);
     MatP R = direct_interpolation(*At, *T, splitting.data());
     if (R->m == 0) break;  // size(P,2) == 0
     MatP P = transpose(*R);
+    tm.lap("interpolation", A->m);
     MatP RA = spgemm(*R, *A);
     MatP RAP = spgemm(*RA, *P);
+    tm.lap("RAP", A->m);
     h->A.push_back(std::move(A));
     h->P.push_back(std::move(P));
     h->R.push_back(std::move(R));

@@ -28,8 +28,16 @@ def main_distributed(args):
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    # AMG_DIST_BACKEND=gloo + AMG_DIST_ONE_GPU=1: functional test of the multi-process path on a box with a
+    # single GPU (every rank on cuda:0, collectives staged through the host); never used for numbers
+    backend = os.environ.get("AMG_DIST_BACKEND", "nccl")
+    if os.environ.get("AMG_DIST_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if rank == 0:
         g.build(only_missing=True)
     dist.barrier()
@@ -62,7 +70,7 @@ def main_distributed(args):
     for _ in range(args.steps):
         dml.precond_apply(0)
     sync()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -78,7 +86,7 @@ def main_distributed(args):
         for _ in range(reps):
             dml.exchange("x", 0, dml.x[0]); ops.spmv(d["A"], dml.x[0], d["res"])
         sync()
-        sp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        sp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(sp, op=dist.ReduceOp.MAX)
         spmv_ms = 1e3 * float(sp.item()) / reps
 
