@@ -294,10 +294,14 @@ class _Hier:
         return SparseMatrixCSC(setup_lib().amgs_hier_get(self.h, level, which), owner=self)
 
 
-def _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, method):
+def _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, method, eltype=None):
     L = setup_lib().amgs_hier_num_levels(hier.h)
     levels = [Level(hier.get(l, 0), hier.get(l, 1), hier.get(l, 2), presmoother, postsmoother) for l in range(L)]
     final_A = hier.get(L, 0)
+    if eltype is not None:  # the element type of the matrix the caller handed in (multilevel.jl:154 promotion)
+        final_A.eltype = eltype
+        for lev in levels:
+            lev.A.eltype = eltype
     if not isinstance(symmetry, HermitianSymmetry):
         # NoSymmetry smoothers need a nonzero stored diagonal (smoother.jl:239-241)
         for lev in levels:
@@ -333,7 +337,7 @@ def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, post
     o.max_coarse = int(max_coarse)
     o.hermitian = int(isinstance(symmetry, HermitianSymmetry))
     hier = _Hier(setup_lib().amgs_ruge_stuben(A._h, C.byref(o)))
-    return _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, "rs")
+    return _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, "rs", A.eltype)
 
 
 def smoothed_aggregation(A, B=None, symmetry=None, strength=None, aggregate=None, smooth=None,
@@ -378,7 +382,7 @@ def smoothed_aggregation(A, B=None, symmetry=None, strength=None, aggregate=None
         Bf = np.asfortranarray(B.reshape(n, nB))
         Bptr = Bf.ctypes.data
     hier = _Hier(setup_lib().amgs_smoothed_aggregation(A._h, Bptr, nB, C.byref(o)))
-    ml = _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, "sa")
+    ml = _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, "sa", A.eltype)
     if verbose:
         print(ml)
     return ml

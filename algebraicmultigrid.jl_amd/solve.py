@@ -60,10 +60,21 @@ def _solve_inplace(x, ml, b, cycle=None, maxiter=100, abstol=0.0, reltol=_SQRT_E
 
 
 def _solve(ml, b, cycle=None, **kwargs):
-    """`_solve(ml, b[, cycle]; kwargs...)`: x = zeros, then `_solve!` (multilevel.jl:152-157)."""
+    """`_solve(ml, b[, cycle]; kwargs...)`: x = zeros, then `_solve!` (multilevel.jl:152-157).
+
+    Element type: the reference returns `promote_type(eltype(ml.workspace), eltype(b))`
+    (multilevel.jl:154; test/runtests.jl:244-259).  The HIP path always computes in f64; a Float32
+    hierarchy with a Float32 right-hand side gets its result rounded to Float32 to keep that contract."""
+    b_in = np.asarray(b)
     b = np.asarray(b, dtype=np.float64)
     x = np.zeros_like(b)
-    return _solve_inplace(x, ml, b, cycle, **kwargs)
+    out = _solve_inplace(x, ml, b, cycle, **kwargs)
+    A0 = ml.levels[0].A if ml.levels else ml.final_A
+    if A0.eltype == np.float32 and b_in.dtype == np.float32:
+        if isinstance(out, tuple):
+            return out[0].astype(np.float32), out[1].astype(np.float32)
+        return out.astype(np.float32)
+    return out
 
 
 # ---- CommonSolve-style adapter (multilevel.jl:241-264) ------------------------

@@ -34,6 +34,7 @@ class SparseMatrixCSC:
         self.rowval = _view(L.amgs_mat_rowval(handle), self._nnz, np.int32)
         self.nzval = _view(L.amgs_mat_nzval(handle), self._nnz, np.float64)
         self._sym = None
+        self.eltype = np.dtype(np.float64)  # element type the CALLER handed in (storage/arithmetic is always f64)
         self._T = None
 
     def __del__(self):
@@ -60,7 +61,10 @@ class SparseMatrixCSC:
         A = sp.csc_matrix(A)
         A.sum_duplicates()
         A.sort_indices()
-        return cls.from_arrays(A.shape[0], A.shape[1], A.indptr, A.indices, A.data)
+        out = cls.from_arrays(A.shape[0], A.shape[1], A.indptr, A.indices, A.data)
+        if A.dtype == np.float32:
+            out.eltype = np.dtype(np.float32)
+        return out
 
     @classmethod
     def from_dense(cls, M):

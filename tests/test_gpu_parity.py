@@ -366,3 +366,13 @@ def test_multiple_right_hand_sides_block_workspace():
         Z = AMG.aspreconditioner(ml).ldiv(B)
         for c in range(3):
             assert rel(Z[:, c], oh.precond(B[:, c])) <= TOL
+
+
+def test_eltype_promotion_contract():  # runtests.jl:244-259
+    a = AMG.poisson(100).to_scipy()
+    b = uniform(100, 1)
+    for T, V in ((np.float64, np.float64), (np.float32, np.float32), (np.float64, np.float32), (np.float32, np.float64)):
+        ml = AMG.smoothed_aggregation(a.astype(T))
+        x = AMG._solve(ml, b.astype(V))
+        assert x.dtype == np.promote_types(T, V)
+        assert np.linalg.norm(a @ x.astype(np.float64) - b) <= (1e-5 if x.dtype == np.float32 else 1e-7) * np.linalg.norm(b)
