@@ -78,7 +78,14 @@ struct GsSchedule {
   int64_t bytes = 0;
   struct Seg { int l0, l1; bool chain; int rows; };  // dependency levels [l0, l1); rows per workgroup (launch)
   std::vector<Seg> segs;
+  // block-inverse path (small, densely coupled operators; see gs_block_kernel)
+  struct Outer { int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; double* tinv = nullptr; };
+  Outer blk_f, blk_b;
+  double* blk_diag = nullptr;
+  int nblk = 0;  // 0 = block path not built for this operator
   void free_dev() {
+    for (Outer* o : {&blk_f, &blk_b}) { hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv); *o = Outer(); }
+    hipFree(blk_diag); blk_diag = nullptr;
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
     hipFree(perm); hipFree(dpos); hipFree(diag); hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
     d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = bp = xp = nullptr; rowmeta = desc = nullptr; permx = nullptr;
@@ -98,7 +105,6 @@ struct amgh_csr {
   double* diag = nullptr;
   GsSchedule* gs = nullptr;
   int64_t bytes = 0;
-  bool owns = true;
 };
 
 namespace {
@@ -107,7 +113,8 @@ namespace {
 int g_gs_block_target = 256;   // aim for at least this many workgroups per wide level
 int g_gs_min_rows = 4;         // but never fewer rows per workgroup than this
 int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (one per thread)
-int g_gs_threads = 256;        // workgroup size of the per-level launches (64 or 256)
+int g_gs_threads = 256;
+int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)
 
 unsigned long long* g_chain_tim = nullptr;  // diagnostics buffer (amgh_debug_chain_timing)
 
@@ -146,7 +153,7 @@ int csr_upload(amgh_csr* op, int device, int64_t nrows, int64_t ncols, const int
 
 void csr_free(amgh_csr* op) {
   if (!op) return;
-  if (op->owns) { hipFree(op->rowptr); hipFree(op->col); hipFree(op->val); }
+  hipFree(op->rowptr); hipFree(op->col); hipFree(op->val);
   hipFree(op->dpos); hipFree(op->diag);
   if (op->gs) { op->gs->free_dev(); delete op->gs; }
   op->rowptr = op->col = op->dpos = nullptr; op->val = op->diag = nullptr; op->gs = nullptr;
@@ -166,6 +173,59 @@ int csr_ensure_diag(amgh_csr* op, hipStream_t st) {
                        op->val, (int)n, op->dpos, op->diag);
   HIP_TRY(hipGetLastError());
   op->bytes += op->nrows * 12;
+  return AMGH_OK;
+}
+
+// Block-inverse data of one sweep direction: the outer matrix (operator minus the in-block triangle
+// and diagonal) and the dense inverses of the in-block triangles.
+int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int32_t* rowptr, const int32_t* col,
+                      const double* val, const std::vector<double>& diag) {
+  const int B = kBlk;
+  const int nblk = (int)((n + B - 1) / B);
+  std::vector<int32_t> orow(n + 1, 0), ocol;
+  std::vector<double> oval;
+  ocol.reserve(rowptr[n]); oval.reserve(rowptr[n]);
+  std::vector<double> tinv((size_t)nblk * B * B, 0.0), T((size_t)B * B);
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int64_t i0 = (int64_t)blk * B, i1 = std::min<int64_t>(i0 + B, n);
+    std::fill(T.begin(), T.end(), 0.0);
+    for (int64_t i = i0; i < i1; ++i) {
+      const bool skip = diag[i] == 0.0;  // row without a usable diagonal keeps its x: T row = e_i
+      for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+        const int32_t c = col[j];
+        const bool in_tri = c >= i0 && c < i1 && (backward ? c >= i : c <= i);
+        if (in_tri) {
+          if (!skip) T[(size_t)(i - i0) * B + (c - i0)] += val[j];
+        } else if (!skip) {
+          ocol.push_back(c); oval.push_back(val[j]);
+        }
+      }
+      if (skip) T[(size_t)(i - i0) * B + (i - i0)] = 1.0;
+      orow[i + 1] = (int32_t)ocol.size();
+    }
+    for (int64_t i = i1; i < i0 + B; ++i) T[(size_t)(i - i0) * B + (i - i0)] = 1.0;  // padding rows
+    // invert the triangle column by column (forward / backward substitution on the identity)
+    double* X = tinv.data() + (size_t)blk * B * B;
+    for (int c = 0; c < B; ++c) {
+      if (!backward) {
+        for (int i = c; i < B; ++i) {
+          double s = (i == c) ? 1.0 : 0.0;
+          for (int j = c; j < i; ++j) s -= T[(size_t)i * B + j] * X[(size_t)j * B + c];
+          X[(size_t)i * B + c] = s / T[(size_t)i * B + i];
+        }
+      } else {
+        for (int i = c; i >= 0; --i) {
+          double s = (i == c) ? 1.0 : 0.0;
+          for (int j = i + 1; j <= c; ++j) s -= T[(size_t)i * B + j] * X[(size_t)j * B + c];
+          X[(size_t)i * B + c] = s / T[(size_t)i * B + i];
+        }
+      }
+    }
+  }
+  RC_TRY(dev_upload(&o->rowptr, orow.data(), n + 1));
+  RC_TRY(dev_upload(&o->col, ocol.data(), (int64_t)ocol.size()));
+  RC_TRY(dev_upload(&o->val, oval.data(), (int64_t)oval.size()));
+  RC_TRY(dev_upload(&o->tinv, tinv.data(), (int64_t)tinv.size()));
   return AMGH_OK;
 }
 
@@ -247,6 +307,22 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   }
   g->n = n;
   g->bytes = (n + 1) * 4 + nnz * 12 + n * 16 + (g->nlev + 1) * 4 + n * 24 + g->nlev * 16 + g->ncols * 12;
+  // Block-inverse path: worth it when level scheduling has degenerated (many more dependency levels
+  // than index blocks) and the dense blocks stay small.
+  {
+    const int nblk = (int)((n + kBlk - 1) / kBlk);
+    if (n >= 16 && n <= 262144 && g->nlev >= 3 * nblk) {
+      std::vector<double> dg(n, 0.0);
+      for (int64_t i = 0; i < n; ++i)
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
+          if (col[j] == i) dg[i] = val[j];
+      RC_TRY(blockgs_build_dir(&g->blk_f, false, n, rowptr, col, val, dg));
+      RC_TRY(blockgs_build_dir(&g->blk_b, true, n, rowptr, col, val, dg));
+      RC_TRY(dev_upload(&g->blk_diag, dg.data(), n));
+      g->nblk = nblk;
+      g->bytes += 2 * ((int64_t)nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4) + n * 8;
+    }
+  }
   // segments: runs of narrow dependency levels are chained in one workgroup
   // A dependency level is chained (stays inside one workgroup) when it has at most
   // one row per thread and its products fit one LDS pass; anything larger is worth
@@ -411,6 +487,16 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
   if (g->n <= 0) return AMGH_OK;
+  if (g->nblk > 0 && g_gs_block_inverse && !sor) {
+    // small densely coupled operator: n/128 sequential block steps in natural row order
+    BlockArgs ba{};
+    const GsSchedule::Outer& o = backward ? g->blk_b : g->blk_f;
+    ba.rowptr = o.rowptr; ba.col = o.col; ba.val = o.val; ba.tinv = o.tinv; ba.diag = g->blk_diag;
+    ba.x = x; ba.b = b; ba.n = (int32_t)g->n; ba.nblk = g->nblk; ba.backward = backward ? 1 : 0;
+    hipLaunchKernelGGL(gs_block_kernel, dim3(1), dim3(kBlkThreads), 0, st, ba);
+    HIP_TRY(hipGetLastError());
+    return AMGH_OK;
+  }
   if (first) {
     hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n)), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n);
     hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols)), dim3(256), 0, st, (const double*)x, g->permx,
@@ -1367,6 +1453,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_min_rows")) g_gs_min_rows = value;
   else if (!strcmp(name, "gs_nnz_per_wg")) g_gs_nnz_per_wg = value;
   else if (!strcmp(name, "gs_threads")) g_gs_threads = value;
+  else if (!strcmp(name, "gs_block_inverse")) g_gs_block_inverse = value;
   else return AMGH_EINVAL;
   return AMGH_OK;
 }

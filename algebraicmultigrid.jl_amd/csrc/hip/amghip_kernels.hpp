@@ -1,10 +1,12 @@
 // amghip_kernels.hpp — gfx950 (CDNA4, wave64) device kernels of the AMG solve phase.
 //
-// Everything here is HBM-bound sparse/stream work (0.135 flop/B on the fine
-// Poisson SpMV), so no MFMA: the design rules are coalesced streaming of the CSR
+// Everything here is HBM- or latency-bound sparse/stream work (0.135 flop/B on the fine
+// Poisson SpMV), so no MFMA: the design rules are coalesced 16-byte streaming of the CSR
 // arrays, LDS-staged products with a sequential per-row sum (which also makes the
 // result bit-reproducible and equal to a scalar CPU loop), wavefront __shfl
-// reductions for norms/dots, XCD-contiguous row-block mapping for L2 locality.
+// reductions for norms/dots.  An XCD-contiguous row-block mapping is available as a
+// configuration switch; it measured 5-10 % SLOWER than the default round-robin mapping
+// on the 256^3 operator (profiles/r01_spmv_variants.log) and is off in the shipped config.
 //
 // Arithmetic is kept un-contracted (no FMA fusion across the product and the
 // running sum: the product is rounded when it is staged in LDS), so a row's sum
@@ -52,9 +54,10 @@ template <bool SKEWED>
 __device__ __forceinline__ int lidx(int k) { return SKEWED ? skew(k) : k; }
 __device__ __forceinline__ double seq_sum_skip(const double* s, int lo, int hi, int dp, double acc);
 
-// XCD-contiguous block mapping (workgroup b is observed to run on XCD b % 8):
+// Optional XCD-contiguous block mapping (workgroup b is observed to run on XCD b % 8):
 // give each XCD a contiguous eighth of the row blocks so that the +-nx rows'
-// x entries are re-used out of that XCD's own L2.  Speed only, never correctness.
+// x entries are re-used out of that XCD's own L2.  Speed only, never correctness
+// (and measured slower than round-robin here, see the header comment).
 // The grid must be launched with 8*ceil(nb/8) workgroups.
 __device__ __forceinline__ int xcd_block(int b, int nb) {
   const int per = (nb + kNumXcd - 1) / kNumXcd;
@@ -65,7 +68,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef int i2_t __attribute__((ext_vector_type(2)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 
-// matrix streams are read once: non-temporal loads keep them from evicting x from L2
+// matrix streams are read once: optional non-temporal loads (measured neutral-to-negative, off by default)
 template <bool NT, class T>
 __device__ __forceinline__ T ld_stream(const T* p) {
   if (NT) return __builtin_nontemporal_load(p);
@@ -457,6 +460,101 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
     atomicAdd(a.tim + 5, nlv);
     atomicAdd(a.tim + 6, 1ull);
     atomicAdd(a.tim + 7, tacc[5]);
+  }
+}
+
+// ---- block-inverse Gauss-Seidel for small, densely coupled operators ------------------------
+// Coarse AMG levels have few rows but long rows (60-124 nonzeros) and therefore almost as many
+// dependency levels as rows: level scheduling degenerates to ~1 row per step.  For those operators
+// the sweep is re-blocked by ROW INDEX: with B = kBlk consecutive rows per block,
+//   forward:  x_I <- T_II^{-1} ( b_I - sum_{j not in-block-lower} a_ij x_j ),  T_II = (D + L)_II
+// visits the blocks in order, so the result is the lexicographic Gauss-Seidel iterate; the
+// in-block triangular solve is one dense B x B product with the pre-inverted block (rounding
+// differs from the scalar recurrence at the 1e-15 level; the exact-order path stays available,
+// amgh_debug_set_tunable("gs_block_inverse", 0)).  n/B sequential steps instead of ~n.
+constexpr int kBlk = 128;
+constexpr int kBlkThreads = 1024;  // 128 rows x 8 partial sums in the dense phase
+constexpr int kBlkLds = 8192;
+
+struct BlockArgs {
+  const int32_t* rowptr;  // "outer" matrix of this direction: the operator minus the in-block triangle
+  const int32_t* col;     //   (forward: minus in-block entries with col <= row; backward: col >= row)
+  const double* val;
+  const double* tinv;     // nblk x kBlk x kBlk row-major: inverse of the in-block triangle (+ diagonal)
+  const double* diag;     // diagonal of each row, 0 if absent (such rows keep x, smoother.jl:87)
+  double* x;
+  const double* b;
+  int32_t n;
+  int32_t nblk;
+  int32_t backward;
+};
+
+// this thread's 16 entries of the block inverse (row drow, columns part*16..+15); the half of the
+// block that is structurally zero (above the diagonal forward, below it backward) is not read
+__device__ __forceinline__ void blk_load_tinv(const BlockArgs& a, int blk, int drow, int part, double (&tv)[16]) {
+  const bool nz = a.backward ? (part * 16 + 15 >= drow) : (part * 16 <= drow);
+  if (nz) {
+    const d2_t* tp = (const d2_t*)(a.tinv + ((size_t)blk * kBlk + drow) * kBlk + part * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const d2_t v = tp[e]; tv[2 * e] = v.x; tv[2 * e + 1] = v.y; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tv[e] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
+  __shared__ double s_prod[kBlkLds];
+  __shared__ double s_vec[kBlk];
+  const int tid = threadIdx.x;
+  const int drow = tid >> 3, part = tid & 7;  // dense phase: 8 lanes share a row, 16 columns each
+  double tv[16];
+  blk_load_tinv(a, a.backward ? a.nblk - 1 : 0, drow, part, tv);
+  for (int step = 0; step < a.nblk; ++step) {
+    const int blk = a.backward ? a.nblk - 1 - step : step;
+    const int i0 = blk * kBlk;
+    const int rows = min(kBlk, a.n - i0);
+    // phase 1: s_i = b_i - (outer row i) . x      (all x entries referenced are final or old)
+    const int p0 = a.rowptr[i0], p1 = a.rowptr[i0 + rows];
+    int rs = 0, re = 0;
+    double d = 0.0, bb = 0.0, xo = 0.0, acc = 0.0;
+    if (tid < rows) {
+      rs = a.rowptr[i0 + tid]; re = a.rowptr[i0 + tid + 1];
+      d = a.diag[i0 + tid]; bb = a.b[i0 + tid]; xo = a.x[i0 + tid];
+    }
+    for (int c0 = p0; c0 < p1; c0 += kBlkLds) {
+      const int c1 = min(c0 + kBlkLds, p1);
+      // one CU streams the whole operator: keep 4 independent (val, col) -> x chains in flight per thread
+      int k = c0 + tid;
+      for (; k + 3 * kBlkThreads < c1; k += 4 * kBlkThreads) {
+        double v[4], xv[4];
+        int c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a.val[k + e * kBlkThreads]; c[e] = a.col[k + e * kBlkThreads]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] = a.x[c[e]];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_prod[k + e * kBlkThreads - c0] = v[e] * xv[e];
+      }
+      for (; k < c1; k += kBlkThreads) s_prod[k - c0] = a.val[k] * a.x[a.col[k]];
+      __syncthreads();
+      if (tid < rows) acc = seq_sum_range(s_prod, max(rs, c0) - c0, min(re, c1) - c0, acc);
+      if (c1 < p1) __syncthreads();
+    }
+    if (tid < kBlk) s_vec[tid] = (tid < rows) ? ((d == 0.0) ? xo : bb - acc) : 0.0;
+    __syncthreads();
+    // phase 2: x_I = Tinv_II . s
+    double sum = 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum += tv[e] * s_vec[part * 16 + e];
+    sum += __shfl_xor(sum, 1, kWave);
+    sum += __shfl_xor(sum, 2, kWave);
+    sum += __shfl_xor(sum, 4, kWave);
+    // the next block's inverse streams in while this step finishes and the next one starts
+    if (step + 1 < a.nblk) blk_load_tinv(a, a.backward ? blk - 1 : blk + 1, drow, part, tv);
+    if (part == 0 && drow < rows) a.x[i0 + drow] = sum;
+    __threadfence_block();
+    __syncthreads();
   }
 }
 

@@ -33,11 +33,6 @@ def row_ranges(n, nranks):
     return [(cuts[p], cuts[p + 1]) for p in range(nranks)]
 
 
-def _csr_of(M, as_rows=True):
-    """(rowptr, col, val) of a SparseMatrixCSC in CSR."""
-    return M.csr_arrays()
-
-
 class VectorPlan:
     """Halo plan of one distributed vector: which off-range entries this rank reads (union over
     all operators that consume the vector) and which of its own entries other ranks read."""

@@ -25,11 +25,6 @@ class _Csr:
         self.colptr, self.rowval, self.nzval = self.rowptr, self.col, self.val
 
 
-class _Sm:
-    def __init__(self, kind, sweep, omega):
-        self.kind, self.sweep_code, self.iter, self.omega = kind, sweep, 1, omega
-
-
 class CpuOps:
     """Reference arithmetic on CPU tensors: y = M x with M given by CSR rows == oracle's A' product."""
 

@@ -1,0 +1,82 @@
+"""Error behaviour of the C ABI on a real device: every misuse returns a negative code, nothing
+throws or crashes (include/amghip.h conventions)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import amg_amd as AMG
+from amg_amd._libs import amgh_smoother_t
+
+pytestmark = pytest.mark.gpu
+
+EINVAL, ESTATE, EUNSUPPORTED = -2, -3, -5
+
+
+def _csr(A):
+    rp, ci, va = A.csr_arrays()
+    return rp.ctypes.data, ci.ctypes.data, va.ctypes.data
+
+
+def test_state_machine_and_argument_checks():
+    lib = AMG.hip_lib()
+    A = AMG.poisson(40)
+    ml = AMG.ruge_stuben(A, max_levels=2)
+    lev = ml.levels[0]
+    h = C.c_void_p()
+    assert lib.amgh_create(C.byref(h), 99, 1) == EINVAL                     # no such device
+    assert lib.amgh_create(C.byref(h), 0, 1) == 0
+    gs = amgh_smoother_t(1, 2, 1, 0, 1.0)
+    bad = amgh_smoother_t(7, 0, 1, 0, 1.0)
+    a, p, r = _csr(lev.A), (lev.R.colptr.ctypes.data, lev.R.rowval.ctypes.data, lev.R.nzval.ctypes.data), \
+        (lev.P.colptr.ctypes.data, lev.P.rowval.ctypes.data, lev.P.nzval.ctypes.data)
+    n, nc = lev.A.m, lev.P.n
+    x = np.zeros(n); b = np.ones(n); it = C.c_int(0)
+    # not finalized yet
+    assert lib.amgh_solve(h, b.ctypes.data, x.ctypes.data, 0, 10, 0.0, 1e-8, 1, None, C.byref(it)) == ESTATE
+    assert lib.amgh_finalize(h) == ESTATE                                    # no coarse level set
+    assert lib.amgh_push_level(h, n, nc, *a, None, None, None, *p, *r, C.byref(bad), C.byref(gs)) == EINVAL
+    assert lib.amgh_push_level(h, n, nc, None, None, None, None, None, None, *p, *r, C.byref(gs), C.byref(gs)) == EINVAL
+    assert lib.amgh_push_level(h, n, nc, *a, None, None, None, *p, *r, C.byref(gs), C.byref(gs)) == 0
+    # next level must have n == previous nc
+    assert lib.amgh_push_level(h, n, nc, *a, None, None, None, *p, *r, C.byref(gs), C.byref(gs)) == EINVAL
+    fa = _csr(ml.final_A)
+    op = np.asfortranarray(ml.coarse_solver.dense_operator())
+    assert lib.amgh_set_coarse(h, nc + 1, *fa, op.ctypes.data) == EINVAL     # size mismatch with the last level
+    assert lib.amgh_set_coarse(h, nc, *fa, None) == EINVAL
+    assert lib.amgh_set_coarse(h, nc, *fa, op.ctypes.data) == 0
+    assert lib.amgh_set_coarse(h, nc, *fa, op.ctypes.data) == ESTATE         # already set
+    assert lib.amgh_finalize(h) == 0
+    assert lib.amgh_finalize(h) == ESTATE
+    assert lib.amgh_push_level(h, n, nc, *a, None, None, None, *p, *r, C.byref(gs), C.byref(gs)) == ESTATE
+    assert lib.amgh_solve(h, None, x.ctypes.data, 0, 10, 0.0, 1e-8, 1, None, C.byref(it)) == EINVAL
+    assert lib.amgh_solve(h, b.ctypes.data, x.ctypes.data, 5, 10, 0.0, 1e-8, 1, None, C.byref(it)) == EINVAL  # bad cycle
+    assert lib.amgh_solve(h, b.ctypes.data, x.ctypes.data, 0, -1, 0.0, 1e-8, 1, None, C.byref(it)) == EINVAL
+    assert lib.amgh_level_spmv(h, 9, 0, b.ctypes.data, x.ctypes.data) == EINVAL
+    assert lib.amgh_solve(h, b.ctypes.data, x.ctypes.data, 0, 50, 0.0, 1e-10, 1, None, C.byref(it)) == 0
+    assert np.linalg.norm(A.to_scipy() @ x - b) <= 1e-9 * np.linalg.norm(b) and 0 < it.value <= 50
+    assert lib.amgh_num_levels(h) == 1 and lib.amgh_level_size(h, 0) == n and lib.amgh_level_size(h, 1) == nc
+    assert lib.amgh_device_bytes(h) > 0
+    lib.amgh_destroy(h)
+    lib.amgh_destroy(None)                                                   # no-op
+
+
+def test_hierarchy_without_levels_needs_final_A_and_pcg_rejects_blocks():
+    lib = AMG.hip_lib()
+    A = AMG.poisson(8)
+    op = np.asfortranarray(np.linalg.inv(A.toarray()))
+    h = C.c_void_p()
+    assert lib.amgh_create(C.byref(h), 0, 1) == 0
+    assert lib.amgh_set_coarse(h, 8, None, None, None, op.ctypes.data) == 0
+    assert lib.amgh_finalize(h) == ESTATE    # no levels and no final_A: the residual of multilevel.jl:188 has no operator
+    lib.amgh_destroy(h)
+    ml = AMG.ruge_stuben(AMG.poisson(50))
+    dev = ml.device(nrhs=2)
+    B = np.ones((50, 2), order="F"); X = np.zeros((50, 2), order="F"); it = C.c_int(0)
+    assert lib.amgh_pcg(dev.h, B.ctypes.data, X.ctypes.data, 0, 1, 10, 0.0, 1e-8, None, C.byref(it)) == EUNSUPPORTED
+
+
+def test_strerror_covers_hip_codes():
+    lib = AMG.hip_lib()
+    assert b"HIP error" in lib.amgh_strerror(-1001)
+    assert b"unknown" in lib.amgh_strerror(-7)

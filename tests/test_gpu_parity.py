@@ -375,4 +375,5 @@ def test_eltype_promotion_contract():  # runtests.jl:244-259
         ml = AMG.smoothed_aggregation(a.astype(T))
         x = AMG._solve(ml, b.astype(V))
         assert x.dtype == np.promote_types(T, V)
-        assert np.linalg.norm(a @ x.astype(np.float64) - b) <= (1e-5 if x.dtype == np.float32 else 1e-7) * np.linalg.norm(b)
+        # a Float32 result carries its rounding (|x| ~ 2e2, cond ~ 4e3) into the residual
+        assert np.linalg.norm(a @ x.astype(np.float64) - b) <= (1e-3 if x.dtype == np.float32 else 1e-7) * np.linalg.norm(b)
