@@ -76,8 +76,10 @@ struct GsSchedule {
   int32_t* permx = nullptr; // perm extended by the identity over halo columns
   int64_t n = 0, ncols = 0;
   int64_t bytes = 0;
-  struct Seg { int l0, l1; bool chain; int rows; };  // dependency levels [l0, l1); rows per workgroup (launch)
+  struct Seg { int l0, l1; bool chain; int rows; int slot0, nslots; };  // dependency levels [l0, l1); launch shape
   std::vector<Seg> segs;
+  // slot layout of the wide levels (gs_slot_kernel)
+  int32_t* wcol = nullptr; double* wval = nullptr; int32_t* slot_row = nullptr; i4_t* wmeta = nullptr;
   // block-inverse path (small, densely coupled operators; see gs_block_kernel)
   struct Outer { int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; double* tinv = nullptr; };
   Outer blk_f, blk_b;
@@ -86,6 +88,7 @@ struct GsSchedule {
   void free_dev() {
     for (Outer* o : {&blk_f, &blk_b}) { hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv); *o = Outer(); }
     hipFree(blk_diag); blk_diag = nullptr;
+    hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
     hipFree(perm); hipFree(dpos); hipFree(diag); hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
     d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = bp = xp = nullptr; rowmeta = desc = nullptr; permx = nullptr;
@@ -114,6 +117,7 @@ int g_gs_block_target = 256;   // aim for at least this many workgroups per wide
 int g_gs_min_rows = 4;         // but never fewer rows per workgroup than this
 int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (one per thread)
 int g_gs_threads = 256;
+int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)
 
 unsigned long long* g_chain_tim = nullptr;  // diagnostics buffer (amgh_debug_chain_timing)
@@ -361,7 +365,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         }
         ++e;
       }
-      g->segs.push_back({l, e, true, cls});
+      g->segs.push_back({l, e, true, cls, 0, 0});
       l = e;
     } else {
       // rows per workgroup for this level's launch: about one LDS pass of products per
@@ -369,8 +373,57 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       const int width = g->lvl_ptr[l + 1] - g->lvl_ptr[l];
       const int lnnz = prow[g->lvl_ptr[l + 1]] - prow[g->lvl_ptr[l]];
       const double avg = std::max(1.0, (double)lnnz / width);
-      g->segs.push_back({l, l + 1, false, (int)std::min(1e6, avg * 16.0)});  // 16 x mean row length
+      g->segs.push_back({l, l + 1, false, (int)std::min(1e6, avg * 16.0), 0, -1});  // 16 x mean row length
       ++l;
+    }
+  }
+  // slot layout for the wide levels whose rows all fit a slot
+  {
+    std::vector<int32_t> wcol, slot_row;
+    std::vector<double> wval;
+    std::vector<i4_t> wmeta(n, i4_t{0, 0, -1, 0});
+    for (auto& sg : g->segs) {
+      if (sg.chain) continue;
+      const int ra = g->lvl_ptr[sg.l0], rb = g->lvl_ptr[sg.l0 + 1];
+      bool fits = true;
+      for (int p2 = ra; p2 < rb && fits; ++p2) fits = prow[p2 + 1] - prow[p2] <= kSlot;
+      if (!fits) continue;
+      sg.slot0 = (int)slot_row.size();
+      int fill = kSlot;  // force a new slot for the level's first row
+      for (int p2 = ra; p2 < rb; ++p2) {
+        const int len = prow[p2 + 1] - prow[p2];
+        if (fill + len > kSlot) {  // open a new slot (pad the previous one)
+          wcol.resize(slot_row.size() * (size_t)kSlot, 0);
+          wval.resize(slot_row.size() * (size_t)kSlot, 0.0);
+          slot_row.push_back(p2);
+          fill = 0;
+        }
+        const int32_t start = (int32_t)((slot_row.size() - 1) * (size_t)kSlot + fill);
+        for (int32_t j = prow[p2]; j < prow[p2 + 1]; ++j) { wcol.push_back(pcol[j]); wval.push_back(pval[j]); }
+        wmeta[p2] = i4_t{start, start + len, pdpos[p2] >= 0 ? start + (pdpos[p2] - prow[p2]) : -1, 0};
+        fill += len;
+      }
+      sg.nslots = (int)slot_row.size() - sg.slot0;
+    }
+    if (!slot_row.empty()) {
+      wcol.resize(slot_row.size() * (size_t)kSlot, 0);
+      wval.resize(slot_row.size() * (size_t)kSlot, 0.0);
+      // slot_row[s + 1] must close the last slot of every level: append per-level end markers by
+      // storing, for each slot, its end row in a parallel array packed as slot_row2
+      std::vector<int32_t> sr2(2 * slot_row.size());
+      for (auto& sg : g->segs) {
+        if (sg.chain || sg.nslots <= 0) continue;
+        for (int q = 0; q < sg.nslots; ++q) {
+          const int sidx = sg.slot0 + q;
+          sr2[2 * sidx] = slot_row[sidx];
+          sr2[2 * sidx + 1] = (q + 1 < sg.nslots) ? slot_row[sidx + 1] : g->lvl_ptr[sg.l0 + 1];
+        }
+      }
+      RC_TRY(dev_upload(&g->wcol, wcol.data(), (int64_t)wcol.size()));
+      RC_TRY(dev_upload(&g->wval, wval.data(), (int64_t)wval.size()));
+      RC_TRY(dev_upload(&g->slot_row, sr2.data(), (int64_t)sr2.size()));
+      RC_TRY(dev_upload(&g->wmeta, wmeta.data(), n));
+      g->bytes += (int64_t)wcol.size() * 12 + (int64_t)sr2.size() * 4 + n * 16;
     }
   }
   return AMGH_OK;
@@ -515,6 +568,13 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       else { c.lvl_begin = s.l1 - 1; c.lvl_end = s.l0 - 1; c.step = -1; }
       const bool ldsx = g->ncols <= kChainLdsX;  // x (halo included) fits LDS
       RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)g->ncols, st));
+    } else if (s.nslots > 0 && g_gs_slots) {
+      SlotArgs sa{};
+      sa.wcol = g->wcol; sa.wval = g->wval; sa.slot_row = g->slot_row; sa.wmeta = g->wmeta;
+      sa.diag = g->diag; sa.bp = g->bp; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;
+      if (sor) hipLaunchKernelGGL(gs_slot_kernel<true>, dim3(s.nslots), dim3(kSlot), 0, st, sa);
+      else hipLaunchKernelGGL(gs_slot_kernel<false>, dim3(s.nslots), dim3(kSlot), 0, st, sa);
+      HIP_TRY(hipGetLastError());
     } else {
       StreamArgs a{};
       a.rowptr = g->rowptr; a.col = g->col; a.val = g->val;
@@ -1454,6 +1514,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_nnz_per_wg")) g_gs_nnz_per_wg = value;
   else if (!strcmp(name, "gs_threads")) g_gs_threads = value;
   else if (!strcmp(name, "gs_block_inverse")) g_gs_block_inverse = value;
+  else if (!strcmp(name, "gs_slots")) g_gs_slots = value;
   else return AMGH_EINVAL;
   return AMGH_OK;
 }

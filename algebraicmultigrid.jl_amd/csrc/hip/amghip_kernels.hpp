@@ -463,6 +463,51 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
   }
 }
 
+// ---- one WIDE dependency level from the slot layout -------------------------------------------
+// A wide level's launch is latency-bound: kernarg -> row pointers -> col/val -> x gather are four
+// dependent round trips.  The slot layout removes one: the level's nonzeros are packed into slots of
+// kSlot = 256 entries (whole rows only, zero padding), workgroup b owns slot slot0 + b, so the
+// addresses of its col/val loads follow from the kernel arguments and blockIdx alone; which rows the
+// slot holds (slot_row, rowmeta) is fetched in parallel and only needed for the row sums.
+constexpr int kSlot = 256;
+
+struct SlotArgs {
+  const int32_t* wcol;      // slot arrays: nslots * kSlot entries (padding: col 0, val 0)
+  const double* wval;
+  const int32_t* slot_row;  // per slot: {first row, end row} in dependency-level order
+  const i4_t* wmeta;        // per level-ordered row: {start, end, diagonal position} in the slot arrays
+  const double* diag;
+  const double* bp;
+  double* x;                // x in dependency-level order
+  double omega;
+  int32_t slot0;            // first slot of this dependency level
+};
+
+template <bool SOR>
+__global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
+  __shared__ double s_prod[kSlot];
+  const int tid = threadIdx.x;
+  const int s = a.slot0 + blockIdx.x;
+  const int base = s * kSlot;
+  const double v = a.wval[base + tid];
+  const int c = a.wcol[base + tid];
+  const int r0 = a.slot_row[2 * s], r1 = a.slot_row[2 * s + 1];
+  i4_t m = i4_t{0, 0, -1, 0};
+  double d = 0.0, bb = 0.0;
+  if (tid < r1 - r0) {
+    m = a.wmeta[r0 + tid];
+    d = a.diag[r0 + tid];
+    bb = a.bp[r0 + tid];
+  }
+  s_prod[tid] = v * a.x[c];
+  __syncthreads();
+  if (tid < r1 - r0 && d != 0.0) {
+    const double acc = seq_sum_skip(s_prod, m.x - base, m.y - base, m.z - base, 0.0);
+    const int i = r0 + tid;
+    a.x[i] = SOR ? (1.0 - a.omega) * a.x[i] + (a.omega / d) * (bb - acc) : (bb - acc) / d;
+  }
+}
+
 // ---- block-inverse Gauss-Seidel for small, densely coupled operators ------------------------
 // Coarse AMG levels have few rows but long rows (60-124 nonzeros) and therefore almost as many
 // dependency levels as rows: level scheduling degenerates to ~1 row per step.  For those operators
