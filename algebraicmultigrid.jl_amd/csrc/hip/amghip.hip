@@ -84,7 +84,8 @@ struct GsSchedule {
   struct Outer { int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; double* tinv = nullptr; };
   Outer blk_f, blk_b;
   double* blk_diag = nullptr;
-  int nblk = 0;  // 0 = block path not built for this operator
+  int nblk = 0;  // 0 = block path not used for this operator
+  double blk_cond = 0.0;  // largest inf-norm condition estimate of an in-block triangle
   void free_dev() {
     for (Outer* o : {&blk_f, &blk_b}) { hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv); *o = Outer(); }
     hipFree(blk_diag); blk_diag = nullptr;
@@ -183,7 +184,7 @@ int csr_ensure_diag(amgh_csr* op, hipStream_t st) {
 // Block-inverse data of one sweep direction: the outer matrix (operator minus the in-block triangle
 // and diagonal) and the dense inverses of the in-block triangles.
 int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int32_t* rowptr, const int32_t* col,
-                      const double* val, const std::vector<double>& diag) {
+                      const double* val, const std::vector<double>& diag, double* max_cond) {
   const int B = kBlk;
   const int nblk = (int)((n + B - 1) / B);
   std::vector<int32_t> orow(n + 1, 0), ocol;
@@ -225,6 +226,16 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int3
         }
       }
     }
+    // inf-norm condition estimate of the triangle: an explicit inverse is only as accurate as
+    // cond(T) * eps, the caller falls back to the exact-order sweeps when a block is badly conditioned
+    double nt = 0.0, nx = 0.0;
+    for (int i = 0; i < B; ++i) {
+      double rt = 0.0, rx = 0.0;
+      for (int j = 0; j < B; ++j) { rt += std::fabs(T[(size_t)i * B + j]); rx += std::fabs(X[(size_t)i * B + j]); }
+      nt = std::max(nt, rt); nx = std::max(nx, rx);
+    }
+    const double cond = nt * nx;
+    if (!(cond <= *max_cond)) *max_cond = std::isfinite(cond) ? cond : 1e300;
   }
   RC_TRY(dev_upload(&o->rowptr, orow.data(), n + 1));
   RC_TRY(dev_upload(&o->col, ocol.data(), (int64_t)ocol.size()));
@@ -320,11 +331,19 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       for (int64_t i = 0; i < n; ++i)
         for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
           if (col[j] == i) dg[i] = val[j];
-      RC_TRY(blockgs_build_dir(&g->blk_f, false, n, rowptr, col, val, dg));
-      RC_TRY(blockgs_build_dir(&g->blk_b, true, n, rowptr, col, val, dg));
+      double max_cond = 0.0;
+      RC_TRY(blockgs_build_dir(&g->blk_f, false, n, rowptr, col, val, dg, &max_cond));
+      RC_TRY(blockgs_build_dir(&g->blk_b, true, n, rowptr, col, val, dg, &max_cond));
       RC_TRY(dev_upload(&g->blk_diag, dg.data(), n));
-      g->nblk = nblk;
-      g->bytes += 2 * ((int64_t)nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4) + n * 8;
+      g->blk_cond = max_cond;
+      if (getenv("AMGH_VERBOSE"))
+        fprintf(stderr, "[amghip] n=%lld dependency levels=%d index blocks=%d max triangle cond=%.3g -> %s\n", (long long)n,
+                g->nlev, nblk, max_cond, max_cond <= 1e4 ? "block-inverse sweeps" : "exact-order sweeps");
+      // explicit triangle inverses lose ~cond * eps: keep the 1e-10 contract with margin
+      if (max_cond <= 1e4) {
+        g->nblk = nblk;
+        g->bytes += 2 * ((int64_t)nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4) + n * 8;
+      }
     }
   }
   // segments: runs of narrow dependency levels are chained in one workgroup
