@@ -132,6 +132,7 @@ def hip_lib():
     L.amgh_csr_create.argtypes = [C.POINTER(vp), C.c_int, i64, i64, vp, vp, vp]
     L.amgh_csr_destroy.argtypes = [vp]
     L.amgh_csr_destroy.restype = None
+    L.amgh_csr_prepare.argtypes = [vp, C.c_int, C.c_int]
     L.amgh_csr_spmv_d.argtypes = [vp, vp, vp, vp]
     L.amgh_csr_residual_d.argtypes = [vp, vp, vp, vp, vp]
     L.amgh_csr_spmv_add_d.argtypes = [vp, vp, vp, vp]

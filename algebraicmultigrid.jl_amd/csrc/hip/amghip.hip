@@ -1376,6 +1376,14 @@ void amgh_csr_destroy(amgh_csr_t* op) {
   csr_free(op);
   delete op;
 }
+int amgh_csr_prepare(amgh_csr_t* op, int jacobi, int gs) {
+  if (!op) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(op->device));
+  if (jacobi) RC_TRY(csr_ensure_diag(op, nullptr));
+  if (gs) RC_TRY(csr_ensure_gs(op));
+  HIP_TRY(hipDeviceSynchronize());
+  return AMGH_OK;
+}
 int amgh_csr_spmv_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream) {
   if (!op || !x_d || !y_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(op->device));

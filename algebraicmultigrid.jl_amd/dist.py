@@ -145,6 +145,8 @@ class DistMultiLevel:
                 r1 - r0, xp.nloc + xp.nhalo, *_local_block(*csr[l]["S"], r0, r1, xp))
             d["P"] = ops.make_csr(r1 - r0, xpc.nloc + xpc.nhalo, *_local_block(*csr[l]["P"], r0, r1, xpc))
             d["R"] = ops.make_csr(c1 - c0, rp.nloc + rp.nhalo, *_local_block(*csr[l]["R"], c0, c1, rp))
+            kinds = {ml.levels[l].presmoother.kind, ml.levels[l].postsmoother.kind}
+            ops.prepare(d["S"], jacobi=2 in kinds, gs=bool(kinds & {1, 3}))   # schedules built here, not in the first cycle
             d["res"] = ops.zeros(rp.nloc + rp.nhalo)
             d["tmp"] = ops.zeros(max(r1 - r0, 1))
             self.levels.append(d)
@@ -355,6 +357,10 @@ class HipOps:
     def make_csr(self, nrows, ncols, rowptr, col, val):
         from .device import DeviceCSR
         return DeviceCSR(nrows, ncols, rowptr, col, val, self.device)
+
+    def prepare(self, op, jacobi, gs):
+        if op.nrows:
+            self.check(self.lib.amgh_csr_prepare(op.h, int(jacobi), int(gs)), "csr_prepare")
 
     def make_hierarchy(self, ml):
         from .device import DeviceHierarchy

@@ -187,6 +187,9 @@ int amgh_level_smooth_d(amgh_t* h, int level, int post, double* x_d, const doubl
 int amgh_csr_create(amgh_csr_t** op, int device, int64_t nrows, int64_t ncols,
                     const int32_t* rowptr, const int32_t* col, const double* val);
 void amgh_csr_destroy(amgh_csr_t* op);
+/* Build the smoother metadata of the operator now instead of at the first sweep: jacobi != 0 the
+ * diagonal table, gs != 0 the Gauss-Seidel dependency schedule (host work + uploads).       */
+int amgh_csr_prepare(amgh_csr_t* op, int jacobi, int gs);
 /* y = M x ; y = b - M x ; y += M x   (device pointers; stream = hipStream_t or NULL) */
 int amgh_csr_spmv_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream);
 int amgh_csr_residual_d(amgh_csr_t* op, const double* x_d, const double* b_d, double* r_d, void* stream);

@@ -53,6 +53,9 @@ class CpuOps:
     def make_csr(self, nrows, ncols, rowptr, col, val):
         return _Csr(nrows, ncols, rowptr, col, val)
 
+    def prepare(self, op, jacobi, gs):
+        pass
+
     def make_hierarchy(self, ml):
         return O.OracleHierarchy(ml)
 
