@@ -118,6 +118,7 @@ int g_gs_block_target = 256;   // aim for at least this many workgroups per wide
 int g_gs_min_rows = 4;         // but never fewer rows per workgroup than this
 int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (one per thread)
 int g_gs_threads = 256;
+int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)
 
@@ -591,8 +592,10 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       SlotArgs sa{};
       sa.wcol = g->wcol; sa.wval = g->wval; sa.slot_row = g->slot_row; sa.wmeta = g->wmeta;
       sa.diag = g->diag; sa.bp = g->bp; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;
-      if (sor) hipLaunchKernelGGL(gs_slot_kernel<true>, dim3(s.nslots), dim3(kSlot), 0, st, sa);
-      else hipLaunchKernelGGL(gs_slot_kernel<false>, dim3(s.nslots), dim3(kSlot), 0, st, sa);
+      sa.nslots = s.nslots; sa.xcd_map = g_gs_xcd_map;
+      const int grid = g_gs_xcd_map ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots;
+      if (sor) hipLaunchKernelGGL(gs_slot_kernel<true>, dim3(grid), dim3(kSlot), 0, st, sa);
+      else hipLaunchKernelGGL(gs_slot_kernel<false>, dim3(grid), dim3(kSlot), 0, st, sa);
       HIP_TRY(hipGetLastError());
     } else {
       StreamArgs a{};
@@ -1542,6 +1545,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_threads")) g_gs_threads = value;
   else if (!strcmp(name, "gs_block_inverse")) g_gs_block_inverse = value;
   else if (!strcmp(name, "gs_slots")) g_gs_slots = value;
+  else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
   else return AMGH_EINVAL;
   return AMGH_OK;
 }

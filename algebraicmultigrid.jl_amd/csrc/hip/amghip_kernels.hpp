@@ -481,13 +481,20 @@ struct SlotArgs {
   double* x;                // x in dependency-level order
   double omega;
   int32_t slot0;            // first slot of this dependency level
+  int32_t nslots;           // slots of this dependency level
+  int32_t xcd_map;          // 1: XCD-contiguous slot mapping (grid padded to a multiple of 8)
 };
 
 template <bool SOR>
 __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
   __shared__ double s_prod[kSlot];
   const int tid = threadIdx.x;
-  const int s = a.slot0 + blockIdx.x;
+  int lb = blockIdx.x;
+  if (a.xcd_map) {
+    lb = xcd_block(blockIdx.x, a.nslots);
+    if (lb >= a.nslots) return;
+  }
+  const int s = a.slot0 + lb;
   const int base = s * kSlot;
   const double v = a.wval[base + tid];
   const int c = a.wcol[base + tid];

@@ -6,11 +6,7 @@ import amg_amd as AMG
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 A = AMG.poisson((N, N, N)); ml = AMG.ruge_stuben(A); dev = ml.device(); lib = dev.lib
 print("levels", [l.A.m for l in ml.levels])
-for nnzwg in (128, 256, 512, 1024):
-    for target in (256, 1024, 4096):
-        for minrows in (4, 8):
-            lib.amgh_debug_set_tunable(b"gs_nnz_per_wg", nnzwg)
-            lib.amgh_debug_set_tunable(b"gs_block_target", target)
-            lib.amgh_debug_set_tunable(b"gs_min_rows", minrows)
-            ts = [dev.bench_op(l, 4, 2, 1) for l in range(4)]
-            print(f"nnz/wg={nnzwg:4d} target={target:5d} minrows={minrows:2d}: " + "  ".join(f"L{l} {t:7.3f}" for l, t in enumerate(ts)) + f"   sum {sum(ts):7.3f} ms", flush=True)
+for xm in (0, 1, 0, 1):
+    lib.amgh_debug_set_tunable(b"gs_xcd_map", xm)
+    ts = [dev.bench_op(l, 4, 3, 1) for l in range(5)]
+    print(f"xcd_map={xm}: " + "  ".join(f"L{l} {t:7.3f}" for l, t in enumerate(ts)) + f"   sum {sum(ts):7.3f} ms", flush=True)
