@@ -58,28 +58,47 @@ MatP make(int64_t m, int64_t n) {
   return A;
 }
 
+int num_threads() {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
 // dropzeros!(A): remove stored entries whose value is exactly zero.
+// Count per column in parallel, prefix, compact in parallel (order inside a column is kept).
 void dropzeros(Mat& A) {
-  int64_t w = 0;
-  int32_t start = 0;
-  for (int64_t j = 0; j < A.n; ++j) {
-    int32_t end = A.colptr[j + 1];
-    for (int32_t k = start; k < end; ++k) {
-      if (A.nzval[k] != 0.0) {
-        A.rowval[w] = A.rowval[k];
-        A.nzval[w] = A.nzval[k];
-        ++w;
-      }
-    }
-    start = end;
-    A.colptr[j + 1] = (int32_t)w;
+  const int64_t n = A.n;
+  std::vector<int32_t> np(n + 1, 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < n; ++j) {
+    int32_t c = 0;
+    for (int32_t k = A.colptr[j]; k < A.colptr[j + 1]; ++k) c += (A.nzval[k] != 0.0);
+    np[j + 1] = c;
   }
-  A.rowval.resize(w);
-  A.nzval.resize(w);
+  for (int64_t j = 0; j < n; ++j) np[j + 1] += np[j];
+  const int64_t w = np[n];
+  if (w == A.nnz()) return;
+  std::vector<int32_t> rv(w);
+  std::vector<double> nz(w);
+#pragma omp parallel for schedule(static)
+  for (int64_t j = 0; j < n; ++j) {
+    int32_t o = np[j];
+    for (int32_t k = A.colptr[j]; k < A.colptr[j + 1]; ++k)
+      if (A.nzval[k] != 0.0) {
+        rv[o] = A.rowval[k];
+        nz[o] = A.nzval[k];
+        ++o;
+      }
+  }
+  A.colptr.swap(np);
+  A.rowval.swap(rv);
+  A.nzval.swap(nz);
 }
 
 // copy(A') — counting-sort transpose; rows inside each output column ascend.
-MatP transpose(const Mat& A) {
+MatP transpose_serial(const Mat& A) {
   MatP T = make(A.n, A.m);
   const int64_t nnz = A.nnz();
   T->rowval.resize(nnz);
@@ -96,6 +115,84 @@ MatP transpose(const Mat& A) {
     }
   }
   return T;
+}
+
+// Parallel copy(A'): a stable two-level counting sort.  Source columns are cut into one contiguous chunk
+// per thread (balanced by entries); entries are first scattered, chunk by chunk, into buckets of kBucketRows
+// consecutive rows (stable: chunks are in column order), then every bucket is counting-sorted by row on its
+// own (cache-resident).  Same output as transpose_serial, bit for bit.
+MatP transpose(const Mat& A) {
+  const int64_t nnz = A.nnz();
+  const int T = num_threads();
+  if (T <= 1 || nnz < (int64_t)1 << 18) return transpose_serial(A);
+  constexpr int kShift = 13;  // 8192 rows per bucket
+  const int64_t nb = (A.m + ((int64_t)1 << kShift) - 1) >> kShift;
+  MatP Tm = make(A.n, A.m);
+  Tm->rowval.resize(nnz);
+  Tm->nzval.resize(nnz);
+  // column chunks balanced by nnz
+  std::vector<int64_t> cbeg(T + 1, A.n);
+  cbeg[0] = 0;
+  for (int t = 1; t < T; ++t) {
+    const int64_t target = nnz * t / T;
+    cbeg[t] = std::upper_bound(A.colptr.begin(), A.colptr.end(), (int32_t)target) - A.colptr.begin() - 1;
+    if (cbeg[t] < cbeg[t - 1]) cbeg[t] = cbeg[t - 1];
+    if (cbeg[t] > A.n) cbeg[t] = A.n;
+  }
+  std::vector<int64_t> cnt((size_t)T * nb, 0);
+  std::vector<int64_t> bstart(nb + 1, 0);
+  std::vector<int32_t> trow(nnz), tcol(nnz);
+  std::vector<double> tval(nnz);
+#pragma omp parallel for schedule(static, 1)
+  for (int t = 0; t < T; ++t) {
+    int64_t* c = cnt.data() + (size_t)t * nb;
+    for (int32_t k = A.colptr[cbeg[t]]; k < A.colptr[cbeg[t + 1]]; ++k) c[A.rowval[k] >> kShift]++;
+  }
+  {
+    int64_t run = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+      bstart[b] = run;
+      for (int tt = 0; tt < T; ++tt) {
+        const int64_t v = cnt[(size_t)tt * nb + b];
+        cnt[(size_t)tt * nb + b] = run;
+        run += v;
+      }
+    }
+    bstart[nb] = run;
+  }
+#pragma omp parallel for schedule(static, 1)
+  for (int t = 0; t < T; ++t) {
+    int64_t* c = cnt.data() + (size_t)t * nb;
+    for (int64_t j = cbeg[t]; j < cbeg[t + 1]; ++j)
+      for (int32_t k = A.colptr[j]; k < A.colptr[j + 1]; ++k) {
+        const int32_t r = A.rowval[k];
+        const int64_t o = c[r >> kShift]++;
+        trow[o] = r;
+        tcol[o] = (int32_t)j;
+        tval[o] = A.nzval[k];
+      }
+  }
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t r0 = b << kShift, r1 = std::min<int64_t>(A.m, r0 + ((int64_t)1 << kShift));
+    int32_t next[(1 << kShift) + 1];
+    for (int64_t r = 0; r <= r1 - r0; ++r) next[r] = 0;
+    for (int64_t k = bstart[b]; k < bstart[b + 1]; ++k) next[trow[k] - r0 + 1]++;
+    int64_t run = bstart[b];
+    for (int64_t r = 0; r < r1 - r0; ++r) {  // exclusive prefix -> output start of each row
+      const int32_t v = next[r + 1];
+      Tm->colptr[r0 + r] = (int32_t)run;
+      next[r] = (int32_t)run;
+      run += v;
+    }
+    for (int64_t k = bstart[b]; k < bstart[b + 1]; ++k) {
+      const int32_t p = next[trow[k] - r0]++;
+      Tm->rowval[p] = tcol[k];
+      Tm->nzval[p] = tval[k];
+    }
+  }
+  Tm->colptr[A.m] = (int32_t)nnz;
+  return Tm;
 }
 
 // X*Y for CSC operands (SparseArrays spmatmul semantics): column j of the
@@ -212,7 +309,9 @@ MatP poisson(int ndim, const int64_t* dims) {
 
 // ---- strength.jl:7-70 : Classical(theta)(At) ---------------------------
 void scale_cols_by_largest_entry(Mat& A) {  // strength.jl:61-70, find_max :50-58
-  for (int64_t i = 0; i < A.m && i < A.n; ++i) {  // n = size(A,1)
+  const int64_t lim = std::min(A.m, A.n);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < lim; ++i) {  // n = size(A,1)
     double mx = 0.0;
     for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) mx = std::max(mx, A.nzval[j]);
     for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) A.nzval[j] /= mx;
@@ -222,6 +321,7 @@ void scale_cols_by_largest_entry(Mat& A) {  // strength.jl:61-70, find_max :50-5
 void classical_strength(const Mat& At, double theta, MatP& S, MatP& T) {
   T.reset(new Mat(At));
   const int64_t n = At.n;
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     double mx = 0.0;  // find_max_off_diag, strength.jl:39-48
     for (int32_t j = T->colptr[i]; j < T->colptr[i + 1]; ++j)
@@ -270,6 +370,7 @@ MatP symmetric_strength(const Mat& A, double theta, bool bsr_flag) {
 
 // ---- splitting.jl:8-159 : RS() -----------------------------------------
 void remove_diag(Mat& a) {  // splitting.jl:8-18
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < a.n; ++i)
     for (int32_t j = a.colptr[i]; j < a.colptr[i + 1]; ++j)
       if (a.rowval[j] == i) a.nzval[j] = 0.0;
@@ -281,8 +382,10 @@ void remove_diag(Mat& a) {  // splitting.jl:8-18
 // tie-breaking depends on it (ref_split_test.txt / thing.jl goldens).
 void rs_cf_splitting(const Mat& S, const Mat& T, int32_t* splitting_out) {
   const int64_t n = S.m;
-  std::vector<int64_t> lambda(n + 2, 0), interval_ptr(n + 3, 0), interval_count(n + 3, 0);
-  std::vector<int64_t> index_to_node(n + 2, 0), node_to_index(n + 2, 0);
+  // int32 bookkeeping (n < 2^31): the sweep is a sequential chain of dependent random accesses, so the
+  // working-set size is what sets its speed
+  std::vector<int32_t> lambda(n + 2, 0), interval_ptr(n + 3, 0), interval_count(n + 3, 0);
+  std::vector<int32_t> index_to_node(n + 2, 0), node_to_index(n + 2, 0);
   std::vector<int8_t> splitting(n + 2, U_NODE);
   const int32_t* Sp = S.colptr.data();
   const int32_t* Sj = S.rowval.data();
@@ -381,34 +484,48 @@ MatP direct_interpolation(const Mat& At, const Mat& Tin, const int32_t* splittin
   T.m = Tin.m;
   T.n = Tin.n;
   T.colptr.assign(T.n + 1, 0);
-  T.rowval.reserve(Tin.nnz());
-  T.nzval.reserve(Tin.nnz());
-  for (int64_t i = 0; i < Tin.n; ++i) {
-    int32_t a = At.colptr[i], ae = At.colptr[i + 1];
+  auto masked = [&](int64_t i, int32_t* rv, double* nz) -> int32_t {  // entries of column i; rv == nullptr: count only
+    int32_t a = At.colptr[i], ae = At.colptr[i + 1], c = 0;
     for (int32_t t = Tin.colptr[i]; t < Tin.colptr[i + 1]; ++t) {
       int32_t row = Tin.rowval[t];
       while (a < ae && At.rowval[a] < row) ++a;
       if (a < ae && At.rowval[a] == row) {
         double v = At.nzval[a] * 1.0;
         if (v != 0.0) {
-          T.rowval.push_back(row);
-          T.nzval.push_back(v);
+          if (rv) {
+            rv[c] = row;
+            nz[c] = v;
+          }
+          ++c;
         }
       }
     }
-    T.colptr[i + 1] = (int32_t)T.rowval.size();
-  }
+    return c;
+  };
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < Tin.n; ++i) T.colptr[i + 1] = masked(i, nullptr, nullptr);
+  for (int64_t i = 0; i < Tin.n; ++i) T.colptr[i + 1] += T.colptr[i];
+  T.rowval.resize(T.colptr[T.n]);
+  T.nzval.resize(T.colptr[T.n]);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < Tin.n; ++i) masked(i, T.rowval.data() + T.colptr[i], T.nzval.data() + T.colptr[i]);
 
   // pass 1 (classical.jl:71-89)
   std::vector<int32_t> Bp(n + 1, 0);
-  int64_t nnzc = 0;
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
+    int32_t c = 0;
     if (splitting[i] == C_NODE) {
-      nnzc += 1;
+      c = 1;
     } else {
       for (int32_t j = T.colptr[i]; j < T.colptr[i + 1]; ++j)
-        if (splitting[T.rowval[j]] == C_NODE) nnzc += 1;
+        if (splitting[T.rowval[j]] == C_NODE) c += 1;
     }
+    Bp[i + 1] = c;
+  }
+  int64_t nnzc = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    nnzc += Bp[i + 1];
     check_nnz(nnzc);
     Bp[i + 1] = (int32_t)nnzc;
   }
@@ -416,6 +533,7 @@ MatP direct_interpolation(const Mat& At, const Mat& Tin, const int32_t* splittin
   std::vector<double> Bx(nnzc, 0.0);
   std::vector<int32_t> Bj(nnzc, 0);
   const double eps = std::numeric_limits<double>::epsilon();
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     if (splitting[i] == C_NODE) {
       Bj[Bp[i]] = (int32_t)i;
@@ -485,6 +603,7 @@ MatP direct_interpolation(const Mat& At, const Mat& Tin, const int32_t* splittin
     sum += splitting[i];
   }
   int32_t nc = 0;
+#pragma omp parallel for schedule(static) reduction(max : nc)
   for (int64_t k = 0; k < nnzc; ++k) {
     Bj[k] = map[Bj[k]];
     nc = std::max(nc, Bj[k] + 1);  // isempty(Pj) ? 0 : maximum(Pj)
@@ -905,6 +1024,33 @@ amgs_hier* smoothed_aggregation(const Mat& A0, const double* B0, int nB, const a
 extern "C" {
 
 const char* amgs_last_error(void) { return g_err.c_str(); }
+
+#ifdef _OPENMP
+// Library load: unless OMP_NUM_THREADS says otherwise, do not run more OpenMP threads than the container's CPU
+// quota (cgroup v2 cpu.max / v1 cfs quota) — a 256-CPU host with a 16-CPU quota ran the setup 3x slower with 256
+// throttled threads than with 16 — and never more than 64 (the setup is memory-bound well before that).
+__attribute__((constructor)) static void amgs_default_threads() {
+  if (std::getenv("OMP_NUM_THREADS")) return;
+  int cap = std::min(omp_get_max_threads(), 64);
+  long quota = -1, period = -1;
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64] = {0};
+    if (std::fscanf(f, "%63s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atol(q);
+    std::fclose(f);
+  } else {
+    if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (std::fscanf(g, "%ld", &quota) != 1) quota = -1;
+      std::fclose(g);
+    }
+    if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (std::fscanf(g, "%ld", &period) != 1) period = -1;
+      std::fclose(g);
+    }
+  }
+  if (quota > 0 && period > 0) cap = std::min<long>(cap, std::max<long>(1, (quota + period - 1) / period));
+  omp_set_num_threads(cap);
+}
+#endif
 
 int amgs_set_threads(int nthreads) {
 #ifdef _OPENMP
