@@ -72,7 +72,8 @@ struct GsSchedule {
   i4_t* rowmeta = nullptr;  // per permuted row {start, end, diagonal position, original row}
   i4_t* desc = nullptr;     // per dependency level {first row, end row, first nnz, end nnz}
   double* bp = nullptr;     // right-hand side in dependency-level order (scratch)
-  double* xp = nullptr;     // x in dependency-level order (scratch, ncols entries)
+  double* xp = nullptr;     // x in dependency-level order (scratch, ncols entries per right-hand-side column)
+  int cols_alloc = 1;       // right-hand-side columns bp / xp currently hold
   int32_t* permx = nullptr; // perm extended by the identity over halo columns
   int64_t n = 0, ncols = 0;
   int64_t bytes = 0;
@@ -468,12 +469,12 @@ int csr_ensure_gs(amgh_csr* op) {
 }
 
 template <int MODE, class CFG = DefaultCfg>
-int launch_stream(const StreamArgs& a, hipStream_t st) {
+int launch_stream(const StreamArgs& a, hipStream_t st, int ncolv = 1) {
   const int nrows = a.row_end - a.row_begin;
   if (nrows <= 0) return AMGH_OK;
   const int nb = (nrows + CFG::ROWS - 1) / CFG::ROWS;
   const int grid = CFG::XCD ? ((nb + kNumXcd - 1) / kNumXcd) * kNumXcd : nb;
-  hipLaunchKernelGGL((csr_stream_kernel<MODE, CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), 0, st, a);
+  hipLaunchKernelGGL((csr_stream_kernel<MODE, CFG>), dim3((unsigned)grid, (unsigned)ncolv), dim3(CFG::THREADS), 0, st, a);
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
 }
@@ -482,7 +483,7 @@ int launch_stream(const StreamArgs& a, hipStream_t st) {
 // rows are spread over many small workgroups (rows per workgroup chosen at schedule
 // build time from the level's average row length).
 template <int MODE>
-int launch_gs_level(const StreamArgs& a, int rows, hipStream_t st) {
+int launch_gs_level(const StreamArgs& a, int rows, hipStream_t st, int ncolv = 1) {
   // latency-bound launch: prefer many small workgroups over few full ones — a CU's
   // texture-address unit serialises the x gathers of all its waves
   // `avg16` = 16 x the level's mean row length (schedule build time).  Measured on MI355X
@@ -494,86 +495,105 @@ int launch_gs_level(const StreamArgs& a, int rows, hipStream_t st) {
   while (rows > g_gs_min_rows && width / rows < g_gs_block_target && (int64_t)rows * avg16 > 16 * 64) rows >>= 1;
   if (g_gs_threads == 64) {
     switch (rows) {
-      case 8: return launch_stream<MODE, StreamCfg<64, 8, 2048, 1, false, false>>(a, st);
-      case 16: return launch_stream<MODE, StreamCfg<64, 16, 2048, 1, false, false>>(a, st);
-      case 32: return launch_stream<MODE, StreamCfg<64, 32, 2048, 1, false, false>>(a, st);
-      case 64: return launch_stream<MODE, StreamCfg<64, 64, 2048, 1, false, false>>(a, st);
+      case 8: return launch_stream<MODE, StreamCfg<64, 8, 2048, 1, false, false>>(a, st, ncolv);
+      case 16: return launch_stream<MODE, StreamCfg<64, 16, 2048, 1, false, false>>(a, st, ncolv);
+      case 32: return launch_stream<MODE, StreamCfg<64, 32, 2048, 1, false, false>>(a, st, ncolv);
+      case 64: return launch_stream<MODE, StreamCfg<64, 64, 2048, 1, false, false>>(a, st, ncolv);
       default: break;
     }
   }
   switch (rows) {
-    case 4: return launch_stream<MODE, StreamCfg<256, 4, 2048, 1, false, false>>(a, st);
-    case 8: return launch_stream<MODE, StreamCfg<256, 8, 2048, 1, false, false>>(a, st);
-    case 16: return launch_stream<MODE, StreamCfg<256, 16, 2048, 1, false, false>>(a, st);
-    case 32: return launch_stream<MODE, StreamCfg<256, 32, 2048, 1, false, false>>(a, st);
-    case 64: return launch_stream<MODE, StreamCfg<256, 64, 2048, 1, false, false>>(a, st);
-    case 128: return launch_stream<MODE, StreamCfg<256, 128, 2048, 1, false, false>>(a, st);
-    default: return launch_stream<MODE, StreamCfg<256, 256, 2048, 2, false, false>>(a, st);
+    case 4: return launch_stream<MODE, StreamCfg<256, 4, 2048, 1, false, false>>(a, st, ncolv);
+    case 8: return launch_stream<MODE, StreamCfg<256, 8, 2048, 1, false, false>>(a, st, ncolv);
+    case 16: return launch_stream<MODE, StreamCfg<256, 16, 2048, 1, false, false>>(a, st, ncolv);
+    case 32: return launch_stream<MODE, StreamCfg<256, 32, 2048, 1, false, false>>(a, st, ncolv);
+    case 64: return launch_stream<MODE, StreamCfg<256, 64, 2048, 1, false, false>>(a, st, ncolv);
+    case 128: return launch_stream<MODE, StreamCfg<256, 128, 2048, 1, false, false>>(a, st, ncolv);
+    default: return launch_stream<MODE, StreamCfg<256, 256, 2048, 2, false, false>>(a, st, ncolv);
   }
 }
 
-int csr_apply(const amgh_csr* op, int mode, const double* x, const double* b, double* y, hipStream_t st) {
+// ncolv right-hand-side columns (x: ncols apart, y and b: nrows apart) in one launch
+int csr_apply(const amgh_csr* op, int mode, const double* x, const double* b, double* y, hipStream_t st,
+              int ncolv = 1) {
   StreamArgs a{};
   a.rowptr = op->rowptr; a.col = op->col; a.val = op->val;
   a.x = x; a.y = y; a.b = b;
   a.row_begin = 0; a.row_end = (int32_t)op->nrows;
+  a.ldx = op->ncols; a.ldy = op->nrows; a.ldb = op->nrows;
   switch (mode) {
-    case M_SPMV: return launch_stream<M_SPMV>(a, st);
-    case M_RESID: return launch_stream<M_RESID>(a, st);
-    case M_ADD: return launch_stream<M_ADD>(a, st);
+    case M_SPMV: return launch_stream<M_SPMV>(a, st, ncolv);
+    case M_RESID: return launch_stream<M_RESID>(a, st, ncolv);
+    case M_ADD: return launch_stream<M_ADD>(a, st, ncolv);
   }
   return AMGH_EINVAL;
 }
 
-int csr_jacobi(amgh_csr* op, double omega, const double* xin, const double* b, double* xout, hipStream_t st) {
+int csr_jacobi(amgh_csr* op, double omega, const double* xin, const double* b, double* xout, hipStream_t st,
+               int ncolv = 1) {
   RC_TRY(csr_ensure_diag(op, st));
   StreamArgs a{};
   a.rowptr = op->rowptr; a.col = op->col; a.val = op->val;
   a.x = xin; a.y = xout; a.b = b; a.dpos = op->dpos; a.diag = op->diag; a.omega = omega;
   a.row_begin = 0; a.row_end = (int32_t)op->nrows;
-  return launch_stream<M_JACOBI>(a, st);
+  a.ldx = op->ncols; a.ldy = op->nrows; a.ldb = op->nrows;
+  return launch_stream<M_JACOBI>(a, st, ncolv);
 }
 
 template <int T, int PF>
-int launch_chain_t(const ChainArgs& c, bool sor, bool ldsx, int nx, hipStream_t st) {
-  if (sor && ldsx) hipLaunchKernelGGL((gs_chain_kernel<true, true, T, PF>), dim3(1), dim3(T), 0, st, c, nx);
-  else if (sor) hipLaunchKernelGGL((gs_chain_kernel<true, false, T, PF>), dim3(1), dim3(T), 0, st, c, nx);
-  else if (ldsx) hipLaunchKernelGGL((gs_chain_kernel<false, true, T, PF>), dim3(1), dim3(T), 0, st, c, nx);
-  else hipLaunchKernelGGL((gs_chain_kernel<false, false, T, PF>), dim3(1), dim3(T), 0, st, c, nx);
+int launch_chain_t(const ChainArgs& c, bool sor, bool ldsx, int nx, hipStream_t st, int ncolv) {
+  if (sor && ldsx) hipLaunchKernelGGL((gs_chain_kernel<true, true, T, PF>), dim3(ncolv), dim3(T), 0, st, c, nx);
+  else if (sor) hipLaunchKernelGGL((gs_chain_kernel<true, false, T, PF>), dim3(ncolv), dim3(T), 0, st, c, nx);
+  else if (ldsx) hipLaunchKernelGGL((gs_chain_kernel<false, true, T, PF>), dim3(ncolv), dim3(T), 0, st, c, nx);
+  else hipLaunchKernelGGL((gs_chain_kernel<false, false, T, PF>), dim3(ncolv), dim3(T), 0, st, c, nx);
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
 }
 // threads = workgroup size class of the segment (64 / 256 / 1024), see gs_build
-int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, hipStream_t st) {
+int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, hipStream_t st, int ncolv) {
   switch (threads) {
-    case 64: return launch_chain_t<64, 4>(c, sor, ldsx, nx, st);
-    case 256: return launch_chain_t<256, 4>(c, sor, ldsx, nx, st);
-    default: return launch_chain_t<1024, 4>(c, sor, ldsx, nx, st);  // PF = 8 spills at 1024 threads (128 VGPRs)
+    case 64: return launch_chain_t<64, 4>(c, sor, ldsx, nx, st, ncolv);
+    case 256: return launch_chain_t<256, 4>(c, sor, ldsx, nx, st, ncolv);
+    default: return launch_chain_t<1024, 4>(c, sor, ldsx, nx, st, ncolv);  // PF = 8 spills at 1024 threads (128 VGPRs)
   }
 }
 
 // One Gauss-Seidel / SOR sweep, forward or backward, exact lexicographic order.
 // first: gather b and x into dependency-level order (once per smooth! call);
 // last: scatter x back to natural order.  Between the two x lives in g->xp.
+// ncolv > 1: x (ncols apart) and b (nrows apart) hold ncolv independent right-hand-side columns; every launch
+// covers all of them (gridDim.y, or one workgroup per column in the single-workgroup kernels), so a block of
+// right-hand sides costs the dependency-level latency chain once.
 int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st,
-                 bool first = true, bool last = true) {
+                 bool first = true, bool last = true, int ncolv = 1) {
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
   if (g->n <= 0) return AMGH_OK;
+  if (ncolv > g->cols_alloc) {  // grow the level-ordered scratch (first block solve on this operator)
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(g->bp); hipFree(g->xp); g->bp = g->xp = nullptr;
+    RC_TRY(dev_alloc(&g->bp, g->n * ncolv));
+    RC_TRY(dev_alloc(&g->xp, g->ncols * ncolv));
+    g->bytes += 8 * (g->n + g->ncols) * (ncolv - g->cols_alloc);
+    op->bytes += 8 * (g->n + g->ncols) * (ncolv - g->cols_alloc);
+    g->cols_alloc = ncolv;
+  }
   if (g->nblk > 0 && g_gs_block_inverse && !sor) {
     // small densely coupled operator: n/128 sequential block steps in natural row order
     BlockArgs ba{};
     const GsSchedule::Outer& o = backward ? g->blk_b : g->blk_f;
     ba.rowptr = o.rowptr; ba.col = o.col; ba.val = o.val; ba.tinv = o.tinv; ba.diag = g->blk_diag;
     ba.x = x; ba.b = b; ba.n = (int32_t)g->n; ba.nblk = g->nblk; ba.backward = backward ? 1 : 0;
-    hipLaunchKernelGGL(gs_block_kernel, dim3(1), dim3(kBlkThreads), 0, st, ba);
+    ba.ld = g->n;  // block path: square operator, x and b in natural order
+    hipLaunchKernelGGL(gs_block_kernel, dim3(ncolv), dim3(kBlkThreads), 0, st, ba);
     HIP_TRY(hipGetLastError());
     return AMGH_OK;
   }
   if (first) {
-    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n)), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n);
-    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols)), dim3(256), 0, st, (const double*)x, g->permx,
-                       g->xp, (int)g->ncols);
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n,
+                       (int64_t)g->n, (int64_t)g->n);
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const double*)x, g->permx,
+                       g->xp, (int)g->ncols, (int64_t)g->ncols, (int64_t)g->ncols);
     HIP_TRY(hipGetLastError());
   }
   double* xp = g->xp;
@@ -586,28 +606,31 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       c.rowmeta = g->rowmeta; c.desc = g->desc; c.omega = omega; c.tim = g_chain_tim;
       if (!backward) { c.lvl_begin = s.l0; c.lvl_end = s.l1; c.step = 1; }
       else { c.lvl_begin = s.l1 - 1; c.lvl_end = s.l0 - 1; c.step = -1; }
+      c.ldx = g->ncols; c.ldb = g->n;
       const bool ldsx = g->ncols <= kChainLdsX;  // x (halo included) fits LDS
-      RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)g->ncols, st));
+      RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)g->ncols, st, ncolv));
     } else if (s.nslots > 0 && g_gs_slots) {
       SlotArgs sa{};
       sa.wcol = g->wcol; sa.wval = g->wval; sa.slot_row = g->slot_row; sa.wmeta = g->wmeta;
       sa.diag = g->diag; sa.bp = g->bp; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;
       sa.nslots = s.nslots; sa.xcd_map = g_gs_xcd_map;
+      sa.ldx = g->ncols; sa.ldb = g->n;
       const int grid = g_gs_xcd_map ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots;
-      if (sor) hipLaunchKernelGGL(gs_slot_kernel<true>, dim3(grid), dim3(kSlot), 0, st, sa);
-      else hipLaunchKernelGGL(gs_slot_kernel<false>, dim3(grid), dim3(kSlot), 0, st, sa);
+      if (sor) hipLaunchKernelGGL(gs_slot_kernel<true>, dim3(grid, ncolv), dim3(kSlot), 0, st, sa);
+      else hipLaunchKernelGGL(gs_slot_kernel<false>, dim3(grid, ncolv), dim3(kSlot), 0, st, sa);
       HIP_TRY(hipGetLastError());
     } else {
       StreamArgs a{};
       a.rowptr = g->rowptr; a.col = g->col; a.val = g->val;
       a.x = xp; a.y = xp; a.b = g->bp; a.dpos = g->dpos; a.diag = g->diag; a.perm = nullptr; a.omega = omega;
       a.row_begin = g->lvl_ptr[s.l0]; a.row_end = g->lvl_ptr[s.l0 + 1];
-      RC_TRY(sor ? launch_gs_level<M_SOR>(a, s.rows, st) : launch_gs_level<M_GS>(a, s.rows, st));
+      a.ldx = g->ncols; a.ldy = g->ncols; a.ldb = g->n;
+      RC_TRY(sor ? launch_gs_level<M_SOR>(a, s.rows, st, ncolv) : launch_gs_level<M_GS>(a, s.rows, st, ncolv));
     }
   }
   if (last) {
-    hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(g->n)), dim3(256), 0, st, (const double*)xp, g->perm, x,
-                       (int)g->n);
+    hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const double*)xp, g->perm, x,
+                       (int)g->n, (int64_t)g->ncols, (int64_t)g->n);
     HIP_TRY(hipGetLastError());
   }
   return AMGH_OK;
@@ -738,13 +761,13 @@ int coarse_solve(amgh_t* h, double* x, const double* b) {
 
 // smooth!(x, smoother, b).  `xc` is the buffer that currently holds x; Jacobi
 // sweeps ping-pong between xc and xo (swapped in place).
-int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& xo, const double* b) {
+int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& xo, const double* b, int ncolv = 1) {
   amgh_csr* M = L->smat();
   for (int it = 0; it < s.iter; ++it) {
     switch (s.kind) {
       case AMGH_SMOOTH_NONE: break;
       case AMGH_SMOOTH_JACOBI:
-        RC_TRY(csr_jacobi(M, s.omega, xc, b, xo, h->stream));
+        RC_TRY(csr_jacobi(M, s.omega, xc, b, xo, h->stream, ncolv));
         std::swap(xc, xo);
         break;
       case AMGH_SMOOTH_GS:
@@ -755,9 +778,9 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& 
         const bool sym = s.sweep == AMGH_SWEEP_SYMMETRIC;
         const bool first_it = (it == 0), last_it = (it == s.iter - 1);
         if (s.sweep == AMGH_SWEEP_FORWARD || sym)
-          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it && !sym));
+          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it && !sym, ncolv));
         if (s.sweep == AMGH_SWEEP_BACKWARD || sym)
-          RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream, first_it && !sym, last_it));
+          RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream, first_it && !sym, last_it, ncolv));
         break;
       }
       default: return AMGH_EINVAL;
@@ -782,18 +805,10 @@ int cycle_next(amgh_t* h, int l, double* x, const double* b, int cyc) {
   return AMGH_EINVAL;
 }
 
-// smooth! on one column of an n x bs block (multi-RHS: the reference loops the columns inside
-// every smoother, smoother.jl:77,117): Jacobi goes through the level's temp vector and is copied back.
-int smooth_column(amgh_t* h, Level* L, const amgh_smoother_t& s, double* xcol, const double* bcol) {
-  double* xc = xcol;
-  double* xo = L->tmp;
-  RC_TRY(smooth(h, L, s, xc, xo, bcol));
-  if (xc != xcol) RC_TRY(vec_copy(h, xcol, xc, L->n));
-  return AMGH_OK;
-}
-
 // __solve! (multilevel.jl:214-239).  x, b: n x bs column-major (bs = workspace block size,
-// multilevel.jl:28-59); every operator is applied column by column.
+// multilevel.jl:28-59).  The reference loops the columns inside every operator (smoother.jl:77,117); here
+// each launch covers all bs columns (one grid row / one workgroup per column): per column the arithmetic and
+// its order are those of the single-column path, so the results are bitwise the same.
 int cycle(amgh_t* h, int l, double* x, const double* b, int cyc) {
   Level* L = h->levels[l];
   const int bs = h->nrhs;
@@ -802,16 +817,15 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc) {
   double* xo = L->tmp;
   {
     ProfScope p(h, AMGH_T_PRESMOOTH, l);
-    if (bs == 1) RC_TRY(smooth(h, L, L->pre, xc, xo, b));
-    else for (int c = 0; c < bs; ++c) RC_TRY(smooth_column(h, L, L->pre, x + c * n, b + c * n));
+    RC_TRY(smooth(h, L, L->pre, xc, xo, b, bs));
   }
   {
     ProfScope p(h, AMGH_T_RESIDUAL, l);
-    for (int c = 0; c < bs; ++c) RC_TRY(csr_apply(&L->A, M_RESID, xc + c * n, b + c * n, L->res + c * n, h->stream));
+    RC_TRY(csr_apply(&L->A, M_RESID, xc, b, L->res, h->stream, bs));
   }
   {
     ProfScope p(h, AMGH_T_RESTRICT, l);
-    for (int c = 0; c < bs; ++c) RC_TRY(csr_apply(&L->R, M_SPMV, L->res + c * n, nullptr, L->cb + c * nc, h->stream));
+    RC_TRY(csr_apply(&L->R, M_SPMV, L->res, nullptr, L->cb, h->stream, bs));
   }
   RC_TRY(vec_fill(h, L->cx, nc * bs, 0.0));
   if (l == (int)h->levels.size() - 1) {
@@ -822,14 +836,13 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc) {
   }
   {
     ProfScope p(h, AMGH_T_PROLONG, l);
-    for (int c = 0; c < bs; ++c) RC_TRY(csr_apply(&L->P, M_ADD, L->cx + c * nc, nullptr, xc + c * n, h->stream));
+    RC_TRY(csr_apply(&L->P, M_ADD, L->cx, nullptr, xc, h->stream, bs));
   }
   {
     ProfScope p(h, AMGH_T_POSTSMOOTH, l);
-    if (bs == 1) RC_TRY(smooth(h, L, L->post, xc, xo, b));
-    else for (int c = 0; c < bs; ++c) RC_TRY(smooth_column(h, L, L->post, x + c * n, b + c * n));
+    RC_TRY(smooth(h, L, L->post, xc, xo, b, bs));
   }
-  if (xc != x) RC_TRY(vec_copy(h, x, xc, n));
+  if (xc != x) RC_TRY(vec_copy(h, x, xc, n * bs));
   return AMGH_OK;
 }
 
@@ -888,8 +901,7 @@ int apply_cycle(amgh_t* h, double* x, const double* b, int cyc) {
 int fine_residual(amgh_t* h, const double* x, const double* b, double* r) {
   if (h->levels.empty() && !h->has_finalA) return AMGH_ESTATE;
   const amgh_csr* A = h->levels.empty() ? &h->finalA : &h->levels[0]->A;
-  const int64_t n = A->nrows;
-  for (int c = 0; c < h->nrhs; ++c) RC_TRY(csr_apply(A, M_RESID, x + c * n, b + c * n, r + c * n, h->stream));
+  RC_TRY(csr_apply(A, M_RESID, x, b, r, h->stream, h->nrhs));
   return AMGH_OK;
 }
 int fine_spmv(amgh_t* h, const double* x, double* y) {
@@ -1151,8 +1163,8 @@ int amgh_finalize(amgh_t* h) {
     RC_TRY(dev_alloc(&L->cb, L->nc * h->nrhs));
     ws += 8 * (L->n + 2 * L->nc) * h->nrhs;
     if (L->pre.kind == AMGH_SMOOTH_JACOBI || L->post.kind == AMGH_SMOOTH_JACOBI) {
-      RC_TRY(dev_alloc(&L->tmp, L->n));
-      ws += 8 * L->n;
+      RC_TRY(dev_alloc(&L->tmp, L->n * h->nrhs));
+      ws += 8 * L->n * h->nrhs;
       RC_TRY(csr_ensure_diag(L->smat(), h->stream));
     }
   }
@@ -1420,7 +1432,7 @@ int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const double* src
   if (n == 0) return AMGH_OK;
   HIP_TRY(hipSetDevice(device));
   hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src_d, idx_d, dst_d,
-                     (int)n);
+                     (int)n, (int64_t)0, (int64_t)0);
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
 }

@@ -44,6 +44,9 @@ struct StreamArgs {
   double omega;
   int32_t row_begin;   // rows [row_begin, row_end) of the matrix are processed
   int32_t row_end;
+  // multi-RHS (n x bs blocks, multilevel.jl:28-59): gridDim.y = bs, column blockIdx.y of x / y / b starts
+  // at these element strides (unused when gridDim.y == 1)
+  int64_t ldx, ldy, ldb;
 };
 
 // LDS index skew: breaks the power-of-two strides of rows with 8/16/32 entries
@@ -124,6 +127,11 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
   // sum; many rows per workgroup (SpMV): skewed indices keep the row-strided reads conflict-free
   constexpr bool SK = CFG::ROWS > 64;
   __shared__ double s_prod[LDSN + (LDSN >> 5) + 2];
+  if (gridDim.y > 1) {  // one right-hand-side column per blockIdx.y
+    a.x += blockIdx.y * a.ldx;
+    a.y += blockIdx.y * a.ldy;
+    if (a.b) a.b += blockIdx.y * a.ldb;
+  }
 
   const int nrows = a.row_end - a.row_begin;
   const int nb = (nrows + CFG::ROWS - 1) / CFG::ROWS;
@@ -296,12 +304,16 @@ __device__ __forceinline__ double seq_sum_skip(const double* s, int lo, int hi, 
 // smoother application, so that every level kernel reads it coalesced with no
 // perm -> b dependent hop.
 __global__ void gather_perm_kernel(const double* __restrict__ b, const int32_t* __restrict__ perm,
-                                   double* __restrict__ bp, int n) {
+                                   double* __restrict__ bp, int n, int64_t ld_src, int64_t ld_dst) {
+  b += blockIdx.y * ld_src;  // blockIdx.y = right-hand-side column
+  bp += blockIdx.y * ld_dst;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) bp[r] = b[perm[r]];
 }
 // x[perm[r]] = xp[r]: back from dependency-level order to natural order
 __global__ void scatter_perm_kernel(const double* __restrict__ xp, const int32_t* __restrict__ perm,
-                                    double* __restrict__ x, int n) {
+                                    double* __restrict__ x, int n, int64_t ld_src, int64_t ld_dst) {
+  xp += blockIdx.y * ld_src;
+  x += blockIdx.y * ld_dst;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) x[perm[r]] = xp[r];
 }
 
@@ -324,6 +336,7 @@ struct ChainArgs {
   int32_t lvl_end;
   int32_t step;            // +1 forward, -1 backward (then lvl_begin > lvl_end)
   unsigned long long* tim; // diagnostics (amgh_debug_chain_timing): per-phase shader-cycle sums, or nullptr
+  int64_t ldx, ldb;        // multi-RHS: workgroup blockIdx.x runs the chain for column blockIdx.x of x / bp
 };
 
 constexpr int kChainThreads = 1024;  // = max rows of a chained dependency level: one row per thread
@@ -380,6 +393,11 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
   __shared__ double s_prod[kChainLds];  // un-skewed: few rows per level, bank conflicts are not the issue here
   __shared__ double s_x[LDSX ? kChainLdsX : 1];
   const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {  // independent right-hand-side columns, one workgroup each
+    a.x += blockIdx.x * a.ldx;
+    a.bp += blockIdx.x * a.ldb;
+    a.tim = nullptr;
+  }
   int lv = a.lvl_begin;
   if (lv == a.lvl_end) return;
   i4_t ds = a.desc[lv];
@@ -483,12 +501,17 @@ struct SlotArgs {
   int32_t slot0;            // first slot of this dependency level
   int32_t nslots;           // slots of this dependency level
   int32_t xcd_map;          // 1: XCD-contiguous slot mapping (grid padded to a multiple of 8)
+  int64_t ldx, ldb;         // multi-RHS: column blockIdx.y of x / bp
 };
 
 template <bool SOR>
 __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
   __shared__ double s_prod[kSlot];
   const int tid = threadIdx.x;
+  if (gridDim.y > 1) {
+    a.x += blockIdx.y * a.ldx;
+    a.bp += blockIdx.y * a.ldb;
+  }
   int lb = blockIdx.x;
   if (a.xcd_map) {
     lb = xcd_block(blockIdx.x, a.nslots);
@@ -539,6 +562,7 @@ struct BlockArgs {
   int32_t n;
   int32_t nblk;
   int32_t backward;
+  int64_t ld;  // multi-RHS: workgroup blockIdx.x sweeps column blockIdx.x of x / b
 };
 
 // this thread's 16 entries of the block inverse (row drow, columns part*16..+15); the half of the
@@ -559,6 +583,8 @@ __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
   __shared__ double s_prod[kBlkLds];
   __shared__ double s_vec[kBlk];
   const int tid = threadIdx.x;
+  a.x += blockIdx.x * a.ld;
+  a.b += blockIdx.x * a.ld;
   const int drow = tid >> 3, part = tid & 7;  // dense phase: 8 lanes share a row, 16 columns each
   double tv[16];
   blk_load_tinv(a, a.backward ? a.nblk - 1 : 0, drow, part, tv);

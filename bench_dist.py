@@ -41,7 +41,9 @@ def main_distributed(args):
     if rank == 0:
         g.build(only_missing=True)
     dist.barrier()
-    AMG.setup_lib().amgs_set_threads(max(1, (os.cpu_count() or 8) // world))
+    # the library's default is min(cores, cgroup CPU quota, 64): split that between the ranks of this node
+    L = AMG.setup_lib()
+    L.amgs_set_threads(max(1, L.amgs_set_threads(0) // int(os.environ.get("LOCAL_WORLD_SIZE", world))))
 
     N = args.size
     t0 = time.perf_counter()

@@ -368,6 +368,31 @@ def test_multiple_right_hand_sides_block_workspace():
             assert rel(Z[:, c], oh.precond(B[:, c])) <= TOL
 
 
+def test_multiple_right_hand_sides_all_sweep_kernels():
+    """bs = 4 on a hierarchy whose levels go through every Gauss-Seidel execution path (slot kernel on the wide
+    dependency levels, single-workgroup chains, block-inverse sweeps) and through SOR / Jacobi: one launch
+    covers all columns, each column must still equal the single-RHS oracle run."""
+    A = AMG.poisson((40, 40, 40))
+    n = A.m
+    B = np.stack([uniform(n, 51), A @ np.ones(n), uniform(n, 53) - 0.5, np.cos(np.arange(n))], axis=1)
+    cases = [
+        (dict(), "V"),
+        (dict(presmoother=AMG.SOR(1.2, iter=2), postsmoother=AMG.SOR(0.8, sweep=AMG.BackwardSweep())), "W"),
+        (dict(presmoother=AMG.Jacobi(2 / 3, iter=2), postsmoother=AMG.GaussSeidel(AMG.ForwardSweep())), "F"),
+    ]
+    for kw, cyc in cases:
+        ml = AMG.ruge_stuben(A, **kw)
+        oh = O.OracleHierarchy(ml)
+        cycle = {"V": AMG.V(), "W": AMG.W(), "F": AMG.F()}[cyc]
+        X = AMG._solve(ml, B, cycle, maxiter=3, calculate_residual=False)
+        for c in range(B.shape[1]):
+            xo, _, _ = oh.solve(B[:, c], cycle=cycle.code, maxiter=3, calculate_residual=False)
+            assert rel(X[:, c], xo) <= TOL, (kw, cyc, c)
+        # the same hierarchy still serves single-RHS calls (its scratch was grown, not replaced by a smaller one)
+        x1 = AMG._solve(ml, B[:, 2].copy(), cycle, maxiter=3, calculate_residual=False)
+        assert rel(x1, X[:, 2]) <= 1e-14
+
+
 def test_eltype_promotion_contract():  # runtests.jl:244-259
     a = AMG.poisson(100).to_scipy()
     b = uniform(100, 1)
