@@ -119,6 +119,7 @@ int g_gs_block_target = 256;   // aim for at least this many workgroups per wide
 int g_gs_min_rows = 4;         // but never fewer rows per workgroup than this
 int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (one per thread)
 int g_gs_threads = 256;
+int g_gs_slot_ept = 1;          // slot entries per thread in gs_slot_kernel (1 or 2)
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)
@@ -616,8 +617,13 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       sa.nslots = s.nslots; sa.xcd_map = g_gs_xcd_map;
       sa.ldx = g->ncols; sa.ldb = g->n;
       const int grid = g_gs_xcd_map ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots;
-      if (sor) hipLaunchKernelGGL(gs_slot_kernel<true>, dim3(grid, ncolv), dim3(kSlot), 0, st, sa);
-      else hipLaunchKernelGGL(gs_slot_kernel<false>, dim3(grid, ncolv), dim3(kSlot), 0, st, sa);
+      if (g_gs_slot_ept == 2) {
+        if (sor) hipLaunchKernelGGL((gs_slot_kernel<true, 2>), dim3(grid, ncolv), dim3(kSlot / 2), 0, st, sa);
+        else hipLaunchKernelGGL((gs_slot_kernel<false, 2>), dim3(grid, ncolv), dim3(kSlot / 2), 0, st, sa);
+      } else {
+        if (sor) hipLaunchKernelGGL((gs_slot_kernel<true, 1>), dim3(grid, ncolv), dim3(kSlot), 0, st, sa);
+        else hipLaunchKernelGGL((gs_slot_kernel<false, 1>), dim3(grid, ncolv), dim3(kSlot), 0, st, sa);
+      }
       HIP_TRY(hipGetLastError());
     } else {
       StreamArgs a{};
@@ -1558,6 +1564,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_block_inverse")) g_gs_block_inverse = value;
   else if (!strcmp(name, "gs_slots")) g_gs_slots = value;
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
+  else if (!strcmp(name, "gs_slot_ept")) g_gs_slot_ept = value;
   else return AMGH_EINVAL;
   return AMGH_OK;
 }

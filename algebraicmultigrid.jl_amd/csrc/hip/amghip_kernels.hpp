@@ -504,8 +504,11 @@ struct SlotArgs {
   int64_t ldx, ldb;         // multi-RHS: column blockIdx.y of x / bp
 };
 
-template <bool SOR>
-__global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
+// EPT = slot entries per thread (workgroup = kSlot / EPT threads): 1 -> one 8-B + one 4-B load per thread,
+// 2 -> one 16-B + one 8-B load per thread and half the waves.
+template <bool SOR, int EPT>
+__global__ __launch_bounds__(kSlot / EPT) void gs_slot_kernel(SlotArgs a) {
+  constexpr int T = kSlot / EPT;
   __shared__ double s_prod[kSlot];
   const int tid = threadIdx.x;
   if (gridDim.y > 1) {
@@ -519,9 +522,21 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
   }
   const int s = a.slot0 + lb;
   const int base = s * kSlot;
-  const double v = a.wval[base + tid];
-  const int c = a.wcol[base + tid];
+  double v[EPT];
+  int c[EPT];
+  if (EPT == 1) {
+    v[0] = a.wval[base + tid];
+    c[0] = a.wcol[base + tid];
+  } else {
+    const d2_t vv = *(const d2_t*)(a.wval + base + 2 * tid);
+    const i2_t cc = *(const i2_t*)(a.wcol + base + 2 * tid);
+    v[0] = vv.x; v[EPT - 1] = vv.y; c[0] = cc.x; c[EPT - 1] = cc.y;
+  }
   const int r0 = a.slot_row[2 * s], r1 = a.slot_row[2 * s + 1];
+  double xv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) xv[e] = a.x[c[e]];
+  // rows of the slot: at most kSlot (one entry each), usually far fewer than T
   i4_t m = i4_t{0, 0, -1, 0};
   double d = 0.0, bb = 0.0;
   if (tid < r1 - r0) {
@@ -529,12 +544,23 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
     d = a.diag[r0 + tid];
     bb = a.bp[r0 + tid];
   }
-  s_prod[tid] = v * a.x[c];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) s_prod[EPT * tid + e] = v[e] * xv[e];
   __syncthreads();
   if (tid < r1 - r0 && d != 0.0) {
     const double acc = seq_sum_skip(s_prod, m.x - base, m.y - base, m.z - base, 0.0);
     const int i = r0 + tid;
     a.x[i] = SOR ? (1.0 - a.omega) * a.x[i] + (a.omega / d) * (bb - acc) : (bb - acc) / d;
+  }
+  if (EPT > 1) {  // slots of very short rows: more rows than threads
+    for (int r = r0 + tid + T; r < r1; r += T) {
+      const i4_t m2 = a.wmeta[r];
+      const double d2 = a.diag[r];
+      if (d2 != 0.0) {
+        const double acc = seq_sum_skip(s_prod, m2.x - base, m2.y - base, m2.z - base, 0.0);
+        a.x[r] = SOR ? (1.0 - a.omega) * a.x[r] + (a.omega / d2) * (a.bp[r] - acc) : (a.bp[r] - acc) / d2;
+      }
+    }
   }
 }
 
