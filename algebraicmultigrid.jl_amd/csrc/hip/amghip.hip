@@ -82,14 +82,27 @@ struct GsSchedule {
   // slot layout of the wide levels (gs_slot_kernel)
   int32_t* wcol = nullptr; double* wval = nullptr; int32_t* slot_row = nullptr; i4_t* wmeta = nullptr;
   // block-inverse path (small, densely coupled operators; see gs_block_kernel)
-  struct Outer { int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; double* tinv = nullptr; };
+  struct Outer {
+    int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; double* tinv = nullptr;
+    int32_t* near_ptr = nullptr; i2_t* near_pi = nullptr; double* near_val = nullptr;  // see gs_block_pipe_kernel
+    // entries that reference blocks swept LATER (and the in-block other triangle): they read old x only, so
+    // b - O_next x is one full-chip residual launch before the sequential sweep
+    int32_t* nx_rowptr = nullptr; int32_t* nx_col = nullptr; double* nx_val = nullptr;
+  };
   Outer blk_f, blk_b;
   double* blk_diag = nullptr;
+  double* blk_s = nullptr;  // b - O_next x (n entries per right-hand-side column)
   int nblk = 0;  // 0 = block path not used for this operator
   double blk_cond = 0.0;  // largest inf-norm condition estimate of an in-block triangle
   void free_dev() {
-    for (Outer* o : {&blk_f, &blk_b}) { hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv); *o = Outer(); }
+    for (Outer* o : {&blk_f, &blk_b}) {
+      hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv);
+      hipFree(o->near_ptr); hipFree(o->near_pi); hipFree(o->near_val);
+      hipFree(o->nx_rowptr); hipFree(o->nx_col); hipFree(o->nx_val);
+      *o = Outer();
+    }
     hipFree(blk_diag); blk_diag = nullptr;
+    hipFree(blk_s); blk_s = nullptr;
     hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
     hipFree(perm); hipFree(dpos); hipFree(diag); hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
@@ -120,6 +133,7 @@ int g_gs_min_rows = 4;         // but never fewer rows per workgroup than this
 int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (one per thread)
 int g_gs_threads = 256;
 int g_gs_slot_ept = 1;          // slot entries per thread in gs_slot_kernel (1 or 2)
+int g_gs_block_pipe = 1;        // software-pipelined block sweep (gs_block_pipe_kernel)
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)
@@ -190,12 +204,20 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int3
                       const double* val, const std::vector<double>& diag, double* max_cond) {
   const int B = kBlk;
   const int nblk = (int)((n + B - 1) / B);
-  std::vector<int32_t> orow(n + 1, 0), ocol;
-  std::vector<double> oval;
+  std::vector<int32_t> orow(n + 1, 0), ocol, xrow(n + 1, 0), xcol;
+  std::vector<double> oval, xval;
   ocol.reserve(rowptr[n]); oval.reserve(rowptr[n]);
+  xcol.reserve(rowptr[n]); xval.reserve(rowptr[n]);
   std::vector<double> tinv((size_t)nblk * B * B, 0.0), T((size_t)B * B);
+  // near list: outer entries of a block that reference the block swept just before it (blk - 1 forward, blk + 1
+  // backward), as {position in the block's outer range, column - first row of that block} + value
+  std::vector<int32_t> near_ptr(nblk + 1, 0);
+  std::vector<i2_t> near_pi;
+  std::vector<double> near_val;
   for (int blk = 0; blk < nblk; ++blk) {
     const int64_t i0 = (int64_t)blk * B, i1 = std::min<int64_t>(i0 + B, n);
+    const int64_t q0 = backward ? i0 + B : i0 - B;  // first row of the previously swept block
+    const size_t blk_first = ocol.size();
     std::fill(T.begin(), T.end(), 0.0);
     for (int64_t i = i0; i < i1; ++i) {
       const bool skip = diag[i] == 0.0;  // row without a usable diagonal keeps its x: T row = e_i
@@ -204,13 +226,21 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int3
         const bool in_tri = c >= i0 && c < i1 && (backward ? c >= i : c <= i);
         if (in_tri) {
           if (!skip) T[(size_t)(i - i0) * B + (c - i0)] += val[j];
+        } else if (!skip && (c >= i0 && c < i1 ? true : (backward ? c < i0 : c >= i1))) {
+          xcol.push_back(c); xval.push_back(val[j]);  // old x: in-block other triangle, or a block swept later
         } else if (!skip) {
+          if (c >= q0 && c < q0 + B) {
+            near_pi.push_back(i2_t{(int32_t)(ocol.size() - blk_first), (int32_t)(c - q0)});
+            near_val.push_back(val[j]);
+          }
           ocol.push_back(c); oval.push_back(val[j]);
         }
       }
       if (skip) T[(size_t)(i - i0) * B + (i - i0)] = 1.0;
       orow[i + 1] = (int32_t)ocol.size();
+      xrow[i + 1] = (int32_t)xcol.size();
     }
+    near_ptr[blk + 1] = (int32_t)near_pi.size();
     for (int64_t i = i1; i < i0 + B; ++i) T[(size_t)(i - i0) * B + (i - i0)] = 1.0;  // padding rows
     // invert the triangle column by column (forward / backward substitution on the identity)
     double* X = tinv.data() + (size_t)blk * B * B;
@@ -244,6 +274,12 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int3
   RC_TRY(dev_upload(&o->col, ocol.data(), (int64_t)ocol.size()));
   RC_TRY(dev_upload(&o->val, oval.data(), (int64_t)oval.size()));
   RC_TRY(dev_upload(&o->tinv, tinv.data(), (int64_t)tinv.size()));
+  RC_TRY(dev_upload(&o->near_ptr, near_ptr.data(), (int64_t)near_ptr.size()));
+  RC_TRY(dev_upload(&o->near_pi, near_pi.data(), (int64_t)near_pi.size()));
+  RC_TRY(dev_upload(&o->near_val, near_val.data(), (int64_t)near_val.size()));
+  RC_TRY(dev_upload(&o->nx_rowptr, xrow.data(), n + 1));
+  RC_TRY(dev_upload(&o->nx_col, xcol.data(), (int64_t)xcol.size()));
+  RC_TRY(dev_upload(&o->nx_val, xval.data(), (int64_t)xval.size()));
   return AMGH_OK;
 }
 
@@ -338,6 +374,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       RC_TRY(blockgs_build_dir(&g->blk_f, false, n, rowptr, col, val, dg, &max_cond));
       RC_TRY(blockgs_build_dir(&g->blk_b, true, n, rowptr, col, val, dg, &max_cond));
       RC_TRY(dev_upload(&g->blk_diag, dg.data(), n));
+      RC_TRY(dev_alloc(&g->blk_s, n));
       g->blk_cond = max_cond;
       if (getenv("AMGH_VERBOSE"))
         fprintf(stderr, "[amghip] n=%lld dependency levels=%d index blocks=%d max triangle cond=%.3g -> %s\n", (long long)n,
@@ -570,13 +607,19 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
   if (g->n <= 0) return AMGH_OK;
-  if (ncolv > g->cols_alloc) {  // grow the level-ordered scratch (first block solve on this operator)
+  if (ncolv > g->cols_alloc) {  // grow the per-column scratch (first block solve on this operator)
     HIP_TRY(hipStreamSynchronize(st));
     hipFree(g->bp); hipFree(g->xp); g->bp = g->xp = nullptr;
     RC_TRY(dev_alloc(&g->bp, g->n * ncolv));
     RC_TRY(dev_alloc(&g->xp, g->ncols * ncolv));
-    g->bytes += 8 * (g->n + g->ncols) * (ncolv - g->cols_alloc);
-    op->bytes += 8 * (g->n + g->ncols) * (ncolv - g->cols_alloc);
+    int64_t grown = 8 * (g->n + g->ncols) * (ncolv - g->cols_alloc);
+    if (g->blk_s) {
+      hipFree(g->blk_s); g->blk_s = nullptr;
+      RC_TRY(dev_alloc(&g->blk_s, g->n * ncolv));
+      grown += 8 * g->n * (ncolv - g->cols_alloc);
+    }
+    g->bytes += grown;
+    op->bytes += grown;
     g->cols_alloc = ncolv;
   }
   if (g->nblk > 0 && g_gs_block_inverse && !sor) {
@@ -584,9 +627,21 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     BlockArgs ba{};
     const GsSchedule::Outer& o = backward ? g->blk_b : g->blk_f;
     ba.rowptr = o.rowptr; ba.col = o.col; ba.val = o.val; ba.tinv = o.tinv; ba.diag = g->blk_diag;
-    ba.x = x; ba.b = b; ba.n = (int32_t)g->n; ba.nblk = g->nblk; ba.backward = backward ? 1 : 0;
+    {  // s = b - O_next x: every entry read here keeps its old value during this sweep
+      StreamArgs ra{};
+      ra.rowptr = o.nx_rowptr; ra.col = o.nx_col; ra.val = o.nx_val;
+      ra.x = x; ra.b = b; ra.y = g->blk_s;
+      ra.row_begin = 0; ra.row_end = (int32_t)g->n;
+      ra.ldx = g->n; ra.ldy = g->n; ra.ldb = g->n;
+      // few, long rows: 64 rows per workgroup so that the launch still covers the chip
+      RC_TRY((launch_stream<M_RESID, StreamCfg<256, 64, 4096, 2, false, false>>(ra, st, ncolv)));
+    }
+    ba.x = x; ba.b = g->blk_s; ba.n = (int32_t)g->n; ba.nblk = g->nblk; ba.backward = backward ? 1 : 0;
     ba.ld = g->n;  // block path: square operator, x and b in natural order
-    hipLaunchKernelGGL(gs_block_kernel, dim3(ncolv), dim3(kBlkThreads), 0, st, ba);
+    ba.tim = g_chain_tim;
+    ba.near_ptr = o.near_ptr; ba.near_pi = o.near_pi; ba.near_val = o.near_val;
+    if (g_gs_block_pipe) hipLaunchKernelGGL(gs_block_pipe_kernel, dim3(ncolv), dim3(kPipeThreads), 0, st, ba);
+    else hipLaunchKernelGGL(gs_block_kernel, dim3(ncolv), dim3(kBlkThreads), 0, st, ba);
     HIP_TRY(hipGetLastError());
     return AMGH_OK;
   }
@@ -1564,6 +1619,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_block_inverse")) g_gs_block_inverse = value;
   else if (!strcmp(name, "gs_slots")) g_gs_slots = value;
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
+  else if (!strcmp(name, "gs_block_pipe")) g_gs_block_pipe = value;
   else if (!strcmp(name, "gs_slot_ept")) g_gs_slot_ept = value;
   else return AMGH_EINVAL;
   return AMGH_OK;

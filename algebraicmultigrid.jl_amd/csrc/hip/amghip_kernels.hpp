@@ -589,6 +589,11 @@ struct BlockArgs {
   int32_t nblk;
   int32_t backward;
   int64_t ld;  // multi-RHS: workgroup blockIdx.x sweeps column blockIdx.x of x / b
+  // "near" entries: outer entries of block k that reference the block swept just before it (gs_block_pipe_kernel)
+  const int32_t* near_ptr;  // nblk + 1
+  const i2_t* near_pi;      // {position inside the block's outer range, column - first row of the previous block}
+  const double* near_val;
+  unsigned long long* tim;  // diagnostics (amgh_debug_chain_timing): per-phase shader-cycle sums, or nullptr
 };
 
 // this thread's 16 entries of the block inverse (row drow, columns part*16..+15); the half of the
@@ -614,17 +619,22 @@ __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
   const int drow = tid >> 3, part = tid & 7;  // dense phase: 8 lanes share a row, 16 columns each
   double tv[16];
   blk_load_tinv(a, a.backward ? a.nblk - 1 : 0, drow, part, tv);
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int step = 0; step < a.nblk; ++step) {
+    const unsigned long long t0 = a.tim ? clock64() : 0;
+    unsigned long long t1 = 0, t2 = 0, t3 = 0, t1a = 0, t1b = 0;
     const int blk = a.backward ? a.nblk - 1 - step : step;
     const int i0 = blk * kBlk;
     const int rows = min(kBlk, a.n - i0);
     // phase 1: s_i = b_i - (outer row i) . x      (all x entries referenced are final or old)
     const int p0 = a.rowptr[i0], p1 = a.rowptr[i0 + rows];
+    // row drow is summed by its 8 lanes, entries interleaved (lane p: p, p+8, ...): conflict-free LDS reads.
+    // (One thread per row walking its own segment put 64 lanes on ~16 banks: 12 k of the 28 k cycles per step.)
     int rs = 0, re = 0;
     double d = 0.0, bb = 0.0, xo = 0.0, acc = 0.0;
-    if (tid < rows) {
-      rs = a.rowptr[i0 + tid]; re = a.rowptr[i0 + tid + 1];
-      d = a.diag[i0 + tid]; bb = a.b[i0 + tid]; xo = a.x[i0 + tid];
+    if (drow < rows) {
+      rs = a.rowptr[i0 + drow]; re = a.rowptr[i0 + drow + 1];
+      if (part == 0) { d = a.diag[i0 + drow]; bb = a.b[i0 + drow]; xo = a.x[i0 + drow]; }
     }
     for (int c0 = p0; c0 < p1; c0 += kBlkLds) {
       const int c1 = min(c0 + kBlkLds, p1);
@@ -642,11 +652,18 @@ __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
       }
       for (; k < c1; k += kBlkThreads) s_prod[k - c0] = a.val[k] * a.x[a.col[k]];
       __syncthreads();
-      if (tid < rows) acc = seq_sum_range(s_prod, max(rs, c0) - c0, min(re, c1) - c0, acc);
+      if (a.tim && c0 == p0) t1 = clock64();
+      for (int q = max(rs, c0) - c0 + part, qe = min(re, c1) - c0; q < qe; q += 8) acc += s_prod[q];
       if (c1 < p1) __syncthreads();
     }
-    if (tid < kBlk) s_vec[tid] = (tid < rows) ? ((d == 0.0) ? xo : bb - acc) : 0.0;
+    if (a.tim) t1a = clock64();
+    acc += __shfl_xor(acc, 1, kWave);
+    acc += __shfl_xor(acc, 2, kWave);
+    acc += __shfl_xor(acc, 4, kWave);
+    if (a.tim) t1b = clock64();
+    if (part == 0) s_vec[drow] = (drow < rows) ? ((d == 0.0) ? xo : bb - acc) : 0.0;
     __syncthreads();
+    if (a.tim) t2 = clock64();
     // phase 2: x_I = Tinv_II . s
     double sum = 0.0;
 #pragma unroll
@@ -656,9 +673,205 @@ __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
     sum += __shfl_xor(sum, 4, kWave);
     // the next block's inverse streams in while this step finishes and the next one starts
     if (step + 1 < a.nblk) blk_load_tinv(a, a.backward ? blk - 1 : blk + 1, drow, part, tv);
+    if (a.tim) t3 = clock64();
     if (part == 0 && drow < rows) a.x[i0 + drow] = sum;
     __threadfence_block();
     __syncthreads();
+    if (a.tim) {
+      const unsigned long long t4 = clock64();
+      tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += 1;
+      tacc[5] += t1a - t1; tacc[6] += t1b - t1a; tacc[7] += t2 - t1b;
+    }
+  }
+  if (a.tim && tid == 0 && blockIdx.x == 0) {
+    // [0] loads -> products in LDS, [1] in-order row sums, [2] dense product, [3] x store + fence + barrier, [4] steps
+    for (int q = 0; q < 8; ++q) atomicAdd(a.tim + q, tacc[q]);
+  }
+}
+
+// Software-pipelined block sweep.  gs_block_kernel spends most of a 128-row block step waiting: row pointers ->
+// col/val -> x gather are dependent round trips (and a block has more entries than one round of loads covers),
+// then the x store is fenced (measured: 10.3 k + 7.6 k + 4.1 k of 26.6 k cycles per step on the 38 k-row level of
+// the 256^3 hierarchy, `tools/block_phase.py`).  Here the products of block k+1 are produced WHILE block k is
+// being finished, into a second LDS buffer:
+//   (a) issue block k+1's col/val, row metadata, near list and the ranges two blocks ahead
+//   (b) patch block k's "near" entries (those that reference block k-1, whose x was not final when the products
+//       were formed; a host-built list, a few per cent of the entries) from the LDS copy of x_{k-1}
+//   (c) row sums of block k, 8 lanes per row, entries interleaved (conflict-free LDS reads)
+//   (d) issue block k+1's x gathers      (e) dense product with the inverted triangle, store x_k
+//   (f) block k+1's products -> the other LDS buffer
+// Barriers inside the step order LDS only (lds_barrier), so the loads of (a)/(d) stay in flight across them; the
+// step ends with a full barrier so that every x store is complete before the next gathers are issued.
+constexpr int kPipeThreads = 1024;
+constexpr int kPipePF = 9;                          // leading entries per thread
+constexpr int kPipeCap = kPipePF * kPipeThreads;    // products per LDS buffer (2 x 72 KiB); longer blocks: extra passes
+constexpr int kPipeNPF = 2;                         // near entries per thread held in registers
+
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a) {
+  constexpr int T = kPipeThreads, PF = kPipePF, NPF = kPipeNPF;
+  __shared__ double s_buf[2][kPipeCap];
+  __shared__ double s_vec[kBlk];
+  __shared__ double s_xnew[kBlk];
+  const int tid = threadIdx.x;
+  a.x += blockIdx.x * a.ld;
+  a.b += blockIdx.x * a.ld;
+  const int drow = tid >> 3, part = tid & 7;  // 8 lanes per row, in the row sums and in the dense product
+  const int dir = a.backward ? -1 : 1;
+  int blk = a.backward ? a.nblk - 1 : 0;
+  double tv[16];
+  blk_load_tinv(a, blk, drow, part, tv);
+
+  // state of the block about to be processed (filled one step ahead)
+  int np0, np1, nrs = 0, nre = 0;
+  double nd = 0.0, nbb = 0.0, nxo = 0.0;
+  i2_t qpi[NPF];
+  double qv[NPF];
+  int nq0 = 0, nq1 = 0;
+  // ranges of the block after that (fetched two steps ahead)
+  int n2p0 = 0, n2p1 = 0, n2q0 = 0, n2q1 = 0;
+  {
+    const int i0 = blk * kBlk, rows = min(kBlk, a.n - i0);
+    np0 = a.rowptr[i0];
+    np1 = a.rowptr[i0 + rows];
+    if (drow < rows) {
+      nrs = a.rowptr[i0 + drow]; nre = a.rowptr[i0 + drow + 1];
+      if (part == 0) { nd = a.diag[i0 + drow]; nbb = a.b[i0 + drow]; nxo = a.x[i0 + drow]; }
+    }
+#pragma unroll
+    for (int e = 0; e < NPF; ++e) { qpi[e] = i2_t{-1, 0}; qv[e] = 0.0; }  // the first block has no predecessor
+    const int lim = min(np1, np0 + kPipeCap);
+    int pc[PF];
+    double pv[PF], px[PF];
+#pragma unroll
+    for (int e = 0; e < PF; ++e) {
+      const int k = np0 + tid + e * T;
+      pc[e] = -1; pv[e] = 0.0;
+      if (k < lim) { pc[e] = a.col[k]; pv[e] = a.val[k]; }
+    }
+#pragma unroll
+    for (int e = 0; e < PF; ++e) px[e] = pc[e] >= 0 ? a.x[pc[e]] : 0.0;
+#pragma unroll
+    for (int e = 0; e < PF; ++e)
+      if (pc[e] >= 0) s_buf[0][tid + e * T] = pv[e] * px[e];
+    if (a.nblk > 1) {
+      const int j = blk + dir, j0 = j * kBlk, jr = min(kBlk, a.n - j0);
+      n2p0 = a.rowptr[j0]; n2p1 = a.rowptr[j0 + jr];
+      n2q0 = a.near_ptr[j]; n2q1 = a.near_ptr[j + 1];
+    }
+  }
+  __syncthreads();
+
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int step = 0; step < a.nblk; ++step, blk += dir) {
+    const unsigned long long t0 = a.tim ? clock64() : 0;
+    unsigned long long t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    double* s_cur = s_buf[step & 1];
+    double* s_nxt = s_buf[(step & 1) ^ 1];
+    const int i0 = blk * kBlk;
+    const int rows = min(kBlk, a.n - i0);
+    const int p0 = np0, p1 = np1, rs = nrs, re = nre, q0 = nq0, q1 = nq1;
+    const double d = nd, bb = nbb, xo = nxo;
+    const bool has_next = step + 1 < a.nblk;
+    // (b) near entries of this block, from the registers filled a step ago
+#pragma unroll
+    for (int e = 0; e < NPF; ++e)
+      if (qpi[e].x >= 0 && qpi[e].x < kPipeCap) s_cur[qpi[e].x] = qv[e] * s_xnew[qpi[e].y];
+    for (int i = q0 + NPF * T + tid; i < q1; i += T) {  // more near entries than registers hold
+      const i2_t pi = a.near_pi[i];
+      if (pi.x < kPipeCap) s_cur[pi.x] = a.near_val[i] * s_xnew[pi.y];
+    }
+    // (a) everything the next block needs
+    int pc[PF];
+    double pv[PF];
+    if (has_next) {
+      const int j = blk + dir, j0 = j * kBlk, jr = min(kBlk, a.n - j0);
+      np0 = n2p0; np1 = n2p1; nq0 = n2q0; nq1 = n2q1;
+      const int lim = min(np1, np0 + kPipeCap);
+#pragma unroll
+      for (int e = 0; e < PF; ++e) {
+        const int k = np0 + tid + e * T;
+        pc[e] = -1; pv[e] = 0.0;
+        if (k < lim) { pc[e] = a.col[k]; pv[e] = a.val[k]; }
+      }
+      nrs = nre = 0; nd = nbb = nxo = 0.0;
+      if (drow < jr) {
+        nrs = a.rowptr[j0 + drow]; nre = a.rowptr[j0 + drow + 1];
+        if (part == 0) { nd = a.diag[j0 + drow]; nbb = a.b[j0 + drow]; nxo = a.x[j0 + drow]; }
+      }
+#pragma unroll
+      for (int e = 0; e < NPF; ++e) {
+        const int i = nq0 + tid + e * T;
+        qpi[e] = i2_t{-1, 0}; qv[e] = 0.0;
+        if (i < nq1) { qpi[e] = a.near_pi[i]; qv[e] = a.near_val[i]; }
+      }
+      if (step + 2 < a.nblk) {
+        const int m = blk + 2 * dir, m0 = m * kBlk, mr = min(kBlk, a.n - m0);
+        n2p0 = a.rowptr[m0]; n2p1 = a.rowptr[m0 + mr];
+        n2q0 = a.near_ptr[m]; n2q1 = a.near_ptr[m + 1];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < PF; ++e) { pc[e] = -1; pv[e] = 0.0; }
+    }
+    lds_barrier();
+    if (a.tim) t1 = clock64();
+    // (c) row sums: 8 lanes per row, interleaved
+    double acc = 0.0;
+    for (int q = rs - p0 + part, qe = min(re - p0, kPipeCap); q < qe; q += 8) acc += s_cur[q];
+    for (int c0 = p0 + kPipeCap; c0 < p1; c0 += kPipeCap) {  // block longer than the buffer: fetched on demand
+      const int c1 = min(c0 + kPipeCap, p1);
+      lds_barrier();
+#pragma unroll
+      for (int e = 0; e < PF; ++e) {
+        const int k = c0 + tid + e * T;
+        if (k < c1) s_cur[k - c0] = a.val[k] * a.x[a.col[k]];  // x in HBM is current: the last step ended with a full barrier
+      }
+      lds_barrier();
+      for (int q = max(rs, c0) - c0 + part, qe = min(re, c1) - c0; q < qe; q += 8) acc += s_cur[q];
+    }
+    acc += __shfl_xor(acc, 1, kWave);
+    acc += __shfl_xor(acc, 2, kWave);
+    acc += __shfl_xor(acc, 4, kWave);
+    if (part == 0) s_vec[drow] = (drow < rows) ? ((d == 0.0) ? xo : bb - acc) : 0.0;
+    lds_barrier();
+    if (a.tim) t2 = clock64();
+    // (d) x gathers of the next block's leading entries
+    double px[PF];
+#pragma unroll
+    for (int e = 0; e < PF; ++e) px[e] = pc[e] >= 0 ? a.x[pc[e]] : 0.0;
+    // (e) x_I = Tinv_II . s
+    double sum = 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum += tv[e] * s_vec[part * 16 + e];
+    sum += __shfl_xor(sum, 1, kWave);
+    sum += __shfl_xor(sum, 2, kWave);
+    sum += __shfl_xor(sum, 4, kWave);
+    if (a.tim) t3 = clock64();
+    if (has_next) blk_load_tinv(a, blk + dir, drow, part, tv);
+    if (part == 0 && drow < rows) {
+      a.x[i0 + drow] = sum;
+      s_xnew[drow] = sum;
+    }
+    // (f) next block's products
+#pragma unroll
+    for (int e = 0; e < PF; ++e)
+      if (pc[e] >= 0) s_nxt[tid + e * T] = pv[e] * px[e];
+    if (a.tim) t4 = clock64();
+    __syncthreads();  // full: x stores complete before the next step's gathers
+    if (a.tim) {
+      t5 = clock64();
+      tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += 1; tacc[5] += t5 - t4;
+    }
+  }
+  if (a.tim && tid == 0 && blockIdx.x == 0) {
+    // [0] near patch + issue loads + barrier, [1] row sums, [2] gathers issue + dense, [3] products of next block, [5] full barrier
+    for (int q = 0; q < 8; ++q) atomicAdd(a.tim + q, tacc[q]);
   }
 }
 
