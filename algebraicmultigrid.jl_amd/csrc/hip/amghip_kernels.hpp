@@ -703,8 +703,8 @@ __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
 // Barriers inside the step order LDS only (lds_barrier), so the loads of (a)/(d) stay in flight across them; the
 // step ends with a full barrier so that every x store is complete before the next gathers are issued.
 constexpr int kPipeThreads = 1024;
-constexpr int kPipePF = 9;                          // leading entries per thread
-constexpr int kPipeCap = kPipePF * kPipeThreads;    // products per LDS buffer (2 x 72 KiB); longer blocks: extra passes
+constexpr int kPipePF = 8;                          // leading entries per thread: 2 rounds of 4 consecutive entries (16-B loads)
+constexpr int kPipeCap = kPipePF * kPipeThreads;    // products per LDS buffer (2 x 64 KiB); longer blocks: extra passes
 constexpr int kPipeNPF = 2;                         // near entries per thread held in registers
 
 __device__ __forceinline__ void lds_barrier() {
@@ -712,6 +712,57 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+
+// The leading entries [p0, lim) of a block, 4 consecutive entries per thread and round, from the 16-B aligned
+// position a0 = p0 & ~3 (a single CU is bound by the number of vector-memory instructions it can issue, not by
+// bytes: one 16-B load instead of four 4-B loads).  Entries outside [p0, lim) get col = -1.
+struct PipeEntries {
+  int c[kPipePF];
+  double v[kPipePF];
+};
+__device__ __forceinline__ void pipe_load_entries(const BlockArgs& a, int p0, int lim, int tid, PipeEntries& o) {
+  const int a0 = p0 & ~3;
+#pragma unroll
+  for (int r = 0; r < kPipePF / 4; ++r) {
+    const int k = a0 + 4 * (tid + r * kPipeThreads);
+    if (k < lim) {  // hipMalloc'ed arrays are padded past nnz? no: guard the tail below
+      if (k + 4 <= lim && k >= p0) {
+        const i4_t cc = *(const i4_t*)(a.col + k);
+        const d2_t v0 = *(const d2_t*)(a.val + k);
+        const d2_t v1 = *(const d2_t*)(a.val + k + 2);
+        o.c[4 * r] = cc.x; o.c[4 * r + 1] = cc.y; o.c[4 * r + 2] = cc.z; o.c[4 * r + 3] = cc.w;
+        o.v[4 * r] = v0.x; o.v[4 * r + 1] = v0.y; o.v[4 * r + 2] = v1.x; o.v[4 * r + 3] = v1.y;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool in = k + e >= p0 && k + e < lim;
+          o.c[4 * r + e] = in ? a.col[k + e] : -1;
+          o.v[4 * r + e] = in ? a.val[k + e] : 0.0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o.c[4 * r + e] = -1; o.v[4 * r + e] = 0.0; }
+    }
+  }
+}
+__device__ __forceinline__ void pipe_gather(const BlockArgs& a, const PipeEntries& o, double (&px)[kPipePF]) {
+#pragma unroll
+  for (int e = 0; e < kPipePF; ++e) px[e] = o.c[e] >= 0 ? a.x[o.c[e]] : 0.0;
+}
+__device__ __forceinline__ void pipe_store_products(double* s_dst, int p0, int tid, const PipeEntries& o,
+                                                    const double (&px)[kPipePF]) {
+  const int a0 = p0 & ~3;
+#pragma unroll
+  for (int r = 0; r < kPipePF / 4; ++r) {
+    const int k = a0 + 4 * (tid + r * kPipeThreads) - p0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (o.c[4 * r + e] >= 0) s_dst[k + e] = o.v[4 * r + e] * px[4 * r + e];
+  }
+}
+// entries of [p0, p1) the leading rounds cover (they start at the aligned position below p0)
+__device__ __forceinline__ int pipe_lead_end(int p0, int p1) { return min(p1, (p0 & ~3) + kPipeCap); }
 
 __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a) {
   constexpr int T = kPipeThreads, PF = kPipePF, NPF = kPipeNPF;
@@ -745,20 +796,11 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
     }
 #pragma unroll
     for (int e = 0; e < NPF; ++e) { qpi[e] = i2_t{-1, 0}; qv[e] = 0.0; }  // the first block has no predecessor
-    const int lim = min(np1, np0 + kPipeCap);
-    int pc[PF];
-    double pv[PF], px[PF];
-#pragma unroll
-    for (int e = 0; e < PF; ++e) {
-      const int k = np0 + tid + e * T;
-      pc[e] = -1; pv[e] = 0.0;
-      if (k < lim) { pc[e] = a.col[k]; pv[e] = a.val[k]; }
-    }
-#pragma unroll
-    for (int e = 0; e < PF; ++e) px[e] = pc[e] >= 0 ? a.x[pc[e]] : 0.0;
-#pragma unroll
-    for (int e = 0; e < PF; ++e)
-      if (pc[e] >= 0) s_buf[0][tid + e * T] = pv[e] * px[e];
+    PipeEntries pe;
+    double px[PF];
+    pipe_load_entries(a, np0, pipe_lead_end(np0, np1), tid, pe);
+    pipe_gather(a, pe, px);
+    pipe_store_products(s_buf[0], np0, tid, pe, px);
     if (a.nblk > 1) {
       const int j = blk + dir, j0 = j * kBlk, jr = min(kBlk, a.n - j0);
       n2p0 = a.rowptr[j0]; n2p1 = a.rowptr[j0 + jr];
@@ -778,27 +820,21 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
     const int p0 = np0, p1 = np1, rs = nrs, re = nre, q0 = nq0, q1 = nq1;
     const double d = nd, bb = nbb, xo = nxo;
     const bool has_next = step + 1 < a.nblk;
+    const int lead = pipe_lead_end(p0, p1) - p0;  // entries [0, lead) of this block are in s_cur
     // (b) near entries of this block, from the registers filled a step ago
 #pragma unroll
     for (int e = 0; e < NPF; ++e)
-      if (qpi[e].x >= 0 && qpi[e].x < kPipeCap) s_cur[qpi[e].x] = qv[e] * s_xnew[qpi[e].y];
+      if (qpi[e].x >= 0 && qpi[e].x < lead) s_cur[qpi[e].x] = qv[e] * s_xnew[qpi[e].y];
     for (int i = q0 + NPF * T + tid; i < q1; i += T) {  // more near entries than registers hold
       const i2_t pi = a.near_pi[i];
-      if (pi.x < kPipeCap) s_cur[pi.x] = a.near_val[i] * s_xnew[pi.y];
+      if (pi.x < lead) s_cur[pi.x] = a.near_val[i] * s_xnew[pi.y];
     }
     // (a) everything the next block needs
-    int pc[PF];
-    double pv[PF];
+    PipeEntries pe;
     if (has_next) {
       const int j = blk + dir, j0 = j * kBlk, jr = min(kBlk, a.n - j0);
       np0 = n2p0; np1 = n2p1; nq0 = n2q0; nq1 = n2q1;
-      const int lim = min(np1, np0 + kPipeCap);
-#pragma unroll
-      for (int e = 0; e < PF; ++e) {
-        const int k = np0 + tid + e * T;
-        pc[e] = -1; pv[e] = 0.0;
-        if (k < lim) { pc[e] = a.col[k]; pv[e] = a.val[k]; }
-      }
+      pipe_load_entries(a, np0, pipe_lead_end(np0, np1), tid, pe);
       nrs = nre = 0; nd = nbb = nxo = 0.0;
       if (drow < jr) {
         nrs = a.rowptr[j0 + drow]; nre = a.rowptr[j0 + drow + 1];
@@ -817,14 +853,14 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < PF; ++e) { pc[e] = -1; pv[e] = 0.0; }
+      for (int e = 0; e < PF; ++e) { pe.c[e] = -1; pe.v[e] = 0.0; }
     }
     lds_barrier();
     if (a.tim) t1 = clock64();
     // (c) row sums: 8 lanes per row, interleaved
     double acc = 0.0;
-    for (int q = rs - p0 + part, qe = min(re - p0, kPipeCap); q < qe; q += 8) acc += s_cur[q];
-    for (int c0 = p0 + kPipeCap; c0 < p1; c0 += kPipeCap) {  // block longer than the buffer: fetched on demand
+    for (int q = rs - p0 + part, qe = min(re - p0, lead); q < qe; q += 8) acc += s_cur[q];
+    for (int c0 = p0 + lead; c0 < p1; c0 += kPipeCap) {  // block longer than the buffer: fetched on demand
       const int c1 = min(c0 + kPipeCap, p1);
       lds_barrier();
 #pragma unroll
@@ -843,8 +879,7 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
     if (a.tim) t2 = clock64();
     // (d) x gathers of the next block's leading entries
     double px[PF];
-#pragma unroll
-    for (int e = 0; e < PF; ++e) px[e] = pc[e] >= 0 ? a.x[pc[e]] : 0.0;
+    pipe_gather(a, pe, px);
     // (e) x_I = Tinv_II . s
     double sum = 0.0;
 #pragma unroll
@@ -859,9 +894,7 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
       s_xnew[drow] = sum;
     }
     // (f) next block's products
-#pragma unroll
-    for (int e = 0; e < PF; ++e)
-      if (pc[e] >= 0) s_nxt[tid + e * T] = pv[e] * px[e];
+    pipe_store_products(s_nxt, np0, tid, pe, px);
     if (a.tim) t4 = clock64();
     __syncthreads();  // full: x stores complete before the next step's gathers
     if (a.tim) {
