@@ -88,17 +88,22 @@ struct GsSchedule {
     // entries that reference blocks swept LATER (and the in-block other triangle): they read old x only, so
     // b - O_next x is one full-chip residual launch before the sequential sweep
     int32_t* nx_rowptr = nullptr; int32_t* nx_col = nullptr; double* nx_val = nullptr;
+    // entries that reference EARLIER superblocks: final once that superblock is done, applied to the rows of a
+    // superblock by one parallel launch before its sequential sweep
+    int32_t* sp_rowptr = nullptr; int32_t* sp_col = nullptr; double* sp_val = nullptr;
   };
   Outer blk_f, blk_b;
   double* blk_diag = nullptr;
   double* blk_s = nullptr;  // b - O_next x (n entries per right-hand-side column)
   int nblk = 0;  // 0 = block path not used for this operator
+  int super = 0; // blocks per superblock (0: the whole operator is one superblock)
   double blk_cond = 0.0;  // largest inf-norm condition estimate of an in-block triangle
   void free_dev() {
     for (Outer* o : {&blk_f, &blk_b}) {
       hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv);
       hipFree(o->near_ptr); hipFree(o->near_pi); hipFree(o->near_val);
       hipFree(o->nx_rowptr); hipFree(o->nx_col); hipFree(o->nx_val);
+      hipFree(o->sp_rowptr); hipFree(o->sp_col); hipFree(o->sp_val);
       *o = Outer();
     }
     hipFree(blk_diag); blk_diag = nullptr;
@@ -134,6 +139,7 @@ int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (on
 int g_gs_threads = 256;
 int g_gs_slot_ept = 1;          // slot entries per thread in gs_slot_kernel (1 or 2)
 int g_gs_block_pipe = 1;        // software-pipelined block sweep (gs_block_pipe_kernel)
+int g_gs_super = 8;             // block-inverse sweeps: blocks per superblock (0 = one launch for the whole operator); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)
@@ -200,12 +206,12 @@ int csr_ensure_diag(amgh_csr* op, hipStream_t st) {
 
 // Block-inverse data of one sweep direction: the outer matrix (operator minus the in-block triangle
 // and diagonal) and the dense inverses of the in-block triangles.
-int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int32_t* rowptr, const int32_t* col,
+int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n, const int32_t* rowptr, const int32_t* col,
                       const double* val, const std::vector<double>& diag, double* max_cond) {
   const int B = kBlk;
   const int nblk = (int)((n + B - 1) / B);
-  std::vector<int32_t> orow(n + 1, 0), ocol, xrow(n + 1, 0), xcol;
-  std::vector<double> oval, xval;
+  std::vector<int32_t> orow(n + 1, 0), ocol, xrow(n + 1, 0), xcol, prow(n + 1, 0), pcol;
+  std::vector<double> oval, xval, pval;
   ocol.reserve(rowptr[n]); oval.reserve(rowptr[n]);
   xcol.reserve(rowptr[n]); xval.reserve(rowptr[n]);
   std::vector<double> tinv((size_t)nblk * B * B, 0.0), T((size_t)B * B);
@@ -217,6 +223,9 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int3
   for (int blk = 0; blk < nblk; ++blk) {
     const int64_t i0 = (int64_t)blk * B, i1 = std::min<int64_t>(i0 + B, n);
     const int64_t q0 = backward ? i0 + B : i0 - B;  // first row of the previously swept block
+    // rows of this block's superblock: [s0, s1)
+    const int64_t sb = super > 0 ? blk / super : 0;
+    const int64_t s0 = super > 0 ? sb * super * B : 0, s1 = super > 0 ? std::min<int64_t>(n, (sb + 1) * super * B) : n;
     const size_t blk_first = ocol.size();
     std::fill(T.begin(), T.end(), 0.0);
     for (int64_t i = i0; i < i1; ++i) {
@@ -228,6 +237,8 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int3
           if (!skip) T[(size_t)(i - i0) * B + (c - i0)] += val[j];
         } else if (!skip && (c >= i0 && c < i1 ? true : (backward ? c < i0 : c >= i1))) {
           xcol.push_back(c); xval.push_back(val[j]);  // old x: in-block other triangle, or a block swept later
+        } else if (!skip && (c < s0 || c >= s1)) {
+          pcol.push_back(c); pval.push_back(val[j]);  // an earlier superblock
         } else if (!skip) {
           if (c >= q0 && c < q0 + B) {
             near_pi.push_back(i2_t{(int32_t)(ocol.size() - blk_first), (int32_t)(c - q0)});
@@ -239,6 +250,7 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int3
       if (skip) T[(size_t)(i - i0) * B + (i - i0)] = 1.0;
       orow[i + 1] = (int32_t)ocol.size();
       xrow[i + 1] = (int32_t)xcol.size();
+      prow[i + 1] = (int32_t)pcol.size();
     }
     near_ptr[blk + 1] = (int32_t)near_pi.size();
     for (int64_t i = i1; i < i0 + B; ++i) T[(size_t)(i - i0) * B + (i - i0)] = 1.0;  // padding rows
@@ -280,6 +292,9 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int64_t n, const int3
   RC_TRY(dev_upload(&o->nx_rowptr, xrow.data(), n + 1));
   RC_TRY(dev_upload(&o->nx_col, xcol.data(), (int64_t)xcol.size()));
   RC_TRY(dev_upload(&o->nx_val, xval.data(), (int64_t)xval.size()));
+  RC_TRY(dev_upload(&o->sp_rowptr, prow.data(), n + 1));
+  RC_TRY(dev_upload(&o->sp_col, pcol.data(), (int64_t)pcol.size()));
+  RC_TRY(dev_upload(&o->sp_val, pval.data(), (int64_t)pval.size()));
   return AMGH_OK;
 }
 
@@ -371,8 +386,9 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
           if (col[j] == i) dg[i] = val[j];
       double max_cond = 0.0;
-      RC_TRY(blockgs_build_dir(&g->blk_f, false, n, rowptr, col, val, dg, &max_cond));
-      RC_TRY(blockgs_build_dir(&g->blk_b, true, n, rowptr, col, val, dg, &max_cond));
+      g->super = (g_gs_super > 0 && nblk > g_gs_super) ? g_gs_super : 0;
+      RC_TRY(blockgs_build_dir(&g->blk_f, false, g->super, n, rowptr, col, val, dg, &max_cond));
+      RC_TRY(blockgs_build_dir(&g->blk_b, true, g->super, n, rowptr, col, val, dg, &max_cond));
       RC_TRY(dev_upload(&g->blk_diag, dg.data(), n));
       RC_TRY(dev_alloc(&g->blk_s, n));
       g->blk_cond = max_cond;
@@ -636,12 +652,27 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       // few, long rows: 64 rows per workgroup so that the launch still covers the chip
       RC_TRY((launch_stream<M_RESID, StreamCfg<256, 64, 4096, 2, false, false>>(ra, st, ncolv)));
     }
-    ba.x = x; ba.b = g->blk_s; ba.n = (int32_t)g->n; ba.nblk = g->nblk; ba.backward = backward ? 1 : 0;
+    ba.x = x; ba.b = g->blk_s; ba.n = (int32_t)g->n; ba.backward = backward ? 1 : 0;
     ba.ld = g->n;  // block path: square operator, x and b in natural order
     ba.tim = g_chain_tim;
     ba.near_ptr = o.near_ptr; ba.near_pi = o.near_pi; ba.near_val = o.near_val;
-    if (g_gs_block_pipe) hipLaunchKernelGGL(gs_block_pipe_kernel, dim3(ncolv), dim3(kPipeThreads), 0, st, ba);
-    else hipLaunchKernelGGL(gs_block_kernel, dim3(ncolv), dim3(kBlkThreads), 0, st, ba);
+    const int S = g->super > 0 ? g->super : g->nblk;
+    const int nsuper = (g->nblk + S - 1) / S;
+    for (int q = 0; q < nsuper; ++q) {
+      const int J = backward ? nsuper - 1 - q : q;
+      ba.blk0 = J * S;
+      ba.nblk = std::min(S, g->nblk - ba.blk0);
+      if (q > 0) {  // s -= O_sp x on this superblock's rows: every superblock swept so far is final
+        StreamArgs pa{};
+        pa.rowptr = o.sp_rowptr; pa.col = o.sp_col; pa.val = o.sp_val;
+        pa.x = x; pa.b = g->blk_s; pa.y = g->blk_s;
+        pa.row_begin = ba.blk0 * kBlk; pa.row_end = (int32_t)std::min<int64_t>(g->n, (int64_t)(ba.blk0 + ba.nblk) * kBlk);
+        pa.ldx = g->n; pa.ldy = g->n; pa.ldb = g->n;
+        RC_TRY((launch_stream<M_RESID, StreamCfg<256, 16, 2048, 2, false, false>>(pa, st, ncolv)));
+      }
+      if (g_gs_block_pipe) hipLaunchKernelGGL(gs_block_pipe_kernel, dim3(ncolv), dim3(kPipeThreads), 0, st, ba);
+      else hipLaunchKernelGGL(gs_block_kernel, dim3(ncolv), dim3(kBlkThreads), 0, st, ba);
+    }
     HIP_TRY(hipGetLastError());
     return AMGH_OK;
   }
@@ -1619,6 +1650,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_block_inverse")) g_gs_block_inverse = value;
   else if (!strcmp(name, "gs_slots")) g_gs_slots = value;
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
+  else if (!strcmp(name, "gs_super")) g_gs_super = value;
   else if (!strcmp(name, "gs_block_pipe")) g_gs_block_pipe = value;
   else if (!strcmp(name, "gs_slot_ept")) g_gs_slot_ept = value;
   else return AMGH_EINVAL;

@@ -586,7 +586,8 @@ struct BlockArgs {
   double* x;
   const double* b;
   int32_t n;
-  int32_t nblk;
+  int32_t nblk;      // blocks swept by this launch: blk0 .. blk0 + nblk - 1 (descending when backward)
+  int32_t blk0;
   int32_t backward;
   int64_t ld;  // multi-RHS: workgroup blockIdx.x sweeps column blockIdx.x of x / b
   // "near" entries: outer entries of block k that reference the block swept just before it (gs_block_pipe_kernel)
@@ -618,12 +619,12 @@ __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
   a.b += blockIdx.x * a.ld;
   const int drow = tid >> 3, part = tid & 7;  // dense phase: 8 lanes share a row, 16 columns each
   double tv[16];
-  blk_load_tinv(a, a.backward ? a.nblk - 1 : 0, drow, part, tv);
+  blk_load_tinv(a, a.blk0 + (a.backward ? a.nblk - 1 : 0), drow, part, tv);
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int step = 0; step < a.nblk; ++step) {
     const unsigned long long t0 = a.tim ? clock64() : 0;
     unsigned long long t1 = 0, t2 = 0, t3 = 0, t1a = 0, t1b = 0;
-    const int blk = a.backward ? a.nblk - 1 - step : step;
+    const int blk = a.blk0 + (a.backward ? a.nblk - 1 - step : step);
     const int i0 = blk * kBlk;
     const int rows = min(kBlk, a.n - i0);
     // phase 1: s_i = b_i - (outer row i) . x      (all x entries referenced are final or old)
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
   a.b += blockIdx.x * a.ld;
   const int drow = tid >> 3, part = tid & 7;  // 8 lanes per row, in the row sums and in the dense product
   const int dir = a.backward ? -1 : 1;
-  int blk = a.backward ? a.nblk - 1 : 0;
+  int blk = a.blk0 + (a.backward ? a.nblk - 1 : 0);
   double tv[16];
   blk_load_tinv(a, blk, drow, part, tv);
 
