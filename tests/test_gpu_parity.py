@@ -136,6 +136,49 @@ def test_smoothers_on_amg_coarse_operator_and_zero_diagonal():
         assert rel(x, ref) <= TIGHT and x[7] == x0[7]
 
 
+def _dense_band_spd(n, half_bw, seed, zero_diag_rows=()):
+    """Irregular, densely coupled SPD-like matrix (many dependency levels per row block): the kind of operator the
+    block-inverse Gauss-Seidel sweeps are selected for."""
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        for j in range(max(0, i - half_bw), i):
+            if rng.random() < 0.6:
+                v = -rng.random()
+                rows += [i, j]; cols += [j, i]; vals += [v, v]
+    M = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    d = np.asarray(abs(M).sum(axis=1)).ravel() + 1.0
+    for r in zero_diag_rows:
+        d[r] = 0.0
+    M = (M + sp.diags(d)).tocsc()
+    M.eliminate_zeros()
+    return AMG.SparseMatrixCSC.from_scipy(M)
+
+
+@pytest.mark.parametrize("super_blocks,pipe", [(8, 1), (2, 1), (0, 1), (3, 0), (0, 0)])
+def test_block_inverse_sweeps_all_variants(super_blocks, pipe):
+    """Block-inverse sweeps (gs_block_kernel / gs_block_pipe_kernel, with and without superblocks) against the
+    oracle's scalar lexicographic sweeps: irregular band matrices whose block steps overflow the register-resident
+    leading entries, rows without a usable diagonal, a last block shorter than 128 rows, several iterations."""
+    lib = AMG.hip_lib()
+    lib.amgh_debug_set_tunable(b"gs_super", super_blocks)
+    lib.amgh_debug_set_tunable(b"gs_block_pipe", pipe)
+    try:
+        cases = [_dense_band_spd(1000, 40, 1), _dense_band_spd(700, 150, 2, zero_diag_rows=(5, 300, 699)),
+                 _dense_band_spd(257, 30, 3), _dense_band_spd(130, 129, 4)]
+        for k, A in enumerate(cases):
+            n = A.m
+            x0, b = uniform(n, 60 + k) - 0.5, uniform(n, 70 + k)
+            for s in (FWD, BWD, SYM, AMG.GaussSeidel(AMG.SymmetricSweep(), 3)):
+                x = x0.copy()
+                s(A, x, b)
+                ref = O.smooth(s, A, x0, b)
+                assert rel(x, ref) <= 1e-11, (k, repr(s), rel(x, ref))
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_super", 8)
+        lib.amgh_debug_set_tunable(b"gs_block_pipe", 1)
+
+
 def test_hermitian_flag_on_nonsymmetric_matrix_sweeps_the_transpose():
     """SURVEY §7 hard part 4: with the default HermitianSymmetry the fast smoothers read CSC columns as rows."""
     rng = np.random.default_rng(3)
