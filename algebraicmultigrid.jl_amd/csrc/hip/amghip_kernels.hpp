@@ -487,7 +487,7 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
 // kSlot entries (whole rows only, zero padding), workgroup b owns slot slot0 + b, so the
 // addresses of its col/val loads follow from the kernel arguments and blockIdx alone; which rows the
 // slot holds (slot_row, rowmeta) is fetched in parallel and only needed for the row sums.
-constexpr int kSlot = 512;  // 128: 39.5, 256: 37.5, 512: 36.9 ms per smoother pass over all levels of the 256^3 hierarchy
+constexpr int kSlot = 512;  // 128: 39.5, 256: 37.5, 512: 36.9, 1024: 37.2 ms per smoother pass over all levels of the 256^3 hierarchy
 
 struct SlotArgs {
   const int32_t* wcol;      // slot arrays: nslots * kSlot entries (padding: col 0, val 0)
