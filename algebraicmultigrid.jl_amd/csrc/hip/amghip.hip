@@ -137,7 +137,6 @@ int g_gs_block_target = 256;   // aim for at least this many workgroups per wide
 int g_gs_min_rows = 4;         // but never fewer rows per workgroup than this
 int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (one per thread)
 int g_gs_threads = 256;
-int g_gs_slot_ept = 1;          // slot entries per thread in gs_slot_kernel (1 or 2)
 int g_gs_block_pipe = 1;        // software-pipelined block sweep (gs_block_pipe_kernel)
 int g_gs_super = 8;             // block-inverse sweeps: blocks per superblock (0 = one launch for the whole operator); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
@@ -523,12 +522,15 @@ int csr_ensure_gs(amgh_csr* op) {
 }
 
 template <int MODE, class CFG = DefaultCfg>
-int launch_stream(const StreamArgs& a, hipStream_t st, int ncolv = 1) {
-  const int nrows = a.row_end - a.row_begin;
+int launch_stream(const StreamArgs& a0, hipStream_t st, int ncolv = 1) {
+  const int nrows = a0.row_end - a0.row_begin;
   if (nrows <= 0) return AMGH_OK;
+  StreamArgs a = a0;
+  a.ncolv = ncolv;
   const int nb = (nrows + CFG::ROWS - 1) / CFG::ROWS;
-  const int grid = CFG::XCD ? ((nb + kNumXcd - 1) / kNumXcd) * kNumXcd : nb;
-  hipLaunchKernelGGL((csr_stream_kernel<MODE, CFG>), dim3((unsigned)grid, (unsigned)ncolv), dim3(CFG::THREADS), 0, st, a);
+  // multi-column launches: tiles padded to a multiple of 8, times ncolv (multi_column_block)
+  const int64_t grid = (CFG::XCD || ncolv > 1) ? (int64_t)((nb + kNumXcd - 1) / kNumXcd) * kNumXcd * ncolv : nb;
+  hipLaunchKernelGGL((csr_stream_kernel<MODE, CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), 0, st, a);
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
 }
@@ -609,6 +611,21 @@ int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, h
     case 64: return launch_chain_t<64, 4>(c, sor, ldsx, nx, st, ncolv);
     case 256: return launch_chain_t<256, 4>(c, sor, ldsx, nx, st, ncolv);
     default: return launch_chain_t<1024, 4>(c, sor, ldsx, nx, st, ncolv);  // PF = 8 spills at 1024 threads (128 VGPRs)
+  }
+}
+
+template <int NCV>
+int launch_slot_t(const SlotArgs& sa, bool sor, int grid, hipStream_t st) {
+  if (sor) hipLaunchKernelGGL((gs_slot_kernel<true, NCV>), dim3(grid), dim3(kSlot), 0, st, sa);
+  else hipLaunchKernelGGL((gs_slot_kernel<false, NCV>), dim3(grid), dim3(kSlot), 0, st, sa);
+  return AMGH_OK;
+}
+int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st) {
+  switch (ncv) {
+    case 8: return launch_slot_t<8>(sa, sor, grid, st);
+    case 4: return launch_slot_t<4>(sa, sor, grid, st);
+    case 2: return launch_slot_t<2>(sa, sor, grid, st);
+    default: return launch_slot_t<1>(sa, sor, grid, st);
   }
 }
 
@@ -702,14 +719,11 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       sa.diag = g->diag; sa.bp = g->bp; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;
       sa.nslots = s.nslots; sa.xcd_map = g_gs_xcd_map;
       sa.ldx = g->ncols; sa.ldb = g->n;
-      const int grid = g_gs_xcd_map ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots;
-      if (g_gs_slot_ept == 2) {
-        if (sor) hipLaunchKernelGGL((gs_slot_kernel<true, 2>), dim3(grid, ncolv), dim3(kSlot / 2), 0, st, sa);
-        else hipLaunchKernelGGL((gs_slot_kernel<false, 2>), dim3(grid, ncolv), dim3(kSlot / 2), 0, st, sa);
-      } else {
-        if (sor) hipLaunchKernelGGL((gs_slot_kernel<true, 1>), dim3(grid, ncolv), dim3(kSlot), 0, st, sa);
-        else hipLaunchKernelGGL((gs_slot_kernel<false, 1>), dim3(grid, ncolv), dim3(kSlot), 0, st, sa);
-      }
+      // columns per workgroup: the largest of 8 / 4 / 2 / 1 that divides the block size
+      const int ncv = (ncolv % 8 == 0) ? 8 : (ncolv % 4 == 0) ? 4 : (ncolv % 2 == 0) ? 2 : 1;
+      sa.ncolv = ncolv / ncv;
+      const int grid = ((g_gs_xcd_map || sa.ncolv > 1) ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots) * sa.ncolv;
+      RC_TRY(launch_slot(sa, sor, ncv, grid, st));
       HIP_TRY(hipGetLastError());
     } else {
       StreamArgs a{};
@@ -1652,7 +1666,6 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
   else if (!strcmp(name, "gs_super")) g_gs_super = value;
   else if (!strcmp(name, "gs_block_pipe")) g_gs_block_pipe = value;
-  else if (!strcmp(name, "gs_slot_ept")) g_gs_slot_ept = value;
   else return AMGH_EINVAL;
   return AMGH_OK;
 }

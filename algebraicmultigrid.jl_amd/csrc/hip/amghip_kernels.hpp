@@ -44,9 +44,10 @@ struct StreamArgs {
   double omega;
   int32_t row_begin;   // rows [row_begin, row_end) of the matrix are processed
   int32_t row_end;
-  // multi-RHS (n x bs blocks, multilevel.jl:28-59): gridDim.y = bs, column blockIdx.y of x / y / b starts
-  // at these element strides (unused when gridDim.y == 1)
+  // multi-RHS (n x bs blocks, multilevel.jl:28-59): ncolv = bs columns of x / y / b at these element strides;
+  // the grid is (row tiles padded to a multiple of 8) x ncolv workgroups, see multi_column_block()
   int64_t ldx, ldy, ldb;
+  int32_t ncolv;
 };
 
 // LDS index skew: breaks the power-of-two strides of rows with 8/16/32 entries
@@ -65,6 +66,17 @@ __device__ __forceinline__ double seq_sum_skip(const double* s, int lo, int hi, 
 __device__ __forceinline__ int xcd_block(int b, int nb) {
   const int per = (nb + kNumXcd - 1) / kNumXcd;
   return (b % kNumXcd) * per + b / kNumXcd;  // may be >= nb: caller bounds-checks
+}
+// Workgroup -> (tile, right-hand-side column) for a launch over ncolv columns.  Consecutive workgroup ids go to
+// consecutive XCDs, so within a group of 8 * ncolv workgroups XCD q gets the ncolv columns of tile 8 * group + q
+// back to back: the matrix tile is read from HBM once and served to the other columns by that XCD's L2.
+__device__ __forceinline__ void multi_column_block(int ncolv, int& tile, int& column) {
+  const int bid = blockIdx.x;
+  if (ncolv <= 1) { tile = bid; column = 0; return; }
+  const int per = kNumXcd * ncolv;
+  const int grp = bid / per, rem = bid - grp * per;
+  tile = grp * kNumXcd + (rem & (kNumXcd - 1));
+  column = rem / kNumXcd;
 }
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -127,15 +139,17 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
   // sum; many rows per workgroup (SpMV): skewed indices keep the row-strided reads conflict-free
   constexpr bool SK = CFG::ROWS > 64;
   __shared__ double s_prod[LDSN + (LDSN >> 5) + 2];
-  if (gridDim.y > 1) {  // one right-hand-side column per blockIdx.y
-    a.x += blockIdx.y * a.ldx;
-    a.y += blockIdx.y * a.ldy;
-    if (a.b) a.b += blockIdx.y * a.ldb;
+  int bid, cv;
+  multi_column_block(a.ncolv, bid, cv);
+  if (cv > 0) {
+    a.x += cv * a.ldx;
+    a.y += cv * a.ldy;
+    if (a.b) a.b += cv * a.ldb;
   }
 
   const int nrows = a.row_end - a.row_begin;
   const int nb = (nrows + CFG::ROWS - 1) / CFG::ROWS;
-  const int lb = CFG::XCD ? xcd_block(blockIdx.x, nb) : (int)blockIdx.x;
+  const int lb = CFG::XCD ? xcd_block(bid, nb) : bid;
   if (lb >= nb) return;
   const int r0 = a.row_begin + lb * CFG::ROWS;
   const int r1 = min(r0 + CFG::ROWS, a.row_end);
@@ -501,65 +515,74 @@ struct SlotArgs {
   int32_t slot0;            // first slot of this dependency level
   int32_t nslots;           // slots of this dependency level
   int32_t xcd_map;          // 1: XCD-contiguous slot mapping (grid padded to a multiple of 8)
-  int64_t ldx, ldb;         // multi-RHS: column blockIdx.y of x / bp
+  int64_t ldx, ldb;         // multi-RHS: column strides of x / bp
+  int32_t ncolv;            // column GROUPS of this launch (NCV columns each), mapped by multi_column_block()
 };
 
-// EPT = slot entries per thread (workgroup = kSlot / EPT threads): 1 -> one 8-B + one 4-B load per thread,
-// 2 -> one 16-B + one 8-B load per thread and half the waves.
-template <bool SOR, int EPT>
-__global__ __launch_bounds__(kSlot / EPT) void gs_slot_kernel(SlotArgs a) {
-  constexpr int T = kSlot / EPT;
-  __shared__ double s_prod[kSlot];
+// NCV = right-hand-side columns one workgroup sweeps (multi-RHS blocks): the slot's (col, val) are loaded once and
+// the NCV x gathers of every entry are in flight together, so a block of columns costs the level's latency chain
+// once AND keeps the workgroup count of a single column (a workgroup per column made wide levels throughput-bound:
+// 8 columns = 3 x the time).  Two entries per thread (half the waves) measured 2 % slower than one.
+template <bool SOR, int NCV>
+__global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
+  __shared__ double s_prod[NCV * kSlot];
   const int tid = threadIdx.x;
-  if (gridDim.y > 1) {
-    a.x += blockIdx.y * a.ldx;
-    a.bp += blockIdx.y * a.ldb;
+  int lb, cg;  // slot, column group
+  multi_column_block(a.ncolv, lb, cg);
+  if (cg > 0) {
+    a.x += (int64_t)cg * NCV * a.ldx;
+    a.bp += (int64_t)cg * NCV * a.ldb;
   }
-  int lb = blockIdx.x;
-  if (a.xcd_map) {
-    lb = xcd_block(blockIdx.x, a.nslots);
-    if (lb >= a.nslots) return;
-  }
+  if (a.xcd_map) lb = xcd_block(lb, a.nslots);
+  if (lb >= a.nslots) return;
   const int s = a.slot0 + lb;
   const int base = s * kSlot;
-  double v[EPT];
-  int c[EPT];
-  if (EPT == 1) {
-    v[0] = a.wval[base + tid];
-    c[0] = a.wcol[base + tid];
-  } else {
-    const d2_t vv = *(const d2_t*)(a.wval + base + 2 * tid);
-    const i2_t cc = *(const i2_t*)(a.wcol + base + 2 * tid);
-    v[0] = vv.x; v[EPT - 1] = vv.y; c[0] = cc.x; c[EPT - 1] = cc.y;
-  }
+  const double v = a.wval[base + tid];
+  const int c = a.wcol[base + tid];
   const int r0 = a.slot_row[2 * s], r1 = a.slot_row[2 * s + 1];
-  double xv[EPT];
+  double xv[NCV];
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) xv[e] = a.x[c[e]];
-  // rows of the slot: at most kSlot (one entry each), usually far fewer than T
-  i4_t m = i4_t{0, 0, -1, 0};
-  double d = 0.0, bb = 0.0;
-  if (tid < r1 - r0) {
-    m = a.wmeta[r0 + tid];
-    d = a.diag[r0 + tid];
-    bb = a.bp[r0 + tid];
+  for (int q = 0; q < NCV; ++q) xv[q] = a.x[c + q * a.ldx];
+  // (row, column) tasks of the slot are spread over the threads: task t = column * nrows + row.  The first
+  // TPT tasks of a thread have their row data requested up front (same round trip as the gathers).
+  constexpr int TPT = NCV > 1 ? 2 : 1;
+  const int nrows = r1 - r0, ntask = nrows * NCV;
+  i4_t m[TPT];
+  double d[TPT], bb[TPT];
+  int tr[TPT], tq[TPT];
+#pragma unroll
+  for (int u = 0; u < TPT; ++u) {
+    const int t = tid + u * kSlot;
+    m[u] = i4_t{0, 0, -1, 0}; d[u] = 0.0; bb[u] = 0.0; tr[u] = 0; tq[u] = 0;
+    if (t < ntask) {
+      tq[u] = t / nrows; tr[u] = t - tq[u] * nrows;
+      m[u] = a.wmeta[r0 + tr[u]];
+      d[u] = a.diag[r0 + tr[u]];
+      bb[u] = a.bp[r0 + tr[u] + tq[u] * a.ldb];
+    }
   }
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) s_prod[EPT * tid + e] = v[e] * xv[e];
+  for (int q = 0; q < NCV; ++q) s_prod[q * kSlot + tid] = v * xv[q];
   __syncthreads();
-  if (tid < r1 - r0 && d != 0.0) {
-    const double acc = seq_sum_skip(s_prod, m.x - base, m.y - base, m.z - base, 0.0);
-    const int i = r0 + tid;
-    a.x[i] = SOR ? (1.0 - a.omega) * a.x[i] + (a.omega / d) * (bb - acc) : (bb - acc) / d;
+#pragma unroll
+  for (int u = 0; u < TPT; ++u) {
+    if (tid + u * kSlot < ntask && d[u] != 0.0) {
+      const double acc = seq_sum_skip(s_prod + tq[u] * kSlot, m[u].x - base, m[u].y - base, m[u].z - base, 0.0);
+      double* xq = a.x + tq[u] * a.ldx;
+      const int i = r0 + tr[u];
+      xq[i] = SOR ? (1.0 - a.omega) * xq[i] + (a.omega / d[u]) * (bb[u] - acc) : (bb[u] - acc) / d[u];
+    }
   }
-  if (EPT > 1) {  // slots of very short rows: more rows than threads
-    for (int r = r0 + tid + T; r < r1; r += T) {
-      const i4_t m2 = a.wmeta[r];
-      const double d2 = a.diag[r];
-      if (d2 != 0.0) {
-        const double acc = seq_sum_skip(s_prod, m2.x - base, m2.y - base, m2.z - base, 0.0);
-        a.x[r] = SOR ? (1.0 - a.omega) * a.x[r] + (a.omega / d2) * (a.bp[r] - acc) : (a.bp[r] - acc) / d2;
-      }
+  for (int t = tid + TPT * kSlot; t < ntask; t += kSlot) {  // slots of very short rows: more tasks than 2 per thread
+    const int q = t / nrows, r = t - q * nrows;
+    const i4_t m2 = a.wmeta[r0 + r];
+    const double d2 = a.diag[r0 + r];
+    if (d2 != 0.0) {
+      const double acc = seq_sum_skip(s_prod + q * kSlot, m2.x - base, m2.y - base, m2.z - base, 0.0);
+      double* xq = a.x + q * a.ldx;
+      const int i = r0 + r;
+      const double bq = a.bp[i + q * a.ldb];
+      xq[i] = SOR ? (1.0 - a.omega) * xq[i] + (a.omega / d2) * (bq - acc) : (bq - acc) / d2;
     }
   }
 }

@@ -434,6 +434,11 @@ def test_multiple_right_hand_sides_all_sweep_kernels():
         # the same hierarchy still serves single-RHS calls (its scratch was grown, not replaced by a smaller one)
         x1 = AMG._solve(ml, B[:, 2].copy(), cycle, maxiter=3, calculate_residual=False)
         assert rel(x1, X[:, 2]) <= 1e-14
+        # wider blocks take the 8- and 2-columns-per-workgroup sweep kernels; same columns, same results
+        for reps in (2, 1.5):
+            Bw = np.concatenate([B] * 2, axis=1)[:, : int(4 * reps)]
+            Xw = AMG._solve(ml, Bw, cycle, maxiter=3, calculate_residual=False)
+            assert rel(Xw[:, :4], X) <= 1e-14 and rel(Xw[:, 4:], X[:, : Bw.shape[1] - 4]) <= 1e-14
 
 
 def test_eltype_promotion_contract():  # runtests.jl:244-259
