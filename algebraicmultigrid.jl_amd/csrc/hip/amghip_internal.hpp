@@ -1,0 +1,198 @@
+// amghip_internal.hpp — types and helpers shared by the host side of libamghip: error macros, device
+// allocation helpers, the Gauss-Seidel schedule (GsSchedule), the stand-alone CSR operator (amgh_csr), the
+// launch-shape tunables.  Included by amghip.hip only (one translation unit).
+#pragma once
+#include "amghip_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/amghip.h"
+
+using namespace amgh;
+
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return -(1000 + (int)e_);     \
+  } while (0)
+#define RC_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != AMGH_OK) return rc_; \
+  } while (0)
+
+namespace {
+
+template <class T>
+int dev_alloc(T** p, int64_t count) {
+  *p = nullptr;
+  if (count <= 0) count = 1;
+  hipError_t e = hipMalloc((void**)p, sizeof(T) * (size_t)count);
+  if (e == hipErrorOutOfMemory) return AMGH_ENOMEM;
+  if (e != hipSuccess) return -(1000 + (int)e);
+  return AMGH_OK;
+}
+template <class T>
+int dev_upload(T** p, const T* src, int64_t count) {
+  RC_TRY(dev_alloc(p, count));
+  if (count > 0) HIP_TRY(hipMemcpy(*p, src, sizeof(T) * (size_t)count, hipMemcpyHostToDevice));
+  return AMGH_OK;
+}
+inline int grid_for(int64_t n, int threads = 256) {
+  int64_t g = (n + threads - 1) / threads;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(g, 256 * 8));
+}
+
+// Gauss-Seidel dependency schedule of one square operator.
+struct GsSchedule {
+  int nlev = 0;
+  std::vector<int32_t> lvl_ptr;  // host, nlev+1
+  int32_t* d_lvl_ptr = nullptr;
+  // level-permuted copy of the smoother's matrix
+  int32_t* rowptr = nullptr;
+  int32_t* col = nullptr;
+  double* val = nullptr;
+  int32_t* perm = nullptr;
+  int32_t* dpos = nullptr;
+  double* diag = nullptr;
+  i4_t* rowmeta = nullptr;  // per permuted row {start, end, diagonal position, original row}
+  i4_t* desc = nullptr;     // per dependency level {first row, end row, first nnz, end nnz}
+  double* bp = nullptr;     // right-hand side in dependency-level order (scratch)
+  double* xp = nullptr;     // x in dependency-level order (scratch, ncols entries per right-hand-side column)
+  int cols_alloc = 1;       // right-hand-side columns bp / xp currently hold
+  int32_t* permx = nullptr; // perm extended by the identity over halo columns
+  int64_t n = 0, ncols = 0;
+  int64_t bytes = 0;
+  struct Seg { int l0, l1; bool chain; int rows; int slot0, nslots; };  // dependency levels [l0, l1); launch shape
+  std::vector<Seg> segs;
+  // slot layout of the wide levels (gs_slot_kernel)
+  int32_t* wcol = nullptr; double* wval = nullptr; int32_t* slot_row = nullptr; i4_t* wmeta = nullptr;
+  // block-inverse path (small, densely coupled operators; see gs_block_kernel)
+  struct Outer {
+    int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; double* tinv = nullptr;
+    int32_t* near_ptr = nullptr; i2_t* near_pi = nullptr; double* near_val = nullptr;  // see gs_block_pipe_kernel
+    // entries that reference blocks swept LATER (and the in-block other triangle): they read old x only, so
+    // b - O_next x is one full-chip residual launch before the sequential sweep
+    int32_t* nx_rowptr = nullptr; int32_t* nx_col = nullptr; double* nx_val = nullptr;
+    // entries that reference EARLIER superblocks: final once that superblock is done, applied to the rows of a
+    // superblock by one parallel launch before its sequential sweep
+    int32_t* sp_rowptr = nullptr; int32_t* sp_col = nullptr; double* sp_val = nullptr;
+  };
+  Outer blk_f, blk_b;
+  double* blk_diag = nullptr;
+  double* blk_s = nullptr;  // b - O_next x (n entries per right-hand-side column)
+  int nblk = 0;  // 0 = block path not used for this operator
+  int super = 0; // blocks per superblock (0: the whole operator is one superblock)
+  double blk_cond = 0.0;  // largest inf-norm condition estimate of an in-block triangle
+  void free_dev() {
+    for (Outer* o : {&blk_f, &blk_b}) {
+      hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv);
+      hipFree(o->near_ptr); hipFree(o->near_pi); hipFree(o->near_val);
+      hipFree(o->nx_rowptr); hipFree(o->nx_col); hipFree(o->nx_val);
+      hipFree(o->sp_rowptr); hipFree(o->sp_col); hipFree(o->sp_val);
+      *o = Outer();
+    }
+    hipFree(blk_diag); blk_diag = nullptr;
+    hipFree(blk_s); blk_s = nullptr;
+    hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
+    hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
+    hipFree(perm); hipFree(dpos); hipFree(diag); hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
+    d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = bp = xp = nullptr; rowmeta = desc = nullptr; permx = nullptr;
+  }
+};
+
+}  // namespace
+
+struct amgh_csr {
+  int device = 0;
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* col = nullptr;
+  double* val = nullptr;
+  // smoother metadata in natural row order (Jacobi), built on demand
+  int32_t* dpos = nullptr;
+  double* diag = nullptr;
+  GsSchedule* gs = nullptr;
+  int64_t bytes = 0;
+};
+
+namespace {
+
+// launch-shape tunables of the per-level Gauss-Seidel launches (amgh_debug_set_tunable)
+int g_gs_block_target = 256;   // aim for at least this many workgroups per wide level
+int g_gs_min_rows = 4;         // but never fewer rows per workgroup than this
+int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (one per thread)
+int g_gs_threads = 256;
+int g_gs_block_pipe = 1;        // software-pipelined block sweep (gs_block_pipe_kernel)
+int g_gs_super = 8;             // block-inverse sweeps: blocks per superblock (0 = one launch for the whole operator); read at schedule build
+int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
+int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
+int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)
+
+unsigned long long* g_chain_tim = nullptr;  // diagnostics buffer (amgh_debug_chain_timing)
+
+constexpr int kChainWidth = 1024;  // dependency levels at most this wide are chained
+
+__global__ void find_diag_kernel(const int32_t* rowptr, const int32_t* col, const double* val, int n,
+                                 int32_t* dpos, double* diag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int dp = -1;
+  double d = 0.0;
+  // the reference keeps the LAST matching entry (d = ifelse(i == row, val, d))
+  for (int j = rowptr[i]; j < rowptr[i + 1]; ++j)
+    if (col[j] == i) { dp = j; d = val[j]; }
+  dpos[i] = dp;
+  diag[i] = d;
+}
+
+int csr_upload(amgh_csr* op, int device, int64_t nrows, int64_t ncols, const int32_t* rowptr,
+               const int32_t* col, const double* val) {
+  if (nrows < 0 || ncols < 0 || !rowptr) return AMGH_EINVAL;
+  if (nrows >= INT32_MAX || ncols >= INT32_MAX) return AMGH_EUNSUPPORTED;
+  const int64_t nnz = rowptr[nrows];
+  if (rowptr[0] != 0 || nnz < 0) return AMGH_EINVAL;
+  if (nnz > 0 && (!col || !val)) return AMGH_EINVAL;
+  op->device = device;
+  op->nrows = nrows;
+  op->ncols = ncols;
+  op->nnz = nnz;
+  RC_TRY(dev_upload(&op->rowptr, rowptr, nrows + 1));
+  RC_TRY(dev_upload(&op->col, col, nnz));
+  RC_TRY(dev_upload(&op->val, val, nnz));
+  op->bytes = (nrows + 1) * 4 + nnz * 12;
+  return AMGH_OK;
+}
+
+void csr_free(amgh_csr* op) {
+  if (!op) return;
+  hipFree(op->rowptr); hipFree(op->col); hipFree(op->val);
+  hipFree(op->dpos); hipFree(op->diag);
+  if (op->gs) { op->gs->free_dev(); delete op->gs; }
+  op->rowptr = op->col = op->dpos = nullptr; op->val = op->diag = nullptr; op->gs = nullptr;
+}
+
+int csr_ensure_diag(amgh_csr* op, hipStream_t st) {
+  if (op->dpos) return AMGH_OK;
+  const int64_t n = std::min(op->nrows, op->ncols);
+  RC_TRY(dev_alloc(&op->dpos, op->nrows));
+  RC_TRY(dev_alloc(&op->diag, op->nrows));
+  if (n < op->nrows) {
+    HIP_TRY(hipMemsetAsync(op->dpos, 0xff, sizeof(int32_t) * op->nrows, st));
+    HIP_TRY(hipMemsetAsync(op->diag, 0, sizeof(double) * op->nrows, st));
+  }
+  if (n > 0)
+    hipLaunchKernelGGL(find_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op->rowptr, op->col,
+                       op->val, (int)n, op->dpos, op->diag);
+  HIP_TRY(hipGetLastError());
+  op->bytes += op->nrows * 12;
+  return AMGH_OK;
+}
+
+
+}  // namespace

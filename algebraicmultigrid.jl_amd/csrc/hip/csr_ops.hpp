@@ -1,0 +1,229 @@
+// csr_ops.hpp — launches on one CSR operator: SpMV / residual / add / Jacobi (csr_stream_kernel) and the
+// Gauss-Seidel / SOR sweeps (slot, chain, block-inverse and stream kernels).  Included by amghip.hip.
+#pragma once
+
+namespace {
+
+
+template <int MODE, class CFG = DefaultCfg>
+int launch_stream(const StreamArgs& a0, hipStream_t st, int ncolv = 1) {
+  const int nrows = a0.row_end - a0.row_begin;
+  if (nrows <= 0) return AMGH_OK;
+  StreamArgs a = a0;
+  a.ncolv = ncolv;
+  const int nb = (nrows + CFG::ROWS - 1) / CFG::ROWS;
+  // multi-column launches: tiles padded to a multiple of 8, times ncolv (multi_column_block)
+  const int64_t grid = (CFG::XCD || ncolv > 1) ? (int64_t)((nb + kNumXcd - 1) / kNumXcd) * kNumXcd * ncolv : nb;
+  hipLaunchKernelGGL((csr_stream_kernel<MODE, CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+
+// One dependency level of a Gauss-Seidel / SOR sweep: a latency-bound launch, so the
+// rows are spread over many small workgroups (rows per workgroup chosen at schedule
+// build time from the level's average row length).
+template <int MODE>
+int launch_gs_level(const StreamArgs& a, int rows, hipStream_t st, int ncolv = 1) {
+  // latency-bound launch: prefer many small workgroups over few full ones — a CU's
+  // texture-address unit serialises the x gathers of all its waves
+  // `avg16` = 16 x the level's mean row length (schedule build time).  Measured on MI355X
+  // (tools/gs_tune.py): about one nonzero per thread is the fastest shape at every level.
+  const int width = a.row_end - a.row_begin;
+  const int avg16 = std::max(16, rows);
+  rows = 256;
+  while (rows > g_gs_min_rows && (int64_t)rows * avg16 > (int64_t)g_gs_nnz_per_wg * 16) rows >>= 1;
+  while (rows > g_gs_min_rows && width / rows < g_gs_block_target && (int64_t)rows * avg16 > 16 * 64) rows >>= 1;
+  if (g_gs_threads == 64) {
+    switch (rows) {
+      case 8: return launch_stream<MODE, StreamCfg<64, 8, 2048, 1, false, false>>(a, st, ncolv);
+      case 16: return launch_stream<MODE, StreamCfg<64, 16, 2048, 1, false, false>>(a, st, ncolv);
+      case 32: return launch_stream<MODE, StreamCfg<64, 32, 2048, 1, false, false>>(a, st, ncolv);
+      case 64: return launch_stream<MODE, StreamCfg<64, 64, 2048, 1, false, false>>(a, st, ncolv);
+      default: break;
+    }
+  }
+  switch (rows) {
+    case 4: return launch_stream<MODE, StreamCfg<256, 4, 2048, 1, false, false>>(a, st, ncolv);
+    case 8: return launch_stream<MODE, StreamCfg<256, 8, 2048, 1, false, false>>(a, st, ncolv);
+    case 16: return launch_stream<MODE, StreamCfg<256, 16, 2048, 1, false, false>>(a, st, ncolv);
+    case 32: return launch_stream<MODE, StreamCfg<256, 32, 2048, 1, false, false>>(a, st, ncolv);
+    case 64: return launch_stream<MODE, StreamCfg<256, 64, 2048, 1, false, false>>(a, st, ncolv);
+    case 128: return launch_stream<MODE, StreamCfg<256, 128, 2048, 1, false, false>>(a, st, ncolv);
+    default: return launch_stream<MODE, StreamCfg<256, 256, 2048, 2, false, false>>(a, st, ncolv);
+  }
+}
+
+// ncolv right-hand-side columns (x: ncols apart, y and b: nrows apart) in one launch
+int csr_apply(const amgh_csr* op, int mode, const double* x, const double* b, double* y, hipStream_t st,
+              int ncolv = 1) {
+  StreamArgs a{};
+  a.rowptr = op->rowptr; a.col = op->col; a.val = op->val;
+  a.x = x; a.y = y; a.b = b;
+  a.row_begin = 0; a.row_end = (int32_t)op->nrows;
+  a.ldx = op->ncols; a.ldy = op->nrows; a.ldb = op->nrows;
+  switch (mode) {
+    case M_SPMV: return launch_stream<M_SPMV>(a, st, ncolv);
+    case M_RESID: return launch_stream<M_RESID>(a, st, ncolv);
+    case M_ADD: return launch_stream<M_ADD>(a, st, ncolv);
+  }
+  return AMGH_EINVAL;
+}
+
+int csr_jacobi(amgh_csr* op, double omega, const double* xin, const double* b, double* xout, hipStream_t st,
+               int ncolv = 1) {
+  RC_TRY(csr_ensure_diag(op, st));
+  StreamArgs a{};
+  a.rowptr = op->rowptr; a.col = op->col; a.val = op->val;
+  a.x = xin; a.y = xout; a.b = b; a.dpos = op->dpos; a.diag = op->diag; a.omega = omega;
+  a.row_begin = 0; a.row_end = (int32_t)op->nrows;
+  a.ldx = op->ncols; a.ldy = op->nrows; a.ldb = op->nrows;
+  return launch_stream<M_JACOBI>(a, st, ncolv);
+}
+
+template <int T, int PF>
+int launch_chain_t(const ChainArgs& c, bool sor, bool ldsx, int nx, hipStream_t st, int ncolv) {
+  if (sor && ldsx) hipLaunchKernelGGL((gs_chain_kernel<true, true, T, PF>), dim3(ncolv), dim3(T), 0, st, c, nx);
+  else if (sor) hipLaunchKernelGGL((gs_chain_kernel<true, false, T, PF>), dim3(ncolv), dim3(T), 0, st, c, nx);
+  else if (ldsx) hipLaunchKernelGGL((gs_chain_kernel<false, true, T, PF>), dim3(ncolv), dim3(T), 0, st, c, nx);
+  else hipLaunchKernelGGL((gs_chain_kernel<false, false, T, PF>), dim3(ncolv), dim3(T), 0, st, c, nx);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+// threads = workgroup size class of the segment (64 / 256 / 1024), see gs_build
+int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, hipStream_t st, int ncolv) {
+  switch (threads) {
+    case 64: return launch_chain_t<64, 4>(c, sor, ldsx, nx, st, ncolv);
+    case 256: return launch_chain_t<256, 4>(c, sor, ldsx, nx, st, ncolv);
+    default: return launch_chain_t<1024, 4>(c, sor, ldsx, nx, st, ncolv);  // PF = 8 spills at 1024 threads (128 VGPRs)
+  }
+}
+
+template <int NCV>
+int launch_slot_t(const SlotArgs& sa, bool sor, int grid, hipStream_t st) {
+  if (sor) hipLaunchKernelGGL((gs_slot_kernel<true, NCV>), dim3(grid), dim3(kSlot), 0, st, sa);
+  else hipLaunchKernelGGL((gs_slot_kernel<false, NCV>), dim3(grid), dim3(kSlot), 0, st, sa);
+  return AMGH_OK;
+}
+int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st) {
+  switch (ncv) {
+    case 8: return launch_slot_t<8>(sa, sor, grid, st);
+    case 4: return launch_slot_t<4>(sa, sor, grid, st);
+    case 2: return launch_slot_t<2>(sa, sor, grid, st);
+    default: return launch_slot_t<1>(sa, sor, grid, st);
+  }
+}
+
+// One Gauss-Seidel / SOR sweep, forward or backward, exact lexicographic order.
+// first: gather b and x into dependency-level order (once per smooth! call);
+// last: scatter x back to natural order.  Between the two x lives in g->xp.
+// ncolv > 1: x (ncols apart) and b (nrows apart) hold ncolv independent right-hand-side columns; every launch
+// covers all of them (gridDim.y, or one workgroup per column in the single-workgroup kernels), so a block of
+// right-hand sides costs the dependency-level latency chain once.
+int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st,
+                 bool first = true, bool last = true, int ncolv = 1) {
+  RC_TRY(csr_ensure_gs(op));
+  GsSchedule* g = op->gs;
+  if (g->n <= 0) return AMGH_OK;
+  if (ncolv > g->cols_alloc) {  // grow the per-column scratch (first block solve on this operator)
+    HIP_TRY(hipStreamSynchronize(st));
+    hipFree(g->bp); hipFree(g->xp); g->bp = g->xp = nullptr;
+    RC_TRY(dev_alloc(&g->bp, g->n * ncolv));
+    RC_TRY(dev_alloc(&g->xp, g->ncols * ncolv));
+    int64_t grown = 8 * (g->n + g->ncols) * (ncolv - g->cols_alloc);
+    if (g->blk_s) {
+      hipFree(g->blk_s); g->blk_s = nullptr;
+      RC_TRY(dev_alloc(&g->blk_s, g->n * ncolv));
+      grown += 8 * g->n * (ncolv - g->cols_alloc);
+    }
+    g->bytes += grown;
+    op->bytes += grown;
+    g->cols_alloc = ncolv;
+  }
+  if (g->nblk > 0 && g_gs_block_inverse && !sor) {
+    // small densely coupled operator: n/128 sequential block steps in natural row order
+    BlockArgs ba{};
+    const GsSchedule::Outer& o = backward ? g->blk_b : g->blk_f;
+    ba.rowptr = o.rowptr; ba.col = o.col; ba.val = o.val; ba.tinv = o.tinv; ba.diag = g->blk_diag;
+    {  // s = b - O_next x: every entry read here keeps its old value during this sweep
+      StreamArgs ra{};
+      ra.rowptr = o.nx_rowptr; ra.col = o.nx_col; ra.val = o.nx_val;
+      ra.x = x; ra.b = b; ra.y = g->blk_s;
+      ra.row_begin = 0; ra.row_end = (int32_t)g->n;
+      ra.ldx = g->n; ra.ldy = g->n; ra.ldb = g->n;
+      // few, long rows: 64 rows per workgroup so that the launch still covers the chip
+      RC_TRY((launch_stream<M_RESID, StreamCfg<256, 64, 4096, 2, false, false>>(ra, st, ncolv)));
+    }
+    ba.x = x; ba.b = g->blk_s; ba.n = (int32_t)g->n; ba.backward = backward ? 1 : 0;
+    ba.ld = g->n;  // block path: square operator, x and b in natural order
+    ba.tim = g_chain_tim;
+    ba.near_ptr = o.near_ptr; ba.near_pi = o.near_pi; ba.near_val = o.near_val;
+    const int S = g->super > 0 ? g->super : g->nblk;
+    const int nsuper = (g->nblk + S - 1) / S;
+    for (int q = 0; q < nsuper; ++q) {
+      const int J = backward ? nsuper - 1 - q : q;
+      ba.blk0 = J * S;
+      ba.nblk = std::min(S, g->nblk - ba.blk0);
+      if (q > 0) {  // s -= O_sp x on this superblock's rows: every superblock swept so far is final
+        StreamArgs pa{};
+        pa.rowptr = o.sp_rowptr; pa.col = o.sp_col; pa.val = o.sp_val;
+        pa.x = x; pa.b = g->blk_s; pa.y = g->blk_s;
+        pa.row_begin = ba.blk0 * kBlk; pa.row_end = (int32_t)std::min<int64_t>(g->n, (int64_t)(ba.blk0 + ba.nblk) * kBlk);
+        pa.ldx = g->n; pa.ldy = g->n; pa.ldb = g->n;
+        RC_TRY((launch_stream<M_RESID, StreamCfg<256, 16, 2048, 2, false, false>>(pa, st, ncolv)));
+      }
+      if (g_gs_block_pipe) hipLaunchKernelGGL(gs_block_pipe_kernel, dim3(ncolv), dim3(kPipeThreads), 0, st, ba);
+      else hipLaunchKernelGGL(gs_block_kernel, dim3(ncolv), dim3(kBlkThreads), 0, st, ba);
+    }
+    HIP_TRY(hipGetLastError());
+    return AMGH_OK;
+  }
+  if (first) {
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n,
+                       (int64_t)g->n, (int64_t)g->n);
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const double*)x, g->permx,
+                       g->xp, (int)g->ncols, (int64_t)g->ncols, (int64_t)g->ncols);
+    HIP_TRY(hipGetLastError());
+  }
+  double* xp = g->xp;
+  const int ns = (int)g->segs.size();
+  for (int k = 0; k < ns; ++k) {
+    const GsSchedule::Seg& s = g->segs[backward ? ns - 1 - k : k];
+    if (s.chain) {
+      ChainArgs c{};
+      c.col = g->col; c.val = g->val; c.x = xp; c.bp = g->bp; c.diag = g->diag;
+      c.rowmeta = g->rowmeta; c.desc = g->desc; c.omega = omega; c.tim = g_chain_tim;
+      if (!backward) { c.lvl_begin = s.l0; c.lvl_end = s.l1; c.step = 1; }
+      else { c.lvl_begin = s.l1 - 1; c.lvl_end = s.l0 - 1; c.step = -1; }
+      c.ldx = g->ncols; c.ldb = g->n;
+      const bool ldsx = g->ncols <= kChainLdsX;  // x (halo included) fits LDS
+      RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)g->ncols, st, ncolv));
+    } else if (s.nslots > 0 && g_gs_slots) {
+      SlotArgs sa{};
+      sa.wcol = g->wcol; sa.wval = g->wval; sa.slot_row = g->slot_row; sa.wmeta = g->wmeta;
+      sa.diag = g->diag; sa.bp = g->bp; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;
+      sa.nslots = s.nslots; sa.xcd_map = g_gs_xcd_map;
+      sa.ldx = g->ncols; sa.ldb = g->n;
+      // columns per workgroup: the largest of 8 / 4 / 2 / 1 that divides the block size
+      const int ncv = (ncolv % 8 == 0) ? 8 : (ncolv % 4 == 0) ? 4 : (ncolv % 2 == 0) ? 2 : 1;
+      sa.ncolv = ncolv / ncv;
+      const int grid = ((g_gs_xcd_map || sa.ncolv > 1) ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots) * sa.ncolv;
+      RC_TRY(launch_slot(sa, sor, ncv, grid, st));
+      HIP_TRY(hipGetLastError());
+    } else {
+      StreamArgs a{};
+      a.rowptr = g->rowptr; a.col = g->col; a.val = g->val;
+      a.x = xp; a.y = xp; a.b = g->bp; a.dpos = g->dpos; a.diag = g->diag; a.perm = nullptr; a.omega = omega;
+      a.row_begin = g->lvl_ptr[s.l0]; a.row_end = g->lvl_ptr[s.l0 + 1];
+      a.ldx = g->ncols; a.ldy = g->ncols; a.ldb = g->n;
+      RC_TRY(sor ? launch_gs_level<M_SOR>(a, s.rows, st, ncolv) : launch_gs_level<M_GS>(a, s.rows, st, ncolv));
+    }
+  }
+  if (last) {
+    hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const double*)xp, g->perm, x,
+                       (int)g->n, (int64_t)g->ncols, (int64_t)g->n);
+    HIP_TRY(hipGetLastError());
+  }
+  return AMGH_OK;
+}
+
+}  // namespace

@@ -1,0 +1,327 @@
+// gs_schedule.hpp — host-side construction of the Gauss-Seidel / SOR execution schedule of one operator:
+// dependency levels on the symmetrised pattern, the level-permuted matrix copy, chain segments, slot layout,
+// and the block-inverse data (in-block inverted triangles, old-x part, earlier-superblock part, near lists).
+// Included by amghip.hip after amghip_internal.hpp.
+#pragma once
+
+namespace {
+
+// Block-inverse data of one sweep direction: the outer matrix (operator minus the in-block triangle
+// and diagonal) and the dense inverses of the in-block triangles.
+int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n, const int32_t* rowptr, const int32_t* col,
+                      const double* val, const std::vector<double>& diag, double* max_cond) {
+  const int B = kBlk;
+  const int nblk = (int)((n + B - 1) / B);
+  std::vector<int32_t> orow(n + 1, 0), ocol, xrow(n + 1, 0), xcol, prow(n + 1, 0), pcol;
+  std::vector<double> oval, xval, pval;
+  ocol.reserve(rowptr[n]); oval.reserve(rowptr[n]);
+  xcol.reserve(rowptr[n]); xval.reserve(rowptr[n]);
+  std::vector<double> tinv((size_t)nblk * B * B, 0.0), T((size_t)B * B);
+  // near list: outer entries of a block that reference the block swept just before it (blk - 1 forward, blk + 1
+  // backward), as {position in the block's outer range, column - first row of that block} + value
+  std::vector<int32_t> near_ptr(nblk + 1, 0);
+  std::vector<i2_t> near_pi;
+  std::vector<double> near_val;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int64_t i0 = (int64_t)blk * B, i1 = std::min<int64_t>(i0 + B, n);
+    const int64_t q0 = backward ? i0 + B : i0 - B;  // first row of the previously swept block
+    // rows of this block's superblock: [s0, s1)
+    const int64_t sb = super > 0 ? blk / super : 0;
+    const int64_t s0 = super > 0 ? sb * super * B : 0, s1 = super > 0 ? std::min<int64_t>(n, (sb + 1) * super * B) : n;
+    const size_t blk_first = ocol.size();
+    std::fill(T.begin(), T.end(), 0.0);
+    for (int64_t i = i0; i < i1; ++i) {
+      const bool skip = diag[i] == 0.0;  // row without a usable diagonal keeps its x: T row = e_i
+      for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+        const int32_t c = col[j];
+        const bool in_tri = c >= i0 && c < i1 && (backward ? c >= i : c <= i);
+        if (in_tri) {
+          if (!skip) T[(size_t)(i - i0) * B + (c - i0)] += val[j];
+        } else if (!skip && (c >= i0 && c < i1 ? true : (backward ? c < i0 : c >= i1))) {
+          xcol.push_back(c); xval.push_back(val[j]);  // old x: in-block other triangle, or a block swept later
+        } else if (!skip && (c < s0 || c >= s1)) {
+          pcol.push_back(c); pval.push_back(val[j]);  // an earlier superblock
+        } else if (!skip) {
+          if (c >= q0 && c < q0 + B) {
+            near_pi.push_back(i2_t{(int32_t)(ocol.size() - blk_first), (int32_t)(c - q0)});
+            near_val.push_back(val[j]);
+          }
+          ocol.push_back(c); oval.push_back(val[j]);
+        }
+      }
+      if (skip) T[(size_t)(i - i0) * B + (i - i0)] = 1.0;
+      orow[i + 1] = (int32_t)ocol.size();
+      xrow[i + 1] = (int32_t)xcol.size();
+      prow[i + 1] = (int32_t)pcol.size();
+    }
+    near_ptr[blk + 1] = (int32_t)near_pi.size();
+    for (int64_t i = i1; i < i0 + B; ++i) T[(size_t)(i - i0) * B + (i - i0)] = 1.0;  // padding rows
+    // invert the triangle column by column (forward / backward substitution on the identity)
+    double* X = tinv.data() + (size_t)blk * B * B;
+    for (int c = 0; c < B; ++c) {
+      if (!backward) {
+        for (int i = c; i < B; ++i) {
+          double s = (i == c) ? 1.0 : 0.0;
+          for (int j = c; j < i; ++j) s -= T[(size_t)i * B + j] * X[(size_t)j * B + c];
+          X[(size_t)i * B + c] = s / T[(size_t)i * B + i];
+        }
+      } else {
+        for (int i = c; i >= 0; --i) {
+          double s = (i == c) ? 1.0 : 0.0;
+          for (int j = i + 1; j <= c; ++j) s -= T[(size_t)i * B + j] * X[(size_t)j * B + c];
+          X[(size_t)i * B + c] = s / T[(size_t)i * B + i];
+        }
+      }
+    }
+    // inf-norm condition estimate of the triangle: an explicit inverse is only as accurate as
+    // cond(T) * eps, the caller falls back to the exact-order sweeps when a block is badly conditioned
+    double nt = 0.0, nx = 0.0;
+    for (int i = 0; i < B; ++i) {
+      double rt = 0.0, rx = 0.0;
+      for (int j = 0; j < B; ++j) { rt += std::fabs(T[(size_t)i * B + j]); rx += std::fabs(X[(size_t)i * B + j]); }
+      nt = std::max(nt, rt); nx = std::max(nx, rx);
+    }
+    const double cond = nt * nx;
+    if (!(cond <= *max_cond)) *max_cond = std::isfinite(cond) ? cond : 1e300;
+  }
+  RC_TRY(dev_upload(&o->rowptr, orow.data(), n + 1));
+  RC_TRY(dev_upload(&o->col, ocol.data(), (int64_t)ocol.size()));
+  RC_TRY(dev_upload(&o->val, oval.data(), (int64_t)oval.size()));
+  RC_TRY(dev_upload(&o->tinv, tinv.data(), (int64_t)tinv.size()));
+  RC_TRY(dev_upload(&o->near_ptr, near_ptr.data(), (int64_t)near_ptr.size()));
+  RC_TRY(dev_upload(&o->near_pi, near_pi.data(), (int64_t)near_pi.size()));
+  RC_TRY(dev_upload(&o->near_val, near_val.data(), (int64_t)near_val.size()));
+  RC_TRY(dev_upload(&o->nx_rowptr, xrow.data(), n + 1));
+  RC_TRY(dev_upload(&o->nx_col, xcol.data(), (int64_t)xcol.size()));
+  RC_TRY(dev_upload(&o->nx_val, xval.data(), (int64_t)xval.size()));
+  RC_TRY(dev_upload(&o->sp_rowptr, prow.data(), n + 1));
+  RC_TRY(dev_upload(&o->sp_col, pcol.data(), (int64_t)pcol.size()));
+  RC_TRY(dev_upload(&o->sp_val, pval.data(), (int64_t)pval.size()));
+  return AMGH_OK;
+}
+
+// Build the dependency-level schedule from HOST arrays of the smoother matrix.
+int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
+             const double* val) {
+  const int64_t n = nrows;
+  std::vector<int32_t> lev(n, 0);
+  int32_t maxlev = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t li = lev[i];
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t c = col[j];
+      if (c < i) li = std::max(li, lev[c] + 1);
+    }
+    lev[i] = li;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t c = col[j];
+      if (c > i && c < n) lev[c] = std::max(lev[c], li + 1);
+    }
+    maxlev = std::max(maxlev, li);
+  }
+  g->nlev = (int)(maxlev + 1);
+  g->lvl_ptr.assign(g->nlev + 1, 0);
+  for (int64_t i = 0; i < n; ++i) g->lvl_ptr[lev[i] + 1]++;
+  for (int l = 0; l < g->nlev; ++l) g->lvl_ptr[l + 1] += g->lvl_ptr[l];
+  std::vector<int32_t> perm(n), next(g->lvl_ptr.begin(), g->lvl_ptr.end() - (g->nlev > 0 ? 1 : 0));
+  if (g->nlev == 0) next.clear();
+  for (int64_t i = 0; i < n; ++i) perm[next[lev[i]]++] = (int32_t)i;  // ascending row id inside a level
+  std::vector<int32_t>().swap(lev);
+  // x is kept in dependency-level order during the sweeps: position p holds x[perm[p]]; columns
+  // beyond the square block (halo entries of a sharded operator) keep their place.  Each level
+  // then reads and writes contiguous stretches of x (coalesced, TLB-friendly) instead of a
+  // hyperplane scattered over the whole vector.
+  std::vector<int32_t> inv(std::max<int64_t>(ncols, n));
+  for (int64_t c = 0; c < (int64_t)inv.size(); ++c) inv[c] = (int32_t)c;
+  for (int64_t p2 = 0; p2 < n; ++p2) inv[perm[p2]] = (int32_t)p2;
+  const int64_t nnz = rowptr[n];
+  std::vector<int32_t> prow(n + 1), pcol(nnz), pdpos(n);
+  std::vector<double> pval(nnz), pdiag(n);
+  int64_t w = 0;
+  prow[0] = 0;
+  for (int64_t p = 0; p < n; ++p) {
+    const int32_t i = perm[p];
+    int32_t dp = -1;
+    double d = 0.0;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      pcol[w] = inv[col[j]];   // entries stay in the row's original column order (sum order)
+      pval[w] = val[j];
+      if (col[j] == i) { dp = (int32_t)w; d = val[j]; }
+      ++w;
+    }
+    prow[p + 1] = (int32_t)w;
+    pdpos[p] = dp;
+    pdiag[p] = d;
+  }
+  RC_TRY(dev_upload(&g->rowptr, prow.data(), n + 1));
+  RC_TRY(dev_upload(&g->col, pcol.data(), nnz));
+  RC_TRY(dev_upload(&g->val, pval.data(), nnz));
+  RC_TRY(dev_upload(&g->perm, perm.data(), n));
+  RC_TRY(dev_upload(&g->dpos, pdpos.data(), n));
+  RC_TRY(dev_upload(&g->diag, pdiag.data(), n));
+  RC_TRY(dev_upload(&g->d_lvl_ptr, g->lvl_ptr.data(), g->nlev + 1));
+  {
+    std::vector<i4_t> meta(n), desc(g->nlev);
+    for (int64_t p = 0; p < n; ++p) meta[p] = i4_t{prow[p], prow[p + 1], pdpos[p], perm[p]};
+    for (int l = 0; l < g->nlev; ++l)
+      desc[l] = i4_t{g->lvl_ptr[l], g->lvl_ptr[l + 1], prow[g->lvl_ptr[l]], prow[g->lvl_ptr[l + 1]]};
+    RC_TRY(dev_upload(&g->rowmeta, meta.data(), n));
+    RC_TRY(dev_upload(&g->desc, desc.data(), g->nlev));
+  }
+  RC_TRY(dev_alloc(&g->bp, n));
+  g->ncols = std::max<int64_t>(ncols, n);
+  RC_TRY(dev_alloc(&g->xp, g->ncols));
+  {
+    std::vector<int32_t> permx(g->ncols);
+    for (int64_t c = 0; c < g->ncols; ++c) permx[c] = c < n ? perm[c] : (int32_t)c;
+    RC_TRY(dev_upload(&g->permx, permx.data(), g->ncols));
+  }
+  g->n = n;
+  g->bytes = (n + 1) * 4 + nnz * 12 + n * 16 + (g->nlev + 1) * 4 + n * 24 + g->nlev * 16 + g->ncols * 12;
+  // Block-inverse path: worth it when level scheduling has degenerated (many more dependency levels
+  // than index blocks) and the dense blocks stay small.
+  {
+    const int nblk = (int)((n + kBlk - 1) / kBlk);
+    if (n >= 16 && n <= 262144 && g->nlev >= 3 * nblk) {
+      std::vector<double> dg(n, 0.0);
+      for (int64_t i = 0; i < n; ++i)
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
+          if (col[j] == i) dg[i] = val[j];
+      double max_cond = 0.0;
+      g->super = (g_gs_super > 0 && nblk > g_gs_super) ? g_gs_super : 0;
+      RC_TRY(blockgs_build_dir(&g->blk_f, false, g->super, n, rowptr, col, val, dg, &max_cond));
+      RC_TRY(blockgs_build_dir(&g->blk_b, true, g->super, n, rowptr, col, val, dg, &max_cond));
+      RC_TRY(dev_upload(&g->blk_diag, dg.data(), n));
+      RC_TRY(dev_alloc(&g->blk_s, n));
+      g->blk_cond = max_cond;
+      if (getenv("AMGH_VERBOSE"))
+        fprintf(stderr, "[amghip] n=%lld dependency levels=%d index blocks=%d max triangle cond=%.3g -> %s\n", (long long)n,
+                g->nlev, nblk, max_cond, max_cond <= 1e4 ? "block-inverse sweeps" : "exact-order sweeps");
+      // explicit triangle inverses lose ~cond * eps: keep the 1e-10 contract with margin
+      if (max_cond <= 1e4) {
+        g->nblk = nblk;
+        g->bytes += 2 * ((int64_t)nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4) + n * 8;
+      }
+    }
+  }
+  // segments: runs of narrow dependency levels are chained in one workgroup
+  // A dependency level is chained (stays inside one workgroup) when it has at most
+  // one row per thread and its products fit one LDS pass; anything larger is worth
+  // a launch of its own that spreads over the CUs.
+  auto narrow = [&](int lv) {
+    const int width = g->lvl_ptr[lv + 1] - g->lvl_ptr[lv];
+    const int lnnz = prow[g->lvl_ptr[lv + 1]] - prow[g->lvl_ptr[lv]];
+    return width <= kChainWidth && lnnz <= kChainLds;
+  };
+  // workgroup size class of a chained level: the smallest of 64 / 256 / 1024 threads with one
+  // thread per row and at most ~4 nonzeros per thread (the per-level loop is instruction-issue bound:
+  // more threads = the level's nonzeros spread over all four SIMDs of the CU)
+  auto chain_class = [&](int lv) {
+    const int width = g->lvl_ptr[lv + 1] - g->lvl_ptr[lv];
+    const int lnnz = prow[g->lvl_ptr[lv + 1]] - prow[g->lvl_ptr[lv]];
+    if (width <= 64 && lnnz <= 64 * 4) return 64;
+    if (width <= 256 && lnnz <= 256 * 4) return 256;
+    return 1024;
+  };
+  g->segs.clear();
+  int l = 0;
+  while (l < g->nlev) {
+    if (narrow(l)) {
+      // a segment = run of chained levels of one class; a class change only starts a new launch if
+      // the new run is long enough to pay for it (each launch costs a few microseconds)
+      int e = l + 1;
+      int cls = chain_class(l);
+      while (e < g->nlev && narrow(e)) {
+        const int ce = chain_class(e);
+        if (ce != cls) {
+          int run = 1;  // length of the run of class ce starting at e
+          while (e + run < g->nlev && narrow(e + run) && chain_class(e + run) == ce && run < 16) ++run;
+          if (ce < cls && run < 16) { ++e; continue; }   // short dip to a smaller class: absorb it
+          if (ce > cls && e - l < 16) { cls = ce; ++e; continue; }  // short prefix: promote the segment
+          break;
+        }
+        ++e;
+      }
+      g->segs.push_back({l, e, true, cls, 0, 0});
+      l = e;
+    } else {
+      // rows per workgroup for this level's launch: about one LDS pass of products per
+      // workgroup, as many workgroups as the level can feed (the launch is latency-bound)
+      const int width = g->lvl_ptr[l + 1] - g->lvl_ptr[l];
+      const int lnnz = prow[g->lvl_ptr[l + 1]] - prow[g->lvl_ptr[l]];
+      const double avg = std::max(1.0, (double)lnnz / width);
+      g->segs.push_back({l, l + 1, false, (int)std::min(1e6, avg * 16.0), 0, -1});  // 16 x mean row length
+      ++l;
+    }
+  }
+  // slot layout for the wide levels whose rows all fit a slot
+  {
+    std::vector<int32_t> wcol, slot_row;
+    std::vector<double> wval;
+    std::vector<i4_t> wmeta(n, i4_t{0, 0, -1, 0});
+    for (auto& sg : g->segs) {
+      if (sg.chain) continue;
+      const int ra = g->lvl_ptr[sg.l0], rb = g->lvl_ptr[sg.l0 + 1];
+      bool fits = true;
+      for (int p2 = ra; p2 < rb && fits; ++p2) fits = prow[p2 + 1] - prow[p2] <= kSlot;
+      if (!fits) continue;
+      sg.slot0 = (int)slot_row.size();
+      int fill = kSlot;  // force a new slot for the level's first row
+      for (int p2 = ra; p2 < rb; ++p2) {
+        const int len = prow[p2 + 1] - prow[p2];
+        if (fill + len > kSlot) {  // open a new slot (pad the previous one)
+          wcol.resize(slot_row.size() * (size_t)kSlot, 0);
+          wval.resize(slot_row.size() * (size_t)kSlot, 0.0);
+          slot_row.push_back(p2);
+          fill = 0;
+        }
+        const int32_t start = (int32_t)((slot_row.size() - 1) * (size_t)kSlot + fill);
+        for (int32_t j = prow[p2]; j < prow[p2 + 1]; ++j) { wcol.push_back(pcol[j]); wval.push_back(pval[j]); }
+        wmeta[p2] = i4_t{start, start + len, pdpos[p2] >= 0 ? start + (pdpos[p2] - prow[p2]) : -1, 0};
+        fill += len;
+      }
+      sg.nslots = (int)slot_row.size() - sg.slot0;
+    }
+    if (!slot_row.empty()) {
+      wcol.resize(slot_row.size() * (size_t)kSlot, 0);
+      wval.resize(slot_row.size() * (size_t)kSlot, 0.0);
+      // slot_row[s + 1] must close the last slot of every level: append per-level end markers by
+      // storing, for each slot, its end row in a parallel array packed as slot_row2
+      std::vector<int32_t> sr2(2 * slot_row.size());
+      for (auto& sg : g->segs) {
+        if (sg.chain || sg.nslots <= 0) continue;
+        for (int q = 0; q < sg.nslots; ++q) {
+          const int sidx = sg.slot0 + q;
+          sr2[2 * sidx] = slot_row[sidx];
+          sr2[2 * sidx + 1] = (q + 1 < sg.nslots) ? slot_row[sidx + 1] : g->lvl_ptr[sg.l0 + 1];
+        }
+      }
+      RC_TRY(dev_upload(&g->wcol, wcol.data(), (int64_t)wcol.size()));
+      RC_TRY(dev_upload(&g->wval, wval.data(), (int64_t)wval.size()));
+      RC_TRY(dev_upload(&g->slot_row, sr2.data(), (int64_t)sr2.size()));
+      RC_TRY(dev_upload(&g->wmeta, wmeta.data(), n));
+      g->bytes += (int64_t)wcol.size() * 12 + (int64_t)sr2.size() * 4 + n * 16;
+    }
+  }
+  return AMGH_OK;
+}
+
+int csr_ensure_gs(amgh_csr* op) {
+  if (op->gs) return AMGH_OK;
+  const int64_t n = op->nrows;
+  std::vector<int32_t> rowptr(n + 1), col(op->nnz);
+  std::vector<double> val(op->nnz);
+  HIP_TRY(hipMemcpy(rowptr.data(), op->rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
+  if (op->nnz) {
+    HIP_TRY(hipMemcpy(col.data(), op->col, sizeof(int32_t) * op->nnz, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(val.data(), op->val, sizeof(double) * op->nnz, hipMemcpyDeviceToHost));
+  }
+  GsSchedule* g = new GsSchedule;
+  int rc = gs_build(g, n, op->ncols, rowptr.data(), col.data(), val.data());
+  if (rc != AMGH_OK) { g->free_dev(); delete g; return rc; }
+  op->gs = g;
+  op->bytes += g->bytes;
+  return AMGH_OK;
+}
+
+}  // namespace
