@@ -89,7 +89,20 @@ struct GsSchedule {
   int nblk = 0;  // 0 = block path not used for this operator
   int super = 0; // blocks per superblock (0: the whole operator is one superblock)
   double blk_cond = 0.0;  // largest inf-norm condition estimate of an in-block triangle
+  // merged-level sweeps (gs_schedule.hpp, merge_build): per direction a child schedule over GROUPS of consecutive
+  // dependency levels whose rows were made independent by substitution, plus the other triangle as a plain CSR
+  // for the pre-pass s = b - T x.  Children share perm / bp / xp with this schedule; xp is then laid out as
+  // [x in level order (ncols) ; s (n)] per right-hand-side column (xstride doubles apart).
+  GsSchedule* mf = nullptr;
+  GsSchedule* mb = nullptr;
+  struct Tri { int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; };
+  Tri tri_f, tri_b;       // forward pre-pass: entries of later levels + halo; backward: earlier levels + halo
+  int merge_f = 1, merge_b = 1;  // dependency levels per group
+  int64_t xstride = 0;    // doubles per column of xp (ncols, or ncols + n with merged children)
   void free_dev() {
+    for (GsSchedule** c : {&mf, &mb})
+      if (*c) { (*c)->free_dev(); delete *c; *c = nullptr; }
+    for (Tri* t : {&tri_f, &tri_b}) { hipFree(t->rowptr); hipFree(t->col); hipFree(t->val); *t = Tri(); }
     for (Outer* o : {&blk_f, &blk_b}) {
       hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv);
       hipFree(o->near_ptr); hipFree(o->near_pi); hipFree(o->near_val);
@@ -130,6 +143,7 @@ int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (on
 int g_gs_threads = 256;
 int g_gs_block_pipe = 1;        // software-pipelined block sweep (gs_block_pipe_kernel)
 int g_gs_super = 8;             // block-inverse sweeps: blocks per superblock (0 = one launch for the whole operator); read at schedule build
+int g_gs_merge = 6;             // merged-level sweeps: largest group of dependency levels tried (1 = off); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)

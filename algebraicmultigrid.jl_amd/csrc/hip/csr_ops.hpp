@@ -128,8 +128,8 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     HIP_TRY(hipStreamSynchronize(st));
     hipFree(g->bp); hipFree(g->xp); g->bp = g->xp = nullptr;
     RC_TRY(dev_alloc(&g->bp, g->n * ncolv));
-    RC_TRY(dev_alloc(&g->xp, g->ncols * ncolv));
-    int64_t grown = 8 * (g->n + g->ncols) * (ncolv - g->cols_alloc);
+    RC_TRY(dev_alloc(&g->xp, g->xstride * ncolv));
+    int64_t grown = 8 * (g->n + g->xstride) * (ncolv - g->cols_alloc);
     if (g->blk_s) {
       hipFree(g->blk_s); g->blk_s = nullptr;
       RC_TRY(dev_alloc(&g->blk_s, g->n * ncolv));
@@ -177,32 +177,50 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     HIP_TRY(hipGetLastError());
     return AMGH_OK;
   }
+  const int64_t xs = g->xstride;  // doubles per column of xp
   if (first) {
     hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n,
                        (int64_t)g->n, (int64_t)g->n);
     hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const double*)x, g->permx,
-                       g->xp, (int)g->ncols, (int64_t)g->ncols, (int64_t)g->ncols);
+                       g->xp, (int)g->ncols, (int64_t)g->ncols, xs);
     HIP_TRY(hipGetLastError());
   }
   double* xp = g->xp;
-  const int ns = (int)g->segs.size();
+  // merged-level sweep (GS only): the child schedule of this direction runs on ext = [x ; s], s = b - T x
+  GsSchedule* lay = g;
+  const double* rhs = g->bp;
+  int64_t ldb = g->n;
+  if (!sor && g_gs_merge > 1 && (backward ? g->mb : g->mf)) {
+    lay = backward ? g->mb : g->mf;
+    const GsSchedule::Tri& t = backward ? g->tri_b : g->tri_f;
+    StreamArgs ra{};
+    ra.rowptr = t.rowptr; ra.col = t.col; ra.val = t.val;
+    ra.x = xp; ra.b = g->bp; ra.y = xp + g->ncols;
+    ra.row_begin = 0; ra.row_end = (int32_t)g->n;
+    ra.ldx = xs; ra.ldy = xs; ra.ldb = g->n;
+    RC_TRY(launch_stream<M_RESID>(ra, st, ncolv));
+    rhs = xp + g->ncols;
+    ldb = xs;
+  }
+  const int ns = (int)lay->segs.size();
   for (int k = 0; k < ns; ++k) {
-    const GsSchedule::Seg& s = g->segs[backward ? ns - 1 - k : k];
+    const GsSchedule::Seg& s = lay->segs[backward ? ns - 1 - k : k];
     if (s.chain) {
       ChainArgs c{};
-      c.col = g->col; c.val = g->val; c.x = xp; c.bp = g->bp; c.diag = g->diag;
-      c.rowmeta = g->rowmeta; c.desc = g->desc; c.omega = omega; c.tim = g_chain_tim;
+      c.col = lay->col; c.val = lay->val; c.x = xp; c.bp = rhs; c.diag = lay->diag;
+      c.rowmeta = lay->rowmeta; c.desc = lay->desc; c.omega = omega; c.tim = g_chain_tim;
       if (!backward) { c.lvl_begin = s.l0; c.lvl_end = s.l1; c.step = 1; }
       else { c.lvl_begin = s.l1 - 1; c.lvl_end = s.l0 - 1; c.step = -1; }
-      c.ldx = g->ncols; c.ldb = g->n;
-      const bool ldsx = g->ncols <= kChainLdsX;  // x (halo included) fits LDS
-      RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)g->ncols, st, ncolv));
+      c.ldx = xs; c.ldb = ldb;
+      const int64_t nx = lay == g ? g->ncols : xs;  // entries of x (and s) a chained row may read
+      const bool ldsx = nx <= kChainLdsX;            // they fit LDS
+      RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)nx, st, ncolv));
     } else if (s.nslots > 0 && g_gs_slots) {
       SlotArgs sa{};
-      sa.wcol = g->wcol; sa.wval = g->wval; sa.slot_row = g->slot_row; sa.wmeta = g->wmeta;
-      sa.diag = g->diag; sa.bp = g->bp; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;
+      sa.wcol = lay->wcol; sa.wval = lay->wval; sa.slot_row = lay->slot_row; sa.wmeta = lay->wmeta;
+      sa.diag = lay->diag; sa.bp = rhs; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;
       sa.nslots = s.nslots; sa.xcd_map = g_gs_xcd_map;
-      sa.ldx = g->ncols; sa.ldb = g->n;
+      sa.ldx = xs; sa.ldb = ldb;
       // columns per workgroup: the largest of 8 / 4 / 2 / 1 that divides the block size
       const int ncv = (ncolv % 8 == 0) ? 8 : (ncolv % 4 == 0) ? 4 : (ncolv % 2 == 0) ? 2 : 1;
       sa.ncolv = ncolv / ncv;
@@ -211,16 +229,16 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       HIP_TRY(hipGetLastError());
     } else {
       StreamArgs a{};
-      a.rowptr = g->rowptr; a.col = g->col; a.val = g->val;
-      a.x = xp; a.y = xp; a.b = g->bp; a.dpos = g->dpos; a.diag = g->diag; a.perm = nullptr; a.omega = omega;
-      a.row_begin = g->lvl_ptr[s.l0]; a.row_end = g->lvl_ptr[s.l0 + 1];
-      a.ldx = g->ncols; a.ldy = g->ncols; a.ldb = g->n;
+      a.rowptr = lay->rowptr; a.col = lay->col; a.val = lay->val;
+      a.x = xp; a.y = xp; a.b = rhs; a.dpos = lay->dpos; a.diag = lay->diag; a.perm = nullptr; a.omega = omega;
+      a.row_begin = lay->lvl_ptr[s.l0]; a.row_end = lay->lvl_ptr[s.l0 + 1];
+      a.ldx = xs; a.ldy = xs; a.ldb = ldb;
       RC_TRY(sor ? launch_gs_level<M_SOR>(a, s.rows, st, ncolv) : launch_gs_level<M_GS>(a, s.rows, st, ncolv));
     }
   }
   if (last) {
     hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const double*)xp, g->perm, x,
-                       (int)g->n, (int64_t)g->ncols, (int64_t)g->n);
+                       (int)g->n, xs, (int64_t)g->n);
     HIP_TRY(hipGetLastError());
   }
   return AMGH_OK;

@@ -100,110 +100,44 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n,
   return AMGH_OK;
 }
 
-// Build the dependency-level schedule from HOST arrays of the smoother matrix.
-int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
-             const double* val) {
-  const int64_t n = nrows;
-  std::vector<int32_t> lev(n, 0);
-  int32_t maxlev = -1;
-  for (int64_t i = 0; i < n; ++i) {
-    int32_t li = lev[i];
-    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-      const int32_t c = col[j];
-      if (c < i) li = std::max(li, lev[c] + 1);
-    }
-    lev[i] = li;
-    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-      const int32_t c = col[j];
-      if (c > i && c < n) lev[c] = std::max(lev[c], li + 1);
-    }
-    maxlev = std::max(maxlev, li);
-  }
-  g->nlev = (int)(maxlev + 1);
-  g->lvl_ptr.assign(g->nlev + 1, 0);
-  for (int64_t i = 0; i < n; ++i) g->lvl_ptr[lev[i] + 1]++;
-  for (int l = 0; l < g->nlev; ++l) g->lvl_ptr[l + 1] += g->lvl_ptr[l];
-  std::vector<int32_t> perm(n), next(g->lvl_ptr.begin(), g->lvl_ptr.end() - (g->nlev > 0 ? 1 : 0));
-  if (g->nlev == 0) next.clear();
-  for (int64_t i = 0; i < n; ++i) perm[next[lev[i]]++] = (int32_t)i;  // ascending row id inside a level
-  std::vector<int32_t>().swap(lev);
-  // x is kept in dependency-level order during the sweeps: position p holds x[perm[p]]; columns
-  // beyond the square block (halo entries of a sharded operator) keep their place.  Each level
-  // then reads and writes contiguous stretches of x (coalesced, TLB-friendly) instead of a
-  // hyperplane scattered over the whole vector.
-  std::vector<int32_t> inv(std::max<int64_t>(ncols, n));
-  for (int64_t c = 0; c < (int64_t)inv.size(); ++c) inv[c] = (int32_t)c;
-  for (int64_t p2 = 0; p2 < n; ++p2) inv[perm[p2]] = (int32_t)p2;
-  const int64_t nnz = rowptr[n];
-  std::vector<int32_t> prow(n + 1), pcol(nnz), pdpos(n);
-  std::vector<double> pval(nnz), pdiag(n);
-  int64_t w = 0;
-  prow[0] = 0;
-  for (int64_t p = 0; p < n; ++p) {
-    const int32_t i = perm[p];
-    int32_t dp = -1;
-    double d = 0.0;
-    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-      pcol[w] = inv[col[j]];   // entries stay in the row's original column order (sum order)
-      pval[w] = val[j];
-      if (col[j] == i) { dp = (int32_t)w; d = val[j]; }
-      ++w;
-    }
-    prow[p + 1] = (int32_t)w;
-    pdpos[p] = dp;
-    pdiag[p] = d;
-  }
+// A triangular system in dependency-level order on the host: row p updates x[p] from
+//   diag[p] * x[p] = rhs[p] - sum_{entries != dpos[p]} val * x[col]
+// and rows of one level [lvl_ptr[l], lvl_ptr[l+1]) do not reference each other.
+struct HostLevelCsr {
+  int64_t n = 0;
+  int nlev = 0;
+  std::vector<int32_t> lvl_ptr, prow, pcol, pdpos;
+  std::vector<double> pval, pdiag;
+};
+
+// Upload one level-ordered system and derive its execution layout: row / level descriptors for the chain
+// kernel, segments (runs of narrow levels chained in one workgroup, one launch per wide level), slot arrays.
+// `orig` = original row id of each level-ordered row (rowmeta.w), may be null.
+int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig) {
+  const int64_t n = h.n;
+  const std::vector<int32_t>& prow = h.prow;
+  const std::vector<int32_t>& pcol = h.pcol;
+  const std::vector<int32_t>& pdpos = h.pdpos;
+  const std::vector<double>& pval = h.pval;
+  const int64_t nnz = prow[n];
+  g->n = n;
+  g->nlev = h.nlev;
+  g->lvl_ptr = h.lvl_ptr;
   RC_TRY(dev_upload(&g->rowptr, prow.data(), n + 1));
   RC_TRY(dev_upload(&g->col, pcol.data(), nnz));
   RC_TRY(dev_upload(&g->val, pval.data(), nnz));
-  RC_TRY(dev_upload(&g->perm, perm.data(), n));
   RC_TRY(dev_upload(&g->dpos, pdpos.data(), n));
-  RC_TRY(dev_upload(&g->diag, pdiag.data(), n));
+  RC_TRY(dev_upload(&g->diag, h.pdiag.data(), n));
   RC_TRY(dev_upload(&g->d_lvl_ptr, g->lvl_ptr.data(), g->nlev + 1));
   {
     std::vector<i4_t> meta(n), desc(g->nlev);
-    for (int64_t p = 0; p < n; ++p) meta[p] = i4_t{prow[p], prow[p + 1], pdpos[p], perm[p]};
+    for (int64_t p = 0; p < n; ++p) meta[p] = i4_t{prow[p], prow[p + 1], pdpos[p], orig ? orig[p] : (int32_t)p};
     for (int l = 0; l < g->nlev; ++l)
       desc[l] = i4_t{g->lvl_ptr[l], g->lvl_ptr[l + 1], prow[g->lvl_ptr[l]], prow[g->lvl_ptr[l + 1]]};
     RC_TRY(dev_upload(&g->rowmeta, meta.data(), n));
     RC_TRY(dev_upload(&g->desc, desc.data(), g->nlev));
   }
-  RC_TRY(dev_alloc(&g->bp, n));
-  g->ncols = std::max<int64_t>(ncols, n);
-  RC_TRY(dev_alloc(&g->xp, g->ncols));
-  {
-    std::vector<int32_t> permx(g->ncols);
-    for (int64_t c = 0; c < g->ncols; ++c) permx[c] = c < n ? perm[c] : (int32_t)c;
-    RC_TRY(dev_upload(&g->permx, permx.data(), g->ncols));
-  }
-  g->n = n;
-  g->bytes = (n + 1) * 4 + nnz * 12 + n * 16 + (g->nlev + 1) * 4 + n * 24 + g->nlev * 16 + g->ncols * 12;
-  // Block-inverse path: worth it when level scheduling has degenerated (many more dependency levels
-  // than index blocks) and the dense blocks stay small.
-  {
-    const int nblk = (int)((n + kBlk - 1) / kBlk);
-    if (n >= 16 && n <= 262144 && g->nlev >= 3 * nblk) {
-      std::vector<double> dg(n, 0.0);
-      for (int64_t i = 0; i < n; ++i)
-        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
-          if (col[j] == i) dg[i] = val[j];
-      double max_cond = 0.0;
-      g->super = (g_gs_super > 0 && nblk > g_gs_super) ? g_gs_super : 0;
-      RC_TRY(blockgs_build_dir(&g->blk_f, false, g->super, n, rowptr, col, val, dg, &max_cond));
-      RC_TRY(blockgs_build_dir(&g->blk_b, true, g->super, n, rowptr, col, val, dg, &max_cond));
-      RC_TRY(dev_upload(&g->blk_diag, dg.data(), n));
-      RC_TRY(dev_alloc(&g->blk_s, n));
-      g->blk_cond = max_cond;
-      if (getenv("AMGH_VERBOSE"))
-        fprintf(stderr, "[amghip] n=%lld dependency levels=%d index blocks=%d max triangle cond=%.3g -> %s\n", (long long)n,
-                g->nlev, nblk, max_cond, max_cond <= 1e4 ? "block-inverse sweeps" : "exact-order sweeps");
-      // explicit triangle inverses lose ~cond * eps: keep the 1e-10 contract with margin
-      if (max_cond <= 1e4) {
-        g->nblk = nblk;
-        g->bytes += 2 * ((int64_t)nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4) + n * 8;
-      }
-    }
-  }
+  g->bytes += (n + 1) * 4 + nnz * 12 + n * 12 + (g->nlev + 1) * 4 + n * 16 + g->nlev * 16;
   // segments: runs of narrow dependency levels are chained in one workgroup
   // A dependency level is chained (stays inside one workgroup) when it has at most
   // one row per thread and its products fit one LDS pass; anything larger is worth
@@ -303,6 +237,264 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       g->bytes += (int64_t)wcol.size() * 12 + (int64_t)sr2.size() * 4 + n * 16;
     }
   }
+  return AMGH_OK;
+}
+
+// ---- merged dependency levels -------------------------------------------------------------------
+// A wide dependency level costs one kernel boundary (~3.3 us) however few rows it has.  Substitution removes
+// boundaries: inside a GROUP of m consecutive levels, a row that reads x_c of an earlier level of the same group
+// gets that reference replaced by row c's own update formula,
+//   x_c = (s_c - sum_e val_e * ext[col_e]) / d_c ,
+// so that every row of the group reads only rows of EARLIER groups (final) and right-hand-side entries: all rows
+// of a group are independent and run in one launch.  To keep the substitution one-sided the other triangle is
+// applied first, s = b - T x_old (one full-chip residual launch per sweep), and a row may then reference s of
+// other rows: the kernels see one extended vector ext = [x (ncols) ; s (n)], column ncols + c = s_c.
+// Same iterate as the row-by-row sweep in exact arithmetic; rounding differs at the 1e-16 level (like the
+// block-inverse path, unlike the unmerged schedule, which reproduces the scalar loop bit for bit).
+// Fill grows with m and with the row length, launches shrink with m: the group size is chosen per operator and
+// direction from a cost model on the measured fill.
+struct MergeResult {
+  HostLevelCsr sys;      // grouped levels, composite rows (no diagonal entry: dpos = -1)
+  int64_t max_row = 0;
+};
+
+// backward = false: groups counted from level 0, substitution over the strictly lower triangle (columns of earlier
+// levels); backward = true: groups counted from the last level, over the strictly upper triangle.
+MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool backward) {
+  const int64_t n = base.n;
+  const int nlev = base.nlev;
+  MergeResult R;
+  HostLevelCsr& S = R.sys;
+  S.n = n;
+  S.pdiag = base.pdiag;
+  S.pdpos.assign(n, -1);
+  // grouped level pointers (ascending position in both directions)
+  std::vector<int> grp_of(nlev);
+  for (int l = 0; l < nlev; ++l) grp_of[l] = backward ? (nlev - 1 - l) / m : l / m;
+  const int ngrp = nlev ? (nlev + m - 1) / m : 0;
+  S.nlev = ngrp;
+  S.lvl_ptr.assign(ngrp + 1, 0);
+  std::vector<int32_t> lev_of(n);
+  for (int l = 0; l < nlev; ++l)
+    for (int32_t p = base.lvl_ptr[l]; p < base.lvl_ptr[l + 1]; ++p) lev_of[p] = l;
+  auto gpos = [&](int l) { return backward ? (ngrp - 1 - grp_of[l]) : grp_of[l]; };  // group index in ascending position
+  for (int l = 0; l < nlev; ++l) S.lvl_ptr[gpos(l) + 1] = std::max(S.lvl_ptr[gpos(l) + 1], base.lvl_ptr[l + 1]);
+  for (int q = 0; q < ngrp; ++q) S.lvl_ptr[q + 1] = std::max(S.lvl_ptr[q + 1], S.lvl_ptr[q]);
+  // composite rows, produced in sweep order (ascending p forward, descending p backward) into flat arrays
+  std::vector<int64_t> cptr(n + 1, 0);  // offsets in production order
+  std::vector<int32_t> ccol;
+  std::vector<double> cval;
+  ccol.reserve(base.prow[n]);
+  cval.reserve(base.prow[n]);
+  std::vector<int64_t> where(n, -1);  // production index of row p
+  const int64_t next = ncols + n;
+  std::vector<int32_t> mark(next, -1);
+  std::vector<double> acc(next, 0.0);
+  std::vector<int32_t> touched;
+  int64_t produced = 0;
+  auto add = [&](int32_t c, double v, int32_t tag) {
+    if (mark[c] != tag) { mark[c] = tag; acc[c] = v; touched.push_back(c); }
+    else acc[c] += v;
+  };
+  for (int64_t it = 0; it < n; ++it) {
+    const int64_t p = backward ? n - 1 - it : it;
+    const int lp = lev_of[p];
+    const int gq = grp_of[lp];
+    touched.clear();
+    const int32_t tag = (int32_t)p;
+    for (int32_t j = base.prow[p]; j < base.prow[p + 1]; ++j) {
+      const int32_t c = base.pcol[j];
+      if (c == p || c >= n) continue;  // diagonal; halo entries belong to the pre-pass
+      const int lc = lev_of[c];
+      const bool tri = backward ? lc > lp : lc < lp;
+      if (!tri) continue;              // the other triangle belongs to the pre-pass
+      const double v = base.pval[j];
+      if (grp_of[lc] == gq && base.pdiag[c] != 0.0) {
+        const double f = v / base.pdiag[c];
+        add((int32_t)(ncols + c), f, tag);
+        const int64_t w = where[c];
+        for (int64_t e = cptr[w]; e < cptr[w + 1]; ++e) add(ccol[e], -f * cval[e], tag);
+      } else {
+        add(c, v, tag);  // an earlier group (final), or a row that keeps its x (zero diagonal)
+      }
+    }
+    std::sort(touched.begin(), touched.end());
+    where[p] = produced;
+    for (int32_t c : touched) { ccol.push_back(c); cval.push_back(acc[c]); }
+    cptr[produced + 1] = (int64_t)ccol.size();
+    R.max_row = std::max<int64_t>(R.max_row, (int64_t)touched.size());
+    ++produced;
+    if ((int64_t)ccol.size() >= (int64_t)INT32_MAX - 4096) { R.max_row = INT32_MAX; return R; }  // caller rejects
+  }
+  // assemble in ascending row order
+  S.prow.assign(n + 1, 0);
+  for (int64_t p = 0; p < n; ++p) S.prow[p + 1] = S.prow[p] + (int32_t)(cptr[where[p] + 1] - cptr[where[p]]);
+  S.pcol.resize(S.prow[n]);
+  S.pval.resize(S.prow[n]);
+  for (int64_t p = 0; p < n; ++p) {
+    const int64_t w = where[p];
+    std::copy(ccol.begin() + cptr[w], ccol.begin() + cptr[w + 1], S.pcol.begin() + S.prow[p]);
+    std::copy(cval.begin() + cptr[w], cval.begin() + cptr[w + 1], S.pval.begin() + S.prow[p]);
+  }
+  return R;
+}
+
+// the triangle (plus halo columns) a sweep direction does NOT substitute over: s = b - T x before the sweep
+int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int64_t* bytes) {
+  const int64_t n = base.n;
+  std::vector<int32_t> lev_of(n);
+  for (int l = 0; l < base.nlev; ++l)
+    for (int32_t p = base.lvl_ptr[l]; p < base.lvl_ptr[l + 1]; ++p) lev_of[p] = l;
+  std::vector<int32_t> rp(n + 1, 0), cc;
+  std::vector<double> vv;
+  for (int64_t p = 0; p < n; ++p) {
+    for (int32_t j = base.prow[p]; j < base.prow[p + 1]; ++j) {
+      const int32_t c = base.pcol[j];
+      if (c == p) continue;
+      const bool other = c >= n || (backward ? lev_of[c] < lev_of[p] : lev_of[c] > lev_of[p]);
+      if (other) { cc.push_back(c); vv.push_back(base.pval[j]); }
+    }
+    rp[p + 1] = (int32_t)cc.size();
+  }
+  RC_TRY(dev_upload(&t->rowptr, rp.data(), n + 1));
+  RC_TRY(dev_upload(&t->col, cc.data(), (int64_t)cc.size()));
+  RC_TRY(dev_upload(&t->val, vv.data(), (int64_t)vv.size()));
+  *bytes += (n + 1) * 4 + (int64_t)cc.size() * 12;
+  return AMGH_OK;
+}
+
+// estimated time of one sweep over a grouped system: a kernel boundary per group + streaming its entries
+double merge_cost(int64_t ngroups, int64_t nnz) { return ngroups * 3.8e-6 + 12.0 * (double)nnz / 2.5e12; }
+
+// Build the dependency-level schedule from HOST arrays of the smoother matrix.
+int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
+             const double* val) {
+  const int64_t n = nrows;
+  std::vector<int32_t> lev(n, 0);
+  int32_t maxlev = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t li = lev[i];
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t c = col[j];
+      if (c < i) li = std::max(li, lev[c] + 1);
+    }
+    lev[i] = li;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t c = col[j];
+      if (c > i && c < n) lev[c] = std::max(lev[c], li + 1);
+    }
+    maxlev = std::max(maxlev, li);
+  }
+  HostLevelCsr base;
+  base.n = n;
+  base.nlev = (int)(maxlev + 1);
+  base.lvl_ptr.assign(base.nlev + 1, 0);
+  for (int64_t i = 0; i < n; ++i) base.lvl_ptr[lev[i] + 1]++;
+  for (int l = 0; l < base.nlev; ++l) base.lvl_ptr[l + 1] += base.lvl_ptr[l];
+  std::vector<int32_t> perm(n), next(base.lvl_ptr.begin(), base.lvl_ptr.end() - (base.nlev > 0 ? 1 : 0));
+  if (base.nlev == 0) next.clear();
+  for (int64_t i = 0; i < n; ++i) perm[next[lev[i]]++] = (int32_t)i;  // ascending row id inside a level
+  std::vector<int32_t>().swap(lev);
+  // x is kept in dependency-level order during the sweeps: position p holds x[perm[p]]; columns
+  // beyond the square block (halo entries of a sharded operator) keep their place.  Each level
+  // then reads and writes contiguous stretches of x (coalesced, TLB-friendly) instead of a
+  // hyperplane scattered over the whole vector.
+  std::vector<int32_t> inv(std::max<int64_t>(ncols, n));
+  for (int64_t c = 0; c < (int64_t)inv.size(); ++c) inv[c] = (int32_t)c;
+  for (int64_t p2 = 0; p2 < n; ++p2) inv[perm[p2]] = (int32_t)p2;
+  const int64_t nnz = rowptr[n];
+  base.prow.resize(n + 1);
+  base.pcol.resize(nnz);
+  base.pdpos.resize(n);
+  base.pval.resize(nnz);
+  base.pdiag.resize(n);
+  int64_t w = 0;
+  base.prow[0] = 0;
+  for (int64_t p = 0; p < n; ++p) {
+    const int32_t i = perm[p];
+    int32_t dp = -1;
+    double d = 0.0;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      base.pcol[w] = inv[col[j]];   // entries stay in the row's original column order (sum order)
+      base.pval[w] = val[j];
+      if (col[j] == i) { dp = (int32_t)w; d = val[j]; }
+      ++w;
+    }
+    base.prow[p + 1] = (int32_t)w;
+    base.pdpos[p] = dp;
+    base.pdiag[p] = d;
+  }
+  g->bytes = 0;
+  RC_TRY(layout_upload(g, base, perm.data()));
+  RC_TRY(dev_upload(&g->perm, perm.data(), n));
+  g->ncols = std::max<int64_t>(ncols, n);
+  {
+    std::vector<int32_t> permx(g->ncols);
+    for (int64_t c = 0; c < g->ncols; ++c) permx[c] = c < n ? perm[c] : (int32_t)c;
+    RC_TRY(dev_upload(&g->permx, permx.data(), g->ncols));
+  }
+  g->bytes += n * 4 + g->ncols * 4;
+  // Block-inverse path: worth it when level scheduling has degenerated (many more dependency levels
+  // than index blocks) and the dense blocks stay small.
+  {
+    const int nblk = (int)((n + kBlk - 1) / kBlk);
+    if (n >= 16 && n <= 262144 && g->nlev >= 3 * nblk) {
+      std::vector<double> dg(n, 0.0);
+      for (int64_t i = 0; i < n; ++i)
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
+          if (col[j] == i) dg[i] = val[j];
+      double max_cond = 0.0;
+      g->super = (g_gs_super > 0 && nblk > g_gs_super) ? g_gs_super : 0;
+      RC_TRY(blockgs_build_dir(&g->blk_f, false, g->super, n, rowptr, col, val, dg, &max_cond));
+      RC_TRY(blockgs_build_dir(&g->blk_b, true, g->super, n, rowptr, col, val, dg, &max_cond));
+      RC_TRY(dev_upload(&g->blk_diag, dg.data(), n));
+      RC_TRY(dev_alloc(&g->blk_s, n));
+      g->blk_cond = max_cond;
+      if (getenv("AMGH_VERBOSE"))
+        fprintf(stderr, "[amghip] n=%lld dependency levels=%d index blocks=%d max triangle cond=%.3g -> %s\n", (long long)n,
+                g->nlev, nblk, max_cond, max_cond <= 1e4 ? "block-inverse sweeps" : "exact-order sweeps");
+      // explicit triangle inverses lose ~cond * eps: keep the 1e-10 contract with margin
+      if (max_cond <= 1e4) {
+        g->nblk = nblk;
+        g->bytes += 2 * ((int64_t)nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4) + n * 8;
+      }
+    }
+  }
+  // Merged levels: only where the launch-per-level schedule is what runs (no block path) and there are enough
+  // wide levels for the boundaries to matter.
+  g->xstride = g->ncols;
+  if (g_gs_merge > 1 && g->nblk == 0 && n >= 4096 && g->nlev >= 64) {
+    for (int dir = 0; dir < 2; ++dir) {
+      const bool backward = dir == 1;
+      double best = merge_cost(base.nlev, nnz);
+      int best_m = 1;
+      MergeResult keep;
+      for (int m = 2; m <= g_gs_merge; ++m) {
+        MergeResult r = merge_build(base, g->ncols, m, backward);
+        if (r.max_row > kSlot) break;  // a composite row no longer fits a slot: fill has exploded
+        const double c = merge_cost(r.sys.nlev, r.sys.prow[n]) + 12.0 * (double)nnz / 2 / 4e12;  // + the pre-pass
+        if (getenv("AMGH_VERBOSE"))
+          fprintf(stderr, "[amghip] n=%lld %s merge m=%d: %d groups, %.1f entries/row (max %lld), est. %.2f ms vs %.2f ms\n",
+                  (long long)n, backward ? "bwd" : "fwd", m, r.sys.nlev, (double)r.sys.prow[n] / n, (long long)r.max_row,
+                  1e3 * c, 1e3 * best);
+        if (c < 0.97 * best) { best = c; best_m = m; keep = std::move(r); }
+        else break;
+      }
+      if (best_m > 1) {
+        GsSchedule* ch = new GsSchedule;
+        (backward ? g->mb : g->mf) = ch;
+        ch->ncols = g->ncols;
+        RC_TRY(layout_upload(ch, keep.sys, perm.data()));
+        RC_TRY(tri_upload(backward ? &g->tri_b : &g->tri_f, base, backward, &g->bytes));
+        (backward ? g->merge_b : g->merge_f) = best_m;
+        g->bytes += ch->bytes;
+      }
+    }
+    if (g->mf || g->mb) g->xstride = g->ncols + n;
+  }
+  RC_TRY(dev_alloc(&g->bp, n));
+  RC_TRY(dev_alloc(&g->xp, g->xstride));
+  g->bytes += 8 * (n + g->xstride);
   return AMGH_OK;
 }
 
