@@ -37,8 +37,8 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n,
         const bool in_tri = c >= i0 && c < i1 && (backward ? c >= i : c <= i);
         if (in_tri) {
           if (!skip) T[(size_t)(i - i0) * B + (c - i0)] += val[j];
-        } else if (!skip && (c >= i0 && c < i1 ? true : (backward ? c < i0 : c >= i1))) {
-          xcol.push_back(c); xval.push_back(val[j]);  // old x: in-block other triangle, or a block swept later
+        } else if (!skip && (c >= n || (c >= i0 && c < i1) || (backward ? c < i0 : c >= i1))) {
+          xcol.push_back(c); xval.push_back(val[j]);  // old x: halo column (frozen), in-block other triangle, block swept later
         } else if (!skip && (c < s0 || c >= s1)) {
           pcol.push_back(c); pval.push_back(val[j]);  // an earlier superblock
         } else if (!skip) {

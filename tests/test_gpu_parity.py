@@ -179,6 +179,37 @@ def test_block_inverse_sweeps_all_variants(super_blocks, pipe):
         lib.amgh_debug_set_tunable(b"gs_block_pipe", 1)
 
 
+def _halo_case(A_sq, nloc):
+    """Rows [0, nloc) of a square operator as a rectangular local block (columns >= nloc are frozen halo values, as
+    on a shard) + the equivalent square system for the oracle: identity rows keep the halo entries."""
+    M = A_sq.to_scipy().tocsr()
+    n = M.shape[0]
+    top = M[:nloc, :].tocsr()
+    ext = sp.vstack([top, sp.hstack([sp.csr_matrix((n - nloc, nloc)), sp.identity(n - nloc)])])
+    # the oracle's fast smoothers read CSC column i as row i (smoother.jl:78): hand it the transpose
+    return top, AMG.SparseMatrixCSC.from_scipy(ext.T.tocsc())
+
+
+@pytest.mark.parametrize("which", ["block-inverse", "merged-levels"])
+def test_sweeps_on_rectangular_shard_block_with_halo_columns(which):
+    """Local block of a row-sharded operator (dist.py): Gauss-Seidel over the local rows, halo columns frozen.
+    Covers the block-inverse path and the merged-level path on operators with columns >= nrows."""
+    from amg_amd.device import DeviceCSR
+    if which == "block-inverse":
+        A_sq, nloc = _dense_band_spd(900, 60, 9), 640
+    else:
+        A_sq, nloc = AMG.poisson((24, 24, 24)), 24 * 24 * 20   # 66 dependency levels: merged groups are built
+    top, ext = _halo_case(A_sq, nloc)
+    n = A_sq.m
+    x0, b = uniform(n, 81) - 0.5, uniform(n, 82)
+    b_ext = b.copy(); b_ext[nloc:] = x0[nloc:]           # identity rows: x_halo = b_halo = x0_halo
+    op = DeviceCSR(nloc, n, top.indptr.astype(np.int32), top.indices.astype(np.int32), top.data)
+    for s in (FWD, BWD, SYM, AMG.GaussSeidel(AMG.SymmetricSweep(), 2)):
+        x = op.smooth(s, x0.copy(), b[:nloc])
+        ref = O.smooth(s, ext, x0, b_ext)
+        assert rel(x, ref[:nloc]) <= 1e-11, (which, repr(s), rel(x, ref[:nloc]))
+
+
 def test_hermitian_flag_on_nonsymmetric_matrix_sweeps_the_transpose():
     """SURVEY §7 hard part 4: with the default HermitianSymmetry the fast smoothers read CSC columns as rows."""
     rng = np.random.default_rng(3)
