@@ -258,84 +258,190 @@ struct MergeResult {
   int64_t max_row = 0;
 };
 
-// backward = false: groups counted from level 0, substitution over the strictly lower triangle (columns of earlier
-// levels); backward = true: groups counted from the last level, over the strictly upper triangle.
+// grouping of the dependency levels of `base` into groups of m (counted from level 0 forward, from the last level
+// backward); groups are numbered by ascending position in both directions
+struct MergeGroups {
+  int m = 1, ngrp = 0;
+  bool backward = false;
+  std::vector<int32_t> gptr;  // rows of group q: [gptr[q], gptr[q + 1])
+  std::vector<int32_t> lev_of;
+  int group_of_level(int l, int nlev) const { return backward ? ngrp - 1 - (nlev - 1 - l) / m : l / m; }
+};
+
+MergeGroups merge_groups(const HostLevelCsr& base, int m, bool backward) {
+  MergeGroups G;
+  G.m = m; G.backward = backward;
+  const int nlev = base.nlev;
+  G.ngrp = nlev ? (nlev + m - 1) / m : 0;
+  G.gptr.assign(G.ngrp + 1, 0);
+  for (int l = 0; l < nlev; ++l) {
+    const int q = G.group_of_level(l, nlev);
+    G.gptr[q + 1] = std::max(G.gptr[q + 1], base.lvl_ptr[l + 1]);
+  }
+  for (int q = 0; q < G.ngrp; ++q) G.gptr[q + 1] = std::max(G.gptr[q + 1], G.gptr[q]);
+  G.lev_of.resize(base.n);
+  for (int l = 0; l < nlev; ++l)
+    for (int32_t p = base.lvl_ptr[l]; p < base.lvl_ptr[l + 1]; ++p) G.lev_of[p] = l;
+  return G;
+}
+
+// composite rows of the groups [q0, q1): rows come out in ascending row order; len[p - gptr[q0]] entries each.
+// Returns the longest row, or INT32_MAX when a row outgrows a slot (the caller gives up on this m).
+struct MergeChunk {
+  std::vector<int32_t> len, col;
+  std::vector<double> val;
+};
+int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncols, int q0, int q1, MergeChunk* out) {
+  constexpr int kCap = 2048;  // open-addressing accumulator: rows longer than kSlot are rejected anyway
+  std::vector<int32_t> key(kCap, -1);
+  std::vector<std::pair<int32_t, int32_t>> order;  // {column, accumulator slot} of the row being built
+  std::vector<double> acc(kCap);
+  std::vector<int64_t> off;       // per row of the current group: offset into gcol / gval
+  std::vector<int32_t> gcol, glen;
+  std::vector<double> gval;
+  int64_t max_row = 0;
+  const int32_t row0 = G.gptr[q0];
+  out->len.assign(G.gptr[q1] - row0, 0);
+  out->col.clear();
+  out->val.clear();
+  for (int q = q0; q < q1; ++q) {
+    const int32_t ga = G.gptr[q], gb = G.gptr[q + 1];
+    const int32_t gn = gb - ga;
+    off.assign(gn + 1, 0);
+    glen.assign(gn, 0);
+    gcol.clear();
+    gval.clear();
+    std::vector<int64_t> start(gn, 0);
+    for (int32_t it = 0; it < gn; ++it) {
+      const int32_t p = G.backward ? gb - 1 - it : ga + it;
+      const int lp = G.lev_of[p];
+      order.clear();
+      bool overflow = false;
+      auto add = [&](int32_t c, double v) {
+        uint32_t h = ((uint32_t)c * 2654435761u) & (kCap - 1);
+        while (key[h] != -1 && key[h] != c) h = (h + 1) & (kCap - 1);
+        if (key[h] == -1) {
+          if ((int)order.size() >= kSlot) { overflow = true; return; }
+          key[h] = c; acc[h] = v; order.push_back({c, (int32_t)h});
+        } else {
+          acc[h] += v;
+        }
+      };
+      for (int32_t j = base.prow[p]; j < base.prow[p + 1] && !overflow; ++j) {
+        const int32_t c = base.pcol[j];
+        if (c == p || c >= base.n) continue;  // diagonal; halo entries belong to the pre-pass
+        const int lc = G.lev_of[c];
+        const bool tri = G.backward ? lc > lp : lc < lp;
+        if (!tri) continue;                    // the other triangle belongs to the pre-pass
+        const double v = base.pval[j];
+        if (c >= ga && c < gb && base.pdiag[c] != 0.0) {  // same group: substitute row c's formula
+          const double f = v / base.pdiag[c];
+          add((int32_t)(ncols + c), f);
+          const int32_t lc2 = c - ga;
+          for (int64_t e = start[lc2]; e < start[lc2] + glen[lc2] && !overflow; ++e) add(gcol[e], -f * gval[e]);
+        } else {
+          add(c, v);  // an earlier group (final), or a row that keeps its x (zero diagonal)
+        }
+      }
+      if (overflow) return INT32_MAX;  // (accumulator left dirty: the caller abandons this m)
+      std::sort(order.begin(), order.end());
+      const int32_t lp2 = p - ga;
+      start[lp2] = (int64_t)gcol.size();
+      glen[lp2] = (int32_t)order.size();
+      for (const auto& cs : order) {
+        gcol.push_back(cs.first);
+        gval.push_back(acc[cs.second]);
+        key[cs.second] = -1;  // release the slot
+      }
+      max_row = std::max<int64_t>(max_row, (int64_t)order.size());
+    }
+    // emit the group's rows in ascending row order
+    for (int32_t r = 0; r < gn; ++r) {
+      out->len[ga - row0 + r] = glen[r];
+      out->col.insert(out->col.end(), gcol.begin() + start[r], gcol.begin() + start[r] + glen[r]);
+      out->val.insert(out->val.end(), gval.begin() + start[r], gval.begin() + start[r] + glen[r]);
+    }
+  }
+  return max_row;
+}
+
+int merge_threads() {
+  unsigned hw = std::thread::hardware_concurrency();
+  long quota = -1, period = -1;
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // do not oversubscribe a container's CPU quota
+    char q[64] = {0};
+    if (std::fscanf(f, "%63s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atol(q);
+    std::fclose(f);
+  }
+  int t = (int)std::max(1u, std::min(hw ? hw : 8u, 32u));
+  if (quota > 0 && period > 0) t = (int)std::min<long>(t, std::max<long>(1, (quota + period - 1) / period));
+  if (const char* e = getenv("AMGH_BUILD_THREADS")) t = std::max(1, atoi(e));
+  return t;
+}
+
+// Fill estimate for group size m from a sample of groups: {entries per row, longest row}
+std::pair<double, int64_t> merge_estimate(const HostLevelCsr& base, int64_t ncols, int m, bool backward) {
+  MergeGroups G = merge_groups(base, m, backward);
+  const int nsample = std::min(G.ngrp, 48);
+  int64_t rows = 0, ents = 0, mx = 0;
+  MergeChunk ch;
+  for (int k = 0; k < nsample; ++k) {
+    const int q = (int)((int64_t)k * G.ngrp / nsample);
+    const int64_t r = merge_chunk(base, G, ncols, q, q + 1, &ch);
+    if (r == INT32_MAX) return {1e30, INT32_MAX};
+    mx = std::max(mx, r);
+    rows += (int64_t)ch.len.size();
+    ents += (int64_t)ch.col.size();
+  }
+  return {rows ? (double)ents / rows : 0.0, mx};
+}
+
 MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool backward) {
   const int64_t n = base.n;
-  const int nlev = base.nlev;
   MergeResult R;
   HostLevelCsr& S = R.sys;
+  MergeGroups G = merge_groups(base, m, backward);
   S.n = n;
   S.pdiag = base.pdiag;
   S.pdpos.assign(n, -1);
-  // grouped level pointers (ascending position in both directions)
-  std::vector<int> grp_of(nlev);
-  for (int l = 0; l < nlev; ++l) grp_of[l] = backward ? (nlev - 1 - l) / m : l / m;
-  const int ngrp = nlev ? (nlev + m - 1) / m : 0;
-  S.nlev = ngrp;
-  S.lvl_ptr.assign(ngrp + 1, 0);
-  std::vector<int32_t> lev_of(n);
-  for (int l = 0; l < nlev; ++l)
-    for (int32_t p = base.lvl_ptr[l]; p < base.lvl_ptr[l + 1]; ++p) lev_of[p] = l;
-  auto gpos = [&](int l) { return backward ? (ngrp - 1 - grp_of[l]) : grp_of[l]; };  // group index in ascending position
-  for (int l = 0; l < nlev; ++l) S.lvl_ptr[gpos(l) + 1] = std::max(S.lvl_ptr[gpos(l) + 1], base.lvl_ptr[l + 1]);
-  for (int q = 0; q < ngrp; ++q) S.lvl_ptr[q + 1] = std::max(S.lvl_ptr[q + 1], S.lvl_ptr[q]);
-  // composite rows, produced in sweep order (ascending p forward, descending p backward) into flat arrays
-  std::vector<int64_t> cptr(n + 1, 0);  // offsets in production order
-  std::vector<int32_t> ccol;
-  std::vector<double> cval;
-  ccol.reserve(base.prow[n]);
-  cval.reserve(base.prow[n]);
-  std::vector<int64_t> where(n, -1);  // production index of row p
-  const int64_t next = ncols + n;
-  std::vector<int32_t> mark(next, -1);
-  std::vector<double> acc(next, 0.0);
-  std::vector<int32_t> touched;
-  int64_t produced = 0;
-  auto add = [&](int32_t c, double v, int32_t tag) {
-    if (mark[c] != tag) { mark[c] = tag; acc[c] = v; touched.push_back(c); }
-    else acc[c] += v;
-  };
-  for (int64_t it = 0; it < n; ++it) {
-    const int64_t p = backward ? n - 1 - it : it;
-    const int lp = lev_of[p];
-    const int gq = grp_of[lp];
-    touched.clear();
-    const int32_t tag = (int32_t)p;
-    for (int32_t j = base.prow[p]; j < base.prow[p + 1]; ++j) {
-      const int32_t c = base.pcol[j];
-      if (c == p || c >= n) continue;  // diagonal; halo entries belong to the pre-pass
-      const int lc = lev_of[c];
-      const bool tri = backward ? lc > lp : lc < lp;
-      if (!tri) continue;              // the other triangle belongs to the pre-pass
-      const double v = base.pval[j];
-      if (grp_of[lc] == gq && base.pdiag[c] != 0.0) {
-        const double f = v / base.pdiag[c];
-        add((int32_t)(ncols + c), f, tag);
-        const int64_t w = where[c];
-        for (int64_t e = cptr[w]; e < cptr[w + 1]; ++e) add(ccol[e], -f * cval[e], tag);
-      } else {
-        add(c, v, tag);  // an earlier group (final), or a row that keeps its x (zero diagonal)
-      }
-    }
-    std::sort(touched.begin(), touched.end());
-    where[p] = produced;
-    for (int32_t c : touched) { ccol.push_back(c); cval.push_back(acc[c]); }
-    cptr[produced + 1] = (int64_t)ccol.size();
-    R.max_row = std::max<int64_t>(R.max_row, (int64_t)touched.size());
-    ++produced;
-    if ((int64_t)ccol.size() >= (int64_t)INT32_MAX - 4096) { R.max_row = INT32_MAX; return R; }  // caller rejects
+  S.nlev = G.ngrp;
+  S.lvl_ptr.assign(G.gptr.begin(), G.gptr.end());
+  // groups are independent of each other: contiguous ranges of groups (balanced by rows) per thread
+  const int T = std::max(1, std::min(merge_threads(), G.ngrp));
+  std::vector<int> qcut(T + 1, G.ngrp);
+  qcut[0] = 0;
+  for (int t = 1; t < T; ++t) {
+    const int64_t target = n * t / T;
+    qcut[t] = (int)(std::lower_bound(G.gptr.begin(), G.gptr.end(), (int32_t)target) - G.gptr.begin());
+    qcut[t] = std::min(std::max(qcut[t], qcut[t - 1]), G.ngrp);
   }
-  // assemble in ascending row order
+  std::vector<MergeChunk> chunks(T);
+  std::vector<int64_t> mx(T, 0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() { mx[t] = merge_chunk(base, G, ncols, qcut[t], qcut[t + 1], &chunks[t]); });
+  for (auto& x : th) x.join();
+  int64_t total = 0;
+  for (int t = 0; t < T; ++t) {
+    R.max_row = std::max(R.max_row, mx[t]);
+    total += (int64_t)chunks[t].col.size();
+  }
+  if (R.max_row == INT32_MAX || total >= (int64_t)INT32_MAX - 4096) { R.max_row = INT32_MAX; return R; }
   S.prow.assign(n + 1, 0);
-  for (int64_t p = 0; p < n; ++p) S.prow[p + 1] = S.prow[p] + (int32_t)(cptr[where[p] + 1] - cptr[where[p]]);
-  S.pcol.resize(S.prow[n]);
-  S.pval.resize(S.prow[n]);
-  for (int64_t p = 0; p < n; ++p) {
-    const int64_t w = where[p];
-    std::copy(ccol.begin() + cptr[w], ccol.begin() + cptr[w + 1], S.pcol.begin() + S.prow[p]);
-    std::copy(cval.begin() + cptr[w], cval.begin() + cptr[w + 1], S.pval.begin() + S.prow[p]);
+  S.pcol.resize(total);
+  S.pval.resize(total);
+  int64_t w = 0;
+  for (int t = 0; t < T; ++t) {
+    const int32_t r0 = G.gptr[qcut[t]];
+    for (size_t r = 0; r < chunks[t].len.size(); ++r) S.prow[r0 + r + 1] = chunks[t].len[r];
+    std::copy(chunks[t].col.begin(), chunks[t].col.end(), S.pcol.begin() + w);
+    std::copy(chunks[t].val.begin(), chunks[t].val.end(), S.pval.begin() + w);
+    w += (int64_t)chunks[t].col.size();
+    MergeChunk().len.swap(chunks[t].len);
+    std::vector<int32_t>().swap(chunks[t].col);
+    std::vector<double>().swap(chunks[t].val);
   }
+  for (int64_t p = 0; p < n; ++p) S.prow[p + 1] += S.prow[p];
   return R;
 }
 
@@ -468,17 +574,22 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       const bool backward = dir == 1;
       double best = merge_cost(base.nlev, nnz);
       int best_m = 1;
-      MergeResult keep;
-      for (int m = 2; m <= g_gs_merge; ++m) {
-        MergeResult r = merge_build(base, g->ncols, m, backward);
-        if (r.max_row > kSlot) break;  // a composite row no longer fits a slot: fill has exploded
-        const double c = merge_cost(r.sys.nlev, r.sys.prow[n]) + 12.0 * (double)nnz / 2 / 4e12;  // + the pre-pass
+      for (int m = 2; m <= g_gs_merge; ++m) {  // fill estimated on a sample of groups
+        const std::pair<double, int64_t> est = merge_estimate(base, g->ncols, m, backward);
+        if (est.second > kSlot - kSlot / 8) break;  // composite rows (sampled) are about to outgrow a slot: fill has exploded
+        const int ngrp = (base.nlev + m - 1) / m;
+        const double c = merge_cost(ngrp, (int64_t)(est.first * n)) + 12.0 * (double)nnz / 2 / 4e12;  // + the pre-pass
         if (getenv("AMGH_VERBOSE"))
-          fprintf(stderr, "[amghip] n=%lld %s merge m=%d: %d groups, %.1f entries/row (max %lld), est. %.2f ms vs %.2f ms\n",
-                  (long long)n, backward ? "bwd" : "fwd", m, r.sys.nlev, (double)r.sys.prow[n] / n, (long long)r.max_row,
-                  1e3 * c, 1e3 * best);
-        if (c < 0.97 * best) { best = c; best_m = m; keep = std::move(r); }
+          fprintf(stderr, "[amghip] n=%lld %s merge m=%d: %d groups, ~%.1f entries/row (max %lld), est. %.2f ms vs %.2f ms\n",
+                  (long long)n, backward ? "bwd" : "fwd", m, ngrp, est.first, (long long)est.second, 1e3 * c, 1e3 * best);
+        if (c < 0.97 * best) { best = c; best_m = m; }
         else break;
+      }
+      MergeResult keep;
+      while (best_m > 1) {
+        keep = merge_build(base, g->ncols, best_m, backward);
+        if (keep.max_row <= kSlot) break;
+        --best_m;  // the sample missed a row that outgrows a slot: one level fewer per group
       }
       if (best_m > 1) {
         GsSchedule* ch = new GsSchedule;
