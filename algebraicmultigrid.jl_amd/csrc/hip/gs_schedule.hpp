@@ -544,7 +544,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   // than index blocks) and the dense blocks stay small.
   {
     const int nblk = (int)((n + kBlk - 1) / kBlk);
-    if (n >= 16 && n <= 262144 && g->nlev >= 3 * nblk) {
+    if (g_gs_block_inverse && n >= 16 && n <= 262144 && g->nlev >= 3 * nblk) {
       std::vector<double> dg(n, 0.0);
       for (int64_t i = 0; i < n; ++i)
         for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
