@@ -74,6 +74,7 @@ struct GsSchedule {
   std::vector<Seg> segs;
   // slot layout of the wide levels (gs_slot_kernel)
   int32_t* wcol = nullptr; double* wval = nullptr; int32_t* slot_row = nullptr; i4_t* wmeta = nullptr;
+  int slot_entries = kSlot;  // kSlot (gs_slot_kernel) or kBigSlot (gs_bigslot_kernel: long composite rows)
   // block-inverse path (small, densely coupled operators; see gs_block_kernel)
   struct Outer {
     int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; double* tinv = nullptr;
@@ -145,7 +146,8 @@ int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (on
 int g_gs_threads = 256;
 int g_gs_block_pipe = 1;        // software-pipelined block sweep (gs_block_pipe_kernel)
 int g_gs_super = 8;             // block-inverse sweeps: blocks per superblock (0 = one launch for the whole operator); read at schedule build
-int g_gs_merge = 6;             // merged-level sweeps: largest group of dependency levels tried (1 = off); read at schedule build
+int g_gs_bigslot = 1;           // allow long-row slots (composite rows up to 2048 entries) when merging
+int g_gs_merge = 16;             // merged-level sweeps: largest group of dependency levels tried (1 = off); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)

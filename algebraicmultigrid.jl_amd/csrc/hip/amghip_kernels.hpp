@@ -587,6 +587,70 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
   }
 }
 
+// Long-row slots: composite rows of deeply merged groups have hundreds to ~2000 entries.  Same idea as
+// gs_slot_kernel with 2048 entries per slot (4 per thread) and at most 64 rows per slot; a row is summed by a
+// whole wave (entries interleaved over the 64 lanes: conflict-free LDS reads, a 1600-entry row is 26 steps +
+// a wave reduction instead of 1600 dependent adds), wave w takes rows w, w + 8, ... of the slot.
+constexpr int kBigSlot = 2048;
+constexpr int kBigRows = 64;
+
+template <bool SOR>
+__global__ __launch_bounds__(kSlot) void gs_bigslot_kernel(SlotArgs a) {
+  constexpr int EPT = kBigSlot / kSlot, NW = kSlot / kWave;
+  __shared__ double s_prod[kBigSlot];
+  const int tid = threadIdx.x;
+  int lb, cv;
+  multi_column_block(a.ncolv, lb, cv);
+  if (cv > 0) {
+    a.x += (int64_t)cv * a.ldx;
+    a.bp += (int64_t)cv * a.ldb;
+  }
+  if (a.xcd_map) lb = xcd_block(lb, a.nslots);
+  if (lb >= a.nslots) return;
+  const int s = a.slot0 + lb;
+  const int base = s * kBigSlot;
+  double v[EPT], xv[EPT];
+  int c[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    v[e] = a.wval[base + tid + e * kSlot];
+    c[e] = a.wcol[base + tid + e * kSlot];
+  }
+  const int r0 = a.slot_row[2 * s], nrows = a.slot_row[2 * s + 1] - r0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) xv[e] = a.x[c[e]];
+  const int wv = tid / kWave, ln = tid % kWave;
+  // row data of this wave's first two rows, requested with the gathers
+  i4_t m[2];
+  double d[2], bb[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = wv + u * NW;
+    m[u] = i4_t{0, 0, -1, 0}; d[u] = 0.0; bb[u] = 0.0;
+    if (r < nrows) { m[u] = a.wmeta[r0 + r]; d[u] = a.diag[r0 + r]; bb[u] = a.bp[r0 + r]; }
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) s_prod[tid + e * kSlot] = v[e] * xv[e];
+  __syncthreads();
+  int u = 0;
+  for (int r = wv; r < nrows; r += NW, ++u) {
+    i4_t mm;
+    double dd, bv;
+    if (u < 2) { mm = m[u]; dd = d[u]; bv = bb[u]; }
+    else { mm = a.wmeta[r0 + r]; dd = a.diag[r0 + r]; bv = a.bp[r0 + r]; }
+    const int dz = mm.z - base, qe = mm.y - base;
+    double acc = 0.0;
+    for (int q = mm.x - base + ln; q < qe; q += kWave)
+      if (q != dz) acc += s_prod[q];
+#pragma unroll
+    for (int w = 1; w < kWave; w <<= 1) acc += __shfl_xor(acc, w, kWave);
+    if (ln == 0 && dd != 0.0) {
+      const int i = r0 + r;
+      a.x[i] = SOR ? (1.0 - a.omega) * a.x[i] + (a.omega / dd) * (bv - acc) : (bv - acc) / dd;
+    }
+  }
+}
+
 // ---- block-inverse Gauss-Seidel for small, densely coupled operators ------------------------
 // Coarse AMG levels have few rows but long rows (60-124 nonzeros) and therefore almost as many
 // dependency levels as rows: level scheduling degenerates to ~1 row per step.  For those operators

@@ -221,6 +221,14 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       sa.diag = lay->diag; sa.bp = rhs; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;
       sa.nslots = s.nslots; sa.xcd_map = g_gs_xcd_map;
       sa.ldx = xs; sa.ldb = ldb;
+      if (lay->slot_entries == kBigSlot) {  // long composite rows: 2048-entry slots, 8 lanes per row
+        sa.ncolv = ncolv;
+        const int grid = ((g_gs_xcd_map || ncolv > 1) ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots) * ncolv;
+        if (sor) hipLaunchKernelGGL(gs_bigslot_kernel<true>, dim3(grid), dim3(kSlot), 0, st, sa);
+        else hipLaunchKernelGGL(gs_bigslot_kernel<false>, dim3(grid), dim3(kSlot), 0, st, sa);
+        HIP_TRY(hipGetLastError());
+        continue;
+      }
       // columns per workgroup: the largest of 8 / 4 / 2 / 1 that divides the block size
       const int ncv = (ncolv % 8 == 0) ? 8 : (ncolv % 4 == 0) ? 4 : (ncolv % 2 == 0) ? 2 : 1;
       sa.ncolv = ncolv / ncv;

@@ -113,7 +113,7 @@ struct HostLevelCsr {
 // Upload one level-ordered system and derive its execution layout: row / level descriptors for the chain
 // kernel, segments (runs of narrow levels chained in one workgroup, one launch per wide level), slot arrays.
 // `orig` = original row id of each level-ordered row (rowmeta.w), may be null.
-int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig) {
+int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int slot_entries = kSlot) {
   const int64_t n = h.n;
   const std::vector<int32_t>& prow = h.prow;
   const std::vector<int32_t>& pcol = h.pcol;
@@ -123,6 +123,9 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig) {
   g->n = n;
   g->nlev = h.nlev;
   g->lvl_ptr = h.lvl_ptr;
+  g->slot_entries = slot_entries;
+  const int SE = slot_entries;                                    // entries per slot
+  const int max_rows = SE == kSlot ? kSlot : kBigRows;           // rows per slot
   RC_TRY(dev_upload(&g->rowptr, prow.data(), n + 1));
   RC_TRY(dev_upload(&g->col, pcol.data(), nnz));
   RC_TRY(dev_upload(&g->val, pval.data(), nnz));
@@ -197,28 +200,30 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig) {
       if (sg.chain) continue;
       const int ra = g->lvl_ptr[sg.l0], rb = g->lvl_ptr[sg.l0 + 1];
       bool fits = true;
-      for (int p2 = ra; p2 < rb && fits; ++p2) fits = prow[p2 + 1] - prow[p2] <= kSlot;
+      for (int p2 = ra; p2 < rb && fits; ++p2) fits = prow[p2 + 1] - prow[p2] <= SE;
       if (!fits) continue;
       sg.slot0 = (int)slot_row.size();
-      int fill = kSlot;  // force a new slot for the level's first row
+      int fill = SE, rows_in = 0;  // force a new slot for the level's first row
       for (int p2 = ra; p2 < rb; ++p2) {
         const int len = prow[p2 + 1] - prow[p2];
-        if (fill + len > kSlot) {  // open a new slot (pad the previous one)
-          wcol.resize(slot_row.size() * (size_t)kSlot, 0);
-          wval.resize(slot_row.size() * (size_t)kSlot, 0.0);
+        if (fill + len > SE || rows_in >= max_rows) {  // open a new slot (pad the previous one)
+          wcol.resize(slot_row.size() * (size_t)SE, 0);
+          wval.resize(slot_row.size() * (size_t)SE, 0.0);
           slot_row.push_back(p2);
           fill = 0;
+          rows_in = 0;
         }
-        const int32_t start = (int32_t)((slot_row.size() - 1) * (size_t)kSlot + fill);
+        const int32_t start = (int32_t)((slot_row.size() - 1) * (size_t)SE + fill);
         for (int32_t j = prow[p2]; j < prow[p2 + 1]; ++j) { wcol.push_back(pcol[j]); wval.push_back(pval[j]); }
         wmeta[p2] = i4_t{start, start + len, pdpos[p2] >= 0 ? start + (pdpos[p2] - prow[p2]) : -1, 0};
         fill += len;
+        ++rows_in;
       }
       sg.nslots = (int)slot_row.size() - sg.slot0;
     }
     if (!slot_row.empty()) {
-      wcol.resize(slot_row.size() * (size_t)kSlot, 0);
-      wval.resize(slot_row.size() * (size_t)kSlot, 0.0);
+      wcol.resize(slot_row.size() * (size_t)SE, 0);
+      wval.resize(slot_row.size() * (size_t)SE, 0.0);
       // slot_row[s + 1] must close the last slot of every level: append per-level end markers by
       // storing, for each slot, its end row in a parallel array packed as slot_row2
       std::vector<int32_t> sr2(2 * slot_row.size());
@@ -291,8 +296,9 @@ struct MergeChunk {
   std::vector<int32_t> len, col;
   std::vector<double> val;
 };
-int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncols, int q0, int q1, MergeChunk* out) {
-  constexpr int kCap = 2048;  // open-addressing accumulator: rows longer than kSlot are rejected anyway
+int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncols, int q0, int q1, MergeChunk* out,
+                    int row_cap = kBigSlot) {
+  constexpr int kCap = 4 * kBigSlot;  // open-addressing accumulator: rows longer than row_cap are rejected
   std::vector<int32_t> key(kCap, -1);
   std::vector<std::pair<int32_t, int32_t>> order;  // {column, accumulator slot} of the row being built
   std::vector<double> acc(kCap);
@@ -321,7 +327,7 @@ int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncol
         uint32_t h = ((uint32_t)c * 2654435761u) & (kCap - 1);
         while (key[h] != -1 && key[h] != c) h = (h + 1) & (kCap - 1);
         if (key[h] == -1) {
-          if ((int)order.size() >= kSlot) { overflow = true; return; }
+          if ((int)order.size() >= row_cap) { overflow = true; return; }
           key[h] = c; acc[h] = v; order.push_back({c, (int32_t)h});
         } else {
           acc[h] += v;
@@ -382,18 +388,30 @@ int merge_threads() {
 // Fill estimate for group size m from a sample of groups: {entries per row, longest row}
 std::pair<double, int64_t> merge_estimate(const HostLevelCsr& base, int64_t ncols, int m, bool backward) {
   MergeGroups G = merge_groups(base, m, backward);
-  const int nsample = std::min(G.ngrp, 48);
-  int64_t rows = 0, ents = 0, mx = 0;
-  MergeChunk ch;
-  for (int k = 0; k < nsample; ++k) {
-    const int q = (int)((int64_t)k * G.ngrp / nsample);
-    const int64_t r = merge_chunk(base, G, ncols, q, q + 1, &ch);
-    if (r == INT32_MAX) return {1e30, INT32_MAX};
-    mx = std::max(mx, r);
-    rows += (int64_t)ch.len.size();
-    ents += (int64_t)ch.col.size();
-  }
-  return {rows ? (double)ents / rows : 0.0, mx};
+  if (G.ngrp == 0) return {0.0, 0};
+  // about two million rows in the sample, 8..48 groups, evenly spaced
+  const int64_t rows_per_group = std::max<int64_t>(1, base.n / G.ngrp);
+  const int nsample = (int)std::min<int64_t>(G.ngrp, std::max<int64_t>(8, std::min<int64_t>(48, 2000000 / rows_per_group)));
+  const int T = std::max(1, std::min(merge_threads(), nsample));
+  std::vector<int64_t> rows(T, 0), ents(T, 0), mx(T, 0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t]() {
+      MergeChunk ch;
+      for (int k = t; k < nsample; k += T) {
+        const int q = (int)((int64_t)k * G.ngrp / nsample);
+        const int64_t r = merge_chunk(base, G, ncols, q, q + 1, &ch);
+        mx[t] = std::max(mx[t], r);
+        if (r == INT32_MAX) return;
+        rows[t] += (int64_t)ch.len.size();
+        ents[t] += (int64_t)ch.col.size();
+      }
+    });
+  for (auto& x : th) x.join();
+  int64_t R = 0, E = 0, M = 0;
+  for (int t = 0; t < T; ++t) { R += rows[t]; E += ents[t]; M = std::max(M, mx[t]); }
+  if (M == INT32_MAX) return {1e30, INT32_MAX};
+  return {R ? (double)E / R : 0.0, M};
 }
 
 MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool backward) {
@@ -566,40 +584,72 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       }
     }
   }
-  // Merged levels: only where the launch-per-level schedule is what runs (no block path) and there are enough
-  // wide levels for the boundaries to matter.
+  // Merged levels.  Candidates are compared, per direction, with what would run otherwise: a boundary per
+  // dependency level, or the block-inverse sweep (which merged groups with long-row slots replace when cheaper).
   g->xstride = g->ncols;
-  if (g_gs_merge > 1 && g->nblk == 0 && n >= 4096 && g->nlev >= 64) {
+  if (g_gs_merge > 1 && n >= 4096 && g->nlev >= 64 && (g->nblk == 0 || g_gs_bigslot)) {
+    const int S = g->super > 0 ? g->super : std::max(1, g->nblk);
+    const double block_cost = g->nblk * 5.9e-6 + 2.0 * ((g->nblk + S - 1) / S) * 3.5e-6;
+    int chosen_m[2] = {1, 1}, chosen_cap[2] = {kSlot, kSlot};
     for (int dir = 0; dir < 2; ++dir) {
       const bool backward = dir == 1;
-      double best = merge_cost(base.nlev, nnz);
-      int best_m = 1;
+      double best = g->nblk > 0 ? block_cost : merge_cost(base.nlev, nnz);
+      int worse = 0;
       for (int m = 2; m <= g_gs_merge; ++m) {  // fill estimated on a sample of groups
         const std::pair<double, int64_t> est = merge_estimate(base, g->ncols, m, backward);
-        if (est.second > kSlot - kSlot / 8) break;  // composite rows (sampled) are about to outgrow a slot: fill has exploded
+        int cap = kSlot;
+        if (est.second > kSlot - kSlot / 8) cap = kBigSlot;
+        if (est.second > kBigSlot - kBigSlot / 8 || (cap == kBigSlot && !g_gs_bigslot)) break;  // fill has exploded
         const int ngrp = (base.nlev + m - 1) / m;
-        const double c = merge_cost(ngrp, (int64_t)(est.first * n)) + 12.0 * (double)nnz / 2 / 4e12;  // + the pre-pass
+        // + the pre-pass; a long-row launch costs ~2.5 us more (a wave per row, rows of very different lengths)
+        const double c = merge_cost(ngrp, (int64_t)(est.first * n)) + 12.0 * (double)nnz / 2 / 4e12 +
+                         (cap == kBigSlot ? ngrp * 2.5e-6 : 0.0);
         if (getenv("AMGH_VERBOSE"))
           fprintf(stderr, "[amghip] n=%lld %s merge m=%d: %d groups, ~%.1f entries/row (max %lld), est. %.2f ms vs %.2f ms\n",
                   (long long)n, backward ? "bwd" : "fwd", m, ngrp, est.first, (long long)est.second, 1e3 * c, 1e3 * best);
-        if (c < 0.97 * best) { best = c; best_m = m; }
-        else break;
+        if (c < 0.97 * best) { best = c; chosen_m[dir] = m; chosen_cap[dir] = cap; worse = 0; }
+        else if (++worse >= 6) break;  // well past the minimum (the step to long-row slots is a bump, not the end)
+        if (12.0 * est.first * n / 2.5e12 > best) break;  // streaming the composite rows alone costs more: fill only grows with m
       }
+    }
+    // an operator on the block path keeps it unless both directions are cheaper merged
+    const bool use = g->nblk == 0 ? true : (chosen_m[0] > 1 && chosen_m[1] > 1);
+    for (int dir = 0; dir < 2 && use; ++dir) {
+      const bool backward = dir == 1;
+      int best_m = chosen_m[dir], cap = chosen_cap[dir];
       MergeResult keep;
       while (best_m > 1) {
         keep = merge_build(base, g->ncols, best_m, backward);
-        if (keep.max_row <= kSlot) break;
+        if (keep.max_row > cap && cap == kSlot && g_gs_bigslot && keep.max_row <= kBigSlot) cap = kBigSlot;
+        if (keep.max_row <= cap) break;
         --best_m;  // the sample missed a row that outgrows a slot: one level fewer per group
       }
       if (best_m > 1) {
         GsSchedule* ch = new GsSchedule;
         (backward ? g->mb : g->mf) = ch;
         ch->ncols = g->ncols;
-        RC_TRY(layout_upload(ch, keep.sys, perm.data()));
+        RC_TRY(layout_upload(ch, keep.sys, perm.data(), cap));
         RC_TRY(tri_upload(backward ? &g->tri_b : &g->tri_f, base, backward, &g->bytes));
         (backward ? g->merge_b : g->merge_f) = best_m;
         g->bytes += ch->bytes;
+        if (getenv("AMGH_VERBOSE"))
+          fprintf(stderr, "[amghip] n=%lld %s: groups of %d levels, %d-entry slots, longest row %lld\n", (long long)n,
+                  backward ? "bwd" : "fwd", best_m, cap, (long long)keep.max_row);
       }
+    }
+    if (g->nblk > 0 && g->mf && g->mb) {  // merged groups replace the block-inverse sweeps
+      for (GsSchedule::Outer* o : {&g->blk_f, &g->blk_b}) {
+        hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv);
+        hipFree(o->near_ptr); hipFree(o->near_pi); hipFree(o->near_val);
+        hipFree(o->nx_rowptr); hipFree(o->nx_col); hipFree(o->nx_val);
+        hipFree(o->sp_rowptr); hipFree(o->sp_col); hipFree(o->sp_val);
+        *o = GsSchedule::Outer();
+      }
+      g->bytes -= 2 * ((int64_t)g->nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4);
+      g->nblk = 0;
+    } else if (g->nblk > 0) {  // stays on the block path: drop half-built children
+      for (GsSchedule** c : {&g->mf, &g->mb})
+        if (*c) { g->bytes -= (*c)->bytes; (*c)->free_dev(); delete *c; *c = nullptr; }
     }
     if (g->mf || g->mb) g->xstride = g->ncols + n;
   }
