@@ -203,10 +203,12 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       for (int p2 = ra; p2 < rb && fits; ++p2) fits = prow[p2 + 1] - prow[p2] <= SE;
       if (!fits) continue;
       sg.slot0 = (int)slot_row.size();
-      int fill = SE, rows_in = 0;  // force a new slot for the level's first row
+      int fill = 0, rows_in = 0;
+      bool open = false;  // the level's first row always opens a slot (composite rows can be empty: fill + 0 > SE never fires)
       for (int p2 = ra; p2 < rb; ++p2) {
         const int len = prow[p2 + 1] - prow[p2];
-        if (fill + len > SE || rows_in >= max_rows) {  // open a new slot (pad the previous one)
+        if (!open || fill + len > SE || rows_in >= max_rows) {  // open a new slot (pad the previous one)
+          open = true;
           wcol.resize(slot_row.size() * (size_t)SE, 0);
           wval.resize(slot_row.size() * (size_t)SE, 0.0);
           slot_row.push_back(p2);
@@ -234,6 +236,26 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
           sr2[2 * sidx] = slot_row[sidx];
           sr2[2 * sidx + 1] = (q + 1 < sg.nslots) ? slot_row[sidx + 1] : g->lvl_ptr[sg.l0 + 1];
         }
+      }
+      if (getenv("AMGH_VERBOSE")) {  // self-check of the slot layout
+        int64_t bad = 0;
+        for (auto& sg : g->segs) {
+          if (sg.chain || sg.nslots <= 0) continue;
+          for (int q = 0; q < sg.nslots; ++q) {
+            const int sidx = sg.slot0 + q;
+            const int ra = sr2[2 * sidx], rb = sr2[2 * sidx + 1];
+            if (rb - ra > max_rows || rb <= ra) ++bad;
+            for (int r = ra; r < rb; ++r)
+              if (wmeta[r].x < (int64_t)sidx * SE || wmeta[r].y > (int64_t)(sidx + 1) * SE || wmeta[r].y < wmeta[r].x) ++bad;
+          }
+        }
+        for (auto& sg : g->segs) {  // every row of a slotted level belongs to exactly one of its slots
+          if (sg.chain || sg.nslots <= 0) continue;
+          if (sr2[2 * sg.slot0] != g->lvl_ptr[sg.l0]) ++bad;
+          for (int q = 0; q + 1 < sg.nslots; ++q)
+            if (sr2[2 * (sg.slot0 + q) + 1] != sr2[2 * (sg.slot0 + q + 1)]) ++bad;
+        }
+        if (bad) fprintf(stderr, "[amghip] slot layout self-check: %lld inconsistencies (SE=%d)\n", (long long)bad, SE);
       }
       RC_TRY(dev_upload(&g->wcol, wcol.data(), (int64_t)wcol.size()));
       RC_TRY(dev_upload(&g->wval, wval.data(), (int64_t)wval.size()));
@@ -598,7 +620,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       for (int m = 2; m <= g_gs_merge; ++m) {  // fill estimated on a sample of groups
         const std::pair<double, int64_t> est = merge_estimate(base, g->ncols, m, backward);
         int cap = kSlot;
-        if (est.second > kSlot - kSlot / 8) cap = kBigSlot;
+        if (est.second > kSlot - kSlot / 8 || g_gs_bigslot == 2) cap = kBigSlot;  // (2 = always: test hook)
         if (est.second > kBigSlot - kBigSlot / 8 || (cap == kBigSlot && !g_gs_bigslot)) break;  // fill has exploded
         const int ngrp = (base.nlev + m - 1) / m;
         // + the pre-pass; a long-row launch costs ~2.5 us more (a wave per row, rows of very different lengths)

@@ -179,6 +179,32 @@ def test_block_inverse_sweeps_all_variants(super_blocks, pipe):
         lib.amgh_debug_set_tunable(b"gs_block_pipe", 1)
 
 
+@pytest.mark.parametrize("bigslot", [0, 1, 2])   # 2: long-row slot layout everywhere
+def test_merged_level_sweeps_irregular_operator(bigslot):
+    """Merged dependency levels (substituted groups, pre-pass over the other triangle) on irregular operators with
+    rows that keep their x (zero diagonal): with and without the long-row slot layout, GS forward / backward /
+    symmetric / several iterations, against the oracle's scalar sweeps."""
+    lib = AMG.hip_lib()
+    lib.amgh_debug_set_tunable(b"gs_block_inverse", 0)   # read at schedule build: force the level-scheduled paths
+    lib.amgh_debug_set_tunable(b"gs_bigslot", bigslot)
+    try:
+        cases = [_dense_band_spd(6000, 12, 21, zero_diag_rows=(0, 17, 3000, 5999)), _dense_band_spd(5000, 40, 22)]
+        ml = AMG.ruge_stuben(AMG.poisson((40, 36, 30)))
+        cases.append(ml.levels[1].A)             # Galerkin operator of a 3-D grid (19-point-like rows)
+        cases.append(AMG.ruge_stuben(AMG.poisson((64, 64, 48))).levels[2].A)   # longer rows: deep groups outgrow 512-entry slots
+        for k, A in enumerate(cases):
+            n = A.m
+            x0, b = uniform(n, 90 + k) - 0.5, uniform(n, 95 + k)
+            for s in (FWD, BWD, SYM, AMG.GaussSeidel(AMG.SymmetricSweep(), 2)):
+                x = x0.copy()
+                s(A, x, b)
+                ref = O.smooth(s, A, x0, b)
+                assert rel(x, ref) <= 1e-11, (bigslot, k, repr(s), rel(x, ref))
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_block_inverse", 1)
+        lib.amgh_debug_set_tunable(b"gs_bigslot", 1)
+
+
 def _halo_case(A_sq, nloc):
     """Rows [0, nloc) of a square operator as a rectangular local block (columns >= nloc are frozen halo values, as
     on a shard) + the equivalent square system for the oracle: identity rows keep the halo entries."""
