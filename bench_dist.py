@@ -43,7 +43,10 @@ def main_distributed(args):
     dist.barrier()
     # the library's default is min(cores, cgroup CPU quota, 64): split that between the ranks of this node
     L = AMG.setup_lib()
-    L.amgs_set_threads(max(1, L.amgs_set_threads(0) // int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    nthreads = max(1, L.amgs_set_threads(0) // int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    L.amgs_set_threads(nthreads)
+    # host threads of the smoother-schedule builds in libamghip (merged-level composite rows)
+    os.environ.setdefault("AMGH_BUILD_THREADS", str(nthreads))
 
     N = args.size
     t0 = time.perf_counter()
