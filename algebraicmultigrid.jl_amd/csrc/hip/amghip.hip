@@ -941,6 +941,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_bigslot")) g_gs_bigslot = value;
+  else if (!strcmp(name, "gs_flip")) g_gs_flip = value;
   else if (!strcmp(name, "gs_super")) g_gs_super = value;
   else if (!strcmp(name, "gs_block_pipe")) g_gs_block_pipe = value;
   else return AMGH_EINVAL;

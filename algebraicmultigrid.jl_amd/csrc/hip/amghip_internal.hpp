@@ -102,6 +102,8 @@ struct GsSchedule {
   Tri tri_f, tri_b;       // forward pre-pass: entries of later levels + halo; backward: earlier levels + halo
   int merge_f = 1, merge_b = 1;  // dependency levels per group
   int64_t xstride = 0;    // doubles per column of xp (ncols, or ncols + n with merged children)
+  bool flip_ok = false;   // square operator, no zero diagonal: the next alternating sweep's s follows from the last one
+  int s_dir = -1;         // direction (0 fwd, 1 bwd) whose merged sweep last ran on the current xp / s, -1: none
   void free_dev() {
     for (GsSchedule** c : {&mf, &mb})
       if (*c) { (*c)->free_dev(); delete *c; *c = nullptr; }
@@ -146,6 +148,7 @@ int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (on
 int g_gs_threads = 256;
 int g_gs_block_pipe = 1;        // software-pipelined block sweep (gs_block_pipe_kernel)
 int g_gs_super = 8;             // block-inverse sweeps: blocks per superblock (0 = one launch for the whole operator); read at schedule build
+int g_gs_flip = 1;              // alternating merged sweeps: s of the next sweep from the last one (no matrix pass)
 int g_gs_bigslot = 1;           // allow long-row slots (composite rows up to 2048 entries) when merging
 int g_gs_merge = 16;             // merged-level sweeps: largest group of dependency levels tried (1 = off); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel

@@ -331,6 +331,18 @@ __global__ void scatter_perm_kernel(const double* __restrict__ xp, const int32_t
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) x[perm[r]] = xp[r];
 }
 
+// Right-hand side of the NEXT merged sweep when the directions alternate: after a forward sweep
+// (D + L) x = s_f holds row by row, so the backward pre-pass b - L x is b - s_f + D x — no matrix pass
+// (and symmetrically after a backward sweep).  Level order; blockIdx.y = right-hand-side column.
+__global__ void gs_flip_rhs_kernel(const double* __restrict__ bp, const double* __restrict__ diag,
+                                   const double* __restrict__ xp, double* __restrict__ sp, int n, int64_t ldb, int64_t ldx) {
+  bp += blockIdx.y * ldb;
+  xp += blockIdx.y * ldx;
+  sp += blockIdx.y * ldx;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x)
+    sp[r] = bp[r] - sp[r] + diag[r] * xp[r];
+}
+
 // Single-workgroup chain over consecutive NARROW dependency levels of a
 // Gauss-Seidel/SOR sweep: one thread per row, a workgroup barrier between
 // dependency levels (visibility of x inside one CU needs only the barrier).

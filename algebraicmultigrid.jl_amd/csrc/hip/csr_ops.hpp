@@ -190,17 +190,28 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
   GsSchedule* lay = g;
   const double* rhs = g->bp;
   int64_t ldb = g->n;
+  if (first) g->s_dir = -1;
   if (!sor && g_gs_merge > 1 && (backward ? g->mb : g->mf)) {
     lay = backward ? g->mb : g->mf;
-    const GsSchedule::Tri& t = backward ? g->tri_b : g->tri_f;
-    StreamArgs ra{};
-    ra.rowptr = t.rowptr; ra.col = t.col; ra.val = t.val;
-    ra.x = xp; ra.b = g->bp; ra.y = xp + g->ncols;
-    ra.row_begin = 0; ra.row_end = (int32_t)g->n;
-    ra.ldx = xs; ra.ldy = xs; ra.ldb = g->n;
-    RC_TRY(launch_stream<M_RESID>(ra, st, ncolv));
+    if (g->flip_ok && g_gs_flip && g->s_dir == (backward ? 0 : 1)) {
+      // the previous sweep of this smooth! call ran the other way on the same xp: s follows without a matrix pass
+      hipLaunchKernelGGL(gs_flip_rhs_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const double*)g->bp,
+                         (const double*)lay->diag, (const double*)xp, xp + g->ncols, (int)g->n, (int64_t)g->n, xs);
+      HIP_TRY(hipGetLastError());
+    } else {
+      const GsSchedule::Tri& t = backward ? g->tri_b : g->tri_f;
+      StreamArgs ra{};
+      ra.rowptr = t.rowptr; ra.col = t.col; ra.val = t.val;
+      ra.x = xp; ra.b = g->bp; ra.y = xp + g->ncols;
+      ra.row_begin = 0; ra.row_end = (int32_t)g->n;
+      ra.ldx = xs; ra.ldy = xs; ra.ldb = g->n;
+      RC_TRY(launch_stream<M_RESID>(ra, st, ncolv));
+    }
+    g->s_dir = backward ? 1 : 0;
     rhs = xp + g->ncols;
     ldb = xs;
+  } else {
+    g->s_dir = -1;
   }
   const int ns = (int)lay->segs.size();
   for (int k = 0; k < ns; ++k) {

@@ -674,6 +674,8 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         if (*c) { g->bytes -= (*c)->bytes; (*c)->free_dev(); delete *c; *c = nullptr; }
     }
     if (g->mf || g->mb) g->xstride = g->ncols + n;
+    g->flip_ok = g->mf && g->mb && g->ncols == n;
+    for (int64_t p2 = 0; p2 < n && g->flip_ok; ++p2) g->flip_ok = base.pdiag[p2] != 0.0;
   }
   RC_TRY(dev_alloc(&g->bp, n));
   RC_TRY(dev_alloc(&g->xp, g->xstride));
