@@ -5,6 +5,7 @@
 #include "amghip_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>

@@ -201,6 +201,8 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       const int ra = g->lvl_ptr[sg.l0], rb = g->lvl_ptr[sg.l0 + 1];
       bool fits = true;
       for (int p2 = ra; p2 < rb && fits; ++p2) fits = prow[p2 + 1] - prow[p2] <= SE;
+      // slot positions are int32: a level that would push the slot arrays past 2^31 entries keeps the CSR kernels
+      if (fits && ((int64_t)slot_row.size() + (prow[rb] - prow[ra]) / std::max(1, SE / 2) + (rb - ra) / max_rows + 2) * SE >= (int64_t)INT32_MAX) fits = false;
       if (!fits) continue;
       sg.slot0 = (int)slot_row.size();
       int fill = 0, rows_in = 0;
@@ -513,9 +515,21 @@ int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int6
 double merge_cost(int64_t ngroups, int64_t nnz) { return ngroups * 3.8e-6 + 12.0 * (double)nnz / 2.5e12; }
 
 // Build the dependency-level schedule from HOST arrays of the smoother matrix.
+struct BuildTimer {  // AMGH_VERBOSE: where the host time of a schedule build goes
+  bool on = getenv("AMGH_VERBOSE") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void lap(const char* what, int64_t n) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[amghip] n=%lld build: %-28s %.2f s\n", (long long)n, what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
              const double* val) {
   const int64_t n = nrows;
+  BuildTimer tm;
   std::vector<int32_t> lev(n, 0);
   int32_t maxlev = -1;
   for (int64_t i = 0; i < n; ++i) {
@@ -571,7 +585,9 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
     base.pdiag[p] = d;
   }
   g->bytes = 0;
+  tm.lap("levels + permuted matrix", n);
   RC_TRY(layout_upload(g, base, perm.data()));
+  tm.lap("base layout", n);
   RC_TRY(dev_upload(&g->perm, perm.data(), n));
   g->ncols = std::max<int64_t>(ncols, n);
   {
@@ -606,6 +622,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       }
     }
   }
+  tm.lap("block-inverse data", n);
   // Merged levels.  Candidates are compared, per direction, with what would run otherwise: a boundary per
   // dependency level, or the block-inverse sweep (which merged groups with long-row slots replace when cheaper).
   g->xstride = g->ncols;
@@ -634,6 +651,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         if (12.0 * est.first * n / 2.5e12 > best) break;  // streaming the composite rows alone costs more: fill only grows with m
       }
     }
+    tm.lap("merge estimates", n);
     // an operator on the block path keeps it unless both directions are cheaper merged
     const bool use = g->nblk == 0 ? true : (chosen_m[0] > 1 && chosen_m[1] > 1);
     for (int dir = 0; dir < 2 && use; ++dir) {
@@ -642,6 +660,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       MergeResult keep;
       while (best_m > 1) {
         keep = merge_build(base, g->ncols, best_m, backward);
+        tm.lap("merge build", n);
         if (keep.max_row > cap && cap == kSlot && g_gs_bigslot && keep.max_row <= kBigSlot) cap = kBigSlot;
         if (keep.max_row <= cap) break;
         --best_m;  // the sample missed a row that outgrows a slot: one level fewer per group
@@ -651,7 +670,9 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         (backward ? g->mb : g->mf) = ch;
         ch->ncols = g->ncols;
         RC_TRY(layout_upload(ch, keep.sys, perm.data(), cap));
+        tm.lap("merged layout", n);
         RC_TRY(tri_upload(backward ? &g->tri_b : &g->tri_f, base, backward, &g->bytes));
+        tm.lap("other triangle", n);
         (backward ? g->merge_b : g->merge_f) = best_m;
         g->bytes += ch->bytes;
         if (getenv("AMGH_VERBOSE"))
