@@ -930,6 +930,52 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
   return rc;
 }
 
+// Host-only emulation of ONE merged-level Gauss-Seidel sweep (no device work: usable without a GPU).  Runs the same
+// construction the device schedules use — dependency levels, level order, groups of m levels made independent by
+// substitution, pre-pass over the other triangle — and then applies the composite rows group by group on the host.
+// x: ncols entries (in/out, columns >= nrows are frozen halo values), b: nrows entries.  CPU tests compare it with
+// the scalar lexicographic sweep.  Returns the number of groups, or a negative error code.
+int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
+                                 const double* val, int m, int backward, double* x, const double* b) {
+  if (nrows < 0 || ncols < nrows || !rowptr || m < 1 || !x || !b) return AMGH_EINVAL;
+  const int64_t n = nrows;
+  HostLevelCsr base;
+  std::vector<int32_t> perm;
+  level_order(n, ncols, rowptr, col, val, base, perm);
+  MergeResult R = merge_build(base, ncols, m, backward != 0);
+  if (R.max_row > kBigSlot) return AMGH_EUNSUPPORTED;
+  const HostLevelCsr& S = R.sys;
+  std::vector<double> ext(ncols + n);
+  for (int64_t c = 0; c < ncols; ++c) ext[c] = c < n ? x[perm[c]] : x[c];
+  // pre-pass: s = b - T x over the triangle this direction does not substitute over (+ halo columns)
+  std::vector<int32_t> lev_of(n);
+  for (int l = 0; l < base.nlev; ++l)
+    for (int32_t p = base.lvl_ptr[l]; p < base.lvl_ptr[l + 1]; ++p) lev_of[p] = l;
+  for (int64_t p = 0; p < n; ++p) {
+    double s = b[perm[p]];
+    for (int32_t j = base.prow[p]; j < base.prow[p + 1]; ++j) {
+      const int32_t c = base.pcol[j];
+      if (c == p) continue;
+      const bool other = c >= n || (backward ? lev_of[c] < lev_of[p] : lev_of[c] > lev_of[p]);
+      if (other) s -= base.pval[j] * ext[c];
+    }
+    ext[ncols + p] = s;
+  }
+  // groups in sweep order; rows of a group only read earlier groups and s, so their order does not matter
+  for (int k = 0; k < S.nlev; ++k) {
+    const int q = backward ? S.nlev - 1 - k : k;
+    std::vector<double> xn(S.lvl_ptr[q + 1] - S.lvl_ptr[q]);
+    for (int32_t p = S.lvl_ptr[q]; p < S.lvl_ptr[q + 1]; ++p) {
+      double acc = 0.0;
+      for (int32_t j = S.prow[p]; j < S.prow[p + 1]; ++j) acc += S.pval[j] * ext[S.pcol[j]];
+      xn[p - S.lvl_ptr[q]] = S.pdiag[p] != 0.0 ? (ext[ncols + p] - acc) / S.pdiag[p] : ext[p];
+    }
+    for (int32_t p = S.lvl_ptr[q]; p < S.lvl_ptr[q + 1]; ++p) ext[p] = xn[p - S.lvl_ptr[q]];  // written after all reads
+  }
+  for (int64_t p = 0; p < n; ++p) x[perm[p]] = ext[p];
+  return S.nlev;
+}
+
 int amgh_debug_set_tunable(const char* name, int value) {
   if (!name) return AMGH_EINVAL;
   if (!strcmp(name, "gs_block_target")) g_gs_block_target = value;

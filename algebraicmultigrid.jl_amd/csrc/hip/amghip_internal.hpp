@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>

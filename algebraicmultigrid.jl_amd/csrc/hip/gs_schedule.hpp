@@ -409,6 +409,19 @@ int merge_threads() {
   return t;
 }
 
+// fn(t) for t in [0, T): on T threads when they can be had, inline otherwise (a thread that cannot be created
+// must not take the process down)
+template <class F>
+void run_threads(int T, F fn) {
+  std::vector<std::thread> th;
+  int started = 0;
+  for (; started < T - 1; ++started) {
+    try { th.emplace_back(fn, started); } catch (const std::system_error&) { break; }
+  }
+  for (int t = started; t < T; ++t) fn(t);
+  for (auto& x : th) x.join();
+}
+
 // Fill estimate for group size m from a sample of groups: {entries per row, longest row}
 std::pair<double, int64_t> merge_estimate(const HostLevelCsr& base, int64_t ncols, int m, bool backward) {
   MergeGroups G = merge_groups(base, m, backward);
@@ -418,20 +431,17 @@ std::pair<double, int64_t> merge_estimate(const HostLevelCsr& base, int64_t ncol
   const int nsample = (int)std::min<int64_t>(G.ngrp, std::max<int64_t>(8, std::min<int64_t>(48, 2000000 / rows_per_group)));
   const int T = std::max(1, std::min(merge_threads(), nsample));
   std::vector<int64_t> rows(T, 0), ents(T, 0), mx(T, 0);
-  std::vector<std::thread> th;
-  for (int t = 0; t < T; ++t)
-    th.emplace_back([&, t]() {
-      MergeChunk ch;
-      for (int k = t; k < nsample; k += T) {
-        const int q = (int)((int64_t)k * G.ngrp / nsample);
-        const int64_t r = merge_chunk(base, G, ncols, q, q + 1, &ch);
-        mx[t] = std::max(mx[t], r);
-        if (r == INT32_MAX) return;
-        rows[t] += (int64_t)ch.len.size();
-        ents[t] += (int64_t)ch.col.size();
-      }
-    });
-  for (auto& x : th) x.join();
+  run_threads(T, [&](int t) {
+    MergeChunk ch;
+    for (int k = t; k < nsample; k += T) {
+      const int q = (int)((int64_t)k * G.ngrp / nsample);
+      const int64_t r = merge_chunk(base, G, ncols, q, q + 1, &ch);
+      mx[t] = std::max(mx[t], r);
+      if (r == INT32_MAX) return;
+      rows[t] += (int64_t)ch.len.size();
+      ents[t] += (int64_t)ch.col.size();
+    }
+  });
   int64_t R = 0, E = 0, M = 0;
   for (int t = 0; t < T; ++t) { R += rows[t]; E += ents[t]; M = std::max(M, mx[t]); }
   if (M == INT32_MAX) return {1e30, INT32_MAX};
@@ -459,10 +469,7 @@ MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool bac
   }
   std::vector<MergeChunk> chunks(T);
   std::vector<int64_t> mx(T, 0);
-  std::vector<std::thread> th;
-  for (int t = 0; t < T; ++t)
-    th.emplace_back([&, t]() { mx[t] = merge_chunk(base, G, ncols, qcut[t], qcut[t + 1], &chunks[t]); });
-  for (auto& x : th) x.join();
+  run_threads(T, [&](int t) { mx[t] = merge_chunk(base, G, ncols, qcut[t], qcut[t + 1], &chunks[t]); });
   int64_t total = 0;
   for (int t = 0; t < T; ++t) {
     R.max_row = std::max(R.max_row, mx[t]);
@@ -526,10 +533,10 @@ struct BuildTimer {  // AMGH_VERBOSE: where the host time of a schedule build go
   }
 };
 
-int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
-             const double* val) {
-  const int64_t n = nrows;
-  BuildTimer tm;
+// dependency levels of the symmetrised pattern, the level order (perm: level-ordered row -> original row) and
+// the matrix in that order (columns renumbered, entries of a row in their original order)
+void level_order(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const double* val,
+                 HostLevelCsr& base, std::vector<int32_t>& perm) {
   std::vector<int32_t> lev(n, 0);
   int32_t maxlev = -1;
   for (int64_t i = 0; i < n; ++i) {
@@ -545,13 +552,13 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
     }
     maxlev = std::max(maxlev, li);
   }
-  HostLevelCsr base;
   base.n = n;
   base.nlev = (int)(maxlev + 1);
   base.lvl_ptr.assign(base.nlev + 1, 0);
   for (int64_t i = 0; i < n; ++i) base.lvl_ptr[lev[i] + 1]++;
   for (int l = 0; l < base.nlev; ++l) base.lvl_ptr[l + 1] += base.lvl_ptr[l];
-  std::vector<int32_t> perm(n), next(base.lvl_ptr.begin(), base.lvl_ptr.end() - (base.nlev > 0 ? 1 : 0));
+  perm.resize(n);
+  std::vector<int32_t> next(base.lvl_ptr.begin(), base.lvl_ptr.end() - (base.nlev > 0 ? 1 : 0));
   if (base.nlev == 0) next.clear();
   for (int64_t i = 0; i < n; ++i) perm[next[lev[i]]++] = (int32_t)i;  // ascending row id inside a level
   std::vector<int32_t>().swap(lev);
@@ -584,6 +591,16 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
     base.pdpos[p] = dp;
     base.pdiag[p] = d;
   }
+}
+
+int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
+             const double* val) {
+  const int64_t n = nrows;
+  BuildTimer tm;
+  HostLevelCsr base;
+  std::vector<int32_t> perm;
+  level_order(n, ncols, rowptr, col, val, base, perm);
+  const int64_t nnz = rowptr[n];
   g->bytes = 0;
   tm.lap("levels + permuted matrix", n);
   RC_TRY(layout_upload(g, base, perm.data()));

@@ -244,6 +244,13 @@ int amgh_profile_read(amgh_t* h, double* out, int reset);
  * (issue, gather+stage, barrier, row sums, store+barrier; levels; launches).  enable != 0 starts
  * accumulating; out8 (8 x uint64, may be NULL) receives and resets the sums.               */
 int amgh_debug_chain_timing(int enable, unsigned long long* out8);
+/* Host-only emulation of one merged-level Gauss-Seidel sweep (the construction behind the device schedules:
+ * dependency levels, groups of m levels made independent by substitution, pre-pass over the other triangle).
+ * No device work: CPU tests check it against the scalar lexicographic sweep (smoother.jl:78-88).
+ * x: ncols entries in/out (columns >= nrows are frozen halo values), b: nrows.  Returns the number of groups. */
+int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
+                                 const double* val, int m, int backward, double* x, const double* b);
+
 /* Diagnostics: launch-shape tunables of the per-dependency-level Gauss-Seidel launches
  * ("gs_block_target", "gs_min_rows", "gs_threads"); used by tools/ to pick the defaults.   */
 int amgh_debug_set_tunable(const char* name, int value);
