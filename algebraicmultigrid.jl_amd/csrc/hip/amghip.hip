@@ -64,7 +64,7 @@ struct amgh_handle {
   // AMGH_USE_GRAPH=1).
   bool use_graph = false;
   // hipGraph cache of whole cycles, keyed by the (x, b, cycle) they were captured on
-  struct CycleGraph { const double* x; const double* b; int cyc; hipGraphExec_t exec; };
+  struct CycleGraph { const double* x; const double* b; int cyc; bool xzero; hipGraphExec_t exec; };
   std::vector<CycleGraph> graphs;
 };
 
@@ -142,7 +142,8 @@ int coarse_solve(amgh_t* h, double* x, const double* b) {
 
 // smooth!(x, smoother, b).  `xc` is the buffer that currently holds x; Jacobi
 // sweeps ping-pong between xc and xo (swapped in place).
-int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& xo, const double* b, int ncolv = 1) {
+int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& xo, const double* b, int ncolv = 1,
+           bool xzero = false) {
   amgh_csr* M = L->smat();
   for (int it = 0; it < s.iter; ++it) {
     switch (s.kind) {
@@ -159,9 +160,10 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& 
         const bool sym = s.sweep == AMGH_SWEEP_SYMMETRIC;
         const bool first_it = (it == 0), last_it = (it == s.iter - 1);
         if (s.sweep == AMGH_SWEEP_FORWARD || sym)
-          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it && !sym, ncolv));
+          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it && !sym, ncolv, xzero && first_it));
         if (s.sweep == AMGH_SWEEP_BACKWARD || sym)
-          RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream, first_it && !sym, last_it, ncolv));
+          RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream, first_it && !sym, last_it, ncolv,
+                              xzero && first_it && !sym));
         break;
       }
       default: return AMGH_EINVAL;
@@ -170,18 +172,19 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& 
   return AMGH_OK;
 }
 
-int cycle(amgh_t* h, int l, double* x, const double* b, int cyc);
+int cycle(amgh_t* h, int l, double* x, const double* b, int cyc, bool xzero);
 
 // __solve_next! (multilevel.jl:200-212)
+// x is the parent's freshly zeroed coarse_x (multilevel.jl:226) on the first visit, not on the second (W, F)
 int cycle_next(amgh_t* h, int l, double* x, const double* b, int cyc) {
   switch (cyc) {
-    case AMGH_CYCLE_V: return cycle(h, l, x, b, AMGH_CYCLE_V);
+    case AMGH_CYCLE_V: return cycle(h, l, x, b, AMGH_CYCLE_V, true);
     case AMGH_CYCLE_W:
-      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_W));
-      return cycle(h, l, x, b, AMGH_CYCLE_W);
+      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_W, true));
+      return cycle(h, l, x, b, AMGH_CYCLE_W, false);
     case AMGH_CYCLE_F:
-      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_F));
-      return cycle(h, l, x, b, AMGH_CYCLE_V);
+      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_F, true));
+      return cycle(h, l, x, b, AMGH_CYCLE_V, false);
   }
   return AMGH_EINVAL;
 }
@@ -190,7 +193,7 @@ int cycle_next(amgh_t* h, int l, double* x, const double* b, int cyc) {
 // multilevel.jl:28-59).  The reference loops the columns inside every operator (smoother.jl:77,117); here
 // each launch covers all bs columns (one grid row / one workgroup per column): per column the arithmetic and
 // its order are those of the single-column path, so the results are bitwise the same.
-int cycle(amgh_t* h, int l, double* x, const double* b, int cyc) {
+int cycle(amgh_t* h, int l, double* x, const double* b, int cyc, bool xzero) {
   Level* L = h->levels[l];
   const int bs = h->nrhs;
   const int64_t n = L->n, nc = L->nc;
@@ -198,7 +201,7 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc) {
   double* xo = L->tmp;
   {
     ProfScope p(h, AMGH_T_PRESMOOTH, l);
-    RC_TRY(smooth(h, L, L->pre, xc, xo, b, bs));
+    RC_TRY(smooth(h, L, L->pre, xc, xo, b, bs, xzero));
   }
   {
     ProfScope p(h, AMGH_T_RESIDUAL, l);
@@ -228,39 +231,40 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc) {
 }
 
 // one application of the hierarchy: a cycle, or the coarse solve if no levels
-int apply_once(amgh_t* h, double* x, const double* b, int cyc) {
+int apply_once(amgh_t* h, double* x, const double* b, int cyc, bool xzero) {
   if (h->levels.empty()) {
     ProfScope p(h, AMGH_T_COARSE, 0);
     for (int c = 0; c < h->nrhs; ++c) RC_TRY(coarse_solve(h, x + c * h->ncoarse, b + c * h->ncoarse));
     return AMGH_OK;
   }
-  return cycle(h, 0, x, b, cyc);
+  return cycle(h, 0, x, b, cyc, xzero);
 }
 
 // apply_once through a captured hipGraph: a cycle is thousands of short,
 // launch-bound kernels (one per Gauss-Seidel dependency level), replaying them from a
 // graph takes the host launch cost off the critical path.  Falls back to eager
 // launches when profiling, with a host coarse solver, or if capture fails.
-int apply_cycle(amgh_t* h, double* x, const double* b, int cyc) {
-  if (!h->use_graph || h->profile || h->coarse_fn || h->levels.empty()) return apply_once(h, x, b, cyc);
+// xzero: the caller has just zeroed x (ldiv!, the preconditioner inside PCG)
+int apply_cycle(amgh_t* h, double* x, const double* b, int cyc, bool xzero = false) {
+  if (!h->use_graph || h->profile || h->coarse_fn || h->levels.empty()) return apply_once(h, x, b, cyc, xzero);
   for (auto& g : h->graphs)
-    if (g.x == x && g.b == b && g.cyc == cyc) {
+    if (g.x == x && g.b == b && g.cyc == cyc && g.xzero == xzero) {
       HIP_TRY(hipGraphLaunch(g.exec, h->stream));
       return AMGH_OK;
     }
   hipGraph_t graph = nullptr;
   if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
-    return apply_once(h, x, b, cyc);
+    return apply_once(h, x, b, cyc, xzero);
   }
-  const int rc = apply_once(h, x, b, cyc);
+  const int rc = apply_once(h, x, b, cyc, xzero);
   const hipError_t e = hipStreamEndCapture(h->stream, &graph);
   if (rc != AMGH_OK || e != hipSuccess || !graph) {
     if (graph) hipGraphDestroy(graph);
     (void)hipGetLastError();
     if (rc != AMGH_OK) return rc;
     h->use_graph = false;  // capture unsupported here: stay eager
-    return apply_once(h, x, b, cyc);
+    return apply_once(h, x, b, cyc, xzero);
   }
   hipGraphExec_t exec = nullptr;
   const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -268,13 +272,13 @@ int apply_cycle(amgh_t* h, double* x, const double* b, int cyc) {
   if (ei != hipSuccess) {
     (void)hipGetLastError();
     h->use_graph = false;
-    return apply_once(h, x, b, cyc);
+    return apply_once(h, x, b, cyc, xzero);
   }
   if (h->graphs.size() >= 6) {
     hipGraphExecDestroy(h->graphs.front().exec);
     h->graphs.erase(h->graphs.begin());
   }
-  h->graphs.push_back({x, b, cyc, exec});
+  h->graphs.push_back({x, b, cyc, xzero, exec});
   HIP_TRY(hipGraphLaunch(exec, h->stream));
   return AMGH_OK;
 }
@@ -351,7 +355,7 @@ int pcg_dev(amgh_t* h, const double* b, double* x, int cyc, int use_precond, int
   while (it < maxiter && residual > tol) {
     if (use_precond) {
       RC_TRY(vec_fill(h, c, n, 0.0));
-      RC_TRY(apply_cycle(h, c, r, cyc));
+      RC_TRY(apply_cycle(h, c, r, cyc, true));
     } else {
       RC_TRY(vec_copy(h, c, r, n));
     }
@@ -615,7 +619,7 @@ int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle_) 
   if (!r_d || !z_d || cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   RC_TRY(vec_fill(h, z_d, fine_n(h) * h->nrhs, 0.0));
-  return apply_cycle(h, z_d, r_d, cycle_);
+  return apply_cycle(h, z_d, r_d, cycle_, true);
 }
 
 int amgh_precond_apply(amgh_t* h, const double* r, double* z, int cycle_) {
@@ -636,7 +640,7 @@ int amgh_cycle_d(amgh_t* h, int level, double* x_d, const double* b_d, int cycle
   if (!x_d || !b_d || cycle_ < 0 || cycle_ > 2 || level < 0 || level > (int)h->levels.size()) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   if (level == (int)h->levels.size()) return coarse_solve(h, x_d, b_d);
-  return cycle(h, level, x_d, b_d, cycle_);
+  return cycle(h, level, x_d, b_d, cycle_, false);
 }
 
 int amgh_set_stream(amgh_t* h, void* stream) {

@@ -343,6 +343,14 @@ __global__ void gs_flip_rhs_kernel(const double* __restrict__ bp, const double* 
     sp[r] = bp[r] - sp[r] + diag[r] * xp[r];
 }
 
+// dst[column][0..n) = src[column][0..n): strided copy of a block of right-hand-side columns (blockIdx.y = column)
+__global__ void copy_cols_kernel(double* __restrict__ dst, const double* __restrict__ src, int n, int64_t ld_dst,
+                                 int64_t ld_src) {
+  dst += blockIdx.y * ld_dst;
+  src += blockIdx.y * ld_src;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) dst[r] = src[r];
+}
+
 // Single-workgroup chain over consecutive NARROW dependency levels of a
 // Gauss-Seidel/SOR sweep: one thread per row, a workgroup barrier between
 // dependency levels (visibility of x inside one CU needs only the barrier).

@@ -119,8 +119,10 @@ int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st)
 // ncolv > 1: x (ncols apart) and b (nrows apart) hold ncolv independent right-hand-side columns; every launch
 // covers all of them (gridDim.y, or one workgroup per column in the single-workgroup kernels), so a block of
 // right-hand sides costs the dependency-level latency chain once.
+// xzero: the caller guarantees x == 0 on entry (every coarse-level pre-smoother of a cycle, and the fine one of
+// ldiv!): the gather of x becomes a memset and the first merged pre-pass b - T x is just b.
 int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st,
-                 bool first = true, bool last = true, int ncolv = 1) {
+                 bool first = true, bool last = true, int ncolv = 1, bool xzero = false) {
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
   if (g->n <= 0) return AMGH_OK;
@@ -181,8 +183,12 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
   if (first) {
     hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n,
                        (int64_t)g->n, (int64_t)g->n);
-    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const double*)x, g->permx,
-                       g->xp, (int)g->ncols, (int64_t)g->ncols, xs);
+    if (xzero) {
+      HIP_TRY(hipMemsetAsync(g->xp, 0, sizeof(double) * (size_t)xs * ncolv, st));
+    } else {
+      hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const double*)x, g->permx,
+                         g->xp, (int)g->ncols, (int64_t)g->ncols, xs);
+    }
     HIP_TRY(hipGetLastError());
   }
   double* xp = g->xp;
@@ -197,6 +203,10 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       // the previous sweep of this smooth! call ran the other way on the same xp: s follows without a matrix pass
       hipLaunchKernelGGL(gs_flip_rhs_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const double*)g->bp,
                          (const double*)lay->diag, (const double*)xp, xp + g->ncols, (int)g->n, (int64_t)g->n, xs);
+      HIP_TRY(hipGetLastError());
+    } else if (first && xzero) {  // s = b - T * 0
+      hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, xp + g->ncols,
+                         (const double*)g->bp, (int)g->n, xs, (int64_t)g->n);
       HIP_TRY(hipGetLastError());
     } else {
       const GsSchedule::Tri& t = backward ? g->tri_b : g->tri_f;
