@@ -683,6 +683,7 @@ __global__ __launch_bounds__(kSlot) void gs_bigslot_kernel(SlotArgs a) {
 constexpr int kBlk = 128;
 constexpr int kBlkThreads = 1024;  // 128 rows x 8 partial sums in the dense phase
 constexpr int kBlkLds = 8192;
+constexpr int kBlkSingle = 16;     // operators with at most this many blocks: one gs_block_kernel launch per sweep, no split
 
 struct BlockArgs {
   const int32_t* rowptr;  // "outer" matrix of this direction: the operator minus the in-block triangle

@@ -146,7 +146,8 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     BlockArgs ba{};
     const GsSchedule::Outer& o = backward ? g->blk_b : g->blk_f;
     ba.rowptr = o.rowptr; ba.col = o.col; ba.val = o.val; ba.tinv = o.tinv; ba.diag = g->blk_diag;
-    {  // s = b - O_next x: every entry read here keeps its old value during this sweep
+    const bool single = g->nblk <= kBlkSingle;  // few blocks: everything in one launch (see blockgs_build_dir)
+    if (!single) {  // s = b - O_next x: every entry read here keeps its old value during this sweep
       StreamArgs ra{};
       ra.rowptr = o.nx_rowptr; ra.col = o.nx_col; ra.val = o.nx_val;
       ra.x = x; ra.b = b; ra.y = g->blk_s;
@@ -155,7 +156,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       // few, long rows: 64 rows per workgroup so that the launch still covers the chip
       RC_TRY((launch_stream<M_RESID, StreamCfg<256, 64, 4096, 2, false, false>>(ra, st, ncolv)));
     }
-    ba.x = x; ba.b = g->blk_s; ba.n = (int32_t)g->n; ba.backward = backward ? 1 : 0;
+    ba.x = x; ba.b = single ? b : g->blk_s; ba.n = (int32_t)g->n; ba.backward = backward ? 1 : 0;
     ba.ld = g->n;  // block path: square operator, x and b in natural order
     ba.tim = g_chain_tim;
     ba.near_ptr = o.near_ptr; ba.near_pi = o.near_pi; ba.near_val = o.near_val;
@@ -173,7 +174,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
         pa.ldx = g->n; pa.ldy = g->n; pa.ldb = g->n;
         RC_TRY((launch_stream<M_RESID, StreamCfg<256, 16, 2048, 2, false, false>>(pa, st, ncolv)));
       }
-      if (g_gs_block_pipe) hipLaunchKernelGGL(gs_block_pipe_kernel, dim3(ncolv), dim3(kPipeThreads), 0, st, ba);
+      if (g_gs_block_pipe && !single) hipLaunchKernelGGL(gs_block_pipe_kernel, dim3(ncolv), dim3(kPipeThreads), 0, st, ba);
       else hipLaunchKernelGGL(gs_block_kernel, dim3(ncolv), dim3(kBlkThreads), 0, st, ba);
     }
     HIP_TRY(hipGetLastError());
@@ -184,7 +185,8 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n,
                        (int64_t)g->n, (int64_t)g->n);
     if (xzero) {
-      HIP_TRY(hipMemsetAsync(g->xp, 0, sizeof(double) * (size_t)xs * ncolv, st));
+      const int64_t cnt = xs * ncolv;  // (a fill kernel: hipMemsetAsync of a small buffer costs far more than a launch)
+      hipLaunchKernelGGL(fill_kernel, dim3(grid_for(cnt)), dim3(256), 0, st, g->xp, cnt, 0.0);
     } else {
       hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const double*)x, g->permx,
                          g->xp, (int)g->ncols, (int64_t)g->ncols, xs);

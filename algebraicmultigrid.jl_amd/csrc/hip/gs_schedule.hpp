@@ -12,6 +12,8 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n,
                       const double* val, const std::vector<double>& diag, double* max_cond) {
   const int B = kBlk;
   const int nblk = (int)((n + B - 1) / B);
+  // a few blocks only: an extra launch costs more than it saves, all couplings stay in the one sequential kernel
+  const bool single = nblk <= kBlkSingle;
   std::vector<int32_t> orow(n + 1, 0), ocol, xrow(n + 1, 0), xcol, prow(n + 1, 0), pcol;
   std::vector<double> oval, xval, pval;
   ocol.reserve(rowptr[n]); oval.reserve(rowptr[n]);
@@ -37,9 +39,9 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n,
         const bool in_tri = c >= i0 && c < i1 && (backward ? c >= i : c <= i);
         if (in_tri) {
           if (!skip) T[(size_t)(i - i0) * B + (c - i0)] += val[j];
-        } else if (!skip && (c >= n || (c >= i0 && c < i1) || (backward ? c < i0 : c >= i1))) {
+        } else if (!skip && !single && (c >= n || (c >= i0 && c < i1) || (backward ? c < i0 : c >= i1))) {
           xcol.push_back(c); xval.push_back(val[j]);  // old x: halo column (frozen), in-block other triangle, block swept later
-        } else if (!skip && (c < s0 || c >= s1)) {
+        } else if (!skip && !single && (c < s0 || c >= s1)) {
           pcol.push_back(c); pval.push_back(val[j]);  // an earlier superblock
         } else if (!skip) {
           if (c >= q0 && c < q0 + B) {
@@ -623,7 +625,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
           if (col[j] == i) dg[i] = val[j];
       double max_cond = 0.0;
-      g->super = (g_gs_super > 0 && nblk > g_gs_super) ? g_gs_super : 0;
+      g->super = (g_gs_super > 0 && nblk > g_gs_super && nblk > kBlkSingle) ? g_gs_super : 0;
       RC_TRY(blockgs_build_dir(&g->blk_f, false, g->super, n, rowptr, col, val, dg, &max_cond));
       RC_TRY(blockgs_build_dir(&g->blk_b, true, g->super, n, rowptr, col, val, dg, &max_cond));
       RC_TRY(dev_upload(&g->blk_diag, dg.data(), n));
