@@ -351,6 +351,15 @@ __global__ void copy_cols_kernel(double* __restrict__ dst, const double* __restr
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) dst[r] = src[r];
 }
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for outstanding
+// global loads (s_waitcnt vmcnt(0)), so prefetches issued before it stay in flight across it.  Only valid where
+// the data exchanged between the threads goes through LDS.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Single-workgroup chain over consecutive NARROW dependency levels of a
 // Gauss-Seidel/SOR sweep: one thread per row, a workgroup barrier between
 // dependency levels (visibility of x inside one CU needs only the barrier).
@@ -482,11 +491,12 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
         for (int k = c0 + tid; k < c1; k += T) s_prod[k - c0] = a.val[k] * xs[a.col[k]];
       }
       if (a.tim && c0 == p0) t2 = clock64();
-      __syncthreads();
+      if (LDSX) lds_barrier();  // x and the products live in LDS: the next level's prefetch stays in flight
+      else __syncthreads();
       if (a.tim && c0 == p0) t3 = clock64();
       const int lo = max(cur.m.x, c0), hi = min(cur.m.y, c1);
       acc = seq_sum_skip(s_prod, lo - c0, hi - c0, cur.m.z - c0, acc);
-      if (c1 < p1) __syncthreads();
+      if (c1 < p1) { if (LDSX) lds_barrier(); else __syncthreads(); }
     }
     if (cur.m.w >= 0 && cur.d != 0.0) {
       const int i = ds.x + tid;  // x is in dependency-level order: this row's own position
@@ -496,8 +506,12 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
     }
     const unsigned long long t4 = a.tim ? clock64() : 0;
     if (!has_next) break;
-    if (!LDSX) __threadfence_block();
-    __syncthreads();  // x of this dependency level visible to the whole workgroup (one CU)
+    if (LDSX) {
+      lds_barrier();  // x of this dependency level (in LDS) visible to the whole workgroup
+    } else {
+      __threadfence_block();
+      __syncthreads();  // x of this dependency level (in HBM) visible to the whole workgroup (one CU)
+    }
     if (a.tim) {
       const unsigned long long t5 = clock64();
       tacc[0] += t1 - t0; tacc[5] += t0a - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2; tacc[3] += t4 - t3; tacc[4] += t5 - t4; ++nlv;
@@ -815,12 +829,6 @@ constexpr int kPipeThreads = 1024;
 constexpr int kPipePF = 8;                          // leading entries per thread: 2 rounds of 4 consecutive entries (16-B loads)
 constexpr int kPipeCap = kPipePF * kPipeThreads;    // products per LDS buffer (2 x 64 KiB); longer blocks: extra passes
 constexpr int kPipeNPF = 2;                         // near entries per thread held in registers
-
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 
 // The leading entries [p0, lim) of a block, 4 consecutive entries per thread and round, from the 16-B aligned
 // position a0 = p0 & ~3 (a single CU is bound by the number of vector-memory instructions it can issue, not by
