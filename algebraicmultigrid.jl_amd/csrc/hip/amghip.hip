@@ -143,7 +143,7 @@ int coarse_solve(amgh_t* h, double* x, const double* b) {
 // smooth!(x, smoother, b).  `xc` is the buffer that currently holds x; Jacobi
 // sweeps ping-pong between xc and xo (swapped in place).
 int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& xo, const double* b, int ncolv = 1,
-           bool xzero = false) {
+           bool xzero = false, bool reuse_b = false) {
   amgh_csr* M = L->smat();
   for (int it = 0; it < s.iter; ++it) {
     switch (s.kind) {
@@ -160,10 +160,11 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& 
         const bool sym = s.sweep == AMGH_SWEEP_SYMMETRIC;
         const bool first_it = (it == 0), last_it = (it == s.iter - 1);
         if (s.sweep == AMGH_SWEEP_FORWARD || sym)
-          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it && !sym, ncolv, xzero && first_it));
+          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it && !sym, ncolv, xzero && first_it,
+                              reuse_b || !first_it));
         if (s.sweep == AMGH_SWEEP_BACKWARD || sym)
           RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream, first_it && !sym, last_it, ncolv,
-                              xzero && first_it && !sym));
+                              xzero && first_it && !sym, reuse_b || !first_it));
         break;
       }
       default: return AMGH_EINVAL;
@@ -224,7 +225,9 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc, bool xzero) {
   }
   {
     ProfScope p(h, AMGH_T_POSTSMOOTH, l);
-    RC_TRY(smooth(h, L, L->post, xc, xo, b, bs));
+    // the pre-smoother of this very call left b in level order if it was a level-scheduled GS / SOR (not the block path)
+    const bool b_kept = (L->pre.kind == AMGH_SMOOTH_GS || L->pre.kind == AMGH_SMOOTH_SOR) && L->pre.iter > 0;
+    RC_TRY(smooth(h, L, L->post, xc, xo, b, bs, false, b_kept));
   }
   if (xc != x) RC_TRY(vec_copy(h, x, xc, n * bs));
   return AMGH_OK;

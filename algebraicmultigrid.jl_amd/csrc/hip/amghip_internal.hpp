@@ -69,6 +69,7 @@ struct GsSchedule {
   double* bp = nullptr;     // right-hand side in dependency-level order (scratch)
   double* xp = nullptr;     // x in dependency-level order (scratch, ncols entries per right-hand-side column)
   int cols_alloc = 1;       // right-hand-side columns bp / xp currently hold
+  int bp_cols = 0;          // columns of b gathered into bp by the last level-ordered sweep (0: none)
   int32_t* permx = nullptr; // perm extended by the identity over halo columns
   int64_t n = 0, ncols = 0;
   int64_t bytes = 0;

@@ -121,8 +121,10 @@ int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st)
 // right-hand sides costs the dependency-level latency chain once.
 // xzero: the caller guarantees x == 0 on entry (every coarse-level pre-smoother of a cycle, and the fine one of
 // ldiv!): the gather of x becomes a memset and the first merged pre-pass b - T x is just b.
+// reuse_b: b has not changed since the previous smooth! call on this operator gathered it (post-smoother after the
+// pre-smoother of the same cycle and level): its level-ordered copy is still in place.
 int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st,
-                 bool first = true, bool last = true, int ncolv = 1, bool xzero = false) {
+                 bool first = true, bool last = true, int ncolv = 1, bool xzero = false, bool reuse_b = false) {
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
   if (g->n <= 0) return AMGH_OK;
@@ -140,9 +142,11 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     g->bytes += grown;
     op->bytes += grown;
     g->cols_alloc = ncolv;
+    g->bp_cols = 0;
   }
   if (g->nblk > 0 && g_gs_block_inverse && !sor) {
     // small densely coupled operator: n/128 sequential block steps in natural row order
+    g->bp_cols = 0;  // (no level-ordered copy of b is made on this path)
     BlockArgs ba{};
     const GsSchedule::Outer& o = backward ? g->blk_b : g->blk_f;
     ba.rowptr = o.rowptr; ba.col = o.col; ba.val = o.val; ba.tinv = o.tinv; ba.diag = g->blk_diag;
@@ -182,8 +186,10 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
   }
   const int64_t xs = g->xstride;  // doubles per column of xp
   if (first) {
-    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n,
-                       (int64_t)g->n, (int64_t)g->n);
+    if (!(reuse_b && g->bp_cols == ncolv))
+      hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n,
+                         (int64_t)g->n, (int64_t)g->n);
+    g->bp_cols = ncolv;
     if (xzero) {
       const int64_t cnt = xs * ncolv;  // (a fill kernel: hipMemsetAsync of a small buffer costs far more than a launch)
       hipLaunchKernelGGL(fill_kernel, dim3(grid_for(cnt)), dim3(256), 0, st, g->xp, cnt, 0.0);
