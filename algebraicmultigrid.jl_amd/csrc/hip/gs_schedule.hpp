@@ -287,6 +287,8 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
 struct MergeResult {
   HostLevelCsr sys;      // grouped levels, composite rows (no diagonal entry: dpos = -1)
   int64_t max_row = 0;
+  double growth = 0.0;   // largest (sum of |coefficients| / |diagonal|) of a composite row: substitution amplifies like
+                         // prod |l_ij / d_j| — harmless for diagonally dominant operators, a warning sign otherwise
 };
 
 // grouping of the dependency levels of `base` into groups of m (counted from level 0 forward, from the last level
@@ -321,6 +323,7 @@ MergeGroups merge_groups(const HostLevelCsr& base, int m, bool backward) {
 struct MergeChunk {
   std::vector<int32_t> len, col;
   std::vector<double> val;
+  double growth = 0.0;  // max over rows of sum |composite coefficient| / |diagonal|
 };
 int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncols, int q0, int q1, MergeChunk* out,
                     int row_cap = kBigSlot) {
@@ -336,6 +339,7 @@ int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncol
   out->len.assign(G.gptr[q1] - row0, 0);
   out->col.clear();
   out->val.clear();
+  out->growth = 0.0;
   for (int q = q0; q < q1; ++q) {
     const int32_t ga = G.gptr[q], gb = G.gptr[q + 1];
     const int32_t gn = gb - ga;
@@ -380,11 +384,14 @@ int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncol
       const int32_t lp2 = p - ga;
       start[lp2] = (int64_t)gcol.size();
       glen[lp2] = (int32_t)order.size();
+      double rowsum = 0.0;
       for (const auto& cs : order) {
         gcol.push_back(cs.first);
         gval.push_back(acc[cs.second]);
+        rowsum += std::fabs(acc[cs.second]);
         key[cs.second] = -1;  // release the slot
       }
+      if (base.pdiag[p] != 0.0) out->growth = std::max(out->growth, rowsum / std::fabs(base.pdiag[p]));
       max_row = std::max<int64_t>(max_row, (int64_t)order.size());
     }
     // emit the group's rows in ascending row order
@@ -475,6 +482,7 @@ MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool bac
   int64_t total = 0;
   for (int t = 0; t < T; ++t) {
     R.max_row = std::max(R.max_row, mx[t]);
+    R.growth = std::max(R.growth, chunks[t].growth);
     total += (int64_t)chunks[t].col.size();
   }
   if (R.max_row == INT32_MAX || total >= (int64_t)INT32_MAX - 4096) { R.max_row = INT32_MAX; return R; }
@@ -519,6 +527,11 @@ int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int6
   *bytes += (n + 1) * 4 + (int64_t)cc.size() * 12;
   return AMGH_OK;
 }
+
+// Substituted coefficients grow like prod |l_ij / d_j| along the chains inside a group: bounded by 1 for diagonally
+// dominant operators; a group whose composite rows outgrow this (relative to the diagonal) is not merged (the
+// same 1e-10 contract and reasoning as the condition guard of the block-inverse sweeps).
+constexpr double kMergeGrowthMax = 1e4;
 
 // estimated time of one sweep over a grouped system: a kernel boundary per group + streaming its entries
 double merge_cost(int64_t ngroups, int64_t nnz) { return ngroups * 3.8e-6 + 12.0 * (double)nnz / 2.5e12; }
@@ -681,7 +694,10 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         keep = merge_build(base, g->ncols, best_m, backward);
         tm.lap("merge build", n);
         if (keep.max_row > cap && cap == kSlot && g_gs_bigslot && keep.max_row <= kBigSlot) cap = kBigSlot;
-        if (keep.max_row <= cap) break;
+        if (keep.max_row <= cap && !(keep.growth > kMergeGrowthMax)) break;
+        if (keep.growth > kMergeGrowthMax && getenv("AMGH_VERBOSE"))
+          fprintf(stderr, "[amghip] n=%lld %s merge m=%d rejected: coefficient growth %.3g\n", (long long)n,
+                  backward ? "bwd" : "fwd", best_m, keep.growth);
         --best_m;  // the sample missed a row that outgrows a slot: one level fewer per group
       }
       if (best_m > 1) {
