@@ -585,6 +585,15 @@ int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
   amgh_csr* M = h->levels[l]->smat();
   return M->gs ? M->gs->nlev : 0;
 }
+int amgh_gs_num_sweep_steps(const amgh_t* h, int l, int backward) {
+  if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
+  amgh_csr* M = h->levels[l]->smat();
+  const GsSchedule* g = M->gs;
+  if (!g) return 0;
+  if (g->nblk > 0 && g_gs_block_inverse) return g->nblk;             // block-inverse sweep: sequential block steps
+  const GsSchedule* c = backward ? g->mb : g->mf;
+  return (c && g_gs_merge > 1) ? c->nlev : g->nlev;                  // merged groups, or dependency levels
+}
 
 static int ensure_pcg_bufs(amgh_t* h) {
   if (h->pc_r) return AMGH_OK;

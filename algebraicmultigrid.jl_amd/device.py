@@ -275,6 +275,10 @@ class DeviceHierarchy:
     def gs_dependency_levels(self, level):
         return int(self.lib.amgh_gs_num_dependency_levels(self.h, level))
 
+    def gs_sweep_steps(self, level, backward=False):
+        """Sequential steps of one GS sweep as executed (merged groups / block steps / dependency levels)."""
+        return int(self.lib.amgh_gs_num_sweep_steps(self.h, level, int(backward)))
+
     def profile(self, on=True):
         hip_check(self.lib.amgh_profile_enable(self.h, int(on)), "profile_enable")
 

@@ -157,6 +157,8 @@ def main():
                    "level_sizes": [l.A.m for l in ml.levels] + [ml.final_A.m],
                    "operator_complexity": round(AMG.operator_complexity(ml), 3),
                    "gs_dependency_levels": [dev.gs_dependency_levels(l) for l in range(len(ml.levels))],
+                   "gs_sweep_steps_fwd_bwd": [[dev.gs_sweep_steps(l, False), dev.gs_sweep_steps(l, True)]
+                                              for l in range(len(ml.levels))],
                    "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<SPMV, StreamCfg<1024,1024,8192,4>> (fine-level A, %d rows, %d nnz)" % (n, A.nnz),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -125,6 +125,9 @@ int64_t amgh_level_size(const amgh_t* h, int l); /* size(levels[l].A,1); l==L: f
 int64_t amgh_device_bytes(const amgh_t* h);      /* HBM held by the handle        */
 /* number of Gauss-Seidel dependency levels of level l (0 if no GS smoother)    */
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l);
+/* Sequential steps one Gauss-Seidel sweep over level l takes as executed: merged groups of dependency levels
+ * (DESIGN.md section 4), 128-row block steps on the block-inverse path, or the dependency levels themselves. */
+int amgh_gs_num_sweep_steps(const amgh_t* h, int l, int backward);
 
 /* ------------------------------------------------------------------------- */
 /* Solve phase                                                                  */
