@@ -24,6 +24,10 @@ struct Level {
   amgh_smoother_t pre{}, post{};
   double *res = nullptr, *cx = nullptr, *cb = nullptr, *tmp = nullptr;
   amgh_csr* smat() { return has_S ? &S : &A; }
+  // level-ordered cycle (x stays in the smoother's dependency-level order between pre- and post-smoother):
+  // P with its rows in that order, R with its columns renumbered to it; A in that order is the schedule's own copy
+  amgh_csr Pp, Rp;
+  bool lo_ok = false;
 };
 
 }  // namespace
@@ -142,8 +146,9 @@ int coarse_solve(amgh_t* h, double* x, const double* b) {
 
 // smooth!(x, smoother, b).  `xc` is the buffer that currently holds x; Jacobi
 // sweeps ping-pong between xc and xo (swapped in place).
+// x_resident / no_scatter: see csr_gs_sweep (the level-ordered cycle keeps x in the schedule's own vector)
 int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& xo, const double* b, int ncolv = 1,
-           bool xzero = false, bool reuse_b = false) {
+           bool xzero = false, bool reuse_b = false, bool x_resident = false, bool no_scatter = false) {
   amgh_csr* M = L->smat();
   for (int it = 0; it < s.iter; ++it) {
     switch (s.kind) {
@@ -161,10 +166,10 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& 
         const bool first_it = (it == 0), last_it = (it == s.iter - 1);
         if (s.sweep == AMGH_SWEEP_FORWARD || sym)
           RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it && !sym, ncolv, xzero && first_it,
-                              reuse_b || !first_it));
+                              reuse_b || !first_it, x_resident, no_scatter));
         if (s.sweep == AMGH_SWEEP_BACKWARD || sym)
           RC_TRY(csr_gs_sweep(M, true, sor, s.omega, xc, b, h->stream, first_it && !sym, last_it, ncolv,
-                              xzero && first_it && !sym, reuse_b || !first_it));
+                              xzero && first_it && !sym, reuse_b || !first_it, x_resident, no_scatter));
         break;
       }
       default: return AMGH_EINVAL;
@@ -200,9 +205,41 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc, bool xzero) {
   const int64_t n = L->n, nc = L->nc;
   double* xc = x;
   double* xo = L->tmp;
+  // Level-ordered variant: between the two smoothers x stays in the smoother's dependency-level order (its own xp),
+  // and residual / restriction / prolongation run on level-ordered copies of A, R, P (same entries in the same
+  // order inside every row, so the same sums): no scatter after the pre-smoother, no gather before the post-smoother.
+  GsSchedule* g = L->smat()->gs;
+  const bool lo = L->lo_ok && g_gs_keep_lo && g && g->nblk == 0;
   {
     ProfScope p(h, AMGH_T_PRESMOOTH, l);
-    RC_TRY(smooth(h, L, L->pre, xc, xo, b, bs, xzero));
+    RC_TRY(smooth(h, L, L->pre, xc, xo, b, bs, xzero, false, false, lo));
+  }
+  if (lo) {
+    const int64_t xs = g->xstride;
+    {
+      ProfScope p(h, AMGH_T_RESIDUAL, l);  // r = b - A x, everything in level order (bp was gathered by the pre-smoother)
+      RC_TRY(raw_apply(M_RESID, g->rowptr, g->col, g->val, n, g->xp, xs, g->bp, n, L->res, n, h->stream, bs));
+    }
+    {
+      ProfScope p(h, AMGH_T_RESTRICT, l);
+      RC_TRY(csr_apply(&L->Rp, M_SPMV, L->res, nullptr, L->cb, h->stream, bs));
+    }
+    RC_TRY(vec_fill(h, L->cx, nc * bs, 0.0));
+    if (l == (int)h->levels.size() - 1) {
+      ProfScope p(h, AMGH_T_COARSE, l + 1);
+      for (int c = 0; c < bs; ++c) RC_TRY(coarse_solve(h, L->cx + c * nc, L->cb + c * nc));
+    } else {
+      RC_TRY(cycle_next(h, l + 1, L->cx, L->cb, cyc));
+    }
+    {
+      ProfScope p(h, AMGH_T_PROLONG, l);  // x += P e on the level-ordered x
+      RC_TRY(raw_apply(M_ADD, L->Pp.rowptr, L->Pp.col, L->Pp.val, n, L->cx, nc, nullptr, 0, g->xp, xs, h->stream, bs));
+    }
+    {
+      ProfScope p(h, AMGH_T_POSTSMOOTH, l);
+      RC_TRY(smooth(h, L, L->post, xc, xo, b, bs, false, true, true, false));
+    }
+    return AMGH_OK;
   }
   {
     ProfScope p(h, AMGH_T_RESIDUAL, l);
@@ -449,7 +486,7 @@ void amgh_destroy(amgh_t* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Level* L : h->levels) {
-    csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R);
+    csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
     hipFree(L->res); hipFree(L->cx); hipFree(L->cb); hipFree(L->tmp);
     delete L;
   }
@@ -494,9 +531,31 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
     rc = L->has_S ? gs_build(g, n, n, S_rowptr, S_col, S_val) : gs_build(g, n, n, A_rowptr, A_col, A_val);
     if (rc == AMGH_OK) { M->gs = g; M->bytes += g->bytes; }
     else { g->free_dev(); delete g; }
+    // level-ordered copies of P and R when both smoothers are level-scheduled sweeps over A itself
+    const bool both = (pre->kind == AMGH_SMOOTH_GS || pre->kind == AMGH_SMOOTH_SOR) && pre->iter > 0 &&
+                      (post->kind == AMGH_SMOOTH_GS || post->kind == AMGH_SMOOTH_SOR) && post->iter > 0;
+    if (rc == AMGH_OK && both && !L->has_S && g->nblk == 0 && g_gs_keep_lo && (int64_t)g->h_perm.size() == n) {
+      const std::vector<int32_t>& perm = g->h_perm;
+      std::vector<int32_t> inv(n);
+      for (int64_t p2 = 0; p2 < n; ++p2) inv[perm[p2]] = (int32_t)p2;
+      std::vector<int32_t> prp(n + 1, 0), pcl(P_rowptr[n]);
+      std::vector<double> pvl(P_rowptr[n]);
+      for (int64_t p2 = 0; p2 < n; ++p2) prp[p2 + 1] = prp[p2] + (P_rowptr[perm[p2] + 1] - P_rowptr[perm[p2]]);
+      for (int64_t p2 = 0; p2 < n; ++p2) {
+        const int32_t src = P_rowptr[perm[p2]], len = P_rowptr[perm[p2] + 1] - src;
+        std::copy(P_col + src, P_col + src + len, pcl.begin() + prp[p2]);
+        std::copy(P_val + src, P_val + src + len, pvl.begin() + prp[p2]);
+      }
+      std::vector<int32_t> rcl(R_rowptr[nc]);
+      for (int64_t k = 0; k < R_rowptr[nc]; ++k) rcl[k] = inv[R_col[k]];  // entries keep their order: same sums
+      rc = csr_upload(&L->Pp, h->device, n, nc, prp.data(), pcl.data(), pvl.data());
+      if (rc == AMGH_OK) rc = csr_upload(&L->Rp, h->device, nc, n, R_rowptr, rcl.data(), R_val);
+      L->lo_ok = rc == AMGH_OK;
+    }
+    std::vector<int32_t>().swap(g->h_perm);
   }
   if (rc != AMGH_OK) {
-    csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R);
+    csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
     delete L;
     return rc;
   }
@@ -577,7 +636,7 @@ int64_t amgh_level_size(const amgh_t* h, int l) {
 int64_t amgh_device_bytes(const amgh_t* h) {
   if (!h) return 0;
   int64_t b = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * 8 : 0) + h->finalA.bytes;
-  for (Level* L : h->levels) b += L->A.bytes + L->S.bytes + L->P.bytes + L->R.bytes;
+  for (Level* L : h->levels) b += L->A.bytes + L->S.bytes + L->P.bytes + L->R.bytes + L->Pp.bytes + L->Rp.bytes;
   return b;
 }
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
@@ -1004,6 +1063,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_bigslot")) g_gs_bigslot = value;
   else if (!strcmp(name, "gs_flip")) g_gs_flip = value;
+  else if (!strcmp(name, "gs_keep_lo")) g_gs_keep_lo = value;
   else if (!strcmp(name, "gs_super")) g_gs_super = value;
   else if (!strcmp(name, "gs_block_pipe")) g_gs_block_pipe = value;
   else return AMGH_EINVAL;

@@ -71,6 +71,7 @@ struct GsSchedule {
   int cols_alloc = 1;       // right-hand-side columns bp / xp currently hold
   int bp_cols = 0;          // columns of b gathered into bp by the last level-ordered sweep (0: none)
   int32_t* permx = nullptr; // perm extended by the identity over halo columns
+  std::vector<int32_t> h_perm;  // host copy of perm (level-ordered row -> original row), for level-ordered P / R copies
   int64_t n = 0, ncols = 0;
   int64_t bytes = 0;
   struct Seg { int l0, l1; bool chain; int rows; int slot0, nslots; };  // dependency levels [l0, l1); launch shape
@@ -151,6 +152,7 @@ int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (on
 int g_gs_threads = 256;
 int g_gs_block_pipe = 1;        // software-pipelined block sweep (gs_block_pipe_kernel)
 int g_gs_super = 8;             // block-inverse sweeps: blocks per superblock (0 = one launch for the whole operator); read at schedule build
+int g_gs_keep_lo = 1;           // keep x in level order between pre- and post-smoother (level-ordered residual, R, P)
 int g_gs_flip = 1;              // alternating merged sweeps: s of the next sweep from the last one (no matrix pass)
 int g_gs_bigslot = 1;           // allow long-row slots (composite rows up to 2048 entries) when merging
 int g_gs_merge = 16;             // merged-level sweeps: largest group of dependency levels tried (1 = off); read at schedule build

@@ -98,6 +98,22 @@ int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, h
   }
 }
 
+// SpMV-type launch on raw CSR arrays with explicit column strides (operators and vectors in level order)
+int raw_apply(int mode, const int32_t* rowptr, const int32_t* col, const double* val, int64_t nrows, const double* x,
+              int64_t ldx, const double* b, int64_t ldb, double* y, int64_t ldy, hipStream_t st, int ncolv) {
+  StreamArgs a{};
+  a.rowptr = rowptr; a.col = col; a.val = val;
+  a.x = x; a.y = y; a.b = b;
+  a.row_begin = 0; a.row_end = (int32_t)nrows;
+  a.ldx = ldx; a.ldy = ldy; a.ldb = ldb;
+  switch (mode) {
+    case M_SPMV: return launch_stream<M_SPMV>(a, st, ncolv);
+    case M_RESID: return launch_stream<M_RESID>(a, st, ncolv);
+    case M_ADD: return launch_stream<M_ADD>(a, st, ncolv);
+  }
+  return AMGH_EINVAL;
+}
+
 template <int NCV>
 int launch_slot_t(const SlotArgs& sa, bool sor, int grid, hipStream_t st) {
   if (sor) hipLaunchKernelGGL((gs_slot_kernel<true, NCV>), dim3(grid), dim3(kSlot), 0, st, sa);
@@ -123,8 +139,11 @@ int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st)
 // ldiv!): the gather of x becomes a memset and the first merged pre-pass b - T x is just b.
 // reuse_b: b has not changed since the previous smooth! call on this operator gathered it (post-smoother after the
 // pre-smoother of the same cycle and level): its level-ordered copy is still in place.
+// x_resident: the level-ordered x of this operator (g->xp) is already current: skip the gather of x (the cycle
+// kept x there between the pre- and the post-smoother); no_scatter: leave the result in g->xp only.
 int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st,
-                 bool first = true, bool last = true, int ncolv = 1, bool xzero = false, bool reuse_b = false) {
+                 bool first = true, bool last = true, int ncolv = 1, bool xzero = false, bool reuse_b = false,
+                 bool x_resident = false, bool no_scatter = false) {
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
   if (g->n <= 0) return AMGH_OK;
@@ -190,7 +209,9 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n,
                          (int64_t)g->n, (int64_t)g->n);
     g->bp_cols = ncolv;
-    if (xzero) {
+    if (x_resident) {
+      // nothing: g->xp holds x
+    } else if (xzero) {
       const int64_t cnt = xs * ncolv;  // (a fill kernel: hipMemsetAsync of a small buffer costs far more than a launch)
       hipLaunchKernelGGL(fill_kernel, dim3(grid_for(cnt)), dim3(256), 0, st, g->xp, cnt, 0.0);
     } else {
@@ -273,7 +294,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       RC_TRY(sor ? launch_gs_level<M_SOR>(a, s.rows, st, ncolv) : launch_gs_level<M_GS>(a, s.rows, st, ncolv));
     }
   }
-  if (last) {
+  if (last && !no_scatter) {
     hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const double*)xp, g->perm, x,
                        (int)g->n, xs, (int64_t)g->n);
     HIP_TRY(hipGetLastError());

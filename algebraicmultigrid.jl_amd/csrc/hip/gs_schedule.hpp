@@ -621,6 +621,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   RC_TRY(layout_upload(g, base, perm.data()));
   tm.lap("base layout", n);
   RC_TRY(dev_upload(&g->perm, perm.data(), n));
+  g->h_perm = perm;
   g->ncols = std::max<int64_t>(ncols, n);
   {
     std::vector<int32_t> permx(g->ncols);
