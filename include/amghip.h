@@ -254,8 +254,13 @@ int amgh_debug_chain_timing(int enable, unsigned long long* out8);
 int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
                                  const double* val, int m, int backward, double* x, const double* b);
 
-/* Diagnostics: launch-shape tunables of the per-dependency-level Gauss-Seidel launches
- * ("gs_block_target", "gs_min_rows", "gs_threads"); used by tools/ to pick the defaults.   */
+/* Diagnostics: tunables of the Gauss-Seidel execution (process-wide; used by tools/ to pick the defaults and by
+ * tests to force every path).  Read at every sweep: "gs_xcd_map", "gs_block_pipe", "gs_flip", "gs_keep_lo",
+ * "gs_slots", "gs_block_target", "gs_min_rows", "gs_threads", "gs_nnz_per_wg", and "gs_merge" <= 1 /
+ * "gs_block_inverse" = 0 to bypass already-built merged groups / block-inverse data.  Read when a schedule is BUILT
+ * (amgh_push_level, first stand-alone sweep of an operator): "gs_merge" (largest group of dependency levels tried),
+ * "gs_bigslot" (0 off, 1 cost model, 2 always), "gs_super" (blocks per superblock), "gs_block_inverse".
+ * Returns AMGH_EINVAL for an unknown name.                                                                       */
 int amgh_debug_set_tunable(const char* name, int value);
 
 /* Replay whole cycles from captured hipGraphs (default off: measured no gain on MI355X,
