@@ -49,6 +49,19 @@ def test_sharded_hybrid_gauss_seidel_converges_to_the_same_solution():
     assert abs(len(hist) - len(ho)) <= 2
 
 
+def test_eight_shards_as_on_an_8_gpu_node():
+    """The driver's largest configuration (N = 8): 8 row shards, merged-level schedules on the local blocks, levels
+    below the threshold collapsed onto rank 0."""
+    A = AMG.poisson((64, 64, 64))
+    b = uniform(A.m, 8)
+    ml = AMG.ruge_stuben(A)
+    x, hist, lc = _solve_sharded(ml, b, 8, 8000, reltol=1e-8, maxiter=60)
+    xo, ho, _ = O.OracleHierarchy(ml).solve(b, reltol=1e-8, maxiter=60)
+    assert lc >= 2 and hist[-1] <= 1e-8 * hist[0]
+    assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo)
+    assert abs(len(hist) - len(ho)) <= 2
+
+
 def test_single_rank_sharded_path_equals_plain_solve():
     A = AMG.poisson((20, 20, 20))
     b = uniform(A.m, 7)
