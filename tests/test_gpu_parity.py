@@ -498,6 +498,24 @@ def test_multiple_right_hand_sides_all_sweep_kernels():
             assert rel(Xw[:, :4], X) <= 1e-14 and rel(Xw[:, 4:], X[:, : Bw.shape[1] - 4]) <= 1e-14
 
 
+def test_cycles_are_bitwise_reproducible_run_to_run():
+    """No data races in the sweeps (merged groups, long-row slots, block-inverse pipeline, chains): the same input
+    gives bit-identical output every time, single and multi-RHS."""
+    A = AMG.poisson((48, 48, 40))
+    ml = AMG.ruge_stuben(A)
+    n = A.m
+    p = AMG.aspreconditioner(ml)
+    r = uniform(n, 77) - 0.3
+    z0 = p.ldiv(r)
+    for _ in range(6):
+        assert np.array_equal(p.ldiv(r), z0)
+    R = np.stack([r, uniform(n, 78), np.sin(np.arange(n))], axis=1)
+    Z0 = p.ldiv(R)
+    for _ in range(3):
+        assert np.array_equal(p.ldiv(R), Z0)
+    assert rel(Z0[:, 0], z0) <= 1e-14
+
+
 def test_eltype_promotion_contract():  # runtests.jl:244-259
     a = AMG.poisson(100).to_scipy()
     b = uniform(100, 1)
