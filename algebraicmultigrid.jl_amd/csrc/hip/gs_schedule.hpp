@@ -102,6 +102,34 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n,
   return AMGH_OK;
 }
 
+// host threads for the schedule builds: the container's CPU quota, AMGH_BUILD_THREADS overrides
+int merge_threads() {
+  unsigned hw = std::thread::hardware_concurrency();
+  long quota = -1, period = -1;
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // do not oversubscribe a container's CPU quota
+    char q[64] = {0};
+    if (std::fscanf(f, "%63s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atol(q);
+    std::fclose(f);
+  }
+  int t = (int)std::max(1u, std::min(hw ? hw : 8u, 32u));
+  if (quota > 0 && period > 0) t = (int)std::min<long>(t, std::max<long>(1, (quota + period - 1) / period));
+  if (const char* e = getenv("AMGH_BUILD_THREADS")) t = std::max(1, atoi(e));
+  return t;
+}
+
+// fn(t) for t in [0, T): on T threads when they can be had, inline otherwise (a thread that cannot be created
+// must not take the process down)
+template <class F>
+void run_threads(int T, F fn) {
+  std::vector<std::thread> th;
+  int started = 0;
+  for (; started < T - 1; ++started) {
+    try { th.emplace_back(fn, started); } catch (const std::system_error&) { break; }
+  }
+  for (int t = started; t < T; ++t) fn(t);
+  for (auto& x : th) x.join();
+}
+
 // A triangular system in dependency-level order on the host: row p updates x[p] from
 //   diag[p] * x[p] = rhs[p] - sum_{entries != dpos[p]} val * x[col]
 // and rows of one level [lvl_ptr[l], lvl_ptr[l+1]) do not reference each other.
@@ -209,18 +237,15 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       sg.slot0 = (int)slot_row.size();
       int fill = 0, rows_in = 0;
       bool open = false;  // the level's first row always opens a slot (composite rows can be empty: fill + 0 > SE never fires)
-      for (int p2 = ra; p2 < rb; ++p2) {
+      for (int p2 = ra; p2 < rb; ++p2) {  // pass 1: positions only (the entries are copied in parallel below)
         const int len = prow[p2 + 1] - prow[p2];
-        if (!open || fill + len > SE || rows_in >= max_rows) {  // open a new slot (pad the previous one)
+        if (!open || fill + len > SE || rows_in >= max_rows) {  // open a new slot (the previous one stays zero padded)
           open = true;
-          wcol.resize(slot_row.size() * (size_t)SE, 0);
-          wval.resize(slot_row.size() * (size_t)SE, 0.0);
           slot_row.push_back(p2);
           fill = 0;
           rows_in = 0;
         }
         const int32_t start = (int32_t)((slot_row.size() - 1) * (size_t)SE + fill);
-        for (int32_t j = prow[p2]; j < prow[p2 + 1]; ++j) { wcol.push_back(pcol[j]); wval.push_back(pval[j]); }
         wmeta[p2] = i4_t{start, start + len, pdpos[p2] >= 0 ? start + (pdpos[p2] - prow[p2]) : -1, 0};
         fill += len;
         ++rows_in;
@@ -228,8 +253,24 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       sg.nslots = (int)slot_row.size() - sg.slot0;
     }
     if (!slot_row.empty()) {
-      wcol.resize(slot_row.size() * (size_t)SE, 0);
-      wval.resize(slot_row.size() * (size_t)SE, 0.0);
+      wcol.assign(slot_row.size() * (size_t)SE, 0);
+      wval.assign(slot_row.size() * (size_t)SE, 0.0);
+      {  // pass 2: the rows of the slotted levels into their slots, in parallel over row ranges
+        std::vector<std::pair<int, int>> ranges;
+        for (auto& sg : g->segs)
+          if (!sg.chain && sg.nslots > 0) ranges.push_back({g->lvl_ptr[sg.l0], g->lvl_ptr[sg.l0 + 1]});
+        const int T = std::max(1, std::min<int>(merge_threads(), 16));
+        run_threads(T, [&](int t) {
+          for (const auto& rg : ranges) {
+            const int64_t len = rg.second - rg.first;
+            const int a2 = rg.first + (int)(len * t / T), b2 = rg.first + (int)(len * (t + 1) / T);
+            for (int p2 = a2; p2 < b2; ++p2) {
+              std::copy(pcol.begin() + prow[p2], pcol.begin() + prow[p2 + 1], wcol.begin() + wmeta[p2].x);
+              std::copy(pval.begin() + prow[p2], pval.begin() + prow[p2 + 1], wval.begin() + wmeta[p2].x);
+            }
+          }
+        });
+      }
       // slot_row[s + 1] must close the last slot of every level: append per-level end markers by
       // storing, for each slot, its end row in a parallel array packed as slot_row2
       std::vector<int32_t> sr2(2 * slot_row.size());
@@ -404,32 +445,7 @@ int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncol
   return max_row;
 }
 
-int merge_threads() {
-  unsigned hw = std::thread::hardware_concurrency();
-  long quota = -1, period = -1;
-  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // do not oversubscribe a container's CPU quota
-    char q[64] = {0};
-    if (std::fscanf(f, "%63s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atol(q);
-    std::fclose(f);
-  }
-  int t = (int)std::max(1u, std::min(hw ? hw : 8u, 32u));
-  if (quota > 0 && period > 0) t = (int)std::min<long>(t, std::max<long>(1, (quota + period - 1) / period));
-  if (const char* e = getenv("AMGH_BUILD_THREADS")) t = std::max(1, atoi(e));
-  return t;
-}
 
-// fn(t) for t in [0, T): on T threads when they can be had, inline otherwise (a thread that cannot be created
-// must not take the process down)
-template <class F>
-void run_threads(int T, F fn) {
-  std::vector<std::thread> th;
-  int started = 0;
-  for (; started < T - 1; ++started) {
-    try { th.emplace_back(fn, started); } catch (const std::system_error&) { break; }
-  }
-  for (int t = started; t < T; ++t) fn(t);
-  for (auto& x : th) x.join();
-}
 
 // Fill estimate for group size m from a sample of groups: {entries per row, longest row}
 std::pair<double, int64_t> merge_estimate(const HostLevelCsr& base, int64_t ncols, int m, bool backward) {
@@ -590,22 +606,25 @@ void level_order(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t*
   base.pdpos.resize(n);
   base.pval.resize(nnz);
   base.pdiag.resize(n);
-  int64_t w = 0;
   base.prow[0] = 0;
-  for (int64_t p = 0; p < n; ++p) {
-    const int32_t i = perm[p];
-    int32_t dp = -1;
-    double d = 0.0;
-    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-      base.pcol[w] = inv[col[j]];   // entries stay in the row's original column order (sum order)
-      base.pval[w] = val[j];
-      if (col[j] == i) { dp = (int32_t)w; d = val[j]; }
-      ++w;
+  for (int64_t p = 0; p < n; ++p) base.prow[p + 1] = base.prow[p] + (rowptr[perm[p] + 1] - rowptr[perm[p]]);
+  const int T = std::max(1, std::min<int>(merge_threads(), 16));
+  run_threads(T, [&](int t) {
+    for (int64_t p = n * t / T; p < n * (t + 1) / T; ++p) {
+      const int32_t i = perm[p];
+      int32_t dp = -1;
+      double d = 0.0;
+      int64_t w = base.prow[p];
+      for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+        base.pcol[w] = inv[col[j]];   // entries stay in the row's original column order (sum order)
+        base.pval[w] = val[j];
+        if (col[j] == i) { dp = (int32_t)w; d = val[j]; }
+        ++w;
+      }
+      base.pdpos[p] = dp;
+      base.pdiag[p] = d;
     }
-    base.prow[p + 1] = (int32_t)w;
-    base.pdpos[p] = dp;
-    base.pdiag[p] = d;
-  }
+  });
 }
 
 int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
