@@ -180,44 +180,52 @@ class DistMultiLevel:
             self.ops.gather(t["unpack_idx"], t["recv"], self.ops.view(vec, plan.nloc, plan.nhalo), plan.nhalo)
 
     # ---- smooth!(x, smoother, b) on a sharded level ------------------------------------------------
-    def smooth(self, l, s):
+    def smooth(self, l, s, xzero=False):
+        """xzero: x (local part AND halo) is zero on every rank: the first halo exchange would move zeros."""
         d, x, b = self.levels[l], self.x[l], self.b[l]
         n = d["n"]
+        fresh = xzero   # halo already consistent with the neighbours' x
         for _ in range(s.iter):
             if s.kind == 2:      # Jacobi: exact
-                self.exchange("x", l, x)
+                if not fresh:
+                    self.exchange("x", l, x)
+                fresh = False
                 self.ops.jacobi(d["S"], s.omega, x, b, d["tmp"])
                 self.ops.copy(self.ops.view(x, 0, n), d["tmp"], n)
             elif s.kind in (1, 3):  # Gauss-Seidel / SOR: exact inside the shard, halo frozen per sweep
                 sor = s.kind == 3
                 if s.sweep_code in (0, 2):
-                    self.exchange("x", l, x)
+                    if not fresh:
+                        self.exchange("x", l, x)
+                    fresh = False
                     self.ops.gs(d["S"], False, s.omega, sor, x, b)
                 if s.sweep_code in (1, 2):
-                    self.exchange("x", l, x)
+                    if not fresh:
+                        self.exchange("x", l, x)
+                    fresh = False
                     self.ops.gs(d["S"], True, s.omega, sor, x, b)
 
     # ---- __solve! (multilevel.jl:214-239) ---------------------------------------------------------
-    def cycle(self, l, cyc):
+    def cycle(self, l, cyc, xzero=False):
         if l == self.lc:
             if self.rank == 0:
                 self.ops.coarse_cycle(self.coarse, self.x[l], self.b[l], cyc)
             return
         d = self.levels[l]
         x, b = self.x[l], self.b[l]
-        self.smooth(l, d["pre"])
+        self.smooth(l, d["pre"], xzero)
         self.exchange("x", l, x)
         self.ops.residual(d["A"], x, b, d["res"])
         self.exchange("r", l, d["res"])
         self.ops.spmv(d["R"], d["res"], self.b[l + 1])
-        self.ops.zero(self.x[l + 1], self.xplan[l + 1].nloc)
+        self.ops.zero(self.x[l + 1], self.xplan[l + 1].nloc + self.xplan[l + 1].nhalo)   # coarse_x .= 0, halo included
         self._next(l + 1, cyc)
         self.exchange("x", l + 1, self.x[l + 1])
         self.ops.spmv_add(d["P"], self.x[l + 1], x)
         self.smooth(l, d["post"])
 
-    def _next(self, l, cyc):  # __solve_next! (multilevel.jl:200-212)
-        self.cycle(l, cyc)
+    def _next(self, l, cyc):  # __solve_next! (multilevel.jl:200-212); x is zero on the first visit only
+        self.cycle(l, cyc, True)
         if cyc == CYCLE_W:
             self.cycle(l, CYCLE_W)
         elif cyc == CYCLE_F:
@@ -233,8 +241,8 @@ class DistMultiLevel:
 
     def precond_apply(self, cyc=CYCLE_V):
         """ldiv!: x = 0, one cycle (preconditioner.jl:12-19).  Result stays in self.x[0][:nloc]."""
-        self.ops.zero(self.x[0], self.xplan[0].nloc)
-        self.cycle(0, cyc) if self.lc > 0 else self._collapsed_only(cyc)
+        self.ops.zero(self.x[0], self.xplan[0].nloc + self.xplan[0].nhalo)
+        self.cycle(0, cyc, True) if self.lc > 0 else self._collapsed_only(cyc)
 
     def _collapsed_only(self, cyc):
         if self.rank == 0:
