@@ -139,6 +139,7 @@ def hip_lib():
     L.amgh_csr_spmv_add_d.argtypes = [vp, vp, vp, vp]
     L.amgh_csr_jacobi_d.argtypes = [vp, C.c_double, vp, vp, vp, vp]
     L.amgh_csr_gs_d.argtypes = [vp, C.c_int, C.c_double, C.c_int, vp, vp, vp]
+    L.amgh_csr_gs_ex_d.argtypes = [vp, C.c_int, C.c_double, C.c_int, vp, vp, vp, C.c_int]
     L.amgh_gather_d.argtypes = [C.c_int, i64, vp, vp, vp, vp]
     L.amgh_dot_d.argtypes = [C.c_int, i64, vp, vp, vp, C.POINTER(C.c_double), vp]
     L.amgh_cycle_d.argtypes = [vp, C.c_int, vp, vp, C.c_int]

@@ -882,6 +882,13 @@ int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, double
   HIP_TRY(hipSetDevice(op->device));
   return csr_gs_sweep(op, backward != 0, is_sor != 0, omega, x_d, b_d, (hipStream_t)stream);
 }
+int amgh_csr_gs_ex_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d, const double* b_d,
+                     void* stream, int flags) {
+  if (!op || !x_d || !b_d || (flags & ~AMGH_GS_REUSE_B)) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(op->device));
+  return csr_gs_sweep(op, backward != 0, is_sor != 0, omega, x_d, b_d, (hipStream_t)stream, true, true, 1, false,
+                      (flags & AMGH_GS_REUSE_B) != 0);
+}
 
 int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const double* src_d, double* dst_d, void* stream) {
   if (n < 0 || (n > 0 && (!idx_d || !src_d || !dst_d)) || n >= INT32_MAX) return AMGH_EINVAL;

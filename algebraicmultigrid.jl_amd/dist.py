@@ -180,8 +180,10 @@ class DistMultiLevel:
             self.ops.gather(t["unpack_idx"], t["recv"], self.ops.view(vec, plan.nloc, plan.nhalo), plan.nhalo)
 
     # ---- smooth!(x, smoother, b) on a sharded level ------------------------------------------------
-    def smooth(self, l, s, xzero=False):
-        """xzero: x (local part AND halo) is zero on every rank: the first halo exchange would move zeros."""
+    def smooth(self, l, s, xzero=False, b_kept=False):
+        """xzero: x (local part AND halo) is zero on every rank: the first halo exchange would move zeros.
+        b_kept: the previous smooth! call of this cycle swept the same b with Gauss-Seidel / SOR (its level-ordered
+        copy inside the operator is still valid).  Returns whether this call leaves such a copy."""
         d, x, b = self.levels[l], self.x[l], self.b[l]
         n = d["n"]
         fresh = xzero   # halo already consistent with the neighbours' x
@@ -198,12 +200,15 @@ class DistMultiLevel:
                     if not fresh:
                         self.exchange("x", l, x)
                     fresh = False
-                    self.ops.gs(d["S"], False, s.omega, sor, x, b)
+                    self.ops.gs(d["S"], False, s.omega, sor, x, b, b_kept)
+                    b_kept = True
                 if s.sweep_code in (1, 2):
                     if not fresh:
                         self.exchange("x", l, x)
                     fresh = False
-                    self.ops.gs(d["S"], True, s.omega, sor, x, b)
+                    self.ops.gs(d["S"], True, s.omega, sor, x, b, b_kept)
+                    b_kept = True
+        return b_kept and s.kind in (1, 3) and s.iter > 0
 
     # ---- __solve! (multilevel.jl:214-239) ---------------------------------------------------------
     def cycle(self, l, cyc, xzero=False):
@@ -213,7 +218,7 @@ class DistMultiLevel:
             return
         d = self.levels[l]
         x, b = self.x[l], self.b[l]
-        self.smooth(l, d["pre"], xzero)
+        b_kept = self.smooth(l, d["pre"], xzero)
         self.exchange("x", l, x)
         self.ops.residual(d["A"], x, b, d["res"])
         self.exchange("r", l, d["res"])
@@ -222,7 +227,7 @@ class DistMultiLevel:
         self._next(l + 1, cyc)
         self.exchange("x", l + 1, self.x[l + 1])
         self.ops.spmv_add(d["P"], self.x[l + 1], x)
-        self.smooth(l, d["post"])
+        self.smooth(l, d["post"], False, b_kept)
 
     def _next(self, l, cyc):  # __solve_next! (multilevel.jl:200-212); x is zero on the first visit only
         self.cycle(l, cyc, True)
@@ -393,10 +398,10 @@ class HipOps:
             self.check(self.lib.amgh_csr_jacobi_d(op.h, omega, xin.data_ptr(), b.data_ptr(), xout.data_ptr(),
                                                   self._stream()), "jacobi")
 
-    def gs(self, op, backward, omega, sor, x, b):
+    def gs(self, op, backward, omega, sor, x, b, reuse_b=False):
         if op.nrows:
-            self.check(self.lib.amgh_csr_gs_d(op.h, int(backward), omega, int(sor), x.data_ptr(), b.data_ptr(),
-                                              self._stream()), "gs")
+            self.check(self.lib.amgh_csr_gs_ex_d(op.h, int(backward), omega, int(sor), x.data_ptr(), b.data_ptr(),
+                                                 self._stream(), 1 if reuse_b else 0), "gs")
 
     def gather(self, idx, src, dst, n):
         self.check(self.lib.amgh_gather_d(self.device, n, idx.data_ptr(), src.data_ptr(), dst.data_ptr(),

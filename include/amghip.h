@@ -209,6 +209,12 @@ int amgh_csr_jacobi_d(amgh_csr_t* op, double omega, const double* xin_d, const d
  * otherwise SOR (:193-221).                                                     */
 int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d,
                   const double* b_d, void* stream);
+/* amgh_csr_gs_d with hints.  AMGH_GS_REUSE_B: b_d holds the same values as in the previous sweep on this operator
+ * (the sweeps of one smooth! call, the post-smoother after the pre-smoother of a cycle): its dependency-level-ordered
+ * copy is still in place and is not gathered again. */
+#define AMGH_GS_REUSE_B 1
+int amgh_csr_gs_ex_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d, const double* b_d,
+                     void* stream, int flags);
 
 /* dst[i] = src[idx[i]], i < n  — halo pack / unpack (device pointers).              */
 int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const double* src_d, double* dst_d, void* stream);

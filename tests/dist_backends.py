@@ -86,7 +86,7 @@ class CpuOps:
                 out[i] = (1.0 - omega) * xi[i] + omega * ((bb[i] - rs) / d)
         xout[:n] = torch.from_numpy(out)
 
-    def gs(self, op, backward, omega, sor, x, b):
+    def gs(self, op, backward, omega, sor, x, b, reuse_b=False):
         n = op.nrows
         xv, bb = x.numpy(), b.numpy()
         order = range(n - 1, -1, -1) if backward else range(n)
