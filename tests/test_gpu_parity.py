@@ -192,6 +192,14 @@ def test_merged_level_sweeps_irregular_operator(bigslot):
         ml = AMG.ruge_stuben(AMG.poisson((40, 36, 30)))
         cases.append(ml.levels[1].A)             # Galerkin operator of a 3-D grid (19-point-like rows)
         cases.append(AMG.ruge_stuben(AMG.poisson((64, 64, 48))).levels[2].A)   # longer rows: deep groups outgrow 512-entry slots
+        # nonsymmetric values AND pattern (the schedules symmetrise the pattern for the levels only; both sides sweep
+        # CSC column i as row i, smoother.jl:78)
+        M = cases[1].to_scipy().tolil()
+        rng = np.random.default_rng(5)
+        for i in rng.integers(50, 4900, 300):
+            M[i, i - int(rng.integers(1, 40))] *= 1.7
+            M[i, i - 45] = -0.05
+        cases.append(AMG.SparseMatrixCSC.from_scipy(sp.csc_matrix(M)))
         for k, A in enumerate(cases):
             n = A.m
             x0, b = uniform(n, 90 + k) - 0.5, uniform(n, 95 + k)
