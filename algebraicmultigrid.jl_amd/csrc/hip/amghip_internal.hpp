@@ -106,12 +106,25 @@ struct GsSchedule {
   Tri tri_f, tri_b;       // forward pre-pass: entries of later levels + halo; backward: earlier levels + halo
   int merge_f = 1, merge_b = 1;  // dependency levels per group
   int64_t xstride = 0;    // doubles per column of xp (ncols, or ncols + n with merged children)
-  bool flip_ok = false;   // square operator, no zero diagonal: the next alternating sweep's s follows from the last one
+  // SOR as merged sweeps: (D/w + L) x = b - U x_old + ((1-w)/w) D x_old is a triangular solve with a scaled
+  // diagonal, so the same construction applies, per relaxation factor w (composite coefficients carry powers of w).
+  // Built on the first SOR sweep with that w; two factors are kept (pre- and post-smoother may differ).
+  struct SorSet { double omega = 0.0; GsSchedule* f = nullptr; GsSchedule* b = nullptr; Tri tf, tb; bool built = false; };
+  SorSet sor[2];
+  int sor_next = 0;
+  double s_key = 0.0;     // relaxation factor of the merged sweep that produced the current s (1 = Gauss-Seidel)
+  bool diag_nonzero = false;  // no row keeps its x (zero diagonal): alternating merged sweeps may derive s from the last one
   int s_dir = -1;         // direction (0 fwd, 1 bwd) whose merged sweep last ran on the current xp / s, -1: none
   void free_dev() {
     for (GsSchedule** c : {&mf, &mb})
       if (*c) { (*c)->free_dev(); delete *c; *c = nullptr; }
     for (Tri* t : {&tri_f, &tri_b}) { hipFree(t->rowptr); hipFree(t->col); hipFree(t->val); *t = Tri(); }
+    for (SorSet& ss : sor) {
+      for (GsSchedule** c : {&ss.f, &ss.b})
+        if (*c) { (*c)->free_dev(); delete *c; *c = nullptr; }
+      for (Tri* t : {&ss.tf, &ss.tb}) { hipFree(t->rowptr); hipFree(t->col); hipFree(t->val); *t = Tri(); }
+      ss = SorSet();
+    }
     for (Outer* o : {&blk_f, &blk_b}) {
       hipFree(o->rowptr); hipFree(o->col); hipFree(o->val); hipFree(o->tinv);
       hipFree(o->near_ptr); hipFree(o->near_pi); hipFree(o->near_val);

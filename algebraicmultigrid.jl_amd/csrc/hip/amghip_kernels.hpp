@@ -334,13 +334,15 @@ __global__ void scatter_perm_kernel(const double* __restrict__ xp, const int32_t
 // Right-hand side of the NEXT merged sweep when the directions alternate: after a forward sweep
 // (D + L) x = s_f holds row by row, so the backward pre-pass b - L x is b - s_f + D x — no matrix pass
 // (and symmetrically after a backward sweep).  Level order; blockIdx.y = right-hand-side column.
+// (SOR with factor w: diag holds D / w and the formula is b - s_f + (2 - w) (D / w) x, scale = 2 - w.)
 __global__ void gs_flip_rhs_kernel(const double* __restrict__ bp, const double* __restrict__ diag,
-                                   const double* __restrict__ xp, double* __restrict__ sp, int n, int64_t ldb, int64_t ldx) {
+                                   const double* __restrict__ xp, double* __restrict__ sp, int n, int64_t ldb, int64_t ldx,
+                                   double scale) {
   bp += blockIdx.y * ldb;
   xp += blockIdx.y * ldx;
   sp += blockIdx.y * ldx;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x)
-    sp[r] = bp[r] - sp[r] + diag[r] * xp[r];
+    sp[r] = bp[r] - sp[r] + scale * (diag[r] * xp[r]);
 }
 
 // dst[column][0..n) = src[column][0..n): strided copy of a block of right-hand-side columns (blockIdx.y = column)

@@ -203,6 +203,37 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     HIP_TRY(hipGetLastError());
     return AMGH_OK;
   }
+  // which triangular system runs: the level-by-level one, merged Gauss-Seidel groups, or merged SOR groups (built on
+  // the first sweep with this relaxation factor); merged SOR runs the GS kernels on the scaled system
+  GsSchedule* lay = g;
+  const GsSchedule::Tri* tri = nullptr;
+  double s_key = 0.0, flip_scale = 1.0;
+  bool both_dirs = false;
+  if (g_gs_merge > 1 && !sor && (backward ? g->mb : g->mf)) {
+    lay = backward ? g->mb : g->mf;
+    tri = backward ? &g->tri_b : &g->tri_f;
+    s_key = 1.0;
+    both_dirs = g->mf && g->mb;
+  } else if (g_gs_merge > 1 && sor) {
+    GsSchedule::SorSet* ss = sor_children(g, omega);
+    if (ss && (backward ? ss->b : ss->f)) {
+      lay = backward ? ss->b : ss->f;
+      tri = backward ? &ss->tb : &ss->tf;
+      s_key = omega;
+      flip_scale = 2.0 - omega;
+      both_dirs = ss->f && ss->b;
+      if (g->xstride == g->ncols) {  // first merged system on this operator: x and s share one vector from now on
+        HIP_TRY(hipStreamSynchronize(st));
+        hipFree(g->xp); g->xp = nullptr;
+        g->xstride = g->ncols + g->n;
+        RC_TRY(dev_alloc(&g->xp, g->xstride * g->cols_alloc));
+        g->bytes += 8 * g->n * g->cols_alloc;
+        op->bytes += 8 * g->n * g->cols_alloc;
+        if (!first) return AMGH_ESTATE;  // (cannot happen: the first sweep of a smooth! call builds the children)
+      }
+      sor = false;  // the scaled triangular system is swept like Gauss-Seidel
+    }
+  }
   const int64_t xs = g->xstride;  // doubles per column of xp
   if (first) {
     if (!(reuse_b && g->bp_cols == ncolv))
@@ -221,32 +252,33 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     HIP_TRY(hipGetLastError());
   }
   double* xp = g->xp;
-  // merged-level sweep (GS only): the child schedule of this direction runs on ext = [x ; s], s = b - T x
-  GsSchedule* lay = g;
+  // merged-level sweep: the child schedule of this direction runs on ext = [x ; s], s = b - T x
   const double* rhs = g->bp;
   int64_t ldb = g->n;
   if (first) g->s_dir = -1;
-  if (!sor && g_gs_merge > 1 && (backward ? g->mb : g->mf)) {
-    lay = backward ? g->mb : g->mf;
-    if (g->flip_ok && g_gs_flip && g->s_dir == (backward ? 0 : 1)) {
+  if (lay != g) {
+    const bool flip = g->ncols == g->n && g->diag_nonzero && both_dirs && g_gs_flip &&
+                      g->s_dir == (backward ? 0 : 1) && g->s_key == s_key;
+    if (flip) {
       // the previous sweep of this smooth! call ran the other way on the same xp: s follows without a matrix pass
       hipLaunchKernelGGL(gs_flip_rhs_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const double*)g->bp,
-                         (const double*)lay->diag, (const double*)xp, xp + g->ncols, (int)g->n, (int64_t)g->n, xs);
+                         (const double*)lay->diag, (const double*)xp, xp + g->ncols, (int)g->n, (int64_t)g->n, xs,
+                         flip_scale);
       HIP_TRY(hipGetLastError());
     } else if (first && xzero) {  // s = b - T * 0
       hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, xp + g->ncols,
                          (const double*)g->bp, (int)g->n, xs, (int64_t)g->n);
       HIP_TRY(hipGetLastError());
     } else {
-      const GsSchedule::Tri& t = backward ? g->tri_b : g->tri_f;
       StreamArgs ra{};
-      ra.rowptr = t.rowptr; ra.col = t.col; ra.val = t.val;
+      ra.rowptr = tri->rowptr; ra.col = tri->col; ra.val = tri->val;
       ra.x = xp; ra.b = g->bp; ra.y = xp + g->ncols;
       ra.row_begin = 0; ra.row_end = (int32_t)g->n;
       ra.ldx = xs; ra.ldy = xs; ra.ldb = g->n;
       RC_TRY(launch_stream<M_RESID>(ra, st, ncolv));
     }
     g->s_dir = backward ? 1 : 0;
+    g->s_key = s_key;
     rhs = xp + g->ncols;
     ldb = xs;
   } else {

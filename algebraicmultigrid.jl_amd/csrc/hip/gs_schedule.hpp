@@ -521,7 +521,8 @@ MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool bac
 }
 
 // the triangle (plus halo columns) a sweep direction does NOT substitute over: s = b - T x before the sweep
-int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int64_t* bytes) {
+// diag_shift != 0 (SOR): the diagonal enters the pre-pass with -diag_shift * d, i.e. s = b - T x + diag_shift * D x
+int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int64_t* bytes, double diag_shift = 0.0) {
   const int64_t n = base.n;
   std::vector<int32_t> lev_of(n);
   for (int l = 0; l < base.nlev; ++l)
@@ -535,6 +536,7 @@ int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int6
       const bool other = c >= n || (backward ? lev_of[c] < lev_of[p] : lev_of[c] > lev_of[p]);
       if (other) { cc.push_back(c); vv.push_back(base.pval[j]); }
     }
+    if (diag_shift != 0.0 && base.pdiag[p] != 0.0) { cc.push_back((int32_t)p); vv.push_back(-diag_shift * base.pdiag[p]); }
     rp[p + 1] = (int32_t)cc.size();
   }
   RC_TRY(dev_upload(&t->rowptr, rp.data(), n + 1));
@@ -750,13 +752,86 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         if (*c) { g->bytes -= (*c)->bytes; (*c)->free_dev(); delete *c; *c = nullptr; }
     }
     if (g->mf || g->mb) g->xstride = g->ncols + n;
-    g->flip_ok = g->mf && g->mb && g->ncols == n;
-    for (int64_t p2 = 0; p2 < n && g->flip_ok; ++p2) g->flip_ok = base.pdiag[p2] != 0.0;
   }
+  g->diag_nonzero = true;
+  for (int64_t p2 = 0; p2 < n && g->diag_nonzero; ++p2) g->diag_nonzero = base.pdiag[p2] != 0.0;
   RC_TRY(dev_alloc(&g->bp, n));
   RC_TRY(dev_alloc(&g->xp, g->xstride));
   g->bytes += 8 * (n + g->xstride);
   return AMGH_OK;
+}
+
+// Merged children for SOR with relaxation factor omega, built on demand from the level-ordered matrix already on
+// the device.  Returns the cache entry (children may be null: merging did not pay or was rejected).
+GsSchedule::SorSet* sor_children(GsSchedule* g, double omega) {
+  for (GsSchedule::SorSet& ss : g->sor)
+    if (ss.built && ss.omega == omega) return &ss;
+  GsSchedule::SorSet& ss = g->sor[g->sor_next];
+  g->sor_next ^= 1;
+  for (GsSchedule** c : {&ss.f, &ss.b})
+    if (*c) { g->bytes -= (*c)->bytes; (*c)->free_dev(); delete *c; *c = nullptr; }
+  for (GsSchedule::Tri* t : {&ss.tf, &ss.tb}) { hipFree(t->rowptr); hipFree(t->col); hipFree(t->val); *t = GsSchedule::Tri(); }
+  ss.omega = omega;
+  ss.built = true;
+  const int64_t n = g->n;
+  if (!(g_gs_merge > 1 && n >= 4096 && g->nlev >= 64) || omega == 0.0) return &ss;
+  BuildTimer tm;
+  HostLevelCsr base;
+  base.n = n;
+  base.nlev = g->nlev;
+  base.lvl_ptr = g->lvl_ptr;
+  base.prow.resize(n + 1);
+  if (hipMemcpy(base.prow.data(), g->rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost) != hipSuccess) return &ss;
+  const int64_t nnz = base.prow[n];
+  base.pcol.resize(nnz); base.pval.resize(nnz); base.pdpos.resize(n); base.pdiag.resize(n);
+  if (hipMemcpy(base.pcol.data(), g->col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(base.pval.data(), g->val, sizeof(double) * nnz, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(base.pdpos.data(), g->dpos, sizeof(int32_t) * n, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(base.pdiag.data(), g->diag, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess)
+    return &ss;
+  HostLevelCsr scaled = base;               // the triangular system SOR solves has the diagonal D / omega
+  for (double& dd : scaled.pdiag) dd /= omega;
+  for (int dir = 0; dir < 2; ++dir) {
+    const bool backward = dir == 1;
+    double best = merge_cost(base.nlev, nnz);
+    int best_m = 1, cap = kSlot, worse = 0;
+    for (int m = 2; m <= g_gs_merge; ++m) {
+      const std::pair<double, int64_t> est = merge_estimate(scaled, g->ncols, m, backward);
+      int cap_m = kSlot;
+      if (est.second > kSlot - kSlot / 8 || g_gs_bigslot == 2) cap_m = kBigSlot;
+      if (est.second > kBigSlot - kBigSlot / 8 || (cap_m == kBigSlot && !g_gs_bigslot)) break;
+      const int ngrp = (base.nlev + m - 1) / m;
+      const double c = merge_cost(ngrp, (int64_t)(est.first * n)) + 12.0 * (double)nnz / 2 / 4e12 +
+                       (cap_m == kBigSlot ? ngrp * 2.5e-6 : 0.0);
+      if (c < 0.97 * best) { best = c; best_m = m; cap = cap_m; worse = 0; }
+      else if (++worse >= 6) break;
+      if (12.0 * est.first * n / 2.5e12 > best) break;
+    }
+    MergeResult keep;
+    while (best_m > 1) {
+      keep = merge_build(scaled, g->ncols, best_m, backward);
+      if (keep.max_row > cap && cap == kSlot && g_gs_bigslot && keep.max_row <= kBigSlot) cap = kBigSlot;
+      if (keep.max_row <= cap && !(keep.growth > kMergeGrowthMax)) break;
+      --best_m;
+    }
+    if (best_m > 1) {
+      GsSchedule* ch = new GsSchedule;
+      ch->ncols = g->ncols;
+      if (layout_upload(ch, keep.sys, nullptr, cap) != AMGH_OK ||
+          tri_upload(backward ? &ss.tb : &ss.tf, base, backward, &g->bytes, (1.0 - omega) / omega) != AMGH_OK) {
+        ch->free_dev();
+        delete ch;
+        continue;
+      }
+      (backward ? ss.b : ss.f) = ch;
+      g->bytes += ch->bytes;
+      if (getenv("AMGH_VERBOSE"))
+        fprintf(stderr, "[amghip] n=%lld SOR(%.3g) %s: groups of %d levels, %d-entry slots, longest row %lld\n", (long long)n,
+                omega, backward ? "bwd" : "fwd", best_m, cap, (long long)keep.max_row);
+    }
+  }
+  tm.lap("SOR merged children", n);
+  return &ss;
 }
 
 int csr_ensure_gs(amgh_csr* op) {
