@@ -531,6 +531,12 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
     rc = L->has_S ? gs_build(g, n, n, S_rowptr, S_col, S_val) : gs_build(g, n, n, A_rowptr, A_col, A_val);
     if (rc == AMGH_OK) { M->gs = g; M->bytes += g->bytes; }
     else { g->free_dev(); delete g; }
+    if (rc == AMGH_OK && g->nblk == 0) {  // SOR: its merged groups depend on the relaxation factor, build them now too
+      const int64_t before = g->bytes;
+      if (pre->kind == AMGH_SMOOTH_SOR && pre->iter > 0) (void)sor_children(g, pre->omega);
+      if (post->kind == AMGH_SMOOTH_SOR && post->iter > 0) (void)sor_children(g, post->omega);
+      M->bytes += g->bytes - before;
+    }
     // level-ordered copies of P and R when both smoothers are level-scheduled sweeps over A itself
     const bool both = (pre->kind == AMGH_SMOOTH_GS || pre->kind == AMGH_SMOOTH_SOR) && pre->iter > 0 &&
                       (post->kind == AMGH_SMOOTH_GS || post->kind == AMGH_SMOOTH_SOR) && post->iter > 0;
