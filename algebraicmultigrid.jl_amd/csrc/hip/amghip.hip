@@ -1024,18 +1024,23 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
 // x: ncols entries (in/out, columns >= nrows are frozen halo values), b: nrows entries.  CPU tests compare it with
 // the scalar lexicographic sweep.  Returns the number of groups, or a negative error code.
 int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
-                                 const double* val, int m, int backward, double* x, const double* b) {
-  if (nrows < 0 || ncols < nrows || !rowptr || m < 1 || !x || !b) return AMGH_EINVAL;
+                                 const double* val, int m, int backward, double omega, double* x, const double* b) {
+  if (nrows < 0 || ncols < nrows || !rowptr || m < 1 || !x || !b || omega == 0.0) return AMGH_EINVAL;
   const int64_t n = nrows;
   HostLevelCsr base;
   std::vector<int32_t> perm;
   level_order(n, ncols, rowptr, col, val, base, perm);
-  MergeResult R = merge_build(base, ncols, m, backward != 0);
+  // SOR with factor omega = the triangular solve with diagonal D / omega and the diagonal term
+  // ((1 - omega) / omega) D x_old on the right-hand side; omega = 1 is Gauss-Seidel
+  HostLevelCsr scaled = base;
+  for (double& dd : scaled.pdiag) dd /= omega;
+  const double shift = (1.0 - omega) / omega;
+  MergeResult R = merge_build(scaled, ncols, m, backward != 0);
   if (R.max_row > kBigSlot) return AMGH_EUNSUPPORTED;
   const HostLevelCsr& S = R.sys;
   std::vector<double> ext(ncols + n);
   for (int64_t c = 0; c < ncols; ++c) ext[c] = c < n ? x[perm[c]] : x[c];
-  // pre-pass: s = b - T x over the triangle this direction does not substitute over (+ halo columns)
+  // pre-pass: s = b - T x over the triangle this direction does not substitute over (+ halo columns, + diagonal term)
   std::vector<int32_t> lev_of(n);
   for (int l = 0; l < base.nlev; ++l)
     for (int32_t p = base.lvl_ptr[l]; p < base.lvl_ptr[l + 1]; ++p) lev_of[p] = l;
@@ -1047,6 +1052,7 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
       const bool other = c >= n || (backward ? lev_of[c] < lev_of[p] : lev_of[c] > lev_of[p]);
       if (other) s -= base.pval[j] * ext[c];
     }
+    if (base.pdiag[p] != 0.0) s += shift * base.pdiag[p] * ext[p];
     ext[ncols + p] = s;
   }
   // groups in sweep order; rows of a group only read earlier groups and s, so their order does not matter

@@ -258,7 +258,8 @@ int amgh_debug_chain_timing(int enable, unsigned long long* out8);
  * No device work: CPU tests check it against the scalar lexicographic sweep (smoother.jl:78-88).
  * x: ncols entries in/out (columns >= nrows are frozen halo values), b: nrows.  Returns the number of groups. */
 int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
-                                 const double* val, int m, int backward, double* x, const double* b);
+                                 const double* val, int m, int backward, double omega /* 1 = Gauss-Seidel, else SOR */,
+                                 double* x, const double* b);
 
 /* Diagnostics: tunables of the Gauss-Seidel execution (process-wide; used by tools/ to pick the defaults and by
  * tests to force every path).  Read at every sweep: "gs_xcd_map", "gs_block_pipe", "gs_flip", "gs_keep_lo",

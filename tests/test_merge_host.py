@@ -13,7 +13,7 @@ from oracle import oracle as O
 FWD, BWD = AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep())
 
 
-def _host_sweep(rowptr, col, val, nrows, ncols, m, backward, x, b):
+def _host_sweep(rowptr, col, val, nrows, ncols, m, backward, x, b, omega=1.0):
     lib = AMG.hip_lib()
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
     col = np.ascontiguousarray(col, dtype=np.int32)
@@ -21,7 +21,7 @@ def _host_sweep(rowptr, col, val, nrows, ncols, m, backward, x, b):
     x = np.array(x, dtype=np.float64, copy=True)
     b = np.ascontiguousarray(b, dtype=np.float64)
     rc = lib.amgh_debug_merged_sweep_host(nrows, ncols, rowptr.ctypes.data, col.ctypes.data, val.ctypes.data, m,
-                                          int(backward), x.ctypes.data, b.ctypes.data)
+                                          int(backward), float(omega), x.ctypes.data, b.ctypes.data)
     assert rc >= 0, rc
     return x, rc
 
@@ -60,6 +60,23 @@ def test_merged_sweep_equals_scalar_sweep(m):
             ref = O.smooth(s, A, x0, b)
             assert _rel(x, ref) <= 1e-13, (m, k, back, _rel(x, ref))
             assert ngroups >= 1
+
+
+@pytest.mark.parametrize("omega", [0.5, 1.2, 1.9])
+def test_merged_sor_sweep_equals_scalar_sor(omega):
+    """SOR = the same triangular solve with the diagonal D/omega and ((1-omega)/omega) D x_old on the right-hand side
+    (smoother.jl:193-221): merged groups of that scaled system against the oracle's scalar SOR sweeps."""
+    cases = [AMG.poisson((12, 10, 9)), _irregular(500, 8, 7, zero_diag=(3, 250)),
+             AMG.ruge_stuben(AMG.poisson((20, 18, 16))).levels[1].A]
+    for k, A in enumerate(cases):
+        n = A.m
+        rp, ci, va = A.csr_arrays()
+        x0, b = uniform(n, 40 + k) - 0.5, uniform(n, 50 + k)
+        for m in (1, 3, 8):
+            for back, s in ((0, AMG.SOR(omega, AMG.ForwardSweep())), (1, AMG.SOR(omega, AMG.BackwardSweep()))):
+                x, _ = _host_sweep(rp, ci, va, n, n, m, back, x0, b, omega)
+                ref = O.smooth(s, A, x0, b)
+                assert _rel(x, ref) <= 1e-12, (omega, k, m, back, _rel(x, ref))
 
 
 def test_merged_sweep_with_halo_columns():
