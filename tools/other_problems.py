@@ -1,5 +1,6 @@
 """V-cycle time on problem classes other than the 3-D Poisson headline (robustness of the schedule heuristics):
-2-D Poisson 4096^2 (8190 dependency levels on the fine grid), 3-D Poisson with random diagonal shifts."""
+2-D Poisson 4096^2 (8190 dependency levels on the fine grid), 3-D Poisson with random diagonal shifts, a smoothed-
+aggregation hierarchy with its default symmetric Gauss-Seidel."""
 import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -28,8 +29,11 @@ M = AMG.poisson((160, 160, 160)).to_scipy().tocsr()
 rng = np.random.default_rng(1)
 M = (M + sp.diags(rng.random(M.shape[0]) * 2.0)).tocsc()      # variable coefficients on the diagonal
 cases.append(("poisson((160,160,160)) + random diagonal in [0,2)", AMG.SparseMatrixCSC.from_scipy(M)))
+cases.append(("smoothed_aggregation: poisson((160,160,160))", AMG.poisson((160, 160, 160))))
 for name, A in cases:
-    t0 = time.perf_counter(); ml = AMG.ruge_stuben(A); ts = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ml = AMG.smoothed_aggregation(A) if name.startswith("smoothed_aggregation") else AMG.ruge_stuben(A)
+    ts = time.perf_counter() - t0
     n = A.m
     for merge in (1, 16):
         lib.amgh_debug_set_tunable(b"gs_merge", merge)
