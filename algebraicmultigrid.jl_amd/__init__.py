@@ -22,6 +22,6 @@ from .hierarchy import (Classical, HermitianSymmetry, JacobiProlongation, Level,
 from .solve import (F, Preconditioner, RugeStubenAMG, SmoothedAggregationAMG, V, W, _solve, _solve_inplace,  # noqa: F401
                     aspreconditioner, cg, solve)
 from .device import DeviceBuffer, DeviceCSR, DeviceHierarchy  # noqa: F401
-from . import dist  # noqa: F401
+from . import dist, sharded  # noqa: F401
 
 __all__ = [n for n in dir() if not n.startswith("__")]

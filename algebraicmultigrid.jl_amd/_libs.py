@@ -160,6 +160,37 @@ def hip_lib():
     L.amgh_profile_enable.argtypes = [vp, C.c_int]
     L.amgh_profile_read.argtypes = [vp, vp, C.c_int]
     L.amgh_set_use_graph.argtypes = [vp, C.c_int]
+    # row-sharded hierarchy (amgh_dist_*)
+    i64p = C.POINTER(i64)
+    L.amgh_dist_rccl_available.argtypes = []
+    L.amgh_dist_unique_id.argtypes = [vp]
+    L.amgh_dist_create_rccl.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]
+    L.amgh_local_group_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.amgh_local_group_destroy.argtypes = [vp]
+    L.amgh_local_group_destroy.restype = None
+    L.amgh_local_group_abort.argtypes = [vp]
+    L.amgh_local_group_abort.restype = None
+    L.amgh_dist_create_local.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp]
+    L.amgh_dist_destroy.argtypes = [vp]
+    L.amgh_dist_destroy.restype = None
+    L.amgh_dist_push_level.argtypes = [vp, i64, i64, vp, vp] + [vp] * 12 + [C.POINTER(amgh_smoother_t),
+                                                                            C.POINTER(amgh_smoother_t)]
+    L.amgh_dist_set_tail.argtypes = [vp, vp]
+    L.amgh_dist_finalize.argtypes = [vp]
+    L.amgh_dist_num_sharded_levels.argtypes = [vp]
+    L.amgh_dist_local_range.argtypes = [vp, C.c_int, i64p, i64p]
+    L.amgh_dist_precond_apply_d.argtypes = [vp, vp, vp, C.c_int]
+    L.amgh_dist_solve_d.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, C.POINTER(C.c_int)]
+    L.amgh_dist_spmv_d.argtypes = [vp, C.c_int, vp, vp]
+    L.amgh_dist_sync.argtypes = [vp]
+    L.amgh_dist_barrier.argtypes = [vp]
+    L.amgh_dist_allreduce.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.amgh_dist_stats.argtypes = [vp, vp, C.c_int]
+    L.amgh_dist_device_bytes.restype = i64
+    L.amgh_dist_device_bytes.argtypes = [vp]
+    L.amgh_dist_stream.restype = vp
+    L.amgh_dist_stream.argtypes = [vp]
+    L.amgh_dist_plan_info.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     _hip = L
     return L
 

@@ -68,8 +68,10 @@ struct amgh_handle {
   // AMGH_USE_GRAPH=1).
   bool use_graph = false;
   // hipGraph cache of whole cycles, keyed by the (x, b, cycle) they were captured on
+  // exec == nullptr: this key has been run eagerly once (first-use allocations done), capture on the next call
   struct CycleGraph { const double* x; const double* b; int cyc; bool xzero; hipGraphExec_t exec; };
   std::vector<CycleGraph> graphs;
+  unsigned long long graph_epoch = 0;  // g_sched_epoch the cached graphs were captured under
 };
 
 namespace {
@@ -287,11 +289,36 @@ int apply_once(amgh_t* h, double* x, const double* b, int cyc, bool xzero) {
 // xzero: the caller has just zeroed x (ldiv!, the preconditioner inside PCG)
 int apply_cycle(amgh_t* h, double* x, const double* b, int cyc, bool xzero = false) {
   if (!h->use_graph || h->profile || h->coarse_fn || h->levels.empty()) return apply_once(h, x, b, cyc, xzero);
-  for (auto& g : h->graphs)
+  if (h->graph_epoch != g_sched_epoch) {  // a schedule buffer moved: the captured pointers are stale
+    for (auto& g : h->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+    h->graph_epoch = g_sched_epoch;
+  }
+  size_t warm = h->graphs.size();
+  for (size_t i = 0; i < h->graphs.size(); ++i) {
+    auto& g = h->graphs[i];
     if (g.x == x && g.b == b && g.cyc == cyc && g.xzero == xzero) {
+      if (!g.exec) { warm = i; break; }
       HIP_TRY(hipGraphLaunch(g.exec, h->stream));
       return AMGH_OK;
     }
+  }
+  if (warm == h->graphs.size()) {
+    // first cycle with this key: eager, so that every first-use path (scratch growth, SOR children, diagonal
+    // tables: hipMalloc / hipFree / synchronisation, all illegal during capture) has run before anything is captured
+    RC_TRY(apply_once(h, x, b, cyc, xzero));
+    if (h->graph_epoch != g_sched_epoch) {
+      for (auto& g : h->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
+      h->graphs.clear();
+      h->graph_epoch = g_sched_epoch;
+    }
+    if (h->graphs.size() >= 6) {
+      if (h->graphs.front().exec) hipGraphExecDestroy(h->graphs.front().exec);
+      h->graphs.erase(h->graphs.begin());
+    }
+    h->graphs.push_back({x, b, cyc, xzero, nullptr});
+    return AMGH_OK;
+  }
   hipGraph_t graph = nullptr;
   if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
@@ -314,11 +341,7 @@ int apply_cycle(amgh_t* h, double* x, const double* b, int cyc, bool xzero = fal
     h->use_graph = false;
     return apply_once(h, x, b, cyc, xzero);
   }
-  if (h->graphs.size() >= 6) {
-    hipGraphExecDestroy(h->graphs.front().exec);
-    h->graphs.erase(h->graphs.begin());
-  }
-  h->graphs.push_back({x, b, cyc, xzero, exec});
+  h->graphs[warm].exec = exec;
   HIP_TRY(hipGraphLaunch(exec, h->stream));
   return AMGH_OK;
 }
@@ -494,7 +517,7 @@ void amgh_destroy(amgh_t* h) {
   hipFree(h->coarse_op); hipFree(h->res_final); hipFree(h->partial); hipFree(h->scal);
   hipFree(h->x0); hipFree(h->b0); hipFree(h->pc_r); hipFree(h->pc_c); hipFree(h->pc_u);
   for (auto& e : h->pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  for (auto& g : h->graphs) hipGraphExecDestroy(g.exec);
+  for (auto& g : h->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
   if (h->t0) hipEventDestroy(h->t0);
   if (h->t1) hipEventDestroy(h->t1);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -535,6 +558,9 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
       const int64_t before = g->bytes;
       if (pre->kind == AMGH_SMOOTH_SOR && pre->iter > 0) (void)sor_children(g, pre->omega);
       if (post->kind == AMGH_SMOOTH_SOR && post->iter > 0) (void)sor_children(g, post->omega);
+      bool any_child = false;
+      for (const GsSchedule::SorSet& ss : g->sor) any_child = any_child || ss.f || ss.b;
+      if (any_child) rc = gs_grow_xp_for_merged(g, nullptr);  // now, while no sweep is in flight (never inside one)
       M->bytes += g->bytes - before;
     }
     // level-ordered copies of P and R when both smoothers are level-scheduled sweeps over A itself
@@ -1124,3 +1150,5 @@ int amgh_set_use_graph(amgh_t* h, int on) {
 }
 
 }  // extern "C"
+
+#include "amghip_dist.hpp"

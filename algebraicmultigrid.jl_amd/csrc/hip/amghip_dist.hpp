@@ -1,0 +1,952 @@
+// amghip_dist.hpp — the row-sharded cycle behind the C ABI (include/amghip.h, "Row-sharded hierarchy").
+//
+// BASELINE.json config C4 / SURVEY.md section 8e: the fine levels of the hierarchy are partitioned by contiguous 1-D row
+// ranges, one rank per GPU; every operator application is preceded by an exchange of the halo entries of its input
+// vector; the coarse levels are collapsed onto the rank that owns all their rows (an ordinary amgh_t).  The reference is
+// single-process (multilevel.jl:214-239 is what gets sharded), so there is no reference counterpart of the exchange.
+//
+// Halo exchange = NEIGHBOUR send/recv, not an all-gather: the halo region of a vector is laid out [local | halo sorted
+// by global index], i.e. grouped by owner, so what a peer sends lands directly in place (no unpack kernel); the send
+// side is one gather kernel into a packed buffer.  Transports:
+//   RCCL   one process per GPU; ncclSend/ncclRecv grouped per exchange on a communication stream, overlapped with the
+//          interior rows (rows that read no halo column) of the consuming operator; librccl is dlopen'ed on first use so
+//          that libamghip.so loads on machines without it.
+//   LOCAL  N ranks as N handles of ONE process (threads), peer copies between their streams; ranks may share a device.
+//          This is what the single-GPU test box runs (virtual ranks) and what a single-process multi-GPU host can use.
+// Gauss-Seidel / SOR cannot be both lexicographic and parallel across a row partition: on sharded levels the sweep is
+// exact inside a shard with the halo frozen per directional sweep (processor-block hybrid); Jacobi, residual,
+// restriction and prolongation are exactly the single-GPU arithmetic.
+#pragma once
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <mutex>
+
+namespace {
+
+// ---- transports -------------------------------------------------------------------------------------------------
+struct PeerSpan { int64_t off = 0, cnt = 0; };
+
+struct Transport {
+  int rank = 0, nranks = 1;
+  virtual ~Transport() {}
+  virtual bool async() const { return false; }
+  // setup: every rank contributes a list of int64, every rank gets all lists
+  virtual int allgatherv_host(const std::vector<int64_t>& mine, std::vector<std::vector<int64_t>>& all) = 0;
+  // data path: send sendbuf[send[p].off .. +cnt) to peer p, receive recv[p].cnt doubles from p into recvbuf + recv[p].off.
+  // `st` is the stream the packed send buffer was produced on and on which the received data will be consumed:
+  // begin() may return before the data has arrived, finish() makes `st` wait for it.
+  virtual int exchange_begin(const double* sendbuf, const std::vector<PeerSpan>& send, double* recvbuf,
+                             const std::vector<PeerSpan>& recv, hipStream_t st) = 0;
+  virtual int exchange_finish(hipStream_t st) = 0;
+  virtual int allreduce(double* v, int n, bool max_op) = 0;  // host values, in place
+  virtual int barrier() = 0;
+};
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.lib ? &api : nullptr;
+  tried = true;
+  // whichever librccl the process already has (SONAME match), else the ROCm installation's
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) break;
+  }
+  if (!api.lib) return nullptr;
+  bool ok = true;
+  auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); ok = ok && p; return p; };
+  api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+  api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+  api.Send = (decltype(api.Send))sym("ncclSend");
+  api.Recv = (decltype(api.Recv))sym("ncclRecv");
+  api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+  api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+  api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+  api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+  api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) { dlclose(api.lib); api.lib = nullptr; return nullptr; }
+  return &api;
+}
+
+// where a collective setup step rejected its input (AMGH_VERBOSE=1)
+#define DIST_EINVAL(what)                                                                              \
+  do {                                                                                                 \
+    fprintf(stderr, "[amghip dist] invalid argument: %s (line %d)\n", what, __LINE__);               \
+    return AMGH_EINVAL;                                                                                \
+  } while (0)
+
+#define NCCL_TRY(expr)                                              \
+  do {                                                              \
+    ncclResult_t r_ = (expr);                                       \
+    if (r_ != ncclSuccess) return -(2000 + (int)r_);                \
+  } while (0)
+
+struct RcclTransport : Transport {
+  RcclApi* api = nullptr;
+  ncclComm_t comm = nullptr;
+  hipStream_t cs = nullptr;      // communication stream
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  int64_t* d_i64 = nullptr;      // setup scratch
+  int64_t d_i64_cap = 0;
+  double* d_scal = nullptr;
+  ~RcclTransport() override {
+    if (comm && api) api->CommDestroy(comm);
+    if (cs) hipStreamDestroy(cs);
+    if (ev_ready) hipEventDestroy(ev_ready);
+    if (ev_done) hipEventDestroy(ev_done);
+    hipFree(d_i64); hipFree(d_scal);
+  }
+  bool async() const override { return true; }
+  int init(const void* id, int rank_, int nranks_) {
+    api = rccl_api();
+    if (!api) return AMGH_EUNSUPPORTED;
+    rank = rank_; nranks = nranks_;
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    NCCL_TRY(api->CommInitRank(&comm, nranks, uid, rank));
+    HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    RC_TRY(dev_alloc(&d_scal, 64));
+    return AMGH_OK;
+  }
+  int ensure_i64(int64_t n) {
+    if (n <= d_i64_cap) return AMGH_OK;
+    hipFree(d_i64); d_i64 = nullptr;
+    RC_TRY(dev_alloc(&d_i64, n));
+    d_i64_cap = n;
+    return AMGH_OK;
+  }
+  int allgatherv_host(const std::vector<int64_t>& mine, std::vector<std::vector<int64_t>>& all) override {
+    // counts, then the lists padded to the longest
+    RC_TRY(ensure_i64(2 * (int64_t)nranks + 2));
+    int64_t cnt = (int64_t)mine.size();
+    HIP_TRY(hipMemcpyAsync(d_i64, &cnt, 8, hipMemcpyHostToDevice, cs));
+    NCCL_TRY(api->AllGather(d_i64, d_i64 + 1, 1, ncclInt64, comm, cs));
+    std::vector<int64_t> counts(nranks);
+    HIP_TRY(hipMemcpyAsync(counts.data(), d_i64 + 1, 8 * nranks, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
+    int64_t mx = 1;
+    for (int64_t c : counts) mx = std::max(mx, c);
+    RC_TRY(ensure_i64(mx * (nranks + 1)));
+    if (cnt) HIP_TRY(hipMemcpyAsync(d_i64, mine.data(), 8 * cnt, hipMemcpyHostToDevice, cs));
+    NCCL_TRY(api->AllGather(d_i64, d_i64 + mx, (size_t)mx, ncclInt64, comm, cs));
+    std::vector<int64_t> flat((size_t)mx * nranks);
+    HIP_TRY(hipMemcpyAsync(flat.data(), d_i64 + mx, 8 * mx * nranks, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
+    all.assign(nranks, {});
+    for (int p = 0; p < nranks; ++p) all[p].assign(flat.begin() + (size_t)p * mx, flat.begin() + (size_t)p * mx + counts[p]);
+    return AMGH_OK;
+  }
+  int exchange_begin(const double* sendbuf, const std::vector<PeerSpan>& send, double* recvbuf,
+                     const std::vector<PeerSpan>& recv, hipStream_t st) override {
+    HIP_TRY(hipEventRecord(ev_ready, st));
+    HIP_TRY(hipStreamWaitEvent(cs, ev_ready, 0));
+    NCCL_TRY(api->GroupStart());
+    for (int p = 0; p < nranks; ++p) {
+      if (p == rank) continue;
+      if (send[p].cnt > 0) NCCL_TRY(api->Send(sendbuf + send[p].off, (size_t)send[p].cnt, ncclDouble, p, comm, cs));
+      if (recv[p].cnt > 0) NCCL_TRY(api->Recv(recvbuf + recv[p].off, (size_t)recv[p].cnt, ncclDouble, p, comm, cs));
+    }
+    NCCL_TRY(api->GroupEnd());
+    HIP_TRY(hipEventRecord(ev_done, cs));
+    return AMGH_OK;
+  }
+  int exchange_finish(hipStream_t st) override {
+    HIP_TRY(hipStreamWaitEvent(st, ev_done, 0));
+    return AMGH_OK;
+  }
+  int allreduce(double* v, int n, bool max_op) override {
+    if (n > 64) return AMGH_EINVAL;
+    HIP_TRY(hipMemcpyAsync(d_scal, v, 8 * n, hipMemcpyHostToDevice, cs));
+    NCCL_TRY(api->AllReduce(d_scal, d_scal, (size_t)n, ncclDouble, max_op ? ncclMax : ncclSum, comm, cs));
+    HIP_TRY(hipMemcpyAsync(v, d_scal, 8 * n, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipStreamSynchronize(cs));
+    return AMGH_OK;
+  }
+  int barrier() override {
+    double z = 0.0;
+    return allreduce(&z, 1, false);
+  }
+};
+
+}  // namespace
+
+// N ranks of one process: a rendezvous area shared by their handles
+struct amgh_local_group {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  bool broken = false;
+  // published per rank for the current collective
+  std::vector<const double*> sendbuf;
+  std::vector<const std::vector<PeerSpan>*> sendspans;
+  std::vector<int> device;
+  std::vector<const std::vector<int64_t>*> lists;
+  std::vector<std::vector<double>> vals;
+  // returns false when the group was aborted (a rank failed): nobody hangs
+  bool wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
+    const uint64_t g = gen;
+    if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); return true; }
+    cv.wait(lk, [&] { return gen != g || broken; });
+    return !broken;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(mu);
+    broken = true;
+    cv.notify_all();
+  }
+};
+
+namespace {
+
+struct LocalTransport : Transport {
+  amgh_local_group* g = nullptr;
+  int device = 0;
+  int allgatherv_host(const std::vector<int64_t>& mine, std::vector<std::vector<int64_t>>& all) override {
+    g->lists[rank] = &mine;
+    if (!g->wait()) return AMGH_ESTATE;
+    all.assign(nranks, {});
+    for (int p = 0; p < nranks; ++p) all[p] = *g->lists[p];
+    if (!g->wait()) return AMGH_ESTATE;
+    return AMGH_OK;
+  }
+  int exchange_begin(const double* sendbuf, const std::vector<PeerSpan>& send, double* recvbuf,
+                     const std::vector<PeerSpan>& recv, hipStream_t st) override {
+    if (hipStreamSynchronize(st) != hipSuccess) { g->abort(); return AMGH_ESTATE; }  // my packed entries are complete
+    g->sendbuf[rank] = sendbuf;
+    g->sendspans[rank] = &send;
+    g->device[rank] = device;
+    if (!g->wait()) return AMGH_ESTATE;
+    for (int p = 0; p < nranks; ++p) {
+      if (p == rank || recv[p].cnt <= 0) continue;
+      const PeerSpan& sp = (*g->sendspans[p])[rank];
+      if (sp.cnt != recv[p].cnt) { g->abort(); return AMGH_ESTATE; }
+      const double* src = g->sendbuf[p] + sp.off;
+      hipError_t e = g->device[p] == device
+                         ? hipMemcpyAsync(recvbuf + recv[p].off, src, 8 * sp.cnt, hipMemcpyDeviceToDevice, st)
+                         : hipMemcpyPeerAsync(recvbuf + recv[p].off, device, src, g->device[p], 8 * sp.cnt, st);
+      if (e != hipSuccess) { g->abort(); return -(1000 + (int)e); }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) { g->abort(); return AMGH_ESTATE; }
+    if (!g->wait()) return AMGH_ESTATE;  // nobody repacks a send buffer a peer is still reading
+    return AMGH_OK;
+  }
+  int exchange_finish(hipStream_t) override { return AMGH_OK; }
+  int allreduce(double* v, int n, bool max_op) override {
+    g->vals[rank].assign(v, v + n);
+    if (!g->wait()) return AMGH_ESTATE;
+    for (int i = 0; i < n; ++i) {
+      double acc = g->vals[0][i];  // rank order: every rank computes the same bits
+      for (int p = 1; p < nranks; ++p) acc = max_op ? std::max(acc, g->vals[p][i]) : acc + g->vals[p][i];
+      v[i] = acc;
+    }
+    if (!g->wait()) return AMGH_ESTATE;
+    return AMGH_OK;
+  }
+  int barrier() override { return g->wait() ? AMGH_OK : AMGH_ESTATE; }
+};
+
+// ---- halo plan of one distributed vector -------------------------------------------------------------------------
+struct VecPlan {
+  int64_t r0 = 0, r1 = 0;            // my rows of the vector
+  std::vector<int64_t> halo;         // sorted unique global indices outside [r0, r1) this rank reads
+  std::vector<PeerSpan> recv;        // per peer: where its entries sit in the halo region (offsets relative to the halo)
+  std::vector<PeerSpan> send;        // per peer: span of the packed send buffer
+  int32_t* d_send_idx = nullptr;     // local indices gathered into the send buffer (all peers back to back)
+  int64_t nsend = 0;
+  double* d_sendbuf = nullptr;
+  bool any = false;                  // any rank moves anything (same decision everywhere)
+  int64_t nloc() const { return r1 - r0; }
+  int64_t nhalo() const { return (int64_t)halo.size(); }
+  void free_dev() { hipFree(d_send_idx); hipFree(d_sendbuf); d_send_idx = nullptr; d_sendbuf = nullptr; }
+};
+
+// one local operator block: rows = my rows, columns = [my entries of the input vector | its halo]
+struct DistOp {
+  amgh_csr op;
+  bool present = false;
+  int32_t i0 = 0, i1 = 0;  // rows [i0, i1) read no halo column (interior): they can run while the halo is in flight
+};
+
+struct HostBlock {  // local rows with GLOBAL column indices, kept until finalize
+  std::vector<int32_t> rowptr, col;
+  std::vector<double> val;
+  int64_t nrows = 0;
+  bool present = false;
+};
+
+struct DistLevel {
+  int64_t n_glob = 0, nc_glob = 0;
+  std::vector<int64_t> cuts, ccuts;   // row partition of this level / of the next one
+  HostBlock hA, hS, hP, hR;
+  DistOp A, S, P, R;
+  amgh_smoother_t pre{}, post{};
+  double *x = nullptr, *b = nullptr, *res = nullptr, *tmp = nullptr;  // x: [local | halo], res: [local | halo of R's input]
+  VecPlan rplan;                       // halo plan of res (read by R)
+  DistOp* smat() { return S.present ? &S : &A; }
+};
+
+void sort_unique(std::vector<int64_t>& v) {
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
+}  // namespace
+
+struct amgh_dist {
+  int device = 0;
+  Transport* tr = nullptr;
+  hipStream_t stream = nullptr;
+  std::vector<DistLevel*> levels;
+  std::vector<VecPlan> xplan;          // one per sharded level + one for the first collapsed level (read by the last P)
+  double *xt = nullptr, *bt = nullptr; // vectors of the first collapsed level: [all of it on the owner | halo elsewhere]
+  amgh_t* tail = nullptr;              // the collapsed levels (on the rank that owns them), not owned
+  bool finalized = false;
+  double *partial = nullptr, *scal = nullptr;
+  int64_t ex_count = 0, ex_bytes = 0;  // halo exchanges / bytes sent by this rank since the last reset
+  int overlap = 1;
+};
+
+namespace {
+
+int plan_build(amgh_dist* d, VecPlan& pl, const std::vector<int64_t>& cuts, std::vector<int64_t> needs) {
+  Transport* tr = d->tr;
+  const int N = tr->nranks, me = tr->rank;
+  pl.r0 = cuts[me]; pl.r1 = cuts[me + 1];
+  sort_unique(needs);
+  pl.halo = needs;
+  for (int64_t g : pl.halo)
+    if (g >= pl.r0 && g < pl.r1) DIST_EINVAL("halo entry inside the local range");
+  pl.recv.assign(N, PeerSpan());
+  pl.send.assign(N, PeerSpan());
+  {  // halo entries are sorted, owners are contiguous ranges: one span per owner
+    int64_t pos = 0;
+    for (int p = 0; p < N; ++p) {
+      const int64_t lo = pos;
+      while (pos < (int64_t)pl.halo.size() && pl.halo[pos] < cuts[p + 1]) ++pos;
+      pl.recv[p].off = lo;
+      pl.recv[p].cnt = pos - lo;
+    }
+    if (pos != (int64_t)pl.halo.size()) DIST_EINVAL("column index beyond the vector");
+  }
+  std::vector<std::vector<int64_t>> all;
+  RC_TRY(tr->allgatherv_host(pl.halo, all));
+  std::vector<int32_t> send_idx;
+  pl.any = false;
+  for (int p = 0; p < N; ++p) {
+    pl.any = pl.any || !all[p].empty();
+    pl.send[p].off = (int64_t)send_idx.size();
+    if (p != me)
+      for (int64_t g : all[p])
+        if (g >= pl.r0 && g < pl.r1) send_idx.push_back((int32_t)(g - pl.r0));
+    pl.send[p].cnt = (int64_t)send_idx.size() - pl.send[p].off;
+  }
+  pl.nsend = (int64_t)send_idx.size();
+  RC_TRY(dev_upload(&pl.d_send_idx, send_idx.data(), pl.nsend));
+  RC_TRY(dev_alloc(&pl.d_sendbuf, pl.nsend));
+  return AMGH_OK;
+}
+
+// global column -> position in [local | halo]
+inline int32_t plan_localize(const VecPlan& pl, int64_t g) {
+  if (g >= pl.r0 && g < pl.r1) return (int32_t)(g - pl.r0);
+  const auto it = std::lower_bound(pl.halo.begin(), pl.halo.end(), g);
+  return (int32_t)(pl.nloc() + (it - pl.halo.begin()));
+}
+
+void block_needs(const HostBlock& hb, int64_t c0, int64_t c1, std::vector<int64_t>& needs) {
+  if (!hb.present) return;
+  for (int32_t c : hb.col)
+    if (c < c0 || c >= c1) needs.push_back(c);
+}
+
+int block_upload(amgh_dist* d, DistOp& dop, HostBlock& hb, const VecPlan& pl) {
+  if (!hb.present) return AMGH_OK;
+  const int64_t n = hb.nrows;
+  std::vector<int32_t> lc(hb.col.size());
+  const int64_t nloc = pl.nloc();
+  for (size_t k = 0; k < hb.col.size(); ++k) lc[k] = plan_localize(pl, hb.col[k]);
+  // interior rows: the longest middle range of rows without a halo column
+  int32_t i0 = 0, i1 = (int32_t)n;
+  const int64_t half = n / 2;
+  for (int64_t i = 0; i < n; ++i) {
+    bool halo = false;
+    for (int32_t j = hb.rowptr[i]; j < hb.rowptr[i + 1] && !halo; ++j) halo = lc[j] >= nloc;
+    if (!halo) continue;
+    if (i < half) i0 = (int32_t)i + 1;
+    else { i1 = (int32_t)i; break; }
+  }
+  dop.i0 = std::min(i0, i1); dop.i1 = i1;
+  RC_TRY(csr_upload(&dop.op, d->device, n, nloc + pl.nhalo(), hb.rowptr.data(), lc.data(), hb.val.data()));
+  dop.present = true;
+  hb = HostBlock();
+  return AMGH_OK;
+}
+
+int take_block(HostBlock& hb, int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val) {
+  if (!rowptr) return AMGH_OK;
+  if (rowptr[0] != 0) return AMGH_EINVAL;
+  const int64_t nnz = rowptr[nrows];
+  if (nnz < 0 || (nnz > 0 && (!col || !val))) return AMGH_EINVAL;
+  hb.nrows = nrows;
+  hb.rowptr.assign(rowptr, rowptr + nrows + 1);
+  hb.col.assign(col, col + nnz);
+  hb.val.assign(val, val + nnz);
+  hb.present = true;
+  return AMGH_OK;
+}
+
+// ---- data path ---------------------------------------------------------------------------------------------------
+int halo_begin(amgh_dist* d, VecPlan& pl, double* vec) {
+  if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
+  if (pl.nsend > 0) {
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(pl.nsend)), dim3(256), 0, d->stream, (const double*)vec,
+                       (const int32_t*)pl.d_send_idx, pl.d_sendbuf, (int)pl.nsend, (int64_t)0, (int64_t)0);
+    HIP_TRY(hipGetLastError());
+  }
+  ++d->ex_count;
+  d->ex_bytes += 8 * pl.nsend;
+  return d->tr->exchange_begin(pl.d_sendbuf, pl.send, vec + pl.nloc(), pl.recv, d->stream);
+}
+int halo_finish(amgh_dist* d, VecPlan& pl) {
+  if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
+  return d->tr->exchange_finish(d->stream);
+}
+int halo_exchange(amgh_dist* d, VecPlan& pl, double* vec) {
+  RC_TRY(halo_begin(d, pl, vec));
+  return halo_finish(d, pl);
+}
+
+int rows_apply(const amgh_csr* op, int mode, const double* x, const double* b, double* y, double omega, int32_t ra,
+               int32_t rb, hipStream_t st) {
+  if (rb <= ra) return AMGH_OK;
+  StreamArgs a{};
+  a.rowptr = op->rowptr; a.col = op->col; a.val = op->val;
+  a.x = x; a.y = y; a.b = b; a.dpos = op->dpos; a.diag = op->diag; a.omega = omega;
+  a.row_begin = ra; a.row_end = rb;
+  a.ldx = op->ncols; a.ldy = op->nrows; a.ldb = op->nrows;
+  switch (mode) {
+    case M_SPMV: return launch_stream<M_SPMV>(a, st);
+    case M_RESID: return launch_stream<M_RESID>(a, st);
+    case M_ADD: return launch_stream<M_ADD>(a, st);
+    case M_JACOBI: return launch_stream<M_JACOBI>(a, st);
+  }
+  return AMGH_EINVAL;
+}
+
+// y = op(vec) with the halo of vec exchanged first; interior rows run while the halo is in flight when the transport
+// is asynchronous and the block is big enough for three launches to pay
+int dist_apply(amgh_dist* d, DistOp& dop, int mode, VecPlan& pl, double* vec, const double* b, double* y, double omega,
+               bool skip_exchange = false) {
+  const amgh_csr* op = &dop.op;
+  const int32_t n = (int32_t)op->nrows;
+  if (skip_exchange) return rows_apply(op, mode, vec, b, y, omega, 0, n, d->stream);
+  const bool split = d->overlap && d->tr->async() && pl.any && d->tr->nranks > 1 && (dop.i1 - dop.i0) >= 65536;
+  RC_TRY(halo_begin(d, pl, vec));
+  if (split) {
+    RC_TRY(rows_apply(op, mode, vec, b, y, omega, dop.i0, dop.i1, d->stream));
+    RC_TRY(halo_finish(d, pl));
+    RC_TRY(rows_apply(op, mode, vec, b, y, omega, 0, dop.i0, d->stream));
+    return rows_apply(op, mode, vec, b, y, omega, dop.i1, n, d->stream);
+  }
+  RC_TRY(halo_finish(d, pl));
+  return rows_apply(op, mode, vec, b, y, omega, 0, n, d->stream);
+}
+
+// smooth!(x, smoother, b) on a sharded level.  xzero: x (local part and halo) is zero on every rank, the first exchange
+// would move zeros.  b_kept: the previous smooth! call of this cycle swept the same b with Gauss-Seidel / SOR.
+int dist_smooth(amgh_dist* d, int l, const amgh_smoother_t& s, bool xzero, bool* b_kept) {
+  DistLevel* L = d->levels[l];
+  VecPlan& pl = d->xplan[l];
+  DistOp* M = L->smat();
+  const int64_t n = pl.nloc();
+  bool fresh = xzero;
+  for (int it = 0; it < s.iter; ++it) {
+    if (s.kind == AMGH_SMOOTH_JACOBI) {
+      if (n > 0) RC_TRY(csr_ensure_diag(&M->op, d->stream));
+      RC_TRY(dist_apply(d, *M, M_JACOBI, pl, L->x, L->b, L->tmp, s.omega, fresh));
+      fresh = false;
+      if (n > 0) HIP_TRY(hipMemcpyAsync(L->x, L->tmp, 8 * n, hipMemcpyDeviceToDevice, d->stream));
+    } else if (s.kind == AMGH_SMOOTH_GS || s.kind == AMGH_SMOOTH_SOR) {
+      const bool sor = s.kind == AMGH_SMOOTH_SOR;
+      for (int dir = 0; dir < 2; ++dir) {
+        const bool run = dir == 0 ? (s.sweep == AMGH_SWEEP_FORWARD || s.sweep == AMGH_SWEEP_SYMMETRIC)
+                                  : (s.sweep == AMGH_SWEEP_BACKWARD || s.sweep == AMGH_SWEEP_SYMMETRIC);
+        if (!run) continue;
+        if (!fresh) RC_TRY(halo_exchange(d, pl, L->x));
+        fresh = false;
+        if (n > 0)
+          RC_TRY(csr_gs_sweep(&M->op, dir == 1, sor, s.omega, L->x, L->b, d->stream, true, true, 1, false, *b_kept));
+        *b_kept = true;
+      }
+    } else if (s.kind != AMGH_SMOOTH_NONE) {
+      return AMGH_EINVAL;
+    }
+  }
+  if (!((s.kind == AMGH_SMOOTH_GS || s.kind == AMGH_SMOOTH_SOR) && s.iter > 0)) *b_kept = false;
+  return AMGH_OK;
+}
+
+int dist_cycle(amgh_dist* d, int l, int cyc, bool xzero);
+
+int dist_cycle_next(amgh_dist* d, int l, int cyc) {  // __solve_next! (multilevel.jl:200-212)
+  RC_TRY(dist_cycle(d, l, cyc, true));
+  if (cyc == AMGH_CYCLE_W) return dist_cycle(d, l, AMGH_CYCLE_W, false);
+  if (cyc == AMGH_CYCLE_F) return dist_cycle(d, l, AMGH_CYCLE_V, false);
+  return AMGH_OK;
+}
+
+// __solve! (multilevel.jl:214-239) on level l of the sharded hierarchy
+int dist_cycle(amgh_dist* d, int l, int cyc, bool xzero) {
+  const int lc = (int)d->levels.size();
+  if (l == lc) {  // the collapsed levels: single-GPU cycle on their owner, nothing elsewhere
+    if (!d->tail) return AMGH_OK;
+    if (d->tail->levels.empty()) return coarse_solve(d->tail, d->xt, d->bt);
+    return cycle(d->tail, 0, d->xt, d->bt, cyc, xzero);
+  }
+  DistLevel* L = d->levels[l];
+  VecPlan& xp = d->xplan[l];
+  VecPlan& xpc = d->xplan[l + 1];
+  double* xc = l + 1 == lc ? d->xt : d->levels[l + 1]->x;
+  double* bc = l + 1 == lc ? d->bt : d->levels[l + 1]->b;
+  bool b_kept = false;
+  RC_TRY(dist_smooth(d, l, L->pre, xzero, &b_kept));
+  RC_TRY(dist_apply(d, L->A, M_RESID, xp, L->x, L->b, L->res, 0.0));                                // res = b - A x
+  RC_TRY(dist_apply(d, L->R, M_SPMV, L->rplan, L->res, nullptr, bc, 0.0));                          // b_c = R res
+  const int64_t ncx = xpc.nloc() + xpc.nhalo();
+  if (ncx > 0) HIP_TRY(hipMemsetAsync(xc, 0, 8 * ncx, d->stream));                                  // coarse_x .= 0
+  RC_TRY(dist_cycle_next(d, l + 1, cyc));
+  RC_TRY(dist_apply(d, L->P, M_ADD, xpc, xc, nullptr, L->x, 0.0));                                   // x += P x_c
+  RC_TRY(dist_smooth(d, l, L->post, false, &b_kept));
+  return AMGH_OK;
+}
+
+int dist_apply_cycle(amgh_dist* d, int cyc, bool xzero) {
+  if (d->levels.empty()) {
+    if (!d->tail) return AMGH_OK;
+    if (d->tail->levels.empty()) return coarse_solve(d->tail, d->xt, d->bt);
+    return cycle(d->tail, 0, d->xt, d->bt, cyc, xzero);
+  }
+  return dist_cycle(d, 0, cyc, xzero);
+}
+
+double* dist_x0(amgh_dist* d) { return d->levels.empty() ? d->xt : d->levels[0]->x; }
+double* dist_b0(amgh_dist* d) { return d->levels.empty() ? d->bt : d->levels[0]->b; }
+
+// sum over all ranks of x . y over the local entries (host result, same bits on every rank)
+int dist_dot(amgh_dist* d, const double* x, const double* y, int64_t n, double* out) {
+  double v = 0.0;
+  if (n > 0) {
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kThreads - 1) / kThreads));
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, d->stream, x, y, n, d->partial);
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, d->stream, d->partial, nb, d->scal, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&v, d->scal, 8, hipMemcpyDeviceToHost, d->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  RC_TRY(d->tr->allreduce(&v, 1, false));
+  *out = v;
+  return AMGH_OK;
+}
+
+// || b - A x || over all ranks (multilevel.jl:188-190); res of level 0 is the scratch, as in the reference
+int dist_resnorm(amgh_dist* d, double* out) {
+  double s = 0.0;
+  if (d->levels.empty()) {
+    double v = 0.0;
+    if (d->tail) {
+      amgh_t* h = d->tail;
+      double* res = h->levels.empty() ? h->res_final : h->levels[0]->res;
+      RC_TRY(fine_residual(h, d->xt, d->bt, res));
+      RC_TRY(vec_dot(h, res, res, fine_n(h), h->scal, 0));
+      HIP_TRY(hipMemcpyAsync(&v, h->scal, 8, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    RC_TRY(d->tr->allreduce(&v, 1, false));
+    s = v;
+  } else {
+    DistLevel* L = d->levels[0];
+    RC_TRY(dist_apply(d, L->A, M_RESID, d->xplan[0], L->x, L->b, L->res, 0.0));
+    RC_TRY(dist_dot(d, L->res, L->res, d->xplan[0].nloc(), &s));
+  }
+  *out = std::sqrt(s);
+  return AMGH_OK;
+}
+
+int dist_check(const amgh_dist* d) {
+  if (!d) return AMGH_EINVAL;
+  if (!d->finalized) return AMGH_ESTATE;
+  return AMGH_OK;
+}
+
+void dist_free(amgh_dist* d) {
+  for (DistLevel* L : d->levels) {
+    for (DistOp* o : {&L->A, &L->S, &L->P, &L->R}) csr_free(&o->op);
+    hipFree(L->x); hipFree(L->b); hipFree(L->res); hipFree(L->tmp);
+    L->rplan.free_dev();
+    delete L;
+  }
+  d->levels.clear();
+  for (VecPlan& p : d->xplan) p.free_dev();
+  hipFree(d->xt); hipFree(d->bt); hipFree(d->partial); hipFree(d->scal);
+  if (d->stream) hipStreamDestroy(d->stream);
+  delete d->tr;
+  delete d;
+}
+
+int dist_new(amgh_dist** dp, int device, Transport* tr) {
+  amgh_dist* d = new amgh_dist;
+  d->device = device;
+  d->tr = tr;
+  hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete tr; delete d; return -(1000 + (int)e); }
+  if (const char* ev = getenv("AMGH_DIST_OVERLAP")) d->overlap = atoi(ev);
+  *dp = d;
+  return AMGH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amgh_dist_rccl_available(void) { return rccl_api() ? 1 : 0; }
+
+int amgh_dist_unique_id(void* id128) {
+  if (!id128) return AMGH_EINVAL;
+  RcclApi* api = rccl_api();
+  if (!api) return AMGH_EUNSUPPORTED;
+  ncclUniqueId uid;
+  NCCL_TRY(api->GetUniqueId(&uid));
+  std::memcpy(id128, &uid, sizeof uid);
+  return AMGH_OK;
+}
+
+int amgh_dist_create_rccl(amgh_dist_t** dp, int device, int rank, int nranks, const void* id128) {
+  if (!dp || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return AMGH_EINVAL;
+  *dp = nullptr;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(device));
+  RcclTransport* tr = new RcclTransport;
+  int rc = tr->init(id128, rank, nranks);
+  if (rc != AMGH_OK) { delete tr; return rc; }
+  return dist_new(dp, device, tr);
+}
+
+int amgh_local_group_create(amgh_local_group_t** gp, int nranks) {
+  if (!gp || nranks < 1 || nranks > 1024) return AMGH_EINVAL;
+  amgh_local_group* g = new amgh_local_group;
+  g->n = nranks;
+  g->sendbuf.assign(nranks, nullptr);
+  g->sendspans.assign(nranks, nullptr);
+  g->device.assign(nranks, 0);
+  g->lists.assign(nranks, nullptr);
+  g->vals.assign(nranks, {});
+  *gp = g;
+  return AMGH_OK;
+}
+void amgh_local_group_destroy(amgh_local_group_t* g) { delete g; }
+void amgh_local_group_abort(amgh_local_group_t* g) { if (g) g->abort(); }
+
+int amgh_dist_create_local(amgh_dist_t** dp, int device, int rank, amgh_local_group_t* g) {
+  if (!dp || !g || rank < 0 || rank >= g->n) return AMGH_EINVAL;
+  *dp = nullptr;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(device));
+  LocalTransport* tr = new LocalTransport;
+  tr->g = g; tr->rank = rank; tr->nranks = g->n; tr->device = device;
+  return dist_new(dp, device, tr);
+}
+
+void amgh_dist_destroy(amgh_dist_t* d) {
+  if (!d) return;
+  hipSetDevice(d->device);
+  if (d->stream) hipStreamSynchronize(d->stream);
+  if (d->tail && d->tail->stream == d->stream) {  // the borrowed tail goes back to its own stream (ours is about to die)
+    d->tail->stream = d->tail->own_stream;
+    d->tail->own_stream = nullptr;
+    d->tail->ext_stream = false;
+  }
+  dist_free(d);
+}
+
+int amgh_dist_push_level(amgh_dist_t* d, int64_t n_global, int64_t nc_global, const int64_t* row_cuts,
+                         const int64_t* crow_cuts, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
+                         const int32_t* S_rowptr, const int32_t* S_col, const double* S_val, const int32_t* P_rowptr,
+                         const int32_t* P_col, const double* P_val, const int32_t* R_rowptr, const int32_t* R_col,
+                         const double* R_val, const amgh_smoother_t* pre, const amgh_smoother_t* post) {
+  if (!d || !row_cuts || !crow_cuts || !A_rowptr || !P_rowptr || !R_rowptr || n_global <= 0 || nc_global < 0)
+    return AMGH_EINVAL;
+  if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
+  if (d->finalized) return AMGH_ESTATE;
+  if (n_global >= INT32_MAX || nc_global >= INT32_MAX) return AMGH_EUNSUPPORTED;
+  const int N = d->tr->nranks, me = d->tr->rank;
+  if (row_cuts[0] != 0 || row_cuts[N] != n_global || crow_cuts[0] != 0 || crow_cuts[N] != nc_global)
+    DIST_EINVAL("row_cuts / crow_cuts do not span the level");
+  for (int p = 0; p < N; ++p)
+    if (row_cuts[p] > row_cuts[p + 1] || crow_cuts[p] > crow_cuts[p + 1]) return AMGH_EINVAL;
+  if (!d->levels.empty()) {
+    const DistLevel* prev = d->levels.back();
+    if (prev->nc_glob != n_global) return AMGH_EINVAL;
+    for (int p = 0; p <= N; ++p)
+      if (prev->ccuts[p] != row_cuts[p]) return AMGH_EINVAL;
+  }
+  DistLevel* L = new DistLevel;
+  L->n_glob = n_global; L->nc_glob = nc_global;
+  L->cuts.assign(row_cuts, row_cuts + N + 1);
+  L->ccuts.assign(crow_cuts, crow_cuts + N + 1);
+  L->pre = *pre; L->post = *post;
+  const int64_t nloc = row_cuts[me + 1] - row_cuts[me], ncloc = crow_cuts[me + 1] - crow_cuts[me];
+  int rc = take_block(L->hA, nloc, A_rowptr, A_col, A_val);
+  if (rc == AMGH_OK) rc = take_block(L->hS, nloc, S_rowptr, S_col, S_val);
+  if (rc == AMGH_OK) rc = take_block(L->hP, nloc, P_rowptr, P_col, P_val);
+  if (rc == AMGH_OK) rc = take_block(L->hR, ncloc, R_rowptr, R_col, R_val);
+  if (rc != AMGH_OK) { delete L; return rc; }
+  d->levels.push_back(L);
+  return AMGH_OK;
+}
+
+int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail) {
+  if (!d) return AMGH_EINVAL;
+  if (d->finalized) return AMGH_ESTATE;
+  if (tail && (!tail->finalized || tail->nrhs != 1 || tail->device != d->device)) return AMGH_EINVAL;
+  d->tail = tail;
+  return AMGH_OK;
+}
+
+// Collective: every rank calls it after the same sequence of amgh_dist_push_level calls.
+int amgh_dist_finalize(amgh_dist_t* d) {
+  if (!d) return AMGH_EINVAL;
+  if (d->finalized) return AMGH_ESTATE;
+  HIP_TRY(hipSetDevice(d->device));
+  Transport* tr = d->tr;
+  const int N = tr->nranks, me = tr->rank, lc = (int)d->levels.size();
+  // the first collapsed level: all rows on one rank (crow_cuts of the last sharded level says which); with no sharded
+  // level at all the owner is the rank that holds the tail
+  std::vector<int64_t> tcuts;
+  if (lc > 0) tcuts = d->levels.back()->ccuts;
+  else {
+    double nt = d->tail ? (double)fine_n(d->tail) : 0.0;
+    std::vector<double> v(N, 0.0);
+    v[me] = nt;
+    RC_TRY(tr->allreduce(v.data(), N, false));
+    tcuts.assign(N + 1, 0);
+    for (int p = 0; p < N; ++p) tcuts[p + 1] = tcuts[p] + (int64_t)v[p];
+  }
+  {
+    const int64_t nt = tcuts[me + 1] - tcuts[me];
+    const bool owner_ok = nt == 0 ? true : (d->tail && fine_n(d->tail) == nt && nt == tcuts[N]);
+    double bad = owner_ok ? 0.0 : 1.0;
+    RC_TRY(tr->allreduce(&bad, 1, true));
+    if (bad != 0.0) DIST_EINVAL("the collapsed levels must live on exactly one rank, which passes the tail");
+  }
+  // halo plans: x_l is read by A_l, S_l and by P_{l-1}; res_l by R_l
+  d->xplan.assign(lc + 1, VecPlan());
+  for (int l = 0; l <= lc; ++l) {
+    const std::vector<int64_t>& cuts = l < lc ? d->levels[l]->cuts : tcuts;
+    std::vector<int64_t> needs;
+    if (l < lc) {
+      block_needs(d->levels[l]->hA, cuts[me], cuts[me + 1], needs);
+      block_needs(d->levels[l]->hS, cuts[me], cuts[me + 1], needs);
+    }
+    if (l >= 1) block_needs(d->levels[l - 1]->hP, cuts[me], cuts[me + 1], needs);
+    RC_TRY(plan_build(d, d->xplan[l], cuts, std::move(needs)));
+    if (l < lc) {
+      std::vector<int64_t> rneeds;
+      block_needs(d->levels[l]->hR, cuts[me], cuts[me + 1], rneeds);
+      RC_TRY(plan_build(d, d->levels[l]->rplan, cuts, std::move(rneeds)));
+    }
+  }
+  for (int l = 0; l < lc; ++l) {
+    DistLevel* L = d->levels[l];
+    VecPlan& xp = d->xplan[l];
+    RC_TRY(block_upload(d, L->A, L->hA, xp));
+    RC_TRY(block_upload(d, L->S, L->hS, xp));
+    RC_TRY(block_upload(d, L->P, L->hP, d->xplan[l + 1]));
+    RC_TRY(block_upload(d, L->R, L->hR, L->rplan));
+    const int64_t nloc = xp.nloc();
+    RC_TRY(dev_alloc(&L->x, nloc + xp.nhalo()));
+    RC_TRY(dev_alloc(&L->b, nloc));
+    RC_TRY(dev_alloc(&L->res, nloc + L->rplan.nhalo()));
+    RC_TRY(dev_alloc(&L->tmp, nloc));
+    HIP_TRY(hipMemset(L->x, 0, 8 * std::max<int64_t>(1, nloc + xp.nhalo())));
+    HIP_TRY(hipMemset(L->res, 0, 8 * std::max<int64_t>(1, nloc + L->rplan.nhalo())));
+    // smoother metadata now, not inside the first timed cycle
+    const bool jac = L->pre.kind == AMGH_SMOOTH_JACOBI || L->post.kind == AMGH_SMOOTH_JACOBI;
+    const bool gs = L->pre.kind == AMGH_SMOOTH_GS || L->pre.kind == AMGH_SMOOTH_SOR || L->post.kind == AMGH_SMOOTH_GS ||
+                    L->post.kind == AMGH_SMOOTH_SOR;
+    amgh_csr* M = &L->smat()->op;
+    if (nloc > 0 && jac) RC_TRY(csr_ensure_diag(M, d->stream));
+    if (nloc > 0 && gs) RC_TRY(csr_ensure_gs(M));
+  }
+  {
+    VecPlan& tp = d->xplan[lc];
+    RC_TRY(dev_alloc(&d->xt, tp.nloc() + tp.nhalo()));
+    RC_TRY(dev_alloc(&d->bt, tp.nloc()));
+    HIP_TRY(hipMemset(d->xt, 0, 8 * std::max<int64_t>(1, tp.nloc() + tp.nhalo())));
+  }
+  if (d->tail) {  // the collapsed levels enqueue on this handle's stream
+    d->tail->ext_stream = true;
+    d->tail->own_stream = d->tail->own_stream ? d->tail->own_stream : d->tail->stream;
+    d->tail->stream = d->stream;
+  }
+  RC_TRY(dev_alloc(&d->partial, kRedBlocks));
+  RC_TRY(dev_alloc(&d->scal, 8));
+  HIP_TRY(hipDeviceSynchronize());
+  RC_TRY(tr->barrier());
+  d->finalized = true;
+  return AMGH_OK;
+}
+
+int amgh_dist_num_sharded_levels(const amgh_dist_t* d) { return d ? (int)d->levels.size() : 0; }
+
+int amgh_dist_local_range(const amgh_dist_t* d, int level, int64_t* r0, int64_t* r1) {
+  if (!d || !d->finalized || level < 0 || level > (int)d->levels.size() || !r0 || !r1) return AMGH_EINVAL;
+  *r0 = d->xplan[level].r0;
+  *r1 = d->xplan[level].r1;
+  return AMGH_OK;
+}
+
+// Halo plan of x on `level` (tests, diagnostics): counts, then optionally the arrays.
+// out_counts: {nloc, nhalo, nsend, interior row begin of A, interior row end of A}
+int amgh_dist_plan_info(const amgh_dist_t* d, int level, int64_t* out_counts, int64_t* halo_globals, int32_t* send_idx,
+                        int64_t* send_cnt_per_peer, int64_t* recv_cnt_per_peer) {
+  if (!d || !d->finalized || level < 0 || level > (int)d->levels.size() || !out_counts) return AMGH_EINVAL;
+  const VecPlan& pl = d->xplan[level];
+  out_counts[0] = pl.nloc(); out_counts[1] = pl.nhalo(); out_counts[2] = pl.nsend;
+  out_counts[3] = level < (int)d->levels.size() ? d->levels[level]->A.i0 : 0;
+  out_counts[4] = level < (int)d->levels.size() ? d->levels[level]->A.i1 : 0;
+  if (halo_globals) std::copy(pl.halo.begin(), pl.halo.end(), halo_globals);
+  if (send_idx && pl.nsend > 0) HIP_TRY(hipMemcpy(send_idx, pl.d_send_idx, 4 * pl.nsend, hipMemcpyDeviceToHost));
+  for (int p = 0; p < d->tr->nranks; ++p) {
+    if (send_cnt_per_peer) send_cnt_per_peer[p] = pl.send[p].cnt;
+    if (recv_cnt_per_peer) recv_cnt_per_peer[p] = pl.recv[p].cnt;
+  }
+  return AMGH_OK;
+}
+
+// ldiv!(x, p, b) on the sharded hierarchy: r_loc_d / z_loc_d hold this rank's rows of level 0 (device pointers).
+// Enqueues on the handle's stream; amgh_dist_sync waits for it.
+int amgh_dist_precond_apply_d(amgh_dist_t* d, const double* r_loc_d, double* z_loc_d, int cycle_) {
+  RC_TRY(dist_check(d));
+  if (cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(d->device));
+  const VecPlan& p0 = d->xplan[0];
+  const int64_t n = p0.nloc();
+  if (n > 0 && (!r_loc_d || !z_loc_d)) return AMGH_EINVAL;
+  if (n > 0) HIP_TRY(hipMemcpyAsync(dist_b0(d), r_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
+  if (n + p0.nhalo() > 0) HIP_TRY(hipMemsetAsync(dist_x0(d), 0, 8 * (n + p0.nhalo()), d->stream));
+  RC_TRY(dist_apply_cycle(d, cycle_, true));
+  if (n > 0) HIP_TRY(hipMemcpyAsync(z_loc_d, dist_x0(d), 8 * n, hipMemcpyDeviceToDevice, d->stream));
+  return AMGH_OK;
+}
+
+// _solve!(x, ml, b, cycle; ...) (multilevel.jl:158-198) on the sharded hierarchy: x_loc_d in/out (initial guess).
+int amgh_dist_solve_d(amgh_dist_t* d, const double* b_loc_d, double* x_loc_d, int cycle_, int maxiter, double abstol,
+                      double reltol, int calculate_residual, double* resid_hist, int* iters) {
+  RC_TRY(dist_check(d));
+  if (cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(d->device));
+  const VecPlan& p0 = d->xplan[0];
+  const int64_t n = p0.nloc();
+  if (n > 0 && (!b_loc_d || !x_loc_d)) return AMGH_EINVAL;
+  if (n > 0) {
+    HIP_TRY(hipMemcpyAsync(dist_b0(d), b_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(dist_x0(d), x_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
+  }
+  double nb2 = 0.0;
+  RC_TRY(dist_dot(d, dist_b0(d), dist_b0(d), n, &nb2));
+  const double normb = std::sqrt(nb2);
+  double normres = normb;
+  if (normb != 0.0) abstol = std::max(reltol * normb, abstol);
+  if (resid_hist) resid_hist[0] = normb;
+  int itr = 1;
+  while (itr <= maxiter && (!calculate_residual || normres > abstol)) {
+    RC_TRY(dist_apply_cycle(d, cycle_, false));
+    if (calculate_residual) {
+      RC_TRY(dist_resnorm(d, &normres));
+      if (resid_hist) resid_hist[itr] = normres;
+    }
+    ++itr;
+  }
+  if (iters) *iters = itr - 1;
+  if (n > 0) HIP_TRY(hipMemcpyAsync(x_loc_d, dist_x0(d), 8 * n, hipMemcpyDeviceToDevice, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return AMGH_OK;
+}
+
+// y_loc = A_level x_loc with the halo exchange in front (roofline hook of the sharded SpMV).  Enqueue only.
+int amgh_dist_spmv_d(amgh_dist_t* d, int level, const double* x_loc_d, double* y_loc_d) {
+  RC_TRY(dist_check(d));
+  if (level < 0 || level >= (int)d->levels.size()) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(d->device));
+  DistLevel* L = d->levels[level];
+  VecPlan& pl = d->xplan[level];
+  const int64_t n = pl.nloc();
+  if (n > 0 && (!x_loc_d || !y_loc_d)) return AMGH_EINVAL;
+  if (n > 0 && x_loc_d != L->x) HIP_TRY(hipMemcpyAsync(L->x, x_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
+  return dist_apply(d, L->A, M_SPMV, pl, L->x, nullptr, n > 0 ? y_loc_d : L->tmp, 0.0);
+}
+
+int amgh_dist_sync(amgh_dist_t* d) {
+  if (!d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return AMGH_OK;
+}
+int amgh_dist_barrier(amgh_dist_t* d) {
+  if (!d) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return d->tr->barrier();
+}
+int amgh_dist_allreduce(amgh_dist_t* d, double* v, int n, int max_op) {
+  if (!d || !v || n < 1 || n > 64) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(d->device));
+  return d->tr->allreduce(v, n, max_op != 0);
+}
+// out: {halo exchanges, bytes this rank sent} since the last reset
+int amgh_dist_stats(amgh_dist_t* d, int64_t* out2, int reset) {
+  if (!d || !out2) return AMGH_EINVAL;
+  out2[0] = d->ex_count; out2[1] = d->ex_bytes;
+  if (reset) d->ex_count = d->ex_bytes = 0;
+  return AMGH_OK;
+}
+int64_t amgh_dist_device_bytes(const amgh_dist_t* d) {
+  if (!d) return 0;
+  int64_t b = 0;
+  for (const DistLevel* L : d->levels) {
+    b += L->A.op.bytes + L->S.op.bytes + L->P.op.bytes + L->R.op.bytes;
+    b += 8 * (3 * (L->cuts[d->tr->rank + 1] - L->cuts[d->tr->rank]));
+  }
+  return b;
+}
+void* amgh_dist_stream(amgh_dist_t* d) { return d ? (void*)d->stream : nullptr; }
+
+}  // extern "C"

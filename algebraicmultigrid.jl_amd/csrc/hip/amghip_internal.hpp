@@ -173,6 +173,10 @@ int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in g
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)
 
+// bumped whenever a schedule buffer that captured hipGraphs may point to is reallocated or freed (xp / bp growth,
+// SOR child eviction): handles drop their cached graph execs when it has moved on
+unsigned long long g_sched_epoch = 0;
+
 unsigned long long* g_chain_tim = nullptr;  // diagnostics buffer (amgh_debug_chain_timing)
 
 constexpr int kChainWidth = 1024;  // dependency levels at most this wide are chained

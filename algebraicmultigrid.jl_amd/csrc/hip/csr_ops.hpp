@@ -149,6 +149,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
   if (g->n <= 0) return AMGH_OK;
   if (ncolv > g->cols_alloc) {  // grow the per-column scratch (first block solve on this operator)
     HIP_TRY(hipStreamSynchronize(st));
+    ++g_sched_epoch;
     hipFree(g->bp); hipFree(g->xp); g->bp = g->xp = nullptr;
     RC_TRY(dev_alloc(&g->bp, g->n * ncolv));
     RC_TRY(dev_alloc(&g->xp, g->xstride * ncolv));
@@ -216,21 +217,20 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     both_dirs = g->mf && g->mb;
   } else if (g_gs_merge > 1 && sor) {
     GsSchedule::SorSet* ss = sor_children(g, omega);
-    if (ss && (backward ? ss->b : ss->f)) {
+    // A merged system needs x and s in ONE vector (xstride = ncols + n).  The re-layout frees g->xp, so it may only
+    // happen while no x lives there: at the first sweep of a smooth! call whose x is still in the caller's vector
+    // (amgh_push_level already did it for the hierarchy's own smoothers).  Otherwise this CALL keeps the unmerged
+    // layout (lay = g) — same iterate, just slower — and the next smooth! call re-lays out.
+    if (ss && (ss->f || ss->b) && g->xstride == g->ncols && first && !x_resident) {
+      HIP_TRY(hipStreamSynchronize(st));
+      RC_TRY(gs_grow_xp_for_merged(g, &op->bytes));
+    }
+    if (ss && (backward ? ss->b : ss->f) && g->xstride > g->ncols) {
       lay = backward ? ss->b : ss->f;
       tri = backward ? &ss->tb : &ss->tf;
       s_key = omega;
       flip_scale = 2.0 - omega;
       both_dirs = ss->f && ss->b;
-      if (g->xstride == g->ncols) {  // first merged system on this operator: x and s share one vector from now on
-        HIP_TRY(hipStreamSynchronize(st));
-        hipFree(g->xp); g->xp = nullptr;
-        g->xstride = g->ncols + g->n;
-        RC_TRY(dev_alloc(&g->xp, g->xstride * g->cols_alloc));
-        g->bytes += 8 * g->n * g->cols_alloc;
-        op->bytes += 8 * g->n * g->cols_alloc;
-        if (!first) return AMGH_ESTATE;  // (cannot happen: the first sweep of a smooth! call builds the children)
-      }
       sor = false;  // the scaled triangular system is swept like Gauss-Seidel
     }
   }

@@ -761,6 +761,19 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   return AMGH_OK;
 }
 
+// x and s of a merged system share one vector [x (ncols) ; s (n)] per column: re-lay out xp the first time an operator
+// gets merged children after its schedule was built (SOR children).  Frees xp: callers guarantee no x lives there.
+int gs_grow_xp_for_merged(GsSchedule* g, int64_t* op_bytes) {
+  if (g->xstride != g->ncols) return AMGH_OK;
+  ++g_sched_epoch;
+  hipFree(g->xp); g->xp = nullptr;
+  g->xstride = g->ncols + g->n;
+  RC_TRY(dev_alloc(&g->xp, g->xstride * g->cols_alloc));
+  g->bytes += 8 * g->n * g->cols_alloc;
+  if (op_bytes) *op_bytes += 8 * g->n * g->cols_alloc;
+  return AMGH_OK;
+}
+
 // Merged children for SOR with relaxation factor omega, built on demand from the level-ordered matrix already on
 // the device.  Returns the cache entry (children may be null: merging did not pay or was rejected).
 GsSchedule::SorSet* sor_children(GsSchedule* g, double omega) {
@@ -768,6 +781,7 @@ GsSchedule::SorSet* sor_children(GsSchedule* g, double omega) {
     if (ss.built && ss.omega == omega) return &ss;
   GsSchedule::SorSet& ss = g->sor[g->sor_next];
   g->sor_next ^= 1;
+  if (ss.f || ss.b) ++g_sched_epoch;  // an evicted set may be referenced by captured graphs
   for (GsSchedule** c : {&ss.f, &ss.b})
     if (*c) { g->bytes -= (*c)->bytes; (*c)->free_dev(); delete *c; *c = nullptr; }
   for (GsSchedule::Tri* t : {&ss.tf, &ss.tb}) { hipFree(t->rowptr); hipFree(t->col); hipFree(t->val); *t = GsSchedule::Tri(); }

@@ -4,10 +4,17 @@ Mirrors Julia's `SparseMatrixCSC` (colptr / rowval / nzval), 0-based int32/f64.
 The arrays are zero-copy numpy views of the C++ object.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
 from ._libs import AMGError, setup_lib
+
+
+# the lazily cached transpose / symmetry flag of a matrix may be asked for by several host threads at once (the ranks
+# of a single-process sharded run): create them once — a second wrapper replacing the first would free the arrays
+# the first caller still holds views of
+_cache_lock = threading.Lock()
 
 
 def _view(ptr, n, dtype):
@@ -47,6 +54,11 @@ class SparseMatrixCSC:
     # ---- construction -----------------------------------------------------
     @classmethod
     def from_arrays(cls, m, n, colptr, rowval, nzval):
+        # indices are int32 on both libraries: refuse what does not fit BEFORE the cast wraps it around
+        i32max = np.iinfo(np.int32).max
+        cp = np.asarray(colptr)
+        if max(int(m), int(n)) >= i32max or (cp.size and int(cp[-1]) > i32max):
+            raise AMGError("matrix too large for int32 indices (rows, columns or stored entries >= 2^31)")
         colptr = np.ascontiguousarray(colptr, dtype=np.int32)
         rowval = np.ascontiguousarray(rowval, dtype=np.int32)
         nzval = np.ascontiguousarray(nzval, dtype=np.float64)
@@ -98,7 +110,9 @@ class SparseMatrixCSC:
     def transpose(self):
         """copy(A')"""
         if self._T is None:
-            self._T = SparseMatrixCSC(setup_lib().amgs_mat_transpose(self._h))
+            with _cache_lock:
+                if self._T is None:
+                    self._T = SparseMatrixCSC(setup_lib().amgs_mat_transpose(self._h))
         return self._T
 
     @property
@@ -108,7 +122,9 @@ class SparseMatrixCSC:
     def is_symmetric(self):
         """True when the CSC arrays equal those of A' (so they are also A's CSR)."""
         if self._sym is None:
-            self._sym = bool(setup_lib().amgs_mat_is_symmetric(self._h))
+            with _cache_lock:
+                if self._sym is None:
+                    self._sym = bool(setup_lib().amgs_mat_is_symmetric(self._h))
         return self._sym
 
     def csr_arrays(self):

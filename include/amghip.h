@@ -19,7 +19,8 @@
  *     stream and the call returns after the stream has been synchronised unless
  *     documented otherwise).
  *   - return 0 on success, <0 on error: -2 bad argument, -3 bad state,
- *     -4 out of memory, -5 unsupported, -(1000+hipError_t) for HIP failures.
+ *     -4 out of memory, -5 unsupported, -(1000+hipError_t) for HIP failures,
+ *     -(2000+ncclResult_t) for RCCL failures (row-sharded entry points).
  *     amgh_strerror(rc) gives text.  No exception crosses the boundary.
  *   - a handle is single-threaded and NOT re-entrant, like the reference's
  *     MultiLevel whose workspace is mutated by every solve (multilevel.jl:23-59).
@@ -222,6 +223,83 @@ int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const double* src
  * reduction; synchronises `stream`.  scratch_d: >= 1025 doubles of device scratch.  */
 int amgh_dot_d(int device, int64_t n, const double* x_d, const double* y_d, double* scratch_d, double* out,
                void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Row-sharded hierarchy: the cycle of multilevel.jl:214-239 over N GPUs         */
+/* (BASELINE.json config C4).  The reference is single-process, so these entry   */
+/* points have no reference counterpart; they keep the SHAPES of the single-GPU  */
+/* ones above (push_level / finalize / precond_apply / solve) so that a Julia    */
+/* shim binds them the same way.  Levels are partitioned by contiguous 1-D row   */
+/* ranges (row_cuts: nranks+1 ascending offsets); before every operator the halo */
+/* entries of its input vector travel by neighbour send/recv (RCCL over xGMI, or  */
+/* peer copies between the handles of one process); levels whose rows all sit on  */
+/* one rank ("collapsed") are an ordinary amgh_t on that rank.  Jacobi, residual, */
+/* restriction, prolongation are exactly the single-GPU arithmetic; Gauss-Seidel  */
+/* / SOR is exact inside a shard with the halo frozen per directional sweep.      */
+/* Errors: as above, plus -(2000 + ncclResult_t) for RCCL failures.               */
+/* ------------------------------------------------------------------------- */
+typedef struct amgh_dist amgh_dist_t;
+typedef struct amgh_local_group amgh_local_group_t;
+#define AMGH_DIST_ID_BYTES 128
+/* RCCL transport (one process per GPU): rank 0 calls amgh_dist_unique_id and hands the 128 bytes to
+ * the other ranks by whatever the host has (MPI, a file, torch.distributed's store);
+ * amgh_dist_create_rccl is collective (ncclCommInitRank).  librccl is loaded on first use:
+ * amgh_dist_rccl_available() == 0 and AMGH_EUNSUPPORTED where it is missing.                       */
+int amgh_dist_rccl_available(void);
+int amgh_dist_unique_id(void* id128);
+int amgh_dist_create_rccl(amgh_dist_t** d, int device, int rank, int nranks, const void* id128);
+/* LOCAL transport: N ranks = N handles of ONE process, each driven by its own host thread (every
+ * collective call below blocks until all N ranks have made it); halo entries move by device-to-device
+ * / peer copies.  Ranks may share a device (virtual ranks on a single-GPU box).  amgh_local_group_abort
+ * releases every rank blocked in a collective (they return AMGH_ESTATE) after one of them failed.     */
+int amgh_local_group_create(amgh_local_group_t** g, int nranks);
+void amgh_local_group_destroy(amgh_local_group_t* g);
+void amgh_local_group_abort(amgh_local_group_t* g);
+int amgh_dist_create_local(amgh_dist_t** d, int device, int rank, amgh_local_group_t* g);
+void amgh_dist_destroy(amgh_dist_t* d);
+/* push!(levels, Level(A, P, R, pre, post)) for one SHARDED level: this rank passes its rows only —
+ * rows [row_cuts[rank], row_cuts[rank+1]) of A (n x n), S (as in amgh_push_level; NULL for S == A)
+ * and P (n x nc), rows [crow_cuts[rank], crow_cuts[rank+1]) of R (nc x n) — as CSR with rowptr
+ * starting at 0 and GLOBAL column indices.  crow_cuts is the row partition of the next level and must
+ * equal the row_cuts of the next push; the level after the last pushed one must sit on ONE rank
+ * (crow_cuts = 0,..,0,nc,..,nc), which passes the collapsed levels to amgh_dist_set_tail.           */
+int amgh_dist_push_level(amgh_dist_t* d, int64_t n_global, int64_t nc_global,
+                         const int64_t* row_cuts, const int64_t* crow_cuts,
+                         const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
+                         const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
+                         const int32_t* P_rowptr, const int32_t* P_col, const double* P_val,
+                         const int32_t* R_rowptr, const int32_t* R_col, const double* R_val,
+                         const amgh_smoother_t* pre, const amgh_smoother_t* post);
+/* The collapsed levels: a finalized single-GPU handle (nrhs = 1, same device) holding levels lc.. and
+ * the coarse solver, on the rank that owns them; NULL elsewhere.  Borrowed, not owned; its stream
+ * becomes the sharded handle's.                                                                      */
+int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail);
+/* Collective.  Exchanges the halo needs, builds the send / receive plans, uploads the local blocks
+ * (columns renumbered to [local | halo]) and builds the smoother schedules of the shards.            */
+int amgh_dist_finalize(amgh_dist_t* d);
+int amgh_dist_num_sharded_levels(const amgh_dist_t* d);
+int amgh_dist_local_range(const amgh_dist_t* d, int level, int64_t* r0, int64_t* r1);
+/* ldiv! / _solve! on this rank's rows of the fine vectors (device pointers; collective).
+ * amgh_dist_precond_apply_d only enqueues (amgh_dist_sync waits); amgh_dist_solve_d returns after
+ * the last iteration; its stopping test uses the global residual norm (identical on every rank).     */
+int amgh_dist_precond_apply_d(amgh_dist_t* d, const double* r_loc_d, double* z_loc_d, int cycle);
+int amgh_dist_solve_d(amgh_dist_t* d, const double* b_loc_d, double* x_loc_d, int cycle, int maxiter,
+                      double abstol, double reltol, int calculate_residual,
+                      double* resid_hist /*host*/, int* iters);
+/* y_loc = A_level x_loc, halo exchange included (roofline hook of the sharded SpMV).  Enqueue only.   */
+int amgh_dist_spmv_d(amgh_dist_t* d, int level, const double* x_loc_d, double* y_loc_d);
+int amgh_dist_sync(amgh_dist_t* d);
+int amgh_dist_barrier(amgh_dist_t* d);                                 /* sync + barrier over the ranks */
+int amgh_dist_allreduce(amgh_dist_t* d, double* v, int n, int max_op); /* host values, sum or max       */
+/* out2 = {halo exchanges, bytes sent by this rank} since the last reset                              */
+int amgh_dist_stats(amgh_dist_t* d, int64_t* out2, int reset);
+int64_t amgh_dist_device_bytes(const amgh_dist_t* d);
+void* amgh_dist_stream(amgh_dist_t* d);
+/* Halo plan of x on `level` (tests): out_counts = {local rows, halo entries, entries sent, first and
+ * end interior row of A}; optional arrays: halo_globals[nhalo], send_idx[nsend] (local indices),
+ * per-peer send / receive counts [nranks].                                                           */
+int amgh_dist_plan_info(const amgh_dist_t* d, int level, int64_t* out_counts, int64_t* halo_globals,
+                        int32_t* send_idx, int64_t* send_cnt_per_peer, int64_t* recv_cnt_per_peer);
 
 /* ------------------------------------------------------------------------- */
 /* Device memory + timing helpers for hosts without a HIP binding of their own  */

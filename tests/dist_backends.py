@@ -117,6 +117,43 @@ class CpuOps:
         return float(r @ r)
 
 
+class OracleOps(CpuOps):
+    """CpuOps with the sweeps done by the oracle's C loops (orc_smooth_arrays) instead of Python loops, so that the
+    host emulation of the sharded cycle also runs at full size.  A shard's block is n_loc x (n_loc + n_halo): it is
+    padded to a square matrix whose halo rows are EMPTY — a row without a diagonal keeps its x (smoother.jl:87), which
+    is exactly "halo frozen during the sweep"."""
+
+    def _square(self, op):
+        if not hasattr(op, "_sq"):
+            n = op.ncols
+            rp = np.concatenate([op.rowptr, np.full(n - op.nrows, op.rowptr[-1], dtype=np.int32)])
+            op._sq = (n, np.ascontiguousarray(rp, dtype=np.int32), op.col, op.val)
+        return op._sq
+
+    def _sweep(self, op, kind, sweep, omega, x, b):
+        import ctypes as C
+        n, rp, ci, va = self._square(op)
+        s = O.orc_smoother_t(kind, sweep, 1, 0, float(omega))
+        xv = x.numpy()
+        bb = np.zeros(n)
+        bb[:op.nrows] = b.numpy()[:op.nrows]
+        assert xv.size >= n
+        rc = O.lib().orc_smooth_arrays(n, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, C.byref(s), 1,
+                                       xv.ctypes.data, bb.ctypes.data)
+        assert rc == 0
+
+    def jacobi(self, op, omega, xin, b, xout):
+        if not op.nrows:
+            return
+        tmp = xin.clone()
+        self._sweep(op, 2, 0, omega, tmp, b)
+        xout[:op.nrows] = tmp[:op.nrows]
+
+    def gs(self, op, backward, omega, sor, x, b, reuse_b=False):
+        if op.nrows:
+            self._sweep(op, 3 if sor else 1, 1 if backward else 0, omega, x, b)
+
+
 class ThreadComm:
     """One of N virtual ranks living in threads of one process (single GPU)."""
 

@@ -1,0 +1,146 @@
+"""The row-sharded cycle behind the C ABI (`amgh_dist_*`, include/amghip.h): N ranks on the LOCAL transport
+(threads of this process sharing the one GPU a gpurun box has — halo entries move by device-to-device copies
+between the ranks' streams).  Jacobi / residual / R / P are exactly the single-GPU arithmetic -> compared with the
+oracle at 1e-10 per cycle.  Gauss-Seidel across shards is the processor-block hybrid (exact inside a shard, halo
+frozen per directional sweep): compared PER CYCLE with a host emulation of the same frozen-halo sweeps (the
+Python mirror of the sharded driver with the oracle's loops as local arithmetic).  The RCCL transport is driven
+with one rank (communicator, all-reduce, self-contained exchange plan); more ranks need more GPUs."""
+import numpy as np
+import pytest
+
+import amg_amd as AMG
+from amg_amd import sharded as SH
+from conftest import uniform
+from dist_backends import OracleOps, run_virtual_ranks
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(x, y):
+    return np.linalg.norm(np.asarray(x) - np.asarray(y)) / max(np.linalg.norm(y), 1e-300)
+
+
+def sharded_run(ml, nranks, shard_min_rows, fn):
+    """fn(sh) on every rank; returns the per-rank results."""
+    def work(rank, group):
+        sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, 0, ("local", group), shard_min_rows)
+        return fn(sh)
+    return SH.run_local_ranks(nranks, work)
+
+
+def sharded_solve(ml, b, nranks, shard_min_rows, **kw):
+    res = sharded_run(ml, nranks, shard_min_rows, lambda sh: (*sh.solve(b[sh.r0:sh.r1], **kw), sh.lc, sh.stats()))
+    return np.concatenate([r[0] for r in res]), res[0][1], res[0][2], [r[3] for r in res]
+
+
+def emulated_cycles(ml, b, nranks, shard_min_rows, cycles, cyc=0):
+    """Host emulation of the sharded cycle: iterates after 1..cycles cycles from x0 = 0."""
+    def work(comm):
+        dml = AMG.dist.DistMultiLevel(ml, comm, OracleOps(), shard_min_rows=shard_min_rows)
+        r0, r1 = dml.local_range(0)
+        dml.set_rhs(b[r0:r1])
+        dml.ops.zero(dml.x[0], r1 - r0)
+        out = []
+        for _ in range(cycles):
+            dml.cycle(0, cyc)
+            out.append(dml.ops.download(dml.x[0], r1 - r0))
+        return out
+    res = run_virtual_ranks(nranks, work)
+    return [np.concatenate([r[k] for r in res]) for k in range(cycles)]
+
+
+def sharded_cycles(ml, b, nranks, shard_min_rows, cycles, cyc=0):
+    def fn(sh):
+        out = []
+        for k in range(1, cycles + 1):   # exactly k cycles from x0 = 0 (calculate_residual = False)
+            x, _ = sh.solve(b[sh.r0:sh.r1], cycle=cyc, maxiter=k, calculate_residual=False)
+            out.append(x)
+        return out
+    res = sharded_run(ml, nranks, shard_min_rows, fn)
+    return [np.concatenate([r[k] for r in res]) for k in range(cycles)]
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_sharded_jacobi_equals_the_oracle_cycle_for_cycle(nranks):
+    A = AMG.poisson((32, 24, 20))
+    b = uniform(A.m, 5)
+    jac = AMG.Jacobi(2.0 / 3.0, iter=2)
+    ml = AMG.ruge_stuben(A, presmoother=jac, postsmoother=jac)
+    oh = O.OracleHierarchy(ml)
+    for cyc in (0, 1, 2):
+        x, hist, lc, stats = sharded_solve(ml, b, nranks, 500, cycle=cyc, reltol=1e-8, maxiter=60)
+        assert lc >= 2
+        xo, ho, _ = oh.solve(b, cycle=cyc, reltol=1e-8, maxiter=60)
+        assert len(hist) == len(ho)
+        assert np.allclose(hist, ho, rtol=1e-9)
+        assert rel(x, xo) <= 1e-10
+        assert all(s["halo_exchanges"] > 0 and s["halo_bytes_sent"] > 0 for s in stats)
+
+
+def test_halo_plan_of_a_z_slab_partition():
+    """7-point stencil, first axis fastest, 2 ranks: each rank needs exactly the neighbour's boundary plane, and
+    the rows that read it are the first / last plane of the shard (everything else is interior)."""
+    A = AMG.poisson((8, 8, 12))
+    ml = AMG.ruge_stuben(A, max_levels=2)
+    infos = sharded_run(ml, 2, 100, lambda sh: (sh.plan_info(0), sh.r0, sh.r1))
+    (p0, a0, a1), (p1, b0, b1) = infos
+    assert (a0, a1, b0, b1) == (0, 384, 384, 768)
+    assert np.array_equal(p0["halo"], np.arange(384, 448)) and np.array_equal(p1["halo"], np.arange(320, 384))
+    assert np.array_equal(p0["send_idx"], np.arange(320, 384)) and np.array_equal(p1["send_idx"], np.arange(0, 64))
+    assert p0["send_cnt"].tolist() == [0, 64] and p0["recv_cnt"].tolist() == [0, 64]
+    assert p0["interior"] == (0, 320) and p1["interior"] == (64, 384)
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_hybrid_gauss_seidel_matches_the_frozen_halo_emulation_per_cycle(nranks):
+    A = AMG.poisson((40, 40, 48))
+    b = uniform(A.m, 6)
+    ml = AMG.ruge_stuben(A)
+    got = sharded_cycles(ml, b, nranks, 4000, 3)
+    want = emulated_cycles(ml, b, nranks, 4000, 3)
+    for k in range(3):
+        assert rel(got[k], want[k]) <= 1e-10, (nranks, k)
+    # and the hybrid converges to the same solution as the exact lexicographic sweep, in about as many cycles
+    x, hist, lc, _ = sharded_solve(ml, b, nranks, 4000, reltol=1e-10, maxiter=60)
+    xo, ho, _ = O.OracleHierarchy(ml).solve(b, reltol=1e-10, maxiter=60)
+    assert lc >= 2 and hist[-1] <= 1e-10 * hist[0]
+    assert rel(x, xo) <= 1e-8 and abs(len(hist) - len(ho)) <= 2
+
+
+def test_sor_and_w_cycle_on_shards_match_the_emulation():
+    A = AMG.poisson((32, 32, 32))
+    b = uniform(A.m, 9)
+    ml = AMG.ruge_stuben(A, presmoother=AMG.SOR(1.2, AMG.ForwardSweep()), postsmoother=AMG.SOR(1.2, AMG.BackwardSweep()))
+    got = sharded_cycles(ml, b, 4, 2000, 2, cyc=1)
+    want = emulated_cycles(ml, b, 4, 2000, 2, cyc=1)
+    assert rel(got[0], want[0]) <= 1e-10 and rel(got[1], want[1]) <= 1e-10
+
+
+def test_everything_collapsed_and_single_rank():
+    A = AMG.poisson((20, 20, 20))
+    b = uniform(A.m, 7)
+    ml = AMG.ruge_stuben(A)
+    xo, ho = AMG._solve(ml, b, reltol=1e-8, log=True)
+    # problem below the shard threshold: rank 0 runs the plain single-GPU cycle, the others hold nothing
+    x, hist, lc, _ = sharded_solve(ml, b, 2, 10 ** 9, reltol=1e-8)
+    assert lc == 0 and len(hist) == len(ho) and rel(x, xo) <= 1e-12
+    # one rank, two sharded levels: no exchange at all, the exact sweep
+    x, hist, lc, stats = sharded_solve(ml, b, 1, 500, reltol=1e-8)
+    assert lc >= 2 and len(hist) == len(ho) and rel(x, xo) <= 1e-12 and stats[0]["halo_exchanges"] == 0
+
+
+def test_rccl_transport_with_one_rank():
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce through the dlopen'ed librccl (more ranks need more GPUs)."""
+    lib = AMG.hip_lib()
+    if not lib.amgh_dist_rccl_available():
+        pytest.skip("librccl not found")
+    A = AMG.poisson((20, 20, 20))
+    b = uniform(A.m, 7)
+    ml = AMG.ruge_stuben(A)
+    sh = SH.ShardedHierarchy.from_multilevel(ml, 0, 1, 0, ("rccl", SH.rccl_unique_id()), 500)
+    x, hist = sh.solve(b, reltol=1e-8)
+    xo, ho = AMG._solve(ml, b, reltol=1e-8, log=True)
+    assert len(hist) == len(ho) and rel(x, xo) <= 1e-12
+    assert sh.allreduce([1.5, 2.0])[1] == 2.0 and sh.allreduce([3.0], "max")[0] == 3.0
+    sh.barrier()

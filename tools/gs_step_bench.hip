@@ -1,0 +1,362 @@
+// gs_step_bench — what one merged-group launch of the Gauss-Seidel sweep costs, and why.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/gs_step_bench tools/gs_step_bench.hip
+// A synthetic chain of K dependent "group" launches with the shape of the 256^3 fine-level sweep: launch k updates
+// rows [kR, (k+1)R) from slot-packed composite rows (LEN entries each) whose columns point into the rows of launch
+// k-1 (same relative position +- a window), exactly the access pattern of gs_slot_kernel.  Variants:
+//   T / EPT   workgroup size and entries per thread (slot = T * EPT entries)
+//   STAGE     0 full kernel | 1 no x gather | 2 matrix loads only (no gather, no LDS, one store per row)
+//   eager launches vs ONE hipGraph replay of the whole chain (is the boundary host- or device-bound?)
+// Prints microseconds per launch.  Every variant checks its result against the T512/EPT1 run (same arithmetic order).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <cmath>
+#include <type_traits>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
+struct Args {
+  const int32_t* wcol; const double* wval; const int32_t* slot_row; const i4_t* wmeta; const double* diag; const double* bp;
+  double* x; long long ent0; int nslots; int slot0; int xcd;
+};
+
+__device__ __forceinline__ int xcd_block(int b, int nb) { const int per = (nb + 7) / 8; return (b % 8) * per + b / 8; }
+
+template <int T, int EPT, int STAGE>
+__global__ __launch_bounds__(T) void slot_kernel(Args a) {
+  constexpr int S = T * EPT;
+  __shared__ double s_prod[S];
+  const int tid = threadIdx.x;
+  int lb = blockIdx.x;
+  if (a.xcd) lb = xcd_block(lb, a.nslots);
+  if (lb >= a.nslots) return;
+  const int s = a.slot0 + lb;
+  const long long base = a.ent0 + (long long)lb * S;
+  double v[EPT]; int c[EPT];
+  if (EPT == 1) { v[0] = a.wval[base + tid]; c[0] = a.wcol[base + tid]; }
+  else if (EPT == 2) {
+    const d2_t vv = *(const d2_t*)(a.wval + base + 2 * tid); const i2_t cc = *(const i2_t*)(a.wcol + base + 2 * tid);
+    v[0] = vv.x; v[1] = vv.y; c[0] = cc.x; c[1] = cc.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < EPT / 4; ++q) {
+      const long long o = base + 4 * (tid + q * T);
+      const d2_t v0 = *(const d2_t*)(a.wval + o), v1 = *(const d2_t*)(a.wval + o + 2); const i4_t cc = *(const i4_t*)(a.wcol + o);
+      v[4 * q] = v0.x; v[4 * q + 1] = v0.y; v[4 * q + 2] = v1.x; v[4 * q + 3] = v1.y;
+      c[4 * q] = cc.x; c[4 * q + 1] = cc.y; c[4 * q + 2] = cc.z; c[4 * q + 3] = cc.w;
+    }
+  }
+  const int r0 = a.slot_row[2 * s], r1 = a.slot_row[2 * s + 1];
+  double xv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) xv[e] = (STAGE == 0) ? a.x[c[e]] : 1.0;
+  const int nrows = r1 - r0;
+  i4_t m = i4_t{0, 0, -1, 0}; double d = 0.0, bb = 0.0;
+  if (tid < nrows) { m = a.wmeta[r0 + tid]; d = a.diag[r0 + tid]; bb = a.bp[r0 + tid]; }
+  if (STAGE == 2) {
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) acc += v[e] * (double)c[e];
+    if (tid < nrows) a.x[r0 + tid] = (bb - acc) / d;
+    return;
+  }
+  // entry position of element e of this thread inside the slot
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int pos = (EPT <= 2) ? EPT * tid + e : 4 * (tid + (e / 4) * T) + (e & 3);
+    s_prod[pos] = v[e] * xv[e];
+  }
+  __syncthreads();
+  for (int t = tid; t < nrows; t += T) {
+    if (t != tid) { m = a.wmeta[r0 + t]; d = a.diag[r0 + t]; bb = a.bp[r0 + t]; }
+    double acc = 0.0;
+    const int lo = (int)(m.x - base), hi = (int)(m.y - base);
+    for (int j = lo; j < hi; ++j) acc += s_prod[j];
+    if (d != 0.0) a.x[r0 + t] = (bb - acc) / d;
+  }
+}
+
+struct Layout { std::vector<int32_t> wcol, slot_row; std::vector<double> wval; std::vector<i4_t> wmeta; std::vector<int> slot0, nslots; std::vector<long long> ent0; };
+// SELL-like layout: a wave owns 64 / KL consecutive rows, KL lanes per row; iteration t, lane l reads entry t * KL + (l % KL)
+// of row l / KL from position chunk_base + t * 64 + l (fully coalesced); padding entries have col = -1.
+struct SellArgs { const int32_t* col; const double* val; const i2_t* chunk; const double* diag; const double* bp; double* x; int row0; int nrows; int chunk0; int nchunks; int xcd; };
+template <int KL>
+__global__ __launch_bounds__(256) void sell_kernel(SellArgs a) {
+  constexpr int C = 64 / KL;
+  int wb = blockIdx.x;
+  const int nwg = (a.nchunks + 3) / 4;
+  if (a.xcd) wb = xcd_block(wb, nwg);
+  if (wb >= nwg) return;
+  const int ch = wb * 4 + (threadIdx.x >> 6);
+  if (ch >= a.nchunks) return;
+  const int lane = threadIdx.x & 63;
+  const i2_t cd = a.chunk[a.chunk0 + ch];   // {offset in units of 64 entries, iterations}
+  const long long base = (long long)cd.x * 64 + lane;
+  const int r = ch * C + lane / KL;
+  const bool live = r < a.nrows;
+  double d = 1.0, bb = 0.0;
+  if (live) { d = a.diag[a.row0 + r]; bb = a.bp[a.row0 + r]; }
+  double acc = 0.0;
+  int t = 0;
+  for (; t + 4 <= cd.y; t += 4) {
+    double v[4]; int c[4]; double xv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a.val[base + (long long)(t + e) * 64]; c[e] = a.col[base + (long long)(t + e) * 64]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] = c[e] >= 0 ? a.x[c[e]] : 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (c[e] >= 0) acc += v[e] * xv[e];
+  }
+  for (; t < cd.y; ++t) {
+    const double v = a.val[base + (long long)t * 64]; const int c = a.col[base + (long long)t * 64];
+    if (c >= 0) acc += v * a.x[c];
+  }
+#pragma unroll
+  for (int w = 1; w < KL; w <<= 1) acc += __shfl_xor(acc, w, 64);
+  if (live && (lane % KL) == 0 && d != 0.0) a.x[a.row0 + r] = (bb - acc) / d;
+}
+// the same with EVERY load of the chunk in flight at once (T <= TMAX iterations, fully unrolled): one round trip for
+// col/val, one for the gathers, whatever the row length.  UNI: the iteration count comes from the kernel arguments
+// (uniform per launch) instead of the per-chunk descriptor: no dependent scalar load in front of the stream.
+template <int KL, int TMAX, bool UNI>
+__global__ __launch_bounds__(256) void sell_full_kernel(SellArgs a, int Tuni) {
+  constexpr int C = 64 / KL;
+  int wb = blockIdx.x;
+  const int nwg = (a.nchunks + 3) / 4;
+  if (a.xcd) wb = xcd_block(wb, nwg);
+  if (wb >= nwg) return;
+  const int ch = wb * 4 + (threadIdx.x >> 6);
+  if (ch >= a.nchunks) return;
+  const int lane = threadIdx.x & 63;
+  long long base; int T;
+  if (UNI) { T = Tuni; base = ((long long)a.chunk0 + ch) * Tuni * 64 + lane; }  // chunk0 = first chunk of the launch, all chunks T wide
+  else { const i2_t cd = a.chunk[a.chunk0 + ch]; base = (long long)cd.x * 64 + lane; T = cd.y; }
+  const int r = ch * C + lane / KL;
+  const bool live = r < a.nrows;
+  double v[TMAX]; int c[TMAX]; double xv[TMAX];
+#pragma unroll
+  for (int e = 0; e < TMAX; ++e) { c[e] = -1; if (e < T) c[e] = a.col[base + (long long)e * 64]; }
+#pragma unroll
+  for (int e = 0; e < TMAX; ++e) { v[e] = 0.0; if (e < T) v[e] = a.val[base + (long long)e * 64]; }
+  double d = 1.0, bb = 0.0;
+  if (live) { d = a.diag[a.row0 + r]; bb = a.bp[a.row0 + r]; }
+#pragma unroll
+  for (int e = 0; e < TMAX; ++e) xv[e] = c[e] >= 0 ? a.x[c[e]] : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for (int e = 0; e < TMAX; ++e) if (c[e] >= 0) acc += v[e] * xv[e];
+#pragma unroll
+  for (int w = 1; w < KL; w <<= 1) acc += __shfl_xor(acc, w, 64);
+  if (live && (lane % KL) == 0 && d != 0.0) a.x[a.row0 + r] = (bb - acc) / d;
+}
+struct Sell { std::vector<int32_t> col; std::vector<double> val; std::vector<i2_t> chunk; std::vector<int> chunk0, nchunks; };
+// from the S=512 slot layout (rows of LEN entries, launch k = rows [kR, (k+1)R))
+Sell build_sell(const Layout& L, int K, int R, int LEN, int KL) {
+  Sell S; const int C = 64 / KL; const int T = (LEN + KL - 1) / KL;
+  for (int k = 0; k < K; ++k) {
+    S.chunk0.push_back((int)S.chunk.size());
+    const int nch = (R + C - 1) / C; S.nchunks.push_back(nch);
+    for (int ch = 0; ch < nch; ++ch) {
+      const size_t off = S.col.size(); S.chunk.push_back(i2_t{(int)(off / 64), T});
+      S.col.resize(off + (size_t)T * 64, -1); S.val.resize(off + (size_t)T * 64, 0.0);
+      for (int l = 0; l < 64; ++l) {
+        const int r = ch * C + l / KL; if (r >= R) continue;
+        const i4_t m = L.wmeta[(size_t)k * R + r];
+        for (int t = 0; t < T; ++t) { const int e = t * KL + (l % KL); if (e < LEN) { S.col[off + (size_t)t * 64 + l] = L.wcol[m.x + e]; S.val[off + (size_t)t * 64 + l] = L.wval[m.x + e]; } }
+      }
+    }
+  }
+  return S;
+}
+
+__global__ void empty_kernel(double* x) { if (x == nullptr) x[0] = 1.0; }
+
+
+// K launches of R rows of LEN entries each, slot size S
+int g_pattern = 0;  // 0: random +-1024 window, 1: stencil (fixed offsets, shifted by one per row)
+Layout build(int K, int R, int LEN, int S, long long n) {
+  Layout L;
+  const int rps = S / LEN;  // rows per slot
+  const int spl = (R + rps - 1) / rps;
+  L.wcol.assign((size_t)K * spl * S, 0); L.wval.assign((size_t)K * spl * S, 0.0); L.wmeta.resize((size_t)K * R);
+  uint64_t st = 12345;
+  auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(st >> 33); };
+  for (int k = 0; k < K; ++k) {
+    L.slot0.push_back((int)(L.slot_row.size() / 2)); L.nslots.push_back(spl); L.ent0.push_back((long long)k * spl * S);
+    for (int q = 0; q < spl; ++q) {
+      const int ra = q * rps, rb = std::min(R, ra + rps);
+      L.slot_row.push_back(k * R + ra); L.slot_row.push_back(k * R + rb);
+      for (int r = ra; r < rb; ++r) {
+        const long long start = L.ent0[k] + (long long)q * S + (long long)(r - ra) * LEN;
+        L.wmeta[(size_t)k * R + r] = i4_t{(int)start, (int)(start + LEN), -1, 0};
+        for (int j = 0; j < LEN; ++j) {
+          long long c = (long long)(k == 0 ? K : k - 1) * R + r + (long long)(rnd() % 2048) - 1024;  // previous launch's rows, near r
+          if (g_pattern == 1) c = (long long)(k - 1) * R + r + (long long)(j - LEN / 2) * 257 + (j % 3) - 1;
+          if (k == 0) c = (long long)K * R + (rnd() % R);
+          if (c < 0) c = 0; if (c >= n) c = n - 1;
+          if (k > 0) { const long long lo = (long long)(k - 1) * R, hi = (long long)k * R - 1; if (c < lo) c = lo; if (c > hi) c = hi; }
+          L.wcol[start + j] = (int32_t)c; L.wval[start + j] = -1.0 / (LEN + 1) * (1.0 + 1e-3 * (rnd() % 7));
+        }
+      }
+    }
+  }
+  return L;
+}
+
+template <int T, int EPT, int STAGE>
+double run(const Layout& L, Args a, int K, bool graph, int xcd, hipStream_t st, std::vector<double>* out, long long n, const std::vector<double>& x0, int reps = 3) {
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  hipGraphExec_t exec = nullptr;
+  auto enqueue = [&]() {
+    for (int k = 0; k < K; ++k) {
+      Args b = a; b.ent0 = L.ent0[k]; b.nslots = L.nslots[k]; b.slot0 = L.slot0[k]; b.xcd = xcd;
+      const int grid = xcd ? ((b.nslots + 7) / 8) * 8 : b.nslots;
+      hipLaunchKernelGGL((slot_kernel<T, EPT, STAGE>), dim3(grid), dim3(T), 0, st, b);
+    }
+  };
+  if (graph) {
+    hipGraph_t g; CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); enqueue(); CHECK(hipStreamEndCapture(st, &g));
+    CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0)); CHECK(hipGraphDestroy(g));
+  }
+  for (int rep = 0; rep < reps; ++rep) {
+    CHECK(hipMemcpyAsync(a.x, x0.data(), 8 * n, hipMemcpyHostToDevice, st));
+    CHECK(hipStreamSynchronize(st));
+    CHECK(hipEventRecord(e0, st));
+    if (graph) CHECK(hipGraphLaunch(exec, st)); else enqueue();
+    CHECK(hipEventRecord(e1, st)); CHECK(hipStreamSynchronize(st));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+  }
+  if (exec) CHECK(hipGraphExecDestroy(exec));
+  if (out) { out->resize(n); CHECK(hipMemcpy(out->data(), a.x, 8 * n, hipMemcpyDeviceToHost)); }
+  return 1e3 * best / K;
+}
+
+template <int KL, int TMAX = 0, bool UNI = false>
+double run_sell(const Sell& S, SellArgs a, int K, int R, bool graph, hipStream_t st, std::vector<double>* out, long long n, const std::vector<double>& x0) {
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  auto enqueue = [&]() {
+    for (int k = 0; k < K; ++k) {
+      SellArgs b = a; b.row0 = k * R; b.nrows = R; b.chunk0 = S.chunk0[k]; b.nchunks = S.nchunks[k]; b.xcd = 1;
+      const int nwg = (b.nchunks + 3) / 4;
+      if constexpr (TMAX == 0) hipLaunchKernelGGL((sell_kernel<KL>), dim3(((nwg + 7) / 8) * 8), dim3(256), 0, st, b);
+      else hipLaunchKernelGGL((sell_full_kernel<KL, TMAX, UNI>), dim3(((nwg + 7) / 8) * 8), dim3(256), 0, st, b, (int)S.chunk[0].y);
+    }
+  };
+  hipGraphExec_t exec = nullptr;
+  if (graph) { hipGraph_t g; CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); enqueue(); CHECK(hipStreamEndCapture(st, &g));
+    CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0)); CHECK(hipGraphDestroy(g)); }
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipMemcpyAsync(a.x, x0.data(), 8 * n, hipMemcpyHostToDevice, st)); CHECK(hipStreamSynchronize(st));
+    CHECK(hipEventRecord(e0, st)); if (graph) CHECK(hipGraphLaunch(exec, st)); else enqueue(); CHECK(hipEventRecord(e1, st)); CHECK(hipStreamSynchronize(st));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+  }
+  if (exec) CHECK(hipGraphExecDestroy(exec));
+  if (out) { out->resize(n); CHECK(hipMemcpy(out->data(), a.x, 8 * n, hipMemcpyDeviceToHost)); }
+  return 1e3 * best / K;
+}
+
+template <class Tv> Tv* up(const std::vector<Tv>& v) { Tv* p; CHECK(hipMalloc(&p, sizeof(Tv) * std::max<size_t>(1, v.size()))); CHECK(hipMemcpy(p, v.data(), sizeof(Tv) * v.size(), hipMemcpyHostToDevice)); return p; }
+
+int main(int argc, char** argv) {
+  const int K = argc > 1 ? atoi(argv[1]) : 200;
+  hipStream_t st; CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  // boundary alone: empty kernels, eager vs graph
+  {
+    double* dummy; CHECK(hipMalloc(&dummy, 8));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int wg : {1, 256, 1024}) {
+      for (int graph = 0; graph < 2; ++graph) {
+        hipGraphExec_t exec = nullptr;
+        if (graph) { hipGraph_t g; CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+          for (int k = 0; k < 2000; ++k) hipLaunchKernelGGL(empty_kernel, dim3(wg), dim3(256), 0, st, dummy);
+          CHECK(hipStreamEndCapture(st, &g)); CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0)); CHECK(hipGraphDestroy(g)); }
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+          CHECK(hipStreamSynchronize(st)); CHECK(hipEventRecord(e0, st));
+          if (graph) CHECK(hipGraphLaunch(exec, st)); else for (int k = 0; k < 2000; ++k) hipLaunchKernelGGL(empty_kernel, dim3(wg), dim3(256), 0, st, dummy);
+          CHECK(hipEventRecord(e1, st)); CHECK(hipStreamSynchronize(st)); float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+        }
+        printf("empty kernel x2000, %4d WGs, %s: %.2f us per launch\n", wg, graph ? "graph" : "eager", 1e3 * best / 2000);
+        if (exec) CHECK(hipGraphExecDestroy(exec));
+      }
+    }
+  }
+  for (int pat = 1; pat >= 0; --pat)
+  for (int LEN : {10, 27, 60, 100}) {
+    g_pattern = pat;
+    for (int R : {6400, 22000, 65000, 130000}) {
+      if (LEN == 60 && R > 22000) continue;
+      if (LEN == 100 && R > 6400) continue;
+      if (pat == 0 && !(R == 65000 && LEN == 10) && !(R == 22000 && LEN == 27)) continue;
+      printf("==== pattern %s\n", pat ? "stencil" : "random window");   // rows per launch: x LEN / 512 = 293 / 508 / 1270 / 2540 slots of 512
+      const long long n = (long long)(K + 1) * R;
+      std::vector<double> x0(n), diag(n, 1.0), bp(n);
+      for (long long i = 0; i < n; ++i) { x0[i] = 1.0 + 1e-3 * (i % 97); bp[i] = 0.5 + 1e-3 * (i % 89); }
+      double* dx = up(x0); double* dd = up(diag); double* db = up(bp);
+      std::vector<double> ref;
+      printf("---- LEN %d, %d rows/launch (%d x 512-entry slots, %.1f MB of col/val per launch), K=%d launches\n", LEN, R, (R + 512 / LEN - 1) / (512 / LEN),
+             12.0 * R * LEN / 1e6, K);
+      for (int S : {512, 1024, 2048}) {
+        Layout L = build(K, R, LEN, S, n);
+        Args a{}; a.wcol = up(L.wcol); a.wval = up(L.wval); a.slot_row = up(L.slot_row); a.wmeta = up(L.wmeta); a.diag = dd; a.bp = db; a.x = dx;
+        auto report = [&](const char* name, double us, const std::vector<double>* got) {
+          long long bad = 0;
+          if (got && !ref.empty()) for (long long i = 0; i < n; ++i) bad += ((*got)[i] != ref[i]);
+          printf("  S=%4d %-22s %6.2f us/launch%s\n", S, name, us, got && !ref.empty() ? (bad ? "  MISMATCH" : "  (= reference)") : "");
+        };
+        std::vector<double> got;
+        if (S == 512) {
+          const double t = run<512, 1, 0>(L, a, K, false, 1, st, &ref, n, x0); report("T512 E1 eager xcd", t, nullptr);
+          report("T512 E1 graph xcd", run<512, 1, 0>(L, a, K, true, 1, st, &got, n, x0), &got);
+          report("T256 E2 eager xcd", run<256, 2, 0>(L, a, K, false, 1, st, &got, n, x0), &got);
+          report("T512 E1 no-gather", run<512, 1, 1>(L, a, K, false, 1, st, nullptr, n, x0), nullptr);
+          report("T512 E1 loads-only", run<512, 1, 2>(L, a, K, false, 1, st, nullptr, n, x0), nullptr);
+          auto sell = [&](auto klc, const char* name) {
+            constexpr int KL = decltype(klc)::value;
+            Sell Sl = build_sell(L, K, R, LEN, KL);
+            SellArgs sa{}; sa.col = up(Sl.col); sa.val = up(Sl.val); sa.chunk = up(Sl.chunk); sa.diag = dd; sa.bp = db; sa.x = dx;
+            std::vector<double> g2;
+            const double t = run_sell<KL>(Sl, sa, K, R, false, st, &g2, n, x0);
+            double err = 0; for (long long i = 0; i < n; ++i) err = std::max(err, std::abs(g2[i] - ref[i]) / (1e-300 + std::abs(ref[i])));
+            printf("  SELL %-24s %6.2f us/launch  (max rel diff vs slots %.1e; %.2f x entries stored)\n", name, t, err, (double)Sl.col.size() / ((double)K * R * LEN));
+            const int T = (LEN + KL - 1) / KL;
+            if (T <= 8) {
+              const double t8 = run_sell<KL, 8, false>(Sl, sa, K, R, false, st, &g2, n, x0);
+              double e8 = 0; for (long long i = 0; i < n; ++i) e8 = std::max(e8, std::abs(g2[i] - ref[i]) / (1e-300 + std::abs(ref[i])));
+              const double t8g = run_sell<KL, 8, false>(Sl, sa, K, R, true, st, nullptr, n, x0);
+              const double t8u = run_sell<KL, 8, true>(Sl, sa, K, R, false, st, &g2, n, x0);
+              double e8u = 0; for (long long i = 0; i < n; ++i) e8u = std::max(e8u, std::abs(g2[i] - ref[i]) / (1e-300 + std::abs(ref[i])));
+              printf("       full unroll T<=8: %6.2f us (diff %.1e)   graph %6.2f us   uniform-T, no descriptor load: %6.2f us (diff %.1e)\n", t8, e8, t8g, t8u, e8u);
+            } else if (T <= 16) {
+              const double t16 = run_sell<KL, 16, false>(Sl, sa, K, R, false, st, &g2, n, x0);
+              double e16 = 0; for (long long i = 0; i < n; ++i) e16 = std::max(e16, std::abs(g2[i] - ref[i]) / (1e-300 + std::abs(ref[i])));
+              const double t16u = run_sell<KL, 16, true>(Sl, sa, K, R, false, st, nullptr, n, x0);
+              printf("       full unroll T<=16: %6.2f us (diff %.1e)   uniform-T, no descriptor load: %6.2f us\n", t16, e16, t16u);
+            }
+            hipFree((void*)sa.col); hipFree((void*)sa.val); hipFree((void*)sa.chunk);
+          };
+          sell(std::integral_constant<int, 1>(), "1 lane/row");
+          sell(std::integral_constant<int, 2>(), "2 lanes/row");
+          sell(std::integral_constant<int, 4>(), "4 lanes/row");
+          sell(std::integral_constant<int, 8>(), "8 lanes/row");
+          if (LEN >= 27) sell(std::integral_constant<int, 16>(), "16 lanes/row");
+          if (LEN >= 100) sell(std::integral_constant<int, 32>(), "32 lanes/row");
+        } else if (S == 1024) {
+          report("T256 E4 eager xcd", run<256, 4, 0>(L, a, K, false, 1, st, &got, n, x0), &got);
+        } else {
+          report("T256 E8 eager xcd", run<256, 8, 0>(L, a, K, false, 1, st, &got, n, x0), &got);
+        }
+        hipFree((void*)a.wcol); hipFree((void*)a.wval); hipFree((void*)a.slot_row); hipFree((void*)a.wmeta);
+      }
+      hipFree(dx); hipFree(dd); hipFree(db);
+    }
+  }
+  return 0;
+}
