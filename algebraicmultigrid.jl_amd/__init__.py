@@ -19,8 +19,9 @@ from .hierarchy import (Classical, HermitianSymmetry, JacobiProlongation, Level,
                         MultiLevel, NoSymmetry, Pinv, QRSolver, RS, StandardAggregation, SymmetricStrength,
                         direct_interpolation, fit_candidates, grid_complexity, operator_complexity, poisson,
                         ruge_stuben, smoothed_aggregation)
-from .solve import (F, Preconditioner, RugeStubenAMG, SmoothedAggregationAMG, V, W, _solve, _solve_inplace,  # noqa: F401
-                    aspreconditioner, cg, solve)
+from .solve import (AMGSolver, F, Identity, Preconditioner, RugeStubenAMG, RugeStubenPreconBuilder,  # noqa: F401
+                    SmoothedAggregationAMG, SmoothedAggregationPreconBuilder, V, W, _solve, _solve_inplace,
+                    aspreconditioner, cg, init, solve, solve_)
 from .device import DeviceBuffer, DeviceCSR, DeviceHierarchy  # noqa: F401
 from . import dist, sharded  # noqa: F401
 

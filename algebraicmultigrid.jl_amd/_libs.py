@@ -117,6 +117,7 @@ def hip_lib():
     L.amgh_device_bytes.argtypes = [vp]
     L.amgh_gs_num_dependency_levels.argtypes = [vp, C.c_int]
     L.amgh_gs_num_sweep_steps.argtypes = [vp, C.c_int, C.c_int]
+    L.amgh_gs_sweep_stats.argtypes = [vp, C.c_int, C.c_int, vp]
     solve_args = [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, C.POINTER(C.c_int)]
     L.amgh_solve.argtypes = solve_args
     L.amgh_solve_d.argtypes = solve_args

@@ -459,6 +459,8 @@ bool smoother_valid(const amgh_smoother_t* s) {
 
 }  // namespace
 
+const char* amgh_rccl_error_string(int code);  // amghip_dist.hpp
+
 extern "C" {
 
 const char* amgh_strerror(int rc) {
@@ -469,6 +471,10 @@ const char* amgh_strerror(int rc) {
     case AMGH_ESTATE: return "invalid state (not finalized, already finalized, or operator missing)";
     case AMGH_ENOMEM: return "out of device memory";
     case AMGH_EUNSUPPORTED: return "unsupported configuration";
+  }
+  if (rc <= -2000) {
+    snprintf(buf, sizeof buf, "RCCL error %d: %s", -rc - 2000, amgh_rccl_error_string(-rc - 2000));
+    return buf;
   }
   if (rc <= -1000) {
     snprintf(buf, sizeof buf, "HIP error %d: %s", -rc - 1000, hipGetErrorString((hipError_t)(-rc - 1000)));
@@ -684,6 +690,35 @@ int amgh_gs_num_sweep_steps(const amgh_t* h, int l, int backward) {
   if (g->nblk > 0 && g_gs_block_inverse) return g->nblk;             // block-inverse sweep: sequential block steps
   const GsSchedule* c = backward ? g->mb : g->mf;
   return (c && g_gs_merge > 1) ? c->nlev : g->nlev;                  // merged groups, or dependency levels
+}
+
+int amgh_gs_sweep_stats(const amgh_t* h, int l, int backward, int64_t* out6) {
+  if (!h || l < 0 || l >= (int)h->levels.size() || !out6) return AMGH_EINVAL;
+  for (int q = 0; q < 6; ++q) out6[q] = 0;
+  amgh_csr* M = h->levels[l]->smat();
+  const GsSchedule* g = M->gs;
+  if (!g) return AMGH_OK;
+  if (g->nblk > 0 && g_gs_block_inverse) {  // block-inverse sweep: one launch per superblock (+ its pre-pass), dense inverses streamed
+    const int S = g->super > 0 ? g->super : g->nblk;
+    out6[0] = 2 * ((g->nblk + S - 1) / S);
+    out6[1] = g->n;
+    out6[2] = out6[3] = g->nnz + (int64_t)g->nblk * kBlk * kBlk;
+    out6[5] = 0;
+    return AMGH_OK;
+  }
+  const GsSchedule* c = backward ? g->mb : g->mf;
+  const bool merged = c && g_gs_merge > 1;
+  const GsSchedule* lay = merged ? c : g;
+  out6[0] = (int64_t)lay->segs.size();
+  out6[1] = g->n;
+  int64_t slotted = 0;  // entries of the rows that run from the slot arrays are counted with their padding
+  for (const GsSchedule::Seg& sg : lay->segs)
+    if (!sg.chain && sg.nslots > 0) slotted += (int64_t)sg.nslots * lay->slot_entries;
+  out6[2] = lay->nnz;
+  out6[3] = slotted;
+  out6[4] = merged ? (backward ? g->tri_nnz_b : g->tri_nnz) : 0;
+  out6[5] = merged ? (backward ? g->merge_b : g->merge_f) : 1;
+  return AMGH_OK;
 }
 
 static int ensure_pcg_bufs(amgh_t* h) {

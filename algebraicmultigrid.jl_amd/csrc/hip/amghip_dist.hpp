@@ -630,6 +630,11 @@ int dist_new(amgh_dist** dp, int device, Transport* tr) {
 
 }  // namespace
 
+const char* amgh_rccl_error_string(int code) {
+  RcclApi* api = rccl_api();
+  return api ? api->GetErrorString((ncclResult_t)code) : "librccl not loaded";
+}
+
 extern "C" {
 
 int amgh_dist_rccl_available(void) { return rccl_api() ? 1 : 0; }

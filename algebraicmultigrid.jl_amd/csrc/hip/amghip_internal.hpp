@@ -74,6 +74,10 @@ struct GsSchedule {
   std::vector<int32_t> h_perm;  // host copy of perm (level-ordered row -> original row), for level-ordered P / R copies
   int64_t n = 0, ncols = 0;
   int64_t bytes = 0;
+  int64_t nnz = 0;          // entries of this system's rows (composite rows for a merged child)
+  int64_t slot_total = 0;   // entries the slot arrays hold, zero padding included
+  int64_t tri_nnz = 0;      // (on the parent, per direction [fwd, bwd]) entries of the pre-pass triangles
+  int64_t tri_nnz_b = 0;
   struct Seg { int l0, l1; bool chain; int rows; int slot0, nslots; };  // dependency levels [l0, l1); launch shape
   std::vector<Seg> segs;
   // slot layout of the wide levels (gs_slot_kernel)

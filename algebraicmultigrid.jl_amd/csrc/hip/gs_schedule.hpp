@@ -151,6 +151,7 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
   const std::vector<double>& pval = h.pval;
   const int64_t nnz = prow[n];
   g->n = n;
+  g->nnz = nnz;
   g->nlev = h.nlev;
   g->lvl_ptr = h.lvl_ptr;
   g->slot_entries = slot_entries;
@@ -307,6 +308,7 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       RC_TRY(dev_upload(&g->slot_row, sr2.data(), (int64_t)sr2.size()));
       RC_TRY(dev_upload(&g->wmeta, wmeta.data(), n));
       g->bytes += (int64_t)wcol.size() * 12 + (int64_t)sr2.size() * 4 + n * 16;
+      g->slot_total = (int64_t)wcol.size();
     }
   }
   return AMGH_OK;
@@ -522,7 +524,8 @@ MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool bac
 
 // the triangle (plus halo columns) a sweep direction does NOT substitute over: s = b - T x before the sweep
 // diag_shift != 0 (SOR): the diagonal enters the pre-pass with -diag_shift * d, i.e. s = b - T x + diag_shift * D x
-int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int64_t* bytes, double diag_shift = 0.0) {
+int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int64_t* bytes, double diag_shift = 0.0,
+               int64_t* nnz_out = nullptr) {
   const int64_t n = base.n;
   std::vector<int32_t> lev_of(n);
   for (int l = 0; l < base.nlev; ++l)
@@ -543,6 +546,7 @@ int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int6
   RC_TRY(dev_upload(&t->col, cc.data(), (int64_t)cc.size()));
   RC_TRY(dev_upload(&t->val, vv.data(), (int64_t)vv.size()));
   *bytes += (n + 1) * 4 + (int64_t)cc.size() * 12;
+  if (nnz_out) *nnz_out = (int64_t)cc.size();
   return AMGH_OK;
 }
 
@@ -728,7 +732,8 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         ch->ncols = g->ncols;
         RC_TRY(layout_upload(ch, keep.sys, perm.data(), cap));
         tm.lap("merged layout", n);
-        RC_TRY(tri_upload(backward ? &g->tri_b : &g->tri_f, base, backward, &g->bytes));
+        RC_TRY(tri_upload(backward ? &g->tri_b : &g->tri_f, base, backward, &g->bytes, 0.0,
+                          backward ? &g->tri_nnz_b : &g->tri_nnz));
         tm.lap("other triangle", n);
         (backward ? g->merge_b : g->merge_f) = best_m;
         g->bytes += ch->bytes;

@@ -279,6 +279,12 @@ class DeviceHierarchy:
         """Sequential steps of one GS sweep as executed (merged groups / block steps / dependency levels)."""
         return int(self.lib.amgh_gs_num_sweep_steps(self.h, level, int(backward)))
 
+    def gs_sweep_stats(self, level, backward=False):
+        """{launches, rows, entries, slot_entries (padding included), tri_entries, levels_per_group} of one sweep."""
+        out = np.zeros(6, dtype=np.int64)
+        hip_check(self.lib.amgh_gs_sweep_stats(self.h, level, int(backward), out.ctypes.data), "gs_sweep_stats")
+        return dict(zip(("launches", "rows", "entries", "slot_entries", "tri_entries", "levels_per_group"), map(int, out)))
+
     def profile(self, on=True):
         hip_check(self.lib.amgh_profile_enable(self.h, int(on)), "profile_enable")
 

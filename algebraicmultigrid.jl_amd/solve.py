@@ -96,9 +96,17 @@ _SA_KW = ("B", "symmetry", "strength", "aggregate", "smooth", "presmoother", "po
           "max_levels", "max_coarse", "diagonal_dominance", "keep", "verbose", "coarse_solver")
 
 
-def solve(A, b, alg, cycle=None, **kwargs):
-    """solve(A, b, RugeStubenAMG() | SmoothedAggregationAMG(); kwargs...): the same kwargs go
-    to the setup and to `_solve`, each side ignoring what it does not know (multilevel.jl:252-264)."""
+class AMGSolver:
+    """`AMGSolver(ml, b)` — what `init` returns and `solve!` consumes (multilevel.jl:241-245)."""
+
+    def __init__(self, ml, b):
+        self.ml = ml
+        self.b = b
+
+
+def init(alg, A, b, **kwargs):
+    """CommonSolve `init(::RugeStubenAMG | ::SmoothedAggregationAMG, A, b; kwargs...)` (multilevel.jl:256-261):
+    the setup phase; returns the AMGSolver that `solve_` (Julia: `solve!`) runs."""
     if isinstance(alg, type):
         alg = alg()
     if isinstance(alg, RugeStubenAMG):
@@ -107,7 +115,59 @@ def solve(A, b, alg, cycle=None, **kwargs):
         ml = smoothed_aggregation(A, **{k: v for k, v in kwargs.items() if k in _SA_KW})
     else:
         raise AMGError("alg must be RugeStubenAMG() or SmoothedAggregationAMG()")
-    return _solve(ml, b, cycle, **{k: v for k, v in kwargs.items() if k in _SOLVE_KW})
+    return AMGSolver(ml, b)
+
+
+def solve_(solt, cycle=None, **kwargs):
+    """CommonSolve `solve!(solt::AMGSolver, args...; kwargs...)` = `_solve(solt.ml, solt.b, ...)` (multilevel.jl:262-264)."""
+    if not isinstance(solt, AMGSolver):
+        raise AMGError("solve_: expected the AMGSolver returned by init")
+    return _solve(solt.ml, solt.b, cycle, **{k: v for k, v in kwargs.items() if k in _SOLVE_KW})
+
+
+def solve(A, b, alg, cycle=None, **kwargs):
+    """solve(A, b, RugeStubenAMG() | SmoothedAggregationAMG(); kwargs...) = init + solve! : the same kwargs go
+    to the setup and to `_solve`, each side ignoring what it does not know (multilevel.jl:252-255)."""
+    return solve_(init(alg, A, b, **kwargs), cycle, **kwargs)
+
+
+# ---- LinearSolve `precs` builders (precs.jl:7-38) -------------------------------
+class _PreconBuilder:
+    """Callable `(builder)(A, p) -> (Pl, Pr)`: a left AMG preconditioner and the identity on the right
+    (precs.jl:16-18, 36-38).  `blocksize` is the workspace block size (`Val{bs}`, multilevel.jl:28-35)."""
+    _setup = None
+
+    def __init__(self, blocksize=1, **kwargs):
+        self.blocksize = int(blocksize)
+        self.kwargs = kwargs
+
+    def __call__(self, A, p=None):
+        ml = type(self)._setup(SparseMatrixCSC.coerce(A), **self.kwargs)
+        if self.blocksize > 1:
+            ml.device(nrhs=self.blocksize)   # allocate the n x bs workspace now, as Val{bs} does at setup
+        return aspreconditioner(ml), Identity()
+
+
+class Identity:
+    """LinearAlgebra.I as a right preconditioner."""
+
+    def ldiv(self, b, x=None):
+        if x is None:
+            return np.array(b, dtype=np.float64, copy=True)
+        x[...] = b
+        return x
+
+    solve = ldiv
+
+
+class RugeStubenPreconBuilder(_PreconBuilder):
+    """RugeStubenPreconBuilder(; blocksize = 1, kwargs...) (precs.jl:27-38)."""
+    _setup = staticmethod(ruge_stuben)
+
+
+class SmoothedAggregationPreconBuilder(_PreconBuilder):
+    """SmoothedAggregationPreconBuilder(; blocksize = 1, kwargs...) (precs.jl:7-18)."""
+    _setup = staticmethod(smoothed_aggregation)
 
 
 # ---- preconditioner facade (preconditioner.jl) --------------------------------

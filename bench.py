@@ -51,35 +51,56 @@ def vcycle_bytes(ml, sweeps_per_level):
     return total
 
 
-def pmc_traffic(N):
-    """HBM bytes per fine-level SpMV launch from the committed rocprofv3 PMC passes (FETCH_SIZE with the
-    gfx950 half-count correction + WRITE_SIZE, separate passes: profiles/r01_pmc_spmv_traffic.json).
-    PMC counters cannot be collected from inside this process, so the figure is the measured one of the
-    same kernel on the same matrix; None for any other size."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_spmv_traffic.json")
-    if N != 256 or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)["hbm_traffic_bytes_per_launch"]
+def pmc_traffic(N, enabled=True):
+    """HBM bytes of one fine-level SpMV launch, MEASURED IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE,
+    WRITE_SIZE — they cannot share a pass) over tools/spmv_bench, which launches the shipped kernel on the same
+    matrix plus a known-size read / copy that calibrates the gfx950 FETCH_SIZE half-count in the same process
+    (tools/pmc_traffic.py; method of MI355X_MICROARCH.md, HBM section).  -> (bytes or None, how)."""
+    if not enabled:
+        return None, "skipped (--no-pmc)"
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_traffic as P
+        r = P.measure(N)
+        return r["hbm_traffic_bytes_per_launch"], (
+            "measured in this run: %s; FETCH_SIZE %.0f KiB x %.4f + WRITE_SIZE %.0f KiB x %.4f over %d launches"
+            % (r["method"], r["FETCH_SIZE_KiB_avg"], r["fetch_correction"], r["WRITE_SIZE_KiB_avg"],
+               r["write_correction"], r["launches"]))
+    except Exception as e:  # noqa: BLE001  (no rocprofv3 / counters unavailable: the field is null, never a stale constant)
+        return None, f"unavailable: {type(e).__name__}: {str(e)[:160]}"
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(ml, b, budget_s=20.0):
-    """The CPU restatement of the reference's `_solve` cycle (oracle/amg_oracle.c), single thread,
-    timed on this host on a bounded sample: as many whole V-cycles as fit in ~budget_s (>= 1)."""
+    """The CPU restatement of the reference's `_solve` cycle (oracle/amg_oracle.c, gcc -O3 -march=native), single
+    thread — the reference is single-threaded — timed on this host on a bounded sample: as many whole V-cycles as
+    fit in ~budget_s (>= 1).  Also returns the oracle's V-cycle output for the parity check of the timed result."""
     from oracle import oracle as O
     oh = O.OracleHierarchy(ml)
     n = ml.levels[0].A.m
     t0 = time.perf_counter()
     cycles = 0
     while True:
-        oh.precond(b)
+        z = oh.precond(b)
         cycles += 1
         el = time.perf_counter() - t0
         if el >= budget_s or el / cycles * (cycles + 1) > 1.5 * budget_s:
             break
     return {"value": n * cycles / el, "unit": "unknowns/s", "cores": 1, "kind": "port",
+            "cpu": cpu_model(), "host_cpus": os.cpu_count(),
             "sample": f"{cycles} V-cycle(s) (ldiv! semantics) of the same 3-D Poisson hierarchy, n={n}, "
-                      f"{el:.1f} s, 1 thread of {os.cpu_count()} host CPUs"}
+                      f"{el:.1f} s, 1 thread of {os.cpu_count()} host CPUs ({cpu_model()}); "
+                      "CPU restatement of the reference's _solve cycle (Julia is not installed), gcc -O3 -march=native"}, z
 
 
 def main():
@@ -91,6 +112,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--light", action="store_true", help="profiling runs: skip the extra smoother timing")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--force-dist", action="store_true", help="run the row-sharded driver even with one rank")
     args = ap.parse_args()
 
@@ -143,8 +165,28 @@ def main():
     # one presmoother application (fwd+bwd GS) on the fine level; skipped with --light because every
     # dependency level is a launch and rocprofv3's kernel tracing costs ~10 ms per dispatch
     sweep_ms = None if args.light else dev.bench_op(0, 4, reps=3, warmup=1)
+    # what the sweeps stream per cycle as executed (composite rows of the merged groups, slot padding, pre-pass
+    # triangles) next to what the algorithm needs (the level matrices, once per sweep)
+    sweeps = []
+    launches = stored = composite = tri = 0
+    alg_sweeps = 0
+    for l, lev in enumerate(ml.levels):
+        per = {}
+        for bwd in (False, True):
+            st = dev.gs_sweep_stats(l, bwd)
+            per["bwd" if bwd else "fwd"] = st
+            launches += 2 * st["launches"]                      # pre- and post-smoother run both directions
+            stored += 2 * max(st["slot_entries"], st["entries"])
+            composite += 2 * st["entries"]
+            tri += 2 * st["tri_entries"]
+        alg_sweeps += 4 * (lev.A.nnz * 12 + (lev.A.m + 1) * 4 + 24 * lev.A.m)
+        sweeps.append(per)
+    smooth_ms = None
+    if not args.light:
+        smooth_ms = 2.0 * sum(dev.bench_op(l, 4, reps=2, warmup=1) for l in range(len(ml.levels)))
 
     vb = vcycle_bytes(ml, 4)
+    traffic, traffic_how = pmc_traffic(N, enabled=not args.no_pmc and not args.light)
     out = {
         "metric": f"V-cycle unknowns/sec + fine-level SpMV GB/s (% HBM peak), 3-D Poisson {N}^3",
         "value": value, "unit": "unknowns/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -162,15 +204,38 @@ def main():
                    "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<SPMV, StreamCfg<1024,1024,8192,4>> (fine-level A, %d rows, %d nnz)" % (n, A.nnz),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(N), "algorithmic_bytes": alg, "avg_launch_ms": spmv_ms,
+                     "traffic": traffic, "traffic_source": traffic_how, "algorithmic_bytes": alg, "avg_launch_ms": spmv_ms,
                      "fused_residual_ms": resid_ms,
                      "fused_residual_GBs": (alg + 8 * n) / (resid_ms * 1e-3) / 1e9},
         "vcycle": {"algorithmic_bytes": vb, "achieved_GBs": vb / (ms_per_step * 1e-3) / 1e9,
+                   "frac_of_hbm_peak": vb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                    "fine_symmetric_gs_ms": sweep_ms},
+        # second roofline entry: the kernels that dominate the CYCLE (Gauss-Seidel sweeps: gs_slot / gs_bigslot /
+        # chain / block launches + pre-pass), latency-bound — one launch per merged group of dependency levels
+        "sweep_roofline": {
+            "bound": "hbm", "kernel": "gs_slot_kernel / gs_bigslot_kernel (merged dependency-level groups), all levels, "
+                                      "pre + post smoother, both directions",
+            "launches_per_cycle": launches, "entries_streamed_per_cycle": stored, "composite_entries_per_cycle": composite,
+            "prepass_entries_per_cycle": tri,
+            "bytes_streamed_per_cycle": 12 * (stored + tri), "algorithmic_bytes_per_cycle": alg_sweeps,
+            "inflation": 12 * (stored + tri) / alg_sweeps,
+            "smoother_ms_per_cycle": smooth_ms,
+            "avg_launch_us": None if smooth_ms is None else 1e3 * smooth_ms / max(1, launches),
+            "achieved": None if smooth_ms is None else alg_sweeps / (smooth_ms * 1e-3) / 1e9,
+            "streamed_GBs": None if smooth_ms is None else 12 * (stored + tri) / (smooth_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None if smooth_ms is None else alg_sweeps / (smooth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "per_level": [{"fwd": p["fwd"], "bwd": p["bwd"]} for p in sweeps[:6]]},
         "setup_s": t_setup, "upload_s": t_upload, "hbm_bytes": dev.device_bytes(),
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ml, b, args.cpu_budget)
+        out["cpu_baseline"], z_oracle = cpu_baseline(ml, b, args.cpu_budget)
+        # parity of the TIMED result (checked outside the timed region): the last V-cycle's output against the oracle
+        z = zd.download()
+        err = float(np.linalg.norm(z - z_oracle) / np.linalg.norm(z_oracle))
+        out["parity"] = {"rel_err_vs_oracle": err, "tolerance": 1e-10, "what": "||z - z_oracle|| / ||z_oracle|| of the last timed V-cycle"}
+        if not err <= 1e-10:
+            raise SystemExit(f"bench.py: the timed V-cycle differs from the oracle: rel.err {err:.3e} > 1e-10")
     print(json.dumps(out))
 
 

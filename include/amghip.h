@@ -129,6 +129,10 @@ int amgh_gs_num_dependency_levels(const amgh_t* h, int l);
 /* Sequential steps one Gauss-Seidel sweep over level l takes as executed: merged groups of dependency levels
  * (DESIGN.md section 4), 128-row block steps on the block-inverse path, or the dependency levels themselves. */
 int amgh_gs_num_sweep_steps(const amgh_t* h, int l, int backward);
+/* What one Gauss-Seidel sweep over level l streams, as executed (bench.py's sweep roofline):
+ * out6 = {launches, rows, entries of the (composite) rows, entries the slot launches read incl. zero padding,
+ *         entries of the pre-pass triangle (merged sweeps), dependency levels per merged group (1 = unmerged)}.   */
+int amgh_gs_sweep_stats(const amgh_t* h, int l, int backward, int64_t* out6);
 
 /* ------------------------------------------------------------------------- */
 /* Solve phase                                                                  */

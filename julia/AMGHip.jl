@@ -1,25 +1,28 @@
 # AMGHip.jl — the reference-side binding a maintainer of AlgebraicMultigrid.jl would add to run the
 # solve phase on MI355X through libamghip's C ABI (include/amghip.h).
 #
-# NOT EXECUTED in this repository: there is no Julia toolchain on the build or GPU machines
-# (SURVEY.md §0).  It is written against Julia >= 1.6 semantics and the reference's v2.0.0
-# sources; the same call sequence is exercised from Python (algebraicmultigrid.jl_amd/device.py),
-# which is the tested boundary.  See INTEGRATION.md.
+# A SKETCH: NEVER EXECUTED in this repository — there is no Julia toolchain on the build or GPU machines
+# (SURVEY.md §0).  It is written against Julia >= 1.6 semantics and the reference's v2.0.0 sources; the
+# same call sequence is exercised from Python (algebraicmultigrid.jl_amd/device.py, sharded.py), which is
+# the tested boundary.  See INTEGRATION.md.
 #
-# Design: the hierarchy is built by the reference's own setup (`ruge_stuben`,
-# `smoothed_aggregation`) unchanged.  `hip(ml)` uploads it once and returns a `MultiLevel` whose
-# workspace type parameter TW is `HipWorkspace`; two methods specialised on that type forward
-# `_solve!` and the smoother / mul! hooks to the C ABI, so `_solve(ml, b)`, `aspreconditioner(ml)`,
-# `ldiv!`, `\`, `solve(A, b, RugeStubenAMG())` keep their exact signatures (multilevel.jl:152-198,
-# preconditioner.jl:10-24).
+# Design: the hierarchy is built by the reference's own setup (`ruge_stuben`, `smoothed_aggregation`)
+# unchanged.  `hip(ml)` uploads it once and returns a `MultiLevel` whose workspace type parameter TW is
+# `HipWorkspace`.  ONE method specialised on that type forwards `_solve!` to the C ABI, so `_solve(ml, b)`,
+# `aspreconditioner(ml)`, `ldiv!`, `\`, `solve(A, b, RugeStubenAMG())` (CommonSolve `init` / `solve!`) keep
+# their exact signatures (multilevel.jl:152-198,252-264, preconditioner.jl:10-24).  The per-level hooks of
+# the reference (`smooth!(x, s, b)`, `mul!(y, A, x)`) dispatch on smoother caches and matrix types that are
+# NOT replaced here (the levels keep their host matrices); their device counterparts are exposed as plain
+# functions `level_smooth!` / `level_mul!` instead of new `smooth!` / `mul!` methods.
 module AMGHip
 
 using AlgebraicMultigrid
 using SparseArrays, LinearAlgebra
+using Printf
 import AlgebraicMultigrid: MultiLevel, Level, _solve!, Cycle, V, W, F, GaussSeidel, Jacobi, SOR,
                            ForwardSweep, BackwardSweep, SymmetricSweep, Pinv, QRSolver,
                            HermitianSymmetry, NoSymmetry, FastGSSmoother, FastJacobiSmoother,
-                           FastSORSmoother
+                           FastSORSmoother, aspreconditioner, ruge_stuben, smoothed_aggregation
 
 const libamghip = get(ENV, "LIBAMGHIP", "libamghip.so")
 
@@ -40,11 +43,17 @@ csmoother(s::FastJacobiSmoother) = CSmoother(2, 2, s.iter, 0, Float64(s.ω))
 csmoother(s::FastSORSmoother{S}) where {S} = CSmoother(3, sweepcode(S()), s.iter, 0, Float64(s.ω))
 # NoSymmetry caches map to the same kernels on the true rows (S == A); see amgh_push_level.
 
-"""Workspace type that marks a MultiLevel as resident on the GPU (replaces MultiLevelWorkspace)."""
+"""
+Workspace type that marks a MultiLevel as resident on the GPU (replaces MultiLevelWorkspace{TX,bs}).
+`keep` holds everything the library may call back into or read later (the coarse-solver closure and its
+`@cfunction` trampoline): they must live as long as the handle.
+"""
 mutable struct HipWorkspace
     handle::Ptr{Cvoid}
-    function HipWorkspace(h)
-        w = new(h)
+    bs::Int
+    keep::Vector{Any}
+    function HipWorkspace(h, bs, keep)
+        w = new(h, bs, keep)
         finalizer(w -> ccall((:amgh_destroy, libamghip), Cvoid, (Ptr{Cvoid},), w.handle), w)
     end
 end
@@ -56,13 +65,15 @@ csr(X::SparseMatrixCSC) = csr_of_transpose(copy(X'))
 csr(X::Adjoint{<:Any,<:SparseMatrixCSC}) = csr_of_transpose(parent(X))   # lazy adjoint: arrays are already the CSR
 
 """
-    hip(ml::MultiLevel; device = 0) -> MultiLevel
+    hip(ml::MultiLevel; device = 0, bs = 1) -> MultiLevel
 
 Upload the hierarchy to HBM (amgh_create / amgh_push_level / amgh_set_coarse / amgh_finalize).
+`bs` = workspace block size (the reference's `Val{bs}`, multilevel.jl:28-35): `_solve!` then takes n x bs blocks.
 """
-function hip(ml::MultiLevel; device::Integer = 0, symmetry = HermitianSymmetry())
+function hip(ml::MultiLevel; device::Integer = 0, bs::Integer = 1, symmetry = HermitianSymmetry())
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:amgh_create, libamghip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint), h, device, 1))
+    keep = Any[]
+    check(ccall((:amgh_create, libamghip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint), h, device, bs))
     for lev in ml.levels
         A = lev.A
         n, nc = size(lev.P)
@@ -84,22 +95,26 @@ function hip(ml::MultiLevel; device::Integer = 0, symmetry = HermitianSymmetry()
     fr, fc, fv = csr(fA)
     cs = ml.coarse_solver
     if n <= 2048
-        # Pinv: the stored pinv(Matrix(A)) (coarse_solver.jl:11); otherwise the dense inverse standing in
-        # for the factorisation solve (coarse_solver.jl:75-81)
-        op = cs isa Pinv ? Matrix{Float64}(cs.pinvA) : Matrix{Float64}(inv(Matrix(fA)))
+        # Pinv: the stored pinv(Matrix(A)) (coarse_solver.jl:11).  QRSolver (coarse_solver.jl:66-81) solves with a
+        # pivoted QR, i.e. least squares when final_A is singular: its dense stand-in is the pseudo-inverse too,
+        # NOT inv(), which throws on a singular coarse matrix (e.g. the pure-Neumann Poisson problem).
+        op = cs isa Pinv ? Matrix{Float64}(cs.pinvA) : Matrix{Float64}(pinv(Matrix(fA)))
         check(ccall((:amgh_set_coarse, libamghip), Cint,
                     (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), h[], n, fr, fc, fv, op))
     else
-        # pluggable host coarse solver: the reference's `(cs)(x, b)` protocol through a C callback
-        cb = @cfunction($((user, b, x, n) -> begin
-                 cs(unsafe_wrap(Array, x, n), unsafe_wrap(Array, b, n)); Cint(0)
-             end), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64))
+        # pluggable host coarse solver: the reference's `(cs)(x, b)` protocol through a C callback.  The closure
+        # and its trampoline are stored in the workspace: the library calls them on every coarse solve.
+        closure = (user, b, x, n) -> begin
+            cs(unsafe_wrap(Array, x, n), unsafe_wrap(Array, b, n)); Cint(0)
+        end
+        cb = @cfunction($closure, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64))
+        push!(keep, closure, cb, cs)
         check(ccall((:amgh_set_coarse_host, libamghip), Cint,
                     (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}),
                     h[], n, fr, fc, fv, cb, C_NULL))
     end
     check(ccall((:amgh_finalize, libamghip), Cint, (Ptr{Cvoid},), h[]))
-    MultiLevel(ml.levels, ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother, HipWorkspace(h[]))
+    MultiLevel(ml.levels, ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother, HipWorkspace(h[], Int(bs), keep))
 end
 
 cyclecode(::V) = Cint(0); cyclecode(::W) = Cint(1); cyclecode(::F) = Cint(2)
@@ -107,25 +122,71 @@ cyclecode(::V) = Cint(0); cyclecode(::W) = Cint(1); cyclecode(::F) = Cint(2)
 const HipML = MultiLevel{<:Any,<:Any,<:Any,<:Any,<:Any,<:Any,HipWorkspace}
 
 # _solve!(x, ml, b, cycle; maxiter, abstol, reltol, verbose, log, calculate_residual)  multilevel.jl:158-198
-function AlgebraicMultigrid._solve!(x, ml::HipML, b::AbstractVector{Float64}, cycle::Cycle = V();
+# b, x: vectors (bs = 1) or n x bs matrices — Julia's column-major layout is what amgh_solve takes.
+function AlgebraicMultigrid._solve!(x::AbstractVecOrMat{Float64}, ml::HipML, b::AbstractVecOrMat{Float64},
+                                    cycle::Cycle = V();
                                     maxiter::Int = 100, abstol::Real = 0.0, reltol::Real = sqrt(eps(Float64)),
                                     verbose::Bool = false, log::Bool = false, calculate_residual = true, kwargs...)
+    size(b, 2) == ml.workspace.bs ||
+        throw(DimensionMismatch("hierarchy was uploaded with block size $(ml.workspace.bs), b has $(size(b, 2)) columns"))
+    size(x) == size(b) || throw(DimensionMismatch("x and b differ in size"))
+    xs, bsd = Array{Float64}(x), Array{Float64}(b)     # dense, contiguous
     hist = zeros(Float64, maxiter + 1)
     iters = Ref{Cint}(0)
     check(ccall((:amgh_solve, libamghip), Cint,
                 (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Float64, Float64, Cint, Ptr{Float64}, Ref{Cint}),
-                ml.workspace.handle, b, x, cyclecode(cycle), maxiter, abstol, reltol, calculate_residual, hist, iters))
+                ml.workspace.handle, bsd, xs, cyclecode(cycle), maxiter, abstol, reltol, calculate_residual, hist, iters))
+    copyto!(x, xs)
     if verbose && calculate_residual
         for i in 1:iters[]
-            Printf.@printf "Norm of residual at iteration %6d is %.4e\n" i hist[i]
+            @printf "Norm of residual at iteration %6d is %.4e\n" i hist[i + 1]
         end
     end
     log ? (x, hist[1:(calculate_residual ? iters[] + 1 : 1)]) : x
 end
 
 # `aspreconditioner(ml)`, `ldiv!`, `\` need no new methods: preconditioner.jl:12-19 calls `_solve!` with
-# maxiter = 1, calculate_residual = false, which lands in the method above.  A Krylov loop that wants to
-# stay on the device uses amgh_pcg / amgh_precond_apply_d directly:
+# maxiter = 1, calculate_residual = false, which lands in the method above.  CommonSolve's
+# `solve(A, b, RugeStubenAMG())` = `init` + `solve!` (multilevel.jl:252-264) runs on the GPU once `init` wraps
+# the hierarchy:
+struct HipRugeStubenAMG <: AlgebraicMultigrid.AMGAlg end
+struct HipSmoothedAggregationAMG <: AlgebraicMultigrid.AMGAlg end
+AlgebraicMultigrid.init(::HipRugeStubenAMG, A, b, args...; kwargs...) =
+    AlgebraicMultigrid.AMGSolver(hip(ruge_stuben(A; kwargs...)), b)
+AlgebraicMultigrid.init(::HipSmoothedAggregationAMG, A, b; kwargs...) =
+    AlgebraicMultigrid.AMGSolver(hip(smoothed_aggregation(A; kwargs...)), b)
+
+# LinearSolve `precs` builders (precs.jl:7-38): `(builder)(A, p) -> (Pl, I)`
+struct HipRugeStubenPreconBuilder{Tk}
+    blocksize::Int
+    kwargs::Tk
+end
+HipRugeStubenPreconBuilder(; blocksize = 1, kwargs...) = HipRugeStubenPreconBuilder(blocksize, kwargs)
+(b::HipRugeStubenPreconBuilder)(A::SparseArrays.AbstractSparseMatrixCSC, p) =
+    (aspreconditioner(hip(ruge_stuben(SparseMatrixCSC(A), Val{b.blocksize}; b.kwargs...); bs = b.blocksize)), I)
+struct HipSmoothedAggregationPreconBuilder{Tk}
+    blocksize::Int
+    kwargs::Tk
+end
+HipSmoothedAggregationPreconBuilder(; blocksize = 1, kwargs...) = HipSmoothedAggregationPreconBuilder(blocksize, kwargs)
+(b::HipSmoothedAggregationPreconBuilder)(A::SparseArrays.AbstractSparseMatrixCSC, p) =
+    (aspreconditioner(hip(smoothed_aggregation(SparseMatrixCSC(A), Val{b.blocksize}; b.kwargs...); bs = b.blocksize)), I)
+
+# Per-level hooks on the device (the counterparts of `smooth!(x, levels[l].presmoother, b)` and
+# `mul!(y, levels[l].A | P | R, x)`, multilevel.jl:216-236): plain functions, see the header.
+function level_smooth!(x::Vector{Float64}, ml::HipML, level::Integer, b::Vector{Float64}; post::Bool = false)
+    check(ccall((:amgh_level_smooth, libamghip), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}),
+                ml.workspace.handle, level - 1, post, x, b))
+    x
+end
+function level_mul!(y::Vector{Float64}, ml::HipML, level::Integer, which::Symbol, x::Vector{Float64})
+    code = which === :A ? 0 : which === :P ? 1 : which === :R ? 2 : throw(ArgumentError("which must be :A, :P or :R"))
+    check(ccall((:amgh_level_spmv, libamghip), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}),
+                ml.workspace.handle, level - 1, code, x, y))
+    y
+end
+
+# A Krylov loop that wants to stay on the device uses amgh_pcg / amgh_precond_apply_d directly:
 function cg(ml::HipML, b::Vector{Float64}; cycle::Cycle = V(), maxiter::Int = length(b), abstol = 0.0,
             reltol = sqrt(eps(Float64)))
     x = zeros(length(b)); iters = Ref{Cint}(0)
@@ -134,5 +195,73 @@ function cg(ml::HipML, b::Vector{Float64}; cycle::Cycle = V(), maxiter::Int = le
                 ml.workspace.handle, b, x, cyclecode(cycle), 1, maxiter, abstol, reltol, C_NULL, iters))
     x
 end
+
+# ---- row-sharded hierarchy over N GPUs (amgh_dist_*, include/amghip.h) ----------------------------------------
+# One Julia process per GPU (e.g. under MPI.jl).  Rank 0 makes the RCCL id, the host broadcasts its 128 bytes
+# (`MPI.Bcast!`), every rank pushes ITS rows of the sharded levels with global column indices, rank 0 passes
+# the collapsed levels as an ordinary uploaded hierarchy.
+rccl_unique_id() = (id = zeros(UInt8, 128); check(ccall((:amgh_dist_unique_id, libamghip), Cint, (Ptr{UInt8},), id)); id)
+
+mutable struct HipSharded
+    handle::Ptr{Cvoid}
+    tail::Union{Nothing,MultiLevel}     # keeps the collapsed levels' handle alive
+    r0::Int; r1::Int                    # this rank's fine rows (0-based, half open)
+end
+
+rowcuts(n, N) = Int64[div(p * n, N) for p in 0:N]
+function localrows(M::SparseMatrixCSC, r0, r1)      # rows [r0, r1) of M' as CSR with global columns (= columns of M)
+    lo, hi = M.colptr[r0 + 1], M.colptr[r1 + 1] - 1
+    (Int32.(M.colptr[r0 + 1:r1 + 1] .- lo), Int32.(M.rowval[lo:hi] .- 1), Float64.(M.nzval[lo:hi]))
+end
+
+"""
+    hip_sharded(ml, rank, nranks, id; device = rank, shard_min_rows = 200_000) -> HipSharded
+
+Levels with at least `shard_min_rows` rows are partitioned by contiguous row ranges; the rest is uploaded on rank 0
+(`hip`) and handed over with amgh_dist_set_tail.  Assumes symmetric level operators (A' = A), as the sharded
+Python driver does.
+"""
+function hip_sharded(ml::MultiLevel, rank::Integer, nranks::Integer, id::Vector{UInt8}; device::Integer = rank,
+                     shard_min_rows::Integer = 200_000)
+    d = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:amgh_dist_create_rccl, libamghip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Ptr{UInt8}),
+                d, device, rank, nranks, id))
+    sizes = [[size(l.A, 1) for l in ml.levels]; size(ml.final_A, 1)]
+    lc = 0
+    while lc < length(ml.levels) && sizes[lc + 1] >= shard_min_rows && sizes[lc + 1] >= 8 * nranks
+        lc += 1
+    end
+    for l in 1:lc
+        lev = ml.levels[l]
+        n, nc = sizes[l], sizes[l + 1]
+        cuts = rowcuts(n, nranks)
+        ccuts = l < lc ? rowcuts(nc, nranks) : Int64[0; fill(nc, nranks)]
+        r0, r1, c0, c1 = cuts[rank + 1], cuts[rank + 2], ccuts[rank + 1], ccuts[rank + 2]
+        Ar, Ac, Av = localrows(lev.A, r0, r1)                          # A symmetric: CSC columns are the rows
+        Pr, Pc, Pv = localrows(SparseMatrixCSC(lev.P'), r0, r1)        # rows of P = columns of P'
+        Rr, Rc, Rv = localrows(SparseMatrixCSC(lev.R'), c0, c1)
+        pre, post = Ref(csmoother(lev.presmoother)), Ref(csmoother(lev.postsmoother))
+        GC.@preserve cuts ccuts Ar Ac Av Pr Pc Pv Rr Rc Rv check(ccall((:amgh_dist_push_level, libamghip), Cint,
+            (Ptr{Cvoid}, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+             Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
+             Ref{CSmoother}, Ref{CSmoother}),
+            d[], n, nc, cuts, ccuts, Ar, Ac, Av, C_NULL, C_NULL, C_NULL, Pr, Pc, Pv, Rr, Rc, Rv, pre, post))
+    end
+    tail = nothing
+    if rank == 0
+        tail = hip(MultiLevel(ml.levels[lc + 1:end], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
+                              ml.workspace); device = device)
+        check(ccall((:amgh_dist_set_tail, libamghip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), d[], tail.workspace.handle))
+    end
+    check(ccall((:amgh_dist_finalize, libamghip), Cint, (Ptr{Cvoid},), d[]))
+    cuts0 = rowcuts(sizes[1], nranks)
+    s = HipSharded(d[], tail, lc > 0 ? cuts0[rank + 1] : (rank == 0 ? 0 : sizes[1]), lc > 0 ? cuts0[rank + 2] : sizes[1])
+    finalizer(s -> ccall((:amgh_dist_destroy, libamghip), Cvoid, (Ptr{Cvoid},), s.handle), s)
+end
+
+# device pointers in (this rank's rows), one V / W / F cycle with x = 0 (ldiv!)
+precond_apply_d!(s::HipSharded, r_d::Ptr{Float64}, z_d::Ptr{Float64}, cycle::Cycle = V()) =
+    check(ccall((:amgh_dist_precond_apply_d, libamghip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint),
+                s.handle, r_d, z_d, cyclecode(cycle)))
 
 end # module

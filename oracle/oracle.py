@@ -22,10 +22,31 @@ class orc_smoother_t(C.Structure):
                 ("omega", C.c_double)]
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def build(force=False):
+    """(Re)build liboracle.so.  It is compiled -O3 -march=native and travels prebuilt from the build container to the
+    GPU box: the CPU it was built on is recorded next to it, and a different CPU (or newer sources / Makefile)
+    triggers a rebuild instead of running code tuned for another machine."""
     src = os.path.join(_HERE, "amg_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    mk = os.path.join(_HERE, "Makefile")
+    tag = _SO + ".cpu"
+    built_for = open(tag).read().strip() if os.path.exists(tag) else None
+    stale = (not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(mk))
+             or built_for != cpu_model())
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+        with open(tag, "w") as f:
+            f.write(cpu_model() + "\n")
     return _SO
 
 

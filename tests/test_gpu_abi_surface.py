@@ -1,0 +1,141 @@
+"""Entry points of include/amghip.h that no other GPU test calls directly: the reductions (amgh_dot_d, the norm
+inside _solve), the TimerOutputs-style profile (amgh_profile_enable / _read), the HIP-event timer
+(amgh_timer_begin / _end), hipGraph replay of whole cycles (amgh_set_use_graph), the sweep statistics
+(amgh_gs_sweep_stats), and W / F cycles at a size where every sweep path (slots, long-row slots, chains, block
+inverses) is in use."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import amg_amd as AMG
+from conftest import uniform
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(x, y):
+    return np.linalg.norm(np.asarray(x) - np.asarray(y)) / max(np.linalg.norm(y), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def h128():
+    A = AMG.poisson((128, 128, 128))
+    ml = AMG.ruge_stuben(A)
+    return A, ml, ml.device()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 262144 + 17, 4_000_003])
+def test_dot_and_norm_against_a_compensated_host_sum(n):
+    """amgh_dot_d (two-pass wavefront reduction, fixed grid) vs math.fsum (exactly rounded): the pairwise-ish device
+    sum must stay within 4 ulp * sqrt(n) of sum |x_i y_i| — and give the same bits on every call."""
+    lib = AMG.hip_lib()
+    x = uniform(n, 11) - 0.5
+    y = uniform(n, 12) * 3.0 - 1.0
+    xd, yd = AMG.DeviceBuffer(n, 0, x), AMG.DeviceBuffer(n, 0, y)
+    scratch = AMG.DeviceBuffer(1100, 0)
+    out = C.c_double(0)
+    vals = []
+    for _ in range(3):
+        assert lib.amgh_dot_d(0, n, xd.ptr, yd.ptr, scratch.ptr, C.byref(out), None) == 0
+        vals.append(out.value)
+    assert vals[0] == vals[1] == vals[2]
+    ref = math.fsum((x * y).tolist())
+    bound = 4.0 * np.finfo(np.float64).eps * math.sqrt(n) * float(np.sum(np.abs(x * y)))
+    assert abs(vals[0] - ref) <= bound
+    assert lib.amgh_dot_d(0, n, xd.ptr, xd.ptr, scratch.ptr, C.byref(out), None) == 0
+    ref2 = math.fsum((x * x).tolist())
+    assert abs(out.value - ref2) <= 4.0 * np.finfo(np.float64).eps * math.sqrt(n) * ref2
+
+
+def test_solve_history_is_the_norm_of_the_true_residual(h128):
+    """norm(b) and norm(b - A x) of _solve! (multilevel.jl:170,190) against fsum-based norms of host vectors."""
+    A, ml, dev = h128
+    b = uniform(A.m, 3)
+    x, hist = AMG._solve(ml, b, maxiter=2, reltol=1e-30, log=True)
+    nb = math.sqrt(math.fsum((b * b).tolist()))
+    assert abs(hist[0] - nb) <= 1e-13 * nb
+    r = b - A.to_scipy() @ x
+    nr = math.sqrt(math.fsum((r * r).tolist()))
+    assert abs(hist[-1] - nr) <= 1e-9 * nr      # (the host SpMV rounds differently: 1e-9 on a residual 1e-1 below b)
+
+
+def test_profile_labels_cover_the_cycle(h128):
+    """The six TimerOutputs labels (multilevel.jl:180,216-236) per level: every level reports both smoothers, residual,
+    restriction and prolongation; the coarse solve sits on the last level only; the labelled times add up to the
+    HIP-event time of the whole cycle (within 5 %: what is not labelled is one memset per level)."""
+    A, ml, dev = h128
+    lib = dev.lib
+    n = A.m
+    bd, zd = AMG.DeviceBuffer(n, 0, uniform(n, 0)), AMG.DeviceBuffer(n, 0)
+    for _ in range(2):
+        assert lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0) == 0
+    lib.amgh_dev_sync(0)
+    dev.profile(True)
+    dev.profile_read(reset=True)
+    cycles = 3
+    dev.timer_begin()
+    for _ in range(cycles):
+        assert lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0) == 0
+    total_ms = dev.timer_end()
+    prof = dev.profile_read()
+    dev.profile(False)
+    L = len(ml.levels)
+    assert list(prof) == ["Presmoother", "Residual eval", "Restriction", "Coarse solve", "Prolongation", "Postsmoother"]
+    for lab in ("Presmoother", "Residual eval", "Restriction", "Prolongation", "Postsmoother"):
+        assert np.all(prof[lab][:L] > 0) and prof[lab][L] == 0
+    assert np.all(prof["Coarse solve"][:L] == 0) and prof["Coarse solve"][L] > 0
+    labelled = sum(float(v.sum()) for v in prof.values())
+    assert abs(labelled - total_ms) <= 0.05 * total_ms, (labelled, total_ms)
+    assert prof["Presmoother"][0] + prof["Postsmoother"][0] > 0.1 * labelled   # the fine-level sweeps dominate
+
+
+def test_graph_replay_is_bitwise_the_eager_cycle(h128):
+    A, ml, dev = h128
+    lib = dev.lib
+    n = A.m
+    bd, zd = AMG.DeviceBuffer(n, 0, uniform(n, 4)), AMG.DeviceBuffer(n, 0)
+    assert lib.amgh_set_use_graph(dev.h, 0) == 0
+    assert lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0) == 0
+    lib.amgh_dev_sync(0)
+    eager = zd.download()
+    assert lib.amgh_set_use_graph(dev.h, 1) == 0
+    got = []
+    for _ in range(4):      # eager warm-up, capture + first replay, replays
+        assert lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0) == 0
+        lib.amgh_dev_sync(0)
+        got.append(zd.download())
+    assert lib.amgh_set_use_graph(dev.h, 0) == 0
+    for z in got:
+        assert np.array_equal(z, eager)
+    # a whole solve through cached graphs (cycle + residual per iteration)
+    b = uniform(n, 5)
+    x0, h0 = AMG._solve(ml, b, reltol=1e-6, log=True)
+    lib.amgh_set_use_graph(dev.h, 1)
+    x1, h1 = AMG._solve(ml, b, reltol=1e-6, log=True)
+    lib.amgh_set_use_graph(dev.h, 0)
+    assert np.array_equal(x0, x1) and np.array_equal(h0, h1)
+
+
+def test_sweep_stats_describe_the_schedule(h128):
+    A, ml, dev = h128
+    st = dev.gs_sweep_stats(0, False)
+    assert st["rows"] == A.m and 1 <= st["launches"] <= dev.gs_sweep_steps(0, False)   # narrow groups chain into one launch
+    assert st["entries"] > 0 and st["slot_entries"] >= 0
+    if st["levels_per_group"] > 1:      # merged groups: composite rows + the other triangle as a pre-pass
+        assert st["tri_entries"] > 0 and st["entries"] >= (A.nnz - A.m) // 2
+    assert dev.gs_dependency_levels(0) == 3 * 128 - 2
+
+
+@pytest.mark.parametrize("cyc", [1, 2])
+def test_w_and_f_cycles_at_128_cubed(h128, cyc):
+    A, ml, dev = h128
+    b = uniform(A.m, 6)
+    oh = O.OracleHierarchy(ml)
+    cycle = {1: AMG.W(), 2: AMG.F()}[cyc]
+    x, hist = AMG._solve(ml, b, cycle, maxiter=3, reltol=1e-30, log=True)
+    xo, ho, _ = oh.solve(b, cycle=cyc, maxiter=3, reltol=1e-30)
+    assert len(hist) == len(ho) == 4 and np.allclose(hist, ho, rtol=1e-8)
+    assert rel(x, xo) <= 1e-10

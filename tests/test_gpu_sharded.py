@@ -11,7 +11,7 @@ import pytest
 import amg_amd as AMG
 from amg_amd import sharded as SH
 from conftest import uniform
-from dist_backends import OracleOps, run_virtual_ranks
+from dist_backends import OracleOps, emulate_sharded_cycles, run_virtual_ranks
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -99,8 +99,11 @@ def test_hybrid_gauss_seidel_matches_the_frozen_halo_emulation_per_cycle(nranks)
     ml = AMG.ruge_stuben(A)
     got = sharded_cycles(ml, b, nranks, 4000, 3)
     want = emulated_cycles(ml, b, nranks, 4000, 3)
+    lc = SH.num_sharded_levels([l.A.m for l in ml.levels] + [ml.final_A.m], nranks, 4000)
+    want2 = emulate_sharded_cycles(ml, b, nranks, lc, 3)   # the global-matrix emulation the full-size test uses
     for k in range(3):
         assert rel(got[k], want[k]) <= 1e-10, (nranks, k)
+        assert rel(want2[k], want[k]) <= 1e-12, (nranks, k)
     # and the hybrid converges to the same solution as the exact lexicographic sweep, in about as many cycles
     x, hist, lc, _ = sharded_solve(ml, b, nranks, 4000, reltol=1e-10, maxiter=60)
     xo, ho, _ = O.OracleHierarchy(ml).solve(b, reltol=1e-10, maxiter=60)
