@@ -1140,6 +1140,8 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_block_inverse")) g_gs_block_inverse = value;
   else if (!strcmp(name, "gs_slots")) g_gs_slots = value;
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
+  else if (!strcmp(name, "gs_lpr")) g_gs_lpr = value;
+  else if (!strcmp(name, "gs_ept")) g_gs_ept = value;
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_bigslot")) g_gs_bigslot = value;
   else if (!strcmp(name, "gs_flip")) g_gs_flip = value;

@@ -623,6 +623,63 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
   }
 }
 
+// The same slot launch with LPR lanes per row in the row sums: a composite row of 30-100 entries summed by ONE thread
+// is 30-100 dependent LDS reads + adds while 500 threads of the workgroup idle; LPR lanes take the entries LPR apart
+// and a __shfl_xor tree adds the partial sums.  Changes the order of the additions (not the scalar loop's any more):
+// used for merged groups only, whose composite rows already differ from the scalar recurrence at the 1e-16 level.
+// EPT = 2: 256 threads, two consecutive entries per thread (one 16-byte + one 8-byte load): twice as many
+// workgroups are resident per CU, so that a group of more than ~1000 slots still runs in one residency round.
+template <bool SOR, int LPR, int EPT>
+__global__ __launch_bounds__(kSlot / EPT) void gs_slot_lpr_kernel(SlotArgs a) {
+  static_assert(LPR >= 1 && LPR <= 32 && (LPR & (LPR - 1)) == 0, "lanes per row: a power of two inside one wave");
+  static_assert(EPT == 1 || EPT == 2, "entries per thread");
+  constexpr int T = kSlot / EPT;
+  __shared__ double s_prod[kSlot];
+  const int tid = threadIdx.x;
+  int lb = blockIdx.x;
+  if (a.xcd_map) lb = xcd_block(lb, a.nslots);
+  if (lb >= a.nslots) return;
+  const int s = a.slot0 + lb;
+  const int base = s * kSlot;
+  double v[EPT], xv[EPT];
+  int c[EPT];
+  if (EPT == 1) {
+    v[0] = a.wval[base + tid]; c[0] = a.wcol[base + tid];
+  } else {
+    const d2_t vv = *(const d2_t*)(a.wval + base + 2 * tid);
+    const i2_t cc = *(const i2_t*)(a.wcol + base + 2 * tid);
+    v[0] = vv.x; v[EPT - 1] = vv.y; c[0] = cc.x; c[EPT - 1] = cc.y;
+  }
+  const int r0 = a.slot_row[2 * s], nrows = a.slot_row[2 * s + 1] - r0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) xv[e] = a.x[c[e]];
+  constexpr int RPP = T / LPR;  // rows per pass
+  const int sub = tid % LPR;
+  int r = tid / LPR;
+  i4_t m = i4_t{0, 0, -1, 0};
+  double d = 0.0, bb = 0.0;
+  if (r < nrows) { m = a.wmeta[r0 + r]; d = a.diag[r0 + r]; bb = a.bp[r0 + r]; }  // same round trip as the gather
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) s_prod[EPT * tid + e] = v[e] * xv[e];
+  __syncthreads();
+  for (int pass = 0; pass * RPP < nrows; ++pass, r += RPP) {
+    if (pass > 0) {
+      m = i4_t{0, 0, -1, 0}; d = 0.0; bb = 0.0;
+      if (r < nrows) { m = a.wmeta[r0 + r]; d = a.diag[r0 + r]; bb = a.bp[r0 + r]; }
+    }
+    double acc = 0.0;
+    const int dz = m.z - base, qe = m.y - base;
+    for (int q = m.x - base + sub; q < qe; q += LPR)
+      if (q != dz) acc += s_prod[q];
+#pragma unroll
+    for (int w = 1; w < LPR; w <<= 1) acc += __shfl_xor(acc, w, kWave);
+    if (sub == 0 && r < nrows && d != 0.0) {
+      const int i = r0 + r;
+      a.x[i] = SOR ? (1.0 - a.omega) * a.x[i] + (a.omega / d) * (bb - acc) : (bb - acc) / d;
+    }
+  }
+}
+
 // Long-row slots: composite rows of deeply merged groups have hundreds to ~2000 entries.  Same idea as
 // gs_slot_kernel with 2048 entries per slot (4 per thread) and at most 64 rows per slot; a row is summed by a
 // whole wave (entries interleaved over the 64 lanes: conflict-free LDS reads, a 1600-entry row is 26 steps +

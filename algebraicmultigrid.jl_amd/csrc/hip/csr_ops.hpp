@@ -120,6 +120,25 @@ int launch_slot_t(const SlotArgs& sa, bool sor, int grid, hipStream_t st) {
   else hipLaunchKernelGGL((gs_slot_kernel<false, NCV>), dim3(grid), dim3(kSlot), 0, st, sa);
   return AMGH_OK;
 }
+template <int LPR, int EPT>
+int launch_slot_lpr_t(const SlotArgs& sa, bool sor, int grid, hipStream_t st) {
+  if (sor) hipLaunchKernelGGL((gs_slot_lpr_kernel<true, LPR, EPT>), dim3(grid), dim3(kSlot / EPT), 0, st, sa);
+  else hipLaunchKernelGGL((gs_slot_lpr_kernel<false, LPR, EPT>), dim3(grid), dim3(kSlot / EPT), 0, st, sa);
+  return AMGH_OK;
+}
+template <int EPT>
+int launch_slot_lpr_e(const SlotArgs& sa, bool sor, int lpr, int grid, hipStream_t st) {
+  switch (lpr) {
+    case 1: return launch_slot_lpr_t<1, EPT>(sa, sor, grid, st);
+    case 2: return launch_slot_lpr_t<2, EPT>(sa, sor, grid, st);
+    case 4: return launch_slot_lpr_t<4, EPT>(sa, sor, grid, st);
+    case 8: return launch_slot_lpr_t<8, EPT>(sa, sor, grid, st);
+    default: return launch_slot_lpr_t<16, EPT>(sa, sor, grid, st);
+  }
+}
+int launch_slot_lpr(const SlotArgs& sa, bool sor, int lpr, int ept, int grid, hipStream_t st) {
+  return ept == 2 ? launch_slot_lpr_e<2>(sa, sor, lpr, grid, st) : launch_slot_lpr_e<1>(sa, sor, lpr, grid, st);
+}
 int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st) {
   switch (ncv) {
     case 8: return launch_slot_t<8>(sa, sor, grid, st);
@@ -315,6 +334,21 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       const int ncv = (ncolv % 8 == 0) ? 8 : (ncolv % 4 == 0) ? 4 : (ncolv % 2 == 0) ? 2 : 1;
       sa.ncolv = ncolv / ncv;
       const int grid = ((g_gs_xcd_map || sa.ncolv > 1) ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots) * sa.ncolv;
+      // merged groups with long composite rows: several lanes per row in the row sums (order of additions changes,
+      // so never on the unmerged schedule, which reproduces the scalar loop bit for bit)
+      int lpr = 1;
+      if (lay != g && ncolv == 1 && g_gs_lpr != 1) {
+        const int avg = s.rows / 16;  // mean row length of the group (schedule build time)
+        // measured on the 256^3 hierarchy (profiles/r02_gs_lpr_ept.log): 16 lanes pay from ~100 entries per row
+        // (-15 %), 8 lanes from ~50 (-3 %); 2 and 4 lanes on rows of 10-30 entries are slower than one thread
+        lpr = g_gs_lpr > 1 ? g_gs_lpr : (avg >= 96 ? 16 : avg >= 48 ? 8 : 1);
+      }
+      // more slots than 512-thread workgroups fit on the chip at once (4 per CU): 256-thread workgroups, 2 entries each
+      int ept = 1;
+      // (short rows only: -5 % on the fine level; with rows of ~27 entries the one-thread sums of the 256-thread
+      // variant cost more than the second residency round)
+      if (lay != g && ncolv == 1) ept = g_gs_ept > 0 ? g_gs_ept : ((s.nslots > 1024 && lpr == 1 && s.rows / 16 < 16) ? 2 : 1);
+      if (lpr > 1 || ept > 1) { RC_TRY(launch_slot_lpr(sa, sor, lpr, ept, grid, st)); HIP_TRY(hipGetLastError()); continue; }
       RC_TRY(launch_slot(sa, sor, ncv, grid, st));
       HIP_TRY(hipGetLastError());
     } else {

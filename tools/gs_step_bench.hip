@@ -174,6 +174,122 @@ Sell build_sell(const Layout& L, int K, int R, int LEN, int KL) {
   return S;
 }
 
+// ---- overlapped launches: consecutive groups on TWO streams, ordered by device-side counters instead of the kernel
+// boundary.  Group k's workgroups load their matrix entries and row data (independent of x) as soon as they are
+// resident — while group k-1 is still running — then wait until every workgroup of group k-1 has arrived on its
+// counters, gather x with agent-scope (sc1) loads, finish, store x write-through (sc1) and arrive.  Both grids are
+// capped so that two groups are always co-resident (no deadlock whatever the dispatch order); spins are bounded.
+constexpr int kNCnt = 64;
+struct DepArgs { Args a; unsigned* cnt_prev; unsigned* cnt_cur; unsigned target_prev; int* err; };
+__device__ __forceinline__ double ld_agent(const double* p) {
+  unsigned long long u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __longlong_as_double((long long)u);
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int T, int EPT>
+__global__ __launch_bounds__(T) void slot_dep_kernel(DepArgs d) {
+  constexpr int S = T * EPT;
+  __shared__ double s_prod[S];
+  __shared__ int s_ok;
+  const Args& a = d.a;
+  const int tid = threadIdx.x;
+  bool waited = false;
+  for (int lb0 = blockIdx.x; lb0 < a.nslots; lb0 += gridDim.x) {
+    const int lb = lb0;
+    const int s = a.slot0 + lb;
+    const long long base = a.ent0 + (long long)lb * S;
+    double v[EPT]; int c[EPT];
+    if (EPT == 1) { v[0] = a.wval[base + tid]; c[0] = a.wcol[base + tid]; }
+    else if (EPT == 2) {
+      const d2_t vv = *(const d2_t*)(a.wval + base + 2 * tid); const i2_t cc = *(const i2_t*)(a.wcol + base + 2 * tid);
+      v[0] = vv.x; v[1] = vv.y; c[0] = cc.x; c[1] = cc.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < EPT / 4; ++q) {
+        const long long o = base + 4 * (tid + q * T);
+        const d2_t v0 = *(const d2_t*)(a.wval + o), v1 = *(const d2_t*)(a.wval + o + 2); const i4_t cc = *(const i4_t*)(a.wcol + o);
+        v[4 * q] = v0.x; v[4 * q + 1] = v0.y; v[4 * q + 2] = v1.x; v[4 * q + 3] = v1.y;
+        c[4 * q] = cc.x; c[4 * q + 1] = cc.y; c[4 * q + 2] = cc.z; c[4 * q + 3] = cc.w;
+      }
+    }
+    const int r0 = a.slot_row[2 * s], r1 = a.slot_row[2 * s + 1];
+    const int nrows = r1 - r0;
+    i4_t m = i4_t{0, 0, -1, 0}; double dg = 0.0, bb = 0.0;
+    if (tid < nrows) { m = a.wmeta[r0 + tid]; dg = a.diag[r0 + tid]; bb = a.bp[r0 + tid]; }
+    if (!waited) {  // everything above is in flight while we wait for the previous group
+      waited = true;
+      if (d.cnt_prev) {
+        if (tid < 64) {
+          int spins = 0; bool ok = true;
+          for (;;) {
+            unsigned cval = tid < kNCnt ? __hip_atomic_load(d.cnt_prev + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+            for (int w = 1; w < 64; w <<= 1) cval += __shfl_xor(cval, w, 64);
+            if (cval >= d.target_prev) break;
+            if (++spins > (1 << 18)) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+          }
+          if (tid == 0) { s_ok = ok; if (!ok) *d.err = 1; }
+        }
+        __syncthreads();
+      }
+    }
+    double xv[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) xv[e] = ld_agent(a.x + c[e]);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int pos = (EPT <= 2) ? EPT * tid + e : 4 * (tid + (e / 4) * T) + (e & 3);
+      s_prod[pos] = v[e] * xv[e];
+    }
+    __syncthreads();
+    for (int t = tid; t < nrows; t += T) {
+      if (t != tid) { m = a.wmeta[r0 + t]; dg = a.diag[r0 + t]; bb = a.bp[r0 + t]; }
+      double acc = 0.0;
+      const int lo = (int)(m.x - base), hi = (int)(m.y - base);
+      for (int j = lo; j < hi; ++j) acc += s_prod[j];
+      if (dg != 0.0) st_agent(a.x + r0 + t, (bb - acc) / dg);
+    }
+    __syncthreads();  // s_prod is reused by the next slot of this workgroup
+  }
+  // arrive: every storing wave drains its write-through stores, then ONE lane counts the workgroup in
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(d.cnt_cur + (blockIdx.x % kNCnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int T, int EPT>
+double run_dep(const Layout& L, Args a, int K, int cap, bool two_streams, hipStream_t sa, hipStream_t sb, std::vector<double>* out, long long n,
+               const std::vector<double>& x0, int* herr) {
+  hipEvent_t e0, e1, eb; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&eb));
+  unsigned* cnt; int* err;
+  CHECK(hipMalloc(&cnt, sizeof(unsigned) * kNCnt * (K + 1))); CHECK(hipMalloc(&err, 4));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipMemcpyAsync(a.x, x0.data(), 8 * n, hipMemcpyHostToDevice, sa));
+    CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * kNCnt * (K + 1), sa)); CHECK(hipMemsetAsync(err, 0, 4, sa));
+    CHECK(hipStreamSynchronize(sa)); CHECK(hipStreamSynchronize(sb));
+    CHECK(hipEventRecord(e0, sa));
+    unsigned prev_grid = 0;
+    for (int k = 0; k < K; ++k) {
+      DepArgs d{}; d.a = a; d.a.ent0 = L.ent0[k]; d.a.nslots = L.nslots[k]; d.a.slot0 = L.slot0[k]; d.a.xcd = 0;
+      const int grid = std::min(L.nslots[k], cap);
+      d.cnt_prev = k ? cnt + (size_t)kNCnt * (k - 1) : nullptr; d.cnt_cur = cnt + (size_t)kNCnt * k; d.target_prev = prev_grid; d.err = err;
+      hipLaunchKernelGGL((slot_dep_kernel<T, EPT>), dim3(grid), dim3(T), 0, (two_streams && (k & 1)) ? sb : sa, d);
+      prev_grid = (unsigned)grid;
+    }
+    CHECK(hipEventRecord(eb, sb)); CHECK(hipStreamWaitEvent(sa, eb, 0));
+    CHECK(hipEventRecord(e1, sa)); CHECK(hipStreamSynchronize(sa)); CHECK(hipStreamSynchronize(sb));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+  }
+  CHECK(hipMemcpy(herr, err, 4, hipMemcpyDeviceToHost));
+  if (out) { out->resize(n); CHECK(hipMemcpy(out->data(), a.x, 8 * n, hipMemcpyDeviceToHost)); }
+  CHECK(hipFree(cnt)); CHECK(hipFree(err));
+  return 1e3 * best / K;
+}
+
 __global__ void empty_kernel(double* x) { if (x == nullptr) x[0] = 1.0; }
 
 
@@ -267,6 +383,7 @@ template <class Tv> Tv* up(const std::vector<Tv>& v) { Tv* p; CHECK(hipMalloc(&p
 int main(int argc, char** argv) {
   const int K = argc > 1 ? atoi(argv[1]) : 200;
   hipStream_t st; CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  hipStream_t st2; CHECK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
   // boundary alone: empty kernels, eager vs graph
   {
     double* dummy; CHECK(hipMalloc(&dummy, 8));
@@ -288,8 +405,8 @@ int main(int argc, char** argv) {
       }
     }
   }
-  for (int pat = 1; pat >= 0; --pat)
-  for (int LEN : {10, 27, 60, 100}) {
+  for (int pat = 1; pat >= 1; --pat)
+  for (int LEN : {10, 27, 60}) {
     g_pattern = pat;
     for (int R : {6400, 22000, 65000, 130000}) {
       if (LEN == 60 && R > 22000) continue;
@@ -303,7 +420,7 @@ int main(int argc, char** argv) {
       std::vector<double> ref;
       printf("---- LEN %d, %d rows/launch (%d x 512-entry slots, %.1f MB of col/val per launch), K=%d launches\n", LEN, R, (R + 512 / LEN - 1) / (512 / LEN),
              12.0 * R * LEN / 1e6, K);
-      for (int S : {512, 1024, 2048}) {
+      for (int S : {512, 1024}) {
         Layout L = build(K, R, LEN, S, n);
         Args a{}; a.wcol = up(L.wcol); a.wval = up(L.wval); a.slot_row = up(L.slot_row); a.wmeta = up(L.wmeta); a.diag = dd; a.bp = db; a.x = dx;
         auto report = [&](const char* name, double us, const std::vector<double>* got) {
@@ -317,6 +434,17 @@ int main(int argc, char** argv) {
           report("T512 E1 graph xcd", run<512, 1, 0>(L, a, K, true, 1, st, &got, n, x0), &got);
           report("T256 E2 eager xcd", run<256, 2, 0>(L, a, K, false, 1, st, &got, n, x0), &got);
           report("T512 E1 no-gather", run<512, 1, 1>(L, a, K, false, 1, st, nullptr, n, x0), nullptr);
+          {
+            int herr = 0;
+            double t1 = run_dep<512, 1>(L, a, K, 480, false, st, st2, &got, n, x0, &herr);
+            printf("  S= 512 dep T512 E1 ONE stream (counters + boundary)   %6.2f us/launch  err %d\n", t1, herr);
+            report("dep T512E1 2 streams cap480", run_dep<512, 1>(L, a, K, 480, true, st, st2, &got, n, x0, &herr), &got);
+            printf("       (spin timeout flag %d)\n", herr);
+            report("dep T256E2 2 streams cap960", run_dep<256, 2>(L, a, K, 960, true, st, st2, &got, n, x0, &herr), &got);
+            printf("       (spin timeout flag %d)\n", herr);
+            report("dep T256E2 2 streams cap480", run_dep<256, 2>(L, a, K, 480, true, st, st2, &got, n, x0, &herr), &got);
+            printf("       (spin timeout flag %d)\n", herr);
+          }
           report("T512 E1 loads-only", run<512, 1, 2>(L, a, K, false, 1, st, nullptr, n, x0), nullptr);
           auto sell = [&](auto klc, const char* name) {
             constexpr int KL = decltype(klc)::value;
@@ -342,14 +470,23 @@ int main(int argc, char** argv) {
             }
             hipFree((void*)sa.col); hipFree((void*)sa.val); hipFree((void*)sa.chunk);
           };
+          if (getenv("SELL")) {
           sell(std::integral_constant<int, 1>(), "1 lane/row");
           sell(std::integral_constant<int, 2>(), "2 lanes/row");
           sell(std::integral_constant<int, 4>(), "4 lanes/row");
           sell(std::integral_constant<int, 8>(), "8 lanes/row");
           if (LEN >= 27) sell(std::integral_constant<int, 16>(), "16 lanes/row");
           if (LEN >= 100) sell(std::integral_constant<int, 32>(), "32 lanes/row");
+          }
         } else if (S == 1024) {
           report("T256 E4 eager xcd", run<256, 4, 0>(L, a, K, false, 1, st, &got, n, x0), &got);
+          {
+            int herr = 0;
+            report("dep T256E4 2 streams cap960", run_dep<256, 4>(L, a, K, 960, true, st, st2, &got, n, x0, &herr), &got);
+            printf("       (spin timeout flag %d)\n", herr);
+            report("dep T256E4 2 streams cap480", run_dep<256, 4>(L, a, K, 480, true, st, st2, &got, n, x0, &herr), &got);
+            printf("       (spin timeout flag %d)\n", herr);
+          }
         } else {
           report("T256 E8 eager xcd", run<256, 8, 0>(L, a, K, false, 1, st, &got, n, x0), &got);
         }
