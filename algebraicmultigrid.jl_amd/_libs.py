@@ -69,6 +69,7 @@ def setup_lib():
     L.amgs_symmetric_strength.restype = vp
     L.amgs_symmetric_strength.argtypes = [vp, C.c_double, C.c_int]
     L.amgs_rs_splitting.argtypes = [vp, vp]
+    L.amgs_rs_cf_splitting_patterns.argtypes = [i64, vp, vp, vp, vp, vp]
     L.amgs_direct_interpolation.restype = vp
     L.amgs_direct_interpolation.argtypes = [vp, vp, vp]
     L.amgs_standard_aggregation.restype = vp
@@ -115,6 +116,7 @@ def hip_lib():
     L.amgh_level_size.argtypes = [vp, C.c_int]
     L.amgh_device_bytes.restype = i64
     L.amgh_device_bytes.argtypes = [vp]
+    L.amgh_device_bytes_detail.argtypes = [vp, vp]
     L.amgh_gs_num_dependency_levels.argtypes = [vp, C.c_int]
     L.amgh_gs_num_sweep_steps.argtypes = [vp, C.c_int, C.c_int]
     L.amgh_gs_sweep_stats.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -192,6 +194,18 @@ def hip_lib():
     L.amgh_dist_stream.restype = vp
     L.amgh_dist_stream.argtypes = [vp]
     L.amgh_dist_plan_info.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    # GPU half of the setup phase (amgh_dmat_*, amgh_setup_*)
+    L.amgh_dmat_upload.argtypes = [C.POINTER(vp), C.c_int, i64, i64, vp, vp, vp]
+    L.amgh_dmat_download.argtypes = [vp, vp, vp, vp]
+    L.amgh_dmat_free.argtypes = [vp]
+    L.amgh_dmat_free.restype = None
+    for f in ("amgh_dmat_rows", "amgh_dmat_cols", "amgh_dmat_nnz"):
+        getattr(L, f).restype = i64
+        getattr(L, f).argtypes = [vp]
+    L.amgh_setup_transpose.argtypes = [vp, C.POINTER(vp)]
+    L.amgh_setup_classical_strength.argtypes = [vp, C.c_double, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.amgh_setup_direct_interpolation.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
+    L.amgh_setup_spgemm.argtypes = [vp, vp, C.POINTER(vp)]
     _hip = L
     return L
 

@@ -28,6 +28,7 @@ struct Level {
   // P with its rows in that order, R with its columns renumbered to it; A in that order is the schedule's own copy
   amgh_csr Pp, Rp;
   bool lo_ok = false;
+  bool nat_freed = false;  // memory-lean: the natural-order A (levels >= 1), P and R were released, the cycle runs level-ordered
 };
 
 }  // namespace
@@ -211,7 +212,7 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc, bool xzero) {
   // and residual / restriction / prolongation run on level-ordered copies of A, R, P (same entries in the same
   // order inside every row, so the same sums): no scatter after the pre-smoother, no gather before the post-smoother.
   GsSchedule* g = L->smat()->gs;
-  const bool lo = L->lo_ok && g_gs_keep_lo && g && g->nblk == 0;
+  const bool lo = L->lo_ok && (g_gs_keep_lo || L->nat_freed) && g && g->nblk == 0;
   {
     ProfScope p(h, AMGH_T_PRESMOOTH, l);
     RC_TRY(smooth(h, L, L->pre, xc, xo, b, bs, xzero, false, false, lo));
@@ -592,6 +593,18 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
     }
     std::vector<int32_t>().swap(g->h_perm);
   }
+  if (rc == AMGH_OK && L->lo_ok && gs_lean()) {
+    // memory-lean: between the smoothers the cycle only touches the level-ordered copies (the schedule's own A, Pp,
+    // Rp); the natural-order P, R and — below the fine level, whose A the outer residual of _solve! needs — A go
+    auto drop = [](amgh_csr* op) {
+      hipFree(op->rowptr); hipFree(op->col); hipFree(op->val);
+      op->rowptr = op->col = nullptr; op->val = nullptr;
+      op->bytes -= (op->nrows + 1) * 4 + op->nnz * 12;
+    };
+    drop(&L->P); drop(&L->R);
+    if (!h->levels.empty()) drop(&L->A);
+    L->nat_freed = true;
+  }
   if (rc != AMGH_OK) {
     csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
     delete L;
@@ -676,6 +689,31 @@ int64_t amgh_device_bytes(const amgh_t* h) {
   int64_t b = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * 8 : 0) + h->finalA.bytes;
   for (Level* L : h->levels) b += L->A.bytes + L->S.bytes + L->P.bytes + L->R.bytes + L->Pp.bytes + L->Rp.bytes;
   return b;
+}
+// out8 = {natural-order A/P/R (+ S), level-ordered CSR copies (schedules' A, Pp, Rp), un-merged slot arrays, merged groups:
+//         CSR part, merged groups: slot arrays, pre-pass triangles, block-inverse data + vectors of the schedules, workspace}
+int amgh_device_bytes_detail(const amgh_t* h, int64_t* out8) {
+  if (!h || !out8) return AMGH_EINVAL;
+  for (int q = 0; q < 8; ++q) out8[q] = 0;
+  for (Level* L : h->levels) {
+    for (const amgh_csr* op : {&L->A, &L->S, &L->P, &L->R})
+      if (op->rowptr) out8[0] += (op->nrows + 1) * 4 + op->nnz * 12;
+    out8[1] += L->Pp.bytes + L->Rp.bytes;
+    const GsSchedule* g = L->smat()->gs;
+    if (!g) continue;
+    out8[1] += g->csr_bytes;
+    out8[2] += g->slot_bytes;
+    int64_t known = g->csr_bytes + g->slot_bytes;
+    for (const GsSchedule* c : {g->mf, g->mb})
+      if (c) { out8[3] += c->csr_bytes; out8[4] += c->slot_bytes; known += c->bytes; }
+    const int64_t tri = (g->tri_nnz + g->tri_nnz_b) * 12 + ((g->tri_nnz ? 1 : 0) + (g->tri_nnz_b ? 1 : 0)) * (g->n + 1) * 4;
+    out8[5] += tri;
+    known += tri;
+    out8[6] += std::max<int64_t>(0, g->bytes - known);
+  }
+  out8[0] += h->finalA.bytes;
+  out8[7] = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * 8 : 0);
+  return AMGH_OK;
 }
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
@@ -815,12 +853,13 @@ static amgh_csr* level_op(amgh_t* h, int level, int which) {
   const int L = (int)h->levels.size();
   if (level == L && which == AMGH_OP_A && h->has_finalA) return &h->finalA;
   if (level < 0 || level >= L) return nullptr;
+  amgh_csr* op = nullptr;
   switch (which) {
-    case AMGH_OP_A: return &h->levels[level]->A;
-    case AMGH_OP_P: return &h->levels[level]->P;
-    case AMGH_OP_R: return &h->levels[level]->R;
+    case AMGH_OP_A: op = &h->levels[level]->A; break;
+    case AMGH_OP_P: op = &h->levels[level]->P; break;
+    case AMGH_OP_R: op = &h->levels[level]->R; break;
   }
-  return nullptr;
+  return (op && op->rowptr) ? op : nullptr;  // (memory-lean hierarchies have released some natural-order operators)
 }
 
 int amgh_level_spmv_d(amgh_t* h, int level, int which, const double* x_d, double* y_d) {
@@ -1141,6 +1180,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_slots")) g_gs_slots = value;
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
   else if (!strcmp(name, "gs_lpr")) g_gs_lpr = value;
+  else if (!strcmp(name, "gs_lean")) g_gs_lean = value;
   else if (!strcmp(name, "gs_ept")) g_gs_ept = value;
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_bigslot")) g_gs_bigslot = value;
@@ -1189,3 +1229,4 @@ int amgh_set_use_graph(amgh_t* h, int on) {
 }  // extern "C"
 
 #include "amghip_dist.hpp"
+#include "amghip_setup.hpp"

@@ -74,6 +74,8 @@ struct GsSchedule {
   std::vector<int32_t> h_perm;  // host copy of perm (level-ordered row -> original row), for level-ordered P / R copies
   int64_t n = 0, ncols = 0;
   int64_t bytes = 0;
+  bool compacted = false;   // memory-lean child: the CSR copy holds only the rows no slot launch covers
+  int64_t csr_bytes = 0, slot_bytes = 0;  // device bytes of the CSR copy (+ row / level descriptors) and of the slot arrays
   int64_t nnz = 0;          // entries of this system's rows (composite rows for a merged child)
   int64_t slot_total = 0;   // entries the slot arrays hold, zero padding included
   int64_t tri_nnz = 0;      // (on the parent, per direction [fwd, bwd]) entries of the pre-pass triangles
@@ -175,6 +177,7 @@ int g_gs_bigslot = 1;           // allow long-row slots (composite rows up to 20
 int g_gs_merge = 16;             // merged-level sweeps: largest group of dependency levels tried (1 = off); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
+int g_gs_lean = -1;             // memory-lean schedules: -1 = AMGH_LEAN environment variable, 0 off, 1 on; read at schedule build
 int g_gs_ept = 0;               // entries per thread of merged slot launches (0 = 2 when a group has more than 1024 slots, else 1)
 int g_gs_lpr = 0;               // lanes per row in the row sums of merged slot launches (0 = by row length, 1 = one thread per row)
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)

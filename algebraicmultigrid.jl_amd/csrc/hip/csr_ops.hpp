@@ -316,7 +316,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       const int64_t nx = lay == g ? g->ncols : xs;  // entries of x (and s) a chained row may read
       const bool ldsx = nx <= kChainLdsX;            // they fit LDS
       RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)nx, st, ncolv));
-    } else if (s.nslots > 0 && g_gs_slots) {
+    } else if (s.nslots > 0 && (g_gs_slots || lay->compacted)) {
       SlotArgs sa{};
       sa.wcol = lay->wcol; sa.wval = lay->wval; sa.slot_row = lay->slot_row; sa.wmeta = lay->wmeta;
       sa.diag = lay->diag; sa.bp = rhs; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;

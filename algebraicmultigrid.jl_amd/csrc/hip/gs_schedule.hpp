@@ -102,6 +102,13 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n,
   return AMGH_OK;
 }
 
+// memory-lean schedules (tunable "gs_lean" or AMGH_LEAN=1 in the environment; read when a schedule is built)
+bool gs_lean() {
+  if (g_gs_lean >= 0) return g_gs_lean != 0;
+  const char* e = getenv("AMGH_LEAN");
+  return e && e[0] == '1';
+}
+
 // host threads for the schedule builds: the container's CPU quota, AMGH_BUILD_THREADS overrides
 int merge_threads() {
   unsigned hw = std::thread::hardware_concurrency();
@@ -143,7 +150,10 @@ struct HostLevelCsr {
 // Upload one level-ordered system and derive its execution layout: row / level descriptors for the chain
 // kernel, segments (runs of narrow levels chained in one workgroup, one launch per wide level), slot arrays.
 // `orig` = original row id of each level-ordered row (rowmeta.w), may be null.
-int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int slot_entries = kSlot) {
+// compact (memory-lean mode, merged children only): the CSR copy keeps just the rows no slot launch covers (chained
+// narrow groups, rows too long for a slot); every other row lives in the slot arrays only.
+int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int slot_entries = kSlot,
+                  bool compact = false) {
   const int64_t n = h.n;
   const std::vector<int32_t>& prow = h.prow;
   const std::vector<int32_t>& pcol = h.pcol;
@@ -157,21 +167,9 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
   g->slot_entries = slot_entries;
   const int SE = slot_entries;                                    // entries per slot
   const int max_rows = SE == kSlot ? kSlot : kBigRows;           // rows per slot
-  RC_TRY(dev_upload(&g->rowptr, prow.data(), n + 1));
-  RC_TRY(dev_upload(&g->col, pcol.data(), nnz));
-  RC_TRY(dev_upload(&g->val, pval.data(), nnz));
-  RC_TRY(dev_upload(&g->dpos, pdpos.data(), n));
   RC_TRY(dev_upload(&g->diag, h.pdiag.data(), n));
   RC_TRY(dev_upload(&g->d_lvl_ptr, g->lvl_ptr.data(), g->nlev + 1));
-  {
-    std::vector<i4_t> meta(n), desc(g->nlev);
-    for (int64_t p = 0; p < n; ++p) meta[p] = i4_t{prow[p], prow[p + 1], pdpos[p], orig ? orig[p] : (int32_t)p};
-    for (int l = 0; l < g->nlev; ++l)
-      desc[l] = i4_t{g->lvl_ptr[l], g->lvl_ptr[l + 1], prow[g->lvl_ptr[l]], prow[g->lvl_ptr[l + 1]]};
-    RC_TRY(dev_upload(&g->rowmeta, meta.data(), n));
-    RC_TRY(dev_upload(&g->desc, desc.data(), g->nlev));
-  }
-  g->bytes += (n + 1) * 4 + nnz * 12 + n * 12 + (g->nlev + 1) * 4 + n * 16 + g->nlev * 16;
+  g->bytes += n * 8 + (g->nlev + 1) * 4;
   // segments: runs of narrow dependency levels are chained in one workgroup
   // A dependency level is chained (stays inside one workgroup) when it has at most
   // one row per thread and its products fit one LDS pass; anything larger is worth
@@ -309,7 +307,50 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       RC_TRY(dev_upload(&g->wmeta, wmeta.data(), n));
       g->bytes += (int64_t)wcol.size() * 12 + (int64_t)sr2.size() * 4 + n * 16;
       g->slot_total = (int64_t)wcol.size();
+      g->slot_bytes = (int64_t)wcol.size() * 12 + (int64_t)sr2.size() * 4 + n * 16;
     }
+  }
+  // the CSR copy (chain kernel, stream-kernel fallback): all rows, or — compact — only those no slot launch covers
+  {
+    std::vector<int32_t> cprow, ccol, cdpos;
+    std::vector<double> cval;
+    const std::vector<int32_t>* urow = &prow;
+    const std::vector<int32_t>* ucol = &pcol;
+    const std::vector<int32_t>* udpos = &pdpos;
+    const std::vector<double>* uval = &pval;
+    if (compact) {
+      std::vector<char> keep(n, 0);
+      for (const auto& sg : g->segs)
+        if (sg.chain || sg.nslots <= 0)
+          for (int32_t p2 = g->lvl_ptr[sg.l0]; p2 < g->lvl_ptr[sg.l1]; ++p2) keep[p2] = 1;
+      cprow.assign(n + 1, 0);
+      for (int64_t p2 = 0; p2 < n; ++p2) cprow[p2 + 1] = cprow[p2] + (keep[p2] ? prow[p2 + 1] - prow[p2] : 0);
+      ccol.resize(cprow[n]);
+      cval.resize(cprow[n]);
+      cdpos.assign(n, -1);
+      for (int64_t p2 = 0; p2 < n; ++p2) {
+        if (!keep[p2]) continue;
+        std::copy(pcol.begin() + prow[p2], pcol.begin() + prow[p2 + 1], ccol.begin() + cprow[p2]);
+        std::copy(pval.begin() + prow[p2], pval.begin() + prow[p2 + 1], cval.begin() + cprow[p2]);
+        if (pdpos[p2] >= 0) cdpos[p2] = pdpos[p2] - prow[p2] + cprow[p2];
+      }
+      urow = &cprow; ucol = &ccol; udpos = &cdpos; uval = &cval;
+      g->compacted = true;
+    }
+    const int64_t unnz = (*urow)[n];
+    RC_TRY(dev_upload(&g->rowptr, urow->data(), n + 1));
+    RC_TRY(dev_upload(&g->col, ucol->data(), unnz));
+    RC_TRY(dev_upload(&g->val, uval->data(), unnz));
+    RC_TRY(dev_upload(&g->dpos, udpos->data(), n));
+    std::vector<i4_t> meta(n), desc(g->nlev);
+    for (int64_t p2 = 0; p2 < n; ++p2)
+      meta[p2] = i4_t{(*urow)[p2], (*urow)[p2 + 1], (*udpos)[p2], orig ? orig[p2] : (int32_t)p2};
+    for (int l2 = 0; l2 < g->nlev; ++l2)
+      desc[l2] = i4_t{g->lvl_ptr[l2], g->lvl_ptr[l2 + 1], (*urow)[g->lvl_ptr[l2]], (*urow)[g->lvl_ptr[l2 + 1]]};
+    RC_TRY(dev_upload(&g->rowmeta, meta.data(), n));
+    RC_TRY(dev_upload(&g->desc, desc.data(), g->nlev));
+    g->csr_bytes = (n + 1) * 4 + unnz * 12 + n * 4 + n * 16 + g->nlev * 16;
+    g->bytes += g->csr_bytes;
   }
   return AMGH_OK;
 }
@@ -730,7 +771,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         GsSchedule* ch = new GsSchedule;
         (backward ? g->mb : g->mf) = ch;
         ch->ncols = g->ncols;
-        RC_TRY(layout_upload(ch, keep.sys, perm.data(), cap));
+        RC_TRY(layout_upload(ch, keep.sys, perm.data(), cap, gs_lean()));
         tm.lap("merged layout", n);
         RC_TRY(tri_upload(backward ? &g->tri_b : &g->tri_f, base, backward, &g->bytes, 0.0,
                           backward ? &g->tri_nnz_b : &g->tri_nnz));
@@ -757,6 +798,15 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         if (*c) { g->bytes -= (*c)->bytes; (*c)->free_dev(); delete *c; *c = nullptr; }
     }
     if (g->mf || g->mb) g->xstride = g->ncols + n;
+    if (gs_lean() && g->mf && g->mb && g->nblk == 0 && g->wcol) {
+      // memory-lean: both directions always run merged groups, the un-merged slot copy would only serve a run with
+      // merging switched off at run time — that run falls back to the CSR stream kernel
+      hipFree(g->wcol); hipFree(g->wval); hipFree(g->slot_row); hipFree(g->wmeta);
+      g->wcol = g->slot_row = nullptr; g->wval = nullptr; g->wmeta = nullptr;
+      for (auto& sg : g->segs) if (!sg.chain) { sg.nslots = -1; sg.slot0 = 0; }
+      g->bytes -= g->slot_bytes;
+      g->slot_bytes = 0; g->slot_total = 0;
+    }
   }
   g->diag_nonzero = true;
   for (int64_t p2 = 0; p2 < n && g->diag_nonzero; ++p2) g->diag_nonzero = base.pdiag[p2] != 0.0;

@@ -380,17 +380,19 @@ void remove_diag(Mat& a) {  // splitting.jl:8-18
 // RS_CF_splitting(S, T = copy(S')).  Index bookkeeping kept 1-based (arrays
 // sized n+2) so the bucket arithmetic mirrors splitting.jl:25-159 literally;
 // tie-breaking depends on it (ref_split_test.txt / thing.jl goldens).
+void rs_cf_splitting_raw(int64_t n, const int32_t* Sp, const int32_t* Sj, const int32_t* Tp, const int32_t* Tj,
+                         int32_t* splitting_out);
 void rs_cf_splitting(const Mat& S, const Mat& T, int32_t* splitting_out) {
-  const int64_t n = S.m;
+  rs_cf_splitting_raw(S.m, S.colptr.data(), S.rowval.data(), T.colptr.data(), T.rowval.data(), splitting_out);
+}
+// the sweep itself works on the two PATTERNS only (column pointers + row indices of S and of T = S')
+void rs_cf_splitting_raw(int64_t n, const int32_t* Sp, const int32_t* Sj, const int32_t* Tp, const int32_t* Tj,
+                         int32_t* splitting_out) {
   // int32 bookkeeping (n < 2^31): the sweep is a sequential chain of dependent random accesses, so the
   // working-set size is what sets its speed
   std::vector<int32_t> lambda(n + 2, 0), interval_ptr(n + 3, 0), interval_count(n + 3, 0);
   std::vector<int32_t> index_to_node(n + 2, 0), node_to_index(n + 2, 0);
   std::vector<int8_t> splitting(n + 2, U_NODE);
-  const int32_t* Sp = S.colptr.data();
-  const int32_t* Sj = S.rowval.data();
-  const int32_t* Tp = T.colptr.data();
-  const int32_t* Tj = T.rowval.data();
 
   for (int64_t i = 1; i <= n; ++i) {
     lambda[i] = Sp[i] - Sp[i - 1];
@@ -1117,6 +1119,13 @@ int amgs_rs_splitting(amgs_mat* S, int32_t* splitting) {
   return Guard::rc([&]() {
     if (S->m != S->n) throw std::runtime_error("rs_splitting: S must be square");
     rs_splitting(*S, splitting);
+  });
+}
+int amgs_rs_cf_splitting_patterns(int64_t n, const int32_t* Sp, const int32_t* Sj, const int32_t* Tp, const int32_t* Tj,
+                                  int32_t* splitting) {
+  return Guard::rc([&]() {
+    if (n < 0 || !Sp || !Tp || !splitting) throw std::runtime_error("rs_cf_splitting: bad arguments");
+    rs_cf_splitting_raw(n, Sp, Sj, Tp, Tj, splitting);
   });
 }
 amgs_mat* amgs_direct_interpolation(const amgs_mat* At, const amgs_mat* T, const int32_t* splitting) {

@@ -272,6 +272,13 @@ class DeviceHierarchy:
     def device_bytes(self):
         return int(self.lib.amgh_device_bytes(self.h))
 
+    def device_bytes_detail(self):
+        out = np.zeros(8, dtype=np.int64)
+        hip_check(self.lib.amgh_device_bytes_detail(self.h, out.ctypes.data), "device_bytes_detail")
+        keys = ("natural_APR", "level_ordered_csr", "unmerged_slots", "merged_csr", "merged_slots", "prepass_triangles",
+                "block_and_vectors", "workspace")
+        return dict(zip(keys, map(int, out)))
+
     def gs_dependency_levels(self, level):
         return int(self.lib.amgh_gs_num_dependency_levels(self.h, level))
 

@@ -315,11 +315,104 @@ def _unwrap(A, symmetry):
     return SparseMatrixCSC.coerce(A), symmetry
 
 
+class _DMat:
+    """SparseMatrixCSC on HBM (amgh_dmat_*): the operand type of the GPU half of the setup phase."""
+
+    def __init__(self, handle, lib):
+        self.h, self.lib = handle, lib
+        self.m, self.n, self.nnz = (int(lib.amgh_dmat_rows(handle)), int(lib.amgh_dmat_cols(handle)),
+                                    int(lib.amgh_dmat_nnz(handle)))
+
+    @classmethod
+    def upload(cls, A, lib, device=0):
+        h = C.c_void_p()
+        from ._libs import hip_check
+        hip_check(lib.amgh_dmat_upload(C.byref(h), device, A.m, A.n, A.colptr.ctypes.data, A.rowval.ctypes.data,
+                                       A.nzval.ctypes.data), "dmat_upload")
+        return cls(h.value, lib)
+
+    def download(self, values=True):
+        from ._libs import hip_check
+        cp = np.empty(self.n + 1, dtype=np.int32)
+        rv = np.empty(self.nnz, dtype=np.int32)
+        nz = np.empty(self.nnz, dtype=np.float64) if values else None
+        hip_check(self.lib.amgh_dmat_download(self.h, cp.ctypes.data, rv.ctypes.data, nz.ctypes.data if values else None),
+                  "dmat_download")
+        return cp, rv, nz
+
+    def to_host(self):
+        cp, rv, nz = self.download()
+        return SparseMatrixCSC.from_arrays(self.m, self.n, cp, rv, nz)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.amgh_dmat_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0):
+    """extend_hierarchy_rs! (classical.jl:36-55) with strength, interpolation, transposes and R*A*P on the GPU
+    (amgh_setup_*, include/amghip.h) and the sequential C/F splitting on the host (amgs_rs_cf_splitting_patterns).
+    Returns [(A, P, R), ...], final_A as host matrices — bitwise what the host library builds."""
+    from ._libs import hip_check, hip_lib
+    lib, L = hip_lib(), setup_lib()
+    if lib.amgh_device_count() <= 0:
+        raise AMGError("ruge_stuben(setup='gpu'): no HIP device visible")
+
+    def call2(fn, *args, what=""):
+        a, b = C.c_void_p(), C.c_void_p()
+        hip_check(fn(*args, C.byref(a), C.byref(b)), what)
+        return _DMat(a.value, lib), _DMat(b.value, lib)
+
+    def spgemm(X, Y):
+        c = C.c_void_p()
+        rc = lib.amgh_setup_spgemm(X.h, Y.h, C.byref(c))
+        if rc == -5:   # a column of the product outgrew the LDS table: this one product on the host
+            return _DMat.upload(X.to_host() @ Y.to_host(), lib, device)
+        hip_check(rc, "setup_spgemm")
+        return _DMat(c.value, lib)
+
+    out = []
+    A_host, dA = A, _DMat.upload(A, lib, device)
+    while len(out) + 1 < max_levels and A_host.m > max_coarse:
+        n = A_host.m
+        if hermitian:
+            dAt = dA
+        else:
+            t = C.c_void_p()
+            hip_check(lib.amgh_setup_transpose(dA.h, C.byref(t)), "setup_transpose")
+            dAt = _DMat(t.value, lib)
+        s_, t_, sn, tn = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        hip_check(lib.amgh_setup_classical_strength(dAt.h, theta, C.byref(s_), C.byref(t_), C.byref(sn), C.byref(tn)),
+                  "setup_classical_strength")
+        dS, dT, dSn, dTn = (_DMat(v.value, lib) for v in (s_, t_, sn, tn))
+        Sp, Sj, _ = dSn.download(values=False)
+        Tp, Tj, _ = dTn.download(values=False)
+        splitting = np.empty(n, dtype=np.int32)
+        if L.amgs_rs_cf_splitting_patterns(n, Sp.ctypes.data, Sj.ctypes.data, Tp.ctypes.data, Tj.ctypes.data,
+                                           splitting.ctypes.data) != 0:
+            raise AMGError(L.amgs_last_error().decode())
+        del dS, dSn, dTn
+        dR, dP = call2(lib.amgh_setup_direct_interpolation, dAt.h, dT.h, splitting.ctypes.data, what="setup_direct_interpolation")
+        if dR.m == 0:        # size(P, 2) == 0: stop coarsening (classical.jl:43)
+            break
+        dRAP = spgemm(spgemm(dR, dA), dP)
+        out.append((A_host, dP.to_host(), dR.to_host()))
+        A_host, dA = dRAP.to_host(), dRAP
+    return out, A_host
+
+
 def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, postsmoother=None,
-                max_levels=10, max_coarse=10, coarse_solver=None, **kwargs):
+                max_levels=10, max_coarse=10, coarse_solver=None, setup=None, **kwargs):
     """ruge_stuben(A; strength=Classical(0.25), symmetry=HermitianSymmetry(), CF=RS(),
     presmoother=GaussSeidel(), postsmoother=GaussSeidel(), max_levels=10, max_coarse=10,
-    coarse_solver=QRSolver)   — classical.jl:6-34."""
+    coarse_solver=QRSolver)   — classical.jl:6-34.
+
+    setup = "host" (libamgsetup, C++/OpenMP) | "gpu" (strength, interpolation and R*A*P on the MI355X, C/F splitting
+    on the host; same hierarchy bit for bit).  Default: the environment variable AMG_SETUP, else "host"."""
     if kwargs.get("B") is not None:  # classical.jl:18
         raise AMGError("near null space `B` is only supported for smoothed aggregation AMG, not Ruge-Stüben AMG.")
     strength = strength if strength is not None else Classical(0.25)
@@ -336,6 +429,20 @@ def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, post
     o.max_levels = int(max_levels)
     o.max_coarse = int(max_coarse)
     o.hermitian = int(isinstance(symmetry, HermitianSymmetry))
+    import os
+    setup = setup if setup is not None else os.environ.get("AMG_SETUP", "host")
+    if setup == "gpu":
+        lv, final_A = _ruge_stuben_gpu(A, strength.theta, int(max_levels), int(max_coarse), bool(o.hermitian))
+        levels = [Level(a, p, r, presmoother, postsmoother) for a, p, r in lv]
+        for m_ in [final_A] + [l.A for l in levels]:
+            m_.eltype = A.eltype
+        if not isinstance(symmetry, HermitianSymmetry):
+            for lev in levels:
+                for s_ in (presmoother, postsmoother):
+                    s_.check_no_symmetry(lev.A)
+        return MultiLevel(levels, final_A, coarse_solver(final_A), presmoother, postsmoother, symmetry, method="rs")
+    if setup != "host":
+        raise AMGError("ruge_stuben: setup must be 'host' or 'gpu'")
     hier = _Hier(setup_lib().amgs_ruge_stuben(A._h, C.byref(o)))
     return _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, "rs", A.eltype)
 

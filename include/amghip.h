@@ -124,6 +124,13 @@ int amgh_finalize(amgh_t* h);
 int amgh_num_levels(const amgh_t* h);            /* length(ml.levels)            */
 int64_t amgh_level_size(const amgh_t* h, int l); /* size(levels[l].A,1); l==L: final */
 int64_t amgh_device_bytes(const amgh_t* h);      /* HBM held by the handle        */
+/* The same by category: out8 = {natural-order A / S / P / R, level-ordered CSR copies (the schedules' A, P, R),
+ * un-merged slot arrays, merged groups: CSR part, merged groups: slot arrays, pre-pass triangles,
+ * block-inverse data + schedule vectors, workspace + coarse operator}.  Memory-lean mode (AMGH_LEAN=1 or tunable
+ * "gs_lean", read at amgh_push_level) keeps only what the default cycle touches: no un-merged slot copy and no CSR
+ * copy of slotted composite rows where both sweep directions run merged groups, no natural-order P / R / coarse-level
+ * A where the cycle runs level-ordered (amgh_level_spmv on a released operator returns AMGH_EINVAL).                 */
+int amgh_device_bytes_detail(const amgh_t* h, int64_t* out8);
 /* number of Gauss-Seidel dependency levels of level l (0 if no GS smoother)    */
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l);
 /* Sequential steps one Gauss-Seidel sweep over level l takes as executed: merged groups of dependency levels
@@ -304,6 +311,38 @@ void* amgh_dist_stream(amgh_dist_t* d);
  * per-peer send / receive counts [nranks].                                                           */
 int amgh_dist_plan_info(const amgh_dist_t* d, int level, int64_t* out_counts, int64_t* halo_globals,
                         int32_t* send_idx, int64_t* send_cnt_per_peer, int64_t* recv_cnt_per_peer);
+
+/* ------------------------------------------------------------------------- */
+/* Setup phase, data-parallel half on the GPU: what             */
+/* extend_hierarchy_rs! (classical.jl:36-55) does per level except the sequential */
+/* C/F splitting (splitting.jl:25-159, host: amgs_rs_cf_splitting_patterns).      */
+/* Matrices are Julia's CSC on HBM; results are bitwise those of the host library */
+/* libamgsetup (same order of every floating-point operation).                    */
+/* ------------------------------------------------------------------------- */
+typedef struct amgh_dmat amgh_dmat_t; /* SparseMatrixCSC{Float64,Int32} on HBM (0-based) */
+int amgh_dmat_upload(amgh_dmat_t** M, int device, int64_t m, int64_t n, const int32_t* colptr,
+                     const int32_t* rowval, const double* nzval);
+/* any of the three output arrays may be NULL (patterns only: nzval = NULL)      */
+int amgh_dmat_download(const amgh_dmat_t* M, int32_t* colptr, int32_t* rowval, double* nzval);
+void amgh_dmat_free(amgh_dmat_t* M);
+int64_t amgh_dmat_rows(const amgh_dmat_t* M);
+int64_t amgh_dmat_cols(const amgh_dmat_t* M);
+int64_t amgh_dmat_nnz(const amgh_dmat_t* M);
+/* copy(A')                                                                       */
+int amgh_setup_transpose(const amgh_dmat_t* A, amgh_dmat_t** At);
+/* S, T = Classical(theta)(At)  (strength.jl:7-37): T = thresholded |At| scaled by its column maxima,
+ * S = T'.  Sn, Tn (both NULL or both non-NULL): the PATTERNS the C/F splitting consumes — S without its
+ * diagonal (remove_diag, splitting.jl:8-18) and its transpose — so the host needs no matrix work of its own. */
+int amgh_setup_classical_strength(const amgh_dmat_t* At, double theta, amgh_dmat_t** S, amgh_dmat_t** T,
+                                  amgh_dmat_t** Sn, amgh_dmat_t** Tn);
+/* P, R = direct_interpolation(At, T, splitting)  (classical.jl:57-189); splitting is a HOST array
+ * (1 = C node, 0 = F node).  R: nc x n, P = R': n x nc.                                                        */
+int amgh_setup_direct_interpolation(const amgh_dmat_t* At, const amgh_dmat_t* T, const int32_t* splitting,
+                                    amgh_dmat_t** R, amgh_dmat_t** P);
+/* C = X * Y with SparseArrays' spmatmul semantics (structural zeros kept, rows sorted): the two products of
+ * RAP = R * A * P (classical.jl:44).  AMGH_EUNSUPPORTED when a column of the product has more than ~440
+ * entries (the caller then forms this product with the host library).                                          */
+int amgh_setup_spgemm(const amgh_dmat_t* X, const amgh_dmat_t* Y, amgh_dmat_t** C);
 
 /* ------------------------------------------------------------------------- */
 /* Device memory + timing helpers for hosts without a HIP binding of their own  */

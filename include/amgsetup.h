@@ -70,6 +70,10 @@ amgs_mat* amgs_symmetric_strength(const amgs_mat* A, double theta,
 /* RS()(S): removes the diagonal of S IN PLACE, then RS_CF_splitting.         */
 /* splitting[n]: 0 = F, 1 = C                                                 */
 int amgs_rs_splitting(amgs_mat* S, int32_t* splitting);
+/* The sequential sweep alone (splitting.jl:25-159) on two PATTERNS: S without its diagonal and T = S' (column      */
+/* pointers n+1, row indices) — what the GPU setup path hands over (amgh_setup_classical_strength, amghip.h).      */
+int amgs_rs_cf_splitting_patterns(int64_t n, const int32_t* Sp, const int32_t* Sj, const int32_t* Tp,
+                                  const int32_t* Tj, int32_t* splitting);
 /* direct_interpolation(At, T, splitting) -> R (n_c x n, CSC); P = R'         */
 amgs_mat* amgs_direct_interpolation(const amgs_mat* At, const amgs_mat* T,
                                     const int32_t* splitting);

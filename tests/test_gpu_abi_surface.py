@@ -139,3 +139,33 @@ def test_w_and_f_cycles_at_128_cubed(h128, cyc):
     xo, ho, _ = oh.solve(b, cycle=cyc, maxiter=3, reltol=1e-30)
     assert len(hist) == len(ho) == 4 and np.allclose(hist, ho, rtol=1e-8)
     assert rel(x, xo) <= 1e-10
+
+
+def test_memory_lean_hierarchy_is_bitwise_the_default_one():
+    """AMGH_LEAN / tunable gs_lean: no un-merged slot copy, no CSR copy of slotted composite rows, no natural-order
+    P / R / coarse A where the cycle runs level-ordered — same kernels on the same numbers, fewer bytes."""
+    from amg_amd.device import DeviceHierarchy
+    lib = AMG.hip_lib()
+    A = AMG.poisson((64, 64, 64))
+    ml = AMG.ruge_stuben(A)
+    b = uniform(A.m, 8)
+    full = DeviceHierarchy(ml, 0, 1)
+    try:
+        assert lib.amgh_debug_set_tunable(b"gs_lean", 1) == 0
+        lean = DeviceHierarchy(ml, 0, 1)
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_lean", -1)
+    zf, zl = full.precond_apply(b), lean.precond_apply(b)
+    assert np.array_equal(zf, zl)
+    xf, hf, _ = full.solve(b, np.zeros_like(b), 0, 30, 0.0, 1e-8, True, True)
+    xl, hl, _ = lean.solve(b, np.zeros_like(b), 0, 30, 0.0, 1e-8, True, True)
+    assert np.array_equal(xf, xl) and np.array_equal(hf, hl)
+    df, dl = full.device_bytes_detail(), lean.device_bytes_detail()
+    assert dl["unmerged_slots"] < df["unmerged_slots"] and dl["merged_csr"] < 0.2 * df["merged_csr"]
+    assert dl["natural_APR"] < df["natural_APR"]
+    assert lean.device_bytes() < 0.75 * full.device_bytes()
+    assert abs(sum(df.values()) - full.device_bytes()) <= 0.02 * full.device_bytes()   # the categories add up
+    # a released operator is refused, not read
+    with pytest.raises(AMG.AMGError):
+        lean.spmv(1, 0, np.ones(ml.levels[1].A.m))
+    assert np.array_equal(lean.spmv(0, 0, b), full.spmv(0, 0, b))     # the fine-level A stays (outer residual of _solve!)
