@@ -28,6 +28,7 @@ struct Level {
   // P with its rows in that order, R with its columns renumbered to it; A in that order is the schedule's own copy
   amgh_csr Pp, Rp;
   bool lo_ok = false;
+  double* lo_val = nullptr;  // S != A with the same pattern: values of A in the order of the schedule's level-ordered copy of S
   bool nat_freed = false;  // memory-lean: the natural-order A (levels >= 1), P and R were released, the cycle runs level-ordered
 };
 
@@ -221,7 +222,9 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc, bool xzero) {
     const int64_t xs = g->xstride;
     {
       ProfScope p(h, AMGH_T_RESIDUAL, l);  // r = b - A x, everything in level order (bp was gathered by the pre-smoother)
-      RC_TRY(raw_apply(M_RESID, g->rowptr, g->col, g->val, n, g->xp, xs, g->bp, n, L->res, n, h->stream, bs));
+      // (A itself in level order: the schedule's copy, or — when the smoother sweeps S = A' — A's values on S's pattern)
+      RC_TRY(raw_apply(M_RESID, g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, n, g->xp, xs, g->bp, n, L->res, n,
+                       h->stream, bs));
     }
     {
       ProfScope p(h, AMGH_T_RESTRICT, l);
@@ -517,7 +520,7 @@ void amgh_destroy(amgh_t* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   for (Level* L : h->levels) {
     csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
-    hipFree(L->res); hipFree(L->cx); hipFree(L->cb); hipFree(L->tmp);
+    hipFree(L->res); hipFree(L->cx); hipFree(L->cb); hipFree(L->tmp); hipFree(L->lo_val);
     delete L;
   }
   csr_free(&h->finalA);
@@ -573,20 +576,46 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
     // level-ordered copies of P and R when both smoothers are level-scheduled sweeps over A itself
     const bool both = (pre->kind == AMGH_SMOOTH_GS || pre->kind == AMGH_SMOOTH_SOR) && pre->iter > 0 &&
                       (post->kind == AMGH_SMOOTH_GS || post->kind == AMGH_SMOOTH_SOR) && post->iter > 0;
-    if (rc == AMGH_OK && both && !L->has_S && g->nblk == 0 && g_gs_keep_lo && (int64_t)g->h_perm.size() == n) {
+    // S distinct from A (Hermitian convention on a matrix that is symmetric only up to rounding, e.g. every Galerkin
+    // coarse operator): the level-ordered cycle needs A's VALUES on the schedule's copy of S — possible when the two
+    // have the same pattern (then row perm[p] of A lists the same columns in the same order as row p of the copy)
+    bool same_pattern = !L->has_S;
+    if (L->has_S && rc == AMGH_OK && both && g->nblk == 0 && g_gs_keep_lo && (int64_t)g->h_perm.size() == n &&
+        A_rowptr[n] == S_rowptr[n] && std::equal(A_rowptr, A_rowptr + n + 1, S_rowptr) &&
+        std::equal(A_col, A_col + A_rowptr[n], S_col)) {
+      const std::vector<int32_t>& perm = g->h_perm;
+      std::vector<double> lv((size_t)A_rowptr[n]);
+      std::vector<int32_t> off(n + 1, 0);
+      for (int64_t p2 = 0; p2 < n; ++p2) off[p2 + 1] = off[p2] + (A_rowptr[perm[p2] + 1] - A_rowptr[perm[p2]]);
+      const int T = std::max(1, std::min<int>(merge_threads(), 16));
+      run_threads(T, [&](int t) {
+        for (int64_t p2 = n * t / T; p2 < n * (t + 1) / T; ++p2) {
+          const int32_t src = A_rowptr[perm[p2]], len = A_rowptr[perm[p2] + 1] - src;
+          std::copy(A_val + src, A_val + src + len, lv.begin() + off[p2]);
+        }
+      });
+      rc = dev_upload(&L->lo_val, lv.data(), (int64_t)lv.size());
+      same_pattern = rc == AMGH_OK;
+      if (same_pattern) M->bytes += 8 * (int64_t)lv.size();
+    }
+    if (rc == AMGH_OK && both && same_pattern && g->nblk == 0 && g_gs_keep_lo && (int64_t)g->h_perm.size() == n) {
       const std::vector<int32_t>& perm = g->h_perm;
       std::vector<int32_t> inv(n);
       for (int64_t p2 = 0; p2 < n; ++p2) inv[perm[p2]] = (int32_t)p2;
       std::vector<int32_t> prp(n + 1, 0), pcl(P_rowptr[n]);
       std::vector<double> pvl(P_rowptr[n]);
       for (int64_t p2 = 0; p2 < n; ++p2) prp[p2 + 1] = prp[p2] + (P_rowptr[perm[p2] + 1] - P_rowptr[perm[p2]]);
-      for (int64_t p2 = 0; p2 < n; ++p2) {
-        const int32_t src = P_rowptr[perm[p2]], len = P_rowptr[perm[p2] + 1] - src;
-        std::copy(P_col + src, P_col + src + len, pcl.begin() + prp[p2]);
-        std::copy(P_val + src, P_val + src + len, pvl.begin() + prp[p2]);
-      }
+      const int T2 = std::max(1, std::min<int>(merge_threads(), 16));
       std::vector<int32_t> rcl(R_rowptr[nc]);
-      for (int64_t k = 0; k < R_rowptr[nc]; ++k) rcl[k] = inv[R_col[k]];  // entries keep their order: same sums
+      const int64_t rnnz = R_rowptr[nc];
+      run_threads(T2, [&](int t) {
+        for (int64_t p2 = n * t / T2; p2 < n * (t + 1) / T2; ++p2) {
+          const int32_t src = P_rowptr[perm[p2]], len = P_rowptr[perm[p2] + 1] - src;
+          std::copy(P_col + src, P_col + src + len, pcl.begin() + prp[p2]);
+          std::copy(P_val + src, P_val + src + len, pvl.begin() + prp[p2]);
+        }
+        for (int64_t k = rnnz * t / T2; k < rnnz * (t + 1) / T2; ++k) rcl[k] = inv[R_col[k]];  // entries keep their order: same sums
+      });
       rc = csr_upload(&L->Pp, h->device, n, nc, prp.data(), pcl.data(), pvl.data());
       if (rc == AMGH_OK) rc = csr_upload(&L->Rp, h->device, nc, n, R_rowptr, rcl.data(), R_val);
       L->lo_ok = rc == AMGH_OK;
@@ -602,11 +631,12 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
       op->bytes -= (op->nrows + 1) * 4 + op->nnz * 12;
     };
     drop(&L->P); drop(&L->R);
-    if (!h->levels.empty()) drop(&L->A);
+    if (!h->levels.empty()) { drop(&L->A); if (L->has_S) drop(&L->S); }
     L->nat_freed = true;
   }
   if (rc != AMGH_OK) {
     csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
+    hipFree(L->lo_val);
     delete L;
     return rc;
   }

@@ -149,6 +149,8 @@ struct GsSchedule {
 
 }  // namespace
 
+#include "dev_scan.hpp"
+
 struct amgh_csr {
   int device = 0;
   int64_t nrows = 0, ncols = 0, nnz = 0;

@@ -147,6 +147,89 @@ struct HostLevelCsr {
   std::vector<double> pval, pdiag;
 };
 
+// ---- schedule construction on the device ------------------------------------------------------------------------------
+// rows of a level-ordered CSR copied into their slots (positions computed on the host: wmeta), padding stays zero
+__global__ void slot_fill_kernel(const int32_t* prow, const int32_t* pcol, const double* pval, const i4_t* wmeta, int n,
+                                 int32_t* wcol, double* wval) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const i4_t m = wmeta[p];
+  const int len = m.y - m.x;
+  if (len <= 0) return;  // row not in a slotted segment
+  const int32_t src = prow[p];
+  for (int e = 0; e < len; ++e) {
+    wcol[m.x + e] = pcol[src + e];
+    wval[m.x + e] = pval[src + e];
+  }
+}
+// dependency level of every level-ordered row
+__global__ void lev_of_kernel(const int32_t* lvl_ptr, int nlev, int n, int32_t* lev_of) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int lo = 0, hi = nlev;  // largest l with lvl_ptr[l] <= p
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (lvl_ptr[mid] <= p) lo = mid; else hi = mid;
+  }
+  lev_of[p] = lo;
+}
+// the triangle (plus halo columns) a sweep direction does not substitute over, counted (tp == nullptr) or written
+__global__ void tri_kernel(const int32_t* prow, const int32_t* pcol, const double* pval, const double* pdiag,
+                           const int32_t* lev_of, int n, int backward, double diag_shift, const int32_t* tp, int32_t* tc,
+                           double* tv, int32_t* cnt) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int lp = lev_of[p];
+  int32_t c = 0, o = tp ? tp[p] : 0;
+  for (int32_t j = prow[p]; j < prow[p + 1]; ++j) {
+    const int32_t col = pcol[j];
+    if (col == p) continue;
+    const bool other = col >= n || (backward ? lev_of[col] < lp : lev_of[col] > lp);
+    if (other) {
+      if (tp) { tc[o] = col; tv[o] = pval[j]; ++o; }
+      ++c;
+    }
+  }
+  if (diag_shift != 0.0 && pdiag[p] != 0.0) {
+    if (tp) { tc[o] = p; tv[o] = -diag_shift * pdiag[p]; }
+    ++c;
+  }
+  if (!tp) cnt[p] = c;
+}
+
+// s = b - T x pre-pass matrix of one direction, built on the device from the schedule's own level-ordered copy
+int tri_build_dev(GsSchedule::Tri* t, const GsSchedule* g, bool backward, int64_t* bytes, double diag_shift,
+                  int64_t* nnz_out) {
+  const int64_t n = g->n;
+  if (n <= 0) return AMGH_OK;
+  int32_t *lev_of = nullptr, *cnt = nullptr;
+  RC_TRY(dev_alloc(&lev_of, n));
+  int rc = dev_alloc(&cnt, n + 1);
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  int64_t total = 0;
+  if (rc == AMGH_OK) {
+    hipLaunchKernelGGL(lev_of_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)g->d_lvl_ptr, g->nlev, (int)n, lev_of);
+    hipLaunchKernelGGL(tri_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)g->rowptr, (const int32_t*)g->col,
+                       (const double*)g->val, (const double*)g->diag, (const int32_t*)lev_of, (int)n, backward ? 1 : 0,
+                       diag_shift, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, cnt);
+    rc = dev_alloc(&t->rowptr, n + 1);
+  }
+  if (rc == AMGH_OK) rc = dev_exclusive_scan(cnt, t->rowptr, n, &total, nullptr);
+  if (rc == AMGH_OK) rc = dev_alloc(&t->col, total);
+  if (rc == AMGH_OK) rc = dev_alloc(&t->val, total);
+  if (rc == AMGH_OK) {
+    hipLaunchKernelGGL(tri_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)g->rowptr, (const int32_t*)g->col,
+                       (const double*)g->val, (const double*)g->diag, (const int32_t*)lev_of, (int)n, backward ? 1 : 0,
+                       diag_shift, (const int32_t*)t->rowptr, t->col, t->val, (int32_t*)nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) rc = -1001;
+  }
+  hipFree(lev_of); hipFree(cnt);
+  if (rc != AMGH_OK) return rc;
+  *bytes += (n + 1) * 4 + total * 12;
+  if (nnz_out) *nnz_out = total;
+  return AMGH_OK;
+}
+
 // Upload one level-ordered system and derive its execution layout: row / level descriptors for the chain
 // kernel, segments (runs of narrow levels chained in one workgroup, one launch per wide level), slot arrays.
 // `orig` = original row id of each level-ordered row (rowmeta.w), may be null.
@@ -165,6 +248,7 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
   g->nlev = h.nlev;
   g->lvl_ptr = h.lvl_ptr;
   g->slot_entries = slot_entries;
+  bool full_csr_on_device = false;  // the slot fill already put the whole CSR copy on the device
   const int SE = slot_entries;                                    // entries per slot
   const int max_rows = SE == kSlot ? kSlot : kBigRows;           // rows per slot
   RC_TRY(dev_upload(&g->diag, h.pdiag.data(), n));
@@ -222,8 +306,7 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
   }
   // slot layout for the wide levels whose rows all fit a slot
   {
-    std::vector<int32_t> wcol, slot_row;
-    std::vector<double> wval;
+    std::vector<int32_t> slot_row;
     std::vector<i4_t> wmeta(n, i4_t{0, 0, -1, 0});
     for (auto& sg : g->segs) {
       if (sg.chain) continue;
@@ -252,24 +335,6 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       sg.nslots = (int)slot_row.size() - sg.slot0;
     }
     if (!slot_row.empty()) {
-      wcol.assign(slot_row.size() * (size_t)SE, 0);
-      wval.assign(slot_row.size() * (size_t)SE, 0.0);
-      {  // pass 2: the rows of the slotted levels into their slots, in parallel over row ranges
-        std::vector<std::pair<int, int>> ranges;
-        for (auto& sg : g->segs)
-          if (!sg.chain && sg.nslots > 0) ranges.push_back({g->lvl_ptr[sg.l0], g->lvl_ptr[sg.l0 + 1]});
-        const int T = std::max(1, std::min<int>(merge_threads(), 16));
-        run_threads(T, [&](int t) {
-          for (const auto& rg : ranges) {
-            const int64_t len = rg.second - rg.first;
-            const int a2 = rg.first + (int)(len * t / T), b2 = rg.first + (int)(len * (t + 1) / T);
-            for (int p2 = a2; p2 < b2; ++p2) {
-              std::copy(pcol.begin() + prow[p2], pcol.begin() + prow[p2 + 1], wcol.begin() + wmeta[p2].x);
-              std::copy(pval.begin() + prow[p2], pval.begin() + prow[p2 + 1], wval.begin() + wmeta[p2].x);
-            }
-          }
-        });
-      }
       // slot_row[s + 1] must close the last slot of every level: append per-level end markers by
       // storing, for each slot, its end row in a parallel array packed as slot_row2
       std::vector<int32_t> sr2(2 * slot_row.size());
@@ -301,13 +366,35 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
         }
         if (bad) fprintf(stderr, "[amghip] slot layout self-check: %lld inconsistencies (SE=%d)\n", (long long)bad, SE);
       }
-      RC_TRY(dev_upload(&g->wcol, wcol.data(), (int64_t)wcol.size()));
-      RC_TRY(dev_upload(&g->wval, wval.data(), (int64_t)wval.size()));
+      // the entries go into their slots ON THE DEVICE, from the level-ordered CSR (one upload of the matrix instead of
+      // two, no host-side slot arrays): the host only decided the positions
+      const int64_t wtotal = (int64_t)slot_row.size() * SE;
+      RC_TRY(dev_alloc(&g->wcol, wtotal));
+      RC_TRY(dev_alloc(&g->wval, wtotal));
+      HIP_TRY(hipMemsetAsync(g->wcol, 0, sizeof(int32_t) * wtotal, nullptr));
+      HIP_TRY(hipMemsetAsync(g->wval, 0, sizeof(double) * wtotal, nullptr));
       RC_TRY(dev_upload(&g->slot_row, sr2.data(), (int64_t)sr2.size()));
       RC_TRY(dev_upload(&g->wmeta, wmeta.data(), n));
-      g->bytes += (int64_t)wcol.size() * 12 + (int64_t)sr2.size() * 4 + n * 16;
-      g->slot_total = (int64_t)wcol.size();
-      g->slot_bytes = (int64_t)wcol.size() * 12 + (int64_t)sr2.size() * 4 + n * 16;
+      int32_t *t_row = nullptr, *t_col = nullptr;
+      double* t_val = nullptr;
+      int rcf = dev_upload(&t_row, prow.data(), n + 1);
+      if (rcf == AMGH_OK) rcf = dev_upload(&t_col, pcol.data(), nnz);
+      if (rcf == AMGH_OK) rcf = dev_upload(&t_val, pval.data(), nnz);
+      if (rcf == AMGH_OK) {
+        hipLaunchKernelGGL(slot_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)t_row,
+                           (const int32_t*)t_col, (const double*)t_val, (const i4_t*)g->wmeta, (int)n, g->wcol, g->wval);
+        if (hipDeviceSynchronize() != hipSuccess) rcf = -1001;
+      }
+      if (rcf == AMGH_OK && !compact) {  // the same arrays are this system's CSR copy
+        g->rowptr = t_row; g->col = t_col; g->val = t_val;
+        t_row = t_col = nullptr; t_val = nullptr;
+        full_csr_on_device = true;
+      }
+      hipFree(t_row); hipFree(t_col); hipFree(t_val);
+      RC_TRY(rcf);
+      g->bytes += wtotal * 12 + (int64_t)sr2.size() * 4 + n * 16;
+      g->slot_total = wtotal;
+      g->slot_bytes = wtotal * 12 + (int64_t)sr2.size() * 4 + n * 16;
     }
   }
   // the CSR copy (chain kernel, stream-kernel fallback): all rows, or — compact — only those no slot launch covers
@@ -338,9 +425,11 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       g->compacted = true;
     }
     const int64_t unnz = (*urow)[n];
-    RC_TRY(dev_upload(&g->rowptr, urow->data(), n + 1));
-    RC_TRY(dev_upload(&g->col, ucol->data(), unnz));
-    RC_TRY(dev_upload(&g->val, uval->data(), unnz));
+    if (!full_csr_on_device) {
+      RC_TRY(dev_upload(&g->rowptr, urow->data(), n + 1));
+      RC_TRY(dev_upload(&g->col, ucol->data(), unnz));
+      RC_TRY(dev_upload(&g->val, uval->data(), unnz));
+    }
     RC_TRY(dev_upload(&g->dpos, udpos->data(), n));
     std::vector<i4_t> meta(n), desc(g->nlev);
     for (int64_t p2 = 0; p2 < n; ++p2)
@@ -494,9 +583,10 @@ int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncol
 std::pair<double, int64_t> merge_estimate(const HostLevelCsr& base, int64_t ncols, int m, bool backward) {
   MergeGroups G = merge_groups(base, m, backward);
   if (G.ngrp == 0) return {0.0, 0};
-  // about two million rows in the sample, 8..48 groups, evenly spaced
+  // about 600 k rows in the sample, 8..48 groups, evenly spaced (the estimate only ranks group sizes; the build
+  // re-checks the longest row)
   const int64_t rows_per_group = std::max<int64_t>(1, base.n / G.ngrp);
-  const int nsample = (int)std::min<int64_t>(G.ngrp, std::max<int64_t>(8, std::min<int64_t>(48, 2000000 / rows_per_group)));
+  const int nsample = (int)std::min<int64_t>(G.ngrp, std::max<int64_t>(8, std::min<int64_t>(48, 600000 / rows_per_group)));
   const int T = std::max(1, std::min(merge_threads(), nsample));
   std::vector<int64_t> rows(T, 0), ents(T, 0), mx(T, 0);
   run_threads(T, [&](int t) {
@@ -561,34 +651,6 @@ MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool bac
   }
   for (int64_t p = 0; p < n; ++p) S.prow[p + 1] += S.prow[p];
   return R;
-}
-
-// the triangle (plus halo columns) a sweep direction does NOT substitute over: s = b - T x before the sweep
-// diag_shift != 0 (SOR): the diagonal enters the pre-pass with -diag_shift * d, i.e. s = b - T x + diag_shift * D x
-int tri_upload(GsSchedule::Tri* t, const HostLevelCsr& base, bool backward, int64_t* bytes, double diag_shift = 0.0,
-               int64_t* nnz_out = nullptr) {
-  const int64_t n = base.n;
-  std::vector<int32_t> lev_of(n);
-  for (int l = 0; l < base.nlev; ++l)
-    for (int32_t p = base.lvl_ptr[l]; p < base.lvl_ptr[l + 1]; ++p) lev_of[p] = l;
-  std::vector<int32_t> rp(n + 1, 0), cc;
-  std::vector<double> vv;
-  for (int64_t p = 0; p < n; ++p) {
-    for (int32_t j = base.prow[p]; j < base.prow[p + 1]; ++j) {
-      const int32_t c = base.pcol[j];
-      if (c == p) continue;
-      const bool other = c >= n || (backward ? lev_of[c] < lev_of[p] : lev_of[c] > lev_of[p]);
-      if (other) { cc.push_back(c); vv.push_back(base.pval[j]); }
-    }
-    if (diag_shift != 0.0 && base.pdiag[p] != 0.0) { cc.push_back((int32_t)p); vv.push_back(-diag_shift * base.pdiag[p]); }
-    rp[p + 1] = (int32_t)cc.size();
-  }
-  RC_TRY(dev_upload(&t->rowptr, rp.data(), n + 1));
-  RC_TRY(dev_upload(&t->col, cc.data(), (int64_t)cc.size()));
-  RC_TRY(dev_upload(&t->val, vv.data(), (int64_t)vv.size()));
-  *bytes += (n + 1) * 4 + (int64_t)cc.size() * 12;
-  if (nnz_out) *nnz_out = (int64_t)cc.size();
-  return AMGH_OK;
 }
 
 // Substituted coefficients grow like prod |l_ij / d_j| along the chains inside a group: bounded by 1 for diagonally
@@ -773,8 +835,8 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         ch->ncols = g->ncols;
         RC_TRY(layout_upload(ch, keep.sys, perm.data(), cap, gs_lean()));
         tm.lap("merged layout", n);
-        RC_TRY(tri_upload(backward ? &g->tri_b : &g->tri_f, base, backward, &g->bytes, 0.0,
-                          backward ? &g->tri_nnz_b : &g->tri_nnz));
+        RC_TRY(tri_build_dev(backward ? &g->tri_b : &g->tri_f, g, backward, &g->bytes, 0.0,
+                             backward ? &g->tri_nnz_b : &g->tri_nnz));
         tm.lap("other triangle", n);
         (backward ? g->merge_b : g->merge_f) = best_m;
         g->bytes += ch->bytes;
@@ -887,7 +949,7 @@ GsSchedule::SorSet* sor_children(GsSchedule* g, double omega) {
       GsSchedule* ch = new GsSchedule;
       ch->ncols = g->ncols;
       if (layout_upload(ch, keep.sys, nullptr, cap) != AMGH_OK ||
-          tri_upload(backward ? &ss.tb : &ss.tf, base, backward, &g->bytes, (1.0 - omega) / omega) != AMGH_OK) {
+          tri_build_dev(backward ? &ss.tb : &ss.tf, g, backward, &g->bytes, (1.0 - omega) / omega, nullptr) != AMGH_OK) {
         ch->free_dev();
         delete ch;
         continue;

@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--light", action="store_true", help="profiling runs: skip the extra smoother timing")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--force-dist", action="store_true", help="run the row-sharded driver even with one rank")
+    ap.add_argument("--setup", default="gpu", choices=("gpu", "host"), help="where the data-parallel half of ruge_stuben runs")
     args = ap.parse_args()
 
     if args.gpus > 1 or args.force_dist:
@@ -129,7 +130,9 @@ def main():
     N = args.size
     t0 = time.perf_counter()
     A = AMG.poisson((N, N, N))
-    ml = AMG.ruge_stuben(A)            # defaults: Classical(0.25), RS(), symmetric Gauss-Seidel pre/post
+    # defaults: Classical(0.25), RS(), symmetric Gauss-Seidel pre/post; strength / interpolation / R*A*P on the GPU
+    # (bitwise the host library's hierarchy, tests/test_gpu_setup.py), the sequential C/F splitting on the host
+    ml = AMG.ruge_stuben(A, setup=args.setup)
     t_setup = time.perf_counter() - t0
     n = A.m
     t0 = time.perf_counter()

@@ -65,7 +65,7 @@ def main_distributed(args):
     tail = None
     if rank == 0:
         A = AMG.poisson((N, N, N))
-        ml = AMG.ruge_stuben(A)          # defaults: Classical(0.25), RS(), symmetric Gauss-Seidel pre/post
+        ml = AMG.ruge_stuben(A, setup=getattr(args, "setup", "gpu"))   # defaults: Classical(0.25), RS(), symmetric GS
         sizes = [l.A.m for l in ml.levels] + [ml.final_A.m]
         lc = SH.num_sharded_levels(sizes, world)
         levels = SH.level_arrays(ml, lc)
