@@ -203,6 +203,7 @@ def hip_lib():
         getattr(L, f).restype = i64
         getattr(L, f).argtypes = [vp]
     L.amgh_setup_transpose.argtypes = [vp, C.POINTER(vp)]
+    L.amgh_dmat_equal.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.amgh_setup_classical_strength.argtypes = [vp, C.c_double, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.amgh_setup_direct_interpolation.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     L.amgh_setup_spgemm.argtypes = [vp, vp, C.POINTER(vp)]

@@ -393,6 +393,37 @@ int64_t amgh_dmat_rows(const amgh_dmat_t* M) { return M ? M->m : -1; }
 int64_t amgh_dmat_cols(const amgh_dmat_t* M) { return M ? M->n : -1; }
 int64_t amgh_dmat_nnz(const amgh_dmat_t* M) { return M ? M->nnz : -1; }
 
+// *same = 1 when the two matrices have identical arrays (A == copy(A') is how the host mirror detects symmetry)
+__global__ void dmat_equal_kernel(const int32_t* p1, const int32_t* i1, const double* v1, const int32_t* p2,
+                                  const int32_t* i2, const double* v2, int64_t n, int64_t nnz, int32_t* differ) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz + n + 1; k += (int64_t)gridDim.x * blockDim.x) {
+    bool d;
+    if (k <= n) d = p1[k] != p2[k];
+    else { const int64_t q = k - n - 1; d = i1[q] != i2[q] || !(v1[q] == v2[q]); }
+    if (d) *differ = 1;
+  }
+}
+int amgh_dmat_equal(const amgh_dmat_t* A, const amgh_dmat_t* B, int* same) {
+  RC_TRY(dmat_check(A));
+  RC_TRY(dmat_check(B));
+  if (!same) return AMGH_EINVAL;
+  *same = 0;
+  if (A->m != B->m || A->n != B->n || A->nnz != B->nnz) return AMGH_OK;
+  HIP_TRY(hipSetDevice(A->device));
+  int32_t* differ = nullptr;
+  RC_TRY(dev_alloc(&differ, 1));
+  HIP_TRY(hipMemset(differ, 0, sizeof(int32_t)));
+  hipLaunchKernelGGL(dmat_equal_kernel, dim3(grid_for(A->nnz + A->n + 1)), dim3(256), 0, nullptr, (const int32_t*)A->ptr,
+                     (const int32_t*)A->idx, (const double*)A->val, (const int32_t*)B->ptr, (const int32_t*)B->idx,
+                     (const double*)B->val, A->n, A->nnz, differ);
+  int32_t h = 1;
+  hipError_t e = hipMemcpy(&h, differ, sizeof(int32_t), hipMemcpyDeviceToHost);
+  hipFree(differ);
+  if (e != hipSuccess) return -(1000 + (int)e);
+  *same = h == 0;
+  return AMGH_OK;
+}
+
 int amgh_setup_transpose(const amgh_dmat_t* A, amgh_dmat_t** At) {
   RC_TRY(dmat_check(A));
   if (!At) return AMGH_EINVAL;

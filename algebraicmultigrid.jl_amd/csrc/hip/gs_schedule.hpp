@@ -235,8 +235,19 @@ int tri_build_dev(GsSchedule::Tri* t, const GsSchedule* g, bool backward, int64_
 // `orig` = original row id of each level-ordered row (rowmeta.w), may be null.
 // compact (memory-lean mode, merged children only): the CSR copy keeps just the rows no slot launch covers (chained
 // narrow groups, rows too long for a slot); every other row lives in the slot arrays only.
+// dev_src (optional): the rows' entries are already on the device as a contiguous CSR (h.pcol / h.pval are empty; only
+// h.prow, the row lengths, is used on the host); ownership of the three arrays passes to this function.
+struct DevCsr { int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; };
+__global__ void compact_rows_kernel(const int32_t* prow, const int32_t* pcol, const double* pval, const int32_t* cprow, int n,
+                                    int32_t* ccol, double* cval) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int len = cprow[p + 1] - cprow[p];
+  const int32_t src = prow[p], dst = cprow[p];
+  for (int e = 0; e < len; ++e) { ccol[dst + e] = pcol[src + e]; cval[dst + e] = pval[src + e]; }
+}
 int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int slot_entries = kSlot,
-                  bool compact = false) {
+                  bool compact = false, DevCsr* dev_src = nullptr) {
   const int64_t n = h.n;
   const std::vector<int32_t>& prow = h.prow;
   const std::vector<int32_t>& pcol = h.pcol;
@@ -377,9 +388,14 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       RC_TRY(dev_upload(&g->wmeta, wmeta.data(), n));
       int32_t *t_row = nullptr, *t_col = nullptr;
       double* t_val = nullptr;
-      int rcf = dev_upload(&t_row, prow.data(), n + 1);
-      if (rcf == AMGH_OK) rcf = dev_upload(&t_col, pcol.data(), nnz);
-      if (rcf == AMGH_OK) rcf = dev_upload(&t_val, pval.data(), nnz);
+      int rcf = AMGH_OK;
+      if (dev_src) {
+        t_row = dev_src->rowptr; t_col = dev_src->col; t_val = dev_src->val;
+      } else {
+        rcf = dev_upload(&t_row, prow.data(), n + 1);
+        if (rcf == AMGH_OK) rcf = dev_upload(&t_col, pcol.data(), nnz);
+        if (rcf == AMGH_OK) rcf = dev_upload(&t_val, pval.data(), nnz);
+      }
       if (rcf == AMGH_OK) {
         hipLaunchKernelGGL(slot_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)t_row,
                            (const int32_t*)t_col, (const double*)t_val, (const i4_t*)g->wmeta, (int)n, g->wcol, g->wval);
@@ -389,8 +405,9 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
         g->rowptr = t_row; g->col = t_col; g->val = t_val;
         t_row = t_col = nullptr; t_val = nullptr;
         full_csr_on_device = true;
+        if (dev_src) *dev_src = DevCsr();
       }
-      hipFree(t_row); hipFree(t_col); hipFree(t_val);
+      if (!dev_src) { hipFree(t_row); hipFree(t_col); hipFree(t_val); }
       RC_TRY(rcf);
       g->bytes += wtotal * 12 + (int64_t)sr2.size() * 4 + n * 16;
       g->slot_total = wtotal;
@@ -412,24 +429,46 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
           for (int32_t p2 = g->lvl_ptr[sg.l0]; p2 < g->lvl_ptr[sg.l1]; ++p2) keep[p2] = 1;
       cprow.assign(n + 1, 0);
       for (int64_t p2 = 0; p2 < n; ++p2) cprow[p2 + 1] = cprow[p2] + (keep[p2] ? prow[p2 + 1] - prow[p2] : 0);
-      ccol.resize(cprow[n]);
-      cval.resize(cprow[n]);
       cdpos.assign(n, -1);
+      if (!dev_src) {
+        ccol.resize(cprow[n]);
+        cval.resize(cprow[n]);
+      }
       for (int64_t p2 = 0; p2 < n; ++p2) {
         if (!keep[p2]) continue;
-        std::copy(pcol.begin() + prow[p2], pcol.begin() + prow[p2 + 1], ccol.begin() + cprow[p2]);
-        std::copy(pval.begin() + prow[p2], pval.begin() + prow[p2 + 1], cval.begin() + cprow[p2]);
+        if (!dev_src) {
+          std::copy(pcol.begin() + prow[p2], pcol.begin() + prow[p2 + 1], ccol.begin() + cprow[p2]);
+          std::copy(pval.begin() + prow[p2], pval.begin() + prow[p2 + 1], cval.begin() + cprow[p2]);
+        }
         if (pdpos[p2] >= 0) cdpos[p2] = pdpos[p2] - prow[p2] + cprow[p2];
       }
       urow = &cprow; ucol = &ccol; udpos = &cdpos; uval = &cval;
       g->compacted = true;
     }
     const int64_t unnz = (*urow)[n];
-    if (!full_csr_on_device) {
+    if (!full_csr_on_device && dev_src) {
+      // entries already on the device: all rows (no slotted level at all) or the kept rows gathered by a kernel
+      if (!compact) {
+        if (!dev_src->rowptr) RC_TRY(dev_upload(&dev_src->rowptr, prow.data(), n + 1));
+        g->rowptr = dev_src->rowptr; g->col = dev_src->col; g->val = dev_src->val;
+        *dev_src = DevCsr();
+      } else {
+        RC_TRY(dev_upload(&g->rowptr, urow->data(), n + 1));
+        RC_TRY(dev_alloc(&g->col, unnz));
+        RC_TRY(dev_alloc(&g->val, unnz));
+        if (!dev_src->rowptr) RC_TRY(dev_upload(&dev_src->rowptr, prow.data(), n + 1));
+        if (n > 0)
+          hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
+                             (const int32_t*)dev_src->rowptr, (const int32_t*)dev_src->col, (const double*)dev_src->val,
+                             (const int32_t*)g->rowptr, (int)n, g->col, g->val);
+        HIP_TRY(hipDeviceSynchronize());
+      }
+    } else if (!full_csr_on_device) {
       RC_TRY(dev_upload(&g->rowptr, urow->data(), n + 1));
       RC_TRY(dev_upload(&g->col, ucol->data(), unnz));
       RC_TRY(dev_upload(&g->val, uval->data(), unnz));
     }
+    if (dev_src) { hipFree(dev_src->rowptr); hipFree(dev_src->col); hipFree(dev_src->val); *dev_src = DevCsr(); }
     RC_TRY(dev_upload(&g->dpos, udpos->data(), n));
     std::vector<i4_t> meta(n), desc(g->nlev);
     for (int64_t p2 = 0; p2 < n; ++p2)
@@ -661,6 +700,10 @@ constexpr double kMergeGrowthMax = 1e4;
 // estimated time of one sweep over a grouped system: a kernel boundary per group + streaming its entries
 double merge_cost(int64_t ngroups, int64_t nnz) { return ngroups * 3.8e-6 + 12.0 * (double)nnz / 2.5e12; }
 
+}  // namespace
+#include "gs_merge_dev.hpp"
+namespace {
+
 // Build the dependency-level schedule from HOST arrays of the smoother matrix.
 struct BuildTimer {  // AMGH_VERBOSE: where the host time of a schedule build goes
   bool on = getenv("AMGH_VERBOSE") != nullptr;
@@ -791,10 +834,121 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
     const int S = g->super > 0 ? g->super : std::max(1, g->nblk);
     const double block_cost = g->nblk * 5.9e-6 + 2.0 * ((g->nblk + S - 1) / S) * 3.5e-6;
     int chosen_m[2] = {1, 1}, chosen_cap[2] = {kSlot, kSlot};
+    const bool host_merge = getenv("AMGH_HOST_MERGE") != nullptr;  // the host construction (reference for the device one)
+    if (!host_merge) {
+      // Candidates are BUILT on the device (milliseconds each: gs_merge_dev.hpp) instead of estimated from a sample on
+      // the host: exact entry counts and longest rows for the cost model, and the chosen one is already there.
+      int32_t* d_lev_of = nullptr;
+      RC_TRY(dev_alloc(&d_lev_of, n));
+      hipLaunchKernelGGL(lev_of_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)g->d_lvl_ptr,
+                         g->nlev, (int)n, d_lev_of);
+      MergeDev chosen[2];
+      int rc2 = AMGH_OK;
+      for (int dir = 0; dir < 2 && rc2 == AMGH_OK; ++dir) {
+        const bool backward = dir == 1;
+        double best = g->nblk > 0 ? block_cost : merge_cost(base.nlev, nnz);
+        int worse = 0;
+        // the backward grouping mirrors the forward one (same pattern, levels counted from the other end): its best
+        // group size sits next to the forward one, so only that neighbourhood is built
+        // (if nothing is accepted there — e.g. its rows outgrow the slots earlier — the search restarts from 2)
+        for (int attempt = 0; attempt < 2 && rc2 == AMGH_OK; ++attempt) {
+        const int m_lo = (attempt == 0 && dir == 1 && chosen_m[0] > 2) ? chosen_m[0] - 1 : 2;
+        if (attempt == 1 && (chosen_m[dir] > 1 || !(dir == 1 && chosen_m[0] > 2))) break;
+        worse = 0;
+        for (int m = m_lo; m <= std::min(g_gs_merge, kMergeMaxRounds); ++m) {
+          MergeDev md;
+          rc2 = merge_build_dev(g, d_lev_of, g->diag, m, backward, &md);
+          if (rc2 != AMGH_OK) break;
+          if (md.failed || md.max_row > kBigSlot - kBigSlot / 8) { md.free_dev(); break; }  // fill has exploded
+          int cap = kSlot;
+          if (md.max_row > kSlot || g_gs_bigslot == 2) cap = kBigSlot;  // (2 = always: test hook)
+          if (cap == kBigSlot && !g_gs_bigslot) { md.free_dev(); break; }
+          if (md.growth > kMergeGrowthMax) {  // substitution amplifies on this operator: no deeper groups
+            if (getenv("AMGH_VERBOSE"))
+              fprintf(stderr, "[amghip] n=%lld %s merge m=%d rejected: coefficient growth %.3g\n", (long long)n,
+                      backward ? "bwd" : "fwd", m, md.growth);
+            md.free_dev();
+            break;
+          }
+          const int ngrp = (base.nlev + m - 1) / m;
+          // + the pre-pass; a long-row launch costs ~2.5 us more (a wave per row, rows of very different lengths)
+          const double c = merge_cost(ngrp, md.total) + 12.0 * (double)nnz / 2 / 4e12 + (cap == kBigSlot ? ngrp * 2.5e-6 : 0.0);
+          if (getenv("AMGH_VERBOSE"))
+            fprintf(stderr, "[amghip] n=%lld %s merge m=%d: %d groups, %.1f entries/row (max %lld), est. %.2f ms vs %.2f ms\n",
+                    (long long)n, backward ? "bwd" : "fwd", m, ngrp, (double)md.total / n, (long long)md.max_row, 1e3 * c, 1e3 * best);
+          const bool stream_bound = 12.0 * (double)md.total / 2.5e12 > best;  // streaming the composite rows alone costs more
+          if (c < 0.97 * best) {
+            best = c; chosen_m[dir] = m; chosen_cap[dir] = cap; worse = 0;
+            chosen[dir].free_dev();
+            chosen[dir] = std::move(md);
+            md = MergeDev();
+          } else {
+            md.free_dev();
+            // well past the minimum — but the step to long-row slots is a bump, not the end: operators that compete with
+            // the block-inverse path (small, long rows) only pay off at deep groups, keep looking there
+            if (++worse >= (g->nblk > 0 ? 8 : 4)) break;
+          }
+          if (stream_bound) break;
+        }
+        }
+      }
+      tm.lap("merge candidates (device)", n);
+      const bool use = g->nblk == 0 ? true : (chosen_m[0] > 1 && chosen_m[1] > 1);
+      for (int dir = 0; dir < 2 && rc2 == AMGH_OK; ++dir) {
+        const bool backward = dir == 1;
+        MergeDev& md = chosen[dir];
+        if (!use || chosen_m[dir] <= 1) { md.free_dev(); continue; }
+        const int best_m = chosen_m[dir], cap = chosen_cap[dir];
+        // the grouped system: groups as levels, composite rows gathered into one CSR on the device
+        HostLevelCsr sys;
+        MergeGroups G = merge_groups(base, best_m, backward);
+        sys.n = n;
+        sys.pdiag = base.pdiag;
+        sys.pdpos.assign(n, -1);
+        sys.nlev = G.ngrp;
+        sys.lvl_ptr.assign(G.gptr.begin(), G.gptr.end());
+        sys.prow.assign(n + 1, 0);
+        for (int64_t p2 = 0; p2 < n; ++p2) sys.prow[p2 + 1] = sys.prow[p2] + md.h_clen[p2];
+        DevCsr src;
+        rc2 = dev_upload(&src.rowptr, sys.prow.data(), n + 1);
+        if (rc2 == AMGH_OK) rc2 = dev_alloc(&src.col, md.total);
+        if (rc2 == AMGH_OK) rc2 = dev_alloc(&src.val, md.total);
+        if (rc2 == AMGH_OK) {
+          MergeArgs a{};
+          a.n = (int)n; a.clen = md.clen; a.coff = md.coff; a.lev_of = d_lev_of; a.nlev = g->nlev; a.m = best_m;
+          a.backward = backward ? 1 : 0; a.ngrp = md.ngrp;
+          for (int q = 0; q < kMergeMaxRounds; ++q) { a.rcol[q] = md.rcol[q]; a.rval[q] = md.rval[q]; }
+          hipLaunchKernelGGL(merge_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, a,
+                             (const int32_t*)src.rowptr, src.col, src.val);
+          if (hipDeviceSynchronize() != hipSuccess) rc2 = -1001;
+        }
+        const int64_t max_row = md.max_row;
+        md.free_dev();
+        if (rc2 == AMGH_OK) {
+          GsSchedule* ch = new GsSchedule;
+          (backward ? g->mb : g->mf) = ch;
+          ch->ncols = g->ncols;
+          rc2 = layout_upload(ch, sys, perm.data(), cap, gs_lean(), &src);
+          tm.lap("merged layout", n);
+          if (rc2 == AMGH_OK)
+            rc2 = tri_build_dev(backward ? &g->tri_b : &g->tri_f, g, backward, &g->bytes, 0.0,
+                                backward ? &g->tri_nnz_b : &g->tri_nnz);
+          tm.lap("other triangle", n);
+          (backward ? g->merge_b : g->merge_f) = best_m;
+          g->bytes += ch->bytes;
+          if (getenv("AMGH_VERBOSE"))
+            fprintf(stderr, "[amghip] n=%lld %s: groups of %d levels, %d-entry slots, longest row %lld\n", (long long)n,
+                    backward ? "bwd" : "fwd", best_m, cap, (long long)max_row);
+        }
+        hipFree(src.rowptr); hipFree(src.col); hipFree(src.val);
+      }
+      for (MergeDev& md : chosen) md.free_dev();
+      hipFree(d_lev_of);
+      RC_TRY(rc2);
+    } else {
     for (int dir = 0; dir < 2; ++dir) {
       const bool backward = dir == 1;
-      double best = g->nblk > 0 ? block_cost : merge_cost(base.nlev, nnz);
-      int worse = 0;
+      double best = g->nblk > 0 ? block_cost : merge_cost(base.nlev, nnz);      int worse = 0;
       for (int m = 2; m <= g_gs_merge; ++m) {  // fill estimated on a sample of groups
         const std::pair<double, int64_t> est = merge_estimate(base, g->ncols, m, backward);
         int cap = kSlot;
@@ -808,7 +962,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           fprintf(stderr, "[amghip] n=%lld %s merge m=%d: %d groups, ~%.1f entries/row (max %lld), est. %.2f ms vs %.2f ms\n",
                   (long long)n, backward ? "bwd" : "fwd", m, ngrp, est.first, (long long)est.second, 1e3 * c, 1e3 * best);
         if (c < 0.97 * best) { best = c; chosen_m[dir] = m; chosen_cap[dir] = cap; worse = 0; }
-        else if (++worse >= 6) break;  // well past the minimum (the step to long-row slots is a bump, not the end)
+        else if (++worse >= 4) break;  // well past the minimum (the step to long-row slots is a bump, not the end)
         if (12.0 * est.first * n / 2.5e12 > best) break;  // streaming the composite rows alone costs more: fill only grows with m
       }
     }
@@ -844,6 +998,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           fprintf(stderr, "[amghip] n=%lld %s: groups of %d levels, %d-entry slots, longest row %lld\n", (long long)n,
                   backward ? "bwd" : "fwd", best_m, cap, (long long)keep.max_row);
       }
+    }
     }
     if (g->nblk > 0 && g->mf && g->mb) {  // merged groups replace the block-inverse sweeps
       for (GsSchedule::Outer* o : {&g->blk_f, &g->blk_b}) {
@@ -935,7 +1090,7 @@ GsSchedule::SorSet* sor_children(GsSchedule* g, double omega) {
       const double c = merge_cost(ngrp, (int64_t)(est.first * n)) + 12.0 * (double)nnz / 2 / 4e12 +
                        (cap_m == kBigSlot ? ngrp * 2.5e-6 : 0.0);
       if (c < 0.97 * best) { best = c; best_m = m; cap = cap_m; worse = 0; }
-      else if (++worse >= 6) break;
+      else if (++worse >= 4) break;
       if (12.0 * est.first * n / 2.5e12 > best) break;
     }
     MergeResult keep;

@@ -164,10 +164,15 @@ class DeviceHierarchy:
         hip_check(self.lib.amgh_create(C.byref(h), device, self.nrhs), "create")
         self.h = h.value
         hermitian = isinstance(ml.symmetry, HermitianSymmetry)
+        import os
+        import time
+        verbose = bool(os.environ.get("AMGH_VERBOSE"))
         for lev in ml.levels:
+            t_lev = time.perf_counter()
             A = lev.A
             n, nc = A.m, lev.P.n
             Ar, Ac, Av = A.csr_arrays()                  # true A rows
+            t_arr = time.perf_counter() - t_lev
             if hermitian and not A.is_symmetric():
                 Sr, Sc, Sv = A.colptr, A.rowval, A.nzval  # column i read as row i
             else:
@@ -184,6 +189,9 @@ class DeviceHierarchy:
             hip_check(self.lib.amgh_push_level(self.h, n, nc, _ptr(Ar), _ptr(Ac), _ptr(Av), _ptr(Sr), _ptr(Sc),
                                                _ptr(Sv), _ptr(Pr), _ptr(Pc), _ptr(Pv), _ptr(Rr), _ptr(Rc), _ptr(Rv),
                                                C.byref(pre), C.byref(post)), "push_level")
+            if verbose:
+                print(f"[amghip] n={n} python: csr_arrays {t_arr:.2f} s, level total {time.perf_counter() - t_lev:.2f} s",
+                      file=__import__("sys").stderr, flush=True)
         fA = ml.final_A
         fr, fc, fv = fA.csr_arrays()
         cs = ml.coarse_solver

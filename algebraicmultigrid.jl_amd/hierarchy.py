@@ -375,16 +375,34 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0):
         hip_check(rc, "setup_spgemm")
         return _DMat(c.value, lib)
 
+    def prime_symmetry(M_host, dM):
+        """issymmetric(M) and copy(M') from the device while M is there (milliseconds), so that the upload of the
+        hierarchy (which asks every level's A for its CSR arrays) does not transpose on the host again."""
+        t = C.c_void_p()
+        hip_check(lib.amgh_setup_transpose(dM.h, C.byref(t)), "setup_transpose")
+        dT = _DMat(t.value, lib)
+        same = C.c_int(0)
+        hip_check(lib.amgh_dmat_equal(dM.h, dT.h, C.byref(same)), "dmat_equal")
+        M_host._sym = bool(same.value)
+        if not M_host._sym:
+            M_host._T = dT.to_host()
+            M_host._T._sym = False
+            M_host._T._T = M_host
+        return dT
+
     out = []
     A_host, dA = A, _DMat.upload(A, lib, device)
     while len(out) + 1 < max_levels and A_host.m > max_coarse:
         n = A_host.m
+        dAT = prime_symmetry(A_host, dA) if A_host._sym is None else None
         if hermitian:
             dAt = dA
         else:
-            t = C.c_void_p()
-            hip_check(lib.amgh_setup_transpose(dA.h, C.byref(t)), "setup_transpose")
-            dAt = _DMat(t.value, lib)
+            if dAT is None:
+                t = C.c_void_p()
+                hip_check(lib.amgh_setup_transpose(dA.h, C.byref(t)), "setup_transpose")
+                dAT = _DMat(t.value, lib)
+            dAt = dAT
         s_, t_, sn, tn = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         hip_check(lib.amgh_setup_classical_strength(dAt.h, theta, C.byref(s_), C.byref(t_), C.byref(sn), C.byref(tn)),
                   "setup_classical_strength")
@@ -402,6 +420,8 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0):
         dRAP = spgemm(spgemm(dR, dA), dP)
         out.append((A_host, dP.to_host(), dR.to_host()))
         A_host, dA = dRAP.to_host(), dRAP
+    if A_host._sym is None:
+        prime_symmetry(A_host, dA)
     return out, A_host
 
 

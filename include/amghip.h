@@ -330,6 +330,8 @@ int64_t amgh_dmat_cols(const amgh_dmat_t* M);
 int64_t amgh_dmat_nnz(const amgh_dmat_t* M);
 /* copy(A')                                                                       */
 int amgh_setup_transpose(const amgh_dmat_t* A, amgh_dmat_t** At);
+/* *same = 1 when A and B hold identical arrays (issymmetric(A): compare with its transpose) */
+int amgh_dmat_equal(const amgh_dmat_t* A, const amgh_dmat_t* B, int* same);
 /* S, T = Classical(theta)(At)  (strength.jl:7-37): T = thresholded |At| scaled by its column maxima,
  * S = T'.  Sn, Tn (both NULL or both non-NULL): the PATTERNS the C/F splitting consumes — S without its
  * diagonal (remove_diag, splitting.jl:8-18) and its transpose — so the host needs no matrix work of its own. */

@@ -169,3 +169,41 @@ def test_memory_lean_hierarchy_is_bitwise_the_default_one():
     with pytest.raises(AMG.AMGError):
         lean.spmv(1, 0, np.ones(ml.levels[1].A.m))
     assert np.array_equal(lean.spmv(0, 0, b), full.spmv(0, 0, b))     # the fine-level A stays (outer residual of _solve!)
+
+
+@pytest.mark.parametrize("case", ["poisson3d", "rs_coarse", "irregular"])
+def test_device_built_merged_groups_equal_the_host_construction_bit_for_bit(case, monkeypatch):
+    """The composite rows of the merged dependency-level groups are built on the device (gs_merge_dev.hpp); the host
+    construction (AMGH_HOST_MERGE=1) is its reference: same grouping decisions aside, a sweep through either must
+    give the same bits, because every coefficient is accumulated in the same order."""
+    from amg_amd.device import DeviceCSR
+    if case == "poisson3d":
+        A = AMG.poisson((40, 40, 40))
+    elif case == "rs_coarse":
+        A = AMG.ruge_stuben(AMG.poisson((48, 48, 48)), max_levels=3).levels[1].A     # a 19-point-like Galerkin operator
+    else:
+        import scipy.sparse as sp
+        rng = np.random.default_rng(5)
+        n = 6000
+        B = sp.random(n, n, density=4.0 / n, random_state=7, format="csr")
+        B = B + B.T + sp.diags(np.arange(n) % 5 + 8.0)
+        B = B + sp.diags([-0.3 * np.ones(n - 1), -0.3 * np.ones(n - 1)], [-1, 1])
+        A = AMG.SparseMatrixCSC.from_scipy(B.tocsc())
+    rp, ci, va = A.colptr, A.rowval, A.nzval      # column i swept as row i (smoother.jl:81-86)
+    n = A.m
+    x0, b = uniform(n, 3) - 0.5, uniform(n, 4)
+    gs = AMG.GaussSeidel(AMG.SymmetricSweep(), 2)
+    lib = AMG.hip_lib()
+    out = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("AMGH_HOST_MERGE", "1")
+        else:
+            monkeypatch.delenv("AMGH_HOST_MERGE", raising=False)
+        op = DeviceCSR(n, n, rp, ci, va)
+        assert lib.amgh_csr_prepare(op.h, 0, 1) == 0
+        out[mode] = op.smooth(gs, x0.copy(), b)
+    assert np.array_equal(out["device"], out["host"])
+    # and both are the lexicographic sweep
+    xo = O.smooth(gs, A, x0, b)
+    assert rel(out["device"], xo) <= 1e-11
