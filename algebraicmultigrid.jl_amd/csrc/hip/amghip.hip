@@ -1211,6 +1211,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
   else if (!strcmp(name, "gs_lpr")) g_gs_lpr = value;
   else if (!strcmp(name, "gs_lean")) g_gs_lean = value;
+  else if (!strcmp(name, "gs_sell")) g_gs_sell = value;
   else if (!strcmp(name, "gs_ept")) g_gs_ept = value;
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_bigslot")) g_gs_bigslot = value;

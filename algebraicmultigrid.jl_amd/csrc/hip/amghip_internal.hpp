@@ -80,11 +80,17 @@ struct GsSchedule {
   int64_t slot_total = 0;   // entries the slot arrays hold, zero padding included
   int64_t tri_nnz = 0;      // (on the parent, per direction [fwd, bwd]) entries of the pre-pass triangles
   int64_t tri_nnz_b = 0;
-  struct Seg { int l0, l1; bool chain; int rows; int slot0, nslots; };  // dependency levels [l0, l1); launch shape
+  struct Seg {  // dependency levels [l0, l1); launch shape
+    int l0, l1; bool chain; int rows; int slot0, nslots;
+    int sell_k = 0, sell_chunk0 = 0, sell_nchunks = 0;  // SELL-like layout of this group (0: none)
+  };
   std::vector<Seg> segs;
   // slot layout of the wide levels (gs_slot_kernel)
   int32_t* wcol = nullptr; double* wval = nullptr; int32_t* slot_row = nullptr; i4_t* wmeta = nullptr;
   int slot_entries = kSlot;  // kSlot (gs_slot_kernel) or kBigSlot (gs_bigslot_kernel: long composite rows)
+  // SELL-like copy of the merged groups (gs_sell_kernel)
+  int32_t* scol = nullptr; double* sval = nullptr; i2_t* schunk = nullptr;
+  int64_t sell_bytes = 0, sell_total = 0;
   // block-inverse path (small, densely coupled operators; see gs_block_kernel)
   struct Outer {
     int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; double* tinv = nullptr;
@@ -141,6 +147,7 @@ struct GsSchedule {
     hipFree(blk_diag); blk_diag = nullptr;
     hipFree(blk_s); blk_s = nullptr;
     hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
+    hipFree(scol); hipFree(sval); hipFree(schunk); scol = nullptr; sval = nullptr; schunk = nullptr;
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
     hipFree(perm); hipFree(dpos); hipFree(diag); hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
     d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = bp = xp = nullptr; rowmeta = desc = nullptr; permx = nullptr;
@@ -179,6 +186,7 @@ int g_gs_bigslot = 1;           // allow long-row slots (composite rows up to 20
 int g_gs_merge = 16;             // merged-level sweeps: largest group of dependency levels tried (1 = off); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
+int g_gs_sell = 1;              // merged groups from the SELL-like layout where it was built (0 = slot kernels); build: read at schedule build too
 int g_gs_lean = -1;             // memory-lean schedules: -1 = AMGH_LEAN environment variable, 0 off, 1 on; read at schedule build
 int g_gs_ept = 0;               // entries per thread of merged slot launches (0 = 2 when a group has more than 1024 slots, else 1)
 int g_gs_lpr = 0;               // lanes per row in the row sums of merged slot launches (0 = by row length, 1 = one thread per row)

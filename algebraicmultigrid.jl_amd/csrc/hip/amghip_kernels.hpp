@@ -680,6 +680,97 @@ __global__ __launch_bounds__(kSlot / EPT) void gs_slot_lpr_kernel(SlotArgs a) {
   }
 }
 
+// ---- merged groups from a SELL-like layout ---------------------------------------------------------------------------
+// The slot kernels stage every product in LDS and pay two dependent phases behind the matrix stream (gather, then
+// LDS + row sums).  Here a WAVE owns a chunk of 64 / K consecutive rows of the group, K lanes per row: entry t * K + sub
+// of row r sits at chunk_base + t * 64 + lane (lane = r * K + sub), so the col / val loads of an iteration are one
+// coalesced 64-entry line, neighbouring lanes gather neighbouring x (neighbouring rows read neighbouring columns), and
+// a lane accumulates its own entries in registers — no LDS, no barrier; the K partial sums of a row meet in a
+// __shfl_xor tree.  Padding entries carry col = -1.  (tools/gs_step_bench: -18 % per launch on 27-entry rows, -35 % on
+// 60-entry rows against the slot kernel; profiles/r02_gs_step_bench_sell.log.)  K = 1 adds in index order like the
+// scalar loop; K > 1 changes the order of the additions (merged groups only, whose rows already differ at 1e-16).
+struct SellArgs {
+  const int32_t* scol;      // padded entries, chunk after chunk
+  const double* sval;
+  const i2_t* chunk;        // per chunk {offset in units of 64 entries, iterations}
+  const double* diag;
+  const double* bp;
+  double* x;
+  double omega;
+  int32_t row0, nrows;      // the group's rows (level order)
+  int32_t chunk0, nchunks;
+  int32_t xcd_map;
+};
+template <bool SOR, int K, int BATCH>
+__global__ __launch_bounds__(256) void gs_sell_kernel(SellArgs a) {
+  constexpr int C = kWave / K;
+  const int nwg = (a.nchunks + 3) >> 2;
+  int wb = blockIdx.x;
+  if (a.xcd_map) wb = xcd_block(wb, nwg);
+  if (wb >= nwg) return;
+  const int ch = wb * 4 + (threadIdx.x >> 6);
+  if (ch >= a.nchunks) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const i2_t cd = a.chunk[a.chunk0 + ch];
+  const int64_t base = (int64_t)(uint32_t)cd.x * kWave + lane;
+  const int r = ch * C + lane / K;
+  const bool live = r < a.nrows;
+  double d = 0.0, bb = 0.0;
+  if (live) { d = a.diag[a.row0 + r]; bb = a.bp[a.row0 + r]; }
+  double acc = 0.0;
+  int t = 0;
+  for (; t + BATCH <= cd.y; t += BATCH) {
+    double v[BATCH], xv[BATCH];
+    int c[BATCH];
+#pragma unroll
+    for (int e = 0; e < BATCH; ++e) c[e] = a.scol[base + (int64_t)(t + e) * kWave];
+#pragma unroll
+    for (int e = 0; e < BATCH; ++e) v[e] = a.sval[base + (int64_t)(t + e) * kWave];
+#pragma unroll
+    for (int e = 0; e < BATCH; ++e) xv[e] = c[e] >= 0 ? a.x[c[e]] : 0.0;
+#pragma unroll
+    for (int e = 0; e < BATCH; ++e)
+      if (c[e] >= 0) acc += v[e] * xv[e];
+  }
+  if (t < cd.y) {  // tail of 1 .. BATCH-1 iterations, loads issued together
+    double v[BATCH], xv[BATCH];
+    int c[BATCH];
+#pragma unroll
+    for (int e = 0; e < BATCH - 1; ++e) c[e] = (t + e < cd.y) ? a.scol[base + (int64_t)(t + e) * kWave] : -1;
+#pragma unroll
+    for (int e = 0; e < BATCH - 1; ++e) v[e] = (t + e < cd.y) ? a.sval[base + (int64_t)(t + e) * kWave] : 0.0;
+#pragma unroll
+    for (int e = 0; e < BATCH - 1; ++e) xv[e] = c[e] >= 0 ? a.x[c[e]] : 0.0;
+#pragma unroll
+    for (int e = 0; e < BATCH - 1; ++e)
+      if (c[e] >= 0) acc += v[e] * xv[e];
+  }
+#pragma unroll
+  for (int w = 1; w < K; w <<= 1) acc += __shfl_xor(acc, w, kWave);
+  if (live && (lane % K) == 0 && d != 0.0) {
+    const int i = a.row0 + r;
+    a.x[i] = SOR ? (1.0 - a.omega) * a.x[i] + (a.omega / d) * (bb - acc) : (bb - acc) / d;
+  }
+}
+// a group's rows from the (composite) CSR into the SELL arrays: one thread per lane slot of a chunk
+__global__ void sell_fill_kernel(const int32_t* prow, const int32_t* pcol, const double* pval, const i2_t* chunk,
+                                 int chunk0, int nchunks, int row0, int nrows, int K, int32_t* scol, double* sval) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ch = (int)(gid >> 6), lane = (int)(gid & 63);
+  if (ch >= nchunks) return;
+  const i2_t cd = chunk[chunk0 + ch];
+  const int C = kWave / K;
+  const int r = ch * C + lane / K, sub = lane % K;
+  const int64_t base = (int64_t)(uint32_t)cd.x * kWave + lane;
+  int32_t a0 = 0, len = 0;
+  if (r < nrows) { a0 = prow[row0 + r]; len = prow[row0 + r + 1] - a0; }
+  for (int t = 0; t < cd.y; ++t) {
+    const int e = t * K + sub;
+    if (e < len) { scol[base + (int64_t)t * kWave] = pcol[a0 + e]; sval[base + (int64_t)t * kWave] = pval[a0 + e]; }
+    else { scol[base + (int64_t)t * kWave] = -1; sval[base + (int64_t)t * kWave] = 0.0; }
+  }
+}
+
 // Long-row slots: composite rows of deeply merged groups have hundreds to ~2000 entries.  Same idea as
 // gs_slot_kernel with 2048 entries per slot (4 per thread) and at most 64 rows per slot; a row is summed by a
 // whole wave (entries interleaved over the 64 lanes: conflict-free LDS reads, a 1600-entry row is 26 steps +

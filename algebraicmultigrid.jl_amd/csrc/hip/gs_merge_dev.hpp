@@ -44,7 +44,7 @@ struct MergeArgs {
   unsigned long long* growth;  // max over rows of sum |coefficient| / |diagonal| (bit pattern of a non-negative double)
   int32_t* fail;
   int fill;       // 0 count, 1 fill
-  int only_ovf;   // long-row pass: rows flagged by the 16-lane pass only
+  int tier;       // 0: 128-slot tables (all rows), 1: 512 slots, 2: a workgroup per row with 4096 slots — rows flagged by the tier before
   // workgroup -> rows: only the levels of this round are launched.  blk_ptr[q] = first workgroup of group q's level
   // of the round (ROWS rows per workgroup), lvl_ptr = rows of every dependency level
   const int32_t* blk_ptr; const int32_t* lvl_ptr;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
   if (live) {
     lp = a.lev_of[p];
     live = merge_round_of(lp, a) == a.round;
-    if (live && a.only_ovf) live = a.ovf[p] != 0;
+    if (live) live = a.ovf[p] == (unsigned char)a.tier;  // tier 0: every row; tier t: rows that outgrew tier t-1's table
   }
   if (!__syncthreads_or(live ? 1 : 0)) return;  // no row of this workgroup belongs to the round (rows of a level are contiguous)
   for (int t = ln; t < CAP; t += LANES) key[t] = -1;
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
   //  long-row pass too — harmless, it recomputes the same row)
   if (!live) return;
   if (too_full) {
-    if (a.only_ovf || CAP >= 4096) { if (ln == 0) *a.fail = 1; return; }
-    if (ln == 0) { a.ovf[p] = 1; *a.any_ovf = 1; if (!a.fill) a.cnt[p] = 0; }
+    if (CAP >= 4096) { if (ln == 0) *a.fail = 1; return; }
+    if (ln == 0) { a.ovf[p] = (unsigned char)(a.tier + 1); *a.any_ovf = 1; if (!a.fill) a.cnt[p] = 0; }
     return;
   }
   if (!a.fill) { if (ln == 0) a.cnt[p] = cn; return; }
@@ -187,7 +187,10 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
 
 // all composite rows of grouping (m, backward) of schedule g, on the device.  dscale: SOR solves with the diagonal
 // D / omega (dscale = 1 / omega), Gauss-Seidel with D (dscale = 1).
-int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const double* d_diag, int m, bool backward, MergeDev* out) {
+// min_tier: the smallest table worth trying (0: 128 slots, 1: 512, 2: 4096 — the caller knows the longest row of the
+// previous, shallower grouping; rows only grow with m)
+int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const double* d_diag, int m, bool backward, MergeDev* out,
+                    int min_tier = 0) {
   const int64_t n = g->n;
   MergeDev& R = *out;
   R.m = m; R.backward = backward;
@@ -205,9 +208,9 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const double* 
   if (rc == AMGH_OK) rc = dev_alloc(&ovf, n);
   if (rc == AMGH_OK) rc = dev_alloc(&growth, 1);
   if (rc == AMGH_OK && hipMemsetAsync(growth, 0, 8, nullptr) != hipSuccess) rc = -1001;
-  constexpr int LS = 16, RS = 4, CS = 512;       // 16 lanes per row
-  constexpr int LB = 256, RB = 1, CB = 4096;     // a workgroup per row
-  const size_t lds_s = (size_t)RS * CS * 24, lds_b = (size_t)RB * CB * 24;
+  constexpr int LS = 16, RS = 4, CT = 128, CS = 512;  // 16 lanes per row, small / medium table
+  constexpr int LB = 256, RB = 1, CB = 4096;          // a workgroup per row
+  const size_t lds_t = (size_t)RS * CT * 24, lds_s = (size_t)RS * CS * 24, lds_b = (size_t)RB * CB * 24;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)merge_rows_kernel<LB, RB, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
@@ -218,6 +221,7 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const double* 
   a.prow = g->rowptr; a.pcol = g->col; a.pval = g->val; a.pdiag = d_diag; a.lev_of = d_lev_of;
   a.n = (int)n; a.ncols = (int)g->ncols; a.nlev = g->nlev; a.m = m; a.ngrp = R.ngrp; a.backward = backward ? 1 : 0;
   a.clen = R.clen; a.coff = R.coff; a.cnt = cnt; a.ovf = ovf; a.any_ovf = flags; a.fail = flags + 1;
+  a.tier = 0;
   a.off = off; a.clen_out = R.clen; a.coff_out = R.coff; a.growth = growth;
   a.lvl_ptr = g->d_lvl_ptr;
   int32_t *blk_s = nullptr, *blk_b = nullptr;
@@ -240,18 +244,45 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const double* 
     if (hipMemcpy(blk_s, hs.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(blk_b, hb.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess) { rc = -1001; break; }
     if (hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), nullptr) != hipSuccess ||
-        hipMemsetAsync(ovf, 0, n, nullptr) != hipSuccess || hipMemsetAsync(flags, 0, 8, nullptr) != hipSuccess) { rc = -1001; break; }
-    a.fill = 0; a.only_ovf = 0; a.blk_ptr = blk_s;
-    hipLaunchKernelGGL((merge_rows_kernel<LS, RS, CS>), dim3(grid_s), dim3(LS * RS), lds_s, nullptr, a);
-    int32_t hf[2] = {0, 0};
-    if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = -1001; break; }
-    const bool any_ovf = hf[0] != 0;
-    if (any_ovf) {
-      a.only_ovf = 1; a.blk_ptr = blk_b;
-      hipLaunchKernelGGL((merge_rows_kernel<LB, RB, CB>), dim3(grid_b), dim3(LB * RB), lds_b, nullptr, a);
-      if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = -1001; break; }
-    }
-    if (hf[1]) { R.failed = true; break; }
+        hipMemsetAsync(ovf, min_tier, n, nullptr) != hipSuccess || hipMemsetAsync(flags, 0, 8, nullptr) != hipSuccess) { rc = -1001; break; }
+    // three table sizes: most rows are short (128 slots, 13 waves per CU); rows that outgrow a table are flagged and
+    // redone by the next tier
+    auto run_tiers = [&](int fill, bool* any1, bool* any2) -> int {
+      a.fill = fill;
+      int32_t hf[2] = {0, 0};
+      a.tier = 0; a.blk_ptr = blk_s;
+      if (min_tier == 0) {
+        hipLaunchKernelGGL((merge_rows_kernel<LS, RS, CT>), dim3(grid_s), dim3(LS * RS), lds_t, nullptr, a);
+        if (!fill) {
+          if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1001;
+          *any1 = hf[0] != 0;
+        }
+      } else if (!fill) {
+        *any1 = true;
+        *any2 = min_tier >= 2;
+      }
+      if (*any1) {
+        if (!fill && hipMemsetAsync(flags, 0, 4, nullptr) != hipSuccess) return -1001;
+        a.tier = 1;
+        if (min_tier <= 1) {
+          hipLaunchKernelGGL((merge_rows_kernel<LS, RS, CS>), dim3(grid_s), dim3(LS * RS), lds_s, nullptr, a);
+          if (!fill) {
+            if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1001;
+            *any2 = hf[0] != 0;
+          }
+        }
+        if (*any2) {
+          a.tier = 2; a.blk_ptr = blk_b;
+          hipLaunchKernelGGL((merge_rows_kernel<LB, RB, CB>), dim3(grid_b), dim3(LB * RB), lds_b, nullptr, a);
+        }
+      }
+      if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1001;
+      if (hf[1]) R.failed = true;
+      return AMGH_OK;
+    };
+    bool any1 = false, any2 = false;
+    rc = run_tiers(0, &any1, &any2);
+    if (rc != AMGH_OK || R.failed) break;
     int64_t total = 0;
     rc = dev_exclusive_scan(cnt, off, n, &total, nullptr);
     if (rc == AMGH_EUNSUPPORTED) { R.failed = true; rc = AMGH_OK; break; }
@@ -262,12 +293,11 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const double* 
     if (rc != AMGH_OK) break;
     R.total += total;
     a.out_col = R.rcol[k]; a.out_val = R.rval[k];
-    a.fill = 1; a.only_ovf = 0; a.blk_ptr = blk_s;
-    hipLaunchKernelGGL((merge_rows_kernel<LS, RS, CS>), dim3(grid_s), dim3(LS * RS), lds_s, nullptr, a);
-    if (any_ovf) {
-      a.only_ovf = 1; a.blk_ptr = blk_b;
-      hipLaunchKernelGGL((merge_rows_kernel<LB, RB, CB>), dim3(grid_b), dim3(LB * RB), lds_b, nullptr, a);
-    }
+    // the fill passes flag the same rows again (same tables): the flags of the count pass stay valid, ovf is reset so
+    // that tier 0 sees every row
+    if (hipMemsetAsync(ovf, min_tier, n, nullptr) != hipSuccess) { rc = -1001; break; }
+    rc = run_tiers(1, &any1, &any2);
+    if (rc != AMGH_OK || R.failed) break;
     if (hipGetLastError() != hipSuccess) rc = -1001;
   }
   if (rc == AMGH_OK && !R.failed) {

@@ -483,6 +483,63 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
   return AMGH_OK;
 }
 
+// SELL-like copy of the slotted groups of a merged child whose rows are long enough for it to pay (see gs_sell_kernel):
+// lanes per row K by the group's mean row length (about 4 entries per lane), iterations per chunk by the longest row
+// of the chunk.  Filled on the device from the child's CSR copy (which must hold all rows: not for compacted children).
+int sell_build(GsSchedule* g, const std::vector<int32_t>& prow) {
+  if (g->compacted || !g->rowptr) return AMGH_OK;
+  std::vector<i2_t> chunk;
+  int64_t total64 = 0;
+  for (auto& sg : g->segs) {
+    sg.sell_k = 0;
+    if (sg.chain || sg.nslots <= 0) continue;
+    const int32_t ra = g->lvl_ptr[sg.l0], rb = g->lvl_ptr[sg.l0 + 1];
+    const int rows = rb - ra;
+    if (rows <= 0) continue;
+    const double mean = (double)(prow[rb] - prow[ra]) / rows;
+    // measured on the 256^3 hierarchy (profiles/r02_gs_sell_levels.log): -29 % on the 38 k-row level (rows of 230-330
+    // entries, where it replaces the long-row slot kernel), -5 % at ~110 entries per row, nothing at 60, +2 % at 27
+    // (composite rows of one chunk differ a lot in length: the chunk runs as long as its longest row)
+    if (mean < 96.0) continue;
+    int K = 8;
+    while (K < 64 && K * 4 < mean) K <<= 1;
+    const int C = kWave / K;
+    const int nch = (rows + C - 1) / C;
+    int64_t seg64 = 0;
+    const size_t first = chunk.size();
+    bool ok = true;
+    for (int c = 0; c < nch && ok; ++c) {
+      int32_t mx = 0;
+      for (int32_t r = ra + c * C; r < std::min<int32_t>(rb, ra + (c + 1) * C); ++r) mx = std::max(mx, prow[r + 1] - prow[r]);
+      const int T = (mx + K - 1) / K;
+      if (total64 + seg64 >= (int64_t)UINT32_MAX - 4096) ok = false;
+      chunk.push_back(i2_t{(int32_t)(uint32_t)(total64 + seg64), T});
+      seg64 += T;
+    }
+    // padding beyond 1.6 x the group's entries: not worth it (rows of very different lengths side by side)
+    if (!ok || seg64 * kWave > 1.6 * (double)(prow[rb] - prow[ra]) + 4096) { chunk.resize(first); continue; }
+    sg.sell_k = K; sg.sell_chunk0 = (int)first; sg.sell_nchunks = nch;
+    total64 += seg64;
+  }
+  if (chunk.empty()) return AMGH_OK;
+  RC_TRY(dev_upload(&g->schunk, chunk.data(), (int64_t)chunk.size()));
+  RC_TRY(dev_alloc(&g->scol, total64 * kWave));
+  RC_TRY(dev_alloc(&g->sval, total64 * kWave));
+  for (const auto& sg : g->segs) {
+    if (sg.sell_k <= 0) continue;
+    const int32_t ra = g->lvl_ptr[sg.l0], rb = g->lvl_ptr[sg.l0 + 1];
+    const int64_t threads = (int64_t)sg.sell_nchunks * kWave;
+    hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr,
+                       (const int32_t*)g->rowptr, (const int32_t*)g->col, (const double*)g->val, (const i2_t*)g->schunk,
+                       sg.sell_chunk0, sg.sell_nchunks, (int)ra, (int)(rb - ra), sg.sell_k, g->scol, g->sval);
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  g->sell_total = total64 * kWave;
+  g->sell_bytes = total64 * kWave * 12 + (int64_t)chunk.size() * 8;
+  g->bytes += g->sell_bytes;
+  return AMGH_OK;
+}
+
 // ---- merged dependency levels -------------------------------------------------------------------
 // A wide dependency level costs one kernel boundary (~3.3 us) however few rows it has.  Substitution removes
 // boundaries: inside a GROUP of m consecutive levels, a row that reads x_c of an earlier level of the same group
@@ -855,9 +912,11 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         const int m_lo = (attempt == 0 && dir == 1 && chosen_m[0] > 2) ? chosen_m[0] - 1 : 2;
         if (attempt == 1 && (chosen_m[dir] > 1 || !(dir == 1 && chosen_m[0] > 2))) break;
         worse = 0;
+        int64_t prev_max = 0;  // longest composite row of the previous (shallower) candidate: rows only grow with m
         for (int m = m_lo; m <= std::min(g_gs_merge, kMergeMaxRounds); ++m) {
           MergeDev md;
-          rc2 = merge_build_dev(g, d_lev_of, g->diag, m, backward, &md);
+          rc2 = merge_build_dev(g, d_lev_of, g->diag, m, backward, &md, prev_max > 440 ? 2 : prev_max > 110 ? 1 : 0);
+          prev_max = md.max_row;
           if (rc2 != AMGH_OK) break;
           if (md.failed || md.max_row > kBigSlot - kBigSlot / 8) { md.free_dev(); break; }  // fill has exploded
           int cap = kSlot;
@@ -886,7 +945,8 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
             md.free_dev();
             // well past the minimum — but the step to long-row slots is a bump, not the end: operators that compete with
             // the block-inverse path (small, long rows) only pay off at deep groups, keep looking there
-            if (++worse >= (g->nblk > 0 ? 8 : 4)) break;
+            // (large operators: the cost curve is smooth and every further candidate costs a full build of more entries)
+            if (++worse >= (g->nblk > 0 ? 8 : 2)) break;
           }
           if (stream_bound) break;
         }
@@ -929,6 +989,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           (backward ? g->mb : g->mf) = ch;
           ch->ncols = g->ncols;
           rc2 = layout_upload(ch, sys, perm.data(), cap, gs_lean(), &src);
+          if (rc2 == AMGH_OK && g_gs_sell && !gs_lean()) rc2 = sell_build(ch, sys.prow);
           tm.lap("merged layout", n);
           if (rc2 == AMGH_OK)
             rc2 = tri_build_dev(backward ? &g->tri_b : &g->tri_f, g, backward, &g->bytes, 0.0,

@@ -149,12 +149,16 @@ def test_memory_lean_hierarchy_is_bitwise_the_default_one():
     A = AMG.poisson((64, 64, 64))
     ml = AMG.ruge_stuben(A)
     b = uniform(A.m, 8)
-    full = DeviceHierarchy(ml, 0, 1)
+    # (the default hierarchy also carries a SELL-like copy of long-row groups whose row sums add in another order;
+    #  the lean one has none: compare like with like)
+    assert lib.amgh_debug_set_tunable(b"gs_sell", 0) == 0
     try:
+        full = DeviceHierarchy(ml, 0, 1)
         assert lib.amgh_debug_set_tunable(b"gs_lean", 1) == 0
         lean = DeviceHierarchy(ml, 0, 1)
     finally:
         lib.amgh_debug_set_tunable(b"gs_lean", -1)
+        lib.amgh_debug_set_tunable(b"gs_sell", 1)
     zf, zl = full.precond_apply(b), lean.precond_apply(b)
     assert np.array_equal(zf, zl)
     xf, hf, _ = full.solve(b, np.zeros_like(b), 0, 30, 0.0, 1e-8, True, True)
@@ -195,14 +199,21 @@ def test_device_built_merged_groups_equal_the_host_construction_bit_for_bit(case
     gs = AMG.GaussSeidel(AMG.SymmetricSweep(), 2)
     lib = AMG.hip_lib()
     out = {}
-    for mode in ("device", "host"):
-        if mode == "host":
-            monkeypatch.setenv("AMGH_HOST_MERGE", "1")
-        else:
-            monkeypatch.delenv("AMGH_HOST_MERGE", raising=False)
-        op = DeviceCSR(n, n, rp, ci, va)
-        assert lib.amgh_csr_prepare(op.h, 0, 1) == 0
-        out[mode] = op.smooth(gs, x0.copy(), b)
+    # groups of exactly 2 levels on both sides (the host path chooses from a sampled estimate, the device path from
+    # exact counts: with more candidates they may pick different group sizes), and no SELL-like copy (device path only)
+    assert lib.amgh_debug_set_tunable(b"gs_merge", 2) == 0 and lib.amgh_debug_set_tunable(b"gs_sell", 0) == 0
+    try:
+        for mode in ("device", "host"):
+            if mode == "host":
+                monkeypatch.setenv("AMGH_HOST_MERGE", "1")
+            else:
+                monkeypatch.delenv("AMGH_HOST_MERGE", raising=False)
+            op = DeviceCSR(n, n, rp, ci, va)
+            assert lib.amgh_csr_prepare(op.h, 0, 1) == 0
+            out[mode] = op.smooth(gs, x0.copy(), b)
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_merge", 16)
+        lib.amgh_debug_set_tunable(b"gs_sell", 1)
     assert np.array_equal(out["device"], out["host"])
     # and both are the lexicographic sweep
     xo = O.smooth(gs, A, x0, b)
