@@ -15,7 +15,8 @@ from ._libs import AMGError, gpu_available, hip_lib, setup_lib  # noqa: F401
 from .sparse import SparseMatrixCSC  # noqa: F401
 from .smoothers import (BackwardSweep, ForwardSweep, GaussSeidel, Jacobi, SingularException, SOR,  # noqa: F401
                         SymmetricSweep)
-from .hierarchy import (Classical, HermitianSymmetry, JacobiProlongation, Level, LocalWeighting,  # noqa: F401
+from .hierarchy import (Classical, DenseLUFactorization, HermitianSymmetry, JacobiProlongation, Level,  # noqa: F401
+                        LinearSolveWrapper, LocalWeighting, SuperLUFactorization,
                         MultiLevel, NoSymmetry, Pinv, QRSolver, RS, StandardAggregation, SymmetricStrength,
                         direct_interpolation, fit_candidates, grid_complexity, operator_complexity, poisson,
                         ruge_stuben, smoothed_aggregation)

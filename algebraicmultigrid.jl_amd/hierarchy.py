@@ -202,6 +202,67 @@ class QRSolver(CoarseSolver):
         return "QRSolver"
 
 
+class _LinearSolveWrapperInternal(CoarseSolver):
+    """LinearSolveWrapperInternal (coarse_solver.jl:24-42): a third-party factorisation, set up once (`init(linprob,
+    alg)`), solved per right-hand-side column (`p.linsolve.b = b[:, i]; x[:, i] = solve!(p.linsolve).u`).  Always the
+    host-callback protocol (amgh_set_coarse_host): the library calls `(cs)(x, b)` on every coarse solve."""
+
+    def __init__(self, A, alg):
+        super().__init__(A)
+        self.alg = alg
+        self._fact = alg.factorize(self.A.to_scipy())
+
+    def uses_dense(self):
+        return False
+
+    def host_solve(self, b):
+        b = np.asarray(b, dtype=np.float64)
+        if b.ndim == 2:
+            return np.column_stack([self._fact(b[:, i]) for i in range(b.shape[1])])
+        return self._fact(b)
+
+    def __repr__(self):
+        return repr(self.alg)
+
+
+class LinearSolveWrapper:
+    """LinearSolveWrapper(alg) (coarse_solver.jl:50-58): pass a linear-solver algorithm of another package as the coarse
+    solver, `ruge_stuben(A; coarse_solver = LinearSolveWrapper(alg))`.  `alg` needs `factorize(A_scipy_csc) -> solve(b)`;
+    `SuperLUFactorization` / `UMFPACKLikeFactorization` below wrap SciPy's sparse direct solvers the way LinearSolve.jl
+    wraps KLU / UMFPACK."""
+
+    def __init__(self, alg):
+        if not hasattr(alg, "factorize"):
+            raise AMGError("LinearSolveWrapper: alg must provide factorize(A) -> callable solve(b)")
+        self.alg = alg
+
+    def __call__(self, A):
+        return _LinearSolveWrapperInternal(A, self.alg)
+
+
+class SuperLUFactorization:
+    """SciPy's SuperLU (sparse LU with partial pivoting) as a LinearSolveWrapper algorithm."""
+
+    def factorize(self, A):
+        import scipy.sparse.linalg as spla
+        return spla.splu(A.tocsc()).solve
+
+    def __repr__(self):
+        return "SuperLUFactorization()"
+
+
+class DenseLUFactorization:
+    """LAPACK getrf / getrs on the dense coarse matrix (LinearSolve.jl's LUFactorization on a small matrix)."""
+
+    def factorize(self, A):
+        import scipy.linalg as sla
+        lu = sla.lu_factor(A.toarray())
+        return lambda b: sla.lu_solve(lu, b)
+
+    def __repr__(self):
+        return "DenseLUFactorization()"
+
+
 _default_coarse_solver = QRSolver  # coarse_solver.jl:84
 
 

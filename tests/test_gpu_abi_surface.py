@@ -218,3 +218,55 @@ def test_device_built_merged_groups_equal_the_host_construction_bit_for_bit(case
     # and both are the lexicographic sweep
     xo = O.smooth(gs, A, x0, b)
     assert rel(out["device"], xo) <= 1e-11
+
+
+@pytest.mark.parametrize("alg", ["superlu", "dense_lu"])
+def test_linear_solve_wrapper_coarse_solver(alg):
+    """coarse_solver = LinearSolveWrapper(alg) (coarse_solver.jl:24-58): a third-party factorisation set up once and
+    called back by the device cycle through amgh_set_coarse_host for every coarse solve — V and W cycles, one
+    right-hand side and a block (the wrapper loops the columns, coarse_solver.jl:36-41)."""
+    A = AMG.poisson((24, 24, 24))
+    algo = AMG.SuperLUFactorization() if alg == "superlu" else AMG.DenseLUFactorization()
+    ml = AMG.ruge_stuben(A, max_levels=3, coarse_solver=AMG.LinearSolveWrapper(algo))   # a coarsest level of ~600 rows
+    assert ml.final_A.m > 100 and not ml.coarse_solver.uses_dense()
+    ref = AMG.ruge_stuben(A, max_levels=3)                                              # default QRSolver: dense operator on device
+    b = uniform(A.m, 12)
+    oh = O.OracleHierarchy(ml)
+    for cyc, cycle in ((0, AMG.V()), (1, AMG.W())):
+        x, hist = AMG._solve(ml, b, cycle, reltol=1e-9, log=True)
+        xo, ho, _ = oh.solve(b, cycle=cyc, reltol=1e-9)
+        assert len(hist) == len(ho) and rel(x, xo) <= 1e-10
+        xr, hr = AMG._solve(ref, b, cycle, reltol=1e-9, log=True)
+        assert len(hr) == len(hist) and rel(x, xr) <= 1e-9
+    B = np.column_stack([b, uniform(A.m, 13), uniform(A.m, 14) - 0.5])
+    X = AMG._solve(ml, B, reltol=1e-9)
+    for c in range(3):
+        assert rel(X[:, c], AMG._solve(ml, B[:, c].copy(), reltol=1e-9)) <= 1e-12
+    z = AMG.aspreconditioner(ml).ldiv(b)
+    assert rel(z, oh.precond(b)) <= 1e-10
+
+
+def test_precs_builders_and_commonsolve_split():
+    """LinearSolve `precs` builders (precs.jl:7-38): `(builder)(A, p) -> (Pl, I)` with Pl usable as `cg(A, b; Pl)`;
+    CommonSolve `init` + `solve!` (multilevel.jl:252-264) = `solve`."""
+    A = AMG.poisson((40, 40))
+    b = uniform(A.m, 21)
+    for builder, setup in ((AMG.RugeStubenPreconBuilder(), AMG.ruge_stuben),
+                           (AMG.SmoothedAggregationPreconBuilder(), AMG.smoothed_aggregation),
+                           (AMG.RugeStubenPreconBuilder(blocksize=1, max_levels=3), lambda M: AMG.ruge_stuben(M, max_levels=3))):
+        Pl, Pr = builder(A, None)
+        assert isinstance(Pl, AMG.Preconditioner) and isinstance(Pr, AMG.Identity)
+        assert np.array_equal(Pr.ldiv(b), b)
+        x, info = AMG.cg(A, b, Pl=Pl, reltol=1e-10, log=True)
+        oh = O.OracleHierarchy(setup(A))
+        xo, ho, it = oh.pcg(b, reltol=1e-10)
+        assert info["iters"] == it and rel(x, xo) <= 1e-9
+    # a scipy matrix goes in like an AbstractSparseMatrixCSC
+    Pl2, _ = AMG.RugeStubenPreconBuilder()(A.to_scipy(), None)
+    assert rel(Pl2.ldiv(b), AMG.aspreconditioner(AMG.ruge_stuben(A)).ldiv(b)) == 0.0
+    # init / solve!
+    solt = AMG.init(AMG.RugeStubenAMG(), A, b, max_levels=4)
+    assert isinstance(solt, AMG.AMGSolver) and len(solt.ml) == 4
+    x1 = AMG.solve_(solt, reltol=1e-9)
+    x2 = AMG.solve(A, b, AMG.RugeStubenAMG(), max_levels=4, reltol=1e-9)
+    assert np.array_equal(x1, x2)
