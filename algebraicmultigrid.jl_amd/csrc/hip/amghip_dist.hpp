@@ -914,8 +914,9 @@ int amgh_dist_spmv_d(amgh_dist_t* d, int level, const double* x_loc_d, double* y
   DistLevel* L = d->levels[level];
   VecPlan& pl = d->xplan[level];
   const int64_t n = pl.nloc();
-  if (n > 0 && (!x_loc_d || !y_loc_d)) return AMGH_EINVAL;
-  if (n > 0 && x_loc_d != L->x) HIP_TRY(hipMemcpyAsync(L->x, x_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
+  if (n > 0 && !y_loc_d) return AMGH_EINVAL;
+  // x_loc_d == NULL: multiply the level's own x (what the last cycle left there) — no copy in front of the exchange
+  if (n > 0 && x_loc_d && x_loc_d != L->x) HIP_TRY(hipMemcpyAsync(L->x, x_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
   return dist_apply(d, L->A, M_SPMV, pl, L->x, nullptr, n > 0 ? y_loc_d : L->tmp, 0.0);
 }
 

@@ -111,16 +111,15 @@ def main_distributed(args):
     # fine-level sharded SpMV (neighbour exchange + local rows), timed the same way
     spmv_ms = None
     if sh.lc > 0:
-        x = AMG.DeviceBuffer(max(sh.nloc, 1), local_rank, uniform(n, 1)[sh.r0:sh.r1] if sh.nloc else None)
         y = AMG.DeviceBuffer(max(sh.nloc, 1), local_rank)
         lib = sh.lib
-        for _ in range(3):
-            lib.amgh_dist_spmv_d(sh.h, 0, x.ptr, y.ptr)
+        for _ in range(3):      # x = the level's resident vector (the last cycle's result): exchange + local rows, no copy
+            lib.amgh_dist_spmv_d(sh.h, 0, None, y.ptr)
         sh.barrier()
         reps = 20
         t0 = time.perf_counter()
         for _ in range(reps):
-            lib.amgh_dist_spmv_d(sh.h, 0, x.ptr, y.ptr)
+            lib.amgh_dist_spmv_d(sh.h, 0, None, y.ptr)
         sh.barrier()
         spmv_ms = 1e3 * float(sh.allreduce([time.perf_counter() - t0], "max")[0]) / reps
 

@@ -297,7 +297,8 @@ int amgh_dist_precond_apply_d(amgh_dist_t* d, const double* r_loc_d, double* z_l
 int amgh_dist_solve_d(amgh_dist_t* d, const double* b_loc_d, double* x_loc_d, int cycle, int maxiter,
                       double abstol, double reltol, int calculate_residual,
                       double* resid_hist /*host*/, int* iters);
-/* y_loc = A_level x_loc, halo exchange included (roofline hook of the sharded SpMV).  Enqueue only.   */
+/* y_loc = A_level x_loc, halo exchange included (roofline hook of the sharded SpMV).  Enqueue only.
+ * x_loc_d = NULL multiplies the level's resident x (as the last cycle left it) without a copy.       */
 int amgh_dist_spmv_d(amgh_dist_t* d, int level, const double* x_loc_d, double* y_loc_d);
 int amgh_dist_sync(amgh_dist_t* d);
 int amgh_dist_barrier(amgh_dist_t* d);                                 /* sync + barrier over the ranks */

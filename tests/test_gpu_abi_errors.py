@@ -80,3 +80,50 @@ def test_strerror_covers_hip_codes():
     lib = AMG.hip_lib()
     assert b"HIP error" in lib.amgh_strerror(-1001)
     assert b"unknown" in lib.amgh_strerror(-7)
+
+
+def test_sharded_abi_error_codes():
+    """amgh_dist_*: bad arguments and bad states come back as codes, nothing throws or hangs."""
+    import ctypes as C
+    lib = AMG.hip_lib()
+    vp = C.c_void_p
+    assert lib.amgh_local_group_create(None, 2) == -2
+    g = vp()
+    assert lib.amgh_local_group_create(C.byref(g), 0) == -2
+    assert lib.amgh_local_group_create(C.byref(g), 1) == 0
+    d = vp()
+    assert lib.amgh_dist_create_local(C.byref(d), 0, 5, g) == -2            # rank outside the group
+    assert lib.amgh_dist_create_local(C.byref(d), 99, 0, g) == -2           # no such device
+    assert lib.amgh_dist_create_local(C.byref(d), 0, 0, g) == 0
+    # not finalized yet
+    assert lib.amgh_dist_precond_apply_d(d, None, None, 0) == -3
+    r0, r1 = C.c_int64(0), C.c_int64(0)
+    assert lib.amgh_dist_local_range(d, 0, C.byref(r0), C.byref(r1)) == -2
+    # push_level: cuts that do not span the level, missing arrays
+    A = AMG.poisson((6, 6))
+    rp, ci, va = A.csr_arrays()
+    pre = AMG.GaussSeidel().c_struct()
+    cuts_bad = np.array([0, 5], dtype=np.int64)
+    cuts = np.array([0, A.m], dtype=np.int64)
+    ccuts = np.array([0, 4], dtype=np.int64)
+    args = lambda rc_, cc_: (d, A.m, 4, rc_.ctypes.data, cc_.ctypes.data, rp.ctypes.data, ci.ctypes.data, va.ctypes.data,  # noqa: E731
+                             None, None, None, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, rp.ctypes.data,
+                             ci.ctypes.data, va.ctypes.data, C.byref(pre), C.byref(pre))
+    assert lib.amgh_dist_push_level(*args(cuts_bad, ccuts)) == -2
+    assert lib.amgh_dist_push_level(d, A.m, 4, cuts.ctypes.data, ccuts.ctypes.data, None, None, None, None, None, None,
+                                    None, None, None, None, None, None, C.byref(pre), C.byref(pre)) == -2
+    # a tail that is not finalized / of another block size is refused
+    h = vp()
+    assert lib.amgh_create(C.byref(h), 0, 1) == 0
+    assert lib.amgh_dist_set_tail(d, h) == -2
+    lib.amgh_destroy(h)
+    # finalize without levels and without a tail: a hierarchy of size 0 is fine, solve on it is a no-op
+    assert lib.amgh_dist_finalize(d) == 0
+    assert lib.amgh_dist_finalize(d) == -3
+    assert lib.amgh_dist_precond_apply_d(d, None, None, 7) == -2
+    assert lib.amgh_dist_spmv_d(d, 0, None, None) == -2                      # no sharded level
+    out2 = np.zeros(2, dtype=np.int64)
+    assert lib.amgh_dist_stats(d, out2.ctypes.data, 1) == 0 and out2.tolist() == [0, 0]
+    assert lib.amgh_strerror(-2005).decode().startswith("RCCL error 5")
+    lib.amgh_dist_destroy(d)
+    lib.amgh_local_group_destroy(g)
