@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int kMergeMaxRounds = 16;
+constexpr int kMergeMaxRounds = 32;
 
 struct MergeDev {
   int m = 1, ngrp = 0;

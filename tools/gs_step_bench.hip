@@ -260,6 +260,119 @@ __global__ __launch_bounds__(T) void slot_dep_kernel(DepArgs d) {
   if (tid == 0) __hip_atomic_fetch_add(d.cnt_cur + (blockIdx.x % kNCnt), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <class Tv> Tv* up(const std::vector<Tv>& v);
+// ---- ONE persistent launch for the whole chain, groups separated by an XCD-hierarchical grid barrier (the primitive the
+// guide prices at 4.1 / 5.9 / 9.7 us for 256 / 512 / 1024 workgroups): arrivals are counted per XCC (s_getreg XCC_ID, no
+// placement assumption), the last arriver of an XCC releases that XCD's L2 once and arrives on the top counter, sees all
+// XCCs there, acquires and publishes the XCC's generation; everybody else polls its XCC's generation word (relaxed,
+// s_sleep) and then invalidates its L1 once.  The matrix entries of the NEXT group's first slot are loaded before the
+// barrier (they do not depend on x).  Every spin is bounded.
+struct XcdBar { unsigned xcc_cnt[8][16]; unsigned xcc_gen[8][16]; unsigned top[16]; unsigned census[8][16]; unsigned start[16]; };
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u; }
+__device__ __forceinline__ bool spin_until(unsigned* p, unsigned want, int* err) {
+  int spins = 0;
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;  // somebody timed out: unwind
+    if (++spins > (1 << 19)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+  }
+  return true;
+}
+__device__ __forceinline__ void xcd_barrier(XcdBar* b, unsigned xcc, unsigned nwg_xcc, unsigned nxcc, unsigned step, int* err) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's x stores are in its XCD's L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&b->xcc_cnt[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == nwg_xcc * (step + 1) - 1) {   // last arriver of this XCC: the XCD leader of this step
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&b->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      spin_until(&b->top[0], nxcc * (step + 1), err);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(&b->xcc_gen[xcc][0], step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      spin_until(&b->xcc_gen[xcc][0], step + 1, err);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
+  __syncthreads();
+}
+struct PersistArgs { Args a; const long long* ent0; const int* nslots; const int* slot0; int K; XcdBar* bar; int* err; };
+template <int T>
+__global__ __launch_bounds__(T) void slot_persistent_kernel(PersistArgs pa) {
+  __shared__ double s_prod[T];
+  __shared__ unsigned s_info[2];
+  const Args& a = pa.a;
+  const int tid = threadIdx.x;
+  XcdBar* bar = pa.bar;
+  const unsigned xcc = xcc_id();
+  // census: how many workgroups run on each XCC (dispatch placement is not ours to assume), then one plain barrier
+  if (tid == 0) {
+    __hip_atomic_fetch_add(&bar->census[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&bar->start[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    spin_until(&bar->start[0], gridDim.x, pa.err);
+    unsigned nx = 0;
+    for (int q = 0; q < 8; ++q) nx += __hip_atomic_load(&bar->census[q][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    s_info[0] = __hip_atomic_load(&bar->census[xcc][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_info[1] = nx;
+  }
+  __syncthreads();
+  const unsigned nwg_xcc = s_info[0], nxcc = s_info[1];
+  // matrix entries of my first slot of group 0
+  double v = 0.0; int c = 0;
+  if ((int)blockIdx.x < pa.nslots[0]) { const long long base = pa.ent0[0] + (long long)blockIdx.x * T; v = a.wval[base + tid]; c = a.wcol[base + tid]; }
+  for (int k = 0; k < pa.K; ++k) {
+    const int ns = pa.nslots[k];
+    for (int lb = blockIdx.x; lb < ns; lb += gridDim.x) {
+      const int s = pa.slot0[k] + lb;
+      const long long base = pa.ent0[k] + (long long)lb * T;
+      if (lb != (int)blockIdx.x) { v = a.wval[base + tid]; c = a.wcol[base + tid]; }   // (first slot: prefetched before the barrier)
+      const int r0 = a.slot_row[2 * s], nrows = a.slot_row[2 * s + 1] - r0;
+      const double xv = a.x[c];
+      i4_t m = i4_t{0, 0, -1, 0}; double dg = 0.0, bb = 0.0;
+      if (tid < nrows) { m = a.wmeta[r0 + tid]; dg = a.diag[r0 + tid]; bb = a.bp[r0 + tid]; }
+      s_prod[tid] = v * xv;
+      __syncthreads();
+      if (tid < nrows) {
+        double acc = 0.0;
+        for (int j = (int)(m.x - base); j < (int)(m.y - base); ++j) acc += s_prod[j];
+        if (dg != 0.0) a.x[r0 + tid] = (bb - acc) / dg;
+      }
+      __syncthreads();
+    }
+    if (k + 1 < pa.K) {
+      // next group's first slot: independent of x, in flight across the barrier
+      if ((int)blockIdx.x < pa.nslots[k + 1]) {
+        const long long base = pa.ent0[k + 1] + (long long)blockIdx.x * T;
+        v = a.wval[base + tid]; c = a.wcol[base + tid];
+      }
+      xcd_barrier(bar, xcc, nwg_xcc, nxcc, (unsigned)k, pa.err);
+    }
+  }
+}
+double run_persistent(const Layout& L, Args a, int K, int grid, hipStream_t st, std::vector<double>* out, long long n,
+                      const std::vector<double>& x0, int* herr) {
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  XcdBar* bar; int* err;
+  CHECK(hipMalloc(&bar, sizeof(XcdBar))); CHECK(hipMalloc(&err, 4));
+  long long* d_ent0 = up(L.ent0); int* d_ns = up(L.nslots); int* d_s0 = up(L.slot0);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipMemcpyAsync(a.x, x0.data(), 8 * n, hipMemcpyHostToDevice, st));
+    CHECK(hipMemsetAsync(bar, 0, sizeof(XcdBar), st)); CHECK(hipMemsetAsync(err, 0, 4, st));
+    CHECK(hipStreamSynchronize(st));
+    PersistArgs pa{}; pa.a = a; pa.a.xcd = 0; pa.ent0 = d_ent0; pa.nslots = d_ns; pa.slot0 = d_s0; pa.K = K; pa.bar = bar; pa.err = err;
+    CHECK(hipEventRecord(e0, st));
+    hipLaunchKernelGGL((slot_persistent_kernel<512>), dim3(grid), dim3(512), 0, st, pa);
+    CHECK(hipEventRecord(e1, st)); CHECK(hipStreamSynchronize(st));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+  }
+  CHECK(hipMemcpy(herr, err, 4, hipMemcpyDeviceToHost));
+  if (out) { out->resize(n); CHECK(hipMemcpy(out->data(), a.x, 8 * n, hipMemcpyDeviceToHost)); }
+  CHECK(hipFree(bar)); CHECK(hipFree(err)); CHECK(hipFree(d_ent0)); CHECK(hipFree(d_ns)); CHECK(hipFree(d_s0));
+  return 1e3 * best / K;
+}
+
 template <int T, int EPT>
 double run_dep(const Layout& L, Args a, int K, int cap, bool two_streams, hipStream_t sa, hipStream_t sb, std::vector<double>* out, long long n,
                const std::vector<double>& x0, int* herr) {
@@ -438,6 +551,12 @@ int main(int argc, char** argv) {
             int herr = 0;
             double t1 = run_dep<512, 1>(L, a, K, 480, false, st, st2, &got, n, x0, &herr);
             printf("  S= 512 dep T512 E1 ONE stream (counters + boundary)   %6.2f us/launch  err %d\n", t1, herr);
+            for (int grid : {256, 512, 1024}) {
+              char nm[64]; snprintf(nm, sizeof nm, "persistent xcd-barrier %d WG", grid);
+              const double tp = run_persistent(L, a, K, grid, st, &got, n, x0, &herr);
+              report(nm, tp, &got);
+              printf("       (spin timeout flag %d)\n", herr);
+            }
             report("dep T512E1 2 streams cap480", run_dep<512, 1>(L, a, K, 480, true, st, st2, &got, n, x0, &herr), &got);
             printf("       (spin timeout flag %d)\n", herr);
             report("dep T256E2 2 streams cap960", run_dep<256, 2>(L, a, K, 960, true, st, st2, &got, n, x0, &herr), &got);
