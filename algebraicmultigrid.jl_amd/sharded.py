@@ -48,7 +48,8 @@ def level_arrays(ml, lc):
         d = dict(n=A.m, nc=lev.P.n, A=A.csr_arrays(), S=None,
                  P=(lev.R.colptr, lev.R.rowval, lev.R.nzval),   # CSR of P = CSC arrays of R
                  R=(lev.P.colptr, lev.P.rowval, lev.P.nzval),
-                 pre=_smoother_tuple(lev.presmoother), post=_smoother_tuple(lev.postsmoother))
+                 pre=_smoother_tuple(lev.presmoother), post=_smoother_tuple(lev.postsmoother),
+                 _keep=lev)       # the arrays are views of the matrices' native memory: the level must outlive them
         if not A.is_symmetric():
             d["S"] = (A.colptr, A.rowval, A.nzval)               # column i read as row i (smoother.jl:81-86)
         out.append(d)
@@ -70,7 +71,7 @@ def export_levels(levels, dirpath):
             for name, arr in zip(("rowptr", "col", "val"), d[key]):
                 np.save(os.path.join(dirpath, f"L{l}_{key}_{name}.npy"), np.ascontiguousarray(arr))
         meta.append([d["n"], d["nc"], int(d["S"] is not None), *d["pre"], *d["post"]])
-    np.save(os.path.join(dirpath, "meta.npy"), np.array(meta, dtype=np.float64).reshape(len(levels), -1))
+    np.save(os.path.join(dirpath, "meta.npy"), np.array(meta, dtype=np.float64).reshape(len(levels), 11))
 
 
 def load_levels(dirpath):

@@ -23,6 +23,45 @@ import time
 import numpy as np
 
 
+def node_levels(rank, world, bcast, build):
+    """The host hierarchy ONCE per node: rank 0 runs `build()` (-> MultiLevel), decides how many levels are sharded,
+    and — for world > 1 — exports the sharded levels' matrices as .npy files; every other rank maps them and will read
+    only its own rows.  `bcast(obj)` broadcasts a small Python object from rank 0.  Returns (levels, info, tail, dir):
+    `tail` (the collapsed levels as a MultiLevel) on rank 0 only."""
+    import amg_amd as AMG
+    from amg_amd import sharded as SH
+    shm = None
+    tail = None
+    levels = None
+    if rank == 0:
+        ml = build()
+        A = ml.levels[0].A if ml.levels else ml.final_A
+        sizes = [l.A.m for l in ml.levels] + [ml.final_A.m]
+        lc = SH.num_sharded_levels(sizes, world)
+        levels = SH.level_arrays(ml, lc)
+        tail = AMG.MultiLevel(ml.levels[lc:], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
+                              ml.symmetry, method=ml.method)
+        info = dict(n_tail=sizes[lc], nnz=A.nnz, nlev=len(ml), lc=lc, sizes=sizes)
+        if world > 1:
+            # shared memory if it has the room (a container's /dev/shm can be as small as 64 MB), else the temp directory
+            need = sum(a.nbytes for d in levels for key in ("A", "S", "P", "R") if d[key] is not None for a in d[key])
+            base = tempfile.gettempdir()
+            try:
+                if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 1.25 * need:
+                    base = "/dev/shm"
+            except OSError:
+                pass
+            shm = tempfile.mkdtemp(prefix="amgh_levels_", dir=base)
+            SH.export_levels(levels, shm)
+        info["shm"] = shm
+    else:
+        info = None
+    info = bcast(info)
+    if rank != 0:
+        levels = SH.load_levels(info["shm"])
+    return levels, info, tail, shm
+
+
 def main_distributed(args):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("NCCL_DEBUG", "WARN")
@@ -61,28 +100,9 @@ def main_distributed(args):
     n = N ** 3
     # ---- host hierarchy: once per node --------------------------------------------------------------------------
     t0 = time.perf_counter()
-    shm = None
-    tail = None
-    if rank == 0:
-        A = AMG.poisson((N, N, N))
-        ml = AMG.ruge_stuben(A, setup=getattr(args, "setup", "gpu"))   # defaults: Classical(0.25), RS(), symmetric GS
-        sizes = [l.A.m for l in ml.levels] + [ml.final_A.m]
-        lc = SH.num_sharded_levels(sizes, world)
-        levels = SH.level_arrays(ml, lc)
-        tail = AMG.MultiLevel(ml.levels[lc:], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
-                              ml.symmetry, method=ml.method)
-        info = dict(n_tail=sizes[lc], nnz=A.nnz, nlev=len(ml), lc=lc, sizes=sizes)
-        if world > 1:
-            base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-            shm = tempfile.mkdtemp(prefix="amgh_levels_", dir=base)
-            SH.export_levels(levels, shm)
-        info["shm"] = shm
-    else:
-        info = None
-    info = bcast(info)
+    levels, info, tail, shm = node_levels(rank, world, bcast,
+                                          lambda: AMG.ruge_stuben(AMG.poisson((N, N, N)), setup=getattr(args, "setup", "gpu")))
     t_setup = time.perf_counter() - t0
-    if rank != 0:
-        levels = SH.load_levels(info["shm"])
     # ---- the sharded handle -------------------------------------------------------------------------------------
     t0 = time.perf_counter()
     uid = bcast(SH.rccl_unique_id() if rank == 0 else None)

@@ -34,3 +34,14 @@ def test_gloo_world_size_2():
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT)
     out = r.stdout.decode()
     assert r.returncode == 0 and "DIST_WORKER_OK" in out, out[-3000:]
+
+
+def test_node_levels_gloo():
+    """bench_dist.py's once-per-node hand-over of the host hierarchy (export on rank 0, memory-mapped row slices on the
+    others), world_size 2 over gloo."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29537", os.path.join(ROOT, "tests", "node_levels_worker.py")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "NODE_LEVELS_OK" in out, out[-3000:]
