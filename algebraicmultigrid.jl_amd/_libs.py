@@ -108,6 +108,9 @@ def hip_lib():
     L.amgh_destroy.argtypes = [vp]
     L.amgh_destroy.restype = None
     L.amgh_push_level.argtypes = [vp, i64, i64] + [vp] * 12 + [C.POINTER(amgh_smoother_t), C.POINTER(amgh_smoother_t)]
+    L.amgh_push_level_begin.argtypes = [vp, i64] + [vp] * 6 + [C.POINTER(amgh_smoother_t), C.POINTER(amgh_smoother_t)]
+    L.amgh_push_level_end.argtypes = [vp, i64] + [vp] * 6
+    L.amgh_push_level_abort.argtypes = [vp]
     L.amgh_set_coarse.argtypes = [vp, i64, vp, vp, vp, vp]
     L.amgh_set_coarse_host.argtypes = [vp, i64, vp, vp, vp, COARSE_FN, vp]
     L.amgh_finalize.argtypes = [vp]

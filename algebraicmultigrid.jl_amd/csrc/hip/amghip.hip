@@ -29,6 +29,7 @@ struct Level {
   amgh_csr Pp, Rp;
   bool lo_ok = false;
   double* lo_val = nullptr;  // S != A with the same pattern: values of A in the order of the schedule's level-ordered copy of S
+  bool lo_want = false;    // between amgh_push_level_begin and _end: the level-ordered P / R are to be built
   bool nat_freed = false;  // memory-lean: the natural-order A (levels >= 1), P and R were released, the cycle runs level-ordered
 };
 
@@ -41,6 +42,7 @@ struct amgh_handle {
   hipStream_t own_stream = nullptr;  // the stream created by amgh_create (when an external one is in use)
   bool ext_stream = false;
   std::vector<Level*> levels;
+  Level* pending_level = nullptr;  // between amgh_push_level_begin and amgh_push_level_end
   // coarsest
   int64_t ncoarse = -1;
   amgh_csr finalA;
@@ -514,10 +516,13 @@ int amgh_create(amgh_t** hp, int device, int nrhs) {
   return AMGH_OK;
 }
 
+static void level_discard(Level* L);
+
 void amgh_destroy(amgh_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->pending_level) level_discard(h->pending_level);
   for (Level* L : h->levels) {
     csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
     hipFree(L->res); hipFree(L->cx); hipFree(L->cb); hipFree(L->tmp); hipFree(L->lo_val);
@@ -535,26 +540,30 @@ void amgh_destroy(amgh_t* h) {
   delete h;
 }
 
-int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, const int32_t* A_col,
-                    const double* A_val, const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
-                    const int32_t* P_rowptr, const int32_t* P_col, const double* P_val, const int32_t* R_rowptr,
-                    const int32_t* R_col, const double* R_val, const amgh_smoother_t* pre,
-                    const amgh_smoother_t* post) {
-  if (!h || n <= 0 || nc < 0 || !A_rowptr || !P_rowptr || !R_rowptr) return AMGH_EINVAL;
+static void level_discard(Level* L) {
+  csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
+  hipFree(L->lo_val);
+  delete L;
+}
+
+// First half of push!(levels, Level(A, P, R, pre, post)): everything that needs A (and S) only — the uploads and the
+// smoother schedule.  A caller that produces P and R later (the setup phase: C/F splitting on the host, then
+// interpolation) can run this half on another host thread meanwhile.
+int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
+                          const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
+                          const amgh_smoother_t* pre, const amgh_smoother_t* post) {
+  if (!h || n <= 0 || !A_rowptr) return AMGH_EINVAL;
   if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
-  if (h->finalized) return AMGH_ESTATE;
+  if (h->finalized || h->pending_level) return AMGH_ESTATE;
   if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
-  if (P_rowptr[n] != R_rowptr[nc]) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   Level* L = new Level;
-  L->n = n; L->nc = nc; L->pre = *pre; L->post = *post;
+  L->n = n; L->pre = *pre; L->post = *post;
   int rc = csr_upload(&L->A, h->device, n, n, A_rowptr, A_col, A_val);
   if (rc == AMGH_OK && S_rowptr) {
     L->has_S = true;
     rc = csr_upload(&L->S, h->device, n, n, S_rowptr, S_col, S_val);
   }
-  if (rc == AMGH_OK) rc = csr_upload(&L->P, h->device, n, nc, P_rowptr, P_col, P_val);
-  if (rc == AMGH_OK) rc = csr_upload(&L->R, h->device, nc, n, R_rowptr, R_col, R_val);
   const bool need_gs = pre->kind == AMGH_SMOOTH_GS || pre->kind == AMGH_SMOOTH_SOR ||
                        post->kind == AMGH_SMOOTH_GS || post->kind == AMGH_SMOOTH_SOR;
   if (rc == AMGH_OK && need_gs) {
@@ -598,30 +607,54 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
       same_pattern = rc == AMGH_OK;
       if (same_pattern) M->bytes += 8 * (int64_t)lv.size();
     }
-    if (rc == AMGH_OK && both && same_pattern && g->nblk == 0 && g_gs_keep_lo && (int64_t)g->h_perm.size() == n) {
-      const std::vector<int32_t>& perm = g->h_perm;
-      std::vector<int32_t> inv(n);
-      for (int64_t p2 = 0; p2 < n; ++p2) inv[perm[p2]] = (int32_t)p2;
-      std::vector<int32_t> prp(n + 1, 0), pcl(P_rowptr[n]);
-      std::vector<double> pvl(P_rowptr[n]);
-      for (int64_t p2 = 0; p2 < n; ++p2) prp[p2 + 1] = prp[p2] + (P_rowptr[perm[p2] + 1] - P_rowptr[perm[p2]]);
-      const int T2 = std::max(1, std::min<int>(merge_threads(), 16));
-      std::vector<int32_t> rcl(R_rowptr[nc]);
-      const int64_t rnnz = R_rowptr[nc];
-      run_threads(T2, [&](int t) {
-        for (int64_t p2 = n * t / T2; p2 < n * (t + 1) / T2; ++p2) {
-          const int32_t src = P_rowptr[perm[p2]], len = P_rowptr[perm[p2] + 1] - src;
-          std::copy(P_col + src, P_col + src + len, pcl.begin() + prp[p2]);
-          std::copy(P_val + src, P_val + src + len, pvl.begin() + prp[p2]);
-        }
-        for (int64_t k = rnnz * t / T2; k < rnnz * (t + 1) / T2; ++k) rcl[k] = inv[R_col[k]];  // entries keep their order: same sums
-      });
-      rc = csr_upload(&L->Pp, h->device, n, nc, prp.data(), pcl.data(), pvl.data());
-      if (rc == AMGH_OK) rc = csr_upload(&L->Rp, h->device, nc, n, R_rowptr, rcl.data(), R_val);
-      L->lo_ok = rc == AMGH_OK;
-    }
-    std::vector<int32_t>().swap(g->h_perm);
+    // what the second half needs to know: the level-ordered P / R are wanted (g->h_perm is kept until then)
+    L->lo_want = rc == AMGH_OK && both && same_pattern && g->nblk == 0 && g_gs_keep_lo && (int64_t)g->h_perm.size() == n;
+    if (!L->lo_want) std::vector<int32_t>().swap(g->h_perm);
   }
+  if (rc != AMGH_OK) {
+    level_discard(L);
+    return rc;
+  }
+  h->pending_level = L;
+  return AMGH_OK;
+}
+
+// Second half: P and R (natural order and, for the level-ordered cycle, permuted), then the level joins the hierarchy.
+int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const int32_t* P_col, const double* P_val,
+                        const int32_t* R_rowptr, const int32_t* R_col, const double* R_val) {
+  if (!h || nc < 0 || !P_rowptr || !R_rowptr) return AMGH_EINVAL;
+  if (h->finalized || !h->pending_level) return AMGH_ESTATE;
+  Level* L = h->pending_level;
+  const int64_t n = L->n;
+  if (P_rowptr[n] != R_rowptr[nc]) return AMGH_EINVAL;   // the pending level stays: the caller may retry or destroy
+  HIP_TRY(hipSetDevice(h->device));
+  L->nc = nc;
+  int rc = csr_upload(&L->P, h->device, n, nc, P_rowptr, P_col, P_val);
+  if (rc == AMGH_OK) rc = csr_upload(&L->R, h->device, nc, n, R_rowptr, R_col, R_val);
+  GsSchedule* g = L->smat()->gs;
+  if (rc == AMGH_OK && L->lo_want && g) {
+    const std::vector<int32_t>& perm = g->h_perm;
+    std::vector<int32_t> inv(n);
+    for (int64_t p2 = 0; p2 < n; ++p2) inv[perm[p2]] = (int32_t)p2;
+    std::vector<int32_t> prp(n + 1, 0), pcl(P_rowptr[n]);
+    std::vector<double> pvl(P_rowptr[n]);
+    for (int64_t p2 = 0; p2 < n; ++p2) prp[p2 + 1] = prp[p2] + (P_rowptr[perm[p2] + 1] - P_rowptr[perm[p2]]);
+    const int T2 = std::max(1, std::min<int>(merge_threads(), 16));
+    std::vector<int32_t> rcl(R_rowptr[nc]);
+    const int64_t rnnz = R_rowptr[nc];
+    run_threads(T2, [&](int t) {
+      for (int64_t p2 = n * t / T2; p2 < n * (t + 1) / T2; ++p2) {
+        const int32_t src = P_rowptr[perm[p2]], len = P_rowptr[perm[p2] + 1] - src;
+        std::copy(P_col + src, P_col + src + len, pcl.begin() + prp[p2]);
+        std::copy(P_val + src, P_val + src + len, pvl.begin() + prp[p2]);
+      }
+      for (int64_t k = rnnz * t / T2; k < rnnz * (t + 1) / T2; ++k) rcl[k] = inv[R_col[k]];  // entries keep their order: same sums
+    });
+    rc = csr_upload(&L->Pp, h->device, n, nc, prp.data(), pcl.data(), pvl.data());
+    if (rc == AMGH_OK) rc = csr_upload(&L->Rp, h->device, nc, n, R_rowptr, rcl.data(), R_val);
+    L->lo_ok = rc == AMGH_OK;
+  }
+  if (g) std::vector<int32_t>().swap(g->h_perm);
   if (rc == AMGH_OK && L->lo_ok && gs_lean()) {
     // memory-lean: between the smoothers the cycle only touches the level-ordered copies (the schedule's own A, Pp,
     // Rp); the natural-order P, R and — below the fine level, whose A the outer residual of _solve! needs — A go
@@ -634,20 +667,45 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
     if (!h->levels.empty()) { drop(&L->A); if (L->has_S) drop(&L->S); }
     L->nat_freed = true;
   }
+  h->pending_level = nullptr;
   if (rc != AMGH_OK) {
-    csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
-    hipFree(L->lo_val);
-    delete L;
+    level_discard(L);
     return rc;
   }
   h->levels.push_back(L);
   return AMGH_OK;
 }
 
+// The caller found out that the begun level is the coarsest one after all (size(P, 2) == 0, classical.jl:43).
+int amgh_push_level_abort(amgh_t* h) {
+  if (!h) return AMGH_EINVAL;
+  if (!h->pending_level) return AMGH_ESTATE;
+  hipSetDevice(h->device);
+  level_discard(h->pending_level);
+  h->pending_level = nullptr;
+  return AMGH_OK;
+}
+
+int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, const int32_t* A_col,
+                    const double* A_val, const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
+                    const int32_t* P_rowptr, const int32_t* P_col, const double* P_val, const int32_t* R_rowptr,
+                    const int32_t* R_col, const double* R_val, const amgh_smoother_t* pre,
+                    const amgh_smoother_t* post) {
+  if (!h || n <= 0 || nc < 0 || !A_rowptr || !P_rowptr || !R_rowptr) return AMGH_EINVAL;
+  if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
+  if (h->finalized || h->pending_level) return AMGH_ESTATE;
+  if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
+  if (P_rowptr[n] != R_rowptr[nc]) return AMGH_EINVAL;
+  RC_TRY(amgh_push_level_begin(h, n, A_rowptr, A_col, A_val, S_rowptr, S_col, S_val, pre, post));
+  int rc = amgh_push_level_end(h, nc, P_rowptr, P_col, P_val, R_rowptr, R_col, R_val);
+  if (rc != AMGH_OK && h->pending_level) { level_discard(h->pending_level); h->pending_level = nullptr; }
+  return rc;
+}
+
 int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
                     const double* dense_op) {
   if (!h || n < 0 || !dense_op) return AMGH_EINVAL;
-  if (h->finalized || h->ncoarse >= 0) return AMGH_ESTATE;
+  if (h->finalized || h->ncoarse >= 0 || h->pending_level) return AMGH_ESTATE;
   if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
   if (n > 46000) return AMGH_EUNSUPPORTED;  // dense n*n operator
   HIP_TRY(hipSetDevice(h->device));
@@ -663,7 +721,7 @@ int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t
 int amgh_set_coarse_host(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
                          amgh_coarse_fn fn, void* user) {
   if (!h || n < 0 || !fn) return AMGH_EINVAL;
-  if (h->finalized || h->ncoarse >= 0) return AMGH_ESTATE;
+  if (h->finalized || h->ncoarse >= 0 || h->pending_level) return AMGH_ESTATE;
   if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
   if (n >= INT32_MAX) return AMGH_EUNSUPPORTED;
   HIP_TRY(hipSetDevice(h->device));
@@ -681,7 +739,7 @@ int amgh_set_coarse_host(amgh_t* h, int64_t n, const int32_t* A_rowptr, const in
 
 int amgh_finalize(amgh_t* h) {
   if (!h) return AMGH_EINVAL;
-  if (h->finalized || h->ncoarse < 0) return AMGH_ESTATE;
+  if (h->finalized || h->ncoarse < 0 || h->pending_level) return AMGH_ESTATE;
   if (h->levels.empty() && !h->has_finalA) return AMGH_ESTATE;
   HIP_TRY(hipSetDevice(h->device));
   int64_t ws = 0;

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -41,10 +42,122 @@ int dev_alloc(T** p, int64_t count) {
   if (e != hipSuccess) return -(1000 + (int)e);
   return AMGH_OK;
 }
+// Large transfers between pageable host memory and HBM.  hipMemcpy on pageable memory moves ~4 GB/s here (one host
+// thread staging through the runtime's bounce buffer, and — for a freshly allocated destination — taking every page
+// fault itself); the matrices of a 256^3 hierarchy are several GB each way.  staged_copy splits the range over a few
+// host threads, each with its own stream and two pinned 8 MB buffers: the DMA of one piece runs while the thread
+// copies (and faults in) the previous one.
+struct StageLane {
+  hipStream_t stream = nullptr;
+  void* buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+struct StageSet {
+  int device = -1;
+  std::vector<StageLane> lanes;
+};
+constexpr size_t kStagePiece = size_t(8) << 20;
+constexpr int kStageLanes = 8;
+inline std::mutex& stage_mutex() { static std::mutex m; return m; }
+inline std::vector<StageSet*>& stage_pool() { static std::vector<StageSet*> p; return p; }
+
+inline StageSet* stage_acquire(int device) {
+  {
+    std::lock_guard<std::mutex> lk(stage_mutex());
+    auto& pool = stage_pool();
+    for (size_t i = 0; i < pool.size(); ++i)
+      if (pool[i]->device == device) { StageSet* s = pool[i]; pool.erase(pool.begin() + i); return s; }
+  }
+  StageSet* s = new StageSet;
+  s->device = device;
+  s->lanes.resize(kStageLanes);
+  bool ok = true;
+  for (StageLane& L : s->lanes) {
+    ok = ok && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2; ++k) {
+      ok = ok && hipHostMalloc(&L.buf[k], kStagePiece, hipHostMallocDefault) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming) == hipSuccess;
+    }
+  }
+  if (!ok) {   // no pinned memory to be had: the caller falls back to plain hipMemcpy
+    for (StageLane& L : s->lanes) {
+      for (int k = 0; k < 2; ++k) { if (L.buf[k]) hipHostFree(L.buf[k]); if (L.ev[k]) hipEventDestroy(L.ev[k]); }
+      if (L.stream) hipStreamDestroy(L.stream);
+    }
+    delete s;
+    return nullptr;
+  }
+  return s;
+}
+inline void stage_release(StageSet* s) {
+  std::lock_guard<std::mutex> lk(stage_mutex());
+  stage_pool().push_back(s);
+}
+
+// dst <- src, `bytes` bytes, one side pageable host memory and the other device memory on the CURRENT device.
+// Synchronous (like hipMemcpy): the data is there on return.
+inline hipError_t staged_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  if (bytes < 4 * kStagePiece) return hipMemcpy(dst, src, bytes, kind);
+  int device = 0;
+  hipError_t e0 = hipGetDevice(&device);
+  if (e0 != hipSuccess) return e0;
+  StageSet* set = stage_acquire(device);
+  if (!set) { (void)hipGetLastError(); return hipMemcpy(dst, src, bytes, kind); }
+  const size_t npiece = (bytes + kStagePiece - 1) / kStagePiece;
+  const int T = (int)std::min<size_t>(kStageLanes, npiece / 2);
+  std::vector<hipError_t> err(T, hipSuccess);
+  auto lane_fn = [&](int t) {
+    hipSetDevice(device);
+    StageLane& L = set->lanes[t];
+    const size_t p0 = npiece * t / T, p1 = npiece * (t + 1) / T;
+    auto piece_len = [&](size_t p) { return std::min(kStagePiece, bytes - p * kStagePiece); };
+    hipError_t e = hipSuccess;
+    if (kind == hipMemcpyDeviceToHost) {
+      if (p0 < p1) {
+        e = hipMemcpyAsync(L.buf[0], (const char*)src + p0 * kStagePiece, piece_len(p0), kind, L.stream);
+        if (e == hipSuccess) e = hipEventRecord(L.ev[0], L.stream);
+      }
+      for (size_t p = p0; p < p1 && e == hipSuccess; ++p) {
+        const int k = (int)((p - p0) & 1);
+        if (p + 1 < p1) {
+          e = hipMemcpyAsync(L.buf[k ^ 1], (const char*)src + (p + 1) * kStagePiece, piece_len(p + 1), kind, L.stream);
+          if (e == hipSuccess) e = hipEventRecord(L.ev[k ^ 1], L.stream);
+          if (e != hipSuccess) break;
+        }
+        e = hipEventSynchronize(L.ev[k]);
+        if (e == hipSuccess) std::memcpy((char*)dst + p * kStagePiece, L.buf[k], piece_len(p));
+      }
+    } else {
+      for (size_t p = p0; p < p1 && e == hipSuccess; ++p) {
+        const int k = (int)((p - p0) & 1);
+        if (p >= p0 + 2) e = hipEventSynchronize(L.ev[k]);   // the DMA that last read this buffer
+        if (e != hipSuccess) break;
+        std::memcpy(L.buf[k], (const char*)src + p * kStagePiece, piece_len(p));
+        e = hipMemcpyAsync((char*)dst + p * kStagePiece, L.buf[k], piece_len(p), kind, L.stream);
+        if (e == hipSuccess) e = hipEventRecord(L.ev[k], L.stream);
+      }
+    }
+    hipError_t es = hipStreamSynchronize(L.stream);
+    err[t] = e != hipSuccess ? e : es;
+  };
+  {
+    std::vector<std::thread> th;
+    int started = 0;
+    for (; started < T - 1; ++started) {
+      try { th.emplace_back(lane_fn, started); } catch (const std::system_error&) { break; }
+    }
+    for (int t = started; t < T; ++t) lane_fn(t);
+    for (auto& x : th) x.join();
+  }
+  stage_release(set);
+  for (hipError_t e : err) if (e != hipSuccess) return e;
+  return hipSuccess;
+}
+
 template <class T>
 int dev_upload(T** p, const T* src, int64_t count) {
   RC_TRY(dev_alloc(p, count));
-  if (count > 0) HIP_TRY(hipMemcpy(*p, src, sizeof(T) * (size_t)count, hipMemcpyHostToDevice));
+  if (count > 0) HIP_TRY(staged_copy(*p, src, sizeof(T) * (size_t)count, hipMemcpyHostToDevice));
   return AMGH_OK;
 }
 inline int grid_for(int64_t n, int threads = 256) {

@@ -369,9 +369,9 @@ int amgh_dmat_upload(amgh_dmat_t** out, int device, int64_t m, int64_t n, const 
   if (colptr[0] != 0 || nnz < 0 || (nnz > 0 && (!rowval || !nzval))) return AMGH_EINVAL;
   amgh_dmat* M = nullptr;
   RC_TRY(dmat_alloc(&M, device, m, n, nnz));
-  hipError_t e = hipMemcpy(M->ptr, colptr, sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice);
-  if (e == hipSuccess && nnz) e = hipMemcpy(M->idx, rowval, sizeof(int32_t) * nnz, hipMemcpyHostToDevice);
-  if (e == hipSuccess && nnz) e = hipMemcpy(M->val, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice);
+  hipError_t e = staged_copy(M->ptr, colptr, sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice);
+  if (e == hipSuccess && nnz) e = staged_copy(M->idx, rowval, sizeof(int32_t) * nnz, hipMemcpyHostToDevice);
+  if (e == hipSuccess && nnz) e = staged_copy(M->val, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice);
   if (e != hipSuccess) { dmat_free(M); return -(1000 + (int)e); }
   *out = M;
   return AMGH_OK;
@@ -379,9 +379,10 @@ int amgh_dmat_upload(amgh_dmat_t** out, int device, int64_t m, int64_t n, const 
 int amgh_dmat_download(const amgh_dmat_t* M, int32_t* colptr, int32_t* rowval, double* nzval) {
   RC_TRY(dmat_check(M));
   HIP_TRY(hipSetDevice(M->device));
-  if (colptr) HIP_TRY(hipMemcpy(colptr, M->ptr, sizeof(int32_t) * (M->n + 1), hipMemcpyDeviceToHost));
-  if (rowval && M->nnz) HIP_TRY(hipMemcpy(rowval, M->idx, sizeof(int32_t) * M->nnz, hipMemcpyDeviceToHost));
-  if (nzval && M->nnz && M->val) HIP_TRY(hipMemcpy(nzval, M->val, sizeof(double) * M->nnz, hipMemcpyDeviceToHost));
+  HIP_TRY(hipStreamSynchronize(nullptr));   // the staged copies run on their own streams: whatever produced M (null stream) is done first
+  if (colptr) HIP_TRY(staged_copy(colptr, M->ptr, sizeof(int32_t) * (M->n + 1), hipMemcpyDeviceToHost));
+  if (rowval && M->nnz) HIP_TRY(staged_copy(rowval, M->idx, sizeof(int32_t) * M->nnz, hipMemcpyDeviceToHost));
+  if (nzval && M->nnz && M->val) HIP_TRY(staged_copy(nzval, M->val, sizeof(double) * M->nnz, hipMemcpyDeviceToHost));
   return AMGH_OK;
 }
 void amgh_dmat_free(amgh_dmat_t* M) {

@@ -386,10 +386,161 @@ void rs_cf_splitting(const Mat& S, const Mat& T, int32_t* splitting_out) {
   rs_cf_splitting_raw(S.m, S.colptr.data(), S.rowval.data(), T.colptr.data(), T.rowval.data(), splitting_out);
 }
 // the sweep itself works on the two PATTERNS only (column pointers + row indices of S and of T = S')
+//
+// The sweep is one sequential chain of dependent random accesses (the bucket bookkeeping of splitting.jl:25-159 has
+// to be followed step by step for the integer goldens), so its speed is set by cache misses per visited node: the
+// per-node fields (lambda, position in the bucket array, C/F/U state) live in ONE 8-byte record, and the records of a
+// node's neighbours are prefetched before the loop that walks them.
+namespace {
+struct SplitNode {
+  int32_t lambda;
+  uint32_t pos_state;  // position in index_to_node (30 bits) | state (2 bits: 0 = U, 1 = C, 2 = F)
+};
+constexpr uint32_t kStU = 0u, kStC = 1u, kStF = 2u;
+inline uint32_t st_of(const SplitNode& v) { return v.pos_state >> 30; }
+inline int64_t pos_of(const SplitNode& v) { return (int64_t)(v.pos_state & 0x3fffffffu); }
+inline void set_state(SplitNode& v, uint32_t st) { v.pos_state = (v.pos_state & 0x3fffffffu) | (st << 30); }
+inline void set_pos(SplitNode& v, int64_t p) { v.pos_state = (v.pos_state & 0xc0000000u) | (uint32_t)p; }
+
+void rs_cf_splitting_packed(int64_t n, const int32_t* Sp, const int32_t* Sj, const int32_t* Tp, const int32_t* Tj,
+                            int32_t* splitting_out) {
+  std::vector<SplitNode> node(n + 2, SplitNode{0, 0});
+  std::vector<int32_t> interval_ptr(n + 3, 0), interval_count(n + 3, 0), index_to_node(n + 2, 0);
+  for (int64_t i = 1; i <= n; ++i) {
+    node[i].lambda = Sp[i] - Sp[i - 1];
+    interval_count[node[i].lambda + 1] += 1;
+  }
+  {
+    int64_t s = 0;
+    for (int64_t k = 1; k <= n; ++k) {
+      s += interval_count[k];
+      interval_ptr[k + 1] = (int32_t)s;
+    }
+  }
+  std::fill(interval_count.begin(), interval_count.end(), 0);
+  for (int64_t i = 1; i <= n; ++i) {
+    int64_t li = node[i].lambda + 1;
+    interval_count[li] += 1;
+    int64_t index = interval_ptr[li] + interval_count[li];
+    index_to_node[index] = (int32_t)i;
+    set_pos(node[i], index);
+    if (node[i].lambda == 0) set_state(node[i], kStF);
+  }
+  SplitNode* nd = node.data();
+  int32_t* i2n = index_to_node.data();
+  const bool dry = !std::getenv("AMGS_SPLIT_NODRY");
+  for (int64_t top_index = n; top_index >= 1; --top_index) {
+    // look-ahead on the nodes that are next in line (their place may still change: prefetches only)
+    if (top_index > 8) {
+      __builtin_prefetch(&nd[i2n[top_index - 8]], 1, 1);
+      __builtin_prefetch(&Sp[i2n[top_index - 8] - 1], 0, 1);
+      const int64_t i4 = i2n[top_index - 4];
+      __builtin_prefetch(&Sj[Sp[i4 - 1]], 0, 1);
+      __builtin_prefetch(&Tj[Tp[i4 - 1]], 0, 1);
+      const int64_t i2 = i2n[top_index - 2];
+      if (st_of(nd[i2]) != kStF)
+        for (int32_t j = Sp[i2 - 1]; j < Sp[i2]; ++j) {
+          __builtin_prefetch(&nd[Sj[j] + 1], 1, 1);
+          __builtin_prefetch(&Tp[Sj[j]], 0, 1);
+        }
+    }
+    int64_t i = i2n[top_index];
+    int64_t li = nd[i].lambda + 1;
+    interval_count[li] -= 1;
+    if (st_of(nd[i]) == kStF) continue;
+    set_state(nd[i], kStC);
+    const int32_t s0 = Sp[i - 1], s1 = Sp[i];
+    for (int32_t j = s0; j < s1; ++j) {
+      __builtin_prefetch(&nd[Sj[j] + 1], 1, 1);
+      __builtin_prefetch(&Tp[Sj[j]], 0, 1);
+    }
+    for (int32_t j = Tp[i - 1]; j < Tp[i]; ++j) __builtin_prefetch(&nd[Tj[j] + 1], 1, 1);
+    if (dry) {
+      // dry passes over what the real pass below will touch, one level of indirection at a time, so that the misses
+      // of a whole neighbourhood are in flight together instead of one after the other
+      for (int32_t j = s0; j < s1; ++j) {
+        const int64_t row = (int64_t)Sj[j] + 1;
+        if (st_of(nd[row]) == kStU) __builtin_prefetch(&Tj[Tp[row - 1]], 0, 1);
+      }
+      for (int32_t j = s0; j < s1; ++j) {
+        const int64_t row = (int64_t)Sj[j] + 1;
+        if (st_of(nd[row]) == kStU)
+          for (int32_t k = Tp[row - 1]; k < Tp[row]; ++k) __builtin_prefetch(&nd[Tj[k] + 1], 1, 1);
+      }
+      for (int32_t j = s0; j < s1; ++j) {
+        const int64_t row = (int64_t)Sj[j] + 1;
+        if (st_of(nd[row]) == kStU)
+          for (int32_t k = Tp[row - 1]; k < Tp[row]; ++k) {
+            const SplitNode& nk = nd[(int64_t)Tj[k] + 1];
+            if (st_of(nk) == kStU) {
+              __builtin_prefetch(&i2n[pos_of(nk)], 1, 1);
+              const int64_t lk = nk.lambda + 1;
+              __builtin_prefetch(&nd[i2n[interval_ptr[lk] + interval_count[lk]]], 1, 1);
+            }
+          }
+      }
+    }
+    for (int32_t j = s0; j < s1; ++j) {
+      int64_t row = (int64_t)Sj[j] + 1;
+      if (st_of(nd[row]) == kStU) {
+        set_state(nd[row], kStF);
+        const int32_t t0 = Tp[row - 1], t1 = Tp[row];
+        for (int32_t k = t0; k < t1; ++k) __builtin_prefetch(&nd[Tj[k] + 1], 1, 1);
+        for (int32_t k = t0; k < t1; ++k) {
+          int64_t rowk = (int64_t)Tj[k] + 1;
+          SplitNode& nk = nd[rowk];
+          if (st_of(nk) == kStU) {
+            if (nk.lambda >= n - 1) continue;
+            int64_t lk = nk.lambda + 1;
+            int64_t old_pos = pos_of(nk);
+            int64_t new_pos = interval_ptr[lk] + interval_count[lk];
+            int64_t swap_node = i2n[new_pos];
+            i2n[old_pos] = (int32_t)swap_node;
+            i2n[new_pos] = (int32_t)rowk;
+            set_pos(nk, new_pos);
+            set_pos(nd[swap_node], old_pos);
+            nk.lambda += 1;
+            interval_count[lk] -= 1;
+            interval_count[lk + 1] += 1;
+            interval_ptr[lk + 1] = (int32_t)(new_pos - 1);
+          }
+        }
+      }
+    }
+    for (int32_t j = Tp[i - 1]; j < Tp[i]; ++j) {
+      int64_t row = (int64_t)Tj[j] + 1;
+      SplitNode& nr = nd[row];
+      if (st_of(nr) == kStU) {
+        if (nr.lambda == 0) continue;
+        int64_t lj = nr.lambda + 1;
+        int64_t old_pos = pos_of(nr);
+        int64_t new_pos = interval_ptr[lj] + 1;
+        int64_t swap_node = i2n[new_pos];
+        i2n[old_pos] = (int32_t)swap_node;
+        i2n[new_pos] = (int32_t)row;
+        set_pos(nr, new_pos);
+        set_pos(nd[swap_node], old_pos);
+        nr.lambda -= 1;
+        interval_count[lj] -= 1;
+        interval_count[lj - 1] += 1;
+        interval_ptr[lj] += 1;
+      }
+    }
+  }
+  for (int64_t i = 1; i <= n; ++i) {
+    uint32_t st = st_of(nd[i]);
+    splitting_out[i - 1] = st == kStC ? C_NODE : (st == kStF ? F_NODE : U_NODE);
+  }
+}
+}  // namespace
+
 void rs_cf_splitting_raw(int64_t n, const int32_t* Sp, const int32_t* Sj, const int32_t* Tp, const int32_t* Tj,
                          int32_t* splitting_out) {
-  // int32 bookkeeping (n < 2^31): the sweep is a sequential chain of dependent random accesses, so the
-  // working-set size is what sets its speed
+  if (n + 2 < (int64_t(1) << 30) && !std::getenv("AMGS_SPLIT_PLAIN")) {
+    rs_cf_splitting_packed(n, Sp, Sj, Tp, Tj, splitting_out);
+    return;
+  }
+  // plain-array form of the same sweep (n >= 2^30, or AMGS_SPLIT_PLAIN for the A/B test)
   std::vector<int32_t> lambda(n + 2, 0), interval_ptr(n + 3, 0), interval_count(n + 3, 0);
   std::vector<int32_t> index_to_node(n + 2, 0), node_to_index(n + 2, 0);
   std::vector<int8_t> splitting(n + 2, U_NODE);

@@ -156,42 +156,71 @@ class DeviceHierarchy:
 
     def __init__(self, ml, device=0, nrhs=1):
         from .hierarchy import HermitianSymmetry
+        self._open(device, nrhs, isinstance(ml.symmetry, HermitianSymmetry))
+        for lev in ml.levels:
+            self.push_begin(lev.A, lev.presmoother, lev.postsmoother)
+            self.push_end(lev)
+        self.finish(ml)
+
+    # ---- construction, level by level (the setup phase drives these itself when it builds on the GPU: push_begin
+    # ---- of a level runs on a worker thread while the host does that level's C/F splitting) ------------------------
+    @classmethod
+    def incremental(cls, device, nrhs, hermitian):
+        self = cls.__new__(cls)
+        self._open(device, nrhs, hermitian)
+        return self
+
+    def _open(self, device, nrhs, hermitian):
         self.lib = require_gpu()
         self.device = device
-        self.ml = ml
+        self.ml = None
         self.nrhs = int(nrhs)
+        self.hermitian = bool(hermitian)
+        self.h = None
         h = C.c_void_p()
         hip_check(self.lib.amgh_create(C.byref(h), device, self.nrhs), "create")
         self.h = h.value
-        hermitian = isinstance(ml.symmetry, HermitianSymmetry)
+
+    def push_begin(self, A, presmoother, postsmoother):
+        """amgh_push_level_begin: A (and S) to HBM, smoother schedules.  Needs nothing but A."""
         import os
         import time
-        verbose = bool(os.environ.get("AMGH_VERBOSE"))
-        for lev in ml.levels:
-            t_lev = time.perf_counter()
-            A = lev.A
-            n, nc = A.m, lev.P.n
-            Ar, Ac, Av = A.csr_arrays()                  # true A rows
-            t_arr = time.perf_counter() - t_lev
-            if hermitian and not A.is_symmetric():
-                Sr, Sc, Sv = A.colptr, A.rowval, A.nzval  # column i read as row i
-            else:
-                Sr = Sc = Sv = None                      # S == A
-            # CSR of P (n x nc) = CSC arrays of R (nc x n), and vice versa.
-            Pr, Pc, Pv = lev.R.colptr, lev.R.rowval, lev.R.nzval
-            Rr, Rc, Rv = lev.P.colptr, lev.P.rowval, lev.P.nzval
-            if lev.R.shape != (nc, n) or lev.P.shape != (n, nc):
-                raise AMGError("Level: P must be n x nc and R nc x n")
-            for s in (lev.presmoother, lev.postsmoother):
-                if not isinstance(s, Smoother):
-                    raise AMGError(f"unsupported smoother {s!r}")
-            pre, post = lev.presmoother.c_struct(), lev.postsmoother.c_struct()
-            hip_check(self.lib.amgh_push_level(self.h, n, nc, _ptr(Ar), _ptr(Ac), _ptr(Av), _ptr(Sr), _ptr(Sc),
-                                               _ptr(Sv), _ptr(Pr), _ptr(Pc), _ptr(Pv), _ptr(Rr), _ptr(Rc), _ptr(Rv),
-                                               C.byref(pre), C.byref(post)), "push_level")
-            if verbose:
-                print(f"[amghip] n={n} python: csr_arrays {t_arr:.2f} s, level total {time.perf_counter() - t_lev:.2f} s",
-                      file=__import__("sys").stderr, flush=True)
+        t_lev = time.perf_counter()
+        n = A.m
+        Ar, Ac, Av = A.csr_arrays()                  # true A rows
+        t_arr = time.perf_counter() - t_lev
+        if self.hermitian and not A.is_symmetric():
+            Sr, Sc, Sv = A.colptr, A.rowval, A.nzval  # column i read as row i
+        else:
+            Sr = Sc = Sv = None                      # S == A
+        for s in (presmoother, postsmoother):
+            if not isinstance(s, Smoother):
+                raise AMGError(f"unsupported smoother {s!r}")
+        pre, post = presmoother.c_struct(), postsmoother.c_struct()
+        hip_check(self.lib.amgh_push_level_begin(self.h, n, _ptr(Ar), _ptr(Ac), _ptr(Av), _ptr(Sr), _ptr(Sc), _ptr(Sv),
+                                                 C.byref(pre), C.byref(post)), "push_level_begin")
+        if os.environ.get("AMGH_VERBOSE"):
+            print(f"[amghip] n={n} python: csr_arrays {t_arr:.2f} s, push_level_begin total {time.perf_counter() - t_lev:.2f} s",
+                  file=__import__("sys").stderr, flush=True)
+
+    def push_end(self, lev):
+        """amgh_push_level_end: P and R of the level whose A was pushed last."""
+        n, nc = lev.A.m, lev.P.n
+        # CSR of P (n x nc) = CSC arrays of R (nc x n), and vice versa.
+        Pr, Pc, Pv = lev.R.colptr, lev.R.rowval, lev.R.nzval
+        Rr, Rc, Rv = lev.P.colptr, lev.P.rowval, lev.P.nzval
+        if lev.R.shape != (nc, n) or lev.P.shape != (n, nc):
+            raise AMGError("Level: P must be n x nc and R nc x n")
+        hip_check(self.lib.amgh_push_level_end(self.h, nc, _ptr(Pr), _ptr(Pc), _ptr(Pv), _ptr(Rr), _ptr(Rc), _ptr(Rv)),
+                  "push_level_end")
+
+    def push_abort(self):
+        """amgh_push_level_abort: the level begun last turned out to be the coarsest one."""
+        hip_check(self.lib.amgh_push_level_abort(self.h), "push_level_abort")
+
+    def finish(self, ml):
+        """Coarsest level + amgh_finalize; `ml` is the hierarchy the pushed levels belong to."""
+        self.ml = ml
         fA = ml.final_A
         fr, fc, fv = fA.csr_arrays()
         cs = ml.coarse_solver

@@ -414,10 +414,50 @@ class _DMat:
             pass
 
 
-def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0):
+class _Pipeline:
+    """Calls executed in order on ONE host thread (ctypes releases the GIL inside the library); the first exception
+    stops the queue and is re-raised by close()."""
+
+    def __init__(self):
+        import queue
+        import threading
+        self.q = queue.Queue()
+        self.exc = None
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if self.exc is not None:
+                continue
+            fn, args = item
+            try:
+                fn(*args)
+            except BaseException as e:  # noqa: BLE001 - handed to the closing thread
+                self.exc = e
+
+    def submit(self, fn, *args):
+        self.q.put((fn, args))
+
+    def close(self, reraise=True):
+        self.q.put(None)
+        self.t.join()
+        if reraise and self.exc is not None:
+            raise self.exc
+
+
+def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0, builder=None, smoothers=None):
     """extend_hierarchy_rs! (classical.jl:36-55) with strength, interpolation, transposes and R*A*P on the GPU
     (amgh_setup_*, include/amghip.h) and the sequential C/F splitting on the host (amgs_rs_cf_splitting_patterns).
-    Returns [(A, P, R), ...], final_A as host matrices — bitwise what the host library builds."""
+    Returns [(A, P, R), ...], final_A as host matrices — bitwise what the host library builds.
+
+    With `builder` (a DeviceHierarchy.incremental) the solve-phase handle is filled on the way: the upload of a level's
+    A and the construction of its smoother schedules (amgh_push_level_begin) need only A, so a second host thread does
+    them — and the level's P, R (amgh_push_level_end) once they exist — while this thread goes on with strength / C/F
+    splitting / interpolation / R*A*P of this and the following levels."""
     from ._libs import hip_check, hip_lib
     lib, L = hip_lib(), setup_lib()
     if lib.amgh_device_count() <= 0:
@@ -451,49 +491,90 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0):
             M_host._T._T = M_host
         return dT
 
+    import os
+    import time
+    timing = {} if os.environ.get("AMG_SETUP_TIMING") else None
+    t_last = [time.perf_counter()]
+
+    def tick(label):
+        if timing is not None:
+            now = time.perf_counter()
+            timing[label] = timing.get(label, 0.0) + now - t_last[0]
+            t_last[0] = now
+
     out = []
     A_host, dA = A, _DMat.upload(A, lib, device)
-    while len(out) + 1 < max_levels and A_host.m > max_coarse:
-        n = A_host.m
-        dAT = prime_symmetry(A_host, dA) if A_host._sym is None else None
-        if hermitian:
-            dAt = dA
-        else:
-            if dAT is None:
-                t = C.c_void_p()
-                hip_check(lib.amgh_setup_transpose(dA.h, C.byref(t)), "setup_transpose")
-                dAT = _DMat(t.value, lib)
-            dAt = dAT
-        s_, t_, sn, tn = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        hip_check(lib.amgh_setup_classical_strength(dAt.h, theta, C.byref(s_), C.byref(t_), C.byref(sn), C.byref(tn)),
-                  "setup_classical_strength")
-        dS, dT, dSn, dTn = (_DMat(v.value, lib) for v in (s_, t_, sn, tn))
-        Sp, Sj, _ = dSn.download(values=False)
-        Tp, Tj, _ = dTn.download(values=False)
-        splitting = np.empty(n, dtype=np.int32)
-        if L.amgs_rs_cf_splitting_patterns(n, Sp.ctypes.data, Sj.ctypes.data, Tp.ctypes.data, Tj.ctypes.data,
-                                           splitting.ctypes.data) != 0:
-            raise AMGError(L.amgs_last_error().decode())
-        del dS, dSn, dTn
-        dR, dP = call2(lib.amgh_setup_direct_interpolation, dAt.h, dT.h, splitting.ctypes.data, what="setup_direct_interpolation")
-        if dR.m == 0:        # size(P, 2) == 0: stop coarsening (classical.jl:43)
-            break
-        dRAP = spgemm(spgemm(dR, dA), dP)
-        out.append((A_host, dP.to_host(), dR.to_host()))
-        A_host, dA = dRAP.to_host(), dRAP
+    tick("upload A")
+    pipe = _Pipeline() if builder is not None else None
+    try:
+        while len(out) + 1 < max_levels and A_host.m > max_coarse:
+            n = A_host.m
+            dAT = prime_symmetry(A_host, dA) if A_host._sym is None else None
+            if hermitian:
+                dAt = dA
+            else:
+                if dAT is None:
+                    t = C.c_void_p()
+                    hip_check(lib.amgh_setup_transpose(dA.h, C.byref(t)), "setup_transpose")
+                    dAT = _DMat(t.value, lib)
+                dAt = dAT
+            tick("transpose / symmetry")
+            if pipe is not None:
+                pipe.submit(builder.push_begin, A_host, *smoothers)
+            s_, t_, sn, tn = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            hip_check(lib.amgh_setup_classical_strength(dAt.h, theta, C.byref(s_), C.byref(t_), C.byref(sn), C.byref(tn)),
+                      "setup_classical_strength")
+            dS, dT, dSn, dTn = (_DMat(v.value, lib) for v in (s_, t_, sn, tn))
+            tick("strength")
+            Sp, Sj, _ = dSn.download(values=False)
+            Tp, Tj, _ = dTn.download(values=False)
+            tick("download S, T patterns")
+            splitting = np.empty(n, dtype=np.int32)
+            if L.amgs_rs_cf_splitting_patterns(n, Sp.ctypes.data, Sj.ctypes.data, Tp.ctypes.data, Tj.ctypes.data,
+                                               splitting.ctypes.data) != 0:
+                raise AMGError(L.amgs_last_error().decode())
+            del dS, dSn, dTn
+            tick("C/F splitting (host)")
+            dR, dP = call2(lib.amgh_setup_direct_interpolation, dAt.h, dT.h, splitting.ctypes.data, what="setup_direct_interpolation")
+            if dR.m == 0:        # size(P, 2) == 0: stop coarsening (classical.jl:43)
+                if pipe is not None:
+                    pipe.submit(builder.push_abort)
+                break
+            tick("interpolation")
+            dRAP = spgemm(spgemm(dR, dA), dP)
+            tick("R*A*P")
+            out.append((A_host, dP.to_host(), dR.to_host()))
+            A_next = dRAP.to_host()
+            tick("download P, R, RAP")
+            if pipe is not None:
+                pipe.submit(builder.push_end, Level(*out[-1], *smoothers))
+            A_host, dA = A_next, dRAP
+    except BaseException:
+        if pipe is not None:      # never tear the handle down under a running push
+            pipe.close(reraise=False)
+        raise
+    if pipe is not None:
+        pipe.close()
+        tick("wait for the smoother schedules")
     if A_host._sym is None:
         prime_symmetry(A_host, dA)
+    if timing is not None:
+        import sys
+        print("ruge_stuben(setup='gpu') seconds: " + ", ".join(f"{k} {v:.2f}" for k, v in timing.items()),
+              file=sys.stderr, flush=True)
     return out, A_host
 
 
 def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, postsmoother=None,
-                max_levels=10, max_coarse=10, coarse_solver=None, setup=None, **kwargs):
+                max_levels=10, max_coarse=10, coarse_solver=None, setup=None, device=None, **kwargs):
     """ruge_stuben(A; strength=Classical(0.25), symmetry=HermitianSymmetry(), CF=RS(),
     presmoother=GaussSeidel(), postsmoother=GaussSeidel(), max_levels=10, max_coarse=10,
     coarse_solver=QRSolver)   — classical.jl:6-34.
 
     setup = "host" (libamgsetup, C++/OpenMP) | "gpu" (strength, interpolation and R*A*P on the MI355X, C/F splitting
-    on the host; same hierarchy bit for bit).  Default: the environment variable AMG_SETUP, else "host"."""
+    on the host; same hierarchy bit for bit).  Default: the environment variable AMG_SETUP, else "host".
+    device = a GPU ordinal (with setup="gpu"): the solve-phase hierarchy `ml.device(device)` is built on the way, each
+    level's smoother schedules on a worker thread while the host does that level's C/F splitting."""
     if kwargs.get("B") is not None:  # classical.jl:18
         raise AMGError("near null space `B` is only supported for smoothed aggregation AMG, not Ruge-Stüben AMG.")
     strength = strength if strength is not None else Classical(0.25)
@@ -513,7 +594,12 @@ def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, post
     import os
     setup = setup if setup is not None else os.environ.get("AMG_SETUP", "host")
     if setup == "gpu":
-        lv, final_A = _ruge_stuben_gpu(A, strength.theta, int(max_levels), int(max_coarse), bool(o.hermitian))
+        builder = None
+        if device is not None:
+            from .device import DeviceHierarchy
+            builder = DeviceHierarchy.incremental(int(device), 1, bool(o.hermitian))
+        lv, final_A = _ruge_stuben_gpu(A, strength.theta, int(max_levels), int(max_coarse), bool(o.hermitian),
+                                       device=int(device or 0), builder=builder, smoothers=(presmoother, postsmoother))
         levels = [Level(a, p, r, presmoother, postsmoother) for a, p, r in lv]
         for m_ in [final_A] + [l.A for l in levels]:
             m_.eltype = A.eltype
@@ -521,7 +607,11 @@ def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, post
             for lev in levels:
                 for s_ in (presmoother, postsmoother):
                     s_.check_no_symmetry(lev.A)
-        return MultiLevel(levels, final_A, coarse_solver(final_A), presmoother, postsmoother, symmetry, method="rs")
+        ml = MultiLevel(levels, final_A, coarse_solver(final_A), presmoother, postsmoother, symmetry, method="rs")
+        if builder is not None:
+            builder.finish(ml)
+            ml._dev[(int(device), 1)] = builder
+        return ml
     if setup != "host":
         raise AMGError("ruge_stuben: setup must be 'host' or 'gpu'")
     hier = _Hier(setup_lib().amgs_ruge_stuben(A._h, C.byref(o)))

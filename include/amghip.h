@@ -97,6 +97,21 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc,
                     const int32_t* R_rowptr, const int32_t* R_col, const double* R_val,
                     const amgh_smoother_t* pre, const amgh_smoother_t* post);
 
+/* The same push in two halves, for a caller that knows A before P and R — the setup phase itself
+ * (classical.jl:36-55: strength and C/F splitting of A come before the interpolation that gives P, R):
+ * _begin uploads A (S) and builds the smoother schedules, which needs nothing else; _end adds P and R and
+ * appends the level.  _begin may run on another host thread while the caller computes P and R (one
+ * pending level per handle; every other call on the handle between the two returns AMGH_ESTATE).        */
+int amgh_push_level_begin(amgh_t* h, int64_t n,
+                          const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
+                          const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
+                          const amgh_smoother_t* pre, const amgh_smoother_t* post);
+int amgh_push_level_end(amgh_t* h, int64_t nc,
+                        const int32_t* P_rowptr, const int32_t* P_col, const double* P_val,
+                        const int32_t* R_rowptr, const int32_t* R_col, const double* R_val);
+/* Drops the begun level instead (coarsening stopped: size(P, 2) == 0, classical.jl:43).                */
+int amgh_push_level_abort(amgh_t* h);
+
 /* Coarsest level: final_A and the coarse solver (coarse_solver.jl).  The
  * callable `(cs)(x, b)` becomes x = dense_op * b with dense_op (n x n,
  * column-major) computed by the host shim: pinv(Matrix(A)) for Pinv

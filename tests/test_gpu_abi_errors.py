@@ -61,6 +61,50 @@ def test_state_machine_and_argument_checks():
     lib.amgh_destroy(None)                                                   # no-op
 
 
+def test_push_level_in_two_halves_state_machine():
+    """amgh_push_level_begin / _end / _abort: one pending level per handle, everything else refuses meanwhile."""
+    lib = AMG.hip_lib()
+    A = AMG.poisson(60)
+    ml = AMG.ruge_stuben(A, max_levels=2)
+    lev = ml.levels[0]
+    gs = amgh_smoother_t(1, 2, 1, 0, 1.0)
+    a, p, r = _csr(lev.A), (lev.R.colptr.ctypes.data, lev.R.rowval.ctypes.data, lev.R.nzval.ctypes.data), \
+        (lev.P.colptr.ctypes.data, lev.P.rowval.ctypes.data, lev.P.nzval.ctypes.data)
+    n, nc = lev.A.m, lev.P.n
+    fa = _csr(ml.final_A)
+    op = np.asfortranarray(ml.coarse_solver.dense_operator())
+    h = C.c_void_p()
+    assert lib.amgh_create(C.byref(h), 0, 1) == 0
+    assert lib.amgh_push_level_end(h, nc, *p, *r) == ESTATE                  # nothing begun
+    assert lib.amgh_push_level_abort(h) == ESTATE
+    assert lib.amgh_push_level_begin(h, n, None, None, None, None, None, None, C.byref(gs), C.byref(gs)) == EINVAL
+    assert lib.amgh_push_level_begin(h, n, *a, None, None, None, C.byref(gs), C.byref(gs)) == 0
+    assert lib.amgh_push_level_begin(h, n, *a, None, None, None, C.byref(gs), C.byref(gs)) == ESTATE   # one at a time
+    assert lib.amgh_push_level(h, n, nc, *a, None, None, None, *p, *r, C.byref(gs), C.byref(gs)) == ESTATE
+    assert lib.amgh_set_coarse(h, nc, *fa, op.ctypes.data) == ESTATE
+    assert lib.amgh_finalize(h) == ESTATE
+    assert lib.amgh_push_level_abort(h) == 0                                  # "it was the coarsest level after all"
+    assert lib.amgh_num_levels(h) == 0
+    assert lib.amgh_push_level_begin(h, n, *a, None, None, None, C.byref(gs), C.byref(gs)) == 0
+    assert lib.amgh_push_level_end(h, nc, None, None, None, *r) == EINVAL
+    assert lib.amgh_push_level_end(h, nc, *p, *r) == 0
+    assert lib.amgh_num_levels(h) == 1
+    assert lib.amgh_set_coarse(h, nc, *fa, op.ctypes.data) == 0
+    assert lib.amgh_finalize(h) == 0
+    # the same cycle as the one-call push, bit for bit
+    b = np.linspace(0.5, 1.5, n); z1 = np.zeros(n); z2 = np.zeros(n)
+    assert lib.amgh_precond_apply(h, b.ctypes.data, z1.ctypes.data, 0) == 0
+    ref = ml.device()
+    assert lib.amgh_precond_apply(ref.h, b.ctypes.data, z2.ctypes.data, 0) == 0
+    assert np.array_equal(z1, z2)
+    # a handle destroyed with a level still pending releases it
+    h2 = C.c_void_p()
+    assert lib.amgh_create(C.byref(h2), 0, 1) == 0
+    assert lib.amgh_push_level_begin(h2, n, *a, None, None, None, C.byref(gs), C.byref(gs)) == 0
+    lib.amgh_destroy(h2)
+    lib.amgh_destroy(h)
+
+
 def test_hierarchy_without_levels_needs_final_A_and_pcg_rejects_blocks():
     lib = AMG.hip_lib()
     A = AMG.poisson(8)

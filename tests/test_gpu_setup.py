@@ -79,3 +79,34 @@ def test_gpu_setup_solves_like_the_host_setup():
     xg, hg = AMG._solve(AMG.ruge_stuben(A, setup="gpu"), b, log=True)
     xh, hh = AMG._solve(AMG.ruge_stuben(A, setup="host"), b, log=True)
     assert np.array_equal(xg, xh) and np.array_equal(hg, hh)
+
+
+@pytest.mark.parametrize("dims", [(40, 40, 40), (300, 200), (5000,)])
+def test_hierarchy_built_beside_the_setup_equals_the_one_built_after_it(dims):
+    """ruge_stuben(setup="gpu", device=0): every level's upload + smoother schedules run on a worker thread while the
+    host does that level's C/F splitting (amgh_push_level_begin / _end).  Same hierarchy, same cycle bit for bit."""
+    A = AMG.poisson(dims)
+    after = AMG.ruge_stuben(A, setup="gpu")
+    beside = AMG.ruge_stuben(A, setup="gpu", device=0)
+    assert (0, 1) in beside._dev and (0, 1) not in after._dev           # the handle is there before anyone asks
+    assert len(after) == len(beside)
+    for a, b in zip(after.levels, beside.levels):
+        assert same(a.A, b.A) and same(a.P, b.P) and same(a.R, b.R)
+    d1, d2 = after.device(), beside.device()
+    assert d2 is beside._dev[(0, 1)]
+    assert d1.lib.amgh_num_levels(d1.h) == d2.lib.amgh_num_levels(d2.h) == len(after.levels)
+    r = uniform(A.m, 5)
+    for cycle in (AMG.V(), AMG.W()):
+        assert np.array_equal(AMG.aspreconditioner(after, cycle).ldiv(r), AMG.aspreconditioner(beside, cycle).ldiv(r))
+    x, hist = AMG._solve(beside, r, log=True, reltol=1e-10)
+    assert np.linalg.norm(A.to_scipy() @ x - r) <= 1e-9 * np.linalg.norm(r)
+
+
+def test_built_beside_the_setup_when_coarsening_stops_early_or_never_starts():
+    # max_levels = 1: no level at all; tiny operator: below max_coarse from the start
+    for A, kw in ((AMG.poisson(30), dict(max_levels=1)), (AMG.poisson(8), {}), (AMG.poisson((12, 12)), dict(max_levels=2))):
+        ml = AMG.ruge_stuben(A, setup="gpu", device=0, **kw)
+        ref = AMG.ruge_stuben(A, setup="host", **kw)
+        assert len(ml) == len(ref)
+        r = uniform(A.m, 2)
+        assert np.allclose(AMG.aspreconditioner(ml).ldiv(r), AMG.aspreconditioner(ref).ldiv(r), rtol=1e-12, atol=1e-14)

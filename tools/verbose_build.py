@@ -1,5 +1,14 @@
+"""Where the seconds before the first cycle go: ruge_stuben(setup=...) stage times (AMG_SETUP_TIMING) and the upload /
+schedule construction per level (AMGH_VERBOSE).   usage: python tools/verbose_build.py [N=256] [setup=gpu]"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+os.environ.setdefault("AMG_SETUP_TIMING", "1")
+os.environ.setdefault("AMGH_VERBOSE", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import amg_amd as AMG
-t0=time.time(); A = AMG.poisson((256,256,256)); ml = AMG.ruge_stuben(A); print("setup", time.time()-t0, flush=True)
-t0=time.time(); dev = ml.device(); print("upload", time.time()-t0, flush=True)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+mode = sys.argv[2] if len(sys.argv) > 2 else "gpu"
+AMG.ruge_stuben(AMG.poisson((12, 12, 12)), setup=mode).device()     # library load / HIP context outside the timings
+print("---- timed from here", flush=True)
+t0 = time.time(); A = AMG.poisson((N, N, N)); print("poisson", round(time.time() - t0, 2), flush=True)
+t0 = time.time(); ml = AMG.ruge_stuben(A, setup=mode); print("setup", round(time.time() - t0, 2), flush=True)
+t0 = time.time(); dev = ml.device(); print("upload", round(time.time() - t0, 2), flush=True)
