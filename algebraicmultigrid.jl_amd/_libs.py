@@ -12,6 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SETUP_SO = os.path.join(_HERE, "libamgsetup.so")
 HIP_SO = os.path.join(_HERE, "libamghip.so")
+HIP_F32_SO = os.path.join(_HERE, "libamghip_f32.so")   # the same source with amgh_real = float (solve phase only)
 
 i32p = C.POINTER(C.c_int32)
 f64p = C.POINTER(C.c_double)
@@ -35,9 +36,11 @@ class amgh_smoother_t(C.Structure):
 
 
 COARSE_FN = C.CFUNCTYPE(C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), i64)
+COARSE_FN_F32 = C.CFUNCTYPE(C.c_int, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), i64)
 
 _setup = None
 _hip = None
+_hip_f32 = None
 
 
 def setup_lib():
@@ -93,15 +96,8 @@ def setup_lib():
     return L
 
 
-def hip_lib():
-    """Load libamghip.so.  Raises AMGError if it has not been built."""
-    global _hip
-    if _hip is not None:
-        return _hip
-    if not os.path.exists(HIP_SO):
-        raise AMGError(f"{HIP_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                       "(the solve phase has no CPU fallback)")
-    L = C.CDLL(HIP_SO)
+def _bind_solve_phase(L, creal, coarse_fn):
+    """argtypes of the solve-phase handle and the stand-alone operators (both instances of the library)."""
     L.amgh_strerror.restype = C.c_char_p
     L.amgh_strerror.argtypes = [C.c_int]
     L.amgh_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
@@ -112,7 +108,7 @@ def hip_lib():
     L.amgh_push_level_end.argtypes = [vp, i64] + [vp] * 6
     L.amgh_push_level_abort.argtypes = [vp]
     L.amgh_set_coarse.argtypes = [vp, i64, vp, vp, vp, vp]
-    L.amgh_set_coarse_host.argtypes = [vp, i64, vp, vp, vp, COARSE_FN, vp]
+    L.amgh_set_coarse_host.argtypes = [vp, i64, vp, vp, vp, coarse_fn, vp]
     L.amgh_finalize.argtypes = [vp]
     L.amgh_num_levels.argtypes = [vp]
     L.amgh_level_size.restype = i64
@@ -147,7 +143,7 @@ def hip_lib():
     L.amgh_csr_gs_d.argtypes = [vp, C.c_int, C.c_double, C.c_int, vp, vp, vp]
     L.amgh_csr_gs_ex_d.argtypes = [vp, C.c_int, C.c_double, C.c_int, vp, vp, vp, C.c_int]
     L.amgh_gather_d.argtypes = [C.c_int, i64, vp, vp, vp, vp]
-    L.amgh_dot_d.argtypes = [C.c_int, i64, vp, vp, vp, C.POINTER(C.c_double), vp]
+    L.amgh_dot_d.argtypes = [C.c_int, i64, vp, vp, vp, C.POINTER(creal), vp]
     L.amgh_cycle_d.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     L.amgh_set_stream.argtypes = [vp, vp]
     L.amgh_dev_alloc.argtypes = [C.c_int, i64, C.POINTER(vp)]
@@ -166,6 +162,22 @@ def hip_lib():
     L.amgh_profile_enable.argtypes = [vp, C.c_int]
     L.amgh_profile_read.argtypes = [vp, vp, C.c_int]
     L.amgh_set_use_graph.argtypes = [vp, C.c_int]
+
+
+def hip_lib(dtype=None):
+    """Load libamghip.so (dtype None / float64) or its Float32 instance libamghip_f32.so (dtype float32).
+    Raises AMGError if it has not been built."""
+    global _hip
+    if dtype is not None and _np_dtype(dtype).itemsize == 4:
+        return hip_lib_f32()
+    if _hip is not None:
+        return _hip
+    if not os.path.exists(HIP_SO):
+        raise AMGError(f"{HIP_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the solve phase has no CPU fallback)")
+    L = C.CDLL(HIP_SO)
+    L.real_dtype = "float64"
+    _bind_solve_phase(L, C.c_double, COARSE_FN)
     # row-sharded hierarchy (amgh_dist_*)
     i64p = C.POINTER(i64)
     L.amgh_dist_rccl_available.argtypes = []
@@ -211,6 +223,26 @@ def hip_lib():
     L.amgh_setup_direct_interpolation.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     L.amgh_setup_spgemm.argtypes = [vp, vp, C.POINTER(vp)]
     _hip = L
+    return L
+
+
+def _np_dtype(dtype):
+    import numpy as np
+    return np.dtype(dtype)
+
+
+def hip_lib_f32():
+    """The Float32 instance of the solve phase (same entry points, amgh_real = float)."""
+    global _hip_f32
+    if _hip_f32 is not None:
+        return _hip_f32
+    if not os.path.exists(HIP_F32_SO):
+        raise AMGError(f"{HIP_F32_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the solve phase has no CPU fallback)")
+    L = C.CDLL(HIP_F32_SO)
+    L.real_dtype = "float32"
+    _bind_solve_phase(L, C.c_float, COARSE_FN_F32)
+    _hip_f32 = L
     return L
 
 

@@ -22,13 +22,13 @@ struct Level {
   amgh_csr A, S, P, R;
   bool has_S = false;  // S distinct from A
   amgh_smoother_t pre{}, post{};
-  double *res = nullptr, *cx = nullptr, *cb = nullptr, *tmp = nullptr;
+  real *res = nullptr, *cx = nullptr, *cb = nullptr, *tmp = nullptr;
   amgh_csr* smat() { return has_S ? &S : &A; }
   // level-ordered cycle (x stays in the smoother's dependency-level order between pre- and post-smoother):
   // P with its rows in that order, R with its columns renumbered to it; A in that order is the schedule's own copy
   amgh_csr Pp, Rp;
   bool lo_ok = false;
-  double* lo_val = nullptr;  // S != A with the same pattern: values of A in the order of the schedule's level-ordered copy of S
+  real* lo_val = nullptr;  // S != A with the same pattern: values of A in the order of the schedule's level-ordered copy of S
   bool lo_want = false;    // between amgh_push_level_begin and _end: the level-ordered P / R are to be built
   bool nat_freed = false;  // memory-lean: the natural-order A (levels >= 1), P and R were released, the cycle runs level-ordered
 };
@@ -47,17 +47,17 @@ struct amgh_handle {
   int64_t ncoarse = -1;
   amgh_csr finalA;
   bool has_finalA = false;
-  double* coarse_op = nullptr;
+  real* coarse_op = nullptr;
   amgh_coarse_fn coarse_fn = nullptr;  // host-side pluggable coarse solver
   void* coarse_user = nullptr;
-  std::vector<double> coarse_hb, coarse_hx;
-  double* res_final = nullptr;  // res_vecs[1] when there are no levels
+  std::vector<real> coarse_hb, coarse_hx;
+  real* res_final = nullptr;  // res_vecs[1] when there are no levels
   bool finalized = false;
   // reductions / scalars
-  double* partial = nullptr;   // kRedBlocks
-  double* scal = nullptr;      // device scalars: [0] norm/dot out, [1] rho, [2] rho_prev, [3] alpha, [4] beta, [5] tmp
+  real* partial = nullptr;   // kRedBlocks
+  real* scal = nullptr;      // device scalars: [0] norm/dot out, [1] rho, [2] rho_prev, [3] alpha, [4] beta, [5] tmp
   // internal fine-level buffers for host-pointer entry points and PCG
-  double *x0 = nullptr, *b0 = nullptr, *pc_r = nullptr, *pc_c = nullptr, *pc_u = nullptr;
+  real *x0 = nullptr, *b0 = nullptr, *pc_r = nullptr, *pc_c = nullptr, *pc_u = nullptr;
   int64_t ws_bytes = 0;
   // profiling
   bool profile = false;
@@ -73,7 +73,7 @@ struct amgh_handle {
   bool use_graph = false;
   // hipGraph cache of whole cycles, keyed by the (x, b, cycle) they were captured on
   // exec == nullptr: this key has been run eagerly once (first-use allocations done), capture on the next call
-  struct CycleGraph { const double* x; const double* b; int cyc; bool xzero; hipGraphExec_t exec; };
+  struct CycleGraph { const real* x; const real* b; int cyc; bool xzero; hipGraphExec_t exec; };
   std::vector<CycleGraph> graphs;
   unsigned long long graph_epoch = 0;  // g_sched_epoch the cached graphs were captured under
 };
@@ -107,41 +107,41 @@ int prof_flush(amgh_t* h) {
   return AMGH_OK;
 }
 
-int vec_fill(amgh_t* h, double* x, int64_t n, double v) {
+int vec_fill(amgh_t* h, real* x, int64_t n, real v) {
   if (n <= 0) return AMGH_OK;
-  if (v == 0.0) { HIP_TRY(hipMemsetAsync(x, 0, sizeof(double) * n, h->stream)); return AMGH_OK; }
+  if (v == 0.0) { HIP_TRY(hipMemsetAsync(x, 0, sizeof(real) * n, h->stream)); return AMGH_OK; }
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, x, n, v);
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
 }
-int vec_copy(amgh_t* h, double* dst, const double* src, int64_t n) {
+int vec_copy(amgh_t* h, real* dst, const real* src, int64_t n) {
   if (n <= 0 || dst == src) return AMGH_OK;
-  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(real) * n, hipMemcpyDeviceToDevice, h->stream));
   return AMGH_OK;
 }
 // out_d[0] = sum x*y (op 0) or sqrt(sum x*x) (op 1)
-int vec_dot(amgh_t* h, const double* x, const double* y, int64_t n, double* out_d, int op) {
+int vec_dot(amgh_t* h, const real* x, const real* y, int64_t n, real* out_d, int op) {
   const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kThreads - 1) / kThreads));
   hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, h->stream, x, y, n, h->partial);
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, h->stream, h->partial, nb, out_d, op);
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
 }
-int vec_norm_host(amgh_t* h, const double* x, int64_t n, double* out) {
+int vec_norm_host(amgh_t* h, const real* x, int64_t n, real* out) {
   RC_TRY(vec_dot(h, x, x, n, h->scal, 1));
-  HIP_TRY(hipMemcpyAsync(out, h->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(out, h->scal, sizeof(real), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return AMGH_OK;
 }
 
-int coarse_solve(amgh_t* h, double* x, const double* b) {
+int coarse_solve(amgh_t* h, real* x, const real* b) {
   const int n = (int)h->ncoarse;
   if (n <= 0) return AMGH_OK;
   if (h->coarse_fn) {
-    HIP_TRY(hipMemcpyAsync(h->coarse_hb.data(), b, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->coarse_hb.data(), b, sizeof(real) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->coarse_fn(h->coarse_user, h->coarse_hb.data(), h->coarse_hx.data(), n) != 0) return AMGH_ESTATE;
-    HIP_TRY(hipMemcpyAsync(x, h->coarse_hx.data(), sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(x, h->coarse_hx.data(), sizeof(real) * n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return AMGH_OK;
   }
@@ -153,7 +153,7 @@ int coarse_solve(amgh_t* h, double* x, const double* b) {
 // smooth!(x, smoother, b).  `xc` is the buffer that currently holds x; Jacobi
 // sweeps ping-pong between xc and xo (swapped in place).
 // x_resident / no_scatter: see csr_gs_sweep (the level-ordered cycle keeps x in the schedule's own vector)
-int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& xo, const double* b, int ncolv = 1,
+int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, real*& xc, real*& xo, const real* b, int ncolv = 1,
            bool xzero = false, bool reuse_b = false, bool x_resident = false, bool no_scatter = false) {
   amgh_csr* M = L->smat();
   for (int it = 0; it < s.iter; ++it) {
@@ -184,11 +184,11 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, double*& xc, double*& 
   return AMGH_OK;
 }
 
-int cycle(amgh_t* h, int l, double* x, const double* b, int cyc, bool xzero);
+int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero);
 
 // __solve_next! (multilevel.jl:200-212)
 // x is the parent's freshly zeroed coarse_x (multilevel.jl:226) on the first visit, not on the second (W, F)
-int cycle_next(amgh_t* h, int l, double* x, const double* b, int cyc) {
+int cycle_next(amgh_t* h, int l, real* x, const real* b, int cyc) {
   switch (cyc) {
     case AMGH_CYCLE_V: return cycle(h, l, x, b, AMGH_CYCLE_V, true);
     case AMGH_CYCLE_W:
@@ -205,12 +205,12 @@ int cycle_next(amgh_t* h, int l, double* x, const double* b, int cyc) {
 // multilevel.jl:28-59).  The reference loops the columns inside every operator (smoother.jl:77,117); here
 // each launch covers all bs columns (one grid row / one workgroup per column): per column the arithmetic and
 // its order are those of the single-column path, so the results are bitwise the same.
-int cycle(amgh_t* h, int l, double* x, const double* b, int cyc, bool xzero) {
+int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero) {
   Level* L = h->levels[l];
   const int bs = h->nrhs;
   const int64_t n = L->n, nc = L->nc;
-  double* xc = x;
-  double* xo = L->tmp;
+  real* xc = x;
+  real* xo = L->tmp;
   // Level-ordered variant: between the two smoothers x stays in the smoother's dependency-level order (its own xp),
   // and residual / restriction / prolongation run on level-ordered copies of A, R, P (same entries in the same
   // order inside every row, so the same sums): no scatter after the pre-smoother, no gather before the post-smoother.
@@ -279,7 +279,7 @@ int cycle(amgh_t* h, int l, double* x, const double* b, int cyc, bool xzero) {
 }
 
 // one application of the hierarchy: a cycle, or the coarse solve if no levels
-int apply_once(amgh_t* h, double* x, const double* b, int cyc, bool xzero) {
+int apply_once(amgh_t* h, real* x, const real* b, int cyc, bool xzero) {
   if (h->levels.empty()) {
     ProfScope p(h, AMGH_T_COARSE, 0);
     for (int c = 0; c < h->nrhs; ++c) RC_TRY(coarse_solve(h, x + c * h->ncoarse, b + c * h->ncoarse));
@@ -293,7 +293,7 @@ int apply_once(amgh_t* h, double* x, const double* b, int cyc, bool xzero) {
 // graph takes the host launch cost off the critical path.  Falls back to eager
 // launches when profiling, with a host coarse solver, or if capture fails.
 // xzero: the caller has just zeroed x (ldiv!, the preconditioner inside PCG)
-int apply_cycle(amgh_t* h, double* x, const double* b, int cyc, bool xzero = false) {
+int apply_cycle(amgh_t* h, real* x, const real* b, int cyc, bool xzero = false) {
   if (!h->use_graph || h->profile || h->coarse_fn || h->levels.empty()) return apply_once(h, x, b, cyc, xzero);
   if (h->graph_epoch != g_sched_epoch) {  // a schedule buffer moved: the captured pointers are stale
     for (auto& g : h->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
@@ -352,13 +352,13 @@ int apply_cycle(amgh_t* h, double* x, const double* b, int cyc, bool xzero = fal
   return AMGH_OK;
 }
 
-int fine_residual(amgh_t* h, const double* x, const double* b, double* r) {
+int fine_residual(amgh_t* h, const real* x, const real* b, real* r) {
   if (h->levels.empty() && !h->has_finalA) return AMGH_ESTATE;
   const amgh_csr* A = h->levels.empty() ? &h->finalA : &h->levels[0]->A;
   RC_TRY(csr_apply(A, M_RESID, x, b, r, h->stream, h->nrhs));
   return AMGH_OK;
 }
-int fine_spmv(amgh_t* h, const double* x, double* y) {
+int fine_spmv(amgh_t* h, const real* x, real* y) {
   if (h->levels.empty()) {
     if (!h->has_finalA) return AMGH_ESTATE;
     return csr_apply(&h->finalA, M_SPMV, x, nullptr, y, h->stream);
@@ -367,15 +367,15 @@ int fine_spmv(amgh_t* h, const double* x, double* y) {
 }
 
 // _solve! (multilevel.jl:158-198) on device pointers
-int solve_dev(amgh_t* h, const double* b, double* x, int cyc, int maxiter, double abstol, double reltol,
-              int calc_res, double* hist, int* iters) {
+int solve_dev(amgh_t* h, const real* b, real* x, int cyc, int maxiter, double abstol, double reltol,
+              int calc_res, real* hist, int* iters) {
   const int64_t n = fine_n(h) * h->nrhs;  // norm(b) of an n x bs matrix is the Frobenius norm
-  double normb = 0.0;
+  real normb = 0.0;
   RC_TRY(vec_norm_host(h, b, n, &normb));
-  double normres = normb;
+  real normres = normb;
   if (normb != 0.0) abstol = std::max(reltol * normb, abstol);
   if (hist) hist[0] = normb;
-  double* res = h->levels.empty() ? h->res_final : h->levels[0]->res;
+  real* res = h->levels.empty() ? h->res_final : h->levels[0]->res;
   int itr = 1;
   while (itr <= maxiter && (!calc_res || normres > abstol)) {
     RC_TRY(apply_cycle(h, x, b, cyc));
@@ -407,19 +407,19 @@ int scal_copy(amgh_t* h, int out, int a) {
 //   c = Pl \ r ; rho_prev = rho ; rho = c.r ; beta = rho/rho_prev ; u = c + beta u
 //   c = A u ; alpha = rho / u.c ; x += alpha u ; r -= alpha c ; residual = |r|
 // stop when residual <= max(reltol*|r0|, abstol) or maxiter reached.
-int pcg_dev(amgh_t* h, const double* b, double* x, int cyc, int use_precond, int maxiter, double abstol,
-            double reltol, double* hist, int* iters) {
+int pcg_dev(amgh_t* h, const real* b, real* x, int cyc, int use_precond, int maxiter, double abstol,
+            double reltol, real* hist, int* iters) {
   const int64_t n = fine_n(h);
-  double* r = h->pc_r; double* c = h->pc_c; double* u = h->pc_u;
+  real* r = h->pc_r; real* c = h->pc_c; real* u = h->pc_u;
   RC_TRY(vec_fill(h, x, n, 0.0));
   RC_TRY(vec_fill(h, u, n, 0.0));
   RC_TRY(vec_copy(h, r, b, n));
-  double residual = 0.0;
+  real residual = 0.0;
   RC_TRY(vec_norm_host(h, r, n, &residual));
-  const double tol = std::max(reltol * residual, abstol);
+  const real tol = std::max(reltol * residual, abstol);
   if (hist) hist[0] = residual;
-  const double one = 1.0;
-  HIP_TRY(hipMemcpyAsync(h->scal + 1, &one, sizeof(double), hipMemcpyHostToDevice, h->stream));  // rho = 1
+  const real one = 1.0;
+  HIP_TRY(hipMemcpyAsync(h->scal + 1, &one, sizeof(real), hipMemcpyHostToDevice, h->stream));  // rho = 1
   int it = 0;
   while (it < maxiter && residual > tol) {
     if (use_precond) {
@@ -549,8 +549,8 @@ static void level_discard(Level* L) {
 // First half of push!(levels, Level(A, P, R, pre, post)): everything that needs A (and S) only — the uploads and the
 // smoother schedule.  A caller that produces P and R later (the setup phase: C/F splitting on the host, then
 // interpolation) can run this half on another host thread meanwhile.
-int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
-                          const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
+int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
+                          const int32_t* S_rowptr, const int32_t* S_col, const real* S_val,
                           const amgh_smoother_t* pre, const amgh_smoother_t* post) {
   if (!h || n <= 0 || !A_rowptr) return AMGH_EINVAL;
   if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
@@ -593,7 +593,7 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
         A_rowptr[n] == S_rowptr[n] && std::equal(A_rowptr, A_rowptr + n + 1, S_rowptr) &&
         std::equal(A_col, A_col + A_rowptr[n], S_col)) {
       const std::vector<int32_t>& perm = g->h_perm;
-      std::vector<double> lv((size_t)A_rowptr[n]);
+      std::vector<real> lv((size_t)A_rowptr[n]);
       std::vector<int32_t> off(n + 1, 0);
       for (int64_t p2 = 0; p2 < n; ++p2) off[p2 + 1] = off[p2] + (A_rowptr[perm[p2] + 1] - A_rowptr[perm[p2]]);
       const int T = std::max(1, std::min<int>(merge_threads(), 16));
@@ -620,8 +620,8 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
 }
 
 // Second half: P and R (natural order and, for the level-ordered cycle, permuted), then the level joins the hierarchy.
-int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const int32_t* P_col, const double* P_val,
-                        const int32_t* R_rowptr, const int32_t* R_col, const double* R_val) {
+int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const int32_t* P_col, const real* P_val,
+                        const int32_t* R_rowptr, const int32_t* R_col, const real* R_val) {
   if (!h || nc < 0 || !P_rowptr || !R_rowptr) return AMGH_EINVAL;
   if (h->finalized || !h->pending_level) return AMGH_ESTATE;
   Level* L = h->pending_level;
@@ -637,7 +637,7 @@ int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const in
     std::vector<int32_t> inv(n);
     for (int64_t p2 = 0; p2 < n; ++p2) inv[perm[p2]] = (int32_t)p2;
     std::vector<int32_t> prp(n + 1, 0), pcl(P_rowptr[n]);
-    std::vector<double> pvl(P_rowptr[n]);
+    std::vector<real> pvl(P_rowptr[n]);
     for (int64_t p2 = 0; p2 < n; ++p2) prp[p2 + 1] = prp[p2] + (P_rowptr[perm[p2] + 1] - P_rowptr[perm[p2]]);
     const int T2 = std::max(1, std::min<int>(merge_threads(), 16));
     std::vector<int32_t> rcl(R_rowptr[nc]);
@@ -687,9 +687,9 @@ int amgh_push_level_abort(amgh_t* h) {
 }
 
 int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, const int32_t* A_col,
-                    const double* A_val, const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
-                    const int32_t* P_rowptr, const int32_t* P_col, const double* P_val, const int32_t* R_rowptr,
-                    const int32_t* R_col, const double* R_val, const amgh_smoother_t* pre,
+                    const real* A_val, const int32_t* S_rowptr, const int32_t* S_col, const real* S_val,
+                    const int32_t* P_rowptr, const int32_t* P_col, const real* P_val, const int32_t* R_rowptr,
+                    const int32_t* R_col, const real* R_val, const amgh_smoother_t* pre,
                     const amgh_smoother_t* post) {
   if (!h || n <= 0 || nc < 0 || !A_rowptr || !P_rowptr || !R_rowptr) return AMGH_EINVAL;
   if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
@@ -702,8 +702,8 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc, const int32_t* A_rowptr, c
   return rc;
 }
 
-int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
-                    const double* dense_op) {
+int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
+                    const real* dense_op) {
   if (!h || n < 0 || !dense_op) return AMGH_EINVAL;
   if (h->finalized || h->ncoarse >= 0 || h->pending_level) return AMGH_ESTATE;
   if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
@@ -718,7 +718,7 @@ int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t
   return AMGH_OK;
 }
 
-int amgh_set_coarse_host(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
+int amgh_set_coarse_host(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
                          amgh_coarse_fn fn, void* user) {
   if (!h || n < 0 || !fn) return AMGH_EINVAL;
   if (h->finalized || h->ncoarse >= 0 || h->pending_level) return AMGH_ESTATE;
@@ -857,28 +857,28 @@ static int ensure_pcg_bufs(amgh_t* h) {
   return AMGH_OK;
 }
 
-int amgh_solve_d(amgh_t* h, const double* b_d, double* x_d, int cycle_, int maxiter, double abstol, double reltol,
-                 int calculate_residual, double* resid_hist, int* iters) {
+int amgh_solve_d(amgh_t* h, const real* b_d, real* x_d, int cycle_, int maxiter, double abstol, double reltol,
+                 int calculate_residual, real* resid_hist, int* iters) {
   RC_TRY(check_ready(h));
   if (!b_d || !x_d || cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   return solve_dev(h, b_d, x_d, cycle_, maxiter, abstol, reltol, calculate_residual, resid_hist, iters);
 }
 
-int amgh_solve(amgh_t* h, const double* b, double* x, int cycle_, int maxiter, double abstol, double reltol,
-               int calculate_residual, double* resid_hist, int* iters) {
+int amgh_solve(amgh_t* h, const real* b, real* x, int cycle_, int maxiter, double abstol, double reltol,
+               int calculate_residual, real* resid_hist, int* iters) {
   RC_TRY(check_ready(h));
   if (!b || !x || cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   const int64_t n = fine_n(h) * h->nrhs;
-  HIP_TRY(hipMemcpyAsync(h->b0, b, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->x0, x, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->b0, b, sizeof(real) * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->x0, x, sizeof(real) * n, hipMemcpyHostToDevice, h->stream));
   RC_TRY(solve_dev(h, h->b0, h->x0, cycle_, maxiter, abstol, reltol, calculate_residual, resid_hist, iters));
-  HIP_TRY(hipMemcpy(x, h->x0, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(x, h->x0, sizeof(real) * n, hipMemcpyDeviceToHost));
   return AMGH_OK;
 }
 
-int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle_) {
+int amgh_precond_apply_d(amgh_t* h, const real* r_d, real* z_d, int cycle_) {
   RC_TRY(check_ready(h));
   if (!r_d || !z_d || cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
@@ -886,20 +886,20 @@ int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle_) 
   return apply_cycle(h, z_d, r_d, cycle_, true);
 }
 
-int amgh_precond_apply(amgh_t* h, const double* r, double* z, int cycle_) {
+int amgh_precond_apply(amgh_t* h, const real* r, real* z, int cycle_) {
   RC_TRY(check_ready(h));
   if (!r || !z) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   const int64_t n = fine_n(h) * h->nrhs;
-  HIP_TRY(hipMemcpyAsync(h->b0, r, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->b0, r, sizeof(real) * n, hipMemcpyHostToDevice, h->stream));
   RC_TRY(amgh_precond_apply_d(h, h->b0, h->x0, cycle_));
   HIP_TRY(hipStreamSynchronize(h->stream));
   RC_TRY(prof_flush(h));
-  HIP_TRY(hipMemcpy(z, h->x0, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(z, h->x0, sizeof(real) * n, hipMemcpyDeviceToHost));
   return AMGH_OK;
 }
 
-int amgh_cycle_d(amgh_t* h, int level, double* x_d, const double* b_d, int cycle_) {
+int amgh_cycle_d(amgh_t* h, int level, real* x_d, const real* b_d, int cycle_) {
   RC_TRY(check_ready(h));
   if (!x_d || !b_d || cycle_ < 0 || cycle_ > 2 || level < 0 || level > (int)h->levels.size()) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
@@ -915,8 +915,8 @@ int amgh_set_stream(amgh_t* h, void* stream) {
   return AMGH_OK;
 }
 
-int amgh_pcg_d(amgh_t* h, const double* b_d, double* x_d, int cycle_, int use_precond, int maxiter, double abstol,
-               double reltol, double* resid_hist, int* iters) {
+int amgh_pcg_d(amgh_t* h, const real* b_d, real* x_d, int cycle_, int use_precond, int maxiter, double abstol,
+               double reltol, real* resid_hist, int* iters) {
   RC_TRY(check_ready(h));
   if (!b_d || !x_d || cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
   if (h->nrhs != 1) return AMGH_EUNSUPPORTED;  // IterativeSolvers' cg takes vectors
@@ -925,15 +925,15 @@ int amgh_pcg_d(amgh_t* h, const double* b_d, double* x_d, int cycle_, int use_pr
   return pcg_dev(h, b_d, x_d, cycle_, use_precond, maxiter, abstol, reltol, resid_hist, iters);
 }
 
-int amgh_pcg(amgh_t* h, const double* b, double* x, int cycle_, int use_precond, int maxiter, double abstol,
-             double reltol, double* resid_hist, int* iters) {
+int amgh_pcg(amgh_t* h, const real* b, real* x, int cycle_, int use_precond, int maxiter, double abstol,
+             double reltol, real* resid_hist, int* iters) {
   RC_TRY(check_ready(h));
   if (!b || !x) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   const int64_t n = fine_n(h);
-  HIP_TRY(hipMemcpyAsync(h->b0, b, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->b0, b, sizeof(real) * n, hipMemcpyHostToDevice, h->stream));
   RC_TRY(amgh_pcg_d(h, h->b0, h->x0, cycle_, use_precond, maxiter, abstol, reltol, resid_hist, iters));
-  HIP_TRY(hipMemcpy(x, h->x0, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(x, h->x0, sizeof(real) * n, hipMemcpyDeviceToHost));
   return AMGH_OK;
 }
 
@@ -950,7 +950,7 @@ static amgh_csr* level_op(amgh_t* h, int level, int which) {
   return (op && op->rowptr) ? op : nullptr;  // (memory-lean hierarchies have released some natural-order operators)
 }
 
-int amgh_level_spmv_d(amgh_t* h, int level, int which, const double* x_d, double* y_d) {
+int amgh_level_spmv_d(amgh_t* h, int level, int which, const real* x_d, real* y_d) {
   RC_TRY(check_ready(h));
   amgh_csr* op = level_op(h, level, which);
   if (!op || !x_d || !y_d) return AMGH_EINVAL;
@@ -960,22 +960,22 @@ int amgh_level_spmv_d(amgh_t* h, int level, int which, const double* x_d, double
   return AMGH_OK;
 }
 
-int amgh_level_spmv(amgh_t* h, int level, int which, const double* x, double* y) {
+int amgh_level_spmv(amgh_t* h, int level, int which, const real* x, real* y) {
   RC_TRY(check_ready(h));
   amgh_csr* op = level_op(h, level, which);
   if (!op || !x || !y) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
-  double *xd = nullptr, *yd = nullptr;
+  real *xd = nullptr, *yd = nullptr;
   RC_TRY(dev_upload(&xd, x, op->ncols));
   int rc = dev_alloc(&yd, op->nrows);
   if (rc == AMGH_OK) rc = csr_apply(op, M_SPMV, xd, nullptr, yd, h->stream);
   if (rc == AMGH_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = -1000 - (int)hipGetLastError();
-  if (rc == AMGH_OK && hipMemcpy(y, yd, sizeof(double) * op->nrows, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
+  if (rc == AMGH_OK && hipMemcpy(y, yd, sizeof(real) * op->nrows, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
   hipFree(xd); hipFree(yd);
   return rc;
 }
 
-int amgh_level_residual_d(amgh_t* h, int level, const double* x_d, const double* b_d, double* r_d) {
+int amgh_level_residual_d(amgh_t* h, int level, const real* x_d, const real* b_d, real* r_d) {
   RC_TRY(check_ready(h));
   amgh_csr* op = level_op(h, level, AMGH_OP_A);
   if (!op || !x_d || !b_d || !r_d) return AMGH_EINVAL;
@@ -985,18 +985,18 @@ int amgh_level_residual_d(amgh_t* h, int level, const double* x_d, const double*
   return AMGH_OK;
 }
 
-static int level_smooth_enqueue(amgh_t* h, int level, int post, double* x_d, const double* b_d) {
+static int level_smooth_enqueue(amgh_t* h, int level, int post, real* x_d, const real* b_d) {
   Level* L = h->levels[level];
   const amgh_smoother_t& s = post ? L->post : L->pre;
-  double* xc = x_d;
-  double* xo = L->tmp;
+  real* xc = x_d;
+  real* xo = L->tmp;
   if (s.kind == AMGH_SMOOTH_JACOBI && !xo) return AMGH_ESTATE;
   RC_TRY(smooth(h, L, s, xc, xo, b_d));
   if (xc != x_d) RC_TRY(vec_copy(h, x_d, xc, L->n));
   return AMGH_OK;
 }
 
-int amgh_level_smooth_d(amgh_t* h, int level, int post, double* x_d, const double* b_d) {
+int amgh_level_smooth_d(amgh_t* h, int level, int post, real* x_d, const real* b_d) {
   RC_TRY(check_ready(h));
   if (level < 0 || level >= (int)h->levels.size() || !x_d || !b_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
@@ -1005,24 +1005,24 @@ int amgh_level_smooth_d(amgh_t* h, int level, int post, double* x_d, const doubl
   return AMGH_OK;
 }
 
-int amgh_level_smooth(amgh_t* h, int level, int post, double* x, const double* b) {
+int amgh_level_smooth(amgh_t* h, int level, int post, real* x, const real* b) {
   RC_TRY(check_ready(h));
   if (level < 0 || level >= (int)h->levels.size() || !x || !b) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   const int64_t n = h->levels[level]->n;
-  double *xd = nullptr, *bd = nullptr;
+  real *xd = nullptr, *bd = nullptr;
   RC_TRY(dev_upload(&xd, x, n));
   int rc = dev_upload(&bd, b, n);
   if (rc == AMGH_OK) rc = level_smooth_enqueue(h, level, post, xd, bd);
   if (rc == AMGH_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = -1001;
-  if (rc == AMGH_OK && hipMemcpy(x, xd, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
+  if (rc == AMGH_OK && hipMemcpy(x, xd, sizeof(real) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
   hipFree(xd); hipFree(bd);
   return rc;
 }
 
 // ---- stand-alone operators ------------------------------------------------
 int amgh_csr_create(amgh_csr_t** opp, int device, int64_t nrows, int64_t ncols, const int32_t* rowptr,
-                    const int32_t* col, const double* val) {
+                    const int32_t* col, const real* val) {
   if (!opp) return AMGH_EINVAL;
   *opp = nullptr;
   int ndev = 0;
@@ -1049,34 +1049,34 @@ int amgh_csr_prepare(amgh_csr_t* op, int jacobi, int gs) {
   HIP_TRY(hipDeviceSynchronize());
   return AMGH_OK;
 }
-int amgh_csr_spmv_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream) {
+int amgh_csr_spmv_d(amgh_csr_t* op, const real* x_d, real* y_d, void* stream) {
   if (!op || !x_d || !y_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(op->device));
   return csr_apply(op, M_SPMV, x_d, nullptr, y_d, (hipStream_t)stream);
 }
-int amgh_csr_residual_d(amgh_csr_t* op, const double* x_d, const double* b_d, double* r_d, void* stream) {
+int amgh_csr_residual_d(amgh_csr_t* op, const real* x_d, const real* b_d, real* r_d, void* stream) {
   if (!op || !x_d || !b_d || !r_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(op->device));
   return csr_apply(op, M_RESID, x_d, b_d, r_d, (hipStream_t)stream);
 }
-int amgh_csr_spmv_add_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream) {
+int amgh_csr_spmv_add_d(amgh_csr_t* op, const real* x_d, real* y_d, void* stream) {
   if (!op || !x_d || !y_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(op->device));
   return csr_apply(op, M_ADD, x_d, nullptr, y_d, (hipStream_t)stream);
 }
-int amgh_csr_jacobi_d(amgh_csr_t* op, double omega, const double* xin_d, const double* b_d, double* xout_d,
+int amgh_csr_jacobi_d(amgh_csr_t* op, double omega, const real* xin_d, const real* b_d, real* xout_d,
                       void* stream) {
   if (!op || !xin_d || !b_d || !xout_d || xin_d == xout_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(op->device));
   return csr_jacobi(op, omega, xin_d, b_d, xout_d, (hipStream_t)stream);
 }
-int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d, const double* b_d,
+int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, real* x_d, const real* b_d,
                   void* stream) {
   if (!op || !x_d || !b_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(op->device));
   return csr_gs_sweep(op, backward != 0, is_sor != 0, omega, x_d, b_d, (hipStream_t)stream);
 }
-int amgh_csr_gs_ex_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d, const double* b_d,
+int amgh_csr_gs_ex_d(amgh_csr_t* op, int backward, double omega, int is_sor, real* x_d, const real* b_d,
                      void* stream, int flags) {
   if (!op || !x_d || !b_d || (flags & ~AMGH_GS_REUSE_B)) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(op->device));
@@ -1084,7 +1084,7 @@ int amgh_csr_gs_ex_d(amgh_csr_t* op, int backward, double omega, int is_sor, dou
                       (flags & AMGH_GS_REUSE_B) != 0);
 }
 
-int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const double* src_d, double* dst_d, void* stream) {
+int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const real* src_d, real* dst_d, void* stream) {
   if (n < 0 || (n > 0 && (!idx_d || !src_d || !dst_d)) || n >= INT32_MAX) return AMGH_EINVAL;
   if (n == 0) return AMGH_OK;
   HIP_TRY(hipSetDevice(device));
@@ -1094,7 +1094,7 @@ int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const double* src
   return AMGH_OK;
 }
 
-int amgh_dot_d(int device, int64_t n, const double* x_d, const double* y_d, double* scratch_d, double* out,
+int amgh_dot_d(int device, int64_t n, const real* x_d, const real* y_d, real* scratch_d, real* out,
                void* stream) {
   if (n < 0 || !scratch_d || !out || (n > 0 && (!x_d || !y_d))) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(device));
@@ -1103,7 +1103,7 @@ int amgh_dot_d(int device, int64_t n, const double* x_d, const double* y_d, doub
   hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, st, x_d, y_d, n, scratch_d + 1);
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, st, scratch_d + 1, nb, scratch_d, 0);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(out, scratch_d, sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(out, scratch_d, sizeof(real), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return AMGH_OK;
 }
@@ -1161,14 +1161,14 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
   HIP_TRY(hipSetDevice(h->device));
   amgh_csr* op = level_op(h, level, which <= AMGH_OP_R ? which : AMGH_OP_A);
   if (!op) return AMGH_EINVAL;
-  double *x = nullptr, *y = nullptr, *b = nullptr;
+  real *x = nullptr, *y = nullptr, *b = nullptr;
   const int64_t nx = std::max(op->ncols, op->nrows);
   RC_TRY(dev_alloc(&x, nx));
   RC_TRY(dev_alloc(&y, nx));
   RC_TRY(dev_alloc(&b, nx));
   // deterministic non-trivial contents (a zero fill would flatter DVFS)
   {
-    std::vector<double> hx(nx);
+    std::vector<real> hx(nx);
     uint64_t s = 0x9E3779B97F4A7C15ull;
     for (int64_t i = 0; i < nx; ++i) {
       s += 0x9E3779B97F4A7C15ull;
@@ -1176,11 +1176,11 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
       z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
       z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
       z ^= z >> 31;
-      hx[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+      hx[i] = (real)(z >> 11) * (1.0 / 9007199254740992.0);
     }
-    hipMemcpy(x, hx.data(), sizeof(double) * nx, hipMemcpyHostToDevice);
-    hipMemcpy(b, hx.data(), sizeof(double) * nx, hipMemcpyHostToDevice);
-    hipMemcpy(y, hx.data(), sizeof(double) * nx, hipMemcpyHostToDevice);
+    hipMemcpy(x, hx.data(), sizeof(real) * nx, hipMemcpyHostToDevice);
+    hipMemcpy(b, hx.data(), sizeof(real) * nx, hipMemcpyHostToDevice);
+    hipMemcpy(y, hx.data(), sizeof(real) * nx, hipMemcpyHostToDevice);
   }
   int rc = AMGH_OK;
   auto run = [&]() -> int {
@@ -1212,7 +1212,7 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
 // x: ncols entries (in/out, columns >= nrows are frozen halo values), b: nrows entries.  CPU tests compare it with
 // the scalar lexicographic sweep.  Returns the number of groups, or a negative error code.
 int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
-                                 const double* val, int m, int backward, double omega, double* x, const double* b) {
+                                 const real* val, int m, int backward, double omega, real* x, const real* b) {
   if (nrows < 0 || ncols < nrows || !rowptr || m < 1 || !x || !b || omega == 0.0) return AMGH_EINVAL;
   const int64_t n = nrows;
   HostLevelCsr base;
@@ -1221,19 +1221,19 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
   // SOR with factor omega = the triangular solve with diagonal D / omega and the diagonal term
   // ((1 - omega) / omega) D x_old on the right-hand side; omega = 1 is Gauss-Seidel
   HostLevelCsr scaled = base;
-  for (double& dd : scaled.pdiag) dd /= omega;
-  const double shift = (1.0 - omega) / omega;
+  for (real& dd : scaled.pdiag) dd /= omega;
+  const real shift = (1.0 - omega) / omega;
   MergeResult R = merge_build(scaled, ncols, m, backward != 0);
   if (R.max_row > kBigSlot) return AMGH_EUNSUPPORTED;
   const HostLevelCsr& S = R.sys;
-  std::vector<double> ext(ncols + n);
+  std::vector<real> ext(ncols + n);
   for (int64_t c = 0; c < ncols; ++c) ext[c] = c < n ? x[perm[c]] : x[c];
   // pre-pass: s = b - T x over the triangle this direction does not substitute over (+ halo columns, + diagonal term)
   std::vector<int32_t> lev_of(n);
   for (int l = 0; l < base.nlev; ++l)
     for (int32_t p = base.lvl_ptr[l]; p < base.lvl_ptr[l + 1]; ++p) lev_of[p] = l;
   for (int64_t p = 0; p < n; ++p) {
-    double s = b[perm[p]];
+    real s = b[perm[p]];
     for (int32_t j = base.prow[p]; j < base.prow[p + 1]; ++j) {
       const int32_t c = base.pcol[j];
       if (c == p) continue;
@@ -1246,9 +1246,9 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
   // groups in sweep order; rows of a group only read earlier groups and s, so their order does not matter
   for (int k = 0; k < S.nlev; ++k) {
     const int q = backward ? S.nlev - 1 - k : k;
-    std::vector<double> xn(S.lvl_ptr[q + 1] - S.lvl_ptr[q]);
+    std::vector<real> xn(S.lvl_ptr[q + 1] - S.lvl_ptr[q]);
     for (int32_t p = S.lvl_ptr[q]; p < S.lvl_ptr[q + 1]; ++p) {
-      double acc = 0.0;
+      real acc = 0.0;
       for (int32_t j = S.prow[p]; j < S.prow[p + 1]; ++j) acc += S.pval[j] * ext[S.pcol[j]];
       xn[p - S.lvl_ptr[q]] = S.pdiag[p] != 0.0 ? (ext[ncols + p] - acc) / S.pdiag[p] : ext[p];
     }
@@ -1317,5 +1317,13 @@ int amgh_set_use_graph(amgh_t* h, int on) {
 
 }  // extern "C"
 
+// the row-sharded cycle and the GPU half of the setup are Float64 only: the Float32 instance (-DAMGH_REAL=float
+// -DAMGH_SOLVE_ONLY) carries the solve-phase handle and the stand-alone operators
+#ifndef AMGH_SOLVE_ONLY
 #include "amghip_dist.hpp"
+#else
+const char* amgh_rccl_error_string(int) { return "(no row-sharded path in this instance)"; }
+#endif
+#ifndef AMGH_SOLVE_ONLY
 #include "amghip_setup.hpp"
+#endif

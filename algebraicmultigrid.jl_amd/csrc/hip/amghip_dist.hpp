@@ -38,10 +38,10 @@ struct Transport {
   // data path: send sendbuf[send[p].off .. +cnt) to peer p, receive recv[p].cnt doubles from p into recvbuf + recv[p].off.
   // `st` is the stream the packed send buffer was produced on and on which the received data will be consumed:
   // begin() may return before the data has arrived, finish() makes `st` wait for it.
-  virtual int exchange_begin(const double* sendbuf, const std::vector<PeerSpan>& send, double* recvbuf,
+  virtual int exchange_begin(const real* sendbuf, const std::vector<PeerSpan>& send, real* recvbuf,
                              const std::vector<PeerSpan>& recv, hipStream_t st) = 0;
   virtual int exchange_finish(hipStream_t st) = 0;
-  virtual int allreduce(double* v, int n, bool max_op) = 0;  // host values, in place
+  virtual int allreduce(real* v, int n, bool max_op) = 0;  // host values, in place
   virtual int barrier() = 0;
 };
 
@@ -106,7 +106,7 @@ struct RcclTransport : Transport {
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   int64_t* d_i64 = nullptr;      // setup scratch
   int64_t d_i64_cap = 0;
-  double* d_scal = nullptr;
+  real* d_scal = nullptr;
   ~RcclTransport() override {
     if (comm && api) api->CommDestroy(comm);
     if (cs) hipStreamDestroy(cs);
@@ -156,7 +156,7 @@ struct RcclTransport : Transport {
     for (int p = 0; p < nranks; ++p) all[p].assign(flat.begin() + (size_t)p * mx, flat.begin() + (size_t)p * mx + counts[p]);
     return AMGH_OK;
   }
-  int exchange_begin(const double* sendbuf, const std::vector<PeerSpan>& send, double* recvbuf,
+  int exchange_begin(const real* sendbuf, const std::vector<PeerSpan>& send, real* recvbuf,
                      const std::vector<PeerSpan>& recv, hipStream_t st) override {
     HIP_TRY(hipEventRecord(ev_ready, st));
     HIP_TRY(hipStreamWaitEvent(cs, ev_ready, 0));
@@ -174,7 +174,7 @@ struct RcclTransport : Transport {
     HIP_TRY(hipStreamWaitEvent(st, ev_done, 0));
     return AMGH_OK;
   }
-  int allreduce(double* v, int n, bool max_op) override {
+  int allreduce(real* v, int n, bool max_op) override {
     if (n > 64) return AMGH_EINVAL;
     HIP_TRY(hipMemcpyAsync(d_scal, v, 8 * n, hipMemcpyHostToDevice, cs));
     NCCL_TRY(api->AllReduce(d_scal, d_scal, (size_t)n, ncclDouble, max_op ? ncclMax : ncclSum, comm, cs));
@@ -183,7 +183,7 @@ struct RcclTransport : Transport {
     return AMGH_OK;
   }
   int barrier() override {
-    double z = 0.0;
+    real z = 0.0;
     return allreduce(&z, 1, false);
   }
 };
@@ -199,11 +199,11 @@ struct amgh_local_group {
   uint64_t gen = 0;
   bool broken = false;
   // published per rank for the current collective
-  std::vector<const double*> sendbuf;
+  std::vector<const real*> sendbuf;
   std::vector<const std::vector<PeerSpan>*> sendspans;
   std::vector<int> device;
   std::vector<const std::vector<int64_t>*> lists;
-  std::vector<std::vector<double>> vals;
+  std::vector<std::vector<real>> vals;
   // returns false when the group was aborted (a rank failed): nobody hangs
   bool wait() {
     std::unique_lock<std::mutex> lk(mu);
@@ -233,7 +233,7 @@ struct LocalTransport : Transport {
     if (!g->wait()) return AMGH_ESTATE;
     return AMGH_OK;
   }
-  int exchange_begin(const double* sendbuf, const std::vector<PeerSpan>& send, double* recvbuf,
+  int exchange_begin(const real* sendbuf, const std::vector<PeerSpan>& send, real* recvbuf,
                      const std::vector<PeerSpan>& recv, hipStream_t st) override {
     if (hipStreamSynchronize(st) != hipSuccess) { g->abort(); return AMGH_ESTATE; }  // my packed entries are complete
     g->sendbuf[rank] = sendbuf;
@@ -244,7 +244,7 @@ struct LocalTransport : Transport {
       if (p == rank || recv[p].cnt <= 0) continue;
       const PeerSpan& sp = (*g->sendspans[p])[rank];
       if (sp.cnt != recv[p].cnt) { g->abort(); return AMGH_ESTATE; }
-      const double* src = g->sendbuf[p] + sp.off;
+      const real* src = g->sendbuf[p] + sp.off;
       hipError_t e = g->device[p] == device
                          ? hipMemcpyAsync(recvbuf + recv[p].off, src, 8 * sp.cnt, hipMemcpyDeviceToDevice, st)
                          : hipMemcpyPeerAsync(recvbuf + recv[p].off, device, src, g->device[p], 8 * sp.cnt, st);
@@ -255,11 +255,11 @@ struct LocalTransport : Transport {
     return AMGH_OK;
   }
   int exchange_finish(hipStream_t) override { return AMGH_OK; }
-  int allreduce(double* v, int n, bool max_op) override {
+  int allreduce(real* v, int n, bool max_op) override {
     g->vals[rank].assign(v, v + n);
     if (!g->wait()) return AMGH_ESTATE;
     for (int i = 0; i < n; ++i) {
-      double acc = g->vals[0][i];  // rank order: every rank computes the same bits
+      real acc = g->vals[0][i];  // rank order: every rank computes the same bits
       for (int p = 1; p < nranks; ++p) acc = max_op ? std::max(acc, g->vals[p][i]) : acc + g->vals[p][i];
       v[i] = acc;
     }
@@ -277,7 +277,7 @@ struct VecPlan {
   std::vector<PeerSpan> send;        // per peer: span of the packed send buffer
   int32_t* d_send_idx = nullptr;     // local indices gathered into the send buffer (all peers back to back)
   int64_t nsend = 0;
-  double* d_sendbuf = nullptr;
+  real* d_sendbuf = nullptr;
   bool any = false;                  // any rank moves anything (same decision everywhere)
   int64_t nloc() const { return r1 - r0; }
   int64_t nhalo() const { return (int64_t)halo.size(); }
@@ -293,7 +293,7 @@ struct DistOp {
 
 struct HostBlock {  // local rows with GLOBAL column indices, kept until finalize
   std::vector<int32_t> rowptr, col;
-  std::vector<double> val;
+  std::vector<real> val;
   int64_t nrows = 0;
   bool present = false;
 };
@@ -304,7 +304,7 @@ struct DistLevel {
   HostBlock hA, hS, hP, hR;
   DistOp A, S, P, R;
   amgh_smoother_t pre{}, post{};
-  double *x = nullptr, *b = nullptr, *res = nullptr, *tmp = nullptr;  // x: [local | halo], res: [local | halo of R's input]
+  real *x = nullptr, *b = nullptr, *res = nullptr, *tmp = nullptr;  // x: [local | halo], res: [local | halo of R's input]
   VecPlan rplan;                       // halo plan of res (read by R)
   DistOp* smat() { return S.present ? &S : &A; }
 };
@@ -322,10 +322,10 @@ struct amgh_dist {
   hipStream_t stream = nullptr;
   std::vector<DistLevel*> levels;
   std::vector<VecPlan> xplan;          // one per sharded level + one for the first collapsed level (read by the last P)
-  double *xt = nullptr, *bt = nullptr; // vectors of the first collapsed level: [all of it on the owner | halo elsewhere]
+  real *xt = nullptr, *bt = nullptr; // vectors of the first collapsed level: [all of it on the owner | halo elsewhere]
   amgh_t* tail = nullptr;              // the collapsed levels (on the rank that owns them), not owned
   bool finalized = false;
-  double *partial = nullptr, *scal = nullptr;
+  real *partial = nullptr, *scal = nullptr;
   int64_t ex_count = 0, ex_bytes = 0;  // halo exchanges / bytes sent by this rank since the last reset
   int overlap = 1;
 };
@@ -406,7 +406,7 @@ int block_upload(amgh_dist* d, DistOp& dop, HostBlock& hb, const VecPlan& pl) {
   return AMGH_OK;
 }
 
-int take_block(HostBlock& hb, int64_t nrows, const int32_t* rowptr, const int32_t* col, const double* val) {
+int take_block(HostBlock& hb, int64_t nrows, const int32_t* rowptr, const int32_t* col, const real* val) {
   if (!rowptr) return AMGH_OK;
   if (rowptr[0] != 0) return AMGH_EINVAL;
   const int64_t nnz = rowptr[nrows];
@@ -420,10 +420,10 @@ int take_block(HostBlock& hb, int64_t nrows, const int32_t* rowptr, const int32_
 }
 
 // ---- data path ---------------------------------------------------------------------------------------------------
-int halo_begin(amgh_dist* d, VecPlan& pl, double* vec) {
+int halo_begin(amgh_dist* d, VecPlan& pl, real* vec) {
   if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
   if (pl.nsend > 0) {
-    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(pl.nsend)), dim3(256), 0, d->stream, (const double*)vec,
+    hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(pl.nsend)), dim3(256), 0, d->stream, (const real*)vec,
                        (const int32_t*)pl.d_send_idx, pl.d_sendbuf, (int)pl.nsend, (int64_t)0, (int64_t)0);
     HIP_TRY(hipGetLastError());
   }
@@ -435,12 +435,12 @@ int halo_finish(amgh_dist* d, VecPlan& pl) {
   if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
   return d->tr->exchange_finish(d->stream);
 }
-int halo_exchange(amgh_dist* d, VecPlan& pl, double* vec) {
+int halo_exchange(amgh_dist* d, VecPlan& pl, real* vec) {
   RC_TRY(halo_begin(d, pl, vec));
   return halo_finish(d, pl);
 }
 
-int rows_apply(const amgh_csr* op, int mode, const double* x, const double* b, double* y, double omega, int32_t ra,
+int rows_apply(const amgh_csr* op, int mode, const real* x, const real* b, real* y, real omega, int32_t ra,
                int32_t rb, hipStream_t st) {
   if (rb <= ra) return AMGH_OK;
   StreamArgs a{};
@@ -459,7 +459,7 @@ int rows_apply(const amgh_csr* op, int mode, const double* x, const double* b, d
 
 // y = op(vec) with the halo of vec exchanged first; interior rows run while the halo is in flight when the transport
 // is asynchronous and the block is big enough for three launches to pay
-int dist_apply(amgh_dist* d, DistOp& dop, int mode, VecPlan& pl, double* vec, const double* b, double* y, double omega,
+int dist_apply(amgh_dist* d, DistOp& dop, int mode, VecPlan& pl, real* vec, const real* b, real* y, real omega,
                bool skip_exchange = false) {
   const amgh_csr* op = &dop.op;
   const int32_t n = (int32_t)op->nrows;
@@ -530,8 +530,8 @@ int dist_cycle(amgh_dist* d, int l, int cyc, bool xzero) {
   DistLevel* L = d->levels[l];
   VecPlan& xp = d->xplan[l];
   VecPlan& xpc = d->xplan[l + 1];
-  double* xc = l + 1 == lc ? d->xt : d->levels[l + 1]->x;
-  double* bc = l + 1 == lc ? d->bt : d->levels[l + 1]->b;
+  real* xc = l + 1 == lc ? d->xt : d->levels[l + 1]->x;
+  real* bc = l + 1 == lc ? d->bt : d->levels[l + 1]->b;
   bool b_kept = false;
   RC_TRY(dist_smooth(d, l, L->pre, xzero, &b_kept));
   RC_TRY(dist_apply(d, L->A, M_RESID, xp, L->x, L->b, L->res, 0.0));                                // res = b - A x
@@ -553,12 +553,12 @@ int dist_apply_cycle(amgh_dist* d, int cyc, bool xzero) {
   return dist_cycle(d, 0, cyc, xzero);
 }
 
-double* dist_x0(amgh_dist* d) { return d->levels.empty() ? d->xt : d->levels[0]->x; }
-double* dist_b0(amgh_dist* d) { return d->levels.empty() ? d->bt : d->levels[0]->b; }
+real* dist_x0(amgh_dist* d) { return d->levels.empty() ? d->xt : d->levels[0]->x; }
+real* dist_b0(amgh_dist* d) { return d->levels.empty() ? d->bt : d->levels[0]->b; }
 
 // sum over all ranks of x . y over the local entries (host result, same bits on every rank)
-int dist_dot(amgh_dist* d, const double* x, const double* y, int64_t n, double* out) {
-  double v = 0.0;
+int dist_dot(amgh_dist* d, const real* x, const real* y, int64_t n, real* out) {
+  real v = 0.0;
   if (n > 0) {
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kThreads - 1) / kThreads));
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, d->stream, x, y, n, d->partial);
@@ -573,13 +573,13 @@ int dist_dot(amgh_dist* d, const double* x, const double* y, int64_t n, double* 
 }
 
 // || b - A x || over all ranks (multilevel.jl:188-190); res of level 0 is the scratch, as in the reference
-int dist_resnorm(amgh_dist* d, double* out) {
-  double s = 0.0;
+int dist_resnorm(amgh_dist* d, real* out) {
+  real s = 0.0;
   if (d->levels.empty()) {
-    double v = 0.0;
+    real v = 0.0;
     if (d->tail) {
       amgh_t* h = d->tail;
-      double* res = h->levels.empty() ? h->res_final : h->levels[0]->res;
+      real* res = h->levels.empty() ? h->res_final : h->levels[0]->res;
       RC_TRY(fine_residual(h, d->xt, d->bt, res));
       RC_TRY(vec_dot(h, res, res, fine_n(h), h->scal, 0));
       HIP_TRY(hipMemcpyAsync(&v, h->scal, 8, hipMemcpyDeviceToHost, h->stream));
@@ -702,10 +702,10 @@ void amgh_dist_destroy(amgh_dist_t* d) {
 }
 
 int amgh_dist_push_level(amgh_dist_t* d, int64_t n_global, int64_t nc_global, const int64_t* row_cuts,
-                         const int64_t* crow_cuts, const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
-                         const int32_t* S_rowptr, const int32_t* S_col, const double* S_val, const int32_t* P_rowptr,
-                         const int32_t* P_col, const double* P_val, const int32_t* R_rowptr, const int32_t* R_col,
-                         const double* R_val, const amgh_smoother_t* pre, const amgh_smoother_t* post) {
+                         const int64_t* crow_cuts, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
+                         const int32_t* S_rowptr, const int32_t* S_col, const real* S_val, const int32_t* P_rowptr,
+                         const int32_t* P_col, const real* P_val, const int32_t* R_rowptr, const int32_t* R_col,
+                         const real* R_val, const amgh_smoother_t* pre, const amgh_smoother_t* post) {
   if (!d || !row_cuts || !crow_cuts || !A_rowptr || !P_rowptr || !R_rowptr || n_global <= 0 || nc_global < 0)
     return AMGH_EINVAL;
   if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
@@ -757,8 +757,8 @@ int amgh_dist_finalize(amgh_dist_t* d) {
   std::vector<int64_t> tcuts;
   if (lc > 0) tcuts = d->levels.back()->ccuts;
   else {
-    double nt = d->tail ? (double)fine_n(d->tail) : 0.0;
-    std::vector<double> v(N, 0.0);
+    real nt = d->tail ? (real)fine_n(d->tail) : 0.0;
+    std::vector<real> v(N, 0.0);
     v[me] = nt;
     RC_TRY(tr->allreduce(v.data(), N, false));
     tcuts.assign(N + 1, 0);
@@ -767,7 +767,7 @@ int amgh_dist_finalize(amgh_dist_t* d) {
   {
     const int64_t nt = tcuts[me + 1] - tcuts[me];
     const bool owner_ok = nt == 0 ? true : (d->tail && fine_n(d->tail) == nt && nt == tcuts[N]);
-    double bad = owner_ok ? 0.0 : 1.0;
+    real bad = owner_ok ? 0.0 : 1.0;
     RC_TRY(tr->allreduce(&bad, 1, true));
     if (bad != 0.0) DIST_EINVAL("the collapsed levels must live on exactly one rank, which passes the tail");
   }
@@ -858,7 +858,7 @@ int amgh_dist_plan_info(const amgh_dist_t* d, int level, int64_t* out_counts, in
 
 // ldiv!(x, p, b) on the sharded hierarchy: r_loc_d / z_loc_d hold this rank's rows of level 0 (device pointers).
 // Enqueues on the handle's stream; amgh_dist_sync waits for it.
-int amgh_dist_precond_apply_d(amgh_dist_t* d, const double* r_loc_d, double* z_loc_d, int cycle_) {
+int amgh_dist_precond_apply_d(amgh_dist_t* d, const real* r_loc_d, real* z_loc_d, int cycle_) {
   RC_TRY(dist_check(d));
   if (cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(d->device));
@@ -873,8 +873,8 @@ int amgh_dist_precond_apply_d(amgh_dist_t* d, const double* r_loc_d, double* z_l
 }
 
 // _solve!(x, ml, b, cycle; ...) (multilevel.jl:158-198) on the sharded hierarchy: x_loc_d in/out (initial guess).
-int amgh_dist_solve_d(amgh_dist_t* d, const double* b_loc_d, double* x_loc_d, int cycle_, int maxiter, double abstol,
-                      double reltol, int calculate_residual, double* resid_hist, int* iters) {
+int amgh_dist_solve_d(amgh_dist_t* d, const real* b_loc_d, real* x_loc_d, int cycle_, int maxiter, double abstol,
+                      double reltol, int calculate_residual, real* resid_hist, int* iters) {
   RC_TRY(dist_check(d));
   if (cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(d->device));
@@ -885,10 +885,10 @@ int amgh_dist_solve_d(amgh_dist_t* d, const double* b_loc_d, double* x_loc_d, in
     HIP_TRY(hipMemcpyAsync(dist_b0(d), b_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
     HIP_TRY(hipMemcpyAsync(dist_x0(d), x_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
   }
-  double nb2 = 0.0;
+  real nb2 = 0.0;
   RC_TRY(dist_dot(d, dist_b0(d), dist_b0(d), n, &nb2));
-  const double normb = std::sqrt(nb2);
-  double normres = normb;
+  const real normb = std::sqrt(nb2);
+  real normres = normb;
   if (normb != 0.0) abstol = std::max(reltol * normb, abstol);
   if (resid_hist) resid_hist[0] = normb;
   int itr = 1;
@@ -907,7 +907,7 @@ int amgh_dist_solve_d(amgh_dist_t* d, const double* b_loc_d, double* x_loc_d, in
 }
 
 // y_loc = A_level x_loc with the halo exchange in front (roofline hook of the sharded SpMV).  Enqueue only.
-int amgh_dist_spmv_d(amgh_dist_t* d, int level, const double* x_loc_d, double* y_loc_d) {
+int amgh_dist_spmv_d(amgh_dist_t* d, int level, const real* x_loc_d, real* y_loc_d) {
   RC_TRY(dist_check(d));
   if (level < 0 || level >= (int)d->levels.size()) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(d->device));
@@ -932,7 +932,7 @@ int amgh_dist_barrier(amgh_dist_t* d) {
   HIP_TRY(hipStreamSynchronize(d->stream));
   return d->tr->barrier();
 }
-int amgh_dist_allreduce(amgh_dist_t* d, double* v, int n, int max_op) {
+int amgh_dist_allreduce(amgh_dist_t* d, real* v, int n, int max_op) {
   if (!d || !v || n < 1 || n > 64) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(d->device));
   return d->tr->allreduce(v, n, max_op != 0);

@@ -173,14 +173,14 @@ struct GsSchedule {
   // level-permuted copy of the smoother's matrix
   int32_t* rowptr = nullptr;
   int32_t* col = nullptr;
-  double* val = nullptr;
+  real* val = nullptr;
   int32_t* perm = nullptr;
   int32_t* dpos = nullptr;
-  double* diag = nullptr;
+  real* diag = nullptr;
   i4_t* rowmeta = nullptr;  // per permuted row {start, end, diagonal position, original row}
   i4_t* desc = nullptr;     // per dependency level {first row, end row, first nnz, end nnz}
-  double* bp = nullptr;     // right-hand side in dependency-level order (scratch)
-  double* xp = nullptr;     // x in dependency-level order (scratch, ncols entries per right-hand-side column)
+  real* bp = nullptr;     // right-hand side in dependency-level order (scratch)
+  real* xp = nullptr;     // x in dependency-level order (scratch, ncols entries per right-hand-side column)
   int cols_alloc = 1;       // right-hand-side columns bp / xp currently hold
   int bp_cols = 0;          // columns of b gathered into bp by the last level-ordered sweep (0: none)
   int32_t* permx = nullptr; // perm extended by the identity over halo columns
@@ -199,25 +199,25 @@ struct GsSchedule {
   };
   std::vector<Seg> segs;
   // slot layout of the wide levels (gs_slot_kernel)
-  int32_t* wcol = nullptr; double* wval = nullptr; int32_t* slot_row = nullptr; i4_t* wmeta = nullptr;
+  int32_t* wcol = nullptr; real* wval = nullptr; int32_t* slot_row = nullptr; i4_t* wmeta = nullptr;
   int slot_entries = kSlot;  // kSlot (gs_slot_kernel) or kBigSlot (gs_bigslot_kernel: long composite rows)
   // SELL-like copy of the merged groups (gs_sell_kernel)
-  int32_t* scol = nullptr; double* sval = nullptr; i2_t* schunk = nullptr;
+  int32_t* scol = nullptr; real* sval = nullptr; i2_t* schunk = nullptr;
   int64_t sell_bytes = 0, sell_total = 0;
   // block-inverse path (small, densely coupled operators; see gs_block_kernel)
   struct Outer {
-    int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; double* tinv = nullptr;
-    int32_t* near_ptr = nullptr; i2_t* near_pi = nullptr; double* near_val = nullptr;  // see gs_block_pipe_kernel
+    int32_t* rowptr = nullptr; int32_t* col = nullptr; real* val = nullptr; real* tinv = nullptr;
+    int32_t* near_ptr = nullptr; i2_t* near_pi = nullptr; real* near_val = nullptr;  // see gs_block_pipe_kernel
     // entries that reference blocks swept LATER (and the in-block other triangle): they read old x only, so
     // b - O_next x is one full-chip residual launch before the sequential sweep
-    int32_t* nx_rowptr = nullptr; int32_t* nx_col = nullptr; double* nx_val = nullptr;
+    int32_t* nx_rowptr = nullptr; int32_t* nx_col = nullptr; real* nx_val = nullptr;
     // entries that reference EARLIER superblocks: final once that superblock is done, applied to the rows of a
     // superblock by one parallel launch before its sequential sweep
-    int32_t* sp_rowptr = nullptr; int32_t* sp_col = nullptr; double* sp_val = nullptr;
+    int32_t* sp_rowptr = nullptr; int32_t* sp_col = nullptr; real* sp_val = nullptr;
   };
   Outer blk_f, blk_b;
-  double* blk_diag = nullptr;
-  double* blk_s = nullptr;  // b - O_next x (n entries per right-hand-side column)
+  real* blk_diag = nullptr;
+  real* blk_s = nullptr;  // b - O_next x (n entries per right-hand-side column)
   int nblk = 0;  // 0 = block path not used for this operator
   int super = 0; // blocks per superblock (0: the whole operator is one superblock)
   double blk_cond = 0.0;  // largest inf-norm condition estimate of an in-block triangle
@@ -227,17 +227,17 @@ struct GsSchedule {
   // [x in level order (ncols) ; s (n)] per right-hand-side column (xstride doubles apart).
   GsSchedule* mf = nullptr;
   GsSchedule* mb = nullptr;
-  struct Tri { int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; };
+  struct Tri { int32_t* rowptr = nullptr; int32_t* col = nullptr; real* val = nullptr; };
   Tri tri_f, tri_b;       // forward pre-pass: entries of later levels + halo; backward: earlier levels + halo
   int merge_f = 1, merge_b = 1;  // dependency levels per group
   int64_t xstride = 0;    // doubles per column of xp (ncols, or ncols + n with merged children)
   // SOR as merged sweeps: (D/w + L) x = b - U x_old + ((1-w)/w) D x_old is a triangular solve with a scaled
   // diagonal, so the same construction applies, per relaxation factor w (composite coefficients carry powers of w).
   // Built on the first SOR sweep with that w; two factors are kept (pre- and post-smoother may differ).
-  struct SorSet { double omega = 0.0; GsSchedule* f = nullptr; GsSchedule* b = nullptr; Tri tf, tb; bool built = false; };
+  struct SorSet { real omega = 0.0; GsSchedule* f = nullptr; GsSchedule* b = nullptr; Tri tf, tb; bool built = false; };
   SorSet sor[2];
   int sor_next = 0;
-  double s_key = 0.0;     // relaxation factor of the merged sweep that produced the current s (1 = Gauss-Seidel)
+  real s_key = 0.0;     // relaxation factor of the merged sweep that produced the current s (1 = Gauss-Seidel)
   bool diag_nonzero = false;  // no row keeps its x (zero diagonal): alternating merged sweeps may derive s from the last one
   int s_dir = -1;         // direction (0 fwd, 1 bwd) whose merged sweep last ran on the current xp / s, -1: none
   void free_dev() {
@@ -276,10 +276,10 @@ struct amgh_csr {
   int64_t nrows = 0, ncols = 0, nnz = 0;
   int32_t* rowptr = nullptr;
   int32_t* col = nullptr;
-  double* val = nullptr;
+  real* val = nullptr;
   // smoother metadata in natural row order (Jacobi), built on demand
   int32_t* dpos = nullptr;
-  double* diag = nullptr;
+  real* diag = nullptr;
   GsSchedule* gs = nullptr;
   int64_t bytes = 0;
 };
@@ -313,12 +313,12 @@ unsigned long long* g_chain_tim = nullptr;  // diagnostics buffer (amgh_debug_ch
 
 constexpr int kChainWidth = 1024;  // dependency levels at most this wide are chained
 
-__global__ void find_diag_kernel(const int32_t* rowptr, const int32_t* col, const double* val, int n,
-                                 int32_t* dpos, double* diag) {
+__global__ void find_diag_kernel(const int32_t* rowptr, const int32_t* col, const real* val, int n,
+                                 int32_t* dpos, real* diag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int dp = -1;
-  double d = 0.0;
+  real d = 0.0;
   // the reference keeps the LAST matching entry (d = ifelse(i == row, val, d))
   for (int j = rowptr[i]; j < rowptr[i + 1]; ++j)
     if (col[j] == i) { dp = j; d = val[j]; }
@@ -327,7 +327,7 @@ __global__ void find_diag_kernel(const int32_t* rowptr, const int32_t* col, cons
 }
 
 int csr_upload(amgh_csr* op, int device, int64_t nrows, int64_t ncols, const int32_t* rowptr,
-               const int32_t* col, const double* val) {
+               const int32_t* col, const real* val) {
   if (nrows < 0 || ncols < 0 || !rowptr) return AMGH_EINVAL;
   if (nrows >= INT32_MAX || ncols >= INT32_MAX) return AMGH_EUNSUPPORTED;
   const int64_t nnz = rowptr[nrows];
@@ -359,7 +359,7 @@ int csr_ensure_diag(amgh_csr* op, hipStream_t st) {
   RC_TRY(dev_alloc(&op->diag, op->nrows));
   if (n < op->nrows) {
     HIP_TRY(hipMemsetAsync(op->dpos, 0xff, sizeof(int32_t) * op->nrows, st));
-    HIP_TRY(hipMemsetAsync(op->diag, 0, sizeof(double) * op->nrows, st));
+    HIP_TRY(hipMemsetAsync(op->diag, 0, sizeof(real) * op->nrows, st));
   }
   if (n > 0)
     hipLaunchKernelGGL(find_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op->rowptr, op->col,

@@ -16,7 +16,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The arithmetic type of the whole library: Float64 by default; the Float32 instance of the reference's generic code
+// (eltype(A) == Float32, test/runtests.jl:244-259) is the SAME source compiled with -DAMGH_REAL=float into its own
+// shared object (libamghip_f32.so, same entry points with float in place of double).
+#ifndef AMGH_REAL
+#define AMGH_REAL double
+#endif
+
 namespace amgh {
+
+using real = AMGH_REAL;
 
 constexpr int kWave = 64;
 constexpr int kThreads = 256;        // 4 waves / workgroup
@@ -34,14 +43,14 @@ enum StreamMode : int {
 struct StreamArgs {
   const int32_t* rowptr;  // CSR of the (possibly level-permuted) matrix
   const int32_t* col;
-  const double* val;
-  const double* x;     // gather source (length ncols)
-  double* y;           // output
-  const double* b;     // RESID / smoothers
+  const real* val;
+  const real* x;     // gather source (length ncols)
+  real* y;           // output
+  const real* b;     // RESID / smoothers
   const int32_t* dpos; // position of the diagonal entry of each row, -1 if absent
-  const double* diag;  // diagonal value of each row (0 if absent)
+  const real* diag;  // diagonal value of each row (0 if absent)
   const int32_t* perm; // GS/SOR: original row id of permuted row p (nullptr = identity)
-  double omega;
+  real omega;
   int32_t row_begin;   // rows [row_begin, row_end) of the matrix are processed
   int32_t row_end;
   // multi-RHS (n x bs blocks, multilevel.jl:28-59): ncolv = bs columns of x / y / b at these element strides;
@@ -56,7 +65,7 @@ struct StreamArgs {
 __device__ __forceinline__ int skew(int k) { return k + (k >> 5); }
 template <bool SKEWED>
 __device__ __forceinline__ int lidx(int k) { return SKEWED ? skew(k) : k; }
-__device__ __forceinline__ double seq_sum_skip(const double* s, int lo, int hi, int dp, double acc);
+__device__ __forceinline__ real seq_sum_skip(const real* s, int lo, int hi, int dp, real acc);
 
 // Optional XCD-contiguous block mapping (workgroup b is observed to run on XCD b % 8):
 // give each XCD a contiguous eighth of the row blocks so that the +-nx rows'
@@ -79,7 +88,7 @@ __device__ __forceinline__ void multi_column_block(int ncolv, int& tile, int& co
   column = rem / kNumXcd;
 }
 
-typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef real d2_t __attribute__((ext_vector_type(2)));
 typedef int i2_t __attribute__((ext_vector_type(2)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 
@@ -106,10 +115,10 @@ struct StreamCfg {
 // position dp when SKIPD.  The LDS reads of 8 products are issued together; the
 // additions stay strictly sequential, so the result is the scalar loop's.
 template <bool SKIPD>
-__device__ __forceinline__ double seq_sum(const double* s_prod, int lo, int hi, int c0, int dp, double acc) {
+__device__ __forceinline__ real seq_sum(const real* s_prod, int lo, int hi, int c0, int dp, real acc) {
   int j = lo;
   for (; j + 8 <= hi; j += 8) {
-    double p[8];
+    real p[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) p[e] = s_prod[skew(j + e - c0)];
 #pragma unroll
@@ -119,7 +128,7 @@ __device__ __forceinline__ double seq_sum(const double* s_prod, int lo, int hi, 
     }
   }
   for (; j < hi; ++j) {
-    const double p = s_prod[skew(j - c0)];
+    const real p = s_prod[skew(j - c0)];
     if (SKIPD) acc = (j != dp) ? acc + p : acc;
     else acc += p;
   }
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
   // few rows per workgroup (latency-bound GS launches): plain LDS indices + the pipelined in-order
   // sum; many rows per workgroup (SpMV): skewed indices keep the row-strided reads conflict-free
   constexpr bool SK = CFG::ROWS > 64;
-  __shared__ double s_prod[LDSN + (LDSN >> 5) + 2];
+  __shared__ real s_prod[LDSN + (LDSN >> 5) + 2];
   int bid, cv;
   multi_column_block(a.ncolv, bid, cv);
   if (cv > 0) {
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
   const int tid = threadIdx.x;
 
   int rs[RPT], re[RPT], dp[RPT], gi[RPT];
-  double acc[RPT], gd[RPT], gb[RPT];
+  real acc[RPT], gd[RPT], gb[RPT];
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
     const int r = r0 + tid + q * T;
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
     const int c1 = min(c0 + LDSN, p1);
     if (VEC == 1) {
       for (int k = c0 + tid; k < c1; k += T) {
-        const double v = ld_stream<NT>(a.val + k);
+        const real v = ld_stream<NT>(a.val + k);
         const int c = ld_stream<NT>(a.col + k);
         s_prod[lidx<SK>(k - c0)] = v * a.x[c];
       }
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
       const int a0 = c0 & ~(VEC - 1);  // hipMalloc'ed arrays: index multiple of VEC => 16 B aligned
       for (int k = a0 + VEC * tid; k < c1; k += VEC * T) {
         if (k >= c0 && k + VEC <= c1) {
-          double v[VEC];
+          real v[VEC];
           int c[VEC];
           if (VEC == 2) {
             const d2_t vv = ld_stream<NT>((const d2_t*)(a.val + k));
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
             v[0] = v0.x; v[1] = v0.y; v[VEC - 2] = v1.x; v[VEC - 1] = v1.y;
             c[0] = cc.x; c[1] = cc.y; c[VEC - 2] = cc.z; c[VEC - 1] = cc.w;
           }
-          double xv[VEC];
+          real xv[VEC];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) xv[e] = a.x[c[e]];
 #pragma unroll
@@ -239,13 +248,13 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
     } else if (MODE == M_ADD) {
       a.y[r] = a.y[r] + acc[q];
     } else if (MODE == M_JACOBI) {
-      const double d = a.diag[r];
-      const double t = a.x[r];
-      const double cand = (1.0 - a.omega) * t + a.omega * ((a.b[r] - acc[q]) / d);
+      const real d = a.diag[r];
+      const real t = a.x[r];
+      const real cand = (1.0 - a.omega) * t + a.omega * ((a.b[r] - acc[q]) / d);
       a.y[r] = (d == 0.0) ? t : cand;
     } else {
       const int i = gi[q];
-      const double d = gd[q];
+      const real d = gd[q];
       if (d != 0.0) {
         if (MODE == M_GS) {
           a.y[i] = (gb[q] - acc[q]) / d;
@@ -263,10 +272,10 @@ using DefaultCfg = StreamCfg<1024, 1024, 8192, 4, false, false>;
 // In-order sum of s[lo..hi) (plain, un-skewed LDS indices): batches of 8 LDS reads with immediate
 // offsets from one base address, the next batch in flight while the current one is added — the
 // additions themselves stay one strictly sequential chain (the reference's order).
-__device__ __forceinline__ double seq_sum_range(const double* s, int lo, int hi, double acc) {
+__device__ __forceinline__ real seq_sum_range(const real* s, int lo, int hi, real acc) {
   int j = lo;
   if (hi - j >= 8) {
-    double p[8], q[8];
+    real p[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) p[e] = s[j + e];
     j += 8;
@@ -296,7 +305,7 @@ __device__ __forceinline__ double seq_sum_range(const double* s, int lo, int hi,
     }
   }
   if (j < hi) {  // tail of 1..7: the reads go out together, the adds stay ordered and conditional
-    double r[7];
+    real r[7];
 #pragma unroll
     for (int e = 0; e < 7; ++e) r[e] = s[min(j + e, hi - 1)];
 #pragma unroll
@@ -306,7 +315,7 @@ __device__ __forceinline__ double seq_sum_range(const double* s, int lo, int hi,
   return acc;
 }
 // the same, leaving out position dp (the diagonal) when it falls inside [lo, hi)
-__device__ __forceinline__ double seq_sum_skip(const double* s, int lo, int hi, int dp, double acc) {
+__device__ __forceinline__ real seq_sum_skip(const real* s, int lo, int hi, int dp, real acc) {
   if (dp >= lo && dp < hi) {
     acc = seq_sum_range(s, lo, dp, acc);
     return seq_sum_range(s, dp + 1, hi, acc);
@@ -317,15 +326,15 @@ __device__ __forceinline__ double seq_sum_skip(const double* s, int lo, int hi, 
 // bp[r] = b[perm[r]]: right-hand side gathered into dependency-level order once per
 // smoother application, so that every level kernel reads it coalesced with no
 // perm -> b dependent hop.
-__global__ void gather_perm_kernel(const double* __restrict__ b, const int32_t* __restrict__ perm,
-                                   double* __restrict__ bp, int n, int64_t ld_src, int64_t ld_dst) {
+__global__ void gather_perm_kernel(const real* __restrict__ b, const int32_t* __restrict__ perm,
+                                   real* __restrict__ bp, int n, int64_t ld_src, int64_t ld_dst) {
   b += blockIdx.y * ld_src;  // blockIdx.y = right-hand-side column
   bp += blockIdx.y * ld_dst;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) bp[r] = b[perm[r]];
 }
 // x[perm[r]] = xp[r]: back from dependency-level order to natural order
-__global__ void scatter_perm_kernel(const double* __restrict__ xp, const int32_t* __restrict__ perm,
-                                    double* __restrict__ x, int n, int64_t ld_src, int64_t ld_dst) {
+__global__ void scatter_perm_kernel(const real* __restrict__ xp, const int32_t* __restrict__ perm,
+                                    real* __restrict__ x, int n, int64_t ld_src, int64_t ld_dst) {
   xp += blockIdx.y * ld_src;
   x += blockIdx.y * ld_dst;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) x[perm[r]] = xp[r];
@@ -335,9 +344,9 @@ __global__ void scatter_perm_kernel(const double* __restrict__ xp, const int32_t
 // (D + L) x = s_f holds row by row, so the backward pre-pass b - L x is b - s_f + D x — no matrix pass
 // (and symmetrically after a backward sweep).  Level order; blockIdx.y = right-hand-side column.
 // (SOR with factor w: diag holds D / w and the formula is b - s_f + (2 - w) (D / w) x, scale = 2 - w.)
-__global__ void gs_flip_rhs_kernel(const double* __restrict__ bp, const double* __restrict__ diag,
-                                   const double* __restrict__ xp, double* __restrict__ sp, int n, int64_t ldb, int64_t ldx,
-                                   double scale) {
+__global__ void gs_flip_rhs_kernel(const real* __restrict__ bp, const real* __restrict__ diag,
+                                   const real* __restrict__ xp, real* __restrict__ sp, int n, int64_t ldb, int64_t ldx,
+                                   real scale) {
   bp += blockIdx.y * ldb;
   xp += blockIdx.y * ldx;
   sp += blockIdx.y * ldx;
@@ -346,7 +355,7 @@ __global__ void gs_flip_rhs_kernel(const double* __restrict__ bp, const double* 
 }
 
 // dst[column][0..n) = src[column][0..n): strided copy of a block of right-hand-side columns (blockIdx.y = column)
-__global__ void copy_cols_kernel(double* __restrict__ dst, const double* __restrict__ src, int n, int64_t ld_dst,
+__global__ void copy_cols_kernel(real* __restrict__ dst, const real* __restrict__ src, int n, int64_t ld_dst,
                                  int64_t ld_src) {
   dst += blockIdx.y * ld_dst;
   src += blockIdx.y * ld_src;
@@ -370,13 +379,13 @@ __device__ __forceinline__ void lds_barrier() {
 // would dominate.
 struct ChainArgs {
   const int32_t* col;      // level-permuted matrix
-  const double* val;
-  double* x;
-  const double* bp;        // b in dependency-level order (gather_perm_kernel)
-  const double* diag;      // per permuted row
+  const real* val;
+  real* x;
+  const real* bp;        // b in dependency-level order (gather_perm_kernel)
+  const real* diag;      // per permuted row
   const i4_t* rowmeta;     // per permuted row: {row start, row end, diagonal position, original row id}
   const i4_t* desc;        // per dependency level: {first row, last row + 1, first nnz, last nnz + 1}
-  double omega;
+  real omega;
   int32_t lvl_begin;       // dependency levels [lvl_begin, lvl_end) in sweep order
   int32_t lvl_end;
   int32_t step;            // +1 forward, -1 backward (then lvl_begin > lvl_end)
@@ -395,8 +404,8 @@ constexpr int kChainLdsX = 8192;     // operators with at most this many columns
 template <int PF>
 struct ChainRow {
   i4_t m;       // rowmeta
-  double d, b;  // diagonal, right-hand side
-  double pv[PF];
+  real d, b;  // diagonal, right-hand side
+  real pv[PF];
   int pc[PF];
 };
 
@@ -435,8 +444,8 @@ __device__ __forceinline__ void chain_prefetch(const ChainArgs& a, const i4_t ds
 template <bool SOR, bool LDSX, int T, int PF>
 __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
   static_assert(PF * T <= kChainLds, "prefetched nonzeros must fit the first LDS pass");
-  __shared__ double s_prod[kChainLds];  // un-skewed: few rows per level, bank conflicts are not the issue here
-  __shared__ double s_x[LDSX ? kChainLdsX : 1];
+  __shared__ real s_prod[kChainLds];  // un-skewed: few rows per level, bank conflicts are not the issue here
+  __shared__ real s_x[LDSX ? kChainLdsX : 1];
   const int tid = threadIdx.x;
   if (blockIdx.x > 0) {  // independent right-hand-side columns, one workgroup each
     a.x += blockIdx.x * a.ldx;
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
     for (int i = tid; i < n; i += T) s_x[i] = a.x[i];
     __syncthreads();
   }
-  const double* xs = LDSX ? (const double*)s_x : (const double*)a.x;
+  const real* xs = LDSX ? (const real*)s_x : (const real*)a.x;
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, nlv = 0;
   for (;;) {
     const unsigned long long t0 = a.tim ? clock64() : 0;
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
     // critical path first: the x gathers of this level's (already prefetched) leading
     // nonzeros are issued BEFORE the next level's prefetch loads — vector-memory results
     // return in order, so anything issued ahead of the gathers would delay them.
-    double xv[PF];
+    real xv[PF];
 #pragma unroll
     for (int e = 0; e < PF; ++e) {
       const int k = p0 + tid + e * T;
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
     const unsigned long long t1 = a.tim ? clock64() : 0;
     unsigned long long t2 = 0, t3 = 0;
 
-    double acc = 0.0;
+    real acc = 0.0;
     for (int c0 = p0; c0 < p1; c0 += kChainLds) {
       const int c1 = min(c0 + kChainLds, p1);
       if (c0 == p0) {
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
     }
     if (cur.m.w >= 0 && cur.d != 0.0) {
       const int i = ds.x + tid;  // x is in dependency-level order: this row's own position
-      const double xn = SOR ? (1.0 - a.omega) * xs[i] + (a.omega / cur.d) * (cur.b - acc) : (cur.b - acc) / cur.d;
+      const real xn = SOR ? (1.0 - a.omega) * xs[i] + (a.omega / cur.d) * (cur.b - acc) : (cur.b - acc) / cur.d;
       if (LDSX) s_x[i] = xn;
       a.x[i] = xn;  // LDSX: fire-and-forget copy to HBM, nobody in this launch reads it back
     }
@@ -541,13 +550,13 @@ constexpr int kSlot = 512;  // 128: 39.5, 256: 37.5, 512: 36.9, 1024: 37.2 ms pe
 
 struct SlotArgs {
   const int32_t* wcol;      // slot arrays: nslots * kSlot entries (padding: col 0, val 0)
-  const double* wval;
+  const real* wval;
   const int32_t* slot_row;  // per slot: {first row, end row} in dependency-level order
   const i4_t* wmeta;        // per level-ordered row: {start, end, diagonal position} in the slot arrays
-  const double* diag;
-  const double* bp;
-  double* x;                // x in dependency-level order
-  double omega;
+  const real* diag;
+  const real* bp;
+  real* x;                // x in dependency-level order
+  real omega;
   int32_t slot0;            // first slot of this dependency level
   int32_t nslots;           // slots of this dependency level
   int32_t xcd_map;          // 1: XCD-contiguous slot mapping (grid padded to a multiple of 8)
@@ -561,7 +570,7 @@ struct SlotArgs {
 // 8 columns = 3 x the time).  Two entries per thread (half the waves) measured 2 % slower than one.
 template <bool SOR, int NCV>
 __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
-  __shared__ double s_prod[NCV * kSlot];
+  __shared__ real s_prod[NCV * kSlot];
   const int tid = threadIdx.x;
   int lb, cg;  // slot, column group
   multi_column_block(a.ncolv, lb, cg);
@@ -573,10 +582,10 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
   if (lb >= a.nslots) return;
   const int s = a.slot0 + lb;
   const int base = s * kSlot;
-  const double v = a.wval[base + tid];
+  const real v = a.wval[base + tid];
   const int c = a.wcol[base + tid];
   const int r0 = a.slot_row[2 * s], r1 = a.slot_row[2 * s + 1];
-  double xv[NCV];
+  real xv[NCV];
 #pragma unroll
   for (int q = 0; q < NCV; ++q) xv[q] = a.x[c + q * a.ldx];
   // (row, column) tasks of the slot are spread over the threads: task t = column * nrows + row.  The first
@@ -584,7 +593,7 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
   constexpr int TPT = NCV > 1 ? 2 : 1;
   const int nrows = r1 - r0, ntask = nrows * NCV;
   i4_t m[TPT];
-  double d[TPT], bb[TPT];
+  real d[TPT], bb[TPT];
   int tr[TPT], tq[TPT];
 #pragma unroll
   for (int u = 0; u < TPT; ++u) {
@@ -603,8 +612,8 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
 #pragma unroll
   for (int u = 0; u < TPT; ++u) {
     if (tid + u * kSlot < ntask && d[u] != 0.0) {
-      const double acc = seq_sum_skip(s_prod + tq[u] * kSlot, m[u].x - base, m[u].y - base, m[u].z - base, 0.0);
-      double* xq = a.x + tq[u] * a.ldx;
+      const real acc = seq_sum_skip(s_prod + tq[u] * kSlot, m[u].x - base, m[u].y - base, m[u].z - base, 0.0);
+      real* xq = a.x + tq[u] * a.ldx;
       const int i = r0 + tr[u];
       xq[i] = SOR ? (1.0 - a.omega) * xq[i] + (a.omega / d[u]) * (bb[u] - acc) : (bb[u] - acc) / d[u];
     }
@@ -612,12 +621,12 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
   for (int t = tid + TPT * kSlot; t < ntask; t += kSlot) {  // slots of very short rows: more tasks than 2 per thread
     const int q = t / nrows, r = t - q * nrows;
     const i4_t m2 = a.wmeta[r0 + r];
-    const double d2 = a.diag[r0 + r];
+    const real d2 = a.diag[r0 + r];
     if (d2 != 0.0) {
-      const double acc = seq_sum_skip(s_prod + q * kSlot, m2.x - base, m2.y - base, m2.z - base, 0.0);
-      double* xq = a.x + q * a.ldx;
+      const real acc = seq_sum_skip(s_prod + q * kSlot, m2.x - base, m2.y - base, m2.z - base, 0.0);
+      real* xq = a.x + q * a.ldx;
       const int i = r0 + r;
-      const double bq = a.bp[i + q * a.ldb];
+      const real bq = a.bp[i + q * a.ldb];
       xq[i] = SOR ? (1.0 - a.omega) * xq[i] + (a.omega / d2) * (bq - acc) : (bq - acc) / d2;
     }
   }
@@ -634,14 +643,14 @@ __global__ __launch_bounds__(kSlot / EPT) void gs_slot_lpr_kernel(SlotArgs a) {
   static_assert(LPR >= 1 && LPR <= 32 && (LPR & (LPR - 1)) == 0, "lanes per row: a power of two inside one wave");
   static_assert(EPT == 1 || EPT == 2, "entries per thread");
   constexpr int T = kSlot / EPT;
-  __shared__ double s_prod[kSlot];
+  __shared__ real s_prod[kSlot];
   const int tid = threadIdx.x;
   int lb = blockIdx.x;
   if (a.xcd_map) lb = xcd_block(lb, a.nslots);
   if (lb >= a.nslots) return;
   const int s = a.slot0 + lb;
   const int base = s * kSlot;
-  double v[EPT], xv[EPT];
+  real v[EPT], xv[EPT];
   int c[EPT];
   if (EPT == 1) {
     v[0] = a.wval[base + tid]; c[0] = a.wcol[base + tid];
@@ -657,7 +666,7 @@ __global__ __launch_bounds__(kSlot / EPT) void gs_slot_lpr_kernel(SlotArgs a) {
   const int sub = tid % LPR;
   int r = tid / LPR;
   i4_t m = i4_t{0, 0, -1, 0};
-  double d = 0.0, bb = 0.0;
+  real d = 0.0, bb = 0.0;
   if (r < nrows) { m = a.wmeta[r0 + r]; d = a.diag[r0 + r]; bb = a.bp[r0 + r]; }  // same round trip as the gather
 #pragma unroll
   for (int e = 0; e < EPT; ++e) s_prod[EPT * tid + e] = v[e] * xv[e];
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(kSlot / EPT) void gs_slot_lpr_kernel(SlotArgs a) {
       m = i4_t{0, 0, -1, 0}; d = 0.0; bb = 0.0;
       if (r < nrows) { m = a.wmeta[r0 + r]; d = a.diag[r0 + r]; bb = a.bp[r0 + r]; }
     }
-    double acc = 0.0;
+    real acc = 0.0;
     const int dz = m.z - base, qe = m.y - base;
     for (int q = m.x - base + sub; q < qe; q += LPR)
       if (q != dz) acc += s_prod[q];
@@ -691,12 +700,12 @@ __global__ __launch_bounds__(kSlot / EPT) void gs_slot_lpr_kernel(SlotArgs a) {
 // scalar loop; K > 1 changes the order of the additions (merged groups only, whose rows already differ at 1e-16).
 struct SellArgs {
   const int32_t* scol;      // padded entries, chunk after chunk
-  const double* sval;
+  const real* sval;
   const i2_t* chunk;        // per chunk {offset in units of 64 entries, iterations}
-  const double* diag;
-  const double* bp;
-  double* x;
-  double omega;
+  const real* diag;
+  const real* bp;
+  real* x;
+  real omega;
   int32_t row0, nrows;      // the group's rows (level order)
   int32_t chunk0, nchunks;
   int32_t xcd_map;
@@ -715,12 +724,12 @@ __global__ __launch_bounds__(256) void gs_sell_kernel(SellArgs a) {
   const int64_t base = (int64_t)(uint32_t)cd.x * kWave + lane;
   const int r = ch * C + lane / K;
   const bool live = r < a.nrows;
-  double d = 0.0, bb = 0.0;
+  real d = 0.0, bb = 0.0;
   if (live) { d = a.diag[a.row0 + r]; bb = a.bp[a.row0 + r]; }
-  double acc = 0.0;
+  real acc = 0.0;
   int t = 0;
   for (; t + BATCH <= cd.y; t += BATCH) {
-    double v[BATCH], xv[BATCH];
+    real v[BATCH], xv[BATCH];
     int c[BATCH];
 #pragma unroll
     for (int e = 0; e < BATCH; ++e) c[e] = a.scol[base + (int64_t)(t + e) * kWave];
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(256) void gs_sell_kernel(SellArgs a) {
       if (c[e] >= 0) acc += v[e] * xv[e];
   }
   if (t < cd.y) {  // tail of 1 .. BATCH-1 iterations, loads issued together
-    double v[BATCH], xv[BATCH];
+    real v[BATCH], xv[BATCH];
     int c[BATCH];
 #pragma unroll
     for (int e = 0; e < BATCH - 1; ++e) c[e] = (t + e < cd.y) ? a.scol[base + (int64_t)(t + e) * kWave] : -1;
@@ -753,8 +762,8 @@ __global__ __launch_bounds__(256) void gs_sell_kernel(SellArgs a) {
   }
 }
 // a group's rows from the (composite) CSR into the SELL arrays: one thread per lane slot of a chunk
-__global__ void sell_fill_kernel(const int32_t* prow, const int32_t* pcol, const double* pval, const i2_t* chunk,
-                                 int chunk0, int nchunks, int row0, int nrows, int K, int32_t* scol, double* sval) {
+__global__ void sell_fill_kernel(const int32_t* prow, const int32_t* pcol, const real* pval, const i2_t* chunk,
+                                 int chunk0, int nchunks, int row0, int nrows, int K, int32_t* scol, real* sval) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int ch = (int)(gid >> 6), lane = (int)(gid & 63);
   if (ch >= nchunks) return;
@@ -781,7 +790,7 @@ constexpr int kBigRows = 64;
 template <bool SOR>
 __global__ __launch_bounds__(kSlot) void gs_bigslot_kernel(SlotArgs a) {
   constexpr int EPT = kBigSlot / kSlot, NW = kSlot / kWave;
-  __shared__ double s_prod[kBigSlot];
+  __shared__ real s_prod[kBigSlot];
   const int tid = threadIdx.x;
   int lb, cv;
   multi_column_block(a.ncolv, lb, cv);
@@ -793,7 +802,7 @@ __global__ __launch_bounds__(kSlot) void gs_bigslot_kernel(SlotArgs a) {
   if (lb >= a.nslots) return;
   const int s = a.slot0 + lb;
   const int base = s * kBigSlot;
-  double v[EPT], xv[EPT];
+  real v[EPT], xv[EPT];
   int c[EPT];
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
@@ -806,7 +815,7 @@ __global__ __launch_bounds__(kSlot) void gs_bigslot_kernel(SlotArgs a) {
   const int wv = tid / kWave, ln = tid % kWave;
   // row data of this wave's first two rows, requested with the gathers
   i4_t m[2];
-  double d[2], bb[2];
+  real d[2], bb[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int r = wv + u * NW;
@@ -819,11 +828,11 @@ __global__ __launch_bounds__(kSlot) void gs_bigslot_kernel(SlotArgs a) {
   int u = 0;
   for (int r = wv; r < nrows; r += NW, ++u) {
     i4_t mm;
-    double dd, bv;
+    real dd, bv;
     if (u < 2) { mm = m[u]; dd = d[u]; bv = bb[u]; }
     else { mm = a.wmeta[r0 + r]; dd = a.diag[r0 + r]; bv = a.bp[r0 + r]; }
     const int dz = mm.z - base, qe = mm.y - base;
-    double acc = 0.0;
+    real acc = 0.0;
     for (int q = mm.x - base + ln; q < qe; q += kWave)
       if (q != dz) acc += s_prod[q];
 #pragma unroll
@@ -852,11 +861,11 @@ constexpr int kBlkSingle = 16;     // operators with at most this many blocks: o
 struct BlockArgs {
   const int32_t* rowptr;  // "outer" matrix of this direction: the operator minus the in-block triangle
   const int32_t* col;     //   (forward: minus in-block entries with col <= row; backward: col >= row)
-  const double* val;
-  const double* tinv;     // nblk x kBlk x kBlk row-major: inverse of the in-block triangle (+ diagonal)
-  const double* diag;     // diagonal of each row, 0 if absent (such rows keep x, smoother.jl:87)
-  double* x;
-  const double* b;
+  const real* val;
+  const real* tinv;     // nblk x kBlk x kBlk row-major: inverse of the in-block triangle (+ diagonal)
+  const real* diag;     // diagonal of each row, 0 if absent (such rows keep x, smoother.jl:87)
+  real* x;
+  const real* b;
   int32_t n;
   int32_t nblk;      // blocks swept by this launch: blk0 .. blk0 + nblk - 1 (descending when backward)
   int32_t blk0;
@@ -865,13 +874,13 @@ struct BlockArgs {
   // "near" entries: outer entries of block k that reference the block swept just before it (gs_block_pipe_kernel)
   const int32_t* near_ptr;  // nblk + 1
   const i2_t* near_pi;      // {position inside the block's outer range, column - first row of the previous block}
-  const double* near_val;
+  const real* near_val;
   unsigned long long* tim;  // diagnostics (amgh_debug_chain_timing): per-phase shader-cycle sums, or nullptr
 };
 
 // this thread's 16 entries of the block inverse (row drow, columns part*16..+15); the half of the
 // block that is structurally zero (above the diagonal forward, below it backward) is not read
-__device__ __forceinline__ void blk_load_tinv(const BlockArgs& a, int blk, int drow, int part, double (&tv)[16]) {
+__device__ __forceinline__ void blk_load_tinv(const BlockArgs& a, int blk, int drow, int part, real (&tv)[16]) {
   const bool nz = a.backward ? (part * 16 + 15 >= drow) : (part * 16 <= drow);
   if (nz) {
     const d2_t* tp = (const d2_t*)(a.tinv + ((size_t)blk * kBlk + drow) * kBlk + part * 16);
@@ -884,13 +893,13 @@ __device__ __forceinline__ void blk_load_tinv(const BlockArgs& a, int blk, int d
 }
 
 __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
-  __shared__ double s_prod[kBlkLds];
-  __shared__ double s_vec[kBlk];
+  __shared__ real s_prod[kBlkLds];
+  __shared__ real s_vec[kBlk];
   const int tid = threadIdx.x;
   a.x += blockIdx.x * a.ld;
   a.b += blockIdx.x * a.ld;
   const int drow = tid >> 3, part = tid & 7;  // dense phase: 8 lanes share a row, 16 columns each
-  double tv[16];
+  real tv[16];
   blk_load_tinv(a, a.blk0 + (a.backward ? a.nblk - 1 : 0), drow, part, tv);
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int step = 0; step < a.nblk; ++step) {
@@ -904,7 +913,7 @@ __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
     // row drow is summed by its 8 lanes, entries interleaved (lane p: p, p+8, ...): conflict-free LDS reads.
     // (One thread per row walking its own segment put 64 lanes on ~16 banks: 12 k of the 28 k cycles per step.)
     int rs = 0, re = 0;
-    double d = 0.0, bb = 0.0, xo = 0.0, acc = 0.0;
+    real d = 0.0, bb = 0.0, xo = 0.0, acc = 0.0;
     if (drow < rows) {
       rs = a.rowptr[i0 + drow]; re = a.rowptr[i0 + drow + 1];
       if (part == 0) { d = a.diag[i0 + drow]; bb = a.b[i0 + drow]; xo = a.x[i0 + drow]; }
@@ -914,7 +923,7 @@ __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
       // one CU streams the whole operator: keep 4 independent (val, col) -> x chains in flight per thread
       int k = c0 + tid;
       for (; k + 3 * kBlkThreads < c1; k += 4 * kBlkThreads) {
-        double v[4], xv[4];
+        real v[4], xv[4];
         int c[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = a.val[k + e * kBlkThreads]; c[e] = a.col[k + e * kBlkThreads]; }
@@ -938,7 +947,7 @@ __global__ __launch_bounds__(kBlkThreads) void gs_block_kernel(BlockArgs a) {
     __syncthreads();
     if (a.tim) t2 = clock64();
     // phase 2: x_I = Tinv_II . s
-    double sum = 0.0;
+    real sum = 0.0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sum += tv[e] * s_vec[part * 16 + e];
     sum += __shfl_xor(sum, 1, kWave);
@@ -985,7 +994,7 @@ constexpr int kPipeNPF = 2;                         // near entries per thread h
 // bytes: one 16-B load instead of four 4-B loads).  Entries outside [p0, lim) get col = -1.
 struct PipeEntries {
   int c[kPipePF];
-  double v[kPipePF];
+  real v[kPipePF];
 };
 __device__ __forceinline__ void pipe_load_entries(const BlockArgs& a, int p0, int lim, int tid, PipeEntries& o) {
   const int a0 = p0 & ~3;
@@ -1013,12 +1022,12 @@ __device__ __forceinline__ void pipe_load_entries(const BlockArgs& a, int p0, in
     }
   }
 }
-__device__ __forceinline__ void pipe_gather(const BlockArgs& a, const PipeEntries& o, double (&px)[kPipePF]) {
+__device__ __forceinline__ void pipe_gather(const BlockArgs& a, const PipeEntries& o, real (&px)[kPipePF]) {
 #pragma unroll
   for (int e = 0; e < kPipePF; ++e) px[e] = o.c[e] >= 0 ? a.x[o.c[e]] : 0.0;
 }
-__device__ __forceinline__ void pipe_store_products(double* s_dst, int p0, int tid, const PipeEntries& o,
-                                                    const double (&px)[kPipePF]) {
+__device__ __forceinline__ void pipe_store_products(real* s_dst, int p0, int tid, const PipeEntries& o,
+                                                    const real (&px)[kPipePF]) {
   const int a0 = p0 & ~3;
 #pragma unroll
   for (int r = 0; r < kPipePF / 4; ++r) {
@@ -1033,23 +1042,23 @@ __device__ __forceinline__ int pipe_lead_end(int p0, int p1) { return min(p1, (p
 
 __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a) {
   constexpr int T = kPipeThreads, PF = kPipePF, NPF = kPipeNPF;
-  __shared__ double s_buf[2][kPipeCap];
-  __shared__ double s_vec[kBlk];
-  __shared__ double s_xnew[kBlk];
+  __shared__ real s_buf[2][kPipeCap];
+  __shared__ real s_vec[kBlk];
+  __shared__ real s_xnew[kBlk];
   const int tid = threadIdx.x;
   a.x += blockIdx.x * a.ld;
   a.b += blockIdx.x * a.ld;
   const int drow = tid >> 3, part = tid & 7;  // 8 lanes per row, in the row sums and in the dense product
   const int dir = a.backward ? -1 : 1;
   int blk = a.blk0 + (a.backward ? a.nblk - 1 : 0);
-  double tv[16];
+  real tv[16];
   blk_load_tinv(a, blk, drow, part, tv);
 
   // state of the block about to be processed (filled one step ahead)
   int np0, np1, nrs = 0, nre = 0;
-  double nd = 0.0, nbb = 0.0, nxo = 0.0;
+  real nd = 0.0, nbb = 0.0, nxo = 0.0;
   i2_t qpi[NPF];
-  double qv[NPF];
+  real qv[NPF];
   int nq0 = 0, nq1 = 0;
   // ranges of the block after that (fetched two steps ahead)
   int n2p0 = 0, n2p1 = 0, n2q0 = 0, n2q1 = 0;
@@ -1064,7 +1073,7 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
 #pragma unroll
     for (int e = 0; e < NPF; ++e) { qpi[e] = i2_t{-1, 0}; qv[e] = 0.0; }  // the first block has no predecessor
     PipeEntries pe;
-    double px[PF];
+    real px[PF];
     pipe_load_entries(a, np0, pipe_lead_end(np0, np1), tid, pe);
     pipe_gather(a, pe, px);
     pipe_store_products(s_buf[0], np0, tid, pe, px);
@@ -1080,12 +1089,12 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
   for (int step = 0; step < a.nblk; ++step, blk += dir) {
     const unsigned long long t0 = a.tim ? clock64() : 0;
     unsigned long long t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-    double* s_cur = s_buf[step & 1];
-    double* s_nxt = s_buf[(step & 1) ^ 1];
+    real* s_cur = s_buf[step & 1];
+    real* s_nxt = s_buf[(step & 1) ^ 1];
     const int i0 = blk * kBlk;
     const int rows = min(kBlk, a.n - i0);
     const int p0 = np0, p1 = np1, rs = nrs, re = nre, q0 = nq0, q1 = nq1;
-    const double d = nd, bb = nbb, xo = nxo;
+    const real d = nd, bb = nbb, xo = nxo;
     const bool has_next = step + 1 < a.nblk;
     const int lead = pipe_lead_end(p0, p1) - p0;  // entries [0, lead) of this block are in s_cur
     // (b) near entries of this block, from the registers filled a step ago
@@ -1125,7 +1134,7 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
     lds_barrier();
     if (a.tim) t1 = clock64();
     // (c) row sums: 8 lanes per row, interleaved
-    double acc = 0.0;
+    real acc = 0.0;
     for (int q = rs - p0 + part, qe = min(re - p0, lead); q < qe; q += 8) acc += s_cur[q];
     for (int c0 = p0 + lead; c0 < p1; c0 += kPipeCap) {  // block longer than the buffer: fetched on demand
       const int c1 = min(c0 + kPipeCap, p1);
@@ -1145,10 +1154,10 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
     lds_barrier();
     if (a.tim) t2 = clock64();
     // (d) x gathers of the next block's leading entries
-    double px[PF];
+    real px[PF];
     pipe_gather(a, pe, px);
     // (e) x_I = Tinv_II . s
-    double sum = 0.0;
+    real sum = 0.0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sum += tv[e] * s_vec[part * 16 + e];
     sum += __shfl_xor(sum, 1, kWave);
@@ -1176,31 +1185,31 @@ __global__ __launch_bounds__(kPipeThreads) void gs_block_pipe_kernel(BlockArgs a
 }
 
 // ---- vector kernels ------------------------------------------------------
-__global__ void fill_kernel(double* x, int64_t n, double v) {
+__global__ void fill_kernel(real* x, int64_t n, real v) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = v;
 }
-__global__ void copy_kernel(double* dst, const double* src, int64_t n) {
+__global__ void copy_kernel(real* dst, const real* src, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 // y = y + alpha * x, alpha read from device memory (scaled by sign)
-__global__ void axpy_dev_kernel(double* y, const double* x, const double* alpha, double sign, int64_t n) {
-  const double al = sign * alpha[0];
+__global__ void axpy_dev_kernel(real* y, const real* x, const real* alpha, real sign, int64_t n) {
+  const real al = sign * alpha[0];
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = y[i] + al * x[i];
 }
 // u = c + beta * u
-__global__ void xpby_dev_kernel(double* u, const double* c, const double* beta, int64_t n) {
-  const double be = beta[0];
+__global__ void xpby_dev_kernel(real* u, const real* c, const real* beta, int64_t n) {
+  const real be = beta[0];
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) u[i] = c[i] + be * u[i];
 }
 
-// wave64 + LDS block reduction of a double
-__device__ __forceinline__ double block_reduce_sum(double v, double* s_part) {
+// wave64 + LDS block reduction of a real
+__device__ __forceinline__ real block_reduce_sum(real v, real* s_part) {
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   if (lane == 0) s_part[w] = v;
   __syncthreads();
-  double r = 0.0;
+  real r = 0.0;
   if (threadIdx.x == 0) {
     const int nw = (blockDim.x + kWave - 1) / kWave;
     for (int i = 0; i < nw; ++i) r += s_part[i];
@@ -1210,33 +1219,33 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* s_part) {
 
 constexpr int kRedBlocks = 1024;
 // partial[b] = sum_i x[i]*y[i] over this block's grid-stride slice (deterministic)
-__global__ __launch_bounds__(kThreads) void dot_partial_kernel(const double* x, const double* y, int64_t n, double* partial) {
-  __shared__ double s_part[kThreads / kWave];
-  double v = 0.0;
+__global__ __launch_bounds__(kThreads) void dot_partial_kernel(const real* x, const real* y, int64_t n, real* partial) {
+  __shared__ real s_part[kThreads / kWave];
+  real v = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v += x[i] * y[i];
-  const double r = block_reduce_sum(v, s_part);
+  const real r = block_reduce_sum(v, s_part);
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 // out[0] = op(sum partial); op: 0 identity, 1 sqrt
-__global__ __launch_bounds__(kThreads) void reduce_final_kernel(const double* partial, int np, double* out, int op) {
-  __shared__ double s_part[kThreads / kWave];
-  double v = 0.0;
+__global__ __launch_bounds__(kThreads) void reduce_final_kernel(const real* partial, int np, real* out, int op) {
+  __shared__ real s_part[kThreads / kWave];
+  real v = 0.0;
   for (int i = threadIdx.x; i < np; i += blockDim.x) v += partial[i];
-  const double r = block_reduce_sum(v, s_part);
+  const real r = block_reduce_sum(v, s_part);
   if (threadIdx.x == 0) out[0] = op ? sqrt(r) : r;
 }
 // tiny scalar programs for the device-resident PCG recurrence
 // op 0: out = a / b ; op 1: out = a (copy)
-__global__ void scalar_kernel(double* out, const double* a, const double* b, int op) {
+__global__ void scalar_kernel(real* out, const real* a, const real* b, int op) {
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (op == 0) ? a[0] / b[0] : a[0];
 }
 
 // x = M * b, M dense n x n column-major (coarse solve, coarse_solver.jl:16).
 // One thread per output row, columns ascending.
-__global__ void dense_gemv_kernel(const double* M, const double* b, double* x, int n) {
+__global__ void dense_gemv_kernel(const real* M, const real* b, real* x, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double acc = 0.0;
+  real acc = 0.0;
   for (int j = 0; j < n; ++j) acc += M[i + (size_t)j * n] * b[j];
   x[i] = acc;
 }

@@ -54,7 +54,7 @@ int launch_gs_level(const StreamArgs& a, int rows, hipStream_t st, int ncolv = 1
 }
 
 // ncolv right-hand-side columns (x: ncols apart, y and b: nrows apart) in one launch
-int csr_apply(const amgh_csr* op, int mode, const double* x, const double* b, double* y, hipStream_t st,
+int csr_apply(const amgh_csr* op, int mode, const real* x, const real* b, real* y, hipStream_t st,
               int ncolv = 1) {
   StreamArgs a{};
   a.rowptr = op->rowptr; a.col = op->col; a.val = op->val;
@@ -69,7 +69,7 @@ int csr_apply(const amgh_csr* op, int mode, const double* x, const double* b, do
   return AMGH_EINVAL;
 }
 
-int csr_jacobi(amgh_csr* op, double omega, const double* xin, const double* b, double* xout, hipStream_t st,
+int csr_jacobi(amgh_csr* op, real omega, const real* xin, const real* b, real* xout, hipStream_t st,
                int ncolv = 1) {
   RC_TRY(csr_ensure_diag(op, st));
   StreamArgs a{};
@@ -99,8 +99,8 @@ int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, h
 }
 
 // SpMV-type launch on raw CSR arrays with explicit column strides (operators and vectors in level order)
-int raw_apply(int mode, const int32_t* rowptr, const int32_t* col, const double* val, int64_t nrows, const double* x,
-              int64_t ldx, const double* b, int64_t ldb, double* y, int64_t ldy, hipStream_t st, int ncolv) {
+int raw_apply(int mode, const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x,
+              int64_t ldx, const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st, int ncolv) {
   StreamArgs a{};
   a.rowptr = rowptr; a.col = col; a.val = val;
   a.x = x; a.y = y; a.b = b;
@@ -174,7 +174,7 @@ int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st)
 // pre-smoother of the same cycle and level): its level-ordered copy is still in place.
 // x_resident: the level-ordered x of this operator (g->xp) is already current: skip the gather of x (the cycle
 // kept x there between the pre- and the post-smoother); no_scatter: leave the result in g->xp only.
-int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x, const double* b, hipStream_t st,
+int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, const real* b, hipStream_t st,
                  bool first = true, bool last = true, int ncolv = 1, bool xzero = false, bool reuse_b = false,
                  bool x_resident = false, bool no_scatter = false) {
   RC_TRY(csr_ensure_gs(op));
@@ -241,7 +241,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
   // the first sweep with this relaxation factor); merged SOR runs the GS kernels on the scaled system
   GsSchedule* lay = g;
   const GsSchedule::Tri* tri = nullptr;
-  double s_key = 0.0, flip_scale = 1.0;
+  real s_key = 0.0, flip_scale = 1.0;
   bool both_dirs = false;
   if (g_gs_merge > 1 && !sor && (backward ? g->mb : g->mf)) {
     lay = backward ? g->mb : g->mf;
@@ -279,14 +279,14 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
       const int64_t cnt = xs * ncolv;  // (a fill kernel: hipMemsetAsync of a small buffer costs far more than a launch)
       hipLaunchKernelGGL(fill_kernel, dim3(grid_for(cnt)), dim3(256), 0, st, g->xp, cnt, 0.0);
     } else {
-      hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const double*)x, g->permx,
+      hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const real*)x, g->permx,
                          g->xp, (int)g->ncols, (int64_t)g->ncols, xs);
     }
     HIP_TRY(hipGetLastError());
   }
-  double* xp = g->xp;
+  real* xp = g->xp;
   // merged-level sweep: the child schedule of this direction runs on ext = [x ; s], s = b - T x
-  const double* rhs = g->bp;
+  const real* rhs = g->bp;
   int64_t ldb = g->n;
   if (first) g->s_dir = -1;
   if (lay != g) {
@@ -294,13 +294,13 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
                       g->s_dir == (backward ? 0 : 1) && g->s_key == s_key;
     if (flip) {
       // the previous sweep of this smooth! call ran the other way on the same xp: s follows without a matrix pass
-      hipLaunchKernelGGL(gs_flip_rhs_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const double*)g->bp,
-                         (const double*)lay->diag, (const double*)xp, xp + g->ncols, (int)g->n, (int64_t)g->n, xs,
+      hipLaunchKernelGGL(gs_flip_rhs_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const real*)g->bp,
+                         (const real*)lay->diag, (const real*)xp, xp + g->ncols, (int)g->n, (int64_t)g->n, xs,
                          flip_scale);
       HIP_TRY(hipGetLastError());
     } else if (first && xzero) {  // s = b - T * 0
       hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, xp + g->ncols,
-                         (const double*)g->bp, (int)g->n, xs, (int64_t)g->n);
+                         (const real*)g->bp, (int)g->n, xs, (int64_t)g->n);
       HIP_TRY(hipGetLastError());
     } else {
       StreamArgs ra{};
@@ -384,7 +384,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, double omega, double* x,
     }
   }
   if (last && !no_scatter) {
-    hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const double*)xp, g->perm, x,
+    hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const real*)xp, g->perm, x,
                        (int)g->n, xs, (int64_t)g->n);
     HIP_TRY(hipGetLastError());
   }

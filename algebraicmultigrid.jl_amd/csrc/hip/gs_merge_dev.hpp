@@ -21,7 +21,7 @@ struct MergeDev {
   int32_t* clen = nullptr;            // per level-ordered row: entries of its composite row
   int32_t* coff = nullptr;            // ... offset inside its round's pool
   int32_t* rcol[kMergeMaxRounds] = {};
-  double* rval[kMergeMaxRounds] = {};
+  real* rval[kMergeMaxRounds] = {};
   int64_t total = 0, max_row = 0;
   double growth = 0.0;
   bool failed = false;                // a row outgrew the long-row table (the caller gives up on this m)
@@ -34,14 +34,14 @@ struct MergeDev {
 };
 
 struct MergeArgs {
-  const int32_t* prow; const int32_t* pcol; const double* pval; const double* pdiag; const int32_t* lev_of;
+  const int32_t* prow; const int32_t* pcol; const real* pval; const real* pdiag; const int32_t* lev_of;
   int n, ncols, nlev, m, ngrp, backward, round;
   const int32_t* clen; const int32_t* coff;
-  const int32_t* rcol[kMergeMaxRounds]; const double* rval[kMergeMaxRounds];
+  const int32_t* rcol[kMergeMaxRounds]; const real* rval[kMergeMaxRounds];
   // count pass: cnt / ovf out;  fill pass: off in, this round's pool + clen / coff out
   int32_t* cnt; unsigned char* ovf; int32_t* any_ovf;
-  const int32_t* off; int32_t* out_col; double* out_val; int32_t* clen_out; int32_t* coff_out;
-  unsigned long long* growth;  // max over rows of sum |coefficient| / |diagonal| (bit pattern of a non-negative double)
+  const int32_t* off; int32_t* out_col; real* out_val; int32_t* clen_out; int32_t* coff_out;
+  unsigned long long* growth;  // max over rows of sum |coefficient| / |diagonal| (bit pattern of a non-negative real)
   int32_t* fail;
   int fill;       // 0 count, 1 fill
   int tier;       // 0: 128-slot tables (all rows), 1: 512 slots, 2: a workgroup per row with 4096 slots — rows flagged by the tier before
@@ -62,8 +62,8 @@ __device__ __forceinline__ int merge_round_of(int l, const MergeArgs& a) {
 template <int LANES, int ROWS, int CAP>
 __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* s_valb = (double*)smem;                              // ROWS * CAP
-  double* s_dvalb = s_valb + ROWS * CAP;                       // ROWS * CAP
+  real* s_valb = (real*)smem;                              // ROWS * CAP
+  real* s_dvalb = s_valb + ROWS * CAP;                       // ROWS * CAP
   int32_t* s_keyb = (int32_t*)(s_dvalb + ROWS * CAP);          // ROWS * CAP
   int32_t* s_dkeyb = s_keyb + ROWS * CAP;                      // ROWS * CAP
   __shared__ int32_t s_cnt[ROWS], s_pos[ROWS], s_steps;
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
     }
   }
   int32_t* key = s_keyb + grp * CAP;
-  double* val = s_valb + grp * CAP;
+  real* val = s_valb + grp * CAP;
   int32_t* dkey = s_dkeyb + grp * CAP;
-  double* dval = s_dvalb + grp * CAP;
+  real* dval = s_dvalb + grp * CAP;
   bool live = p < a.n;
   int lp = 0;
   if (live) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
   const int steps = s_steps;
   const int gp = live ? merge_group_of(lp, a) : 0;
   bool overflow = false;
-  auto add = [&](int32_t c, double v) {
+  auto add = [&](int32_t c, real v) {
     uint32_t hsh = ((uint32_t)c * 2654435761u) & (CAP - 1);
     int probes = 0;
     for (;;) {
@@ -124,15 +124,15 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
         const int lc = a.lev_of[c];
         const bool tri = a.backward ? lc > lp : lc < lp;
         if (tri) {              // the other triangle belongs to the pre-pass
-          const double v = a.pval[j];
-          const double dc = a.pdiag[c];
+          const real v = a.pval[j];
+          const real dc = a.pdiag[c];
           if (merge_group_of(lc, a) == gp && dc != 0.0) {  // same group: substitute row c's formula
-            const double f = v / dc;
+            const real f = v / dc;
             if (ln == 0) add(a.ncols + c, f);
             const int rc = merge_round_of(lc, a);
             const int32_t o = a.coff[c], len = a.clen[c];
             const int32_t* cc = a.rcol[rc] + o;
-            const double* cv = a.rval[rc] + o;
+            const real* cv = a.rval[rc] + o;
             for (int32_t e = ln; e < len; e += LANES) add(cc[e], a.fill ? -f * cv[e] : 0.0);
           } else if (ln == 0) {
             add(c, v);          // an earlier group (final), or a row that keeps its x (zero diagonal)
@@ -170,16 +170,16 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
     for (int32_t f = 0; f < cn; ++f) rank += (dkey[f] < ke);
     a.out_col[base + rank] = ke;
     a.out_val[base + rank] = dval[e];
-    part += fabs(dval[e]);
+    part += fabs((double)dval[e]);
   }
   atomicAdd(&s_sum[grp], part);  // (order of this sum does not matter: growth is a coarse guard, 1e4)
   __syncthreads();
   if (ln == 0) {
     a.clen_out[p] = cn;
     a.coff_out[p] = base;
-    const double d = a.pdiag[p];
+    const real d = a.pdiag[p];
     if (d != 0.0) {
-      const double gr = s_sum[grp] / fabs(d);
+      const double gr = s_sum[grp] / fabs((double)d);
       atomicMax(a.growth, (unsigned long long)__double_as_longlong(gr));
     }
   }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
 // D / omega (dscale = 1 / omega), Gauss-Seidel with D (dscale = 1).
 // min_tier: the smallest table worth trying (0: 128 slots, 1: 512, 2: 4096 — the caller knows the longest row of the
 // previous, shallower grouping; rows only grow with m)
-int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const double* d_diag, int m, bool backward, MergeDev* out,
+int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_diag, int m, bool backward, MergeDev* out,
                     int min_tier = 0) {
   const int64_t n = g->n;
   MergeDev& R = *out;
@@ -316,14 +316,14 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const double* 
 }
 
 // the composite rows as ONE contiguous CSR on the device (rows in level order): gather from the round pools
-__global__ void merge_gather_kernel(MergeArgs a, const int32_t* prow_new, int32_t* col, double* val) {
+__global__ void merge_gather_kernel(MergeArgs a, const int32_t* prow_new, int32_t* col, real* val) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.n) return;
   const int len = a.clen[p];
   if (len <= 0) return;
   const int rc = merge_round_of(a.lev_of[p], a);
   const int32_t* cc = a.rcol[rc] + a.coff[p];
-  const double* cv = a.rval[rc] + a.coff[p];
+  const real* cv = a.rval[rc] + a.coff[p];
   const int32_t dst = prow_new[p];
   for (int e = 0; e < len; ++e) { col[dst + e] = cc[e]; val[dst + e] = cv[e]; }
 }

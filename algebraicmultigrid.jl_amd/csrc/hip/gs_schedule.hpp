@@ -9,21 +9,21 @@ namespace {
 // Block-inverse data of one sweep direction: the outer matrix (operator minus the in-block triangle
 // and diagonal) and the dense inverses of the in-block triangles.
 int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n, const int32_t* rowptr, const int32_t* col,
-                      const double* val, const std::vector<double>& diag, double* max_cond) {
+                      const real* val, const std::vector<real>& diag, double* max_cond) {
   const int B = kBlk;
   const int nblk = (int)((n + B - 1) / B);
   // a few blocks only: an extra launch costs more than it saves, all couplings stay in the one sequential kernel
   const bool single = nblk <= kBlkSingle;
   std::vector<int32_t> orow(n + 1, 0), ocol, xrow(n + 1, 0), xcol, prow(n + 1, 0), pcol;
-  std::vector<double> oval, xval, pval;
+  std::vector<real> oval, xval, pval;
   ocol.reserve(rowptr[n]); oval.reserve(rowptr[n]);
   xcol.reserve(rowptr[n]); xval.reserve(rowptr[n]);
-  std::vector<double> tinv((size_t)nblk * B * B, 0.0), T((size_t)B * B);
+  std::vector<real> tinv((size_t)nblk * B * B, 0.0), T((size_t)B * B);
   // near list: outer entries of a block that reference the block swept just before it (blk - 1 forward, blk + 1
   // backward), as {position in the block's outer range, column - first row of that block} + value
   std::vector<int32_t> near_ptr(nblk + 1, 0);
   std::vector<i2_t> near_pi;
-  std::vector<double> near_val;
+  std::vector<real> near_val;
   for (int blk = 0; blk < nblk; ++blk) {
     const int64_t i0 = (int64_t)blk * B, i1 = std::min<int64_t>(i0 + B, n);
     const int64_t q0 = backward ? i0 + B : i0 - B;  // first row of the previously swept block
@@ -59,17 +59,17 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n,
     near_ptr[blk + 1] = (int32_t)near_pi.size();
     for (int64_t i = i1; i < i0 + B; ++i) T[(size_t)(i - i0) * B + (i - i0)] = 1.0;  // padding rows
     // invert the triangle column by column (forward / backward substitution on the identity)
-    double* X = tinv.data() + (size_t)blk * B * B;
+    real* X = tinv.data() + (size_t)blk * B * B;
     for (int c = 0; c < B; ++c) {
       if (!backward) {
         for (int i = c; i < B; ++i) {
-          double s = (i == c) ? 1.0 : 0.0;
+          real s = (i == c) ? 1.0 : 0.0;
           for (int j = c; j < i; ++j) s -= T[(size_t)i * B + j] * X[(size_t)j * B + c];
           X[(size_t)i * B + c] = s / T[(size_t)i * B + i];
         }
       } else {
         for (int i = c; i >= 0; --i) {
-          double s = (i == c) ? 1.0 : 0.0;
+          real s = (i == c) ? 1.0 : 0.0;
           for (int j = i + 1; j <= c; ++j) s -= T[(size_t)i * B + j] * X[(size_t)j * B + c];
           X[(size_t)i * B + c] = s / T[(size_t)i * B + i];
         }
@@ -144,13 +144,13 @@ struct HostLevelCsr {
   int64_t n = 0;
   int nlev = 0;
   std::vector<int32_t> lvl_ptr, prow, pcol, pdpos;
-  std::vector<double> pval, pdiag;
+  std::vector<real> pval, pdiag;
 };
 
 // ---- schedule construction on the device ------------------------------------------------------------------------------
 // rows of a level-ordered CSR copied into their slots (positions computed on the host: wmeta), padding stays zero
-__global__ void slot_fill_kernel(const int32_t* prow, const int32_t* pcol, const double* pval, const i4_t* wmeta, int n,
-                                 int32_t* wcol, double* wval) {
+__global__ void slot_fill_kernel(const int32_t* prow, const int32_t* pcol, const real* pval, const i4_t* wmeta, int n,
+                                 int32_t* wcol, real* wval) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const i4_t m = wmeta[p];
@@ -174,9 +174,9 @@ __global__ void lev_of_kernel(const int32_t* lvl_ptr, int nlev, int n, int32_t* 
   lev_of[p] = lo;
 }
 // the triangle (plus halo columns) a sweep direction does not substitute over, counted (tp == nullptr) or written
-__global__ void tri_kernel(const int32_t* prow, const int32_t* pcol, const double* pval, const double* pdiag,
-                           const int32_t* lev_of, int n, int backward, double diag_shift, const int32_t* tp, int32_t* tc,
-                           double* tv, int32_t* cnt) {
+__global__ void tri_kernel(const int32_t* prow, const int32_t* pcol, const real* pval, const real* pdiag,
+                           const int32_t* lev_of, int n, int backward, real diag_shift, const int32_t* tp, int32_t* tc,
+                           real* tv, int32_t* cnt) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const int lp = lev_of[p];
@@ -198,7 +198,7 @@ __global__ void tri_kernel(const int32_t* prow, const int32_t* pcol, const doubl
 }
 
 // s = b - T x pre-pass matrix of one direction, built on the device from the schedule's own level-ordered copy
-int tri_build_dev(GsSchedule::Tri* t, const GsSchedule* g, bool backward, int64_t* bytes, double diag_shift,
+int tri_build_dev(GsSchedule::Tri* t, const GsSchedule* g, bool backward, int64_t* bytes, real diag_shift,
                   int64_t* nnz_out) {
   const int64_t n = g->n;
   if (n <= 0) return AMGH_OK;
@@ -210,8 +210,8 @@ int tri_build_dev(GsSchedule::Tri* t, const GsSchedule* g, bool backward, int64_
   if (rc == AMGH_OK) {
     hipLaunchKernelGGL(lev_of_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)g->d_lvl_ptr, g->nlev, (int)n, lev_of);
     hipLaunchKernelGGL(tri_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)g->rowptr, (const int32_t*)g->col,
-                       (const double*)g->val, (const double*)g->diag, (const int32_t*)lev_of, (int)n, backward ? 1 : 0,
-                       diag_shift, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, cnt);
+                       (const real*)g->val, (const real*)g->diag, (const int32_t*)lev_of, (int)n, backward ? 1 : 0,
+                       diag_shift, (const int32_t*)nullptr, (int32_t*)nullptr, (real*)nullptr, cnt);
     rc = dev_alloc(&t->rowptr, n + 1);
   }
   if (rc == AMGH_OK) rc = dev_exclusive_scan(cnt, t->rowptr, n, &total, nullptr);
@@ -219,7 +219,7 @@ int tri_build_dev(GsSchedule::Tri* t, const GsSchedule* g, bool backward, int64_
   if (rc == AMGH_OK) rc = dev_alloc(&t->val, total);
   if (rc == AMGH_OK) {
     hipLaunchKernelGGL(tri_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)g->rowptr, (const int32_t*)g->col,
-                       (const double*)g->val, (const double*)g->diag, (const int32_t*)lev_of, (int)n, backward ? 1 : 0,
+                       (const real*)g->val, (const real*)g->diag, (const int32_t*)lev_of, (int)n, backward ? 1 : 0,
                        diag_shift, (const int32_t*)t->rowptr, t->col, t->val, (int32_t*)nullptr);
     if (hipDeviceSynchronize() != hipSuccess) rc = -1001;
   }
@@ -237,9 +237,9 @@ int tri_build_dev(GsSchedule::Tri* t, const GsSchedule* g, bool backward, int64_
 // narrow groups, rows too long for a slot); every other row lives in the slot arrays only.
 // dev_src (optional): the rows' entries are already on the device as a contiguous CSR (h.pcol / h.pval are empty; only
 // h.prow, the row lengths, is used on the host); ownership of the three arrays passes to this function.
-struct DevCsr { int32_t* rowptr = nullptr; int32_t* col = nullptr; double* val = nullptr; };
-__global__ void compact_rows_kernel(const int32_t* prow, const int32_t* pcol, const double* pval, const int32_t* cprow, int n,
-                                    int32_t* ccol, double* cval) {
+struct DevCsr { int32_t* rowptr = nullptr; int32_t* col = nullptr; real* val = nullptr; };
+__global__ void compact_rows_kernel(const int32_t* prow, const int32_t* pcol, const real* pval, const int32_t* cprow, int n,
+                                    int32_t* ccol, real* cval) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const int len = cprow[p + 1] - cprow[p];
@@ -252,7 +252,7 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
   const std::vector<int32_t>& prow = h.prow;
   const std::vector<int32_t>& pcol = h.pcol;
   const std::vector<int32_t>& pdpos = h.pdpos;
-  const std::vector<double>& pval = h.pval;
+  const std::vector<real>& pval = h.pval;
   const int64_t nnz = prow[n];
   g->n = n;
   g->nnz = nnz;
@@ -383,11 +383,11 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       RC_TRY(dev_alloc(&g->wcol, wtotal));
       RC_TRY(dev_alloc(&g->wval, wtotal));
       HIP_TRY(hipMemsetAsync(g->wcol, 0, sizeof(int32_t) * wtotal, nullptr));
-      HIP_TRY(hipMemsetAsync(g->wval, 0, sizeof(double) * wtotal, nullptr));
+      HIP_TRY(hipMemsetAsync(g->wval, 0, sizeof(real) * wtotal, nullptr));
       RC_TRY(dev_upload(&g->slot_row, sr2.data(), (int64_t)sr2.size()));
       RC_TRY(dev_upload(&g->wmeta, wmeta.data(), n));
       int32_t *t_row = nullptr, *t_col = nullptr;
-      double* t_val = nullptr;
+      real* t_val = nullptr;
       int rcf = AMGH_OK;
       if (dev_src) {
         t_row = dev_src->rowptr; t_col = dev_src->col; t_val = dev_src->val;
@@ -398,7 +398,7 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       }
       if (rcf == AMGH_OK) {
         hipLaunchKernelGGL(slot_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)t_row,
-                           (const int32_t*)t_col, (const double*)t_val, (const i4_t*)g->wmeta, (int)n, g->wcol, g->wval);
+                           (const int32_t*)t_col, (const real*)t_val, (const i4_t*)g->wmeta, (int)n, g->wcol, g->wval);
         if (hipDeviceSynchronize() != hipSuccess) rcf = -1001;
       }
       if (rcf == AMGH_OK && !compact) {  // the same arrays are this system's CSR copy
@@ -417,11 +417,11 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
   // the CSR copy (chain kernel, stream-kernel fallback): all rows, or — compact — only those no slot launch covers
   {
     std::vector<int32_t> cprow, ccol, cdpos;
-    std::vector<double> cval;
+    std::vector<real> cval;
     const std::vector<int32_t>* urow = &prow;
     const std::vector<int32_t>* ucol = &pcol;
     const std::vector<int32_t>* udpos = &pdpos;
-    const std::vector<double>* uval = &pval;
+    const std::vector<real>* uval = &pval;
     if (compact) {
       std::vector<char> keep(n, 0);
       for (const auto& sg : g->segs)
@@ -459,7 +459,7 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
         if (!dev_src->rowptr) RC_TRY(dev_upload(&dev_src->rowptr, prow.data(), n + 1));
         if (n > 0)
           hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
-                             (const int32_t*)dev_src->rowptr, (const int32_t*)dev_src->col, (const double*)dev_src->val,
+                             (const int32_t*)dev_src->rowptr, (const int32_t*)dev_src->col, (const real*)dev_src->val,
                              (const int32_t*)g->rowptr, (int)n, g->col, g->val);
         HIP_TRY(hipDeviceSynchronize());
       }
@@ -530,7 +530,7 @@ int sell_build(GsSchedule* g, const std::vector<int32_t>& prow) {
     const int32_t ra = g->lvl_ptr[sg.l0], rb = g->lvl_ptr[sg.l0 + 1];
     const int64_t threads = (int64_t)sg.sell_nchunks * kWave;
     hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr,
-                       (const int32_t*)g->rowptr, (const int32_t*)g->col, (const double*)g->val, (const i2_t*)g->schunk,
+                       (const int32_t*)g->rowptr, (const int32_t*)g->col, (const real*)g->val, (const i2_t*)g->schunk,
                        sg.sell_chunk0, sg.sell_nchunks, (int)ra, (int)(rb - ra), sg.sell_k, g->scol, g->sval);
   }
   HIP_TRY(hipDeviceSynchronize());
@@ -591,7 +591,7 @@ MergeGroups merge_groups(const HostLevelCsr& base, int m, bool backward) {
 // Returns the longest row, or INT32_MAX when a row outgrows a slot (the caller gives up on this m).
 struct MergeChunk {
   std::vector<int32_t> len, col;
-  std::vector<double> val;
+  std::vector<real> val;
   double growth = 0.0;  // max over rows of sum |composite coefficient| / |diagonal|
 };
 int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncols, int q0, int q1, MergeChunk* out,
@@ -599,10 +599,10 @@ int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncol
   constexpr int kCap = 4 * kBigSlot;  // open-addressing accumulator: rows longer than row_cap are rejected
   std::vector<int32_t> key(kCap, -1);
   std::vector<std::pair<int32_t, int32_t>> order;  // {column, accumulator slot} of the row being built
-  std::vector<double> acc(kCap);
+  std::vector<real> acc(kCap);
   std::vector<int64_t> off;       // per row of the current group: offset into gcol / gval
   std::vector<int32_t> gcol, glen;
-  std::vector<double> gval;
+  std::vector<real> gval;
   int64_t max_row = 0;
   const int32_t row0 = G.gptr[q0];
   out->len.assign(G.gptr[q1] - row0, 0);
@@ -622,7 +622,7 @@ int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncol
       const int lp = G.lev_of[p];
       order.clear();
       bool overflow = false;
-      auto add = [&](int32_t c, double v) {
+      auto add = [&](int32_t c, real v) {
         uint32_t h = ((uint32_t)c * 2654435761u) & (kCap - 1);
         while (key[h] != -1 && key[h] != c) h = (h + 1) & (kCap - 1);
         if (key[h] == -1) {
@@ -638,9 +638,9 @@ int64_t merge_chunk(const HostLevelCsr& base, const MergeGroups& G, int64_t ncol
         const int lc = G.lev_of[c];
         const bool tri = G.backward ? lc > lp : lc < lp;
         if (!tri) continue;                    // the other triangle belongs to the pre-pass
-        const double v = base.pval[j];
+        const real v = base.pval[j];
         if (c >= ga && c < gb && base.pdiag[c] != 0.0) {  // same group: substitute row c's formula
-          const double f = v / base.pdiag[c];
+          const real f = v / base.pdiag[c];
           add((int32_t)(ncols + c), f);
           const int32_t lc2 = c - ga;
           for (int64_t e = start[lc2]; e < start[lc2] + glen[lc2] && !overflow; ++e) add(gcol[e], -f * gval[e]);
@@ -743,7 +743,7 @@ MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool bac
     w += (int64_t)chunks[t].col.size();
     MergeChunk().len.swap(chunks[t].len);
     std::vector<int32_t>().swap(chunks[t].col);
-    std::vector<double>().swap(chunks[t].val);
+    std::vector<real>().swap(chunks[t].val);
   }
   for (int64_t p = 0; p < n; ++p) S.prow[p + 1] += S.prow[p];
   return R;
@@ -752,7 +752,11 @@ MergeResult merge_build(const HostLevelCsr& base, int64_t ncols, int m, bool bac
 // Substituted coefficients grow like prod |l_ij / d_j| along the chains inside a group: bounded by 1 for diagonally
 // dominant operators; a group whose composite rows outgrow this (relative to the diagonal) is not merged (the
 // same 1e-10 contract and reasoning as the condition guard of the block-inverse sweeps).
-constexpr double kMergeGrowthMax = 1e4;
+// (in Float32 the same amplification costs 2^29 times more relative accuracy: the guard tightens with the unit roundoff)
+// block-inverse sweeps replace the recurrence inside a block by a dense triangular inverse: accurate to cond * eps.
+// 1e4 in Float64; in Float32 the same error budget admits no block worth inverting, the sweeps stay exact-order.
+constexpr double kBlockCondMax = sizeof(real) == 8 ? 1e4 : 1e4 * 2.220446049250313e-16 / 1.1920929e-07;
+constexpr double kMergeGrowthMax = sizeof(real) == 8 ? 1e4 : 1e2;
 
 // estimated time of one sweep over a grouped system: a kernel boundary per group + streaming its entries
 double merge_cost(int64_t ngroups, int64_t nnz) { return ngroups * 3.8e-6 + 12.0 * (double)nnz / 2.5e12; }
@@ -775,7 +779,7 @@ struct BuildTimer {  // AMGH_VERBOSE: where the host time of a schedule build go
 
 // dependency levels of the symmetrised pattern, the level order (perm: level-ordered row -> original row) and
 // the matrix in that order (columns renumbered, entries of a row in their original order)
-void level_order(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const double* val,
+void level_order(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val,
                  HostLevelCsr& base, std::vector<int32_t>& perm) {
   std::vector<int32_t> lev(n, 0);
   int32_t maxlev = -1;
@@ -822,7 +826,7 @@ void level_order(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t*
     for (int64_t p = n * t / T; p < n * (t + 1) / T; ++p) {
       const int32_t i = perm[p];
       int32_t dp = -1;
-      double d = 0.0;
+      real d = 0.0;
       int64_t w = base.prow[p];
       for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
         base.pcol[w] = inv[col[j]];   // entries stay in the row's original column order (sum order)
@@ -837,7 +841,7 @@ void level_order(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t*
 }
 
 int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
-             const double* val) {
+             const real* val) {
   const int64_t n = nrows;
   BuildTimer tm;
   HostLevelCsr base;
@@ -862,7 +866,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   {
     const int nblk = (int)((n + kBlk - 1) / kBlk);
     if (g_gs_block_inverse && n >= 16 && n <= 262144 && g->nlev >= 3 * nblk) {
-      std::vector<double> dg(n, 0.0);
+      std::vector<real> dg(n, 0.0);
       for (int64_t i = 0; i < n; ++i)
         for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
           if (col[j] == i) dg[i] = val[j];
@@ -875,9 +879,9 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       g->blk_cond = max_cond;
       if (getenv("AMGH_VERBOSE"))
         fprintf(stderr, "[amghip] n=%lld dependency levels=%d index blocks=%d max triangle cond=%.3g -> %s\n", (long long)n,
-                g->nlev, nblk, max_cond, max_cond <= 1e4 ? "block-inverse sweeps" : "exact-order sweeps");
+                g->nlev, nblk, max_cond, max_cond <= kBlockCondMax ? "block-inverse sweeps" : "exact-order sweeps");
       // explicit triangle inverses lose ~cond * eps: keep the 1e-10 contract with margin
-      if (max_cond <= 1e4) {
+      if (max_cond <= kBlockCondMax) {
         g->nblk = nblk;
         g->bytes += 2 * ((int64_t)nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4) + n * 8;
       }
@@ -1109,7 +1113,7 @@ int gs_grow_xp_for_merged(GsSchedule* g, int64_t* op_bytes) {
 
 // Merged children for SOR with relaxation factor omega, built on demand from the level-ordered matrix already on
 // the device.  Returns the cache entry (children may be null: merging did not pay or was rejected).
-GsSchedule::SorSet* sor_children(GsSchedule* g, double omega) {
+GsSchedule::SorSet* sor_children(GsSchedule* g, real omega) {
   for (GsSchedule::SorSet& ss : g->sor)
     if (ss.built && ss.omega == omega) return &ss;
   GsSchedule::SorSet& ss = g->sor[g->sor_next];
@@ -1132,12 +1136,12 @@ GsSchedule::SorSet* sor_children(GsSchedule* g, double omega) {
   const int64_t nnz = base.prow[n];
   base.pcol.resize(nnz); base.pval.resize(nnz); base.pdpos.resize(n); base.pdiag.resize(n);
   if (hipMemcpy(base.pcol.data(), g->col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(base.pval.data(), g->val, sizeof(double) * nnz, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(base.pval.data(), g->val, sizeof(real) * nnz, hipMemcpyDeviceToHost) != hipSuccess ||
       hipMemcpy(base.pdpos.data(), g->dpos, sizeof(int32_t) * n, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(base.pdiag.data(), g->diag, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess)
+      hipMemcpy(base.pdiag.data(), g->diag, sizeof(real) * n, hipMemcpyDeviceToHost) != hipSuccess)
     return &ss;
   HostLevelCsr scaled = base;               // the triangular system SOR solves has the diagonal D / omega
-  for (double& dd : scaled.pdiag) dd /= omega;
+  for (real& dd : scaled.pdiag) dd /= omega;
   for (int dir = 0; dir < 2; ++dir) {
     const bool backward = dir == 1;
     double best = merge_cost(base.nlev, nnz);
@@ -1185,11 +1189,11 @@ int csr_ensure_gs(amgh_csr* op) {
   if (op->gs) return AMGH_OK;
   const int64_t n = op->nrows;
   std::vector<int32_t> rowptr(n + 1), col(op->nnz);
-  std::vector<double> val(op->nnz);
+  std::vector<real> val(op->nnz);
   HIP_TRY(hipMemcpy(rowptr.data(), op->rowptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToHost));
   if (op->nnz) {
     HIP_TRY(hipMemcpy(col.data(), op->col, sizeof(int32_t) * op->nnz, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(val.data(), op->val, sizeof(double) * op->nnz, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(val.data(), op->val, sizeof(real) * op->nnz, hipMemcpyDeviceToHost));
   }
   GsSchedule* g = new GsSchedule;
   int rc = gs_build(g, n, op->ncols, rowptr.data(), col.data(), val.data());

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._libs import COARSE_FN, AMGError, gpu_available, hip_check, hip_lib
+from ._libs import COARSE_FN, COARSE_FN_F32, AMGError, gpu_available, hip_check, hip_lib
 from .smoothers import Smoother
 from .sparse import SparseMatrixCSC
 
@@ -17,8 +17,9 @@ CYCLE_V, CYCLE_W, CYCLE_F = 0, 1, 2
 T_LABELS = ["Presmoother", "Residual eval", "Restriction", "Coarse solve", "Prolongation", "Postsmoother"]
 
 
-def require_gpu():
-    lib = hip_lib()
+def require_gpu(dtype=None):
+    """The library instance for element type `dtype` (None / float64: libamghip.so, float32: libamghip_f32.so)."""
+    lib = hip_lib(dtype)
     if lib.amgh_device_count() <= 0:
         raise AMGError("no HIP device visible: the AMG solve phase runs on MI355X only (no CPU fallback)")
     return lib
@@ -29,26 +30,27 @@ def _ptr(a):
 
 
 class DeviceBuffer:
-    """A device allocation of `n` doubles (amgh_dev_alloc / amgh_dev_free)."""
+    """A device allocation of `n` reals (amgh_dev_alloc / amgh_dev_free); dtype float64 (default) or float32."""
 
-    def __init__(self, n, device=0, host=None):
-        self.lib = require_gpu()
+    def __init__(self, n, device=0, host=None, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        self.lib = require_gpu(self.dtype)
         self.n = int(n)
         self.device = device
         p = C.c_void_p()
-        hip_check(self.lib.amgh_dev_alloc(device, 8 * max(self.n, 1), C.byref(p)), "dev_alloc")
+        hip_check(self.lib.amgh_dev_alloc(device, self.dtype.itemsize * max(self.n, 1), C.byref(p)), "dev_alloc")
         self.ptr = p.value
         if host is not None:
             self.upload(host)
 
     def upload(self, host):
-        host = np.ascontiguousarray(host, dtype=np.float64)
+        host = np.ascontiguousarray(host, dtype=self.dtype)
         assert host.size == self.n
-        hip_check(self.lib.amgh_dev_upload(self.device, self.ptr, host.ctypes.data, 8 * self.n), "upload")
+        hip_check(self.lib.amgh_dev_upload(self.device, self.ptr, host.ctypes.data, self.dtype.itemsize * self.n), "upload")
 
     def download(self):
-        out = np.empty(self.n, dtype=np.float64)
-        hip_check(self.lib.amgh_dev_download(self.device, out.ctypes.data, self.ptr, 8 * self.n), "download")
+        out = np.empty(self.n, dtype=self.dtype)
+        hip_check(self.lib.amgh_dev_download(self.device, out.ctypes.data, self.ptr, self.dtype.itemsize * self.n), "download")
         return out
 
     def __del__(self):
@@ -63,11 +65,12 @@ class DeviceBuffer:
 class DeviceCSR:
     """Stand-alone CSR operator on HBM (amgh_csr_*)."""
 
-    def __init__(self, nrows, ncols, rowptr, col, val, device=0):
-        self.lib = require_gpu()
+    def __init__(self, nrows, ncols, rowptr, col, val, device=0, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        self.lib = require_gpu(self.dtype)
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         col = np.ascontiguousarray(col, dtype=np.int32)
-        val = np.ascontiguousarray(val, dtype=np.float64)
+        val = np.ascontiguousarray(val, dtype=self.dtype)
         self.nrows, self.ncols, self.device = int(nrows), int(ncols), device
         h = C.c_void_p()
         hip_check(self.lib.amgh_csr_create(C.byref(h), device, nrows, ncols, _ptr(rowptr), _ptr(col), _ptr(val)),
@@ -86,23 +89,23 @@ class DeviceCSR:
         hip_check(self.lib.amgh_dev_sync(self.device), "sync")
 
     def spmv(self, x):
-        xd = DeviceBuffer(self.ncols, self.device, x)
-        yd = DeviceBuffer(self.nrows, self.device)
+        xd = DeviceBuffer(self.ncols, self.device, x, dtype=self.dtype)
+        yd = DeviceBuffer(self.nrows, self.device, dtype=self.dtype)
         hip_check(self.lib.amgh_csr_spmv_d(self.h, xd.ptr, yd.ptr, None), "csr_spmv")
         self.sync()
         return yd.download()
 
     def residual(self, x, b):
-        xd = DeviceBuffer(self.ncols, self.device, x)
-        bd = DeviceBuffer(self.nrows, self.device, b)
-        rd = DeviceBuffer(self.nrows, self.device)
+        xd = DeviceBuffer(self.ncols, self.device, x, dtype=self.dtype)
+        bd = DeviceBuffer(self.nrows, self.device, b, dtype=self.dtype)
+        rd = DeviceBuffer(self.nrows, self.device, dtype=self.dtype)
         hip_check(self.lib.amgh_csr_residual_d(self.h, xd.ptr, bd.ptr, rd.ptr, None), "csr_residual")
         self.sync()
         return rd.download()
 
     def spmv_add(self, x, y):
-        xd = DeviceBuffer(self.ncols, self.device, x)
-        yd = DeviceBuffer(self.nrows, self.device, y)
+        xd = DeviceBuffer(self.ncols, self.device, x, dtype=self.dtype)
+        yd = DeviceBuffer(self.nrows, self.device, y, dtype=self.dtype)
         hip_check(self.lib.amgh_csr_spmv_add_d(self.h, xd.ptr, yd.ptr, None), "csr_spmv_add")
         self.sync()
         return yd.download()
@@ -110,9 +113,9 @@ class DeviceCSR:
     def smooth(self, config, x, b):
         """Run `config.iter` sweeps in place on host vector x (returns new x)."""
         n = self.nrows
-        xd = DeviceBuffer(self.ncols, self.device, x)
-        bd = DeviceBuffer(n, self.device, b)
-        tmp = DeviceBuffer(self.ncols, self.device, x) if config.kind == 2 else None
+        xd = DeviceBuffer(self.ncols, self.device, x, dtype=self.dtype)
+        bd = DeviceBuffer(n, self.device, b, dtype=self.dtype)
+        tmp = DeviceBuffer(self.ncols, self.device, x, dtype=self.dtype) if config.kind == 2 else None
         cur, other = xd, tmp
         for _ in range(config.iter):
             if config.kind == 2:
@@ -141,22 +144,22 @@ def smoother_matrix_csr(A, symmetry):
     return A.csr_arrays()
 
 
-def smooth_standalone(config, A, x, b, symmetry=None):
+def smooth_standalone(config, A, x, b, symmetry=None, dtype=np.float64):
     from .hierarchy import HermitianSymmetry
     A = SparseMatrixCSC.coerce(A)
     if symmetry is not None and not isinstance(symmetry, HermitianSymmetry):
         config.check_no_symmetry(A)
     rp, ci, va = smoother_matrix_csr(A, symmetry)
-    op = DeviceCSR(A.m, A.n, rp, ci, va)
-    x[...] = op.smooth(config, np.asarray(x, dtype=np.float64), np.asarray(b, dtype=np.float64))
+    op = DeviceCSR(A.m, A.n, rp, ci, va, dtype=dtype)
+    x[...] = op.smooth(config, np.asarray(x, dtype=dtype), np.asarray(b, dtype=dtype))
 
 
 class DeviceHierarchy:
     """MultiLevel on HBM: amgh_create / push_level / set_coarse / finalize."""
 
-    def __init__(self, ml, device=0, nrhs=1):
+    def __init__(self, ml, device=0, nrhs=1, dtype=np.float64):
         from .hierarchy import HermitianSymmetry
-        self._open(device, nrhs, isinstance(ml.symmetry, HermitianSymmetry))
+        self._open(device, nrhs, isinstance(ml.symmetry, HermitianSymmetry), dtype)
         for lev in ml.levels:
             self.push_begin(lev.A, lev.presmoother, lev.postsmoother)
             self.push_end(lev)
@@ -165,13 +168,14 @@ class DeviceHierarchy:
     # ---- construction, level by level (the setup phase drives these itself when it builds on the GPU: push_begin
     # ---- of a level runs on a worker thread while the host does that level's C/F splitting) ------------------------
     @classmethod
-    def incremental(cls, device, nrhs, hermitian):
+    def incremental(cls, device, nrhs, hermitian, dtype=np.float64):
         self = cls.__new__(cls)
-        self._open(device, nrhs, hermitian)
+        self._open(device, nrhs, hermitian, dtype)
         return self
 
-    def _open(self, device, nrhs, hermitian):
-        self.lib = require_gpu()
+    def _open(self, device, nrhs, hermitian, dtype=np.float64):
+        self.dtype = np.dtype(dtype)      # the arithmetic type of this handle: libamghip.so or its Float32 instance
+        self.lib = require_gpu(self.dtype)
         self.device = device
         self.ml = None
         self.nrhs = int(nrhs)
@@ -188,9 +192,10 @@ class DeviceHierarchy:
         t_lev = time.perf_counter()
         n = A.m
         Ar, Ac, Av = A.csr_arrays()                  # true A rows
+        Av = self._vals(Av)
         t_arr = time.perf_counter() - t_lev
         if self.hermitian and not A.is_symmetric():
-            Sr, Sc, Sv = A.colptr, A.rowval, A.nzval  # column i read as row i
+            Sr, Sc, Sv = A.colptr, A.rowval, self._vals(A.nzval)  # column i read as row i
         else:
             Sr = Sc = Sv = None                      # S == A
         for s in (presmoother, postsmoother):
@@ -207,8 +212,8 @@ class DeviceHierarchy:
         """amgh_push_level_end: P and R of the level whose A was pushed last."""
         n, nc = lev.A.m, lev.P.n
         # CSR of P (n x nc) = CSC arrays of R (nc x n), and vice versa.
-        Pr, Pc, Pv = lev.R.colptr, lev.R.rowval, lev.R.nzval
-        Rr, Rc, Rv = lev.P.colptr, lev.P.rowval, lev.P.nzval
+        Pr, Pc, Pv = lev.R.colptr, lev.R.rowval, self._vals(lev.R.nzval)
+        Rr, Rc, Rv = lev.P.colptr, lev.P.rowval, self._vals(lev.P.nzval)
         if lev.R.shape != (nc, n) or lev.P.shape != (n, nc):
             raise AMGError("Level: P must be n x nc and R nc x n")
         hip_check(self.lib.amgh_push_level_end(self.h, nc, _ptr(Pr), _ptr(Pc), _ptr(Pv), _ptr(Rr), _ptr(Rc), _ptr(Rv)),
@@ -218,14 +223,19 @@ class DeviceHierarchy:
         """amgh_push_level_abort: the level begun last turned out to be the coarsest one."""
         hip_check(self.lib.amgh_push_level_abort(self.h), "push_level_abort")
 
+    def _vals(self, v):
+        """Matrix values in this handle's arithmetic type (the host mirror stores Float64 throughout)."""
+        return v if self.dtype.itemsize == 8 else np.ascontiguousarray(v, dtype=self.dtype)
+
     def finish(self, ml):
         """Coarsest level + amgh_finalize; `ml` is the hierarchy the pushed levels belong to."""
         self.ml = ml
         fA = ml.final_A
         fr, fc, fv = fA.csr_arrays()
+        fv = self._vals(fv)
         cs = ml.coarse_solver
         if getattr(cs, "uses_dense", lambda: True)():
-            op = np.asfortranarray(cs.dense_operator(), dtype=np.float64)
+            op = np.asfortranarray(cs.dense_operator(), dtype=self.dtype)
             hip_check(self.lib.amgh_set_coarse(self.h, fA.m, _ptr(fr), _ptr(fc), _ptr(fv), _ptr(op)), "set_coarse")
         else:
             # pluggable host coarse solver: the reference's `(cs)(x, b)` protocol
@@ -233,11 +243,11 @@ class DeviceHierarchy:
                 try:
                     b = np.ctypeslib.as_array(bp, shape=(n,))
                     x = np.ctypeslib.as_array(xp, shape=(n,))
-                    x[...] = cs.host_solve(b)
+                    x[...] = cs.host_solve(np.asarray(b, dtype=np.float64))
                     return 0
                 except Exception:  # never let an exception cross the C boundary
                     return 1
-            self._coarse_cb = COARSE_FN(_cb)
+            self._coarse_cb = (COARSE_FN if self.dtype.itemsize == 8 else COARSE_FN_F32)(_cb)
             hip_check(self.lib.amgh_set_coarse_host(self.h, fA.m, _ptr(fr), _ptr(fc), _ptr(fv), self._coarse_cb, None),
                       "set_coarse_host")
         hip_check(self.lib.amgh_finalize(self.h), "finalize")
@@ -254,9 +264,9 @@ class DeviceHierarchy:
     # ---- solve phase ---------------------------------------------------------
     def solve(self, b, x0, cycle, maxiter, abstol, reltol, calculate_residual, log):
         # n x bs blocks travel column-major, as Julia holds them
-        b = np.asfortranarray(b, dtype=np.float64)
-        x = np.array(x0, dtype=np.float64, copy=True, order="F")
-        hist = np.zeros(maxiter + 1, dtype=np.float64)
+        b = np.asfortranarray(b, dtype=self.dtype)
+        x = np.array(x0, dtype=self.dtype, copy=True, order="F")
+        hist = np.zeros(maxiter + 1, dtype=self.dtype)
         iters = C.c_int(0)
         hip_check(self.lib.amgh_solve(self.h, b.ctypes.data, x.ctypes.data, cycle, maxiter, abstol, reltol,
                                       int(bool(calculate_residual)), hist.ctypes.data, C.byref(iters)), "solve")
@@ -264,17 +274,17 @@ class DeviceHierarchy:
         return x, hist[:n_hist].copy(), iters.value
 
     def precond_apply(self, r, cycle=CYCLE_V):
-        r = np.asfortranarray(r, dtype=np.float64)
+        r = np.asfortranarray(r, dtype=self.dtype)
         z = np.empty_like(r, order="F")
         hip_check(self.lib.amgh_precond_apply(self.h, r.ctypes.data, z.ctypes.data, cycle), "precond_apply")
         return z
 
     def pcg(self, b, cycle=CYCLE_V, use_precond=True, maxiter=None, abstol=0.0, reltol=None):
-        b = np.ascontiguousarray(b, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=self.dtype)
         maxiter = self.n if maxiter is None else int(maxiter)
-        reltol = float(np.sqrt(np.finfo(np.float64).eps)) if reltol is None else float(reltol)
+        reltol = float(np.sqrt(np.finfo(self.dtype).eps)) if reltol is None else float(reltol)
         x = np.zeros_like(b)
-        hist = np.zeros(maxiter + 1, dtype=np.float64)
+        hist = np.zeros(maxiter + 1, dtype=self.dtype)
         iters = C.c_int(0)
         hip_check(self.lib.amgh_pcg(self.h, b.ctypes.data, x.ctypes.data, cycle, int(bool(use_precond)), maxiter,
                                     abstol, reltol, hist.ctypes.data, C.byref(iters)), "pcg")
@@ -282,9 +292,9 @@ class DeviceHierarchy:
 
     # ---- per-level hooks -----------------------------------------------------
     def spmv(self, level, which, x):
-        x = np.ascontiguousarray(x, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=self.dtype)
         nr = self._op_rows(level, which)
-        y = np.empty(nr, dtype=np.float64)
+        y = np.empty(nr, dtype=self.dtype)
         hip_check(self.lib.amgh_level_spmv(self.h, level, which, x.ctypes.data, y.ctypes.data), "level_spmv")
         return y
 
@@ -296,8 +306,8 @@ class DeviceHierarchy:
         return lev.P.n if which == OP_R else lev.A.m
 
     def smooth(self, level, post, x, b):
-        x = np.array(x, dtype=np.float64, copy=True)
-        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.array(x, dtype=self.dtype, copy=True)
+        b = np.ascontiguousarray(b, dtype=self.dtype)
         hip_check(self.lib.amgh_level_smooth(self.h, level, int(post), x.ctypes.data, b.ctypes.data), "level_smooth")
         return x
 

@@ -301,13 +301,15 @@ class MultiLevel:
     def __len__(self):
         return len(self.levels) + 1
 
-    def device(self, device=0, nrhs=1):
+    def device(self, device=0, nrhs=1, dtype=None):
         """The HBM-resident hierarchy (libamghip handle) for workspace block size `nrhs`
-        (the reference's `Val{bs}`, multilevel.jl:28-35); built on first use."""
-        key = (device, int(nrhs))
+        (the reference's `Val{bs}`, multilevel.jl:28-35); built on first use.  dtype: the arithmetic type of the
+        handle — float64 (default), or float32 = the Float32 instance of the library (eltype(A) == Float32)."""
+        f32 = dtype is not None and np.dtype(dtype).itemsize == 4
+        key = (device, int(nrhs), "f32") if f32 else (device, int(nrhs))
         if key not in self._dev:
             from .device import DeviceHierarchy
-            self._dev[key] = DeviceHierarchy(self, device, int(nrhs))
+            self._dev[key] = DeviceHierarchy(self, device, int(nrhs), np.float32 if f32 else np.float64)
         return self._dev[key]
 
     def __repr__(self):

@@ -37,21 +37,33 @@ def _cycle_code(cycle):
 _SQRT_EPS = float(np.sqrt(np.finfo(np.float64).eps))
 
 
-def _solve_inplace(x, ml, b, cycle=None, maxiter=100, abstol=0.0, reltol=_SQRT_EPS, verbose=False, log=False,
+def _arith_dtype(ml, b):
+    """The arithmetic type of a solve: Float32 when the hierarchy AND the right-hand side are Float32 (then every
+    operation of the reference's generic code is a Float32 one: multilevel.jl:154,166, test/runtests.jl:244-259) —
+    the Float32 instance of the library runs it; any mix promotes to Float64 as promote_type does."""
+    A0 = ml.levels[0].A if ml.levels else ml.final_A
+    return np.dtype(np.float32 if (A0.eltype == np.float32 and np.asarray(b).dtype == np.float32) else np.float64)
+
+
+def _solve_inplace(x, ml, b, cycle=None, maxiter=100, abstol=0.0, reltol=None, verbose=False, log=False,
                    calculate_residual=True, **kwargs):
     """`_solve!(x, ml, b, cycle; maxiter, abstol, reltol, verbose, log, calculate_residual)`
-    (multilevel.jl:158-198).  x is the initial guess and is overwritten."""
+    (multilevel.jl:158-198).  x is the initial guess and is overwritten.
+    reltol defaults to sqrt(eps(real(eltype(b)))) (multilevel.jl:162)."""
     if not isinstance(ml, MultiLevel):
         raise AMGError("ml must be a MultiLevel")
-    b = np.asarray(b, dtype=np.float64)
+    dt = _arith_dtype(ml, b)
+    if reltol is None:
+        reltol = float(np.sqrt(np.finfo(np.float32 if np.asarray(b).dtype == np.float32 else np.float64).eps))
+    b = np.asarray(b, dtype=dt)
     if b.ndim not in (1, 2):
         raise AMGError("b must be a vector or an n x bs matrix")
     n = ml.levels[0].A.m if ml.levels else ml.final_A.m
     if b.shape[0] != n or x.shape != b.shape:
         raise AMGError("DimensionMismatch: x, b must have length size(A, 1)")
     bs = 1 if b.ndim == 1 else b.shape[1]   # workspace block size (`Val{bs}`, multilevel.jl:28-35)
-    xs, hist, iters = ml.device(nrhs=bs).solve(b, x, _cycle_code(cycle), int(maxiter), float(abstol),
-                                               float(reltol), calculate_residual, log)
+    xs, hist, iters = ml.device(nrhs=bs, dtype=dt).solve(b, x, _cycle_code(cycle), int(maxiter), float(abstol),
+                                                         float(reltol), calculate_residual, log)
     x[...] = xs
     if verbose and calculate_residual:
         for i in range(iters):
@@ -63,18 +75,14 @@ def _solve(ml, b, cycle=None, **kwargs):
     """`_solve(ml, b[, cycle]; kwargs...)`: x = zeros, then `_solve!` (multilevel.jl:152-157).
 
     Element type: the reference returns `promote_type(eltype(ml.workspace), eltype(b))`
-    (multilevel.jl:154; test/runtests.jl:244-259).  The HIP path always computes in f64; a Float32
-    hierarchy with a Float32 right-hand side gets its result rounded to Float32 to keep that contract."""
+    (multilevel.jl:154; test/runtests.jl:244-259).  Float32 hierarchy + Float32 right-hand side: the whole solve runs
+    in Float32 on the library's Float32 instance; any mix: Float64."""
+    dt = _arith_dtype(ml, b)
     b_in = np.asarray(b)
-    b = np.asarray(b, dtype=np.float64)
-    x = np.zeros_like(b)
-    out = _solve_inplace(x, ml, b, cycle, **kwargs)
-    A0 = ml.levels[0].A if ml.levels else ml.final_A
-    if A0.eltype == np.float32 and b_in.dtype == np.float32:
-        if isinstance(out, tuple):
-            return out[0].astype(np.float32), out[1].astype(np.float32)
-        return out.astype(np.float32)
-    return out
+    x = np.zeros(b_in.shape, dtype=dt)
+    if dt == np.float64 and b_in.dtype == np.float32 and "reltol" not in kwargs:
+        kwargs = dict(kwargs, reltol=float(np.sqrt(np.finfo(np.float32).eps)))   # eltype(b) sets the default tolerance
+    return _solve_inplace(x, ml, b_in if dt == np.float32 else np.asarray(b_in, dtype=np.float64), cycle, **kwargs)
 
 
 # ---- CommonSolve-style adapter (multilevel.jl:241-264) ------------------------
@@ -179,10 +187,11 @@ class Preconditioner:
 
     def ldiv(self, b, x=None):
         """ldiv!(x, p, b): x .= 0 then exactly one cycle without residual (preconditioner.jl:12-19)."""
-        b = np.asarray(b, dtype=np.float64)
+        dt = _arith_dtype(self.ml, b)
+        b = np.asarray(b, dtype=dt)
         if self.init == "zero":
             bs = 1 if b.ndim == 1 else b.shape[1]
-            z = self.ml.device(nrhs=bs).precond_apply(b, _cycle_code(self.cycle))
+            z = self.ml.device(nrhs=bs, dtype=dt).precond_apply(b, _cycle_code(self.cycle))
         else:
             z = b.copy()
             _solve_inplace(z, self.ml, b, self.cycle, maxiter=1, calculate_residual=False)

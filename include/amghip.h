@@ -34,6 +34,17 @@
 extern "C" {
 #endif
 
+/* The element type of matrices and vectors: the reference's hierarchy is generic in eltype(A)
+ * (multilevel.jl:14-21, test/runtests.jl:244-259 runs Float64 and Float32).  libamghip.so is the
+ * Float64 instance; libamghip_f32.so is the same source compiled with -DAMGH_REAL=float and exports
+ * the same entry points with amgh_real = float (the solve-phase handle and the stand-alone operators;
+ * scalar parameters — tolerances, relaxation factors, timings — stay double in both).  A caller picks
+ * the library by eltype, as the Julia method table would (julia/AMGHip.jl).                          */
+#ifndef AMGH_REAL
+#define AMGH_REAL double
+#endif
+typedef AMGH_REAL amgh_real;
+
 typedef struct amgh_handle amgh_t; /* MultiLevel on HBM   (multilevel.jl:14-21) */
 typedef struct amgh_csr amgh_csr_t; /* one CSR operator on HBM                   */
 
@@ -91,10 +102,10 @@ void amgh_destroy(amgh_t* h);
  *       sweeps act on the true rows, S = A.  Pass S_rowptr = NULL for S == A.
  *   P : n x nc CSR,  R : nc x n CSR  (multilevel.jl:223,233).                  */
 int amgh_push_level(amgh_t* h, int64_t n, int64_t nc,
-                    const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
-                    const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
-                    const int32_t* P_rowptr, const int32_t* P_col, const double* P_val,
-                    const int32_t* R_rowptr, const int32_t* R_col, const double* R_val,
+                    const int32_t* A_rowptr, const int32_t* A_col, const amgh_real* A_val,
+                    const int32_t* S_rowptr, const int32_t* S_col, const amgh_real* S_val,
+                    const int32_t* P_rowptr, const int32_t* P_col, const amgh_real* P_val,
+                    const int32_t* R_rowptr, const int32_t* R_col, const amgh_real* R_val,
                     const amgh_smoother_t* pre, const amgh_smoother_t* post);
 
 /* The same push in two halves, for a caller that knows A before P and R — the setup phase itself
@@ -103,12 +114,12 @@ int amgh_push_level(amgh_t* h, int64_t n, int64_t nc,
  * appends the level.  _begin may run on another host thread while the caller computes P and R (one
  * pending level per handle; every other call on the handle between the two returns AMGH_ESTATE).        */
 int amgh_push_level_begin(amgh_t* h, int64_t n,
-                          const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
-                          const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
+                          const int32_t* A_rowptr, const int32_t* A_col, const amgh_real* A_val,
+                          const int32_t* S_rowptr, const int32_t* S_col, const amgh_real* S_val,
                           const amgh_smoother_t* pre, const amgh_smoother_t* post);
 int amgh_push_level_end(amgh_t* h, int64_t nc,
-                        const int32_t* P_rowptr, const int32_t* P_col, const double* P_val,
-                        const int32_t* R_rowptr, const int32_t* R_col, const double* R_val);
+                        const int32_t* P_rowptr, const int32_t* P_col, const amgh_real* P_val,
+                        const int32_t* R_rowptr, const int32_t* R_col, const amgh_real* R_val);
 /* Drops the begun level instead (coarsening stopped: size(P, 2) == 0, classical.jl:43).                */
 int amgh_push_level_abort(amgh_t* h);
 
@@ -120,7 +131,7 @@ int amgh_push_level_abort(amgh_t* h);
  * hierarchy has no levels (multilevel.jl:179-180 + residual :188); may be NULL
  * otherwise.                                                                    */
 int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col,
-                    const double* A_val, const double* dense_op);
+                    const amgh_real* A_val, const amgh_real* dense_op);
 
 /* Pluggable coarse solver run on the HOST — the counterpart of the reference's
  * coarse-solver protocol `(cs)(x, b)` (coarse_solver.jl:2,35-42,75-81; e.g.
@@ -128,9 +139,9 @@ int amgh_set_coarse(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t
  * operator).  Each coarse solve copies b to the host, calls fn(user, b, x), copies
  * x back (two PCIe hops + a stream sync; meant for large or exotic coarse
  * problems, not for the default path).  fn returns 0 on success.               */
-typedef int (*amgh_coarse_fn)(void* user, const double* b_host, double* x_host, int64_t n);
+typedef int (*amgh_coarse_fn)(void* user, const amgh_real* b_host, amgh_real* x_host, int64_t n);
 int amgh_set_coarse_host(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col,
-                         const double* A_val, amgh_coarse_fn fn, void* user);
+                         const amgh_real* A_val, amgh_coarse_fn fn, void* user);
 
 /* Allocates the workspace (res_vecs, coarse_xs, coarse_bs), builds the
  * Gauss-Seidel dependency schedules.  Must be called once before any solve.     */
@@ -165,24 +176,24 @@ int amgh_gs_sweep_stats(const amgh_t* h, int l, int backward, int64_t* out6);
  * caller (the max(reltol*norm(b), abstol) rule of :170-173 is applied inside).
  * resid_hist: NULL or maxiter+1 doubles; [0] = norm(b), [k] = residual after
  * cycle k (the `log=true` vector, :169,174,191).  *iters = cycles performed.    */
-int amgh_solve(amgh_t* h, const double* b, double* x, int cycle, int maxiter,
+int amgh_solve(amgh_t* h, const amgh_real* b, amgh_real* x, int cycle, int maxiter,
                double abstol, double reltol, int calculate_residual,
-               double* resid_hist, int* iters);
-int amgh_solve_d(amgh_t* h, const double* b_d, double* x_d, int cycle, int maxiter,
+               amgh_real* resid_hist, int* iters);
+int amgh_solve_d(amgh_t* h, const amgh_real* b_d, amgh_real* x_d, int cycle, int maxiter,
                  double abstol, double reltol, int calculate_residual,
-                 double* resid_hist /*host*/, int* iters);
+                 amgh_real* resid_hist /*host*/, int* iters);
 
 /* ldiv!(x, p::Preconditioner, b): x .= 0; exactly one cycle, no residual
  * (preconditioner.jl:12-19).  The _d form only enqueues on the handle's stream
  * (no synchronisation) so that a caller-side Krylov loop can stay asynchronous. */
-int amgh_precond_apply(amgh_t* h, const double* r, double* z, int cycle);
-int amgh_precond_apply_d(amgh_t* h, const double* r_d, double* z_d, int cycle);
+int amgh_precond_apply(amgh_t* h, const amgh_real* r, amgh_real* z, int cycle);
+int amgh_precond_apply_d(amgh_t* h, const amgh_real* r_d, amgh_real* z_d, int cycle);
 
 /* One `__solve!(x, ml, cycle, b, lvl)` (multilevel.jl:214-239) starting at level `level` on
  * caller-provided device vectors of that level's size; x is NOT zeroed (the W/F re-entry of
  * multilevel.jl:204-212 continues from the current x).  Enqueue only, no synchronisation.
  * Used by the row-sharded multi-GPU driver for the levels collapsed onto rank 0.        */
-int amgh_cycle_d(amgh_t* h, int level, double* x_d, const double* b_d, int cycle);
+int amgh_cycle_d(amgh_t* h, int level, amgh_real* x_d, const amgh_real* b_d, int cycle);
 /* Make the handle enqueue on the caller's hipStream_t (e.g. torch's current stream);
  * NULL selects the default (null) stream.                                               */
 int amgh_set_stream(amgh_t* h, void* stream);
@@ -192,62 +203,62 @@ int amgh_set_stream(amgh_t* h, void* stream);
  * runtests.jl:186,204, README.md:54-56).  IterativeSolvers.jl's PCG recurrence,
  * entirely on device; x0 = 0.  use_precond = 0 gives plain CG.
  * resid_hist: NULL or maxiter+1 doubles ([0] = norm(b)).                         */
-int amgh_pcg(amgh_t* h, const double* b, double* x, int cycle, int use_precond,
-             int maxiter, double abstol, double reltol, double* resid_hist, int* iters);
-int amgh_pcg_d(amgh_t* h, const double* b_d, double* x_d, int cycle, int use_precond,
-               int maxiter, double abstol, double reltol, double* resid_hist, int* iters);
+int amgh_pcg(amgh_t* h, const amgh_real* b, amgh_real* x, int cycle, int use_precond,
+             int maxiter, double abstol, double reltol, amgh_real* resid_hist, int* iters);
+int amgh_pcg_d(amgh_t* h, const amgh_real* b_d, amgh_real* x_d, int cycle, int use_precond,
+               int maxiter, double abstol, double reltol, amgh_real* resid_hist, int* iters);
 
 /* ------------------------------------------------------------------------- */
 /* Per-level operators — unit-test and roofline hooks                           */
 /* ------------------------------------------------------------------------- */
 /* mul!(y, M, x) with M = levels[l].A | .P | .R (multilevel.jl:188,219,223,233) */
-int amgh_level_spmv(amgh_t* h, int level, int which, const double* x, double* y);
-int amgh_level_spmv_d(amgh_t* h, int level, int which, const double* x_d, double* y_d);
+int amgh_level_spmv(amgh_t* h, int level, int which, const amgh_real* x, amgh_real* y);
+int amgh_level_spmv_d(amgh_t* h, int level, int which, const amgh_real* x_d, amgh_real* y_d);
 /* res = b - A x  (multilevel.jl:219-220)                                        */
-int amgh_level_residual_d(amgh_t* h, int level, const double* x_d, const double* b_d, double* r_d);
+int amgh_level_residual_d(amgh_t* h, int level, const amgh_real* x_d, const amgh_real* b_d, amgh_real* r_d);
 /* smooth!(x, levels[l].presmoother | .postsmoother, b)  (smoother.jl:61-90,
  * 113-141, 193-221); post = 0 | 1                                               */
-int amgh_level_smooth(amgh_t* h, int level, int post, double* x, const double* b);
-int amgh_level_smooth_d(amgh_t* h, int level, int post, double* x_d, const double* b_d);
+int amgh_level_smooth(amgh_t* h, int level, int post, amgh_real* x, const amgh_real* b);
+int amgh_level_smooth_d(amgh_t* h, int level, int post, amgh_real* x_d, const amgh_real* b_d);
 
 /* ------------------------------------------------------------------------- */
 /* Stand-alone CSR operators on HBM (used by the row-sharded multi-GPU driver,  */
 /* where each rank holds n_local x (n_local + n_halo) blocks, and by tests).     */
 /* ------------------------------------------------------------------------- */
 int amgh_csr_create(amgh_csr_t** op, int device, int64_t nrows, int64_t ncols,
-                    const int32_t* rowptr, const int32_t* col, const double* val);
+                    const int32_t* rowptr, const int32_t* col, const amgh_real* val);
 void amgh_csr_destroy(amgh_csr_t* op);
 /* Build the smoother metadata of the operator now instead of at the first sweep: jacobi != 0 the
  * diagonal table, gs != 0 the Gauss-Seidel dependency schedule (host work + uploads).       */
 int amgh_csr_prepare(amgh_csr_t* op, int jacobi, int gs);
 /* y = M x ; y = b - M x ; y += M x   (device pointers; stream = hipStream_t or NULL) */
-int amgh_csr_spmv_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream);
-int amgh_csr_residual_d(amgh_csr_t* op, const double* x_d, const double* b_d, double* r_d, void* stream);
-int amgh_csr_spmv_add_d(amgh_csr_t* op, const double* x_d, double* y_d, void* stream);
+int amgh_csr_spmv_d(amgh_csr_t* op, const amgh_real* x_d, amgh_real* y_d, void* stream);
+int amgh_csr_residual_d(amgh_csr_t* op, const amgh_real* x_d, const amgh_real* b_d, amgh_real* r_d, void* stream);
+int amgh_csr_spmv_add_d(amgh_csr_t* op, const amgh_real* x_d, amgh_real* y_d, void* stream);
 /* one damped-Jacobi sweep on the leading nrows x nrows block's diagonal:
  * xout[i] = (1-w) xin[i] + w (b[i] - sum_{j != i} m_ij xin[j]) / m_ii ; rows with
  * m_ii == 0 keep xin[i] (smoother.jl:113-141).  xin has ncols entries (halo
  * included), xout nrows.                                                        */
-int amgh_csr_jacobi_d(amgh_csr_t* op, double omega, const double* xin_d, const double* b_d,
-                      double* xout_d, void* stream);
+int amgh_csr_jacobi_d(amgh_csr_t* op, double omega, const amgh_real* xin_d, const amgh_real* b_d,
+                      amgh_real* xout_d, void* stream);
 /* Gauss-Seidel / SOR sweep in exact lexicographic order over the leading
  * nrows x nrows block (columns >= nrows are halo entries held fixed);
  * backward != 0 sweeps n..1.  omega = 1 is Gauss-Seidel (smoother.jl:61-90),
  * otherwise SOR (:193-221).                                                     */
-int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d,
-                  const double* b_d, void* stream);
+int amgh_csr_gs_d(amgh_csr_t* op, int backward, double omega, int is_sor, amgh_real* x_d,
+                  const amgh_real* b_d, void* stream);
 /* amgh_csr_gs_d with hints.  AMGH_GS_REUSE_B: b_d holds the same values as in the previous sweep on this operator
  * (the sweeps of one smooth! call, the post-smoother after the pre-smoother of a cycle): its dependency-level-ordered
  * copy is still in place and is not gathered again. */
 #define AMGH_GS_REUSE_B 1
-int amgh_csr_gs_ex_d(amgh_csr_t* op, int backward, double omega, int is_sor, double* x_d, const double* b_d,
+int amgh_csr_gs_ex_d(amgh_csr_t* op, int backward, double omega, int is_sor, amgh_real* x_d, const amgh_real* b_d,
                      void* stream, int flags);
 
 /* dst[i] = src[idx[i]], i < n  — halo pack / unpack (device pointers).              */
-int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const double* src_d, double* dst_d, void* stream);
+int amgh_gather_d(int device, int64_t n, const int32_t* idx_d, const amgh_real* src_d, amgh_real* dst_d, void* stream);
 /* *out (HOST) = sum_i x[i]*y[i] over device vectors; deterministic two-pass wavefront
  * reduction; synchronises `stream`.  scratch_d: >= 1025 doubles of device scratch.  */
-int amgh_dot_d(int device, int64_t n, const double* x_d, const double* y_d, double* scratch_d, double* out,
+int amgh_dot_d(int device, int64_t n, const amgh_real* x_d, const amgh_real* y_d, amgh_real* scratch_d, amgh_real* out,
                void* stream);
 
 /* ------------------------------------------------------------------------- */
@@ -291,10 +302,10 @@ void amgh_dist_destroy(amgh_dist_t* d);
  * (crow_cuts = 0,..,0,nc,..,nc), which passes the collapsed levels to amgh_dist_set_tail.           */
 int amgh_dist_push_level(amgh_dist_t* d, int64_t n_global, int64_t nc_global,
                          const int64_t* row_cuts, const int64_t* crow_cuts,
-                         const int32_t* A_rowptr, const int32_t* A_col, const double* A_val,
-                         const int32_t* S_rowptr, const int32_t* S_col, const double* S_val,
-                         const int32_t* P_rowptr, const int32_t* P_col, const double* P_val,
-                         const int32_t* R_rowptr, const int32_t* R_col, const double* R_val,
+                         const int32_t* A_rowptr, const int32_t* A_col, const amgh_real* A_val,
+                         const int32_t* S_rowptr, const int32_t* S_col, const amgh_real* S_val,
+                         const int32_t* P_rowptr, const int32_t* P_col, const amgh_real* P_val,
+                         const int32_t* R_rowptr, const int32_t* R_col, const amgh_real* R_val,
                          const amgh_smoother_t* pre, const amgh_smoother_t* post);
 /* The collapsed levels: a finalized single-GPU handle (nrhs = 1, same device) holding levels lc.. and
  * the coarse solver, on the rank that owns them; NULL elsewhere.  Borrowed, not owned; its stream
@@ -308,13 +319,13 @@ int amgh_dist_local_range(const amgh_dist_t* d, int level, int64_t* r0, int64_t*
 /* ldiv! / _solve! on this rank's rows of the fine vectors (device pointers; collective).
  * amgh_dist_precond_apply_d only enqueues (amgh_dist_sync waits); amgh_dist_solve_d returns after
  * the last iteration; its stopping test uses the global residual norm (identical on every rank).     */
-int amgh_dist_precond_apply_d(amgh_dist_t* d, const double* r_loc_d, double* z_loc_d, int cycle);
-int amgh_dist_solve_d(amgh_dist_t* d, const double* b_loc_d, double* x_loc_d, int cycle, int maxiter,
+int amgh_dist_precond_apply_d(amgh_dist_t* d, const amgh_real* r_loc_d, amgh_real* z_loc_d, int cycle);
+int amgh_dist_solve_d(amgh_dist_t* d, const amgh_real* b_loc_d, amgh_real* x_loc_d, int cycle, int maxiter,
                       double abstol, double reltol, int calculate_residual,
-                      double* resid_hist /*host*/, int* iters);
+                      amgh_real* resid_hist /*host*/, int* iters);
 /* y_loc = A_level x_loc, halo exchange included (roofline hook of the sharded SpMV).  Enqueue only.
  * x_loc_d = NULL multiplies the level's resident x (as the last cycle left it) without a copy.       */
-int amgh_dist_spmv_d(amgh_dist_t* d, int level, const double* x_loc_d, double* y_loc_d);
+int amgh_dist_spmv_d(amgh_dist_t* d, int level, const amgh_real* x_loc_d, amgh_real* y_loc_d);
 int amgh_dist_sync(amgh_dist_t* d);
 int amgh_dist_barrier(amgh_dist_t* d);                                 /* sync + barrier over the ranks */
 int amgh_dist_allreduce(amgh_dist_t* d, double* v, int n, int max_op); /* host values, sum or max       */
@@ -397,8 +408,8 @@ int amgh_debug_chain_timing(int enable, unsigned long long* out8);
  * No device work: CPU tests check it against the scalar lexicographic sweep (smoother.jl:78-88).
  * x: ncols entries in/out (columns >= nrows are frozen halo values), b: nrows.  Returns the number of groups. */
 int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
-                                 const double* val, int m, int backward, double omega /* 1 = Gauss-Seidel, else SOR */,
-                                 double* x, const double* b);
+                                 const amgh_real* val, int m, int backward, double omega /* 1 = Gauss-Seidel, else SOR */,
+                                 amgh_real* x, const amgh_real* b);
 
 /* Diagnostics: tunables of the Gauss-Seidel execution (process-wide; used by tools/ to pick the defaults and by
  * tests to force every path).  Read at every sweep: "gs_xcd_map", "gs_block_pipe", "gs_flip", "gs_keep_lo",

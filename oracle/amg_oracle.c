@@ -31,11 +31,21 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* The element type of matrices and vectors.  The reference's code is generic in it; its tests run Float64 and
+ * Float32 (test/runtests.jl:244-259).  liboracle.so is the Float64 restatement, liboracle_f32.so the same file
+ * compiled with -DORC_REAL=float: every sum, product and division below then rounds to Float32 exactly where the
+ * Julia code instantiated for Float32 does (relaxation factors and tolerances stay Float64, as the reference's
+ * smoother fields and keyword defaults are).                                                                    */
+#ifndef ORC_REAL
+#define ORC_REAL double
+#endif
+typedef ORC_REAL real_t;
+
 typedef struct {
   int64_t m, n;
   const int32_t* colptr;
   const int32_t* rowval;
-  const double* nzval;
+  const real_t* nzval;
 } csc_t;
 
 typedef struct {
@@ -48,72 +58,72 @@ typedef struct {
 
 /* ---- SparseArrays mul! --------------------------------------------------- */
 /* y = A*x, CSC: y[rowval[j]] += nzval[j]*x[col], columns ascending            */
-void orc_spmv(const csc_t* A, const double* x, double* y) {
+void orc_spmv(const csc_t* A, const real_t* x, real_t* y) {
   for (int64_t i = 0; i < A->m; ++i) y[i] = 0.0;
   for (int64_t c = 0; c < A->n; ++c) {
-    const double xc = x[c];
+    const real_t xc = x[c];
     for (int32_t j = A->colptr[c]; j < A->colptr[c + 1]; ++j) y[A->rowval[j]] += A->nzval[j] * xc;
   }
 }
 /* y = A'*x, CSC of A: y[col] = sum_j nzval[j]*x[rowval[j]]                     */
-void orc_spmv_adj(const csc_t* A, const double* x, double* y) {
+void orc_spmv_adj(const csc_t* A, const real_t* x, real_t* y) {
   for (int64_t c = 0; c < A->n; ++c) {
-    double t = 0.0;
+    real_t t = 0.0;
     for (int32_t j = A->colptr[c]; j < A->colptr[c + 1]; ++j) t += A->nzval[j] * x[A->rowval[j]];
     y[c] = t;
   }
 }
-double orc_norm2(const double* x, int64_t n) {
-  double s = 0.0;
+real_t orc_norm2(const real_t* x, int64_t n) {
+  real_t s = 0.0;
   for (int64_t i = 0; i < n; ++i) s += x[i] * x[i];
   return sqrt(s);
 }
-static double dot(const double* x, const double* y, int64_t n) {
-  double s = 0.0;
+static real_t dot(const real_t* x, const real_t* y, int64_t n) {
+  real_t s = 0.0;
   for (int64_t i = 0; i < n; ++i) s += x[i] * y[i];
   return s;
 }
 
 /* ---- smoother.jl:61-90  gs!(A, b, x, start, step, stop) -------------------- */
-void orc_gs(const csc_t* A, const double* b, double* x, int backward) {
+void orc_gs(const csc_t* A, const real_t* b, real_t* x, int backward) {
   const int64_t n = A->m;
   for (int64_t t = 0; t < n; ++t) {
     const int64_t i = backward ? n - 1 - t : t;
-    double rsum = 0.0, d = 0.0;
+    real_t rsum = 0.0, d = 0.0;
     for (int32_t j = A->colptr[i]; j < A->colptr[i + 1]; ++j) {
       const int32_t row = A->rowval[j];
-      const double val = A->nzval[j];
+      const real_t val = A->nzval[j];
       if (i == row) d = val; else rsum += val * x[row];
     }
     if (d != 0.0) x[i] = (b[i] - rsum) / d;
   }
 }
 /* ---- smoother.jl:193-221 sor_step! ---------------------------------------- */
-void orc_sor(const csc_t* A, const double* b, double* x, double omega, int backward) {
+void orc_sor(const csc_t* A, const real_t* b, real_t* x, double omega, int backward) {
   const int64_t n = A->m;
   for (int64_t t = 0; t < n; ++t) {
     const int64_t i = backward ? n - 1 - t : t;
-    double rsum = 0.0, d = 0.0;
+    real_t rsum = 0.0, d = 0.0;
     for (int32_t j = A->colptr[i]; j < A->colptr[i + 1]; ++j) {
       const int32_t row = A->rowval[j];
-      const double val = A->nzval[j];
+      const real_t val = A->nzval[j];
       if (i == row) d = val; else rsum += val * x[row];
     }
     if (d != 0.0) x[i] = (1 - omega) * x[i] + (omega / d) * (b[i] - rsum);
   }
 }
 /* ---- smoother.jl:113-141 FastJacobiSmoother, one sweep --------------------- */
-void orc_jacobi(const csc_t* A, const double* b, double* x, double* temp, double omega) {
+void orc_jacobi(const csc_t* A, const real_t* b, real_t* x, real_t* temp, double omega) {
   const int64_t n = A->m;
   for (int64_t i = 0; i < n; ++i) temp[i] = x[i];
   for (int64_t i = 0; i < n; ++i) {
-    double rsum = 0.0, diag = 0.0;
+    real_t rsum = 0.0, diag = 0.0;
     for (int32_t j = A->colptr[i]; j < A->colptr[i + 1]; ++j) {
       const int32_t row = A->rowval[j];
-      const double val = A->nzval[j];
+      const real_t val = A->nzval[j];
       if (row == i) diag = val; else rsum += val * temp[row];
     }
-    const double xcand = (1.0 - omega) * temp[i] + omega * ((b[i] - rsum) / diag);
+    const real_t xcand = (1.0 - omega) * temp[i] + omega * ((b[i] - rsum) / diag);
     if (diag != 0.0) x[i] = xcand;
   }
 }
@@ -131,25 +141,25 @@ int64_t orc_diag_indices(const csc_t* A, int32_t* diag) {
   return 0;
 }
 /* z := alpha*U*x + beta*y, U strictly upper (smoother.jl:373-389); z may alias x */
-static void gsm_upper(const csc_t* A, const int32_t* diag, double alpha, const double* x, double beta,
-                      const double* y, double* z) {
+static void gsm_upper(const csc_t* A, const int32_t* diag, double alpha, const real_t* x, double beta,
+                      const real_t* y, real_t* z) {
   for (int64_t col = 0; col < A->n; ++col) {
-    const double ax = alpha * x[col];
+    const real_t ax = alpha * x[col];
     for (int32_t j = A->colptr[col]; j <= diag[col] - 1; ++j) z[A->rowval[j]] += A->nzval[j] * ax;
     z[col] = beta * y[col];
   }
 }
 /* z := alpha*L*x + beta*y, L strictly lower (smoother.jl:395-408) */
-static void gsm_lower(const csc_t* A, const int32_t* diag, double alpha, const double* x, double beta,
-                      const double* y, double* z) {
+static void gsm_lower(const csc_t* A, const int32_t* diag, double alpha, const real_t* x, double beta,
+                      const real_t* y, real_t* z) {
   for (int64_t col = A->n - 1; col >= 0; --col) {
-    const double ax = alpha * x[col];
+    const real_t ax = alpha * x[col];
     z[col] = beta * y[col];
     for (int32_t j = diag[col] + 1; j <= A->colptr[col + 1] - 1; ++j) z[A->rowval[j]] += A->nzval[j] * ax;
   }
 }
 /* forward_sub!(F, x) (smoother.jl:282-300) */
-static void forward_sub(const csc_t* A, const int32_t* diag, double* x) {
+static void forward_sub(const csc_t* A, const int32_t* diag, real_t* x) {
   for (int64_t col = 0; col < A->n; ++col) {
     const int32_t idx = diag[col];
     x[col] /= A->nzval[idx];
@@ -157,7 +167,7 @@ static void forward_sub(const csc_t* A, const int32_t* diag, double* x) {
   }
 }
 /* forward_sub!(alpha, F, x, beta, y) (smoother.jl:305-323) */
-static void forward_sub_ab(const csc_t* A, const int32_t* diag, double alpha, double* x, double beta, const double* y) {
+static void forward_sub_ab(const csc_t* A, const int32_t* diag, double alpha, real_t* x, double beta, const real_t* y) {
   for (int64_t col = 0; col < A->n; ++col) {
     const int32_t idx = diag[col];
     x[col] = alpha * x[col] / A->nzval[idx] + beta * y[col];
@@ -165,14 +175,14 @@ static void forward_sub_ab(const csc_t* A, const int32_t* diag, double alpha, do
   }
 }
 /* backward_sub!(F, x) (smoother.jl:329-347) */
-static void backward_sub(const csc_t* A, const int32_t* diag, double* x) {
+static void backward_sub(const csc_t* A, const int32_t* diag, real_t* x) {
   for (int64_t col = A->n - 1; col >= 0; --col) {
     const int32_t idx = diag[col];
     x[col] /= A->nzval[idx];
     for (int32_t i = A->colptr[col]; i <= idx - 1; ++i) x[A->rowval[i]] -= A->nzval[i] * x[col];
   }
 }
-static void backward_sub_ab(const csc_t* A, const int32_t* diag, double alpha, double* x, double beta, const double* y) {
+static void backward_sub_ab(const csc_t* A, const int32_t* diag, double alpha, real_t* x, double beta, const real_t* y) {
   for (int64_t col = A->n - 1; col >= 0; --col) {
     const int32_t idx = diag[col];
     x[col] = alpha * x[col] / A->nzval[idx] + beta * y[col];
@@ -181,8 +191,8 @@ static void backward_sub_ab(const csc_t* A, const int32_t* diag, double alpha, d
 }
 /* GS / SOR smooth! of the NoSymmetry family (smoother.jl:410-582); A is the TRUE
  * matrix in CSC.  tmp: n doubles (SOR only).                                   */
-static void nosym_gs_sor(const csc_t* A, const int32_t* diag, const orc_smoother_t* s, double* x, const double* b,
-                         double* tmp) {
+static void nosym_gs_sor(const csc_t* A, const int32_t* diag, const orc_smoother_t* s, real_t* x, const real_t* b,
+                         real_t* tmp) {
   const int64_t n = A->n;
   for (int it = 0; it < s->iter; ++it) {
     if (s->kind == 1) {
@@ -195,20 +205,20 @@ static void nosym_gs_sor(const csc_t* A, const int32_t* diag, const orc_smoother
       if (s->sweep == 0 || s->sweep == 2) {
         gsm_upper(A, diag, -1.0, x, 1.0, b, tmp);
         forward_sub_ab(A, diag, s->omega, tmp, 1.0 - s->omega, x);
-        memcpy(x, tmp, sizeof(double) * n);
+        memcpy(x, tmp, sizeof(real_t) * n);
       }
       if (s->sweep == 1 || s->sweep == 2) {
         gsm_lower(A, diag, -1.0, x, 1.0, b, tmp);
         backward_sub_ab(A, diag, s->omega, tmp, 1.0 - s->omega, x);
-        memcpy(x, tmp, sizeof(double) * n);
+        memcpy(x, tmp, sizeof(real_t) * n);
       }
     }
   }
 }
 /* JacobiSmoother (NoSymmetry), smoother.jl:157-171 */
-static void nosym_jacobi(const csc_t* A, const orc_smoother_t* s, double* x, const double* b, double* temp) {
+static void nosym_jacobi(const csc_t* A, const orc_smoother_t* s, real_t* x, const real_t* b, real_t* temp) {
   const int64_t n = A->n;
-  double* dv = (double*)calloc(n ? n : 1, sizeof(double));
+  real_t* dv = (real_t*)calloc(n ? n : 1, sizeof(real_t));
   for (int64_t c = 0; c < n; ++c)
     for (int32_t j = A->colptr[c]; j < A->colptr[c + 1]; ++j)
       if (A->rowval[j] == c) dv[c] += A->nzval[j];
@@ -223,12 +233,12 @@ static void nosym_jacobi(const csc_t* A, const orc_smoother_t* s, double* x, con
 
 /* smooth!(x, setup_smoother(config, A, symmetry), b).  Returns 0, or the 1-based
  * column of a SingularException for the NoSymmetry GS/SOR family.              */
-int64_t orc_smooth(const csc_t* A, const orc_smoother_t* s, int hermitian, double* x, const double* b) {
+int64_t orc_smooth(const csc_t* A, const orc_smoother_t* s, int hermitian, real_t* x, const real_t* b) {
   const int64_t n = A->m;
   if (s->kind == 0 || s->iter <= 0) return 0;
   if (hermitian) {
     if (s->kind == 2) {
-      double* temp = (double*)malloc(sizeof(double) * (n ? n : 1));
+      real_t* temp = (real_t*)malloc(sizeof(real_t) * (n ? n : 1));
       for (int it = 0; it < s->iter; ++it) orc_jacobi(A, b, x, temp, s->omega);
       free(temp);
     } else {
@@ -239,7 +249,7 @@ int64_t orc_smooth(const csc_t* A, const orc_smoother_t* s, int hermitian, doubl
     }
     return 0;
   }
-  double* tmp = (double*)calloc(n ? n : 1, sizeof(double));
+  real_t* tmp = (real_t*)calloc(n ? n : 1, sizeof(real_t));
   int64_t rc = 0;
   if (s->kind == 2) {
     nosym_jacobi(A, s, x, b, tmp);
@@ -261,7 +271,7 @@ typedef struct {
   int m_is_R;
   orc_smoother_t pre, post;
   int hermitian;
-  double *res, *cx, *cb;
+  real_t *res, *cx, *cb;
 } orc_level;
 
 typedef struct {
@@ -269,10 +279,10 @@ typedef struct {
   orc_level* lev;
   csc_t finalA;
   int64_t ncoarse;
-  const double* coarse_op; /* ncoarse x ncoarse column-major, or NULL */
-  int (*coarse_fn)(void* user, const double* b, double* x, int64_t n); /* pluggable (cs)(x,b) */
+  const real_t* coarse_op; /* ncoarse x ncoarse column-major, or NULL */
+  int (*coarse_fn)(void* user, const real_t* b, real_t* x, int64_t n); /* pluggable (cs)(x,b) */
   void* coarse_user;
-  double* res_final;
+  real_t* res_final;
 } orc_hier;
 
 orc_hier* orc_create(void) { return (orc_hier*)calloc(1, sizeof(orc_hier)); }
@@ -284,8 +294,8 @@ void orc_destroy(orc_hier* h) {
 }
 
 /* arrays are BORROWED (must outlive the hierarchy) */
-int orc_push_level(orc_hier* h, int64_t n, int64_t nc, const int32_t* Ap, const int32_t* Ai, const double* Ax,
-                   int m_is_R, const int32_t* Mp, const int32_t* Mi, const double* Mx, const orc_smoother_t* pre,
+int orc_push_level(orc_hier* h, int64_t n, int64_t nc, const int32_t* Ap, const int32_t* Ai, const real_t* Ax,
+                   int m_is_R, const int32_t* Mp, const int32_t* Mi, const real_t* Mx, const orc_smoother_t* pre,
                    const orc_smoother_t* post, int hermitian) {
   if (h->nlev == h->cap) {
     h->cap = h->cap ? 2 * h->cap : 8;
@@ -297,45 +307,45 @@ int orc_push_level(orc_hier* h, int64_t n, int64_t nc, const int32_t* Ap, const 
   L->M = m_is_R ? (csc_t){nc, n, Mp, Mi, Mx} : (csc_t){n, nc, Mp, Mi, Mx};
   L->m_is_R = m_is_R;
   L->pre = *pre; L->post = *post; L->hermitian = hermitian;
-  L->res = (double*)malloc(sizeof(double) * (n ? n : 1));
-  L->cx = (double*)malloc(sizeof(double) * (nc ? nc : 1));
-  L->cb = (double*)malloc(sizeof(double) * (nc ? nc : 1));
+  L->res = (real_t*)malloc(sizeof(real_t) * (n ? n : 1));
+  L->cx = (real_t*)malloc(sizeof(real_t) * (nc ? nc : 1));
+  L->cb = (real_t*)malloc(sizeof(real_t) * (nc ? nc : 1));
   return 0;
 }
-int orc_set_coarse(orc_hier* h, int64_t n, const int32_t* Ap, const int32_t* Ai, const double* Ax, const double* op) {
+int orc_set_coarse(orc_hier* h, int64_t n, const int32_t* Ap, const int32_t* Ai, const real_t* Ax, const real_t* op) {
   h->finalA = (csc_t){n, n, Ap, Ai, Ax};
   h->ncoarse = n;
   h->coarse_op = op;
-  h->res_final = (double*)malloc(sizeof(double) * (n ? n : 1));
+  h->res_final = (real_t*)malloc(sizeof(real_t) * (n ? n : 1));
   return 0;
 }
 
-int orc_set_coarse_fn(orc_hier* h, int (*fn)(void*, const double*, double*, int64_t), void* user) {
+int orc_set_coarse_fn(orc_hier* h, int (*fn)(void*, const real_t*, real_t*, int64_t), void* user) {
   h->coarse_fn = fn; h->coarse_user = user;
   return 0;
 }
 
 /* (cs)(x, b): Pinv -> mul!(x, pinvA, b) (coarse_solver.jl:16); QRSolver ->
  * factorization \ b (coarse_solver.jl:75-81) — both as x = op*b.               */
-static void coarse_solve(const orc_hier* h, double* x, const double* b) {
+static void coarse_solve(const orc_hier* h, real_t* x, const real_t* b) {
   const int64_t n = h->ncoarse;
   if (h->coarse_fn) { h->coarse_fn(h->coarse_user, b, x, n); return; }
   for (int64_t i = 0; i < n; ++i) {
-    double acc = 0.0;
+    real_t acc = 0.0;
     for (int64_t j = 0; j < n; ++j) acc += h->coarse_op[i + j * n] * b[j];
     x[i] = acc;
   }
 }
 
-static void cycle(orc_hier* h, int l, double* x, const double* b, int cyc);
+static void cycle(orc_hier* h, int l, real_t* x, const real_t* b, int cyc);
 /* __solve_next! (multilevel.jl:200-212) */
-static void cycle_next(orc_hier* h, int l, double* x, const double* b, int cyc) {
+static void cycle_next(orc_hier* h, int l, real_t* x, const real_t* b, int cyc) {
   if (cyc == 0) { cycle(h, l, x, b, 0); }
   else if (cyc == 1) { cycle(h, l, x, b, 1); cycle(h, l, x, b, 1); }
   else { cycle(h, l, x, b, 2); cycle(h, l, x, b, 0); }
 }
 /* __solve! (multilevel.jl:214-239) */
-static void cycle(orc_hier* h, int l, double* x, const double* b, int cyc) {
+static void cycle(orc_hier* h, int l, real_t* x, const real_t* b, int cyc) {
   orc_level* L = &h->lev[l];
   const int64_t n = L->A.m;
   const int64_t nc = L->m_is_R ? L->M.m : L->M.n;
@@ -353,14 +363,14 @@ static void cycle(orc_hier* h, int l, double* x, const double* b, int cyc) {
 
 /* _solve!(x, ml, b, cycle; maxiter, abstol, reltol, log, calculate_residual)
  * (multilevel.jl:158-198).  hist: NULL or maxiter+1.                          */
-int orc_solve(orc_hier* h, const double* b, double* x, int cyc, int maxiter, double abstol, double reltol,
-              int calc_res, double* hist, int* iters) {
+int orc_solve(orc_hier* h, const real_t* b, real_t* x, int cyc, int maxiter, double abstol, double reltol,
+              int calc_res, real_t* hist, int* iters) {
   const csc_t* A = h->nlev ? &h->lev[0].A : &h->finalA;
   const int64_t n = A->m;
-  double normb = orc_norm2(b, n), normres = normb;
+  real_t normb = orc_norm2(b, n), normres = normb;
   if (normb != 0) abstol = fmax(reltol * normb, abstol);
   if (hist) hist[0] = normb;
-  double* res = h->nlev ? h->lev[0].res : h->res_final;
+  real_t* res = h->nlev ? h->lev[0].res : h->res_final;
   int itr = 1;
   while (itr <= maxiter && (!calc_res || normres > abstol)) {
     if (h->nlev == 0) coarse_solve(h, x, b); else cycle(h, 0, x, b, cyc);
@@ -377,34 +387,34 @@ int orc_solve(orc_hier* h, const double* b, double* x, int cyc, int maxiter, dou
 }
 
 /* ldiv!(x, p, b) (preconditioner.jl:12-19) */
-void orc_precond(orc_hier* h, const double* b, double* x, int cyc) {
+void orc_precond(orc_hier* h, const real_t* b, real_t* x, int cyc) {
   const int64_t n = h->nlev ? h->lev[0].A.m : h->finalA.m;
   for (int64_t i = 0; i < n; ++i) x[i] = 0.0;
   orc_solve(h, b, x, cyc, 1, 0.0, 0.0, 0, NULL, NULL);
 }
 
 /* IterativeSolvers.jl cg(A, b; Pl = p, abstol, reltol, maxiter): PCGIterable.  x0 = 0. */
-int orc_pcg(orc_hier* h, const double* b, double* x, int cyc, int use_precond, int maxiter, double abstol,
-            double reltol, double* hist, int* iters) {
+int orc_pcg(orc_hier* h, const real_t* b, real_t* x, int cyc, int use_precond, int maxiter, double abstol,
+            double reltol, real_t* hist, int* iters) {
   const csc_t* A = h->nlev ? &h->lev[0].A : &h->finalA;
   const int64_t n = A->m;
-  double* r = (double*)malloc(sizeof(double) * n);
-  double* c = (double*)malloc(sizeof(double) * n);
-  double* u = (double*)calloc(n, sizeof(double));
+  real_t* r = (real_t*)malloc(sizeof(real_t) * n);
+  real_t* c = (real_t*)malloc(sizeof(real_t) * n);
+  real_t* u = (real_t*)calloc(n, sizeof(real_t));
   for (int64_t i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; }
-  double residual = orc_norm2(r, n);
+  real_t residual = orc_norm2(r, n);
   const double tol = fmax(reltol * residual, abstol);
   if (hist) hist[0] = residual;
-  double rho = 1.0;
+  real_t rho = 1.0;
   int it = 0;
   while (it < maxiter && residual > tol) {
-    if (use_precond) orc_precond(h, r, c, cyc); else memcpy(c, r, sizeof(double) * n);
-    const double rho_prev = rho;
+    if (use_precond) orc_precond(h, r, c, cyc); else memcpy(c, r, sizeof(real_t) * n);
+    const real_t rho_prev = rho;
     rho = dot(c, r, n);
-    const double beta = rho / rho_prev;
+    const real_t beta = rho / rho_prev;
     for (int64_t i = 0; i < n; ++i) u[i] = c[i] + beta * u[i];
     orc_spmv(A, u, c);
-    const double alpha = rho / dot(u, c, n);
+    const real_t alpha = rho / dot(u, c, n);
     for (int64_t i = 0; i < n; ++i) x[i] += alpha * u[i];
     for (int64_t i = 0; i < n; ++i) r[i] -= alpha * c[i];
     residual = orc_norm2(r, n);
@@ -417,13 +427,13 @@ int orc_pcg(orc_hier* h, const double* b, double* x, int cyc, int use_precond, i
 }
 
 /* helpers for ctypes callers that hold raw arrays */
-void orc_spmv_arrays(int64_t m, int64_t n, const int32_t* p, const int32_t* i, const double* v, const double* x,
-                     double* y, int adjoint) {
+void orc_spmv_arrays(int64_t m, int64_t n, const int32_t* p, const int32_t* i, const real_t* v, const real_t* x,
+                     real_t* y, int adjoint) {
   csc_t A = {m, n, p, i, v};
   if (adjoint) orc_spmv_adj(&A, x, y); else orc_spmv(&A, x, y);
 }
-int64_t orc_smooth_arrays(int64_t n, const int32_t* p, const int32_t* i, const double* v, const orc_smoother_t* s,
-                          int hermitian, double* x, const double* b) {
+int64_t orc_smooth_arrays(int64_t n, const int32_t* p, const int32_t* i, const real_t* v, const orc_smoother_t* s,
+                          int hermitian, real_t* x, const real_t* b) {
   csc_t A = {n, n, p, i, v};
   return orc_smooth(&A, s, hermitian, x, b);
 }

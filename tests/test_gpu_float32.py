@@ -1,0 +1,158 @@
+"""The Float32 instance of the solve phase (libamghip_f32.so: the library's source compiled with amgh_real = float)
+against the Float32 instance of the CPU oracle (liboracle_f32.so: the restatement compiled with real_t = float).
+
+The reference's hierarchy is generic in eltype(A); its tests run Float64 and Float32 (test/runtests.jl:244-259).
+Both sides here get the SAME Float32 matrices (the Float64 hierarchy rounded once), so what is compared is the Float32
+arithmetic of the cycle.  Tolerance: the two differ in the ORDER of Float32 additions only where the Float64 paths
+differ at 1e-13 .. 1e-11 (merged dependency levels, lanes-per-row sums); scaled by eps(Float32) / eps(Float64) that is
+5e-5 relative in the 2-norm — written below as F32_TOL."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import amg_amd as AMG
+from amg_amd.device import DeviceCSR, smooth_standalone
+from conftest import load_csc, uniform
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 5e-5
+F32 = np.float32
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def as_f32_matrix(A):
+    """The Float32 matrix a Julia user would pass: T.(A)."""
+    S = A.to_scipy().astype(F32)
+    return AMG.SparseMatrixCSC.from_scipy(S)
+
+
+def test_the_float32_instance_is_a_different_library_with_the_same_entry_points():
+    l64, l32 = AMG.hip_lib(), AMG.hip_lib("float32")
+    assert l64 is not l32 and l64.real_dtype == "float64" and l32.real_dtype == "float32"
+    for name in ("amgh_create", "amgh_push_level", "amgh_push_level_begin", "amgh_push_level_end", "amgh_set_coarse",
+                 "amgh_finalize", "amgh_solve", "amgh_solve_d", "amgh_precond_apply_d", "amgh_pcg", "amgh_cycle_d",
+                 "amgh_level_spmv", "amgh_level_smooth", "amgh_csr_create", "amgh_csr_gs_d", "amgh_dot_d"):
+        assert hasattr(l32, name), name
+    assert not hasattr(l32, "amgh_dist_create_rccl")      # the row-sharded path is Float64 only
+
+
+def test_standalone_operators_in_float32():
+    A = AMG.poisson((20, 18, 16))
+    n = A.m
+    rp, ci, va = A.csr_arrays()
+    op = DeviceCSR(n, n, rp, ci, va, dtype=F32)
+    x, b = (uniform(n, 3) - 0.5).astype(F32), uniform(n, 4).astype(F32)
+    y = op.spmv(x)
+    assert y.dtype == F32 and rel(y, O.spmv(A, x, dtype=F32)) <= 1e-6
+    r = op.residual(x, b)
+    assert rel(r, b - O.spmv(A, x, dtype=F32)) <= 1e-6
+    # dot / norm through the Float32 reduction
+    lib = AMG.hip_lib("float32")
+    xd, sc = AMG.DeviceBuffer(n, 0, x, dtype=F32), AMG.DeviceBuffer(2048, 0, dtype=F32)
+    out = C.c_float(0)
+    assert lib.amgh_dot_d(0, n, xd.ptr, xd.ptr, sc.ptr, C.byref(out), None) == 0
+    assert abs(out.value - float(np.dot(x.astype(np.float64), x.astype(np.float64)))) <= 1e-5 * float(np.dot(x, x))
+
+
+@pytest.mark.parametrize("shape", [(300,), (48, 40), (20, 18, 16), (64, 64, 48)])
+def test_smoothers_in_float32_vs_float32_oracle(shape):
+    A = AMG.poisson(shape)
+    n = A.m
+    x0, b = (uniform(n, 11) - 0.5).astype(F32), uniform(n, 12).astype(F32)
+    for s in (AMG.Jacobi(2 / 3), AMG.Jacobi(0.5, iter=3), AMG.GaussSeidel(AMG.ForwardSweep()),
+              AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(), AMG.GaussSeidel(AMG.SymmetricSweep(), 3),
+              AMG.SOR(0.5, iter=2), AMG.SOR(1.2, AMG.ForwardSweep())):
+        x = x0.copy()
+        smooth_standalone(s, A, x, b, dtype=F32)
+        ref = O.smooth(s, A, x0, b, hermitian=True, dtype=F32)
+        assert x.dtype == F32 and rel(x, ref) <= F32_TOL, repr(s)
+        assert rel(x, x0) > 1e-3                 # it did sweep
+
+
+def _hierarchies():
+    yield "rs poisson 3-D", AMG.ruge_stuben(as_f32_matrix(AMG.poisson((24, 24, 24))))
+    yield "rs poisson 2-D", AMG.ruge_stuben(as_f32_matrix(AMG.poisson((70, 50))))
+    yield "sa poisson 1-D", AMG.smoothed_aggregation(as_f32_matrix(AMG.poisson(1000)))
+    yield "sa poisson 3-D jacobi", AMG.smoothed_aggregation(as_f32_matrix(AMG.poisson((20, 20, 20))),
+                                                              presmoother=AMG.Jacobi(2 / 3), postsmoother=AMG.Jacobi(2 / 3))
+    yield "rs randlap sor", AMG.ruge_stuben(as_f32_matrix(load_csc("randlap")), presmoother=AMG.SOR(1.1),
+                                            postsmoother=AMG.SOR(1.1))
+
+
+@pytest.mark.parametrize("cycle", [0, 1, 2])
+def test_cycles_in_float32_vs_float32_oracle(cycle):
+    cyc = (AMG.V(), AMG.W(), AMG.F())[cycle]
+    for name, ml in _hierarchies():
+        A0 = ml.levels[0].A
+        assert A0.eltype == F32, name
+        r = uniform(A0.m, 5).astype(F32)
+        z = AMG.aspreconditioner(ml, cyc).ldiv(r)
+        assert z.dtype == F32, name
+        dev = ml.device(dtype=F32)
+        assert dev.lib is AMG.hip_lib("float32") and dev.dtype == F32      # it ran on the Float32 instance
+        ref = O.OracleHierarchy(ml, dtype=F32).precond(r, cycle)
+        assert ref.dtype == F32
+        assert rel(z, ref) <= F32_TOL, (name, rel(z, ref))
+        # and it is Float32 arithmetic, not a rounded Float64 cycle: the Float64 result differs at the 1e-7 level
+        z64 = O.OracleHierarchy(ml).precond(r.astype(np.float64), cycle)
+        assert 1e-9 < rel(z, z64) < 1e-3, (name, rel(z, z64))
+
+
+def test_solve_in_float32_follows_the_float32_oracle():
+    for name, ml in _hierarchies():
+        A0 = ml.levels[0].A
+        n = A0.m
+        b = (A0.to_scipy() @ np.ones(n)).astype(F32)
+        x, hist = AMG._solve(ml, b, log=True, maxiter=40)
+        assert x.dtype == F32 and hist.dtype == F32, name
+        oh = O.OracleHierarchy(ml, dtype=F32)
+        xo, ho, ito = oh.solve(b, maxiter=40)            # default reltol = sqrt(eps(Float32)) on both sides
+        assert abs(len(hist) - len(ho)) <= 1, (name, len(hist), len(ho))
+        k = min(len(hist), len(ho))
+        # early residuals agree tightly; near the Float32 floor they are rounding noise on both sides
+        assert np.allclose(hist[:min(k, 4)], ho[:min(k, 4)], rtol=1e-3), name
+        assert hist[k - 1] <= 10 * max(ho[k - 1], 3e-4 * ho[0]), name
+        assert rel(x, xo) <= 1e-3, (name, rel(x, xo))
+        if "poisson" in name:        # (randlap is a singular graph Laplacian: A * ones = 0)
+            assert rel(x, np.ones(n)) <= 5e-3, name
+
+
+def test_multiple_right_hand_sides_in_float32():
+    ml = AMG.ruge_stuben(as_f32_matrix(AMG.poisson((20, 20, 16))))
+    n = ml.levels[0].A.m
+    B = np.stack([uniform(n, 1), uniform(n, 2) - 0.5, np.sin(np.arange(n))], axis=1).astype(F32)
+    Z = AMG.aspreconditioner(ml).ldiv(B)
+    assert Z.dtype == F32 and Z.shape == B.shape
+    oh = O.OracleHierarchy(ml, dtype=F32)
+    for j in range(B.shape[1]):
+        assert rel(Z[:, j], oh.precond(np.ascontiguousarray(B[:, j]))) <= F32_TOL
+
+
+def test_eltype_rules_pick_the_instance():   # runtests.jl:244-259, multilevel.jl:154
+    a = AMG.poisson(100).to_scipy()
+    b = uniform(100, 1)
+    for T, V in ((np.float64, np.float64), (F32, F32), (np.float64, F32), (F32, np.float64)):
+        ml = AMG.smoothed_aggregation(a.astype(T))
+        x = AMG._solve(ml, b.astype(V))
+        assert x.dtype == np.promote_types(T, V)
+        both32 = T == F32 and V == F32
+        assert ((0, 1, "f32") in ml._dev) == both32 and ((0, 1) in ml._dev) == (not both32)
+
+
+def test_float32_handle_keeps_exact_order_sweeps_where_float64_inverts_blocks():
+    """Block-inverse sweeps are accurate to cond * eps: admitted up to cond 1e4 in Float64, never in Float32."""
+    ml = AMG.ruge_stuben(as_f32_matrix(AMG.poisson((24, 24, 24))))
+    d64, d32 = ml.device(), ml.device(dtype=F32)
+    L = len(ml.levels)
+    steps64 = [d64.gs_sweep_steps(l) for l in range(L)]
+    steps32 = [d32.gs_sweep_steps(l) for l in range(L)]
+    levels = [d32.gs_dependency_levels(l) for l in range(L)]
+    assert levels == [d64.gs_dependency_levels(l) for l in range(L)]
+    assert all(s32 >= s64 for s32, s64 in zip(steps32, steps64))

@@ -531,5 +531,6 @@ def test_eltype_promotion_contract():  # runtests.jl:244-259
         ml = AMG.smoothed_aggregation(a.astype(T))
         x = AMG._solve(ml, b.astype(V))
         assert x.dtype == np.promote_types(T, V)
-        # a Float32 result carries its rounding (|x| ~ 2e2, cond ~ 4e3) into the residual
-        assert np.linalg.norm(a @ x.astype(np.float64) - b) <= (1e-3 if x.dtype == np.float32 else 1e-7) * np.linalg.norm(b)
+        # the default reltol is sqrt(eps(eltype(b))) (multilevel.jl:162): a Float32 right-hand side stops at 3.5e-4;
+        # a Float32 result also carries its rounding (|x| ~ 2e2, cond ~ 4e3) into the residual
+        assert np.linalg.norm(a @ x.astype(np.float64) - b) <= (1e-3 if V == np.float32 else 1e-7) * np.linalg.norm(b)
