@@ -25,6 +25,8 @@ import AlgebraicMultigrid: MultiLevel, Level, _solve!, Cycle, V, W, F, GaussSeid
                            FastSORSmoother, aspreconditioner, ruge_stuben, smoothed_aggregation
 
 const libamghip = get(ENV, "LIBAMGHIP", "libamghip.so")
+# the Float32 instance: the same source compiled with amgh_real = float (include/amghip.h), same entry points
+const libamghip_f32 = get(ENV, "LIBAMGHIP_F32", "libamghip_f32.so")
 
 struct AMGHipError <: Exception
     rc::Cint
@@ -33,7 +35,7 @@ Base.showerror(io::IO, e::AMGHipError) =
     print(io, "libamghip: ", unsafe_string(ccall((:amgh_strerror, libamghip), Cstring, (Cint,), e.rc)))
 check(rc) = rc == 0 ? nothing : throw(AMGHipError(rc))
 
-# amgh_smoother_t (include/amghip.h)
+# amgh_smoother_t (include/amghip.h); the relaxation factor stays Float64 in both instances
 struct CSmoother
     kind::Int32; sweep::Int32; iter::Int32; pad::Int32; omega::Float64
 end
@@ -44,97 +46,112 @@ csmoother(s::FastSORSmoother{S}) where {S} = CSmoother(3, sweepcode(S()), s.iter
 # NoSymmetry caches map to the same kernels on the true rows (S == A); see amgh_push_level.
 
 """
-Workspace type that marks a MultiLevel as resident on the GPU (replaces MultiLevelWorkspace{TX,bs}).
+Workspace type that marks a MultiLevel as resident on the GPU (replaces MultiLevelWorkspace{TX,bs}); `T` is the
+arithmetic type of the handle = the instance of the library it lives in (Float64: libamghip, Float32: libamghip_f32).
 `keep` holds everything the library may call back into or read later (the coarse-solver closure and its
 `@cfunction` trampoline): they must live as long as the handle.
 """
-mutable struct HipWorkspace
+mutable struct HipWorkspace{T}
     handle::Ptr{Cvoid}
     bs::Int
     keep::Vector{Any}
-    function HipWorkspace(h, bs, keep)
-        w = new(h, bs, keep)
-        finalizer(w -> ccall((:amgh_destroy, libamghip), Cvoid, (Ptr{Cvoid},), w.handle), w)
+    function HipWorkspace{T}(h, bs, keep) where {T}
+        w = new{T}(h, bs, keep)
+        finalizer(destroy!, w)
     end
 end
-Base.eltype(::HipWorkspace) = Float64
+Base.eltype(::HipWorkspace{T}) where {T} = T
+destroy!(w::HipWorkspace{Float64}) = ccall((:amgh_destroy, libamghip), Cvoid, (Ptr{Cvoid},), w.handle)
+destroy!(w::HipWorkspace{Float32}) = ccall((:amgh_destroy, libamghip_f32), Cvoid, (Ptr{Cvoid},), w.handle)
 
 # 0-based int32 CSR arrays of M given Julia's 1-based CSC of M' (CSC arrays of X are CSR arrays of X')
-csr_of_transpose(X::SparseMatrixCSC) = (Int32.(X.colptr .- 1), Int32.(X.rowval .- 1), Float64.(X.nzval))
-csr(X::SparseMatrixCSC) = csr_of_transpose(copy(X'))
-csr(X::Adjoint{<:Any,<:SparseMatrixCSC}) = csr_of_transpose(parent(X))   # lazy adjoint: arrays are already the CSR
+csr_of_transpose(::Type{T}, X::SparseMatrixCSC) where {T} = (Int32.(X.colptr .- 1), Int32.(X.rowval .- 1), T.(X.nzval))
+csr(::Type{T}, X::SparseMatrixCSC) where {T} = csr_of_transpose(T, copy(X'))
+csr(::Type{T}, X::Adjoint{<:Any,<:SparseMatrixCSC}) where {T} = csr_of_transpose(T, parent(X))   # lazy adjoint: already the CSR
+
+cyclecode(::V) = Cint(0); cyclecode(::W) = Cint(1); cyclecode(::F) = Cint(2)
+
+const HipML{T} = MultiLevel{<:Any,<:Any,<:Any,<:Any,<:Any,<:Any,HipWorkspace{T}}
 
 """
     hip(ml::MultiLevel; device = 0, bs = 1) -> MultiLevel
 
 Upload the hierarchy to HBM (amgh_create / amgh_push_level / amgh_set_coarse / amgh_finalize).
 `bs` = workspace block size (the reference's `Val{bs}`, multilevel.jl:28-35): `_solve!` then takes n x bs blocks.
+The arithmetic type is eltype of the hierarchy (Float64 or Float32; anything else is promoted to Float64).
 """
-function hip(ml::MultiLevel; device::Integer = 0, bs::Integer = 1, symmetry = HermitianSymmetry())
+function hip(ml::MultiLevel; kwargs...)
+    A = isempty(ml.levels) ? ml.final_A : ml.levels[1].A
+    hip(eltype(A) === Float32 ? Float32 : Float64, ml; kwargs...)
+end
+
+# one set of methods per instance of the library: `ccall` needs the library as a constant
+for (T, lib) in ((Float64, :libamghip), (Float32, :libamghip_f32))
+@eval begin
+
+function hip(::Type{$T}, ml::MultiLevel; device::Integer = 0, bs::Integer = 1, symmetry = HermitianSymmetry())
     h = Ref{Ptr{Cvoid}}(C_NULL)
     keep = Any[]
-    check(ccall((:amgh_create, libamghip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint), h, device, bs))
+    check(ccall((:amgh_create, $lib), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint), h, device, bs))
     for lev in ml.levels
         A = lev.A
         n, nc = size(lev.P)
-        Ar, Ac, Av = csr(A)                                   # true rows: mul!(res, A, x)
+        Ar, Ac, Av = csr($T, A)                               # true rows: mul!(res, A, x)
         sym = symmetry isa HermitianSymmetry
         # the "fast" smoothers read CSC column i as row i (smoother.jl:81-86): S = CSC arrays as CSR
-        S = (sym && !issymmetric(A)) ? csr_of_transpose(A) : nothing
-        Pr, Pc, Pv = csr(lev.P); Rr, Rc, Rv = csr(lev.R)
+        S = (sym && !issymmetric(A)) ? csr_of_transpose($T, A) : nothing
+        Pr, Pc, Pv = csr($T, lev.P); Rr, Rc, Rv = csr($T, lev.R)
         pre, post = Ref(csmoother(lev.presmoother)), Ref(csmoother(lev.postsmoother))
-        GC.@preserve Ar Ac Av S Pr Pc Pv Rr Rc Rv check(ccall((:amgh_push_level, libamghip), Cint,
-            (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64},
-             Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ref{CSmoother}, Ref{CSmoother}),
+        GC.@preserve Ar Ac Av S Pr Pc Pv Rr Rc Rv check(ccall((:amgh_push_level, $lib), Cint,
+            (Ptr{Cvoid}, Int64, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{$T}, Ptr{Int32}, Ptr{Int32}, Ptr{$T},
+             Ptr{Int32}, Ptr{Int32}, Ptr{$T}, Ptr{Int32}, Ptr{Int32}, Ptr{$T}, Ref{CSmoother}, Ref{CSmoother}),
             h[], n, nc, Ar, Ac, Av,
             S === nothing ? C_NULL : S[1], S === nothing ? C_NULL : S[2], S === nothing ? C_NULL : S[3],
             Pr, Pc, Pv, Rr, Rc, Rv, pre, post))
     end
     fA = ml.final_A
     n = size(fA, 1)
-    fr, fc, fv = csr(fA)
+    fr, fc, fv = csr($T, fA)
     cs = ml.coarse_solver
     if n <= 2048
         # Pinv: the stored pinv(Matrix(A)) (coarse_solver.jl:11).  QRSolver (coarse_solver.jl:66-81) solves with a
         # pivoted QR, i.e. least squares when final_A is singular: its dense stand-in is the pseudo-inverse too,
         # NOT inv(), which throws on a singular coarse matrix (e.g. the pure-Neumann Poisson problem).
-        op = cs isa Pinv ? Matrix{Float64}(cs.pinvA) : Matrix{Float64}(pinv(Matrix(fA)))
-        check(ccall((:amgh_set_coarse, libamghip), Cint,
-                    (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), h[], n, fr, fc, fv, op))
+        op = cs isa Pinv ? Matrix{$T}(cs.pinvA) : Matrix{$T}(pinv(Matrix(fA)))
+        check(ccall((:amgh_set_coarse, $lib), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{$T}, Ptr{$T}), h[], n, fr, fc, fv, op))
     else
         # pluggable host coarse solver: the reference's `(cs)(x, b)` protocol through a C callback.  The closure
         # and its trampoline are stored in the workspace: the library calls them on every coarse solve.
         closure = (user, b, x, n) -> begin
             cs(unsafe_wrap(Array, x, n), unsafe_wrap(Array, b, n)); Cint(0)
         end
-        cb = @cfunction($closure, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64))
+        cb = @cfunction($(Expr(:$, :closure)), Cint, (Ptr{Cvoid}, Ptr{$T}, Ptr{$T}, Int64))
         push!(keep, closure, cb, cs)
-        check(ccall((:amgh_set_coarse_host, libamghip), Cint,
-                    (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}),
+        check(ccall((:amgh_set_coarse_host, $lib), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{$T}, Ptr{Cvoid}, Ptr{Cvoid}),
                     h[], n, fr, fc, fv, cb, C_NULL))
     end
-    check(ccall((:amgh_finalize, libamghip), Cint, (Ptr{Cvoid},), h[]))
-    MultiLevel(ml.levels, ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother, HipWorkspace(h[], Int(bs), keep))
+    check(ccall((:amgh_finalize, $lib), Cint, (Ptr{Cvoid},), h[]))
+    MultiLevel(ml.levels, ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
+               HipWorkspace{$T}(h[], Int(bs), keep))
 end
-
-cyclecode(::V) = Cint(0); cyclecode(::W) = Cint(1); cyclecode(::F) = Cint(2)
-
-const HipML = MultiLevel{<:Any,<:Any,<:Any,<:Any,<:Any,<:Any,HipWorkspace}
 
 # _solve!(x, ml, b, cycle; maxiter, abstol, reltol, verbose, log, calculate_residual)  multilevel.jl:158-198
 # b, x: vectors (bs = 1) or n x bs matrices — Julia's column-major layout is what amgh_solve takes.
-function AlgebraicMultigrid._solve!(x::AbstractVecOrMat{Float64}, ml::HipML, b::AbstractVecOrMat{Float64},
+# Any other eltype of x / b is converted to the handle's (promote_type as multilevel.jl:154 does, then the handle's).
+function AlgebraicMultigrid._solve!(x::AbstractVecOrMat, ml::HipML{$T}, b::AbstractVecOrMat,
                                     cycle::Cycle = V();
-                                    maxiter::Int = 100, abstol::Real = 0.0, reltol::Real = sqrt(eps(Float64)),
+                                    maxiter::Int = 100, abstol::Real = 0.0, reltol::Real = sqrt(eps(real(eltype(b)))),
                                     verbose::Bool = false, log::Bool = false, calculate_residual = true, kwargs...)
     size(b, 2) == ml.workspace.bs ||
         throw(DimensionMismatch("hierarchy was uploaded with block size $(ml.workspace.bs), b has $(size(b, 2)) columns"))
     size(x) == size(b) || throw(DimensionMismatch("x and b differ in size"))
-    xs, bsd = Array{Float64}(x), Array{Float64}(b)     # dense, contiguous
-    hist = zeros(Float64, maxiter + 1)
+    xs, bsd = Array{$T}(x), Array{$T}(b)     # dense, contiguous
+    hist = zeros($T, maxiter + 1)
     iters = Ref{Cint}(0)
-    check(ccall((:amgh_solve, libamghip), Cint,
-                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Float64, Float64, Cint, Ptr{Float64}, Ref{Cint}),
+    check(ccall((:amgh_solve, $lib), Cint,
+                (Ptr{Cvoid}, Ptr{$T}, Ptr{$T}, Cint, Cint, Float64, Float64, Cint, Ptr{$T}, Ref{Cint}),
                 ml.workspace.handle, bsd, xs, cyclecode(cycle), maxiter, abstol, reltol, calculate_residual, hist, iters))
     copyto!(x, xs)
     if verbose && calculate_residual
@@ -144,6 +161,33 @@ function AlgebraicMultigrid._solve!(x::AbstractVecOrMat{Float64}, ml::HipML, b::
     end
     log ? (x, hist[1:(calculate_residual ? iters[] + 1 : 1)]) : x
 end
+
+# Per-level hooks on the device (the counterparts of `smooth!(x, levels[l].presmoother, b)` and `mul!(y, op, x)` on
+# level `level`, 1-based); A, P, R of the level by `which`.
+function level_smooth!(x::Vector{$T}, ml::HipML{$T}, level::Integer, b::Vector{$T}; post::Bool = false)
+    check(ccall((:amgh_level_smooth, $lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{$T}, Ptr{$T}),
+                ml.workspace.handle, level - 1, post, x, b))
+    x
+end
+function level_mul!(y::Vector{$T}, ml::HipML{$T}, level::Integer, which::Symbol, x::Vector{$T})
+    code = which === :A ? 0 : which === :P ? 1 : which === :R ? 2 : throw(ArgumentError("which must be :A, :P or :R"))
+    check(ccall((:amgh_level_spmv, $lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{$T}, Ptr{$T}),
+                ml.workspace.handle, level - 1, code, x, y))
+    y
+end
+
+# device-resident preconditioned CG: IterativeSolvers' cg(A, b; Pl = aspreconditioner(ml)) in one call
+function cg(ml::HipML{$T}, b::Vector{$T}; cycle::Cycle = V(), maxiter::Int = length(b), abstol = 0.0,
+            reltol = sqrt(eps($T)))
+    x = zeros($T, length(b)); hist = zeros($T, maxiter + 1); iters = Ref{Cint}(0)
+    check(ccall((:amgh_pcg, $lib), Cint,
+                (Ptr{Cvoid}, Ptr{$T}, Ptr{$T}, Cint, Cint, Cint, Float64, Float64, Ptr{$T}, Ref{Cint}),
+                ml.workspace.handle, b, x, cyclecode(cycle), 1, maxiter, abstol, reltol, hist, iters))
+    x, hist[1:iters[] + 1]
+end
+
+end # @eval
+end # for (T, lib)
 
 # `aspreconditioner(ml)`, `ldiv!`, `\` need no new methods: preconditioner.jl:12-19 calls `_solve!` with
 # maxiter = 1, calculate_residual = false, which lands in the method above.  CommonSolve's
@@ -172,31 +216,7 @@ HipSmoothedAggregationPreconBuilder(; blocksize = 1, kwargs...) = HipSmoothedAgg
 (b::HipSmoothedAggregationPreconBuilder)(A::SparseArrays.AbstractSparseMatrixCSC, p) =
     (aspreconditioner(hip(smoothed_aggregation(SparseMatrixCSC(A), Val{b.blocksize}; b.kwargs...); bs = b.blocksize)), I)
 
-# Per-level hooks on the device (the counterparts of `smooth!(x, levels[l].presmoother, b)` and
-# `mul!(y, levels[l].A | P | R, x)`, multilevel.jl:216-236): plain functions, see the header.
-function level_smooth!(x::Vector{Float64}, ml::HipML, level::Integer, b::Vector{Float64}; post::Bool = false)
-    check(ccall((:amgh_level_smooth, libamghip), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}),
-                ml.workspace.handle, level - 1, post, x, b))
-    x
-end
-function level_mul!(y::Vector{Float64}, ml::HipML, level::Integer, which::Symbol, x::Vector{Float64})
-    code = which === :A ? 0 : which === :P ? 1 : which === :R ? 2 : throw(ArgumentError("which must be :A, :P or :R"))
-    check(ccall((:amgh_level_spmv, libamghip), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}),
-                ml.workspace.handle, level - 1, code, x, y))
-    y
-end
-
-# A Krylov loop that wants to stay on the device uses amgh_pcg / amgh_precond_apply_d directly:
-function cg(ml::HipML, b::Vector{Float64}; cycle::Cycle = V(), maxiter::Int = length(b), abstol = 0.0,
-            reltol = sqrt(eps(Float64)))
-    x = zeros(length(b)); iters = Ref{Cint}(0)
-    check(ccall((:amgh_pcg, libamghip), Cint,
-                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Cint, Float64, Float64, Ptr{Float64}, Ref{Cint}),
-                ml.workspace.handle, b, x, cyclecode(cycle), 1, maxiter, abstol, reltol, C_NULL, iters))
-    x
-end
-
-# ---- row-sharded hierarchy over N GPUs (amgh_dist_*, include/amghip.h) ----------------------------------------
+# ---- row-sharded hierarchy over N GPUs (amgh_dist_*, include/amghip.h; Float64 instance only) ------------------
 # One Julia process per GPU (e.g. under MPI.jl).  Rank 0 makes the RCCL id, the host broadcasts its 128 bytes
 # (`MPI.Bcast!`), every rank pushes ITS rows of the sharded levels with global column indices, rank 0 passes
 # the collapsed levels as an ordinary uploaded hierarchy.
@@ -249,7 +269,7 @@ function hip_sharded(ml::MultiLevel, rank::Integer, nranks::Integer, id::Vector{
     end
     tail = nothing
     if rank == 0
-        tail = hip(MultiLevel(ml.levels[lc + 1:end], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
+        tail = hip(Float64, MultiLevel(ml.levels[lc + 1:end], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
                               ml.workspace); device = device)
         check(ccall((:amgh_dist_set_tail, libamghip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), d[], tail.workspace.handle))
     end
