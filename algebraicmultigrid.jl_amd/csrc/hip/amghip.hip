@@ -1272,6 +1272,10 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_sell")) g_gs_sell = value;
   else if (!strcmp(name, "gs_ept")) g_gs_ept = value;
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
+  else if (!strcmp(name, "gs_merge_force")) g_gs_merge_force = value;
+  else if (!strcmp(name, "gs_zone")) g_gs_zone = value;
+  else if (!strcmp(name, "gs_zone_t0_ns")) g_gs_zone_t0_ns = value;
+  else if (!strcmp(name, "gs_zone_floor_ns")) g_gs_zone_floor_ns = value;
   else if (!strcmp(name, "gs_bigslot")) g_gs_bigslot = value;
   else if (!strcmp(name, "gs_flip")) g_gs_flip = value;
   else if (!strcmp(name, "gs_keep_lo")) g_gs_keep_lo = value;

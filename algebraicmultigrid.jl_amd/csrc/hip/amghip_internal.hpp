@@ -297,6 +297,10 @@ int g_gs_keep_lo = 1;           // keep x in level order between pre- and post-s
 int g_gs_flip = 1;              // alternating merged sweeps: s of the next sweep from the last one (no matrix pass)
 int g_gs_bigslot = 1;           // allow long-row slots (composite rows up to 2048 entries) when merging
 int g_gs_merge = 16;             // merged-level sweeps: largest group of dependency levels tried (1 = off); read at schedule build
+int g_gs_zone_t0_ns = 3000;      // ... its per-launch price (ns) and the floor below which a launch does not get cheaper (ns; 0 = none)
+int g_gs_zone_floor_ns = 0;
+int g_gs_zone = 1;               // groups of different depth along a sweep (deep where levels are small); read at schedule build
+int g_gs_merge_force = 0;        // measurement hook: groups of exactly this many levels wherever they can be built (0 = cost model); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
 int g_gs_sell = 1;              // merged groups from the SELL-like layout where it was built (0 = slot kernels); build: read at schedule build too

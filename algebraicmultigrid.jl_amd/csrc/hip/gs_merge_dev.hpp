@@ -15,9 +15,33 @@ namespace {
 
 constexpr int kMergeMaxRounds = 32;
 
-struct MergeDev {
-  int m = 1, ngrp = 0;
+// A grouping of the dependency levels of one sweep: group q = levels [gb[q], gb[q+1]) (ascending level boundaries,
+// gb[0] = 0, gb[ngrp] = nlev).  A forward sweep runs the groups in ascending order and the levels of a group in
+// ascending order (round k of group q = level gb[q] + k); a backward sweep both in descending order (round k = level
+// gb[q+1] - 1 - k).  Groups need not have the same depth: deep where the levels are small (the launch is at its
+// latency floor whatever it carries), shallow where they are large (substitution inflates the rows).
+struct MergeGrouping {
+  std::vector<int32_t> gb;
   bool backward = false;
+  int ngrp() const { return (int)gb.size() - 1; }
+  int depth() const { int d = 0; for (int q = 0; q + 1 < (int)gb.size(); ++q) d = std::max(d, gb[q + 1] - gb[q]); return d; }
+  static MergeGrouping uniform(int nlev, int m, bool backward) {   // groups of m levels counted from the start of the sweep
+    MergeGrouping G;
+    G.backward = backward;
+    const int ngrp = nlev ? (nlev + m - 1) / m : 0;
+    G.gb.assign(ngrp + 1, 0);
+    for (int q = 0; q <= ngrp; ++q)
+      G.gb[q] = backward ? (q == 0 ? 0 : std::max(0, nlev - (ngrp - q) * m)) : std::min(nlev, q * m);
+    return G;
+  }
+};
+
+struct MergeDev {
+  int m = 1, ngrp = 0;                // m = deepest group
+  bool backward = false;
+  MergeGrouping grouping;
+  int32_t* d_grp_of_lev = nullptr;    // per dependency level: its group / its round inside the group (device)
+  int32_t* d_rnd_of_lev = nullptr;
   int32_t* clen = nullptr;            // per level-ordered row: entries of its composite row
   int32_t* coff = nullptr;            // ... offset inside its round's pool
   int32_t* rcol[kMergeMaxRounds] = {};
@@ -27,15 +51,17 @@ struct MergeDev {
   bool failed = false;                // a row outgrew the long-row table (the caller gives up on this m)
   std::vector<int32_t> h_clen;        // host copy of clen
   void free_dev() {
-    hipFree(clen); hipFree(coff);
-    clen = coff = nullptr;
+    hipFree(clen); hipFree(coff); hipFree(d_grp_of_lev); hipFree(d_rnd_of_lev);
+    clen = coff = nullptr; d_grp_of_lev = d_rnd_of_lev = nullptr;
     for (int k = 0; k < kMergeMaxRounds; ++k) { hipFree(rcol[k]); hipFree(rval[k]); rcol[k] = nullptr; rval[k] = nullptr; }
   }
 };
 
 struct MergeArgs {
   const int32_t* prow; const int32_t* pcol; const real* pval; const real* pdiag; const int32_t* lev_of;
-  int n, ncols, nlev, m, ngrp, backward, round;
+  int n, ncols, nlev, ngrp, backward, round;
+  const int32_t* grp_of_lev; const int32_t* rnd_of_lev;   // per dependency level
+  const int32_t* rlev;                                    // per group: its level of the current round, or -1
   const int32_t* clen; const int32_t* coff;
   const int32_t* rcol[kMergeMaxRounds]; const real* rval[kMergeMaxRounds];
   // count pass: cnt / ovf out;  fill pass: off in, this round's pool + clen / coff out
@@ -50,12 +76,8 @@ struct MergeArgs {
   const int32_t* blk_ptr; const int32_t* lvl_ptr;
 };
 
-__device__ __forceinline__ int merge_group_of(int l, const MergeArgs& a) {
-  return a.backward ? a.ngrp - 1 - (a.nlev - 1 - l) / a.m : l / a.m;
-}
-__device__ __forceinline__ int merge_round_of(int l, const MergeArgs& a) {
-  return a.backward ? (a.nlev - 1 - l) % a.m : l % a.m;
-}
+__device__ __forceinline__ int merge_group_of(int l, const MergeArgs& a) { return a.grp_of_lev[l]; }
+__device__ __forceinline__ int merge_round_of(int l, const MergeArgs& a) { return a.rnd_of_lev[l]; }
 
 // LANES lanes per row, ROWS rows per workgroup, CAP table slots per row.  Dynamic LDS: per row CAP x (key, value,
 // dense key, dense value).
@@ -77,7 +99,7 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
       const int mid = (lo + hi) >> 1;
       if (a.blk_ptr[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
     }
-    const int l = a.backward ? a.nlev - 1 - ((a.ngrp - 1 - lo) * a.m + a.round) : lo * a.m + a.round;
+    const int l = a.rlev[lo];
     if (l >= 0 && l < a.nlev) {
       const int r = a.lvl_ptr[l] + ((int)blockIdx.x - a.blk_ptr[lo]) * ROWS + grp;
       if (r < a.lvl_ptr[l + 1]) p = r;
@@ -189,13 +211,23 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
 // D / omega (dscale = 1 / omega), Gauss-Seidel with D (dscale = 1).
 // min_tier: the smallest table worth trying (0: 128 slots, 1: 512, 2: 4096 — the caller knows the longest row of the
 // previous, shallower grouping; rows only grow with m)
-int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_diag, int m, bool backward, MergeDev* out,
+int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_diag, const MergeGrouping& G, MergeDev* out,
                     int min_tier = 0) {
   const int64_t n = g->n;
   MergeDev& R = *out;
-  R.m = m; R.backward = backward;
-  R.ngrp = g->nlev ? (g->nlev + m - 1) / m : 0;
+  const bool backward = G.backward;
+  const int m = G.depth();
+  R.m = m; R.backward = backward; R.grouping = G;
+  R.ngrp = G.ngrp();
   if (m > kMergeMaxRounds) return AMGH_EUNSUPPORTED;
+  if (R.ngrp < 0 || (g->nlev > 0 && (G.gb.front() != 0 || G.gb.back() != g->nlev))) return AMGH_EINVAL;
+  {
+    std::vector<int32_t> gol(std::max(g->nlev, 1), 0), rol(std::max(g->nlev, 1), 0);
+    for (int q = 0; q < R.ngrp; ++q)
+      for (int l = G.gb[q]; l < G.gb[q + 1]; ++l) { gol[l] = q; rol[l] = backward ? G.gb[q + 1] - 1 - l : l - G.gb[q]; }
+    RC_TRY(dev_upload(&R.d_grp_of_lev, gol.data(), (int64_t)gol.size()));
+    RC_TRY(dev_upload(&R.d_rnd_of_lev, rol.data(), (int64_t)rol.size()));
+  }
   RC_TRY(dev_alloc(&R.clen, n));
   RC_TRY(dev_alloc(&R.coff, n));
   HIP_TRY(hipMemsetAsync(R.clen, 0, sizeof(int32_t) * n, nullptr));
@@ -219,29 +251,34 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
   }
   MergeArgs a{};
   a.prow = g->rowptr; a.pcol = g->col; a.pval = g->val; a.pdiag = d_diag; a.lev_of = d_lev_of;
-  a.n = (int)n; a.ncols = (int)g->ncols; a.nlev = g->nlev; a.m = m; a.ngrp = R.ngrp; a.backward = backward ? 1 : 0;
+  a.n = (int)n; a.ncols = (int)g->ncols; a.nlev = g->nlev; a.ngrp = R.ngrp; a.backward = backward ? 1 : 0;
+  a.grp_of_lev = R.d_grp_of_lev; a.rnd_of_lev = R.d_rnd_of_lev;
   a.clen = R.clen; a.coff = R.coff; a.cnt = cnt; a.ovf = ovf; a.any_ovf = flags; a.fail = flags + 1;
   a.tier = 0;
   a.off = off; a.clen_out = R.clen; a.coff_out = R.coff; a.growth = growth;
   a.lvl_ptr = g->d_lvl_ptr;
-  int32_t *blk_s = nullptr, *blk_b = nullptr;
+  int32_t *blk_s = nullptr, *blk_b = nullptr, *rlev = nullptr;
   if (rc == AMGH_OK) rc = dev_alloc(&blk_s, R.ngrp + 1);
   if (rc == AMGH_OK) rc = dev_alloc(&blk_b, R.ngrp + 1);
-  std::vector<int32_t> hs(R.ngrp + 1), hb(R.ngrp + 1);
+  if (rc == AMGH_OK) rc = dev_alloc(&rlev, R.ngrp + 1);
+  a.rlev = rlev;
+  std::vector<int32_t> hs(R.ngrp + 1), hb(R.ngrp + 1), hl(R.ngrp + 1, -1);
   for (int k = 0; k < m && rc == AMGH_OK; ++k) {
     for (int q = 0; q < kMergeMaxRounds; ++q) { a.rcol[q] = R.rcol[q]; a.rval[q] = R.rval[q]; }
     a.round = k;
     // only the levels of this round are launched: workgroups per group for both launch shapes
     hs[0] = hb[0] = 0;
     for (int q = 0; q < R.ngrp; ++q) {
-      const int l = backward ? g->nlev - 1 - ((R.ngrp - 1 - q) * m + k) : q * m + k;
+      const int l = k < G.gb[q + 1] - G.gb[q] ? (backward ? G.gb[q + 1] - 1 - k : G.gb[q] + k) : -1;
+      hl[q] = l;
       const int w = (l >= 0 && l < g->nlev) ? g->lvl_ptr[l + 1] - g->lvl_ptr[l] : 0;
       hs[q + 1] = hs[q] + (w + RS - 1) / RS;
       hb[q + 1] = hb[q] + w;
     }
     const unsigned grid_s = (unsigned)hs[R.ngrp], grid_b = (unsigned)hb[R.ngrp];
     if (grid_s == 0) continue;
-    if (hipMemcpy(blk_s, hs.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemcpy(rlev, hl.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(blk_s, hs.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(blk_b, hb.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess) { rc = -1001; break; }
     if (hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), nullptr) != hipSuccess ||
         hipMemsetAsync(ovf, min_tier, n, nullptr) != hipSuccess || hipMemsetAsync(flags, 0, 8, nullptr) != hipSuccess) { rc = -1001; break; }
@@ -310,7 +347,7 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
       for (int64_t p2 = 0; p2 < n; ++p2) R.max_row = std::max<int64_t>(R.max_row, R.h_clen[p2]);
     }
   }
-  hipFree(cnt); hipFree(off); hipFree(flags); hipFree(ovf); hipFree(growth); hipFree(blk_s); hipFree(blk_b);
+  hipFree(cnt); hipFree(off); hipFree(flags); hipFree(ovf); hipFree(growth); hipFree(blk_s); hipFree(blk_b); hipFree(rlev);
   if (rc != AMGH_OK) R.free_dev();
   return rc;
 }

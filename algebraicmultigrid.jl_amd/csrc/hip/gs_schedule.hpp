@@ -905,6 +905,8 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
                          g->nlev, (int)n, d_lev_of);
       MergeDev chosen[2];
       int rc2 = AMGH_OK;
+      // average composite entries per row of every uniform depth that was built (index = depth; 0 = not built)
+      std::vector<double> fill[2] = {std::vector<double>(kMergeMaxRounds + 2, 0.0), std::vector<double>(kMergeMaxRounds + 2, 0.0)};
       for (int dir = 0; dir < 2 && rc2 == AMGH_OK; ++dir) {
         const bool backward = dir == 1;
         double best = g->nblk > 0 ? block_cost : merge_cost(base.nlev, nnz);
@@ -913,15 +915,19 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         // group size sits next to the forward one, so only that neighbourhood is built
         // (if nothing is accepted there — e.g. its rows outgrow the slots earlier — the search restarts from 2)
         for (int attempt = 0; attempt < 2 && rc2 == AMGH_OK; ++attempt) {
-        const int m_lo = (attempt == 0 && dir == 1 && chosen_m[0] > 2) ? chosen_m[0] - 1 : 2;
+        int m_lo = (attempt == 0 && dir == 1 && chosen_m[0] > 2) ? chosen_m[0] - 1 : 2;
         if (attempt == 1 && (chosen_m[dir] > 1 || !(dir == 1 && chosen_m[0] > 2))) break;
         worse = 0;
         int64_t prev_max = 0;  // longest composite row of the previous (shallower) candidate: rows only grow with m
-        for (int m = m_lo; m <= std::min(g_gs_merge, kMergeMaxRounds); ++m) {
+        int m_hi = std::min(g_gs_merge, kMergeMaxRounds);
+        if (g_gs_merge_force > 1) m_lo = m_hi = std::min(g_gs_merge_force, kMergeMaxRounds);   // measurement hook: exactly this depth
+        for (int m = m_lo; m <= m_hi; ++m) {
           MergeDev md;
-          rc2 = merge_build_dev(g, d_lev_of, g->diag, m, backward, &md, prev_max > 440 ? 2 : prev_max > 110 ? 1 : 0);
+          rc2 = merge_build_dev(g, d_lev_of, g->diag, MergeGrouping::uniform(g->nlev, m, backward), &md,
+                                prev_max > 440 ? 2 : prev_max > 110 ? 1 : 0);
           prev_max = md.max_row;
           if (rc2 != AMGH_OK) break;
+          if (!md.failed) fill[dir][m] = (double)md.total / (double)n;
           if (md.failed || md.max_row > kBigSlot - kBigSlot / 8) { md.free_dev(); break; }  // fill has exploded
           int cap = kSlot;
           if (md.max_row > kSlot || g_gs_bigslot == 2) cap = kBigSlot;  // (2 = always: test hook)
@@ -940,7 +946,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
             fprintf(stderr, "[amghip] n=%lld %s merge m=%d: %d groups, %.1f entries/row (max %lld), est. %.2f ms vs %.2f ms\n",
                     (long long)n, backward ? "bwd" : "fwd", m, ngrp, (double)md.total / n, (long long)md.max_row, 1e3 * c, 1e3 * best);
           const bool stream_bound = 12.0 * (double)md.total / 2.5e12 > best;  // streaming the composite rows alone costs more
-          if (c < 0.97 * best) {
+          if (c < 0.97 * best || g_gs_merge_force > 1) {
             best = c; chosen_m[dir] = m; chosen_cap[dir] = cap; worse = 0;
             chosen[dir].free_dev();
             chosen[dir] = std::move(md);
@@ -958,14 +964,119 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       }
       tm.lap("merge candidates (device)", n);
       const bool use = g->nblk == 0 ? true : (chosen_m[0] > 1 && chosen_m[1] > 1);
+      // Groups of DIFFERENT depth along the sweep.  Where the dependency levels are small — the two ends of a sweep over
+      // a grid-like operator — a launch is at its latency floor whatever it carries, so deeper groups there are nearly
+      // free, while in the middle the uniform optimum stands.  Per level: the depth d minimising
+      //   t0 / d + b * rows(level) * fill(d)
+      // with fill(d) measured on the uniform candidates above and extrapolated geometrically beyond them; groups are
+      // then cut greedily along the sweep (a group is as deep as every level in it tolerates), BUILT exactly, and kept
+      // when the per-group cost model says they win.  Measured (profiles/r02_zone_sweep.log): -12 % launches on the two
+      // finest levels for -3 % sweep time; pricing a launch higher (deeper middle) LOSES: the long composite rows of deep
+      // groups cost more than the launches they save.
+      for (int dir = 0; dir < 2 && rc2 == AMGH_OK && use && g_gs_zone && g_gs_merge_force <= 1; ++dir) {
+        const bool backward = dir == 1;
+        if (chosen_m[dir] <= 1 || chosen[dir].failed) continue;
+        const int depth_cap = std::min(g_gs_merge, kMergeMaxRounds);
+        if (depth_cap <= chosen_m[dir]) continue;
+        std::vector<double> fl(depth_cap + 1, 0.0);
+        fl[1] = 1.0 + 0.5 * std::max<double>(0.0, (double)nnz / (double)n - 1.0);    // one triangle + the s column
+        int last = 1;
+        for (int d = 2; d <= depth_cap; ++d) {
+          double f = fill[dir][d] > 0.0 ? fill[dir][d] : fill[1 - dir][d];   // (the mirrored direction fills alike)
+          if (f > 0.0) { fl[d] = f; last = d; }
+          else {
+            const double ratio = last >= 2 && fl[last - 1] > 0.0 ? std::max(1.05, fl[last] / fl[last - 1]) : 1.6;
+            fl[d] = fl[d - 1] * ratio;
+          }
+        }
+        // the constants of merge_cost (fitted on whole sweeps of all levels): per byte they are pessimistic for the fine
+        // level (its gathers are regular, ~5 TB/s while streaming) and right for the coarser ones (~2.6 TB/s) — a per-entry
+        // price that is too LOW deepens the middle of a sweep and loses (measured: 32.1 -> 34.1 ms with 6 us + 4.8 TB/s)
+        // and below ~6 MB a launch does not get cheaper any more: 4.7 us of kernel + the boundary (the same probe)
+        const double t0 = 1e-9 * g_gs_zone_t0_ns, bsec = 12.0 / 2.5e12, floor_s = 1e-9 * g_gs_zone_floor_ns;
+        auto group_cost = [&](int64_t entries, bool big) {
+          return std::max(floor_s, t0 + bsec * (double)entries) + (big ? 2.5e-6 : 0.0);
+        };
+        auto sweep_cost = [&](const MergeDev& md, const MergeGrouping& G, bool big) {
+          double c = 0.0;
+          for (int q = 0; q < G.ngrp(); ++q) {
+            int64_t e = 0;
+            for (int32_t p2 = base.lvl_ptr[G.gb[q]]; p2 < base.lvl_ptr[G.gb[q + 1]]; ++p2) e += md.h_clen[p2];
+            c += group_cost(e, big);
+          }
+          return c;
+        };
+        const bool big = chosen_cap[dir] == kBigSlot;
+        const int64_t row_limit = big ? kBigSlot - kBigSlot / 8 : kSlot - kSlot / 8;
+        if (chosen[dir].max_row > row_limit / 2) continue;       // deeper groups would outgrow the slots: nothing to try
+        const double uniform_cost = sweep_cost(chosen[dir], chosen[dir].grouping, big);
+        int cap_try = std::min(depth_cap, 2 * chosen_m[dir] + 2);   // (deeper than that has never fitted a 512-entry slot)
+        for (int attempt = 0; attempt < 4 && rc2 == AMGH_OK; ++attempt) {
+          // per level (in sweep order) the depth it would like
+          std::vector<int> want(g->nlev, 1);
+          for (int sidx = 0; sidx < g->nlev; ++sidx) {
+            const int l = backward ? g->nlev - 1 - sidx : sidx;
+            const double rows = (double)(base.lvl_ptr[l + 1] - base.lvl_ptr[l]);
+            double bestc = 1e300;
+            for (int d = 1; d <= cap_try; ++d) {
+              const double c = std::max(floor_s, t0 + bsec * rows * d * fl[d]) / d;
+              if (c < bestc * (1.0 - 1e-9)) { bestc = c; want[sidx] = d; }
+            }
+            want[sidx] = std::max(want[sidx], std::min(chosen_m[dir], cap_try));   // never shallower than the uniform choice
+          }
+          std::vector<int32_t> cuts{0};
+          for (int sidx = 0; sidx < g->nlev;) {
+            int d = std::min(want[sidx], g->nlev - sidx);
+            for (;;) {
+              int tol = d;
+              for (int t = sidx; t < sidx + d; ++t) tol = std::min(tol, want[t]);
+              if (tol >= d || d <= 1) break;
+              d = std::max(tol, 1);
+            }
+            sidx += d;
+            cuts.push_back(sidx);
+          }
+          MergeGrouping Z;
+          Z.backward = backward;
+          Z.gb.resize(cuts.size());
+          for (size_t k = 0; k < cuts.size(); ++k) Z.gb[k] = backward ? g->nlev - cuts[cuts.size() - 1 - k] : cuts[k];
+          if (Z.depth() <= chosen_m[dir]) break;                 // nothing deeper anywhere: the uniform grouping stands
+          MergeDev md;
+          rc2 = merge_build_dev(g, d_lev_of, g->diag, Z, &md, chosen[dir].max_row > 440 ? 2 : chosen[dir].max_row > 110 ? 1 : 0);
+          if (rc2 != AMGH_OK) break;
+          const bool fits = !md.failed && md.max_row <= row_limit && !(md.growth > kMergeGrowthMax);
+          const double zc = fits ? sweep_cost(md, Z, big) : 1e300;
+          if (getenv("AMGH_VERBOSE"))
+            fprintf(stderr, "[amghip] n=%lld %s zoned groups (depth <= %d): %d groups (uniform m=%d: %d), %.1f entries/row (max %lld)%s, "
+                    "est. %.2f ms vs %.2f ms\n", (long long)n, backward ? "bwd" : "fwd", cap_try, Z.ngrp(), chosen_m[dir],
+                    chosen[dir].ngrp, md.failed ? 0.0 : (double)md.total / n, (long long)md.max_row, fits ? "" : " [does not fit]",
+                    fits ? 1e3 * zc : -1.0, 1e3 * uniform_cost);
+          if (fits && zc < 0.97 * uniform_cost) {
+            chosen[dir].free_dev();
+            chosen[dir] = std::move(md);
+            md = MergeDev();
+            break;
+          }
+          md.free_dev();
+          if (fits) break;                                       // it fits and still does not win: deeper will not either
+          cap_try = std::max(chosen_m[dir] + 1, (cap_try * 3) / 4);
+          if (cap_try <= chosen_m[dir]) break;
+        }
+      }
+      tm.lap("zoned groups (device)", n);
       for (int dir = 0; dir < 2 && rc2 == AMGH_OK; ++dir) {
         const bool backward = dir == 1;
         MergeDev& md = chosen[dir];
         if (!use || chosen_m[dir] <= 1) { md.free_dev(); continue; }
-        const int best_m = chosen_m[dir], cap = chosen_cap[dir];
+        const int cap = chosen_cap[dir];
+        // levels per group as reported: the average depth of the grouping in use
+        const int best_m = std::max(1, (int)std::lround((double)g->nlev / std::max(1, md.ngrp)));
         // the grouped system: groups as levels, composite rows gathered into one CSR on the device
         HostLevelCsr sys;
-        MergeGroups G = merge_groups(base, best_m, backward);
+        struct { int ngrp; std::vector<int32_t> gptr; } G;
+        G.ngrp = md.ngrp;
+        G.gptr.resize(md.ngrp + 1);
+        for (int q = 0; q <= md.ngrp; ++q) G.gptr[q] = base.lvl_ptr[md.grouping.gb[q]];
         sys.n = n;
         sys.pdiag = base.pdiag;
         sys.pdpos.assign(n, -1);
@@ -979,8 +1090,9 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         if (rc2 == AMGH_OK) rc2 = dev_alloc(&src.val, md.total);
         if (rc2 == AMGH_OK) {
           MergeArgs a{};
-          a.n = (int)n; a.clen = md.clen; a.coff = md.coff; a.lev_of = d_lev_of; a.nlev = g->nlev; a.m = best_m;
+          a.n = (int)n; a.clen = md.clen; a.coff = md.coff; a.lev_of = d_lev_of; a.nlev = g->nlev;
           a.backward = backward ? 1 : 0; a.ngrp = md.ngrp;
+          a.grp_of_lev = md.d_grp_of_lev; a.rnd_of_lev = md.d_rnd_of_lev;
           for (int q = 0; q < kMergeMaxRounds; ++q) { a.rcol[q] = md.rcol[q]; a.rval[q] = md.rval[q]; }
           hipLaunchKernelGGL(merge_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, a,
                              (const int32_t*)src.rowptr, src.col, src.val);
