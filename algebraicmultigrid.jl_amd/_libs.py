@@ -81,6 +81,7 @@ def setup_lib():
     L.amgs_fit_candidates.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.POINTER(vp), C.POINTER(i64)]
     L.amgs_jacobi_prolongation.restype = vp
     L.amgs_jacobi_prolongation.argtypes = [vp, vp, C.c_double]
+    L.amgs_improve_candidates.argtypes = [vp, vp, C.c_int, C.c_int]
     L.amgs_free.argtypes = [vp]
     L.amgs_default_options_rs.argtypes = [C.POINTER(amgs_options)]
     L.amgs_default_options_sa.argtypes = [C.POINTER(amgs_options)]
@@ -222,6 +223,7 @@ def hip_lib(dtype=None):
     L.amgh_setup_classical_strength.argtypes = [vp, C.c_double, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.amgh_setup_direct_interpolation.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     L.amgh_setup_spgemm.argtypes = [vp, vp, C.POINTER(vp)]
+    L.amgh_setup_jacobi_prolongation.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]
     _hip = L
     return L
 

@@ -536,6 +536,98 @@ int amgh_setup_direct_interpolation(const amgh_dmat_t* At, const amgh_dmat_t* T,
 
 // C = X * Y (the two products of R * A * P, classical.jl:44).  AMGH_EUNSUPPORTED when a column of the product has more
 // entries than the LDS table of a lane group holds (the caller then uses the host library for this product).
+// ---- aggregation.jl:30-59 : P = JacobiProlongation(omega)(A, T) = T - (omega * D^-1 A) * T, D_i = sum_j |a_ij| -----------------
+} // extern "C"
+namespace {
+// column i of At = row i of A with its entries in ascending column order: the order the host loop adds them in
+__global__ void row_abs_inv_kernel(const int32_t* tp, const double* tv, int64_t n, double* dinv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double d = 0.0;
+  for (int32_t j = tp[i]; j < tp[i + 1]; ++j) d += fabs(tv[j]);
+  dinv[i] = d != 0.0 ? 1.0 / d : d;
+}
+__global__ void scale_rows_kernel(const int32_t* idx, const double* val, int64_t nnz, const double* dinv, double omega,
+                                  double* out) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+    double v = val[k] * dinv[idx[k]];   // scale_rows! (aggregation.jl:49-59) ...
+    v *= omega;                         // ... then rmul!(., omega): two roundings, as on the host
+    out[k] = v;
+  }
+}
+// C = X - Y column by column (both sorted by row), exact zeros not stored.  cp == nullptr: count pass.
+__global__ void sparse_sub_kernel(const int32_t* xp, const int32_t* xi, const double* xv, const int32_t* yp,
+                                  const int32_t* yi, const double* yv, int64_t n, const int32_t* cp, int32_t* ci,
+                                  double* cv, int32_t* cnt) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int32_t a = xp[j], ae = xp[j + 1], b = yp[j], be = yp[j + 1], c = 0;
+  const int32_t base = cp ? cp[j] : 0;
+  while (a < ae || b < be) {
+    int32_t row;
+    double v;
+    if (b >= be || (a < ae && xi[a] < yi[b])) { row = xi[a]; v = xv[a] - 0.0; ++a; }
+    else if (a >= ae || yi[b] < xi[a]) { row = yi[b]; v = 0.0 - yv[b]; ++b; }
+    else { row = xi[a]; v = xv[a] - yv[b]; ++a; ++b; }
+    if (v != 0.0) {
+      if (cp) { ci[base + c] = row; cv[base + c] = v; }
+      ++c;
+    }
+  }
+  if (!cp) cnt[j] = c;
+}
+}  // namespace
+extern "C" {
+
+int amgh_setup_jacobi_prolongation(const amgh_dmat_t* A, const amgh_dmat_t* T, double omega, amgh_dmat_t** P) {
+  RC_TRY(dmat_check(A));
+  RC_TRY(dmat_check(T));
+  if (!P || A->m != A->n || T->m != A->n) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(A->device));
+  const int64_t n = A->n, nc = T->n;
+  amgh_dmat *At = nullptr, *DS = nullptr, *W = nullptr, *C = nullptr;
+  double* dinv = nullptr;
+  int32_t *cnt = nullptr, *cp = nullptr;
+  int rc = dmat_transpose(A, &At, true, nullptr);
+  if (rc == AMGH_OK) rc = dev_alloc(&dinv, n);
+  if (rc == AMGH_OK && n > 0)
+    hipLaunchKernelGGL(row_abs_inv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)At->ptr,
+                       (const double*)At->val, n, dinv);
+  if (rc == AMGH_OK) rc = dmat_alloc(&DS, A->device, n, n, A->nnz);
+  if (rc == AMGH_OK) {
+    if (hipMemcpyAsync(DS->ptr, A->ptr, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToDevice, nullptr) != hipSuccess ||
+        hipMemcpyAsync(DS->idx, A->idx, sizeof(int32_t) * A->nnz, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = -1001;
+    if (rc == AMGH_OK && A->nnz > 0)
+      hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)grid_for(A->nnz)), dim3(256), 0, nullptr, (const int32_t*)A->idx,
+                         (const double*)A->val, A->nnz, (const double*)dinv, omega, DS->val);
+  }
+  if (rc == AMGH_OK) rc = dmat_spgemm(DS, T, &W, nullptr);      // AMGH_EUNSUPPORTED: a column outgrew the table
+  if (rc == AMGH_OK) rc = dev_alloc(&cnt, nc + 1);
+  if (rc == AMGH_OK && nc > 0)
+    hipLaunchKernelGGL(sparse_sub_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)T->ptr,
+                       (const int32_t*)T->idx, (const double*)T->val, (const int32_t*)W->ptr, (const int32_t*)W->idx,
+                       (const double*)W->val, nc, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, cnt);
+  int64_t total = 0;
+  if (rc == AMGH_OK) rc = dev_alloc(&cp, nc + 1);
+  if (rc == AMGH_OK) rc = dev_exclusive_scan(cnt, cp, nc, &total, nullptr);
+  if (rc == AMGH_OK) rc = dmat_alloc(&C, A->device, n, nc, total);
+  if (rc == AMGH_OK) {
+    hipFree(C->ptr);
+    C->ptr = cp;
+    cp = nullptr;
+    if (nc > 0)
+      hipLaunchKernelGGL(sparse_sub_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)T->ptr,
+                         (const int32_t*)T->idx, (const double*)T->val, (const int32_t*)W->ptr, (const int32_t*)W->idx,
+                         (const double*)W->val, nc, (const int32_t*)C->ptr, C->idx, C->val, (int32_t*)nullptr);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) rc = -1001;
+  }
+  dmat_free(At); dmat_free(DS); dmat_free(W);
+  hipFree(dinv); hipFree(cnt); hipFree(cp);
+  if (rc != AMGH_OK) { dmat_free(C); return rc; }
+  *P = C;
+  return AMGH_OK;
+}
+
 int amgh_setup_spgemm(const amgh_dmat_t* X, const amgh_dmat_t* Y, amgh_dmat_t** C) {
   RC_TRY(dmat_check(X));
   RC_TRY(dmat_check(Y));

@@ -1132,6 +1132,7 @@ amgs_hier* smoothed_aggregation(const Mat& A0, const double* B0, int nB, const a
   bool bsr_flag = false;
   while ((int)h->A.size() + 1 < o.max_levels && A->m > o.max_coarse) {
     const int64_t n = A->m;
+    Timer tm;  // AMGS_TIMING=1: the labels of aggregation.jl:126-145
     MatP S;
     if (o.hermitian) {
       S = symmetric_strength(*A, o.theta, bsr_flag);
@@ -1139,7 +1140,9 @@ amgs_hier* smoothed_aggregation(const Mat& A0, const double* B0, int nB, const a
       MatP At = transpose(*A);
       S = symmetric_strength(*At, o.theta, bsr_flag);
     }
+    tm.lap("strength", n);
     MatP AggOp = standard_aggregation(*S);
+    tm.lap("aggregation", n);
     if (AggOp->m == 0) break;
     // improve_candidates(A, B, 0): always the Hermitian fast path
     // (aggregation.jl:135-136, smoother.jl:34-38); symmetric sweep x iter.
@@ -1153,14 +1156,18 @@ amgs_hier* smoothed_aggregation(const Mat& A0, const double* B0, int nB, const a
           gs_sweep_host(*A, zero.data(), B.data() + (size_t)c * n, false);
         }
     }
+    tm.lap("improve candidates", n);
     std::vector<double> Bc;
     MatP T = vector_path ? fit_candidates_vector(*AggOp, B.data(), 1e-10, Bc)
                          : fit_candidates_matrix(*AggOp, B.data(), nB, 1e-10, Bc);
+    tm.lap("fit candidates", n);
     MatP P = jacobi_prolongation(*A, *T, o.sa_omega);
+    tm.lap("smooth prolongator", n);
     if (P->n == 0) break;
     MatP R = transpose(*P);
     MatP RA = spgemm(*R, *A);
     MatP RAP = spgemm(*RA, *P);
+    tm.lap("RAP", n);
     h->A.push_back(std::move(A));
     h->P.push_back(std::move(P));
     h->R.push_back(std::move(R));
@@ -1304,6 +1311,18 @@ amgs_mat* amgs_fit_candidates(const amgs_mat* AggOp, const double* B, int nB, in
 }
 amgs_mat* amgs_jacobi_prolongation(const amgs_mat* A, const amgs_mat* T, double omega) {
   return Guard::ptr([&]() -> amgs_mat* { return jacobi_prolongation(*A, *T, omega).release(); });
+}
+int amgs_improve_candidates(const amgs_mat* A, double* B, int nB, int iters) {
+  return Guard::rc([&]() {
+    if (A->m != A->n) throw std::runtime_error("improve_candidates: matrix must be square");
+    const int64_t n = A->m;
+    std::vector<double> zero(n, 0.0);
+    for (int c = 0; c < nB; ++c)
+      for (int it = 0; it < iters; ++it) {
+        gs_sweep_host(*A, zero.data(), B + (size_t)c * n, true);
+        gs_sweep_host(*A, zero.data(), B + (size_t)c * n, false);
+      }
+  });
 }
 void amgs_free(void* p) { std::free(p); }
 

@@ -567,6 +567,64 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0, buil
     return out, A_host
 
 
+def _smoothed_aggregation_gpu(A, B, theta, omega, improve_iters, hermitian, max_levels, max_coarse, device=0):
+    """extend_hierarchy_sa! (aggregation.jl:116-157) with its two heavy steps on the GPU: the prolongation smoothing
+    P = T - (omega D^-1 A) T (amgh_setup_jacobi_prolongation: row sums, scaling, SpGEMM, subtraction) and R*A*P
+    (transpose + two SpGEMMs).  Strength, the sequential aggregation, improve_candidates (Gauss-Seidel on the
+    candidates) and fit_candidates (a QR per aggregate) run in the host library on the level matrix, which is
+    downloaded anyway.  Returns [(A, P, R), ...], final_A — bitwise what amgs_smoothed_aggregation builds."""
+    from ._libs import hip_check, hip_lib
+    lib, L = hip_lib(), setup_lib()
+    if lib.amgh_device_count() <= 0:
+        raise AMGError("smoothed_aggregation(setup='gpu'): no HIP device visible")
+
+    def spgemm(X, Y):
+        c = C.c_void_p()
+        rc = lib.amgh_setup_spgemm(X.h, Y.h, C.byref(c))
+        if rc == -5:   # a column of the product outgrew the LDS table: this one product on the host
+            return _DMat.upload(X.to_host() @ Y.to_host(), lib, device)
+        hip_check(rc, "setup_spgemm")
+        return _DMat(c.value, lib)
+
+    vector = B is None or B.ndim == 1
+    n0 = A.m
+    Bcur = np.ones(n0) if B is None else np.array(B, dtype=np.float64, order="F", copy=True)
+    out = []
+    A_host, dA = A, _DMat.upload(A, lib, device)
+    bsr_flag = False
+    strength = SymmetricStrength(theta)
+    while len(out) + 1 < max_levels and A_host.m > max_coarse:
+        n = A_host.m
+        S, _ = strength(A_host if hermitian else A_host.transpose(), bsr_flag)
+        AggOp = SparseMatrixCSC(L.amgs_standard_aggregation(S._h))
+        if AggOp.m == 0:
+            break
+        nB = 1 if vector else Bcur.shape[1]
+        Bf = np.asfortranarray(Bcur.reshape(n, nB))
+        if L.amgs_improve_candidates(A_host._h, Bf.ctypes.data, nB, int(improve_iters)) != 0:
+            raise AMGError(L.amgs_last_error().decode())
+        T, Bc = fit_candidates(AggOp, Bf[:, 0] if vector else Bf)
+        dT = _DMat.upload(T, lib, device)
+        p = C.c_void_p()
+        rc = lib.amgh_setup_jacobi_prolongation(dA.h, dT.h, omega, C.byref(p))
+        if rc == -5:
+            dP = _DMat.upload(SparseMatrixCSC(L.amgs_jacobi_prolongation(A_host._h, T._h, omega)), lib, device)
+        else:
+            hip_check(rc, "setup_jacobi_prolongation")
+            dP = _DMat(p.value, lib)
+        if dP.n == 0:
+            break
+        r = C.c_void_p()
+        hip_check(lib.amgh_setup_transpose(dP.h, C.byref(r)), "setup_transpose")
+        dR = _DMat(r.value, lib)
+        dRAP = spgemm(spgemm(dR, dA), dP)
+        out.append((A_host, dP.to_host(), dR.to_host()))
+        A_host, dA = dRAP.to_host(), dRAP
+        Bcur = Bc
+        bsr_flag = True
+    return out, A_host
+
+
 def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, postsmoother=None,
                 max_levels=10, max_coarse=10, coarse_solver=None, setup=None, device=None, **kwargs):
     """ruge_stuben(A; strength=Classical(0.25), symmetry=HermitianSymmetry(), CF=RS(),
@@ -623,10 +681,13 @@ def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, post
 def smoothed_aggregation(A, B=None, symmetry=None, strength=None, aggregate=None, smooth=None,
                          presmoother=None, postsmoother=None, improve_candidates=None, max_levels=10,
                          max_coarse=10, diagonal_dominance=False, keep=False, verbose=False,
-                         coarse_solver=None, **kwargs):
+                         coarse_solver=None, setup=None, **kwargs):
     """smoothed_aggregation(A; B=nothing, symmetry, strength=SymmetricStrength(),
     aggregate=StandardAggregation(), smooth=JacobiProlongation(4/3), presmoother, postsmoother,
-    improve_candidates=GaussSeidel(iter=4), max_levels, max_coarse, coarse_solver) — aggregation.jl:66-114."""
+    improve_candidates=GaussSeidel(iter=4), max_levels, max_coarse, coarse_solver) — aggregation.jl:66-114.
+
+    setup = "host" (libamgsetup) | "gpu" (prolongation smoothing and R*A*P on the MI355X, strength / aggregation /
+    candidates on the host; same hierarchy bit for bit).  Default: the environment variable AMG_SETUP, else "host"."""
     if np.iscomplexobj(getattr(A, "data", np.zeros(0))):
         raise AMGError("Symmetric strength not implemented for complex matrices.")
     strength = strength if strength is not None else SymmetricStrength()
@@ -661,6 +722,25 @@ def smoothed_aggregation(A, B=None, symmetry=None, strength=None, aggregate=None
         nB = 1 if B.ndim == 1 else B.shape[1]
         Bf = np.asfortranarray(B.reshape(n, nB))
         Bptr = Bf.ctypes.data
+    import os
+    setup = setup if setup is not None else os.environ.get("AMG_SETUP", "host")
+    if setup == "gpu":
+        lv, final_A = _smoothed_aggregation_gpu(A, None if B is None else B, strength.theta, smooth.omega,
+                                                int(improve_candidates.iter), bool(o.hermitian), int(max_levels),
+                                                int(max_coarse))
+        levels = [Level(a, p, r, presmoother, postsmoother) for a, p, r in lv]
+        for m_ in [final_A] + [l.A for l in levels]:
+            m_.eltype = A.eltype
+        if not isinstance(symmetry, HermitianSymmetry):
+            for lev in levels:
+                for s_ in (presmoother, postsmoother):
+                    s_.check_no_symmetry(lev.A)
+        ml = MultiLevel(levels, final_A, coarse_solver(final_A), presmoother, postsmoother, symmetry, method="sa")
+        if verbose:
+            print(ml)
+        return ml
+    if setup != "host":
+        raise AMGError("smoothed_aggregation: setup must be 'host' or 'gpu'")
     hier = _Hier(setup_lib().amgs_smoothed_aggregation(A._h, Bptr, nB, C.byref(o)))
     ml = _build_multilevel(hier, presmoother, postsmoother, coarse_solver, symmetry, "sa", A.eltype)
     if verbose:

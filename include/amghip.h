@@ -372,6 +372,10 @@ int amgh_setup_direct_interpolation(const amgh_dmat_t* At, const amgh_dmat_t* T,
  * RAP = R * A * P (classical.jl:44).  AMGH_EUNSUPPORTED when a column of the product has more than ~440
  * entries (the caller then forms this product with the host library).                                          */
 int amgh_setup_spgemm(const amgh_dmat_t* X, const amgh_dmat_t* Y, amgh_dmat_t** C);
+/* P = JacobiProlongation(omega)(A, T) = T - (omega * D^-1 * A) * T with D_i = sum_j |a_ij| (aggregation.jl:30-59):
+ * the prolongation smoothing of smoothed_aggregation, the same sums in the same order as the host library
+ * (bitwise the same P).  AMGH_EUNSUPPORTED as amgh_setup_spgemm.                                               */
+int amgh_setup_jacobi_prolongation(const amgh_dmat_t* A, const amgh_dmat_t* T, double omega, amgh_dmat_t** P);
 
 /* ------------------------------------------------------------------------- */
 /* Device memory + timing helpers for hosts without a HIP binding of their own  */

@@ -89,6 +89,9 @@ amgs_mat* amgs_fit_candidates(const amgs_mat* AggOp, const double* B, int nB,
 /* JacobiProlongation(omega)(A, T, S, B, degree=1, LocalWeighting())          */
 amgs_mat* amgs_jacobi_prolongation(const amgs_mat* A, const amgs_mat* T,
                                    double omega);
+/* improve_candidates(A, B, 0): `iters` symmetric Gauss-Seidel sweeps on A x = 0 applied to every column of B
+ * (n x nB, column-major, in place) — aggregation.jl:75,135-136 with the Hermitian fast path of smoother.jl:34-38. */
+int amgs_improve_candidates(const amgs_mat* A, double* B, int nB, int iters);
 void amgs_free(void*);
 
 /* ---- drivers ------------------------------------------------------------ */

@@ -110,3 +110,38 @@ def test_built_beside_the_setup_when_coarsening_stops_early_or_never_starts():
         assert len(ml) == len(ref)
         r = uniform(A.m, 2)
         assert np.allclose(AMG.aspreconditioner(ml).ldiv(r), AMG.aspreconditioner(ref).ldiv(r), rtol=1e-12, atol=1e-14)
+
+
+def check_sa_hierarchy(A, **kw):
+    h = AMG.smoothed_aggregation(A, setup="host", **kw)
+    g = AMG.smoothed_aggregation(A, setup="gpu", **kw)
+    assert len(h) == len(g)
+    for l, (a, b) in enumerate(zip(h.levels, g.levels)):
+        assert same(a.A, b.A), f"A differs on level {l}"
+        assert same(a.P, b.P), f"P differs on level {l}"
+        assert same(a.R, b.R), f"R differs on level {l}"
+    assert same(h.final_A, g.final_A)
+    return g
+
+
+@pytest.mark.parametrize("dims", [(1000,), (60, 50), (24, 24, 24), (9,), (40, 3, 17)])
+def test_gpu_smoothed_aggregation_builds_the_host_hierarchy_bit_for_bit(dims):
+    """smoothed_aggregation(setup="gpu"): prolongation smoothing (row sums, scaling, SpGEMM, subtraction) and R*A*P on
+    the device (amgh_setup_jacobi_prolongation, aggregation.jl:30-59,147) — same sums in the same order as libamgsetup."""
+    g = check_sa_hierarchy(AMG.poisson(dims))
+    if dims == (1000,):     # the host library's level sizes for this matrix (aggregates of three)
+        assert [l.A.m for l in g.levels] + [g.final_A.m] == [1000, 334, 112, 38, 13, 5]
+
+
+def test_gpu_smoothed_aggregation_with_candidates_and_other_options():
+    from conftest import load_npz
+    d = load_npz("lin_elastic_2d")       # block-dof elasticity with three rigid-body modes: the QR path of fit_candidates
+    A = load_csc("lin_elastic_2d")
+    g = check_sa_hierarchy(A, B=d["B"])
+    x, hist = AMG._solve(g, d["b"], log=True, reltol=1e-10)
+    assert len(hist) - 1 == 27           # nns_test.jl:213-226
+    check_sa_hierarchy(AMG.poisson((30, 30)), strength=AMG.SymmetricStrength(0.1), max_levels=3)
+    check_sa_hierarchy(AMG.poisson((30, 30)), smooth=AMG.JacobiProlongation(1.0), improve_candidates=AMG.GaussSeidel(iter=2))
+    check_sa_hierarchy(AMG.poisson(500), B=np.linspace(1.0, 2.0, 500))
+    check_sa_hierarchy(load_csc("randlap"))
+    check_sa_hierarchy(AMG.poisson((20, 20)), symmetry=AMG.NoSymmetry())
