@@ -813,6 +813,7 @@ int amgh_gs_num_sweep_steps(const amgh_t* h, int l, int backward) {
   amgh_csr* M = h->levels[l]->smat();
   const GsSchedule* g = M->gs;
   if (!g) return 0;
+  if (g->dti_f && g_gs_dense_tri && g_gs_block_inverse) return (int)g->dti_off.size() - 1;   // dense triangular sweep: blocks
   if (g->nblk > 0 && g_gs_block_inverse) return g->nblk;             // block-inverse sweep: sequential block steps
   const GsSchedule* c = backward ? g->mb : g->mf;
   return (c && g_gs_merge > 1) ? c->nlev : g->nlev;                  // merged groups, or dependency levels
@@ -824,6 +825,12 @@ int amgh_gs_sweep_stats(const amgh_t* h, int l, int backward, int64_t* out6) {
   amgh_csr* M = h->levels[l]->smat();
   const GsSchedule* g = M->gs;
   if (!g) return AMGH_OK;
+  if (g->dti_f && g_gs_dense_tri && g_gs_block_inverse) {  // dense triangular sweep: pre-pass + one triangular GEMV
+    out6[0] = 2 * ((int64_t)g->dti_off.size() - 1);
+    out6[1] = g->n;
+    out6[2] = out6[3] = g->nnz + g->dti_off.back() / 2;
+    return AMGH_OK;
+  }
   if (g->nblk > 0 && g_gs_block_inverse) {  // block-inverse sweep: one launch per superblock (+ its pre-pass), dense inverses streamed
     const int S = g->super > 0 ? g->super : g->nblk;
     out6[0] = 2 * ((g->nblk + S - 1) / S);
@@ -1274,6 +1281,8 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_merge_force")) g_gs_merge_force = value;
   else if (!strcmp(name, "gs_zone")) g_gs_zone = value;
+  else if (!strcmp(name, "gs_dense_tri")) g_gs_dense_tri = value;
+  else if (!strcmp(name, "gs_dense_blk")) g_gs_dense_blk = value;
   else if (!strcmp(name, "gs_zone_t0_ns")) g_gs_zone_t0_ns = value;
   else if (!strcmp(name, "gs_zone_floor_ns")) g_gs_zone_floor_ns = value;
   else if (!strcmp(name, "gs_bigslot")) g_gs_bigslot = value;

@@ -220,7 +220,16 @@ struct GsSchedule {
   real* blk_s = nullptr;  // b - O_next x (n entries per right-hand-side column)
   int nblk = 0;  // 0 = block path not used for this operator
   int super = 0; // blocks per superblock (0: the whole operator is one superblock)
-  double blk_cond = 0.0;  // largest inf-norm condition estimate of an in-block triangle
+  double blk_cond = 0.0;
+  // small operators: the triangles of LARGE diagonal blocks (the whole matrix up to kDenseTriMax rows, else dti_B rows)
+  // inverted densely.  A sweep walks the blocks: s = b - (everything outside the block's triangle) x on the block's
+  // rows — a launch over the whole chip — then x_blk = T_blk^-1 s, one triangular GEMV: two launches per block
+  // instead of B / 128 sequential steps of one workgroup.
+  real* dti_f = nullptr;  // (D + L)_blk^-1 of every block, each nb x nb row-major, one after the other (natural order)
+  real* dti_b = nullptr;  // (D + U)_blk^-1
+  int dti_B = 0;          // rows per block (the last one may be shorter)
+  std::vector<int64_t> dti_off;  // first element of block k in dti_f / dti_b
+  double dti_cond = 0.0;  // largest inf-norm condition estimate of an in-block triangle
   // merged-level sweeps (gs_schedule.hpp, merge_build): per direction a child schedule over GROUPS of consecutive
   // dependency levels whose rows were made independent by substitution, plus the other triangle as a plain CSR
   // for the pre-pass s = b - T x.  Children share perm / bp / xp with this schedule; xp is then laid out as
@@ -228,6 +237,7 @@ struct GsSchedule {
   GsSchedule* mf = nullptr;
   GsSchedule* mb = nullptr;
   struct Tri { int32_t* rowptr = nullptr; int32_t* col = nullptr; real* val = nullptr; };
+  Tri dtri_f, dtri_b;     // pre-pass matrices of the dense sweeps, natural order: A without the in-block lower (forward) / upper (backward) triangle and diagonal
   Tri tri_f, tri_b;       // forward pre-pass: entries of later levels + halo; backward: earlier levels + halo
   int merge_f = 1, merge_b = 1;  // dependency levels per group
   int64_t xstride = 0;    // doubles per column of xp (ncols, or ncols + n with merged children)
@@ -257,6 +267,8 @@ struct GsSchedule {
       hipFree(o->sp_rowptr); hipFree(o->sp_col); hipFree(o->sp_val);
       *o = Outer();
     }
+    hipFree(dti_f); hipFree(dti_b); dti_f = dti_b = nullptr;
+    for (Tri* t : {&dtri_f, &dtri_b}) { hipFree(t->rowptr); hipFree(t->col); hipFree(t->val); *t = Tri(); }
     hipFree(blk_diag); blk_diag = nullptr;
     hipFree(blk_s); blk_s = nullptr;
     hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
@@ -307,6 +319,8 @@ int g_gs_sell = 1;              // merged groups from the SELL-like layout where
 int g_gs_lean = -1;             // memory-lean schedules: -1 = AMGH_LEAN environment variable, 0 off, 1 on; read at schedule build
 int g_gs_ept = 0;               // entries per thread of merged slot launches (0 = 2 when a group has more than 1024 slots, else 1)
 int g_gs_lpr = 0;               // lanes per row in the row sums of merged slot launches (0 = by row length, 1 = one thread per row)
+int g_gs_dense_blk = 4096;       // ... rows per dense block above kDenseTriMax rows; read at schedule build
+int g_gs_dense_tri = 1;          // small operators: sweeps through the dense inverse of the whole triangle (0 = block-inverse / exact order); build + sweep
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)
 
 // bumped whenever a schedule buffer that captured hipGraphs may point to is reallocated or freed (xp / bp growth,

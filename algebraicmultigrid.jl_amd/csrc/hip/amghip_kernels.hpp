@@ -1240,6 +1240,63 @@ __global__ void scalar_kernel(real* out, const real* a, const real* b, int op) {
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (op == 0) ? a[0] / b[0] : a[0];
 }
 
+// ---- dense triangular inverse (small operators) -------------------------------------------------------------------
+// X = (D + L)^-1 (upper = 0) or (D + U)^-1 (upper = 1) of a diagonal block of a CSR matrix, dense n x n ROW-major: one thread per column c
+// runs the substitution T X[:, c] = e_c down (up) the rows; a column depends on itself only, and the threads of a
+// workgroup walk the rows together, so the row's entries are one broadcast load.  X must be zeroed by the caller.
+__global__ void tri_inverse_kernel(const int32_t* rowptr, const int32_t* col, const real* val, int row0, int n, int upper,
+                                   real* X) {
+  // the triangle of the diagonal block of rows / columns [row0, row0 + n): entries outside the block are not part of it
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const int c_first = blockIdx.x * blockDim.x, c_last = min(n, c_first + (int)blockDim.x) - 1;
+  const int s0 = upper ? n - 1 - c_last : c_first;     // rows before the workgroup's first column are zero in every column
+  for (int s = s0; s < n; ++s) {
+    const int i = upper ? n - 1 - s : s;
+    const bool act = upper ? i <= c : i >= c;
+    real acc = (i == c) ? 1.0 : 0.0, d = 0.0;
+    for (int32_t j = rowptr[row0 + i]; j < rowptr[row0 + i + 1]; ++j) {
+      const int32_t cj = col[j] - row0;
+      const real v = val[j];
+      if (cj == i) d = v;
+      else if (act && cj >= 0 && cj < n && (upper ? cj > i : cj < i)) acc -= v * X[(size_t)cj * n + c];
+    }
+    if (act) X[(size_t)i * n + c] = acc / d;
+  }
+}
+// out[i] = sum_j |X[i, j]| (inf-norm rows of the inverse: the condition estimate of the triangle)
+__global__ void dense_abs_rowsum_kernel(const real* X, int n, real* out) {
+  const int i = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave, ln = threadIdx.x % kWave;
+  if (i >= n) return;
+  real acc = 0.0;
+  for (int j = ln; j < n; j += kWave) acc += fabs(X[(size_t)i * n + j]);
+  for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+  if (ln == 0) out[i] = acc;
+}
+// x = X s with X lower (upper = 0: columns 0..i of row i) or upper triangular, row-major: one 256-thread workgroup per
+// row, threads across the columns (coalesced; a thread owns every 256th entry, so all its loads are independent and in
+// flight together — a wavefront per row walked a 4 096-entry row in 64 dependent round trips), then a fixed
+// shuffle tree and the four wave partials added in order (deterministic).  gridDim.y = right-hand-side columns.
+__global__ __launch_bounds__(kThreads) void tri_gemv_kernel(const real* X, const real* s, real* x, int n, int upper, int64_t lds,
+                                                              int64_t ldx) {
+  __shared__ real s_part[kThreads / kWave];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const real* sv = s + (int64_t)blockIdx.y * lds;
+  const real* row = X + (size_t)i * n;
+  const int lo = upper ? i : 0, hi = upper ? n : i + 1;
+  real acc = 0.0;
+  for (int j = lo + tid; j < hi; j += kThreads) acc += row[j] * sv[j];
+  for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
+  if (tid % kWave == 0) s_part[tid / kWave] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    real t = s_part[0];
+#pragma unroll
+    for (int w = 1; w < kThreads / kWave; ++w) t += s_part[w];
+    x[(int64_t)blockIdx.y * ldx + i] = t;
+  }
+}
+
 // x = M * b, M dense n x n column-major (coarse solve, coarse_solver.jl:16).
 // One thread per output row, columns ascending.
 __global__ void dense_gemv_kernel(const real* M, const real* b, real* x, int n) {

@@ -53,6 +53,17 @@ int launch_gs_level(const StreamArgs& a, int rows, hipStream_t st, int ncolv = 1
   }
 }
 
+// SpMV-type launches pick their shape by size: the default configuration gives a workgroup 1 024 rows — right for the
+// big operators (it streams), but a coarse level of a few thousand LONG rows then runs on a handful of CUs
+// (5 195 rows of 124 entries: 6 workgroups, 0.18 ms for 8 MB).  Below 2^18 rows: 64 rows per 256-thread workgroup.
+// The per-row sums are the same in-order sums either way.
+using SmallCfg = StreamCfg<256, 64, 4096, 2, false, false>;
+template <int MODE>
+int launch_stream_sized(const StreamArgs& a, hipStream_t st, int ncolv) {
+  if (a.row_end - a.row_begin < (1 << 18)) return launch_stream<MODE, SmallCfg>(a, st, ncolv);
+  return launch_stream<MODE>(a, st, ncolv);
+}
+
 // ncolv right-hand-side columns (x: ncols apart, y and b: nrows apart) in one launch
 int csr_apply(const amgh_csr* op, int mode, const real* x, const real* b, real* y, hipStream_t st,
               int ncolv = 1) {
@@ -62,9 +73,9 @@ int csr_apply(const amgh_csr* op, int mode, const real* x, const real* b, real* 
   a.row_begin = 0; a.row_end = (int32_t)op->nrows;
   a.ldx = op->ncols; a.ldy = op->nrows; a.ldb = op->nrows;
   switch (mode) {
-    case M_SPMV: return launch_stream<M_SPMV>(a, st, ncolv);
-    case M_RESID: return launch_stream<M_RESID>(a, st, ncolv);
-    case M_ADD: return launch_stream<M_ADD>(a, st, ncolv);
+    case M_SPMV: return launch_stream_sized<M_SPMV>(a, st, ncolv);
+    case M_RESID: return launch_stream_sized<M_RESID>(a, st, ncolv);
+    case M_ADD: return launch_stream_sized<M_ADD>(a, st, ncolv);
   }
   return AMGH_EINVAL;
 }
@@ -77,7 +88,7 @@ int csr_jacobi(amgh_csr* op, real omega, const real* xin, const real* b, real* x
   a.x = xin; a.y = xout; a.b = b; a.dpos = op->dpos; a.diag = op->diag; a.omega = omega;
   a.row_begin = 0; a.row_end = (int32_t)op->nrows;
   a.ldx = op->ncols; a.ldy = op->nrows; a.ldb = op->nrows;
-  return launch_stream<M_JACOBI>(a, st, ncolv);
+  return launch_stream_sized<M_JACOBI>(a, st, ncolv);
 }
 
 template <int T, int PF>
@@ -107,9 +118,9 @@ int raw_apply(int mode, const int32_t* rowptr, const int32_t* col, const real* v
   a.row_begin = 0; a.row_end = (int32_t)nrows;
   a.ldx = ldx; a.ldy = ldy; a.ldb = ldb;
   switch (mode) {
-    case M_SPMV: return launch_stream<M_SPMV>(a, st, ncolv);
-    case M_RESID: return launch_stream<M_RESID>(a, st, ncolv);
-    case M_ADD: return launch_stream<M_ADD>(a, st, ncolv);
+    case M_SPMV: return launch_stream_sized<M_SPMV>(a, st, ncolv);
+    case M_RESID: return launch_stream_sized<M_RESID>(a, st, ncolv);
+    case M_ADD: return launch_stream_sized<M_ADD>(a, st, ncolv);
   }
   return AMGH_EINVAL;
 }
@@ -196,6 +207,30 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
     op->bytes += grown;
     g->cols_alloc = ncolv;
     g->bp_cols = 0;
+  }
+  if (g->dti_f && g_gs_dense_tri && g_gs_block_inverse && !sor) {
+    // small operator with the triangles of its (large) diagonal blocks inverted densely: block after block,
+    // s = b - (everything outside the block's triangle) x on the block's rows, then x_blk = T_blk^-1 s
+    g->bp_cols = 0;  // (no level-ordered copy of b is made on this path)
+    const GsSchedule::Tri& t = backward ? g->dtri_b : g->dtri_f;
+    const int B = g->dti_B, nb = (int)g->dti_off.size() - 1;
+    for (int q = 0; q < nb; ++q) {
+      const int k = backward ? nb - 1 - q : q;
+      const int r0 = k * B, rb = (int)std::min<int64_t>(B, g->n - r0);
+      StreamArgs ra{};
+      ra.rowptr = t.rowptr; ra.col = t.col; ra.val = t.val;
+      ra.x = x; ra.b = b; ra.y = g->blk_s;
+      ra.row_begin = r0; ra.row_end = r0 + rb;
+      ra.ldx = g->n; ra.ldy = g->n; ra.ldb = g->n;
+      // (a block's rows are few and long: 16 per workgroup, or the pre-pass of a 4 096-row block runs on 64 CUs)
+      if (nb > 1) RC_TRY((launch_stream<M_RESID, StreamCfg<256, 16, 4096, 2, false, false>>(ra, st, ncolv)));
+      else RC_TRY((launch_stream<M_RESID, StreamCfg<256, 64, 4096, 2, false, false>>(ra, st, ncolv)));
+      hipLaunchKernelGGL(tri_gemv_kernel, dim3((unsigned)rb, ncolv), dim3(kThreads), 0, st,
+                         (const real*)((backward ? g->dti_b : g->dti_f) + g->dti_off[k]), (const real*)(g->blk_s + r0), x + r0, rb,
+                         backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+    }
+    HIP_TRY(hipGetLastError());
+    return AMGH_OK;
   }
   if (g->nblk > 0 && g_gs_block_inverse && !sor) {
     // small densely coupled operator: n/128 sequential block steps in natural row order
