@@ -572,7 +572,7 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
     GsSchedule* g = new GsSchedule;
     rc = L->has_S ? gs_build(g, n, n, S_rowptr, S_col, S_val) : gs_build(g, n, n, A_rowptr, A_col, A_val);
     if (rc == AMGH_OK) { M->gs = g; M->bytes += g->bytes; }
-    else { g->free_dev(); delete g; }
+    else { g->free_dev(); delete g; g = nullptr; }   // (nothing below may touch g on this path)
     if (rc == AMGH_OK && g->nblk == 0) {  // SOR: its merged groups depend on the relaxation factor, build them now too
       const int64_t before = g->bytes;
       if (pre->kind == AMGH_SMOOTH_SOR && pre->iter > 0) (void)sor_children(g, pre->omega);
@@ -609,7 +609,7 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
     }
     // what the second half needs to know: the level-ordered P / R are wanted (g->h_perm is kept until then)
     L->lo_want = rc == AMGH_OK && both && same_pattern && g->nblk == 0 && g_gs_keep_lo && (int64_t)g->h_perm.size() == n;
-    if (!L->lo_want) std::vector<int32_t>().swap(g->h_perm);
+    if (g && !L->lo_want) std::vector<int32_t>().swap(g->h_perm);
   }
   if (rc != AMGH_OK) {
     level_discard(L);
@@ -1280,6 +1280,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_ept")) g_gs_ept = value;
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_merge_force")) g_gs_merge_force = value;
+  else if (!strcmp(name, "gs_merge_force_maxn")) g_gs_merge_force_maxn = value;
   else if (!strcmp(name, "gs_zone")) g_gs_zone = value;
   else if (!strcmp(name, "gs_dense_tri")) g_gs_dense_tri = value;
   else if (!strcmp(name, "gs_dense_blk")) g_gs_dense_blk = value;

@@ -312,6 +312,7 @@ int g_gs_merge = 16;             // merged-level sweeps: largest group of depend
 int g_gs_zone_t0_ns = 3000;      // ... its per-launch price (ns) and the floor below which a launch does not get cheaper (ns; 0 = none)
 int g_gs_zone_floor_ns = 0;
 int g_gs_zone = 1;               // groups of different depth along a sweep (deep where levels are small); read at schedule build
+int g_gs_merge_force_maxn = 0;   // ... only on operators with at most this many rows (0 = all)
 int g_gs_merge_force = 0;        // measurement hook: groups of exactly this many levels wherever they can be built (0 = cost model); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)

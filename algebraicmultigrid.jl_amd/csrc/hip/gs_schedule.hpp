@@ -979,6 +979,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
     const int S = g->super > 0 ? g->super : std::max(1, g->nblk);
     const double block_cost = g->nblk * 5.9e-6 + 2.0 * ((g->nblk + S - 1) / S) * 3.5e-6;
     int chosen_m[2] = {1, 1}, chosen_cap[2] = {kSlot, kSlot};
+    const int force_m = (g_gs_merge_force > 1 && (g_gs_merge_force_maxn <= 0 || n <= g_gs_merge_force_maxn)) ? g_gs_merge_force : 0;
     const bool host_merge = getenv("AMGH_HOST_MERGE") != nullptr;  // the host construction (reference for the device one)
     if (!host_merge) {
       // Candidates are BUILT on the device (milliseconds each: gs_merge_dev.hpp) instead of estimated from a sample on
@@ -1004,7 +1005,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         worse = 0;
         int64_t prev_max = 0;  // longest composite row of the previous (shallower) candidate: rows only grow with m
         int m_hi = std::min(g_gs_merge, kMergeMaxRounds);
-        if (g_gs_merge_force > 1) m_lo = m_hi = std::min(g_gs_merge_force, kMergeMaxRounds);   // measurement hook: exactly this depth
+        if (force_m > 1) m_lo = m_hi = std::min(force_m, kMergeMaxRounds);   // measurement hook: exactly this depth
         for (int m = m_lo; m <= m_hi; ++m) {
           MergeDev md;
           rc2 = merge_build_dev(g, d_lev_of, g->diag, MergeGrouping::uniform(g->nlev, m, backward), &md,
@@ -1012,7 +1013,11 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           prev_max = md.max_row;
           if (rc2 != AMGH_OK) break;
           if (!md.failed) fill[dir][m] = (double)md.total / (double)n;
-          if (md.failed || md.max_row > kBigSlot - kBigSlot / 8) { md.free_dev(); break; }  // fill has exploded
+          if (md.failed || md.max_row > kBigSlot - kBigSlot / 8) {  // fill has exploded
+            if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] n=%lld %s m=%d given up: failed %d, max row %lld\n", (long long)n, backward ? "bwd" : "fwd", m, (int)md.failed, (long long)md.max_row);
+            md.free_dev();
+            break;
+          }
           int cap = kSlot;
           if (md.max_row > kSlot || g_gs_bigslot == 2) cap = kBigSlot;  // (2 = always: test hook)
           if (cap == kBigSlot && !g_gs_bigslot) { md.free_dev(); break; }
@@ -1025,12 +1030,17 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           }
           const int ngrp = (base.nlev + m - 1) / m;
           // + the pre-pass; a long-row launch costs ~2.5 us more (a wave per row, rows of very different lengths)
-          const double c = merge_cost(ngrp, md.total) + 12.0 * (double)nnz / 2 / 4e12 + (cap == kBigSlot ? ngrp * 2.5e-6 : 0.0);
+          // long-row slots: the 2 048-entry slot kernel costs ~2.5 us more per launch; groups whose rows average >= 96
+          // entries run from the SELL-like copy instead (sell_build), where the surcharge is ~0.5 us (measured on the
+          // 228 k-row level of the 256^3 hierarchy: groups of 8-9 levels 1.45 ms per pass, 5-6 levels 1.78 ms)
+          const bool sell_rows = g_gs_sell && !gs_lean() && (double)md.total / (double)n >= 96.0;
+          const double c = merge_cost(ngrp, md.total) + 12.0 * (double)nnz / 2 / 4e12 +
+                           (cap == kBigSlot ? ngrp * (sell_rows ? 0.5e-6 : 2.5e-6) : 0.0);
           if (getenv("AMGH_VERBOSE"))
             fprintf(stderr, "[amghip] n=%lld %s merge m=%d: %d groups, %.1f entries/row (max %lld), est. %.2f ms vs %.2f ms\n",
                     (long long)n, backward ? "bwd" : "fwd", m, ngrp, (double)md.total / n, (long long)md.max_row, 1e3 * c, 1e3 * best);
           const bool stream_bound = 12.0 * (double)md.total / 2.5e12 > best;  // streaming the composite rows alone costs more
-          if (c < 0.97 * best || g_gs_merge_force > 1) {
+          if (c < 0.97 * best || force_m > 1) {
             best = c; chosen_m[dir] = m; chosen_cap[dir] = cap; worse = 0;
             chosen[dir].free_dev();
             chosen[dir] = std::move(md);
@@ -1057,7 +1067,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       // when the per-group cost model says they win.  Measured (profiles/r02_zone_sweep.log): -12 % launches on the two
       // finest levels for -3 % sweep time; pricing a launch higher (deeper middle) LOSES: the long composite rows of deep
       // groups cost more than the launches they save.
-      for (int dir = 0; dir < 2 && rc2 == AMGH_OK && use && g_gs_zone && g_gs_merge_force <= 1; ++dir) {
+      for (int dir = 0; dir < 2 && rc2 == AMGH_OK && use && g_gs_zone && force_m <= 1; ++dir) {
         const bool backward = dir == 1;
         if (chosen_m[dir] <= 1 || chosen[dir].failed) continue;
         const int depth_cap = std::min(g_gs_merge, kMergeMaxRounds);
