@@ -30,6 +30,12 @@ struct Level {
   bool lo_ok = false;
   real* lo_val = nullptr;  // S != A with the same pattern: values of A in the order of the schedule's level-ordered copy of S
   bool lo_want = false;    // between amgh_push_level_begin and _end: the level-ordered P / R are to be built
+  // the COARSE side in the next level's dependency-level order too (set when the next level is pushed and runs the
+  // level-ordered cycle): Rp's rows and Pp's columns are renumbered to it, the restricted residual is written straight
+  // into the next level's level-ordered right-hand side and the correction read from its level-ordered x — no gather
+  // of b / scatter of x on the next level, and the gathers of R and P stay local (a coarse hyperplane's fine
+  // neighbours sit in adjacent fine hyperplanes)
+  bool coarse_lo = false;
   bool nat_freed = false;  // memory-lean: the natural-order A (levels >= 1), P and R were released, the cycle runs level-ordered
 };
 
@@ -184,19 +190,21 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, real*& xc, real*& xo, 
   return AMGH_OK;
 }
 
-int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero);
+int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo_io = false);
 
 // __solve_next! (multilevel.jl:200-212)
 // x is the parent's freshly zeroed coarse_x (multilevel.jl:226) on the first visit, not on the second (W, F)
-int cycle_next(amgh_t* h, int l, real* x, const real* b, int cyc) {
+// lo_io: b is already in this level's level-ordered right-hand side (the level above restricted into it) and x is to
+// stay in its level-ordered vector (the level above prolongs from there)
+int cycle_next(amgh_t* h, int l, real* x, const real* b, int cyc, bool lo_io = false) {
   switch (cyc) {
-    case AMGH_CYCLE_V: return cycle(h, l, x, b, AMGH_CYCLE_V, true);
+    case AMGH_CYCLE_V: return cycle(h, l, x, b, AMGH_CYCLE_V, true, lo_io);
     case AMGH_CYCLE_W:
-      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_W, true));
-      return cycle(h, l, x, b, AMGH_CYCLE_W, false);
+      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_W, true, lo_io));
+      return cycle(h, l, x, b, AMGH_CYCLE_W, false, lo_io);
     case AMGH_CYCLE_F:
-      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_F, true));
-      return cycle(h, l, x, b, AMGH_CYCLE_V, false);
+      RC_TRY(cycle(h, l, x, b, AMGH_CYCLE_F, true, lo_io));
+      return cycle(h, l, x, b, AMGH_CYCLE_V, false, lo_io);
   }
   return AMGH_EINVAL;
 }
@@ -205,7 +213,7 @@ int cycle_next(amgh_t* h, int l, real* x, const real* b, int cyc) {
 // multilevel.jl:28-59).  The reference loops the columns inside every operator (smoother.jl:77,117); here
 // each launch covers all bs columns (one grid row / one workgroup per column): per column the arithmetic and
 // its order are those of the single-column path, so the results are bitwise the same.
-int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero) {
+int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo_io) {
   Level* L = h->levels[l];
   const int bs = h->nrhs;
   const int64_t n = L->n, nc = L->nc;
@@ -215,12 +223,17 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero) {
   // and residual / restriction / prolongation run on level-ordered copies of A, R, P (same entries in the same
   // order inside every row, so the same sums): no scatter after the pre-smoother, no gather before the post-smoother.
   GsSchedule* g = L->smat()->gs;
-  const bool lo = L->lo_ok && (g_gs_keep_lo || L->nat_freed) && g && g->nblk == 0;
+  const bool lo = L->lo_ok && (g_gs_keep_lo || L->nat_freed || lo_io) && g && g->nblk == 0;
+  if (lo_io && !lo) return AMGH_ESTATE;   // (cannot happen: the level above only hands over in level order what was built for it)
   {
     ProfScope p(h, AMGH_T_PRESMOOTH, l);
-    RC_TRY(smooth(h, L, L->pre, xc, xo, b, bs, xzero, false, false, lo));
+    RC_TRY(smooth(h, L, L->pre, xc, xo, b, bs, xzero, /*reuse_b*/ lo_io, /*x_resident*/ lo_io && !xzero, /*no_scatter*/ lo));
   }
   if (lo) {
+    // the next level takes its vectors in its own level order (Rp's rows / Pp's columns were renumbered when it was pushed)
+    Level* C = (L->coarse_lo && l + 1 < (int)h->levels.size()) ? h->levels[l + 1] : nullptr;
+    GsSchedule* cg = C ? C->smat()->gs : nullptr;
+    if (C && !(cg && C->lo_ok && cg->nblk == 0 && cg->cols_alloc >= bs)) return AMGH_ESTATE;
     const int64_t xs = g->xstride;
     {
       ProfScope p(h, AMGH_T_RESIDUAL, l);  // r = b - A x, everything in level order (bp was gathered by the pre-smoother)
@@ -230,22 +243,24 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero) {
     }
     {
       ProfScope p(h, AMGH_T_RESTRICT, l);
-      RC_TRY(csr_apply(&L->Rp, M_SPMV, L->res, nullptr, L->cb, h->stream, bs));
+      RC_TRY(csr_apply(&L->Rp, M_SPMV, L->res, nullptr, C ? cg->bp : L->cb, h->stream, bs));
+      if (C) cg->bp_cols = bs;          // the next level's level-ordered right-hand side is in place
     }
-    RC_TRY(vec_fill(h, L->cx, nc * bs, 0.0));
+    if (!C) RC_TRY(vec_fill(h, L->cx, nc * bs, 0.0));
     if (l == (int)h->levels.size() - 1) {
       ProfScope p(h, AMGH_T_COARSE, l + 1);
       for (int c = 0; c < bs; ++c) RC_TRY(coarse_solve(h, L->cx + c * nc, L->cb + c * nc));
     } else {
-      RC_TRY(cycle_next(h, l + 1, L->cx, L->cb, cyc));
+      RC_TRY(cycle_next(h, l + 1, L->cx, L->cb, cyc, C != nullptr));
     }
     {
       ProfScope p(h, AMGH_T_PROLONG, l);  // x += P e on the level-ordered x
-      RC_TRY(raw_apply(M_ADD, L->Pp.rowptr, L->Pp.col, L->Pp.val, n, L->cx, nc, nullptr, 0, g->xp, xs, h->stream, bs));
+      RC_TRY(raw_apply(M_ADD, L->Pp.rowptr, L->Pp.col, L->Pp.val, n, C ? cg->xp : L->cx, C ? cg->xstride : nc, nullptr, 0, g->xp,
+                       xs, h->stream, bs));
     }
     {
       ProfScope p(h, AMGH_T_POSTSMOOTH, l);
-      RC_TRY(smooth(h, L, L->post, xc, xo, b, bs, false, true, true, false));
+      RC_TRY(smooth(h, L, L->post, xc, xo, b, bs, false, true, true, /*no_scatter*/ lo_io));
     }
     return AMGH_OK;
   }
@@ -546,6 +561,67 @@ static void level_discard(Level* L) {
   delete L;
 }
 
+namespace {
+__global__ void perm_rowlen_kernel(const int32_t* rowptr, const int32_t* perm, int64_t n, int32_t* len) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) len[p] = rowptr[perm[p] + 1] - rowptr[perm[p]];
+}
+__global__ void perm_rows_kernel(const int32_t* rowptr, const int32_t* col, const real* val, const int32_t* perm,
+                                 const int32_t* new_rowptr, int64_t n, int32_t* ncol, real* nval) {
+  // one wavefront per row (rows of R have a handful of entries): entries keep their order inside the row
+  const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int ln = threadIdx.x % kWave;
+  if (p >= n) return;
+  const int32_t src = rowptr[perm[p]], len = rowptr[perm[p] + 1] - src, dst = new_rowptr[p];
+  for (int e = ln; e < len; e += kWave) { ncol[dst + e] = col[src + e]; nval[dst + e] = val[src + e]; }
+}
+__global__ void renumber_cols_kernel(int32_t* col, int64_t nnz, const int32_t* inv) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) col[k] = inv[col[k]];
+}
+__global__ void invert_perm_kernel(const int32_t* perm, int64_t n, int32_t* inv) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) inv[perm[p]] = (int32_t)p;
+}
+
+// Renumber the coarse side of level `prev` (rows of Rp, columns of Pp) to the dependency-level order of the next
+// level, whose schedule `g` has just been built (g->perm: position -> natural row, on the device).
+int coarse_side_to_level_order(Level* prev, const GsSchedule* g) {
+  const int64_t nc = prev->nc;
+  if ((int64_t)g->n != nc || !prev->Rp.rowptr || !prev->Pp.rowptr) return AMGH_OK;
+  int32_t *inv = nullptr, *len = nullptr, *nrp = nullptr, *ncol = nullptr;
+  real* nval = nullptr;
+  int rc = dev_alloc(&inv, nc);
+  if (rc == AMGH_OK) rc = dev_alloc(&len, nc + 1);
+  if (rc == AMGH_OK) rc = dev_alloc(&nrp, nc + 1);
+  if (rc == AMGH_OK) rc = dev_alloc(&ncol, prev->Rp.nnz);
+  if (rc == AMGH_OK) rc = dev_alloc(&nval, prev->Rp.nnz);
+  if (rc == AMGH_OK) {
+    const unsigned grid = (unsigned)((nc + 255) / 256);
+    hipLaunchKernelGGL(invert_perm_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)g->perm, nc, inv);
+    hipLaunchKernelGGL(perm_rowlen_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)prev->Rp.rowptr, (const int32_t*)g->perm, nc, len);
+    int64_t total = 0;
+    rc = dev_exclusive_scan(len, nrp, nc, &total, nullptr);
+    if (rc == AMGH_OK && total != prev->Rp.nnz) rc = AMGH_EINVAL;
+  }
+  if (rc == AMGH_OK) {
+    hipLaunchKernelGGL(perm_rows_kernel, dim3((unsigned)((nc * kWave + 255) / 256)), dim3(256), 0, nullptr,
+                       (const int32_t*)prev->Rp.rowptr, (const int32_t*)prev->Rp.col, (const real*)prev->Rp.val,
+                       (const int32_t*)g->perm, (const int32_t*)nrp, nc, ncol, nval);
+    hipLaunchKernelGGL(renumber_cols_kernel, dim3((unsigned)grid_for(prev->Pp.nnz)), dim3(256), 0, nullptr, prev->Pp.col,
+                       prev->Pp.nnz, (const int32_t*)inv);
+    if (hipDeviceSynchronize() != hipSuccess) rc = -1001;
+  }
+  if (rc == AMGH_OK) {
+    hipFree(prev->Rp.rowptr); hipFree(prev->Rp.col); hipFree(prev->Rp.val);
+    prev->Rp.rowptr = nrp; prev->Rp.col = ncol; prev->Rp.val = nval;
+    nrp = ncol = nullptr; nval = nullptr;
+    prev->coarse_lo = true;
+  }
+  hipFree(inv); hipFree(len); hipFree(nrp); hipFree(ncol); hipFree(nval);
+  return rc == AMGH_EUNSUPPORTED ? AMGH_OK : rc;   // (scan size limits: the natural-order coarse side stays)
+}
+}  // namespace
+
 // First half of push!(levels, Level(A, P, R, pre, post)): everything that needs A (and S) only — the uploads and the
 // smoother schedule.  A caller that produces P and R later (the setup phase: C/F splitting on the host, then
 // interpolation) can run this half on another host thread meanwhile.
@@ -672,6 +748,11 @@ int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const in
     level_discard(L);
     return rc;
   }
+  // this level runs the level-ordered cycle: the level above hands its coarse vectors over in that order
+  if (L->lo_ok && g && g->nblk == 0 && g_gs_keep_lo && g_gs_coarse_lo && !h->levels.empty() && h->levels.back()->lo_ok && h->nrhs >= 1) {
+    rc = coarse_side_to_level_order(h->levels.back(), g);
+    if (rc != AMGH_OK) { level_discard(L); return rc; }
+  }
   h->levels.push_back(L);
   return AMGH_OK;
 }
@@ -754,6 +835,10 @@ int amgh_finalize(amgh_t* h) {
       RC_TRY(csr_ensure_diag(L->smat(), h->stream));
     }
   }
+  // a level that receives its right-hand side in level order gets it written into its schedule's own vector by the
+  // level above: sized for the block of right-hand sides before the first cycle
+  for (size_t l = 0; l + 1 < h->levels.size(); ++l)
+    if (h->levels[l]->coarse_lo) RC_TRY(gs_ensure_cols(h->levels[l + 1]->smat(), h->nrhs, h->stream));
   const int64_t n = fine_n(h);
   if (h->levels.empty()) { RC_TRY(dev_alloc(&h->res_final, n * h->nrhs)); ws += 8 * n * h->nrhs; }
   RC_TRY(dev_alloc(&h->partial, kRedBlocks));
@@ -1282,6 +1367,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_merge_force")) g_gs_merge_force = value;
   else if (!strcmp(name, "gs_merge_force_maxn")) g_gs_merge_force_maxn = value;
   else if (!strcmp(name, "gs_zone")) g_gs_zone = value;
+  else if (!strcmp(name, "gs_coarse_lo")) g_gs_coarse_lo = value;
   else if (!strcmp(name, "gs_dense_tri")) g_gs_dense_tri = value;
   else if (!strcmp(name, "gs_dense_blk")) g_gs_dense_blk = value;
   else if (!strcmp(name, "gs_zone_t0_ns")) g_gs_zone_t0_ns = value;

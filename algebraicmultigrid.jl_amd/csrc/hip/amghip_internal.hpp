@@ -305,6 +305,7 @@ int g_gs_nnz_per_wg = 256;     // and about this many nonzeros per workgroup (on
 int g_gs_threads = 256;
 int g_gs_block_pipe = 1;        // software-pipelined block sweep (gs_block_pipe_kernel)
 int g_gs_super = 8;             // block-inverse sweeps: blocks per superblock (0 = one launch for the whole operator); read at schedule build
+int g_gs_coarse_lo = 1;         // ... and hand the coarse vectors of a level over in the next level's order (read at amgh_push_level)
 int g_gs_keep_lo = 1;           // keep x in level order between pre- and post-smoother (level-ordered residual, R, P)
 int g_gs_flip = 1;              // alternating merged sweeps: s of the next sweep from the last one (no matrix pass)
 int g_gs_bigslot = 1;           // allow long-row slots (composite rows up to 2048 entries) when merging

@@ -185,29 +185,35 @@ int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st)
 // pre-smoother of the same cycle and level): its level-ordered copy is still in place.
 // x_resident: the level-ordered x of this operator (g->xp) is already current: skip the gather of x (the cycle
 // kept x there between the pre- and the post-smoother); no_scatter: leave the result in g->xp only.
+// the schedule's per-column scratch (level-ordered b, x [; s], block-path s) for blocks of ncolv right-hand sides
+int gs_ensure_cols(amgh_csr* op, int ncolv, hipStream_t st) {
+  GsSchedule* g = op->gs;
+  if (!g || ncolv <= g->cols_alloc) return AMGH_OK;
+  HIP_TRY(hipStreamSynchronize(st));
+  ++g_sched_epoch;
+  hipFree(g->bp); hipFree(g->xp); g->bp = g->xp = nullptr;
+  RC_TRY(dev_alloc(&g->bp, g->n * ncolv));
+  RC_TRY(dev_alloc(&g->xp, g->xstride * ncolv));
+  int64_t grown = 8 * (g->n + g->xstride) * (ncolv - g->cols_alloc);
+  if (g->blk_s) {
+    hipFree(g->blk_s); g->blk_s = nullptr;
+    RC_TRY(dev_alloc(&g->blk_s, g->n * ncolv));
+    grown += 8 * g->n * (ncolv - g->cols_alloc);
+  }
+  g->bytes += grown;
+  op->bytes += grown;
+  g->cols_alloc = ncolv;
+  g->bp_cols = 0;
+  return AMGH_OK;
+}
+
 int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, const real* b, hipStream_t st,
                  bool first = true, bool last = true, int ncolv = 1, bool xzero = false, bool reuse_b = false,
                  bool x_resident = false, bool no_scatter = false) {
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
   if (g->n <= 0) return AMGH_OK;
-  if (ncolv > g->cols_alloc) {  // grow the per-column scratch (first block solve on this operator)
-    HIP_TRY(hipStreamSynchronize(st));
-    ++g_sched_epoch;
-    hipFree(g->bp); hipFree(g->xp); g->bp = g->xp = nullptr;
-    RC_TRY(dev_alloc(&g->bp, g->n * ncolv));
-    RC_TRY(dev_alloc(&g->xp, g->xstride * ncolv));
-    int64_t grown = 8 * (g->n + g->xstride) * (ncolv - g->cols_alloc);
-    if (g->blk_s) {
-      hipFree(g->blk_s); g->blk_s = nullptr;
-      RC_TRY(dev_alloc(&g->blk_s, g->n * ncolv));
-      grown += 8 * g->n * (ncolv - g->cols_alloc);
-    }
-    g->bytes += grown;
-    op->bytes += grown;
-    g->cols_alloc = ncolv;
-    g->bp_cols = 0;
-  }
+  RC_TRY(gs_ensure_cols(op, ncolv, st));
   if (g->dti_f && g_gs_dense_tri && g_gs_block_inverse && !sor) {
     // small operator with the triangles of its (large) diagonal blocks inverted densely: block after block,
     // s = b - (everything outside the block's triangle) x on the block's rows, then x_blk = T_blk^-1 s
