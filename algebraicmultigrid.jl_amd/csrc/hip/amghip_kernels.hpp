@@ -1244,9 +1244,13 @@ __global__ void scalar_kernel(real* out, const real* a, const real* b, int op) {
 // X = (D + L)^-1 (upper = 0) or (D + U)^-1 (upper = 1) of a diagonal block of a CSR matrix, dense n x n ROW-major: one thread per column c
 // runs the substitution T X[:, c] = e_c down (up) the rows; a column depends on itself only, and the threads of a
 // workgroup walk the rows together, so the row's entries are one broadcast load.  X must be zeroed by the caller.
-__global__ void tri_inverse_kernel(const int32_t* rowptr, const int32_t* col, const real* val, int row0, int n, int upper,
-                                   real* X) {
-  // the triangle of the diagonal block of rows / columns [row0, row0 + n): entries outside the block are not part of it
+__global__ void tri_inverse_kernel(const int32_t* rowptr, const int32_t* col, const real* val, int B, int ntot,
+                                   const int64_t* off, real* Xf, real* Xb) {
+  // blockIdx.y = diagonal block k (rows / columns [k B, min(ntot, (k + 1) B))), blockIdx.z = 0: (D + L)^-1, 1: (D + U)^-1 —
+  // all blocks and both triangles in ONE launch (each is a chain of n dependent row steps: they only pay side by side).
+  // Entries outside the block are not part of its triangle.
+  const int row0 = blockIdx.y * B, n = min(B, ntot - row0), upper = blockIdx.z;
+  real* X = (upper ? Xb : Xf) + off[blockIdx.y];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   const int c_first = blockIdx.x * blockDim.x, c_last = min(n, c_first + (int)blockDim.x) - 1;
@@ -1265,13 +1269,17 @@ __global__ void tri_inverse_kernel(const int32_t* rowptr, const int32_t* col, co
   }
 }
 // out[i] = sum_j |X[i, j]| (inf-norm rows of the inverse: the condition estimate of the triangle)
-__global__ void dense_abs_rowsum_kernel(const real* X, int n, real* out) {
+__global__ void dense_abs_rowsum_kernel(const real* Xf, const real* Xb, int B, int ntot, const int64_t* off, real* out_f,
+                                        real* out_b) {
+  // blockIdx.y = diagonal block, blockIdx.z = triangle; one wavefront per row of the block
+  const int row0 = blockIdx.y * B, n = min(B, ntot - row0);
+  const real* X = (blockIdx.z ? Xb : Xf) + off[blockIdx.y];
   const int i = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave, ln = threadIdx.x % kWave;
   if (i >= n) return;
   real acc = 0.0;
   for (int j = ln; j < n; j += kWave) acc += fabs(X[(size_t)i * n + j]);
   for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
-  if (ln == 0) out[i] = acc;
+  if (ln == 0) (blockIdx.z ? out_b : out_f)[row0 + i] = acc;
 }
 // x = X s with X lower (upper = 0: columns 0..i of row i) or upper triangular, row-major: one 256-thread workgroup per
 // row, threads across the columns (coalesced; a thread owns every 256th entry, so all its loads are independent and in

@@ -901,27 +901,27 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         g->dti_B = B;
         g->dti_off.assign(nb + 1, 0);
         for (int k = 0; k < nb; ++k) { const int64_t rb = std::min<int64_t>(B, n - (int64_t)k * B); g->dti_off[k + 1] = g->dti_off[k] + rb * rb; }
-        int32_t* d_rp = nullptr; int32_t* d_ci = nullptr; real* d_va = nullptr; real* d_rs = nullptr;
+        int32_t* d_rp = nullptr; int32_t* d_ci = nullptr; real* d_va = nullptr; real* d_rs = nullptr; int64_t* d_off = nullptr;
         int rc3 = dev_upload(&d_rp, rowptr, n + 1);
         if (rc3 == AMGH_OK) rc3 = dev_upload(&d_ci, col, nnz);
         if (rc3 == AMGH_OK) rc3 = dev_upload(&d_va, val, nnz);
-        if (rc3 == AMGH_OK) rc3 = dev_alloc(&d_rs, n);
+        if (rc3 == AMGH_OK) rc3 = dev_upload(&d_off, g->dti_off.data(), nb + 1);
+        if (rc3 == AMGH_OK) rc3 = dev_alloc(&d_rs, 2 * n);
         if (rc3 == AMGH_OK) rc3 = dev_alloc(&g->dti_f, g->dti_off[nb]);
         if (rc3 == AMGH_OK) rc3 = dev_alloc(&g->dti_b, g->dti_off[nb]);
         double cond = 0.0;
         if (rc3 == AMGH_OK) {
-          std::vector<real> rs(n);
+          std::vector<real> rs(2 * n);
+          if (hipMemsetAsync(g->dti_f, 0, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess ||
+              hipMemsetAsync(g->dti_b, 0, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess) rc3 = -1001;
+          if (rc3 == AMGH_OK) {
+            hipLaunchKernelGGL(tri_inverse_kernel, dim3((unsigned)((B + 63) / 64), nb, 2), dim3(64), 0, nullptr, (const int32_t*)d_rp,
+                               (const int32_t*)d_ci, (const real*)d_va, B, (int)n, (const int64_t*)d_off, g->dti_f, g->dti_b);
+            hipLaunchKernelGGL(dense_abs_rowsum_kernel, dim3((unsigned)((B + 3) / 4), nb, 2), dim3(4 * kWave), 0, nullptr,
+                               (const real*)g->dti_f, (const real*)g->dti_b, B, (int)n, (const int64_t*)d_off, d_rs, d_rs + n);
+            if (hipMemcpy(rs.data(), d_rs, sizeof(real) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) rc3 = -1001;
+          }
           for (int dir = 0; dir < 2 && rc3 == AMGH_OK; ++dir) {
-            real* X = dir ? g->dti_b : g->dti_f;
-            if (hipMemsetAsync(X, 0, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess) { rc3 = -1001; break; }
-            for (int k = 0; k < nb; ++k) {
-              const int r0 = k * B, rb = (int)std::min<int64_t>(B, n - r0);
-              hipLaunchKernelGGL(tri_inverse_kernel, dim3((unsigned)((rb + 63) / 64)), dim3(64), 0, nullptr, (const int32_t*)d_rp,
-                                 (const int32_t*)d_ci, (const real*)d_va, r0, rb, dir, X + g->dti_off[k]);
-              hipLaunchKernelGGL(dense_abs_rowsum_kernel, dim3((unsigned)((rb + 3) / 4)), dim3(4 * kWave), 0, nullptr,
-                                 (const real*)(X + g->dti_off[k]), rb, d_rs + r0);
-            }
-            if (hipMemcpy(rs.data(), d_rs, sizeof(real) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc3 = -1001; break; }
             for (int k = 0; k < nb; ++k) {   // ||T_blk||_inf on the host, ||T_blk^-1||_inf from the device rows
               const int64_t r0 = (int64_t)k * B, r1 = std::min<int64_t>(n, r0 + B);
               double nt = 0.0, nx = 0.0;
@@ -930,7 +930,8 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
                 for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
                   if (col[j] >= r0 && col[j] < r1 && (dir ? col[j] >= i : col[j] <= i)) r += std::fabs((double)val[j]);
                 nt = std::max(nt, r);
-                nx = std::isfinite((double)rs[i]) ? std::max(nx, (double)rs[i]) : 1e300;
+                const double xr = (double)rs[(size_t)dir * n + i];
+                nx = std::isfinite(xr) ? std::max(nx, xr) : 1e300;
               }
               cond = std::max(cond, nt * nx);
             }
@@ -955,7 +956,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           if (rc3 == AMGH_OK) rc3 = dev_upload(&t.col, tc.data(), (int64_t)tc.size());
           if (rc3 == AMGH_OK) rc3 = dev_upload(&t.val, tv.data(), (int64_t)tv.size());
         }
-        hipFree(d_rp); hipFree(d_ci); hipFree(d_va); hipFree(d_rs);
+        hipFree(d_rp); hipFree(d_ci); hipFree(d_va); hipFree(d_rs); hipFree(d_off);
         g->dti_cond = cond;
         if (getenv("AMGH_VERBOSE"))
           fprintf(stderr, "[amghip] n=%lld dense triangle inverses, %d block(s) of %d rows: cond %.3g -> %s\n", (long long)n, nb, B, cond,
