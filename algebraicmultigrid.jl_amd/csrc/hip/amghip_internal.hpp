@@ -154,6 +154,17 @@ inline hipError_t staged_copy(void* dst, const void* src, size_t bytes, hipMemcp
   return hipSuccess;
 }
 
+// zero a (possibly very large) device range: in pieces of 1 GiB (a single multi-GB memset has been seen to fail with
+// "invalid argument" — the slot arrays of a 512^3 fine level are 5.6 and 11 GB)
+inline hipError_t dev_zero(void* p, size_t bytes, hipStream_t st) {
+  const size_t piece = size_t(1) << 30;
+  for (size_t o = 0; o < bytes; o += piece) {
+    const hipError_t e = hipMemsetAsync((char*)p + o, 0, std::min(piece, bytes - o), st);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 template <class T>
 int dev_upload(T** p, const T* src, int64_t count) {
   RC_TRY(dev_alloc(p, count));

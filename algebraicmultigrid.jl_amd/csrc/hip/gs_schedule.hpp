@@ -382,8 +382,8 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       const int64_t wtotal = (int64_t)slot_row.size() * SE;
       RC_TRY(dev_alloc(&g->wcol, wtotal));
       RC_TRY(dev_alloc(&g->wval, wtotal));
-      HIP_TRY(hipMemsetAsync(g->wcol, 0, sizeof(int32_t) * wtotal, nullptr));
-      HIP_TRY(hipMemsetAsync(g->wval, 0, sizeof(real) * wtotal, nullptr));
+      HIP_TRY(dev_zero(g->wcol, sizeof(int32_t) * (size_t)wtotal, nullptr));
+      HIP_TRY(dev_zero(g->wval, sizeof(real) * (size_t)wtotal, nullptr));
       RC_TRY(dev_upload(&g->slot_row, sr2.data(), (int64_t)sr2.size()));
       RC_TRY(dev_upload(&g->wmeta, wmeta.data(), n));
       int32_t *t_row = nullptr, *t_col = nullptr;
@@ -912,8 +912,8 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         double cond = 0.0;
         if (rc3 == AMGH_OK) {
           std::vector<real> rs(2 * n);
-          if (hipMemsetAsync(g->dti_f, 0, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess ||
-              hipMemsetAsync(g->dti_b, 0, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess) rc3 = -1001;
+          if (dev_zero(g->dti_f, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess ||
+              dev_zero(g->dti_b, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess) rc3 = -1001;
           if (rc3 == AMGH_OK) {
             hipLaunchKernelGGL(tri_inverse_kernel, dim3((unsigned)((B + 63) / 64), nb, 2), dim3(64), 0, nullptr, (const int32_t*)d_rp,
                                (const int32_t*)d_ci, (const real*)d_va, B, (int)n, (const int64_t*)d_off, g->dti_f, g->dti_b);
