@@ -75,6 +75,17 @@ __global__ void prepass_kernel(const int32_t* rp, const int32_t* ci, const doubl
   s[i] = acc;
 }
 
+// the pre-pass in tile-local order: s_loc[local row] = b - U x for every local row of every tile (recomputed copies too)
+__global__ void prepass_local_kernel(const int32_t* rp, const int32_t* ci, const double* va, const double* b, const double* x,
+                                     const int32_t* grow, int64_t nlocal, double* s_loc) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nlocal) return;
+  const int64_t i = grow[k] & 0x7fffffff;
+  double acc = b[i];
+  for (int32_t j = rp[i]; j < rp[i + 1]; ++j) if (ci[j] > i) acc -= va[j] * x[ci[j]];
+  s_loc[k] = acc;
+}
+
 // One workgroup = one tile of one group.  The global loads run AHEAD of the sub-levels: the external x values go to
 // LDS first, and — one row per thread and sub-level — the rows' operands (global row, diagonal or its reciprocal, s,
 // entries) are loaded into registers a CHUNK of MC sub-levels ahead: while chunk c is computed from LDS and registers
@@ -90,7 +101,8 @@ struct TileD {
 struct ArgsD {
   const TileD* tiles; const int32_t* grow; const double* diag; const int32_t* ext_col; const int32_t* eidx; const double* eval;
   const int4* pk_i; const double4* pk_d;   // K <= 3: one row = {idx0, idx1, idx2, global row} + {val0, val1, val2, diag}: three 16-byte loads
-  const double* s; double* x; int m; int use_rcp; int packed;   // stage: 0 full | 1 operand loads only | 2 sub-level loop only
+  const double* s; double* x; int m; int use_rcp; int packed;
+  const double* s_loc; int local_s;   // s in tile-local order (written by a tile-shaped pre-pass): no dependent load behind the row id   // stage: 0 full | 1 operand loads only | 2 sub-level loop only
 };
 // a workgroup barrier that orders LDS only: it does not wait for global loads or stores in flight (__syncthreads()
 // waits for vmcnt(0): every sub-level would pay the write latency of its own x stores, and the prefetch its loads)
@@ -132,8 +144,16 @@ __device__ __forceinline__ void fetch_chunk(const ArgsD& a, const TileD& t, int 
       }
     }
   }
+  if (a.local_s) {
 #pragma unroll
-  for (int q = 0; q < MC; ++q) if (o.g[q] != -2) o.sv[q] = a.s[o.g[q] & 0x7fffffff];
+    for (int q = 0; q < MC; ++q) {
+      const int ql = q0 + q;
+      if (ql < a.m) { const int r0 = t.sub_ptr[ql], nr = t.sub_ptr[ql + 1] - r0; if (tid < nr) o.sv[q] = a.s_loc[t.row0 + r0 + tid]; }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < MC; ++q) if (o.g[q] != -2) o.sv[q] = a.s[o.g[q] & 0x7fffffff];
+  }
 }
 
 template <int MC, int KMAX, int THREADS, int STAGE>
@@ -202,7 +222,7 @@ struct Built {
 };
 
 int main(int argc, char** argv) {
-  if (argc < 6) { printf("usage: %s poisson N m block|blob W [threads=512] [rcp=0] [chunk=4] [packed=1]   |   %s file PATH m blob W [threads] [rcp] [chunk]\n", argv[0], argv[0]); return 1; }
+  if (argc < 6) { printf("usage: %s poisson N m block|blob W [threads=512] [rcp=0] [chunk=4] [packed=1] [local_s=0]   |   %s file PATH m blob W [threads] [rcp] [chunk]\n", argv[0], argv[0]); return 1; }
   const bool is_poisson = !strcmp(argv[1], "poisson");
   const int N = is_poisson ? atoi(argv[2]) : 0;
   Csr A = is_poisson ? poisson3(N) : load(argv[2]);
@@ -453,7 +473,9 @@ int main(int argc, char** argv) {
   double* d_va = (double*)up(A.va.data(), A.va.size() * 8);
   double* d_b = (double*)up(b.data(), n * 8); double* d_x = (double*)up(x0.data(), n * 8);
   double* d_s; CHECK(hipMalloc(&d_s, n * 8));
-  a.s = d_s; a.x = d_x; a.m = m; a.use_rcp = use_rcp;
+  const int local_s = argc > 10 ? atoi(argv[10]) : 0;
+  double* d_sloc; CHECK(hipMalloc(&d_sloc, std::max<size_t>(8, B.grow.size() * 8)));
+  a.s = d_s; a.x = d_x; a.m = m; a.use_rcp = use_rcp; a.s_loc = d_sloc; a.local_s = local_s;
   hipStream_t st; CHECK(hipStreamCreate(&st));
   hipEvent_t e0, e1, e2; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&e2));
   int kmax = 0, max_nr = 0;
@@ -487,7 +509,12 @@ int main(int argc, char** argv) {
 #undef TL3
   };
   auto sweep = [&]() {
-    hipLaunchKernelGGL(prepass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_rp, d_ci, d_va, d_b, d_x, n, d_s);
+    if (local_s) {
+      const int64_t nl = (int64_t)B.grow.size();
+      hipLaunchKernelGGL(prepass_local_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, d_rp, d_ci, d_va, d_b, d_x, a.grow, nl, d_sloc);
+    } else {
+      hipLaunchKernelGGL(prepass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_rp, d_ci, d_va, d_b, d_x, n, d_s);
+    }
     CHECK(hipEventRecord(e1, st));
     for (int g = 0; g < ngrp; ++g) {
       const int nt = launch_tile0[g + 1] - launch_tile0[g];
