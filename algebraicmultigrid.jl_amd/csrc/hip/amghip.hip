@@ -568,12 +568,14 @@ __global__ void perm_rowlen_kernel(const int32_t* rowptr, const int32_t* perm, i
 }
 __global__ void perm_rows_kernel(const int32_t* rowptr, const int32_t* col, const real* val, const int32_t* perm,
                                  const int32_t* new_rowptr, int64_t n, int32_t* ncol, real* nval) {
-  // one wavefront per row (rows of R have a handful of entries): entries keep their order inside the row
-  const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  // one wavefront per row (rows of R have a handful of entries), grid-stride over the rows (a launch of n * 64 threads
+  // passes 2^32 threads at 67 M rows: "invalid configuration argument"); entries keep their order inside the row
   const int ln = threadIdx.x % kWave;
-  if (p >= n) return;
-  const int32_t src = rowptr[perm[p]], len = rowptr[perm[p] + 1] - src, dst = new_rowptr[p];
-  for (int e = ln; e < len; e += kWave) { ncol[dst + e] = col[src + e]; nval[dst + e] = val[src + e]; }
+  const int64_t waves = (int64_t)gridDim.x * (blockDim.x / kWave);
+  for (int64_t p = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; p < n; p += waves) {
+    const int32_t src = rowptr[perm[p]], len = rowptr[perm[p] + 1] - src, dst = new_rowptr[p];
+    for (int e = ln; e < len; e += kWave) { ncol[dst + e] = col[src + e]; nval[dst + e] = val[src + e]; }
+  }
 }
 __global__ void renumber_cols_kernel(int32_t* col, int64_t nnz, const int32_t* inv) {
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) col[k] = inv[col[k]];
@@ -604,12 +606,12 @@ int coarse_side_to_level_order(Level* prev, const GsSchedule* g) {
     if (rc == AMGH_OK && total != prev->Rp.nnz) rc = AMGH_EINVAL;
   }
   if (rc == AMGH_OK) {
-    hipLaunchKernelGGL(perm_rows_kernel, dim3((unsigned)((nc * kWave + 255) / 256)), dim3(256), 0, nullptr,
+    hipLaunchKernelGGL(perm_rows_kernel, dim3((unsigned)std::min<int64_t>((nc * kWave + 255) / 256, 1 << 20)), dim3(256), 0, nullptr,
                        (const int32_t*)prev->Rp.rowptr, (const int32_t*)prev->Rp.col, (const real*)prev->Rp.val,
                        (const int32_t*)g->perm, (const int32_t*)nrp, nc, ncol, nval);
     hipLaunchKernelGGL(renumber_cols_kernel, dim3((unsigned)grid_for(prev->Pp.nnz)), dim3(256), 0, nullptr, prev->Pp.col,
                        prev->Pp.nnz, (const int32_t*)inv);
-    if (hipDeviceSynchronize() != hipSuccess) rc = -1001;
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = -1001;
   }
   if (rc == AMGH_OK) {
     hipFree(prev->Rp.rowptr); hipFree(prev->Rp.col); hipFree(prev->Rp.val);
@@ -691,6 +693,7 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
     level_discard(L);
     return rc;
   }
+  dbg_pending("end of amgh_push_level_begin");
   h->pending_level = L;
   return AMGH_OK;
 }
@@ -753,6 +756,7 @@ int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const in
     rc = coarse_side_to_level_order(h->levels.back(), g);
     if (rc != AMGH_OK) { level_discard(L); return rc; }
   }
+  dbg_pending("end of amgh_push_level_end");
   h->levels.push_back(L);
   return AMGH_OK;
 }

@@ -165,6 +165,14 @@ inline hipError_t dev_zero(void* p, size_t bytes, hipStream_t st) {
   return hipSuccess;
 }
 
+// AMGH_VERBOSE: report (and clear) a launch error that is still pending — kernel launches with an invalid configuration
+// do not fail any later synchronous call, they only show up in hipGetLastError
+inline void dbg_pending(const char* where) {
+  if (!getenv("AMGH_VERBOSE")) return;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) fprintf(stderr, "[amghip] pending HIP error at %s: %s\n", where, hipGetErrorString(e));
+}
+
 template <class T>
 int dev_upload(T** p, const T* src, int64_t count) {
   RC_TRY(dev_alloc(p, count));

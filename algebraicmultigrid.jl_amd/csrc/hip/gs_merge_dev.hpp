@@ -15,6 +15,12 @@ namespace {
 
 constexpr int kMergeMaxRounds = 32;
 
+// AMGH_VERBOSE: say which HIP call of the builder failed (the caller only sees -1001)
+inline int merge_fail(const char* what) {
+  if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] merged-group builder: %s failed: %s\n", what, hipGetErrorString(hipGetLastError()));
+  return -1001;
+}
+
 // A grouping of the dependency levels of one sweep: group q = levels [gb[q], gb[q+1]) (ascending level boundaries,
 // gb[0] = 0, gb[ngrp] = nlev).  A forward sweep runs the groups in ascending order and the levels of a group in
 // ascending order (round k of group q = level gb[q] + k); a backward sweep both in descending order (round k = level
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
 // previous, shallower grouping; rows only grow with m)
 int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_diag, const MergeGrouping& G, MergeDev* out,
                     int min_tier = 0) {
+  dbg_pending("entry of the merged-group builder");
   const int64_t n = g->n;
   MergeDev& R = *out;
   const bool backward = G.backward;
@@ -279,9 +286,9 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
     if (grid_s == 0) continue;
     if (hipMemcpy(rlev, hl.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(blk_s, hs.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(blk_b, hb.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess) { rc = -1001; break; }
+        hipMemcpy(blk_b, hb.data(), sizeof(int32_t) * (R.ngrp + 1), hipMemcpyHostToDevice) != hipSuccess) { rc = merge_fail("upload of the round's launch tables"); break; }
     if (hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), nullptr) != hipSuccess ||
-        hipMemsetAsync(ovf, min_tier, n, nullptr) != hipSuccess || hipMemsetAsync(flags, 0, 8, nullptr) != hipSuccess) { rc = -1001; break; }
+        hipMemsetAsync(ovf, min_tier, n, nullptr) != hipSuccess || hipMemsetAsync(flags, 0, 8, nullptr) != hipSuccess) { rc = merge_fail("reset of the round's counters"); break; }
     // three table sizes: most rows are short (128 slots, 13 waves per CU); rows that outgrow a table are flagged and
     // redone by the next tier
     auto run_tiers = [&](int fill, bool* any1, bool* any2) -> int {
@@ -291,7 +298,7 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
       if (min_tier == 0) {
         hipLaunchKernelGGL((merge_rows_kernel<LS, RS, CT>), dim3(grid_s), dim3(LS * RS), lds_t, nullptr, a);
         if (!fill) {
-          if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1001;
+          if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return merge_fail("tier-0 launch / flags");
           *any1 = hf[0] != 0;
         }
       } else if (!fill) {
@@ -304,7 +311,7 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
         if (min_tier <= 1) {
           hipLaunchKernelGGL((merge_rows_kernel<LS, RS, CS>), dim3(grid_s), dim3(LS * RS), lds_s, nullptr, a);
           if (!fill) {
-            if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1001;
+            if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return merge_fail("tier-1 launch / flags");
             *any2 = hf[0] != 0;
           }
         }
@@ -313,12 +320,21 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
           hipLaunchKernelGGL((merge_rows_kernel<LB, RB, CB>), dim3(grid_b), dim3(LB * RB), lds_b, nullptr, a);
         }
       }
-      if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1001;
+      if (hipMemcpy(hf, flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return merge_fail("tier-2 launch / flags");
       if (hf[1]) R.failed = true;
       return AMGH_OK;
     };
     bool any1 = false, any2 = false;
     rc = run_tiers(0, &any1, &any2);
+    if (rc == AMGH_OK) {
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) {
+        if (getenv("AMGH_VERBOSE"))
+          fprintf(stderr, "[amghip] merged-group builder: count pass of round %d: %s (grids %u / %u, tiers %d %d)\n", k, hipGetErrorString(e),
+                  grid_s, grid_b, (int)any1, (int)any2);
+        rc = -1001;
+      }
+    }
     if (rc != AMGH_OK || R.failed) break;
     int64_t total = 0;
     rc = dev_exclusive_scan(cnt, off, n, &total, nullptr);
@@ -335,7 +351,15 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
     if (hipMemsetAsync(ovf, min_tier, n, nullptr) != hipSuccess) { rc = -1001; break; }
     rc = run_tiers(1, &any1, &any2);
     if (rc != AMGH_OK || R.failed) break;
-    if (hipGetLastError() != hipSuccess) rc = -1001;
+    {
+      const hipError_t e = hipGetLastError();
+      if (e != hipSuccess) {
+        if (getenv("AMGH_VERBOSE"))
+          fprintf(stderr, "[amghip] merged-group builder: fill pass of round %d: %s (grids %u / %u, total %lld, tiers %d %d)\n", k,
+                  hipGetErrorString(e), grid_s, grid_b, (long long)total, (int)any1, (int)any2);
+        rc = -1001;
+      }
+    }
   }
   if (rc == AMGH_OK && !R.failed) {
     R.h_clen.resize(n);

@@ -851,9 +851,9 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   level_order(n, ncols, rowptr, col, val, base, perm);
   const int64_t nnz = rowptr[n];
   g->bytes = 0;
-  tm.lap("levels + permuted matrix", n);
+  tm.lap("levels + permuted matrix", n); dbg_pending("levels + permuted matrix");
   RC_TRY(layout_upload(g, base, perm.data()));
-  tm.lap("base layout", n);
+  tm.lap("base layout", n); dbg_pending("base layout");
   RC_TRY(dev_upload(&g->perm, perm.data(), n));
   g->h_perm = perm;
   g->ncols = std::max<int64_t>(ncols, n);
@@ -972,7 +972,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       }
     }
   }
-  tm.lap("block-inverse data", n);
+  tm.lap("block-inverse data", n); dbg_pending("block-inverse data");
   // Merged levels.  Candidates are compared, per direction, with what would run otherwise: a boundary per
   // dependency level, or the block-inverse sweep (which merged groups with long-row slots replace when cheaper).
   g->xstride = g->ncols;
@@ -1057,7 +1057,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         }
         }
       }
-      tm.lap("merge candidates (device)", n);
+      tm.lap("merge candidates (device)", n); dbg_pending("merge candidates (device)");
       const bool use = g->nblk == 0 ? true : (chosen_m[0] > 1 && chosen_m[1] > 1);
       // Groups of DIFFERENT depth along the sweep.  Where the dependency levels are small — the two ends of a sweep over
       // a grid-like operator — a launch is at its latency floor whatever it carries, so deeper groups there are nearly
@@ -1158,7 +1158,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           if (cap_try <= chosen_m[dir]) break;
         }
       }
-      tm.lap("zoned groups (device)", n);
+      tm.lap("zoned groups (device)", n); dbg_pending("zoned groups (device)");
       for (int dir = 0; dir < 2 && rc2 == AMGH_OK; ++dir) {
         const bool backward = dir == 1;
         MergeDev& md = chosen[dir];
@@ -1201,11 +1201,11 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           ch->ncols = g->ncols;
           rc2 = layout_upload(ch, sys, perm.data(), cap, gs_lean(), &src);
           if (rc2 == AMGH_OK && g_gs_sell && !gs_lean()) rc2 = sell_build(ch, sys.prow);
-          tm.lap("merged layout", n);
+          tm.lap("merged layout", n); dbg_pending("merged layout");
           if (rc2 == AMGH_OK)
             rc2 = tri_build_dev(backward ? &g->tri_b : &g->tri_f, g, backward, &g->bytes, 0.0,
                                 backward ? &g->tri_nnz_b : &g->tri_nnz);
-          tm.lap("other triangle", n);
+          tm.lap("other triangle", n); dbg_pending("other triangle");
           (backward ? g->merge_b : g->merge_f) = best_m;
           g->bytes += ch->bytes;
           if (getenv("AMGH_VERBOSE"))
@@ -1260,10 +1260,10 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         (backward ? g->mb : g->mf) = ch;
         ch->ncols = g->ncols;
         RC_TRY(layout_upload(ch, keep.sys, perm.data(), cap, gs_lean()));
-        tm.lap("merged layout", n);
+        tm.lap("merged layout", n); dbg_pending("merged layout");
         RC_TRY(tri_build_dev(backward ? &g->tri_b : &g->tri_f, g, backward, &g->bytes, 0.0,
                              backward ? &g->tri_nnz_b : &g->tri_nnz));
-        tm.lap("other triangle", n);
+        tm.lap("other triangle", n); dbg_pending("other triangle");
         (backward ? g->merge_b : g->merge_f) = best_m;
         g->bytes += ch->bytes;
         if (getenv("AMGH_VERBOSE"))
