@@ -635,6 +635,7 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
   if (h->finalized || h->pending_level) return AMGH_ESTATE;
   if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
+  (void)hipGetLastError();   // (whatever an earlier, unrelated call left behind is not this level's)
   Level* L = new Level;
   L->n = n; L->pre = *pre; L->post = *post;
   int rc = csr_upload(&L->A, h->device, n, n, A_rowptr, A_col, A_val);
@@ -693,7 +694,16 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
     level_discard(L);
     return rc;
   }
-  dbg_pending("end of amgh_push_level_begin");
+  // a kernel launched with an invalid configuration fails no later call: it only shows in hipGetLastError — and its
+  // output is then garbage (seen once: 2^32 threads at 67 M rows).  Never let a level through with one pending.
+  {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] pending HIP error at the end of amgh_push_level_begin: %s\n", hipGetErrorString(e));
+      level_discard(L);
+      return -(1000 + (int)e);
+    }
+  }
   h->pending_level = L;
   return AMGH_OK;
 }
@@ -707,6 +717,7 @@ int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const in
   const int64_t n = L->n;
   if (P_rowptr[n] != R_rowptr[nc]) return AMGH_EINVAL;   // the pending level stays: the caller may retry or destroy
   HIP_TRY(hipSetDevice(h->device));
+  (void)hipGetLastError();
   L->nc = nc;
   int rc = csr_upload(&L->P, h->device, n, nc, P_rowptr, P_col, P_val);
   if (rc == AMGH_OK) rc = csr_upload(&L->R, h->device, nc, n, R_rowptr, R_col, R_val);
@@ -756,7 +767,14 @@ int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const in
     rc = coarse_side_to_level_order(h->levels.back(), g);
     if (rc != AMGH_OK) { level_discard(L); return rc; }
   }
-  dbg_pending("end of amgh_push_level_end");
+  {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] pending HIP error at the end of amgh_push_level_end: %s\n", hipGetErrorString(e));
+      level_discard(L);
+      return -(1000 + (int)e);
+    }
+  }
   h->levels.push_back(L);
   return AMGH_OK;
 }

@@ -964,7 +964,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         if (rc3 != AMGH_OK || !(cond <= kBlockCondMax)) {
           hipFree(g->dti_f); hipFree(g->dti_b); g->dti_f = g->dti_b = nullptr;
           for (GsSchedule::Tri* t : {&g->dtri_f, &g->dtri_b}) { hipFree(t->rowptr); hipFree(t->col); hipFree(t->val); *t = GsSchedule::Tri(); }
-          if (rc3 == AMGH_ENOMEM) rc3 = AMGH_OK;    // no room for the dense blocks: the 128-row block sweeps stay
+          if (rc3 == AMGH_ENOMEM) { rc3 = AMGH_OK; (void)hipGetLastError(); }   // no room for the dense blocks: the 128-row block sweeps stay
           RC_TRY(rc3);
         } else {
           g->bytes += 2 * g->dti_off[nb] * (int64_t)sizeof(real) + 2 * (nnz * 12 + (n + 1) * 4);
