@@ -163,6 +163,7 @@ def test_block_inverse_sweeps_all_variants(super_blocks, pipe):
     lib = AMG.hip_lib()
     lib.amgh_debug_set_tunable(b"gs_super", super_blocks)
     lib.amgh_debug_set_tunable(b"gs_block_pipe", pipe)
+    lib.amgh_debug_set_tunable(b"gs_dense_tri", 0)       # (the dense whole-triangle sweeps would take these operators over)
     try:
         cases = [_dense_band_spd(1000, 40, 1), _dense_band_spd(700, 150, 2, zero_diag_rows=(5, 300, 699)),
                  _dense_band_spd(257, 30, 3), _dense_band_spd(130, 129, 4)]
@@ -177,6 +178,41 @@ def test_block_inverse_sweeps_all_variants(super_blocks, pipe):
     finally:
         lib.amgh_debug_set_tunable(b"gs_super", 8)
         lib.amgh_debug_set_tunable(b"gs_block_pipe", 1)
+        lib.amgh_debug_set_tunable(b"gs_dense_tri", 1)
+
+
+@pytest.mark.parametrize("blk", [4096, 300, 256])
+def test_dense_triangular_sweeps(blk):
+    """Small operators: the triangle of the whole matrix (one block) or of `blk`-row diagonal blocks inverted densely on
+    the device; a sweep = per block, pre-pass over everything outside the block's triangle + one triangular GEMV
+    (tri_inverse_kernel / tri_gemv_kernel).  Against the oracle's scalar lexicographic sweeps, and for blocks of
+    right-hand sides through a hierarchy whose coarse levels take this path."""
+    lib = AMG.hip_lib()
+    lib.amgh_debug_set_tunable(b"gs_dense_blk", blk)
+    try:
+        cases = [_dense_band_spd(1000, 40, 1), _dense_band_spd(257, 30, 3), _dense_band_spd(130, 129, 4)]
+        cases.append(_dense_band_spd(9000, 25, 7))          # > 8192 rows: several diagonal blocks, the last one shorter
+        for k, A in enumerate(cases):
+            n = A.m
+            x0, b = uniform(n, 160 + k) - 0.5, uniform(n, 170 + k)
+            for s in (FWD, BWD, SYM, AMG.GaussSeidel(AMG.SymmetricSweep(), 3)):
+                x = x0.copy()
+                s(A, x, b)
+                ref = O.smooth(s, A, x0, b)
+                assert rel(x, ref) <= 1e-11, (k, repr(s), rel(x, ref))
+        # inside a cycle, single and blocked right-hand sides (the coarse levels of this hierarchy are dense-swept)
+        A = AMG.poisson((20, 20, 20))
+        ml = AMG.ruge_stuben(A)
+        dev = ml.device()
+        assert any(dev.gs_sweep_steps(l) <= 3 for l in range(1, len(ml.levels)))     # a level swept in <= 3 block steps
+        oh = O.OracleHierarchy(ml)
+        R = np.stack([uniform(A.m, 1), uniform(A.m, 2) - 0.5, np.cos(np.arange(A.m))], axis=1)
+        Z = AMG.aspreconditioner(ml).ldiv(R)
+        for j in range(3):
+            assert rel(Z[:, j], oh.precond(np.ascontiguousarray(R[:, j]))) <= TOL
+            assert np.array_equal(Z[:, j], AMG.aspreconditioner(ml).ldiv(np.ascontiguousarray(R[:, j])))
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_dense_blk", 4096)
 
 
 @pytest.mark.parametrize("bigslot", [0, 1, 2])   # 2: long-row slot layout everywhere
