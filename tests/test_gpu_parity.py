@@ -570,3 +570,31 @@ def test_eltype_promotion_contract():  # runtests.jl:244-259
         # the default reltol is sqrt(eps(eltype(b))) (multilevel.jl:162): a Float32 right-hand side stops at 3.5e-4;
         # a Float32 result also carries its rounding (|x| ~ 2e2, cond ~ 4e3) into the residual
         assert np.linalg.norm(a @ x.astype(np.float64) - b) <= (1e-3 if V == np.float32 else 1e-7) * np.linalg.norm(b)
+
+
+def test_level_ordered_handover_between_levels_is_bitwise_the_natural_one():
+    """gs_coarse_lo: Rp's rows / Pp's columns renumbered to the next level's dependency-level order, the restricted
+    residual written into that level's level-ordered right-hand side, the correction read from its level-ordered x.
+    Every sum keeps its order: V / W / F cycles and blocks of right-hand sides come out bit for bit."""
+    from amg_amd.device import DeviceHierarchy
+    lib = AMG.hip_lib()
+    A = AMG.poisson((40, 36, 32))
+    ml = AMG.ruge_stuben(A)
+    n = A.m
+    R = np.asfortranarray(np.stack([uniform(n, 5), uniform(n, 6) - 0.5, np.sin(np.arange(n))], axis=1))
+    out = {}
+    try:
+        for flag in (0, 1):
+            lib.amgh_debug_set_tunable(b"gs_coarse_lo", flag)
+            for bs in (1, 3):
+                dev = DeviceHierarchy(ml, 0, bs)
+                for cyc in (0, 1, 2):
+                    out[(flag, bs, cyc)] = dev.precond_apply(R if bs == 3 else np.ascontiguousarray(R[:, 0]), cyc)
+                del dev
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_coarse_lo", 1)
+    for bs in (1, 3):
+        for cyc in (0, 1, 2):
+            assert np.array_equal(out[(0, bs, cyc)], out[(1, bs, cyc)]), (bs, cyc)
+    oh = O.OracleHierarchy(ml)
+    assert rel(out[(1, 1, 0)], oh.precond(np.ascontiguousarray(R[:, 0]))) <= TOL
