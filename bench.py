@@ -198,8 +198,18 @@ def main():
         alg_sweeps += 4 * (lev.A.nnz * 12 + (lev.A.m + 1) * 4 + 24 * lev.A.m)
         sweeps.append(per)
     smooth_ms = None
+    cycle_breakdown = None
     if not args.light:
-        smooth_ms = 2.0 * sum(dev.bench_op(l, 4, reps=2, warmup=1) for l in range(len(ml.levels)))
+        # the smoother's share of the cycle AS IT RUNS (hipEvent labels of the cycle = the reference's TimerOutputs labels);
+        # amgh_bench_op would time the stand-alone sweep, which also gathers / scatters x between numberings
+        dev.profile(True)
+        for _ in range(3):
+            step()
+        lib.amgh_dev_sync(0)
+        prof = dev.profile_read()
+        dev.profile(False)
+        smooth_ms = float(sum(prof[k].sum() for k in prof if k in ("Presmoother", "Postsmoother"))) / 3.0
+        cycle_breakdown = {k: round(float(prof[k].sum()) / 3.0, 4) for k in prof}
 
     vb = vcycle_bytes(ml, 4)
     traffic, traffic_how = pmc_traffic(N, enabled=not args.no_pmc and not args.light)
@@ -235,7 +245,7 @@ def main():
             "prepass_entries_per_cycle": tri,
             "bytes_streamed_per_cycle": 12 * (stored + tri), "algorithmic_bytes_per_cycle": alg_sweeps,
             "inflation": 12 * (stored + tri) / alg_sweeps,
-            "smoother_ms_per_cycle": smooth_ms,
+            "smoother_ms_per_cycle": smooth_ms, "cycle_ms_by_label": cycle_breakdown,
             "avg_launch_us": None if smooth_ms is None else 1e3 * smooth_ms / max(1, launches),
             "achieved": None if smooth_ms is None else alg_sweeps / (smooth_ms * 1e-3) / 1e9,
             "streamed_GBs": None if smooth_ms is None else 12 * (stored + tri) / (smooth_ms * 1e-3) / 1e9,
