@@ -627,21 +627,21 @@ int coarse_side_to_level_order(Level* prev, const GsSchedule* g) {
 // First half of push!(levels, Level(A, P, R, pre, post)): everything that needs A (and S) only — the uploads and the
 // smoother schedule.  A caller that produces P and R later (the setup phase: C/F splitting on the host, then
 // interpolation) can run this half on another host thread meanwhile.
-int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
-                          const int32_t* S_rowptr, const int32_t* S_col, const real* S_val,
-                          const amgh_smoother_t* pre, const amgh_smoother_t* post) {
-  if (!h || n <= 0 || !A_rowptr) return AMGH_EINVAL;
-  if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
-  if (h->finalized || h->pending_level) return AMGH_ESTATE;
-  if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
-  HIP_TRY(hipSetDevice(h->device));
+// A level's own half — A (S) in HBM and the smoother schedules — touches no handle: any number of them may be under
+// construction on different host threads.
+struct amgh_level { Level* L = nullptr; int device = 0; };
+
+static int level_prepare(int device, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
+                         const int32_t* S_rowptr, const int32_t* S_col, const real* S_val,
+                         const amgh_smoother_t* pre, const amgh_smoother_t* post, Level** out) {
+  HIP_TRY(hipSetDevice(device));
   (void)hipGetLastError();   // (whatever an earlier, unrelated call left behind is not this level's)
   Level* L = new Level;
   L->n = n; L->pre = *pre; L->post = *post;
-  int rc = csr_upload(&L->A, h->device, n, n, A_rowptr, A_col, A_val);
+  int rc = csr_upload(&L->A, device, n, n, A_rowptr, A_col, A_val);
   if (rc == AMGH_OK && S_rowptr) {
     L->has_S = true;
-    rc = csr_upload(&L->S, h->device, n, n, S_rowptr, S_col, S_val);
+    rc = csr_upload(&L->S, device, n, n, S_rowptr, S_col, S_val);
   }
   const bool need_gs = pre->kind == AMGH_SMOOTH_GS || pre->kind == AMGH_SMOOTH_SOR ||
                        post->kind == AMGH_SMOOTH_GS || post->kind == AMGH_SMOOTH_SOR;
@@ -704,7 +704,54 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
       return -(1000 + (int)e);
     }
   }
+  *out = L;
+  return AMGH_OK;
+}
+
+int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
+                          const int32_t* S_rowptr, const int32_t* S_col, const real* S_val,
+                          const amgh_smoother_t* pre, const amgh_smoother_t* post) {
+  if (!h || n <= 0 || !A_rowptr) return AMGH_EINVAL;
+  if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
+  if (h->finalized || h->pending_level) return AMGH_ESTATE;
+  if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
+  Level* L = nullptr;
+  RC_TRY(level_prepare(h->device, n, A_rowptr, A_col, A_val, S_rowptr, S_col, S_val, pre, post, &L));
   h->pending_level = L;
+  return AMGH_OK;
+}
+
+// The first half without a handle: several levels' schedules can be under construction at once (one call per host
+// thread); amgh_push_level_prepared then makes one of them the handle's pending level, in hierarchy order.
+int amgh_level_prepare(int device, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
+                       const int32_t* S_rowptr, const int32_t* S_col, const real* S_val,
+                       const amgh_smoother_t* pre, const amgh_smoother_t* post, amgh_level_t** out) {
+  if (!out || n <= 0 || !A_rowptr) return AMGH_EINVAL;
+  *out = nullptr;
+  if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
+  Level* L = nullptr;
+  RC_TRY(level_prepare(device, n, A_rowptr, A_col, A_val, S_rowptr, S_col, S_val, pre, post, &L));
+  amgh_level_t* p = new amgh_level_t;
+  p->L = L; p->device = device;
+  *out = p;
+  return AMGH_OK;
+}
+
+void amgh_level_free(amgh_level_t* p) {
+  if (!p) return;
+  if (p->L) { hipSetDevice(p->device); level_discard(p->L); }
+  delete p;
+}
+
+// On AMGH_OK the handle owns the level and `p` is gone; on an error `p` is untouched (amgh_level_free it).
+int amgh_push_level_prepared(amgh_t* h, amgh_level_t* p) {
+  if (!h || !p || !p->L) return AMGH_EINVAL;
+  if (h->finalized || h->pending_level) return AMGH_ESTATE;
+  if (p->device != h->device) return AMGH_EINVAL;
+  if (!h->levels.empty() && h->levels.back()->nc != p->L->n) return AMGH_EINVAL;
+  h->pending_level = p->L;
+  p->L = nullptr;
+  delete p;
   return AMGH_OK;
 }
 

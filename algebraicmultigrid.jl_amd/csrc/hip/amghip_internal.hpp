@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <system_error>
@@ -346,7 +347,7 @@ int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely couple
 
 // bumped whenever a schedule buffer that captured hipGraphs may point to is reallocated or freed (xp / bp growth,
 // SOR child eviction): handles drop their cached graph execs when it has moved on
-unsigned long long g_sched_epoch = 0;
+std::atomic<unsigned long long> g_sched_epoch{0};   // (levels may be prepared on several host threads)
 
 unsigned long long* g_chain_tim = nullptr;  // diagnostics buffer (amgh_debug_chain_timing)
 

@@ -185,15 +185,12 @@ class DeviceHierarchy:
         hip_check(self.lib.amgh_create(C.byref(h), device, self.nrhs), "create")
         self.h = h.value
 
-    def push_begin(self, A, presmoother, postsmoother):
-        """amgh_push_level_begin: A (and S) to HBM, smoother schedules.  Needs nothing but A."""
-        import os
-        import time
-        t_lev = time.perf_counter()
+    def _level_args(self, A, presmoother, postsmoother):
+        """(n, A rows, S rows or NULLs, pre, post) as amgh_push_level_begin / amgh_level_prepare take them; the arrays are
+        kept alive by the returned tuple."""
         n = A.m
         Ar, Ac, Av = A.csr_arrays()                  # true A rows
         Av = self._vals(Av)
-        t_arr = time.perf_counter() - t_lev
         if self.hermitian and not A.is_symmetric():
             Sr, Sc, Sv = A.colptr, A.rowval, self._vals(A.nzval)  # column i read as row i
         else:
@@ -202,11 +199,48 @@ class DeviceHierarchy:
             if not isinstance(s, Smoother):
                 raise AMGError(f"unsupported smoother {s!r}")
         pre, post = presmoother.c_struct(), postsmoother.c_struct()
-        hip_check(self.lib.amgh_push_level_begin(self.h, n, _ptr(Ar), _ptr(Ac), _ptr(Av), _ptr(Sr), _ptr(Sc), _ptr(Sv),
-                                                 C.byref(pre), C.byref(post)), "push_level_begin")
+        return (n, _ptr(Ar), _ptr(Ac), _ptr(Av), _ptr(Sr), _ptr(Sc), _ptr(Sv), C.byref(pre), C.byref(post)), (Ar, Ac, Av, Sr, Sc, Sv, pre, post)
+
+    def push_begin(self, A, presmoother, postsmoother):
+        """amgh_push_level_begin: A (and S) to HBM, smoother schedules.  Needs nothing but A."""
+        import os
+        import time
+        t_lev = time.perf_counter()
+        args, keep = self._level_args(A, presmoother, postsmoother)
+        hip_check(self.lib.amgh_push_level_begin(self.h, *args), "push_level_begin")
+        del keep
         if os.environ.get("AMGH_VERBOSE"):
-            print(f"[amghip] n={n} python: csr_arrays {t_arr:.2f} s, push_level_begin total {time.perf_counter() - t_lev:.2f} s",
+            print(f"[amghip] n={A.m} python: push_level_begin total {time.perf_counter() - t_lev:.2f} s",
                   file=__import__("sys").stderr, flush=True)
+
+    def prepare(self, A, presmoother, postsmoother):
+        """amgh_level_prepare: the same work into a free-standing level (no handle state: callable from several host
+        threads at once).  Returns the level's address for push_prepared / free_prepared."""
+        import os
+        import time
+        t_lev = time.perf_counter()
+        args, keep = self._level_args(A, presmoother, postsmoother)
+        out = C.c_void_p()
+        hip_check(self.lib.amgh_level_prepare(self.device, *args, C.byref(out)), "level_prepare")
+        del keep
+        if os.environ.get("AMGH_VERBOSE"):
+            print(f"[amghip] n={A.m} python: level_prepare total {time.perf_counter() - t_lev:.2f} s (clock {t_lev % 1000:.2f} .. {time.perf_counter() % 1000:.2f})",
+                  file=__import__("sys").stderr, flush=True)
+        return out.value
+
+    def push_prepared(self, level):
+        """amgh_push_level_prepared: the prepared level (an address, or a Future of one) becomes the pending level."""
+        fut = level if hasattr(level, "result") else None
+        if fut is not None:
+            level = fut.result()
+            fut._taken = True          # (whatever happens below, the address is not the future's any more)
+        rc = self.lib.amgh_push_level_prepared(self.h, level)
+        if rc != 0:
+            self.lib.amgh_level_free(level)
+        hip_check(rc, "push_level_prepared")
+
+    def free_prepared(self, level):
+        self.lib.amgh_level_free(level)
 
     def push_end(self, lev):
         """amgh_push_level_end: P and R of the level whose A was pushed last."""
@@ -216,8 +250,14 @@ class DeviceHierarchy:
         Rr, Rc, Rv = lev.P.colptr, lev.P.rowval, self._vals(lev.P.nzval)
         if lev.R.shape != (nc, n) or lev.P.shape != (n, nc):
             raise AMGError("Level: P must be n x nc and R nc x n")
+        import os
+        import time
+        t0 = time.perf_counter()
         hip_check(self.lib.amgh_push_level_end(self.h, nc, _ptr(Pr), _ptr(Pc), _ptr(Pv), _ptr(Rr), _ptr(Rc), _ptr(Rv)),
                   "push_level_end")
+        if os.environ.get("AMGH_VERBOSE"):
+            print(f"[amghip] n={n} python: push_level_end {time.perf_counter() - t0:.2f} s (clock {t0 % 1000:.2f} .. {time.perf_counter() % 1000:.2f})",
+                  file=__import__("sys").stderr, flush=True)
 
     def push_abort(self):
         """amgh_push_level_abort: the level begun last turned out to be the coarsest one."""

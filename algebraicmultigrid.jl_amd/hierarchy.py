@@ -505,13 +505,82 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0, buil
             t_last[0] = now
 
     out = []
-    A_host, dA = A, _DMat.upload(A, lib, device)
+    hostA = [A]                 # hostA[l]: the level matrix on the host (from level 1 on: filled by the download thread)
+    dA = _DMat.upload(A, lib, device)
     tick("upload A")
     pipe = _Pipeline() if builder is not None else None
+    # With a builder, a third thread brings P, R and the next level's A to the host (the host MultiLevel and the schedule
+    # builder want them; the next level's strength / splitting / interpolation work on the device copies and on the
+    # S, T patterns) and feeds the builder in order; without one everything runs on this thread.
+    dl = _Pipeline() if pipe is not None else None
+
+    def run(fn, *args):
+        if dl is not None:
+            dl.submit(fn, *args)
+        else:
+            fn(*args)
+
+    def set_symmetry(l, dT, same):
+        """issymmetric(A_l) and copy(A_l') as the device found them (see prime_symmetry)."""
+        M = hostA[l]
+        M._sym = same
+        if not same:
+            M._T = dT.to_host()
+            M._T._sym = False
+            M._T._T = M
+
+    # Schedules of up to two levels at a time (amgh_level_prepare touches no handle): level l+1's matrix exists long
+    # before the schedules of the much larger level l are done.  The levels join the handle in order (`pipe`).
+    pool = None
+    prepared = []
+    if pipe is not None:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=2)
+
+    def prepare_level(l):
+        while len(prepared) <= l:
+            prepared.append(None)
+        if prepared[l] is None:
+            prepared[l] = pool.submit(builder.prepare, hostA[l], *smoothers)
+
+    def begin_level(l):
+        prepare_level(l)
+        pipe.submit(builder.push_prepared, prepared[l])
+
+    def drop_prepared():
+        """After a failure: levels that were prepared and never reached the handle."""
+        pool.shutdown(wait=True)
+        for fut in prepared:
+            if fut is not None and fut.exception() is None and not getattr(fut, "_taken", False):
+                builder.free_prepared(fut.result())
+
+    def finish_level(l, dP, dR, dRAP, nAT, nsame):
+        hostA.append(dRAP.to_host())
+        if nAT is not None:
+            set_symmetry(l + 1, nAT, nsame)
+            # (starting the next level's schedules HERE, ~0.7 s earlier, was measured and is worse: two large levels
+            # under construction at once slow each other down by more than the overlap — every synchronous copy and
+            # hipFree of one waits for the other's kernels; begin_level starts them when the level is begun)
+        out.append((hostA[l], dP.to_host(), dR.to_host()))
+        if pipe is not None:
+            pipe.submit(builder.push_end, Level(*out[-1], *smoothers))
+
+    def symmetry_of(dM):
+        """(copy(M'), issymmetric(M)) on the device."""
+        t = C.c_void_p()
+        hip_check(lib.amgh_setup_transpose(dM.h, C.byref(t)), "setup_transpose")
+        dT = _DMat(t.value, lib)
+        same = C.c_int(0)
+        hip_check(lib.amgh_dmat_equal(dM.h, dT.h, C.byref(same)), "dmat_equal")
+        return dT, bool(same.value)
+
+    lvl, n = 0, A.m
+    dAT = None
     try:
-        while len(out) + 1 < max_levels and A_host.m > max_coarse:
-            n = A_host.m
-            dAT = prime_symmetry(A_host, dA) if A_host._sym is None else None
+        if A._sym is None and max_levels > 1 and n > max_coarse:
+            dAT, same = symmetry_of(dA)
+            set_symmetry(0, dAT, same)
+        while lvl + 1 < max_levels and n > max_coarse:
             if hermitian:
                 dAt = dA
             else:
@@ -522,7 +591,7 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0, buil
                 dAt = dAT
             tick("transpose / symmetry")
             if pipe is not None:
-                pipe.submit(builder.push_begin, A_host, *smoothers)
+                run(begin_level, lvl)
             s_, t_, sn, tn = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
             hip_check(lib.amgh_setup_classical_strength(dAt.h, theta, C.byref(s_), C.byref(t_), C.byref(sn), C.byref(tn)),
                       "setup_classical_strength")
@@ -540,24 +609,37 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0, buil
             dR, dP = call2(lib.amgh_setup_direct_interpolation, dAt.h, dT.h, splitting.ctypes.data, what="setup_direct_interpolation")
             if dR.m == 0:        # size(P, 2) == 0: stop coarsening (classical.jl:43)
                 if pipe is not None:
-                    pipe.submit(builder.push_abort)
+                    run(pipe.submit, builder.push_abort)
                 break
             tick("interpolation")
             dRAP = spgemm(spgemm(dR, dA), dP)
             tick("R*A*P")
-            out.append((A_host, dP.to_host(), dR.to_host()))
-            A_next = dRAP.to_host()
+            nAT = nsame = None
+            if lvl + 2 < max_levels and dRAP.m > max_coarse:      # the product is the next level: issymmetric / copy(A') now
+                nAT, nsame = symmetry_of(dRAP)
+            run(finish_level, lvl, dP, dR, dRAP, nAT, nsame)
             tick("download P, R, RAP")
-            if pipe is not None:
-                pipe.submit(builder.push_end, Level(*out[-1], *smoothers))
-            A_host, dA = A_next, dRAP
+            dA, dAT, n, lvl = dRAP, nAT, dRAP.m, lvl + 1
+            del dP, dR, dRAP, nAT, dAt
     except BaseException:
-        if pipe is not None:      # never tear the handle down under a running push
-            pipe.close(reraise=False)
+        for q in (dl, pipe):      # never tear the handle down under a running push
+            if q is not None:
+                q.close(reraise=False)
+        if pool is not None:
+            drop_prepared()
         raise
-    if pipe is not None:
-        pipe.close()
-        tick("wait for the smoother schedules")
+    if dl is not None:
+        try:
+            dl.close()
+            tick("wait for the downloads")
+            pipe.close()
+            tick("wait for the smoother schedules")
+        except BaseException:
+            pipe.close(reraise=False)
+            drop_prepared()
+            raise
+        pool.shutdown(wait=True)
+    A_host = hostA[-1]
     if A_host._sym is None:
         prime_symmetry(A_host, dA)
     if timing is not None:

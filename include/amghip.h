@@ -123,6 +123,19 @@ int amgh_push_level_end(amgh_t* h, int64_t nc,
 /* Drops the begun level instead (coarsening stopped: size(P, 2) == 0, classical.jl:43).                */
 int amgh_push_level_abort(amgh_t* h);
 
+/* _begin without a handle: the level's A (S) goes to HBM and its smoother schedules are built into a free-standing
+ * object.  Thread-safe — a setup phase that produces level l+1's A while level l's schedules are still under
+ * construction prepares them on different host threads — and amgh_push_level_prepared then makes the object the
+ * handle's pending level (exactly the state after _begin; levels join in hierarchy order: _prepared, _end, ...).
+ * On AMGH_OK the handle owns the level; otherwise the caller still does (amgh_level_free).                    */
+typedef struct amgh_level amgh_level_t;
+int amgh_level_prepare(int device, int64_t n,
+                       const int32_t* A_rowptr, const int32_t* A_col, const amgh_real* A_val,
+                       const int32_t* S_rowptr, const int32_t* S_col, const amgh_real* S_val,
+                       const amgh_smoother_t* pre, const amgh_smoother_t* post, amgh_level_t** out);
+int amgh_push_level_prepared(amgh_t* h, amgh_level_t* level);
+void amgh_level_free(amgh_level_t* level);
+
 /* Coarsest level: final_A and the coarse solver (coarse_solver.jl).  The
  * callable `(cs)(x, b)` becomes x = dense_op * b with dense_op (n x n,
  * column-major) computed by the host shim: pinv(Matrix(A)) for Pinv

@@ -105,6 +105,75 @@ def test_push_level_in_two_halves_state_machine():
     lib.amgh_destroy(h)
 
 
+def test_levels_prepared_without_a_handle_join_in_order():
+    """amgh_level_prepare (several at once, on host threads) / amgh_push_level_prepared / amgh_level_free."""
+    import threading
+    lib = AMG.hip_lib()
+    ml = AMG.ruge_stuben(AMG.poisson((24, 24, 20)), max_levels=3)
+    assert len(ml.levels) == 2
+    gs = amgh_smoother_t(1, 2, 1, 0, 1.0)
+    bad = amgh_smoother_t(9, 2, 1, 0, 1.0)
+    preps = [C.c_void_p(), C.c_void_p()]
+    rcs = [None, None]
+
+    def prep(i):
+        lev = ml.levels[i]
+        rcs[i] = lib.amgh_level_prepare(0, lev.A.m, *_csr(lev.A), None, None, None, C.byref(gs), C.byref(gs), C.byref(preps[i]))
+
+    th = [threading.Thread(target=prep, args=(i,)) for i in (1, 0)]      # the coarser one first, both at once
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert rcs == [0, 0] and preps[0].value and preps[1].value
+    extra = C.c_void_p()
+    a0 = _csr(ml.levels[0].A)
+    assert lib.amgh_level_prepare(0, ml.levels[0].A.m, *a0, None, None, None, C.byref(bad), C.byref(gs), C.byref(extra)) == EINVAL
+    assert lib.amgh_level_prepare(0, 0, *a0, None, None, None, C.byref(gs), C.byref(gs), C.byref(extra)) == EINVAL
+    assert extra.value is None
+    assert lib.amgh_level_prepare(0, ml.levels[0].A.m, *a0, None, None, None, C.byref(gs), C.byref(gs), C.byref(extra)) == 0
+    lib.amgh_level_free(extra)                                               # never pushed
+    lib.amgh_level_free(None)
+
+    def pr(lev):
+        return ((lev.R.colptr.ctypes.data, lev.R.rowval.ctypes.data, lev.R.nzval.ctypes.data),
+                (lev.P.colptr.ctypes.data, lev.P.rowval.ctypes.data, lev.P.nzval.ctypes.data))
+
+    h = C.c_void_p()
+    assert lib.amgh_create(C.byref(h), 0, 1) == 0
+    assert lib.amgh_push_level_prepared(h, None) == EINVAL
+    assert lib.amgh_push_level_prepared(h, preps[0]) == 0
+    assert lib.amgh_push_level_prepared(h, preps[1]) == ESTATE               # one pending level per handle; still the caller's
+    p, r = pr(ml.levels[0])
+    assert lib.amgh_push_level_end(h, ml.levels[0].P.n, *p, *r) == 0
+    assert lib.amgh_push_level_prepared(h, preps[1]) == 0
+    p, r = pr(ml.levels[1])
+    assert lib.amgh_push_level_end(h, ml.levels[1].P.n, *p, *r) == 0
+    op = np.asfortranarray(ml.coarse_solver.dense_operator())
+    assert lib.amgh_set_coarse(h, ml.final_A.m, *_csr(ml.final_A), op.ctypes.data) == 0
+    assert lib.amgh_finalize(h) == 0
+    n = ml.levels[0].A.m
+    b = np.linspace(0.5, 1.5, n); z1 = np.zeros(n); z2 = np.zeros(n)
+    assert lib.amgh_precond_apply(h, b.ctypes.data, z1.ctypes.data, 0) == 0
+    ref = ml.device()
+    assert lib.amgh_precond_apply(ref.h, b.ctypes.data, z2.ctypes.data, 0) == 0
+    assert np.array_equal(z1, z2)
+    # a level of the wrong size for this place in the hierarchy stays the caller's
+    wrong = C.c_void_p()
+    h2 = C.c_void_p()
+    assert lib.amgh_create(C.byref(h2), 0, 1) == 0
+    assert lib.amgh_level_prepare(0, ml.levels[0].A.m, *a0, None, None, None, C.byref(gs), C.byref(gs), C.byref(wrong)) == 0
+    assert lib.amgh_push_level_prepared(h2, wrong) == 0
+    p, r = pr(ml.levels[0])
+    assert lib.amgh_push_level_end(h2, ml.levels[0].P.n, *p, *r) == 0
+    again = C.c_void_p()
+    assert lib.amgh_level_prepare(0, ml.levels[0].A.m, *a0, None, None, None, C.byref(gs), C.byref(gs), C.byref(again)) == 0
+    assert lib.amgh_push_level_prepared(h2, again) == EINVAL                 # n != nc of the level above
+    lib.amgh_level_free(again)
+    lib.amgh_destroy(h2)
+    lib.amgh_destroy(h)
+
+
 def test_hierarchy_without_levels_needs_final_A_and_pcg_rejects_blocks():
     lib = AMG.hip_lib()
     A = AMG.poisson(8)

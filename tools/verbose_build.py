@@ -12,5 +12,6 @@ AMG.ruge_stuben(AMG.poisson((12, 12, 12)), setup=mode).device()     # library lo
 print("---- timed from here", flush=True)
 t0 = time.time(); A = AMG.poisson((N, N, N)); print("poisson", round(time.time() - t0, 2), flush=True)
 overlap = len(sys.argv) > 3 and sys.argv[3] == "1"
-t0 = time.time(); ml = AMG.ruge_stuben(A, setup=mode, device=0 if overlap else None); print("setup" + (" + upload + schedules (overlapped)" if overlap else ""), round(time.time() - t0, 2), flush=True)
+print("clock %.2f" % (time.perf_counter() % 1000), flush=True)
+t0 = time.time(); ml = AMG.ruge_stuben(A, setup=mode, device=0 if overlap else None); print("setup" + (" + upload + schedules (overlapped)" if overlap else ""), round(time.time() - t0, 2), "clock %.2f" % (time.perf_counter() % 1000), flush=True)
 t0 = time.time(); dev = ml.device(); print("upload", round(time.time() - t0, 2), flush=True)
