@@ -14,7 +14,7 @@ __global__ __launch_bounds__(kScanT) void scan_block_kernel(const int32_t* in, i
 #pragma unroll
   for (int o = 1; o < kWave; o <<= 1) {
     const long long y = __shfl_up(x, o, kWave);
-    if ((threadIdx.x & (kWave - 1)) >= o) x += y;
+    if ((int)(threadIdx.x & (kWave - 1)) >= o) x += y;
   }
   const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
   if (lane == kWave - 1) s_w[w] = x;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kScanT) void scan_sums_kernel(long long* bsum, int 
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
       const long long y = __shfl_up(x, o, kWave);
-      if ((threadIdx.x & (kWave - 1)) >= o) x += y;
+      if ((int)(threadIdx.x & (kWave - 1)) >= o) x += y;
     }
     const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     if (lane == kWave - 1) s_w[w] = x;
