@@ -529,13 +529,13 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0, buil
             M._T._sym = False
             M._T._T = M
 
-    # Schedules of up to two levels at a time (amgh_level_prepare touches no handle): level l+1's matrix exists long
+    # Schedules of up to three levels at a time (AMG_PREPARE_THREADS; amgh_level_prepare touches no handle): level l+1's matrix exists long
     # before the schedules of the much larger level l are done.  The levels join the handle in order (`pipe`).
     pool = None
     prepared = []
     if pipe is not None:
         from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=2)
+        pool = ThreadPoolExecutor(max_workers=int(__import__("os").environ.get("AMG_PREPARE_THREADS", "3")))
 
     def prepare_level(l):
         while len(prepared) <= l:
