@@ -716,7 +716,9 @@ def ruge_stuben(A, strength=None, symmetry=None, CF=None, presmoother=None, post
     setup = "host" (libamgsetup, C++/OpenMP) | "gpu" (strength, interpolation and R*A*P on the MI355X, C/F splitting
     on the host; same hierarchy bit for bit).  Default: the environment variable AMG_SETUP, else "host".
     device = a GPU ordinal (with setup="gpu"): the solve-phase hierarchy `ml.device(device)` is built on the way, each
-    level's smoother schedules on a worker thread while the host does that level's C/F splitting."""
+    level's smoother schedules on worker threads while the host does that level's C/F splitting (up to
+    AMG_PREPARE_THREADS = 3 levels under construction at once: their transient buffers add up — for a problem close to
+    the HBM capacity, e.g. 512^3 memory-lean, build first and call ml.device() afterwards)."""
     if kwargs.get("B") is not None:  # classical.jl:18
         raise AMGError("near null space `B` is only supported for smoothed aggregation AMG, not Ruge-Stüben AMG.")
     strength = strength if strength is not None else Classical(0.25)
