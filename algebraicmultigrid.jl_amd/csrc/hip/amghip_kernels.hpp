@@ -709,8 +709,11 @@ struct SellArgs {
   int32_t row0, nrows;      // the group's rows (level order)
   int32_t chunk0, nchunks;
   int32_t xcd_map;
+  int64_t ldx, ldb;         // column strides of x and bp (blocks of right-hand sides)
 };
-template <bool SOR, int K, int BATCH>
+// NCV columns of a block of right-hand sides per launch (blockIdx.y picks the column group): the matrix entries are
+// read once for all of them; each column's additions run in the order of the single-column launch (bitwise the same).
+template <bool SOR, int K, int BATCH, int NCV>
 __global__ __launch_bounds__(256) void gs_sell_kernel(SellArgs a) {
   constexpr int C = kWave / K;
   const int nwg = (a.nchunks + 3) >> 2;
@@ -724,41 +727,65 @@ __global__ __launch_bounds__(256) void gs_sell_kernel(SellArgs a) {
   const int64_t base = (int64_t)(uint32_t)cd.x * kWave + lane;
   const int r = ch * C + lane / K;
   const bool live = r < a.nrows;
-  real d = 0.0, bb = 0.0;
-  if (live) { d = a.diag[a.row0 + r]; bb = a.bp[a.row0 + r]; }
-  real acc = 0.0;
+  real* x = a.x + (int64_t)blockIdx.y * NCV * a.ldx;
+  const real* bp = a.bp + (int64_t)blockIdx.y * NCV * a.ldb;
+  real d = 0.0, bb[NCV], acc[NCV];
+#pragma unroll
+  for (int k = 0; k < NCV; ++k) { bb[k] = 0.0; acc[k] = 0.0; }
+  if (live) {
+    d = a.diag[a.row0 + r];
+#pragma unroll
+    for (int k = 0; k < NCV; ++k) bb[k] = bp[a.row0 + r + k * a.ldb];
+  }
   int t = 0;
   for (; t + BATCH <= cd.y; t += BATCH) {
-    real v[BATCH], xv[BATCH];
+    real v[BATCH], xv[BATCH][NCV];
     int c[BATCH];
 #pragma unroll
     for (int e = 0; e < BATCH; ++e) c[e] = a.scol[base + (int64_t)(t + e) * kWave];
 #pragma unroll
     for (int e = 0; e < BATCH; ++e) v[e] = a.sval[base + (int64_t)(t + e) * kWave];
 #pragma unroll
-    for (int e = 0; e < BATCH; ++e) xv[e] = c[e] >= 0 ? a.x[c[e]] : 0.0;
+    for (int e = 0; e < BATCH; ++e)
+#pragma unroll
+      for (int k = 0; k < NCV; ++k) xv[e][k] = c[e] >= 0 ? x[c[e] + k * a.ldx] : 0.0;
 #pragma unroll
     for (int e = 0; e < BATCH; ++e)
-      if (c[e] >= 0) acc += v[e] * xv[e];
+      if (c[e] >= 0) {
+#pragma unroll
+        for (int k = 0; k < NCV; ++k) acc[k] += v[e] * xv[e][k];
+      }
   }
   if (t < cd.y) {  // tail of 1 .. BATCH-1 iterations, loads issued together
-    real v[BATCH], xv[BATCH];
+    real v[BATCH], xv[BATCH][NCV];
     int c[BATCH];
 #pragma unroll
     for (int e = 0; e < BATCH - 1; ++e) c[e] = (t + e < cd.y) ? a.scol[base + (int64_t)(t + e) * kWave] : -1;
 #pragma unroll
     for (int e = 0; e < BATCH - 1; ++e) v[e] = (t + e < cd.y) ? a.sval[base + (int64_t)(t + e) * kWave] : 0.0;
 #pragma unroll
-    for (int e = 0; e < BATCH - 1; ++e) xv[e] = c[e] >= 0 ? a.x[c[e]] : 0.0;
+    for (int e = 0; e < BATCH - 1; ++e)
+#pragma unroll
+      for (int k = 0; k < NCV; ++k) xv[e][k] = c[e] >= 0 ? x[c[e] + k * a.ldx] : 0.0;
 #pragma unroll
     for (int e = 0; e < BATCH - 1; ++e)
-      if (c[e] >= 0) acc += v[e] * xv[e];
+      if (c[e] >= 0) {
+#pragma unroll
+        for (int k = 0; k < NCV; ++k) acc[k] += v[e] * xv[e][k];
+      }
   }
 #pragma unroll
-  for (int w = 1; w < K; w <<= 1) acc += __shfl_xor(acc, w, kWave);
+  for (int k = 0; k < NCV; ++k) {
+#pragma unroll
+    for (int w = 1; w < K; w <<= 1) acc[k] += __shfl_xor(acc[k], w, kWave);
+  }
   if (live && (lane % K) == 0 && d != 0.0) {
     const int i = a.row0 + r;
-    a.x[i] = SOR ? (1.0 - a.omega) * a.x[i] + (a.omega / d) * (bb - acc) : (bb - acc) / d;
+#pragma unroll
+    for (int k = 0; k < NCV; ++k) {
+      real* xi = x + i + k * a.ldx;
+      *xi = SOR ? (1.0 - a.omega) * *xi + (a.omega / d) * (bb[k] - acc[k]) : (bb[k] - acc[k]) / d;
+    }
   }
 }
 // a group's rows from the (composite) CSR into the SELL arrays: one thread per lane slot of a chunk

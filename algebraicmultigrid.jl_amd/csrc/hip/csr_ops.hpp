@@ -150,18 +150,28 @@ int launch_slot_lpr_e(const SlotArgs& sa, bool sor, int lpr, int grid, hipStream
 int launch_slot_lpr(const SlotArgs& sa, bool sor, int lpr, int ept, int grid, hipStream_t st) {
   return ept == 2 ? launch_slot_lpr_e<2>(sa, sor, lpr, grid, st) : launch_slot_lpr_e<1>(sa, sor, lpr, grid, st);
 }
-template <int K>
-int launch_sell_k(const SellArgs& a, bool sor, int grid, hipStream_t st) {
-  if (sor) hipLaunchKernelGGL((gs_sell_kernel<true, K, 4>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((gs_sell_kernel<false, K, 4>), dim3(grid), dim3(256), 0, st, a);
+template <int K, int NCV>
+int launch_sell_kc(const SellArgs& a, bool sor, dim3 grid, hipStream_t st) {
+  // (wide blocks: 2 entries in flight per lane instead of 4 — 4 x 8 gathered values would not fit the registers)
+  constexpr int BATCH = NCV >= 8 ? 2 : 4;
+  if (sor) hipLaunchKernelGGL((gs_sell_kernel<true, K, BATCH, NCV>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gs_sell_kernel<false, K, BATCH, NCV>), grid, dim3(256), 0, st, a);
   return AMGH_OK;
 }
-int launch_sell(const SellArgs& a, bool sor, int k, int grid, hipStream_t st) {
+template <int K>
+int launch_sell_k(const SellArgs& a, bool sor, int grid, int ncolv, hipStream_t st) {
+  // columns per launch: the largest of 8 / 4 / 2 / 1 that divides the block size
+  if (ncolv % 8 == 0) return launch_sell_kc<K, 8>(a, sor, dim3(grid, ncolv / 8), st);
+  if (ncolv % 4 == 0) return launch_sell_kc<K, 4>(a, sor, dim3(grid, ncolv / 4), st);
+  if (ncolv % 2 == 0) return launch_sell_kc<K, 2>(a, sor, dim3(grid, ncolv / 2), st);
+  return launch_sell_kc<K, 1>(a, sor, dim3(grid, ncolv), st);
+}
+int launch_sell(const SellArgs& a, bool sor, int k, int grid, int ncolv, hipStream_t st) {
   switch (k) {
-    case 8: return launch_sell_k<8>(a, sor, grid, st);
-    case 16: return launch_sell_k<16>(a, sor, grid, st);
-    case 32: return launch_sell_k<32>(a, sor, grid, st);
-    default: return launch_sell_k<64>(a, sor, grid, st);
+    case 8: return launch_sell_k<8>(a, sor, grid, ncolv, st);
+    case 16: return launch_sell_k<16>(a, sor, grid, ncolv, st);
+    case 32: return launch_sell_k<32>(a, sor, grid, ncolv, st);
+    default: return launch_sell_k<64>(a, sor, grid, ncolv, st);
   }
 }
 int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st) {
@@ -371,14 +381,15 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       const int64_t nx = lay == g ? g->ncols : xs;  // entries of x (and s) a chained row may read
       const bool ldsx = nx <= kChainLdsX;            // they fit LDS
       RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)nx, st, ncolv));
-    } else if (s.sell_k > 0 && lay->scol && g_gs_sell && ncolv == 1) {
+    } else if (s.sell_k > 0 && lay->scol && g_gs_sell) {
       SellArgs la{};
       la.scol = lay->scol; la.sval = lay->sval; la.chunk = lay->schunk; la.diag = lay->diag; la.bp = rhs; la.x = xp;
       la.omega = omega; la.row0 = lay->lvl_ptr[s.l0]; la.nrows = lay->lvl_ptr[s.l0 + 1] - lay->lvl_ptr[s.l0];
       la.chunk0 = s.sell_chunk0; la.nchunks = s.sell_nchunks; la.xcd_map = g_gs_xcd_map;
+      la.ldx = xs; la.ldb = ldb;
       const int nwg = (s.sell_nchunks + 3) / 4;
       const int grid = g_gs_xcd_map ? ((nwg + kNumXcd - 1) / kNumXcd) * kNumXcd : nwg;
-      RC_TRY(launch_sell(la, sor, s.sell_k, grid, st));
+      RC_TRY(launch_sell(la, sor, s.sell_k, grid, ncolv, st));
       HIP_TRY(hipGetLastError());
     } else if (s.nslots > 0 && (g_gs_slots || lay->compacted)) {
       SlotArgs sa{};

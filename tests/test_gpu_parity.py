@@ -512,6 +512,32 @@ def test_multiple_right_hand_sides_block_workspace():
             assert rel(Z[:, c], oh.precond(B[:, c])) <= TOL
 
 
+@pytest.mark.parametrize("bs", [8, 6, 3])
+def test_block_of_right_hand_sides_on_long_row_groups_equals_single_columns_bitwise(bs):
+    """Groups with long composite rows run from the SELL-like copy; a block of right-hand sides goes through the same
+    kernel with 8 / 2 / 1 columns per launch (the matrix entries read once for all of them) and every column's
+    additions in the single-column order: bit for bit the column-by-column result, and the oracle's within TOL."""
+    A = AMG.poisson((64, 64, 64))
+    n = A.m
+    ml = AMG.ruge_stuben(A)
+    B = np.stack([uniform(n, 70 + c) - 0.25 * c for c in range(bs)], axis=1)
+    lib = AMG.hip_lib()
+    # (single right-hand sides sum the 50-100-entry rows of the slot launches with 8 / 16 lanes per row and the short
+    #  ones two entries per thread — another order of additions; switch both off to compare like with like)
+    assert lib.amgh_debug_set_tunable(b"gs_lpr", 1) == 0 and lib.amgh_debug_set_tunable(b"gs_ept", 1) == 0
+    try:
+        Z = AMG.aspreconditioner(ml).ldiv(B)
+        singles = [AMG.aspreconditioner(ml).ldiv(B[:, c].copy()) for c in range(bs)]
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_lpr", 0)
+        lib.amgh_debug_set_tunable(b"gs_ept", 0)
+    oh = O.OracleHierarchy(ml)
+    for c in range(bs):
+        assert np.array_equal(Z[:, c], singles[c]), (c, rel(Z[:, c], singles[c]))
+        if c in (0, bs - 1):
+            assert rel(Z[:, c], oh.precond(B[:, c])) <= TOL
+
+
 def test_multiple_right_hand_sides_all_sweep_kernels():
     """bs = 4 on a hierarchy whose levels go through every Gauss-Seidel execution path (slot kernel on the wide
     dependency levels, single-workgroup chains, block-inverse sweeps) and through SOR / Jacobi: one launch
