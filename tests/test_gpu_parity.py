@@ -512,14 +512,14 @@ def test_multiple_right_hand_sides_block_workspace():
             assert rel(Z[:, c], oh.precond(B[:, c])) <= TOL
 
 
-@pytest.mark.parametrize("bs", [8, 6, 3])
-def test_block_of_right_hand_sides_on_long_row_groups_equals_single_columns_bitwise(bs):
+@pytest.mark.parametrize("bs,sor", [(8, False), (6, False), (3, False), (4, True)])
+def test_block_of_right_hand_sides_on_long_row_groups_equals_single_columns_bitwise(bs, sor):
     """Groups with long composite rows run from the SELL-like copy; a block of right-hand sides goes through the same
     kernel with 8 / 2 / 1 columns per launch (the matrix entries read once for all of them) and every column's
     additions in the single-column order: bit for bit the column-by-column result, and the oracle's within TOL."""
     A = AMG.poisson((64, 64, 64))
     n = A.m
-    ml = AMG.ruge_stuben(A)
+    ml = AMG.ruge_stuben(A, presmoother=AMG.SOR(1.2), postsmoother=AMG.SOR(1.2)) if sor else AMG.ruge_stuben(A)
     B = np.stack([uniform(n, 70 + c) - 0.25 * c for c in range(bs)], axis=1)
     lib = AMG.hip_lib()
     # (single right-hand sides sum the 50-100-entry rows of the slot launches with 8 / 16 lanes per row and the short
