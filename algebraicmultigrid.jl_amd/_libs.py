@@ -194,6 +194,7 @@ def hip_lib(dtype=None):
     L.amgh_local_group_abort.argtypes = [vp]
     L.amgh_local_group_abort.restype = None
     L.amgh_dist_create_local.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp]
+    L.amgh_dist_create_ipc.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.amgh_dist_destroy.argtypes = [vp]
     L.amgh_dist_destroy.restype = None
     L.amgh_dist_push_level.argtypes = [vp, i64, i64, vp, vp] + [vp] * 12 + [C.POINTER(amgh_smoother_t),
@@ -214,6 +215,7 @@ def hip_lib(dtype=None):
     L.amgh_dist_stream.restype = vp
     L.amgh_dist_stream.argtypes = [vp]
     L.amgh_dist_plan_info.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.amgh_dist_plan_info2.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     # GPU half of the setup phase (amgh_dmat_*, amgh_setup_*)
     L.amgh_dmat_upload.argtypes = [C.POINTER(vp), C.c_int, i64, i64, vp, vp, vp]
     L.amgh_dmat_download.argtypes = [vp, vp, vp, vp]

@@ -13,6 +13,12 @@
 //          that libamghip.so loads on machines without it.
 //   LOCAL  N ranks as N handles of ONE process (threads), peer copies between their streams; ranks may share a device.
 //          This is what the single-GPU test box runs (virtual ranks) and what a single-process multi-GPU host can use.
+//   IPC    one process per rank, no library in between (amghip_ipc.hpp): the packed send buffers are peer-mapped with
+//          hipIpc memory handles, the hand-off is a pair of sequence flags per (vector, peer) in a POSIX shared-memory
+//          segment that the streams themselves write and wait on (hipStreamWriteValue64 / hipStreamWaitValue64) — no
+//          host round trip per exchange; the consumer pulls its halo entries with one device-to-device copy per peer.
+//          Two processes may share a GPU (which RCCL refuses), so the single-GPU test box runs this path with real
+//          processes; device = -1 builds the halo plans only (host memory, no GPU: the CPU multi-process test).
 // Gauss-Seidel / SOR cannot be both lexicographic and parallel across a row partition: on sharded levels the sweep is
 // exact inside a shard with the halo frozen per directional sweep (processor-block hybrid); Jacobi, residual,
 // restriction and prolongation are exactly the single-GPU arithmetic.
@@ -26,8 +32,27 @@
 
 namespace {
 
-// ---- transports -------------------------------------------------------------------------------------------------
+// ---- halo plan of one distributed vector -------------------------------------------------------------------------
 struct PeerSpan { int64_t off = 0, cnt = 0; };
+
+struct VecPlan {
+  int id = -1;                       // position in the handle's list of plans (the same on every rank)
+  int64_t r0 = 0, r1 = 0;            // my rows of the vector
+  std::vector<int64_t> halo;         // sorted unique global indices outside [r0, r1) this rank reads
+  std::vector<PeerSpan> recv;        // per peer: where its entries sit in the halo region (offsets relative to the halo)
+  std::vector<PeerSpan> send;        // per peer: span of the packed send buffer
+  std::vector<int32_t> h_send_idx;   // local indices gathered into the send buffer (all peers back to back)
+  int32_t* d_send_idx = nullptr;     // ... on the device
+  int64_t nsend = 0;
+  real* d_sendbuf = nullptr;         // `copies` buffers of nsend entries
+  int copies = 1;
+  bool any = false;                  // any rank moves anything (same decision everywhere)
+  int64_t nloc() const { return r1 - r0; }
+  int64_t nhalo() const { return (int64_t)halo.size(); }
+  void free_dev() { hipFree(d_send_idx); hipFree(d_sendbuf); d_send_idx = nullptr; d_sendbuf = nullptr; }
+};
+
+// ---- transports -------------------------------------------------------------------------------------------------
 
 struct Transport {
   int rank = 0, nranks = 1;
@@ -35,14 +60,26 @@ struct Transport {
   virtual bool async() const { return false; }
   // setup: every rank contributes a list of int64, every rank gets all lists
   virtual int allgatherv_host(const std::vector<int64_t>& mine, std::vector<std::vector<int64_t>>& all) = 0;
-  // data path: send sendbuf[send[p].off .. +cnt) to peer p, receive recv[p].cnt doubles from p into recvbuf + recv[p].off.
-  // `st` is the stream the packed send buffer was produced on and on which the received data will be consumed:
-  // begin() may return before the data has arrived, finish() makes `st` wait for it.
-  virtual int exchange_begin(const real* sendbuf, const std::vector<PeerSpan>& send, real* recvbuf,
-                             const std::vector<PeerSpan>& recv, hipStream_t st) = 0;
-  virtual int exchange_finish(hipStream_t st) = 0;
-  virtual int allreduce(real* v, int n, bool max_op) = 0;  // host values, in place
+  // a plan's send buffer exists: whatever the transport keeps per plan (collective; IPC maps the peers' buffers)
+  virtual int send_copies() const { return 1; }
+  virtual int plan_attach(VecPlan&) { return AMGH_OK; }
+  virtual void plan_detach(VecPlan&) {}
+  // data path of one exchange of plan pl, in this order:
+  //   pack_target()    which copy of the send buffer the pack kernel fills (may enqueue waits on `st`)
+  //   exchange_begin() send sendbuf[send[p].off .. +cnt) to peer p, receive recv[p].cnt entries from p into
+  //                    recvbuf + recv[p].off.  `st` is the stream the packed send buffer was produced on and on which
+  //                    the received data will be consumed; it may return before the data has arrived,
+  //   exchange_finish() makes `st` wait for it.
+  virtual int pack_target(VecPlan& pl, hipStream_t, real** sendbuf) { *sendbuf = pl.d_sendbuf; return AMGH_OK; }
+  virtual int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st) = 0;
+  virtual int exchange_finish(VecPlan& pl, hipStream_t st) = 0;
+  virtual int allreduce(double* v, int n, bool max_op) = 0;  // host values, in place
   virtual int barrier() = 0;
+  // host wait for a stream whose work may depend on other ranks (a transport that can, bounds the wait)
+  virtual int wait_stream(hipStream_t st) {
+    HIP_TRY(hipStreamSynchronize(st));
+    return AMGH_OK;
+  }
 };
 
 struct RcclApi {
@@ -50,6 +87,8 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -75,6 +114,8 @@ RcclApi* rccl_api() {
   api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
   api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+  api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
+  api.CommGetAsyncError = (decltype(api.CommGetAsyncError))sym("ncclCommGetAsyncError");
   api.Send = (decltype(api.Send))sym("ncclSend");
   api.Recv = (decltype(api.Recv))sym("ncclRecv");
   api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
@@ -106,7 +147,15 @@ struct RcclTransport : Transport {
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   int64_t* d_i64 = nullptr;      // setup scratch
   int64_t d_i64_cap = 0;
-  real* d_scal = nullptr;
+  double* d_scal = nullptr;
+  bool broken = false;
+  // A rank that fails between two collectives must not leave its peers blocked in ncclRecv / ncclAllReduce for ever:
+  // aborting the communicator makes their pending operations fail (they return -(2000 + ncclResult_t)).
+  int fail(int rc) {
+    if (!broken && comm && api) { api->CommAbort(comm); comm = nullptr; }
+    broken = true;
+    return rc;
+  }
   ~RcclTransport() override {
     if (comm && api) api->CommDestroy(comm);
     if (cs) hipStreamDestroy(cs);
@@ -142,48 +191,72 @@ struct RcclTransport : Transport {
     HIP_TRY(hipMemcpyAsync(d_i64, &cnt, 8, hipMemcpyHostToDevice, cs));
     NCCL_TRY(api->AllGather(d_i64, d_i64 + 1, 1, ncclInt64, comm, cs));
     std::vector<int64_t> counts(nranks);
-    HIP_TRY(hipMemcpyAsync(counts.data(), d_i64 + 1, 8 * nranks, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipMemcpyAsync(counts.data(), d_i64 + 1, sizeof(int64_t) * nranks, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipStreamSynchronize(cs));
     int64_t mx = 1;
     for (int64_t c : counts) mx = std::max(mx, c);
     RC_TRY(ensure_i64(mx * (nranks + 1)));
-    if (cnt) HIP_TRY(hipMemcpyAsync(d_i64, mine.data(), 8 * cnt, hipMemcpyHostToDevice, cs));
+    if (cnt) HIP_TRY(hipMemcpyAsync(d_i64, mine.data(), sizeof(int64_t) * cnt, hipMemcpyHostToDevice, cs));
     NCCL_TRY(api->AllGather(d_i64, d_i64 + mx, (size_t)mx, ncclInt64, comm, cs));
     std::vector<int64_t> flat((size_t)mx * nranks);
-    HIP_TRY(hipMemcpyAsync(flat.data(), d_i64 + mx, 8 * mx * nranks, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipMemcpyAsync(flat.data(), d_i64 + mx, sizeof(int64_t) * mx * nranks, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipStreamSynchronize(cs));
     all.assign(nranks, {});
     for (int p = 0; p < nranks; ++p) all[p].assign(flat.begin() + (size_t)p * mx, flat.begin() + (size_t)p * mx + counts[p]);
     return AMGH_OK;
   }
-  int exchange_begin(const real* sendbuf, const std::vector<PeerSpan>& send, real* recvbuf,
-                     const std::vector<PeerSpan>& recv, hipStream_t st) override {
-    HIP_TRY(hipEventRecord(ev_ready, st));
-    HIP_TRY(hipStreamWaitEvent(cs, ev_ready, 0));
-    NCCL_TRY(api->GroupStart());
-    for (int p = 0; p < nranks; ++p) {
+  int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st) override {
+    if (broken) return AMGH_ESTATE;
+    const ncclDataType_t dt = sizeof(real) == 8 ? ncclDouble : ncclFloat;
+    hipError_t e = hipEventRecord(ev_ready, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev_ready, 0);
+    if (e != hipSuccess) return fail(-(1000 + (int)e));
+    ncclResult_t r = api->GroupStart();
+    for (int p = 0; p < nranks && r == ncclSuccess; ++p) {
       if (p == rank) continue;
-      if (send[p].cnt > 0) NCCL_TRY(api->Send(sendbuf + send[p].off, (size_t)send[p].cnt, ncclDouble, p, comm, cs));
-      if (recv[p].cnt > 0) NCCL_TRY(api->Recv(recvbuf + recv[p].off, (size_t)recv[p].cnt, ncclDouble, p, comm, cs));
+      if (pl.send[p].cnt > 0) r = api->Send(sendbuf + pl.send[p].off, (size_t)pl.send[p].cnt, dt, p, comm, cs);
+      if (r == ncclSuccess && pl.recv[p].cnt > 0)
+        r = api->Recv(recvbuf + pl.recv[p].off, (size_t)pl.recv[p].cnt, dt, p, comm, cs);
     }
-    NCCL_TRY(api->GroupEnd());
-    HIP_TRY(hipEventRecord(ev_done, cs));
+    const ncclResult_t r2 = api->GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return fail(-(2000 + (int)r));
+    e = hipEventRecord(ev_done, cs);
+    if (e != hipSuccess) return fail(-(1000 + (int)e));
     return AMGH_OK;
   }
-  int exchange_finish(hipStream_t st) override {
+  int exchange_finish(VecPlan&, hipStream_t st) override {
     HIP_TRY(hipStreamWaitEvent(st, ev_done, 0));
     return AMGH_OK;
   }
-  int allreduce(real* v, int n, bool max_op) override {
+  int allreduce(double* v, int n, bool max_op) override {
     if (n > 64) return AMGH_EINVAL;
-    HIP_TRY(hipMemcpyAsync(d_scal, v, 8 * n, hipMemcpyHostToDevice, cs));
-    NCCL_TRY(api->AllReduce(d_scal, d_scal, (size_t)n, ncclDouble, max_op ? ncclMax : ncclSum, comm, cs));
-    HIP_TRY(hipMemcpyAsync(v, d_scal, 8 * n, hipMemcpyDeviceToHost, cs));
-    HIP_TRY(hipStreamSynchronize(cs));
+    if (broken) return AMGH_ESTATE;
+    HIP_TRY(hipMemcpyAsync(d_scal, v, sizeof(double) * n, hipMemcpyHostToDevice, cs));
+    const ncclResult_t r = api->AllReduce(d_scal, d_scal, (size_t)n, ncclDouble, max_op ? ncclMax : ncclSum, comm, cs);
+    if (r != ncclSuccess) return fail(-(2000 + (int)r));
+    HIP_TRY(hipMemcpyAsync(v, d_scal, sizeof(double) * n, hipMemcpyDeviceToHost, cs));
+    RC_TRY(wait_stream(cs));
     return AMGH_OK;
   }
+  // the communicator reports asynchronous failures (a peer that died, a link error): poll it while waiting so that a
+  // rank whose peer is gone returns an error instead of blocking in hipStreamSynchronize for ever
+  int wait_stream(hipStream_t st) override {
+    for (int64_t spins = 0;; ++spins) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) return AMGH_OK;
+      if (q != hipErrorNotReady) return -(1000 + (int)q);
+      if (broken) return AMGH_ESTATE;
+      if ((spins & 1023) == 1023 && comm && api->CommGetAsyncError) {
+        ncclResult_t ar = ncclSuccess;
+        if (api->CommGetAsyncError(comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+          return fail(-(2000 + (int)ar));
+      }
+      if (spins > 64) std::this_thread::yield();
+    }
+  }
   int barrier() override {
-    real z = 0.0;
+    double z = 0.0;
     return allreduce(&z, 1, false);
   }
 };
@@ -203,7 +276,7 @@ struct amgh_local_group {
   std::vector<const std::vector<PeerSpan>*> sendspans;
   std::vector<int> device;
   std::vector<const std::vector<int64_t>*> lists;
-  std::vector<std::vector<real>> vals;
+  std::vector<std::vector<double>> vals;
   // returns false when the group was aborted (a rank failed): nobody hangs
   bool wait() {
     std::unique_lock<std::mutex> lk(mu);
@@ -233,8 +306,8 @@ struct LocalTransport : Transport {
     if (!g->wait()) return AMGH_ESTATE;
     return AMGH_OK;
   }
-  int exchange_begin(const real* sendbuf, const std::vector<PeerSpan>& send, real* recvbuf,
-                     const std::vector<PeerSpan>& recv, hipStream_t st) override {
+  int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st) override {
+    const std::vector<PeerSpan>&send = pl.send, &recv = pl.recv;
     if (hipStreamSynchronize(st) != hipSuccess) { g->abort(); return AMGH_ESTATE; }  // my packed entries are complete
     g->sendbuf[rank] = sendbuf;
     g->sendspans[rank] = &send;
@@ -246,20 +319,20 @@ struct LocalTransport : Transport {
       if (sp.cnt != recv[p].cnt) { g->abort(); return AMGH_ESTATE; }
       const real* src = g->sendbuf[p] + sp.off;
       hipError_t e = g->device[p] == device
-                         ? hipMemcpyAsync(recvbuf + recv[p].off, src, 8 * sp.cnt, hipMemcpyDeviceToDevice, st)
-                         : hipMemcpyPeerAsync(recvbuf + recv[p].off, device, src, g->device[p], 8 * sp.cnt, st);
+                         ? hipMemcpyAsync(recvbuf + recv[p].off, src, sizeof(real) * sp.cnt, hipMemcpyDeviceToDevice, st)
+                         : hipMemcpyPeerAsync(recvbuf + recv[p].off, device, src, g->device[p], sizeof(real) * sp.cnt, st);
       if (e != hipSuccess) { g->abort(); return -(1000 + (int)e); }
     }
     if (hipStreamSynchronize(st) != hipSuccess) { g->abort(); return AMGH_ESTATE; }
     if (!g->wait()) return AMGH_ESTATE;  // nobody repacks a send buffer a peer is still reading
     return AMGH_OK;
   }
-  int exchange_finish(hipStream_t) override { return AMGH_OK; }
-  int allreduce(real* v, int n, bool max_op) override {
+  int exchange_finish(VecPlan&, hipStream_t) override { return AMGH_OK; }
+  int allreduce(double* v, int n, bool max_op) override {
     g->vals[rank].assign(v, v + n);
     if (!g->wait()) return AMGH_ESTATE;
     for (int i = 0; i < n; ++i) {
-      real acc = g->vals[0][i];  // rank order: every rank computes the same bits
+      double acc = g->vals[0][i];  // rank order: every rank computes the same bits
       for (int p = 1; p < nranks; ++p) acc = max_op ? std::max(acc, g->vals[p][i]) : acc + g->vals[p][i];
       v[i] = acc;
     }
@@ -267,21 +340,6 @@ struct LocalTransport : Transport {
     return AMGH_OK;
   }
   int barrier() override { return g->wait() ? AMGH_OK : AMGH_ESTATE; }
-};
-
-// ---- halo plan of one distributed vector -------------------------------------------------------------------------
-struct VecPlan {
-  int64_t r0 = 0, r1 = 0;            // my rows of the vector
-  std::vector<int64_t> halo;         // sorted unique global indices outside [r0, r1) this rank reads
-  std::vector<PeerSpan> recv;        // per peer: where its entries sit in the halo region (offsets relative to the halo)
-  std::vector<PeerSpan> send;        // per peer: span of the packed send buffer
-  int32_t* d_send_idx = nullptr;     // local indices gathered into the send buffer (all peers back to back)
-  int64_t nsend = 0;
-  real* d_sendbuf = nullptr;
-  bool any = false;                  // any rank moves anything (same decision everywhere)
-  int64_t nloc() const { return r1 - r0; }
-  int64_t nhalo() const { return (int64_t)halo.size(); }
-  void free_dev() { hipFree(d_send_idx); hipFree(d_sendbuf); d_send_idx = nullptr; d_sendbuf = nullptr; }
 };
 
 // one local operator block: rows = my rows, columns = [my entries of the input vector | its halo]
@@ -325,6 +383,8 @@ struct amgh_dist {
   real *xt = nullptr, *bt = nullptr; // vectors of the first collapsed level: [all of it on the owner | halo elsewhere]
   amgh_t* tail = nullptr;              // the collapsed levels (on the rank that owns them), not owned
   bool finalized = false;
+  bool host_only = false;              // device < 0: halo plans in host memory only, no GPU call anywhere
+  int nplans = 0;
   real *partial = nullptr, *scal = nullptr;
   int64_t ex_count = 0, ex_bytes = 0;  // halo exchanges / bytes sent by this rank since the last reset
   int overlap = 1;
@@ -335,6 +395,7 @@ namespace {
 int plan_build(amgh_dist* d, VecPlan& pl, const std::vector<int64_t>& cuts, std::vector<int64_t> needs) {
   Transport* tr = d->tr;
   const int N = tr->nranks, me = tr->rank;
+  pl.id = d->nplans++;
   pl.r0 = cuts[me]; pl.r1 = cuts[me + 1];
   sort_unique(needs);
   pl.halo = needs;
@@ -354,7 +415,8 @@ int plan_build(amgh_dist* d, VecPlan& pl, const std::vector<int64_t>& cuts, std:
   }
   std::vector<std::vector<int64_t>> all;
   RC_TRY(tr->allgatherv_host(pl.halo, all));
-  std::vector<int32_t> send_idx;
+  std::vector<int32_t>& send_idx = pl.h_send_idx;
+  send_idx.clear();
   pl.any = false;
   for (int p = 0; p < N; ++p) {
     pl.any = pl.any || !all[p].empty();
@@ -365,9 +427,11 @@ int plan_build(amgh_dist* d, VecPlan& pl, const std::vector<int64_t>& cuts, std:
     pl.send[p].cnt = (int64_t)send_idx.size() - pl.send[p].off;
   }
   pl.nsend = (int64_t)send_idx.size();
+  if (d->host_only) return AMGH_OK;
+  pl.copies = tr->send_copies();
   RC_TRY(dev_upload(&pl.d_send_idx, send_idx.data(), pl.nsend));
-  RC_TRY(dev_alloc(&pl.d_sendbuf, pl.nsend));
-  return AMGH_OK;
+  RC_TRY(dev_alloc(&pl.d_sendbuf, pl.copies * pl.nsend));
+  return tr->plan_attach(pl);
 }
 
 // global column -> position in [local | halo]
@@ -400,7 +464,8 @@ int block_upload(amgh_dist* d, DistOp& dop, HostBlock& hb, const VecPlan& pl) {
     else { i1 = (int32_t)i; break; }
   }
   dop.i0 = std::min(i0, i1); dop.i1 = i1;
-  RC_TRY(csr_upload(&dop.op, d->device, n, nloc + pl.nhalo(), hb.rowptr.data(), lc.data(), hb.val.data()));
+  if (!d->host_only)
+    RC_TRY(csr_upload(&dop.op, d->device, n, nloc + pl.nhalo(), hb.rowptr.data(), lc.data(), hb.val.data()));
   dop.present = true;
   hb = HostBlock();
   return AMGH_OK;
@@ -422,18 +487,20 @@ int take_block(HostBlock& hb, int64_t nrows, const int32_t* rowptr, const int32_
 // ---- data path ---------------------------------------------------------------------------------------------------
 int halo_begin(amgh_dist* d, VecPlan& pl, real* vec) {
   if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
+  real* sendbuf = nullptr;
+  RC_TRY(d->tr->pack_target(pl, d->stream, &sendbuf));
   if (pl.nsend > 0) {
     hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(pl.nsend)), dim3(256), 0, d->stream, (const real*)vec,
-                       (const int32_t*)pl.d_send_idx, pl.d_sendbuf, (int)pl.nsend, (int64_t)0, (int64_t)0);
+                       (const int32_t*)pl.d_send_idx, sendbuf, (int)pl.nsend, (int64_t)0, (int64_t)0);
     HIP_TRY(hipGetLastError());
   }
   ++d->ex_count;
-  d->ex_bytes += 8 * pl.nsend;
-  return d->tr->exchange_begin(pl.d_sendbuf, pl.send, vec + pl.nloc(), pl.recv, d->stream);
+  d->ex_bytes += (int64_t)sizeof(real) * pl.nsend;
+  return d->tr->exchange_begin(pl, sendbuf, vec + pl.nloc(), d->stream);
 }
 int halo_finish(amgh_dist* d, VecPlan& pl) {
   if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
-  return d->tr->exchange_finish(d->stream);
+  return d->tr->exchange_finish(pl, d->stream);
 }
 int halo_exchange(amgh_dist* d, VecPlan& pl, real* vec) {
   RC_TRY(halo_begin(d, pl, vec));
@@ -489,7 +556,7 @@ int dist_smooth(amgh_dist* d, int l, const amgh_smoother_t& s, bool xzero, bool*
       if (n > 0) RC_TRY(csr_ensure_diag(&M->op, d->stream));
       RC_TRY(dist_apply(d, *M, M_JACOBI, pl, L->x, L->b, L->tmp, s.omega, fresh));
       fresh = false;
-      if (n > 0) HIP_TRY(hipMemcpyAsync(L->x, L->tmp, 8 * n, hipMemcpyDeviceToDevice, d->stream));
+      if (n > 0) HIP_TRY(hipMemcpyAsync(L->x, L->tmp, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
     } else if (s.kind == AMGH_SMOOTH_GS || s.kind == AMGH_SMOOTH_SOR) {
       const bool sor = s.kind == AMGH_SMOOTH_SOR;
       for (int dir = 0; dir < 2; ++dir) {
@@ -537,7 +604,7 @@ int dist_cycle(amgh_dist* d, int l, int cyc, bool xzero) {
   RC_TRY(dist_apply(d, L->A, M_RESID, xp, L->x, L->b, L->res, 0.0));                                // res = b - A x
   RC_TRY(dist_apply(d, L->R, M_SPMV, L->rplan, L->res, nullptr, bc, 0.0));                          // b_c = R res
   const int64_t ncx = xpc.nloc() + xpc.nhalo();
-  if (ncx > 0) HIP_TRY(hipMemsetAsync(xc, 0, 8 * ncx, d->stream));                                  // coarse_x .= 0
+  if (ncx > 0) HIP_TRY(hipMemsetAsync(xc, 0, sizeof(real) * ncx, d->stream));                                  // coarse_x .= 0
   RC_TRY(dist_cycle_next(d, l + 1, cyc));
   RC_TRY(dist_apply(d, L->P, M_ADD, xpc, xc, nullptr, L->x, 0.0));                                   // x += P x_c
   RC_TRY(dist_smooth(d, l, L->post, false, &b_kept));
@@ -564,11 +631,12 @@ int dist_dot(amgh_dist* d, const real* x, const real* y, int64_t n, real* out) {
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, d->stream, x, y, n, d->partial);
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kThreads), 0, d->stream, d->partial, nb, d->scal, 0);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&v, d->scal, 8, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(&v, d->scal, sizeof(real), hipMemcpyDeviceToHost, d->stream));
   }
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  RC_TRY(d->tr->allreduce(&v, 1, false));
-  *out = v;
+  RC_TRY(d->tr->wait_stream(d->stream));
+  double vd = (double)v;   // partial sums of the ranks are added in double whatever the eltype
+  RC_TRY(d->tr->allreduce(&vd, 1, false));
+  *out = (real)vd;
   return AMGH_OK;
 }
 
@@ -582,11 +650,12 @@ int dist_resnorm(amgh_dist* d, real* out) {
       real* res = h->levels.empty() ? h->res_final : h->levels[0]->res;
       RC_TRY(fine_residual(h, d->xt, d->bt, res));
       RC_TRY(vec_dot(h, res, res, fine_n(h), h->scal, 0));
-      HIP_TRY(hipMemcpyAsync(&v, h->scal, 8, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+      HIP_TRY(hipMemcpyAsync(&v, h->scal, sizeof(real), hipMemcpyDeviceToHost, h->stream));
+      RC_TRY(d->tr->wait_stream(h->stream));
     }
-    RC_TRY(d->tr->allreduce(&v, 1, false));
-    s = v;
+    double vd = (double)v;
+    RC_TRY(d->tr->allreduce(&vd, 1, false));
+    s = (real)vd;
   } else {
     DistLevel* L = d->levels[0];
     RC_TRY(dist_apply(d, L->A, M_RESID, d->xplan[0], L->x, L->b, L->res, 0.0));
@@ -599,20 +668,26 @@ int dist_resnorm(amgh_dist* d, real* out) {
 int dist_check(const amgh_dist* d) {
   if (!d) return AMGH_EINVAL;
   if (!d->finalized) return AMGH_ESTATE;
+  if (d->host_only) return AMGH_EUNSUPPORTED;  // plans only: there is no data path without a device
   return AMGH_OK;
 }
 
 void dist_free(amgh_dist* d) {
   for (DistLevel* L : d->levels) {
-    for (DistOp* o : {&L->A, &L->S, &L->P, &L->R}) csr_free(&o->op);
-    hipFree(L->x); hipFree(L->b); hipFree(L->res); hipFree(L->tmp);
-    L->rplan.free_dev();
+    if (!d->host_only) {
+      for (DistOp* o : {&L->A, &L->S, &L->P, &L->R}) csr_free(&o->op);
+      hipFree(L->x); hipFree(L->b); hipFree(L->res); hipFree(L->tmp);
+      d->tr->plan_detach(L->rplan);
+      L->rplan.free_dev();
+    }
     delete L;
   }
   d->levels.clear();
-  for (VecPlan& p : d->xplan) p.free_dev();
-  hipFree(d->xt); hipFree(d->bt); hipFree(d->partial); hipFree(d->scal);
-  if (d->stream) hipStreamDestroy(d->stream);
+  if (!d->host_only) {
+    for (VecPlan& p : d->xplan) { d->tr->plan_detach(p); p.free_dev(); }
+    hipFree(d->xt); hipFree(d->bt); hipFree(d->partial); hipFree(d->scal);
+    if (d->stream) hipStreamDestroy(d->stream);
+  }
   delete d->tr;
   delete d;
 }
@@ -621,14 +696,19 @@ int dist_new(amgh_dist** dp, int device, Transport* tr) {
   amgh_dist* d = new amgh_dist;
   d->device = device;
   d->tr = tr;
-  hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete tr; delete d; return -(1000 + (int)e); }
+  d->host_only = device < 0;
+  if (!d->host_only) {
+    hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete tr; delete d; return -(1000 + (int)e); }
+  }
   if (const char* ev = getenv("AMGH_DIST_OVERLAP")) d->overlap = atoi(ev);
   *dp = d;
   return AMGH_OK;
 }
 
 }  // namespace
+
+#include "amghip_ipc.hpp"
 
 const char* amgh_rccl_error_string(int code) {
   RcclApi* api = rccl_api();
@@ -689,10 +769,30 @@ int amgh_dist_create_local(amgh_dist_t** dp, int device, int rank, amgh_local_gr
   return dist_new(dp, device, tr);
 }
 
+// IPC transport (one process per rank, shared memory + hipIpc): every rank passes the same `shm_name` ("/name", as
+// shm_open takes it); rank 0 creates the segment, the call returns when all `nranks` processes have attached
+// (collective).  device < 0: plans only (no GPU).
+int amgh_dist_create_ipc(amgh_dist_t** dp, int device, int rank, int nranks, const char* shm_name) {
+  if (!dp || !shm_name || shm_name[0] != '/' || std::strlen(shm_name) > 200 || nranks < 1 || nranks > kIpcMaxRanks ||
+      rank < 0 || rank >= nranks)
+    return AMGH_EINVAL;
+  *dp = nullptr;
+  if (device >= 0) {
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device >= ndev) return AMGH_EINVAL;
+    HIP_TRY(hipSetDevice(device));
+  }
+  IpcTransport* tr = new IpcTransport;
+  const int rc = tr->init(shm_name, rank, nranks, device < 0 ? -1 : device);
+  if (rc != AMGH_OK) { delete tr; return rc; }
+  return dist_new(dp, device < 0 ? -1 : device, tr);
+}
+
 void amgh_dist_destroy(amgh_dist_t* d) {
   if (!d) return;
-  hipSetDevice(d->device);
-  if (d->stream) hipStreamSynchronize(d->stream);
+  if (!d->host_only) hipSetDevice(d->device);
+  if (d->stream) d->tr->wait_stream(d->stream);
   if (d->tail && d->tail->stream == d->stream) {  // the borrowed tail goes back to its own stream (ours is about to die)
     d->tail->stream = d->tail->own_stream;
     d->tail->own_stream = nullptr;
@@ -740,7 +840,7 @@ int amgh_dist_push_level(amgh_dist_t* d, int64_t n_global, int64_t nc_global, co
 int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail) {
   if (!d) return AMGH_EINVAL;
   if (d->finalized) return AMGH_ESTATE;
-  if (tail && (!tail->finalized || tail->nrhs != 1 || tail->device != d->device)) return AMGH_EINVAL;
+  if (tail && (d->host_only || !tail->finalized || tail->nrhs != 1 || tail->device != d->device)) return AMGH_EINVAL;
   d->tail = tail;
   return AMGH_OK;
 }
@@ -749,7 +849,7 @@ int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail) {
 int amgh_dist_finalize(amgh_dist_t* d) {
   if (!d) return AMGH_EINVAL;
   if (d->finalized) return AMGH_ESTATE;
-  HIP_TRY(hipSetDevice(d->device));
+  if (!d->host_only) HIP_TRY(hipSetDevice(d->device));
   Transport* tr = d->tr;
   const int N = tr->nranks, me = tr->rank, lc = (int)d->levels.size();
   // the first collapsed level: all rows on one rank (crow_cuts of the last sharded level says which); with no sharded
@@ -757,8 +857,8 @@ int amgh_dist_finalize(amgh_dist_t* d) {
   std::vector<int64_t> tcuts;
   if (lc > 0) tcuts = d->levels.back()->ccuts;
   else {
-    real nt = d->tail ? (real)fine_n(d->tail) : 0.0;
-    std::vector<real> v(N, 0.0);
+    double nt = d->tail ? (double)fine_n(d->tail) : 0.0;
+    std::vector<double> v(N, 0.0);
     v[me] = nt;
     RC_TRY(tr->allreduce(v.data(), N, false));
     tcuts.assign(N + 1, 0);
@@ -766,8 +866,9 @@ int amgh_dist_finalize(amgh_dist_t* d) {
   }
   {
     const int64_t nt = tcuts[me + 1] - tcuts[me];
-    const bool owner_ok = nt == 0 ? true : (d->tail && fine_n(d->tail) == nt && nt == tcuts[N]);
-    real bad = owner_ok ? 0.0 : 1.0;
+    // (plans only: the owner has no GPU handle to pass, the partition alone says who it is)
+    const bool owner_ok = nt == 0 ? true : nt == tcuts[N] && (d->host_only || (d->tail && fine_n(d->tail) == nt));
+    double bad = owner_ok ? 0.0 : 1.0;
     RC_TRY(tr->allreduce(&bad, 1, true));
     if (bad != 0.0) DIST_EINVAL("the collapsed levels must live on exactly one rank, which passes the tail");
   }
@@ -795,13 +896,14 @@ int amgh_dist_finalize(amgh_dist_t* d) {
     RC_TRY(block_upload(d, L->S, L->hS, xp));
     RC_TRY(block_upload(d, L->P, L->hP, d->xplan[l + 1]));
     RC_TRY(block_upload(d, L->R, L->hR, L->rplan));
+    if (d->host_only) continue;
     const int64_t nloc = xp.nloc();
     RC_TRY(dev_alloc(&L->x, nloc + xp.nhalo()));
     RC_TRY(dev_alloc(&L->b, nloc));
     RC_TRY(dev_alloc(&L->res, nloc + L->rplan.nhalo()));
     RC_TRY(dev_alloc(&L->tmp, nloc));
-    HIP_TRY(hipMemset(L->x, 0, 8 * std::max<int64_t>(1, nloc + xp.nhalo())));
-    HIP_TRY(hipMemset(L->res, 0, 8 * std::max<int64_t>(1, nloc + L->rplan.nhalo())));
+    HIP_TRY(hipMemset(L->x, 0, sizeof(real) * std::max<int64_t>(1, nloc + xp.nhalo())));
+    HIP_TRY(hipMemset(L->res, 0, sizeof(real) * std::max<int64_t>(1, nloc + L->rplan.nhalo())));
     // smoother metadata now, not inside the first timed cycle
     const bool jac = L->pre.kind == AMGH_SMOOTH_JACOBI || L->post.kind == AMGH_SMOOTH_JACOBI;
     const bool gs = L->pre.kind == AMGH_SMOOTH_GS || L->pre.kind == AMGH_SMOOTH_SOR || L->post.kind == AMGH_SMOOTH_GS ||
@@ -810,11 +912,16 @@ int amgh_dist_finalize(amgh_dist_t* d) {
     if (nloc > 0 && jac) RC_TRY(csr_ensure_diag(M, d->stream));
     if (nloc > 0 && gs) RC_TRY(csr_ensure_gs(M));
   }
+  if (d->host_only) {
+    RC_TRY(tr->barrier());
+    d->finalized = true;
+    return AMGH_OK;
+  }
   {
     VecPlan& tp = d->xplan[lc];
     RC_TRY(dev_alloc(&d->xt, tp.nloc() + tp.nhalo()));
     RC_TRY(dev_alloc(&d->bt, tp.nloc()));
-    HIP_TRY(hipMemset(d->xt, 0, 8 * std::max<int64_t>(1, tp.nloc() + tp.nhalo())));
+    HIP_TRY(hipMemset(d->xt, 0, sizeof(real) * std::max<int64_t>(1, tp.nloc() + tp.nhalo())));
   }
   if (d->tail) {  // the collapsed levels enqueue on this handle's stream
     d->tail->ext_stream = true;
@@ -838,22 +945,30 @@ int amgh_dist_local_range(const amgh_dist_t* d, int level, int64_t* r0, int64_t*
   return AMGH_OK;
 }
 
-// Halo plan of x on `level` (tests, diagnostics): counts, then optionally the arrays.
-// out_counts: {nloc, nhalo, nsend, interior row begin of A, interior row end of A}
-int amgh_dist_plan_info(const amgh_dist_t* d, int level, int64_t* out_counts, int64_t* halo_globals, int32_t* send_idx,
-                        int64_t* send_cnt_per_peer, int64_t* recv_cnt_per_peer) {
-  if (!d || !d->finalized || level < 0 || level > (int)d->levels.size() || !out_counts) return AMGH_EINVAL;
-  const VecPlan& pl = d->xplan[level];
+// Halo plan of a distributed vector (tests, diagnostics): which = 0: x of `level` (0..lc; lc = the first collapsed level),
+// which = 1: the residual of `level` (what R reads).  Counts, then optionally the arrays.
+// out_counts: {nloc, nhalo, nsend, interior row begin, interior row end of the consuming operator (A / R)}
+int amgh_dist_plan_info2(const amgh_dist_t* d, int level, int which, int64_t* out_counts, int64_t* halo_globals,
+                         int32_t* send_idx, int64_t* send_cnt_per_peer, int64_t* recv_cnt_per_peer) {
+  if (!d || !d->finalized || level < 0 || !out_counts || (which != 0 && which != 1)) return AMGH_EINVAL;
+  const int lc = (int)d->levels.size();
+  if (level > lc || (which == 1 && level >= lc)) return AMGH_EINVAL;
+  const VecPlan& pl = which == 0 ? d->xplan[level] : d->levels[level]->rplan;
   out_counts[0] = pl.nloc(); out_counts[1] = pl.nhalo(); out_counts[2] = pl.nsend;
-  out_counts[3] = level < (int)d->levels.size() ? d->levels[level]->A.i0 : 0;
-  out_counts[4] = level < (int)d->levels.size() ? d->levels[level]->A.i1 : 0;
+  const DistOp* op = level < lc ? (which == 0 ? &d->levels[level]->A : &d->levels[level]->R) : nullptr;
+  out_counts[3] = op ? op->i0 : 0;
+  out_counts[4] = op ? op->i1 : 0;
   if (halo_globals) std::copy(pl.halo.begin(), pl.halo.end(), halo_globals);
-  if (send_idx && pl.nsend > 0) HIP_TRY(hipMemcpy(send_idx, pl.d_send_idx, 4 * pl.nsend, hipMemcpyDeviceToHost));
+  if (send_idx) std::copy(pl.h_send_idx.begin(), pl.h_send_idx.end(), send_idx);
   for (int p = 0; p < d->tr->nranks; ++p) {
     if (send_cnt_per_peer) send_cnt_per_peer[p] = pl.send[p].cnt;
     if (recv_cnt_per_peer) recv_cnt_per_peer[p] = pl.recv[p].cnt;
   }
   return AMGH_OK;
+}
+int amgh_dist_plan_info(const amgh_dist_t* d, int level, int64_t* out_counts, int64_t* halo_globals, int32_t* send_idx,
+                        int64_t* send_cnt_per_peer, int64_t* recv_cnt_per_peer) {
+  return amgh_dist_plan_info2(d, level, 0, out_counts, halo_globals, send_idx, send_cnt_per_peer, recv_cnt_per_peer);
 }
 
 // ldiv!(x, p, b) on the sharded hierarchy: r_loc_d / z_loc_d hold this rank's rows of level 0 (device pointers).
@@ -865,10 +980,10 @@ int amgh_dist_precond_apply_d(amgh_dist_t* d, const real* r_loc_d, real* z_loc_d
   const VecPlan& p0 = d->xplan[0];
   const int64_t n = p0.nloc();
   if (n > 0 && (!r_loc_d || !z_loc_d)) return AMGH_EINVAL;
-  if (n > 0) HIP_TRY(hipMemcpyAsync(dist_b0(d), r_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
-  if (n + p0.nhalo() > 0) HIP_TRY(hipMemsetAsync(dist_x0(d), 0, 8 * (n + p0.nhalo()), d->stream));
+  if (n > 0) HIP_TRY(hipMemcpyAsync(dist_b0(d), r_loc_d, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
+  if (n + p0.nhalo() > 0) HIP_TRY(hipMemsetAsync(dist_x0(d), 0, sizeof(real) * (n + p0.nhalo()), d->stream));
   RC_TRY(dist_apply_cycle(d, cycle_, true));
-  if (n > 0) HIP_TRY(hipMemcpyAsync(z_loc_d, dist_x0(d), 8 * n, hipMemcpyDeviceToDevice, d->stream));
+  if (n > 0) HIP_TRY(hipMemcpyAsync(z_loc_d, dist_x0(d), sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
   return AMGH_OK;
 }
 
@@ -882,8 +997,8 @@ int amgh_dist_solve_d(amgh_dist_t* d, const real* b_loc_d, real* x_loc_d, int cy
   const int64_t n = p0.nloc();
   if (n > 0 && (!b_loc_d || !x_loc_d)) return AMGH_EINVAL;
   if (n > 0) {
-    HIP_TRY(hipMemcpyAsync(dist_b0(d), b_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
-    HIP_TRY(hipMemcpyAsync(dist_x0(d), x_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(dist_b0(d), b_loc_d, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(dist_x0(d), x_loc_d, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
   }
   real nb2 = 0.0;
   RC_TRY(dist_dot(d, dist_b0(d), dist_b0(d), n, &nb2));
@@ -901,9 +1016,8 @@ int amgh_dist_solve_d(amgh_dist_t* d, const real* b_loc_d, real* x_loc_d, int cy
     ++itr;
   }
   if (iters) *iters = itr - 1;
-  if (n > 0) HIP_TRY(hipMemcpyAsync(x_loc_d, dist_x0(d), 8 * n, hipMemcpyDeviceToDevice, d->stream));
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  return AMGH_OK;
+  if (n > 0) HIP_TRY(hipMemcpyAsync(x_loc_d, dist_x0(d), sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
+  return d->tr->wait_stream(d->stream);
 }
 
 // y_loc = A_level x_loc with the halo exchange in front (roofline hook of the sharded SpMV).  Enqueue only.
@@ -916,25 +1030,27 @@ int amgh_dist_spmv_d(amgh_dist_t* d, int level, const real* x_loc_d, real* y_loc
   const int64_t n = pl.nloc();
   if (n > 0 && !y_loc_d) return AMGH_EINVAL;
   // x_loc_d == NULL: multiply the level's own x (what the last cycle left there) — no copy in front of the exchange
-  if (n > 0 && x_loc_d && x_loc_d != L->x) HIP_TRY(hipMemcpyAsync(L->x, x_loc_d, 8 * n, hipMemcpyDeviceToDevice, d->stream));
+  if (n > 0 && x_loc_d && x_loc_d != L->x) HIP_TRY(hipMemcpyAsync(L->x, x_loc_d, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
   return dist_apply(d, L->A, M_SPMV, pl, L->x, nullptr, n > 0 ? y_loc_d : L->tmp, 0.0);
 }
 
 int amgh_dist_sync(amgh_dist_t* d) {
   if (!d) return AMGH_EINVAL;
+  if (d->host_only) return AMGH_OK;
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  return AMGH_OK;
+  return d->tr->wait_stream(d->stream);
 }
 int amgh_dist_barrier(amgh_dist_t* d) {
   if (!d) return AMGH_EINVAL;
-  HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipStreamSynchronize(d->stream));
+  if (!d->host_only) {
+    HIP_TRY(hipSetDevice(d->device));
+    RC_TRY(d->tr->wait_stream(d->stream));
+  }
   return d->tr->barrier();
 }
-int amgh_dist_allreduce(amgh_dist_t* d, real* v, int n, int max_op) {
+int amgh_dist_allreduce(amgh_dist_t* d, double* v, int n, int max_op) {
   if (!d || !v || n < 1 || n > 64) return AMGH_EINVAL;
-  HIP_TRY(hipSetDevice(d->device));
+  if (!d->host_only) HIP_TRY(hipSetDevice(d->device));
   return d->tr->allreduce(v, n, max_op != 0);
 }
 // out: {halo exchanges, bytes this rank sent} since the last reset
@@ -949,7 +1065,7 @@ int64_t amgh_dist_device_bytes(const amgh_dist_t* d) {
   int64_t b = 0;
   for (const DistLevel* L : d->levels) {
     b += L->A.op.bytes + L->S.op.bytes + L->P.op.bytes + L->R.op.bytes;
-    b += 8 * (3 * (L->cuts[d->tr->rank + 1] - L->cuts[d->tr->rank]));
+    b += (int64_t)sizeof(real) * (3 * (L->cuts[d->tr->rank + 1] - L->cuts[d->tr->rank]));
   }
   return b;
 }

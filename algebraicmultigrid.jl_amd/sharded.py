@@ -1,8 +1,9 @@
 """Row-sharded hierarchy on N GPUs — thin ctypes layer over libamghip's `amgh_dist_*` C ABI.
 
 BASELINE.json config C4: fine levels partitioned by contiguous 1-D row ranges, halo entries of every
-operator's input vector exchanged by neighbour send/recv (RCCL over xGMI, one process per GPU; or the
-LOCAL transport: N ranks as threads of one process), coarse levels collapsed onto rank 0.  Nothing is
+operator's input vector exchanged by neighbour send/recv (RCCL over xGMI, one process per GPU; the IPC
+transport: one process per rank, peer-mapped send buffers and stream-written flags in shared memory; or
+the LOCAL transport: N ranks as threads of one process), coarse levels collapsed onto rank 0.  Nothing is
 computed here: every rank slices ITS rows out of the level matrices and hands them to the library, which
 builds the halo plans, runs the cycle and talks to RCCL itself.  No torch, no CPU fallback.
 
@@ -16,7 +17,7 @@ import threading
 
 import numpy as np
 
-from ._libs import AMGError, amgh_smoother_t, hip_check
+from ._libs import AMGError, amgh_smoother_t, hip_check, hip_lib
 from .device import DeviceBuffer, DeviceHierarchy, require_gpu
 from .hierarchy import HermitianSymmetry, MultiLevel
 
@@ -135,15 +136,23 @@ class ShardedHierarchy:
     levels : list from `level_arrays` / `load_levels` (the sharded levels; this rank reads its rows only)
     sizes  : rows of level lc (the first collapsed level)
     tail   : MultiLevel of the collapsed levels on rank 0, None elsewhere
-    transport : ("rccl", id_bytes) or ("local", LocalGroup)
+    transport : ("rccl", id_bytes), ("ipc", "/fresh_shm_name") or ("local", LocalGroup)
+    device < 0 (IPC transport only): plans only — the collective setup in host memory, no GPU anywhere; the solve
+    entry points are unavailable, `plan_info` is what such a handle is for.
     """
 
     def __init__(self, levels, n_tail, tail, rank, nranks, device, transport):
-        self.lib = require_gpu()
         self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
+        self.plans_only = self.device < 0
+        self.lib = hip_lib() if self.plans_only else require_gpu()
         h = C.c_void_p()
         kind, arg = transport
-        if kind == "rccl":
+        if self.plans_only and kind != "ipc":
+            raise AMGError("device < 0 (plans only) needs the IPC transport")
+        if kind == "ipc":
+            hip_check(self.lib.amgh_dist_create_ipc(C.byref(h), self.device, self.rank, self.nranks,
+                                                    str(arg).encode()), "dist_create_ipc")
+        elif kind == "rccl":
             idb = (C.c_char * ID_BYTES).from_buffer_copy(arg)
             hip_check(self.lib.amgh_dist_create_rccl(C.byref(h), self.device, self.rank, self.nranks, idb), "dist_create_rccl")
         elif kind == "local":
@@ -173,7 +182,7 @@ class ShardedHierarchy:
                 ptr(S[0]), ptr(S[1]), ptr(S[2]), ptr(P[0]), ptr(P[1]), ptr(P[2]), ptr(R[0]), ptr(R[1]), ptr(R[2]),
                 C.byref(pre), C.byref(post)), "dist_push_level")
         self.tail = None
-        if tail is not None:
+        if tail is not None and not self.plans_only:
             self.tail = DeviceHierarchy(tail, self.device)
             hip_check(self.lib.amgh_dist_set_tail(self.h, self.tail.h), "dist_set_tail")
         hip_check(self.lib.amgh_dist_finalize(self.h), "dist_finalize")
@@ -181,8 +190,9 @@ class ShardedHierarchy:
         hip_check(self.lib.amgh_dist_local_range(self.h, 0, C.byref(r0), C.byref(r1)), "dist_local_range")
         self.r0, self.r1 = r0.value, r1.value
         self.nloc = self.r1 - self.r0
-        self._b = DeviceBuffer(max(self.nloc, 1), self.device)
-        self._x = DeviceBuffer(max(self.nloc, 1), self.device)
+        if not self.plans_only:
+            self._b = DeviceBuffer(max(self.nloc, 1), self.device)
+            self._x = DeviceBuffer(max(self.nloc, 1), self.device)
 
     @classmethod
     def from_multilevel(cls, ml, rank, nranks, device, transport, shard_min_rows=200_000):
@@ -287,15 +297,16 @@ class ShardedHierarchy:
         hip_check(self.lib.amgh_dist_stats(self.h, out.ctypes.data, int(reset)), "dist_stats")
         return {"halo_exchanges": int(out[0]), "halo_bytes_sent": int(out[1])}
 
-    def plan_info(self, level):
+    def plan_info(self, level, which=0):
+        """Halo plan of x (which = 0; level = lc is the first collapsed level) or of the residual (which = 1)."""
         cnt = np.zeros(5, dtype=np.int64)
-        hip_check(self.lib.amgh_dist_plan_info(self.h, level, cnt.ctypes.data, None, None, None, None), "plan_info")
+        hip_check(self.lib.amgh_dist_plan_info2(self.h, level, which, cnt.ctypes.data, None, None, None, None), "plan_info")
         halo = np.zeros(max(int(cnt[1]), 1), dtype=np.int64)
         send = np.zeros(max(int(cnt[2]), 1), dtype=np.int32)
         sc = np.zeros(self.nranks, dtype=np.int64)
         rc = np.zeros(self.nranks, dtype=np.int64)
-        hip_check(self.lib.amgh_dist_plan_info(self.h, level, cnt.ctypes.data, halo.ctypes.data, send.ctypes.data,
-                                               sc.ctypes.data, rc.ctypes.data), "plan_info")
+        hip_check(self.lib.amgh_dist_plan_info2(self.h, level, which, cnt.ctypes.data, halo.ctypes.data,
+                                                send.ctypes.data, sc.ctypes.data, rc.ctypes.data), "plan_info")
         return dict(nloc=int(cnt[0]), halo=halo[:cnt[1]], send_idx=send[:cnt[2]], send_cnt=sc, recv_cnt=rc,
                     interior=(int(cnt[3]), int(cnt[4])))
 

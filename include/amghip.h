@@ -306,6 +306,19 @@ int amgh_local_group_create(amgh_local_group_t** g, int nranks);
 void amgh_local_group_destroy(amgh_local_group_t* g);
 void amgh_local_group_abort(amgh_local_group_t* g);
 int amgh_dist_create_local(amgh_dist_t** d, int device, int rank, amgh_local_group_t* g);
+/* IPC transport: one PROCESS per rank and only shared memory between them — the ranks' packed send
+ * buffers are peer-mapped with hipIpc memory handles, the hand-off of an exchange is a sequence flag the
+ * producer's stream writes and the consumer's stream waits on (hipStreamWriteValue64 / WaitValue64 on a
+ * page of a POSIX shared-memory segment), the consumer pulls its halo entries with one device-to-device
+ * copy per peer; no host thread takes part in an exchange.  Every rank passes the same fresh
+ * `shm_name` ("/name", shm_open syntax); rank 0 creates the segment; the call returns when all
+ * `nranks` (<= 64) processes have attached (collective).  Ranks may share a device (RCCL refuses that),
+ * so a single-GPU box can run the multi-process path.  Host waits are bounded (AMGH_IPC_TIMEOUT_S,
+ * default 300 s) and notice peers that died: the survivors release every flag and return AMGH_ESTATE
+ * instead of hanging.  device < 0: PLANS ONLY — the collective setup (halo needs, send / receive
+ * plans, interior ranges, collapse) in host memory with no GPU call; the solve entry points then
+ * return AMGH_EUNSUPPORTED (what the CPU multi-process test drives).                                */
+int amgh_dist_create_ipc(amgh_dist_t** d, int device, int rank, int nranks, const char* shm_name);
 void amgh_dist_destroy(amgh_dist_t* d);
 /* push!(levels, Level(A, P, R, pre, post)) for one SHARDED level: this rank passes its rows only —
  * rows [row_cuts[rank], row_cuts[rank+1]) of A (n x n), S (as in amgh_push_level; NULL for S == A)
@@ -351,6 +364,11 @@ void* amgh_dist_stream(amgh_dist_t* d);
  * per-peer send / receive counts [nranks].                                                           */
 int amgh_dist_plan_info(const amgh_dist_t* d, int level, int64_t* out_counts, int64_t* halo_globals,
                         int32_t* send_idx, int64_t* send_cnt_per_peer, int64_t* recv_cnt_per_peer);
+/* the same for which = 0: x of `level` (level = number of sharded levels: the first collapsed level),
+ * which = 1: the residual of `level` (read by R); interior rows are those of A / R                   */
+int amgh_dist_plan_info2(const amgh_dist_t* d, int level, int which, int64_t* out_counts,
+                         int64_t* halo_globals, int32_t* send_idx, int64_t* send_cnt_per_peer,
+                         int64_t* recv_cnt_per_peer);
 
 /* ------------------------------------------------------------------------- */
 /* Setup phase, data-parallel half on the GPU: what             */

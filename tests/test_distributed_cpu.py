@@ -45,3 +45,40 @@ def test_node_levels_gloo():
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT)
     out = r.stdout.decode()
     assert r.returncode == 0 and "NODE_LEVELS_OK" in out, out[-3000:]
+
+
+def _spawn_ipc_workers(nranks, extra=()):
+    name = "/amgh_t_%d_%s" % (os.getpid(), os.urandom(4).hex())
+    env = dict(os.environ, OMP_NUM_THREADS="2", AMGH_IPC_TIMEOUT_S="60")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_plan_worker.py"), str(r), str(nranks),
+                               name, *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT)
+             for r in range(nranks)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out.decode()))
+    return outs
+
+
+def test_ipc_plans_two_and_three_processes():
+    """`amgh_dist_*` itself (not a mirror of it) through the collective setup with real processes: halo needs exchanged
+    over the IPC transport's shared-memory rendezvous, plans, interior ranges, collapse, host all-reduce / barrier —
+    no GPU (device = -1 builds the plans only)."""
+    for nranks in (2, 3):
+        outs = _spawn_ipc_workers(nranks)
+        for r, (rc, out) in enumerate(outs):
+            assert rc == 0 and f"IPC_PLAN_RANK_{r}_OK" in out, (nranks, r, out[-3000:])
+
+
+def test_ipc_dead_peer_does_not_hang_the_others():
+    """A rank that dies between two collectives: the survivors return AMGH_ESTATE (pid watch) instead of waiting."""
+    outs = _spawn_ipc_workers(3, extra=("die",))
+    assert outs[2][0] == 7
+    for r in (0, 1):
+        rc, out = outs[r]
+        assert rc == 0 and f"IPC_PLAN_RANK_{r}_SAW_DEAD_PEER" in out, (r, out[-3000:])
