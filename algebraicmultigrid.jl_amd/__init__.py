@@ -24,6 +24,6 @@ from .solve import (AMGSolver, F, Identity, Preconditioner, RugeStubenAMG, RugeS
                     SmoothedAggregationAMG, SmoothedAggregationPreconBuilder, V, W, _solve, _solve_inplace,
                     aspreconditioner, cg, init, solve, solve_)
 from .device import DeviceBuffer, DeviceCSR, DeviceHierarchy  # noqa: F401
-from . import dist, sharded  # noqa: F401
+from . import sharded  # noqa: F401
 
 __all__ = [n for n in dir() if not n.startswith("__")]

@@ -1,38 +1,51 @@
 #!/usr/bin/env python3
 """bench_dist.py — N > 1 leg of bench.py: the 3-D Poisson V-cycle row-sharded over N MI355X, one process per GPU,
-through libamghip's `amgh_dist_*` C ABI (RCCL over xGMI called by the library itself: neighbour send/recv of halo
-entries, coarse levels collapsed onto rank 0).  STRONG scaling: the 256^3 problem is fixed, each rank owns 1/N of
-the rows of every sharded level.
+through libamghip's `amgh_dist_*` C ABI (neighbour exchange of halo entries before every operator, coarse levels
+collapsed onto rank 0).  STRONG scaling: the 256^3 problem is fixed, each rank owns 1/N of the rows of every sharded
+level.
 
 Launched by:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-                  --master-port P bench.py --gpus N --steps K --warmup W
+                  --master-port P bench.py --gpus N --steps K --warmup W [--transport rccl|ipc] [--smoother gs|jacobi]
 
-torch is used for ONE thing here: the rendezvous the launcher already provides (a gloo group on CPU to hand the
-128-byte RCCL id from rank 0 to the others and to find out who built the hierarchy).  It never touches the GPU; the
-timed barriers and the max-over-ranks are the library's own (stream sync + RCCL all-reduce).
+One run measures up to three configurations on the SAME hierarchy (A, P, R of every level are shared):
+  primary    --smoother (default gs: ruge_stuben defaults, BASELINE.json C4) over --transport (default rccl: RCCL
+             send/recv called by the library; falls back to ipc if RCCL cannot be initialised) -> the JSON line's value;
+  "jacobi"   the same hierarchy smoothed by Jacobi(2/3): the curve that CAN scale (lexicographic Gauss-Seidel keeps
+             256 + 256 + 256/N - 2 dependency levels per shard);
+  "ipc"      the primary smoother over the IPC transport (hipIpc peer-mapped send buffers + stream-written flags).
+Every configuration is SELF-CHECKING on rank 0 (outside the timed region): the assembled result of the last timed
+cycle against the oracle (Jacobi: exact, <= 1e-10) or against the host emulation of the frozen-halo sweeps
+(Gauss-Seidel, <= 1e-10; tests/sharded_emulation.py); a failed check fails the run.  Rank 0 also times the CPU
+restatement of the reference's cycle (`cpu_baseline`, as bench.py does).
 
-The host hierarchy is built ONCE per node (rank 0), the level matrices of the sharded levels go to /dev/shm as
-.npy files and every other rank maps them and reads only its own rows.
+torch is used for ONE thing: the rendezvous the launcher already provides (a gloo group on CPU: the 128-byte RCCL id /
+the shared-memory name, small broadcasts).  It never touches the GPU; the timed barriers and the max-over-ranks are the
+library's own.  The host hierarchy is built ONCE per node (rank 0); the level matrices of the sharded levels go to
+/dev/shm as .npy files and every other rank maps them and reads only its own rows.
 """
 import json
 import os
 import shutil
+import sys
 import tempfile
 import time
 
 import numpy as np
+
+PARITY_TOL = 1e-10
 
 
 def node_levels(rank, world, bcast, build):
     """The host hierarchy ONCE per node: rank 0 runs `build()` (-> MultiLevel), decides how many levels are sharded,
     and — for world > 1 — exports the sharded levels' matrices as .npy files; every other rank maps them and will read
     only its own rows.  `bcast(obj)` broadcasts a small Python object from rank 0.  Returns (levels, info, tail, dir):
-    `tail` (the collapsed levels as a MultiLevel) on rank 0 only."""
+    `tail` (the collapsed levels as a MultiLevel) on rank 0 only; info["ml"] is the whole hierarchy on rank 0."""
     import amg_amd as AMG
     from amg_amd import sharded as SH
     shm = None
     tail = None
     levels = None
+    ml = None
     if rank == 0:
         ml = build()
         A = ml.levels[0].A if ml.levels else ml.final_A
@@ -59,12 +72,102 @@ def node_levels(rank, world, bcast, build):
     info = bcast(info)
     if rank != 0:
         levels = SH.load_levels(info["shm"])
+    info = dict(info, ml=ml)
     return levels, info, tail, shm
+
+
+def with_smoother(ml, sm):
+    """The same hierarchy (A, P, R shared) smoothed by `sm` on every level."""
+    import amg_amd as AMG
+    lv = [AMG.Level(l.A, l.P, l.R, sm, sm) for l in ml.levels]
+    return AMG.MultiLevel(lv, ml.final_A, ml.coarse_solver, sm, sm, ml.symmetry, method=ml.method)
+
+
+class Run:
+    """One measured configuration: a sharded handle, K timed cycles, the assembled result on rank 0."""
+
+    def __init__(self, ctx, label, levels, tail, transport):
+        from amg_amd import sharded as SH
+        self.ctx, self.label = ctx, label
+        t0 = time.perf_counter()
+        self.sh = SH.ShardedHierarchy(levels, ctx["info"]["n_tail"], tail, ctx["rank"], ctx["world"], ctx["device"], transport)
+        self.shard_s = time.perf_counter() - t0
+        self.transport = transport[0]
+
+    def measure(self, b, steps, warmup):
+        sh = self.sh
+        sh.barrier()
+        sh.set_rhs(b[sh.r0:sh.r1])
+        for _ in range(warmup):
+            sh.precond_apply_d(0)
+        sh.barrier()
+        sh.stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sh.precond_apply_d(0)
+        sh.barrier()
+        elapsed = float(sh.allreduce([time.perf_counter() - t0], "max")[0])
+        st = sh.stats(reset=True)
+        z_loc = sh._down(sh._x)                         # the LAST timed cycle's result, before anything else runs
+        out = {"ms_per_step": 1e3 * elapsed / steps, "elapsed": elapsed, "transport": self.transport, "shard_s": self.shard_s,
+               "halo_exchanges_per_cycle": st["halo_exchanges"] / max(1, steps),
+               "halo_bytes_sent_per_cycle_max_rank": sh.allreduce([st["halo_bytes_sent"] / max(1, steps)], "max")[0],
+               "halo_bytes_sent_per_cycle_all_ranks": sh.allreduce([st["halo_bytes_sent"] / max(1, steps)], "sum")[0]}
+        return out, z_loc
+
+    def spmv_ms(self, reps=20):
+        """fine-level sharded SpMV (neighbour exchange + local rows) on the level's resident x, timed like the cycle"""
+        import amg_amd as AMG
+        sh = self.sh
+        if sh.lc == 0:
+            return None
+        y = AMG.DeviceBuffer(max(sh.nloc, 1), self.ctx["device"])
+        for _ in range(3):
+            sh.lib.amgh_dist_spmv_d(sh.h, 0, None, y.ptr)
+        sh.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            sh.lib.amgh_dist_spmv_d(sh.h, 0, None, y.ptr)
+        sh.barrier()
+        return 1e3 * float(sh.allreduce([time.perf_counter() - t0], "max")[0]) / reps
+
+    def close(self):
+        self.sh.barrier()
+        self.sh.close()
+
+
+def assemble_on_rank0(ctx, tag, z_loc):
+    """Every rank's rows of a result vector -> the whole vector on rank 0 (through the node's shared directory)."""
+    d = ctx["gdir"]
+    np.save(os.path.join(d, f"z_{tag}_{ctx['rank']}.npy"), z_loc)
+    ctx["barrier"]()
+    z = None
+    if ctx["rank"] == 0:
+        z = np.concatenate([np.load(os.path.join(d, f"z_{tag}_{r}.npy")) for r in range(ctx["world"])])
+    ctx["barrier"]()
+    return z
+
+
+def check_parity(ctx, ml, b, z, kind):
+    """rank 0: the assembled result of one cycle from x = 0 against the checker (never part of the timed region)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    if kind == "jacobi":
+        from oracle import oracle as O
+        want = O.OracleHierarchy(ml).precond(b)
+        what = "||z - z_oracle|| / ||z_oracle||, oracle V-cycle (Jacobi smoothers are exact across shards)"
+    else:
+        from sharded_emulation import emulate_sharded_cycles
+        want = emulate_sharded_cycles(ml, b, ctx["world"], ctx["info"]["lc"], 1)[0]
+        what = ("||z - z_emul|| / ||z_emul||, host emulation of the sharded cycle with the oracle's loops "
+                "(Gauss-Seidel exact inside a shard, halo frozen per directional sweep)")
+    err = float(np.linalg.norm(z - want) / np.linalg.norm(want))
+    return {"rel_err": err, "tolerance": PARITY_TOL, "what": what, "ok": bool(err <= PARITY_TOL)}
 
 
 def main_distributed(args):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("NCCL_DEBUG", "WARN")
+    os.environ.setdefault("AMGH_IPC_TIMEOUT_S", "120")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
@@ -85,17 +188,33 @@ def main_distributed(args):
         dist.broadcast_object_list(box, src=0)
         return box[0]
 
+    def all_ok(flag):
+        if world == 1:
+            return bool(flag)
+        box = [None] * world
+        dist.all_gather_object(box, bool(flag))
+        return all(box)
+
+    def host_barrier():
+        if world > 1:
+            dist.barrier()
+
     import __graft_entry__ as g
     if rank == 0:
         g.build(only_missing=True)
-    if world > 1:
-        dist.barrier()
+    host_barrier()
     import amg_amd as AMG
     from amg_amd import sharded as SH
-    from bench import spmv_bytes, uniform
+    from bench import cpu_baseline, spmv_bytes, uniform
 
-    if os.environ.get("AMG_DIST_ONE_GPU") == "1":   # functional check on a single-GPU box: every rank on device 0
+    one_gpu = os.environ.get("AMG_DIST_ONE_GPU") == "1"   # functional check on a single-GPU box: every rank on device 0
+    if one_gpu:
         local_rank = 0
+    transport = getattr(args, "transport", None) or os.environ.get("AMGH_DIST_TRANSPORT", "rccl")
+    smoother = getattr(args, "smoother", None) or "gs"
+    secondary = not getattr(args, "no_secondary", False)
+    if one_gpu and world > 1 and transport == "rccl":
+        transport = "ipc"                                  # RCCL refuses two ranks on one device
     N = args.size
     n = N ** 3
     # ---- host hierarchy: once per node --------------------------------------------------------------------------
@@ -103,80 +222,124 @@ def main_distributed(args):
     levels, info, tail, shm = node_levels(rank, world, bcast,
                                           lambda: AMG.ruge_stuben(AMG.poisson((N, N, N)), setup=getattr(args, "setup", "gpu")))
     t_setup = time.perf_counter() - t0
-    # ---- the sharded handle -------------------------------------------------------------------------------------
-    t0 = time.perf_counter()
-    uid = bcast(SH.rccl_unique_id() if rank == 0 else None)
-    sh = SH.ShardedHierarchy(levels, info["n_tail"], tail, rank, world, local_rank, ("rccl", uid))
-    t_shard = time.perf_counter() - t0
-    sh.barrier()
-    if rank == 0 and shm:
-        shutil.rmtree(shm, ignore_errors=True)
+    ml = info["ml"]                                        # rank 0 only
+    gdir = bcast(tempfile.mkdtemp(prefix="amgh_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) if rank == 0 else None)
+    ctx = dict(rank=rank, world=world, device=local_rank, info=info, gdir=gdir, barrier=host_barrier)
+    jac = AMG.Jacobi(2.0 / 3.0)
+    jac_tuple = SH._smoother_tuple(jac)
+
+    def variant(kind):
+        """(level arrays, collapsed levels, host hierarchy for the checker) of smoother `kind`"""
+        if kind == "gs":
+            return levels, tail, ml
+        lv = [dict(d, pre=jac_tuple, post=jac_tuple) for d in levels]
+        return lv, (with_smoother(tail, jac) if tail is not None else None), (with_smoother(ml, jac) if ml is not None else None)
+
+    def transport_spec(kind):
+        if kind == "rccl":
+            return ("rccl", bcast(SH.rccl_unique_id() if rank == 0 else None))
+        return ("ipc", bcast("/amgh_b_%d_%s" % (os.getpid(), os.urandom(4).hex()) if rank == 0 else None))
+
     b = uniform(n, 0)
-    sh.set_rhs(b[sh.r0:sh.r1])
+    notes = {}
 
-    for _ in range(args.warmup):
-        sh.precond_apply_d(0)
-    sh.barrier()
-    sh.stats(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sh.precond_apply_d(0)
-    sh.barrier()
-    elapsed = float(sh.allreduce([time.perf_counter() - t0], "max")[0])
-    st = sh.stats(reset=True)
-    ex_per_cycle = st["halo_exchanges"] / max(1, args.steps)
-    halo = sh.allreduce([st["halo_bytes_sent"] / max(1, args.steps)], "max")[0]
-    halo_sum = sh.allreduce([st["halo_bytes_sent"] / max(1, args.steps)], "sum")[0]
+    def run_config(label, kind, tkind, want_spmv=False):
+        lv, tl, ml_k = variant(kind)
+        run, err = None, None
+        try:
+            run = Run(ctx, label, lv, tl, transport_spec(tkind))
+        except AMG.AMGError as e:
+            err = str(e)
+        if not all_ok(run is not None):
+            if run is not None:
+                run.sh.close()
+            return None, (err or "another rank failed to create the handle")
+        res, z_loc = run.measure(b, args.steps, args.warmup)
+        if want_spmv:
+            res["spmv_ms"] = run.spmv_ms()
+        z = assemble_on_rank0(ctx, label, z_loc)
+        if rank == 0:
+            res["parity"] = check_parity(ctx, ml_k, b, z, kind)
+        run.close()
+        res["value"] = n * args.steps / res["elapsed"]
+        ok = bcast(res["parity"]["ok"] if rank == 0 else None)
+        return res, (None if ok else "parity check failed")
 
-    # fine-level sharded SpMV (neighbour exchange + local rows), timed the same way
-    spmv_ms = None
-    if sh.lc > 0:
-        y = AMG.DeviceBuffer(max(sh.nloc, 1), local_rank)
-        lib = sh.lib
-        for _ in range(3):      # x = the level's resident vector (the last cycle's result): exchange + local rows, no copy
-            lib.amgh_dist_spmv_d(sh.h, 0, None, y.ptr)
-        sh.barrier()
-        reps = 20
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            lib.amgh_dist_spmv_d(sh.h, 0, None, y.ptr)
-        sh.barrier()
-        spmv_ms = 1e3 * float(sh.allreduce([time.perf_counter() - t0], "max")[0]) / reps
-
-    # parity of the timed output (outside the timed region): global residual reduction of ONE cycle must match the
-    # single-GPU / oracle figure to the digits the hybrid smoother allows; here only sanity (finite, contracting)
-    z_norm2 = sh.allreduce([float(np.sum(sh._down(sh._x) ** 2))], "sum")[0]
+    # ---- primary configuration ----------------------------------------------------------------------------------
+    primary, err = run_config("primary", smoother, transport, want_spmv=True)
+    if primary is None and transport == "rccl":
+        notes["rccl_error"] = err
+        transport = "ipc"
+        primary, err = run_config("primary", smoother, transport, want_spmv=True)
+    if primary is None:
+        raise SystemExit(f"bench_dist.py: no transport could be initialised: {err}")
+    if err:
+        if rank == 0:
+            print(json.dumps({"error": err, "parity": primary.get("parity")}), file=sys.stderr, flush=True)
+        raise SystemExit(f"bench_dist.py: {err}: {primary.get('parity')}")
+    # ---- secondary configurations (same hierarchy; a failure here never costs the primary line) ------------------
+    extra = {}
+    if secondary and world > 1:
+        todo = []
+        if smoother != "jacobi":
+            todo.append(("jacobi", "jacobi", transport))
+        if transport != "ipc":
+            todo.append(("ipc", smoother, "ipc"))
+        for label, kind, tkind in todo:
+            try:
+                res, e2 = run_config(label, kind, tkind)
+                extra[label] = {"error": e2} if res is None else dict(res, **({"error": e2} if e2 else {}))
+            except Exception as ex:  # noqa: BLE001
+                extra[label] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+                break                                   # the ranks may no longer be in step: stop measuring
+    cpu = None
+    if rank == 0 and not getattr(args, "no_cpu_baseline", False):
+        cpu, _ = cpu_baseline(ml, b, getattr(args, "cpu_budget", 20.0))
+    host_barrier()
 
     if rank == 0:
         alg = spmv_bytes(info["nnz"], n, n)
+        spmv_ms = primary.get("spmv_ms")
+        smooth_txt = ("ruge_stuben defaults (symmetric Gauss-Seidel pre+post: exact inside a shard, halo frozen per "
+                      "directional sweep)" if smoother == "gs" else "Jacobi(2/3) pre+post (exact across shards)")
+        tr_txt = {"rccl": "RCCL send/recv called by libamghip", "ipc": "hipIpc peer-mapped send buffers + stream-written "
+                  "flags in shared memory (libamghip's IPC transport)"}[primary["transport"]]
+        strip = lambda r: {k: v for k, v in r.items() if k not in ("elapsed",)}  # noqa: E731
         out = {
             "metric": f"V-cycle unknowns/sec + fine-level SpMV GB/s (% HBM peak), 3-D Poisson {N}^3",
-            "value": n * args.steps / elapsed, "unit": "unknowns/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "value": primary["value"], "unit": "unknowns/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": primary["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "poisson((%d,%d,%d)) 7-point, ruge_stuben defaults, one V-cycle per step (ldiv!), "
-                                   "rows of every level >= 200000 rows 1-D row-sharded, neighbour send/recv of halo "
-                                   "entries before every operator (RCCL called by libamghip, interior rows overlapped), "
-                                   "coarser levels collapsed to rank 0; Gauss-Seidel is exact inside a shard, halo frozen "
-                                   "per directional sweep" % (N, N, N),
+            "config": {"workload": "poisson((%d,%d,%d)) 7-point, %s, one V-cycle per step (ldiv!), levels of >= 200000 rows "
+                                   "1-D row-sharded, neighbour exchange of halo entries before every operator (%s, interior "
+                                   "rows overlapped), coarser levels collapsed to rank 0" % (N, N, N, smooth_txt, tr_txt),
                        "unknowns": n, "nnz": info["nnz"], "levels": info["nlev"], "sharded_levels": info["lc"],
-                       "halo_exchanges_per_cycle": ex_per_cycle, "halo_bytes_sent_per_cycle_max_rank": halo,
-                       "halo_bytes_sent_per_cycle_all_ranks": halo_sum,
-                       "parallelism": f"row-shard x{world} (RCCL send/recv halos, libamghip amgh_dist_*)"},
+                       "smoother": smoother, "transport": primary["transport"],
+                       "halo_exchanges_per_cycle": primary["halo_exchanges_per_cycle"],
+                       "halo_bytes_sent_per_cycle_max_rank": primary["halo_bytes_sent_per_cycle_max_rank"],
+                       "halo_bytes_sent_per_cycle_all_ranks": primary["halo_bytes_sent_per_cycle_all_ranks"],
+                       "all_ranks_on_one_gpu": bool(one_gpu and world > 1),
+                       "parallelism": f"row-shard x{world} ({primary['transport']} halos, libamghip amgh_dist_*)"},
             "roofline": None if spmv_ms is None else {
                 "bound": "hbm", "kernel": "csr_stream_kernel<SPMV> on n/N local rows + neighbour halo exchange",
                 "achieved": alg / (spmv_ms * 1e-3) / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                 "frac": alg / (spmv_ms * 1e-3) / 1e9 / (8000.0 * world), "traffic": None,
+                "traffic_source": "not measured in the N > 1 leg (bench.py at N = 1 measures it with rocprofv3 PMC passes)",
                 "avg_launch_ms": spmv_ms},
-            "check": {"z_norm": float(np.sqrt(z_norm2)), "finite": bool(np.isfinite(z_norm2))},
-            "setup_s": t_setup, "shard_s": t_shard,
+            "parity": primary["parity"],
+            "cpu_baseline": cpu,
+            "setup_s": t_setup, "shard_s": primary["shard_s"],
+            **({"secondary": {k: strip(v) for k, v in extra.items()}} if extra else {}),
+            **notes,
         }
-    sh.barrier()
-    sh.close()
+    host_barrier()
+    if rank == 0:
+        for d in (shm, gdir):
+            if d:
+                shutil.rmtree(d, ignore_errors=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        import sys
         sys.stderr.flush()
         print(json.dumps(out), flush=True)   # the ONE JSON line, after everything RCCL may print

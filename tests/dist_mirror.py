@@ -1,4 +1,6 @@
-"""Row-sharded multi-GPU V-cycle (BASELINE.json config C4).
+"""TEST-SIDE mirror of the row-sharded V-cycle (BASELINE.json config C4) — an independent emulation in
+Python of what libamghip's `amgh_dist_*` does natively; the product is algebraicmultigrid.jl_amd/sharded.py over the
+C ABI, this file only serves the tests (gloo world_size-2 run, host emulation of the frozen-halo sweeps).
 
 The reference is single-process; this is the one place the new build adds a real exchange step:
 levels with many rows are partitioned by contiguous 1-D row ranges across the ranks (for the
@@ -21,8 +23,7 @@ exchange of the halo entries of its input vector, and the coarse levels are coll
 """
 import numpy as np
 
-from ._libs import AMGError
-from .hierarchy import HermitianSymmetry, MultiLevel
+from amg_amd import AMGError, HermitianSymmetry, MultiLevel
 
 CYCLE_V, CYCLE_W, CYCLE_F = 0, 1, 2
 
@@ -293,11 +294,7 @@ class TorchComm:
         self.world_size = dist.get_world_size()
 
     def all_gather(self, recv, send):
-        try:
-            self.dist.all_gather_into_tensor(recv, send)
-        except (RuntimeError, AttributeError, NotImplementedError):
-            chunks = list(recv.view(self.world_size, -1).unbind(0))
-            self.dist.all_gather(chunks, send)
+        self.dist.all_gather_into_tensor(recv, send)
 
     def all_reduce_sum(self, value):
         import torch
@@ -331,8 +328,8 @@ class HipOps:
 
         import torch
 
-        from ._libs import hip_check
-        from .device import require_gpu
+        from amg_amd._libs import hip_check
+        from amg_amd.device import require_gpu
         self.C, self.torch, self.check = C, torch, hip_check
         self.lib = require_gpu()
         self.device = int(device)
@@ -368,7 +365,7 @@ class HipOps:
         dst[:n].copy_(src[:n])
 
     def make_csr(self, nrows, ncols, rowptr, col, val):
-        from .device import DeviceCSR
+        from amg_amd.device import DeviceCSR
         return DeviceCSR(nrows, ncols, rowptr, col, val, self.device)
 
     def prepare(self, op, jacobi, gs):
@@ -376,7 +373,7 @@ class HipOps:
             self.check(self.lib.amgh_csr_prepare(op.h, int(jacobi), int(gs)), "csr_prepare")
 
     def make_hierarchy(self, ml):
-        from .device import DeviceHierarchy
+        from amg_amd.device import DeviceHierarchy
         dev = DeviceHierarchy(ml, self.device)
         self.check(self.lib.amgh_set_stream(dev.h, self._stream()), "set_stream")
         return dev

@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import amg_amd as AMG  # noqa: E402
+import dist_mirror as D  # noqa: E402
 from conftest import uniform  # noqa: E402
 from dist_backends import CpuOps  # noqa: E402
 from oracle import oracle as O  # noqa: E402
@@ -24,7 +25,7 @@ def gather_x(comm, x_local):
 
 def main():
     dist.init_process_group("gloo")
-    comm = AMG.dist.TorchComm()
+    comm = D.TorchComm()
     rank = comm.rank
     ops = CpuOps()
     A = AMG.poisson((14, 12, 10))
@@ -34,7 +35,7 @@ def main():
     jac = AMG.Jacobi(2.0 / 3.0, iter=2)
     ml = AMG.ruge_stuben(A, presmoother=jac, postsmoother=jac)
     oh = O.OracleHierarchy(ml)
-    dml = AMG.dist.DistMultiLevel(ml, comm, ops, shard_min_rows=100)
+    dml = D.DistMultiLevel(ml, comm, ops, shard_min_rows=100)
     assert dml.lc >= 2, dml.lc            # at least two sharded levels + a collapsed tail
     r0, r1 = dml.local_range(0)
     for cyc in (0, 1, 2):
@@ -54,7 +55,7 @@ def main():
     # 2. default smoother (symmetric Gauss-Seidel): processor-block hybrid across shards — not the
     #    same iterates, the same solution: both converge to A^-1 b within the solver tolerance
     ml = AMG.ruge_stuben(A)
-    dml = AMG.dist.DistMultiLevel(ml, comm, ops, shard_min_rows=100)
+    dml = D.DistMultiLevel(ml, comm, ops, shard_min_rows=100)
     x_loc, hist = dml.solve(b[r0:r1], reltol=1e-10, maxiter=60)
     x = gather_x(comm, x_loc)
     xo, ho, _ = O.OracleHierarchy(ml).solve(b, reltol=1e-10, maxiter=60)
@@ -62,7 +63,7 @@ def main():
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-8
     assert abs(len(hist) - len(ho)) <= 2, (len(hist), len(ho))
     # 3. everything collapsed onto rank 0 (problem smaller than the shard threshold)
-    dml = AMG.dist.DistMultiLevel(ml, comm, ops, shard_min_rows=10 ** 9)
+    dml = D.DistMultiLevel(ml, comm, ops, shard_min_rows=10 ** 9)
     assert dml.lc == 0
     x_loc, hist = dml.solve(b[:n] if rank == 0 else b[:0], reltol=1e-8)
     if rank == 0:

@@ -7,19 +7,20 @@ import sys
 import numpy as np
 
 import amg_amd as AMG
+import dist_mirror as D  # noqa: E402
 from conftest import ROOT
 
 
 def test_row_ranges_and_vector_plan():
-    assert AMG.dist.row_ranges(10, 3) == [(0, 3), (3, 6), (6, 10)]
+    assert D.row_ranges(10, 3) == [(0, 3), (3, 6), (6, 10)]
     A = AMG.poisson((4, 4, 6))
     rp, ci, va = A.csr_arrays()
-    ranges = AMG.dist.row_ranges(A.m, 2)
-    needs = AMG.dist._needs(rp, ci, ranges, ranges)
+    ranges = D.row_ranges(A.m, 2)
+    needs = D._needs(rp, ci, ranges, ranges)
     # z-slab partition of a 7-point stencil: each rank needs exactly the neighbour's boundary plane
     assert np.array_equal(needs[0], np.arange(48, 64)) and np.array_equal(needs[1], np.arange(32, 48))
-    p0 = AMG.dist.VectorPlan(ranges, 0, needs)
-    p1 = AMG.dist.VectorPlan(ranges, 1, needs)
+    p0 = D.VectorPlan(ranges, 0, needs)
+    p1 = D.VectorPlan(ranges, 1, needs)
     assert p0.max_send == p1.max_send == 16 and p0.total_send == 32
     assert np.array_equal(p0.send_idx, np.arange(32, 48)) and np.array_equal(p1.send_idx, np.arange(0, 16))
     assert np.array_equal(p0.unpack_idx, 16 + np.arange(16)) and np.array_equal(p1.unpack_idx, np.arange(16))

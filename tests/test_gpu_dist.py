@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import amg_amd as AMG
+import dist_mirror as D  # noqa: E402
 from conftest import uniform
 from dist_backends import run_virtual_ranks
 from oracle import oracle as O
@@ -14,8 +15,8 @@ pytestmark = pytest.mark.gpu
 
 def _solve_sharded(ml, b, nranks, shard_min_rows, cyc=0, **kw):
     def work(comm):
-        ops = AMG.dist.HipOps(0)
-        dml = AMG.dist.DistMultiLevel(ml, comm, ops, shard_min_rows=shard_min_rows)
+        ops = D.HipOps(0)
+        dml = D.DistMultiLevel(ml, comm, ops, shard_min_rows=shard_min_rows)
         r0, r1 = dml.local_range(0)
         x, hist = dml.solve(b[r0:r1], cyc=cyc, **kw)
         return x, hist, dml.lc
@@ -66,8 +67,8 @@ def test_single_rank_sharded_path_equals_plain_solve():
     A = AMG.poisson((20, 20, 20))
     b = uniform(A.m, 7)
     ml = AMG.ruge_stuben(A)
-    ops = AMG.dist.HipOps(0)
-    dml = AMG.dist.DistMultiLevel(ml, AMG.dist.SingleComm(), ops, shard_min_rows=500)
+    ops = D.HipOps(0)
+    dml = D.DistMultiLevel(ml, D.SingleComm(), ops, shard_min_rows=500)
     x, hist = dml.solve(b, reltol=1e-8)
     xo, ho = AMG._solve(ml, b, reltol=1e-8, log=True)
     assert len(hist) == len(ho) and np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)

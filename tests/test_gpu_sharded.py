@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import amg_amd as AMG
+import dist_mirror as D  # noqa: E402
 from amg_amd import sharded as SH
 from conftest import uniform
 from dist_backends import OracleOps, emulate_sharded_cycles, run_virtual_ranks
@@ -37,7 +38,7 @@ def sharded_solve(ml, b, nranks, shard_min_rows, **kw):
 def emulated_cycles(ml, b, nranks, shard_min_rows, cycles, cyc=0):
     """Host emulation of the sharded cycle: iterates after 1..cycles cycles from x0 = 0."""
     def work(comm):
-        dml = AMG.dist.DistMultiLevel(ml, comm, OracleOps(), shard_min_rows=shard_min_rows)
+        dml = D.DistMultiLevel(ml, comm, OracleOps(), shard_min_rows=shard_min_rows)
         r0, r1 = dml.local_range(0)
         dml.set_rhs(b[r0:r1])
         dml.ops.zero(dml.x[0], r1 - r0)
