@@ -17,6 +17,8 @@
 
 namespace {
 
+constexpr int64_t kGraphAutoRows = 65536;   // hierarchies whose widest level is at most this replay their cycle from a hipGraph
+
 struct Level {
   int64_t n = 0, nc = 0;
   amgh_csr A, S, P, R;
@@ -77,6 +79,7 @@ struct amgh_handle {
   // aborts on the replay (malformed AQL packet).  So graphs are opt-in (amgh_set_use_graph or
   // AMGH_USE_GRAPH=1).
   bool use_graph = false;
+  bool graph_auto = true;   // nobody (environment, amgh_set_use_graph) has decided: amgh_finalize does, by the hierarchy's size
   // hipGraph cache of whole cycles, keyed by the (x, b, cycle) they were captured on
   // exec == nullptr: this key has been run eagerly once (first-use allocations done), capture on the next call
   struct CycleGraph { const real* x; const real* b; int cyc; bool xzero; hipGraphExec_t exec; };
@@ -526,7 +529,7 @@ int amgh_create(amgh_t** hp, int device, int nrhs) {
   if (e != hipSuccess) { delete h; return -(1000 + (int)e); }
   hipEventCreate(&h->t0);
   hipEventCreate(&h->t1);
-  if (const char* e = getenv("AMGH_USE_GRAPH")) h->use_graph = (e[0] == '1');
+  if (const char* e = getenv("AMGH_USE_GRAPH")) { h->use_graph = (e[0] == '1'); h->graph_auto = false; }
   *hp = h;
   return AMGH_OK;
 }
@@ -590,9 +593,12 @@ __global__ void invert_perm_kernel(const int32_t* perm, int64_t n, int32_t* inv)
 int coarse_side_to_level_order(Level* prev, const GsSchedule* g) {
   const int64_t nc = prev->nc;
   if ((int64_t)g->n != nc || !prev->Rp.rowptr || !prev->Pp.rowptr) return AMGH_OK;
-  int32_t *inv = nullptr, *len = nullptr, *nrp = nullptr, *ncol = nullptr;
+  // Transactional: the renumbered Rp rows AND Pp columns are built beside the old ones and swapped in together only
+  // when everything has succeeded — a failure leaves `prev` exactly as it was (natural-order coarse side).
+  int32_t *inv = nullptr, *len = nullptr, *nrp = nullptr, *ncol = nullptr, *npcol = nullptr;
   real* nval = nullptr;
   int rc = dev_alloc(&inv, nc);
+  if (rc == AMGH_OK) rc = dev_alloc(&npcol, prev->Pp.nnz);
   if (rc == AMGH_OK) rc = dev_alloc(&len, nc + 1);
   if (rc == AMGH_OK) rc = dev_alloc(&nrp, nc + 1);
   if (rc == AMGH_OK) rc = dev_alloc(&ncol, prev->Rp.nnz);
@@ -609,17 +615,20 @@ int coarse_side_to_level_order(Level* prev, const GsSchedule* g) {
     hipLaunchKernelGGL(perm_rows_kernel, dim3((unsigned)std::min<int64_t>((nc * kWave + 255) / 256, 1 << 20)), dim3(256), 0, nullptr,
                        (const int32_t*)prev->Rp.rowptr, (const int32_t*)prev->Rp.col, (const real*)prev->Rp.val,
                        (const int32_t*)g->perm, (const int32_t*)nrp, nc, ncol, nval);
-    hipLaunchKernelGGL(renumber_cols_kernel, dim3((unsigned)grid_for(prev->Pp.nnz)), dim3(256), 0, nullptr, prev->Pp.col,
+    if (prev->Pp.nnz > 0 &&
+        hipMemcpyAsync(npcol, prev->Pp.col, sizeof(int32_t) * (size_t)prev->Pp.nnz, hipMemcpyDeviceToDevice, nullptr) != hipSuccess)
+      rc = -1001;
+    hipLaunchKernelGGL(renumber_cols_kernel, dim3((unsigned)grid_for(prev->Pp.nnz)), dim3(256), 0, nullptr, npcol,
                        prev->Pp.nnz, (const int32_t*)inv);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = -1001;
   }
   if (rc == AMGH_OK) {
-    hipFree(prev->Rp.rowptr); hipFree(prev->Rp.col); hipFree(prev->Rp.val);
-    prev->Rp.rowptr = nrp; prev->Rp.col = ncol; prev->Rp.val = nval;
-    nrp = ncol = nullptr; nval = nullptr;
+    hipFree(prev->Rp.rowptr); hipFree(prev->Rp.col); hipFree(prev->Rp.val); hipFree(prev->Pp.col);
+    prev->Rp.rowptr = nrp; prev->Rp.col = ncol; prev->Rp.val = nval; prev->Pp.col = npcol;
+    nrp = ncol = npcol = nullptr; nval = nullptr;
     prev->coarse_lo = true;
   }
-  hipFree(inv); hipFree(len); hipFree(nrp); hipFree(ncol); hipFree(nval);
+  hipFree(inv); hipFree(len); hipFree(nrp); hipFree(ncol); hipFree(nval); hipFree(npcol);
   return rc == AMGH_EUNSUPPORTED ? AMGH_OK : rc;   // (scan size limits: the natural-order coarse side stays)
 }
 }  // namespace
@@ -684,7 +693,7 @@ static int level_prepare(int device, int64_t n, const int32_t* A_rowptr, const i
       });
       rc = dev_upload(&L->lo_val, lv.data(), (int64_t)lv.size());
       same_pattern = rc == AMGH_OK;
-      if (same_pattern) M->bytes += 8 * (int64_t)lv.size();
+      if (same_pattern) M->bytes += kRealB * (int64_t)lv.size();
     }
     // what the second half needs to know: the level-ordered P / R are wanted (g->h_perm is kept until then)
     L->lo_want = rc == AMGH_OK && both && same_pattern && g->nblk == 0 && g_gs_keep_lo && (int64_t)g->h_perm.size() == n;
@@ -792,13 +801,13 @@ int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const in
     L->lo_ok = rc == AMGH_OK;
   }
   if (g) std::vector<int32_t>().swap(g->h_perm);
-  if (rc == AMGH_OK && L->lo_ok && gs_lean()) {
-    // memory-lean: between the smoothers the cycle only touches the level-ordered copies (the schedule's own A, Pp,
+  if (rc == AMGH_OK && L->lo_ok && gs_trim()) {
+    // trimmed footprint (the default): between the smoothers the cycle only touches the level-ordered copies (the schedule's own A, Pp,
     // Rp); the natural-order P, R and — below the fine level, whose A the outer residual of _solve! needs — A go
     auto drop = [](amgh_csr* op) {
       hipFree(op->rowptr); hipFree(op->col); hipFree(op->val);
       op->rowptr = op->col = nullptr; op->val = nullptr;
-      op->bytes -= (op->nrows + 1) * 4 + op->nnz * 12;
+      op->bytes -= (op->nrows + 1) * 4 + op->nnz * kEntB;
     };
     drop(&L->P); drop(&L->R);
     if (!h->levels.empty()) { drop(&L->A); if (L->has_S) drop(&L->S); }
@@ -809,18 +818,19 @@ int amgh_push_level_end(amgh_t* h, int64_t nc, const int32_t* P_rowptr, const in
     level_discard(L);
     return rc;
   }
-  // this level runs the level-ordered cycle: the level above hands its coarse vectors over in that order
-  if (L->lo_ok && g && g->nblk == 0 && g_gs_keep_lo && g_gs_coarse_lo && !h->levels.empty() && h->levels.back()->lo_ok && h->nrhs >= 1) {
-    rc = coarse_side_to_level_order(h->levels.back(), g);
-    if (rc != AMGH_OK) { level_discard(L); return rc; }
-  }
-  {
+  {  // whatever this level's own construction left pending is reported BEFORE the previous level is touched
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
       if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] pending HIP error at the end of amgh_push_level_end: %s\n", hipGetErrorString(e));
       level_discard(L);
       return -(1000 + (int)e);
     }
+  }
+  // this level runs the level-ordered cycle: the level above hands its coarse vectors over in that order (the last step:
+  // it either renumbers the previous level's coarse side completely or leaves it untouched, and nothing after it can fail)
+  if (L->lo_ok && g && g->nblk == 0 && g_gs_keep_lo && g_gs_coarse_lo && !h->levels.empty() && h->levels.back()->lo_ok && h->nrhs >= 1) {
+    rc = coarse_side_to_level_order(h->levels.back(), g);
+    if (rc != AMGH_OK) { level_discard(L); return rc; }
   }
   h->levels.push_back(L);
   return AMGH_OK;
@@ -897,10 +907,10 @@ int amgh_finalize(amgh_t* h) {
     RC_TRY(dev_alloc(&L->res, L->n * h->nrhs));
     RC_TRY(dev_alloc(&L->cx, L->nc * h->nrhs));
     RC_TRY(dev_alloc(&L->cb, L->nc * h->nrhs));
-    ws += 8 * (L->n + 2 * L->nc) * h->nrhs;
+    ws += kRealB * (L->n + 2 * L->nc) * h->nrhs;
     if (L->pre.kind == AMGH_SMOOTH_JACOBI || L->post.kind == AMGH_SMOOTH_JACOBI) {
       RC_TRY(dev_alloc(&L->tmp, L->n * h->nrhs));
-      ws += 8 * L->n * h->nrhs;
+      ws += kRealB * L->n * h->nrhs;
       RC_TRY(csr_ensure_diag(L->smat(), h->stream));
     }
   }
@@ -909,13 +919,22 @@ int amgh_finalize(amgh_t* h) {
   for (size_t l = 0; l + 1 < h->levels.size(); ++l)
     if (h->levels[l]->coarse_lo) RC_TRY(gs_ensure_cols(h->levels[l + 1]->smat(), h->nrhs, h->stream));
   const int64_t n = fine_n(h);
-  if (h->levels.empty()) { RC_TRY(dev_alloc(&h->res_final, n * h->nrhs)); ws += 8 * n * h->nrhs; }
+  if (h->levels.empty()) { RC_TRY(dev_alloc(&h->res_final, n * h->nrhs)); ws += kRealB * n * h->nrhs; }
   RC_TRY(dev_alloc(&h->partial, kRedBlocks));
   RC_TRY(dev_alloc(&h->scal, 8));
   RC_TRY(dev_alloc(&h->x0, n * h->nrhs));
   RC_TRY(dev_alloc(&h->b0, n * h->nrhs));
-  ws += 16 * n * h->nrhs;
+  ws += 2 * kRealB * n * h->nrhs;
   h->ws_bytes = ws;
+  // Small hierarchies are pure launch latency and HOST-bound (a cycle of ~100 kernels of a few microseconds each: the
+  // host needs ~3 us per eager launch, a graph replays them at the device's ~1.5 us boundary): graph replay by default
+  // when every level is small.  A big hierarchy keeps eager launches — its host runs far ahead of the device and the
+  // replay buys nothing.  AMGH_USE_GRAPH / amgh_set_use_graph decide otherwise.
+  if (h->graph_auto && !h->levels.empty()) {
+    int64_t widest = 0;
+    for (Level* L : h->levels) widest = std::max(widest, L->n);
+    h->use_graph = widest <= kGraphAutoRows;
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->finalized = true;
   return AMGH_OK;
@@ -928,7 +947,7 @@ int64_t amgh_level_size(const amgh_t* h, int l) {
 }
 int64_t amgh_device_bytes(const amgh_t* h) {
   if (!h) return 0;
-  int64_t b = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * 8 : 0) + h->finalA.bytes;
+  int64_t b = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * kRealB : 0) + h->finalA.bytes;
   for (Level* L : h->levels) b += L->A.bytes + L->S.bytes + L->P.bytes + L->R.bytes + L->Pp.bytes + L->Rp.bytes;
   return b;
 }
@@ -939,7 +958,7 @@ int amgh_device_bytes_detail(const amgh_t* h, int64_t* out8) {
   for (int q = 0; q < 8; ++q) out8[q] = 0;
   for (Level* L : h->levels) {
     for (const amgh_csr* op : {&L->A, &L->S, &L->P, &L->R})
-      if (op->rowptr) out8[0] += (op->nrows + 1) * 4 + op->nnz * 12;
+      if (op->rowptr) out8[0] += (op->nrows + 1) * 4 + op->nnz * kEntB;
     out8[1] += L->Pp.bytes + L->Rp.bytes;
     const GsSchedule* g = L->smat()->gs;
     if (!g) continue;
@@ -947,14 +966,14 @@ int amgh_device_bytes_detail(const amgh_t* h, int64_t* out8) {
     out8[2] += g->slot_bytes;
     int64_t known = g->csr_bytes + g->slot_bytes;
     for (const GsSchedule* c : {g->mf, g->mb})
-      if (c) { out8[3] += c->csr_bytes; out8[4] += c->slot_bytes; known += c->bytes; }
-    const int64_t tri = (g->tri_nnz + g->tri_nnz_b) * 12 + ((g->tri_nnz ? 1 : 0) + (g->tri_nnz_b ? 1 : 0)) * (g->n + 1) * 4;
+      if (c) { out8[3] += c->csr_bytes; out8[4] += c->bytes - c->csr_bytes; known += c->bytes; }   // [4]: slots, SELL-like copy, diagonals
+    const int64_t tri = (g->tri_nnz + g->tri_nnz_b) * kEntB + ((g->tri_nnz ? 1 : 0) + (g->tri_nnz_b ? 1 : 0)) * (g->n + 1) * 4;
     out8[5] += tri;
     known += tri;
     out8[6] += std::max<int64_t>(0, g->bytes - known);
   }
   out8[0] += h->finalA.bytes;
-  out8[7] = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * 8 : 0);
+  out8[7] = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * kRealB : 0);
   return AMGH_OK;
 }
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
@@ -1014,7 +1033,7 @@ static int ensure_pcg_bufs(amgh_t* h) {
   RC_TRY(dev_alloc(&h->pc_r, n));
   RC_TRY(dev_alloc(&h->pc_c, n));
   RC_TRY(dev_alloc(&h->pc_u, n));
-  h->ws_bytes += 24 * n;
+  h->ws_bytes += 3 * kRealB * n;
   return AMGH_OK;
 }
 
@@ -1111,37 +1130,118 @@ static amgh_csr* level_op(amgh_t* h, int level, int which) {
   return (op && op->rowptr) ? op : nullptr;  // (memory-lean hierarchies have released some natural-order operators)
 }
 
+// The level's operator in LEVEL ORDER (what the cycle itself multiplies with): rows / columns / values and the two
+// permutations (position -> natural index; nullptr = natural order on that side) of its row side and its column side.
+struct LoOp {
+  const int32_t *rowptr = nullptr, *col = nullptr;
+  const real* val = nullptr;
+  int64_t nrows = 0, ncols = 0;
+  const int32_t *row_perm = nullptr, *col_perm = nullptr;
+};
+static bool level_lo_op(amgh_t* h, int level, int which, LoOp* o) {
+  if (level < 0 || level >= (int)h->levels.size()) return false;
+  Level* L = h->levels[level];
+  GsSchedule* g = L->smat()->gs;
+  if (!L->lo_ok || !g || !g->perm) return false;
+  const int32_t* coarse_perm = nullptr;
+  if (L->coarse_lo) {
+    if (level + 1 >= (int)h->levels.size()) return false;
+    GsSchedule* cg = h->levels[level + 1]->smat()->gs;
+    if (!cg || !cg->perm) return false;
+    coarse_perm = cg->perm;
+  }
+  switch (which) {
+    case AMGH_OP_A:
+      if ((int64_t)g->ncols != L->n) return false;
+      *o = LoOp{g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, L->n, L->n, g->perm, g->perm};
+      return g->rowptr != nullptr && !g->compacted;
+    case AMGH_OP_P:
+      *o = LoOp{L->Pp.rowptr, L->Pp.col, L->Pp.val, L->n, L->nc, g->perm, coarse_perm};
+      return L->Pp.rowptr != nullptr;
+    case AMGH_OP_R:
+      *o = LoOp{L->Rp.rowptr, L->Rp.col, L->Rp.val, L->nc, L->n, coarse_perm, g->perm};
+      return L->Rp.rowptr != nullptr;
+  }
+  return false;
+}
+
+// y = op x (M_SPMV) or y = b - op x (M_RESID) for the stand-alone hooks, natural order in and out.  Where the
+// natural-order copy of the operator was released (the default footprint keeps only what the cycle multiplies with),
+// the level-ordered copy does the product between a gather of x and a scatter of y: same entries in the same order
+// inside every row, hence the same sums.
+static int level_apply(amgh_t* h, int level, int which, int mode, const real* x_d, const real* b_d, real* y_d) {
+  if (amgh_csr* op = level_op(h, level, which)) return csr_apply(op, mode, x_d, b_d, y_d, h->stream);
+  LoOp o;
+  if (!level_lo_op(h, level, which, &o)) return AMGH_EINVAL;
+  real *xi = nullptr, *yo = nullptr, *bi = nullptr;
+  int rc = AMGH_OK;
+  const real* xin = x_d;
+  const real* bin = b_d;
+  if (o.col_perm) {
+    rc = dev_alloc(&xi, o.ncols);
+    if (rc == AMGH_OK)
+      hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(o.ncols)), dim3(256), 0, h->stream, x_d, o.col_perm, xi, (int)o.ncols,
+                         (int64_t)0, (int64_t)0);
+    xin = xi;
+  }
+  if (rc == AMGH_OK && o.row_perm) {
+    rc = dev_alloc(&yo, o.nrows);
+    if (rc == AMGH_OK && mode == M_RESID) {
+      rc = dev_alloc(&bi, o.nrows);
+      if (rc == AMGH_OK)
+        hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(o.nrows)), dim3(256), 0, h->stream, b_d, o.row_perm, bi, (int)o.nrows,
+                           (int64_t)0, (int64_t)0);
+      bin = bi;
+    }
+  }
+  if (rc == AMGH_OK)
+    rc = raw_apply(mode, o.rowptr, o.col, o.val, o.nrows, xin, o.ncols, bin, o.nrows, o.row_perm ? yo : y_d, o.nrows, h->stream, 1);
+  if (rc == AMGH_OK && o.row_perm)
+    hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(o.nrows)), dim3(256), 0, h->stream, (const real*)yo, o.row_perm, y_d,
+                       (int)o.nrows, (int64_t)0, (int64_t)0);
+  if (rc == AMGH_OK && hipGetLastError() != hipSuccess) rc = -1001;
+  if (hipStreamSynchronize(h->stream) != hipSuccess && rc == AMGH_OK) rc = -1001;   // the temporaries go now
+  hipFree(xi); hipFree(yo); hipFree(bi);
+  return rc;
+}
+// rows x columns of the level's operator (whichever copy exists)
+static bool level_op_shape(amgh_t* h, int level, int which, int64_t* nrows, int64_t* ncols) {
+  if (amgh_csr* op = level_op(h, level, which)) { *nrows = op->nrows; *ncols = op->ncols; return true; }
+  LoOp o;
+  if (!level_lo_op(h, level, which, &o)) return false;
+  *nrows = o.nrows; *ncols = o.ncols;
+  return true;
+}
+
 int amgh_level_spmv_d(amgh_t* h, int level, int which, const real* x_d, real* y_d) {
   RC_TRY(check_ready(h));
-  amgh_csr* op = level_op(h, level, which);
-  if (!op || !x_d || !y_d) return AMGH_EINVAL;
+  if (!x_d || !y_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
-  RC_TRY(csr_apply(op, M_SPMV, x_d, nullptr, y_d, h->stream));
+  RC_TRY(level_apply(h, level, which, M_SPMV, x_d, nullptr, y_d));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return AMGH_OK;
 }
 
 int amgh_level_spmv(amgh_t* h, int level, int which, const real* x, real* y) {
   RC_TRY(check_ready(h));
-  amgh_csr* op = level_op(h, level, which);
-  if (!op || !x || !y) return AMGH_EINVAL;
+  int64_t nr = 0, ncl = 0;
+  if (!x || !y || !level_op_shape(h, level, which, &nr, &ncl)) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   real *xd = nullptr, *yd = nullptr;
-  RC_TRY(dev_upload(&xd, x, op->ncols));
-  int rc = dev_alloc(&yd, op->nrows);
-  if (rc == AMGH_OK) rc = csr_apply(op, M_SPMV, xd, nullptr, yd, h->stream);
+  RC_TRY(dev_upload(&xd, x, ncl));
+  int rc = dev_alloc(&yd, nr);
+  if (rc == AMGH_OK) rc = level_apply(h, level, which, M_SPMV, xd, nullptr, yd);
   if (rc == AMGH_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = -1000 - (int)hipGetLastError();
-  if (rc == AMGH_OK && hipMemcpy(y, yd, sizeof(real) * op->nrows, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
+  if (rc == AMGH_OK && hipMemcpy(y, yd, sizeof(real) * nr, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
   hipFree(xd); hipFree(yd);
   return rc;
 }
 
 int amgh_level_residual_d(amgh_t* h, int level, const real* x_d, const real* b_d, real* r_d) {
   RC_TRY(check_ready(h));
-  amgh_csr* op = level_op(h, level, AMGH_OP_A);
-  if (!op || !x_d || !b_d || !r_d) return AMGH_EINVAL;
+  if (!x_d || !b_d || !r_d) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
-  RC_TRY(csr_apply(op, M_RESID, x_d, b_d, r_d, h->stream));
+  RC_TRY(level_apply(h, level, AMGH_OP_A, M_RESID, x_d, b_d, r_d));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return AMGH_OK;
 }
@@ -1320,10 +1420,16 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
   RC_TRY(check_ready(h));
   if (!avg_ms || reps <= 0 || warmup < 0) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
-  amgh_csr* op = level_op(h, level, which <= AMGH_OP_R ? which : AMGH_OP_A);
-  if (!op) return AMGH_EINVAL;
+  // which: 0 / 1 / 2 = A / P / R products, 3 = fused residual, 4 = pre-smoother; 5 / 6 / 7 = residual / P / R on the
+  // LEVEL-ORDERED copies, exactly as the cycle launches them.  0-3 take the natural-order operator where the hierarchy
+  // still holds it and the level-ordered one otherwise (vectors in that order: no gather / scatter in the timing).
+  const int base_which = which <= AMGH_OP_R ? which : which == 6 ? AMGH_OP_P : which == 7 ? AMGH_OP_R : AMGH_OP_A;
+  amgh_csr* op = which >= 5 ? nullptr : level_op(h, level, base_which);
+  LoOp lo;
+  if (!op && which != 4 && !level_lo_op(h, level, base_which, &lo)) return AMGH_EINVAL;
+  if (!op && which == 4 && (level < 0 || level >= (int)h->levels.size())) return AMGH_EINVAL;
   real *x = nullptr, *y = nullptr, *b = nullptr;
-  const int64_t nx = std::max(op->ncols, op->nrows);
+  const int64_t nx = op ? std::max(op->ncols, op->nrows) : which == 4 ? h->levels[level]->n : std::max(lo.ncols, lo.nrows);
   RC_TRY(dev_alloc(&x, nx));
   RC_TRY(dev_alloc(&y, nx));
   RC_TRY(dev_alloc(&b, nx));
@@ -1345,8 +1451,13 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
   }
   int rc = AMGH_OK;
   auto run = [&]() -> int {
-    if (which <= AMGH_OP_R) return csr_apply(op, M_SPMV, x, nullptr, y, h->stream);
-    if (which == 3) return csr_apply(op, M_RESID, x, b, y, h->stream);
+    if (which == 4) {
+      if (level >= (int)h->levels.size()) return AMGH_EINVAL;
+      return level_smooth_enqueue(h, level, 0, y, b);
+    }
+    const int mode = (which == 3 || which == 5) ? M_RESID : M_SPMV;
+    if (op) return csr_apply(op, mode, x, b, y, h->stream);
+    return raw_apply(mode, lo.rowptr, lo.col, lo.val, lo.nrows, x, lo.ncols, b, lo.nrows, y, lo.nrows, h->stream, 1);
     if (which == 4) {
       if (level >= (int)h->levels.size()) return AMGH_EINVAL;
       return level_smooth_enqueue(h, level, 0, y, b);
@@ -1431,6 +1542,8 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_lpr")) g_gs_lpr = value;
   else if (!strcmp(name, "gs_lean")) g_gs_lean = value;
   else if (!strcmp(name, "gs_sell")) g_gs_sell = value;
+  else if (!strcmp(name, "gs_sample")) g_gs_sample = value;
+  else if (!strcmp(name, "gs_tiny")) g_gs_tiny = value;
   else if (!strcmp(name, "gs_ept")) g_gs_ept = value;
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_merge_force")) g_gs_merge_force = value;
@@ -1447,6 +1560,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_super")) g_gs_super = value;
   else if (!strcmp(name, "gs_block_pipe")) g_gs_block_pipe = value;
   else return AMGH_EINVAL;
+  ++g_sched_epoch;   // captured cycles bake the execution path in: every handle captures again after a change
   return AMGH_OK;
 }
 
@@ -1481,6 +1595,7 @@ int amgh_profile_read(amgh_t* h, double* out, int reset) {
 int amgh_set_use_graph(amgh_t* h, int on) {
   if (!h) return AMGH_EINVAL;
   h->use_graph = on != 0;
+  h->graph_auto = false;
   return AMGH_OK;
 }
 

@@ -34,6 +34,10 @@ using namespace amgh;
 
 namespace {
 
+// byte accounting (amgh_device_bytes*): one real, one matrix entry (int32 column + real value) of THIS instance
+constexpr int64_t kRealB = (int64_t)sizeof(real);
+constexpr int64_t kEntB = 4 + (int64_t)sizeof(real);
+
 template <class T>
 int dev_alloc(T** p, int64_t count) {
   *p = nullptr;
@@ -197,6 +201,8 @@ struct GsSchedule {
   int32_t* perm = nullptr;
   int32_t* dpos = nullptr;
   real* diag = nullptr;
+  bool diag_shared = false;   // (merged Gauss-Seidel child: the parent's array — same rows in the same order)
+  bool tiny_ok = false;       // the whole operator fits LDS (gs_chain_tiny_kernel): rows, nonzeros, levels and columns within kTiny*
   i4_t* rowmeta = nullptr;  // per permuted row {start, end, diagonal position, original row}
   i4_t* desc = nullptr;     // per dependency level {first row, end row, first nnz, end nnz}
   real* bp = nullptr;     // right-hand side in dependency-level order (scratch)
@@ -246,7 +252,7 @@ struct GsSchedule {
   // rows — a launch over the whole chip — then x_blk = T_blk^-1 s, one triangular GEMV: two launches per block
   // instead of B / 128 sequential steps of one workgroup.
   real* dti_f = nullptr;  // (D + L)_blk^-1 of every block, each nb x nb row-major, one after the other (natural order)
-  real* dti_b = nullptr;  // (D + U)_blk^-1
+  real* dti_b = nullptr;  // (D + U)_blk^-1: the SAME array — lower triangles hold the forward inverses, upper the backward ones
   int dti_B = 0;          // rows per block (the last one may be shorter)
   std::vector<int64_t> dti_off;  // first element of block k in dti_f / dti_b
   double dti_cond = 0.0;  // largest inf-norm condition estimate of an in-block triangle
@@ -287,14 +293,16 @@ struct GsSchedule {
       hipFree(o->sp_rowptr); hipFree(o->sp_col); hipFree(o->sp_val);
       *o = Outer();
     }
-    hipFree(dti_f); hipFree(dti_b); dti_f = dti_b = nullptr;
+    hipFree(dti_f); if (dti_b != dti_f) hipFree(dti_b);
+    dti_f = dti_b = nullptr;
     for (Tri* t : {&dtri_f, &dtri_b}) { hipFree(t->rowptr); hipFree(t->col); hipFree(t->val); *t = Tri(); }
     hipFree(blk_diag); blk_diag = nullptr;
     hipFree(blk_s); blk_s = nullptr;
     hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
     hipFree(scol); hipFree(sval); hipFree(schunk); scol = nullptr; sval = nullptr; schunk = nullptr;
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
-    hipFree(perm); hipFree(dpos); hipFree(diag); hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
+    hipFree(perm); hipFree(dpos); if (!diag_shared) hipFree(diag);
+    hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
     d_lvl_ptr = rowptr = col = perm = dpos = nullptr; val = diag = bp = xp = nullptr; rowmeta = desc = nullptr; permx = nullptr;
   }
 };
@@ -337,8 +345,10 @@ int g_gs_merge_force_maxn = 0;   // ... only on operators with at most this many
 int g_gs_merge_force = 0;        // measurement hook: groups of exactly this many levels wherever they can be built (0 = cost model); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
+int g_gs_tiny = 1;              // chained levels of an operator that fits LDS entirely: gs_chain_tiny_kernel (0 = gs_chain_kernel); read at every sweep
+int g_gs_sample = 1;            // candidate group sizes of the merged sweeps from a sample of the groups (0 = every candidate built in full); read at schedule build
 int g_gs_sell = 1;              // merged groups from the SELL-like layout where it was built (0 = slot kernels); build: read at schedule build too
-int g_gs_lean = -1;             // memory-lean schedules: -1 = AMGH_LEAN environment variable, 0 off, 1 on; read at schedule build
+int g_gs_lean = -1;             // footprint policy: -1 = AMGH_LEAN environment variable (unset: trim), 0 = full (every copy kept), 1 = lean, 2 = trim; read at schedule build
 int g_gs_ept = 0;               // entries per thread of merged slot launches (0 = 2 when a group has more than 1024 slots, else 1)
 int g_gs_lpr = 0;               // lanes per row in the row sums of merged slot launches (0 = by row length, 1 = one thread per row)
 int g_gs_dense_blk = 4096;       // ... rows per dense block above kDenseTriMax rows; read at schedule build
@@ -380,7 +390,7 @@ int csr_upload(amgh_csr* op, int device, int64_t nrows, int64_t ncols, const int
   RC_TRY(dev_upload(&op->rowptr, rowptr, nrows + 1));
   RC_TRY(dev_upload(&op->col, col, nnz));
   RC_TRY(dev_upload(&op->val, val, nnz));
-  op->bytes = (nrows + 1) * 4 + nnz * 12;
+  op->bytes = (nrows + 1) * 4 + nnz * kEntB;
   return AMGH_OK;
 }
 
@@ -405,7 +415,7 @@ int csr_ensure_diag(amgh_csr* op, hipStream_t st) {
     hipLaunchKernelGGL(find_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op->rowptr, op->col,
                        op->val, (int)n, op->dpos, op->diag);
   HIP_TRY(hipGetLastError());
-  op->bytes += op->nrows * 12;
+  op->bytes += op->nrows * kEntB;
   return AMGH_OK;
 }
 

@@ -540,6 +540,51 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
   }
 }
 
+// ---- the chain with the WHOLE operator in LDS --------------------------------------------------------------------------
+// gs_chain_kernel keeps x in LDS and prefetches the next level's rows one level ahead, but every level still waits for
+// that prefetch: one global-memory round trip (~2 us at the clocks of an otherwise idle chip) per dependency level,
+// against ~0.2 us of LDS work.  A tiny operator (lin_elastic_2d: 208 rows, 2 632 nonzeros, 46 levels; the reference's
+// nns_test.jl:213-226 configuration) fits LDS entirely — matrix, row data, level descriptors, x, b: it is loaded once,
+// and the per-level loop touches no global memory at all.  Same products, same in-order row sums as gs_chain_kernel
+// (bitwise the same result); x goes back to HBM when the sweep is over.
+constexpr int kTinyRows = 1024;     // rows (= columns, = levels at most)
+constexpr int kTinyNnz = 6144;
+constexpr int kTinyLvlNnz = 2048;   // nonzeros of one dependency level
+template <bool SOR, int T>
+__global__ __launch_bounds__(T) void gs_chain_tiny_kernel(ChainArgs a, int n, int nnz, int nlev) {
+  __shared__ real s_val[kTinyNnz];
+  __shared__ int32_t s_col[kTinyNnz];
+  __shared__ i4_t s_meta[kTinyRows];
+  __shared__ i4_t s_desc[kTinyRows];
+  __shared__ real s_d[kTinyRows], s_b[kTinyRows], s_x[kTinyRows];
+  __shared__ real s_prod[kTinyLvlNnz];
+  const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {  // independent right-hand-side columns, one workgroup each
+    a.x += blockIdx.x * a.ldx;
+    a.bp += blockIdx.x * a.ldb;
+  }
+  if (a.lvl_begin == a.lvl_end) return;
+  for (int k = tid; k < nnz; k += T) { s_val[k] = a.val[k]; s_col[k] = a.col[k]; }
+  for (int r = tid; r < n; r += T) { s_meta[r] = a.rowmeta[r]; s_d[r] = a.diag[r]; s_b[r] = a.bp[r]; s_x[r] = a.x[r]; }
+  for (int l = tid; l < nlev; l += T) s_desc[l] = a.desc[l];
+  __syncthreads();
+  for (int lv = a.lvl_begin; lv != a.lvl_end; lv += a.step) {
+    const i4_t ds = s_desc[lv];
+    const int p0 = ds.z, p1 = ds.w;
+    for (int k = p0 + tid; k < p1; k += T) s_prod[k - p0] = s_val[k] * s_x[s_col[k]];
+    lds_barrier();
+    const int r = ds.x + tid;
+    if (r < ds.y) {
+      const i4_t m = s_meta[r];
+      const real d = s_d[r];
+      const real acc = seq_sum_skip(s_prod, m.x - p0, m.y - p0, m.z - p0, 0.0);
+      if (d != 0.0) s_x[r] = SOR ? (1.0 - a.omega) * s_x[r] + (a.omega / d) * (s_b[r] - acc) : (s_b[r] - acc) / d;
+    }
+    lds_barrier();   // this level's x is visible, s_prod may be overwritten
+  }
+  for (int r = tid; r < n; r += T) a.x[r] = s_x[r];
+}
+
 // ---- one WIDE dependency level from the slot layout -------------------------------------------
 // A wide level's launch is latency-bound: kernarg -> row pointers -> col/val -> x gather are four
 // dependent round trips.  The slot layout removes one: the level's nonzeros are packed into slots of
@@ -1270,7 +1315,9 @@ __global__ void scalar_kernel(real* out, const real* a, const real* b, int op) {
 // ---- dense triangular inverse (small operators) -------------------------------------------------------------------
 // X = (D + L)^-1 (upper = 0) or (D + U)^-1 (upper = 1) of a diagonal block of a CSR matrix, dense n x n ROW-major: one thread per column c
 // runs the substitution T X[:, c] = e_c down (up) the rows; a column depends on itself only, and the threads of a
-// workgroup walk the rows together, so the row's entries are one broadcast load.  X must be zeroed by the caller.
+// workgroup walk the rows together, so the row's entries are one broadcast load.  Xf and Xb may be the SAME array:
+// the lower triangle of a block's square holds (D + L)^-1, the upper (D + U)^-1, and the diagonal they share is
+// 1 / d_ii in both (written twice with the same bits); every read stays inside the column's own triangle.
 __global__ void tri_inverse_kernel(const int32_t* rowptr, const int32_t* col, const real* val, int B, int ntot,
                                    const int64_t* off, real* Xf, real* Xb) {
   // blockIdx.y = diagonal block k (rows / columns [k B, min(ntot, (k + 1) B))), blockIdx.z = 0: (D + L)^-1, 1: (D + U)^-1 —
@@ -1290,7 +1337,7 @@ __global__ void tri_inverse_kernel(const int32_t* rowptr, const int32_t* col, co
       const int32_t cj = col[j] - row0;
       const real v = val[j];
       if (cj == i) d = v;
-      else if (act && cj >= 0 && cj < n && (upper ? cj > i : cj < i)) acc -= v * X[(size_t)cj * n + c];
+      else if (act && cj >= 0 && cj < n && (upper ? (cj > i && cj <= c) : (cj < i && cj >= c))) acc -= v * X[(size_t)cj * n + c];
     }
     if (act) X[(size_t)i * n + c] = acc / d;
   }
@@ -1304,7 +1351,8 @@ __global__ void dense_abs_rowsum_kernel(const real* Xf, const real* Xb, int B, i
   const int i = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave, ln = threadIdx.x % kWave;
   if (i >= n) return;
   real acc = 0.0;
-  for (int j = ln; j < n; j += kWave) acc += fabs(X[(size_t)i * n + j]);
+  const int lo = blockIdx.z ? i : 0, hi = blockIdx.z ? n : i + 1;   // this triangle's part of the (possibly shared) square
+  for (int j = lo + ln; j < hi; j += kWave) acc += fabs(X[(size_t)i * n + j]);
   for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
   if (ln == 0) (blockIdx.z ? out_b : out_f)[row0 + i] = acc;
 }

@@ -100,6 +100,21 @@ int launch_chain_t(const ChainArgs& c, bool sor, bool ldsx, int nx, hipStream_t 
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
 }
+template <int T>
+int launch_chain_tiny_t(const ChainArgs& c, bool sor, int n, int nnz, int nlev, hipStream_t st, int ncolv) {
+  if (sor) hipLaunchKernelGGL((gs_chain_tiny_kernel<true, T>), dim3(ncolv), dim3(T), 0, st, c, n, nnz, nlev);
+  else hipLaunchKernelGGL((gs_chain_tiny_kernel<false, T>), dim3(ncolv), dim3(T), 0, st, c, n, nnz, nlev);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+// the whole operator in LDS (gs_chain_tiny_kernel): workgroup size by the segment's widest level, as below
+int launch_chain_tiny(const ChainArgs& c, bool sor, int threads, int n, int nnz, int nlev, hipStream_t st, int ncolv) {
+  switch (threads) {
+    case 64: return launch_chain_tiny_t<64>(c, sor, n, nnz, nlev, st, ncolv);
+    case 256: return launch_chain_tiny_t<256>(c, sor, n, nnz, nlev, st, ncolv);
+    default: return launch_chain_tiny_t<1024>(c, sor, n, nnz, nlev, st, ncolv);
+  }
+}
 // threads = workgroup size class of the segment (64 / 256 / 1024), see gs_build
 int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, hipStream_t st, int ncolv) {
   switch (threads) {
@@ -291,7 +306,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
   // which triangular system runs: the level-by-level one, merged Gauss-Seidel groups, or merged SOR groups (built on
   // the first sweep with this relaxation factor); merged SOR runs the GS kernels on the scaled system
   GsSchedule* lay = g;
-  const GsSchedule::Tri* tri = nullptr;
+  GsSchedule::Tri* tri = nullptr;
   real s_key = 0.0, flip_scale = 1.0;
   bool both_dirs = false;
   if (g_gs_merge > 1 && !sor && (backward ? g->mb : g->mf)) {
@@ -354,6 +369,15 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
                          (const real*)g->bp, (int)g->n, xs, (int64_t)g->n);
       HIP_TRY(hipGetLastError());
     } else {
+      if (!tri->rowptr && g->n > 0 && tri == (backward ? &g->tri_b : &g->tri_f)) {
+        // trimmed footprint: the backward pre-pass triangle is only needed by sweeps that START backward (alternating
+        // sweeps derive s from the forward one) — built when a sweep first asks for it (never during graph capture:
+        // the first cycle of every kind runs eagerly)
+        HIP_TRY(hipStreamSynchronize(st));
+        const int64_t before = g->bytes;
+        RC_TRY(tri_build_dev(tri, g, backward, &g->bytes, 0.0, backward ? &g->tri_nnz_b : &g->tri_nnz));
+        op->bytes += g->bytes - before;
+      }
       StreamArgs ra{};
       ra.rowptr = tri->rowptr; ra.col = tri->col; ra.val = tri->val;
       ra.x = xp; ra.b = g->bp; ra.y = xp + g->ncols;
@@ -380,6 +404,10 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       c.ldx = xs; c.ldb = ldb;
       const int64_t nx = lay == g ? g->ncols : xs;  // entries of x (and s) a chained row may read
       const bool ldsx = nx <= kChainLdsX;            // they fit LDS
+      if (lay == g && g->tiny_ok && g->ncols == g->n && g_gs_tiny && !g_chain_tim) {   // the whole operator fits LDS: no global access per level
+        RC_TRY(launch_chain_tiny(c, sor, s.rows, (int)g->n, (int)g->nnz, g->nlev, st, ncolv));
+        continue;
+      }
       RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)nx, st, ncolv));
     } else if (s.sell_k > 0 && lay->scol && g_gs_sell) {
       SellArgs la{};

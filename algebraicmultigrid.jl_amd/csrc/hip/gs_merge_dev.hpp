@@ -53,6 +53,7 @@ struct MergeDev {
   int32_t* rcol[kMergeMaxRounds] = {};
   real* rval[kMergeMaxRounds] = {};
   int64_t total = 0, max_row = 0;
+  int64_t sampled_rows = 0;           // rows whose composite row was built (= n unless the build sampled the groups)
   double growth = 0.0;
   bool failed = false;                // a row outgrew the long-row table (the caller gives up on this m)
   std::vector<int32_t> h_clen;        // host copy of clen
@@ -217,8 +218,11 @@ __global__ __launch_bounds__(LANES * ROWS) void merge_rows_kernel(MergeArgs a) {
 // D / omega (dscale = 1 / omega), Gauss-Seidel with D (dscale = 1).
 // min_tier: the smallest table worth trying (0: 128 slots, 1: 512, 2: 4096 — the caller knows the longest row of the
 // previous, shallower grouping; rows only grow with m)
+// sample_stride > 1: a COST-MODEL build — only every sample_stride-th group is built (entries per row, longest row and
+// coefficient growth of a grouping are bulk properties; the candidate group sizes that are thrown away need not be
+// built in full); total / max_row / growth then describe the sampled rows (sampled_rows of them).
 int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_diag, const MergeGrouping& G, MergeDev* out,
-                    int min_tier = 0) {
+                    int min_tier = 0, int sample_stride = 1) {
   dbg_pending("entry of the merged-group builder");
   const int64_t n = g->n;
   MergeDev& R = *out;
@@ -276,7 +280,8 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
     // only the levels of this round are launched: workgroups per group for both launch shapes
     hs[0] = hb[0] = 0;
     for (int q = 0; q < R.ngrp; ++q) {
-      const int l = k < G.gb[q + 1] - G.gb[q] ? (backward ? G.gb[q + 1] - 1 - k : G.gb[q] + k) : -1;
+      int l = k < G.gb[q + 1] - G.gb[q] ? (backward ? G.gb[q + 1] - 1 - k : G.gb[q] + k) : -1;
+      if (sample_stride > 1 && q % sample_stride != sample_stride / 2) l = -1;   // not in the sample
       hl[q] = l;
       const int w = (l >= 0 && l < g->nlev) ? g->lvl_ptr[l + 1] - g->lvl_ptr[l] : 0;
       hs[q + 1] = hs[q] + (w + RS - 1) / RS;
@@ -369,6 +374,11 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
     else {
       std::memcpy(&R.growth, &gbits, 8);
       for (int64_t p2 = 0; p2 < n; ++p2) R.max_row = std::max<int64_t>(R.max_row, R.h_clen[p2]);
+      R.sampled_rows = n;
+      if (sample_stride > 1) {
+        R.sampled_rows = 0;
+        for (int q = sample_stride / 2; q < R.ngrp; q += sample_stride) R.sampled_rows += g->lvl_ptr[G.gb[q + 1]] - g->lvl_ptr[G.gb[q]];
+      }
     }
   }
   hipFree(cnt); hipFree(off); hipFree(flags); hipFree(ovf); hipFree(growth); hipFree(blk_s); hipFree(blk_b); hipFree(rlev);

@@ -102,12 +102,23 @@ int blockgs_build_dir(GsSchedule::Outer* o, bool backward, int super, int64_t n,
   return AMGH_OK;
 }
 
-// memory-lean schedules (tunable "gs_lean" or AMGH_LEAN=1 in the environment; read when a schedule is built)
-bool gs_lean() {
-  if (g_gs_lean >= 0) return g_gs_lean != 0;
+// Footprint policy (tunable "gs_lean" or AMGH_LEAN in the environment; read when a schedule is built):
+//   trim (default; AMGH_LEAN=2 / unset)  keep what the default cycle touches: no un-merged slot copy and no CSR copy of
+//        slotted composite rows where both directions run merged groups (the CSR copy serves the SELL-like build first),
+//        no natural-order P / R / coarse-level A where the cycle runs level-ordered (the stand-alone hooks then go
+//        through the level-ordered copies), the backward pre-pass triangle built on first use;
+//   lean (AMGH_LEAN=1)  trim + the composite rows compacted the moment they are laid out (lowest peak during the build)
+//        and no SELL-like copies;
+//   full (AMGH_LEAN=0)  every copy kept (run-time tunables can then switch between all execution paths at full speed).
+// Same kernels on the same numbers in all three: the results are bitwise the same.
+int gs_footprint() {
+  if (g_gs_lean >= 0) return g_gs_lean == 0 ? 0 : g_gs_lean == 1 ? 2 : 1;
   const char* e = getenv("AMGH_LEAN");
-  return e && e[0] == '1';
+  if (!e || !e[0]) return 1;
+  return e[0] == '0' ? 0 : e[0] == '1' ? 2 : 1;
 }
+bool gs_lean() { return gs_footprint() == 2; }
+bool gs_trim() { return gs_footprint() >= 1; }
 
 // host threads for the schedule builds: the container's CPU quota, AMGH_BUILD_THREADS overrides
 int merge_threads() {
@@ -225,7 +236,7 @@ int tri_build_dev(GsSchedule::Tri* t, const GsSchedule* g, bool backward, int64_
   }
   hipFree(lev_of); hipFree(cnt);
   if (rc != AMGH_OK) return rc;
-  *bytes += (n + 1) * 4 + total * 12;
+  *bytes += (n + 1) * 4 + total * kEntB;
   if (nnz_out) *nnz_out = total;
   return AMGH_OK;
 }
@@ -247,7 +258,7 @@ __global__ void compact_rows_kernel(const int32_t* prow, const int32_t* pcol, co
   for (int e = 0; e < len; ++e) { ccol[dst + e] = pcol[src + e]; cval[dst + e] = pval[src + e]; }
 }
 int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int slot_entries = kSlot,
-                  bool compact = false, DevCsr* dev_src = nullptr) {
+                  bool compact = false, DevCsr* dev_src = nullptr, real* shared_diag = nullptr) {
   const int64_t n = h.n;
   const std::vector<int32_t>& prow = h.prow;
   const std::vector<int32_t>& pcol = h.pcol;
@@ -262,9 +273,10 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
   bool full_csr_on_device = false;  // the slot fill already put the whole CSR copy on the device
   const int SE = slot_entries;                                    // entries per slot
   const int max_rows = SE == kSlot ? kSlot : kBigRows;           // rows per slot
-  RC_TRY(dev_upload(&g->diag, h.pdiag.data(), n));
+  if (shared_diag) { g->diag = shared_diag; g->diag_shared = true; }   // a merged child sweeps the parent's rows: one copy of their diagonal
+  else RC_TRY(dev_upload(&g->diag, h.pdiag.data(), n));
   RC_TRY(dev_upload(&g->d_lvl_ptr, g->lvl_ptr.data(), g->nlev + 1));
-  g->bytes += n * 8 + (g->nlev + 1) * 4;
+  g->bytes += (shared_diag ? 0 : n * kRealB) + (g->nlev + 1) * 4;
   // segments: runs of narrow dependency levels are chained in one workgroup
   // A dependency level is chained (stays inside one workgroup) when it has at most
   // one row per thread and its products fit one LDS pass; anything larger is worth
@@ -409,9 +421,9 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       }
       if (!dev_src) { hipFree(t_row); hipFree(t_col); hipFree(t_val); }
       RC_TRY(rcf);
-      g->bytes += wtotal * 12 + (int64_t)sr2.size() * 4 + n * 16;
+      g->bytes += wtotal * kEntB + (int64_t)sr2.size() * 4 + n * 16;
       g->slot_total = wtotal;
-      g->slot_bytes = wtotal * 12 + (int64_t)sr2.size() * 4 + n * 16;
+      g->slot_bytes = wtotal * kEntB + (int64_t)sr2.size() * 4 + n * 16;
     }
   }
   // the CSR copy (chain kernel, stream-kernel fallback): all rows, or — compact — only those no slot launch covers
@@ -477,9 +489,67 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
       desc[l2] = i4_t{g->lvl_ptr[l2], g->lvl_ptr[l2 + 1], (*urow)[g->lvl_ptr[l2]], (*urow)[g->lvl_ptr[l2 + 1]]};
     RC_TRY(dev_upload(&g->rowmeta, meta.data(), n));
     RC_TRY(dev_upload(&g->desc, desc.data(), g->nlev));
-    g->csr_bytes = (n + 1) * 4 + unnz * 12 + n * 4 + n * 16 + g->nlev * 16;
+    g->csr_bytes = (n + 1) * 4 + unnz * kEntB + n * 4 + n * 16 + g->nlev * 16;
     g->bytes += g->csr_bytes;
+    // small enough to be swept out of LDS as a whole (gs_chain_tiny_kernel)?
+    int64_t widest = 0;
+    for (int l2 = 0; l2 < g->nlev; ++l2) widest = std::max<int64_t>(widest, prow[g->lvl_ptr[l2 + 1]] - prow[g->lvl_ptr[l2]]);
+    g->tiny_ok = !compact && n <= kTinyRows && nnz <= kTinyNnz && widest <= kTinyLvlNnz && g->nlev <= kTinyRows;
   }
+  return AMGH_OK;
+}
+
+// Trimmed footprint: after the SELL-like build has read it, the CSR copy of a merged child keeps only the rows no slot
+// (or SELL) launch covers — chained narrow groups, rows too long for a slot; what layout_upload(compact = true) does at
+// once, done afterwards.  Composite rows carry no diagonal position (dpos = -1 everywhere).
+int child_compact_late(GsSchedule* g, const std::vector<int32_t>& prow, const int32_t* orig) {
+  if (g->compacted || !g->rowptr) return AMGH_OK;
+  const int64_t n = g->n;
+  std::vector<int32_t> cprow(n + 1, 0);
+  bool any_kept = false;
+  {
+    std::vector<char> keep(n, 0);
+    for (const auto& sg : g->segs)
+      if (sg.chain || sg.nslots <= 0)
+        for (int32_t p2 = g->lvl_ptr[sg.l0]; p2 < g->lvl_ptr[sg.l1]; ++p2) keep[p2] = 1;
+    for (int64_t p2 = 0; p2 < n; ++p2) {
+      cprow[p2 + 1] = cprow[p2] + (keep[p2] ? prow[p2 + 1] - prow[p2] : 0);
+      any_kept = any_kept || keep[p2];
+    }
+  }
+  const int64_t unnz = cprow[n];
+  int32_t *nrp = nullptr, *ncol = nullptr;
+  real* nval = nullptr;
+  int rc = dev_upload(&nrp, cprow.data(), n + 1);
+  if (rc == AMGH_OK) rc = dev_alloc(&ncol, unnz);
+  if (rc == AMGH_OK) rc = dev_alloc(&nval, unnz);
+  if (rc == AMGH_OK && n > 0) {
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)g->rowptr,
+                       (const int32_t*)g->col, (const real*)g->val, (const int32_t*)nrp, (int)n, ncol, nval);
+    if (hipDeviceSynchronize() != hipSuccess) rc = -1001;
+  }
+  if (rc != AMGH_OK) { hipFree(nrp); hipFree(ncol); hipFree(nval); return rc; }
+  hipFree(g->rowptr); hipFree(g->col); hipFree(g->val);
+  g->rowptr = nrp; g->col = ncol; g->val = nval;
+  g->compacted = true;
+  // row / level descriptors of the chain kernel follow the new positions
+  hipFree(g->rowmeta); hipFree(g->desc); hipFree(g->dpos);
+  g->rowmeta = nullptr; g->desc = nullptr; g->dpos = nullptr;
+  int64_t meta_bytes = 0;
+  if (any_kept) {
+    std::vector<i4_t> meta(n), desc(g->nlev);
+    for (int64_t p2 = 0; p2 < n; ++p2) meta[p2] = i4_t{cprow[p2], cprow[p2 + 1], -1, orig ? orig[p2] : (int32_t)p2};
+    for (int l2 = 0; l2 < g->nlev; ++l2)
+      desc[l2] = i4_t{g->lvl_ptr[l2], g->lvl_ptr[l2 + 1], cprow[g->lvl_ptr[l2]], cprow[g->lvl_ptr[l2 + 1]]};
+    std::vector<int32_t> dp(n, -1);
+    RC_TRY(dev_upload(&g->rowmeta, meta.data(), n));
+    RC_TRY(dev_upload(&g->desc, desc.data(), g->nlev));
+    RC_TRY(dev_upload(&g->dpos, dp.data(), n));
+    meta_bytes = n * 4 + n * 16 + g->nlev * 16;
+  }
+  const int64_t now = (n + 1) * 4 + unnz * kEntB + meta_bytes;
+  g->bytes += now - g->csr_bytes;
+  g->csr_bytes = now;
   return AMGH_OK;
 }
 
@@ -535,7 +605,7 @@ int sell_build(GsSchedule* g, const std::vector<int32_t>& prow) {
   }
   HIP_TRY(hipDeviceSynchronize());
   g->sell_total = total64 * kWave;
-  g->sell_bytes = total64 * kWave * 12 + (int64_t)chunk.size() * 8;
+  g->sell_bytes = total64 * kWave * kEntB + (int64_t)chunk.size() * 8;
   g->bytes += g->sell_bytes;
   return AMGH_OK;
 }
@@ -885,7 +955,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       // explicit triangle inverses lose ~cond * eps: keep the 1e-10 contract with margin
       if (max_cond <= kBlockCondMax) {
         g->nblk = nblk;
-        g->bytes += 2 * ((int64_t)nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4) + n * 8;
+        g->bytes += 2 * ((int64_t)nblk * kBlk * kBlk * kRealB + nnz * kEntB + (n + 1) * 4) + n * kRealB;
       }
       // Small enough for the triangles of LARGE diagonal blocks to be inverted densely — the whole triangle up to
       // kDenseTriMax rows (2 n^2 reals), blocks of g_gs_dense_blk rows up to kDenseBlkMax rows (8 B n bytes): a sweep is
@@ -908,12 +978,11 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         if (rc3 == AMGH_OK) rc3 = dev_upload(&d_off, g->dti_off.data(), nb + 1);
         if (rc3 == AMGH_OK) rc3 = dev_alloc(&d_rs, 2 * n);
         if (rc3 == AMGH_OK) rc3 = dev_alloc(&g->dti_f, g->dti_off[nb]);
-        if (rc3 == AMGH_OK) rc3 = dev_alloc(&g->dti_b, g->dti_off[nb]);
+        if (rc3 == AMGH_OK) g->dti_b = g->dti_f;   // one square per block: lower triangle forward, upper backward
         double cond = 0.0;
         if (rc3 == AMGH_OK) {
           std::vector<real> rs(2 * n);
-          if (dev_zero(g->dti_f, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess ||
-              dev_zero(g->dti_b, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess) rc3 = -1001;
+          if (dev_zero(g->dti_f, sizeof(real) * (size_t)g->dti_off[nb], nullptr) != hipSuccess) rc3 = -1001;
           if (rc3 == AMGH_OK) {
             hipLaunchKernelGGL(tri_inverse_kernel, dim3((unsigned)((B + 63) / 64), nb, 2), dim3(64), 0, nullptr, (const int32_t*)d_rp,
                                (const int32_t*)d_ci, (const real*)d_va, B, (int)n, (const int64_t*)d_off, g->dti_f, g->dti_b);
@@ -962,12 +1031,12 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           fprintf(stderr, "[amghip] n=%lld dense triangle inverses, %d block(s) of %d rows: cond %.3g -> %s\n", (long long)n, nb, B, cond,
                   (rc3 == AMGH_OK && cond <= kBlockCondMax) ? "dense triangular sweeps" : "kept the block sweeps");
         if (rc3 != AMGH_OK || !(cond <= kBlockCondMax)) {
-          hipFree(g->dti_f); hipFree(g->dti_b); g->dti_f = g->dti_b = nullptr;
+          hipFree(g->dti_f); g->dti_f = g->dti_b = nullptr;
           for (GsSchedule::Tri* t : {&g->dtri_f, &g->dtri_b}) { hipFree(t->rowptr); hipFree(t->col); hipFree(t->val); *t = GsSchedule::Tri(); }
           if (rc3 == AMGH_ENOMEM) { rc3 = AMGH_OK; (void)hipGetLastError(); }   // no room for the dense blocks: the 128-row block sweeps stay
           RC_TRY(rc3);
         } else {
-          g->bytes += 2 * g->dti_off[nb] * (int64_t)sizeof(real) + 2 * (nnz * 12 + (n + 1) * 4);
+          g->bytes += g->dti_off[nb] * kRealB + 2 * (nnz * kEntB + (n + 1) * 4);
         }
       }
     }
@@ -990,6 +1059,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
       hipLaunchKernelGGL(lev_of_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)g->d_lvl_ptr,
                          g->nlev, (int)n, d_lev_of);
       MergeDev chosen[2];
+      bool sampled[2] = {false, false};
       int rc2 = AMGH_OK;
       // average composite entries per row of every uniform depth that was built (index = depth; 0 = not built)
       std::vector<double> fill[2] = {std::vector<double>(kMergeMaxRounds + 2, 0.0), std::vector<double>(kMergeMaxRounds + 2, 0.0)};
@@ -1009,10 +1079,16 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         if (force_m > 1) m_lo = m_hi = std::min(force_m, kMergeMaxRounds);   // measurement hook: exactly this depth
         for (int m = m_lo; m <= m_hi; ++m) {
           MergeDev md;
+          // candidates are COST-MODEL builds: every stride-th group only (entries per row, longest row and growth are bulk
+          // properties of a grouping) — all but one of them are thrown away; the chosen one is built in full below
+          const int stride = (force_m > 1 || !g_gs_sample) ? 1 : std::max(1, std::min(8, ((g->nlev + m - 1) / m) / 12));
           rc2 = merge_build_dev(g, d_lev_of, g->diag, MergeGrouping::uniform(g->nlev, m, backward), &md,
-                                prev_max > 440 ? 2 : prev_max > 110 ? 1 : 0);
+                                prev_max > 440 ? 2 : prev_max > 110 ? 1 : 0, stride);
           prev_max = md.max_row;
           if (rc2 != AMGH_OK) break;
+          sampled[dir] = stride > 1;
+          if (stride > 1 && !md.failed)   // scale the sample to the operator
+            md.total = (int64_t)((double)md.total * (double)n / (double)std::max<int64_t>(1, md.sampled_rows));
           if (!md.failed) fill[dir][m] = (double)md.total / (double)n;
           if (md.failed || md.max_row > kBigSlot - kBigSlot / 8) {  // fill has exploded
             if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] n=%lld %s m=%d given up: failed %d, max row %lld\n", (long long)n, backward ? "bwd" : "fwd", m, (int)md.failed, (long long)md.max_row);
@@ -1055,6 +1131,35 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           }
           if (stream_bound) break;
         }
+        }
+      }
+      // the chosen depths in full (the candidates above were samples); a row the sample did not see may outgrow the slots:
+      // then one level fewer per group
+      for (int dir = 0; dir < 2 && rc2 == AMGH_OK; ++dir) {
+        if (!sampled[dir] || chosen_m[dir] <= 1) continue;
+        const bool backward = dir == 1;
+        const int64_t smax = chosen[dir].max_row;
+        chosen[dir].free_dev();
+        chosen[dir] = MergeDev();
+        while (chosen_m[dir] > 1 && rc2 == AMGH_OK) {
+          MergeDev md;
+          rc2 = merge_build_dev(g, d_lev_of, g->diag, MergeGrouping::uniform(g->nlev, chosen_m[dir], backward), &md,
+                                smax > 440 ? 2 : smax > 110 ? 1 : 0);
+          if (rc2 != AMGH_OK) break;
+          int cap = (md.max_row > kSlot || g_gs_bigslot == 2) ? kBigSlot : kSlot;
+          const bool ok = !md.failed && md.max_row <= kBigSlot - kBigSlot / 8 && !(cap == kBigSlot && !g_gs_bigslot) &&
+                          !(md.growth > kMergeGrowthMax);
+          if (ok) {
+            if (getenv("AMGH_VERBOSE"))
+              fprintf(stderr, "[amghip] n=%lld %s merge m=%d built in full: %.1f entries/row (max %lld)\n", (long long)n,
+                      backward ? "bwd" : "fwd", chosen_m[dir], (double)md.total / n, (long long)md.max_row);
+            fill[dir][chosen_m[dir]] = (double)md.total / (double)n;
+            chosen_cap[dir] = cap;
+            chosen[dir] = std::move(md);
+            break;
+          }
+          md.free_dev();
+          --chosen_m[dir];
         }
       }
       tm.lap("merge candidates (device)", n); dbg_pending("merge candidates (device)");
@@ -1199,10 +1304,11 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           GsSchedule* ch = new GsSchedule;
           (backward ? g->mb : g->mf) = ch;
           ch->ncols = g->ncols;
-          rc2 = layout_upload(ch, sys, perm.data(), cap, gs_lean(), &src);
+          rc2 = layout_upload(ch, sys, perm.data(), cap, gs_lean(), &src, g->diag);
           if (rc2 == AMGH_OK && g_gs_sell && !gs_lean()) rc2 = sell_build(ch, sys.prow);
+          if (rc2 == AMGH_OK && gs_trim()) rc2 = child_compact_late(ch, sys.prow, perm.data());
           tm.lap("merged layout", n); dbg_pending("merged layout");
-          if (rc2 == AMGH_OK)
+          if (rc2 == AMGH_OK && !(backward && gs_trim()))   // (trimmed: the backward triangle on first use, csr_gs_sweep)
             rc2 = tri_build_dev(backward ? &g->tri_b : &g->tri_f, g, backward, &g->bytes, 0.0,
                                 backward ? &g->tri_nnz_b : &g->tri_nnz);
           tm.lap("other triangle", n); dbg_pending("other triangle");
@@ -1259,10 +1365,11 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         GsSchedule* ch = new GsSchedule;
         (backward ? g->mb : g->mf) = ch;
         ch->ncols = g->ncols;
-        RC_TRY(layout_upload(ch, keep.sys, perm.data(), cap, gs_lean()));
+        RC_TRY(layout_upload(ch, keep.sys, perm.data(), cap, gs_trim(), nullptr, g->diag));
         tm.lap("merged layout", n); dbg_pending("merged layout");
-        RC_TRY(tri_build_dev(backward ? &g->tri_b : &g->tri_f, g, backward, &g->bytes, 0.0,
-                             backward ? &g->tri_nnz_b : &g->tri_nnz));
+        if (!(backward && gs_trim()))
+          RC_TRY(tri_build_dev(backward ? &g->tri_b : &g->tri_f, g, backward, &g->bytes, 0.0,
+                               backward ? &g->tri_nnz_b : &g->tri_nnz));
         tm.lap("other triangle", n); dbg_pending("other triangle");
         (backward ? g->merge_b : g->merge_f) = best_m;
         g->bytes += ch->bytes;
@@ -1280,15 +1387,15 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         hipFree(o->sp_rowptr); hipFree(o->sp_col); hipFree(o->sp_val);
         *o = GsSchedule::Outer();
       }
-      g->bytes -= 2 * ((int64_t)g->nblk * kBlk * kBlk * 8 + nnz * 12 + (n + 1) * 4);
+      g->bytes -= 2 * ((int64_t)g->nblk * kBlk * kBlk * kRealB + nnz * kEntB + (n + 1) * 4);
       g->nblk = 0;
     } else if (g->nblk > 0) {  // stays on the block path: drop half-built children
       for (GsSchedule** c : {&g->mf, &g->mb})
         if (*c) { g->bytes -= (*c)->bytes; (*c)->free_dev(); delete *c; *c = nullptr; }
     }
     if (g->mf || g->mb) g->xstride = g->ncols + n;
-    if (gs_lean() && g->mf && g->mb && g->nblk == 0 && g->wcol) {
-      // memory-lean: both directions always run merged groups, the un-merged slot copy would only serve a run with
+    if (gs_trim() && g->mf && g->mb && g->nblk == 0 && g->wcol) {
+      // trimmed footprint: both directions always run merged groups, the un-merged slot copy would only serve a run with
       // merging switched off at run time — that run falls back to the CSR stream kernel
       hipFree(g->wcol); hipFree(g->wval); hipFree(g->slot_row); hipFree(g->wmeta);
       g->wcol = g->slot_row = nullptr; g->wval = nullptr; g->wmeta = nullptr;

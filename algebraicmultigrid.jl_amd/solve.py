@@ -152,7 +152,11 @@ class _PreconBuilder:
     def __call__(self, A, p=None):
         ml = type(self)._setup(SparseMatrixCSC.coerce(A), **self.kwargs)
         if self.blocksize > 1:
-            ml.device(nrhs=self.blocksize)   # allocate the n x bs workspace now, as Val{bs} does at setup
+            # allocate the n x bs workspace now, as Val{bs} does at setup — in the hierarchy's own eltype (a Float32
+            # matrix gets the Float32 instance of the library, as eltype(workspace) follows eltype(A), multilevel.jl:36)
+            A0 = ml.levels[0].A if ml.levels else ml.final_A
+            f32 = np.dtype(getattr(A0, "eltype", np.float64)).itemsize == 4
+            ml.device(nrhs=self.blocksize, dtype=np.float32 if f32 else None)
         return aspreconditioner(ml), Identity()
 
 
@@ -161,7 +165,7 @@ class Identity:
 
     def ldiv(self, b, x=None):
         if x is None:
-            return np.array(b, dtype=np.float64, copy=True)
+            return np.array(b, copy=True)   # LinearAlgebra.I keeps the eltype (a Float32 Krylov vector stays Float32)
         x[...] = b
         return x
 

@@ -261,7 +261,7 @@ def main():
             "per_level": [{"fwd": p["fwd"], "bwd": p["bwd"]} for p in sweeps[:6]]},
         "setup_s": t_setup, "upload_s": t_upload, "setup_overlapped_with_upload": bool(overlap),
         **({"overlap_error": overlap_error} if overlap_error else {}),
-        "hbm_bytes": dev.device_bytes(),
+        "hbm_bytes": dev.device_bytes(), "hbm_bytes_by_category": dev.device_bytes_detail(),
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"], z_oracle = cpu_baseline(ml, b, args.cpu_budget)

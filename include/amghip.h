@@ -455,8 +455,11 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
  * Returns AMGH_EINVAL for an unknown name.                                                                       */
 int amgh_debug_set_tunable(const char* name, int value);
 
-/* Replay whole cycles from captured hipGraphs (default off: measured no gain on MI355X,
- * the cycle is GPU-latency-bound; AMGH_USE_GRAPH=1 in the environment also enables it). */
+/* Replay whole cycles from captured hipGraphs.  Default (decided by amgh_finalize): ON for hierarchies
+ * whose widest level has at most 65 536 rows — their cycle is ~100 kernels of a few microseconds and the
+ * host is the bottleneck of eager launches — OFF for larger ones (the host runs far ahead of the device,
+ * a replay buys nothing).  This call, or AMGH_USE_GRAPH=0/1 in the environment, overrides the default
+ * (rocprofv3's kernel tracing aborts on graph replays of this size: profile with AMGH_USE_GRAPH=0).   */
 int amgh_set_use_graph(amgh_t* h, int on);
 
 #ifdef __cplusplus

@@ -141,38 +141,117 @@ def test_w_and_f_cycles_at_128_cubed(h128, cyc):
     assert rel(x, xo) <= 1e-10
 
 
-def test_memory_lean_hierarchy_is_bitwise_the_default_one():
-    """AMGH_LEAN / tunable gs_lean: no un-merged slot copy, no CSR copy of slotted composite rows, no natural-order
-    P / R / coarse A where the cycle runs level-ordered — same kernels on the same numbers, fewer bytes."""
+def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_graphs():
+    """An operator that fits LDS entirely (rows, nonzeros, level descriptors, x, b) runs its chained dependency levels
+    in gs_chain_tiny_kernel — no global memory access per level — with the products and in-order row sums of
+    gs_chain_kernel: bitwise the same sweep.  Hierarchies whose widest level has <= 65 536 rows replay their cycle from a
+    hipGraph by default (they are host-launch bound): bitwise the eager cycle, and PCG on the reference's
+    lin_elastic_2d configuration (nns_test.jl:213-226) keeps its 13 iterations."""
+    from amg_amd.device import DeviceHierarchy
+    from conftest import load_csc, load_npz
+    lib = AMG.hip_lib()
+    d = load_npz("lin_elastic_2d")
+    A = load_csc("lin_elastic_2d")
+    x0, b = uniform(A.m, 3), uniform(A.m, 4)
+    # one stand-alone sweep each way, GS and SOR, both kernels
+    out = {}
+    for tiny in (1, 0):
+        assert lib.amgh_debug_set_tunable(b"gs_tiny", tiny) == 0
+        try:
+            for cfg in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2),
+                        AMG.SOR(1.3, AMG.SymmetricSweep())):
+                xs = x0.copy()
+                AMG.device.smooth_standalone(cfg, A, xs, b)       # in place
+                out[(tiny, repr((type(cfg).__name__, cfg.sweep_code, cfg.iter, cfg.omega)))] = xs
+        finally:
+            lib.amgh_debug_set_tunable(b"gs_tiny", 1)
+    for (tiny, key), v in out.items():
+        if tiny == 1:
+            assert np.array_equal(v, out[(0, key)]), key
+    # the hierarchy: default (graph replay decided by amgh_finalize) vs eager, tiny kernel vs regular chain
+    ml = AMG.smoothed_aggregation(A, B=d["B"])
+    auto = DeviceHierarchy(ml, 0, 1)
+    eager = DeviceHierarchy(ml, 0, 1)
+    assert lib.amgh_set_use_graph(eager.h, 0) == 0
+    z_e = eager.precond_apply(d["b"])
+    for _ in range(4):      # eager warm-up, capture + first replay, replays
+        assert np.array_equal(auto.precond_apply(d["b"]), z_e)
+    lib.amgh_debug_set_tunable(b"gs_tiny", 0)
+    try:
+        assert np.array_equal(DeviceHierarchy(ml, 0, 1).precond_apply(d["b"]), z_e)
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_tiny", 1)
+    assert rel(z_e, O.OracleHierarchy(ml).precond(d["b"])) <= 1e-10
+    xp, log = AMG.cg(A, d["b"], Pl=AMG.aspreconditioner(ml), reltol=1e-10, log=True)
+    xpo, _, itp = O.OracleHierarchy(ml).pcg(d["b"], reltol=1e-10)
+    assert log["iters"] == itp == 13 and rel(xp, xpo) <= 1e-9
+    # a big hierarchy keeps eager launches by default: nothing to check but that the rule reads the sizes
+    # (AMGH_USE_GRAPH in the environment overrides both)
+
+
+def test_footprint_policies_are_bitwise_the_same_hierarchy():
+    """AMGH_LEAN / tunable gs_lean — full (0: every copy kept), trim (2, the default: no un-merged slot copy, no CSR
+    copy of slotted composite rows once the SELL-like build has read it, no natural-order P / R / coarse A where the
+    cycle runs level-ordered, backward pre-pass triangle on first use), lean (1: trim + compaction at layout time, no
+    SELL-like copies): same kernels on the same numbers, fewer bytes."""
     from amg_amd.device import DeviceHierarchy
     lib = AMG.hip_lib()
     A = AMG.poisson((64, 64, 64))
     ml = AMG.ruge_stuben(A)
     b = uniform(A.m, 8)
-    # (the default hierarchy also carries a SELL-like copy of long-row groups whose row sums add in another order;
-    #  the lean one has none: compare like with like)
-    assert lib.amgh_debug_set_tunable(b"gs_sell", 0) == 0
     try:
+        assert lib.amgh_debug_set_tunable(b"gs_lean", 0) == 0
         full = DeviceHierarchy(ml, 0, 1)
+        assert lib.amgh_debug_set_tunable(b"gs_lean", -1) == 0     # the default policy
+        trim = DeviceHierarchy(ml, 0, 1)
+        # (full and trim carry a SELL-like copy of long-row groups whose row sums add in another order; the lean one has
+        #  none: compare like with like)
+        assert lib.amgh_debug_set_tunable(b"gs_sell", 0) == 0
+        assert lib.amgh_debug_set_tunable(b"gs_lean", 0) == 0
+        full_nosell = DeviceHierarchy(ml, 0, 1)
         assert lib.amgh_debug_set_tunable(b"gs_lean", 1) == 0
         lean = DeviceHierarchy(ml, 0, 1)
     finally:
         lib.amgh_debug_set_tunable(b"gs_lean", -1)
         lib.amgh_debug_set_tunable(b"gs_sell", 1)
-    zf, zl = full.precond_apply(b), lean.precond_apply(b)
-    assert np.array_equal(zf, zl)
-    xf, hf, _ = full.solve(b, np.zeros_like(b), 0, 30, 0.0, 1e-8, True, True)
-    xl, hl, _ = lean.solve(b, np.zeros_like(b), 0, 30, 0.0, 1e-8, True, True)
-    assert np.array_equal(xf, xl) and np.array_equal(hf, hl)
-    df, dl = full.device_bytes_detail(), lean.device_bytes_detail()
-    assert dl["unmerged_slots"] < df["unmerged_slots"] and dl["merged_csr"] < 0.2 * df["merged_csr"]
-    assert dl["natural_APR"] < df["natural_APR"]
-    assert lean.device_bytes() < 0.75 * full.device_bytes()
-    assert abs(sum(df.values()) - full.device_bytes()) <= 0.02 * full.device_bytes()   # the categories add up
-    # a released operator is refused, not read
-    with pytest.raises(AMG.AMGError):
-        lean.spmv(1, 0, np.ones(ml.levels[1].A.m))
-    assert np.array_equal(lean.spmv(0, 0, b), full.spmv(0, 0, b))     # the fine-level A stays (outer residual of _solve!)
+    for a, c in ((full, trim), (full_nosell, lean)):
+        if a is full_nosell:
+            lib.amgh_debug_set_tunable(b"gs_sell", 0)
+        try:
+            assert np.array_equal(a.precond_apply(b), c.precond_apply(b))
+            xa, ha, _ = a.solve(b, np.zeros_like(b), 0, 30, 0.0, 1e-8, True, True)
+            xc, hc, _ = c.solve(b, np.zeros_like(b), 0, 30, 0.0, 1e-8, True, True)
+            assert np.array_equal(xa, xc) and np.array_equal(ha, hc)
+        finally:
+            lib.amgh_debug_set_tunable(b"gs_sell", 1)
+    df, dt, dl = full.device_bytes_detail(), trim.device_bytes_detail(), lean.device_bytes_detail()
+    for d in (dt, dl):
+        assert d["unmerged_slots"] < df["unmerged_slots"] and d["natural_APR"] < df["natural_APR"]
+        assert d["prepass_triangles"] < 0.6 * df["prepass_triangles"]      # symmetric sweeps never ask for the backward one
+    assert dl["merged_csr"] < 0.2 * df["merged_csr"] and dt["merged_csr"] < 0.5 * df["merged_csr"]
+    assert trim.device_bytes() < 0.75 * full.device_bytes() and lean.device_bytes() <= trim.device_bytes()
+    for dev, d in ((full, df), (trim, dt)):
+        assert abs(sum(d.values()) - dev.device_bytes()) <= 0.02 * dev.device_bytes()   # the categories add up
+    # the stand-alone hooks of a released natural-order operator go through the level-ordered copy: the same products
+    for lvl in (0, 1):
+        n, nc = ml.levels[lvl].A.m, ml.levels[lvl].P.n
+        xn, xc = uniform(n, 20 + lvl), uniform(nc, 30 + lvl)
+        for dev in (trim, lean):
+            assert np.array_equal(dev.spmv(lvl, 0, xn), full.spmv(lvl, 0, xn))      # A
+            assert np.array_equal(dev.spmv(lvl, 1, xc), full.spmv(lvl, 1, xc))      # P
+            assert np.array_equal(dev.spmv(lvl, 2, xn), full.spmv(lvl, 2, xn))      # R
+    # a smoother that STARTS backward builds the backward pre-pass triangle on first use
+    x0 = uniform(A.m, 9)
+    ml_b = AMG.ruge_stuben(A, presmoother=AMG.GaussSeidel(AMG.BackwardSweep()), postsmoother=AMG.GaussSeidel(AMG.BackwardSweep()))
+    zb = DeviceHierarchy(ml_b, 0, 1).precond_apply(x0)
+    lib.amgh_debug_set_tunable(b"gs_lean", 0)
+    try:
+        zb_full = DeviceHierarchy(ml_b, 0, 1).precond_apply(x0)
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_lean", -1)
+    assert np.array_equal(zb, zb_full)
+    from oracle import oracle as O
+    assert rel(zb, O.OracleHierarchy(ml_b).precond(x0)) <= 1e-10
 
 
 @pytest.mark.parametrize("case", ["poisson3d", "rs_coarse", "irregular"])

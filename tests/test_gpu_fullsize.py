@@ -43,6 +43,32 @@ def c3():
     return A, ml
 
 
+def test_c3_gpu_built_hierarchy_is_the_host_built_one_at_full_size(c3):
+    """What bench.py times (`ruge_stuben(A, setup="gpu", device=0)`: strength, interpolation, transposes and R*A*P on
+    the GPU, the HBM hierarchy built level by level beside the splitting) is THE reference hierarchy, not merely a
+    convergent one: every level's A, P and R equal the host library's (pinned by the reference's setup goldens) bit
+    for bit at 256^3 — structure and values.  At this size the SpGEMM meets columns that outgrow its LDS hash table
+    (the host-library fallback), which the small cases of tests/test_gpu_setup.py never reach."""
+    A, ml = c3
+    g = AMG.ruge_stuben(A, setup="gpu", device=0)
+    assert len(g) == len(ml)
+
+    def same(X, Y):
+        return (X.shape == Y.shape and np.array_equal(X.colptr, Y.colptr) and np.array_equal(X.rowval, Y.rowval)
+                and np.array_equal(X.nzval, Y.nzval))
+    for l, (a, b) in enumerate(zip(ml.levels, g.levels)):
+        assert same(a.A, b.A), f"A differs on level {l}"
+        assert same(a.P, b.P), f"P differs on level {l}"
+        assert same(a.R, b.R), f"R differs on level {l}"
+    assert same(ml.final_A, g.final_A)
+    # and the handle built on the way runs the same cycle as the one built afterwards from the host hierarchy
+    b = uniform(A.m, 0)
+    z_pipe = AMG.aspreconditioner(g).ldiv(b)
+    z_host = AMG.aspreconditioner(ml).ldiv(b)
+    assert np.array_equal(z_pipe, z_host)
+    del g
+
+
 def test_c3_poisson_256cubed_rs_gauss_seidel_full_size(c3):
     A, ml = c3
     n = A.m

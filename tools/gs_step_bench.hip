@@ -403,6 +403,72 @@ double run_dep(const Layout& L, Args a, int K, int cap, bool two_streams, hipStr
   return 1e3 * best / K;
 }
 
+
+// ---- software-pipelined slot walk (round-3 verdict, task 1A): the grid is the RESIDENT capacity (G workgroups), workgroup
+// b walks slots b, b + G, b + 2G, ... of ONE launch with register double buffering: the col / val loads of slot k+2 and the
+// x gather of slot k+1 are issued before the LDS row sums of slot k (two s_prod buffers: one barrier per slot).
+template <int T>
+__global__ __launch_bounds__(T) void slot_pipe_kernel(Args a) {
+  __shared__ double s_prod[2][T];
+  const int tid = threadIdx.x;
+  const int G = gridDim.x;
+  int lb = blockIdx.x;
+  if (lb >= a.nslots) return;
+  // prologue: slot 0's entries, slot 1's entries, slot 0's gather
+  long long base0 = a.ent0 + (long long)lb * T;
+  double v0 = a.wval[base0 + tid]; int c0 = a.wcol[base0 + tid];
+  int r00 = a.slot_row[2 * (a.slot0 + lb)], r01 = a.slot_row[2 * (a.slot0 + lb) + 1];
+  double v1 = 0.0; int c1 = 0; int r10 = 0, r11 = 0; long long base1 = 0;
+  const bool has1 = lb + G < a.nslots;
+  if (has1) { base1 = a.ent0 + (long long)(lb + G) * T; v1 = a.wval[base1 + tid]; c1 = a.wcol[base1 + tid];
+              r10 = a.slot_row[2 * (a.slot0 + lb + G)]; r11 = a.slot_row[2 * (a.slot0 + lb + G) + 1]; }
+  double x0 = a.x[c0];
+  i4_t m0 = i4_t{0, 0, -1, 0}; double d0 = 0.0, b0 = 0.0;
+  if (tid < r01 - r00) { m0 = a.wmeta[r00 + tid]; d0 = a.diag[r00 + tid]; b0 = a.bp[r00 + tid]; }
+  int buf = 0;
+  for (;; lb += G) {
+    // issue: entries of slot lb + 2G, gather + row data of slot lb + G
+    double v2 = 0.0; int c2 = 0; int r20 = 0, r21 = 0; long long base2 = 0;
+    const bool cur1 = lb + G < a.nslots, has2 = lb + 2 * G < a.nslots;
+    if (has2) { base2 = a.ent0 + (long long)(lb + 2 * G) * T; v2 = a.wval[base2 + tid]; c2 = a.wcol[base2 + tid];
+                r20 = a.slot_row[2 * (a.slot0 + lb + 2 * G)]; r21 = a.slot_row[2 * (a.slot0 + lb + 2 * G) + 1]; }
+    double x1 = 0.0; i4_t m1 = i4_t{0, 0, -1, 0}; double d1 = 0.0, b1 = 0.0;
+    if (cur1) { x1 = a.x[c1]; if (tid < r11 - r10) { m1 = a.wmeta[r10 + tid]; d1 = a.diag[r10 + tid]; b1 = a.bp[r10 + tid]; } }
+    // finish slot lb
+    s_prod[buf][tid] = v0 * x0;
+    __syncthreads();
+    const int nrows = r01 - r00;
+    if (tid < nrows) {
+      double acc = 0.0;
+      const int lo = (int)(m0.x - base0), hi = (int)(m0.y - base0);
+      for (int j = lo; j < hi; ++j) acc += s_prod[buf][j];
+      if (d0 != 0.0) a.x[r00 + tid] = (b0 - acc) / d0;
+    }
+    if (!cur1) break;
+    buf ^= 1;
+    v0 = v1; c0 = c1; x0 = x1; m0 = m1; d0 = d1; b0 = b1; r00 = r10; r01 = r11; base0 = base1;
+    v1 = v2; c1 = c2; r10 = r20; r11 = r21; base1 = base2;
+  }
+}
+template <int T>
+double run_pipe(const Layout& L, Args a, int K, int G, hipStream_t st, std::vector<double>* out, long long n, const std::vector<double>& x0) {
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipMemcpyAsync(a.x, x0.data(), 8 * n, hipMemcpyHostToDevice, st));
+    CHECK(hipStreamSynchronize(st));
+    CHECK(hipEventRecord(e0, st));
+    for (int k = 0; k < K; ++k) {
+      Args b = a; b.ent0 = L.ent0[k]; b.nslots = L.nslots[k]; b.slot0 = L.slot0[k]; b.xcd = 0;
+      hipLaunchKernelGGL((slot_pipe_kernel<T>), dim3(std::min(G, b.nslots)), dim3(T), 0, st, b);
+    }
+    CHECK(hipEventRecord(e1, st)); CHECK(hipStreamSynchronize(st));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+  }
+  if (out) { out->resize(n); CHECK(hipMemcpy(out->data(), a.x, 8 * n, hipMemcpyDeviceToHost)); }
+  return 1e3 * best / K;
+}
+
 __global__ void empty_kernel(double* x) { if (x == nullptr) x[0] = 1.0; }
 
 
@@ -521,7 +587,7 @@ int main(int argc, char** argv) {
   for (int pat = 1; pat >= 1; --pat)
   for (int LEN : {10, 27, 60}) {
     g_pattern = pat;
-    for (int R : {6400, 22000, 65000, 130000}) {
+    for (int R : {6400, 22000, 45000, 65000, 130000}) {
       if (LEN == 60 && R > 22000) continue;
       if (LEN == 100 && R > 6400) continue;
       if (pat == 0 && !(R == 65000 && LEN == 10) && !(R == 22000 && LEN == 27)) continue;
@@ -547,6 +613,15 @@ int main(int argc, char** argv) {
           report("T512 E1 graph xcd", run<512, 1, 0>(L, a, K, true, 1, st, &got, n, x0), &got);
           report("T256 E2 eager xcd", run<256, 2, 0>(L, a, K, false, 1, st, &got, n, x0), &got);
           report("T512 E1 no-gather", run<512, 1, 1>(L, a, K, false, 1, st, nullptr, n, x0), nullptr);
+          for (int G : {512, 768, 1024, 2048}) {
+            char nm[64]; snprintf(nm, sizeof nm, "PIPE T512 grid %d", G);
+            report(nm, run_pipe<512>(L, a, K, G, st, &got, n, x0), &got);
+          }
+          for (int G : {1024, 2048}) {
+            char nm[64]; snprintf(nm, sizeof nm, "PIPE T256 grid %d (S=512!)", G);
+            (void)nm; (void)G;
+          }
+          if (!getenv("FULL")) { report("T512 E1 loads-only", run<512, 1, 2>(L, a, K, false, 1, st, nullptr, n, x0), nullptr); hipFree((void*)a.wcol); hipFree((void*)a.wval); hipFree((void*)a.slot_row); hipFree((void*)a.wmeta); continue; }
           {
             int herr = 0;
             double t1 = run_dep<512, 1>(L, a, K, 480, false, st, st2, &got, n, x0, &herr);
