@@ -169,21 +169,8 @@ def _bind_solve_phase(L, creal, coarse_fn):
     L.amgh_set_use_graph.argtypes = [vp, C.c_int]
 
 
-def hip_lib(dtype=None):
-    """Load libamghip.so (dtype None / float64) or its Float32 instance libamghip_f32.so (dtype float32).
-    Raises AMGError if it has not been built."""
-    global _hip
-    if dtype is not None and _np_dtype(dtype).itemsize == 4:
-        return hip_lib_f32()
-    if _hip is not None:
-        return _hip
-    if not os.path.exists(HIP_SO):
-        raise AMGError(f"{HIP_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                       "(the solve phase has no CPU fallback)")
-    L = C.CDLL(HIP_SO)
-    L.real_dtype = "float64"
-    _bind_solve_phase(L, C.c_double, COARSE_FN)
-    # row-sharded hierarchy (amgh_dist_*)
+def _bind_dist(L):
+    """argtypes of the row-sharded hierarchy (amgh_dist_*, amgh_local_group_*): both instances of the library."""
     i64p = C.POINTER(i64)
     L.amgh_dist_rccl_available.argtypes = []
     L.amgh_dist_unique_id.argtypes = [vp]
@@ -216,6 +203,23 @@ def hip_lib(dtype=None):
     L.amgh_dist_stream.argtypes = [vp]
     L.amgh_dist_plan_info.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.amgh_dist_plan_info2.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+
+
+def hip_lib(dtype=None):
+    """Load libamghip.so (dtype None / float64) or its Float32 instance libamghip_f32.so (dtype float32).
+    Raises AMGError if it has not been built."""
+    global _hip
+    if dtype is not None and _np_dtype(dtype).itemsize == 4:
+        return hip_lib_f32()
+    if _hip is not None:
+        return _hip
+    if not os.path.exists(HIP_SO):
+        raise AMGError(f"{HIP_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(the solve phase has no CPU fallback)")
+    L = C.CDLL(HIP_SO)
+    L.real_dtype = "float64"
+    _bind_solve_phase(L, C.c_double, COARSE_FN)
+    _bind_dist(L)
     # GPU half of the setup phase (amgh_dmat_*, amgh_setup_*)
     L.amgh_dmat_upload.argtypes = [C.POINTER(vp), C.c_int, i64, i64, vp, vp, vp]
     L.amgh_dmat_download.argtypes = [vp, vp, vp, vp]
@@ -250,6 +254,7 @@ def hip_lib_f32():
     L = C.CDLL(HIP_F32_SO)
     L.real_dtype = "float32"
     _bind_solve_phase(L, C.c_float, COARSE_FN_F32)
+    _bind_dist(L)
     _hip_f32 = L
     return L
 

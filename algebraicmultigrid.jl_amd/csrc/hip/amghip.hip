@@ -25,6 +25,7 @@ struct Level {
   bool has_S = false;  // S distinct from A
   amgh_smoother_t pre{}, post{};
   real *res = nullptr, *cx = nullptr, *cb = nullptr, *tmp = nullptr;
+  real* il = nullptr;   // blocks of right-hand sides: interleaved copy of what R / P gather (max(n, nc) x bs)
   amgh_csr* smat() { return has_S ? &S : &A; }
   // level-ordered cycle (x stays in the smoother's dependency-level order between pre- and post-smoother):
   // P with its rows in that order, R with its columns renumbered to it; A in that order is the schedule's own copy
@@ -246,7 +247,10 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo
     }
     {
       ProfScope p(h, AMGH_T_RESTRICT, l);
-      RC_TRY(csr_apply(&L->Rp, M_SPMV, L->res, nullptr, C ? cg->bp : L->cb, h->stream, bs));
+      if (L->il && il_block(bs))
+        RC_TRY(il_apply(bs, false, L->Rp.rowptr, L->Rp.col, L->Rp.val, nc, L->res, n, n, L->il, C ? cg->bp : L->cb, nc, h->stream));
+      else
+        RC_TRY(csr_apply(&L->Rp, M_SPMV, L->res, nullptr, C ? cg->bp : L->cb, h->stream, bs));
       if (C) cg->bp_cols = bs;          // the next level's level-ordered right-hand side is in place
     }
     if (!C) RC_TRY(vec_fill(h, L->cx, nc * bs, 0.0));
@@ -258,8 +262,12 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo
     }
     {
       ProfScope p(h, AMGH_T_PROLONG, l);  // x += P e on the level-ordered x
-      RC_TRY(raw_apply(M_ADD, L->Pp.rowptr, L->Pp.col, L->Pp.val, n, C ? cg->xp : L->cx, C ? cg->xstride : nc, nullptr, 0, g->xp,
-                       xs, h->stream, bs));
+      if (L->il && il_block(bs))
+        RC_TRY(il_apply(bs, true, L->Pp.rowptr, L->Pp.col, L->Pp.val, n, C ? cg->xp : L->cx, nc, C ? cg->xstride : nc, L->il,
+                        g->xp, xs, h->stream));
+      else
+        RC_TRY(raw_apply(M_ADD, L->Pp.rowptr, L->Pp.col, L->Pp.val, n, C ? cg->xp : L->cx, C ? cg->xstride : nc, nullptr, 0, g->xp,
+                         xs, h->stream, bs));
     }
     {
       ProfScope p(h, AMGH_T_POSTSMOOTH, l);
@@ -273,7 +281,10 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo
   }
   {
     ProfScope p(h, AMGH_T_RESTRICT, l);
-    RC_TRY(csr_apply(&L->R, M_SPMV, L->res, nullptr, L->cb, h->stream, bs));
+    if (L->il && il_block(bs))
+      RC_TRY(il_apply(bs, false, L->R.rowptr, L->R.col, L->R.val, nc, L->res, n, n, L->il, L->cb, nc, h->stream));
+    else
+      RC_TRY(csr_apply(&L->R, M_SPMV, L->res, nullptr, L->cb, h->stream, bs));
   }
   RC_TRY(vec_fill(h, L->cx, nc * bs, 0.0));
   if (l == (int)h->levels.size() - 1) {
@@ -284,7 +295,10 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo
   }
   {
     ProfScope p(h, AMGH_T_PROLONG, l);
-    RC_TRY(csr_apply(&L->P, M_ADD, L->cx, nullptr, xc, h->stream, bs));
+    if (L->il && il_block(bs))
+      RC_TRY(il_apply(bs, true, L->P.rowptr, L->P.col, L->P.val, n, L->cx, nc, nc, L->il, xc, n, h->stream));
+    else
+      RC_TRY(csr_apply(&L->P, M_ADD, L->cx, nullptr, xc, h->stream, bs));
   }
   {
     ProfScope p(h, AMGH_T_POSTSMOOTH, l);
@@ -543,7 +557,7 @@ void amgh_destroy(amgh_t* h) {
   if (h->pending_level) level_discard(h->pending_level);
   for (Level* L : h->levels) {
     csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
-    hipFree(L->res); hipFree(L->cx); hipFree(L->cb); hipFree(L->tmp); hipFree(L->lo_val);
+    hipFree(L->res); hipFree(L->cx); hipFree(L->cb); hipFree(L->tmp); hipFree(L->lo_val); hipFree(L->il);
     delete L;
   }
   csr_free(&h->finalA);
@@ -908,6 +922,10 @@ int amgh_finalize(amgh_t* h) {
     RC_TRY(dev_alloc(&L->cx, L->nc * h->nrhs));
     RC_TRY(dev_alloc(&L->cb, L->nc * h->nrhs));
     ws += kRealB * (L->n + 2 * L->nc) * h->nrhs;
+    if (h->nrhs == 2 || h->nrhs == 4 || h->nrhs == 8 || h->nrhs == 16) {
+      RC_TRY(dev_alloc(&L->il, std::max(L->n, L->nc) * h->nrhs));
+      ws += kRealB * std::max(L->n, L->nc) * h->nrhs;
+    }
     if (L->pre.kind == AMGH_SMOOTH_JACOBI || L->post.kind == AMGH_SMOOTH_JACOBI) {
       RC_TRY(dev_alloc(&L->tmp, L->n * h->nrhs));
       ws += kRealB * L->n * h->nrhs;
@@ -1544,6 +1562,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_sell")) g_gs_sell = value;
   else if (!strcmp(name, "gs_sample")) g_gs_sample = value;
   else if (!strcmp(name, "gs_tiny")) g_gs_tiny = value;
+  else if (!strcmp(name, "rhs_il")) g_rhs_il = value;
   else if (!strcmp(name, "gs_ept")) g_gs_ept = value;
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_merge_force")) g_gs_merge_force = value;
@@ -1601,13 +1620,10 @@ int amgh_set_use_graph(amgh_t* h, int on) {
 
 }  // extern "C"
 
-// the row-sharded cycle and the GPU half of the setup are Float64 only: the Float32 instance (-DAMGH_REAL=float
-// -DAMGH_SOLVE_ONLY) carries the solve-phase handle and the stand-alone operators
-#ifndef AMGH_SOLVE_ONLY
+// the row-sharded cycle is written in amgh::real like the solve phase: both instances of the library carry it.  The GPU
+// half of the setup is Float64 only (a Float32 hierarchy is built in Float64 and rounded once): the
+// Float32 instance (-DAMGH_REAL=float -DAMGH_NO_SETUP) leaves it out.
 #include "amghip_dist.hpp"
-#else
-const char* amgh_rccl_error_string(int) { return "(no row-sharded path in this instance)"; }
-#endif
-#ifndef AMGH_SOLVE_ONLY
+#ifndef AMGH_NO_SETUP
 #include "amghip_setup.hpp"
 #endif

@@ -585,6 +585,54 @@ __global__ __launch_bounds__(T) void gs_chain_tiny_kernel(ChainArgs a, int n, in
   for (int r = tid; r < n; r += T) a.x[r] = s_x[r];
 }
 
+// ---- restriction / prolongation of a BLOCK of right-hand sides -------------------------------------------------------
+// In the level-ordered cycle the gathers of R and P are one 64-byte sector per matrix entry (a coarse row's fine
+// neighbours sit in different dependency levels, tools/order_probe.py): column by column a block of bs right-hand sides
+// pays that bs times (bs = 8: 3.3 + 3.4 ms on the fine level of the 256^3 hierarchy).  With the gathered vector stored
+// INTERLEAVED (the bs values of a row side by side: one sector for bs = 8) one gather serves every column: BS lanes per
+// row, lane q multiplies column q.  Each lane walks its row's entries in index order with strictly ordered adds — the
+// sums of the single-column stream kernel, bit for bit.
+template <int BS>
+__global__ __launch_bounds__(256) void to_interleaved_kernel(const real* __restrict__ src, int64_t ld, real* __restrict__ dst,
+                                                             int64_t n) {
+  __shared__ real tile[BS][65];
+  const int64_t i0 = (int64_t)blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * BS; e += 256) {
+    const int q = e >> 6, r = e & 63;
+    if (i0 + r < n) tile[q][r] = src[i0 + r + (int64_t)q * ld];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * BS; e += 256) {
+    const int r = e / BS, q = e % BS;
+    if (i0 + r < n) dst[(i0 + r) * BS + q] = tile[q][r];
+  }
+}
+// y[:, q] = M xil[:, q] (ADD = false) or y[:, q] += M xil[:, q]: xil interleaved (ncols x BS), y column-major (ldy apart)
+template <bool ADD, int BS>
+__global__ __launch_bounds__(256) void csr_il_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     const real* __restrict__ val, int64_t nrows, const real* __restrict__ xil,
+                                                     real* __restrict__ y, int64_t ldy) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / BS;
+  const int q = (int)(t % BS);
+  if (row >= nrows) return;
+  const int32_t j0 = rowptr[row], j1 = rowptr[row + 1];
+  real acc = 0.0;
+  int32_t j = j0;
+  for (; j + 4 <= j1; j += 4) {   // four entries' loads in flight, adds in index order
+    int32_t c[4]; real v[4], xv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { c[e] = col[j + e]; v[e] = val[j + e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] = xil[(int64_t)c[e] * BS + q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += v[e] * xv[e];
+  }
+  for (; j < j1; ++j) acc += val[j] * xil[(int64_t)col[j] * BS + q];
+  real* yp = y + row + (int64_t)q * ldy;
+  *yp = ADD ? *yp + acc : acc;
+}
+
 // ---- one WIDE dependency level from the slot layout -------------------------------------------
 // A wide level's launch is latency-bound: kernarg -> row pointers -> col/val -> x gather are four
 // dependent round trips.  The slot layout removes one: the level's nonzeros are packed into slots of

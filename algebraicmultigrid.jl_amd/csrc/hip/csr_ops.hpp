@@ -140,6 +140,34 @@ int raw_apply(int mode, const int32_t* rowptr, const int32_t* col, const real* v
   return AMGH_EINVAL;
 }
 
+// y = M x / y += M x for a block of bs in {2, 4, 8, 16} right-hand sides through the interleaved copy of x (csr_il_kernel):
+// x: nx rows, ldx apart, column-major; il: scratch of nx * bs reals.  Returns AMGH_EUNSUPPORTED for other block sizes.
+template <int BS>
+int il_apply_t(bool add, const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x, int64_t nx,
+               int64_t ldx, real* il, real* y, int64_t ldy, hipStream_t st) {
+  if (nx > 0)
+    hipLaunchKernelGGL((to_interleaved_kernel<BS>), dim3((unsigned)((nx + 63) / 64)), dim3(256), 0, st, x, ldx, il, nx);
+  const int64_t threads = nrows * BS;
+  if (threads > 0) {
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (add) hipLaunchKernelGGL((csr_il_kernel<true, BS>), dim3(grid), dim3(256), 0, st, rowptr, col, val, nrows, (const real*)il, y, ldy);
+    else hipLaunchKernelGGL((csr_il_kernel<false, BS>), dim3(grid), dim3(256), 0, st, rowptr, col, val, nrows, (const real*)il, y, ldy);
+  }
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+int il_apply(int bs, bool add, const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x,
+             int64_t nx, int64_t ldx, real* il, real* y, int64_t ldy, hipStream_t st) {
+  switch (bs) {
+    case 2: return il_apply_t<2>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st);
+    case 4: return il_apply_t<4>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st);
+    case 8: return il_apply_t<8>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st);
+    case 16: return il_apply_t<16>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st);
+  }
+  return AMGH_EUNSUPPORTED;
+}
+inline bool il_block(int bs) { return g_rhs_il && (bs == 2 || bs == 4 || bs == 8 || bs == 16); }
+
 template <int NCV>
 int launch_slot_t(const SlotArgs& sa, bool sor, int grid, hipStream_t st) {
   if (sor) hipLaunchKernelGGL((gs_slot_kernel<true, NCV>), dim3(grid), dim3(kSlot), 0, st, sa);

@@ -1086,7 +1086,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
                                 prev_max > 440 ? 2 : prev_max > 110 ? 1 : 0, stride);
           prev_max = md.max_row;
           if (rc2 != AMGH_OK) break;
-          sampled[dir] = stride > 1;
+          const bool md_sampled = stride > 1;
           if (stride > 1 && !md.failed)   // scale the sample to the operator
             md.total = (int64_t)((double)md.total * (double)n / (double)std::max<int64_t>(1, md.sampled_rows));
           if (!md.failed) fill[dir][m] = (double)md.total / (double)n;
@@ -1121,6 +1121,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
             best = c; chosen_m[dir] = m; chosen_cap[dir] = cap; worse = 0;
             chosen[dir].free_dev();
             chosen[dir] = std::move(md);
+            sampled[dir] = md_sampled;   // (of the candidate that is KEPT: the stride varies with the number of groups)
             md = MergeDev();
           } else {
             md.free_dev();

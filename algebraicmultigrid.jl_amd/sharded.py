@@ -92,19 +92,19 @@ def load_levels(dirpath):
     return out
 
 
-def _rows(csr, r0, r1):
+def _rows(csr, r0, r1, dtype=np.float64):
     rp, ci, va = csr
     lo, hi = int(rp[r0]), int(rp[r1])
     rowptr = (np.asarray(rp[r0:r1 + 1], dtype=np.int64) - lo).astype(np.int32)
     return (np.ascontiguousarray(rowptr), np.ascontiguousarray(ci[lo:hi], dtype=np.int32),
-            np.ascontiguousarray(va[lo:hi], dtype=np.float64))
+            np.ascontiguousarray(va[lo:hi], dtype=dtype))
 
 
 class LocalGroup:
     """Rendezvous area of N ranks living in one process (amgh_local_group_*)."""
 
-    def __init__(self, nranks):
-        self.lib = require_gpu()
+    def __init__(self, nranks, dtype=np.float64):
+        self.lib = require_gpu(dtype)      # (the group belongs to the library instance whose handles will use it)
         self.n = int(nranks)
         g = C.c_void_p()
         hip_check(self.lib.amgh_local_group_create(C.byref(g), self.n), "local_group_create")
@@ -139,12 +139,15 @@ class ShardedHierarchy:
     transport : ("rccl", id_bytes), ("ipc", "/fresh_shm_name") or ("local", LocalGroup)
     device < 0 (IPC transport only): plans only — the collective setup in host memory, no GPU anywhere; the solve
     entry points are unavailable, `plan_info` is what such a handle is for.
+    dtype : float64 (default) or float32 = the Float32 instance of the library (the hierarchy's values are rounded
+    once, every vector and every operation of the sharded cycle is Float32).
     """
 
-    def __init__(self, levels, n_tail, tail, rank, nranks, device, transport):
+    def __init__(self, levels, n_tail, tail, rank, nranks, device, transport, dtype=np.float64):
         self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
         self.plans_only = self.device < 0
-        self.lib = hip_lib() if self.plans_only else require_gpu()
+        self.dtype = np.dtype(np.float32 if np.dtype(dtype).itemsize == 4 else np.float64)
+        self.lib = hip_lib(self.dtype) if self.plans_only else require_gpu(self.dtype)
         h = C.c_void_p()
         kind, arg = transport
         if self.plans_only and kind != "ipc":
@@ -170,10 +173,10 @@ class ShardedHierarchy:
             rc, cc = self.cuts[l], self.cuts[l + 1]
             r0, r1 = int(rc[self.rank]), int(rc[self.rank + 1])
             c0, c1 = int(cc[self.rank]), int(cc[self.rank + 1])
-            A = _rows(d["A"], r0, r1)
-            S = _rows(d["S"], r0, r1) if d["S"] is not None else (None, None, None)
-            P = _rows(d["P"], r0, r1)
-            R = _rows(d["R"], c0, c1)
+            A = _rows(d["A"], r0, r1, self.dtype)
+            S = _rows(d["S"], r0, r1, self.dtype) if d["S"] is not None else (None, None, None)
+            P = _rows(d["P"], r0, r1, self.dtype)
+            R = _rows(d["R"], c0, c1, self.dtype)
             pre = amgh_smoother_t(d["pre"][0], d["pre"][1], d["pre"][2], 0, d["pre"][3])
             post = amgh_smoother_t(d["post"][0], d["post"][1], d["post"][2], 0, d["post"][3])
             ptr = lambda a: a.ctypes.data if a is not None else None  # noqa: E731
@@ -183,7 +186,7 @@ class ShardedHierarchy:
                 C.byref(pre), C.byref(post)), "dist_push_level")
         self.tail = None
         if tail is not None and not self.plans_only:
-            self.tail = DeviceHierarchy(tail, self.device)
+            self.tail = DeviceHierarchy(tail, self.device, 1, self.dtype)
             hip_check(self.lib.amgh_dist_set_tail(self.h, self.tail.h), "dist_set_tail")
         hip_check(self.lib.amgh_dist_finalize(self.h), "dist_finalize")
         r0, r1 = C.c_int64(0), C.c_int64(0)
@@ -191,11 +194,11 @@ class ShardedHierarchy:
         self.r0, self.r1 = r0.value, r1.value
         self.nloc = self.r1 - self.r0
         if not self.plans_only:
-            self._b = DeviceBuffer(max(self.nloc, 1), self.device)
-            self._x = DeviceBuffer(max(self.nloc, 1), self.device)
+            self._b = DeviceBuffer(max(self.nloc, 1), self.device, dtype=self.dtype)
+            self._x = DeviceBuffer(max(self.nloc, 1), self.device, dtype=self.dtype)
 
     @classmethod
-    def from_multilevel(cls, ml, rank, nranks, device, transport, shard_min_rows=200_000):
+    def from_multilevel(cls, ml, rank, nranks, device, transport, shard_min_rows=200_000, dtype=np.float64):
         """Every rank holds (or maps) the whole host hierarchy; only rank 0 needs the collapsed levels."""
         if not isinstance(ml, MultiLevel):
             raise AMGError("ml must be a MultiLevel")
@@ -205,7 +208,7 @@ class ShardedHierarchy:
         if rank == 0:
             tail = MultiLevel(ml.levels[lc:], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
                               ml.symmetry, method=ml.method)
-        return cls(level_arrays(ml, lc), sizes[lc], tail, rank, nranks, device, transport)
+        return cls(level_arrays(ml, lc), sizes[lc], tail, rank, nranks, device, transport, dtype)
 
     def close(self):
         """Destroy the sharded handle first (it borrows the collapsed levels' handle), then the tail."""
@@ -227,16 +230,16 @@ class ShardedHierarchy:
         return r0.value, r1.value
 
     def _up(self, buf, host):
-        host = np.ascontiguousarray(host, dtype=np.float64)
+        host = np.ascontiguousarray(host, dtype=self.dtype)
         if host.size != self.nloc:
             raise AMGError(f"expected {self.nloc} local entries, got {host.size}")
         if self.nloc:
-            hip_check(self.lib.amgh_dev_upload(self.device, buf.ptr, host.ctypes.data, 8 * self.nloc), "upload")
+            hip_check(self.lib.amgh_dev_upload(self.device, buf.ptr, host.ctypes.data, self.dtype.itemsize * self.nloc), "upload")
 
     def _down(self, buf):
-        out = np.empty(self.nloc, dtype=np.float64)
+        out = np.empty(self.nloc, dtype=self.dtype)
         if self.nloc:
-            hip_check(self.lib.amgh_dev_download(self.device, out.ctypes.data, buf.ptr, 8 * self.nloc), "download")
+            hip_check(self.lib.amgh_dev_download(self.device, out.ctypes.data, buf.ptr, self.dtype.itemsize * self.nloc), "download")
         return out
 
     def set_rhs(self, b_local):
@@ -255,10 +258,10 @@ class ShardedHierarchy:
     def solve(self, b_local, cycle=CYCLE_V, maxiter=100, abstol=0.0, reltol=None, x0_local=None,
               calculate_residual=True):
         """_solve (multilevel.jl:152-198); returns (x_local, residual history)."""
-        reltol = float(np.sqrt(np.finfo(np.float64).eps)) if reltol is None else float(reltol)
+        reltol = float(np.sqrt(np.finfo(self.dtype).eps)) if reltol is None else float(reltol)
         self.set_rhs(b_local)
         self._up(self._x, np.zeros(self.nloc) if x0_local is None else x0_local)
-        hist = np.zeros(maxiter + 1, dtype=np.float64)
+        hist = np.zeros(maxiter + 1, dtype=self.dtype)
         iters = C.c_int(0)
         hip_check(self.lib.amgh_dist_solve_d(self.h, self._b.ptr, self._x.ptr, cycle, maxiter, abstol, reltol,
                                              int(bool(calculate_residual)), hist.ctypes.data, C.byref(iters)), "dist_solve")
@@ -269,16 +272,17 @@ class ShardedHierarchy:
         """y = A_level x on this rank's rows (halo exchange included)."""
         r0, r1 = self.local_range(level)
         n = r1 - r0
-        xd = DeviceBuffer(max(n, 1), self.device)
-        yd = DeviceBuffer(max(n, 1), self.device)
+        xd = DeviceBuffer(max(n, 1), self.device, dtype=self.dtype)
+        yd = DeviceBuffer(max(n, 1), self.device, dtype=self.dtype)
+        isz = self.dtype.itemsize
         if n:
-            x_local = np.ascontiguousarray(x_local, dtype=np.float64)
-            hip_check(self.lib.amgh_dev_upload(self.device, xd.ptr, x_local.ctypes.data, 8 * n), "upload")
+            x_local = np.ascontiguousarray(x_local, dtype=self.dtype)
+            hip_check(self.lib.amgh_dev_upload(self.device, xd.ptr, x_local.ctypes.data, isz * n), "upload")
         hip_check(self.lib.amgh_dist_spmv_d(self.h, level, xd.ptr, yd.ptr), "dist_spmv")
         self.sync()
-        out = np.empty(n, dtype=np.float64)
+        out = np.empty(n, dtype=self.dtype)
         if n:
-            hip_check(self.lib.amgh_dev_download(self.device, out.ctypes.data, yd.ptr, 8 * n), "download")
+            hip_check(self.lib.amgh_dev_download(self.device, out.ctypes.data, yd.ptr, isz * n), "download")
         return out
 
     def sync(self):
@@ -311,11 +315,11 @@ class ShardedHierarchy:
                     interior=(int(cnt[3]), int(cnt[4])))
 
 
-def run_local_ranks(nranks, fn, devices=None):
+def run_local_ranks(nranks, fn, devices=None, dtype=np.float64):
     """Run fn(rank, group) on `nranks` threads of this process (LOCAL transport; ctypes releases the GIL inside the
     library, the collectives rendezvous in C++).  Returns the list of results; the first exception is re-raised and
     releases every rank blocked in a collective."""
-    group = LocalGroup(nranks)
+    group = LocalGroup(nranks, dtype)
     out, err = [None] * nranks, [None] * nranks
 
     def work(r):

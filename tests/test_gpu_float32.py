@@ -40,7 +40,8 @@ def test_the_float32_instance_is_a_different_library_with_the_same_entry_points(
                  "amgh_finalize", "amgh_solve", "amgh_solve_d", "amgh_precond_apply_d", "amgh_pcg", "amgh_cycle_d",
                  "amgh_level_spmv", "amgh_level_smooth", "amgh_csr_create", "amgh_csr_gs_d", "amgh_dot_d"):
         assert hasattr(l32, name), name
-    assert not hasattr(l32, "amgh_dist_create_rccl")      # the row-sharded path is Float64 only
+    assert hasattr(l32, "amgh_dist_create_rccl") and hasattr(l32, "amgh_dist_create_ipc")   # the row-sharded path too
+    assert not hasattr(l32, "amgh_setup_spgemm")          # the GPU half of the setup is Float64 only
 
 
 def test_standalone_operators_in_float32():
@@ -156,3 +157,38 @@ def test_float32_handle_keeps_exact_order_sweeps_where_float64_inverts_blocks():
     levels = [d32.gs_dependency_levels(l) for l in range(L)]
     assert levels == [d64.gs_dependency_levels(l) for l in range(L)]
     assert all(s32 >= s64 for s32, s64 in zip(steps32, steps64))
+
+
+def test_row_sharded_cycle_in_float32():
+    """The sharded path of the Float32 instance (amgh_dist_* with amgh_real = float): Jacobi-smoothed hierarchy on 2
+    and 4 virtual ranks against the Float32 oracle (exact across shards, up to Float32 rounding), Gauss-Seidel against
+    the Float64 sharded run."""
+    from amg_amd import sharded as SH
+    A = AMG.poisson((32, 24, 20))
+    A32 = as_f32_matrix(A)
+    b = uniform(A.m, 5).astype(F32)
+    jac = AMG.Jacobi(2.0 / 3.0, iter=2)
+    ml = AMG.ruge_stuben(A32, presmoother=jac, postsmoother=jac)
+    for nranks in (2, 4):
+        def work(rank, group):
+            sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, 0, ("local", group), 500, dtype=F32)
+            x, hist = sh.solve(b[sh.r0:sh.r1], maxiter=4, calculate_residual=True, reltol=1e-30)
+            z = sh.precond_apply(b[sh.r0:sh.r1])
+            return x, hist, z, sh.lc
+        res = SH.run_local_ranks(nranks, work, dtype=F32)
+        x = np.concatenate([r[0] for r in res])
+        z = np.concatenate([r[2] for r in res])
+        assert x.dtype == F32 and res[0][1].dtype == F32 and res[0][3] >= 2
+        oh = O.OracleHierarchy(ml, dtype=F32)
+        xo, ho, _ = oh.solve(b, maxiter=4, reltol=1e-30)
+        assert rel(x, xo) <= F32_TOL and np.allclose(res[0][1], ho, rtol=1e-3)
+        assert rel(z, oh.precond(b)) <= F32_TOL
+    # default smoother: the frozen-halo hybrid in Float32 stays within Float32 rounding of its Float64 run
+    ml_gs = AMG.ruge_stuben(A32)
+    out = {}
+    for dt in (F32, np.float64):
+        def work(rank, group, dt=dt):
+            sh = SH.ShardedHierarchy.from_multilevel(ml_gs, rank, 2, 0, ("local", group), 500, dtype=dt)
+            return sh.precond_apply(b[sh.r0:sh.r1].astype(dt))
+        out[np.dtype(dt).name] = np.concatenate(SH.run_local_ranks(2, work, dtype=dt))
+    assert out["float32"].dtype == F32 and rel(out["float32"], out["float64"]) <= F32_TOL

@@ -528,7 +528,13 @@ def test_block_of_right_hand_sides_on_long_row_groups_equals_single_columns_bitw
     try:
         Z = AMG.aspreconditioner(ml).ldiv(B)
         singles = [AMG.aspreconditioner(ml).ldiv(B[:, c].copy()) for c in range(bs)]
+        # blocks of 2 / 4 / 8 / 16 columns restrict and prolong through an INTERLEAVED copy of the gathered vector (one
+        # sector serves every column); column by column (rhs_il = 0) must give the same bits
+        assert lib.amgh_debug_set_tunable(b"rhs_il", 0) == 0
+        Z_cols = AMG.aspreconditioner(ml).ldiv(B)
+        assert np.array_equal(Z, Z_cols)
     finally:
+        lib.amgh_debug_set_tunable(b"rhs_il", 1)
         lib.amgh_debug_set_tunable(b"gs_lpr", 0)
         lib.amgh_debug_set_tunable(b"gs_ept", 0)
     oh = O.OracleHierarchy(ml)
