@@ -242,8 +242,11 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo
     {
       ProfScope p(h, AMGH_T_RESIDUAL, l);  // r = b - A x, everything in level order (bp was gathered by the pre-smoother)
       // (A itself in level order: the schedule's copy, or — when the smoother sweeps S = A' — A's values on S's pattern)
-      RC_TRY(raw_apply(M_RESID, g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, n, g->xp, xs, g->bp, n, L->res, n,
-                       h->stream, bs));
+      if (il_block(bs) && g_rhs_il >= 2)   // (2: the block residual reads the matrix once; measured)
+        RC_TRY(resid_cols(bs, g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, n, g->xp, xs, g->bp, n, L->res, n, h->stream));
+      else
+        RC_TRY(raw_apply(M_RESID, g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, n, g->xp, xs, g->bp, n, L->res, n,
+                         h->stream, bs));
     }
     {
       ProfScope p(h, AMGH_T_RESTRICT, l);

@@ -546,7 +546,8 @@ __global__ __launch_bounds__(T) void gs_chain_kernel(ChainArgs a, int n) {
 // against ~0.2 us of LDS work.  A tiny operator (lin_elastic_2d: 208 rows, 2 632 nonzeros, 46 levels; the reference's
 // nns_test.jl:213-226 configuration) fits LDS entirely — matrix, row data, level descriptors, x, b: it is loaded once,
 // and the per-level loop touches no global memory at all.  Same products, same in-order row sums as gs_chain_kernel
-// (bitwise the same result); x goes back to HBM when the sweep is over.
+// (bitwise the same result; the skipped entry is the diagonal, whose product is never added); x goes back to HBM when
+// the sweep is over.
 constexpr int kTinyRows = 1024;     // rows (= columns, = levels at most)
 constexpr int kTinyNnz = 6144;
 constexpr int kTinyLvlNnz = 2048;   // nonzeros of one dependency level
@@ -568,19 +569,51 @@ __global__ __launch_bounds__(T) void gs_chain_tiny_kernel(ChainArgs a, int n, in
   for (int r = tid; r < n; r += T) { s_meta[r] = a.rowmeta[r]; s_d[r] = a.diag[r]; s_b[r] = a.bp[r]; s_x[r] = a.x[r]; }
   for (int l = tid; l < nlev; l += T) s_desc[l] = a.desc[l];
   __syncthreads();
+  // Per level: products of the level's entries by all threads (col / val of the level were fetched into registers one
+  // level ahead: only the x reads are on the critical path), one barrier, in-order row sums by the row's own thread (its
+  // row data fetched one level ahead too), x update, one barrier.
+  constexpr int PF = 2;                      // entries per thread held in registers for the next level
+  i4_t ds = s_desc[a.lvl_begin];
+  i4_t m = i4_t{0, 0, -1, -1};
+  real d = 0.0, bv = 0.0, pv[PF];
+  int pc[PF];
+  auto fetch = [&](const i4_t& dd, i4_t& mm, real& dg, real& bb, real* v, int* c) {
+    const int r = dd.x + tid;
+    mm = i4_t{0, 0, -1, -1}; dg = 0.0; bb = 0.0;
+    if (r < dd.y) { mm = s_meta[r]; dg = s_d[r]; bb = s_b[r]; }
+#pragma unroll
+    for (int e = 0; e < PF; ++e) {
+      const int k = dd.z + tid + e * T;
+      v[e] = 0.0; c[e] = 0;
+      if (k < dd.w) { v[e] = s_val[k]; c[e] = s_col[k]; }
+    }
+  };
+  fetch(ds, m, d, bv, pv, pc);
   for (int lv = a.lvl_begin; lv != a.lvl_end; lv += a.step) {
-    const i4_t ds = s_desc[lv];
     const int p0 = ds.z, p1 = ds.w;
-    for (int k = p0 + tid; k < p1; k += T) s_prod[k - p0] = s_val[k] * s_x[s_col[k]];
+#pragma unroll
+    for (int e = 0; e < PF; ++e) {
+      const int k = p0 + tid + e * T;
+      if (k < p1) s_prod[k - p0] = pv[e] * s_x[pc[e]];
+    }
+    for (int k = p0 + tid + PF * T; k < p1; k += T) s_prod[k - p0] = s_val[k] * s_x[s_col[k]];
+    // the next level's registers: independent of x, in flight across the barrier
+    const int lvn = lv + a.step;
+    i4_t dsn = ds, mn;
+    real dn, bn, pvn[PF];
+    int pcn[PF];
+    if (lvn != a.lvl_end) dsn = s_desc[lvn];
+    fetch(dsn, mn, dn, bn, pvn, pcn);
     lds_barrier();
     const int r = ds.x + tid;
     if (r < ds.y) {
-      const i4_t m = s_meta[r];
-      const real d = s_d[r];
       const real acc = seq_sum_skip(s_prod, m.x - p0, m.y - p0, m.z - p0, 0.0);
-      if (d != 0.0) s_x[r] = SOR ? (1.0 - a.omega) * s_x[r] + (a.omega / d) * (s_b[r] - acc) : (s_b[r] - acc) / d;
+      if (d != 0.0) s_x[r] = SOR ? (1.0 - a.omega) * s_x[r] + (a.omega / d) * (bv - acc) : (bv - acc) / d;
     }
     lds_barrier();   // this level's x is visible, s_prod may be overwritten
+    ds = dsn; m = mn; d = dn; bv = bn;
+#pragma unroll
+    for (int e = 0; e < PF; ++e) { pv[e] = pvn[e]; pc[e] = pcn[e]; }
   }
   for (int r = tid; r < n; r += T) a.x[r] = s_x[r];
 }
@@ -631,6 +664,36 @@ __global__ __launch_bounds__(256) void csr_il_kernel(const int32_t* __restrict__
   for (; j < j1; ++j) acc += val[j] * xil[(int64_t)col[j] * BS + q];
   real* yp = y + row + (int64_t)q * ldy;
   *yp = ADD ? *yp + acc : acc;
+}
+// r[:, q] = b[:, q] - A x[:, q] for a block of BS right-hand sides with x COLUMN-MAJOR (ldx apart; the smoother's own
+// level-ordered vector): BS lanes per row again, so the row's entries are loaded once for the whole block (the stream
+// kernel re-reads the matrix tile per column, from L2 at best); lane q gathers column q — neighbouring rows of a wave
+// gather neighbouring x, sector sharing is per column as in the single-column kernel.  In-order sums: bitwise the
+// stream kernel's residual.
+template <int BS>
+__global__ __launch_bounds__(256) void csr_resid_cols_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                             const real* __restrict__ val, int64_t nrows,
+                                                             const real* __restrict__ x, int64_t ldx, const real* __restrict__ b,
+                                                             int64_t ldb, real* __restrict__ y, int64_t ldy) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / BS;
+  const int q = (int)(t % BS);
+  if (row >= nrows) return;
+  const real* xq = x + (int64_t)q * ldx;
+  const int32_t j0 = rowptr[row], j1 = rowptr[row + 1];
+  real acc = 0.0;
+  int32_t j = j0;
+  for (; j + 4 <= j1; j += 4) {
+    int32_t c[4]; real v[4], xv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { c[e] = col[j + e]; v[e] = val[j + e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] = xq[c[e]];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += v[e] * xv[e];
+  }
+  for (; j < j1; ++j) acc += val[j] * xq[col[j]];
+  y[row + (int64_t)q * ldy] = b[row + (int64_t)q * ldb] - acc;
 }
 
 // ---- one WIDE dependency level from the slot layout -------------------------------------------

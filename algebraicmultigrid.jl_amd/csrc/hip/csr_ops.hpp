@@ -167,6 +167,27 @@ int il_apply(int bs, bool add, const int32_t* rowptr, const int32_t* col, const 
   return AMGH_EUNSUPPORTED;
 }
 inline bool il_block(int bs) { return g_rhs_il && (bs == 2 || bs == 4 || bs == 8 || bs == 16); }
+// r = b - A x for a block of bs in {2, 4, 8, 16} right-hand sides, the matrix read once (csr_resid_cols_kernel)
+template <int BS>
+int resid_cols_t(const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x, int64_t ldx,
+                 const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st) {
+  const int64_t threads = nrows * BS;
+  if (threads > 0)
+    hipLaunchKernelGGL((csr_resid_cols_kernel<BS>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, rowptr, col, val, nrows,
+                       x, ldx, b, ldb, y, ldy);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+int resid_cols(int bs, const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x, int64_t ldx,
+               const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st) {
+  switch (bs) {
+    case 2: return resid_cols_t<2>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st);
+    case 4: return resid_cols_t<4>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st);
+    case 8: return resid_cols_t<8>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st);
+    case 16: return resid_cols_t<16>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st);
+  }
+  return AMGH_EUNSUPPORTED;
+}
 
 template <int NCV>
 int launch_slot_t(const SlotArgs& sa, bool sor, int grid, hipStream_t st) {

@@ -7,6 +7,10 @@ import amg_amd as AMG
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 sizes = [int(a) for a in sys.argv[2:]] or [1, 2, 4, 8]
+# AMG_RHS_IL = 0: column by column | 1: interleaved restriction / prolongation (default) | 2: + block residual
+if os.environ.get("AMG_RHS_IL"):
+    AMG.hip_lib().amgh_debug_set_tunable(b"rhs_il", int(os.environ["AMG_RHS_IL"]))
+    print("rhs_il =", os.environ["AMG_RHS_IL"])
 A = AMG.poisson((N, N, N))
 ml = AMG.ruge_stuben(A)
 n = A.m
