@@ -554,7 +554,15 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0, buil
             if fut is not None and fut.exception() is None and not getattr(fut, "_taken", False):
                 builder.free_prepared(fut.result())
 
+    def check_smoothers(M):
+        """NoSymmetry smoothers need a nonzero stored diagonal (smoother.jl:239-241): validated level by level as the
+        matrices appear, not after the whole hierarchy (and its HBM copy) has been built."""
+        if not hermitian and smoothers is not None:
+            for s_ in smoothers:
+                s_.check_no_symmetry(M)
+
     def finish_level(l, dP, dR, dRAP, nAT, nsame):
+        check_smoothers(hostA[l])
         hostA.append(dRAP.to_host())
         if nAT is not None:
             set_symmetry(l + 1, nAT, nsame)
@@ -580,7 +588,11 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0, buil
         if A._sym is None and max_levels > 1 and n > max_coarse:
             dAT, same = symmetry_of(dA)
             set_symmetry(0, dAT, same)
+        check_smoothers(A)
         while lvl + 1 < max_levels and n > max_coarse:
+            for q in (dl, pipe):      # a worker thread has failed: stop computing further levels
+                if q is not None and q.exc is not None:
+                    raise q.exc
             if hermitian:
                 dAt = dA
             else:
