@@ -240,12 +240,22 @@ end
 Levels with at least `shard_min_rows` rows are partitioned by contiguous row ranges; the rest is uploaded on rank 0
 (`hip`) and handed over with amgh_dist_set_tail.  Assumes symmetric level operators (A' = A), as the sharded
 Python driver does.
+
+`id::Vector{UInt8}` (the 128 bytes of `amgh_dist_unique_id`, broadcast from rank 0) selects the RCCL transport;
+`id::AbstractString` (a fresh shared-memory name in `shm_open` syntax, e.g. "/amgh_1234", the same on every rank)
+selects the IPC transport: one process per rank, hipIpc peer-mapped send buffers, hand-off by flags the streams write
+and wait on — ranks may then share a GPU, which RCCL refuses.
 """
-function hip_sharded(ml::MultiLevel, rank::Integer, nranks::Integer, id::Vector{UInt8}; device::Integer = rank,
-                     shard_min_rows::Integer = 200_000)
+function hip_sharded(ml::MultiLevel, rank::Integer, nranks::Integer, id::Union{Vector{UInt8},AbstractString};
+                     device::Integer = rank, shard_min_rows::Integer = 200_000)
     d = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:amgh_dist_create_rccl, libamghip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Ptr{UInt8}),
-                d, device, rank, nranks, id))
+    if id isa AbstractString
+        check(ccall((:amgh_dist_create_ipc, libamghip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cstring),
+                    d, device, rank, nranks, id))
+    else
+        check(ccall((:amgh_dist_create_rccl, libamghip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Ptr{UInt8}),
+                    d, device, rank, nranks, id))
+    end
     sizes = [[size(l.A, 1) for l in ml.levels]; size(ml.final_A, 1)]
     lc = 0
     while lc < length(ml.levels) && sizes[lc + 1] >= shard_min_rows && sizes[lc + 1] >= 8 * nranks
