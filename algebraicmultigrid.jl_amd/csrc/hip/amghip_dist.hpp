@@ -144,7 +144,9 @@ struct RcclTransport : Transport {
   RcclApi* api = nullptr;
   ncclComm_t comm = nullptr;
   hipStream_t cs = nullptr;      // communication stream
-  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  // one (ready, done) event pair per halo plan: an exchange of one vector never re-records what another one waits on
+  struct EvPair { hipEvent_t ready = nullptr, done = nullptr; };
+  std::vector<EvPair> evs;
   int64_t* d_i64 = nullptr;      // setup scratch
   int64_t d_i64_cap = 0;
   double* d_scal = nullptr;
@@ -159,8 +161,7 @@ struct RcclTransport : Transport {
   ~RcclTransport() override {
     if (comm && api) api->CommDestroy(comm);
     if (cs) hipStreamDestroy(cs);
-    if (ev_ready) hipEventDestroy(ev_ready);
-    if (ev_done) hipEventDestroy(ev_done);
+    for (EvPair& e : evs) { if (e.ready) hipEventDestroy(e.ready); if (e.done) hipEventDestroy(e.done); }
     hipFree(d_i64); hipFree(d_scal);
   }
   bool async() const override { return true; }
@@ -172,8 +173,6 @@ struct RcclTransport : Transport {
     std::memcpy(&uid, id, sizeof uid);
     NCCL_TRY(api->CommInitRank(&comm, nranks, uid, rank));
     HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
     RC_TRY(dev_alloc(&d_scal, 64));
     return AMGH_OK;
   }
@@ -208,8 +207,15 @@ struct RcclTransport : Transport {
   int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st) override {
     if (broken) return AMGH_ESTATE;
     const ncclDataType_t dt = sizeof(real) == 8 ? ncclDouble : ncclFloat;
-    hipError_t e = hipEventRecord(ev_ready, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev_ready, 0);
+    if (pl.id < 0) return AMGH_ESTATE;
+    if ((size_t)pl.id >= evs.size()) evs.resize(pl.id + 1);
+    EvPair& ev = evs[pl.id];
+    if (!ev.ready) {
+      HIP_TRY(hipEventCreateWithFlags(&ev.ready, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ev.done, hipEventDisableTiming));
+    }
+    hipError_t e = hipEventRecord(ev.ready, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev.ready, 0);
     if (e != hipSuccess) return fail(-(1000 + (int)e));
     ncclResult_t r = api->GroupStart();
     for (int p = 0; p < nranks && r == ncclSuccess; ++p) {
@@ -221,12 +227,13 @@ struct RcclTransport : Transport {
     const ncclResult_t r2 = api->GroupEnd();
     if (r == ncclSuccess) r = r2;
     if (r != ncclSuccess) return fail(-(2000 + (int)r));
-    e = hipEventRecord(ev_done, cs);
+    e = hipEventRecord(ev.done, cs);
     if (e != hipSuccess) return fail(-(1000 + (int)e));
     return AMGH_OK;
   }
-  int exchange_finish(VecPlan&, hipStream_t st) override {
-    HIP_TRY(hipStreamWaitEvent(st, ev_done, 0));
+  int exchange_finish(VecPlan& pl, hipStream_t st) override {
+    if (pl.id < 0 || (size_t)pl.id >= evs.size() || !evs[pl.id].done) return AMGH_ESTATE;
+    HIP_TRY(hipStreamWaitEvent(st, evs[pl.id].done, 0));
     return AMGH_OK;
   }
   int allreduce(double* v, int n, bool max_op) override {

@@ -23,7 +23,23 @@ from ipc_cases import build_case  # noqa: E402
 def main():
     rank, nranks, name, outdir, case = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     ml, b, shard_min_rows, plan = build_case(case)
-    sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, 0, ("ipc", name), shard_min_rows)
+    if name.startswith("rccl:"):
+        # RCCL over real GPUs (one per rank): rank 0 publishes the 128-byte id through a file of the output directory
+        import time
+        path = os.path.join(outdir, "rccl_id.bin")
+        if rank == 0:
+            with open(path + ".tmp", "wb") as f:
+                f.write(SH.rccl_unique_id())
+            os.rename(path + ".tmp", path)
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > 120:
+                raise SystemExit("no RCCL id from rank 0")
+            time.sleep(0.05)
+        transport, device = ("rccl", open(path, "rb").read()), rank
+    else:
+        transport, device = ("ipc", name), int(os.environ.get("AMG_IPC_DEVICE_OF_RANK", "0").split(",")[rank % len(os.environ.get("AMG_IPC_DEVICE_OF_RANK", "0").split(","))])
+    sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, device, transport, shard_min_rows)
     bl = b[sh.r0:sh.r1]
     out = {"r0": sh.r0, "r1": sh.r1, "lc": sh.lc}
     if case == "die":

@@ -26,8 +26,8 @@ def rel(x, y):
     return np.linalg.norm(np.asarray(x) - np.asarray(y)) / max(np.linalg.norm(y), 1e-300)
 
 
-def run_ipc(case, nranks, timeout=420, expect_rc=None, env_extra=None):
-    name = "/amgh_g_%d_%s" % (os.getpid(), os.urandom(4).hex())
+def run_ipc(case, nranks, timeout=420, expect_rc=None, env_extra=None, transport="ipc"):
+    name = "rccl:" if transport == "rccl" else "/amgh_g_%d_%s" % (os.getpid(), os.urandom(4).hex())
     env = dict(os.environ, AMGH_IPC_TIMEOUT_S="90", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     with tempfile.TemporaryDirectory() as outdir:
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_gpu_worker.py"), str(r), str(nranks),
@@ -111,3 +111,27 @@ def test_ipc_dead_rank_releases_the_streams_of_the_others():
     for r in (0, 1):
         rc, out = outs[r]
         assert rc == 0 and f"IPC_GPU_RANK_{r}_SAW_DEAD_PEER" in out, (r, out[-3000:])
+
+
+def _gpu_count():
+    return int(AMG.hip_lib().amgh_device_count())
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+@pytest.mark.parametrize("transport", ["rccl", "ipc"])
+def test_two_processes_on_two_gpus(transport):
+    """On a multi-GPU node: one process per GPU over RCCL (ncclSend / ncclRecv called by the library) and over the IPC
+    transport across devices (peer-mapped buffers over xGMI) — the same checks as on one GPU."""
+    ml, b, smr, _ = build_case("gs")
+    lc = SH.num_sharded_levels([l.A.m for l in ml.levels] + [ml.final_A.m], 2, smr)
+    parts = run_ipc("gs", 2, transport=transport, env_extra={"AMG_IPC_DEVICE_OF_RANK": "0,1"})
+    want = emulate_sharded_cycles(ml, b, 2, lc, 3)
+    got = assemble(parts, "cycles")
+    for k in range(3):
+        assert rel(got[k], want[k]) <= 1e-10, (transport, k)
+    ml, b, smr, _ = build_case("jacobi_overlap")
+    parts = run_ipc("jacobi_overlap", 2, transport=transport, env_extra={"AMG_IPC_DEVICE_OF_RANK": "0,1"})
+    want = emulate_sharded_cycles(ml, b, 2, SH.num_sharded_levels([l.A.m for l in ml.levels] + [ml.final_A.m], 2, smr), 2)
+    got = assemble(parts, "cycles")
+    for k in range(2):
+        assert rel(got[k], want[k]) <= 1e-10, (transport, k)
