@@ -947,11 +947,12 @@ int amgh_finalize(amgh_t* h) {
   RC_TRY(dev_alloc(&h->b0, n * h->nrhs));
   ws += 2 * kRealB * n * h->nrhs;
   h->ws_bytes = ws;
-  // Small hierarchies are pure launch latency and HOST-bound (a cycle of ~100 kernels of a few microseconds each: the
-  // host needs ~3 us per eager launch, a graph replays them at the device's ~1.5 us boundary): graph replay by default
-  // when every level is small.  A big hierarchy keeps eager launches — its host runs far ahead of the device and the
-  // replay buys nothing.  AMGH_USE_GRAPH / amgh_set_use_graph decide otherwise.
-  if (h->graph_auto && !h->levels.empty()) {
+  // Graph replay stays opt-in (AMGH_USE_GRAPH=1 / amgh_set_use_graph), for small hierarchies too: measured on C1 / C2 / C5
+  // (profiles/r03_small_configs.log) a replayed cycle is as fast as the eager one (0.243 vs 0.248, 0.241 vs 0.232,
+  // 0.341 vs 0.337 ms) — their kernels take >= 3 us each, the host keeps ahead of the device — and rocprofv3's kernel
+  // tracing aborts on replays of this size.  AMGH_GRAPH_AUTO=1 turns it on for hierarchies whose widest level has at
+  // most kGraphAutoRows rows.
+  if (h->graph_auto && !h->levels.empty() && getenv("AMGH_GRAPH_AUTO") && getenv("AMGH_GRAPH_AUTO")[0] == '1') {
     int64_t widest = 0;
     for (Level* L : h->levels) widest = std::max(widest, L->n);
     h->use_graph = widest <= kGraphAutoRows;

@@ -455,11 +455,10 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
  * Returns AMGH_EINVAL for an unknown name.                                                                       */
 int amgh_debug_set_tunable(const char* name, int value);
 
-/* Replay whole cycles from captured hipGraphs.  Default (decided by amgh_finalize): ON for hierarchies
- * whose widest level has at most 65 536 rows — their cycle is ~100 kernels of a few microseconds and the
- * host is the bottleneck of eager launches — OFF for larger ones (the host runs far ahead of the device,
- * a replay buys nothing).  This call, or AMGH_USE_GRAPH=0/1 in the environment, overrides the default
- * (rocprofv3's kernel tracing aborts on graph replays of this size: profile with AMGH_USE_GRAPH=0).   */
+/* Replay whole cycles from captured hipGraphs (default off: measured no gain on MI355X for big hierarchies —
+ * the cycle is GPU-latency-bound and the host runs far ahead — nor for small ones, whose kernels take >= 3 us each;
+ * AMGH_USE_GRAPH=1 in the environment also enables it, AMGH_GRAPH_AUTO=1 enables it for hierarchies whose widest
+ * level has at most 65 536 rows; rocprofv3's kernel tracing aborts on graph replays of this size).              */
 int amgh_set_use_graph(amgh_t* h, int on);
 
 #ifdef __cplusplus

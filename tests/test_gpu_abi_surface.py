@@ -144,9 +144,8 @@ def test_w_and_f_cycles_at_128_cubed(h128, cyc):
 def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_graphs():
     """An operator that fits LDS entirely (rows, nonzeros, level descriptors, x, b) runs its chained dependency levels
     in gs_chain_tiny_kernel — no global memory access per level — with the products and in-order row sums of
-    gs_chain_kernel: bitwise the same sweep.  Hierarchies whose widest level has <= 65 536 rows replay their cycle from a
-    hipGraph by default (they are host-launch bound): bitwise the eager cycle, and PCG on the reference's
-    lin_elastic_2d configuration (nns_test.jl:213-226) keeps its 13 iterations."""
+    gs_chain_kernel: bitwise the same sweep.  A small hierarchy replayed from a hipGraph (opt-in) is bitwise the eager
+    cycle, and PCG on the reference's lin_elastic_2d configuration (nns_test.jl:213-226) keeps its 13 iterations."""
     from amg_amd.device import DeviceHierarchy
     from conftest import load_csc, load_npz
     lib = AMG.hip_lib()
@@ -171,6 +170,7 @@ def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_gra
     # the hierarchy: default (graph replay decided by amgh_finalize) vs eager, tiny kernel vs regular chain
     ml = AMG.smoothed_aggregation(A, B=d["B"])
     auto = DeviceHierarchy(ml, 0, 1)
+    assert lib.amgh_set_use_graph(auto.h, 1) == 0      # (opt-in: measured no faster than eager launches)
     eager = DeviceHierarchy(ml, 0, 1)
     assert lib.amgh_set_use_graph(eager.h, 0) == 0
     z_e = eager.precond_apply(d["b"])
@@ -185,8 +185,6 @@ def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_gra
     xp, log = AMG.cg(A, d["b"], Pl=AMG.aspreconditioner(ml), reltol=1e-10, log=True)
     xpo, _, itp = O.OracleHierarchy(ml).pcg(d["b"], reltol=1e-10)
     assert log["iters"] == itp == 13 and rel(xp, xpo) <= 1e-9
-    # a big hierarchy keeps eager launches by default: nothing to check but that the rule reads the sizes
-    # (AMGH_USE_GRAPH in the environment overrides both)
 
 
 def test_footprint_policies_are_bitwise_the_same_hierarchy():
