@@ -33,6 +33,12 @@ def build_case(case):
         A = AMG.poisson((40, 40, 48))
         ml = AMG.ruge_stuben(A)
         return ml, uniform(A.m, 6), 4000, [("cycles", dict(cycles=3)), ("solve_v", dict(reltol=1e-10, maxiter=60))]
+    if case == "c4":
+        # BASELINE.json config C4 at FULL size: poisson((256,256,256)), ruge_stuben defaults (every process builds the
+        # hierarchy itself, data-parallel half on the GPU)
+        A = AMG.poisson((256, 256, 256))
+        ml = AMG.ruge_stuben(A, setup="gpu")
+        return ml, uniform(A.m, 0), 200_000, [("cycles", dict(cycles=1))]
     if case == "sor_w":
         A = AMG.poisson((32, 32, 32))
         ml = AMG.ruge_stuben(A, presmoother=AMG.SOR(1.2, AMG.ForwardSweep()), postsmoother=AMG.SOR(1.2, AMG.BackwardSweep()))

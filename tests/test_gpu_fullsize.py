@@ -169,3 +169,41 @@ def test_c4_256cubed_row_sharded_gauss_seidel_matches_the_frozen_halo_emulation_
         assert rel(x, want[k]) <= 1e-10, k
         xo, _, _ = oh.solve(b, maxiter=k + 1, calculate_residual=False)
         assert rel(x, xo) <= 5e-2            # hybrid vs exact sweep: same cycle up to the 3 interfaces per level
+
+
+def test_c4_two_processes_over_the_ipc_transport_full_size(c3):
+    """Config C4 with REAL processes at full size: 256^3 row-sharded over 2 processes (one GPU, IPC transport: hipIpc
+    peer-mapped send buffers + stream-written flags), one V-cycle of the default (Gauss-Seidel) hierarchy against the
+    host emulation of the frozen-halo sweeps at 1e-10."""
+    import subprocess
+    import sys
+    import tempfile
+    import os
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from amg_amd import sharded as SH
+    from sharded_emulation import emulate_sharded_cycles
+    A, ml = c3
+    b = uniform(A.m, 0)
+    name = "/amgh_c4_%d_%s" % (os.getpid(), os.urandom(4).hex())
+    env = dict(os.environ, AMGH_IPC_TIMEOUT_S="300", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_gpu_worker.py"), str(r), "2", name, outdir, "c4"],
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT) for r in range(2)]
+        outs = []
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=900)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            outs.append((p.returncode, out.decode()))
+        for r, (rc, out) in enumerate(outs):
+            assert rc == 0 and f"IPC_GPU_RANK_{r}_OK" in out, (r, out[-3000:])
+        parts = [dict(np.load(os.path.join(outdir, f"rank{r}.npz"))) for r in range(2)]
+    lc = SH.num_sharded_levels([l.A.m for l in ml.levels] + [ml.final_A.m], 2)
+    assert all(int(p["lc"]) == lc for p in parts) and lc >= 3
+    got = np.concatenate([p["cycles"][0] for p in parts])
+    want = emulate_sharded_cycles(ml, b, 2, lc, 1)[0]
+    assert rel(got, want) <= 1e-10
