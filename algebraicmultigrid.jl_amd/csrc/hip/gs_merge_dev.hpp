@@ -54,6 +54,7 @@ struct MergeDev {
   real* rval[kMergeMaxRounds] = {};
   int64_t total = 0, max_row = 0;
   int64_t sampled_rows = 0;           // rows whose composite row was built (= n unless the build sampled the groups)
+  int sample_stride = 1;              // groups q with q % stride == stride / 2 were built (1: all)
   double growth = 0.0;
   bool failed = false;                // a row outgrew the long-row table (the caller gives up on this m)
   std::vector<int32_t> h_clen;        // host copy of clen
@@ -228,7 +229,7 @@ int merge_build_dev(const GsSchedule* g, const int32_t* d_lev_of, const real* d_
   MergeDev& R = *out;
   const bool backward = G.backward;
   const int m = G.depth();
-  R.m = m; R.backward = backward; R.grouping = G;
+  R.m = m; R.backward = backward; R.grouping = G; R.sample_stride = std::max(1, sample_stride);
   R.ngrp = G.ngrp();
   if (m > kMergeMaxRounds) return AMGH_EUNSUPPORTED;
   if (R.ngrp < 0 || (g->nlev > 0 && (G.gb.front() != 0 || G.gb.back() != g->nlev))) return AMGH_EINVAL;

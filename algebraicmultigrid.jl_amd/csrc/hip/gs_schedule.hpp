@@ -1134,35 +1134,6 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         }
         }
       }
-      // the chosen depths in full (the candidates above were samples); a row the sample did not see may outgrow the slots:
-      // then one level fewer per group
-      for (int dir = 0; dir < 2 && rc2 == AMGH_OK; ++dir) {
-        if (!sampled[dir] || chosen_m[dir] <= 1) continue;
-        const bool backward = dir == 1;
-        const int64_t smax = chosen[dir].max_row;
-        chosen[dir].free_dev();
-        chosen[dir] = MergeDev();
-        while (chosen_m[dir] > 1 && rc2 == AMGH_OK) {
-          MergeDev md;
-          rc2 = merge_build_dev(g, d_lev_of, g->diag, MergeGrouping::uniform(g->nlev, chosen_m[dir], backward), &md,
-                                smax > 440 ? 2 : smax > 110 ? 1 : 0);
-          if (rc2 != AMGH_OK) break;
-          int cap = (md.max_row > kSlot || g_gs_bigslot == 2) ? kBigSlot : kSlot;
-          const bool ok = !md.failed && md.max_row <= kBigSlot - kBigSlot / 8 && !(cap == kBigSlot && !g_gs_bigslot) &&
-                          !(md.growth > kMergeGrowthMax);
-          if (ok) {
-            if (getenv("AMGH_VERBOSE"))
-              fprintf(stderr, "[amghip] n=%lld %s merge m=%d built in full: %.1f entries/row (max %lld)\n", (long long)n,
-                      backward ? "bwd" : "fwd", chosen_m[dir], (double)md.total / n, (long long)md.max_row);
-            fill[dir][chosen_m[dir]] = (double)md.total / (double)n;
-            chosen_cap[dir] = cap;
-            chosen[dir] = std::move(md);
-            break;
-          }
-          md.free_dev();
-          --chosen_m[dir];
-        }
-      }
       tm.lap("merge candidates (device)", n); dbg_pending("merge candidates (device)");
       const bool use = g->nblk == 0 ? true : (chosen_m[0] > 1 && chosen_m[1] > 1);
       // Groups of DIFFERENT depth along the sweep.  Where the dependency levels are small — the two ends of a sweep over
@@ -1200,9 +1171,17 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
         };
         auto sweep_cost = [&](const MergeDev& md, const MergeGrouping& G, bool big) {
           double c = 0.0;
+          const int st = md.sample_stride;   // a sampled (cost-model) build holds every st-th group: scale per entry per row
+          int64_t se = 0, sr = 0;
+          if (st > 1)
+            for (int q = st / 2; q < G.ngrp(); q += st)
+              for (int32_t p2 = base.lvl_ptr[G.gb[q]]; p2 < base.lvl_ptr[G.gb[q + 1]]; ++p2) { se += md.h_clen[p2]; ++sr; }
+          const double per_row = sr > 0 ? (double)se / (double)sr : 0.0;
           for (int q = 0; q < G.ngrp(); ++q) {
             int64_t e = 0;
-            for (int32_t p2 = base.lvl_ptr[G.gb[q]]; p2 < base.lvl_ptr[G.gb[q + 1]]; ++p2) e += md.h_clen[p2];
+            if (st > 1 && q % st != st / 2) e = (int64_t)(per_row * (double)(base.lvl_ptr[G.gb[q + 1]] - base.lvl_ptr[G.gb[q]]));
+            else
+              for (int32_t p2 = base.lvl_ptr[G.gb[q]]; p2 < base.lvl_ptr[G.gb[q + 1]]; ++p2) e += md.h_clen[p2];
             c += group_cost(e, big);
           }
           return c;
@@ -1255,6 +1234,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           if (fits && zc < 0.97 * uniform_cost) {
             chosen[dir].free_dev();
             chosen[dir] = std::move(md);
+            sampled[dir] = false;      // (a full build)
             md = MergeDev();
             break;
           }
@@ -1262,6 +1242,36 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
           if (fits) break;                                       // it fits and still does not win: deeper will not either
           cap_try = std::max(chosen_m[dir] + 1, (cap_try * 3) / 4);
           if (cap_try <= chosen_m[dir]) break;
+        }
+      }
+      // where no zoned grouping replaced it, the chosen uniform depth in full (the candidates above were samples: all but
+      // one of them are thrown away, and so is the uniform one when the zoned grouping wins); a row the sample did not
+      // see may outgrow the slots: then one level fewer per group
+      for (int dir = 0; dir < 2 && rc2 == AMGH_OK; ++dir) {
+        if (!sampled[dir] || chosen_m[dir] <= 1) continue;
+        const bool backward = dir == 1;
+        const int64_t smax = chosen[dir].max_row;
+        chosen[dir].free_dev();
+        chosen[dir] = MergeDev();
+        while (chosen_m[dir] > 1 && rc2 == AMGH_OK) {
+          MergeDev md;
+          rc2 = merge_build_dev(g, d_lev_of, g->diag, MergeGrouping::uniform(g->nlev, chosen_m[dir], backward), &md,
+                                smax > 440 ? 2 : smax > 110 ? 1 : 0);
+          if (rc2 != AMGH_OK) break;
+          int cap = (md.max_row > kSlot || g_gs_bigslot == 2) ? kBigSlot : kSlot;
+          const bool ok = !md.failed && md.max_row <= kBigSlot - kBigSlot / 8 && !(cap == kBigSlot && !g_gs_bigslot) &&
+                          !(md.growth > kMergeGrowthMax);
+          if (ok) {
+            if (getenv("AMGH_VERBOSE"))
+              fprintf(stderr, "[amghip] n=%lld %s merge m=%d built in full: %.1f entries/row (max %lld)\n", (long long)n,
+                      backward ? "bwd" : "fwd", chosen_m[dir], (double)md.total / n, (long long)md.max_row);
+            fill[dir][chosen_m[dir]] = (double)md.total / (double)n;
+            chosen_cap[dir] = cap;
+            chosen[dir] = std::move(md);
+            break;
+          }
+          md.free_dev();
+          --chosen_m[dir];
         }
       }
       tm.lap("zoned groups (device)", n); dbg_pending("zoned groups (device)");
