@@ -24,6 +24,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/mman.h>
+
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -402,10 +404,46 @@ inline int64_t pos_of(const SplitNode& v) { return (int64_t)(v.pos_state & 0x3ff
 inline void set_state(SplitNode& v, uint32_t st) { v.pos_state = (v.pos_state & 0x3fffffffu) | (st << 30); }
 inline void set_pos(SplitNode& v, int64_t p) { v.pos_state = (v.pos_state & 0xc0000000u) | (uint32_t)p; }
 
+// The sweep is a chain of dependent RANDOM accesses over hundreds of megabytes (node records, the bucket array, the
+// strength patterns): with 4 KiB pages nearly every access also misses the TLB.  Its working arrays live in anonymous
+// mappings advised MADV_HUGEPAGE before their first touch (transparent huge pages are in `madvise` mode on the target
+// hosts): 2 MiB pages, a page walk per 512 x as many bytes.
+template <class T>
+struct HugeBuf {
+  T* p = nullptr;
+  size_t bytes = 0;
+  explicit HugeBuf(size_t count) {
+    bytes = ((count * sizeof(T) + (size_t(2) << 20) - 1) >> 21) << 21;
+    if (bytes == 0) bytes = size_t(2) << 20;
+    void* q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (q == MAP_FAILED) throw std::bad_alloc();
+    if (!std::getenv("AMGS_NO_HUGEPAGES")) madvise(q, bytes, MADV_HUGEPAGE);   // advice only: failure is harmless
+    p = (T*)q;                                                               // (anonymous mappings start zeroed)
+  }
+  ~HugeBuf() { if (p) munmap(p, bytes); }
+  HugeBuf(const HugeBuf&) = delete;
+  HugeBuf& operator=(const HugeBuf&) = delete;
+  T* data() { return p; }
+  T& operator[](size_t i) { return p[i]; }
+};
+
 void rs_cf_splitting_packed(int64_t n, const int32_t* Sp, const int32_t* Sj, const int32_t* Tp, const int32_t* Tj,
                             int32_t* splitting_out) {
-  std::vector<SplitNode> node(n + 2, SplitNode{0, 0});
-  std::vector<int32_t> interval_ptr(n + 3, 0), interval_count(n + 3, 0), index_to_node(n + 2, 0);
+  HugeBuf<SplitNode> node(n + 2);
+  HugeBuf<int32_t> interval_ptr(n + 3), interval_count(n + 3), index_to_node(n + 2);
+  // (private huge-page copies of the patterns too: measured SLOWER — faulting in that many fresh 2 MiB pages costs more
+  //  than the page walks it saves; AMGS_PATTERN_COPY=1 keeps the experiment available)
+  std::unique_ptr<HugeBuf<int32_t>> cSp, cSj, cTp, cTj;
+  if (n >= (int64_t(1) << 20) && !std::getenv("AMGS_NO_HUGEPAGES") && std::getenv("AMGS_PATTERN_COPY")) {
+    auto dup = [](const int32_t* src, size_t cnt, std::unique_ptr<HugeBuf<int32_t>>& dst) {
+      dst.reset(new HugeBuf<int32_t>(cnt));
+      std::memcpy(dst->data(), src, cnt * sizeof(int32_t));
+      return (const int32_t*)dst->data();
+    };
+    const size_t ns = (size_t)Sp[n], nt = (size_t)Tp[n];
+    Sp = dup(Sp, (size_t)n + 1, cSp); Sj = dup(Sj, ns, cSj);
+    Tp = dup(Tp, (size_t)n + 1, cTp); Tj = dup(Tj, nt, cTj);
+  }
   for (int64_t i = 1; i <= n; ++i) {
     node[i].lambda = Sp[i] - Sp[i - 1];
     interval_count[node[i].lambda + 1] += 1;
@@ -417,7 +455,7 @@ void rs_cf_splitting_packed(int64_t n, const int32_t* Sp, const int32_t* Sj, con
       interval_ptr[k + 1] = (int32_t)s;
     }
   }
-  std::fill(interval_count.begin(), interval_count.end(), 0);
+  std::memset(interval_count.data(), 0, sizeof(int32_t) * (size_t)(n + 3));
   for (int64_t i = 1; i <= n; ++i) {
     int64_t li = node[i].lambda + 1;
     interval_count[li] += 1;

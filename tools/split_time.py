@@ -11,14 +11,15 @@ from amg_amd._libs import setup_lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = setup_lib()
 orig = L.amgs_rs_cf_splitting_patterns
-VARIANTS = (("plain", {"AMGS_SPLIT_PLAIN": "1"}), ("packed", {"AMGS_SPLIT_NODRY": "1"}), ("packed+dry", {}))
+VARIANTS = (("plain", {"AMGS_SPLIT_PLAIN": "1"}), ("packed+dry 4K pages", {"AMGS_NO_HUGEPAGES": "1"}), ("packed+dry huge pages", {}),
+            ("+ pattern copies", {"AMGS_PATTERN_COPY": "1"}))
 
 
 def timed(n, Sp, Sj, Tp, Tj, out):
     ref = None
     line = [f"n={n:9d}"]
     for name, env in VARIANTS * 2:
-        for k in ("AMGS_SPLIT_PLAIN", "AMGS_SPLIT_NODRY"):
+        for k in ("AMGS_SPLIT_PLAIN", "AMGS_SPLIT_NODRY", "AMGS_NO_HUGEPAGES", "AMGS_PATTERN_COPY"):
             os.environ.pop(k, None)
         os.environ.update(env)
         t0 = time.perf_counter()
@@ -29,7 +30,7 @@ def timed(n, Sp, Sj, Tp, Tj, out):
             ref = res
         assert rc == 0 and np.array_equal(ref, res), name
         line.append(f"{name} {dt:6.3f} s")
-    for k in ("AMGS_SPLIT_PLAIN", "AMGS_SPLIT_NODRY"):
+    for k in ("AMGS_SPLIT_PLAIN", "AMGS_SPLIT_NODRY", "AMGS_NO_HUGEPAGES", "AMGS_PATTERN_COPY"):
         os.environ.pop(k, None)
     print("  ".join(line), flush=True)
     return 0
