@@ -170,7 +170,8 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, real*& xc, real*& xo, 
     switch (s.kind) {
       case AMGH_SMOOTH_NONE: break;
       case AMGH_SMOOTH_JACOBI:
-        RC_TRY(csr_jacobi(M, s.omega, xc, b, xo, h->stream, ncolv));
+        if (xzero && it == 0 && g_jacobi_zero) RC_TRY(csr_jacobi_zero(M, s.omega, b, xo, h->stream, ncolv));   // x = 0: no matrix pass
+        else RC_TRY(csr_jacobi(M, s.omega, xc, b, xo, h->stream, ncolv));
         std::swap(xc, xo);
         break;
       case AMGH_SMOOTH_GS:
@@ -1567,6 +1568,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_sample")) g_gs_sample = value;
   else if (!strcmp(name, "gs_tiny")) g_gs_tiny = value;
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;
+  else if (!strcmp(name, "jacobi_zero")) g_jacobi_zero = value;
   else if (!strcmp(name, "gs_ept")) g_gs_ept = value;
   else if (!strcmp(name, "gs_merge")) g_gs_merge = value;
   else if (!strcmp(name, "gs_merge_force")) g_gs_merge_force = value;

@@ -561,7 +561,11 @@ int dist_smooth(amgh_dist* d, int l, const amgh_smoother_t& s, bool xzero, bool*
   for (int it = 0; it < s.iter; ++it) {
     if (s.kind == AMGH_SMOOTH_JACOBI) {
       if (n > 0) RC_TRY(csr_ensure_diag(&M->op, d->stream));
-      RC_TRY(dist_apply(d, *M, M_JACOBI, pl, L->x, L->b, L->tmp, s.omega, fresh));
+      if (fresh && g_jacobi_zero) {   // x = 0 on every rank: no exchange, no matrix pass
+        if (n > 0) RC_TRY(csr_jacobi_zero(&M->op, s.omega, L->b, L->tmp, d->stream));
+      } else {
+        RC_TRY(dist_apply(d, *M, M_JACOBI, pl, L->x, L->b, L->tmp, s.omega, fresh));
+      }
       fresh = false;
       if (n > 0) HIP_TRY(hipMemcpyAsync(L->x, L->tmp, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
     } else if (s.kind == AMGH_SMOOTH_GS || s.kind == AMGH_SMOOTH_SOR) {

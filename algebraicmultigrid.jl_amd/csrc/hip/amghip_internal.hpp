@@ -345,6 +345,7 @@ int g_gs_merge_force_maxn = 0;   // ... only on operators with at most this many
 int g_gs_merge_force = 0;        // measurement hook: groups of exactly this many levels wherever they can be built (0 = cost model); read at schedule build
 int g_gs_xcd_map = 1;           // XCD-contiguous slot -> workgroup mapping in gs_slot_kernel
 int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR stream kernel)
+int g_jacobi_zero = 1;          // Jacobi on x = 0 as a vector kernel (0 = the full sweep); read at every sweep
 int g_rhs_il = 1;               // blocks of 2 / 4 / 8 / 16 right-hand sides: restriction and prolongation gather an interleaved copy of their input (0 = column by column); read at every cycle
 int g_gs_tiny = 1;              // chained levels of an operator that fits LDS entirely: gs_chain_tiny_kernel (0 = gs_chain_kernel); read at every sweep
 int g_gs_sample = 1;            // candidate group sizes of the merged sweeps from a sample of the groups (0 = every candidate built in full); read at schedule build

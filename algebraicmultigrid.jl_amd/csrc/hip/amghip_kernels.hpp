@@ -618,6 +618,22 @@ __global__ __launch_bounds__(T) void gs_chain_tiny_kernel(ChainArgs a, int n, in
   for (int r = tid; r < n; r += T) a.x[r] = s_x[r];
 }
 
+// Damped Jacobi on x = 0 (every pre-smoother below the fine level of a cycle, and the fine one of ldiv!): the sweep's
+// matrix pass multiplies zeros — x_new = (1 - w) 0 + w ((b - 0) / d) is the SAME expression the stream kernel evaluates
+// with a row sum of +0 (bitwise the same result), as a vector kernel.  Rows with a zero diagonal keep their x = 0
+// (smoother.jl:132-137).  gridDim.y = right-hand-side columns.
+__global__ void jacobi_zero_kernel(const real* __restrict__ b, const real* __restrict__ diag, real* __restrict__ y, int64_t n,
+                                   real omega, int64_t ldb, int64_t ldy) {
+  b += blockIdx.y * ldb;
+  y += blockIdx.y * ldy;
+  const real t = 0.0, acc = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    const real d = diag[r];
+    const real cand = (1.0 - omega) * t + omega * ((b[r] - acc) / d);
+    y[r] = (d == 0.0) ? t : cand;
+  }
+}
+
 // ---- restriction / prolongation of a BLOCK of right-hand sides -------------------------------------------------------
 // In the level-ordered cycle the gathers of R and P are one 64-byte sector per matrix entry (a coarse row's fine
 // neighbours sit in different dependency levels, tools/order_probe.py): column by column a block of bs right-hand sides

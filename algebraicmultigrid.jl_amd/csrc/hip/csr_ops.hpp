@@ -91,6 +91,16 @@ int csr_jacobi(amgh_csr* op, real omega, const real* xin, const real* b, real* x
   return launch_stream_sized<M_JACOBI>(a, st, ncolv);
 }
 
+// the same sweep from x = 0: no matrix pass (jacobi_zero_kernel)
+int csr_jacobi_zero(amgh_csr* op, real omega, const real* b, real* xout, hipStream_t st, int ncolv = 1) {
+  RC_TRY(csr_ensure_diag(op, st));
+  if (op->nrows > 0)
+    hipLaunchKernelGGL(jacobi_zero_kernel, dim3((unsigned)std::min<int64_t>((op->nrows + 255) / 256, 1 << 20), ncolv), dim3(256), 0, st,
+                       b, (const real*)op->diag, xout, (int64_t)op->nrows, omega, (int64_t)op->nrows, (int64_t)op->nrows);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+
 template <int T, int PF>
 int launch_chain_t(const ChainArgs& c, bool sor, bool ldsx, int nx, hipStream_t st, int ncolv) {
   if (sor && ldsx) hipLaunchKernelGGL((gs_chain_kernel<true, true, T, PF>), dim3(ncolv), dim3(T), 0, st, c, nx);

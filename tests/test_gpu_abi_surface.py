@@ -187,6 +187,34 @@ def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_gra
     assert log["iters"] == itp == 13 and rel(xp, xpo) <= 1e-9
 
 
+def test_jacobi_on_a_zero_vector_skips_the_matrix_pass_bitwise():
+    """Every pre-smoother below the fine level of a cycle (and the fine one of ldiv!) starts from x = 0: the damped Jacobi
+    sweep is then x = (1 - w) 0 + w ((b - 0) / d), evaluated by a vector kernel instead of a pass over the matrix —
+    the same expression with the same operands: bitwise the full sweep, V / W / F, blocks of right-hand sides, w > 1."""
+    from amg_amd.device import DeviceHierarchy
+    lib = AMG.hip_lib()
+    A = AMG.poisson((48, 40))
+    b = uniform(A.m, 12) - 0.4
+    B = np.stack([b, uniform(A.m, 13), -b], axis=1)
+    for omega, iters in ((2.0 / 3.0, 1), (1.25, 2)):
+        jac = AMG.Jacobi(omega, iter=iters)
+        ml = AMG.smoothed_aggregation(A, presmoother=jac, postsmoother=jac)
+        out = {}
+        for flag in (1, 0):
+            assert lib.amgh_debug_set_tunable(b"jacobi_zero", flag) == 0
+            try:
+                dev1, dev3 = DeviceHierarchy(ml, 0, 1), DeviceHierarchy(ml, 0, 3)
+                for cyc in (0, 1, 2):
+                    out[(flag, cyc, 1)] = dev1.precond_apply(b, cyc)
+                    out[(flag, cyc, 3)] = dev3.precond_apply(B, cyc)
+            finally:
+                lib.amgh_debug_set_tunable(b"jacobi_zero", 1)
+        for (flag, cyc, bs), v in out.items():
+            if flag == 1:
+                assert np.array_equal(v, out[(0, cyc, bs)]), (omega, cyc, bs)
+        assert rel(out[(1, 0, 1)], O.OracleHierarchy(ml).precond(b)) <= 1e-10
+
+
 def test_footprint_policies_are_bitwise_the_same_hierarchy():
     """AMGH_LEAN / tunable gs_lean — full (0: every copy kept), trim (2, the default: no un-merged slot copy, no CSR
     copy of slotted composite rows once the SELL-like build has read it, no natural-order P / R / coarse A where the
