@@ -68,10 +68,13 @@ struct Transport {
   //   pack_target()    which copy of the send buffer the pack kernel fills (may enqueue waits on `st`)
   //   exchange_begin() send sendbuf[send[p].off .. +cnt) to peer p, receive recv[p].cnt entries from p into
   //                    recvbuf + recv[p].off.  `st` is the stream the packed send buffer was produced on and on which
-  //                    the received data will be consumed; it may return before the data has arrived,
+  //                    the received data will be consumed; it may return before the data has arrived.
+  //                    overlap = the caller has work for `st` that does not read the halo (interior rows): the transfer
+  //                    then runs on the transport's own stream between two events; otherwise it is enqueued on `st`
+  //                    itself — a second stream and two events cost more than the exchange (tools/ipc_pingpong.hip),
   //   exchange_finish() makes `st` wait for it.
   virtual int pack_target(VecPlan& pl, hipStream_t, real** sendbuf) { *sendbuf = pl.d_sendbuf; return AMGH_OK; }
-  virtual int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st) = 0;
+  virtual int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st, bool overlap) = 0;
   virtual int exchange_finish(VecPlan& pl, hipStream_t st) = 0;
   virtual int allreduce(double* v, int n, bool max_op) = 0;  // host values, in place
   virtual int barrier() = 0;
@@ -145,7 +148,7 @@ struct RcclTransport : Transport {
   ncclComm_t comm = nullptr;
   hipStream_t cs = nullptr;      // communication stream
   // one (ready, done) event pair per halo plan: an exchange of one vector never re-records what another one waits on
-  struct EvPair { hipEvent_t ready = nullptr, done = nullptr; };
+  struct EvPair { hipEvent_t ready = nullptr, done = nullptr; bool on_cs = false; };
   std::vector<EvPair> evs;
   int64_t* d_i64 = nullptr;      // setup scratch
   int64_t d_i64_cap = 0;
@@ -204,36 +207,42 @@ struct RcclTransport : Transport {
     for (int p = 0; p < nranks; ++p) all[p].assign(flat.begin() + (size_t)p * mx, flat.begin() + (size_t)p * mx + counts[p]);
     return AMGH_OK;
   }
-  int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st) override {
+  int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st, bool overlap) override {
     if (broken) return AMGH_ESTATE;
     const ncclDataType_t dt = sizeof(real) == 8 ? ncclDouble : ncclFloat;
     if (pl.id < 0) return AMGH_ESTATE;
     if ((size_t)pl.id >= evs.size()) evs.resize(pl.id + 1);
     EvPair& ev = evs[pl.id];
-    if (!ev.ready) {
-      HIP_TRY(hipEventCreateWithFlags(&ev.ready, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&ev.done, hipEventDisableTiming));
+    ev.on_cs = overlap;
+    hipStream_t ts = overlap ? cs : st;   // (nothing to overlap: the grouped send / recv sits on the caller's stream)
+    if (overlap) {
+      if (!ev.ready) {
+        HIP_TRY(hipEventCreateWithFlags(&ev.ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev.done, hipEventDisableTiming));
+      }
+      hipError_t e = hipEventRecord(ev.ready, st);
+      if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev.ready, 0);
+      if (e != hipSuccess) return fail(-(1000 + (int)e));
     }
-    hipError_t e = hipEventRecord(ev.ready, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev.ready, 0);
-    if (e != hipSuccess) return fail(-(1000 + (int)e));
     ncclResult_t r = api->GroupStart();
     for (int p = 0; p < nranks && r == ncclSuccess; ++p) {
       if (p == rank) continue;
-      if (pl.send[p].cnt > 0) r = api->Send(sendbuf + pl.send[p].off, (size_t)pl.send[p].cnt, dt, p, comm, cs);
+      if (pl.send[p].cnt > 0) r = api->Send(sendbuf + pl.send[p].off, (size_t)pl.send[p].cnt, dt, p, comm, ts);
       if (r == ncclSuccess && pl.recv[p].cnt > 0)
-        r = api->Recv(recvbuf + pl.recv[p].off, (size_t)pl.recv[p].cnt, dt, p, comm, cs);
+        r = api->Recv(recvbuf + pl.recv[p].off, (size_t)pl.recv[p].cnt, dt, p, comm, ts);
     }
     const ncclResult_t r2 = api->GroupEnd();
     if (r == ncclSuccess) r = r2;
     if (r != ncclSuccess) return fail(-(2000 + (int)r));
-    e = hipEventRecord(ev.done, cs);
-    if (e != hipSuccess) return fail(-(1000 + (int)e));
+    if (overlap) {
+      const hipError_t e = hipEventRecord(ev.done, cs);
+      if (e != hipSuccess) return fail(-(1000 + (int)e));
+    }
     return AMGH_OK;
   }
   int exchange_finish(VecPlan& pl, hipStream_t st) override {
-    if (pl.id < 0 || (size_t)pl.id >= evs.size() || !evs[pl.id].done) return AMGH_ESTATE;
-    HIP_TRY(hipStreamWaitEvent(st, evs[pl.id].done, 0));
+    if (pl.id < 0 || (size_t)pl.id >= evs.size()) return AMGH_ESTATE;
+    if (evs[pl.id].on_cs) HIP_TRY(hipStreamWaitEvent(st, evs[pl.id].done, 0));
     return AMGH_OK;
   }
   int allreduce(double* v, int n, bool max_op) override {
@@ -313,7 +322,7 @@ struct LocalTransport : Transport {
     if (!g->wait()) return AMGH_ESTATE;
     return AMGH_OK;
   }
-  int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st) override {
+  int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st, bool) override {
     const std::vector<PeerSpan>&send = pl.send, &recv = pl.recv;
     if (hipStreamSynchronize(st) != hipSuccess) { g->abort(); return AMGH_ESTATE; }  // my packed entries are complete
     g->sendbuf[rank] = sendbuf;
@@ -492,7 +501,7 @@ int take_block(HostBlock& hb, int64_t nrows, const int32_t* rowptr, const int32_
 }
 
 // ---- data path ---------------------------------------------------------------------------------------------------
-int halo_begin(amgh_dist* d, VecPlan& pl, real* vec) {
+int halo_begin(amgh_dist* d, VecPlan& pl, real* vec, bool overlap = false) {
   if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
   real* sendbuf = nullptr;
   RC_TRY(d->tr->pack_target(pl, d->stream, &sendbuf));
@@ -503,7 +512,7 @@ int halo_begin(amgh_dist* d, VecPlan& pl, real* vec) {
   }
   ++d->ex_count;
   d->ex_bytes += (int64_t)sizeof(real) * pl.nsend;
-  return d->tr->exchange_begin(pl, sendbuf, vec + pl.nloc(), d->stream);
+  return d->tr->exchange_begin(pl, sendbuf, vec + pl.nloc(), d->stream, overlap);
 }
 int halo_finish(amgh_dist* d, VecPlan& pl) {
   if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
@@ -539,7 +548,7 @@ int dist_apply(amgh_dist* d, DistOp& dop, int mode, VecPlan& pl, real* vec, cons
   const int32_t n = (int32_t)op->nrows;
   if (skip_exchange) return rows_apply(op, mode, vec, b, y, omega, 0, n, d->stream);
   const bool split = d->overlap && d->tr->async() && pl.any && d->tr->nranks > 1 && (dop.i1 - dop.i0) >= 65536;
-  RC_TRY(halo_begin(d, pl, vec));
+  RC_TRY(halo_begin(d, pl, vec, split));
   if (split) {
     RC_TRY(rows_apply(op, mode, vec, b, y, omega, dop.i0, dop.i1, d->stream));
     RC_TRY(halo_finish(d, pl));

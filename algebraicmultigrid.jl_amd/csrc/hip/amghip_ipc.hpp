@@ -68,7 +68,7 @@ struct IpcTransport : Transport {
     std::vector<real*> peer;         // peer-mapped send buffers of the producers this rank reads
     std::vector<int64_t> peer_nsend, peer_off;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-    bool attached = false;
+    bool attached = false, on_cs = false;
   };
   std::vector<PlanState> plans;
 
@@ -346,26 +346,34 @@ struct IpcTransport : Transport {
           HIP_TRY(hipStreamWaitValue64(st, dev_flag(done_index(pl.id, q, rank)), k - 2, hipStreamWaitValueGte, ~0ull));
     return AMGH_OK;
   }
-  int exchange_begin(VecPlan& pl, const real*, real* recvbuf, hipStream_t st) override {
+  int exchange_begin(VecPlan& pl, const real*, real* recvbuf, hipStream_t st, bool overlap) override {
     if (broken) return AMGH_ESTATE;
     PlanState& ps = plans[pl.id];
     const uint64_t k = ps.seq;
     if (pl.nsend > 0) HIP_TRY(hipStreamWriteValue64(st, dev_flag(ready_index(pl.id, rank)), k, 0));
-    // the halo region may still be read by what `st` ran before this exchange
-    HIP_TRY(hipEventRecord(ps.ev_ready, st));
-    HIP_TRY(hipStreamWaitEvent(cs, ps.ev_ready, 0));
+    ps.on_cs = overlap;
+    hipStream_t ts = st;
+    if (overlap) {   // the halo region may still be read by what `st` ran before this exchange
+      HIP_TRY(hipEventRecord(ps.ev_ready, st));
+      HIP_TRY(hipStreamWaitEvent(cs, ps.ev_ready, 0));
+      ts = cs;
+    }
     for (int p = 0; p < nranks; ++p) {
       if (p == rank || pl.recv[p].cnt <= 0) continue;
-      HIP_TRY(hipStreamWaitValue64(cs, dev_flag(ready_index(pl.id, p)), k, hipStreamWaitValueGte, ~0ull));
+      HIP_TRY(hipStreamWaitValue64(ts, dev_flag(ready_index(pl.id, p)), k, hipStreamWaitValueGte, ~0ull));
       const real* src = ps.peer[p] + (k & 1) * ps.peer_nsend[p] + ps.peer_off[p];
-      HIP_TRY(hipMemcpyAsync(recvbuf + pl.recv[p].off, src, sizeof(real) * (size_t)pl.recv[p].cnt, hipMemcpyDeviceToDevice, cs));
-      HIP_TRY(hipStreamWriteValue64(cs, dev_flag(done_index(pl.id, rank, p)), k, 0));
+      // a copy KERNEL pulls the entries out of the peer-mapped buffer: hipMemcpyAsync from IPC-mapped memory costs an
+      // order of magnitude more per call (tools/ipc_pingpong.hip: 200 vs 28 us per round trip at 512 KiB)
+      hipLaunchKernelGGL(copy_kernel, dim3(grid_for(pl.recv[p].cnt)), dim3(256), 0, ts, recvbuf + pl.recv[p].off, src,
+                         (int64_t)pl.recv[p].cnt);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamWriteValue64(ts, dev_flag(done_index(pl.id, rank, p)), k, 0));
     }
-    HIP_TRY(hipEventRecord(ps.ev_done, cs));
+    if (overlap) HIP_TRY(hipEventRecord(ps.ev_done, cs));
     return AMGH_OK;
   }
   int exchange_finish(VecPlan& pl, hipStream_t st) override {
-    HIP_TRY(hipStreamWaitEvent(st, plans[pl.id].ev_done, 0));
+    if (plans[pl.id].on_cs) HIP_TRY(hipStreamWaitEvent(st, plans[pl.id].ev_done, 0));
     return AMGH_OK;
   }
   // a stream of this rank may wait for a flag only another process writes: bounded, and released when a peer is gone
