@@ -7,11 +7,13 @@
 //   halo data    every plan's packed send buffer is exported with hipIpcGetMemHandle and mapped by the ranks that read
 //                it; an exchange is: producer packs into copy (k & 1) of its buffer and its STREAM writes k into the
 //                plan's `ready` flag (hipStreamWriteValue64 on a flag page of the segment, host-registered by every
-//                process); the consumer's communication stream waits for that flag (hipStreamWaitValue64), pulls its
-//                entries with one device-to-device copy per producer straight into the halo region of the vector (the
-//                halo is sorted by owner, so they land in place), and writes k into the pair's `done` flag, which the
-//                producer's stream waits on before it reuses the copy (exchange k + 2).  No host thread is involved in
-//                an exchange; interior rows of the consuming operator run while the copy is in flight.
+//                process); the consumer's stream waits for that flag (hipStreamWaitValue64), pulls its entries with one
+//                copy kernel per producer straight into the halo region of the vector (the halo is sorted by owner, so
+//                they land in place), and writes k into the pair's `done` flag, which the producer's stream waits on
+//                before it reuses the copy (exchange k + 2).  No host thread is involved in an exchange.  The transfer is
+//                enqueued on the caller's stream; only when interior rows of the consuming operator are to run
+//                meanwhile does it go to the communication stream between two events (a second stream costs more than
+//                an exchange of this size: tools/ipc_pingpong.hip).
 //   failure      host waits are bounded (AMGH_IPC_TIMEOUT_S, default 300) and watch the peers' pids; a rank that gives
 //                up sets the abort word and RELEASES every flag (writes a huge sequence number), so that no stream of
 //                any rank keeps waiting for a producer that is gone; from then on every call returns AMGH_ESTATE.

@@ -309,8 +309,8 @@ int amgh_dist_create_local(amgh_dist_t** d, int device, int rank, amgh_local_gro
 /* IPC transport: one PROCESS per rank and only shared memory between them — the ranks' packed send
  * buffers are peer-mapped with hipIpc memory handles, the hand-off of an exchange is a sequence flag the
  * producer's stream writes and the consumer's stream waits on (hipStreamWriteValue64 / WaitValue64 on a
- * page of a POSIX shared-memory segment), the consumer pulls its halo entries with one device-to-device
- * copy per peer; no host thread takes part in an exchange.  Every rank passes the same fresh
+ * page of a POSIX shared-memory segment), the consumer pulls its halo entries with one copy kernel per
+ * peer; no host thread takes part in an exchange.  Every rank passes the same fresh
  * `shm_name` ("/name", shm_open syntax); rank 0 creates the segment; the call returns when all
  * `nranks` (<= 64) processes have attached (collective).  Ranks may share a device (RCCL refuses that),
  * so a single-GPU box can run the multi-process path.  Host waits are bounded (AMGH_IPC_TIMEOUT_S,
