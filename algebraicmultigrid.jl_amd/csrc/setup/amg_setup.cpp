@@ -1073,6 +1073,114 @@ void gs_sweep_host(const Mat& A, const double* b, double* x, bool forward) {
   }
 }
 
+// The same sweeps in parallel, EXACTLY: the lexicographic sweep is a sparse triangular solve, its result depends only on
+// the dependency DAG.  With level[i] = 1 + max(level[j] : j adjacent to i, j < i) on the symmetrised pattern, the rows of
+// one level read no row of their own level: a forward sweep visits the levels upward, a backward sweep downward, the rows
+// of a level on all threads — every row runs the scalar loop of gs_sweep_host on the same operands in the same order,
+// so the iterates are bitwise those of the sequential sweep (what the GPU smoothers do per launch, done here with
+// OpenMP for improve_candidates: 8 sweeps over the level matrix, 1.3 s of the 3.8 s of smoothed_aggregation(256^3)).
+struct GsLevels {
+  std::vector<int32_t> lvl_ptr, rows;  // rows of level l: rows[lvl_ptr[l] .. lvl_ptr[l+1]), ascending inside a level
+  int nlev() const { return (int)lvl_ptr.size() - 1; }
+};
+GsLevels gs_levels_host(const Mat& A) {
+  const int64_t n = A.m;
+  std::vector<int32_t> lev(n, 0);
+  int32_t maxlev = -1;
+  // First from the lower neighbours alone (one sequential read pass, no scattered writes) — complete when the pattern is
+  // structurally symmetric, which a parallel pass then verifies: every upper neighbour must sit in a later level.
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t li = 0;
+    for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) {
+      const int32_t c = A.rowval[j];
+      if (c < i) li = std::max(li, lev[c] + 1);
+    }
+    lev[i] = li;
+    maxlev = std::max(maxlev, li);
+  }
+  int64_t bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+  for (int64_t i = 0; i < n; ++i)
+    for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) {
+      const int32_t c = A.rowval[j];
+      if (c > i && c < n && lev[c] <= lev[i]) ++bad;
+    }
+  if (bad) {  // not symmetric: the levels of the symmetrised pattern (as the GPU schedules compute them)
+    std::fill(lev.begin(), lev.end(), 0);
+    maxlev = -1;
+    for (int64_t i = 0; i < n; ++i) {
+      int32_t li = lev[i];
+      for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) {
+        const int32_t c = A.rowval[j];
+        if (c < i) li = std::max(li, lev[c] + 1);
+      }
+      lev[i] = li;
+      for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) {
+        const int32_t c = A.rowval[j];
+        if (c > i && c < n) lev[c] = std::max(lev[c], li + 1);
+      }
+      maxlev = std::max(maxlev, li);
+    }
+  }
+  GsLevels G;
+  G.lvl_ptr.assign(maxlev + 2, 0);
+  for (int64_t i = 0; i < n; ++i) G.lvl_ptr[lev[i] + 1]++;
+  for (int l = 0; l <= maxlev; ++l) G.lvl_ptr[l + 1] += G.lvl_ptr[l];
+  G.rows.resize(n);
+  std::vector<int32_t> next(G.lvl_ptr.begin(), G.lvl_ptr.end() - 1);
+  for (int64_t i = 0; i < n; ++i) G.rows[next[lev[i]]++] = (int32_t)i;
+  return G;
+}
+inline void gs_row_host(const Mat& A, const double* b, double* x, int64_t i) {
+  double rsum = 0.0, d = 0.0;
+  for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) {
+    const int32_t row = A.rowval[j];
+    const double val = A.nzval[j];
+    if (row == i)
+      d = val;
+    else
+      rsum += val * x[row];
+  }
+  if (d != 0.0) x[i] = (b[i] - rsum) / d;
+}
+// iters symmetric sweeps on each of the nB columns of B (b = 0): improve_candidates (aggregation.jl:135-136)
+void improve_candidates_host(const Mat& A, double* B, int nB, int iters) {
+  const int64_t n = A.m;
+  std::vector<double> zero(n, 0.0);
+  int threads = 1;
+#ifdef _OPENMP
+  threads = omp_get_max_threads();
+#endif
+  const bool par = threads > 1 && n >= 100000 && !std::getenv("AMGS_SEQUENTIAL_GS");
+  GsLevels G;
+  if (par) G = gs_levels_host(A);
+  if (!par || (int64_t)G.nlev() * 256 > n) {   // few rows per level: the barriers would cost more than the rows
+    for (int c = 0; c < nB; ++c)
+      for (int it = 0; it < iters; ++it) {
+        gs_sweep_host(A, zero.data(), B + (size_t)c * n, true);
+        gs_sweep_host(A, zero.data(), B + (size_t)c * n, false);
+      }
+    return;
+  }
+  const int nlev = G.nlev();
+  const double* b = zero.data();
+#pragma omp parallel
+  {
+    for (int c = 0; c < nB; ++c) {
+      double* x = B + (size_t)c * n;
+      for (int it = 0; it < iters; ++it)
+        for (int dir = 0; dir < 2; ++dir)
+          for (int q = 0; q < nlev; ++q) {
+            const int l = dir == 0 ? q : nlev - 1 - q;
+            const int32_t r0 = G.lvl_ptr[l], r1 = G.lvl_ptr[l + 1];
+#pragma omp for schedule(static)
+            for (int32_t p = r0; p < r1; ++p) gs_row_host(A, b, x, G.rows[p]);
+            // (implicit barrier: the next level reads what this one wrote)
+          }
+    }
+  }
+}
+
 }  // namespace
 
 struct amgs_hier {
@@ -1184,16 +1292,9 @@ amgs_hier* smoothed_aggregation(const Mat& A0, const double* B0, int nB, const a
     if (AggOp->m == 0) break;
     // improve_candidates(A, B, 0): always the Hermitian fast path
     // (aggregation.jl:135-136, smoother.jl:34-38); symmetric sweep x iter.
-    {
-      std::vector<double> zero(n, 0.0);
-      // gs! loops the columns of B inside each directional pass (smoother.jl:77);
-      // columns are independent, so sweeping column-by-column is equivalent.
-      for (int c = 0; c < nB; ++c)
-        for (int it = 0; it < o.sa_improve_iters; ++it) {
-          gs_sweep_host(*A, zero.data(), B.data() + (size_t)c * n, true);
-          gs_sweep_host(*A, zero.data(), B.data() + (size_t)c * n, false);
-        }
-    }
+    // gs! loops the columns of B inside each directional pass (smoother.jl:77);
+    // columns are independent, so sweeping column-by-column is equivalent.
+    improve_candidates_host(*A, B.data(), nB, o.sa_improve_iters);
     tm.lap("improve candidates", n);
     std::vector<double> Bc;
     MatP T = vector_path ? fit_candidates_vector(*AggOp, B.data(), 1e-10, Bc)
@@ -1353,13 +1454,7 @@ amgs_mat* amgs_jacobi_prolongation(const amgs_mat* A, const amgs_mat* T, double 
 int amgs_improve_candidates(const amgs_mat* A, double* B, int nB, int iters) {
   return Guard::rc([&]() {
     if (A->m != A->n) throw std::runtime_error("improve_candidates: matrix must be square");
-    const int64_t n = A->m;
-    std::vector<double> zero(n, 0.0);
-    for (int c = 0; c < nB; ++c)
-      for (int it = 0; it < iters; ++it) {
-        gs_sweep_host(*A, zero.data(), B + (size_t)c * n, true);
-        gs_sweep_host(*A, zero.data(), B + (size_t)c * n, false);
-      }
+    improve_candidates_host(*A, B, nB, iters);
   });
 }
 void amgs_free(void* p) { std::free(p); }

@@ -680,25 +680,42 @@ def _smoothed_aggregation_gpu(A, B, theta, omega, improve_iters, hermitian, max_
         hip_check(rc, "setup_spgemm")
         return _DMat(c.value, lib)
 
+    import os
+    import time
+    timing = {} if os.environ.get("AMG_SETUP_TIMING") else None
+    t_last = [time.perf_counter()]
+
+    def tick(label):
+        if timing is not None:
+            now = time.perf_counter()
+            timing[label] = timing.get(label, 0.0) + now - t_last[0]
+            t_last[0] = now
+
     vector = B is None or B.ndim == 1
     n0 = A.m
     Bcur = np.ones(n0) if B is None else np.array(B, dtype=np.float64, order="F", copy=True)
     out = []
     A_host, dA = A, _DMat.upload(A, lib, device)
+    tick("upload A")
     bsr_flag = False
     strength = SymmetricStrength(theta)
     while len(out) + 1 < max_levels and A_host.m > max_coarse:
         n = A_host.m
         S, _ = strength(A_host if hermitian else A_host.transpose(), bsr_flag)
+        tick("symmetric strength (host)")
         AggOp = SparseMatrixCSC(L.amgs_standard_aggregation(S._h))
+        tick("aggregation (host)")
         if AggOp.m == 0:
             break
         nB = 1 if vector else Bcur.shape[1]
         Bf = np.asfortranarray(Bcur.reshape(n, nB))
         if L.amgs_improve_candidates(A_host._h, Bf.ctypes.data, nB, int(improve_iters)) != 0:
             raise AMGError(L.amgs_last_error().decode())
+        tick("improve_candidates (host)")
         T, Bc = fit_candidates(AggOp, Bf[:, 0] if vector else Bf)
+        tick("fit_candidates (host)")
         dT = _DMat.upload(T, lib, device)
+        tick("upload T")
         p = C.c_void_p()
         rc = lib.amgh_setup_jacobi_prolongation(dA.h, dT.h, omega, C.byref(p))
         if rc == -5:
@@ -706,16 +723,23 @@ def _smoothed_aggregation_gpu(A, B, theta, omega, improve_iters, hermitian, max_
         else:
             hip_check(rc, "setup_jacobi_prolongation")
             dP = _DMat(p.value, lib)
+        tick("prolongation smoothing (GPU)")
         if dP.n == 0:
             break
         r = C.c_void_p()
         hip_check(lib.amgh_setup_transpose(dP.h, C.byref(r)), "setup_transpose")
         dR = _DMat(r.value, lib)
         dRAP = spgemm(spgemm(dR, dA), dP)
+        tick("R*A*P (GPU)")
         out.append((A_host, dP.to_host(), dR.to_host()))
         A_host, dA = dRAP.to_host(), dRAP
+        tick("download P, R, RAP")
         Bcur = Bc
         bsr_flag = True
+    if timing is not None:
+        import sys
+        print("smoothed_aggregation(setup='gpu') seconds: " + ", ".join(f"{k} {v:.2f}" for k, v in timing.items()),
+              file=sys.stderr, flush=True)
     return out, A_host
 
 

@@ -265,3 +265,24 @@ def test_poisson_gallery():  # gallery.jl:1-63
     A3 = AMG.poisson((8, 8, 8))
     assert A3.m == 512 and A3.nnz == 7 * 512 - 6 * 64
     assert AMG.poisson((256, 1)).nnz == 3 * 256 - 2
+
+
+def test_improve_candidates_level_parallel_sweeps_are_bitwise_the_sequential_ones(monkeypatch):
+    """improve_candidates (aggregation.jl:135-136: symmetric Gauss-Seidel on the candidates, the Hermitian fast path of
+    smoother.jl:61-90) runs its sweeps level-scheduled on all host threads for big operators: rows of one dependency
+    level in parallel, each with the scalar loop's arithmetic — bit for bit the sequential sweeps."""
+    import numpy as np
+    from amg_amd._libs import setup_lib
+    L = setup_lib()
+    A = AMG.poisson((60, 50, 40))        # 120 000 rows: above the threshold of the parallel path
+    n = A.m
+    out = {}
+    for seq in ("1", None):
+        if seq:
+            monkeypatch.setenv("AMGS_SEQUENTIAL_GS", seq)
+        else:
+            monkeypatch.delenv("AMGS_SEQUENTIAL_GS", raising=False)
+        B = np.asfortranarray(np.stack([np.ones(n) + 1e-3 * np.cos(np.arange(n)), np.linspace(-1.0, 1.0, n)], axis=1))
+        assert L.amgs_improve_candidates(A._h, B.ctypes.data, 2, 3) == 0
+        out[seq] = B.copy()
+    assert np.array_equal(out["1"], out[None])
