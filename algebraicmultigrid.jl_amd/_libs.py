@@ -52,6 +52,7 @@ def setup_lib():
     L = C.CDLL(SETUP_SO)
     L.amgs_last_error.restype = C.c_char_p
     L.amgs_set_threads.argtypes = [C.c_int]
+    L.amgs_set_threads_here.argtypes = [C.c_int]
     L.amgs_mat_create.restype = vp
     L.amgs_mat_create.argtypes = [i64, i64, vp, vp, vp]
     L.amgs_mat_free.argtypes = [vp]

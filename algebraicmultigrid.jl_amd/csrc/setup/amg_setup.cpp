@@ -349,14 +349,17 @@ MatP symmetric_strength(const Mat& A, double theta, bool bsr_flag) {
     return S;
   }
   const int64_t n = A.m;
+  const int64_t lim = std::min(n, A.n);
   std::vector<double> diags(n, 0.0);
-  for (int64_t i = 0; i < n && i < A.n; ++i) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < lim; ++i) {
     double d = 0.0;
     for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j)
       if (A.rowval[j] == i) d += A.nzval[j];
     diags[i] = std::fabs(d);
   }
-  for (int64_t i = 0; i < n && i < A.n; ++i) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < lim; ++i) {
     double eps_Aii = theta * theta * diags[i];
     for (int32_t j = A.colptr[i]; j < A.colptr[i + 1]; ++j) {
       int32_t row = A.rowval[j];
@@ -365,7 +368,10 @@ MatP symmetric_strength(const Mat& A, double theta, bool bsr_flag) {
     }
   }
   dropzeros(*S);
-  for (double& v : S->nzval) v = std::fabs(v);
+  const int64_t snz = S->nnz();
+  double* sv = S->nzval.data();
+#pragma omp parallel for schedule(static)
+  for (int64_t k = 0; k < snz; ++k) sv[k] = std::fabs(sv[k]);
   scale_cols_by_largest_entry(*S);
   return S;
 }
@@ -1190,9 +1196,24 @@ struct amgs_hier {
 
 namespace {
 
+// OpenMP's thread count is a per-host-thread setting: a host thread other than the one that loaded the library (a
+// worker of the Python setup pipeline) would start with the runtime's default — every CPU of the machine, whatever the
+// container's quota.  Each entry point therefore adopts the library-wide cap the first time a host thread enters.
+int g_threads_cap = 0;
+inline void adopt_thread_cap() {
+#ifdef _OPENMP
+  static thread_local bool done = false;
+  if (!done) {
+    done = true;
+    if (g_threads_cap > 0) omp_set_num_threads(g_threads_cap);
+  }
+#endif
+}
+
 struct Guard {
   template <class F>
   static auto ptr(F f) -> decltype(f()) {
+    adopt_thread_cap();
     try {
       return f();
     } catch (const std::exception& e) {
@@ -1202,6 +1223,7 @@ struct Guard {
   }
   template <class F>
   static int rc(F f) {
+    adopt_thread_cap();
     try {
       f();
       return 0;
@@ -1347,13 +1369,18 @@ __attribute__((constructor)) static void amgs_default_threads() {
     }
   }
   if (quota > 0 && period > 0) cap = std::min<long>(cap, std::max<long>(1, (quota + period - 1) / period));
+  g_threads_cap = cap;
   omp_set_num_threads(cap);
 }
 #endif
 
 int amgs_set_threads(int nthreads) {
 #ifdef _OPENMP
-  if (nthreads > 0) omp_set_num_threads(nthreads);
+  adopt_thread_cap();
+  if (nthreads > 0) {
+    g_threads_cap = nthreads;
+    omp_set_num_threads(nthreads);
+  }
   return omp_get_max_threads();
 #else
   (void)nthreads;
@@ -1456,6 +1483,16 @@ int amgs_improve_candidates(const amgs_mat* A, double* B, int nB, int iters) {
     if (A->m != A->n) throw std::runtime_error("improve_candidates: matrix must be square");
     improve_candidates_host(*A, B, nB, iters);
   });
+}
+int amgs_set_threads_here(int nthreads) {
+#ifdef _OPENMP
+  adopt_thread_cap();
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+  return omp_get_max_threads();
+#else
+  (void)nthreads;
+  return 1;
+#endif
 }
 void amgs_free(void* p) { std::free(p); }
 

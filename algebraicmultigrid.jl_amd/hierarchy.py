@@ -666,7 +666,10 @@ def _smoothed_aggregation_gpu(A, B, theta, omega, improve_iters, hermitian, max_
     P = T - (omega D^-1 A) T (amgh_setup_jacobi_prolongation: row sums, scaling, SpGEMM, subtraction) and R*A*P
     (transpose + two SpGEMMs).  Strength, the sequential aggregation, improve_candidates (Gauss-Seidel on the
     candidates) and fit_candidates (a QR per aggregate) run in the host library on the level matrix, which is
-    downloaded anyway.  Returns [(A, P, R), ...], final_A — bitwise what amgs_smoothed_aggregation builds."""
+    downloaded anyway.  improve_candidates needs only A and B, strength + aggregation only A: the two chains run side
+    by side on two host threads (half the OpenMP threads each), and a third thread downloads P and R — nothing on the
+    way down reads them — while the next level is under construction.
+    Returns [(A, P, R), ...], final_A — bitwise what amgs_smoothed_aggregation builds."""
     from ._libs import hip_check, hip_lib
     lib, L = hip_lib(), setup_lib()
     if lib.amgh_device_count() <= 0:
@@ -699,43 +702,85 @@ def _smoothed_aggregation_gpu(A, B, theta, omega, improve_iters, hermitian, max_
     tick("upload A")
     bsr_flag = False
     strength = SymmetricStrength(theta)
-    while len(out) + 1 < max_levels and A_host.m > max_coarse:
-        n = A_host.m
-        S, _ = strength(A_host if hermitian else A_host.transpose(), bsr_flag)
-        tick("symmetric strength (host)")
-        AggOp = SparseMatrixCSC(L.amgs_standard_aggregation(S._h))
-        tick("aggregation (host)")
-        if AggOp.m == 0:
-            break
-        nB = 1 if vector else Bcur.shape[1]
-        Bf = np.asfortranarray(Bcur.reshape(n, nB))
-        if L.amgs_improve_candidates(A_host._h, Bf.ctypes.data, nB, int(improve_iters)) != 0:
-            raise AMGError(L.amgs_last_error().decode())
-        tick("improve_candidates (host)")
-        T, Bc = fit_candidates(AggOp, Bf[:, 0] if vector else Bf)
-        tick("fit_candidates (host)")
-        dT = _DMat.upload(T, lib, device)
-        tick("upload T")
-        p = C.c_void_p()
-        rc = lib.amgh_setup_jacobi_prolongation(dA.h, dT.h, omega, C.byref(p))
-        if rc == -5:
-            dP = _DMat.upload(SparseMatrixCSC(L.amgs_jacobi_prolongation(A_host._h, T._h, omega)), lib, device)
-        else:
-            hip_check(rc, "setup_jacobi_prolongation")
-            dP = _DMat(p.value, lib)
-        tick("prolongation smoothing (GPU)")
-        if dP.n == 0:
-            break
-        r = C.c_void_p()
-        hip_check(lib.amgh_setup_transpose(dP.h, C.byref(r)), "setup_transpose")
-        dR = _DMat(r.value, lib)
-        dRAP = spgemm(spgemm(dR, dA), dP)
-        tick("R*A*P (GPU)")
-        out.append((A_host, dP.to_host(), dR.to_host()))
-        A_host, dA = dRAP.to_host(), dRAP
-        tick("download P, R, RAP")
-        Bcur = Bc
-        bsr_flag = True
+    import threading
+    threads_all = int(L.amgs_set_threads(0))
+    side = _Pipeline()            # improve_candidates beside strength + aggregation
+    fetch = _Pipeline()           # downloads of P and R
+    fetched = []
+
+    def improve(A_h, Bf, nB, box, share):
+        L.amgs_set_threads_here(share)
+        if L.amgs_improve_candidates(A_h._h, Bf.ctypes.data, nB, int(improve_iters)) != 0:
+            box.append(AMGError(L.amgs_last_error().decode()))
+
+    def fetch_pr(slot, dP, dR):
+        fetched[slot] = (dP.to_host(), dR.to_host())
+
+    try:
+        while len(out) + 1 < max_levels and A_host.m > max_coarse:
+            n = A_host.m
+            nB = 1 if vector else Bcur.shape[1]
+            Bf = np.asfortranarray(Bcur.reshape(n, nB))
+            if Bf is Bcur or np.shares_memory(Bf, Bcur):
+                Bf = Bf.copy(order="F")            # the sweeps work in place; a level that ends the loop leaves B alone
+            share = max(1, threads_all // 2) if threads_all > 1 and A_host.nnz > 1 << 20 else 0
+            failed, done = [], threading.Event()
+            if share:
+                side.submit(improve, A_host, Bf, nB, failed, share)
+                side.submit(done.set)
+                L.amgs_set_threads_here(threads_all - share)
+            S, _ = strength(A_host if hermitian else A_host.transpose(), bsr_flag)
+            tick("symmetric strength (host)")
+            AggOp = SparseMatrixCSC(L.amgs_standard_aggregation(S._h))
+            tick("aggregation (host)")
+            if share:
+                while not done.wait(0.05):
+                    if side.exc is not None:
+                        break
+                L.amgs_set_threads_here(threads_all)
+                if side.exc is not None:
+                    raise side.exc
+            else:
+                improve(A_host, Bf, nB, failed, threads_all)
+            if failed:
+                raise failed[0]
+            tick("improve_candidates (host)")
+            if AggOp.m == 0:
+                break
+            T, Bc = fit_candidates(AggOp, Bf[:, 0] if vector else Bf)
+            tick("fit_candidates (host)")
+            dT = _DMat.upload(T, lib, device)
+            tick("upload T")
+            p = C.c_void_p()
+            rc = lib.amgh_setup_jacobi_prolongation(dA.h, dT.h, omega, C.byref(p))
+            if rc == -5:
+                dP = _DMat.upload(SparseMatrixCSC(L.amgs_jacobi_prolongation(A_host._h, T._h, omega)), lib, device)
+            else:
+                hip_check(rc, "setup_jacobi_prolongation")
+                dP = _DMat(p.value, lib)
+            tick("prolongation smoothing (GPU)")
+            if dP.n == 0:
+                break
+            r = C.c_void_p()
+            hip_check(lib.amgh_setup_transpose(dP.h, C.byref(r)), "setup_transpose")
+            dR = _DMat(r.value, lib)
+            dRAP = spgemm(spgemm(dR, dA), dP)
+            tick("R*A*P (GPU)")
+            fetched.append(None)
+            fetch.submit(fetch_pr, len(fetched) - 1, dP, dR)
+            out.append(A_host)
+            A_host, dA = dRAP.to_host(), dRAP
+            tick("download RAP")
+            Bcur = Bc
+            bsr_flag = True
+    except BaseException:
+        side.close(reraise=False)
+        fetch.close(reraise=False)
+        raise
+    side.close()
+    fetch.close()
+    out = [(a, *pr) for a, pr in zip(out, fetched)]
+    tick("wait for the downloads of P, R")
     if timing is not None:
         import sys
         print("smoothed_aggregation(setup='gpu') seconds: " + ", ".join(f"{k} {v:.2f}" for k, v in timing.items()),

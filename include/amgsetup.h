@@ -41,6 +41,9 @@ typedef struct amgs_hier amgs_hier; /* hierarchy: levels (A,P,R) + final_A    */
 
 const char* amgs_last_error(void);
 int amgs_set_threads(int nthreads); /* OpenMP threads for SpGEMM/transposes   */
+/* The same for the CALLING host thread only (OpenMP's setting is per host thread; other host threads keep the
+ * library-wide count of amgs_set_threads): two host threads that run library calls side by side split the cores. */
+int amgs_set_threads_here(int nthreads);
 
 /* ---- matrices ---------------------------------------------------------- */
 amgs_mat* amgs_mat_create(int64_t m, int64_t n, const int32_t* colptr,
