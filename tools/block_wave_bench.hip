@@ -1,0 +1,129 @@
+// block_wave_bench — the block-wavefront Gauss-Seidel sweep of tools/gs_blocks.hpp: plan (partition by
+// monotone potentials), layout, forward / backward sweeps checked bit for bit against the scalar loops, timings.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/block_wave_bench tools/block_wave_bench.hip
+// usage: block_wave_bench poisson N [target_rows]
+//        block_wave_bench file PATH [target_rows]    PATH: int64 n, int64 nnz, int32 rowptr[n+1], int32 col[nnz], double val[nnz]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include "gs_blocks.hpp"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+using namespace amgh;
+
+struct Csr { int64_t n = 0; std::vector<int32_t> rp, ci; std::vector<double> va; };
+static Csr poisson3(int N) {
+  Csr A; A.n = (int64_t)N * N * N; A.rp.assign(A.n + 1, 0);
+  A.ci.reserve(7 * A.n); A.va.reserve(7 * A.n);
+  for (int k = 0; k < N; ++k) for (int j = 0; j < N; ++j) for (int i = 0; i < N; ++i) {
+    const int64_t r = i + (int64_t)N * (j + (int64_t)N * k);
+    if (k > 0) { A.ci.push_back((int32_t)(r - (int64_t)N * N)); A.va.push_back(-1.0); }
+    if (j > 0) { A.ci.push_back((int32_t)(r - N)); A.va.push_back(-1.0); }
+    if (i > 0) { A.ci.push_back((int32_t)(r - 1)); A.va.push_back(-1.0); }
+    A.ci.push_back((int32_t)r); A.va.push_back(6.0);
+    if (i < N - 1) { A.ci.push_back((int32_t)(r + 1)); A.va.push_back(-1.0); }
+    if (j < N - 1) { A.ci.push_back((int32_t)(r + N)); A.va.push_back(-1.0); }
+    if (k < N - 1) { A.ci.push_back((int32_t)(r + (int64_t)N * N)); A.va.push_back(-1.0); }
+    A.rp[r + 1] = (int32_t)A.ci.size();
+  }
+  return A;
+}
+static Csr load(const char* path) {
+  Csr A; FILE* f = fopen(path, "rb"); if (!f) { printf("cannot open %s\n", path); exit(1); }
+  int64_t hdr[2]; if (fread(hdr, 8, 2, f) != 2) exit(1);
+  A.n = hdr[0]; A.rp.resize(A.n + 1); A.ci.resize(hdr[1]); A.va.resize(hdr[1]);
+  if (fread(A.rp.data(), 4, A.n + 1, f) != (size_t)A.n + 1 || fread(A.ci.data(), 4, hdr[1], f) != (size_t)hdr[1] ||
+      fread(A.va.data(), 8, hdr[1], f) != (size_t)hdr[1]) exit(1);
+  fclose(f); return A;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) { printf("usage: block_wave_bench poisson N | file PATH  [target_rows]\n"); return 1; }
+  Csr A = std::string(argv[1]) == "poisson" ? poisson3(atoi(argv[2])) : load(argv[2]);
+  const int64_t n = A.n;
+  bw::Params prm; if (argc > 3) prm.target_rows = atoi(argv[3]);
+  const bool want_reg = argc > 4 && atoi(argv[4]) != 0;
+  prm.threads = 8;
+  bw::Plan P;
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool ok = bw::plan<double>(n, A.rp.data(), A.ci.data(), A.va.data(), prm, &P);
+  const double tplan = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (!ok) { printf("plan: not eligible\n"); return 0; }
+  const int nl = (int)P.launch_ptr.size() - 1;
+  const bool use_reg = want_reg && P.blocks[0].maxk == 6 && P.max_rows <= 64 * bw::kRegRpt;
+  printf("kernel: %s\n", use_reg ? "operands in registers" : "operands from LDS (generic)");
+  int maxb = 0, under = 0;
+  for (int l = 0; l < nl; ++l) { const int c = P.launch_ptr[l + 1] - P.launch_ptr[l]; maxb = std::max(maxb, c); under += c < 256; }
+  std::vector<int> rows; for (auto& d : P.blocks) rows.push_back(d.nrows); std::sort(rows.begin(), rows.end());
+  printf("n = %lld nnz = %lld: plan %.2f s; offset cuts %d %d, potential ranges %d %d %d, cells %d x %d x %d -> %zu blocks (rows: min %d median %d max %d), maxk %d\n",
+         (long long)n, (long long)P.nnz, tplan, P.cuts[0], P.cuts[1], P.range[0], P.range[1], P.range[2], P.cells[0], P.cells[1], P.cells[2], P.blocks.size(),
+         rows.front(), rows[rows.size() / 2], rows.back(), P.blocks[0].maxk);
+  printf("launches %d (dependency levels %d), up to %d blocks, %d launches under 256 blocks; sum of deepest blocks %lld levels; external x per row %.3f; LDS %.1f KB; record bytes %.3f GB; model %.3f ms per sweep\n",
+         nl, P.nlevels, maxb, under, (long long)P.sum_depth, (double)P.ext_total / n, P.lds_max / 1024.0, P.rec.size() / 1e9, P.est_seconds * 1e3);
+  // data
+  std::vector<double> b(n), x0(n), xb(n), bb(n);
+  for (int64_t i = 0; i < n; ++i) { b[i] = std::sin(0.37 * (double)(i % 1000)) + 0.5; x0[i] = std::cos(0.11 * (double)(i % 777)); }
+  for (int64_t p = 0; p < n; ++p) { xb[p] = x0[P.perm[p]]; bb[p] = b[P.perm[p]]; }
+  std::vector<double> xr = x0;
+  auto scalar = [&](bool bwd) {
+    for (int64_t s = 0; s < n; ++s) {
+      const int64_t i = bwd ? n - 1 - s : s;
+      double acc = 0.0, dg = 0.0;
+      for (int32_t j = A.rp[i]; j < A.rp[i + 1]; ++j) { if (A.ci[j] == i) dg = A.va[j]; else acc += A.va[j] * xr[A.ci[j]]; }
+      if (dg != 0.0) xr[i] = (b[i] - acc) / dg;
+    }
+  };
+  bw::Desc* d_blocks; unsigned char* d_rec; int32_t* d_ext; double *d_b, *d_x;
+  CHECK(hipMalloc(&d_blocks, sizeof(bw::Desc) * P.blocks.size())); CHECK(hipMalloc(&d_rec, P.rec.size())); CHECK(hipMalloc(&d_ext, 4 * std::max<size_t>(1, P.ext_col.size())));
+  CHECK(hipMalloc(&d_b, 8 * n)); CHECK(hipMalloc(&d_x, 8 * n));
+  CHECK(hipMemcpy(d_blocks, P.blocks.data(), sizeof(bw::Desc) * P.blocks.size(), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_rec, P.rec.data(), P.rec.size(), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_ext, P.ext_col.data(), 4 * P.ext_col.size(), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_b, bb.data(), 8 * n, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+  bw::Args<double> a{d_blocks, d_rec, d_ext, d_b, d_x, n, n, 1.0, 0, nullptr, nullptr, 0};
+  hipStream_t st; CHECK(hipStreamCreate(&st));
+  CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, false, 1, st, use_reg));
+  CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, true, 1, st, use_reg));
+  CHECK(hipStreamSynchronize(st));
+  std::vector<double> xg(n);
+  CHECK(hipMemcpy(xg.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+  scalar(false); scalar(true);
+  int64_t diff = 0; double maxd = 0.0;
+  for (int64_t p = 0; p < n; ++p) { const double e = std::fabs(xg[p] - xr[P.perm[p]]); if (xg[p] != xr[P.perm[p]]) ++diff; maxd = std::max(maxd, e); }
+  printf("forward + backward vs the scalar loops: %lld values differ (max |diff| %.3e)\n", (long long)diff, maxd);
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  const double bytes = (double)P.rec.size() + n * 24.0 + P.ext_total * 12.0;
+  for (int bwd = 0; bwd < 2; ++bwd) {
+    CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, bwd, 1, st, use_reg)); CHECK(hipStreamSynchronize(st));
+    const int reps = 5;
+    CHECK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, bwd, 1, st, use_reg));
+    CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%s sweep: %.3f ms = %d launches x %.2f us (%.0f GB/s)\n", bwd ? "backward" : "forward ", ms / reps, nl, ms / reps / nl * 1e3, bytes / (ms / reps * 1e-3) / 1e9);
+  }
+  // where a launch's time goes: wall-clock stamps (100 MHz) of every block of one forward sweep
+  {
+    long long* d_tim; CHECK(hipMalloc(&d_tim, 32 * P.blocks.size()));
+    a.tim = d_tim;
+    CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, false, 1, st, use_reg)); CHECK(hipStreamSynchronize(st));
+    std::vector<long long> tim(4 * P.blocks.size());
+    CHECK(hipMemcpy(tim.data(), d_tim, 32 * P.blocks.size(), hipMemcpyDeviceToHost));
+    double s_load = 0, s_sweep = 0, s_store = 0, s_span = 0, s_gap = 0; long long prev_end = 0; int cnt = 0;
+    printf("launch: blocks | first start -> last end (span), mean load / sweep / write-back per block, gap to the previous launch [us]\n");
+    for (int l = 0; l < nl; ++l) {
+      long long t0 = -1, t3 = 0; double ld = 0, sw = 0, wb = 0; const int nb = P.launch_ptr[l + 1] - P.launch_ptr[l];
+      for (int b = P.launch_ptr[l]; b < P.launch_ptr[l + 1]; ++b) {
+        const long long* t = &tim[4 * (size_t)b];
+        if (t0 < 0 || t[0] < t0) t0 = t[0];
+        t3 = std::max(t3, t[3]); ld += (t[1] - t[0]) * 0.01; sw += (t[2] - t[1]) * 0.01; wb += (t[3] - t[2]) * 0.01;
+      }
+      const double span = (t3 - t0) * 0.01, gap = l ? (t0 - prev_end) * 0.01 : 0.0;
+      if (l % 8 == 0 || l == nl - 1) printf("  %3d: %4d | span %6.2f  load %6.2f  sweep %6.2f  write-back %5.2f  gap %5.2f\n", l, nb, span, ld / nb, sw / nb, wb / nb, gap);
+      s_load += ld / nb; s_sweep += sw / nb; s_store += wb / nb; s_span += span; s_gap += gap; prev_end = t3; ++cnt;
+    }
+    printf("sum over %d launches: spans %.1f us, gaps %.1f us; mean per launch: load %.2f, sweep %.2f, write-back %.2f us\n", cnt, s_span, s_gap,
+           s_load / cnt, s_sweep / cnt, s_store / cnt);
+  }
+  return 0;
+}

@@ -1,0 +1,707 @@
+// gs_blocks.hpp — exact lexicographic Gauss-Seidel as a WAVEFRONT OF BLOCKS (no substitution, no recomputation).
+//
+// smoother.jl:61-90 sweeps the rows in index order; any order that respects the dependency DAG (row i after every
+// adjacent row c < i, before every adjacent row c > i) gives the same iterate.  The level schedules of gs_schedule.hpp
+// pay a kernel boundary per dependency level (or per group of levels, after substitution).  Here the rows are
+// partitioned into BLOCKS whose quotient graph is acyclic; blocks at the same depth of the quotient DAG are independent
+// and form one launch; inside a block ONE wave walks the block's own dependency levels with the block's x in LDS —
+// LDS operations of one wave execute in program order, so there is no barrier at all between the levels.  Every row is
+// summed by one lane in the stored entry order with separately rounded products and divided by its diagonal: the
+// iterate is the scalar loop's bit for bit, forward and backward from the same layout.
+//
+// Acyclic partition from MONOTONE POTENTIALS: a potential phi is any row function with phi(c) <= phi(i) along every
+// dependency edge c -> i.  Cells of the product quantisation (phi_1 / h_1, phi_2 / h_2, phi_3 / h_3) depend only on cells
+// that are <= in every coordinate, so the quotient graph is acyclic whatever the matrix.  The potentials are longest
+// paths with 0/1 edge weights: phi_k counts the edges of offset class k, the classes being the clusters of the index
+// offsets i - c on a log scale (on a lexicographically ordered grid: the x / y / z neighbours, and the skewed
+// equivalents on the Ruge-Stueben coarse grids of such a grid).  Cells with more rows than a workgroup can hold are cut
+// along the dependency level (one more monotone potential), a single oversized level into chunks of independent rows.
+// The construction is always valid; whether it is USED is a cost-model decision (launches, depth, bytes).
+#pragma once
+#ifndef BW_OPT
+#define BW_OPT 0   // 1: division by the diagonal as reciprocal + one exact correction; 2: x gather issued before the next step's operand loads; 4: next launch's records prefetched
+#endif
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace amgh {
+namespace bw {
+
+struct Desc {          // one block (32 bytes)
+  int32_t row0, nrows; // rows of the block in block order (sorted by in-block dependency level)
+  int32_t rec;         // the block's record in the record buffer, in units of 16 bytes
+  int32_t S;           // row stride of the record's ELL arrays (nrows rounded up to a multiple of 8)
+  int32_t ext0, next;  // external columns: positions of x gathered into LDS behind the block's own x
+  int32_t nlev, maxk;  // STEPS of the block: pieces of <= 64 rows of one in-block dependency level, in order; off-diagonal entries per row (padded, a multiple of kChunk)
+};
+constexpr int kChunk = 6;       // entries summed per batch of LDS reads
+#ifndef BW_THREADS
+#define BW_THREADS 512
+#endif
+constexpr int kThreads = BW_THREADS;   // loading workgroup (the sweep itself is wave 0)
+constexpr int kMaxSteps = 124;  // steps per block (their row pointers live in two registers of wave 0)
+
+// record of a block: vals[maxk][S] | diag[S] | cols[maxk][S] (uint16, local index into the LDS x) | step_ptr[nlev + 1] (uint16: first row of every step)
+template <typename R>
+inline size_t rec_bytes(int S, int maxk, int nlev) {
+  const size_t b = (size_t)maxk * S * sizeof(R) + (size_t)S * sizeof(R) + (size_t)maxk * S * 2 + (size_t)(nlev + 1) * 2;
+  return (b + 15) & ~(size_t)15;
+}
+template <typename R>
+inline size_t lds_bytes(const Desc& d) {
+  return rec_bytes<R>(d.S, d.maxk, d.nlev) + 2 * (size_t)d.S * sizeof(R) + (size_t)(d.nrows + d.next + 1) * sizeof(R) + 16;
+}
+
+struct Plan {
+  int64_t n = 0, nnz = 0;
+  std::vector<int32_t> perm;        // block-order position -> natural row
+  std::vector<Desc> blocks;         // in launch order
+  std::vector<int32_t> launch_ptr;  // launch l = blocks [launch_ptr[l], launch_ptr[l + 1])
+  std::vector<int64_t> launch_rec;  // byte offset of launch l's first record (launch_rec[nlaunch] = all records)
+  std::vector<int32_t> ext_col;     // block-order positions
+  std::vector<unsigned char> rec;   // the records, one after the other
+  size_t lds_max = 0;               // largest dynamic LDS request of a block
+  // what the cost model looks at
+  int nlevels = 0;                  // dependency levels of the operator
+  int64_t sum_depth = 0;            // sum over launches of the deepest block's level count
+  int64_t ext_total = 0;
+  int max_rows = 0;
+  double est_seconds = 0.0;         // modelled time of one directional sweep
+  int cuts[2] = {99, 99};
+  int32_t range[3] = {1, 1, 1};
+  int32_t cells[3] = {1, 1, 1};
+};
+
+template <class F>
+inline void parallel_for(int T, F fn) {
+  if (T <= 1) { fn(0, 1); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back([=] { fn(t, T); });
+  fn(0, T);
+  for (auto& x : th) x.join();
+}
+
+struct Params {
+  int target_rows = 512;     // rows per block aimed at
+  int max_rows = 1024;       // hard cap (uint16 local indices, LDS)
+  size_t lds_limit = 150 * 1024;
+  int threads = 8;
+};
+
+// Returns false when the operator cannot be laid out (rows too long for the LDS budget, local index overflow).
+template <typename R>
+bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, const Params& prm, Plan* out) {
+  Plan& P = *out;
+  P = Plan();
+  P.n = n; P.nnz = rowptr[n];
+  if (n <= 0) return false;
+  // ---- offset classes ----
+  int64_t hist[32] = {0};
+  int maxlen = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int off = 0;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int64_t d = (int64_t)i - col[j];
+      if (d != 0 && col[j] < n) { hist[31 - __builtin_clz((unsigned)(d < 0 ? -d : d))]++; ++off; }
+    }
+    maxlen = std::max(maxlen, off);   // off-diagonal entries of the longest row
+  }
+  {
+    std::vector<int> occ;
+    for (int b = 0; b < 32; ++b) if (hist[b]) occ.push_back(b);
+    std::vector<std::pair<int, int>> gaps;
+    for (size_t k = 0; k + 1 < occ.size(); ++k) gaps.push_back({occ[k + 1] - occ[k], occ[k]});
+    std::stable_sort(gaps.begin(), gaps.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+    for (int g = 0; g < 2 && g < (int)gaps.size(); ++g) if (gaps[g].first >= 2) P.cuts[g] = gaps[g].second;
+    if (P.cuts[0] > P.cuts[1]) std::swap(P.cuts[0], P.cuts[1]);
+  }
+  const int cut0 = P.cuts[0], cut1 = P.cuts[1];
+  auto cls = [cut0, cut1](int64_t d) { const int b = 31 - __builtin_clz((unsigned)d); return b <= cut0 ? 0 : b <= cut1 ? 1 : 2; };
+  // ---- potentials and dependency levels of the symmetrised pattern (one pass in index order) ----
+  std::vector<int32_t> phi[3], lev(n, 0);
+  for (int k = 0; k < 3; ++k) phi[k].assign(n, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t p0 = phi[0][i], p1 = phi[1][i], p2 = phi[2][i], l = lev[i];
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      const int32_t c = col[j];
+      if (c >= i) continue;
+      const int k = cls(i - c);
+      p0 = std::max(p0, phi[0][c] + (k == 0)); p1 = std::max(p1, phi[1][c] + (k == 1)); p2 = std::max(p2, phi[2][c] + (k == 2));
+      l = std::max(l, lev[c] + 1);
+    }
+    phi[0][i] = p0; phi[1][i] = p1; phi[2][i] = p2; lev[i] = l;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {   // an upper entry of row i is a dependency i -> c as well
+      const int32_t c = col[j];
+      if (c <= i || c >= n) continue;
+      const int k = cls(c - i);
+      phi[0][c] = std::max(phi[0][c], p0 + (k == 0)); phi[1][c] = std::max(phi[1][c], p1 + (k == 1)); phi[2][c] = std::max(phi[2][c], p2 + (k == 2));
+      lev[c] = std::max(lev[c], l + 1);
+    }
+  }
+  for (int k = 0; k < 3; ++k) P.range[k] = *std::max_element(phi[k].begin(), phi[k].end()) + 1;
+  P.nlevels = *std::max_element(lev.begin(), lev.end()) + 1;
+  // ---- rows per block from the LDS budget ----
+  const int maxk = ((std::max(1, maxlen) + kChunk - 1) / kChunk) * kChunk;
+  if (maxk > 24) return false;   // (kMaxK: the kernels' register sets)
+  const size_t per_row = (size_t)maxk * (sizeof(R) + 2) + 3 * sizeof(R) + 2 * sizeof(R);   // record + b + x + ~2 external values
+  int cap = (int)std::min<size_t>(prm.max_rows, prm.lds_limit / per_row);
+  cap = (cap / 64) * 64;
+  if (cap < 64) return false;
+  const int target = std::min(prm.target_rows, cap);
+  // ---- cell widths: the same number of cells m along every (non-degenerate) potential, m raised until few rows sit in oversized cells ----
+  double m = std::cbrt((double)n / target);
+  std::vector<int32_t> cell(n);
+  int32_t h[3], nb[3];
+  std::vector<int32_t> count;
+  for (int it = 0; it < 24; ++it) {
+    int64_t ncell = 1;
+    int32_t ht[3], nt[3];
+    for (int k = 0; k < 3; ++k) {
+      ht[k] = std::max<int32_t>(1, (int32_t)std::floor(P.range[k] / m + 0.5));
+      nt[k] = (P.range[k] + ht[k] - 1) / ht[k];
+      ncell *= nt[k];
+    }
+    if (ncell > ((int64_t)1 << 28)) { if (it == 0) return false; break; }
+    for (int k = 0; k < 3; ++k) { h[k] = ht[k]; nb[k] = nt[k]; }
+    count.assign((size_t)ncell, 0);
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t q = (phi[0][i] / h[0]) + nb[0] * ((phi[1][i] / h[1]) + nb[1] * (phi[2][i] / h[2]));
+      cell[i] = q;
+      count[q]++;
+    }
+    int64_t over = 0;
+    for (int32_t cnt : count) if (cnt > cap) over += cnt;
+    if (over * 10 <= n || (h[0] == 1 && h[1] == 1 && h[2] == 1)) break;
+    m *= 1.12;
+  }
+  for (int k = 0; k < 3; ++k) P.cells[k] = nb[k];
+  const int64_t ncell = (int64_t)nb[0] * nb[1] * nb[2];
+  // ---- rows of every cell in (level, index) order; oversized cells cut along the level ----
+  std::vector<int64_t> cptr(ncell + 1, 0);
+  for (int64_t q = 0; q < ncell; ++q) cptr[q + 1] = cptr[q] + count[q];
+  std::vector<int32_t> crow(n);
+  {
+    std::vector<int64_t> next(cptr.begin(), cptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) crow[next[cell[i]]++] = (int32_t)i;
+  }
+  const int T = std::max(1, prm.threads);
+  parallel_for(T, [&](int t, int TT) {
+    for (int64_t q = ncell * t / TT; q < ncell * (t + 1) / TT; ++q)
+      std::stable_sort(crow.begin() + cptr[q], crow.begin() + cptr[q + 1], [&](int32_t a, int32_t b) { return lev[a] < lev[b]; });
+  });
+  // blocks (pre-order: by cell, then by level window)
+  std::vector<int32_t> blk(n);
+  std::vector<int64_t> bptr;        // rows of pre-order block b: crow[bptr[b] .. bptr[b+1])
+  std::vector<int32_t> bsum;        // coordinate sum of the block's cell (a topological key of the quotient graph)
+  bptr.push_back(0);
+  for (int64_t q = 0; q < ncell; ++q) {
+    int64_t a = cptr[q];
+    const int64_t e = cptr[q + 1];
+    if (a == e) continue;
+    const int32_t cs = (int32_t)(q % nb[0] + (q / nb[0]) % nb[1] + q / ((int64_t)nb[0] * nb[1]));
+    while (a < e) {
+      int64_t z = std::min<int64_t>(e, a + cap);
+      if (z < e) {   // cut at a level boundary; a single level longer than the cap is cut into chunks of independent rows
+        int64_t zz = z;
+        while (zz > a && lev[crow[zz - 1]] == lev[crow[z]]) --zz;
+        if (zz > a) z = zz;
+        else { const int32_t l0 = lev[crow[a]]; z = a; while (z < e && z < a + cap && lev[crow[z]] == l0) ++z; }
+      }
+      for (int64_t r = a; r < z; ++r) blk[crow[r]] = (int32_t)(bptr.size() - 1);
+      bptr.push_back(z);
+      bsum.push_back(cs);
+      a = z;
+    }
+  }
+  const int32_t B = (int32_t)bsum.size();
+  std::vector<int32_t>().swap(cell);
+  for (int k = 0; k < 3; ++k) std::vector<int32_t>().swap(phi[k]);
+  // ---- launches: longest path in the quotient graph ----
+  std::vector<int32_t> blev(B, 0);
+  {
+    // edges (block of c) -> (block of i) for c < i adjacent, collected per target block
+    std::vector<int64_t> eptr(B + 1, 0);
+    for (int64_t i = 0; i < n; ++i)
+      for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+        const int32_t c = col[j];
+        if (c >= n || c == i || blk[c] == blk[i]) continue;
+        eptr[(c < i ? blk[i] : blk[c]) + 1]++;
+      }
+    for (int32_t b = 0; b < B; ++b) eptr[b + 1] += eptr[b];
+    std::vector<int32_t> esrc(eptr[B]);
+    std::vector<int64_t> next(eptr.begin(), eptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i)
+      for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+        const int32_t c = col[j];
+        if (c >= n || c == i || blk[c] == blk[i]) continue;
+        if (c < i) esrc[next[blk[i]]++] = blk[c]; else esrc[next[blk[c]]++] = blk[i];
+      }
+    // pre-order is a topological order: cells by coordinate sum would be one, and so is (cell index, window) — a cell
+    // only depends on cells with smaller-or-equal coordinates, i.e. smaller cell index, and inside a cell on earlier windows
+    for (int32_t b = 0; b < B; ++b) {
+      int32_t l = 0;
+      for (int64_t e = eptr[b]; e < eptr[b + 1]; ++e) l = std::max(l, blev[esrc[e]] + 1);
+      blev[b] = l;
+    }
+  }
+  const int nlaunch = *std::max_element(blev.begin(), blev.end()) + 1;
+  // ---- block order: by launch, pre-order inside a launch ----
+  std::vector<int32_t> order(B);
+  P.launch_ptr.assign(nlaunch + 1, 0);
+  for (int32_t b = 0; b < B; ++b) P.launch_ptr[blev[b] + 1]++;
+  for (int l = 0; l < nlaunch; ++l) P.launch_ptr[l + 1] += P.launch_ptr[l];
+  {
+    std::vector<int32_t> next(P.launch_ptr.begin(), P.launch_ptr.end() - 1);
+    for (int32_t b = 0; b < B; ++b) order[next[blev[b]]++] = b;
+  }
+  // ---- in-block dependency levels (index order is a topological order) ----
+  std::vector<int32_t> ilev(n, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t l = ilev[i];
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) { const int32_t c = col[j]; if (c < i && blk[c] == blk[i]) l = std::max(l, ilev[c] + 1); }
+    ilev[i] = l;
+    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) { const int32_t c = col[j]; if (c > i && c < n && blk[c] == blk[i]) ilev[c] = std::max(ilev[c], l + 1); }
+  }
+  // ---- rows in block order ----
+  P.blocks.resize(B);
+  P.perm.resize(n);
+  std::vector<int32_t> inv(n);
+  {
+    int64_t pos = 0;
+    for (int32_t ob = 0; ob < B; ++ob) {
+      const int32_t b = order[ob];
+      Desc& d = P.blocks[ob];
+      d.row0 = (int32_t)pos; d.nrows = (int32_t)(bptr[b + 1] - bptr[b]);
+      for (int64_t r = bptr[b]; r < bptr[b + 1]; ++r) P.perm[pos++] = crow[r];
+    }
+  }
+  parallel_for(T, [&](int t, int TT) {
+    for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
+      const Desc& d = P.blocks[ob];
+      std::stable_sort(P.perm.begin() + d.row0, P.perm.begin() + d.row0 + d.nrows, [&](int32_t a, int32_t b) { return ilev[a] != ilev[b] ? ilev[a] < ilev[b] : a < b; });
+      for (int32_t p = 0; p < d.nrows; ++p) inv[P.perm[d.row0 + p]] = d.row0 + p;
+    }
+  });
+  std::vector<int32_t> obk(B);   // pre-order block -> ordered block
+  for (int32_t ob = 0; ob < B; ++ob) obk[order[ob]] = ob;
+  // ---- external columns, record offsets ----
+  std::vector<int64_t> ext_ptr(B + 1, 0);
+  std::vector<std::vector<int32_t>> exts(B);
+  parallel_for(T, [&](int t, int TT) {
+    for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
+      const Desc& d = P.blocks[ob];
+      std::vector<int32_t>& ex = exts[ob];
+      for (int32_t p = 0; p < d.nrows; ++p) {
+        const int32_t i = P.perm[d.row0 + p];
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+          const int32_t c = col[j];
+          if (c == i || c >= n) continue;
+          const int32_t q = inv[c];
+          if (q < d.row0 || q >= d.row0 + d.nrows) ex.push_back(q);
+        }
+      }
+      std::sort(ex.begin(), ex.end());
+      ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
+    }
+  });
+  size_t rec_total = 0;
+  bool fits = true;
+  for (int32_t ob = 0; ob < B; ++ob) {
+    Desc& d = P.blocks[ob];
+    d.S = (d.nrows + 7) & ~7;
+    d.maxk = maxk;
+    int32_t nl = 0, run = 0, last = -1;   // steps: a level's rows in pieces of 64 (rows are sorted by level)
+    for (int32_t p = 0; p < d.nrows; ++p) {
+      const int32_t l = ilev[P.perm[d.row0 + p]];
+      if (l != last || run == 64) { ++nl; run = 0; last = l; }
+      ++run;
+    }
+    d.nlev = nl;
+    if (nl > kMaxSteps) fits = false;
+    d.ext0 = (int32_t)ext_ptr[ob]; d.next = (int32_t)exts[ob].size();
+    ext_ptr[ob + 1] = ext_ptr[ob] + d.next;
+    if (rec_total / 16 > (size_t)INT32_MAX) fits = false;
+    d.rec = (int32_t)(rec_total / 16);
+    rec_total += rec_bytes<R>(d.S, d.maxk, d.nlev);
+    const size_t l = lds_bytes<R>(d);
+    P.lds_max = std::max(P.lds_max, l);
+    if (d.nrows + d.next + 1 > 65535 || d.nlev > 65534 || l > 160 * 1024) fits = false;
+    P.max_rows = std::max(P.max_rows, d.nrows);
+  }
+  if (!fits || ext_ptr[B] > INT32_MAX) return false;
+  P.launch_rec.assign(nlaunch + 1, (int64_t)rec_total);
+  for (int l = 0; l < nlaunch; ++l) P.launch_rec[l] = (int64_t)P.blocks[P.launch_ptr[l]].rec * 16;
+  P.ext_total = ext_ptr[B];
+  P.ext_col.resize(ext_ptr[B]);
+  P.rec.assign(rec_total, 0);
+  parallel_for(T, [&](int t, int TT) {
+    for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
+      const Desc& d = P.blocks[ob];
+      const std::vector<int32_t>& ex = exts[ob];
+      std::copy(ex.begin(), ex.end(), P.ext_col.begin() + d.ext0);
+      unsigned char* rec = P.rec.data() + (size_t)d.rec * 16;
+      R* vals = (R*)rec;
+      R* diag = vals + (size_t)d.maxk * d.S;
+      uint16_t* cols = (uint16_t*)(diag + d.S);
+      uint16_t* lvlp = cols + (size_t)d.maxk * d.S;
+      const uint16_t zslot = (uint16_t)(d.nrows + d.next);   // LDS slot that holds 0: padding entries are 0 * 0
+      for (size_t e = 0; e < (size_t)d.maxk * d.S; ++e) cols[e] = zslot;
+      {
+        int32_t nl = 0, run = 0, last = -1;
+        for (int32_t p = 0; p < d.nrows; ++p) {
+          const int32_t l = ilev[P.perm[d.row0 + p]];
+          if (l != last || run == 64) { lvlp[nl++] = (uint16_t)p; run = 0; last = l; }
+          ++run;
+        }
+        lvlp[nl] = (uint16_t)d.nrows;
+      }
+      for (int32_t p = 0; p < d.nrows; ++p) {
+        const int32_t i = P.perm[d.row0 + p];
+        int k = 0;
+        R dg = 0;
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {   // entries stay in the row's stored order (the order of the sum)
+          const int32_t c = col[j];
+          if (c == i) { dg = val[j]; continue; }
+          if (c >= n) continue;
+          const int32_t q = inv[c];
+          uint16_t lc;
+          if (q >= d.row0 && q < d.row0 + d.nrows) lc = (uint16_t)(q - d.row0);
+          else lc = (uint16_t)(d.nrows + (std::lower_bound(ex.begin(), ex.end(), q) - ex.begin()));
+          vals[(size_t)k * d.S + p] = val[j];
+          cols[(size_t)k * d.S + p] = lc;
+          ++k;
+        }
+        diag[p] = dg;
+      }
+    }
+  });
+  // ---- modelled time of one sweep: per launch a boundary + the latency chain of a block + its bytes + its deepest block ----
+  {
+    double tsec = 0.0;
+    for (int l = 0; l < nlaunch; ++l) {
+      int depth = 0;
+      double bytes = 0.0;
+      for (int32_t ob = P.launch_ptr[l]; ob < P.launch_ptr[l + 1]; ++ob) {
+        const Desc& d = P.blocks[ob];
+        depth = std::max(depth, d.nlev);
+        bytes += (double)rec_bytes<R>(d.S, d.maxk, d.nlev) + d.nrows * 3.0 * sizeof(R) + d.next * (4.0 + sizeof(R)) * 2;
+      }
+      P.sum_depth += depth;
+      const double step = 0.10e-6 + 0.012e-6 * maxk;   // two LDS round trips + maxk dependent additions + the division
+      tsec += 1.7e-6 + 3.5e-6 + bytes / 4.0e12 + depth * step;
+    }
+    P.est_seconds = tsec;
+  }
+  return true;
+}
+
+// ---- device side -----------------------------------------------------------------------------------------------------
+template <typename R>
+struct Args {
+  const Desc* blocks; const unsigned char* rec; const int32_t* ext_col;
+  const R* b; R* x; int64_t ldb, ldx; R omega; int32_t block0;
+  long long* tim;   // measurement hook (tools/block_wave_bench): 4 wall-clock stamps per block, or null
+  const unsigned char* pre; int64_t pre_bytes;   // the NEXT launch's records (read-only): touched by the idle waves while wave 0 sweeps
+};
+
+// One workgroup per block (blockIdx.y: right-hand-side column).  All waves copy the block's record, b, x and the
+// external x entries into LDS; wave 0 then walks the block's dependency levels alone (no barrier: one wave's LDS
+// operations are ordered) and writes the block's x back.
+//
+// The walk is a chain of dependent LDS round trips, so everything that does not depend on x is taken off it: the level
+// pointers sit in a register (lane l holds lvlp[l], read with v_readlane), and the operands of the NEXT step (a row's
+// columns, values, diagonal and b: read-only) are requested before the current step's x values are read — two register
+// sets, the step loop unrolled by two.  Left on the chain per step: one LDS round trip for x, MAXK dependent
+// additions, the division, the LDS write.
+template <typename R, int MAXK>
+struct RowOps { int c[MAXK]; R v[MAXK]; R dg, bb, rc; int p; };
+
+template <typename R, int MAXK>
+__device__ __forceinline__ void bw_load(RowOps<R, MAXK>& o, int p, bool act, const R* vals, const R* diag, const uint16_t* cols, const R* bl,
+                                        const R* rl, int S, int zslot) {
+  o.p = act ? p : -1;
+  const int q = act ? p : 0;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) { const int c = (int)cols[k * S + q]; o.c[k] = act ? c : zslot; o.v[k] = vals[k * S + q]; }
+  o.dg = diag[q]; o.bb = bl[q];
+  o.rc = (BW_OPT & 1) ? rl[q] : (R)0;
+}
+template <typename R, int MAXK>
+__device__ __forceinline__ void bw_gather(const RowOps<R, MAXK>& o, const R* xl, R (&xv)[MAXK]) {
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) xv[k] = xl[o.c[k]];
+}
+template <typename R, int MAXK, bool SOR>
+__device__ __forceinline__ void bw_finish(const RowOps<R, MAXK>& o, const R (&xv)[MAXK], R* xl, R omega) {
+  R acc = (R)0;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) acc += o.v[k] * xv[k];
+  if (o.p >= 0 && o.dg != (R)0) {
+    if (SOR) { xl[o.p] = ((R)1 - omega) * xl[o.p] + (omega / o.dg) * (o.bb - acc); return; }
+    const R nn = o.bb - acc;
+    R q;
+    if (BW_OPT & 1) {
+      // nn / dg from rc = RN(1 / dg): q0 = RN(nn rc), the exact remainder nn - dg q0 (one fma), q = RN(q0 + rem rc) is
+      // the correctly rounded quotient (Markstein) when nothing leaves the normal range; rc == 0 marks rows whose
+      // diagonal (or quotient) might: they divide
+      q = nn * o.rc;
+      const R rem = __builtin_fma(-o.dg, q, nn);
+      q = __builtin_fma(rem, o.rc, q);
+      const R an = __builtin_fabs(nn);
+      if (!(o.rc != (R)0 && an > (R)1e-200 && an < (R)1e200)) q = nn / o.dg;
+    } else {
+      q = nn / o.dg;
+    }
+    xl[o.p] = q;
+  }
+}
+
+template <typename R, bool SOR, bool BWD, int MAXK>
+__global__ __launch_bounds__(kThreads) void gs_bw_kernel(Args<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const long long t_start = a.tim ? wall_clock64() : 0;
+  const Desc d = a.blocks[a.block0 + blockIdx.x];
+  const int tid = threadIdx.x;
+  const R* __restrict__ b = a.b + (int64_t)blockIdx.y * a.ldb;
+  R* __restrict__ x = a.x + (int64_t)blockIdx.y * a.ldx;
+  const int recb = (int)(((size_t)MAXK * d.S * sizeof(R) + (size_t)d.S * sizeof(R) + (size_t)MAXK * d.S * 2 + (size_t)(d.nlev + 1) * 2 + 15) & ~(size_t)15);
+  {
+    const uint4* src = (const uint4*)(a.rec + (size_t)(uint32_t)d.rec * 16);
+    uint4* dst = (uint4*)lds;
+    const int n16 = recb >> 4;
+    for (int e = tid; e < n16; e += kThreads) dst[e] = src[e];
+  }
+  R* bl = (R*)(lds + recb);
+  R* rl = bl + d.S;
+  R* xl = rl + ((BW_OPT & 1) ? d.S : 0);
+  for (int p = tid; p < d.nrows; p += kThreads) { bl[p] = b[d.row0 + p]; xl[p] = x[d.row0 + p]; }
+  for (int e = tid; e < d.next; e += kThreads) xl[d.nrows + e] = x[a.ext_col[d.ext0 + e]];
+  const int zslot = d.nrows + d.next;
+  if (tid == 0) xl[zslot] = (R)0;
+  __syncthreads();
+  if (BW_OPT & 1) {   // reciprocal diagonals (one true division per row, off the sweep's chain); 0 = "divide"
+    const R* dgl = (const R*)lds + (size_t)MAXK * d.S;
+    for (int p = tid; p < d.nrows; p += kThreads) {
+      const R dg = dgl[p], ad = __builtin_fabs(dg);
+      rl[p] = (ad > (R)1e-100 && ad < (R)1e100) ? (R)1 / dg : (R)0;
+    }
+    __syncthreads();
+  }
+  if (tid >= 64) {
+    if ((BW_OPT & 4) && a.pre_bytes > 0) {   // one dword per 128-byte line of the next launch's records
+      const int64_t nth = (int64_t)gridDim.x * (kThreads - 64);
+      for (int64_t off = ((int64_t)blockIdx.x * (kThreads - 64) + (tid - 64)) * 128; off < a.pre_bytes; off += nth * 128) {
+        unsigned tmp;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(a.pre + off) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+  const long long t_loaded = a.tim ? wall_clock64() : 0;
+  const R* vals = (const R*)lds;
+  const R* diag = vals + (size_t)MAXK * d.S;
+  const uint16_t* cols = (const uint16_t*)(diag + d.S);
+  const uint16_t* stp = cols + (size_t)MAXK * d.S;
+  // step s covers rows [sp(s), sp(s + 1)); lane l keeps step_ptr[l] and step_ptr[l + 64] (v_readlane: no LDS round trip
+  // on the chain); pointers past the last step read as nrows (an empty step)
+  const int lp0 = tid <= d.nlev ? (int)stp[tid] : d.nrows;
+  const int lp1 = tid + 64 <= d.nlev ? (int)stp[tid + 64] : d.nrows;
+  const int ns = d.nlev;
+#define BW_SP(i, out)                                                          \
+  {                                                                            \
+    const int i_ = (i);                                                        \
+    const int u0_ = __builtin_amdgcn_readlane(lp0, i_ & 63);                   \
+    const int u1_ = __builtin_amdgcn_readlane(lp1, i_ & 63);                   \
+    out = i_ < 64 ? u0_ : u1_;                                                 \
+  }
+  // sweep order: forward steps 0 .. ns-1, backward ns-1 .. 0 (step k of the sweep = step ns-1-k of the block)
+#define BW_RANGE(k, r0, r1)                                                    \
+  {                                                                            \
+    const int k_ = (k);                                                        \
+    const int st_ = BWD ? ns - 1 - k_ : k_;                                    \
+    const bool in_ = k_ < ns;                                                  \
+    int q0_, q1_;                                                              \
+    BW_SP(in_ ? st_ : 0, q0_);                                                 \
+    BW_SP(in_ ? st_ + 1 : 0, q1_);                                             \
+    r0 = q0_; r1 = in_ ? q1_ : q0_;                                            \
+  }
+  RowOps<R, MAXK> A, B;
+  R xv[MAXK];
+  int r0, r1;
+  BW_RANGE(0, r0, r1);
+  bw_load<R, MAXK>(A, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, rl, d.S, zslot);
+  for (int k = 0; k < ns; k += 2) {
+    bw_gather<R, MAXK>(A, xl, xv);
+    if (BW_OPT & 2) asm volatile("" ::: "memory");
+    BW_RANGE(k + 1, r0, r1);
+    bw_load<R, MAXK>(B, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, rl, d.S, zslot);
+    bw_finish<R, MAXK, SOR>(A, xv, xl, a.omega);
+    bw_gather<R, MAXK>(B, xl, xv);
+    if (BW_OPT & 2) asm volatile("" ::: "memory");
+    BW_RANGE(k + 2, r0, r1);
+    bw_load<R, MAXK>(A, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, rl, d.S, zslot);
+    bw_finish<R, MAXK, SOR>(B, xv, xl, a.omega);
+  }
+#undef BW_RANGE
+#undef BW_SP
+  const long long t_swept = a.tim ? wall_clock64() : 0;
+  for (int p = tid; p < d.nrows; p += 64) x[d.row0 + p] = xl[p];
+  if (a.tim && tid == 0) {
+    long long* t = a.tim + 4 * (int64_t)(a.block0 + blockIdx.x);
+    t[0] = t_start; t[1] = t_loaded; t[2] = t_swept; t[3] = wall_clock64();
+  }
+}
+
+// The same sweep with the operands of ALL the block's rows in wave 0's registers (blocks of at most 64 * RPT rows of at
+// most MAXK off-diagonal entries: the 7-point fine level): local row p = lane + 64 u sits in register slot u of its lane,
+// loaded from the LDS copy of the record once.  Rows are sorted by level, so slot u covers a contiguous range of levels;
+// slots are walked in order, the levels of a slot in order.  A step is then the x gather, MAXK multiply-adds in entry
+// order, the division and the LDS write — about a third of the instructions of the generic kernel's step, which is
+// what bounds a single wave (one wave64 instruction issues every 4+ cycles).
+template <typename R, bool SOR, bool BWD, int MAXK, int RPT>
+__global__ __launch_bounds__(kThreads) void gs_bw_reg_kernel(Args<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const long long t_start = a.tim ? wall_clock64() : 0;
+  const Desc d = a.blocks[a.block0 + blockIdx.x];
+  const int tid = threadIdx.x;
+  const R* __restrict__ b = a.b + (int64_t)blockIdx.y * a.ldb;
+  R* __restrict__ x = a.x + (int64_t)blockIdx.y * a.ldx;
+  const int recb = (int)(((size_t)MAXK * d.S * sizeof(R) + (size_t)d.S * sizeof(R) + (size_t)MAXK * d.S * 2 + (size_t)(d.nlev + 1) * 2 + 15) & ~(size_t)15);
+  {
+    const uint4* src = (const uint4*)(a.rec + (size_t)(uint32_t)d.rec * 16);
+    uint4* dst = (uint4*)lds;
+    const int n16 = recb >> 4;
+    for (int e = tid; e < n16; e += kThreads) dst[e] = src[e];
+  }
+  R* bl = (R*)(lds + recb);
+  R* rl = bl + d.S;
+  R* xl = rl + ((BW_OPT & 1) ? d.S : 0);
+  for (int p = tid; p < d.nrows; p += kThreads) { bl[p] = b[d.row0 + p]; xl[p] = x[d.row0 + p]; }
+  for (int e = tid; e < d.next; e += kThreads) xl[d.nrows + e] = x[a.ext_col[d.ext0 + e]];
+  const int zslot = d.nrows + d.next;
+  if (tid == 0) xl[zslot] = (R)0;
+  __syncthreads();
+  if (tid >= 64) {
+    if ((BW_OPT & 4) && a.pre_bytes > 0) {
+      const int64_t nth = (int64_t)gridDim.x * (kThreads - 64);
+      for (int64_t off = ((int64_t)blockIdx.x * (kThreads - 64) + (tid - 64)) * 128; off < a.pre_bytes; off += nth * 128) {
+        unsigned tmp;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(a.pre + off) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+  const long long t_loaded = a.tim ? wall_clock64() : 0;
+  const R* vals = (const R*)lds;
+  const R* diag = vals + (size_t)MAXK * d.S;
+  const uint16_t* cols = (const uint16_t*)(diag + d.S);
+  const uint16_t* stp = cols + (size_t)MAXK * d.S;
+  // operands of my rows; which step each of them belongs to (steps = pieces of <= 64 consecutive rows: step_ptr)
+  R v[RPT][MAXK], dg[RPT], bb[RPT];
+  int c[RPT][MAXK];   // byte offsets into xl
+#pragma unroll
+  for (int u = 0; u < RPT; ++u) {
+    const int p = tid + 64 * u;
+    const bool act = p < d.nrows;
+    const int q = act ? p : 0;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) { const int cc = (int)cols[k * d.S + q]; c[u][k] = (act ? cc : zslot) * (int)sizeof(R); v[u][k] = vals[k * d.S + q]; }
+    dg[u] = act ? diag[q] : (R)0;   // (a zero diagonal keeps its x: inactive slots never write)
+    bb[u] = bl[q];
+  }
+  // steps in order; step s covers rows [stp[s], stp[s + 1]): slot u = row / 64 changes inside a step at most once
+  const int lp0 = tid <= d.nlev ? (int)stp[tid] : d.nrows;
+  const int lp1 = tid + 64 <= d.nlev ? (int)stp[tid + 64] : d.nrows;
+  const int ns = d.nlev;
+  char* xb = (char*)xl;
+  for (int k = 0; k < ns; ++k) {
+    const int st = BWD ? ns - 1 - k : k;
+    const int a0 = __builtin_amdgcn_readlane(lp0, st & 63), a1 = __builtin_amdgcn_readlane(lp1, st & 63);
+    const int b0 = __builtin_amdgcn_readlane(lp0, (st + 1) & 63), b1 = __builtin_amdgcn_readlane(lp1, (st + 1) & 63);
+    const int r0 = st < 64 ? a0 : a1, r1 = st + 1 < 64 ? b0 : b1;
+    // rows r0 .. r1-1 (at most 64) live in slots u0 = r0 / 64 and possibly u0 + 1: lane l holds row 64 u + l
+    const int u0 = r0 >> 6, u1 = (r1 - 1) >> 6;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      if (u != u0 && u != u1) continue;            // wave-uniform
+      const int p = tid + 64 * u;
+      if (p >= r0 && p < r1 && dg[u] != (R)0) {
+        R xv[MAXK];
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) xv[j] = *(const R*)(xb + c[u][j]);
+        R acc = (R)0;
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) acc += v[u][j] * xv[j];
+        xl[p] = SOR ? ((R)1 - a.omega) * xl[p] + (a.omega / dg[u]) * (bb[u] - acc) : (bb[u] - acc) / dg[u];
+      }
+    }
+  }
+  const long long t_swept = a.tim ? wall_clock64() : 0;
+  for (int p = tid; p < d.nrows; p += 64) x[d.row0 + p] = xl[p];
+  if (a.tim && tid == 0) {
+    long long* t = a.tim + 4 * (int64_t)(a.block0 + blockIdx.x);
+    t[0] = t_start; t[1] = t_loaded; t[2] = t_swept; t[3] = wall_clock64();
+  }
+}
+
+// launches of one directional sweep: blocks of launch l = [launch_ptr[l], launch_ptr[l + 1])
+// launch_rec[l] = byte offset of launch l's first record in the record buffer (launch_rec[nl] = its size)
+constexpr int kRegRpt = 8;   // register-resident kernel: blocks of at most 64 * kRegRpt rows of at most 6 entries
+template <typename R, int MAXK>
+inline hipError_t sweep_k(const Args<R>& a0, const std::vector<int32_t>& launch_ptr, const std::vector<int64_t>& launch_rec, size_t lds_max,
+                          bool sor, bool backward, int ncols, hipStream_t st, bool reg = false) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (MAXK == 6) {
+      (void)hipFuncSetAttribute((const void*)gs_bw_reg_kernel<R, false, false, 6, kRegRpt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)gs_bw_reg_kernel<R, false, true, 6, kRegRpt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)gs_bw_reg_kernel<R, true, false, 6, kRegRpt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)gs_bw_reg_kernel<R, true, true, 6, kRegRpt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    (void)hipFuncSetAttribute((const void*)gs_bw_kernel<R, false, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gs_bw_kernel<R, false, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gs_bw_kernel<R, true, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gs_bw_kernel<R, true, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int nl = (int)launch_ptr.size() - 1;
+  Args<R> a = a0;
+  for (int s = 0; s < nl; ++s) {
+    const int l = backward ? nl - 1 - s : s;
+    a.block0 = launch_ptr[l];
+    const int ln = backward ? l - 1 : l + 1;   // the launch that follows in this sweep
+    a.pre = nullptr; a.pre_bytes = 0;
+    if (ln >= 0 && ln < nl && !launch_rec.empty()) { a.pre = a0.rec + launch_rec[ln]; a.pre_bytes = launch_rec[ln + 1] - launch_rec[ln]; }
+    const dim3 grid((unsigned)(launch_ptr[l + 1] - launch_ptr[l]), (unsigned)ncols);
+    if (MAXK == 6 && reg) {
+      if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_reg_kernel<R, true, true, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_reg_kernel<R, true, false, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); }
+      else { if (backward) hipLaunchKernelGGL((gs_bw_reg_kernel<R, false, true, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_reg_kernel<R, false, false, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); }
+      continue;
+    }
+    if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_kernel<R, true, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_kernel<R, true, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
+    else { if (backward) hipLaunchKernelGGL((gs_bw_kernel<R, false, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_kernel<R, false, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
+  }
+  return hipGetLastError();
+}
+constexpr int kMaxK = 24;   // longest rows (off-diagonal entries, padded to a multiple of kChunk) the kernels are instantiated for
+template <typename R>
+inline hipError_t sweep(const Args<R>& a, int maxk, const std::vector<int32_t>& launch_ptr, const std::vector<int64_t>& launch_rec,
+                        size_t lds_max, bool sor, bool backward, int ncols, hipStream_t st, bool reg = false) {
+  switch (maxk) {
+    case 6: return sweep_k<R, 6>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st, reg);
+    case 12: return sweep_k<R, 12>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st);
+    case 18: return sweep_k<R, 18>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st);
+    case 24: return sweep_k<R, 24>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace bw
+}  // namespace amgh
