@@ -1,7 +1,7 @@
 // block_wave_bench — the block-wavefront Gauss-Seidel sweep of tools/gs_blocks.hpp: plan (partition by
 // monotone potentials), layout, forward / backward sweeps checked bit for bit against the scalar loops, timings.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/block_wave_bench tools/block_wave_bench.hip
-// usage: block_wave_bench poisson N [target_rows]
+// usage: block_wave_bench poisson N [target_rows]     (7-point, N^3)   |   block_wave_bench poisson2 N [target_rows]   (5-point, N^2)
 //        block_wave_bench file PATH [target_rows]    PATH: int64 n, int64 nnz, int32 rowptr[n+1], int32 col[nnz], double val[nnz]
 #include <chrono>
 #include <cstdio>
@@ -28,6 +28,19 @@ static Csr poisson3(int N) {
   }
   return A;
 }
+static Csr poisson2(int N) {
+  Csr A; A.n = (int64_t)N * N; A.rp.assign(A.n + 1, 0);
+  for (int j = 0; j < N; ++j) for (int i = 0; i < N; ++i) {
+    const int64_t r = i + (int64_t)N * j;
+    if (j > 0) { A.ci.push_back((int32_t)(r - N)); A.va.push_back(-1.0); }
+    if (i > 0) { A.ci.push_back((int32_t)(r - 1)); A.va.push_back(-1.0); }
+    A.ci.push_back((int32_t)r); A.va.push_back(4.0);
+    if (i < N - 1) { A.ci.push_back((int32_t)(r + 1)); A.va.push_back(-1.0); }
+    if (j < N - 1) { A.ci.push_back((int32_t)(r + N)); A.va.push_back(-1.0); }
+    A.rp[r + 1] = (int32_t)A.ci.size();
+  }
+  return A;
+}
 static Csr load(const char* path) {
   Csr A; FILE* f = fopen(path, "rb"); if (!f) { printf("cannot open %s\n", path); exit(1); }
   int64_t hdr[2]; if (fread(hdr, 8, 2, f) != 2) exit(1);
@@ -39,7 +52,7 @@ static Csr load(const char* path) {
 
 int main(int argc, char** argv) {
   if (argc < 3) { printf("usage: block_wave_bench poisson N | file PATH  [target_rows]\n"); return 1; }
-  Csr A = std::string(argv[1]) == "poisson" ? poisson3(atoi(argv[2])) : load(argv[2]);
+  Csr A = std::string(argv[1]) == "poisson" ? poisson3(atoi(argv[2])) : std::string(argv[1]) == "poisson2" ? poisson2(atoi(argv[2])) : load(argv[2]);
   const int64_t n = A.n;
   bw::Params prm; if (argc > 3) prm.target_rows = atoi(argv[3]);
   const bool want_reg = argc > 4 && atoi(argv[4]) != 0;
