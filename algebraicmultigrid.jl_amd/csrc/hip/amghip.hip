@@ -181,6 +181,11 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, real*& xc, real*& xo, 
         // returns to natural order after the last one
         const bool sym = s.sweep == AMGH_SWEEP_SYMMETRIC;
         const bool first_it = (it == 0), last_it = (it == s.iter - 1);
+        if (sym && M->gs && gs_wave_path(M->gs, sor)) {   // a small operator: forward and backward in ONE single-wave launch
+          RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it, ncolv, xzero && first_it,
+                              reuse_b || !first_it, x_resident, no_scatter, true));
+          break;
+        }
         if (s.sweep == AMGH_SWEEP_FORWARD || sym)
           RC_TRY(csr_gs_sweep(M, false, sor, s.omega, xc, b, h->stream, first_it, last_it && !sym, ncolv, xzero && first_it,
                               reuse_b || !first_it, x_resident, no_scatter));

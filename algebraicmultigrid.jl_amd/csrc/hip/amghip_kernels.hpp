@@ -618,6 +618,113 @@ __global__ __launch_bounds__(T) void gs_chain_tiny_kernel(ChainArgs a, int n, in
   for (int r = tid; r < n; r += T) a.x[r] = s_x[r];
 }
 
+// ---- a whole small operator walked by ONE wave --------------------------------------------------------------------
+// gs_chain_tiny_kernel pays two workgroup barriers and ~300 instructions per dependency level (staged products, row
+// sums that skip the diagonal, descriptors).  A single wave needs no barrier at all — its LDS operations execute in
+// program order — and what bounds it is its own instruction issue (tools/wave_chain_probe, profiles/r03_block_wave.log),
+// so the level loop is cut to the bone: the operator is laid out once, at schedule build time, as a RECORD
+//     vals[MAXK][S] | diag[S] | cols[MAXK][S] (uint16 positions in level order) | step_ptr[steps + 1] (uint16)
+// rows in level order, off-diagonal entries only and in their stored order, short rows padded with 0 * x[zero slot];
+// a step is a piece of at most 64 rows of one level.  All waves copy the record, b and x into LDS; wave 0 walks the
+// steps, lane = row: the operands of the NEXT step are requested before the current step's x values are gathered (two
+// register sets, loop unrolled by two), the step pointers sit in two registers (v_readlane).  Per row: gather, MAXK
+// separately rounded multiply-adds in entry order, the division — the scalar loop's arithmetic, bit for bit.
+constexpr int kWaveThreads = 256;
+constexpr int kWaveMaxSteps = 124;
+constexpr int kWaveMaxK = 24;
+struct WaveArgs {
+  const unsigned char* rec; const real* bp; real* x; int64_t ldb, ldx; real omega; int32_t n, S, steps;
+};
+template <int MAXK>
+struct WaveRow { int c[MAXK]; real v[MAXK]; real dg, bb; int p; };
+template <int MAXK>
+__device__ __forceinline__ void wave_load(WaveRow<MAXK>& o, int p, bool act, const real* vals, const real* diag, const uint16_t* cols,
+                                          const real* bl, int S, int zslot) {
+  o.p = act ? p : -1;
+  const int q = act ? p : 0;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) { const int c = (int)cols[k * S + q]; o.c[k] = act ? c : zslot; o.v[k] = vals[k * S + q]; }
+  o.dg = diag[q]; o.bb = bl[q];
+}
+template <int MAXK, bool SOR>
+__device__ __forceinline__ void wave_row(const WaveRow<MAXK>& o, real* xl, real omega) {
+  real xv[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) xv[k] = xl[o.c[k]];
+  real acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) acc += o.v[k] * xv[k];
+  if (o.p >= 0 && o.dg != 0.0) xl[o.p] = SOR ? (1.0 - omega) * xl[o.p] + (omega / o.dg) * (o.bb - acc) : (o.bb - acc) / o.dg;
+}
+// one directional walk over the record's steps (wave 0 only)
+template <bool SOR, bool BWD, int MAXK>
+__device__ __forceinline__ void wave_walk(const real* vals, const real* diag, const uint16_t* cols, const real* bl, real* xl, int S, int n,
+                                          int ns, int lp0, int lp1, real omega, int tid) {
+  const int zslot = n;
+#define AMGH_WAVE_SP(i, out)                                                   \
+  {                                                                            \
+    const int i_ = (i);                                                        \
+    const int u0_ = __builtin_amdgcn_readlane(lp0, i_ & 63);                   \
+    const int u1_ = __builtin_amdgcn_readlane(lp1, i_ & 63);                   \
+    out = i_ < 64 ? u0_ : u1_;                                                 \
+  }
+  // step k of the sweep = step k (forward) or ns - 1 - k (backward) of the record; past the end: an empty step
+#define AMGH_WAVE_RANGE(k, r0, r1)                                             \
+  {                                                                            \
+    const int k_ = (k);                                                        \
+    const int st_ = BWD ? ns - 1 - k_ : k_;                                    \
+    const bool in_ = k_ < ns;                                                  \
+    int q0_, q1_;                                                              \
+    AMGH_WAVE_SP(in_ ? st_ : 0, q0_);                                          \
+    AMGH_WAVE_SP(in_ ? st_ + 1 : 0, q1_);                                      \
+    r0 = q0_; r1 = in_ ? q1_ : q0_;                                            \
+  }
+  WaveRow<MAXK> A, B;
+  int r0, r1;
+  AMGH_WAVE_RANGE(0, r0, r1);
+  wave_load<MAXK>(A, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, S, zslot);
+  for (int k = 0; k < ns; k += 2) {
+    AMGH_WAVE_RANGE(k + 1, r0, r1);
+    wave_load<MAXK>(B, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, S, zslot);
+    wave_row<MAXK, SOR>(A, xl, omega);
+    AMGH_WAVE_RANGE(k + 2, r0, r1);
+    wave_load<MAXK>(A, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, S, zslot);
+    wave_row<MAXK, SOR>(B, xl, omega);
+  }
+#undef AMGH_WAVE_RANGE
+#undef AMGH_WAVE_SP
+}
+// DIR: 0 forward, 1 backward, 2 forward then backward (a symmetric sweep in one launch: the record is loaded once)
+template <bool SOR, int DIR, int MAXK>
+__global__ __launch_bounds__(kWaveThreads) void gs_wave_kernel(WaveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wave_lds[];
+  const int tid = threadIdx.x;
+  const real* __restrict__ b = a.bp + (int64_t)blockIdx.x * a.ldb;   // independent right-hand-side columns, one workgroup each
+  real* __restrict__ x = a.x + (int64_t)blockIdx.x * a.ldx;
+  const int S = a.S, n = a.n, ns = a.steps;
+  const int recb = (int)(((size_t)MAXK * S * sizeof(real) + (size_t)S * sizeof(real) + (size_t)MAXK * S * 2 + (size_t)(ns + 1) * 2 + 15) & ~(size_t)15);
+  {
+    const uint4* src = (const uint4*)a.rec;
+    uint4* dst = (uint4*)wave_lds;
+    for (int e = tid; e < (recb >> 4); e += kWaveThreads) dst[e] = src[e];
+  }
+  real* bl = (real*)(wave_lds + recb);
+  real* xl = bl + S;
+  for (int p = tid; p < n; p += kWaveThreads) { bl[p] = b[p]; xl[p] = x[p]; }
+  if (tid == 0) xl[n] = 0.0;
+  __syncthreads();
+  if (tid >= kWave) return;
+  const real* vals = (const real*)wave_lds;
+  const real* diag = vals + (size_t)MAXK * S;
+  const uint16_t* cols = (const uint16_t*)(diag + S);
+  const uint16_t* stp = cols + (size_t)MAXK * S;
+  const int lp0 = tid <= ns ? (int)stp[tid] : n;
+  const int lp1 = tid + 64 <= ns ? (int)stp[tid + 64] : n;
+  if (DIR != 1) wave_walk<SOR, false, MAXK>(vals, diag, cols, bl, xl, S, n, ns, lp0, lp1, a.omega, tid);
+  if (DIR != 0) wave_walk<SOR, true, MAXK>(vals, diag, cols, bl, xl, S, n, ns, lp0, lp1, a.omega, tid);
+  for (int p = tid; p < n; p += kWave) x[p] = xl[p];
+}
+
 // Damped Jacobi on x = 0 (every pre-smoother below the fine level of a cycle, and the fine one of ldiv!): the sweep's
 // matrix pass multiplies zeros — x_new = (1 - w) 0 + w ((b - 0) / d) is the SAME expression the stream kernel evaluates
 // with a row sum of +0 (bitwise the same result), as a vector kernel.  Rows with a zero diagonal keep their x = 0

@@ -110,6 +110,44 @@ int launch_chain_t(const ChainArgs& c, bool sor, bool ldsx, int nx, hipStream_t 
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
 }
+// the whole operator as one record, walked by a single wave (gs_wave_kernel); dir: 0 forward, 1 backward, 2 both
+template <int MAXK, int DIR>
+int launch_wave_kd(const WaveArgs& a, bool sor, size_t lds, hipStream_t st, int ncolv) {
+  static bool attr_set = false;   // (more than the default 64 KB of dynamic LDS needs the attribute, once per kernel)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gs_wave_kernel<false, DIR, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gs_wave_kernel<true, DIR, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (sor) hipLaunchKernelGGL((gs_wave_kernel<true, DIR, MAXK>), dim3(ncolv), dim3(kWaveThreads), lds, st, a);
+  else hipLaunchKernelGGL((gs_wave_kernel<false, DIR, MAXK>), dim3(ncolv), dim3(kWaveThreads), lds, st, a);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+template <int MAXK>
+int launch_wave_k(const WaveArgs& a, bool sor, int dir, size_t lds, hipStream_t st, int ncolv) {
+  switch (dir) {
+    case 0: return launch_wave_kd<MAXK, 0>(a, sor, lds, st, ncolv);
+    case 1: return launch_wave_kd<MAXK, 1>(a, sor, lds, st, ncolv);
+    default: return launch_wave_kd<MAXK, 2>(a, sor, lds, st, ncolv);
+  }
+}
+int launch_wave(const WaveArgs& a, int maxk, bool sor, int dir, size_t lds, hipStream_t st, int ncolv) {
+  switch (maxk) {
+    case 6: return launch_wave_k<6>(a, sor, dir, lds, st, ncolv);
+    case 12: return launch_wave_k<12>(a, sor, dir, lds, st, ncolv);
+    case 18: return launch_wave_k<18>(a, sor, dir, lds, st, ncolv);
+    case 24: return launch_wave_k<24>(a, sor, dir, lds, st, ncolv);
+  }
+  return AMGH_EINVAL;
+}
+// does a sweep over this operator run as ONE gs_wave_kernel launch?  (then a symmetric sweep may be asked for in one
+// call: csr_gs_sweep(..., sym_pair = true))
+bool gs_wave_path(const GsSchedule* g, bool sor) {
+  if (!g || !g->ww_rec || g->ncols != g->n || g_gs_tiny != 1 || g_chain_tim) return false;
+  if (!sor && g_gs_block_inverse && ((g->dti_f && g_gs_dense_tri) || g->nblk > 0)) return false;   // those paths come first
+  return g->segs.size() == 1 && g->segs[0].chain && g->segs[0].l0 == 0 && g->segs[0].l1 == g->nlev;
+}
 template <int T>
 int launch_chain_tiny_t(const ChainArgs& c, bool sor, int n, int nnz, int nlev, hipStream_t st, int ncolv) {
   if (sor) hipLaunchKernelGGL((gs_chain_tiny_kernel<true, T>), dim3(ncolv), dim3(T), 0, st, c, n, nnz, nlev);
@@ -293,10 +331,13 @@ int gs_ensure_cols(amgh_csr* op, int ncolv, hipStream_t st) {
 
 int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, const real* b, hipStream_t st,
                  bool first = true, bool last = true, int ncolv = 1, bool xzero = false, bool reuse_b = false,
-                 bool x_resident = false, bool no_scatter = false) {
+                 bool x_resident = false, bool no_scatter = false, bool sym_pair = false) {
+  // sym_pair: this call is the forward half of a symmetric sweep and the caller leaves the backward half to it — only
+  // where gs_wave_path() says the sweep is one single-wave launch
   RC_TRY(csr_ensure_gs(op));
   GsSchedule* g = op->gs;
   if (g->n <= 0) return AMGH_OK;
+  if (sym_pair && (backward || !gs_wave_path(g, sor))) return AMGH_EINVAL;
   RC_TRY(gs_ensure_cols(op, ncolv, st));
   if (g->dti_f && g_gs_dense_tri && g_gs_block_inverse && !sor) {
     // small operator with the triangles of its (large) diagonal blocks inverted densely: block after block,
@@ -463,6 +504,13 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       c.ldx = xs; c.ldb = ldb;
       const int64_t nx = lay == g ? g->ncols : xs;  // entries of x (and s) a chained row may read
       const bool ldsx = nx <= kChainLdsX;            // they fit LDS
+      if (lay == g && g->ww_rec && g->ncols == g->n && g_gs_tiny == 1 && !g_chain_tim && s.l0 == 0 && s.l1 == g->nlev) {
+        WaveArgs wa{};   // one record, one wave, no barrier between the levels
+        wa.rec = g->ww_rec; wa.bp = rhs; wa.x = xp; wa.ldb = ldb; wa.ldx = xs; wa.omega = omega;
+        wa.n = (int32_t)g->n; wa.S = g->ww_S; wa.steps = g->ww_steps;
+        RC_TRY(launch_wave(wa, g->ww_maxk, sor, sym_pair ? 2 : backward ? 1 : 0, g->ww_lds, st, ncolv));
+        continue;
+      }
       if (lay == g && g->tiny_ok && g->ncols == g->n && g_gs_tiny && !g_chain_tim) {   // the whole operator fits LDS: no global access per level
         RC_TRY(launch_chain_tiny(c, sor, s.rows, (int)g->n, (int)g->nnz, g->nlev, st, ncolv));
         continue;

@@ -495,6 +495,52 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
     int64_t widest = 0;
     for (int l2 = 0; l2 < g->nlev; ++l2) widest = std::max<int64_t>(widest, prow[g->lvl_ptr[l2 + 1]] - prow[g->lvl_ptr[l2]]);
     g->tiny_ok = !compact && n <= kTinyRows && nnz <= kTinyNnz && widest <= kTinyLvlNnz && g->nlev <= kTinyRows;
+    // ... and as one record for the single-wave walk (gs_wave_kernel)?  Positions are level-order rows: a column beyond
+    // the square block (halo of a sharded operator) rules it out.
+    if (g->tiny_ok && n > 0 && n < 65535) {
+      int maxlen = 0;
+      bool square = true;
+      for (int64_t p2 = 0; p2 < n; ++p2) {
+        int off = 0;
+        for (int32_t j = prow[p2]; j < prow[p2 + 1]; ++j) {
+          if (h.pcol[j] >= n) square = false;
+          if (j != h.pdpos[p2]) ++off;
+        }
+        maxlen = std::max(maxlen, off);
+      }
+      const int maxk = ((std::max(1, maxlen) + 5) / 6) * 6;
+      std::vector<uint16_t> stp;
+      for (int l2 = 0; l2 < g->nlev; ++l2)
+        for (int32_t q = g->lvl_ptr[l2]; q < g->lvl_ptr[l2 + 1]; q += 64) stp.push_back((uint16_t)q);
+      const int steps = (int)stp.size();
+      stp.push_back((uint16_t)n);
+      const int S = (int)((n + 7) & ~(int64_t)7);
+      const size_t recb = ((size_t)maxk * S * sizeof(real) + (size_t)S * sizeof(real) + (size_t)maxk * S * 2 + (size_t)(steps + 1) * 2 + 15) & ~(size_t)15;
+      const size_t lds = recb + (size_t)S * sizeof(real) + (size_t)(n + 1) * sizeof(real) + 16;
+      if (square && maxk <= kWaveMaxK && steps <= kWaveMaxSteps && lds <= 150 * 1024) {
+        std::vector<unsigned char> rec(recb, 0);
+        real* vals = (real*)rec.data();
+        real* dg = vals + (size_t)maxk * S;
+        uint16_t* cols = (uint16_t*)(dg + S);
+        uint16_t* sp = cols + (size_t)maxk * S;
+        for (size_t e = 0; e < (size_t)maxk * S; ++e) cols[e] = (uint16_t)n;   // padding: 0 * x[zero slot]
+        for (int64_t p2 = 0; p2 < n; ++p2) {
+          int k = 0;
+          for (int32_t j = prow[p2]; j < prow[p2 + 1]; ++j) {
+            if (j == h.pdpos[p2]) continue;
+            vals[(size_t)k * S + p2] = h.pval[j];
+            cols[(size_t)k * S + p2] = (uint16_t)h.pcol[j];
+            ++k;
+          }
+          dg[p2] = h.pdiag[p2];
+        }
+        std::copy(stp.begin(), stp.end(), sp);
+        RC_TRY(dev_upload(&g->ww_rec, rec.data(), (int64_t)recb));
+        g->ww_S = S; g->ww_maxk = maxk; g->ww_steps = steps; g->ww_lds = lds;
+        g->bytes += (int64_t)recb;
+        g->csr_bytes += (int64_t)recb;
+      }
+    }
   }
   return AMGH_OK;
 }

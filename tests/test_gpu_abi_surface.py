@@ -142,10 +142,12 @@ def test_w_and_f_cycles_at_128_cubed(h128, cyc):
 
 
 def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_graphs():
-    """An operator that fits LDS entirely (rows, nonzeros, level descriptors, x, b) runs its chained dependency levels
-    in gs_chain_tiny_kernel — no global memory access per level — with the products and in-order row sums of
-    gs_chain_kernel: bitwise the same sweep.  A small hierarchy replayed from a hipGraph (opt-in) is bitwise the eager
-    cycle, and PCG on the reference's lin_elastic_2d configuration (nns_test.jl:213-226) keeps its 13 iterations."""
+    """An operator that fits LDS entirely (rows, nonzeros, level descriptors, x, b) is swept out of LDS: by ONE wave
+    walking its record without any barrier (gs_wave_kernel, gs_tiny = 1: rows of at most 24 off-diagonal entries, a
+    symmetric sweep in one launch) or by gs_chain_tiny_kernel (gs_tiny = 2) — both with the products and in-order row
+    sums of gs_chain_kernel (gs_tiny = 0): bitwise the same sweep.  A small hierarchy replayed from a hipGraph (opt-in)
+    is bitwise the eager cycle, and PCG on the reference's lin_elastic_2d configuration (nns_test.jl:213-226) keeps
+    its 13 iterations."""
     from amg_amd.device import DeviceHierarchy
     from conftest import load_csc, load_npz
     lib = AMG.hip_lib()
@@ -154,19 +156,19 @@ def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_gra
     x0, b = uniform(A.m, 3), uniform(A.m, 4)
     # one stand-alone sweep each way, GS and SOR, both kernels
     out = {}
-    for tiny in (1, 0):
+    for tiny in (1, 2, 0):
         assert lib.amgh_debug_set_tunable(b"gs_tiny", tiny) == 0
         try:
             for cfg in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2),
-                        AMG.SOR(1.3, AMG.SymmetricSweep())):
+                        AMG.SOR(1.3, AMG.SymmetricSweep()), AMG.SOR(0.8, AMG.ForwardSweep(), iter=3)):
                 xs = x0.copy()
                 AMG.device.smooth_standalone(cfg, A, xs, b)       # in place
                 out[(tiny, repr((type(cfg).__name__, cfg.sweep_code, cfg.iter, cfg.omega)))] = xs
         finally:
             lib.amgh_debug_set_tunable(b"gs_tiny", 1)
     for (tiny, key), v in out.items():
-        if tiny == 1:
-            assert np.array_equal(v, out[(0, key)]), key
+        if tiny != 0:
+            assert np.array_equal(v, out[(0, key)]), (tiny, key)
     # the hierarchy: default (graph replay decided by amgh_finalize) vs eager, tiny kernel vs regular chain
     ml = AMG.smoothed_aggregation(A, B=d["B"])
     auto = DeviceHierarchy(ml, 0, 1)
@@ -176,11 +178,17 @@ def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_gra
     z_e = eager.precond_apply(d["b"])
     for _ in range(4):      # eager warm-up, capture + first replay, replays
         assert np.array_equal(auto.precond_apply(d["b"]), z_e)
-    lib.amgh_debug_set_tunable(b"gs_tiny", 0)
-    try:
-        assert np.array_equal(DeviceHierarchy(ml, 0, 1).precond_apply(d["b"]), z_e)
-    finally:
-        lib.amgh_debug_set_tunable(b"gs_tiny", 1)
+    for tiny in (0, 2):
+        lib.amgh_debug_set_tunable(b"gs_tiny", tiny)
+        try:
+            assert np.array_equal(DeviceHierarchy(ml, 0, 1).precond_apply(d["b"]), z_e)
+        finally:
+            lib.amgh_debug_set_tunable(b"gs_tiny", 1)
+    # a block of right-hand sides: one workgroup (one walking wave) per column, bitwise the single columns
+    Bk = np.stack([d["b"], uniform(A.m, 8), -d["b"]], axis=1)
+    Zk = DeviceHierarchy(ml, 0, 3).precond_apply(Bk)
+    for q in range(3):
+        assert np.array_equal(Zk[:, q], eager.precond_apply(np.ascontiguousarray(Bk[:, q])))
     assert rel(z_e, O.OracleHierarchy(ml).precond(d["b"])) <= 1e-10
     xp, log = AMG.cg(A, d["b"], Pl=AMG.aspreconditioner(ml), reltol=1e-10, log=True)
     xpo, _, itp = O.OracleHierarchy(ml).pcg(d["b"], reltol=1e-10)
