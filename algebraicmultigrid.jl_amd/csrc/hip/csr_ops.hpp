@@ -1,6 +1,7 @@
 // csr_ops.hpp — launches on one CSR operator: SpMV / residual / add / Jacobi (csr_stream_kernel) and the
 // Gauss-Seidel / SOR sweeps (slot, chain, block-inverse and stream kernels).  Included by amghip.hip.
 #pragma once
+#include <atomic>
 
 namespace {
 
@@ -113,11 +114,14 @@ int launch_chain_t(const ChainArgs& c, bool sor, bool ldsx, int nx, hipStream_t 
 // the whole operator as one record, walked by a single wave (gs_wave_kernel); dir: 0 forward, 1 backward, 2 both
 template <int MAXK, int DIR>
 int launch_wave_kd(const WaveArgs& a, bool sor, size_t lds, hipStream_t st, int ncolv) {
-  static bool attr_set = false;   // (more than the default 64 KB of dynamic LDS needs the attribute, once per kernel)
-  if (!attr_set) {
+  // more than the default 64 KB of dynamic LDS needs the attribute: once per kernel AND device (ranks of one process
+  // sweep on different devices)
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  if (lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && !((attr_set.load() >> (dev & 63)) & 1)) {
     (void)hipFuncSetAttribute((const void*)gs_wave_kernel<false, DIR, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)gs_wave_kernel<true, DIR, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set.fetch_or((uint64_t)1 << (dev & 63));
   }
   if (sor) hipLaunchKernelGGL((gs_wave_kernel<true, DIR, MAXK>), dim3(ncolv), dim3(kWaveThreads), lds, st, a);
   else hipLaunchKernelGGL((gs_wave_kernel<false, DIR, MAXK>), dim3(ncolv), dim3(kWaveThreads), lds, st, a);

@@ -169,6 +169,19 @@ def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_gra
     for (tiny, key), v in out.items():
         if tiny != 0:
             assert np.array_equal(v, out[(0, key)]), (tiny, key)
+    # a record beyond the default 64 KB of dynamic LDS (900 rows of a 5-point operator + b + x)
+    A2 = AMG.poisson((30, 30))
+    x2, b2 = uniform(A2.m, 5), uniform(A2.m, 6)
+    big = {}
+    for tiny in (1, 0):
+        lib.amgh_debug_set_tunable(b"gs_tiny", tiny)
+        try:
+            xs = x2.copy()
+            AMG.device.smooth_standalone(AMG.GaussSeidel(iter=2), A2, xs, b2)
+            big[tiny] = xs
+        finally:
+            lib.amgh_debug_set_tunable(b"gs_tiny", 1)
+    assert np.array_equal(big[1], big[0]) and rel(big[1], O.smooth(AMG.GaussSeidel(iter=2), A2, x2, b2, hermitian=True)) <= 1e-13
     # the hierarchy: default (graph replay decided by amgh_finalize) vs eager, tiny kernel vs regular chain
     ml = AMG.smoothed_aggregation(A, B=d["B"])
     auto = DeviceHierarchy(ml, 0, 1)
