@@ -55,7 +55,8 @@ int main(int argc, char** argv) {
   Csr A = std::string(argv[1]) == "poisson" ? poisson3(atoi(argv[2])) : std::string(argv[1]) == "poisson2" ? poisson2(atoi(argv[2])) : load(argv[2]);
   const int64_t n = A.n;
   bw::Params prm; if (argc > 3) prm.target_rows = atoi(argv[3]);
-  const bool want_reg = argc > 4 && atoi(argv[4]) != 0;
+  const int want = argc > 4 ? atoi(argv[4]) : 2;   // kernel: 0 generic (operands from the LDS record), 1 operands in registers, 2 packed rows
+  prm.packed = want == 2;
   prm.threads = 8;
   bw::Plan P;
   const auto t0 = std::chrono::steady_clock::now();
@@ -63,8 +64,8 @@ int main(int argc, char** argv) {
   const double tplan = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (!ok) { printf("plan: not eligible\n"); return 0; }
   const int nl = (int)P.launch_ptr.size() - 1;
-  const bool use_reg = want_reg && P.blocks[0].maxk == 6 && P.max_rows <= 64 * bw::kRegRpt;
-  printf("kernel: %s\n", use_reg ? "operands in registers" : "operands from LDS (generic)");
+  const int use_reg = want == 2 ? 2 : (want == 1 && P.blocks[0].maxk == 6 && P.max_rows <= 64 * bw::kRegRpt) ? 1 : 0;
+  printf("kernel: %s\n", use_reg == 2 ? "packed rows" : use_reg == 1 ? "operands in registers" : "operands from LDS (generic)");
   int maxb = 0, under = 0;
   for (int l = 0; l < nl; ++l) { const int c = P.launch_ptr[l + 1] - P.launch_ptr[l]; maxb = std::max(maxb, c); under += c < 256; }
   std::vector<int> rows; for (auto& d : P.blocks) rows.push_back(d.nrows); std::sort(rows.begin(), rows.end());

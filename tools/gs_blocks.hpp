@@ -57,6 +57,26 @@ inline size_t lds_bytes(const Desc& d) {
   return rec_bytes<R>(d.S, d.maxk, d.nlev) + 2 * (size_t)d.S * sizeof(R) + (size_t)(d.nrows + d.next + 1) * sizeof(R) + 16;
 }
 
+// PACKED rows (the format of gs_bw_packed_kernel): a row is one run of 16-byte chunks
+//     [ v0 v1 | v2 v3 | ... | (.. dg rc) | c0 .. c7 | c8 .. ]      values, diagonal, its reciprocal, then the columns as uint16
+// BYTE offsets into the LDS x — so that a step loads a row's operands with a handful of ds_read_b128 off ONE address
+// (a single wave is bound by its instruction count: ~3 ns per instruction, whatever it is).  The chunk count is odd: rows
+// 16 k bytes apart with k odd are read by 64 lanes without bank conflicts.
+template <typename R>
+struct Packed {
+  static constexpr int vpc = 16 / (int)sizeof(R);                       // values per chunk
+  static int nvc(int maxk) { return (maxk + 2 + vpc - 1) / vpc; }       // value chunks: maxk values + diagonal + reciprocal
+  static int ncc(int maxk) { return (maxk + 7) / 8; }                   // column chunks
+  static int chunks(int maxk) { const int k = nvc(maxk) + ncc(maxk); return k | 1; }
+  static size_t row_bytes(int maxk) { return (size_t)16 * chunks(maxk); }
+  static size_t rec_bytes(int nrows, int maxk, int nsteps) { return ((size_t)nrows * row_bytes(maxk) + (size_t)(nsteps + 1) * 2 + 15) & ~(size_t)15; }
+  // LDS: x (nrows + next + 1, padded to 16 bytes) | b (nrows, padded) | the record
+  static size_t lds_bytes(const Desc& d) {
+    const size_t nx = ((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15, nb = ((size_t)d.nrows * sizeof(R) + 15) & ~(size_t)15;
+    return nx + nb + rec_bytes(d.nrows, d.maxk, d.nlev);
+  }
+};
+
 struct Plan {
   int64_t n = 0, nnz = 0;
   std::vector<int32_t> perm;        // block-order position -> natural row
@@ -75,6 +95,7 @@ struct Plan {
   int cuts[2] = {99, 99};
   int32_t range[3] = {1, 1, 1};
   int32_t cells[3] = {1, 1, 1};
+  bool packed = false;
 };
 
 template <class F>
@@ -91,6 +112,7 @@ struct Params {
   int max_rows = 1024;       // hard cap (uint16 local indices, LDS)
   size_t lds_limit = 150 * 1024;
   int threads = 8;
+  bool packed = false;       // records in the packed-row format (gs_bw_packed_kernel)
 };
 
 // Returns false when the operator cannot be laid out (rows too long for the LDS budget, local index overflow).
@@ -327,10 +349,11 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     ext_ptr[ob + 1] = ext_ptr[ob] + d.next;
     if (rec_total / 16 > (size_t)INT32_MAX) fits = false;
     d.rec = (int32_t)(rec_total / 16);
-    rec_total += rec_bytes<R>(d.S, d.maxk, d.nlev);
-    const size_t l = lds_bytes<R>(d);
+    rec_total += prm.packed ? Packed<R>::rec_bytes(d.nrows, d.maxk, d.nlev) : rec_bytes<R>(d.S, d.maxk, d.nlev);
+    const size_t l = prm.packed ? Packed<R>::lds_bytes(d) : lds_bytes<R>(d);
     P.lds_max = std::max(P.lds_max, l);
     if (d.nrows + d.next + 1 > 65535 || d.nlev > 65534 || l > 160 * 1024) fits = false;
+    if (prm.packed && (size_t)(d.nrows + d.next + 1) * sizeof(R) > 65535) fits = false;   // byte offsets in 16 bits
     P.max_rows = std::max(P.max_rows, d.nrows);
   }
   if (!fits || ext_ptr[B] > INT32_MAX) return false;
@@ -339,12 +362,50 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   P.ext_total = ext_ptr[B];
   P.ext_col.resize(ext_ptr[B]);
   P.rec.assign(rec_total, 0);
+  P.packed = prm.packed;
   parallel_for(T, [&](int t, int TT) {
     for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
       const Desc& d = P.blocks[ob];
       const std::vector<int32_t>& ex = exts[ob];
       std::copy(ex.begin(), ex.end(), P.ext_col.begin() + d.ext0);
       unsigned char* rec = P.rec.data() + (size_t)d.rec * 16;
+      if (prm.packed) {
+        const size_t rs = Packed<R>::row_bytes(d.maxk);
+        const int nvc = Packed<R>::nvc(d.maxk);
+        const uint16_t zoff = (uint16_t)((size_t)(d.nrows + d.next) * sizeof(R));   // the LDS slot that holds 0
+        uint16_t* stp = (uint16_t*)(rec + (size_t)d.nrows * rs);
+        int32_t nl = 0, run = 0, last = -1;
+        for (int32_t p = 0; p < d.nrows; ++p) {
+          const int32_t i = P.perm[d.row0 + p];
+          const int32_t l = ilev[i];
+          if (l != last || run == 64) { stp[nl++] = (uint16_t)p; run = 0; last = l; }
+          ++run;
+          R* v = (R*)(rec + (size_t)p * rs);
+          uint16_t* cc = (uint16_t*)(rec + (size_t)p * rs + (size_t)16 * nvc);
+          for (int k = 0; k < 8 * Packed<R>::ncc(d.maxk); ++k) cc[k] = zoff;
+          int k = 0;
+          R dg = 0;
+          for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+            const int32_t c = col[j];
+            if (c == i) { dg = val[j]; continue; }
+            if (c >= n) continue;
+            const int32_t q = inv[c];
+            size_t lc;
+            if (q >= d.row0 && q < d.row0 + d.nrows) lc = (size_t)(q - d.row0);
+            else lc = (size_t)d.nrows + (size_t)(std::lower_bound(ex.begin(), ex.end(), q) - ex.begin());
+            v[k] = val[j];
+            cc[k] = (uint16_t)(lc * sizeof(R));
+            ++k;
+          }
+          v[d.maxk] = dg;
+          // reciprocal for the division-free quotient; 0 = "divide" (diagonals whose reciprocal or products may leave the normal range)
+          const double ad = std::fabs((double)dg);
+          const bool safe = sizeof(R) == 8 ? (ad > 1e-100 && ad < 1e100) : (ad > 1e-12 && ad < 1e12);
+          v[d.maxk + 1] = safe ? (R)1 / dg : (R)0;
+        }
+        stp[nl] = (uint16_t)d.nrows;
+        continue;
+      }
       R* vals = (R*)rec;
       R* diag = vals + (size_t)d.maxk * d.S;
       uint16_t* cols = (uint16_t*)(diag + d.S);
@@ -389,7 +450,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
       for (int32_t ob = P.launch_ptr[l]; ob < P.launch_ptr[l + 1]; ++ob) {
         const Desc& d = P.blocks[ob];
         depth = std::max(depth, d.nlev);
-        bytes += (double)rec_bytes<R>(d.S, d.maxk, d.nlev) + d.nrows * 3.0 * sizeof(R) + d.next * (4.0 + sizeof(R)) * 2;
+        bytes += (double)(prm.packed ? Packed<R>::rec_bytes(d.nrows, d.maxk, d.nlev) : rec_bytes<R>(d.S, d.maxk, d.nlev)) + d.nrows * 3.0 * sizeof(R) + d.next * (4.0 + sizeof(R)) * 2;
       }
       P.sum_depth += depth;
       const double step = 0.10e-6 + 0.012e-6 * maxk;   // two LDS round trips + maxk dependent additions + the division
@@ -651,12 +712,144 @@ __global__ __launch_bounds__(kThreads) void gs_bw_reg_kernel(Args<R> a) {
   }
 }
 
+// ---- the walk on PACKED rows ----------------------------------------------------------------------------------------
+template <typename R> struct Vec16;
+template <> struct Vec16<double> { typedef double2 type; };
+template <> struct Vec16<float> { typedef float4 type; };
+
+template <typename R, int MAXK>
+struct PackedOps {
+  static constexpr int VPC = 16 / (int)sizeof(R), NVC = (MAXK + 2 + VPC - 1) / VPC, NCC = (MAXK + 7) / 8;
+  R v[NVC * VPC];        // values, then diagonal (slot MAXK) and its reciprocal (slot MAXK + 1)
+  uint32_t c[NCC * 4];   // byte offsets of the columns into the LDS x, two per word
+  R bb; int p;
+};
+template <typename R, int MAXK>
+__device__ __forceinline__ void packed_load(PackedOps<R, MAXK>& o, int p, bool act, const unsigned char* rec, const R* bl) {
+  typedef PackedOps<R, MAXK> O;
+  constexpr int KCH = (O::NVC + O::NCC) | 1;
+  o.p = act ? p : -1;
+  const int q = act ? p : 0;
+  const unsigned char* row = rec + (size_t)q * (16 * KCH);
+  typedef typename Vec16<R>::type V;
+#pragma unroll
+  for (int k = 0; k < O::NVC; ++k) *(V*)&o.v[k * O::VPC] = *(const V*)(row + 16 * k);
+#pragma unroll
+  for (int k = 0; k < O::NCC; ++k) *(uint4*)&o.c[4 * k] = *(const uint4*)(row + 16 * (O::NVC + k));
+  o.bb = bl[q];
+}
+template <typename R, int MAXK, bool SOR>
+__device__ __forceinline__ void packed_row(const PackedOps<R, MAXK>& o, R* xl, R omega) {
+  R xv[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    const uint32_t w = o.c[k >> 1];
+    const uint32_t off = (k & 1) ? (w >> 16) : (w & 0xffffu);
+    xv[k] = *(const R*)((const char*)xl + off);
+  }
+  R acc = (R)0;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) acc += o.v[k] * xv[k];
+  const R dg = o.v[MAXK], rc = o.v[MAXK + 1];
+  if (o.p >= 0 && dg != (R)0) {
+    if (SOR) { xl[o.p] = ((R)1 - omega) * xl[o.p] + (omega / dg) * (o.bb - acc); return; }
+    // (bb - acc) / dg from rc = RN(1 / dg): q0 = RN(nn rc), the exact remainder nn - dg q0 (one fma), RN(q0 + rem rc) is the
+    // correctly rounded quotient (Markstein) while nothing leaves the normal range; otherwise divide
+    const R nn = o.bb - acc;
+    R q = nn * rc;
+    const R rem = __builtin_fma(-dg, q, nn);
+    q = __builtin_fma(rem, rc, q);
+    const R an = __builtin_fabs(nn);
+    const bool safe = sizeof(R) == 8 ? (an > (R)1e-200 && an < (R)1e200) : (an > (R)1e-25 && an < (R)1e25);
+    if (!(rc != (R)0 && safe)) q = nn / dg;
+    xl[o.p] = q;
+  }
+}
+template <typename R, bool SOR, bool BWD, int MAXK>
+__global__ __launch_bounds__(kThreads) void gs_bw_packed_kernel(Args<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const long long t_start = a.tim ? wall_clock64() : 0;
+  const Desc d = a.blocks[a.block0 + blockIdx.x];
+  const int tid = threadIdx.x;
+  const R* __restrict__ b = a.b + (int64_t)blockIdx.y * a.ldb;
+  R* __restrict__ x = a.x + (int64_t)blockIdx.y * a.ldx;
+  typedef PackedOps<R, MAXK> O;
+  constexpr int KCH = (O::NVC + O::NCC) | 1;
+  const int nxb = (int)(((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15), nbb = (int)(((size_t)d.nrows * sizeof(R) + 15) & ~(size_t)15);
+  R* xl = (R*)lds;
+  R* bl = (R*)(lds + nxb);
+  unsigned char* rec = lds + nxb + nbb;
+  const int ns = d.nlev;
+  const int recb = (int)(((size_t)d.nrows * (16 * KCH) + (size_t)(ns + 1) * 2 + 15) & ~(size_t)15);
+  {
+    const uint4* src = (const uint4*)(a.rec + (size_t)(uint32_t)d.rec * 16);
+    uint4* dst = (uint4*)rec;
+    for (int e = tid; e < (recb >> 4); e += kThreads) dst[e] = src[e];
+  }
+  for (int p = tid; p < d.nrows; p += kThreads) { bl[p] = b[d.row0 + p]; xl[p] = x[d.row0 + p]; }
+  for (int e = tid; e < d.next; e += kThreads) xl[d.nrows + e] = x[a.ext_col[d.ext0 + e]];
+  if (tid == 0) xl[d.nrows + d.next] = (R)0;
+  __syncthreads();
+  if (tid >= 64) {
+    if ((BW_OPT & 4) && a.pre_bytes > 0) {
+      const int64_t nth = (int64_t)gridDim.x * (kThreads - 64);
+      for (int64_t off = ((int64_t)blockIdx.x * (kThreads - 64) + (tid - 64)) * 128; off < a.pre_bytes; off += nth * 128) {
+        unsigned tmp;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(a.pre + off) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+  const long long t_loaded = a.tim ? wall_clock64() : 0;
+  const uint16_t* stp = (const uint16_t*)(rec + (size_t)d.nrows * (16 * KCH));
+  const int lp0 = tid <= ns ? (int)stp[tid] : d.nrows;
+  const int lp1 = tid + 64 <= ns ? (int)stp[tid + 64] : d.nrows;
+#define BW_SP(i, out)                                                          \
+  {                                                                            \
+    const int i_ = (i);                                                        \
+    const int u0_ = __builtin_amdgcn_readlane(lp0, i_ & 63);                   \
+    const int u1_ = __builtin_amdgcn_readlane(lp1, i_ & 63);                   \
+    out = i_ < 64 ? u0_ : u1_;                                                 \
+  }
+#define BW_RANGE(k, r0, r1)                                                    \
+  {                                                                            \
+    const int k_ = (k);                                                        \
+    const int st_ = BWD ? ns - 1 - k_ : k_;                                    \
+    const bool in_ = k_ < ns;                                                  \
+    int q0_, q1_;                                                              \
+    BW_SP(in_ ? st_ : 0, q0_);                                                 \
+    BW_SP(in_ ? st_ + 1 : 0, q1_);                                             \
+    r0 = q0_; r1 = in_ ? q1_ : q0_;                                            \
+  }
+  PackedOps<R, MAXK> A, B;
+  int r0, r1;
+  BW_RANGE(0, r0, r1);
+  packed_load<R, MAXK>(A, r0 + tid, r0 + tid < r1, rec, bl);
+  for (int k = 0; k < ns; k += 2) {
+    BW_RANGE(k + 1, r0, r1);
+    packed_load<R, MAXK>(B, r0 + tid, r0 + tid < r1, rec, bl);
+    packed_row<R, MAXK, SOR>(A, xl, a.omega);
+    BW_RANGE(k + 2, r0, r1);
+    packed_load<R, MAXK>(A, r0 + tid, r0 + tid < r1, rec, bl);
+    packed_row<R, MAXK, SOR>(B, xl, a.omega);
+  }
+#undef BW_RANGE
+#undef BW_SP
+  const long long t_swept = a.tim ? wall_clock64() : 0;
+  for (int p = tid; p < d.nrows; p += 64) x[d.row0 + p] = xl[p];
+  if (a.tim && tid == 0) {
+    long long* t = a.tim + 4 * (int64_t)(a.block0 + blockIdx.x);
+    t[0] = t_start; t[1] = t_loaded; t[2] = t_swept; t[3] = wall_clock64();
+  }
+}
+
 // launches of one directional sweep: blocks of launch l = [launch_ptr[l], launch_ptr[l + 1])
 // launch_rec[l] = byte offset of launch l's first record in the record buffer (launch_rec[nl] = its size)
 constexpr int kRegRpt = 8;   // register-resident kernel: blocks of at most 64 * kRegRpt rows of at most 6 entries
 template <typename R, int MAXK>
 inline hipError_t sweep_k(const Args<R>& a0, const std::vector<int32_t>& launch_ptr, const std::vector<int64_t>& launch_rec, size_t lds_max,
-                          bool sor, bool backward, int ncols, hipStream_t st, bool reg = false) {
+                          bool sor, bool backward, int ncols, hipStream_t st, int reg = 0) {
   static bool attr_set = false;
   if (!attr_set) {
     if (MAXK == 6) {
@@ -680,7 +873,20 @@ inline hipError_t sweep_k(const Args<R>& a0, const std::vector<int32_t>& launch_
     a.pre = nullptr; a.pre_bytes = 0;
     if (ln >= 0 && ln < nl && !launch_rec.empty()) { a.pre = a0.rec + launch_rec[ln]; a.pre_bytes = launch_rec[ln + 1] - launch_rec[ln]; }
     const dim3 grid((unsigned)(launch_ptr[l + 1] - launch_ptr[l]), (unsigned)ncols);
-    if (MAXK == 6 && reg) {
+    if (reg == 2) {
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, false, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, false, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, true, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, true, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr2 = true;
+      }
+      if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_packed_kernel<R, true, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_packed_kernel<R, true, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
+      else { if (backward) hipLaunchKernelGGL((gs_bw_packed_kernel<R, false, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_packed_kernel<R, false, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
+      continue;
+    }
+    if (MAXK == 6 && reg == 1) {
       if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_reg_kernel<R, true, true, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_reg_kernel<R, true, false, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); }
       else { if (backward) hipLaunchKernelGGL((gs_bw_reg_kernel<R, false, true, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_reg_kernel<R, false, false, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); }
       continue;
@@ -693,12 +899,12 @@ inline hipError_t sweep_k(const Args<R>& a0, const std::vector<int32_t>& launch_
 constexpr int kMaxK = 24;   // longest rows (off-diagonal entries, padded to a multiple of kChunk) the kernels are instantiated for
 template <typename R>
 inline hipError_t sweep(const Args<R>& a, int maxk, const std::vector<int32_t>& launch_ptr, const std::vector<int64_t>& launch_rec,
-                        size_t lds_max, bool sor, bool backward, int ncols, hipStream_t st, bool reg = false) {
+                        size_t lds_max, bool sor, bool backward, int ncols, hipStream_t st, int reg = 0) {
   switch (maxk) {
     case 6: return sweep_k<R, 6>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st, reg);
-    case 12: return sweep_k<R, 12>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st);
-    case 18: return sweep_k<R, 18>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st);
-    case 24: return sweep_k<R, 24>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st);
+    case 12: return sweep_k<R, 12>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st, reg == 2 ? 2 : 0);
+    case 18: return sweep_k<R, 18>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st, reg == 2 ? 2 : 0);
+    case 24: return sweep_k<R, 24>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st, reg == 2 ? 2 : 0);
   }
   return hipErrorInvalidValue;
 }
