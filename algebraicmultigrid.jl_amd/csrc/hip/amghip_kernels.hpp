@@ -621,46 +621,83 @@ __global__ __launch_bounds__(T) void gs_chain_tiny_kernel(ChainArgs a, int n, in
 // ---- a whole small operator walked by ONE wave --------------------------------------------------------------------
 // gs_chain_tiny_kernel pays two workgroup barriers and ~300 instructions per dependency level (staged products, row
 // sums that skip the diagonal, descriptors).  A single wave needs no barrier at all — its LDS operations execute in
-// program order — and what bounds it is its own instruction issue (tools/wave_chain_probe, profiles/r03_block_wave.log),
-// so the level loop is cut to the bone: the operator is laid out once, at schedule build time, as a RECORD
-//     vals[MAXK][S] | diag[S] | cols[MAXK][S] (uint16 positions in level order) | step_ptr[steps + 1] (uint16)
-// rows in level order, off-diagonal entries only and in their stored order, short rows padded with 0 * x[zero slot];
-// a step is a piece of at most 64 rows of one level.  All waves copy the record, b and x into LDS; wave 0 walks the
-// steps, lane = row: the operands of the NEXT step are requested before the current step's x values are gathered (two
-// register sets, loop unrolled by two), the step pointers sit in two registers (v_readlane).  Per row: gather, MAXK
-// separately rounded multiply-adds in entry order, the division — the scalar loop's arithmetic, bit for bit.
+// program order — and what bounds it is its own instruction count, ~3 ns per instruction whatever it is
+// (tools/wave_chain_probe, profiles/r03_block_wave.log).  So the level loop is cut to the bone.  The operator is laid out
+// once, at schedule build time, as a RECORD of PACKED ROWS in level order: a row is one run of 16-byte chunks
+//     [ v0 v1 | v2 v3 | ... | (.. dg rc) | c0 .. c7 | c8 .. ]
+// off-diagonal values in their stored order, the diagonal, its reciprocal, then the columns as uint16 BYTE offsets into
+// the LDS copy of x (short rows padded with 0 * x[zero slot]); the chunk count is odd, so 64 lanes read rows 16 k bytes
+// apart without bank conflicts.  Behind the rows: step_ptr (uint16), a step being a piece of at most 64 rows of one level.
+// All waves copy the record, b and x into LDS; wave 0 walks the steps, lane = row: a handful of ds_read_b128 off ONE
+// address fetch a row's operands, those of the NEXT step are requested before the current step's x values are gathered
+// (two register sets, loop unrolled by two), the step pointers sit in two registers (v_readlane).  Per row: gather, MAXK
+// separately rounded multiply-adds in entry order, then the quotient by the diagonal as q0 = RN(n rc), the exact
+// remainder n - dg q0 (one fma), RN(q0 + rem rc) — the correctly rounded n / dg (Markstein) as long as nothing leaves the
+// normal range, else the division itself: the scalar loop's arithmetic, bit for bit.
 constexpr int kWaveThreads = 256;
 constexpr int kWaveMaxSteps = 124;
 constexpr int kWaveMaxK = 24;
+constexpr int kWaveVpc = 16 / (int)sizeof(real);   // values per chunk
+inline __host__ __device__ int wave_nvc(int maxk) { return (maxk + 2 + kWaveVpc - 1) / kWaveVpc; }
+inline __host__ __device__ int wave_ncc(int maxk) { return (maxk + 7) / 8; }
+inline __host__ __device__ int wave_row_bytes(int maxk) { return 16 * ((wave_nvc(maxk) + wave_ncc(maxk)) | 1); }
 struct WaveArgs {
-  const unsigned char* rec; const real* bp; real* x; int64_t ldb, ldx; real omega; int32_t n, S, steps;
+  const unsigned char* rec; const real* bp; real* x; int64_t ldb, ldx; real omega; int32_t n, steps;
+};
+typedef double wave_f64x2 __attribute__((ext_vector_type(2)));
+typedef float wave_f32x4 __attribute__((ext_vector_type(4)));
+template <typename R> struct WaveVec16;
+template <> struct WaveVec16<double> { typedef wave_f64x2 type; };
+template <> struct WaveVec16<float> { typedef wave_f32x4 type; };
+__device__ __forceinline__ double wave_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float wave_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <int MAXK>
+struct WaveRow {
+  static constexpr int NVC = (MAXK + 2 + kWaveVpc - 1) / kWaveVpc, NCC = (MAXK + 7) / 8, RS = 16 * ((NVC + NCC) | 1);
+  real v[NVC * kWaveVpc];   // values, the diagonal (slot MAXK), its reciprocal (slot MAXK + 1)
+  uint32_t c[NCC * 4];      // column byte offsets, two per word
+  real bb; int p;
 };
 template <int MAXK>
-struct WaveRow { int c[MAXK]; real v[MAXK]; real dg, bb; int p; };
-template <int MAXK>
-__device__ __forceinline__ void wave_load(WaveRow<MAXK>& o, int p, bool act, const real* vals, const real* diag, const uint16_t* cols,
-                                          const real* bl, int S, int zslot) {
+__device__ __forceinline__ void wave_load(WaveRow<MAXK>& o, int p, bool act, const unsigned char* rec, const real* bl) {
+  typedef WaveRow<MAXK> O;
+  typedef typename WaveVec16<real>::type V;
   o.p = act ? p : -1;
   const int q = act ? p : 0;
+  const unsigned char* row = rec + (size_t)q * O::RS;
 #pragma unroll
-  for (int k = 0; k < MAXK; ++k) { const int c = (int)cols[k * S + q]; o.c[k] = act ? c : zslot; o.v[k] = vals[k * S + q]; }
-  o.dg = diag[q]; o.bb = bl[q];
+  for (int k = 0; k < O::NVC; ++k) *(V*)&o.v[k * kWaveVpc] = *(const V*)(row + 16 * k);
+#pragma unroll
+  for (int k = 0; k < O::NCC; ++k) *(uint4*)&o.c[4 * k] = *(const uint4*)(row + 16 * (O::NVC + k));
+  o.bb = bl[q];
 }
 template <int MAXK, bool SOR>
 __device__ __forceinline__ void wave_row(const WaveRow<MAXK>& o, real* xl, real omega) {
   real xv[MAXK];
 #pragma unroll
-  for (int k = 0; k < MAXK; ++k) xv[k] = xl[o.c[k]];
+  for (int k = 0; k < MAXK; ++k) {
+    const uint32_t w = o.c[k >> 1];
+    xv[k] = *(const real*)((const char*)xl + ((k & 1) ? (w >> 16) : (w & 0xffffu)));
+  }
   real acc = 0.0;
 #pragma unroll
   for (int k = 0; k < MAXK; ++k) acc += o.v[k] * xv[k];
-  if (o.p >= 0 && o.dg != 0.0) xl[o.p] = SOR ? (1.0 - omega) * xl[o.p] + (omega / o.dg) * (o.bb - acc) : (o.bb - acc) / o.dg;
+  const real dg = o.v[MAXK], rc = o.v[MAXK + 1];
+  if (o.p >= 0 && dg != 0.0) {
+    if (SOR) { xl[o.p] = (1.0 - omega) * xl[o.p] + (omega / dg) * (o.bb - acc); return; }
+    const real nn = o.bb - acc;
+    real q = nn * rc;
+    const real rem = wave_fma(-dg, q, nn);
+    q = wave_fma(rem, rc, q);
+    const real an = nn < (real)0 ? -nn : nn;
+    const bool safe = sizeof(real) == 8 ? (an > (real)1e-200 && an < (real)1e200) : (an > (real)1e-25 && an < (real)1e25);
+    if (!(rc != 0.0 && safe)) q = nn / dg;
+    xl[o.p] = q;
+  }
 }
 // one directional walk over the record's steps (wave 0 only)
 template <bool SOR, bool BWD, int MAXK>
-__device__ __forceinline__ void wave_walk(const real* vals, const real* diag, const uint16_t* cols, const real* bl, real* xl, int S, int n,
-                                          int ns, int lp0, int lp1, real omega, int tid) {
-  const int zslot = n;
+__device__ __forceinline__ void wave_walk(const unsigned char* rec, const real* bl, real* xl, int ns, int lp0, int lp1, real omega, int tid) {
 #define AMGH_WAVE_SP(i, out)                                                   \
   {                                                                            \
     const int i_ = (i);                                                        \
@@ -682,13 +719,13 @@ __device__ __forceinline__ void wave_walk(const real* vals, const real* diag, co
   WaveRow<MAXK> A, B;
   int r0, r1;
   AMGH_WAVE_RANGE(0, r0, r1);
-  wave_load<MAXK>(A, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, S, zslot);
+  wave_load<MAXK>(A, r0 + tid, r0 + tid < r1, rec, bl);
   for (int k = 0; k < ns; k += 2) {
     AMGH_WAVE_RANGE(k + 1, r0, r1);
-    wave_load<MAXK>(B, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, S, zslot);
+    wave_load<MAXK>(B, r0 + tid, r0 + tid < r1, rec, bl);
     wave_row<MAXK, SOR>(A, xl, omega);
     AMGH_WAVE_RANGE(k + 2, r0, r1);
-    wave_load<MAXK>(A, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, S, zslot);
+    wave_load<MAXK>(A, r0 + tid, r0 + tid < r1, rec, bl);
     wave_row<MAXK, SOR>(B, xl, omega);
   }
 #undef AMGH_WAVE_RANGE
@@ -701,27 +738,27 @@ __global__ __launch_bounds__(kWaveThreads) void gs_wave_kernel(WaveArgs a) {
   const int tid = threadIdx.x;
   const real* __restrict__ b = a.bp + (int64_t)blockIdx.x * a.ldb;   // independent right-hand-side columns, one workgroup each
   real* __restrict__ x = a.x + (int64_t)blockIdx.x * a.ldx;
-  const int S = a.S, n = a.n, ns = a.steps;
-  const int recb = (int)(((size_t)MAXK * S * sizeof(real) + (size_t)S * sizeof(real) + (size_t)MAXK * S * 2 + (size_t)(ns + 1) * 2 + 15) & ~(size_t)15);
+  const int n = a.n, ns = a.steps;
+  // LDS: x (n + 1 entries, the last one the zero slot) | b | the record — each padded to 16 bytes
+  const int nxb = (int)(((size_t)(n + 1) * sizeof(real) + 15) & ~(size_t)15), nbb = (int)(((size_t)n * sizeof(real) + 15) & ~(size_t)15);
+  real* xl = (real*)wave_lds;
+  real* bl = (real*)(wave_lds + nxb);
+  unsigned char* rec = wave_lds + nxb + nbb;
+  const int recb = (int)(((size_t)n * WaveRow<MAXK>::RS + (size_t)(ns + 1) * 2 + 15) & ~(size_t)15);
   {
     const uint4* src = (const uint4*)a.rec;
-    uint4* dst = (uint4*)wave_lds;
+    uint4* dst = (uint4*)rec;
     for (int e = tid; e < (recb >> 4); e += kWaveThreads) dst[e] = src[e];
   }
-  real* bl = (real*)(wave_lds + recb);
-  real* xl = bl + S;
   for (int p = tid; p < n; p += kWaveThreads) { bl[p] = b[p]; xl[p] = x[p]; }
   if (tid == 0) xl[n] = 0.0;
   __syncthreads();
   if (tid >= kWave) return;
-  const real* vals = (const real*)wave_lds;
-  const real* diag = vals + (size_t)MAXK * S;
-  const uint16_t* cols = (const uint16_t*)(diag + S);
-  const uint16_t* stp = cols + (size_t)MAXK * S;
+  const uint16_t* stp = (const uint16_t*)(rec + (size_t)n * WaveRow<MAXK>::RS);
   const int lp0 = tid <= ns ? (int)stp[tid] : n;
   const int lp1 = tid + 64 <= ns ? (int)stp[tid + 64] : n;
-  if (DIR != 1) wave_walk<SOR, false, MAXK>(vals, diag, cols, bl, xl, S, n, ns, lp0, lp1, a.omega, tid);
-  if (DIR != 0) wave_walk<SOR, true, MAXK>(vals, diag, cols, bl, xl, S, n, ns, lp0, lp1, a.omega, tid);
+  if (DIR != 1) wave_walk<SOR, false, MAXK>(rec, bl, xl, ns, lp0, lp1, a.omega, tid);
+  if (DIR != 0) wave_walk<SOR, true, MAXK>(rec, bl, xl, ns, lp0, lp1, a.omega, tid);
   for (int p = tid; p < n; p += kWave) x[p] = xl[p];
 }
 

@@ -511,7 +511,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       if (lay == g && g->ww_rec && g->ncols == g->n && g_gs_tiny == 1 && !g_chain_tim && s.l0 == 0 && s.l1 == g->nlev) {
         WaveArgs wa{};   // one record, one wave, no barrier between the levels
         wa.rec = g->ww_rec; wa.bp = rhs; wa.x = xp; wa.ldb = ldb; wa.ldx = xs; wa.omega = omega;
-        wa.n = (int32_t)g->n; wa.S = g->ww_S; wa.steps = g->ww_steps;
+        wa.n = (int32_t)g->n; wa.steps = g->ww_steps;
         RC_TRY(launch_wave(wa, g->ww_maxk, sor, sym_pair ? 2 : backward ? 1 : 0, g->ww_lds, st, ncolv));
         continue;
       }

@@ -514,29 +514,34 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
         for (int32_t q = g->lvl_ptr[l2]; q < g->lvl_ptr[l2 + 1]; q += 64) stp.push_back((uint16_t)q);
       const int steps = (int)stp.size();
       stp.push_back((uint16_t)n);
-      const int S = (int)((n + 7) & ~(int64_t)7);
-      const size_t recb = ((size_t)maxk * S * sizeof(real) + (size_t)S * sizeof(real) + (size_t)maxk * S * 2 + (size_t)(steps + 1) * 2 + 15) & ~(size_t)15;
-      const size_t lds = recb + (size_t)S * sizeof(real) + (size_t)(n + 1) * sizeof(real) + 16;
-      if (square && maxk <= kWaveMaxK && steps <= kWaveMaxSteps && lds <= 150 * 1024) {
+      const size_t rs = (size_t)wave_row_bytes(maxk);
+      const size_t recb = ((size_t)n * rs + (size_t)(steps + 1) * 2 + 15) & ~(size_t)15;
+      const size_t lds = (((size_t)(n + 1) * sizeof(real) + 15) & ~(size_t)15) + (((size_t)n * sizeof(real) + 15) & ~(size_t)15) + recb;
+      if (square && maxk <= kWaveMaxK && steps <= kWaveMaxSteps && lds <= 150 * 1024 && (size_t)(n + 1) * sizeof(real) <= 65535) {
         std::vector<unsigned char> rec(recb, 0);
-        real* vals = (real*)rec.data();
-        real* dg = vals + (size_t)maxk * S;
-        uint16_t* cols = (uint16_t*)(dg + S);
-        uint16_t* sp = cols + (size_t)maxk * S;
-        for (size_t e = 0; e < (size_t)maxk * S; ++e) cols[e] = (uint16_t)n;   // padding: 0 * x[zero slot]
+        const int nvc = wave_nvc(maxk);
+        const uint16_t zoff = (uint16_t)((size_t)n * sizeof(real));   // the LDS slot that holds 0: padding entries are 0 * 0
         for (int64_t p2 = 0; p2 < n; ++p2) {
+          real* v = (real*)(rec.data() + (size_t)p2 * rs);
+          uint16_t* cc = (uint16_t*)(rec.data() + (size_t)p2 * rs + (size_t)16 * nvc);
+          for (int k = 0; k < 8 * wave_ncc(maxk); ++k) cc[k] = zoff;
           int k = 0;
           for (int32_t j = prow[p2]; j < prow[p2 + 1]; ++j) {
             if (j == h.pdpos[p2]) continue;
-            vals[(size_t)k * S + p2] = h.pval[j];
-            cols[(size_t)k * S + p2] = (uint16_t)h.pcol[j];
+            v[k] = h.pval[j];
+            cc[k] = (uint16_t)((size_t)h.pcol[j] * sizeof(real));
             ++k;
           }
-          dg[p2] = h.pdiag[p2];
+          const real dg = h.pdiag[p2];
+          v[maxk] = dg;
+          // reciprocal for the division-free quotient; 0 = "divide" (a diagonal whose reciprocal or products may leave the normal range)
+          const double ad = std::fabs((double)dg);
+          const bool safe = sizeof(real) == 8 ? (ad > 1e-100 && ad < 1e100) : (ad > 1e-12 && ad < 1e12);
+          v[maxk + 1] = safe ? (real)1 / dg : (real)0;
         }
-        std::copy(stp.begin(), stp.end(), sp);
+        std::copy(stp.begin(), stp.end(), (uint16_t*)(rec.data() + (size_t)n * rs));
         RC_TRY(dev_upload(&g->ww_rec, rec.data(), (int64_t)recb));
-        g->ww_S = S; g->ww_maxk = maxk; g->ww_steps = steps; g->ww_lds = lds;
+        g->ww_S = 0; g->ww_maxk = maxk; g->ww_steps = steps; g->ww_lds = lds;
         g->bytes += (int64_t)recb;
         g->csr_bytes += (int64_t)recb;
       }
