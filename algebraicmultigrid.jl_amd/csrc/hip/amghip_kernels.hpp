@@ -636,7 +636,7 @@ __global__ __launch_bounds__(T) void gs_chain_tiny_kernel(ChainArgs a, int n, in
 // normal range, else the division itself: the scalar loop's arithmetic, bit for bit.
 constexpr int kWaveThreads = 256;
 constexpr int kWaveMaxSteps = 124;
-constexpr int kWaveMaxK = 24;
+constexpr int kWaveMaxK = 36;
 constexpr int kWaveVpc = 16 / (int)sizeof(real);   // values per chunk
 inline __host__ __device__ int wave_nvc(int maxk) { return (maxk + 2 + kWaveVpc - 1) / kWaveVpc; }
 inline __host__ __device__ int wave_ncc(int maxk) { return (maxk + 7) / 8; }

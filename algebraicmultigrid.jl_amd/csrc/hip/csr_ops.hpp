@@ -142,6 +142,8 @@ int launch_wave(const WaveArgs& a, int maxk, bool sor, int dir, size_t lds, hipS
     case 12: return launch_wave_k<12>(a, sor, dir, lds, st, ncolv);
     case 18: return launch_wave_k<18>(a, sor, dir, lds, st, ncolv);
     case 24: return launch_wave_k<24>(a, sor, dir, lds, st, ncolv);
+    case 30: return launch_wave_k<30>(a, sor, dir, lds, st, ncolv);
+    case 36: return launch_wave_k<36>(a, sor, dir, lds, st, ncolv);
   }
   return AMGH_EINVAL;
 }
