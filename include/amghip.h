@@ -448,7 +448,10 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
 
 /* Diagnostics: tunables of the Gauss-Seidel execution (process-wide; used by tools/ to pick the defaults and by
  * tests to force every path).  Read at every sweep: "gs_xcd_map", "gs_block_pipe", "gs_flip", "gs_keep_lo",
- * "gs_slots", "gs_block_target", "gs_min_rows", "gs_threads", "gs_nnz_per_wg", and "gs_merge" <= 1 /
+ * "gs_slots", "gs_block_target", "gs_min_rows", "gs_threads", "gs_nnz_per_wg", "gs_tiny" (operators that fit LDS
+ * entirely: 1 = walked by a single wave from their packed record where one was built, else the whole-operator chain
+ * kernel; 2 = the whole-operator chain kernel; 0 = the regular chain kernel — all three bitwise the same sweep),
+ * "jacobi_zero", "rhs_il", and "gs_merge" <= 1 /
  * "gs_block_inverse" = 0 to bypass already-built merged groups / block-inverse data.  Read when a schedule is BUILT
  * (amgh_push_level, first stand-alone sweep of an operator): "gs_merge" (largest group of dependency levels tried),
  * "gs_bigslot" (0 off, 1 cost model, 2 always), "gs_super" (blocks per superblock), "gs_block_inverse".
