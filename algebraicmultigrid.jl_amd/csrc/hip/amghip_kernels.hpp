@@ -1631,23 +1631,36 @@ __global__ void dense_abs_rowsum_kernel(const real* Xf, const real* Xb, int B, i
 // row, threads across the columns (coalesced; a thread owns every 256th entry, so all its loads are independent and in
 // flight together — a wavefront per row walked a 4 096-entry row in 64 dependent round trips), then a fixed
 // shuffle tree and the four wave partials added in order (deterministic).  gridDim.y = right-hand-side columns.
+// NC = right-hand-side columns per workgroup (blocks of right-hand sides: the row of X is read ONCE for NC columns — a
+// workgroup per column re-read the dense inverse NC times; every column's sum is formed exactly as with NC = 1).
+// gridDim.y = column groups.
+template <int NC>
 __global__ __launch_bounds__(kThreads) void tri_gemv_kernel(const real* X, const real* s, real* x, int n, int upper, int64_t lds,
                                                               int64_t ldx) {
-  __shared__ real s_part[kThreads / kWave];
+  __shared__ real s_part[NC][kThreads / kWave];
   const int i = blockIdx.x, tid = threadIdx.x;
-  const real* sv = s + (int64_t)blockIdx.y * lds;
+  const real* sv = s + (int64_t)blockIdx.y * NC * lds;
   const real* row = X + (size_t)i * n;
   const int lo = upper ? i : 0, hi = upper ? n : i + 1;
-  real acc = 0.0;
-  for (int j = lo + tid; j < hi; j += kThreads) acc += row[j] * sv[j];
-  for (int o = kWave / 2; o > 0; o >>= 1) acc += __shfl_down(acc, o, kWave);
-  if (tid % kWave == 0) s_part[tid / kWave] = acc;
-  __syncthreads();
-  if (tid == 0) {
-    real t = s_part[0];
+  real acc[NC];
 #pragma unroll
-    for (int w = 1; w < kThreads / kWave; ++w) t += s_part[w];
-    x[(int64_t)blockIdx.y * ldx + i] = t;
+  for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+  for (int j = lo + tid; j < hi; j += kThreads) {
+    const real r = row[j];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] += r * sv[j + q * lds];
+  }
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    for (int o = kWave / 2; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, kWave);
+    if (tid % kWave == 0) s_part[q][tid / kWave] = acc[q];
+  }
+  __syncthreads();
+  if (tid < NC) {
+    real t = s_part[tid][0];
+#pragma unroll
+    for (int w = 1; w < kThreads / kWave; ++w) t += s_part[tid][w];
+    x[((int64_t)blockIdx.y * NC + tid) * ldx + i] = t;
   }
 }
 

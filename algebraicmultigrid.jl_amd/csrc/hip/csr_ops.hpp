@@ -362,9 +362,12 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       // (a block's rows are few and long: 16 per workgroup, or the pre-pass of a 4 096-row block runs on 64 CUs)
       if (nb > 1) RC_TRY((launch_stream<M_RESID, StreamCfg<256, 16, 4096, 2, false, false>>(ra, st, ncolv)));
       else RC_TRY((launch_stream<M_RESID, StreamCfg<256, 64, 4096, 2, false, false>>(ra, st, ncolv)));
-      hipLaunchKernelGGL(tri_gemv_kernel, dim3((unsigned)rb, ncolv), dim3(kThreads), 0, st,
-                         (const real*)((backward ? g->dti_b : g->dti_f) + g->dti_off[k]), (const real*)(g->blk_s + r0), x + r0, rb,
-                         backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      const real* Xk = (const real*)((backward ? g->dti_b : g->dti_f) + g->dti_off[k]);
+      // columns per workgroup: the largest of 8 / 4 / 2 / 1 that divides the block of right-hand sides
+      if (ncolv % 8 == 0) hipLaunchKernelGGL(tri_gemv_kernel<8>, dim3((unsigned)rb, ncolv / 8), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      else if (ncolv % 4 == 0) hipLaunchKernelGGL(tri_gemv_kernel<4>, dim3((unsigned)rb, ncolv / 4), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      else if (ncolv % 2 == 0) hipLaunchKernelGGL(tri_gemv_kernel<2>, dim3((unsigned)rb, ncolv / 2), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      else hipLaunchKernelGGL(tri_gemv_kernel<1>, dim3((unsigned)rb, ncolv), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
     }
     HIP_TRY(hipGetLastError());
     return AMGH_OK;
