@@ -136,6 +136,45 @@ def test_smoothers_on_amg_coarse_operator_and_zero_diagonal():
         assert rel(x, ref) <= TIGHT and x[7] == x0[7]
 
 
+def test_small_random_operators_through_the_single_wave_walk():
+    """Operators that fit LDS are walked by one wave from their packed record (gs_wave_kernel): random patterns —
+    non-symmetric, rows without a diagonal entry, zero diagonals, rows of up to ~30 entries — against the oracle, and
+    bitwise against the regular chain kernel (gs_tiny = 0), NoSymmetry convention (the operator's own rows)."""
+    lib = AMG.hip_lib()
+    rng = np.random.default_rng(2024)
+    for trial in range(12):
+        n = int(rng.integers(5, 400))
+        dens = float(rng.choice([0.01, 0.03, 0.08])) if n > 60 else 0.3
+        M = sp.random(n, n, density=min(0.9, dens), random_state=int(rng.integers(1 << 30)), format="lil")
+        if trial % 3 != 2:
+            M = (M + M.T).tolil()                       # symmetric pattern two times out of three
+        for i in range(n):
+            M[i, i] = 4.0 + n * dens + rng.random()      # diagonally dominant: the sweeps stay O(1)
+        if trial % 3 != 2:
+            for i in rng.integers(0, n, size=2):
+                M[int(i), int(i)] = 0.0                  # rows that keep their x (smoother.jl:87); NoSymmetry refuses them
+        M = sp.csc_matrix(M); M.eliminate_zeros()
+        A = AMG.SparseMatrixCSC.from_scipy(M)
+        x0, b = uniform(n, 100 + trial) - 0.5, uniform(n, 200 + trial)
+        sym = None if trial % 3 != 2 else AMG.NoSymmetry()
+        for s in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2),
+                  AMG.SOR(1.2, AMG.SymmetricSweep()), AMG.SOR(0.7, AMG.BackwardSweep(), iter=2)):
+            got = {}
+            for tiny in (1, 0):
+                assert lib.amgh_debug_set_tunable(b"gs_tiny", tiny) == 0
+                assert lib.amgh_debug_set_tunable(b"gs_block_inverse", 0) == 0   # (else well-conditioned triangles are inverted densely)
+                try:
+                    x = x0.copy()
+                    AMG.device.smooth_standalone(s, A, x, b, symmetry=sym)
+                    got[tiny] = x
+                finally:
+                    lib.amgh_debug_set_tunable(b"gs_tiny", 1)
+                    lib.amgh_debug_set_tunable(b"gs_block_inverse", 1)
+            assert np.array_equal(got[1], got[0]), (trial, repr(s))
+            ref = O.smooth(s, A, x0, b, hermitian=sym is None)
+            assert rel(got[1], ref) <= TIGHT, (trial, repr(s))
+
+
 def _dense_band_spd(n, half_bw, seed, zero_diag_rows=()):
     """Irregular, densely coupled SPD-like matrix (many dependency levels per row block): the kind of operator the
     block-inverse Gauss-Seidel sweeps are selected for."""
