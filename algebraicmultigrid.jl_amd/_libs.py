@@ -110,6 +110,7 @@ def _bind_solve_phase(L, creal, coarse_fn):
     L.amgh_push_level_end.argtypes = [vp, i64] + [vp] * 6
     L.amgh_push_level_abort.argtypes = [vp]
     L.amgh_level_prepare.argtypes = [C.c_int, i64] + [vp] * 6 + [C.POINTER(amgh_smoother_t), C.POINTER(amgh_smoother_t), C.POINTER(vp)]
+    L.amgh_level_prepare_nrhs.argtypes = [C.c_int, C.c_int, i64] + [vp] * 6 + [C.POINTER(amgh_smoother_t), C.POINTER(amgh_smoother_t), C.POINTER(vp)]
     L.amgh_push_level_prepared.argtypes = [vp, vp]
     L.amgh_level_free.argtypes = [vp]
     L.amgh_level_free.restype = None

@@ -665,7 +665,7 @@ struct amgh_level { Level* L = nullptr; int device = 0; };
 
 static int level_prepare(int device, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
                          const int32_t* S_rowptr, const int32_t* S_col, const real* S_val,
-                         const amgh_smoother_t* pre, const amgh_smoother_t* post, Level** out) {
+                         const amgh_smoother_t* pre, const amgh_smoother_t* post, Level** out, int nrhs_hint = 0) {
   HIP_TRY(hipSetDevice(device));
   (void)hipGetLastError();   // (whatever an earlier, unrelated call left behind is not this level's)
   Level* L = new Level;
@@ -681,7 +681,7 @@ static int level_prepare(int device, int64_t n, const int32_t* A_rowptr, const i
     // schedule built from the host arrays while we still have them
     amgh_csr* M = L->smat();
     GsSchedule* g = new GsSchedule;
-    rc = L->has_S ? gs_build(g, n, n, S_rowptr, S_col, S_val) : gs_build(g, n, n, A_rowptr, A_col, A_val);
+    rc = L->has_S ? gs_build(g, n, n, S_rowptr, S_col, S_val, nrhs_hint) : gs_build(g, n, n, A_rowptr, A_col, A_val, nrhs_hint);
     if (rc == AMGH_OK) { M->gs = g; M->bytes += g->bytes; }
     else { g->free_dev(); delete g; g = nullptr; }   // (nothing below may touch g on this path)
     if (rc == AMGH_OK && g->nblk == 0) {  // SOR: its merged groups depend on the relaxation factor, build them now too
@@ -748,7 +748,7 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
   if (h->finalized || h->pending_level) return AMGH_ESTATE;
   if (!h->levels.empty() && h->levels.back()->nc != n) return AMGH_EINVAL;
   Level* L = nullptr;
-  RC_TRY(level_prepare(h->device, n, A_rowptr, A_col, A_val, S_rowptr, S_col, S_val, pre, post, &L));
+  RC_TRY(level_prepare(h->device, n, A_rowptr, A_col, A_val, S_rowptr, S_col, S_val, pre, post, &L, h->nrhs));
   h->pending_level = L;
   return AMGH_OK;
 }
@@ -758,11 +758,16 @@ int amgh_push_level_begin(amgh_t* h, int64_t n, const int32_t* A_rowptr, const i
 int amgh_level_prepare(int device, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
                        const int32_t* S_rowptr, const int32_t* S_col, const real* S_val,
                        const amgh_smoother_t* pre, const amgh_smoother_t* post, amgh_level_t** out) {
-  if (!out || n <= 0 || !A_rowptr) return AMGH_EINVAL;
+  return amgh_level_prepare_nrhs(device, 0, n, A_rowptr, A_col, A_val, S_rowptr, S_col, S_val, pre, post, out);
+}
+int amgh_level_prepare_nrhs(int device, int nrhs, int64_t n, const int32_t* A_rowptr, const int32_t* A_col, const real* A_val,
+                            const int32_t* S_rowptr, const int32_t* S_col, const real* S_val,
+                            const amgh_smoother_t* pre, const amgh_smoother_t* post, amgh_level_t** out) {
+  if (!out || n <= 0 || !A_rowptr || nrhs < 0) return AMGH_EINVAL;
   *out = nullptr;
   if (!smoother_valid(pre) || !smoother_valid(post)) return AMGH_EINVAL;
   Level* L = nullptr;
-  RC_TRY(level_prepare(device, n, A_rowptr, A_col, A_val, S_rowptr, S_col, S_val, pre, post, &L));
+  RC_TRY(level_prepare(device, n, A_rowptr, A_col, A_val, S_rowptr, S_col, S_val, pre, post, &L, nrhs));
   amgh_level_t* p = new amgh_level_t;
   p->L = L; p->device = device;
   *out = p;
@@ -1016,6 +1021,7 @@ int amgh_gs_num_sweep_steps(const amgh_t* h, int l, int backward) {
   if (!g) return 0;
   if (g->dti_f && g_gs_dense_tri && g_gs_block_inverse) return (int)g->dti_off.size() - 1;   // dense triangular sweep: blocks
   if (g->nblk > 0 && g_gs_block_inverse) return g->nblk;             // block-inverse sweep: sequential block steps
+  if (g->bw.rec) return (int)g->bw.launch_ptr.size() - 1;            // wavefront of blocks: depths of the quotient DAG
   const GsSchedule* c = backward ? g->mb : g->mf;
   return (c && g_gs_merge > 1) ? c->nlev : g->nlev;                  // merged groups, or dependency levels
 }
@@ -1038,6 +1044,15 @@ int amgh_gs_sweep_stats(const amgh_t* h, int l, int backward, int64_t* out6) {
     out6[1] = g->n;
     out6[2] = out6[3] = g->nnz + (int64_t)g->nblk * kBlk * kBlk;
     out6[5] = 0;
+    return AMGH_OK;
+  }
+  if (g->bw.rec) {   // wavefront of blocks: the operator's own entries (padded to the record's row width), no pre-pass
+    out6[0] = (int64_t)g->bw.launch_ptr.size() - 1;
+    out6[1] = g->n;
+    out6[2] = g->nnz - g->n;
+    out6[3] = g->bw.rec_entries;
+    out6[4] = 0;
+    out6[5] = out6[0] > 0 ? (g->nlev + out6[0] - 1) / out6[0] : 0;
     return AMGH_OK;
   }
   const GsSchedule* c = backward ? g->mb : g->mf;
@@ -1572,6 +1587,9 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_sell")) g_gs_sell = value;
   else if (!strcmp(name, "gs_sample")) g_gs_sample = value;
   else if (!strcmp(name, "gs_tiny")) g_gs_tiny = value;
+  else if (!strcmp(name, "gs_bw")) g_gs_bw = value;
+  else if (!strcmp(name, "gs_bw_rows")) g_gs_bw_rows = value;
+  else if (!strcmp(name, "gs_bw_min_rows")) g_gs_bw_min_rows = value;
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;
   else if (!strcmp(name, "jacobi_zero")) g_jacobi_zero = value;
   else if (!strcmp(name, "gs_ept")) g_gs_ept = value;

@@ -3,6 +3,7 @@
 // launch-shape tunables.  Included by amghip.hip only (one translation unit).
 #pragma once
 #include "amghip_kernels.hpp"
+#include "gs_blocks.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -203,6 +204,15 @@ struct GsSchedule {
   real* diag = nullptr;
   bool diag_shared = false;   // (merged Gauss-Seidel child: the parent's array — same rows in the same order)
   bool tiny_ok = false;       // the whole operator fits LDS (gs_chain_tiny_kernel): rows, nonzeros, levels and columns within kTiny*
+  // wavefront of blocks (gs_blocks.hpp): the rows in BLOCK order (perm), one packed record per block, a launch per depth
+  // of the quotient DAG.  When set, it is the only layout of this schedule (no level layout, no merged children).
+  struct Bw {
+    bw::Desc* blocks = nullptr; unsigned char* rec = nullptr; int32_t* ext_col = nullptr;
+    std::vector<int32_t> launch_ptr;
+    size_t lds_max = 0; int maxk = 0;
+    int64_t rec_bytes = 0, rec_entries = 0, sum_depth = 0;
+    double est_seconds = 0.0;
+  } bw;
   // the same operator as one record walked by a single wave (gs_wave_kernel): built when it fits (rows of at most
   // kWaveMaxK off-diagonal entries, at most kWaveMaxSteps steps, the LDS budget)
   unsigned char* ww_rec = nullptr; int ww_S = 0, ww_maxk = 0, ww_steps = 0; size_t ww_lds = 0;
@@ -304,6 +314,7 @@ struct GsSchedule {
     hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
     hipFree(scol); hipFree(sval); hipFree(schunk); scol = nullptr; sval = nullptr; schunk = nullptr;
     hipFree(ww_rec); ww_rec = nullptr;
+    hipFree(bw.blocks); hipFree(bw.rec); hipFree(bw.ext_col); bw = Bw();
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
     hipFree(perm); hipFree(dpos); if (!diag_shared) hipFree(diag);
     hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
@@ -352,6 +363,9 @@ int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR str
 int g_jacobi_zero = 1;          // Jacobi on x = 0 as a vector kernel (0 = the full sweep); read at every sweep
 int g_rhs_il = 1;               // blocks of 2 / 4 / 8 / 16 right-hand sides: restriction and prolongation gather an interleaved copy of their input (0 = column by column); read at every cycle
 int g_gs_tiny = 1;              // an operator that fits LDS entirely: 1 = gs_wave_kernel where its record was built, else gs_chain_tiny_kernel; 2 = gs_chain_tiny_kernel; 0 = gs_chain_kernel; read at every sweep
+int g_gs_bw = 1;                // wavefront of blocks for single-right-hand-side hierarchies (gs_blocks.hpp): 0 off, 1 where the cost model prefers it, 2 always (tests); read at schedule build
+int g_gs_bw_rows = 512;         // ... rows per block aimed at
+int g_gs_bw_min_rows = 1 << 20; // ... operators below this many rows keep the level schedules (mode 1)
 int g_gs_sample = 1;            // candidate group sizes of the merged sweeps from a sample of the groups (0 = every candidate built in full); read at schedule build
 int g_gs_sell = 1;              // merged groups from the SELL-like layout where it was built (0 = slot kernels); build: read at schedule build too
 int g_gs_lean = -1;             // footprint policy: -1 = AMGH_LEAN environment variable (unset: trim), 0 = full (every copy kept), 1 = lean, 2 = trim; read at schedule build

@@ -501,6 +501,11 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
   } else {
     g->s_dir = -1;
   }
+  if (g->bw.rec) {   // wavefront of blocks: one launch per depth of the quotient DAG, one wave walking each block
+    bw::Args<real> ba{g->bw.blocks, g->bw.rec, g->bw.ext_col, rhs, xp, ldb, xs, omega, 0, nullptr};
+    const hipError_t e = bw::sweep<real>(ba, g->bw.maxk, g->bw.launch_ptr, g->bw.lds_max, sor, backward, ncolv, st);
+    if (e != hipSuccess) return -(1000 + (int)e);
+  }
   const int ns = (int)lay->segs.size();
   for (int k = 0; k < ns; ++k) {
     const GsSchedule::Seg& s = lay->segs[backward ? ns - 1 - k : k];

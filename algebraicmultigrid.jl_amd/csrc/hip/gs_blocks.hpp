@@ -1,4 +1,6 @@
 // gs_blocks.hpp — exact lexicographic Gauss-Seidel as a WAVEFRONT OF BLOCKS (no substitution, no recomputation).
+// Included by gs_schedule.hpp (the schedule of single-right-hand-side hierarchies on stencil-like fine levels) and by
+// tools/block_wave_bench.hip (the stand-alone measurement, profiles/r03_block_wave.log).
 //
 // smoother.jl:61-90 sweeps the rows in index order; any order that respects the dependency DAG (row i after every
 // adjacent row c < i, before every adjacent row c > i) gives the same iterate.  The level schedules of gs_schedule.hpp
@@ -18,11 +20,9 @@
 // along the dependency level (one more monotone potential), a single oversized level into chunks of independent rows.
 // The construction is always valid; whether it is USED is a cost-model decision (launches, depth, bytes).
 #pragma once
-#ifndef BW_OPT
-#define BW_OPT 0   // 1: division by the diagonal as reciprocal + one exact correction; 2: x gather issued before the next step's operand loads; 4: next launch's records prefetched
-#endif
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -35,27 +35,13 @@ namespace bw {
 struct Desc {          // one block (32 bytes)
   int32_t row0, nrows; // rows of the block in block order (sorted by in-block dependency level)
   int32_t rec;         // the block's record in the record buffer, in units of 16 bytes
-  int32_t S;           // row stride of the record's ELL arrays (nrows rounded up to a multiple of 8)
+  int32_t S;           // (unused: rows of a packed record are Packed<R>::row_bytes(maxk) apart)
   int32_t ext0, next;  // external columns: positions of x gathered into LDS behind the block's own x
   int32_t nlev, maxk;  // STEPS of the block: pieces of <= 64 rows of one in-block dependency level, in order; off-diagonal entries per row (padded, a multiple of kChunk)
 };
 constexpr int kChunk = 6;       // entries summed per batch of LDS reads
-#ifndef BW_THREADS
-#define BW_THREADS 512
-#endif
-constexpr int kThreads = BW_THREADS;   // loading workgroup (the sweep itself is wave 0)
+constexpr int kThreads = 512;   // loading workgroup (the sweep itself is wave 0)
 constexpr int kMaxSteps = 124;  // steps per block (their row pointers live in two registers of wave 0)
-
-// record of a block: vals[maxk][S] | diag[S] | cols[maxk][S] (uint16, local index into the LDS x) | step_ptr[nlev + 1] (uint16: first row of every step)
-template <typename R>
-inline size_t rec_bytes(int S, int maxk, int nlev) {
-  const size_t b = (size_t)maxk * S * sizeof(R) + (size_t)S * sizeof(R) + (size_t)maxk * S * 2 + (size_t)(nlev + 1) * 2;
-  return (b + 15) & ~(size_t)15;
-}
-template <typename R>
-inline size_t lds_bytes(const Desc& d) {
-  return rec_bytes<R>(d.S, d.maxk, d.nlev) + 2 * (size_t)d.S * sizeof(R) + (size_t)(d.nrows + d.next + 1) * sizeof(R) + 16;
-}
 
 // PACKED rows (the format of gs_bw_packed_kernel): a row is one run of 16-byte chunks
 //     [ v0 v1 | v2 v3 | ... | (.. dg rc) | c0 .. c7 | c8 .. ]      values, diagonal, its reciprocal, then the columns as uint16
@@ -95,7 +81,6 @@ struct Plan {
   int cuts[2] = {99, 99};
   int32_t range[3] = {1, 1, 1};
   int32_t cells[3] = {1, 1, 1};
-  bool packed = false;
 };
 
 template <class F>
@@ -112,7 +97,6 @@ struct Params {
   int max_rows = 1024;       // hard cap (uint16 local indices, LDS)
   size_t lds_limit = 150 * 1024;
   int threads = 8;
-  bool packed = false;       // records in the packed-row format (gs_bw_packed_kernel)
 };
 
 // Returns false when the operator cannot be laid out (rows too long for the LDS budget, local index overflow).
@@ -133,6 +117,8 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     }
     maxlen = std::max(maxlen, off);   // off-diagonal entries of the longest row
   }
+  const int maxk = ((std::max(1, maxlen) + kChunk - 1) / kChunk) * kChunk;
+  if (maxk > 12) return false;   // (kMaxK: the kernels' register sets; longer rows make the walk instruction-bound, profiles/r03_block_wave.log)
   {
     std::vector<int> occ;
     for (int b = 0; b < 32; ++b) if (hist[b]) occ.push_back(b);
@@ -168,9 +154,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   for (int k = 0; k < 3; ++k) P.range[k] = *std::max_element(phi[k].begin(), phi[k].end()) + 1;
   P.nlevels = *std::max_element(lev.begin(), lev.end()) + 1;
   // ---- rows per block from the LDS budget ----
-  const int maxk = ((std::max(1, maxlen) + kChunk - 1) / kChunk) * kChunk;
-  if (maxk > 24) return false;   // (kMaxK: the kernels' register sets)
-  const size_t per_row = (size_t)maxk * (sizeof(R) + 2) + 3 * sizeof(R) + 2 * sizeof(R);   // record + b + x + ~2 external values
+  const size_t per_row = Packed<R>::row_bytes(maxk) + 2 * sizeof(R) + 2 * sizeof(R);   // packed row + b + x + ~2 external values
   int cap = (int)std::min<size_t>(prm.max_rows, prm.lds_limit / per_row);
   cap = (cap / 64) * 64;
   if (cap < 64) return false;
@@ -349,11 +333,11 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     ext_ptr[ob + 1] = ext_ptr[ob] + d.next;
     if (rec_total / 16 > (size_t)INT32_MAX) fits = false;
     d.rec = (int32_t)(rec_total / 16);
-    rec_total += prm.packed ? Packed<R>::rec_bytes(d.nrows, d.maxk, d.nlev) : rec_bytes<R>(d.S, d.maxk, d.nlev);
-    const size_t l = prm.packed ? Packed<R>::lds_bytes(d) : lds_bytes<R>(d);
+    rec_total += Packed<R>::rec_bytes(d.nrows, d.maxk, d.nlev);
+    const size_t l = Packed<R>::lds_bytes(d);
     P.lds_max = std::max(P.lds_max, l);
     if (d.nrows + d.next + 1 > 65535 || d.nlev > 65534 || l > 160 * 1024) fits = false;
-    if (prm.packed && (size_t)(d.nrows + d.next + 1) * sizeof(R) > 65535) fits = false;   // byte offsets in 16 bits
+    if ((size_t)(d.nrows + d.next + 1) * sizeof(R) > 65535) fits = false;   // byte offsets in 16 bits
     P.max_rows = std::max(P.max_rows, d.nrows);
   }
   if (!fits || ext_ptr[B] > INT32_MAX) return false;
@@ -362,83 +346,46 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   P.ext_total = ext_ptr[B];
   P.ext_col.resize(ext_ptr[B]);
   P.rec.assign(rec_total, 0);
-  P.packed = prm.packed;
   parallel_for(T, [&](int t, int TT) {
     for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
       const Desc& d = P.blocks[ob];
       const std::vector<int32_t>& ex = exts[ob];
       std::copy(ex.begin(), ex.end(), P.ext_col.begin() + d.ext0);
       unsigned char* rec = P.rec.data() + (size_t)d.rec * 16;
-      if (prm.packed) {
-        const size_t rs = Packed<R>::row_bytes(d.maxk);
-        const int nvc = Packed<R>::nvc(d.maxk);
-        const uint16_t zoff = (uint16_t)((size_t)(d.nrows + d.next) * sizeof(R));   // the LDS slot that holds 0
-        uint16_t* stp = (uint16_t*)(rec + (size_t)d.nrows * rs);
-        int32_t nl = 0, run = 0, last = -1;
-        for (int32_t p = 0; p < d.nrows; ++p) {
-          const int32_t i = P.perm[d.row0 + p];
-          const int32_t l = ilev[i];
-          if (l != last || run == 64) { stp[nl++] = (uint16_t)p; run = 0; last = l; }
-          ++run;
-          R* v = (R*)(rec + (size_t)p * rs);
-          uint16_t* cc = (uint16_t*)(rec + (size_t)p * rs + (size_t)16 * nvc);
-          for (int k = 0; k < 8 * Packed<R>::ncc(d.maxk); ++k) cc[k] = zoff;
-          int k = 0;
-          R dg = 0;
-          for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-            const int32_t c = col[j];
-            if (c == i) { dg = val[j]; continue; }
-            if (c >= n) continue;
-            const int32_t q = inv[c];
-            size_t lc;
-            if (q >= d.row0 && q < d.row0 + d.nrows) lc = (size_t)(q - d.row0);
-            else lc = (size_t)d.nrows + (size_t)(std::lower_bound(ex.begin(), ex.end(), q) - ex.begin());
-            v[k] = val[j];
-            cc[k] = (uint16_t)(lc * sizeof(R));
-            ++k;
-          }
-          v[d.maxk] = dg;
-          // reciprocal for the division-free quotient; 0 = "divide" (diagonals whose reciprocal or products may leave the normal range)
-          const double ad = std::fabs((double)dg);
-          const bool safe = sizeof(R) == 8 ? (ad > 1e-100 && ad < 1e100) : (ad > 1e-12 && ad < 1e12);
-          v[d.maxk + 1] = safe ? (R)1 / dg : (R)0;
-        }
-        stp[nl] = (uint16_t)d.nrows;
-        continue;
-      }
-      R* vals = (R*)rec;
-      R* diag = vals + (size_t)d.maxk * d.S;
-      uint16_t* cols = (uint16_t*)(diag + d.S);
-      uint16_t* lvlp = cols + (size_t)d.maxk * d.S;
-      const uint16_t zslot = (uint16_t)(d.nrows + d.next);   // LDS slot that holds 0: padding entries are 0 * 0
-      for (size_t e = 0; e < (size_t)d.maxk * d.S; ++e) cols[e] = zslot;
-      {
-        int32_t nl = 0, run = 0, last = -1;
-        for (int32_t p = 0; p < d.nrows; ++p) {
-          const int32_t l = ilev[P.perm[d.row0 + p]];
-          if (l != last || run == 64) { lvlp[nl++] = (uint16_t)p; run = 0; last = l; }
-          ++run;
-        }
-        lvlp[nl] = (uint16_t)d.nrows;
-      }
+      const size_t rs = Packed<R>::row_bytes(d.maxk);
+      const int nvc = Packed<R>::nvc(d.maxk);
+      const uint16_t zoff = (uint16_t)((size_t)(d.nrows + d.next) * sizeof(R));   // the LDS slot that holds 0
+      uint16_t* stp = (uint16_t*)(rec + (size_t)d.nrows * rs);
+      int32_t nl = 0, run = 0, last = -1;
       for (int32_t p = 0; p < d.nrows; ++p) {
         const int32_t i = P.perm[d.row0 + p];
+        const int32_t l = ilev[i];
+        if (l != last || run == 64) { stp[nl++] = (uint16_t)p; run = 0; last = l; }
+        ++run;
+        R* v = (R*)(rec + (size_t)p * rs);
+        uint16_t* cc = (uint16_t*)(rec + (size_t)p * rs + (size_t)16 * nvc);
+        for (int k = 0; k < 8 * Packed<R>::ncc(d.maxk); ++k) cc[k] = zoff;
         int k = 0;
         R dg = 0;
-        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {   // entries stay in the row's stored order (the order of the sum)
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
           const int32_t c = col[j];
           if (c == i) { dg = val[j]; continue; }
           if (c >= n) continue;
           const int32_t q = inv[c];
-          uint16_t lc;
-          if (q >= d.row0 && q < d.row0 + d.nrows) lc = (uint16_t)(q - d.row0);
-          else lc = (uint16_t)(d.nrows + (std::lower_bound(ex.begin(), ex.end(), q) - ex.begin()));
-          vals[(size_t)k * d.S + p] = val[j];
-          cols[(size_t)k * d.S + p] = lc;
+          size_t lc;
+          if (q >= d.row0 && q < d.row0 + d.nrows) lc = (size_t)(q - d.row0);
+          else lc = (size_t)d.nrows + (size_t)(std::lower_bound(ex.begin(), ex.end(), q) - ex.begin());
+          v[k] = val[j];
+          cc[k] = (uint16_t)(lc * sizeof(R));
           ++k;
         }
-        diag[p] = dg;
+        v[d.maxk] = dg;
+        // reciprocal for the division-free quotient; 0 = "divide" (diagonals whose reciprocal or products may leave the normal range)
+        const double ad = std::fabs((double)dg);
+        const bool safe = sizeof(R) == 8 ? (ad > 1e-100 && ad < 1e100) : (ad > 1e-12 && ad < 1e12);
+        v[d.maxk + 1] = safe ? (R)1 / dg : (R)0;
       }
+      stp[nl] = (uint16_t)d.nrows;
     }
   });
   // ---- modelled time of one sweep: per launch a boundary + the latency chain of a block + its bytes + its deepest block ----
@@ -450,11 +397,13 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
       for (int32_t ob = P.launch_ptr[l]; ob < P.launch_ptr[l + 1]; ++ob) {
         const Desc& d = P.blocks[ob];
         depth = std::max(depth, d.nlev);
-        bytes += (double)(prm.packed ? Packed<R>::rec_bytes(d.nrows, d.maxk, d.nlev) : rec_bytes<R>(d.S, d.maxk, d.nlev)) + d.nrows * 3.0 * sizeof(R) + d.next * (4.0 + sizeof(R)) * 2;
+        bytes += (double)Packed<R>::rec_bytes(d.nrows, d.maxk, d.nlev) + d.nrows * 3.0 * sizeof(R) + d.next * (4.0 + sizeof(R)) * 2;
       }
       P.sum_depth += depth;
-      const double step = 0.10e-6 + 0.012e-6 * maxk;   // two LDS round trips + maxk dependent additions + the division
-      tsec += 1.7e-6 + 3.5e-6 + bytes / 4.0e12 + depth * step;
+      // measured on MI355X (profiles/r03_block_wave.log): boundary 1.6 us, write-back 0.4, a block's own load chain 1.4 (or the launch's
+      // bytes at ~4.5 TB/s), 0.21 + 0.0095 maxk us per step of the walk (a single wave: ~3 ns per instruction)
+      const double step = 0.21e-6 + 0.0095e-6 * maxk;
+      tsec += 1.6e-6 + 0.4e-6 + std::max(1.4e-6, bytes / 4.5e12 + 0.8e-6) + depth * step;
     }
     P.est_seconds = tsec;
   }
@@ -467,250 +416,7 @@ struct Args {
   const Desc* blocks; const unsigned char* rec; const int32_t* ext_col;
   const R* b; R* x; int64_t ldb, ldx; R omega; int32_t block0;
   long long* tim;   // measurement hook (tools/block_wave_bench): 4 wall-clock stamps per block, or null
-  const unsigned char* pre; int64_t pre_bytes;   // the NEXT launch's records (read-only): touched by the idle waves while wave 0 sweeps
 };
-
-// One workgroup per block (blockIdx.y: right-hand-side column).  All waves copy the block's record, b, x and the
-// external x entries into LDS; wave 0 then walks the block's dependency levels alone (no barrier: one wave's LDS
-// operations are ordered) and writes the block's x back.
-//
-// The walk is a chain of dependent LDS round trips, so everything that does not depend on x is taken off it: the level
-// pointers sit in a register (lane l holds lvlp[l], read with v_readlane), and the operands of the NEXT step (a row's
-// columns, values, diagonal and b: read-only) are requested before the current step's x values are read — two register
-// sets, the step loop unrolled by two.  Left on the chain per step: one LDS round trip for x, MAXK dependent
-// additions, the division, the LDS write.
-template <typename R, int MAXK>
-struct RowOps { int c[MAXK]; R v[MAXK]; R dg, bb, rc; int p; };
-
-template <typename R, int MAXK>
-__device__ __forceinline__ void bw_load(RowOps<R, MAXK>& o, int p, bool act, const R* vals, const R* diag, const uint16_t* cols, const R* bl,
-                                        const R* rl, int S, int zslot) {
-  o.p = act ? p : -1;
-  const int q = act ? p : 0;
-#pragma unroll
-  for (int k = 0; k < MAXK; ++k) { const int c = (int)cols[k * S + q]; o.c[k] = act ? c : zslot; o.v[k] = vals[k * S + q]; }
-  o.dg = diag[q]; o.bb = bl[q];
-  o.rc = (BW_OPT & 1) ? rl[q] : (R)0;
-}
-template <typename R, int MAXK>
-__device__ __forceinline__ void bw_gather(const RowOps<R, MAXK>& o, const R* xl, R (&xv)[MAXK]) {
-#pragma unroll
-  for (int k = 0; k < MAXK; ++k) xv[k] = xl[o.c[k]];
-}
-template <typename R, int MAXK, bool SOR>
-__device__ __forceinline__ void bw_finish(const RowOps<R, MAXK>& o, const R (&xv)[MAXK], R* xl, R omega) {
-  R acc = (R)0;
-#pragma unroll
-  for (int k = 0; k < MAXK; ++k) acc += o.v[k] * xv[k];
-  if (o.p >= 0 && o.dg != (R)0) {
-    if (SOR) { xl[o.p] = ((R)1 - omega) * xl[o.p] + (omega / o.dg) * (o.bb - acc); return; }
-    const R nn = o.bb - acc;
-    R q;
-    if (BW_OPT & 1) {
-      // nn / dg from rc = RN(1 / dg): q0 = RN(nn rc), the exact remainder nn - dg q0 (one fma), q = RN(q0 + rem rc) is
-      // the correctly rounded quotient (Markstein) when nothing leaves the normal range; rc == 0 marks rows whose
-      // diagonal (or quotient) might: they divide
-      q = nn * o.rc;
-      const R rem = __builtin_fma(-o.dg, q, nn);
-      q = __builtin_fma(rem, o.rc, q);
-      const R an = __builtin_fabs(nn);
-      if (!(o.rc != (R)0 && an > (R)1e-200 && an < (R)1e200)) q = nn / o.dg;
-    } else {
-      q = nn / o.dg;
-    }
-    xl[o.p] = q;
-  }
-}
-
-template <typename R, bool SOR, bool BWD, int MAXK>
-__global__ __launch_bounds__(kThreads) void gs_bw_kernel(Args<R> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const long long t_start = a.tim ? wall_clock64() : 0;
-  const Desc d = a.blocks[a.block0 + blockIdx.x];
-  const int tid = threadIdx.x;
-  const R* __restrict__ b = a.b + (int64_t)blockIdx.y * a.ldb;
-  R* __restrict__ x = a.x + (int64_t)blockIdx.y * a.ldx;
-  const int recb = (int)(((size_t)MAXK * d.S * sizeof(R) + (size_t)d.S * sizeof(R) + (size_t)MAXK * d.S * 2 + (size_t)(d.nlev + 1) * 2 + 15) & ~(size_t)15);
-  {
-    const uint4* src = (const uint4*)(a.rec + (size_t)(uint32_t)d.rec * 16);
-    uint4* dst = (uint4*)lds;
-    const int n16 = recb >> 4;
-    for (int e = tid; e < n16; e += kThreads) dst[e] = src[e];
-  }
-  R* bl = (R*)(lds + recb);
-  R* rl = bl + d.S;
-  R* xl = rl + ((BW_OPT & 1) ? d.S : 0);
-  for (int p = tid; p < d.nrows; p += kThreads) { bl[p] = b[d.row0 + p]; xl[p] = x[d.row0 + p]; }
-  for (int e = tid; e < d.next; e += kThreads) xl[d.nrows + e] = x[a.ext_col[d.ext0 + e]];
-  const int zslot = d.nrows + d.next;
-  if (tid == 0) xl[zslot] = (R)0;
-  __syncthreads();
-  if (BW_OPT & 1) {   // reciprocal diagonals (one true division per row, off the sweep's chain); 0 = "divide"
-    const R* dgl = (const R*)lds + (size_t)MAXK * d.S;
-    for (int p = tid; p < d.nrows; p += kThreads) {
-      const R dg = dgl[p], ad = __builtin_fabs(dg);
-      rl[p] = (ad > (R)1e-100 && ad < (R)1e100) ? (R)1 / dg : (R)0;
-    }
-    __syncthreads();
-  }
-  if (tid >= 64) {
-    if ((BW_OPT & 4) && a.pre_bytes > 0) {   // one dword per 128-byte line of the next launch's records
-      const int64_t nth = (int64_t)gridDim.x * (kThreads - 64);
-      for (int64_t off = ((int64_t)blockIdx.x * (kThreads - 64) + (tid - 64)) * 128; off < a.pre_bytes; off += nth * 128) {
-        unsigned tmp;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(a.pre + off) : "memory");
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    return;
-  }
-  const long long t_loaded = a.tim ? wall_clock64() : 0;
-  const R* vals = (const R*)lds;
-  const R* diag = vals + (size_t)MAXK * d.S;
-  const uint16_t* cols = (const uint16_t*)(diag + d.S);
-  const uint16_t* stp = cols + (size_t)MAXK * d.S;
-  // step s covers rows [sp(s), sp(s + 1)); lane l keeps step_ptr[l] and step_ptr[l + 64] (v_readlane: no LDS round trip
-  // on the chain); pointers past the last step read as nrows (an empty step)
-  const int lp0 = tid <= d.nlev ? (int)stp[tid] : d.nrows;
-  const int lp1 = tid + 64 <= d.nlev ? (int)stp[tid + 64] : d.nrows;
-  const int ns = d.nlev;
-#define BW_SP(i, out)                                                          \
-  {                                                                            \
-    const int i_ = (i);                                                        \
-    const int u0_ = __builtin_amdgcn_readlane(lp0, i_ & 63);                   \
-    const int u1_ = __builtin_amdgcn_readlane(lp1, i_ & 63);                   \
-    out = i_ < 64 ? u0_ : u1_;                                                 \
-  }
-  // sweep order: forward steps 0 .. ns-1, backward ns-1 .. 0 (step k of the sweep = step ns-1-k of the block)
-#define BW_RANGE(k, r0, r1)                                                    \
-  {                                                                            \
-    const int k_ = (k);                                                        \
-    const int st_ = BWD ? ns - 1 - k_ : k_;                                    \
-    const bool in_ = k_ < ns;                                                  \
-    int q0_, q1_;                                                              \
-    BW_SP(in_ ? st_ : 0, q0_);                                                 \
-    BW_SP(in_ ? st_ + 1 : 0, q1_);                                             \
-    r0 = q0_; r1 = in_ ? q1_ : q0_;                                            \
-  }
-  RowOps<R, MAXK> A, B;
-  R xv[MAXK];
-  int r0, r1;
-  BW_RANGE(0, r0, r1);
-  bw_load<R, MAXK>(A, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, rl, d.S, zslot);
-  for (int k = 0; k < ns; k += 2) {
-    bw_gather<R, MAXK>(A, xl, xv);
-    if (BW_OPT & 2) asm volatile("" ::: "memory");
-    BW_RANGE(k + 1, r0, r1);
-    bw_load<R, MAXK>(B, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, rl, d.S, zslot);
-    bw_finish<R, MAXK, SOR>(A, xv, xl, a.omega);
-    bw_gather<R, MAXK>(B, xl, xv);
-    if (BW_OPT & 2) asm volatile("" ::: "memory");
-    BW_RANGE(k + 2, r0, r1);
-    bw_load<R, MAXK>(A, r0 + tid, r0 + tid < r1, vals, diag, cols, bl, rl, d.S, zslot);
-    bw_finish<R, MAXK, SOR>(B, xv, xl, a.omega);
-  }
-#undef BW_RANGE
-#undef BW_SP
-  const long long t_swept = a.tim ? wall_clock64() : 0;
-  for (int p = tid; p < d.nrows; p += 64) x[d.row0 + p] = xl[p];
-  if (a.tim && tid == 0) {
-    long long* t = a.tim + 4 * (int64_t)(a.block0 + blockIdx.x);
-    t[0] = t_start; t[1] = t_loaded; t[2] = t_swept; t[3] = wall_clock64();
-  }
-}
-
-// The same sweep with the operands of ALL the block's rows in wave 0's registers (blocks of at most 64 * RPT rows of at
-// most MAXK off-diagonal entries: the 7-point fine level): local row p = lane + 64 u sits in register slot u of its lane,
-// loaded from the LDS copy of the record once.  Rows are sorted by level, so slot u covers a contiguous range of levels;
-// slots are walked in order, the levels of a slot in order.  A step is then the x gather, MAXK multiply-adds in entry
-// order, the division and the LDS write — about a third of the instructions of the generic kernel's step, which is
-// what bounds a single wave (one wave64 instruction issues every 4+ cycles).
-template <typename R, bool SOR, bool BWD, int MAXK, int RPT>
-__global__ __launch_bounds__(kThreads) void gs_bw_reg_kernel(Args<R> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const long long t_start = a.tim ? wall_clock64() : 0;
-  const Desc d = a.blocks[a.block0 + blockIdx.x];
-  const int tid = threadIdx.x;
-  const R* __restrict__ b = a.b + (int64_t)blockIdx.y * a.ldb;
-  R* __restrict__ x = a.x + (int64_t)blockIdx.y * a.ldx;
-  const int recb = (int)(((size_t)MAXK * d.S * sizeof(R) + (size_t)d.S * sizeof(R) + (size_t)MAXK * d.S * 2 + (size_t)(d.nlev + 1) * 2 + 15) & ~(size_t)15);
-  {
-    const uint4* src = (const uint4*)(a.rec + (size_t)(uint32_t)d.rec * 16);
-    uint4* dst = (uint4*)lds;
-    const int n16 = recb >> 4;
-    for (int e = tid; e < n16; e += kThreads) dst[e] = src[e];
-  }
-  R* bl = (R*)(lds + recb);
-  R* rl = bl + d.S;
-  R* xl = rl + ((BW_OPT & 1) ? d.S : 0);
-  for (int p = tid; p < d.nrows; p += kThreads) { bl[p] = b[d.row0 + p]; xl[p] = x[d.row0 + p]; }
-  for (int e = tid; e < d.next; e += kThreads) xl[d.nrows + e] = x[a.ext_col[d.ext0 + e]];
-  const int zslot = d.nrows + d.next;
-  if (tid == 0) xl[zslot] = (R)0;
-  __syncthreads();
-  if (tid >= 64) {
-    if ((BW_OPT & 4) && a.pre_bytes > 0) {
-      const int64_t nth = (int64_t)gridDim.x * (kThreads - 64);
-      for (int64_t off = ((int64_t)blockIdx.x * (kThreads - 64) + (tid - 64)) * 128; off < a.pre_bytes; off += nth * 128) {
-        unsigned tmp;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(a.pre + off) : "memory");
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    return;
-  }
-  const long long t_loaded = a.tim ? wall_clock64() : 0;
-  const R* vals = (const R*)lds;
-  const R* diag = vals + (size_t)MAXK * d.S;
-  const uint16_t* cols = (const uint16_t*)(diag + d.S);
-  const uint16_t* stp = cols + (size_t)MAXK * d.S;
-  // operands of my rows; which step each of them belongs to (steps = pieces of <= 64 consecutive rows: step_ptr)
-  R v[RPT][MAXK], dg[RPT], bb[RPT];
-  int c[RPT][MAXK];   // byte offsets into xl
-#pragma unroll
-  for (int u = 0; u < RPT; ++u) {
-    const int p = tid + 64 * u;
-    const bool act = p < d.nrows;
-    const int q = act ? p : 0;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) { const int cc = (int)cols[k * d.S + q]; c[u][k] = (act ? cc : zslot) * (int)sizeof(R); v[u][k] = vals[k * d.S + q]; }
-    dg[u] = act ? diag[q] : (R)0;   // (a zero diagonal keeps its x: inactive slots never write)
-    bb[u] = bl[q];
-  }
-  // steps in order; step s covers rows [stp[s], stp[s + 1]): slot u = row / 64 changes inside a step at most once
-  const int lp0 = tid <= d.nlev ? (int)stp[tid] : d.nrows;
-  const int lp1 = tid + 64 <= d.nlev ? (int)stp[tid + 64] : d.nrows;
-  const int ns = d.nlev;
-  char* xb = (char*)xl;
-  for (int k = 0; k < ns; ++k) {
-    const int st = BWD ? ns - 1 - k : k;
-    const int a0 = __builtin_amdgcn_readlane(lp0, st & 63), a1 = __builtin_amdgcn_readlane(lp1, st & 63);
-    const int b0 = __builtin_amdgcn_readlane(lp0, (st + 1) & 63), b1 = __builtin_amdgcn_readlane(lp1, (st + 1) & 63);
-    const int r0 = st < 64 ? a0 : a1, r1 = st + 1 < 64 ? b0 : b1;
-    // rows r0 .. r1-1 (at most 64) live in slots u0 = r0 / 64 and possibly u0 + 1: lane l holds row 64 u + l
-    const int u0 = r0 >> 6, u1 = (r1 - 1) >> 6;
-#pragma unroll
-    for (int u = 0; u < RPT; ++u) {
-      if (u != u0 && u != u1) continue;            // wave-uniform
-      const int p = tid + 64 * u;
-      if (p >= r0 && p < r1 && dg[u] != (R)0) {
-        R xv[MAXK];
-#pragma unroll
-        for (int j = 0; j < MAXK; ++j) xv[j] = *(const R*)(xb + c[u][j]);
-        R acc = (R)0;
-#pragma unroll
-        for (int j = 0; j < MAXK; ++j) acc += v[u][j] * xv[j];
-        xl[p] = SOR ? ((R)1 - a.omega) * xl[p] + (a.omega / dg[u]) * (bb[u] - acc) : (bb[u] - acc) / dg[u];
-      }
-    }
-  }
-  const long long t_swept = a.tim ? wall_clock64() : 0;
-  for (int p = tid; p < d.nrows; p += 64) x[d.row0 + p] = xl[p];
-  if (a.tim && tid == 0) {
-    long long* t = a.tim + 4 * (int64_t)(a.block0 + blockIdx.x);
-    t[0] = t_start; t[1] = t_loaded; t[2] = t_swept; t[3] = wall_clock64();
-  }
-}
 
 // ---- the walk on PACKED rows ----------------------------------------------------------------------------------------
 template <typename R> struct Vec16;
@@ -790,17 +496,7 @@ __global__ __launch_bounds__(kThreads) void gs_bw_packed_kernel(Args<R> a) {
   for (int e = tid; e < d.next; e += kThreads) xl[d.nrows + e] = x[a.ext_col[d.ext0 + e]];
   if (tid == 0) xl[d.nrows + d.next] = (R)0;
   __syncthreads();
-  if (tid >= 64) {
-    if ((BW_OPT & 4) && a.pre_bytes > 0) {
-      const int64_t nth = (int64_t)gridDim.x * (kThreads - 64);
-      for (int64_t off = ((int64_t)blockIdx.x * (kThreads - 64) + (tid - 64)) * 128; off < a.pre_bytes; off += nth * 128) {
-        unsigned tmp;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(a.pre + off) : "memory");
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    return;
-  }
+  if (tid >= 64) return;
   const long long t_loaded = a.tim ? wall_clock64() : 0;
   const uint16_t* stp = (const uint16_t*)(rec + (size_t)d.nrows * (16 * KCH));
   const int lp0 = tid <= ns ? (int)stp[tid] : d.nrows;
@@ -845,66 +541,37 @@ __global__ __launch_bounds__(kThreads) void gs_bw_packed_kernel(Args<R> a) {
 }
 
 // launches of one directional sweep: blocks of launch l = [launch_ptr[l], launch_ptr[l + 1])
-// launch_rec[l] = byte offset of launch l's first record in the record buffer (launch_rec[nl] = its size)
-constexpr int kRegRpt = 8;   // register-resident kernel: blocks of at most 64 * kRegRpt rows of at most 6 entries
 template <typename R, int MAXK>
-inline hipError_t sweep_k(const Args<R>& a0, const std::vector<int32_t>& launch_ptr, const std::vector<int64_t>& launch_rec, size_t lds_max,
-                          bool sor, bool backward, int ncols, hipStream_t st, int reg = 0) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (MAXK == 6) {
-      (void)hipFuncSetAttribute((const void*)gs_bw_reg_kernel<R, false, false, 6, kRegRpt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)gs_bw_reg_kernel<R, false, true, 6, kRegRpt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)gs_bw_reg_kernel<R, true, false, 6, kRegRpt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)gs_bw_reg_kernel<R, true, true, 6, kRegRpt>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    (void)hipFuncSetAttribute((const void*)gs_bw_kernel<R, false, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gs_bw_kernel<R, false, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gs_bw_kernel<R, true, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gs_bw_kernel<R, true, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+inline hipError_t sweep_k(const Args<R>& a0, const std::vector<int32_t>& launch_ptr, size_t lds_max, bool sor, bool backward, int ncols,
+                          hipStream_t st) {
+  // more than the default 64 KB of dynamic LDS needs the attribute: once per kernel and device
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  if (lds_max > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && !((attr_set.load() >> (dev & 63)) & 1)) {
+    (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, false, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, false, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, true, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, true, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set.fetch_or((uint64_t)1 << (dev & 63));
   }
   const int nl = (int)launch_ptr.size() - 1;
   Args<R> a = a0;
   for (int s = 0; s < nl; ++s) {
     const int l = backward ? nl - 1 - s : s;
     a.block0 = launch_ptr[l];
-    const int ln = backward ? l - 1 : l + 1;   // the launch that follows in this sweep
-    a.pre = nullptr; a.pre_bytes = 0;
-    if (ln >= 0 && ln < nl && !launch_rec.empty()) { a.pre = a0.rec + launch_rec[ln]; a.pre_bytes = launch_rec[ln + 1] - launch_rec[ln]; }
     const dim3 grid((unsigned)(launch_ptr[l + 1] - launch_ptr[l]), (unsigned)ncols);
-    if (reg == 2) {
-      static bool attr2 = false;
-      if (!attr2) {
-        (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, false, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, false, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, true, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)gs_bw_packed_kernel<R, true, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr2 = true;
-      }
-      if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_packed_kernel<R, true, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_packed_kernel<R, true, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
-      else { if (backward) hipLaunchKernelGGL((gs_bw_packed_kernel<R, false, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_packed_kernel<R, false, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
-      continue;
-    }
-    if (MAXK == 6 && reg == 1) {
-      if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_reg_kernel<R, true, true, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_reg_kernel<R, true, false, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); }
-      else { if (backward) hipLaunchKernelGGL((gs_bw_reg_kernel<R, false, true, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_reg_kernel<R, false, false, 6, kRegRpt>), grid, dim3(kThreads), lds_max, st, a); }
-      continue;
-    }
-    if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_kernel<R, true, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_kernel<R, true, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
-    else { if (backward) hipLaunchKernelGGL((gs_bw_kernel<R, false, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_kernel<R, false, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
+    if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_packed_kernel<R, true, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_packed_kernel<R, true, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
+    else { if (backward) hipLaunchKernelGGL((gs_bw_packed_kernel<R, false, true, MAXK>), grid, dim3(kThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_packed_kernel<R, false, false, MAXK>), grid, dim3(kThreads), lds_max, st, a); }
   }
   return hipGetLastError();
 }
-constexpr int kMaxK = 24;   // longest rows (off-diagonal entries, padded to a multiple of kChunk) the kernels are instantiated for
+constexpr int kMaxK = 12;   // longest rows (off-diagonal entries, padded to a multiple of kChunk) the kernels are instantiated for
 template <typename R>
-inline hipError_t sweep(const Args<R>& a, int maxk, const std::vector<int32_t>& launch_ptr, const std::vector<int64_t>& launch_rec,
-                        size_t lds_max, bool sor, bool backward, int ncols, hipStream_t st, int reg = 0) {
+inline hipError_t sweep(const Args<R>& a, int maxk, const std::vector<int32_t>& launch_ptr, size_t lds_max, bool sor, bool backward, int ncols,
+                        hipStream_t st) {
   switch (maxk) {
-    case 6: return sweep_k<R, 6>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st, reg);
-    case 12: return sweep_k<R, 12>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st, reg == 2 ? 2 : 0);
-    case 18: return sweep_k<R, 18>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st, reg == 2 ? 2 : 0);
-    case 24: return sweep_k<R, 24>(a, launch_ptr, launch_rec, lds_max, sor, backward, ncols, st, reg == 2 ? 2 : 0);
+    case 6: return sweep_k<R, 6>(a, launch_ptr, lds_max, sor, backward, ncols, st);
+    case 12: return sweep_k<R, 12>(a, launch_ptr, lds_max, sor, backward, ncols, st);
   }
   return hipErrorInvalidValue;
 }

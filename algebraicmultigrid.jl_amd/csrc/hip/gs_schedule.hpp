@@ -900,6 +900,9 @@ struct BuildTimer {  // AMGH_VERBOSE: where the host time of a schedule build go
   }
 };
 
+void permuted_matrix(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val,
+                     const std::vector<int32_t>& perm, HostLevelCsr& base);
+
 // dependency levels of the symmetrised pattern, the level order (perm: level-ordered row -> original row) and
 // the matrix in that order (columns renumbered, entries of a row in their original order)
 void level_order(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val,
@@ -929,6 +932,13 @@ void level_order(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t*
   if (base.nlev == 0) next.clear();
   for (int64_t i = 0; i < n; ++i) perm[next[lev[i]]++] = (int32_t)i;  // ascending row id inside a level
   std::vector<int32_t>().swap(lev);
+  permuted_matrix(n, ncols, rowptr, col, val, perm, base);
+}
+
+// the matrix with its rows in the order `perm` (position p = row perm[p]) and its columns renumbered to positions
+void permuted_matrix(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val,
+                     const std::vector<int32_t>& perm, HostLevelCsr& base) {
+  base.n = n;
   // x is kept in dependency-level order during the sweeps: position p holds x[perm[p]]; columns
   // beyond the square block (halo entries of a sharded operator) keep their place.  Each level
   // then reads and writes contiguous stretches of x (coalesced, TLB-friendly) instead of a
@@ -963,10 +973,81 @@ void level_order(int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t*
   });
 }
 
+// The schedule as a WAVEFRONT OF BLOCKS (gs_blocks.hpp) where it pays: rows in block order, one packed record per block,
+// a launch per depth of the quotient DAG, one wave walking each block — no substitution, the scalar loop's arithmetic.
+// Sets g->bw (and everything the level-ordered cycle needs: perm, the permuted CSR copy, bp / xp) or leaves g untouched
+// when the operator is not eligible / the cost model says no.
+int bw_build(GsSchedule* g, int64_t n, const int32_t* rowptr, const int32_t* col, const real* val, BuildTimer& tm) {
+  bw::Params prm;
+  prm.target_rows = std::max(64, g_gs_bw_rows);
+  prm.threads = std::max(1, std::min<int>(merge_threads(), 16));
+  bw::Plan P;
+  if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_OK;
+  tm.lap("block partition + records", n);
+  const int64_t nnz = rowptr[n];
+  const int nlaunch = (int)P.launch_ptr.size() - 1;
+  if (g_gs_bw != 2) {
+    // three independent directions (a stencil-like operator: with fewer the blocks are slabs and their walk is long), and
+    // clearly cheaper than groups of ~3 merged levels with ~1.8 x the entries (what such operators get otherwise)
+    const bool three = P.range[0] > 1 && P.range[1] > 1 && P.range[2] > 1;
+    const double merged = merge_cost((P.nlevels + 2) / 3, (int64_t)(1.8 * (double)nnz));
+    if (getenv("AMGH_VERBOSE"))
+      fprintf(stderr, "[amghip] n=%lld wavefront of blocks: %zu blocks, %d launches (dependency levels %d), model %.3f ms vs %.3f ms merged -> %s\n",
+              (long long)n, P.blocks.size(), nlaunch, P.nlevels, P.est_seconds * 1e3, merged * 1e3,
+              (three && P.est_seconds < 0.8 * merged) ? "used" : "not used");
+    if (!three || !(P.est_seconds < 0.8 * merged)) return AMGH_OK;
+  }
+  HostLevelCsr base;
+  permuted_matrix(n, n, rowptr, col, val, P.perm, base);
+  g->n = n; g->ncols = n; g->nnz = nnz; g->nlev = P.nlevels;
+  g->lvl_ptr.clear(); g->segs.clear();
+  RC_TRY(dev_upload(&g->rowptr, base.prow.data(), n + 1));
+  RC_TRY(dev_upload(&g->col, base.pcol.data(), nnz));
+  RC_TRY(dev_upload(&g->val, base.pval.data(), nnz));
+  RC_TRY(dev_upload(&g->dpos, base.pdpos.data(), n));
+  RC_TRY(dev_upload(&g->diag, base.pdiag.data(), n));
+  g->csr_bytes = (n + 1) * 4 + nnz * kEntB + n * 4;
+  g->bytes += g->csr_bytes + n * kRealB;
+  RC_TRY(dev_upload(&g->perm, P.perm.data(), n));
+  RC_TRY(dev_upload(&g->permx, P.perm.data(), n));
+  g->h_perm = P.perm;
+  g->bytes += 2 * n * 4;
+  RC_TRY(dev_upload(&g->bw.blocks, P.blocks.data(), (int64_t)P.blocks.size()));
+  if (P.ext_col.empty()) P.ext_col.push_back(0);   // (a single block has no external column)
+  RC_TRY(dev_upload(&g->bw.ext_col, P.ext_col.data(), (int64_t)P.ext_col.size()));
+  RC_TRY(dev_upload(&g->bw.rec, P.rec.data(), (int64_t)P.rec.size()));
+  g->bw.launch_ptr = P.launch_ptr;
+  g->bw.lds_max = P.lds_max; g->bw.maxk = P.blocks[0].maxk;
+  g->bw.rec_bytes = (int64_t)P.rec.size() + (int64_t)P.blocks.size() * (int64_t)sizeof(bw::Desc) + (int64_t)P.ext_col.size() * 4;
+  g->bw.rec_entries = n * (int64_t)g->bw.maxk;
+  g->bw.sum_depth = P.sum_depth; g->bw.est_seconds = P.est_seconds;
+  g->slot_bytes = g->bw.rec_bytes;
+  g->bytes += g->bw.rec_bytes;
+  g->xstride = g->ncols;
+  g->diag_nonzero = true;
+  for (int64_t p2 = 0; p2 < n && g->diag_nonzero; ++p2) g->diag_nonzero = base.pdiag[p2] != 0.0;
+  RC_TRY(dev_alloc(&g->bp, n));
+  RC_TRY(dev_alloc(&g->xp, g->xstride));
+  g->bytes += 8 * (n + g->xstride);
+  tm.lap("block layout upload", n);
+  if (getenv("AMGH_VERBOSE"))
+    fprintf(stderr, "[amghip] n=%lld fwd / bwd: wavefront of %zu blocks, %d launches, records %.2f GB\n", (long long)n, P.blocks.size(), nlaunch,
+            (double)P.rec.size() / 1e9);
+  return AMGH_OK;
+}
+
+// nrhs_hint: right-hand-side columns the sweeps of this schedule will carry (0 = unknown): the wavefront of blocks is a
+// single-column layout (its records would be re-read per column), chosen only for nrhs_hint == 1
 int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
-             const real* val) {
+             const real* val, int nrhs_hint = 0) {
   const int64_t n = nrows;
   BuildTimer tm;
+  g->bytes = 0;
+  if (g_gs_bw > 0 && nrhs_hint == 1 && ncols <= n && n > 0 && (g_gs_bw == 2 || n >= g_gs_bw_min_rows)) {
+    const int rcb = bw_build(g, n, rowptr, col, val, tm);
+    if (rcb != AMGH_OK) return rcb;
+    if (g->bw.rec) return AMGH_OK;
+  }
   HostLevelCsr base;
   std::vector<int32_t> perm;
   level_order(n, ncols, rowptr, col, val, base, perm);
@@ -1490,6 +1571,7 @@ int gs_grow_xp_for_merged(GsSchedule* g, int64_t* op_bytes) {
 // Merged children for SOR with relaxation factor omega, built on demand from the level-ordered matrix already on
 // the device.  Returns the cache entry (children may be null: merging did not pay or was rejected).
 GsSchedule::SorSet* sor_children(GsSchedule* g, real omega) {
+  if (g->bw.rec) return nullptr;   // the wavefront of blocks sweeps SOR itself (no merged children)
   for (GsSchedule::SorSet& ss : g->sor)
     if (ss.built && ss.omega == omega) return &ss;
   GsSchedule::SorSet& ss = g->sor[g->sor_next];

@@ -221,7 +221,7 @@ class DeviceHierarchy:
         t_lev = time.perf_counter()
         args, keep = self._level_args(A, presmoother, postsmoother)
         out = C.c_void_p()
-        hip_check(self.lib.amgh_level_prepare(self.device, *args, C.byref(out)), "level_prepare")
+        hip_check(self.lib.amgh_level_prepare_nrhs(self.device, int(self.nrhs), *args, C.byref(out)), "level_prepare")
         del keep
         if os.environ.get("AMGH_VERBOSE"):
             print(f"[amghip] n={A.m} python: level_prepare total {time.perf_counter() - t_lev:.2f} s (clock {t_lev % 1000:.2f} .. {time.perf_counter() % 1000:.2f})",

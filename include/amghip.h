@@ -133,6 +133,14 @@ int amgh_level_prepare(int device, int64_t n,
                        const int32_t* A_rowptr, const int32_t* A_col, const amgh_real* A_val,
                        const int32_t* S_rowptr, const int32_t* S_col, const amgh_real* S_val,
                        const amgh_smoother_t* pre, const amgh_smoother_t* post, amgh_level_t** out);
+/* The same with the number of right-hand-side columns the level's sweeps will carry (the nrhs of the handle it is going to
+ * join; 0 = unknown = amgh_level_prepare): a single-column hierarchy may get a single-column smoother layout — on
+ * stencil-like fine levels the exact Gauss-Seidel sweep as a wavefront of blocks walked by single waves
+ * (csrc/hip/gs_blocks.hpp) instead of merged dependency levels.  amgh_push_level_begin passes its handle's nrhs.  */
+int amgh_level_prepare_nrhs(int device, int nrhs, int64_t n,
+                            const int32_t* A_rowptr, const int32_t* A_col, const amgh_real* A_val,
+                            const int32_t* S_rowptr, const int32_t* S_col, const amgh_real* S_val,
+                            const amgh_smoother_t* pre, const amgh_smoother_t* post, amgh_level_t** out);
 int amgh_push_level_prepared(amgh_t* h, amgh_level_t* level);
 void amgh_level_free(amgh_level_t* level);
 

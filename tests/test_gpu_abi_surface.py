@@ -124,8 +124,14 @@ def test_sweep_stats_describe_the_schedule(h128):
     st = dev.gs_sweep_stats(0, False)
     assert st["rows"] == A.m and 1 <= st["launches"] <= dev.gs_sweep_steps(0, False)   # narrow groups chain into one launch
     assert st["entries"] > 0 and st["slot_entries"] >= 0
-    if st["levels_per_group"] > 1:      # merged groups: composite rows + the other triangle as a pre-pass
-        assert st["tri_entries"] > 0 and st["entries"] >= (A.nnz - A.m) // 2
+    # the fine level of a single-right-hand-side hierarchy of this size: a wavefront of blocks — the operator's own
+    # off-diagonal entries (no composite rows, no pre-pass), 3 * 16 - 2 launches for 16^3 blocks of 8^3 rows
+    assert st["tri_entries"] == 0 and st["entries"] == A.nnz - A.m and st["slot_entries"] == 6 * A.m
+    assert st["launches"] == dev.gs_sweep_steps(0, False) == 46
+    # the 19-point level below: merged groups — composite rows + the other triangle as a pre-pass
+    s1 = dev.gs_sweep_stats(1, False)
+    if s1["levels_per_group"] > 1:
+        assert s1["tri_entries"] > 0 and s1["entries"] >= (ml.levels[1].A.nnz - ml.levels[1].A.m) // 2
     assert dev.gs_dependency_levels(0) == 3 * 128 - 2
 
 
@@ -206,6 +212,58 @@ def test_tiny_operators_swept_out_of_lds_and_small_hierarchies_replayed_from_gra
     xp, log = AMG.cg(A, d["b"], Pl=AMG.aspreconditioner(ml), reltol=1e-10, log=True)
     xpo, _, itp = O.OracleHierarchy(ml).pcg(d["b"], reltol=1e-10)
     assert log["iters"] == itp == 13 and rel(xp, xpo) <= 1e-9
+
+
+def test_wavefront_of_blocks_schedule_vs_oracle_and_level_schedules():
+    """Single-right-hand-side hierarchies may sweep stencil-like fine levels as a WAVEFRONT OF BLOCKS (gs_blocks.hpp:
+    acyclic block partition from monotone potentials, one wave walking each block, the scalar loop's arithmetic).
+    Forced here on small operators (gs_bw = 2, blocks of ~64 rows): 3-D / 2-D / 1-D Poisson, an irregular Galerkin
+    operator, symmetric and directional Gauss-Seidel and SOR, V / W / F cycles — against the oracle, and against the
+    same hierarchy on the level schedules (gs_bw = 0).  A block of right-hand sides keeps the level schedules."""
+    from amg_amd.device import DeviceHierarchy
+    lib = AMG.hip_lib()
+    cases = [AMG.poisson((20, 18, 16)), AMG.poisson((48, 40)), AMG.poisson(700)]
+    cases.append(AMG.ruge_stuben(AMG.poisson((24, 24, 24))).levels[1].A)          # 19-point-like rows: too long -> not eligible, level schedules
+    smoothers = [(AMG.GaussSeidel(), AMG.GaussSeidel()), (AMG.GaussSeidel(AMG.ForwardSweep(), iter=2), AMG.GaussSeidel(AMG.BackwardSweep())),
+                 (AMG.SOR(1.2), AMG.SOR(0.8, AMG.ForwardSweep()))]
+    used = 0
+    for A in cases:
+        b = uniform(A.m, 17) - 0.3
+        for pre, post in smoothers:
+            ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=post)
+            oh = O.OracleHierarchy(ml)
+            out = {}
+            for mode in (2, 0):
+                assert lib.amgh_debug_set_tunable(b"gs_bw", mode) == 0
+                assert lib.amgh_debug_set_tunable(b"gs_bw_rows", 64) == 0
+                try:
+                    dev = DeviceHierarchy(ml, 0, 1)
+                    if mode == 2:
+                        st0 = dev.gs_sweep_stats(0, False)
+                        used += bool(dev.gs_sweep_steps(0, False) < dev.gs_dependency_levels(0) and st0["tri_entries"] == 0 and st0["levels_per_group"] >= 1 and st0["slot_entries"] == A.m * 6)
+                    for cyc in (0, 1, 2):
+                        out[(mode, cyc)] = dev.precond_apply(b, cyc)
+                finally:
+                    lib.amgh_debug_set_tunable(b"gs_bw", 1)
+                    lib.amgh_debug_set_tunable(b"gs_bw_rows", 512)
+            for cyc in (0, 1, 2):
+                ref = oh.precond(b, cycle=cyc)
+                assert rel(out[(2, cyc)], ref) <= 1e-10, (A.m, repr(pre), cyc)
+                assert rel(out[(2, cyc)], out[(0, cyc)]) <= 1e-12, (A.m, repr(pre), cyc)
+    assert used >= 6    # the three Poisson operators really ran as wavefronts of blocks
+    # nrhs > 1: never the single-column layout
+    A = cases[0]
+    ml = AMG.ruge_stuben(A)
+    lib.amgh_debug_set_tunable(b"gs_bw", 2)
+    try:
+        dev3 = DeviceHierarchy(ml, 0, 3)
+        B = np.stack([uniform(A.m, 1), uniform(A.m, 2), uniform(A.m, 3)], axis=1)
+        Z = dev3.precond_apply(B)
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_bw", 1)
+    oh = O.OracleHierarchy(ml)
+    for q in range(3):
+        assert rel(Z[:, q], oh.precond(np.ascontiguousarray(B[:, q]))) <= 1e-10
 
 
 def test_jacobi_on_a_zero_vector_skips_the_matrix_pass_bitwise():

@@ -1,4 +1,4 @@
-// block_wave_bench — the block-wavefront Gauss-Seidel sweep of tools/gs_blocks.hpp: plan (partition by
+// block_wave_bench — the block-wavefront Gauss-Seidel sweep of csrc/hip/gs_blocks.hpp: plan (partition by
 // monotone potentials), layout, forward / backward sweeps checked bit for bit against the scalar loops, timings.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/block_wave_bench tools/block_wave_bench.hip
 // usage: block_wave_bench poisson N [target_rows]     (7-point, N^3)   |   block_wave_bench poisson2 N [target_rows]   (5-point, N^2)
@@ -6,7 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include "gs_blocks.hpp"
+#include "../algebraicmultigrid.jl_amd/csrc/hip/gs_blocks.hpp"
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 using namespace amgh;
@@ -55,8 +55,6 @@ int main(int argc, char** argv) {
   Csr A = std::string(argv[1]) == "poisson" ? poisson3(atoi(argv[2])) : std::string(argv[1]) == "poisson2" ? poisson2(atoi(argv[2])) : load(argv[2]);
   const int64_t n = A.n;
   bw::Params prm; if (argc > 3) prm.target_rows = atoi(argv[3]);
-  const int want = argc > 4 ? atoi(argv[4]) : 2;   // kernel: 0 generic (operands from the LDS record), 1 operands in registers, 2 packed rows
-  prm.packed = want == 2;
   prm.threads = 8;
   bw::Plan P;
   const auto t0 = std::chrono::steady_clock::now();
@@ -64,8 +62,6 @@ int main(int argc, char** argv) {
   const double tplan = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (!ok) { printf("plan: not eligible\n"); return 0; }
   const int nl = (int)P.launch_ptr.size() - 1;
-  const int use_reg = want == 2 ? 2 : (want == 1 && P.blocks[0].maxk == 6 && P.max_rows <= 64 * bw::kRegRpt) ? 1 : 0;
-  printf("kernel: %s\n", use_reg == 2 ? "packed rows" : use_reg == 1 ? "operands in registers" : "operands from LDS (generic)");
   int maxb = 0, under = 0;
   for (int l = 0; l < nl; ++l) { const int c = P.launch_ptr[l + 1] - P.launch_ptr[l]; maxb = std::max(maxb, c); under += c < 256; }
   std::vector<int> rows; for (auto& d : P.blocks) rows.push_back(d.nrows); std::sort(rows.begin(), rows.end());
@@ -94,10 +90,10 @@ int main(int argc, char** argv) {
   CHECK(hipMemcpy(d_rec, P.rec.data(), P.rec.size(), hipMemcpyHostToDevice));
   CHECK(hipMemcpy(d_ext, P.ext_col.data(), 4 * P.ext_col.size(), hipMemcpyHostToDevice));
   CHECK(hipMemcpy(d_b, bb.data(), 8 * n, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
-  bw::Args<double> a{d_blocks, d_rec, d_ext, d_b, d_x, n, n, 1.0, 0, nullptr, nullptr, 0};
+  bw::Args<double> a{d_blocks, d_rec, d_ext, d_b, d_x, n, n, 1.0, 0, nullptr};
   hipStream_t st; CHECK(hipStreamCreate(&st));
-  CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, false, 1, st, use_reg));
-  CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, true, 1, st, use_reg));
+  CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.lds_max, false, false, 1, st));
+  CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.lds_max, false, true, 1, st));
   CHECK(hipStreamSynchronize(st));
   std::vector<double> xg(n);
   CHECK(hipMemcpy(xg.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
@@ -108,10 +104,10 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   const double bytes = (double)P.rec.size() + n * 24.0 + P.ext_total * 12.0;
   for (int bwd = 0; bwd < 2; ++bwd) {
-    CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, bwd, 1, st, use_reg)); CHECK(hipStreamSynchronize(st));
+    CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.lds_max, false, bwd, 1, st)); CHECK(hipStreamSynchronize(st));
     const int reps = 5;
     CHECK(hipEventRecord(e0, st));
-    for (int r = 0; r < reps; ++r) CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, bwd, 1, st, use_reg));
+    for (int r = 0; r < reps; ++r) CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.lds_max, false, bwd, 1, st));
     CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     printf("%s sweep: %.3f ms = %d launches x %.2f us (%.0f GB/s)\n", bwd ? "backward" : "forward ", ms / reps, nl, ms / reps / nl * 1e3, bytes / (ms / reps * 1e-3) / 1e9);
@@ -120,7 +116,7 @@ int main(int argc, char** argv) {
   {
     long long* d_tim; CHECK(hipMalloc(&d_tim, 32 * P.blocks.size()));
     a.tim = d_tim;
-    CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.launch_rec, P.lds_max, false, false, 1, st, use_reg)); CHECK(hipStreamSynchronize(st));
+    CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.lds_max, false, false, 1, st)); CHECK(hipStreamSynchronize(st));
     std::vector<long long> tim(4 * P.blocks.size());
     CHECK(hipMemcpy(tim.data(), d_tim, 32 * P.blocks.size(), hipMemcpyDeviceToHost));
     double s_load = 0, s_sweep = 0, s_store = 0, s_span = 0, s_gap = 0; long long prev_end = 0; int cnt = 0;
