@@ -106,6 +106,31 @@ def test_cycles_in_float32_vs_float32_oracle(cycle):
         assert 1e-9 < rel(z, z64) < 1e-3, (name, rel(z, z64))
 
 
+def test_wavefront_of_blocks_in_float32():
+    """The Float32 instance sweeps a single-column fine level as a wavefront of blocks too (packed rows of four values per
+    16-byte chunk, the quotient as reciprocal + one fmaf correction): forced on a small 3-D operator, against the Float32
+    oracle and against the level schedules of the same instance."""
+    from amg_amd.device import DeviceHierarchy
+    lib = AMG.hip_lib("float32")
+    A = as_f32_matrix(AMG.poisson((18, 16, 14)))
+    for pre, post in ((AMG.GaussSeidel(), AMG.GaussSeidel()), (AMG.SOR(1.1), AMG.GaussSeidel(AMG.BackwardSweep(), iter=2))):
+        ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=post)
+        r = uniform(A.m, 9).astype(F32)
+        ref = O.OracleHierarchy(ml, dtype=F32).precond(r)
+        out = {}
+        for mode in (2, 0):
+            assert lib.amgh_debug_set_tunable(b"gs_bw", mode) == 0 and lib.amgh_debug_set_tunable(b"gs_bw_rows", 64) == 0
+            try:
+                dev = DeviceHierarchy(ml, 0, 1, dtype=F32)
+                if mode == 2:
+                    assert dev.gs_sweep_stats(0, False)["slot_entries"] == 6 * A.m      # it is the block layout
+                out[mode] = dev.precond_apply(r)
+            finally:
+                lib.amgh_debug_set_tunable(b"gs_bw", 1)
+                lib.amgh_debug_set_tunable(b"gs_bw_rows", 512)
+        assert out[2].dtype == F32 and rel(out[2], ref) <= F32_TOL and rel(out[2], out[0]) <= F32_TOL
+
+
 def test_solve_in_float32_follows_the_float32_oracle():
     for name, ml in _hierarchies():
         A0 = ml.levels[0].A
