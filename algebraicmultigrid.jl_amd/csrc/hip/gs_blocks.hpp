@@ -41,7 +41,11 @@ struct Desc {          // one block (32 bytes)
 };
 constexpr int kChunk = 6;       // entries summed per batch of LDS reads
 constexpr int kThreads = 512;   // loading workgroup (the sweep itself is wave 0)
-constexpr int kMaxSteps = 124;  // steps per block (their row pointers live in two registers of wave 0)
+constexpr int kMaxSteps = 124;
+#ifndef BW_PLAN_MAXK
+#define BW_PLAN_MAXK 12
+#endif
+constexpr int kPlanMaxK = BW_PLAN_MAXK;   // longest rows (off-diagonal entries, padded) a plan accepts = the kernels instantiated below  // steps per block (their row pointers live in two registers of wave 0)
 
 // PACKED rows (the format of gs_bw_packed_kernel): a row is one run of 16-byte chunks
 //     [ v0 v1 | v2 v3 | ... | (.. dg rc) | c0 .. c7 | c8 .. ]      values, diagonal, its reciprocal, then the columns as uint16
@@ -118,7 +122,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     maxlen = std::max(maxlen, off);   // off-diagonal entries of the longest row
   }
   const int maxk = ((std::max(1, maxlen) + kChunk - 1) / kChunk) * kChunk;
-  if (maxk > 12) return false;   // (kMaxK: the kernels' register sets; longer rows make the walk instruction-bound, profiles/r03_block_wave.log)
+  if (maxk > kPlanMaxK) return false;   // (kMaxK: the kernels' register sets; longer rows make the walk instruction-bound, profiles/r03_block_wave.log)
   {
     std::vector<int> occ;
     for (int b = 0; b < 32; ++b) if (hist[b]) occ.push_back(b);
@@ -572,6 +576,9 @@ inline hipError_t sweep(const Args<R>& a, int maxk, const std::vector<int32_t>& 
   switch (maxk) {
     case 6: return sweep_k<R, 6>(a, launch_ptr, lds_max, sor, backward, ncols, st);
     case 12: return sweep_k<R, 12>(a, launch_ptr, lds_max, sor, backward, ncols, st);
+#if BW_PLAN_MAXK >= 18
+    case 18: return sweep_k<R, 18>(a, launch_ptr, lds_max, sor, backward, ncols, st);
+#endif
   }
   return hipErrorInvalidValue;
 }

@@ -1,6 +1,6 @@
 // block_wave_bench — the block-wavefront Gauss-Seidel sweep of csrc/hip/gs_blocks.hpp: plan (partition by
 // monotone potentials), layout, forward / backward sweeps checked bit for bit against the scalar loops, timings.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/block_wave_bench tools/block_wave_bench.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DBW_PLAN_MAXK=18: rows of up to 18 entries, e.g. level 1] -o tools/block_wave_bench tools/block_wave_bench.hip
 // usage: block_wave_bench poisson N [target_rows]     (7-point, N^3)   |   block_wave_bench poisson2 N [target_rows]   (5-point, N^2)
 //        block_wave_bench file PATH [target_rows]    PATH: int64 n, int64 nnz, int32 rowptr[n+1], int32 col[nnz], double val[nnz]
 #include <chrono>
