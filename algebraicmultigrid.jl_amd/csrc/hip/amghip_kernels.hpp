@@ -691,7 +691,11 @@ __device__ __forceinline__ void wave_row(const WaveRow<MAXK>& o, real* xl, real 
     q = wave_fma(rem, rc, q);
     const real an = nn < (real)0 ? -nn : nn;
     const bool safe = sizeof(real) == 8 ? (an > (real)1e-200 && an < (real)1e200) : (an > (real)1e-25 && an < (real)1e25);
-    if (!(rc != 0.0 && safe)) q = nn / dg;
+    // (a wave-uniform branch: as a plain select the compiler evaluates the whole division sequence in every step)
+    if (__builtin_amdgcn_ballot_w64(!(rc != 0.0 && safe)) != 0) {
+      asm volatile("; rows outside the normal range: the division itself" ::: "memory");   // (keeps the branch a branch)
+      if (!(rc != 0.0 && safe)) q = nn / dg;
+    }
     xl[o.p] = q;
   }
 }

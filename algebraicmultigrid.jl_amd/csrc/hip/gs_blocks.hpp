@@ -471,7 +471,11 @@ __device__ __forceinline__ void packed_row(const PackedOps<R, MAXK>& o, R* xl, R
     q = __builtin_fma(rem, rc, q);
     const R an = __builtin_fabs(nn);
     const bool safe = sizeof(R) == 8 ? (an > (R)1e-200 && an < (R)1e200) : (an > (R)1e-25 && an < (R)1e25);
-    if (!(rc != (R)0 && safe)) q = nn / dg;
+    // (a wave-uniform branch: as a plain select the compiler evaluates the whole division sequence in every step)
+    if (__builtin_amdgcn_ballot_w64(!(rc != (R)0 && safe)) != 0) {
+      asm volatile("; rows outside the normal range: the division itself" ::: "memory");   // (keeps the branch a branch)
+      if (!(rc != (R)0 && safe)) q = nn / dg;
+    }
     xl[o.p] = q;
   }
 }
