@@ -163,6 +163,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   cap = (cap / 64) * 64;
   if (cap < 64) return false;
   const int target = std::min(prm.target_rows, cap);
+  cap = std::min(cap, std::max(64, ((target * 5 / 4 + 63) / 64) * 64));   // blocks stay near the size asked for
   // ---- cell widths: the same number of cells m along every (non-degenerate) potential, m raised until few rows sit in oversized cells ----
   double m = std::cbrt((double)n / target);
   std::vector<int32_t> cell(n);
