@@ -920,7 +920,8 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
     const int t = tid + u * kSlot;
     m[u] = i4_t{0, 0, -1, 0}; d[u] = 0.0; bb[u] = 0.0; tr[u] = 0; tq[u] = 0;
     if (t < ntask) {
-      tq[u] = t / nrows; tr[u] = t - tq[u] * nrows;
+      if (NCV > 1) { tq[u] = t / nrows; tr[u] = t - tq[u] * nrows; }   // (one column: task = row, no integer division)
+      else tr[u] = t;
       m[u] = a.wmeta[r0 + tr[u]];
       d[u] = a.diag[r0 + tr[u]];
       bb[u] = a.bp[r0 + tr[u] + tq[u] * a.ldb];
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(kSlot) void gs_slot_kernel(SlotArgs a) {
     }
   }
   for (int t = tid + TPT * kSlot; t < ntask; t += kSlot) {  // slots of very short rows: more tasks than 2 per thread
-    const int q = t / nrows, r = t - q * nrows;
+    const int q = NCV > 1 ? t / nrows : 0, r = t - q * nrows;
     const i4_t m2 = a.wmeta[r0 + r];
     const real d2 = a.diag[r0 + r];
     if (d2 != 0.0) {
