@@ -92,6 +92,34 @@ typedef real d2_t __attribute__((ext_vector_type(2)));
 typedef int i2_t __attribute__((ext_vector_type(2)));
 typedef int i4_t __attribute__((ext_vector_type(4)));
 
+// acc + the value held by the partner lane of step w of an xor butterfly, partners reached through DPP lane permutes
+// (no LDS crossbar, no wait): w = 1, 2 inside a quad, w = 4 as the mirror image inside 8 lanes, w = 8 inside 16 — after the
+// steps below w the mirrored partner holds the same partial sum as the xor partner, so every lane ends with the sum
+// the __shfl_xor tree forms, added in the same order.  Wider steps use __shfl_xor.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int W>
+__device__ __forceinline__ real tree_add(real acc) {
+#pragma unroll
+  for (int w = 1; w < W; w <<= 1) {
+    if (w == 1) acc += dpp_move<0xB1>(acc);          // quad_perm [1, 0, 3, 2]
+    else if (w == 2) acc += dpp_move<0x4E>(acc);     // quad_perm [2, 3, 0, 1]
+    else if (w == 4) acc += dpp_move<0x141>(acc);    // row_half_mirror
+    else if (w == 8) acc += dpp_move<0x140>(acc);    // row_mirror
+    else acc += __shfl_xor(acc, w, kWave);
+  }
+  return acc;
+}
+
 // matrix streams are read once: optional non-temporal loads (measured neutral-to-negative, off by default)
 template <bool NT, class T>
 __device__ __forceinline__ T ld_stream(const T* p) {
@@ -664,7 +692,7 @@ __device__ __forceinline__ void wave_load(WaveRow<MAXK>& o, int p, bool act, con
   typedef typename WaveVec16<real>::type V;
   o.p = act ? p : -1;
   const int q = act ? p : 0;
-  const unsigned char* row = rec + (size_t)q * O::RS;
+  const unsigned char* row = rec + __umul24((unsigned)q, (unsigned)O::RS);   // (24-bit multiply: full rate)
 #pragma unroll
   for (int k = 0; k < O::NVC; ++k) *(V*)&o.v[k * kWaveVpc] = *(const V*)(row + 16 * k);
 #pragma unroll
@@ -1001,8 +1029,7 @@ __global__ __launch_bounds__(kSlot / EPT) void gs_slot_lpr_kernel(SlotArgs a) {
     const int dz = m.z - base, qe = m.y - base;
     for (int q = m.x - base + sub; q < qe; q += LPR)
       if (q != dz) acc += s_prod[q];
-#pragma unroll
-    for (int w = 1; w < LPR; w <<= 1) acc += __shfl_xor(acc, w, kWave);
+    acc = tree_add<LPR>(acc);
     if (sub == 0 && r < nrows && d != 0.0) {
       const int i = r0 + r;
       a.x[i] = SOR ? (1.0 - a.omega) * a.x[i] + (a.omega / d) * (bb - acc) : (bb - acc) / d;
@@ -1097,8 +1124,7 @@ __global__ __launch_bounds__(256) void gs_sell_kernel(SellArgs a) {
   }
 #pragma unroll
   for (int k = 0; k < NCV; ++k) {
-#pragma unroll
-    for (int w = 1; w < K; w <<= 1) acc[k] += __shfl_xor(acc[k], w, kWave);
+    acc[k] = tree_add<K>(acc[k]);
   }
   if (live && (lane % K) == 0 && d != 0.0) {
     const int i = a.row0 + r;
@@ -1183,8 +1209,7 @@ __global__ __launch_bounds__(kSlot) void gs_bigslot_kernel(SlotArgs a) {
     real acc = 0.0;
     for (int q = mm.x - base + ln; q < qe; q += kWave)
       if (q != dz) acc += s_prod[q];
-#pragma unroll
-    for (int w = 1; w < kWave; w <<= 1) acc += __shfl_xor(acc, w, kWave);
+    acc = tree_add<kWave>(acc);
     if (ln == 0 && dd != 0.0) {
       const int i = r0 + r;
       a.x[i] = SOR ? (1.0 - a.omega) * a.x[i] + (a.omega / dd) * (bv - acc) : (bv - acc) / dd;

@@ -441,7 +441,7 @@ __device__ __forceinline__ void packed_load(PackedOps<R, MAXK>& o, int p, bool a
   constexpr int KCH = (O::NVC + O::NCC) | 1;
   o.p = act ? p : -1;
   const int q = act ? p : 0;
-  const unsigned char* row = rec + (size_t)q * (16 * KCH);
+  const unsigned char* row = rec + __umul24((unsigned)q, 16u * KCH);   // (24-bit multiply: full rate; rows < 2^16, bytes < 2^24)
   typedef typename Vec16<R>::type V;
 #pragma unroll
   for (int k = 0; k < O::NVC; ++k) *(V*)&o.v[k * O::VPC] = *(const V*)(row + 16 * k);
