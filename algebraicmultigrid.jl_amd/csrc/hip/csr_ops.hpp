@@ -565,7 +565,8 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
         const int avg = s.rows / 16;  // mean row length of the group (schedule build time)
         // measured on the 256^3 hierarchy (profiles/r02_gs_lpr_ept.log): 16 lanes pay from ~100 entries per row
         // (-15 %), 8 lanes from ~50 (-3 %); 2 and 4 lanes on rows of 10-30 entries are slower than one thread
-        lpr = g_gs_lpr > 1 ? g_gs_lpr : (avg >= 96 ? 16 : avg >= 48 ? 8 : 1);
+        // (round 3, reduction trees through DPP: 16 lanes already pay from ~56 entries — the 62-entry rows of the 1.4 M-row level 2.44 -> 2.22 ms per pass)
+        lpr = g_gs_lpr > 1 ? g_gs_lpr : (avg >= 56 ? 16 : avg >= 48 ? 8 : 1);
       }
       // more slots than 512-thread workgroups fit on the chip at once (4 per CU): 256-thread workgroups, 2 entries each
       int ept = 1;
