@@ -534,21 +534,26 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       SellArgs la{};
       la.scol = lay->scol; la.sval = lay->sval; la.chunk = lay->schunk; la.diag = lay->diag; la.bp = rhs; la.x = xp;
       la.omega = omega; la.row0 = lay->lvl_ptr[s.l0]; la.nrows = lay->lvl_ptr[s.l0 + 1] - lay->lvl_ptr[s.l0];
-      la.chunk0 = s.sell_chunk0; la.nchunks = s.sell_nchunks; la.xcd_map = g_gs_xcd_map;
+      la.chunk0 = s.sell_chunk0; la.nchunks = s.sell_nchunks;
       la.ldx = xs; la.ldb = ldb;
       const int nwg = (s.sell_nchunks + 3) / 4;
-      const int grid = g_gs_xcd_map ? ((nwg + kNumXcd - 1) / kNumXcd) * kNumXcd : nwg;
+      // XCD-contiguous workgroup mapping only where a launch has several workgroups per CU: below that there is no re-use
+      // to win and the mapping unbalances the XCDs (the 228 538-row level of the 256^3 hierarchy: 1.40 -> 1.29 ms per pass)
+      la.xcd_map = (g_gs_xcd_map && nwg >= 768) ? 1 : 0;
+      const int grid = la.xcd_map ? ((nwg + kNumXcd - 1) / kNumXcd) * kNumXcd : nwg;
       RC_TRY(launch_sell(la, sor, s.sell_k, grid, ncolv, st));
       HIP_TRY(hipGetLastError());
     } else if (s.nslots > 0 && (g_gs_slots || lay->compacted)) {
       SlotArgs sa{};
       sa.wcol = lay->wcol; sa.wval = lay->wval; sa.slot_row = lay->slot_row; sa.wmeta = lay->wmeta;
       sa.diag = lay->diag; sa.bp = rhs; sa.x = xp; sa.omega = omega; sa.slot0 = s.slot0;
-      sa.nslots = s.nslots; sa.xcd_map = g_gs_xcd_map;
+      // (XCD-contiguous mapping only for launches of several workgroups per CU, as for the SELL launches above)
+      const bool xmap = g_gs_xcd_map && (s.nslots >= 768 || ncolv > 1);
+      sa.nslots = s.nslots; sa.xcd_map = xmap ? 1 : 0;
       sa.ldx = xs; sa.ldb = ldb;
       if (lay->slot_entries == kBigSlot) {  // long composite rows: 2048-entry slots, 8 lanes per row
         sa.ncolv = ncolv;
-        const int grid = ((g_gs_xcd_map || ncolv > 1) ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots) * ncolv;
+        const int grid = ((xmap || ncolv > 1) ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots) * ncolv;
         if (sor) hipLaunchKernelGGL(gs_bigslot_kernel<true>, dim3(grid), dim3(kSlot), 0, st, sa);
         else hipLaunchKernelGGL(gs_bigslot_kernel<false>, dim3(grid), dim3(kSlot), 0, st, sa);
         HIP_TRY(hipGetLastError());
@@ -557,7 +562,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       // columns per workgroup: the largest of 8 / 4 / 2 / 1 that divides the block size
       const int ncv = (ncolv % 8 == 0) ? 8 : (ncolv % 4 == 0) ? 4 : (ncolv % 2 == 0) ? 2 : 1;
       sa.ncolv = ncolv / ncv;
-      const int grid = ((g_gs_xcd_map || sa.ncolv > 1) ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots) * sa.ncolv;
+      const int grid = ((xmap || sa.ncolv > 1) ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots) * sa.ncolv;
       // merged groups with long composite rows: several lanes per row in the row sums (order of additions changes,
       // so never on the unmerged schedule, which reproduces the scalar loop bit for bit)
       int lpr = 1;
