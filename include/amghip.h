@@ -464,7 +464,7 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
  * (amgh_push_level, first stand-alone sweep of an operator): "gs_merge" (largest group of dependency levels tried),
  * "gs_bigslot" (0 off, 1 cost model, 2 always), "gs_super" (blocks per superblock), "gs_block_inverse", "gs_bw" (the
  * wavefront-of-blocks layout of single-column hierarchies: 0 off, 1 where its cost model prefers it, 2 always),
- * "gs_bw_rows" (rows per block aimed at, 512), "gs_bw_min_rows" (smallest operator considered in mode 1, 2^20).
+ * "gs_bw_rows" (rows per block aimed at, 512), "gs_bw_min_rows" (smallest operator considered in mode 1, 3 000 000 rows).
  * Returns AMGH_EINVAL for an unknown name.                                                                       */
 int amgh_debug_set_tunable(const char* name, int value);
 

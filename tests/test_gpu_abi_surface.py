@@ -124,15 +124,23 @@ def test_sweep_stats_describe_the_schedule(h128):
     st = dev.gs_sweep_stats(0, False)
     assert st["rows"] == A.m and 1 <= st["launches"] <= dev.gs_sweep_steps(0, False)   # narrow groups chain into one launch
     assert st["entries"] > 0 and st["slot_entries"] >= 0
-    # the fine level of a single-right-hand-side hierarchy of this size: a wavefront of blocks — the operator's own
-    # off-diagonal entries (no composite rows, no pre-pass), 3 * 16 - 2 launches for 16^3 blocks of 8^3 rows
-    assert st["tri_entries"] == 0 and st["entries"] == A.nnz - A.m and st["slot_entries"] == 6 * A.m
-    assert st["launches"] == dev.gs_sweep_steps(0, False) == 46
-    # the 19-point level below: merged groups — composite rows + the other triangle as a pre-pass
-    s1 = dev.gs_sweep_stats(1, False)
-    if s1["levels_per_group"] > 1:
-        assert s1["tri_entries"] > 0 and s1["entries"] >= (ml.levels[1].A.nnz - ml.levels[1].A.m) // 2
+    if st["levels_per_group"] > 1:      # merged groups: composite rows + the other triangle as a pre-pass
+        assert st["tri_entries"] > 0 and st["entries"] >= (A.nnz - A.m) // 2
     assert dev.gs_dependency_levels(0) == 3 * 128 - 2
+    # the same level as a wavefront of blocks (what single-column hierarchies get from 3 M rows on): the operator's own
+    # off-diagonal entries — no composite rows, no pre-pass —, 3 * 16 - 2 launches for 16^3 blocks of 8^3 rows
+    from amg_amd.device import DeviceHierarchy
+    lib = AMG.hip_lib()
+    lib.amgh_debug_set_tunable(b"gs_bw", 2)
+    try:
+        devb = DeviceHierarchy(ml, 0, 1)
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_bw", 1)
+    sb = devb.gs_sweep_stats(0, False)
+    assert sb["tri_entries"] == 0 and sb["entries"] == A.nnz - A.m and sb["slot_entries"] == 6 * A.m
+    assert sb["launches"] == devb.gs_sweep_steps(0, False) == 46 and devb.gs_dependency_levels(0) == 3 * 128 - 2
+    b = uniform(A.m, 77)
+    assert rel(devb.precond_apply(b), dev.precond_apply(b)) <= 1e-12
 
 
 @pytest.mark.parametrize("cyc", [1, 2])
