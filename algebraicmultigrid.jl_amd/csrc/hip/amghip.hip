@@ -1521,6 +1521,79 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
   return rc;
 }
 
+// The wavefront-of-blocks sweep (gs_blocks.hpp) on the HOST, from the very records the device kernel reads: plan (block
+// partition from monotone potentials, launches, packed rows), then launch by launch, block by block, step by step what
+// gs_bw_packed_kernel does — external x entries snapshot at the block's start, rows of a step from the block's x, products
+// and sums in entry order, the quotient as reciprocal + one fma correction (the division itself outside the normal
+// range).  x, b: nrows entries in natural order; omega = 1: Gauss-Seidel, else SOR.  stats4 = {blocks, launches, sum over
+// launches of the deepest block's steps, external columns}.  Returns AMGH_EUNSUPPORTED when the operator cannot be laid
+// out (rows longer than the kernels take).  CPU tests compare it bit for bit with the scalar lexicographic sweep.
+int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t* col, const real* val, int target_rows,
+                             int backward, double omega, real* x, const real* b, int64_t* stats4) {
+  if (nrows <= 0 || !rowptr || !x || !b || omega == 0.0 || target_rows < 1) return AMGH_EINVAL;
+  const int64_t n = nrows;
+  bw::Params prm;
+  prm.target_rows = target_rows;
+  prm.threads = 2;
+  bw::Plan P;
+  if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_EUNSUPPORTED;
+  if (stats4) { stats4[0] = (int64_t)P.blocks.size(); stats4[1] = (int64_t)P.launch_ptr.size() - 1; stats4[2] = P.sum_depth; stats4[3] = P.ext_total; }
+  // every row exactly once
+  {
+    std::vector<char> seen(n, 0);
+    for (int64_t p = 0; p < n; ++p) { if (P.perm[p] < 0 || P.perm[p] >= n || seen[P.perm[p]]) return AMGH_ESTATE; seen[P.perm[p]] = 1; }
+  }
+  std::vector<real> xp(n), bp(n);
+  for (int64_t p = 0; p < n; ++p) { xp[p] = x[P.perm[p]]; bp[p] = b[P.perm[p]]; }
+  const int nl = (int)P.launch_ptr.size() - 1;
+  const real om = (real)omega;
+  for (int s = 0; s < nl; ++s) {
+    const int l = backward ? nl - 1 - s : s;
+    // the blocks of a launch are independent: each works on a snapshot of what the launch started from
+    const std::vector<real> x0 = xp;
+    for (int32_t ob = P.launch_ptr[l]; ob < P.launch_ptr[l + 1]; ++ob) {
+      const bw::Desc& d = P.blocks[ob];
+      const size_t rs = bw::Packed<real>::row_bytes(d.maxk);
+      const int nvc = bw::Packed<real>::nvc(d.maxk);
+      const unsigned char* rec = P.rec.data() + (size_t)d.rec * 16;
+      const uint16_t* stp = (const uint16_t*)(rec + (size_t)d.nrows * rs);
+      std::vector<real> xl(d.nrows + d.next + 1);
+      for (int32_t p = 0; p < d.nrows; ++p) xl[p] = x0[d.row0 + p];
+      for (int32_t e = 0; e < d.next; ++e) xl[d.nrows + e] = x0[P.ext_col[d.ext0 + e]];
+      xl[d.nrows + d.next] = 0.0;
+      for (int k = 0; k < d.nlev; ++k) {
+        const int st = backward ? d.nlev - 1 - k : k;
+        std::vector<real> xn;   // rows of a step are computed from the same state
+        for (int32_t p = stp[st]; p < stp[st + 1]; ++p) {
+          const real* v = (const real*)(rec + (size_t)p * rs);
+          const uint16_t* cc = (const uint16_t*)(rec + (size_t)p * rs + (size_t)16 * nvc);
+          real acc = 0.0;
+          for (int e = 0; e < d.maxk; ++e) acc += v[e] * xl[cc[e] / sizeof(real)];
+          const real dg = v[d.maxk], rc = v[d.maxk + 1];
+          real q = xl[p];
+          if (dg != 0.0) {
+            const real nn = bp[d.row0 + p] - acc;
+            if (om != (real)1) q = ((real)1 - om) * xl[p] + (om / dg) * nn;
+            else {
+              q = nn * rc;
+              const real rem = std::fma(-dg, q, nn);
+              q = std::fma(rem, rc, q);
+              const real an = nn < 0 ? -nn : nn;
+              const bool safe = sizeof(real) == 8 ? (an > (real)1e-200 && an < (real)1e200) : (an > (real)1e-25 && an < (real)1e25);
+              if (!(rc != 0.0 && safe)) q = nn / dg;
+            }
+          }
+          xn.push_back(q);
+        }
+        for (int32_t p = stp[st]; p < stp[st + 1]; ++p) xl[p] = xn[p - stp[st]];
+      }
+      for (int32_t p = 0; p < d.nrows; ++p) xp[d.row0 + p] = xl[p];
+    }
+  }
+  for (int64_t p = 0; p < n; ++p) x[P.perm[p]] = xp[p];
+  return AMGH_OK;
+}
+
 // Host-only emulation of ONE merged-level Gauss-Seidel sweep (no device work: usable without a GPU).  Runs the same
 // construction the device schedules use — dependency levels, level order, groups of m levels made independent by
 // substitution, pre-pass over the other triangle — and then applies the composite rows group by group on the host.
