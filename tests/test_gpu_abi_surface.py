@@ -259,6 +259,28 @@ def test_wavefront_of_blocks_schedule_vs_oracle_and_level_schedules():
                 assert rel(out[(2, cyc)], ref) <= 1e-10, (A.m, repr(pre), cyc)
                 assert rel(out[(2, cyc)], out[(0, cyc)]) <= 1e-12, (A.m, repr(pre), cyc)
     assert used >= 6    # the three Poisson operators really ran as wavefronts of blocks
+    # the device walk is the host execution of the same records — and both the scalar loop — bit for bit
+    A = cases[0]
+    rp, ci, va = A.csr_arrays()
+    x0, bb = uniform(A.m, 21) - 0.5, uniform(A.m, 22)
+    for pre in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2)):
+        ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre)
+        lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_bw_rows", 64)
+        try:
+            dev = DeviceHierarchy(ml, 0, 1)
+            x_dev = dev.smooth(0, False, x0, bb)
+        finally:
+            lib.amgh_debug_set_tunable(b"gs_bw", 1); lib.amgh_debug_set_tunable(b"gs_bw_rows", 512)
+        assert dev.gs_sweep_stats(0, False)["slot_entries"] == 6 * A.m
+        assert np.array_equal(x_dev, O.smooth(pre, A, x0, bb, hermitian=True)), repr(pre)
+        xh = x0.copy()
+        for it in range(pre.iter):
+            for back in ((0,), (1,), (0, 1))[pre.sweep_code]:
+                st = np.zeros(4, dtype=np.int64)
+                rc = lib.amgh_debug_bw_sweep_host(A.m, np.ascontiguousarray(rp, np.int32).ctypes.data, np.ascontiguousarray(ci, np.int32).ctypes.data,
+                                                  np.ascontiguousarray(va).ctypes.data, 64, back, 1.0, xh.ctypes.data, bb.ctypes.data, st.ctypes.data)
+                assert rc == 0
+        assert np.array_equal(x_dev, xh), repr(pre)
     # nrhs > 1: never the single-column layout
     A = cases[0]
     ml = AMG.ruge_stuben(A)
