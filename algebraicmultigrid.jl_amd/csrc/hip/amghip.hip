@@ -1532,6 +1532,8 @@ int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t
                              int backward, double omega, real* x, const real* b, int64_t* stats4) {
   if (nrows <= 0 || !rowptr || !x || !b || omega == 0.0 || target_rows < 1) return AMGH_EINVAL;
   const int64_t n = nrows;
+  for (int32_t j = 0; j < rowptr[n]; ++j)
+    if (col[j] < 0 || col[j] >= n) return AMGH_EINVAL;   // (square operators only: no halo columns here)
   bw::Params prm;
   prm.target_rows = target_rows;
   prm.threads = 2;

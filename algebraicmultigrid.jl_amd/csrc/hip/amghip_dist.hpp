@@ -930,6 +930,7 @@ int amgh_dist_finalize(amgh_dist_t* d) {
                     L->post.kind == AMGH_SMOOTH_SOR;
     amgh_csr* M = &L->smat()->op;
     if (nloc > 0 && jac) RC_TRY(csr_ensure_diag(M, d->stream));
+    M->gs_nrhs_hint = 1;   // (the sharded cycle carries one right-hand side)
     if (nloc > 0 && gs) RC_TRY(csr_ensure_gs(M));
   }
   if (d->host_only) {

@@ -336,6 +336,7 @@ struct amgh_csr {
   int32_t* dpos = nullptr;
   real* diag = nullptr;
   GsSchedule* gs = nullptr;
+  int gs_nrhs_hint = 0;   // right-hand-side columns the sweeps over this operator will carry (0 = unknown), see gs_build
   int64_t bytes = 0;
 };
 

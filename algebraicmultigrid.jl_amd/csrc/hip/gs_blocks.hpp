@@ -117,7 +117,8 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     int off = 0;
     for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
       const int64_t d = (int64_t)i - col[j];
-      if (d != 0 && col[j] < n) { hist[31 - __builtin_clz((unsigned)(d < 0 ? -d : d))]++; ++off; }
+      if (d != 0) ++off;                                   // (halo columns of a row-sharded operator count as entries of the row)
+      if (d != 0 && col[j] < n) hist[31 - __builtin_clz((unsigned)(d < 0 ? -d : d))]++;
     }
     maxlen = std::max(maxlen, off);   // off-diagonal entries of the longest row
   }
@@ -311,8 +312,8 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
         const int32_t i = P.perm[d.row0 + p];
         for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
           const int32_t c = col[j];
-          if (c == i || c >= n) continue;
-          const int32_t q = inv[c];
+          if (c == i) continue;
+          const int32_t q = c >= n ? c : inv[c];            // halo columns keep their place behind the rows
           if (q < d.row0 || q >= d.row0 + d.nrows) ex.push_back(q);
         }
       }
@@ -375,8 +376,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
         for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
           const int32_t c = col[j];
           if (c == i) { dg = val[j]; continue; }
-          if (c >= n) continue;
-          const int32_t q = inv[c];
+          const int32_t q = c >= n ? c : inv[c];
           size_t lc;
           if (q >= d.row0 && q < d.row0 + d.nrows) lc = (size_t)(q - d.row0);
           else lc = (size_t)d.nrows + (size_t)(std::lower_bound(ex.begin(), ex.end(), q) - ex.begin());

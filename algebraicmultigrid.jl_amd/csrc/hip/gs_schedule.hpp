@@ -977,7 +977,7 @@ void permuted_matrix(int64_t n, int64_t ncols, const int32_t* rowptr, const int3
 // a launch per depth of the quotient DAG, one wave walking each block — no substitution, the scalar loop's arithmetic.
 // Sets g->bw (and everything the level-ordered cycle needs: perm, the permuted CSR copy, bp / xp) or leaves g untouched
 // when the operator is not eligible / the cost model says no.
-int bw_build(GsSchedule* g, int64_t n, const int32_t* rowptr, const int32_t* col, const real* val, BuildTimer& tm) {
+int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val, BuildTimer& tm) {
   bw::Params prm;
   prm.target_rows = std::max(64, g_gs_bw_rows);
   prm.threads = std::max(1, std::min<int>(merge_threads(), 16));
@@ -998,8 +998,8 @@ int bw_build(GsSchedule* g, int64_t n, const int32_t* rowptr, const int32_t* col
     if (!three || !(P.est_seconds < 0.8 * merged)) return AMGH_OK;
   }
   HostLevelCsr base;
-  permuted_matrix(n, n, rowptr, col, val, P.perm, base);
-  g->n = n; g->ncols = n; g->nnz = nnz; g->nlev = P.nlevels;
+  permuted_matrix(n, ncols, rowptr, col, val, P.perm, base);
+  g->n = n; g->ncols = std::max<int64_t>(ncols, n); g->nnz = nnz; g->nlev = P.nlevels;
   g->lvl_ptr.clear(); g->segs.clear();
   RC_TRY(dev_upload(&g->rowptr, base.prow.data(), n + 1));
   RC_TRY(dev_upload(&g->col, base.pcol.data(), nnz));
@@ -1009,9 +1009,13 @@ int bw_build(GsSchedule* g, int64_t n, const int32_t* rowptr, const int32_t* col
   g->csr_bytes = (n + 1) * 4 + nnz * kEntB + n * 4;
   g->bytes += g->csr_bytes + n * kRealB;
   RC_TRY(dev_upload(&g->perm, P.perm.data(), n));
-  RC_TRY(dev_upload(&g->permx, P.perm.data(), n));
+  {
+    std::vector<int32_t> permx(g->ncols);   // halo columns of a row-sharded operator keep their place behind the rows
+    for (int64_t c = 0; c < g->ncols; ++c) permx[c] = c < n ? P.perm[c] : (int32_t)c;
+    RC_TRY(dev_upload(&g->permx, permx.data(), g->ncols));
+  }
   g->h_perm = P.perm;
-  g->bytes += 2 * n * 4;
+  g->bytes += n * 4 + g->ncols * 4;
   RC_TRY(dev_upload(&g->bw.blocks, P.blocks.data(), (int64_t)P.blocks.size()));
   if (P.ext_col.empty()) P.ext_col.push_back(0);   // (a single block has no external column)
   RC_TRY(dev_upload(&g->bw.ext_col, P.ext_col.data(), (int64_t)P.ext_col.size()));
@@ -1043,8 +1047,8 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   const int64_t n = nrows;
   BuildTimer tm;
   g->bytes = 0;
-  if (g_gs_bw > 0 && nrhs_hint == 1 && ncols <= n && n > 0 && (g_gs_bw == 2 || n >= g_gs_bw_min_rows)) {
-    const int rcb = bw_build(g, n, rowptr, col, val, tm);
+  if (g_gs_bw > 0 && nrhs_hint == 1 && n > 0 && (g_gs_bw == 2 || n >= g_gs_bw_min_rows)) {
+    const int rcb = bw_build(g, n, ncols, rowptr, col, val, tm);
     if (rcb != AMGH_OK) return rcb;
     if (g->bw.rec) return AMGH_OK;
   }
@@ -1654,7 +1658,7 @@ int csr_ensure_gs(amgh_csr* op) {
     HIP_TRY(hipMemcpy(val.data(), op->val, sizeof(real) * op->nnz, hipMemcpyDeviceToHost));
   }
   GsSchedule* g = new GsSchedule;
-  int rc = gs_build(g, n, op->ncols, rowptr.data(), col.data(), val.data());
+  int rc = gs_build(g, n, op->ncols, rowptr.data(), col.data(), val.data(), op->gs_nrhs_hint);
   if (rc != AMGH_OK) { g->free_dev(); delete g; return rc; }
   op->gs = g;
   op->bytes += g->bytes;

@@ -208,6 +208,14 @@ def main_distributed(args):
     from bench import cpu_baseline, spmv_bytes, uniform
 
     one_gpu = os.environ.get("AMG_DIST_ONE_GPU") == "1"   # functional check on a single-GPU box: every rank on device 0
+    ngpu = int(AMG.hip_lib().amgh_device_count())
+    if not one_gpu and ngpu < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        # more ranks than devices (every rank sees the same count): ranks that set a missing device would fail while the
+        # others wait in a collective for ever — run the functional mode instead and say so in the line
+        one_gpu = True
+        if rank == 0:
+            print(f"bench_dist: {world} ranks but {ngpu} GPU(s) visible: all ranks share device 0 (functional run, not a scaling "
+                  f"measurement)", file=sys.stderr, flush=True)
     if one_gpu:
         local_rank = 0
     transport = getattr(args, "transport", None) or os.environ.get("AMGH_DIST_TRANSPORT", "rccl")
