@@ -980,7 +980,9 @@ void permuted_matrix(int64_t n, int64_t ncols, const int32_t* rowptr, const int3
 int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val, BuildTimer& tm) {
   bw::Params prm;
   prm.target_rows = std::max(64, g_gs_bw_rows);
-  prm.threads = std::max(1, std::min<int>(merge_threads(), 16));
+  // (few host threads: the plan is off the setup's critical path, which is a host thread of its own — the sequential C/F
+  // splitting — sharing a CPU quota with it: 16 threads here cost the 256^3 setup 0.3 s, 4 do not)
+  prm.threads = std::max(1, std::min<int>(merge_threads(), 4));
   bw::Plan P;
   if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_OK;
   tm.lap("block partition + records", n);
