@@ -101,6 +101,8 @@ struct Params {
   int max_rows = 1024;       // hard cap (uint16 local indices, LDS)
   size_t lds_limit = 150 * 1024;
   int threads = 8;
+  bool require_three = false;   // give up right after the offset histogram unless it shows three classes (a caller that would
+                                // reject such a plan anyway: saves the passes over the matrix)
 };
 
 // Returns false when the operator cannot be laid out (rows too long for the LDS budget, local index overflow).
@@ -133,6 +135,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     for (int g = 0; g < 2 && g < (int)gaps.size(); ++g) if (gaps[g].first >= 2) P.cuts[g] = gaps[g].second;
     if (P.cuts[0] > P.cuts[1]) std::swap(P.cuts[0], P.cuts[1]);
   }
+  if (prm.require_three && (P.cuts[0] == 99 || P.cuts[1] == 99)) return false;
   const int cut0 = P.cuts[0], cut1 = P.cuts[1];
   auto cls = [cut0, cut1](int64_t d) { const int b = 31 - __builtin_clz((unsigned)d); return b <= cut0 ? 0 : b <= cut1 ? 1 : 2; };
   // ---- potentials and dependency levels of the symmetrised pattern (one pass in index order) ----
