@@ -1009,6 +1009,19 @@ int amgh_device_bytes_detail(const amgh_t* h, int64_t* out8) {
   out8[7] = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * kRealB : 0);
   return AMGH_OK;
 }
+// Diagnostics of the chained wavefront of blocks (gs_bw_chain_kernel): how many flag polls gave up (always 0: a block
+// only waits for blocks with smaller tickets; the bound turns a protocol error into wrong numbers instead of a hang).
+// -1 when level l has no such schedule.  Synchronises the device.
+int amgh_debug_bw_poll_giveups(const amgh_t* h, int l) {
+  if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
+  amgh_csr* M = h->levels[l]->smat();
+  const GsSchedule* g = M->gs;
+  if (!g || !g->bw.err) return -1;
+  int32_t v = 0;
+  if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(&v, g->bw.err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)v;
+}
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
   amgh_csr* M = h->levels[l]->smat();
@@ -1047,12 +1060,13 @@ int amgh_gs_sweep_stats(const amgh_t* h, int l, int backward, int64_t* out6) {
     return AMGH_OK;
   }
   if (g->bw.rec) {   // wavefront of blocks: the operator's own entries (padded to the record's row width), no pre-pass
-    out6[0] = (int64_t)g->bw.launch_ptr.size() - 1;
+    const int64_t depths = (int64_t)g->bw.launch_ptr.size() - 1;
+    out6[0] = (g_gs_bw_chain && g->bw.flags) ? 1 : depths;   // chained by flags: one launch per sweep
     out6[1] = g->n;
     out6[2] = g->nnz - g->n;
     out6[3] = g->bw.rec_entries;
     out6[4] = 0;
-    out6[5] = out6[0] > 0 ? (g->nlev + out6[0] - 1) / out6[0] : 0;
+    out6[5] = depths > 0 ? (g->nlev + depths - 1) / depths : 0;
     return AMGH_OK;
   }
   const GsSchedule* c = backward ? g->mb : g->mf;
@@ -1664,6 +1678,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_tiny")) g_gs_tiny = value;
   else if (!strcmp(name, "gs_bw")) g_gs_bw = value;
   else if (!strcmp(name, "gs_bw_rows")) g_gs_bw_rows = value;
+  else if (!strcmp(name, "gs_bw_chain")) g_gs_bw_chain = value;
   else if (!strcmp(name, "gs_bw_min_rows")) g_gs_bw_min_rows = value;
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;
   else if (!strcmp(name, "jacobi_zero")) g_jacobi_zero = value;

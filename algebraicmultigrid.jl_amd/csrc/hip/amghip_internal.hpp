@@ -212,6 +212,10 @@ struct GsSchedule {
     size_t lds_max = 0; int maxk = 0;
     int64_t rec_bytes = 0, rec_entries = 0, sum_depth = 0;
     double est_seconds = 0.0;
+    // the whole sweep as ONE launch (gs_bw_chain_kernel): blocks chained by flags instead of kernel boundaries
+    int32_t *dep_ptr = nullptr, *dep = nullptr, *sdep_ptr = nullptr, *sdep = nullptr;
+    unsigned int* flags = nullptr; unsigned long long* head = nullptr; int32_t* err = nullptr;
+    int32_t nblocks = 0;
   } bw;
   // the same operator as one record walked by a single wave (gs_wave_kernel): built when it fits (rows of at most
   // kWaveMaxK off-diagonal entries, at most kWaveMaxSteps steps, the LDS budget)
@@ -314,7 +318,9 @@ struct GsSchedule {
     hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
     hipFree(scol); hipFree(sval); hipFree(schunk); scol = nullptr; sval = nullptr; schunk = nullptr;
     hipFree(ww_rec); ww_rec = nullptr;
-    hipFree(bw.blocks); hipFree(bw.rec); hipFree(bw.ext_col); bw = Bw();
+    hipFree(bw.blocks); hipFree(bw.rec); hipFree(bw.ext_col);
+    hipFree(bw.dep_ptr); hipFree(bw.dep); hipFree(bw.sdep_ptr); hipFree(bw.sdep); hipFree(bw.flags); hipFree(bw.head); hipFree(bw.err);
+    bw = Bw();
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
     hipFree(perm); hipFree(dpos); if (!diag_shared) hipFree(diag);
     hipFree(rowmeta); hipFree(desc); hipFree(bp); hipFree(xp); hipFree(permx);
@@ -366,6 +372,7 @@ int g_rhs_il = 1;               // blocks of 2 / 4 / 8 / 16 right-hand sides: re
 int g_gs_tiny = 1;              // an operator that fits LDS entirely: 1 = gs_wave_kernel where its record was built, else gs_chain_tiny_kernel; 2 = gs_chain_tiny_kernel; 0 = gs_chain_kernel; read at every sweep
 int g_gs_bw = 1;                // wavefront of blocks for single-right-hand-side hierarchies (gs_blocks.hpp): 0 off, 1 where the cost model prefers it, 2 always (tests); read at schedule build
 int g_gs_bw_rows = 512;         // ... rows per block aimed at
+int g_gs_bw_chain = 1;          // the wavefront of blocks as one launch per sweep, blocks chained by flags (0: one launch per depth of the quotient graph)
 int g_gs_bw_min_rows = 3000000; // ... operators below this many rows keep the level schedules (mode 1): 128^3 (2.1 M rows) is 10 % faster on merged groups, 160^3 (4.1 M) equal, 192^3 9 % and 256^3 13 % faster as a wavefront of blocks
 int g_gs_sample = 1;            // candidate group sizes of the merged sweeps from a sample of the groups (0 = every candidate built in full); read at schedule build
 int g_gs_sell = 1;              // merged groups from the SELL-like layout where it was built (0 = slot kernels); build: read at schedule build too

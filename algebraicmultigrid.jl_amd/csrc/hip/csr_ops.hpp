@@ -503,7 +503,14 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
   }
   if (g->bw.rec) {   // wavefront of blocks: one launch per depth of the quotient DAG, one wave walking each block
     bw::Args<real> ba{g->bw.blocks, g->bw.rec, g->bw.ext_col, rhs, xp, ldb, xs, omega, 0, nullptr};
-    const hipError_t e = bw::sweep<real>(ba, g->bw.maxk, g->bw.launch_ptr, g->bw.lds_max, sor, backward, ncolv, st);
+    hipError_t e;
+    if (g_gs_bw_chain && ncolv == 1 && g->bw.flags) {   // one launch, blocks chained by flags
+      bw::ChainArgs<real> ca{ba, backward ? g->bw.sdep_ptr : g->bw.dep_ptr, backward ? g->bw.sdep : g->bw.dep, g->bw.flags, g->bw.head,
+                             g->bw.nblocks, g->bw.err};
+      e = bw::sweep_chain<real>(ca, g->bw.maxk, g->bw.lds_max, sor, backward, st);
+    } else {
+      e = bw::sweep<real>(ba, g->bw.maxk, g->bw.launch_ptr, g->bw.lds_max, sor, backward, ncolv, st);
+    }
     if (e != hipSuccess) return -(1000 + (int)e);
   }
   const int ns = (int)lay->segs.size();

@@ -35,7 +35,7 @@ namespace bw {
 struct Desc {          // one block (32 bytes)
   int32_t row0, nrows; // rows of the block in block order (sorted by in-block dependency level)
   int32_t rec;         // the block's record in the record buffer, in units of 16 bytes
-  int32_t S;           // (unused: rows of a packed record are Packed<R>::row_bytes(maxk) apart)
+  int32_t npre;        // external columns that lie BEFORE the block in block order (the first npre of the sorted list): written by predecessor blocks
   int32_t ext0, next;  // external columns: positions of x gathered into LDS behind the block's own x
   int32_t nlev, maxk;  // STEPS of the block: pieces of <= 64 rows of one in-block dependency level, in order; off-diagonal entries per row (padded, a multiple of kChunk)
 };
@@ -75,13 +75,16 @@ struct Plan {
   std::vector<int64_t> launch_rec;  // byte offset of launch l's first record (launch_rec[nlaunch] = all records)
   std::vector<int32_t> ext_col;     // block-order positions
   std::vector<unsigned char> rec;   // the records, one after the other
+  std::vector<int32_t> dep_ptr, dep;    // quotient graph on ordered blocks: the blocks a block waits for in the forward sweep ...
+  std::vector<int32_t> sdep_ptr, sdep;  // ... and in the backward sweep (its successors); the chained kernel (one launch per sweep)
   size_t lds_max = 0;               // largest dynamic LDS request of a block
   // what the cost model looks at
   int nlevels = 0;                  // dependency levels of the operator
   int64_t sum_depth = 0;            // sum over launches of the deepest block's level count
   int64_t ext_total = 0;
   int max_rows = 0;
-  double est_seconds = 0.0;         // modelled time of one directional sweep
+  double est_seconds = 0.0;         // modelled time of one directional sweep, one launch per depth ...
+  double est_chain_seconds = 0.0;   // ... and as one launch, blocks chained by flags
   int cuts[2] = {99, 99};
   int32_t range[3] = {1, 1, 1};
   int32_t cells[3] = {1, 1, 1};
@@ -238,9 +241,9 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   for (int k = 0; k < 3; ++k) std::vector<int32_t>().swap(phi[k]);
   // ---- launches: longest path in the quotient graph ----
   std::vector<int32_t> blev(B, 0);
+  std::vector<int64_t> eptr(B + 1, 0);   // edges (block of c) -> (block of i) for c < i adjacent, collected per target block (pre-order)
+  std::vector<int32_t> esrc;
   {
-    // edges (block of c) -> (block of i) for c < i adjacent, collected per target block
-    std::vector<int64_t> eptr(B + 1, 0);
     for (int64_t i = 0; i < n; ++i)
       for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
         const int32_t c = col[j];
@@ -248,7 +251,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
         eptr[(c < i ? blk[i] : blk[c]) + 1]++;
       }
     for (int32_t b = 0; b < B; ++b) eptr[b + 1] += eptr[b];
-    std::vector<int32_t> esrc(eptr[B]);
+    esrc.resize(eptr[B]);
     std::vector<int64_t> next(eptr.begin(), eptr.end() - 1);
     for (int64_t i = 0; i < n; ++i)
       for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
@@ -304,6 +307,30 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   });
   std::vector<int32_t> obk(B);   // pre-order block -> ordered block
   for (int32_t ob = 0; ob < B; ++ob) obk[order[ob]] = ob;
+  // ---- the quotient graph on ordered blocks (distinct predecessors / successors of every block) ----
+  {
+    P.dep_ptr.assign(B + 1, 0);
+    std::vector<std::vector<int32_t>> pre(B);
+    parallel_for(T, [&](int t, int TT) {
+      for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
+        const int32_t b = order[ob];
+        std::vector<int32_t>& v = pre[ob];
+        for (int64_t e = eptr[b]; e < eptr[b + 1]; ++e) v.push_back(obk[esrc[e]]);
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+      }
+    });
+    P.sdep_ptr.assign(B + 1, 0);
+    for (int32_t ob = 0; ob < B; ++ob) { P.dep_ptr[ob + 1] = P.dep_ptr[ob] + (int32_t)pre[ob].size(); for (int32_t q : pre[ob]) P.sdep_ptr[q + 1]++; }
+    for (int32_t ob = 0; ob < B; ++ob) P.sdep_ptr[ob + 1] += P.sdep_ptr[ob];
+    P.dep.resize(P.dep_ptr[B]); P.sdep.resize(P.sdep_ptr[B]);
+    std::vector<int32_t> nx(P.sdep_ptr.begin(), P.sdep_ptr.end() - 1);
+    for (int32_t ob = 0; ob < B; ++ob) {
+      std::copy(pre[ob].begin(), pre[ob].end(), P.dep.begin() + P.dep_ptr[ob]);
+      for (int32_t q : pre[ob]) P.sdep[nx[q]++] = ob;
+    }
+    std::vector<int64_t>().swap(eptr); std::vector<int32_t>().swap(esrc);
+  }
   // ---- external columns, record offsets ----
   std::vector<int64_t> ext_ptr(B + 1, 0);
   std::vector<std::vector<int32_t>> exts(B);
@@ -328,7 +355,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   bool fits = true;
   for (int32_t ob = 0; ob < B; ++ob) {
     Desc& d = P.blocks[ob];
-    d.S = (d.nrows + 7) & ~7;
+    d.npre = (int32_t)(std::lower_bound(exts[ob].begin(), exts[ob].end(), d.row0) - exts[ob].begin());
     d.maxk = maxk;
     int32_t nl = 0, run = 0, last = -1;   // steps: a level's rows in pieces of 64 (rows are sorted by level)
     for (int32_t p = 0; p < d.nrows; ++p) {
@@ -345,7 +372,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     rec_total += Packed<R>::rec_bytes(d.nrows, d.maxk, d.nlev);
     const size_t l = Packed<R>::lds_bytes(d);
     P.lds_max = std::max(P.lds_max, l);
-    if (d.nrows + d.next + 1 > 65535 || d.nlev > 65534 || l > 160 * 1024) fits = false;
+    if (d.nrows + d.next + 1 > 65535 || d.nlev > 65534 || l > 160 * 1024 - 64) fits = false;   // (- 64: the chained kernel's static LDS)
     if ((size_t)(d.nrows + d.next + 1) * sizeof(R) > 65535) fits = false;   // byte offsets in 16 bits
     P.max_rows = std::max(P.max_rows, d.nrows);
   }
@@ -414,6 +441,16 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
       tsec += 1.6e-6 + 0.4e-6 + std::max(1.4e-6, bytes / 4.5e12 + 0.8e-6) + depth * step;
     }
     P.est_seconds = tsec;
+    // chained by flags (one launch per sweep): along the critical path a depth costs its deepest block's walk plus the hand-off
+    // (write-through, flag, the fetch behind it: 2.3 us), the record loads run ahead of it; in the wide middle of the wavefront the
+    // LDS slots bound the rate instead (a block holds its slot for load + wait + walk).  256^3: modelled 0.90, measured 0.93 ms
+    {
+      const double step = 0.21e-6 + 0.0095e-6 * maxk;
+      const double slots = 256.0 * std::max<size_t>(1, (160 * 1024) / std::max<size_t>(1, P.lds_max));
+      double walk_all = 0.0;
+      for (const Desc& d : P.blocks) walk_all += 4.8e-6 + d.nlev * step;
+      P.est_chain_seconds = (double)P.sum_depth * step + nlaunch * 2.3e-6 + 0.3 * walk_all / slots;
+    }
   }
   return true;
 }
@@ -483,33 +520,67 @@ __device__ __forceinline__ void packed_row(const PackedOps<R, MAXK>& o, R* xl, R
     xl[o.p] = q;
   }
 }
+// A block's inputs into LDS with every global load of a thread in flight at once: a load / LDS-store loop costs one memory
+// round trip per iteration (the compiler waits for each load before its store), and the external x values are two
+// dependent round trips away (their positions first) — so the positions are requested first, then b, x and the record
+// in batches of 8 x 16 bytes per thread, then the gathers, and only then anything is waited for.
+// External columns [e0, e1) only (the chained kernel fetches the others after its flags).
+// (keeps a loaded value — and so its load — above this point: without it the compiler sinks every load into the
+// conditional LDS store that uses it, one memory round trip after the other)
+__device__ __forceinline__ void pin(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void pin(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(int32_t& v) { asm volatile("" : "+v"(v)); }
+template <typename R>
+__device__ __forceinline__ void block_load(const Args<R>& a, const Desc& d, const R* __restrict__ b, const R* x, R* xl, R* bl,
+                                           unsigned char* rec, int recb, int e0, int e1, int tid) {
+  constexpr int EU = 2, RU = 8;
+  int32_t ec[EU];
+#pragma unroll
+  for (int k = 0; k < EU; ++k) { const int e = e0 + tid + k * kThreads; ec[k] = a.ext_col[e < e1 ? d.ext0 + e : 0]; }   // (idle lanes: entry 0, a valid position)
+  R bv[2], xv[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { const int p = tid + k * kThreads; const int q = d.row0 + (p < d.nrows ? p : 0); bv[k] = b[q]; xv[k] = x[q]; }
+  const uint4* src = (const uint4*)(a.rec + (size_t)(uint32_t)d.rec * 16);
+  uint4* dst = (uint4*)rec;
+  const int nq = recb >> 4;
+  uint4 r[RU];
+#pragma unroll
+  for (int k = 0; k < RU; ++k) { const int e = tid + k * kThreads; r[k] = src[e < nq ? e : 0]; }
+  R xe[EU];
+#pragma unroll
+  for (int k = 0; k < EU; ++k) xe[k] = x[ec[k]];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { pin(bv[k]); pin(xv[k]); }
+#pragma unroll
+  for (int k = 0; k < RU; ++k) pin(r[k]);
+#pragma unroll
+  for (int k = 0; k < EU; ++k) pin(xe[k]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { const int p = tid + k * kThreads; if (p < d.nrows) { bl[p] = bv[k]; xl[p] = xv[k]; } }
+#pragma unroll
+  for (int k = 0; k < RU; ++k) { const int e = tid + k * kThreads; if (e < nq) dst[e] = r[k]; }
+  for (int e8 = tid + RU * kThreads; e8 < nq; e8 += RU * kThreads) {   // (records beyond 64 KB)
+#pragma unroll
+    for (int k = 0; k < RU; ++k) { const int e = e8 + k * kThreads; r[k] = src[e < nq ? e : 0]; }
+#pragma unroll
+    for (int k = 0; k < RU; ++k) pin(r[k]);
+#pragma unroll
+    for (int k = 0; k < RU; ++k) { const int e = e8 + k * kThreads; if (e < nq) dst[e] = r[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < EU; ++k) { const int e = e0 + tid + k * kThreads; if (e < e1) xl[d.nrows + e] = xe[k]; }
+  for (int p = tid + 2 * kThreads; p < d.nrows; p += kThreads) { bl[p] = b[d.row0 + p]; xl[p] = x[d.row0 + p]; }        // (never: blocks hold <= 1024 rows)
+  for (int e = e0 + tid + EU * kThreads; e < e1; e += kThreads) xl[d.nrows + e] = x[a.ext_col[d.ext0 + e]];            // (more than 1024 external columns)
+  if (tid == 0) xl[d.nrows + d.next] = (R)0;
+}
+// wave 0 walks the block's steps (rows of one in-block dependency level, at most 64): the next step's operands are loaded
+// while the current one is summed; LDS operations of one wave execute in program order — no barrier
 template <typename R, bool SOR, bool BWD, int MAXK>
-__global__ __launch_bounds__(kThreads) void gs_bw_packed_kernel(Args<R> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const long long t_start = a.tim ? wall_clock64() : 0;
-  const Desc d = a.blocks[a.block0 + blockIdx.x];
-  const int tid = threadIdx.x;
-  const R* __restrict__ b = a.b + (int64_t)blockIdx.y * a.ldb;
-  R* __restrict__ x = a.x + (int64_t)blockIdx.y * a.ldx;
+__device__ __forceinline__ void packed_walk(const unsigned char* rec, const R* bl, R* xl, const Desc& d, int tid, R omega) {
   typedef PackedOps<R, MAXK> O;
   constexpr int KCH = (O::NVC + O::NCC) | 1;
-  const int nxb = (int)(((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15), nbb = (int)(((size_t)d.nrows * sizeof(R) + 15) & ~(size_t)15);
-  R* xl = (R*)lds;
-  R* bl = (R*)(lds + nxb);
-  unsigned char* rec = lds + nxb + nbb;
   const int ns = d.nlev;
-  const int recb = (int)(((size_t)d.nrows * (16 * KCH) + (size_t)(ns + 1) * 2 + 15) & ~(size_t)15);
-  {
-    const uint4* src = (const uint4*)(a.rec + (size_t)(uint32_t)d.rec * 16);
-    uint4* dst = (uint4*)rec;
-    for (int e = tid; e < (recb >> 4); e += kThreads) dst[e] = src[e];
-  }
-  for (int p = tid; p < d.nrows; p += kThreads) { bl[p] = b[d.row0 + p]; xl[p] = x[d.row0 + p]; }
-  for (int e = tid; e < d.next; e += kThreads) xl[d.nrows + e] = x[a.ext_col[d.ext0 + e]];
-  if (tid == 0) xl[d.nrows + d.next] = (R)0;
-  __syncthreads();
-  if (tid >= 64) return;
-  const long long t_loaded = a.tim ? wall_clock64() : 0;
   const uint16_t* stp = (const uint16_t*)(rec + (size_t)d.nrows * (16 * KCH));
   const int lp0 = tid <= ns ? (int)stp[tid] : d.nrows;
   const int lp1 = tid + 64 <= ns ? (int)stp[tid + 64] : d.nrows;
@@ -537,19 +608,170 @@ __global__ __launch_bounds__(kThreads) void gs_bw_packed_kernel(Args<R> a) {
   for (int k = 0; k < ns; k += 2) {
     BW_RANGE(k + 1, r0, r1);
     packed_load<R, MAXK>(B, r0 + tid, r0 + tid < r1, rec, bl);
-    packed_row<R, MAXK, SOR>(A, xl, a.omega);
+    packed_row<R, MAXK, SOR>(A, xl, omega);
     BW_RANGE(k + 2, r0, r1);
     packed_load<R, MAXK>(A, r0 + tid, r0 + tid < r1, rec, bl);
-    packed_row<R, MAXK, SOR>(B, xl, a.omega);
+    packed_row<R, MAXK, SOR>(B, xl, omega);
   }
 #undef BW_RANGE
 #undef BW_SP
+}
+template <typename R, bool SOR, bool BWD, int MAXK>
+__global__ __launch_bounds__(kThreads) void gs_bw_packed_kernel(Args<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const long long t_start = a.tim ? wall_clock64() : 0;
+  const Desc d = a.blocks[a.block0 + blockIdx.x];
+  const int tid = threadIdx.x;
+  const R* __restrict__ b = a.b + (int64_t)blockIdx.y * a.ldb;
+  R* __restrict__ x = a.x + (int64_t)blockIdx.y * a.ldx;
+  typedef PackedOps<R, MAXK> O;
+  constexpr int KCH = (O::NVC + O::NCC) | 1;
+  const int nxb = (int)(((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15), nbb = (int)(((size_t)d.nrows * sizeof(R) + 15) & ~(size_t)15);
+  R* xl = (R*)lds;
+  R* bl = (R*)(lds + nxb);
+  unsigned char* rec = lds + nxb + nbb;
+  const int ns = d.nlev;
+  const int recb = (int)(((size_t)d.nrows * (16 * KCH) + (size_t)(ns + 1) * 2 + 15) & ~(size_t)15);
+  block_load<R>(a, d, b, x, xl, bl, rec, recb, 0, d.next, tid);
+  __syncthreads();
+  if (tid >= 64) return;
+  const long long t_loaded = a.tim ? wall_clock64() : 0;
+  packed_walk<R, SOR, BWD, MAXK>(rec, bl, xl, d, tid, a.omega);
   const long long t_swept = a.tim ? wall_clock64() : 0;
   for (int p = tid; p < d.nrows; p += 64) x[d.row0 + p] = xl[p];
   if (a.tim && tid == 0) {
     long long* t = a.tim + 4 * (int64_t)(a.block0 + blockIdx.x);
     t[0] = t_start; t[1] = t_loaded; t[2] = t_swept; t[3] = wall_clock64();
   }
+}
+
+// ---- the whole sweep in ONE launch: blocks chained by flags ------------------------------------------------------------
+// The launches above pay, per depth of the quotient graph, a kernel boundary AND the blocks' own load (the record has to
+// arrive before the walk starts) AND the deepest block of the launch.  Here every workgroup draws a ticket (its block,
+// in the order of the launches: a block only waits for blocks with smaller tickets, which are running or done whatever
+// the dispatch order — no deadlock), loads its record, b and x without waiting for anybody, then wave 0 polls the flags
+// of the blocks it depends on, fetches the x values they wrote (agent-scope loads: past this CU's L1 and this XCD's L2),
+// walks, writes its x through (agent-scope stores), drains them and raises its own flag.  Flags hold the sweep's epoch
+// (the ticket counter divided by the number of blocks: no reset between sweeps, graph-replay safe).
+template <typename R>
+struct ChainArgs {
+  Args<R> a;
+  const int32_t* dep_ptr; const int32_t* dep;   // the blocks a block waits for (of this direction)
+  unsigned int* flags;                          // per block: epoch of the last sweep that finished it
+  unsigned long long* head;                     // ticket counter (never reset)
+  int32_t nblocks;
+  int32_t* err;                                 // set when a poll gave up (cannot happen; bounds a hang to seconds)
+};
+template <typename R> __device__ __forceinline__ R agent_load(const R* p);
+template <> __device__ __forceinline__ double agent_load<double>(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <> __device__ __forceinline__ float agent_load<float>(const float* p) {
+  return __uint_as_float(__hip_atomic_load((const unsigned int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void agent_store(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_store(float* p, float v) {
+  __hip_atomic_store((unsigned int*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename R, bool SOR, bool BWD, int MAXK>
+__global__ __launch_bounds__(kThreads) void gs_bw_chain_kernel(ChainArgs<R> c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  __shared__ unsigned long long s_ticket;
+  const Args<R>& a = c.a;
+  const int tid = threadIdx.x;
+  const long long t_start = a.tim ? wall_clock64() : 0;
+  if (tid == 0) s_ticket = atomicAdd(c.head, 1ull);
+  __syncthreads();
+  const unsigned long long ticket = s_ticket;
+  const unsigned int epoch = (unsigned int)(ticket / (unsigned long long)c.nblocks) + 1u;
+  const int t = (int)(ticket % (unsigned long long)c.nblocks);
+  const int ob = BWD ? c.nblocks - 1 - t : t;
+  const Desc d = a.blocks[ob];
+  const R* __restrict__ b = a.b;
+  R* x = a.x;
+  typedef PackedOps<R, MAXK> O;
+  constexpr int KCH = (O::NVC + O::NCC) | 1;
+  const int nxb = (int)(((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15), nbb = (int)(((size_t)d.nrows * sizeof(R) + 15) & ~(size_t)15);
+  R* xl = (R*)lds;
+  R* bl = (R*)(lds + nxb);
+  unsigned char* rec = lds + nxb + nbb;
+  const int ns = d.nlev;
+  const int recb = (int)(((size_t)d.nrows * (16 * KCH) + (size_t)(ns + 1) * 2 + 15) & ~(size_t)15);
+  // external x that nobody writes before this block has run: the far side of the sweep (and halo columns)
+  const int e0 = BWD ? 0 : d.npre, e1 = BWD ? d.npre : d.next;
+  block_load<R>(a, d, b, x, xl, bl, rec, recb, e0, e1, tid);
+  __syncthreads();
+  if (tid >= 64) return;
+  const long long t_loaded = a.tim ? wall_clock64() : 0;
+  // the near side: positions now (static data), values once the flags are up — one round trip behind the last flag
+  const int f0 = BWD ? d.npre : 0, f1 = BWD ? d.next : d.npre;
+  constexpr int FU = 6;   // 384 values by one wave in one batch (a 512-row block of a 7-point grid has 192 per side)
+  int32_t fc[FU];
+#pragma unroll
+  for (int k = 0; k < FU; ++k) { const int e = f0 + tid + 64 * k; fc[k] = a.ext_col[e < f1 ? d.ext0 + e : 0]; }
+#pragma unroll
+  for (int k = 0; k < FU; ++k) pin(fc[k]);
+  // the blocks this one depends on have raised their flags
+  for (int e = c.dep_ptr[ob] + tid; e < c.dep_ptr[ob + 1]; e += 64) {
+    const unsigned int* f = c.flags + c.dep[e];
+    int spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 24)) { *c.err = 1; break; }
+    }
+  }
+  // (the polls above are complete for every lane before any lane goes on: the loop is left by the whole wave)
+  asm volatile("" ::: "memory");   // the fetches below stay below
+  {
+    R fv[FU];
+#pragma unroll
+    for (int k = 0; k < FU; ++k) fv[k] = agent_load<R>(x + fc[k]);
+#pragma unroll
+    for (int k = 0; k < FU; ++k) pin(fv[k]);
+#pragma unroll
+    for (int k = 0; k < FU; ++k) { const int e = f0 + tid + 64 * k; if (e < f1) xl[d.nrows + e] = fv[k]; }
+    for (int e = f0 + tid + 64 * FU; e < f1; e += 64) xl[d.nrows + e] = agent_load<R>(x + a.ext_col[d.ext0 + e]);
+  }
+  const long long t_ready = a.tim ? wall_clock64() : 0;
+  packed_walk<R, SOR, BWD, MAXK>(rec, bl, xl, d, tid, a.omega);
+  const long long t_swept = a.tim ? wall_clock64() : 0;
+  for (int p = tid; p < d.nrows; p += 64) agent_store(x + d.row0 + p, xl[p]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) __hip_atomic_store(c.flags + ob, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.tim && tid == 0) {
+    long long* tt = a.tim + 5 * (int64_t)ob;
+    tt[0] = t_start; tt[1] = t_loaded; tt[2] = t_ready; tt[3] = t_swept; tt[4] = wall_clock64();
+  }
+}
+template <typename R, int MAXK>
+inline hipError_t sweep_chain_k(const ChainArgs<R>& c, size_t lds_max, bool sor, bool backward, hipStream_t st) {
+  static std::atomic<uint64_t> attr_set{0};   // (the kernel's static 8 bytes — the ticket — count against the 160 KB as well)
+  int dev = 0;
+  if (lds_max > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && !((attr_set.load() >> (dev & 63)) & 1)) {
+    (void)hipFuncSetAttribute((const void*)gs_bw_chain_kernel<R, false, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    (void)hipFuncSetAttribute((const void*)gs_bw_chain_kernel<R, false, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    (void)hipFuncSetAttribute((const void*)gs_bw_chain_kernel<R, true, false, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    (void)hipFuncSetAttribute((const void*)gs_bw_chain_kernel<R, true, true, MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    attr_set.fetch_or((uint64_t)1 << (dev & 63));
+  }
+  const dim3 grid((unsigned)c.nblocks);
+  if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_chain_kernel<R, true, true, MAXK>), grid, dim3(kThreads), lds_max, st, c); else hipLaunchKernelGGL((gs_bw_chain_kernel<R, true, false, MAXK>), grid, dim3(kThreads), lds_max, st, c); }
+  else { if (backward) hipLaunchKernelGGL((gs_bw_chain_kernel<R, false, true, MAXK>), grid, dim3(kThreads), lds_max, st, c); else hipLaunchKernelGGL((gs_bw_chain_kernel<R, false, false, MAXK>), grid, dim3(kThreads), lds_max, st, c); }
+  return hipGetLastError();
+}
+// (c.dep_ptr / c.dep: the caller passes the predecessor lists for a forward sweep, the successor lists for a backward one)
+template <typename R>
+inline hipError_t sweep_chain(const ChainArgs<R>& c, int maxk, size_t lds_max, bool sor, bool backward, hipStream_t st) {
+  switch (maxk) {
+    case 6: return sweep_chain_k<R, 6>(c, lds_max, sor, backward, st);
+    case 12: return sweep_chain_k<R, 12>(c, lds_max, sor, backward, st);
+#if BW_PLAN_MAXK >= 18
+    case 18: return sweep_chain_k<R, 18>(c, lds_max, sor, backward, st);
+#endif
+  }
+  return hipErrorInvalidValue;
 }
 
 // launches of one directional sweep: blocks of launch l = [launch_ptr[l], launch_ptr[l + 1])

@@ -994,11 +994,12 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
     // clearly cheaper than groups of ~3 merged levels with ~1.8 x the entries (what such operators get otherwise)
     const bool three = P.range[0] > 1 && P.range[1] > 1 && P.range[2] > 1;
     const double merged = merge_cost((P.nlevels + 2) / 3, (int64_t)(1.8 * (double)nnz));
+    const double est = g_gs_bw_chain ? P.est_chain_seconds : P.est_seconds;
     if (getenv("AMGH_VERBOSE"))
-      fprintf(stderr, "[amghip] n=%lld wavefront of blocks: %zu blocks, %d launches (dependency levels %d), model %.3f ms vs %.3f ms merged -> %s\n",
-              (long long)n, P.blocks.size(), nlaunch, P.nlevels, P.est_seconds * 1e3, merged * 1e3,
-              (three && P.est_seconds < 0.8 * merged) ? "used" : "not used");
-    if (!three || !(P.est_seconds < 0.8 * merged)) return AMGH_OK;
+      fprintf(stderr, "[amghip] n=%lld wavefront of blocks: %zu blocks, %d depths (dependency levels %d), model %.3f ms (%.3f as one launch per depth) vs %.3f ms merged -> %s\n",
+              (long long)n, P.blocks.size(), nlaunch, P.nlevels, est * 1e3, P.est_seconds * 1e3, merged * 1e3,
+              (three && est < 0.8 * merged) ? "used" : "not used");
+    if (!three || !(est < 0.8 * merged)) return AMGH_OK;
   }
   HostLevelCsr base;
   permuted_matrix(n, ncols, rowptr, col, val, P.perm, base);
@@ -1024,6 +1025,23 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   RC_TRY(dev_upload(&g->bw.ext_col, P.ext_col.data(), (int64_t)P.ext_col.size()));
   RC_TRY(dev_upload(&g->bw.rec, P.rec.data(), (int64_t)P.rec.size()));
   g->bw.launch_ptr = P.launch_ptr;
+  {   // the quotient graph and the flags of the chained sweep
+    const int64_t B = (int64_t)P.blocks.size();
+    if (P.dep.empty()) P.dep.push_back(0);
+    if (P.sdep.empty()) P.sdep.push_back(0);
+    RC_TRY(dev_upload(&g->bw.dep_ptr, P.dep_ptr.data(), B + 1));
+    RC_TRY(dev_upload(&g->bw.dep, P.dep.data(), (int64_t)P.dep.size()));
+    RC_TRY(dev_upload(&g->bw.sdep_ptr, P.sdep_ptr.data(), B + 1));
+    RC_TRY(dev_upload(&g->bw.sdep, P.sdep.data(), (int64_t)P.sdep.size()));
+    RC_TRY(dev_alloc(&g->bw.flags, B));
+    RC_TRY(dev_alloc(&g->bw.head, 1));
+    RC_TRY(dev_alloc(&g->bw.err, 1));
+    if (hipMemset(g->bw.flags, 0, (size_t)B * 4) != hipSuccess || hipMemset(g->bw.head, 0, 8) != hipSuccess ||
+        hipMemset(g->bw.err, 0, 4) != hipSuccess)
+      return -1001;
+    g->bw.nblocks = (int32_t)B;
+    g->bytes += (2 * (B + 1) + (int64_t)P.dep.size() + (int64_t)P.sdep.size() + B) * 4 + 12;
+  }
   g->bw.lds_max = P.lds_max; g->bw.maxk = P.blocks[0].maxk;
   g->bw.rec_bytes = (int64_t)P.rec.size() + (int64_t)P.blocks.size() * (int64_t)sizeof(bw::Desc) + (int64_t)P.ext_col.size() * 4;
   g->bw.rec_entries = n * (int64_t)g->bw.maxk;

@@ -462,6 +462,12 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
 int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t* col, const amgh_real* val, int target_rows,
                              int backward, double omega, amgh_real* x, const amgh_real* b, int64_t* stats4);
 
+/* Diagnostics of the chained wavefront of blocks (one launch per sweep, blocks ordered by flags instead of kernel
+ * boundaries): the number of flag polls that gave up on level l — always 0 (a block only waits for blocks holding
+ * smaller tickets); the bound exists so that a protocol error would give wrong numbers instead of a hang.  -1 when the
+ * level has no such schedule.  Synchronises the device.                                                              */
+int amgh_debug_bw_poll_giveups(const amgh_t* h, int l);
+
 /* Diagnostics: tunables of the Gauss-Seidel execution (process-wide; used by tools/ to pick the defaults and by
  * tests to force every path).  Read at every sweep: "gs_xcd_map", "gs_block_pipe", "gs_flip", "gs_keep_lo",
  * "gs_slots", "gs_block_target", "gs_min_rows", "gs_threads", "gs_nnz_per_wg", "gs_tiny" (operators that fit LDS
@@ -472,7 +478,9 @@ int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t
  * (amgh_push_level, first stand-alone sweep of an operator): "gs_merge" (largest group of dependency levels tried),
  * "gs_bigslot" (0 off, 1 cost model, 2 always), "gs_super" (blocks per superblock), "gs_block_inverse", "gs_bw" (the
  * wavefront-of-blocks layout of single-column hierarchies: 0 off, 1 where its cost model prefers it, 2 always),
- * "gs_bw_rows" (rows per block aimed at, 512), "gs_bw_min_rows" (smallest operator considered in mode 1, 3 000 000 rows).
+ * "gs_bw_rows" (rows per block aimed at, 512), "gs_bw_min_rows" (smallest operator considered in mode 1, 3 000 000 rows);
+ * read at every sweep: "gs_bw_chain" (1: the wavefront of blocks as ONE launch per sweep, blocks chained by flags;
+ * 0: one launch per depth of the quotient graph — bitwise the same sweep).
  * Returns AMGH_EINVAL for an unknown name.                                                                       */
 int amgh_debug_set_tunable(const char* name, int value);
 

@@ -128,7 +128,8 @@ def test_sweep_stats_describe_the_schedule(h128):
         assert st["tri_entries"] > 0 and st["entries"] >= (A.nnz - A.m) // 2
     assert dev.gs_dependency_levels(0) == 3 * 128 - 2
     # the same level as a wavefront of blocks (what single-column hierarchies get from 3 M rows on): the operator's own
-    # off-diagonal entries — no composite rows, no pre-pass —, 3 * 16 - 2 launches for 16^3 blocks of 8^3 rows
+    # off-diagonal entries — no composite rows, no pre-pass —, 3 * 16 - 2 depths of the quotient graph for 16^3 blocks of
+    # 8^3 rows, executed as ONE launch (blocks chained by flags) or, tunable gs_bw_chain = 0, as a launch per depth
     from amg_amd.device import DeviceHierarchy
     lib = AMG.hip_lib()
     lib.amgh_debug_set_tunable(b"gs_bw", 2)
@@ -138,9 +139,26 @@ def test_sweep_stats_describe_the_schedule(h128):
         lib.amgh_debug_set_tunable(b"gs_bw", 1)
     sb = devb.gs_sweep_stats(0, False)
     assert sb["tri_entries"] == 0 and sb["entries"] == A.nnz - A.m and sb["slot_entries"] == 6 * A.m
-    assert sb["launches"] == devb.gs_sweep_steps(0, False) == 46 and devb.gs_dependency_levels(0) == 3 * 128 - 2
+    assert sb["launches"] == 1 and devb.gs_sweep_steps(0, False) == 46 and devb.gs_dependency_levels(0) == 3 * 128 - 2
     b = uniform(A.m, 77)
-    assert rel(devb.precond_apply(b), dev.precond_apply(b)) <= 1e-12
+    zb = devb.precond_apply(b)
+    assert rel(zb, dev.precond_apply(b)) <= 1e-12
+    lib.amgh_debug_set_tunable(b"gs_bw_chain", 0)
+    try:
+        assert devb.gs_sweep_stats(0, False)["launches"] == 46
+        assert np.array_equal(devb.precond_apply(b), zb)        # the same sweep bit for bit
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_bw_chain", 1)
+    assert lib.amgh_debug_bw_poll_giveups(devb.h, 0) == 0 and lib.amgh_debug_bw_poll_giveups(dev.h, 0) == -1
+    # blocks of 10^3 rows: 98 KB of LDS per workgroup (beyond the 64 KB a kernel gets without asking), another partition,
+    # the same sweep bit for bit
+    lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_bw_rows", 1000)
+    try:
+        devc = DeviceHierarchy(ml, 0, 1)
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_bw", 1); lib.amgh_debug_set_tunable(b"gs_bw_rows", 512)
+    assert devc.gs_sweep_steps(0, False) == 3 * 13 - 2 and np.array_equal(devc.precond_apply(b), zb)
+    assert lib.amgh_debug_bw_poll_giveups(devc.h, 0) == 0
 
 
 @pytest.mark.parametrize("cyc", [1, 2])
@@ -269,8 +287,16 @@ def test_wavefront_of_blocks_schedule_vs_oracle_and_level_schedules():
         try:
             dev = DeviceHierarchy(ml, 0, 1)
             x_dev = dev.smooth(0, False, x0, bb)
+            # ONE launch per sweep (blocks chained by flags, the default) and one launch per depth of the quotient graph: the same bits
+            assert dev.gs_sweep_stats(0, False)["launches"] == 1 and lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+            for rep in range(3):      # (epochs of the flags: repeated sweeps on the same schedule)
+                assert np.array_equal(dev.smooth(0, False, x0, bb), x_dev)
+            assert lib.amgh_debug_set_tunable(b"gs_bw_chain", 0) == 0
+            assert dev.gs_sweep_stats(0, False)["launches"] == dev.gs_sweep_steps(0, False) > 1
+            assert np.array_equal(dev.smooth(0, False, x0, bb), x_dev), repr(pre)
+            assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
         finally:
-            lib.amgh_debug_set_tunable(b"gs_bw", 1); lib.amgh_debug_set_tunable(b"gs_bw_rows", 512)
+            lib.amgh_debug_set_tunable(b"gs_bw", 1); lib.amgh_debug_set_tunable(b"gs_bw_rows", 512); lib.amgh_debug_set_tunable(b"gs_bw_chain", 1)
         assert dev.gs_sweep_stats(0, False)["slot_entries"] == 6 * A.m
         assert np.array_equal(x_dev, O.smooth(pre, A, x0, bb, hermitian=True)), repr(pre)
         xh = x0.copy()

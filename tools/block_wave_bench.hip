@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
   CHECK(hipMalloc(&d_b, 8 * n)); CHECK(hipMalloc(&d_x, 8 * n));
   CHECK(hipMemcpy(d_blocks, P.blocks.data(), sizeof(bw::Desc) * P.blocks.size(), hipMemcpyHostToDevice));
   CHECK(hipMemcpy(d_rec, P.rec.data(), P.rec.size(), hipMemcpyHostToDevice));
-  CHECK(hipMemcpy(d_ext, P.ext_col.data(), 4 * P.ext_col.size(), hipMemcpyHostToDevice));
+  CHECK(hipMemset(d_ext, 0, 4 * std::max<size_t>(1, P.ext_col.size()))); CHECK(hipMemcpy(d_ext, P.ext_col.data(), 4 * P.ext_col.size(), hipMemcpyHostToDevice));
   CHECK(hipMemcpy(d_b, bb.data(), 8 * n, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
   bw::Args<double> a{d_blocks, d_rec, d_ext, d_b, d_x, n, n, 1.0, 0, nullptr};
   hipStream_t st; CHECK(hipStreamCreate(&st));
@@ -134,6 +134,71 @@ int main(int argc, char** argv) {
     }
     printf("sum over %d launches: spans %.1f us, gaps %.1f us; mean per launch: load %.2f, sweep %.2f, write-back %.2f us\n", cnt, s_span, s_gap,
            s_load / cnt, s_sweep / cnt, s_store / cnt);
+  }
+  // ---- the same sweeps as ONE launch each: blocks chained by flags (gs_bw_chain_kernel) ----
+  {
+    const int32_t B = (int32_t)P.blocks.size();
+    int32_t *d_dp, *d_d, *d_sp, *d_s, *d_err; unsigned int* d_flags; unsigned long long* d_head; long long* d_tim;
+    CHECK(hipMalloc(&d_dp, 4 * (B + 1))); CHECK(hipMalloc(&d_sp, 4 * (B + 1)));
+    CHECK(hipMalloc(&d_d, 4 * std::max<size_t>(1, P.dep.size()))); CHECK(hipMalloc(&d_s, 4 * std::max<size_t>(1, P.sdep.size())));
+    CHECK(hipMalloc(&d_flags, 4 * (size_t)B)); CHECK(hipMalloc(&d_head, 8)); CHECK(hipMalloc(&d_err, 4)); CHECK(hipMalloc(&d_tim, 40 * (size_t)B));
+    CHECK(hipMemcpy(d_dp, P.dep_ptr.data(), 4 * (B + 1), hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_sp, P.sdep_ptr.data(), 4 * (B + 1), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_d, P.dep.data(), 4 * P.dep.size(), hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_s, P.sdep.data(), 4 * P.sdep.size(), hipMemcpyHostToDevice));
+    CHECK(hipMemset(d_flags, 0, 4 * (size_t)B)); CHECK(hipMemset(d_head, 0, 8)); CHECK(hipMemset(d_err, 0, 4));
+    a.tim = nullptr;
+    bw::ChainArgs<double> cf{a, d_dp, d_d, d_flags, d_head, B, d_err}, cb{a, d_sp, d_s, d_flags, d_head, B, d_err};
+    int maxdep = 0; for (int32_t b = 0; b < B; ++b) maxdep = std::max(maxdep, P.dep_ptr[b + 1] - P.dep_ptr[b]);
+    printf("== chained: one launch per sweep, %d blocks, %.2f dependencies per block (max %d)\n", B, (double)P.dep.size() / B, maxdep);
+    CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+    CHECK(bw::sweep_chain<double>(cf, P.blocks[0].maxk, P.lds_max, false, false, st));
+    CHECK(bw::sweep_chain<double>(cb, P.blocks[0].maxk, P.lds_max, false, true, st));
+    CHECK(hipStreamSynchronize(st));
+    CHECK(hipMemcpy(xg.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+    int err = 0; CHECK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+    xr = x0; scalar(false); scalar(true);
+    diff = 0; maxd = 0.0;
+    for (int64_t p = 0; p < n; ++p) { const double e = std::fabs(xg[p] - xr[P.perm[p]]); if (xg[p] != xr[P.perm[p]]) ++diff; maxd = std::max(maxd, e); }
+    printf("chained forward + backward vs the scalar loops: %lld values differ (max |diff| %.3e), poll give-ups %d\n", (long long)diff, maxd, err);
+    for (int bwd = 0; bwd < 2; ++bwd) {
+      const bw::ChainArgs<double>& c = bwd ? cb : cf;
+      CHECK(bw::sweep_chain<double>(c, P.blocks[0].maxk, P.lds_max, false, bwd, st)); CHECK(hipStreamSynchronize(st));
+      const int reps = 5;
+      CHECK(hipEventRecord(e0, st));
+      for (int r = 0; r < reps; ++r) CHECK(bw::sweep_chain<double>(c, P.blocks[0].maxk, P.lds_max, false, bwd, st));
+      CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+      float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      printf("chained %s sweep: %.3f ms (%.0f GB/s)\n", bwd ? "backward" : "forward ", ms / reps, bytes / (ms / reps * 1e-3) / 1e9);
+    }
+    // repeated sweeps keep agreeing with themselves (epochs, stale lines): 20 forward sweeps chained vs launched
+    {
+      std::vector<double> xc(n), xl2(n);
+      CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+      for (int r = 0; r < 20; ++r) CHECK(bw::sweep_chain<double>(r & 1 ? cb : cf, P.blocks[0].maxk, P.lds_max, false, r & 1, st));
+      CHECK(hipStreamSynchronize(st)); CHECK(hipMemcpy(xc.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+      CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+      for (int r = 0; r < 20; ++r) CHECK(bw::sweep<double>(a, P.blocks[0].maxk, P.launch_ptr, P.lds_max, false, r & 1, 1, st));
+      CHECK(hipStreamSynchronize(st)); CHECK(hipMemcpy(xl2.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+      int64_t dd = 0; for (int64_t p = 0; p < n; ++p) dd += xc[p] != xl2[p];
+      CHECK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+      printf("20 alternating sweeps, chained vs launched: %lld values differ, poll give-ups %d\n", (long long)dd, err);
+    }
+    cf.a.tim = d_tim;
+    CHECK(bw::sweep_chain<double>(cf, P.blocks[0].maxk, P.lds_max, false, false, st)); CHECK(hipStreamSynchronize(st));
+    std::vector<long long> tim(5 * (size_t)B);
+    CHECK(hipMemcpy(tim.data(), d_tim, 40 * (size_t)B, hipMemcpyDeviceToHost));
+    long long tmin = tim[0], tmax = 0; double ld = 0, wt = 0, wk = 0, wb = 0;
+    for (int32_t b = 0; b < B; ++b) {
+      const long long* t = &tim[5 * (size_t)b];
+      tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[4]);
+      ld += (t[1] - t[0]) * 0.01; wt += (t[2] - t[1]) * 0.01; wk += (t[3] - t[2]) * 0.01; wb += (t[4] - t[3]) * 0.01;
+    }
+    printf("chained forward sweep, stamps: first start -> last end %.1f us; mean per block: load %.2f, wait + fetch %.2f, walk %.2f, write-through + flag %.2f us\n",
+           (tmax - tmin) * 0.01, ld / B, wt / B, wk / B, wb / B);
+    // the critical path as the stamps show it: per launch depth, the latest end
+    for (int l = 0; l < nl; l += std::max(1, nl / 12)) {
+      long long te = 0, ts = -1; for (int b = P.launch_ptr[l]; b < P.launch_ptr[l + 1]; ++b) { te = std::max(te, tim[5 * (size_t)b + 4]); if (ts < 0 || tim[5 * (size_t)b] < ts) ts = tim[5 * (size_t)b]; }
+      printf("  depth %3d: %4d blocks, first start %8.1f us, last end %8.1f us\n", l, P.launch_ptr[l + 1] - P.launch_ptr[l], (ts - tmin) * 0.01, (te - tmin) * 0.01);
+    }
   }
   return 0;
 }

@@ -15,6 +15,12 @@ dev = DeviceHierarchy(ml, 0, 1)
 bd = AMG.DeviceBuffer(n, 0, np.random.default_rng(0).random(n)); zd = AMG.DeviceBuffer(n, 0)
 for _ in range(3): lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0)
 lib.amgh_dev_sync(0)
+if os.environ.get("SA_FIRST_CYCLES"):      # the cycles right after the build, one by one (a one-off 60 ms stall was seen there)
+    one = []
+    for _ in range(16):
+        t0 = time.perf_counter(); lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0); lib.amgh_dev_sync(0)
+        one.append(1e3 * (time.perf_counter() - t0))
+    print("first cycles, one by one (ms):", " ".join(f"{t:.1f}" for t in one))
 rounds = []
 for _ in range(4):
     t0 = time.perf_counter()
