@@ -43,7 +43,7 @@ constexpr int kChunk = 6;       // entries summed per batch of LDS reads
 constexpr int kThreads = 512;   // loading workgroup (the sweep itself is wave 0)
 constexpr int kMaxSteps = 124;
 #ifndef BW_PLAN_MAXK
-#define BW_PLAN_MAXK 12
+#define BW_PLAN_MAXK 18
 #endif
 constexpr int kPlanMaxK = BW_PLAN_MAXK;   // longest rows (off-diagonal entries, padded) a plan accepts = the kernels instantiated below  // steps per block (their row pointers live in two registers of wave 0)
 
@@ -799,7 +799,7 @@ inline hipError_t sweep_k(const Args<R>& a0, const std::vector<int32_t>& launch_
   }
   return hipGetLastError();
 }
-constexpr int kMaxK = 12;   // longest rows (off-diagonal entries, padded to a multiple of kChunk) the kernels are instantiated for
+constexpr int kMaxK = BW_PLAN_MAXK;   // longest rows (off-diagonal entries, padded to a multiple of kChunk) the kernels are instantiated for
 template <typename R>
 inline hipError_t sweep(const Args<R>& a, int maxk, const std::vector<int32_t>& launch_ptr, size_t lds_max, bool sor, bool backward, int ncols,
                         hipStream_t st) {

@@ -246,7 +246,7 @@ def main():
         # second roofline entry: the kernels that dominate the CYCLE (Gauss-Seidel sweeps: gs_slot / gs_bigslot /
         # chain / block launches + pre-pass), latency-bound — one launch per merged group of dependency levels
         "sweep_roofline": {
-            "bound": "hbm", "kernel": "gs_bw_packed_kernel (fine level: wavefront of blocks) + gs_slot_kernel / gs_bigslot_kernel "
+            "bound": "hbm", "kernel": "gs_bw_chain_kernel (two finest levels: wavefront of blocks, one launch per sweep) + gs_slot_kernel / gs_bigslot_kernel "
                                       "(merged dependency-level groups), all levels, pre + post smoother, both directions",
             "launches_per_cycle": launches, "entries_streamed_per_cycle": stored, "composite_entries_per_cycle": composite,
             "prepass_entries_per_cycle": tri,

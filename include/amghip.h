@@ -457,7 +457,7 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
 /* Diagnostics: one Gauss-Seidel (omega = 1) or SOR sweep as a WAVEFRONT OF BLOCKS (csrc/hip/gs_blocks.hpp) computed on the
  * host from the very plan and packed records the device kernel uses — block partition, launches, steps, the reciprocal
  * quotient.  x (in / out), b: nrows entries; stats4 = {blocks, launches, sum of the deepest blocks' steps, external
- * columns} (may be NULL).  AMGH_EUNSUPPORTED when the operator cannot be laid out (rows of more than 12 off-diagonal
+ * columns} (may be NULL).  AMGH_EUNSUPPORTED when the operator cannot be laid out (rows of more than 18 off-diagonal
  * entries).  CPU tests compare it bit for bit with the scalar lexicographic sweep (smoother.jl:61-90).             */
 int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t* col, const amgh_real* val, int target_rows,
                              int backward, double omega, amgh_real* x, const amgh_real* b, int64_t* stats4);

@@ -121,8 +121,14 @@ def test_block_wave_sor_and_float32():
 
 def test_block_wave_plan_refuses_long_rows_and_counts_launches():
     ml = AMG.ruge_stuben(AMG.poisson((16, 16, 16)))
-    A1 = ml.levels[1].A                                   # 19-point-like rows: more than 12 off-diagonal entries
-    rc, _, _ = _bw_sweep(A1, np.zeros(A1.m), np.ones(A1.m), 64, 0)
+    A1 = ml.levels[1].A                                   # 19-point-like rows: up to 18 off-diagonal entries, the longest the records take
+    x0, b1 = uniform(A1.m, 31) - 0.5, uniform(A1.m, 32)
+    for back in (0, 1):
+        rc, x, _ = _bw_sweep(A1, x0, b1, 64, back)
+        assert rc == 0 and np.array_equal(x, _scalar_sweep(A1, x0, b1, back))
+    A2 = ml.levels[2].A                                   # longer rows still
+    assert np.diff(A2.colptr).max() - 1 > 18
+    rc, _, _ = _bw_sweep(A2, np.zeros(A2.m), np.ones(A2.m), 64, 0)
     assert rc == -5                                       # AMGH_EUNSUPPORTED
     rc, _, _ = _bw_sweep(AMG.poisson(400), np.zeros(400), np.ones(400), 256, 0)
     assert rc == -5                                       # a chain in blocks of more than 124 rows: more steps than a block's walk takes

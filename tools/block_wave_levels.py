@@ -20,5 +20,5 @@ for li in levels:
         np.asarray(M.nzval, dtype=np.float64).tofile(f)
     for t in targets:
         print(f"==== level {li}: {M.m} rows, {M.nnz} entries, target rows {t}", flush=True)
-        subprocess.run([os.path.join(here, "block_wave_bench"), "file", path, t], check=False)
+        subprocess.run([os.path.join(here, os.environ.get("BW_BENCH", "block_wave_bench")), "file", path, t], check=False)
     os.remove(path)
