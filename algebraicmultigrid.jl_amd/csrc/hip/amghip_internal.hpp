@@ -373,7 +373,7 @@ int g_gs_tiny = 1;              // an operator that fits LDS entirely: 1 = gs_wa
 int g_gs_bw = 1;                // wavefront of blocks for single-right-hand-side hierarchies (gs_blocks.hpp): 0 off, 1 where the cost model prefers it, 2 always (tests); read at schedule build
 int g_gs_bw_rows = 512;         // ... rows per block aimed at
 int g_gs_bw_chain = 1;          // the wavefront of blocks as one launch per sweep, blocks chained by flags (0: one launch per depth of the quotient graph)
-int g_gs_bw_min_rows = 3000000; // ... operators below this many rows keep the level schedules (mode 1): 128^3 (2.1 M rows) is 10 % faster on merged groups, 160^3 (4.1 M) equal, 192^3 9 % and 256^3 13 % faster as a wavefront of blocks
+int g_gs_bw_min_rows = 3000000; // ... operators below this many rows keep the level schedules in mode 1 (half as many for rows of at most 7 entries: tools/bw_threshold.py, profiles/r03_bw_threshold.log)
 int g_gs_sample = 1;            // candidate group sizes of the merged sweeps from a sample of the groups (0 = every candidate built in full); read at schedule build
 int g_gs_sell = 1;              // merged groups from the SELL-like layout where it was built (0 = slot kernels); build: read at schedule build too
 int g_gs_lean = -1;             // footprint policy: -1 = AMGH_LEAN environment variable (unset: trim), 0 = full (every copy kept), 1 = lean, 2 = trim; read at schedule build

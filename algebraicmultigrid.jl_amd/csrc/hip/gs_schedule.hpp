@@ -1068,7 +1068,11 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   const int64_t n = nrows;
   BuildTimer tm;
   g->bytes = 0;
-  if (g_gs_bw > 0 && nrhs_hint == 1 && n > 0 && (g_gs_bw == 2 || n >= g_gs_bw_min_rows)) {
+  // (size thresholds measured with the chained kernel, profiles/r03_bw_threshold.log: 7-point rows pay from ~1.5 M rows — 128^3:
+  // 7.38 -> 7.22 ms per cycle, 96^3: 4.40 -> 4.52 —, 19-point rows from ~3 M — the 2.0 M-row second level of 160^3: 9.95 -> 10.51 ms)
+  bool bw_size_ok = n >= g_gs_bw_min_rows;
+  if (!bw_size_ok && n >= g_gs_bw_min_rows / 2 && n > 0 && rowptr[n] <= 7 * n) bw_size_ok = true;
+  if (g_gs_bw > 0 && nrhs_hint == 1 && n > 0 && (g_gs_bw == 2 || bw_size_ok)) {
     const int rcb = bw_build(g, n, ncols, rowptr, col, val, tm);
     if (rcb != AMGH_OK) return rcb;
     if (g->bw.rec) return AMGH_OK;

@@ -478,7 +478,7 @@ int amgh_debug_bw_poll_giveups(const amgh_t* h, int l);
  * (amgh_push_level, first stand-alone sweep of an operator): "gs_merge" (largest group of dependency levels tried),
  * "gs_bigslot" (0 off, 1 cost model, 2 always), "gs_super" (blocks per superblock), "gs_block_inverse", "gs_bw" (the
  * wavefront-of-blocks layout of single-column hierarchies: 0 off, 1 where its cost model prefers it, 2 always),
- * "gs_bw_rows" (rows per block aimed at, 512), "gs_bw_min_rows" (smallest operator considered in mode 1, 3 000 000 rows);
+ * "gs_bw_rows" (rows per block aimed at, 512), "gs_bw_min_rows" (smallest operator considered in mode 1: 3 000 000 rows, half of it for operators of at most 7 entries per row);
  * read at every sweep: "gs_bw_chain" (1: the wavefront of blocks as ONE launch per sweep, blocks chained by flags;
  * 0: one launch per depth of the quotient graph — bitwise the same sweep).
  * Returns AMGH_EINVAL for an unknown name.                                                                       */

@@ -120,18 +120,24 @@ def test_graph_replay_is_bitwise_the_eager_cycle(h128):
 
 
 def test_sweep_stats_describe_the_schedule(h128):
-    A, ml, dev = h128
+    A, ml, dev0 = h128
+    from amg_amd.device import DeviceHierarchy
+    lib = AMG.hip_lib()
+    lib.amgh_debug_set_tunable(b"gs_bw", 0)          # the merged dependency-level groups (what levels below ~1.5 M rows get)
+    try:
+        dev = DeviceHierarchy(ml, 0, 1)
+    finally:
+        lib.amgh_debug_set_tunable(b"gs_bw", 1)
     st = dev.gs_sweep_stats(0, False)
     assert st["rows"] == A.m and 1 <= st["launches"] <= dev.gs_sweep_steps(0, False)   # narrow groups chain into one launch
     assert st["entries"] > 0 and st["slot_entries"] >= 0
     if st["levels_per_group"] > 1:      # merged groups: composite rows + the other triangle as a pre-pass
         assert st["tri_entries"] > 0 and st["entries"] >= (A.nnz - A.m) // 2
     assert dev.gs_dependency_levels(0) == 3 * 128 - 2
-    # the same level as a wavefront of blocks (what single-column hierarchies get from 3 M rows on): the operator's own
+    # the same level as a wavefront of blocks (what single-column hierarchies get from 1.5 M 7-point rows on — so the
+    # fixture's own fine level —, from 3 M rows otherwise): the operator's own
     # off-diagonal entries — no composite rows, no pre-pass —, 3 * 16 - 2 depths of the quotient graph for 16^3 blocks of
     # 8^3 rows, executed as ONE launch (blocks chained by flags) or, tunable gs_bw_chain = 0, as a launch per depth
-    from amg_amd.device import DeviceHierarchy
-    lib = AMG.hip_lib()
     lib.amgh_debug_set_tunable(b"gs_bw", 2)
     try:
         devb = DeviceHierarchy(ml, 0, 1)
@@ -150,6 +156,8 @@ def test_sweep_stats_describe_the_schedule(h128):
     finally:
         lib.amgh_debug_set_tunable(b"gs_bw_chain", 1)
     assert lib.amgh_debug_bw_poll_giveups(devb.h, 0) == 0 and lib.amgh_debug_bw_poll_giveups(dev.h, 0) == -1
+    # (the default at this size: the fine level as blocks, the 1.0 M-row second level on merged groups — forced above)
+    assert dev0.gs_sweep_stats(0, False) == sb and rel(dev0.precond_apply(b), zb) <= 1e-12
     # blocks of 10^3 rows: 98 KB of LDS per workgroup (beyond the 64 KB a kernel gets without asking), another partition,
     # the same sweep bit for bit
     lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_bw_rows", 1000)
