@@ -23,10 +23,14 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace amgh {
@@ -67,6 +71,19 @@ struct Packed {
   }
 };
 
+// (a byte buffer whose resize does not touch the pages: the records — gigabytes — are zeroed and filled block by block
+// by the threads that build them instead of twice, first by one thread)
+template <typename T>
+struct NoInit {
+  typedef T value_type;
+  NoInit() = default;
+  template <class U> NoInit(const NoInit<U>&) {}
+  T* allocate(size_t k) { return static_cast<T*>(::operator new(k * sizeof(T))); }
+  void deallocate(T* p, size_t) { ::operator delete(p); }
+  template <class U, class... A> void construct(U* p, A&&... a) { if (sizeof...(A)) ::new ((void*)p) U(std::forward<A>(a)...); }
+  template <class U> bool operator==(const NoInit<U>&) const { return true; }
+  template <class U> bool operator!=(const NoInit<U>&) const { return false; }
+};
 struct Plan {
   int64_t n = 0, nnz = 0;
   std::vector<int32_t> perm;        // block-order position -> natural row
@@ -74,7 +91,7 @@ struct Plan {
   std::vector<int32_t> launch_ptr;  // launch l = blocks [launch_ptr[l], launch_ptr[l + 1])
   std::vector<int64_t> launch_rec;  // byte offset of launch l's first record (launch_rec[nlaunch] = all records)
   std::vector<int32_t> ext_col;     // block-order positions
-  std::vector<unsigned char> rec;   // the records, one after the other
+  std::vector<unsigned char, NoInit<unsigned char>> rec;   // the records, one after the other
   std::vector<int32_t> dep_ptr, dep;    // quotient graph on ordered blocks: the blocks a block waits for in the forward sweep ...
   std::vector<int32_t> sdep_ptr, sdep;  // ... and in the backward sweep (its successors); the chained kernel (one launch per sweep)
   size_t lds_max = 0;               // largest dynamic LDS request of a block
@@ -115,12 +132,22 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   P = Plan();
   P.n = n; P.nnz = rowptr[n];
   if (n <= 0) return false;
+  const bool timing = getenv("BW_PLAN_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[bw plan] %-34s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   // ---- offset classes ----
   int64_t hist[32] = {0};
   int maxlen = 0;
+  int64_t cmax = n - 1;   // largest column (halo columns of a row-sharded operator lie behind the rows)
   for (int64_t i = 0; i < n; ++i) {
     int off = 0;
     for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+      cmax = std::max<int64_t>(cmax, col[j]);
       const int64_t d = (int64_t)i - col[j];
       if (d != 0) ++off;                                   // (halo columns of a row-sharded operator count as entries of the row)
       if (d != 0 && col[j] < n) hist[31 - __builtin_clz((unsigned)(d < 0 ? -d : d))]++;
@@ -139,6 +166,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     if (P.cuts[0] > P.cuts[1]) std::swap(P.cuts[0], P.cuts[1]);
   }
   if (prm.require_three && (P.cuts[0] == 99 || P.cuts[1] == 99)) return false;
+  lap("offset histogram");
   const int cut0 = P.cuts[0], cut1 = P.cuts[1];
   auto cls = [cut0, cut1](int64_t d) { const int b = 31 - __builtin_clz((unsigned)d); return b <= cut0 ? 0 : b <= cut1 ? 1 : 2; };
   // ---- potentials and dependency levels of the symmetrised pattern (one pass in index order) ----
@@ -163,6 +191,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     }
   }
   for (int k = 0; k < 3; ++k) P.range[k] = *std::max_element(phi[k].begin(), phi[k].end()) + 1;
+  lap("potentials + levels");
   P.nlevels = *std::max_element(lev.begin(), lev.end()) + 1;
   // ---- rows per block from the LDS budget ----
   const size_t per_row = Packed<R>::row_bytes(maxk) + 2 * sizeof(R) + 2 * sizeof(R);   // packed row + b + x + ~2 external values
@@ -198,6 +227,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     m *= 1.12;
   }
   for (int k = 0; k < 3; ++k) P.cells[k] = nb[k];
+  lap("cell widths");
   const int64_t ncell = (int64_t)nb[0] * nb[1] * nb[2];
   // ---- rows of every cell in (level, index) order; oversized cells cut along the level ----
   std::vector<int64_t> cptr(ncell + 1, 0);
@@ -212,6 +242,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     for (int64_t q = ncell * t / TT; q < ncell * (t + 1) / TT; ++q)
       std::stable_sort(crow.begin() + cptr[q], crow.begin() + cptr[q + 1], [&](int32_t a, int32_t b) { return lev[a] < lev[b]; });
   });
+  lap("rows of cells, sorted");
   // blocks (pre-order: by cell, then by level window)
   std::vector<int32_t> blk(n);
   std::vector<int64_t> bptr;        // rows of pre-order block b: crow[bptr[b] .. bptr[b+1])
@@ -239,6 +270,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   const int32_t B = (int32_t)bsum.size();
   std::vector<int32_t>().swap(cell);
   for (int k = 0; k < 3; ++k) std::vector<int32_t>().swap(phi[k]);
+  lap("blocks");
   // ---- launches: longest path in the quotient graph ----
   std::vector<int32_t> blev(B, 0);
   std::vector<int64_t> eptr(B + 1, 0);   // edges (block of c) -> (block of i) for c < i adjacent, collected per target block (pre-order)
@@ -268,6 +300,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     }
   }
   const int nlaunch = *std::max_element(blev.begin(), blev.end()) + 1;
+  lap("quotient edges + depths");
   // ---- block order: by launch, pre-order inside a launch ----
   std::vector<int32_t> order(B);
   P.launch_ptr.assign(nlaunch + 1, 0);
@@ -285,6 +318,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     ilev[i] = l;
     for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) { const int32_t c = col[j]; if (c > i && c < n && blk[c] == blk[i]) ilev[c] = std::max(ilev[c], l + 1); }
   }
+  lap("in-block levels");
   // ---- rows in block order ----
   P.blocks.resize(B);
   P.perm.resize(n);
@@ -307,6 +341,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   });
   std::vector<int32_t> obk(B);   // pre-order block -> ordered block
   for (int32_t ob = 0; ob < B; ++ob) obk[order[ob]] = ob;
+  lap("block order");
   // ---- the quotient graph on ordered blocks (distinct predecessors / successors of every block) ----
   {
     P.dep_ptr.assign(B + 1, 0);
@@ -331,10 +366,12 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     }
     std::vector<int64_t>().swap(eptr); std::vector<int32_t>().swap(esrc);
   }
+  lap("dependency lists");
   // ---- external columns, record offsets ----
   std::vector<int64_t> ext_ptr(B + 1, 0);
   std::vector<std::vector<int32_t>> exts(B);
   parallel_for(T, [&](int t, int TT) {
+    std::vector<int32_t> seen((size_t)cmax + 1, -1);   // per thread: the block that listed a position last (each position once per block)
     for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
       const Desc& d = P.blocks[ob];
       std::vector<int32_t>& ex = exts[ob];
@@ -344,13 +381,13 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
           const int32_t c = col[j];
           if (c == i) continue;
           const int32_t q = c >= n ? c : inv[c];            // halo columns keep their place behind the rows
-          if (q < d.row0 || q >= d.row0 + d.nrows) ex.push_back(q);
+          if ((q < d.row0 || q >= d.row0 + d.nrows) && seen[q] != ob) { seen[q] = ob; ex.push_back(q); }
         }
       }
       std::sort(ex.begin(), ex.end());
-      ex.erase(std::unique(ex.begin(), ex.end()), ex.end());
     }
   });
+  lap("external columns");
   size_t rec_total = 0;
   bool fits = true;
   for (int32_t ob = 0; ob < B; ++ob) {
@@ -381,13 +418,17 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   for (int l = 0; l < nlaunch; ++l) P.launch_rec[l] = (int64_t)P.blocks[P.launch_ptr[l]].rec * 16;
   P.ext_total = ext_ptr[B];
   P.ext_col.resize(ext_ptr[B]);
-  P.rec.assign(rec_total, 0);
+  lap("descriptors");
+  P.rec.resize(rec_total);
   parallel_for(T, [&](int t, int TT) {
+    std::vector<int32_t> where((size_t)cmax + 1);      // per thread: index of a position in the current block's external list
     for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
       const Desc& d = P.blocks[ob];
       const std::vector<int32_t>& ex = exts[ob];
       std::copy(ex.begin(), ex.end(), P.ext_col.begin() + d.ext0);
+      for (size_t e = 0; e < ex.size(); ++e) where[ex[e]] = (int32_t)e;
       unsigned char* rec = P.rec.data() + (size_t)d.rec * 16;
+      std::memset(rec, 0, Packed<R>::rec_bytes(d.nrows, d.maxk, d.nlev));
       const size_t rs = Packed<R>::row_bytes(d.maxk);
       const int nvc = Packed<R>::nvc(d.maxk);
       const uint16_t zoff = (uint16_t)((size_t)(d.nrows + d.next) * sizeof(R));   // the LDS slot that holds 0
@@ -409,7 +450,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
           const int32_t q = c >= n ? c : inv[c];
           size_t lc;
           if (q >= d.row0 && q < d.row0 + d.nrows) lc = (size_t)(q - d.row0);
-          else lc = (size_t)d.nrows + (size_t)(std::lower_bound(ex.begin(), ex.end(), q) - ex.begin());
+          else lc = (size_t)d.nrows + (size_t)where[q];
           v[k] = val[j];
           cc[k] = (uint16_t)(lc * sizeof(R));
           ++k;
@@ -423,6 +464,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
       stp[nl] = (uint16_t)d.nrows;
     }
   });
+  lap("records");
   // ---- modelled time of one sweep: per launch a boundary + the latency chain of a block + its bytes + its deepest block ----
   {
     double tsec = 0.0;
