@@ -983,6 +983,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   // (few host threads: the plan is off the setup's critical path, which is a host thread of its own — the sequential C/F
   // splitting — sharing a CPU quota with it: 16 threads here cost the 256^3 setup 0.3 s, 4 do not)
   prm.threads = std::max(1, std::min<int>(merge_threads(), 4));
+  if (const char* e = getenv("AMGH_BW_THREADS")) prm.threads = std::max(1, atoi(e));   // (measurement hook)
   prm.require_three = g_gs_bw != 2;   // (the cost-model branch below insists on three offset classes)
   bw::Plan P;
   if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_OK;
