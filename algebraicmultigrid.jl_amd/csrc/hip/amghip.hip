@@ -1559,6 +1559,42 @@ int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t
     std::vector<char> seen(n, 0);
     for (int64_t p = 0; p < n; ++p) { if (P.perm[p] < 0 || P.perm[p] >= n || seen[P.perm[p]]) return AMGH_ESTATE; seen[P.perm[p]] = 1; }
   }
+  // what the chained kernel (one launch per sweep, gs_bw_chain_kernel) relies on: a block's external positions split at npre into
+  // those BEFORE the block in block order — every one of them inside a block of its predecessor list, all with smaller tickets —
+  // and those behind it — inside blocks of its successor list, all with larger tickets; the two lists are each other's transpose
+  {
+    const int32_t B = (int32_t)P.blocks.size();
+    if ((int32_t)P.dep_ptr.size() != B + 1 || (int32_t)P.sdep_ptr.size() != B + 1) return AMGH_ESTATE;
+    std::vector<int32_t> first(B);
+    for (int32_t ob = 0; ob < B; ++ob) {
+      first[ob] = P.blocks[ob].row0;
+      if (ob && first[ob] != P.blocks[ob - 1].row0 + P.blocks[ob - 1].nrows) return AMGH_ESTATE;
+    }
+    auto block_of = [&](int32_t q) { return (int32_t)(std::upper_bound(first.begin(), first.end(), q) - first.begin()) - 1; };
+    int64_t transposed = 0;
+    for (int32_t ob = 0; ob < B; ++ob) {
+      const bw::Desc& d = P.blocks[ob];
+      if (d.npre < 0 || d.npre > d.next) return AMGH_ESTATE;
+      for (int32_t e = 0; e < d.next; ++e) {
+        const int32_t q = P.ext_col[d.ext0 + e];
+        const bool near = e < d.npre;
+        if (near ? !(q < d.row0) : !(q >= d.row0 + d.nrows)) return AMGH_ESTATE;
+        if (e && !(P.ext_col[d.ext0 + e - 1] < q)) return AMGH_ESTATE;                       // sorted, each position once
+        const int32_t bq = block_of(q);
+        const std::vector<int32_t>& lst = near ? P.dep : P.sdep;
+        const std::vector<int32_t>& ptr = near ? P.dep_ptr : P.sdep_ptr;
+        if (!std::binary_search(lst.begin() + ptr[ob], lst.begin() + ptr[ob + 1], bq)) return AMGH_ESTATE;
+      }
+      for (int32_t e = P.dep_ptr[ob]; e < P.dep_ptr[ob + 1]; ++e) {
+        const int32_t pb = P.dep[e];
+        if (pb < 0 || pb >= ob) return AMGH_ESTATE;                                          // smaller tickets only
+        if (std::binary_search(P.sdep.begin() + P.sdep_ptr[pb], P.sdep.begin() + P.sdep_ptr[pb + 1], ob)) ++transposed;
+      }
+      for (int32_t e = P.sdep_ptr[ob]; e < P.sdep_ptr[ob + 1]; ++e)
+        if (P.sdep[e] <= ob || P.sdep[e] >= B) return AMGH_ESTATE;
+    }
+    if (transposed != (int64_t)P.dep.size() || P.dep.size() != P.sdep.size()) return AMGH_ESTATE;
+  }
   std::vector<real> xp(n), bp(n);
   for (int64_t p = 0; p < n; ++p) { xp[p] = x[P.perm[p]]; bp[p] = b[P.perm[p]]; }
   const int nl = (int)P.launch_ptr.size() - 1;

@@ -458,7 +458,10 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
  * host from the very plan and packed records the device kernel uses — block partition, launches, steps, the reciprocal
  * quotient.  x (in / out), b: nrows entries; stats4 = {blocks, launches, sum of the deepest blocks' steps, external
  * columns} (may be NULL).  AMGH_EUNSUPPORTED when the operator cannot be laid out (rows of more than 18 off-diagonal
- * entries).  CPU tests compare it bit for bit with the scalar lexicographic sweep (smoother.jl:61-90).             */
+ * entries).  CPU tests compare it bit for bit with the scalar lexicographic sweep (smoother.jl:61-90).  Before it
+ * sweeps it checks what the chained kernel relies on — every external position of a block lies in a block of its
+ * predecessor list (smaller tickets) or of its successor list (larger tickets), split at the descriptor's npre, the two
+ * lists transposes of each other — and returns AMGH_ESTATE if the plan violates it.                                    */
 int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t* col, const amgh_real* val, int target_rows,
                              int backward, double omega, amgh_real* x, const amgh_real* b, int64_t* stats4);
 

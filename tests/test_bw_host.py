@@ -4,7 +4,10 @@ the quotient as reciprocal + one fma correction (csrc/hip/gs_blocks.hpp) — is 
 device kernel reads (`amgh_debug_bw_sweep_host`) and compared BIT FOR BIT with the scalar lexicographic sweep of
 smoother.jl:61-90 — the oracle's loop for symmetric operators, and the same loop written out in Python for the rows of a
 non-symmetric one (where the reference's NoSymmetry sweep multiplies by a stored inverse diagonal instead of dividing).  The device kernel then only has to do the same arithmetic (tests/test_gpu_abi_surface.py,
-tools/block_wave_bench)."""
+tools/block_wave_bench).
+The same call validates the plan's quotient graph — what orders the blocks of the one-launch (chained) sweep: every external
+position of a block inside a block of its predecessor / successor list, tickets strictly ordered (AMGH_ESTATE otherwise).
+"""
 import ctypes as C
 
 import numpy as np
