@@ -19,6 +19,11 @@
 // equivalents on the Ruge-Stueben coarse grids of such a grid).  Cells with more rows than a workgroup can hold are cut
 // along the dependency level (one more monotone potential), a single oversized level into chunks of independent rows.
 // The construction is always valid; whether it is USED is a cost-model decision (launches, depth, bytes).
+//
+// Execution: ONE launch per sweep (gs_bw_chain_kernel, the default for single-column sweeps) — workgroups draw tickets in
+// the order of the quotient DAG's depths and a block waits for the flags of the few blocks it depends on instead of a
+// kernel boundary, its record load running ahead of that chain —, or one launch per depth (gs_bw_packed_kernel: blocks of
+// right-hand sides, tunable gs_bw_chain = 0).  Same records, same arithmetic, the same bits.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>

@@ -1,6 +1,9 @@
 // block_wave_bench — the block-wavefront Gauss-Seidel sweep of csrc/hip/gs_blocks.hpp: plan (partition by
-// monotone potentials), layout, forward / backward sweeps checked bit for bit against the scalar loops, timings.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DBW_PLAN_MAXK=18: rows of up to 18 entries, e.g. level 1] -o tools/block_wave_bench tools/block_wave_bench.hip
+// monotone potentials), layout, forward / backward sweeps checked bit for bit against the scalar loops, timings — as one
+// launch per depth of the block graph (gs_bw_packed_kernel, with in-kernel clocks per launch) and as ONE launch per sweep
+// with the blocks chained by flags (gs_bw_chain_kernel: stamps per block and per depth, 20 alternating sweeps against the
+// launched ones, poll give-ups).  BW_PLAN_TIMING=1: laps of the plan.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/block_wave_bench tools/block_wave_bench.hip
 // usage: block_wave_bench poisson N [target_rows]     (7-point, N^3)   |   block_wave_bench poisson2 N [target_rows]   (5-point, N^2)
 //        block_wave_bench file PATH [target_rows]    PATH: int64 n, int64 nnz, int32 rowptr[n+1], int32 col[nnz], double val[nnz]
 #include <chrono>
