@@ -54,6 +54,9 @@ constexpr int kMaxSteps = 124;
 #ifndef BW_PLAN_MAXK
 #define BW_PLAN_MAXK 18
 #endif
+#ifndef BW_POLL_SLEEP
+#define BW_POLL_SLEEP 8   // x 64 clocks between two polls of a flag (256^3 fine level, ms per sweep: 0: 0.932, 1: 0.920, 2: 0.921, 8: 0.910, 16: 0.914, 32: 0.924; tools/block_wave_bench -DBW_POLL_SLEEP=...)
+#endif
 constexpr int kPlanMaxK = BW_PLAN_MAXK;   // longest rows (off-diagonal entries, padded) a plan accepts = the kernels instantiated below  // steps per block (their row pointers live in two registers of wave 0)
 
 // PACKED rows (the format of gs_bw_packed_kernel): a row is one run of 16-byte chunks
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(kThreads) void gs_bw_chain_kernel(ChainArgs<R> c) {
     const unsigned int* f = c.flags + c.dep[e];
     int spins = 0;
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(BW_POLL_SLEEP);
       if (++spins > (1 << 24)) { *c.err = 1; break; }
     }
   }
@@ -784,7 +787,17 @@ __global__ __launch_bounds__(kThreads) void gs_bw_chain_kernel(ChainArgs<R> c) {
   const long long t_ready = a.tim ? wall_clock64() : 0;
   packed_walk<R, SOR, BWD, MAXK>(rec, bl, xl, d, tid, a.omega);
   const long long t_swept = a.tim ? wall_clock64() : 0;
-  for (int p = tid; p < d.nrows; p += 64) agent_store(x + d.row0 + p, xl[p]);
+  {   // (the values out of LDS in one batch, then the stores: a read / wait / store loop pays an LDS round trip per iteration)
+    constexpr int WU = 10;
+    R wv[WU];
+#pragma unroll
+    for (int k = 0; k < WU; ++k) { const int p = tid + 64 * k; wv[k] = xl[p < d.nrows ? p : 0]; }
+#pragma unroll
+    for (int k = 0; k < WU; ++k) pin(wv[k]);
+#pragma unroll
+    for (int k = 0; k < WU; ++k) { const int p = tid + 64 * k; if (p < d.nrows) agent_store(x + d.row0 + p, wv[k]); }
+    for (int p = tid + 64 * WU; p < d.nrows; p += 64) agent_store(x + d.row0 + p, xl[p]);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0) __hip_atomic_store(c.flags + ob, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.tim && tid == 0) {
