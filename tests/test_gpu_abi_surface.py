@@ -330,6 +330,40 @@ def test_wavefront_of_blocks_schedule_vs_oracle_and_level_schedules():
         assert rel(Z[:, q], oh.precond(np.ascontiguousarray(B[:, q]))) <= 1e-10
 
 
+def test_chained_blocks_on_random_patterns_are_the_host_plan_bit_for_bit():
+    """The block layout on operators that are NOT grids: random sparsity, structurally non-symmetric (a block then reads
+    old values of blocks that never read it back — the far / near split of its external positions and its predecessor /
+    successor lists are all that orders the chained kernel) and symmetric with zero diagonals (rows the sweep skips).
+    Forward, backward and symmetric sweeps on the device, one launch per sweep and one launch per depth, against the
+    host execution of the same plan (amgh_debug_bw_sweep_host: bitwise the scalar loop, tests/test_bw_host.py)."""
+    from amg_amd.device import DeviceHierarchy
+    from test_bw_host import _short_rows
+    lib = AMG.hip_lib()
+    for A, herm in ((_short_rows(6000, 6, False), False), (_short_rows(5000, 5, True, zero_diag=(0, 17, 4999)), True)):
+        rp, ci, va = AMG.device.smoother_matrix_csr(A, None)      # what a HermitianSymmetry hierarchy sweeps: the CSC arrays read as rows
+        rp, ci, va = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(va)
+        x0, bb = uniform(A.m, 41) - 0.5, uniform(A.m, 42)
+        for pre in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2)):
+            ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre)
+            lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_bw_rows", 64)
+            try:
+                dev = DeviceHierarchy(ml, 0, 1)
+                st = dev.gs_sweep_stats(0, False)
+                assert st["launches"] == 1 and st["tri_entries"] == 0 and dev.gs_sweep_steps(0, False) > 1     # really the block layout
+                x_dev = dev.smooth(0, False, x0, bb)
+                lib.amgh_debug_set_tunable(b"gs_bw_chain", 0)
+                x_launched = dev.smooth(0, False, x0, bb)
+            finally:
+                lib.amgh_debug_set_tunable(b"gs_bw", 1); lib.amgh_debug_set_tunable(b"gs_bw_rows", 512); lib.amgh_debug_set_tunable(b"gs_bw_chain", 1)
+            xh = x0.copy()
+            for it in range(pre.iter):
+                for back in ((0,), (1,), (0, 1))[pre.sweep_code]:
+                    rc = lib.amgh_debug_bw_sweep_host(A.m, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, 64, back, 1.0, xh.ctypes.data, bb.ctypes.data, None)
+                    assert rc == 0
+            assert np.array_equal(x_dev, xh) and np.array_equal(x_launched, xh), (herm, repr(pre))
+            assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+
+
 def test_jacobi_on_a_zero_vector_skips_the_matrix_pass_bitwise():
     """Every pre-smoother below the fine level of a cycle (and the fine one of ldiv!) starts from x = 0: the damped Jacobi
     sweep is then x = (1 - w) 0 + w ((b - 0) / d), evaluated by a vector kernel instead of a pass over the matrix —
