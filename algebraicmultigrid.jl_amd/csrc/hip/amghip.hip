@@ -430,7 +430,7 @@ int solve_dev(amgh_t* h, const real* b, real* x, int cyc, int maxiter, double ab
   if (iters) *iters = itr - 1;
   HIP_TRY(hipStreamSynchronize(h->stream));
   RC_TRY(prof_flush(h));
-  return AMGH_OK;
+  return bw_err_check();
 }
 
 int scal_div(amgh_t* h, int out, int a, int b) {
@@ -486,7 +486,7 @@ int pcg_dev(amgh_t* h, const real* b, real* x, int cyc, int use_precond, int max
   if (iters) *iters = it;
   HIP_TRY(hipStreamSynchronize(h->stream));
   RC_TRY(prof_flush(h));
-  return AMGH_OK;
+  return bw_err_check();
 }
 
 int check_ready(const amgh_t* h) {
@@ -1016,11 +1016,17 @@ int amgh_debug_bw_poll_giveups(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
   amgh_csr* M = h->levels[l]->smat();
   const GsSchedule* g = M->gs;
-  if (!g || !g->bw.err) return -1;
-  int32_t v = 0;
+  if (!g || !g->bw.on || !g->bw.err) return -1;
   if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpy(&v, g->bw.err, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int)v;
+  return (int)*(volatile int32_t*)g->bw.err;   // (the process-wide word, left as it is: the next synchronising entry point reports it)
+}
+int amgh_debug_bw_mode(const amgh_t* h, int l) {
+  if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
+  amgh_csr* M = h->levels[l]->smat();
+  const GsSchedule* g = M->gs;
+  if (!g || !g->bw.on) return 0;
+  if (g->bw.flow.on && (g_gs_bw_flow || !g->bw.rec)) return 3;
+  return (g_gs_bw_chain && g->bw.flags) ? 2 : 1;
 }
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
@@ -1034,7 +1040,7 @@ int amgh_gs_num_sweep_steps(const amgh_t* h, int l, int backward) {
   if (!g) return 0;
   if (g->dti_f && g_gs_dense_tri && g_gs_block_inverse) return (int)g->dti_off.size() - 1;   // dense triangular sweep: blocks
   if (g->nblk > 0 && g_gs_block_inverse) return g->nblk;             // block-inverse sweep: sequential block steps
-  if (g->bw.rec) return (int)g->bw.launch_ptr.size() - 1;            // wavefront of blocks: depths of the quotient DAG
+  if (g->bw.on) return (int)g->bw.launch_ptr.size() - 1;             // wavefront of blocks: depths of the quotient DAG
   const GsSchedule* c = backward ? g->mb : g->mf;
   return (c && g_gs_merge > 1) ? c->nlev : g->nlev;                  // merged groups, or dependency levels
 }
@@ -1059,9 +1065,10 @@ int amgh_gs_sweep_stats(const amgh_t* h, int l, int backward, int64_t* out6) {
     out6[5] = 0;
     return AMGH_OK;
   }
-  if (g->bw.rec) {   // wavefront of blocks: the operator's own entries (padded to the record's row width), no pre-pass
+  if (g->bw.on) {   // wavefront of blocks: the operator's own entries (padded to the record's row width), no pre-pass
     const int64_t depths = (int64_t)g->bw.launch_ptr.size() - 1;
-    out6[0] = (g_gs_bw_chain && g->bw.flags) ? 1 : depths;   // chained by flags: one launch per sweep
+    const bool one = (g->bw.flow.on && (g_gs_bw_flow || !g->bw.rec)) || (g_gs_bw_chain && g->bw.flags);
+    out6[0] = one ? 1 : depths;   // dataflow / chained by flags: one launch per sweep
     out6[1] = g->n;
     out6[2] = g->nnz - g->n;
     out6[3] = g->bw.rec_entries;
@@ -1119,6 +1126,7 @@ int amgh_precond_apply_d(amgh_t* h, const real* r_d, real* z_d, int cycle_) {
   RC_TRY(check_ready(h));
   if (!r_d || !z_d || cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
+  RC_TRY(bw_err_check());   // (asynchronous: a sweep of an earlier call that gave up a poll is reported here, or by amgh_dev_sync)
   RC_TRY(vec_fill(h, z_d, fine_n(h) * h->nrhs, 0.0));
   return apply_cycle(h, z_d, r_d, cycle_, true);
 }
@@ -1132,6 +1140,7 @@ int amgh_precond_apply(amgh_t* h, const real* r, real* z, int cycle_) {
   RC_TRY(amgh_precond_apply_d(h, h->b0, h->x0, cycle_));
   HIP_TRY(hipStreamSynchronize(h->stream));
   RC_TRY(prof_flush(h));
+  RC_TRY(bw_err_check());
   HIP_TRY(hipMemcpy(z, h->x0, sizeof(real) * n, hipMemcpyDeviceToHost));
   return AMGH_OK;
 }
@@ -1320,7 +1329,7 @@ int amgh_level_smooth_d(amgh_t* h, int level, int post, real* x_d, const real* b
   HIP_TRY(hipSetDevice(h->device));
   RC_TRY(level_smooth_enqueue(h, level, post, x_d, b_d));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  return AMGH_OK;
+  return bw_err_check();
 }
 
 int amgh_level_smooth(amgh_t* h, int level, int post, real* x, const real* b) {
@@ -1333,6 +1342,7 @@ int amgh_level_smooth(amgh_t* h, int level, int post, real* x, const real* b) {
   int rc = dev_upload(&bd, b, n);
   if (rc == AMGH_OK) rc = level_smooth_enqueue(h, level, post, xd, bd);
   if (rc == AMGH_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = -1001;
+  if (rc == AMGH_OK) rc = bw_err_check();
   if (rc == AMGH_OK && hipMemcpy(x, xd, sizeof(real) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
   hipFree(xd); hipFree(bd);
   return rc;
@@ -1453,7 +1463,7 @@ int amgh_dev_download(int device, void* dst, const void* src_d, int64_t bytes) {
 int amgh_dev_sync(int device) {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipDeviceSynchronize());
-  return AMGH_OK;
+  return bw_err_check();
 }
 void* amgh_stream(amgh_t* h) { return h ? (void*)h->stream : nullptr; }
 
@@ -1715,6 +1725,9 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_bw")) g_gs_bw = value;
   else if (!strcmp(name, "gs_bw_rows")) g_gs_bw_rows = value;
   else if (!strcmp(name, "gs_bw_chain")) g_gs_bw_chain = value;
+  else if (!strcmp(name, "gs_bw_flow")) g_gs_bw_flow = value;
+  else if (!strcmp(name, "gs_bw_spin")) g_gs_bw_spin = value;
+  else if (!strcmp(name, "gs_bw_skip_pub")) g_gs_bw_skip_pub = value;
   else if (!strcmp(name, "gs_bw_min_rows")) g_gs_bw_min_rows = value;
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;
   else if (!strcmp(name, "jacobi_zero")) g_jacobi_zero = value;

@@ -4,6 +4,7 @@
 #pragma once
 #include "amghip_kernels.hpp"
 #include "gs_blocks.hpp"
+#include "gs_flow.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -214,8 +215,17 @@ struct GsSchedule {
     double est_seconds = 0.0;
     // the whole sweep as ONE launch (gs_bw_chain_kernel): blocks chained by flags instead of kernel boundaries
     int32_t *dep_ptr = nullptr, *dep = nullptr, *sdep_ptr = nullptr, *sdep = nullptr;
-    unsigned int* flags = nullptr; unsigned long long* head = nullptr; int32_t* err = nullptr;
+    unsigned int* flags = nullptr; unsigned long long* head = nullptr;
+    int32_t* err = nullptr;   // the process-wide error word (bw_err_word(): pinned host memory, not owned)
     int32_t nblocks = 0;
+    bool on = false;          // this schedule IS a wavefront of blocks (rec may be absent when only the dataflow layout was kept)
+    // the sweep as a DATAFLOW (gs_flow.hpp): rows published as they are computed, records streamed into registers
+    struct FlowDev {
+      bw::FlowDesc* fd = nullptr; unsigned char* srec = nullptr; uint32_t* aux = nullptr;
+      int32_t* fl_mb = nullptr; uint16_t* fl_slot = nullptr; void* mbox = nullptr;
+      int64_t nmail = 0; size_t lds_max = 0; int64_t bytes = 0;
+      bool on = false;
+    } flow;
   } bw;
   // the same operator as one record walked by a single wave (gs_wave_kernel): built when it fits (rows of at most
   // kWaveMaxK off-diagonal entries, at most kWaveMaxSteps steps, the LDS budget)
@@ -319,7 +329,8 @@ struct GsSchedule {
     hipFree(scol); hipFree(sval); hipFree(schunk); scol = nullptr; sval = nullptr; schunk = nullptr;
     hipFree(ww_rec); ww_rec = nullptr;
     hipFree(bw.blocks); hipFree(bw.rec); hipFree(bw.ext_col);
-    hipFree(bw.dep_ptr); hipFree(bw.dep); hipFree(bw.sdep_ptr); hipFree(bw.sdep); hipFree(bw.flags); hipFree(bw.head); hipFree(bw.err);
+    hipFree(bw.dep_ptr); hipFree(bw.dep); hipFree(bw.sdep_ptr); hipFree(bw.sdep); hipFree(bw.flags); hipFree(bw.head);
+    hipFree(bw.flow.fd); hipFree(bw.flow.srec); hipFree(bw.flow.aux); hipFree(bw.flow.fl_mb); hipFree(bw.flow.fl_slot); hipFree(bw.flow.mbox);
     bw = Bw();
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
     hipFree(perm); hipFree(dpos); if (!diag_shared) hipFree(diag);
@@ -372,6 +383,9 @@ int g_rhs_il = 1;               // blocks of 2 / 4 / 8 / 16 right-hand sides: re
 int g_gs_tiny = 1;              // an operator that fits LDS entirely: 1 = gs_wave_kernel where its record was built, else gs_chain_tiny_kernel; 2 = gs_chain_tiny_kernel; 0 = gs_chain_kernel; read at every sweep
 int g_gs_bw = 1;                // wavefront of blocks for single-right-hand-side hierarchies (gs_blocks.hpp): 0 off, 1 where the cost model prefers it, 2 always (tests); read at schedule build
 int g_gs_bw_rows = 512;         // ... rows per block aimed at
+int g_gs_bw_flow = 1;           // the wavefront of blocks as a dataflow (gs_flow.hpp) where the pattern is structurally symmetric: 1 = on, 0 = off (chained / launched sweeps); build: the layout is only built when on; read at every sweep too
+int g_gs_bw_spin = 0;           // polls before a wait of the dataflow / chained sweep gives up (0 = the default, ~seconds); test hook
+int g_gs_bw_skip_pub = -1;      // test hook: the block with this ticket publishes nothing in dataflow sweeps (a forced protocol error); -1 = none
 int g_gs_bw_chain = 1;          // the wavefront of blocks as one launch per sweep, blocks chained by flags (0: one launch per depth of the quotient graph)
 int g_gs_bw_min_rows = 3000000; // ... operators below this many rows keep the level schedules in mode 1 (half as many for rows of at most 7 entries: tools/bw_threshold.py, profiles/r03_bw_threshold.log)
 int g_gs_sample = 1;            // candidate group sizes of the merged sweeps from a sample of the groups (0 = every candidate built in full); read at schedule build

@@ -501,15 +501,25 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
   } else {
     g->s_dir = -1;
   }
-  if (g->bw.rec) {   // wavefront of blocks: one launch per depth of the quotient DAG, one wave walking each block
-    bw::Args<real> ba{g->bw.blocks, g->bw.rec, g->bw.ext_col, rhs, xp, ldb, xs, omega, 0, nullptr};
-    hipError_t e;
-    if (g_gs_bw_chain && ncolv == 1 && g->bw.flags) {   // one launch, blocks chained by flags
-      bw::ChainArgs<real> ca{ba, backward ? g->bw.sdep_ptr : g->bw.dep_ptr, backward ? g->bw.sdep : g->bw.dep, g->bw.flags, g->bw.head,
-                             g->bw.nblocks, g->bw.err};
-      e = bw::sweep_chain<real>(ca, g->bw.maxk, g->bw.lds_max, sor, backward, st);
+  if (g->bw.on) {   // wavefront of blocks
+    hipError_t e = hipSuccess;
+    const bool flow = g->bw.flow.on && (g_gs_bw_flow || !g->bw.rec);
+    if (flow) {   // as a dataflow: rows published as they are computed, blocks start on finished faces (one launch per column)
+      for (int c = 0; c < ncolv && e == hipSuccess; ++c) {
+        bw::FlowArgs<real> fa{g->bw.blocks, g->bw.flow.fd, g->bw.flow.srec, g->bw.flow.aux, g->bw.ext_col, g->bw.flow.fl_mb, g->bw.flow.fl_slot,
+                              g->bw.flow.mbox, rhs + (int64_t)c * ldb, xp + (int64_t)c * xs, omega, g->bw.head, g->bw.nblocks, (int32_t)g->bw.flow.nmail,
+                              g->bw.err, nullptr, (unsigned)g_gs_bw_spin, (int32_t)g_gs_bw_skip_pub};
+        e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st);
+      }
     } else {
-      e = bw::sweep<real>(ba, g->bw.maxk, g->bw.launch_ptr, g->bw.lds_max, sor, backward, ncolv, st);
+      bw::Args<real> ba{g->bw.blocks, g->bw.rec, g->bw.ext_col, rhs, xp, ldb, xs, omega, 0, nullptr};
+      if (g_gs_bw_chain && ncolv == 1 && g->bw.flags) {   // one launch, blocks chained by flags
+        bw::ChainArgs<real> ca{ba, backward ? g->bw.sdep_ptr : g->bw.dep_ptr, backward ? g->bw.sdep : g->bw.dep, g->bw.flags, g->bw.head,
+                               g->bw.nblocks, g->bw.err};
+        e = bw::sweep_chain<real>(ca, g->bw.maxk, g->bw.lds_max, sor, backward, st);
+      } else {    // one launch per depth of the quotient DAG, one wave walking each block
+        e = bw::sweep<real>(ba, g->bw.maxk, g->bw.launch_ptr, g->bw.lds_max, sor, backward, ncolv, st);
+      }
     }
     if (e != hipSuccess) return -(1000 + (int)e);
   }

@@ -1,0 +1,671 @@
+// gs_flow.hpp — the wavefront of blocks of gs_blocks.hpp executed as a DATAFLOW: blocks start on finished faces.
+// Included by gs_schedule.hpp (single-column sweeps of block-ordered levels) and tools/block_wave_bench.hip.
+//
+// smoother.jl:61-90 (gs!) / :193-221 (sor_step!) in exact lexicographic order, the same plan, partition and arithmetic as
+// gs_blocks.hpp — what changes is WHEN a block may run.  The chained kernel there hands a block over as a whole: a successor
+// waits for its predecessors' flags, so along the critical path every depth of the quotient graph costs the deepest block's
+// whole walk (22 steps of an 8 x 8 x 8 block) plus a flag hand-off, and a block holds 41-124 KB of LDS (its record) from its
+// load to its last step.  Here
+//   * a row that another block reads is PUBLISHED the moment it is computed: one 16-byte write-through store of two
+//     self-tagged 8-byte granules {value half, sweep epoch} into the row's MAILBOX (the data is the flag: no drain, no fence,
+//     no separate flag word — the "R2" hand-off of the CDNA4 guide);
+//   * a second wave of the block's workgroup, the FETCHER, polls the mailboxes of the block's near-side external columns in
+//     the order the walk needs them, stores the values into the block's LDS x and advances a progress word in LDS; the
+//     walker checks that word before each step.  A successor therefore runs a few steps — not a block — behind its
+//     predecessor: 766 + fill serial steps on the 256^3 fine level instead of 94 x 22;
+//   * the packed rows are STREAMED from HBM straight into the walker's registers, a few steps ahead of their use (one
+//     coalesced 16-byte load per chunk: the record is stored chunk-major per step), b and the publish word with them;
+//     LDS holds only x (own rows + external columns): 7-11 KB per block instead of 51-136, so 8 blocks per CU are resident
+//     and the wide middle of the wavefront is no longer bound by LDS slots.
+// Order of operations per row: unchanged (products in stored entry order, separately rounded, one quotient) — the iterate
+// is the scalar loop's bit for bit; tests/test_gpu_flow.py compares it with the chained kernel, the host execution of the plan and the scalar loop.
+//
+// Progress guarantee: workgroups draw tickets in the order of the quotient DAG's depths (as the chained kernel); a block
+// only ever waits for values of blocks with smaller tickets, which are running or done whatever the dispatch order.
+// The data dependencies must carry the anti-dependencies as well (a block's far-side x is read at its start, before any
+// successor may overwrite it): true when the pattern is structurally symmetric — plan-time check, otherwise the chained
+// kernel keeps the level.  Every poll is bounded; a give-up sets *err (read by the solve path: AMGH_ESTATE).
+#pragma once
+#include "gs_blocks.hpp"
+
+namespace amgh {
+namespace bw {
+
+constexpr int kFlowThreads = 128;       // wave 0 walks, wave 1 fetches
+constexpr int32_t kPubFwd = 1 << 30;    // pub word: mailbox index | directions in which the row is published
+constexpr int32_t kPubBwd = (int32_t)(1u << 31);
+constexpr int32_t kPubMask = (1 << 30) - 1;
+#ifndef BW_FLOW_WAVES
+#define BW_FLOW_WAVES 4                 // waves per SIMD the kernel is compiled for (128 registers per lane: 8 blocks per CU)
+#endif
+#ifndef BW_FLOW_DEPTH
+#define BW_FLOW_DEPTH 4                 // steps whose operands are in flight ahead of the walk
+#endif
+
+struct FlowDesc {      // per block, beside Desc (16 bytes)
+  int32_t aux;         // offset into the aux array: step words of the forward walk [nlev + 1], then of the backward walk [nlev + 1]
+  int32_t npost;       // external columns behind the block that are rows (not halo columns of a sharded operator)
+  int32_t pad0, pad1;
+};
+// step word k of a walk (in walking order): first row | rows << 11 | near-side values the step needs in LDS << 18; word nlev: 0 | 0 | all
+constexpr int kStepRowBits = 11, kStepCntBits = 7, kStepNeedMax = (1 << 14) - 1;
+inline uint32_t step_word(int r0, int nr, int need) { return (uint32_t)r0 | ((uint32_t)nr << kStepRowBits) | ((uint32_t)need << (kStepRowBits + kStepCntBits)); }
+
+struct Flow {
+  std::vector<FlowDesc> fd;
+  std::vector<uint32_t> aux;
+  std::vector<int32_t> fl_mb;       // per block at ext0: mailboxes of the forward fetch list (npre entries, in the order of
+  std::vector<uint16_t> fl_slot;    // first use), then of the backward list (npost entries); and the LDS x slot each one fills
+  std::vector<int32_t> pub;         // per row in block order
+  std::vector<unsigned char, NoInit<unsigned char>> srec;   // the records, chunk-major per step (same offsets as Plan::rec)
+  int64_t nmail = 0;
+  size_t lds_max = 0;
+};
+
+// true when every off-diagonal entry (i, c) with c a row has its transpose (c, i) stored
+inline bool structurally_symmetric(int64_t n, const int32_t* rowptr, const int32_t* col, int threads) {
+  std::atomic<int> bad{0};
+  parallel_for(std::max(1, threads), [&](int t, int TT) {
+    for (int64_t i = n * t / TT; i < n * (t + 1) / TT && !bad.load(std::memory_order_relaxed); ++i)
+      for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+        const int32_t c = col[j];
+        if (c == i || c >= n) continue;
+        bool found = false;
+        for (int32_t q = rowptr[c]; q < rowptr[c + 1]; ++q) if (col[q] == i) { found = true; break; }
+        if (!found) { bad.store(1); break; }
+      }
+  });
+  return bad.load() == 0;
+}
+
+// The dataflow view of a plan: mailboxes, fetch lists in order of use, the records transposed for coalesced streaming.
+template <typename R>
+bool flow_build(const Plan& P, int threads, Flow* out) {
+  Flow& F = *out;
+  F = Flow();
+  const int64_t n = P.n;
+  const int32_t B = (int32_t)P.blocks.size();
+  typedef Packed<R> Pk;
+  // rows other blocks read, in which sweep direction they read them as NEW values, and which block reads them first
+  F.pub.assign(n, 0);
+  std::vector<int32_t> reader(n, -1);   // forward: the first block behind that reads the row; rows only read backward: the last block before
+  for (int32_t ob = 0; ob < B; ++ob) {
+    const Desc& d = P.blocks[ob];
+    for (int32_t e = 0; e < d.next; ++e) {
+      const int32_t q = P.ext_col[d.ext0 + e];
+      if (q >= n) continue;                                 // halo column: never written
+      if (e < d.npre) {                                     // before the block: a new value of the forward sweep
+        if (!(F.pub[q] & kPubFwd) || ob < reader[q]) reader[q] = ob;
+        F.pub[q] |= kPubFwd;
+      } else {
+        if (!(F.pub[q] & kPubFwd)) reader[q] = std::max(reader[q], ob);
+        F.pub[q] |= kPubBwd;
+      }
+    }
+  }
+  // mailboxes: a block's published rows grouped by (direction, reading block), in block order inside a group — what one
+  // reader fetches from one block is then a run of consecutive cells in the order it needs them (coalesced polls), and what
+  // a step publishes towards one reader is a run as well (merged write-through stores)
+  int64_t nm = 0;
+  {
+    std::vector<int64_t> base(B + 1, 0);
+    for (int32_t ob = 0; ob < B; ++ob) {
+      const Desc& d = P.blocks[ob];
+      int64_t c = 0;
+      for (int32_t p = 0; p < d.nrows; ++p) c += F.pub[d.row0 + p] != 0;
+      base[ob + 1] = base[ob] + c;
+    }
+    nm = base[B];
+    if (nm >= kPubMask) return false;
+    parallel_for(std::max(1, threads), [&](int t, int TT) {
+      std::vector<int32_t> rows;
+      for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
+        const Desc& d = P.blocks[ob];
+        rows.clear();
+        for (int32_t p = 0; p < d.nrows; ++p) if (F.pub[d.row0 + p] != 0) rows.push_back(d.row0 + p);
+        std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) {
+          const int fx = (F.pub[x] & kPubFwd) ? 0 : 1, fy = (F.pub[y] & kPubFwd) ? 0 : 1;
+          if (fx != fy) return fx < fy;
+          return reader[x] < reader[y];
+        });
+        for (size_t i = 0; i < rows.size(); ++i) F.pub[rows[i]] |= (int32_t)(base[ob] + (int64_t)i);
+      }
+    });
+    for (int64_t q = 0; q < n; ++q) if (F.pub[q] == 0) F.pub[q] = kPubMask;   // (no direction bits: never published)
+  }
+  F.nmail = nm;
+  F.fd.resize(B);
+  int64_t aux_total = 0;
+  for (int32_t ob = 0; ob < B; ++ob) {
+    F.fd[ob].aux = (int32_t)aux_total;
+    aux_total += 2 * ((int64_t)P.blocks[ob].nlev + 1);
+    if (aux_total > INT32_MAX || P.blocks[ob].nrows >= (1 << kStepRowBits) || P.blocks[ob].next > kStepNeedMax) return false;
+  }
+  F.aux.assign((size_t)aux_total, 0);
+  F.fl_mb.assign(std::max<size_t>(1, P.ext_col.size()), 0);
+  F.fl_slot.assign(std::max<size_t>(1, P.ext_col.size()), 0);
+  F.srec.resize(P.rec.size());
+  std::atomic<size_t> lds_max{0};
+  parallel_for(std::max(1, threads), [&](int t, int TT) {
+    std::vector<int32_t> use, order;
+    size_t my_lds = 0;
+    for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
+      const Desc& d = P.blocks[ob];
+      FlowDesc& f = F.fd[ob];
+      const unsigned char* rec = P.rec.data() + (size_t)d.rec * 16;
+      unsigned char* srec = F.srec.data() + (size_t)d.rec * 16;
+      const size_t rs = Pk::row_bytes(d.maxk);
+      const int kch = Pk::chunks(d.maxk), nvc = Pk::nvc(d.maxk);
+      const uint16_t* stp = (const uint16_t*)(rec + (size_t)d.nrows * rs);
+      const int ns = d.nlev;
+      uint32_t* ax = F.aux.data() + f.aux;
+      // first / last step that reads each external slot
+      use.assign((size_t)d.next * 2, 0);
+      for (int32_t e = 0; e < d.next; ++e) { use[2 * e] = INT32_MAX; use[2 * e + 1] = -1; }
+      for (int s = 0; s < ns; ++s)
+        for (int32_t p = stp[s]; p < stp[s + 1]; ++p) {
+          const uint16_t* cc = (const uint16_t*)(rec + (size_t)p * rs + (size_t)16 * nvc);
+          for (int k = 0; k < d.maxk; ++k) {
+            const int32_t slot = (int32_t)(cc[k] / sizeof(R));
+            if (slot < d.nrows || slot >= d.nrows + d.next) continue;
+            const int32_t e = slot - d.nrows;
+            use[2 * e] = std::min(use[2 * e], s); use[2 * e + 1] = std::max(use[2 * e + 1], s);
+          }
+        }
+      int32_t npost = 0;
+      for (int32_t e = d.npre; e < d.next; ++e) if (P.ext_col[d.ext0 + e] < n) ++npost;
+      f.npost = npost; f.pad0 = f.pad1 = 0;
+      // forward list: near side = columns before the block, by first use; need_fwd[k] = entries step k needs complete
+      order.resize(d.npre);
+      for (int32_t e = 0; e < d.npre; ++e) order[e] = e;
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return use[2 * a] < use[2 * b]; });
+      {
+        int32_t done = 0;
+        for (int k = 0; k < ns; ++k) {
+          while (done < d.npre && use[2 * order[done]] <= k) ++done;
+          ax[k] = step_word(stp[k], stp[k + 1] - stp[k], done);
+        }
+        ax[ns] = step_word(0, 0, d.npre);
+        for (int32_t i = 0; i < d.npre; ++i) {
+          const int32_t e = order[i];
+          F.fl_mb[d.ext0 + i] = F.pub[P.ext_col[d.ext0 + e]] & kPubMask;
+          F.fl_slot[d.ext0 + i] = (uint16_t)(d.nrows + e);
+        }
+      }
+      // backward list: columns behind the block (rows only), by first use in the reversed walk (step ns - 1 - k)
+      order.resize(npost);
+      for (int32_t i = 0; i < npost; ++i) order[i] = d.npre + i;    // (halo columns sort last in ext_col: the first npost are rows)
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return use[2 * a + 1] > use[2 * b + 1]; });
+      {
+        int32_t done = 0;
+        for (int k = 0; k < ns; ++k) {
+          while (done < npost && ns - 1 - use[2 * order[done] + 1] <= k) ++done;
+          ax[ns + 1 + k] = step_word(stp[ns - 1 - k], stp[ns - k] - stp[ns - 1 - k], done);
+        }
+        ax[2 * ns + 1] = step_word(0, 0, npost);
+        for (int32_t i = 0; i < npost; ++i) {
+          const int32_t e = order[i];
+          F.fl_mb[d.ext0 + d.npre + i] = F.pub[P.ext_col[d.ext0 + e]] & kPubMask;
+          F.fl_slot[d.ext0 + d.npre + i] = (uint16_t)(d.nrows + e);
+        }
+      }
+      // the record, chunk-major per step: chunk c of the step's row t at 16 (kch stp[s] + c nr + t)
+      for (int s = 0; s < ns; ++s) {
+        const int32_t r0 = stp[s], nr = stp[s + 1] - stp[s];
+        for (int c = 0; c < kch; ++c)
+          for (int32_t q = 0; q < nr; ++q)
+            std::memcpy(srec + ((size_t)kch * r0 + (size_t)c * nr + q) * 16, rec + (size_t)(r0 + q) * rs + (size_t)16 * c, 16);
+      }
+      // the publish word rides in the spare dword of the row's last column chunk
+      {
+        const int cdw = ((d.maxk + 1) / 2 - 1) % 4 + 1;   // dwords of that chunk that hold columns (FlowOps::CTAIL)
+        for (int s = 0; s < ns; ++s) {
+          const int32_t r0 = stp[s], nr = stp[s + 1] - stp[s];
+          for (int32_t q = 0; q < nr; ++q)
+            std::memcpy(srec + ((size_t)kch * r0 + (size_t)(nvc + Pk::ncc(d.maxk) - 1) * nr + q) * 16 + 4 * cdw, &F.pub[d.row0 + r0 + q], 4);
+        }
+      }
+      std::memcpy(srec + (size_t)d.nrows * rs, rec + (size_t)d.nrows * rs, Pk::rec_bytes(d.nrows, d.maxk, d.nlev) - (size_t)d.nrows * rs);
+      my_lds = std::max(my_lds, (((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15) + 16);
+    }
+    size_t cur = lds_max.load();
+    while (my_lds > cur && !lds_max.compare_exchange_weak(cur, my_lds)) {}
+  });
+  F.lds_max = lds_max.load();
+  return true;
+}
+
+// ---- device side -----------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename R>
+struct FlowArgs {
+  const Desc* blocks; const FlowDesc* fd;
+  const unsigned char* srec; const uint32_t* aux;
+  const int32_t* ext_col; const int32_t* fl_mb; const uint16_t* fl_slot;
+  void* mbox;                        // 16 bytes per mailbox (double: {lo, epoch, hi, epoch}); 8 (float: {value, epoch})
+  const R* b; R* x; R omega;
+  unsigned long long* head;          // ticket counter (never reset): epoch = ticket / nblocks + 1
+  int32_t nblocks;
+  int32_t nmail;                     // mailboxes (1024 spare cells behind them)
+  int32_t* err;
+  long long* tim;                    // measurement hook: 4 stamps per block, then 128 step stamps per block, or null
+  unsigned int spin_limit;           // polls before a wait gives up (0: the default)
+  int32_t skip_pub;                  // test hook: the block of this ticket publishes nothing (a forced protocol error), -1: none
+};
+
+template <typename R> struct Mail;
+template <> struct Mail<double> {
+  static constexpr int kBytes = 16;
+  typedef u32x4 cell;
+  static __device__ __forceinline__ cell load(__amdgpu_buffer_rsrc_t rs, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16); }   // sc1: past this CU's L1
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned off, double v, unsigned epoch) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    cell c; c.x = (unsigned)u; c.y = epoch; c.z = (unsigned)(u >> 32); c.w = epoch;
+    __builtin_amdgcn_raw_buffer_store_b128(c, rs, off, 0, 16);                                    // sc1: write-through
+  }
+  static __device__ __forceinline__ bool valid(const cell& c, unsigned epoch) { return c.y == epoch && c.w == epoch; }
+  static __device__ __forceinline__ double value(const cell& c) { return __longlong_as_double((long long)(((unsigned long long)c.z << 32) | c.x)); }
+};
+template <> struct Mail<float> {
+  static constexpr int kBytes = 8;
+  typedef u32x2 cell;
+  static __device__ __forceinline__ cell load(__amdgpu_buffer_rsrc_t rs, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 16); }
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned off, float v, unsigned epoch) {
+    cell c; c.x = __float_as_uint(v); c.y = epoch;
+    __builtin_amdgcn_raw_buffer_store_b64(c, rs, off, 0, 16);
+  }
+  static __device__ __forceinline__ bool valid(const cell& c, unsigned epoch) { return c.y == epoch; }
+  static __device__ __forceinline__ float value(const cell& c) { return __uint_as_float(c.x); }
+};
+
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <int NDW> struct Dw;
+template <> struct Dw<1> { typedef unsigned int type; };
+template <> struct Dw<2> { typedef u32x2 type; };
+template <> struct Dw<3> { typedef u32x3 type; };
+template <> struct Dw<4> { typedef u32x4 type; };
+__device__ __forceinline__ u32x4 widen(unsigned int v) { u32x4 r = {v, 0u, 0u, 0u}; return r; }
+__device__ __forceinline__ u32x4 widen(u32x2 v) { u32x4 r = {v.x, v.y, 0u, 0u}; return r; }
+__device__ __forceinline__ u32x4 widen(u32x3 v) { u32x4 r = {v.x, v.y, v.z, 0u}; return r; }
+__device__ __forceinline__ u32x4 widen(u32x4 v) { return v; }
+// The walker's memory operations are written out: the compiler counts the loads it schedules itself, but in this loop its
+// counting collapses (any load issued before a loop it cannot analyse, any branch with a store inside, makes it wait for
+// nearly everything in flight at every step), and the pipeline below lives on exact counts.  A load's destination is a
+// compiler-allocated register ("=v"); nothing reads it before the flow_wait statement that names it ("+v").
+__device__ __forceinline__ i32x4 make_rsrc(const void* base) {
+  const unsigned long long u = (unsigned long long)base;
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)u);
+  r.y = __builtin_amdgcn_readfirstlane((int)((u >> 32) & 0xffffu));
+  r.z = 0x7ffffff0; r.w = 0x00020000;
+  return r;
+}
+template <int NDW>
+__device__ __forceinline__ void asm_load(typename Dw<NDW>::type& r, unsigned voff, i32x4 rs, unsigned soff) {
+  if constexpr (NDW == 4) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+  else if constexpr (NDW == 3) asm volatile("buffer_load_dwordx3 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+  else if constexpr (NDW == 2) asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+  else asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void asm_store_sc1(u32x4 v, unsigned voff, i32x4 rs) {   // write-through; (s_nop: the data registers are read after issue)
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void asm_store_sc1(u32x2 v, unsigned voff, i32x4 rs) {
+  asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen sc1" :: "v"(v), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void asm_store(u32x2 v, unsigned voff, i32x4 rs) {
+  asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void asm_store(unsigned int v, unsigned voff, i32x4 rs) {
+  asm volatile("buffer_store_dword %0, %1, %2, 0 offen" :: "v"(v), "v"(voff), "s"(rs) : "memory");
+}
+
+template <typename R, int MAXK>
+struct FlowOps {
+  static constexpr int VPC = 16 / (int)sizeof(R), NVC = (MAXK + 2 + VPC - 1) / VPC, NCC = (MAXK + 7) / 8, KCH = (NVC + NCC) | 1;
+  // dwords of the last value / column chunk that carry data (a load fetches exactly those)
+  static constexpr int VTAIL = ((MAXK + 2) * (int)sizeof(R) / 4 - 1) % 4 + 1, CTAIL = ((MAXK + 1) / 2 - 1) % 4 + 1;
+  static_assert(CTAIL < 4, "the publish word rides in the spare dword behind the row's last columns");
+  static constexpr int NLOAD = NVC + NCC + 1;   // loads per step: the chunks and b
+  u32x4 vf[NVC > 1 ? NVC - 1 : 1];              // full value chunks
+  typename Dw<VTAIL>::type vt;                  // the last one: ... diagonal, reciprocal
+  u32x4 cf[NCC > 1 ? NCC - 1 : 1];              // full column chunks
+  typename Dw<CTAIL + 1>::type ct;              // the last one: columns, publish word
+  typename Dw<(int)sizeof(R) / 4>::type bb;
+  int p; int need;
+  __device__ __forceinline__ u32x4 vchunk(int c) const { return c < NVC - 1 ? vf[c] : widen(vt); }
+  __device__ __forceinline__ u32x4 cchunk(int c) const { return c < NCC - 1 ? cf[c] : widen(ct); }
+  __device__ __forceinline__ int32_t pub() const { const u32x4 c = widen(ct); return (int32_t)(CTAIL == 1 ? c.y : CTAIL == 2 ? c.z : c.w); }
+};
+// every load of o has landed once at most N younger memory operations are in flight
+template <int N, typename O>
+__device__ __forceinline__ void flow_wait(O& o) {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
+#pragma unroll
+  for (int c = 0; c < O::NVC - 1; ++c) asm volatile("" : "+v"(o.vf[c]));
+  asm volatile("" : "+v"(o.vt));
+#pragma unroll
+  for (int c = 0; c < O::NCC - 1; ++c) asm volatile("" : "+v"(o.cf[c]));
+  asm volatile("" : "+v"(o.ct));
+  asm volatile("" : "+v"(o.bb));
+}
+template <typename R, typename O> __device__ __forceinline__ R chunk_value(const O& o, int k) {   // value k of the row (k: a constant after unrolling)
+  if constexpr (sizeof(R) == 8) {
+    const u32x4 c = o.vchunk(k >> 1);
+    return (k & 1) ? __hiloint2double((int)c.w, (int)c.z) : __hiloint2double((int)c.y, (int)c.x);
+  } else {
+    const u32x4 c = o.vchunk(k >> 2);
+    const unsigned w = (k & 3) == 0 ? c.x : (k & 3) == 1 ? c.y : (k & 3) == 2 ? c.z : c.w;
+    return __uint_as_float(w);
+  }
+}
+template <typename R> __device__ __forceinline__ R load_real(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ double load_real<double>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+  return __hiloint2double((int)t[1], (int)t[0]);
+}
+template <> __device__ __forceinline__ float load_real<float>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void store_real(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, double v) {
+  u32x2 t; t.x = (unsigned)__double2loint(v); t.y = (unsigned)__double2hiint(v);
+  __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, soff, 0);
+}
+__device__ __forceinline__ void store_real(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
+
+// a pointer every lane holds alike, moved into scalar registers (a buffer descriptor the compiler cannot prove uniform is
+// wrapped in a serialising "waterfall" loop around every access)
+template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long u = (unsigned long long)p;
+  return (T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)u));
+}
+template <int MAXK> struct FlowDepth { static constexpr int value = MAXK <= 6 ? BW_FLOW_DEPTH : MAXK <= 12 ? (BW_FLOW_DEPTH < 4 ? BW_FLOW_DEPTH : 4) : 3; };
+static_assert(BW_FLOW_DEPTH >= 2 && BW_FLOW_DEPTH <= 6, "the first round of the pipeline is written out for up to six sets");
+
+template <typename R, bool SOR, bool BWD, int MAXK>
+__global__ __launch_bounds__(kFlowThreads, (MAXK <= 6 ? BW_FLOW_WAVES : 2)) void gs_bw_flow_kernel(FlowArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  typedef FlowOps<R, MAXK> O;
+  typedef Mail<R> M;
+  constexpr int D = FlowDepth<MAXK>::value;
+  constexpr int RB = (int)sizeof(R);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const long long t_start = a.tim ? wall_clock64() : 0;
+  // (the ticket travels through the first word of the dynamic LDS — no static LDS: the base stays 16-byte aligned)
+  unsigned long long* s_ticket = (unsigned long long*)lds;
+  // (a launch starts with every resident workgroup at this line at once; one word takes ~88 atomics per microsecond, and the
+  // first blocks' loads queue behind the burst — so the first workgroups stagger their draw, 12 ns apart: far less than the
+  // time before their blocks can run.  A pure delay: tickets are still drawn by whoever comes)
+  if (blockIdx.x < 2048u) for (unsigned i = 0; i < (blockIdx.x >> 5); ++i) __builtin_amdgcn_s_sleep(14);
+  if (tid == 0) *s_ticket = atomicAdd(a.head, 1ull);
+  __syncthreads();
+  // (made wave-uniform by hand: everything derived from it — descriptors, step words, buffer offsets — then lives in scalar
+  // registers; left to the compiler, a value read from LDS counts as divergent and every buffer access becomes a waterfall loop)
+  const unsigned long long tv = *s_ticket;
+  const unsigned long long ticket = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
+  __syncthreads();   // (the word is x[0] from here on)
+  const unsigned int epoch = (unsigned int)(ticket / (unsigned long long)a.nblocks) + 1u;
+  const int tk = (int)(ticket % (unsigned long long)a.nblocks);
+  const int ob = __builtin_amdgcn_readfirstlane(BWD ? a.nblocks - 1 - tk : tk);
+  const Desc d = a.blocks[ob];
+  const FlowDesc f = a.fd[ob];
+  const int ns = d.nlev;
+  const int nxb = (int)(((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15);
+  R* xl = (R*)lds;
+  unsigned int* progress = (unsigned int*)(lds + nxb);
+  R* x = a.x;
+  const unsigned spin_limit = a.spin_limit ? a.spin_limit : (1u << 22);
+  __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.mbox), 0, 0x7ffffff0, 0x00020000);
+  // the walker's pipeline starts ahead of the block's load phase: step words, then the operands of the first D steps
+  const uint32_t* ax = a.aux + f.aux + (BWD ? ns + 1 : 0);
+  // (step words by scalar loads, one issue ahead: a vector-loaded register read inside the main loop makes the compiler
+  // drain every load in flight there — its counting loses track of a load issued before a loop it cannot analyse)
+  typedef const uint32_t __attribute__((address_space(4))) cu32;   // (constant address space: read-only for the kernel's lifetime, so a uniform index is a scalar load)
+  const cu32* axc = (const cu32*)(unsigned long long)uniform_ptr(ax);
+  unsigned sw_next = axc[0];
+  const i32x4 rs_rec = make_rsrc(a.srec + (size_t)(uint32_t)d.rec * 16);
+  const i32x4 rs_b = make_rsrc(a.b + d.row0);
+  const i32x4 rs_x = make_rsrc(x + d.row0);
+  const i32x4 rs_mst = make_rsrc(a.mbox);
+  // operands of walking step kk into o (steps behind the last one: a harmless re-read of the block's first chunk);
+  // O::NLOAD loads, always
+  auto issue = [&](O& o, int kk) {
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)sw_next);   // the word of step min(kk, ns): the steps are issued in order
+    sw_next = axc[kk + 1 < ns ? kk + 1 : ns];
+    const int r0 = (int)(w & ((1u << kStepRowBits) - 1)), nr = (int)((w >> kStepRowBits) & ((1u << kStepCntBits) - 1));
+    o.need = (int)(w >> (kStepRowBits + kStepCntBits));
+    // (idle lanes repeat the step's first row: the same reads, the same value to the same places — no branch in a step)
+    const int tt = lane < nr ? lane : 0;
+    o.p = r0 + tt;
+    const unsigned voff = (unsigned)tt * 16u;
+    const unsigned s0 = (unsigned)r0 * (16u * O::KCH), sd = (unsigned)nr * 16u;
+#pragma unroll
+    for (int c = 0; c < O::NVC - 1; ++c) asm_load<4>(o.vf[c], voff, rs_rec, s0 + (unsigned)c * sd);
+    asm_load<O::VTAIL>(o.vt, voff, rs_rec, s0 + (unsigned)(O::NVC - 1) * sd);
+#pragma unroll
+    for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)(O::NVC + c) * sd);
+    asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NVC + O::NCC - 1) * sd);
+    asm_load<RB / 4>(o.bb, (unsigned)tt * RB, rs_b, (unsigned)r0 * RB);
+  };
+  O ops[D];
+  if (tid < 64) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(ops[j], j);
+  }
+  // ---- load phase (the fetcher wave; the walker's operand loads are already in flight): own x, every external column as
+  // it stands ----
+  if (tid >= 64) {
+    constexpr int XU = 5, EU = 4;   // (batches: every load of a batch in flight at once)
+    for (int p0 = 0; p0 < d.nrows; p0 += 64 * XU) {
+      R xv[XU];
+#pragma unroll
+      for (int k = 0; k < XU; ++k) { const int p = p0 + lane + 64 * k; xv[k] = x[d.row0 + (p < d.nrows ? p : 0)]; }
+#pragma unroll
+      for (int k = 0; k < XU; ++k) pin(xv[k]);
+#pragma unroll
+      for (int k = 0; k < XU; ++k) { const int p = p0 + lane + 64 * k; if (p < d.nrows) xl[p] = xv[k]; }
+    }
+    // (far side: the columns the sweep has not reached — behind the block going forward, before it going backward — and halo
+    // columns; the near side arrives through the mailboxes)
+    const int nfar = BWD ? d.npre + (d.next - d.npre - f.npost) : d.next - d.npre;
+    for (int e0 = 0; e0 < nfar; e0 += 64 * EU) {
+      int32_t ec[EU]; int es[EU];
+#pragma unroll
+      for (int k = 0; k < EU; ++k) {
+        const int i = e0 + lane + 64 * k;
+        es[k] = BWD ? (i < d.npre ? i : i + f.npost) : d.npre + i;   // slot in the external list
+        ec[k] = a.ext_col[i < nfar ? d.ext0 + es[k] : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < EU; ++k) pin(ec[k]);
+      R xe[EU];
+#pragma unroll
+      for (int k = 0; k < EU; ++k) xe[k] = x[ec[k]];
+#pragma unroll
+      for (int k = 0; k < EU; ++k) pin(xe[k]);
+#pragma unroll
+      for (int k = 0; k < EU; ++k) { const int i = e0 + lane + 64 * k; if (i < nfar) xl[d.nrows + es[k]] = xe[k]; }
+    }
+    if (lane == 0) { xl[d.nrows + d.next] = (R)0; *progress = 0u; }
+  }
+  __syncthreads();
+  if (tid >= 64) {
+    // ---- the fetcher: near-side values out of their mailboxes, in the order the walk needs them.  A window of U x 64 list
+    // entries is polled (only the groups up to the one behind the first missing entry); the progress word counts the LEADING
+    // entries that have arrived, so the walker goes on as soon as what its next step reads is there ----
+    constexpr int U = 3;
+    const int nf = BWD ? f.npost : d.npre;
+    const int f0 = d.ext0 + (BWD ? d.npre : 0);
+    unsigned total_spins = 0;
+    bool fail = false;
+    for (int w0 = 0; w0 < nf && !fail; w0 += 64 * U) {
+      int32_t mb[U]; int slot[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = w0 + 64 * u + lane;
+        mb[u] = a.fl_mb[e < nf ? f0 + e : f0];
+        slot[u] = a.fl_slot[e < nf ? f0 + e : f0];
+        ok[u] = !(e < nf);
+      }
+      int first = 0;   // leading entries of the window that have arrived
+      for (;;) {
+        typename M::cell c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (!ok[u] && 64 * u <= first + 64) c[u] = M::load(rs_mail, (unsigned)mb[u] * (unsigned)M::kBytes);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (!ok[u] && 64 * u <= first + 64 && M::valid(c[u], epoch)) { xl[slot[u]] = M::value(c[u]); ok[u] = true; }
+        int nfirst = 64 * U;
+#pragma unroll
+        for (int u = U - 1; u >= 0; --u) {
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(!ok[u]);
+          if (m) nfirst = 64 * u + (int)__builtin_ctzll(m);
+        }
+        // (LDS operations of one wave execute in program order: the values are in place before the progress word moves)
+        if (nfirst != first && lane == 0) __hip_atomic_store(progress, (unsigned)(w0 + nfirst < nf ? w0 + nfirst : nf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool moved = nfirst != first;
+        first = nfirst;
+        if (first == 64 * U) break;
+        if (!moved) __builtin_amdgcn_s_sleep(4);
+        if (++total_spins > spin_limit) { fail = true; break; }
+      }
+    }
+    if (fail && lane == 0) { *a.err = 1; __hip_atomic_store(progress, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    return;
+  }
+  // ---- the walker ----
+  __builtin_amdgcn_s_setprio(2);
+  const long long t_loaded = a.tim ? wall_clock64() : 0;
+  const int32_t pubdir = BWD ? kPubBwd : kPubFwd;
+  const bool mute = a.skip_pub == tk;
+  const unsigned spare = (unsigned)a.nmail + (unsigned)(ob & 1023);   // (behind the mailboxes: 1024 cells nobody reads)
+  unsigned seen = 0;
+  bool gave_up = false;
+  auto step = [&](const O& o, int kk) {
+    // the near-side values this step reads are in LDS
+    if ((unsigned)o.need > seen) {
+      unsigned spins = 0;
+      for (;;) {
+        seen = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (seen >= (unsigned)o.need) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 4u * spin_limit) { gave_up = true; break; }
+      }
+    }
+    asm volatile("" ::: "memory");   // the gathers stay below the progress word
+    R xv[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const u32x4 cw = o.cchunk(k >> 3);
+      const unsigned w = ((k >> 1) & 3) == 0 ? cw.x : ((k >> 1) & 3) == 1 ? cw.y : ((k >> 1) & 3) == 2 ? cw.z : cw.w;
+      const unsigned off = (k & 1) ? (w >> 16) : (w & 0xffffu);
+      xv[k] = *(const R*)((const char*)xl + off);
+    }
+    const R xo = xl[o.p];
+    R acc = (R)0;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) acc += chunk_value<R>(o, k) * xv[k];
+    const R dg = chunk_value<R>(o, MAXK), rc = chunk_value<R>(o, MAXK + 1);
+    R bbv;
+    if constexpr (sizeof(R) == 8) bbv = __hiloint2double((int)o.bb.y, (int)o.bb.x); else bbv = __uint_as_float(o.bb);
+    const R nn = bbv - acc;
+    R q;
+    if (SOR) q = ((R)1 - a.omega) * xo + (a.omega / dg) * nn;
+    else {
+      // (bb - acc) / dg from rc = RN(1 / dg): the correctly rounded quotient (Markstein) inside the normal range — packed_row
+      q = nn * rc;
+      const R rem = __builtin_fma(-dg, q, nn);
+      q = __builtin_fma(rem, rc, q);
+      const R an = __builtin_fabs(nn);
+      const bool safe = sizeof(R) == 8 ? (an > (R)1e-200 && an < (R)1e200) : (an > (R)1e-25 && an < (R)1e25);
+      if (__builtin_amdgcn_ballot_w64(!(rc != (R)0 && safe) && dg != (R)0) != 0) {
+        asm volatile("; rows outside the normal range: the division itself" ::: "memory");
+        if (!(rc != (R)0 && safe)) q = nn / dg;
+      }
+    }
+    q = dg != (R)0 ? q : xo;   // a zero diagonal: the row keeps its value (smoother.jl:87) — and publishes it: its readers wait for the tag
+    xl[o.p] = q;
+    // a row another block reads: into its mailbox at once, tagged with the sweep's epoch; every other lane into the block's
+    // spare cell (one more line per step instead of a branch around the store)
+    const int32_t pw = o.pub();
+    const unsigned cell = ((pw & pubdir) && !mute) ? (unsigned)(pw & kPubMask) : spare;
+    if constexpr (sizeof(R) == 8) {
+      const unsigned qlo = (unsigned)__double2loint(q), qhi = (unsigned)__double2hiint(q);
+      u32x4 cv = {qlo, epoch, qhi, epoch};
+      asm_store_sc1(cv, cell * 16u, rs_mst);
+      u32x2 xv2 = {qlo, qhi};
+      asm_store(xv2, (unsigned)o.p * 8u, rs_x);
+    } else {
+      u32x2 cv = {__float_as_uint(q), epoch};
+      asm_store_sc1(cv, cell * 8u, rs_mst);
+      asm_store(__float_as_uint(q), (unsigned)o.p * 4u, rs_x);
+    }
+#ifdef BW_FLOW_STEP_STAMPS   // (measurement builds only: a conditional store in the step makes the compiler's load counting conservative)
+    if (a.tim && lane == 0) a.tim[4 * (int64_t)a.nblocks + 128 * (int64_t)ob + kk] = wall_clock64();
+#endif
+  };
+  // The pipeline: D register sets; a step waits for its own set (vmcnt counted exactly: between a set's loads and its use lie
+  // the loads and the two stores of the D - 1 steps in between — fewer at the start, where the sets were loaded back to back),
+  // computes, stores, and re-loads the set for the step D ahead.
+  constexpr int L = O::NLOAD, S = 2;
+  int k = 0;
+  if (ns >= D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {   // the first round: set j was followed by D - 1 - j more sets and j whole steps
+      if (j == 0) flow_wait<(D - 1) * L>(ops[0]);
+      else if (j == 1) flow_wait<(D - 2) * L + 1 * (L + S)>(ops[1 < D ? 1 : 0]);
+      else if (j == 2) flow_wait<(D > 2 ? D - 3 : 0) * L + 2 * (L + S)>(ops[2 < D ? 2 : 0]);
+      else if (j == 3) flow_wait<(D > 3 ? D - 4 : 0) * L + 3 * (L + S)>(ops[3 < D ? 3 : 0]);
+      else if (j == 4) flow_wait<(D > 4 ? D - 5 : 0) * L + 4 * (L + S)>(ops[4 < D ? 4 : 0]);
+      else flow_wait<(D > 5 ? D - 6 : 0) * L + 5 * (L + S)>(ops[5 < D ? 5 : 0]);
+      step(ops[j], j);
+      issue(ops[j], j + D);
+    }
+    for (k = D; k + D <= ns; k += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        flow_wait<(D - 1) * (L + S)>(ops[j]);
+        step(ops[j], k + j);
+        issue(ops[j], k + j + D);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j)
+    if (k + j < ns) { flow_wait<0>(ops[j]); step(ops[j], k + j); }
+  if (gave_up && lane == 0) *a.err = 2;
+  if (a.tim && lane == 0) {
+    long long* tt = a.tim + 4 * (int64_t)ob;
+    tt[0] = t_start; tt[1] = t_loaded; tt[2] = wall_clock64(); tt[3] = 0;
+  }
+}
+
+template <typename R, int MAXK>
+inline hipError_t sweep_flow_k(const FlowArgs<R>& a, size_t lds_max, bool sor, bool backward, hipStream_t st) {
+  const dim3 grid((unsigned)a.nblocks);
+  if (lds_max > 64 * 1024) return hipErrorInvalidValue;
+  if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_flow_kernel<R, true, true, MAXK>), grid, dim3(kFlowThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_flow_kernel<R, true, false, MAXK>), grid, dim3(kFlowThreads), lds_max, st, a); }
+  else { if (backward) hipLaunchKernelGGL((gs_bw_flow_kernel<R, false, true, MAXK>), grid, dim3(kFlowThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_flow_kernel<R, false, false, MAXK>), grid, dim3(kFlowThreads), lds_max, st, a); }
+  return hipGetLastError();
+}
+template <typename R>
+inline hipError_t sweep_flow(const FlowArgs<R>& a, int maxk, size_t lds_max, bool sor, bool backward, hipStream_t st) {
+  switch (maxk) {
+    case 6: return sweep_flow_k<R, 6>(a, lds_max, sor, backward, st);
+    case 12: return sweep_flow_k<R, 12>(a, lds_max, sor, backward, st);
+#if BW_PLAN_MAXK >= 18
+    case 18: return sweep_flow_k<R, 18>(a, lds_max, sor, backward, st);
+#endif
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace bw
+}  // namespace amgh

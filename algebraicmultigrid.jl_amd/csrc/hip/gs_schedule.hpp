@@ -886,6 +886,7 @@ double merge_cost(int64_t ngroups, int64_t nnz) { return ngroups * 3.8e-6 + 12.0
 
 }  // namespace
 #include "gs_merge_dev.hpp"
+#include "gs_flow.hpp"
 namespace {
 
 // Build the dependency-level schedule from HOST arrays of the smoother matrix.
@@ -973,6 +974,31 @@ void permuted_matrix(int64_t n, int64_t ncols, const int32_t* rowptr, const int3
   });
 }
 
+// The word a bounded poll of the chained / dataflow sweeps raises when it gives up (gs_blocks.hpp, gs_flow.hpp): ONE word
+// per process in pinned host memory that the kernels write through its device address — the host reads it after any
+// synchronisation at no cost (no copy), and every entry point that synchronises turns a raised word into AMGH_ESTATE
+// (bw_err_check) instead of handing out the numbers of a sweep that went on with stale values.
+inline int32_t* bw_err_word() {
+  static int32_t* word = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) { word = (int32_t*)p; *word = 0; }
+    else (void)hipGetLastError();
+  });
+  return word;
+}
+// AMGH_ESTATE (and the word lowered again) when a sweep since the last check gave up a poll; call behind a synchronisation
+inline int bw_err_check() {
+  int32_t* w = bw_err_word();
+  if (!w) return AMGH_OK;
+  const int32_t v = *(volatile int32_t*)w;
+  if (v == 0) return AMGH_OK;
+  *(volatile int32_t*)w = 0;
+  if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] a block sweep gave up a poll (code %d): AMGH_ESTATE\n", (int)v);
+  return AMGH_ESTATE;
+}
+
 // The schedule as a WAVEFRONT OF BLOCKS (gs_blocks.hpp) where it pays: rows in block order, one packed record per block,
 // a launch per depth of the quotient DAG, one wave walking each block — no substitution, the scalar loop's arithmetic.
 // Sets g->bw (and everything the level-ordered cycle needs: perm, the permuted CSR copy, bp / xp) or leaves g untouched
@@ -1024,10 +1050,40 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   RC_TRY(dev_upload(&g->bw.blocks, P.blocks.data(), (int64_t)P.blocks.size()));
   if (P.ext_col.empty()) P.ext_col.push_back(0);   // (a single block has no external column)
   RC_TRY(dev_upload(&g->bw.ext_col, P.ext_col.data(), (int64_t)P.ext_col.size()));
-  RC_TRY(dev_upload(&g->bw.rec, P.rec.data(), (int64_t)P.rec.size()));
   g->bw.launch_ptr = P.launch_ptr;
-  {   // the quotient graph and the flags of the chained sweep
-    const int64_t B = (int64_t)P.blocks.size();
+  g->bw.err = bw_err_word();
+  if (!g->bw.err) return -1001;
+  const int64_t B = (int64_t)P.blocks.size();
+  RC_TRY(dev_alloc(&g->bw.head, 1));
+  if (hipMemset(g->bw.head, 0, 8) != hipSuccess) return -1001;
+  g->bw.nblocks = (int32_t)B;
+  // the sweep as a dataflow (gs_flow.hpp) where the data dependencies carry the anti-dependencies: structurally symmetric patterns
+  if (g_gs_bw_flow && ncols <= n && bw::structurally_symmetric(n, rowptr, col, prm.threads)) {
+    bw::Flow F;
+    if (bw::flow_build<real>(P, prm.threads, &F) && F.lds_max <= 64 * 1024 && (F.nmail + 1024) * (int64_t)bw::Mail<real>::kBytes < 0x7ffffff0ll) {
+      tm.lap("dataflow layout", n);
+      GsSchedule::Bw::FlowDev& fl = g->bw.flow;
+      RC_TRY(dev_upload(&fl.fd, F.fd.data(), (int64_t)F.fd.size()));
+      RC_TRY(dev_upload(&fl.srec, F.srec.data(), (int64_t)F.srec.size()));
+      if (F.aux.empty()) F.aux.push_back(0);
+      RC_TRY(dev_upload(&fl.aux, F.aux.data(), (int64_t)F.aux.size()));
+      RC_TRY(dev_upload(&fl.fl_mb, F.fl_mb.data(), (int64_t)F.fl_mb.size()));
+      RC_TRY(dev_upload(&fl.fl_slot, F.fl_slot.data(), (int64_t)F.fl_slot.size()));
+      const size_t mbytes = (size_t)(F.nmail + 1024) * bw::Mail<real>::kBytes;
+      if (hipMalloc(&fl.mbox, mbytes) != hipSuccess) { (void)hipGetLastError(); return AMGH_ENOMEM; }
+      if (hipMemset(fl.mbox, 0, mbytes) != hipSuccess) return -1001;   // (epoch 0 is never a sweep's)
+      fl.nmail = F.nmail; fl.lds_max = F.lds_max;
+      fl.bytes = (int64_t)F.fd.size() * (int64_t)sizeof(bw::FlowDesc) + (int64_t)F.srec.size() + (int64_t)F.aux.size() * 4 + (int64_t)F.fl_mb.size() * 6 + (int64_t)mbytes;
+      fl.on = true;
+      g->bytes += fl.bytes;
+      tm.lap("dataflow upload", n);
+    }
+  }
+  // the row-major records, the quotient graph and the flags of the launched / chained sweeps: all of it where the dataflow
+  // layout is absent, and under the `full` footprint (run-time tunables then switch between the three executions)
+  const bool keep_rec = !g->bw.flow.on || !gs_trim();
+  if (keep_rec) {
+    RC_TRY(dev_upload(&g->bw.rec, P.rec.data(), (int64_t)P.rec.size()));
     if (P.dep.empty()) P.dep.push_back(0);
     if (P.sdep.empty()) P.sdep.push_back(0);
     RC_TRY(dev_upload(&g->bw.dep_ptr, P.dep_ptr.data(), B + 1));
@@ -1035,20 +1091,16 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
     RC_TRY(dev_upload(&g->bw.sdep_ptr, P.sdep_ptr.data(), B + 1));
     RC_TRY(dev_upload(&g->bw.sdep, P.sdep.data(), (int64_t)P.sdep.size()));
     RC_TRY(dev_alloc(&g->bw.flags, B));
-    RC_TRY(dev_alloc(&g->bw.head, 1));
-    RC_TRY(dev_alloc(&g->bw.err, 1));
-    if (hipMemset(g->bw.flags, 0, (size_t)B * 4) != hipSuccess || hipMemset(g->bw.head, 0, 8) != hipSuccess ||
-        hipMemset(g->bw.err, 0, 4) != hipSuccess)
-      return -1001;
-    g->bw.nblocks = (int32_t)B;
+    if (hipMemset(g->bw.flags, 0, (size_t)B * 4) != hipSuccess) return -1001;
     g->bytes += (2 * (B + 1) + (int64_t)P.dep.size() + (int64_t)P.sdep.size() + B) * 4 + 12;
   }
+  g->bw.on = true;
   g->bw.lds_max = P.lds_max; g->bw.maxk = P.blocks[0].maxk;
-  g->bw.rec_bytes = (int64_t)P.rec.size() + (int64_t)P.blocks.size() * (int64_t)sizeof(bw::Desc) + (int64_t)P.ext_col.size() * 4;
+  g->bw.rec_bytes = (keep_rec ? (int64_t)P.rec.size() : 0) + g->bw.flow.bytes + (int64_t)P.blocks.size() * (int64_t)sizeof(bw::Desc) + (int64_t)P.ext_col.size() * 4;
   g->bw.rec_entries = n * (int64_t)g->bw.maxk;
   g->bw.sum_depth = P.sum_depth; g->bw.est_seconds = P.est_seconds;
   g->slot_bytes = g->bw.rec_bytes;
-  g->bytes += g->bw.rec_bytes;
+  g->bytes += g->bw.rec_bytes - g->bw.flow.bytes;   // (the dataflow layout was counted as it went up)
   g->xstride = g->ncols;
   g->diag_nonzero = true;
   for (int64_t p2 = 0; p2 < n && g->diag_nonzero; ++p2) g->diag_nonzero = base.pdiag[p2] != 0.0;
@@ -1057,8 +1109,8 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   g->bytes += 8 * (n + g->xstride);
   tm.lap("block layout upload", n);
   if (getenv("AMGH_VERBOSE"))
-    fprintf(stderr, "[amghip] n=%lld fwd / bwd: wavefront of %zu blocks, %d launches, records %.2f GB\n", (long long)n, P.blocks.size(), nlaunch,
-            (double)P.rec.size() / 1e9);
+    fprintf(stderr, "[amghip] n=%lld fwd / bwd: wavefront of %zu blocks, %d depths, records %.2f GB%s\n", (long long)n, P.blocks.size(), nlaunch,
+            (double)P.rec.size() / 1e9, g->bw.flow.on ? (keep_rec ? ", dataflow layout (+ the chained one)" : ", dataflow layout only") : ", chained (no dataflow layout)");
   return AMGH_OK;
 }
 
@@ -1076,7 +1128,7 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   if (g_gs_bw > 0 && nrhs_hint == 1 && n > 0 && (g_gs_bw == 2 || bw_size_ok)) {
     const int rcb = bw_build(g, n, ncols, rowptr, col, val, tm);
     if (rcb != AMGH_OK) return rcb;
-    if (g->bw.rec) return AMGH_OK;
+    if (g->bw.on) return AMGH_OK;
   }
   HostLevelCsr base;
   std::vector<int32_t> perm;
@@ -1605,7 +1657,7 @@ int gs_grow_xp_for_merged(GsSchedule* g, int64_t* op_bytes) {
 // Merged children for SOR with relaxation factor omega, built on demand from the level-ordered matrix already on
 // the device.  Returns the cache entry (children may be null: merging did not pay or was rejected).
 GsSchedule::SorSet* sor_children(GsSchedule* g, real omega) {
-  if (g->bw.rec) return nullptr;   // the wavefront of blocks sweeps SOR itself (no merged children)
+  if (g->bw.on) return nullptr;   // the wavefront of blocks sweeps SOR itself (no merged children)
   for (GsSchedule::SorSet& ss : g->sor)
     if (ss.built && ss.omega == omega) return &ss;
   GsSchedule::SorSet& ss = g->sor[g->sor_next];

@@ -465,11 +465,20 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
 int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t* col, const amgh_real* val, int target_rows,
                              int backward, double omega, amgh_real* x, const amgh_real* b, int64_t* stats4);
 
-/* Diagnostics of the chained wavefront of blocks (one launch per sweep, blocks ordered by flags instead of kernel
- * boundaries): the number of flag polls that gave up on level l — always 0 (a block only waits for blocks holding
- * smaller tickets); the bound exists so that a protocol error would give wrong numbers instead of a hang.  -1 when the
- * level has no such schedule.  Synchronises the device.                                                              */
+/* Diagnostics of the single-launch wavefronts of blocks (blocks ordered by flags or by the data they wait for instead of
+ * kernel boundaries): the process-wide word a bounded poll raises when it gives up, read behind a device
+ * synchronisation — always 0 (a block only waits for blocks holding smaller tickets).  A raised word is what turns the
+ * next synchronising entry point (amgh_solve, amgh_pcg, amgh_precond_apply, amgh_level_smooth, amgh_dev_sync; the
+ * asynchronous amgh_precond_apply_d on its next call) into AMGH_ESTATE instead of handing out the numbers of a sweep
+ * that went on with stale values; this call leaves it as it is.  -1 when level l has no such schedule.              */
 int amgh_debug_bw_poll_giveups(const amgh_t* h, int l);
+
+/* Diagnostics: how level l's Gauss-Seidel / SOR sweeps of ONE right-hand side run with the tunables as they stand
+ * (smoother.jl:61-90, :193-221 — exact lexicographic order in every mode): 0 = level schedules (no wavefront of blocks),
+ * 1 = wavefront of blocks, one launch per depth of the block graph, 2 = one launch, blocks chained by flags, 3 = one
+ * launch as a dataflow (rows published into mailboxes as they are computed; structurally symmetric patterns).  -1: no
+ * such level.                                                                                                         */
+int amgh_debug_bw_mode(const amgh_t* h, int l);
 
 /* Diagnostics: tunables of the Gauss-Seidel execution (process-wide; used by tools/ to pick the defaults and by
  * tests to force every path).  Read at every sweep: "gs_xcd_map", "gs_block_pipe", "gs_flip", "gs_keep_lo",

@@ -137,24 +137,31 @@ def test_sweep_stats_describe_the_schedule(h128):
     # the same level as a wavefront of blocks (what single-column hierarchies get from 1.5 M 7-point rows on — so the
     # fixture's own fine level —, from 3 M rows otherwise): the operator's own
     # off-diagonal entries — no composite rows, no pre-pass —, 3 * 16 - 2 depths of the quotient graph for 16^3 blocks of
-    # 8^3 rows, executed as ONE launch (blocks chained by flags) or, tunable gs_bw_chain = 0, as a launch per depth
-    lib.amgh_debug_set_tunable(b"gs_bw", 2)
+    # 8^3 rows, executed as ONE launch — a dataflow (rows published as they are computed: gs_bw_flow, the default), or the
+    # blocks chained by flags (gs_bw_flow = 0) — or, gs_bw_chain = 0 as well, as a launch per depth.  The `full` footprint
+    # keeps all three layouts (the default keeps the dataflow layout only)
+    lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_lean", 0)
     try:
         devb = DeviceHierarchy(ml, 0, 1)
     finally:
-        lib.amgh_debug_set_tunable(b"gs_bw", 1)
+        lib.amgh_debug_set_tunable(b"gs_bw", 1); lib.amgh_debug_set_tunable(b"gs_lean", -1)
     sb = devb.gs_sweep_stats(0, False)
     assert sb["tri_entries"] == 0 and sb["entries"] == A.nnz - A.m and sb["slot_entries"] == 6 * A.m
     assert sb["launches"] == 1 and devb.gs_sweep_steps(0, False) == 46 and devb.gs_dependency_levels(0) == 3 * 128 - 2
     b = uniform(A.m, 77)
     zb = devb.precond_apply(b)
     assert rel(zb, dev.precond_apply(b)) <= 1e-12
-    lib.amgh_debug_set_tunable(b"gs_bw_chain", 0)
+    lib.amgh_debug_set_tunable(b"gs_bw_flow", 0)
     try:
+        assert devb.gs_sweep_stats(0, False)["launches"] == 1
+        assert np.array_equal(devb.precond_apply(b), zb)        # chained by flags: the same sweep bit for bit
+        lib.amgh_debug_set_tunable(b"gs_bw_chain", 0)
         assert devb.gs_sweep_stats(0, False)["launches"] == 46
-        assert np.array_equal(devb.precond_apply(b), zb)        # the same sweep bit for bit
+        assert np.array_equal(devb.precond_apply(b), zb)        # a launch per depth: the same sweep bit for bit
+        assert dev0.gs_sweep_stats(0, False)["launches"] == 1   # (the default footprint holds the dataflow layout only)
+        assert np.array_equal(dev0.precond_apply(b), dev0.precond_apply(b))
     finally:
-        lib.amgh_debug_set_tunable(b"gs_bw_chain", 1)
+        lib.amgh_debug_set_tunable(b"gs_bw_chain", 1); lib.amgh_debug_set_tunable(b"gs_bw_flow", 1)
     assert lib.amgh_debug_bw_poll_giveups(devb.h, 0) == 0 and lib.amgh_debug_bw_poll_giveups(dev.h, 0) == -1
     # (the default at this size: the fine level as blocks, the 1.0 M-row second level on merged groups — forced above)
     assert dev0.gs_sweep_stats(0, False) == sb and rel(dev0.precond_apply(b), zb) <= 1e-12
@@ -291,20 +298,26 @@ def test_wavefront_of_blocks_schedule_vs_oracle_and_level_schedules():
     x0, bb = uniform(A.m, 21) - 0.5, uniform(A.m, 22)
     for pre in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2)):
         ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre)
-        lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_bw_rows", 64)
+        lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_bw_rows", 64); lib.amgh_debug_set_tunable(b"gs_lean", 0)
         try:
             dev = DeviceHierarchy(ml, 0, 1)
             x_dev = dev.smooth(0, False, x0, bb)
-            # ONE launch per sweep (blocks chained by flags, the default) and one launch per depth of the quotient graph: the same bits
+            # ONE launch per sweep — as a dataflow (rows published as they are computed, the default), or the blocks chained by
+            # flags (gs_bw_flow = 0) — and one launch per depth of the quotient graph (gs_bw_chain = 0 as well): the same bits
             assert dev.gs_sweep_stats(0, False)["launches"] == 1 and lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
-            for rep in range(3):      # (epochs of the flags: repeated sweeps on the same schedule)
+            for rep in range(3):      # (epochs of the mailboxes: repeated sweeps on the same schedule)
                 assert np.array_equal(dev.smooth(0, False, x0, bb), x_dev)
+            assert lib.amgh_debug_set_tunable(b"gs_bw_flow", 0) == 0
+            assert dev.gs_sweep_stats(0, False)["launches"] == 1
+            for rep in range(3):      # (epochs of the flags)
+                assert np.array_equal(dev.smooth(0, False, x0, bb), x_dev), repr(pre)
             assert lib.amgh_debug_set_tunable(b"gs_bw_chain", 0) == 0
             assert dev.gs_sweep_stats(0, False)["launches"] == dev.gs_sweep_steps(0, False) > 1
             assert np.array_equal(dev.smooth(0, False, x0, bb), x_dev), repr(pre)
             assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
         finally:
             lib.amgh_debug_set_tunable(b"gs_bw", 1); lib.amgh_debug_set_tunable(b"gs_bw_rows", 512); lib.amgh_debug_set_tunable(b"gs_bw_chain", 1)
+            lib.amgh_debug_set_tunable(b"gs_bw_flow", 1); lib.amgh_debug_set_tunable(b"gs_lean", -1)
         assert dev.gs_sweep_stats(0, False)["slot_entries"] == 6 * A.m
         assert np.array_equal(x_dev, O.smooth(pre, A, x0, bb, hermitian=True)), repr(pre)
         xh = x0.copy()
@@ -333,8 +346,9 @@ def test_wavefront_of_blocks_schedule_vs_oracle_and_level_schedules():
 def test_chained_blocks_on_random_patterns_are_the_host_plan_bit_for_bit():
     """The block layout on operators that are NOT grids: random sparsity, structurally non-symmetric (a block then reads
     old values of blocks that never read it back — the far / near split of its external positions and its predecessor /
-    successor lists are all that orders the chained kernel) and symmetric with zero diagonals (rows the sweep skips).
-    Forward, backward and symmetric sweeps on the device, one launch per sweep and one launch per depth, against the
+    successor lists are all that orders the chained kernel; the dataflow sweep, whose only order is the data it waits for,
+    declines such a pattern) and symmetric with zero diagonals (rows the sweep skips — and still publishes).
+    Forward, backward and symmetric sweeps on the device — dataflow, chained, one launch per depth — against the
     host execution of the same plan (amgh_debug_bw_sweep_host: bitwise the scalar loop, tests/test_bw_host.py)."""
     from amg_amd.device import DeviceHierarchy
     from test_bw_host import _short_rows
@@ -345,16 +359,20 @@ def test_chained_blocks_on_random_patterns_are_the_host_plan_bit_for_bit():
         x0, bb = uniform(A.m, 41) - 0.5, uniform(A.m, 42)
         for pre in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2)):
             ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre)
-            lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_bw_rows", 64)
+            lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_bw_rows", 64); lib.amgh_debug_set_tunable(b"gs_lean", 0)
             try:
                 dev = DeviceHierarchy(ml, 0, 1)
                 st = dev.gs_sweep_stats(0, False)
                 assert st["launches"] == 1 and st["tri_entries"] == 0 and dev.gs_sweep_steps(0, False) > 1     # really the block layout
-                x_dev = dev.smooth(0, False, x0, bb)
+                x_dev = dev.smooth(0, False, x0, bb)          # (the symmetric pattern: as a dataflow; the non-symmetric one: chained by flags)
+                lib.amgh_debug_set_tunable(b"gs_bw_flow", 0)
+                x_chained = dev.smooth(0, False, x0, bb)
                 lib.amgh_debug_set_tunable(b"gs_bw_chain", 0)
                 x_launched = dev.smooth(0, False, x0, bb)
             finally:
                 lib.amgh_debug_set_tunable(b"gs_bw", 1); lib.amgh_debug_set_tunable(b"gs_bw_rows", 512); lib.amgh_debug_set_tunable(b"gs_bw_chain", 1)
+                lib.amgh_debug_set_tunable(b"gs_bw_flow", 1); lib.amgh_debug_set_tunable(b"gs_lean", -1)
+            assert np.array_equal(x_chained, x_launched)
             xh = x0.copy()
             for it in range(pre.iter):
                 for back in ((0,), (1,), (0, 1))[pre.sweep_code]:

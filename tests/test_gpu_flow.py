@@ -1,0 +1,223 @@
+"""The wavefront of blocks as a DATAFLOW (csrc/hip/gs_flow.hpp): rows published into mailboxes the moment they are
+computed, blocks starting on finished faces, the packed rows streamed straight into registers.  Same plan, same
+arithmetic as the chained and launched sweeps of gs_blocks.hpp — and so the scalar lexicographic loop of
+/root/reference/src/smoother.jl:61-90 (gs!) and :193-221 (sor_step!) BIT FOR BIT: against the oracle's loops, against
+the host execution of the plan (amgh_debug_bw_sweep_host), against the two other executions on the device.  Plus what a
+protocol built on polling owes its callers: a wait that gives up is an error code, never numbers (a forced protocol
+error), and a soak under memory load, eager and graph-replayed."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+import amg_amd as AMG
+from amg_amd.device import DeviceHierarchy
+from conftest import uniform
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(x, y):
+    return np.linalg.norm(np.asarray(x) - np.asarray(y)) / max(np.linalg.norm(y), 1e-300)
+
+
+class tunables:
+    """amgh_debug_set_tunable for the duration of a with block (values restored to the given defaults)."""
+    DEFAULTS = {"gs_bw": 1, "gs_bw_rows": 512, "gs_bw_chain": 1, "gs_bw_flow": 1, "gs_lean": -1, "gs_bw_spin": 0, "gs_bw_skip_pub": -1}
+
+    def __init__(self, lib, **kw):
+        self.lib, self.kw = lib, kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            assert self.lib.amgh_debug_set_tunable(k.encode(), int(v)) == 0
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            self.lib.amgh_debug_set_tunable(k.encode(), self.DEFAULTS[k])
+
+
+def _host_plan_sweeps(lib, A, pre, x0, bb, rows):
+    rp, ci, va = AMG.device.smoother_matrix_csr(A, None)
+    rp, ci, va = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(va)
+    xh = x0.copy()
+    omega = getattr(pre, "omega", 1.0)
+    for _ in range(pre.iter):
+        for back in ((0,), (1,), (0, 1))[pre.sweep_code]:
+            rc = lib.amgh_debug_bw_sweep_host(A.m, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, rows, back, float(omega), xh.ctypes.data, bb.ctypes.data, None)
+            assert rc == 0
+    return xh
+
+
+def test_dataflow_sweep_is_the_scalar_loop_bit_for_bit():
+    """Gauss-Seidel forward / backward / symmetric / repeated, on grids and on an irregular symmetric pattern with zero
+    diagonals (rows the sweep skips, smoother.jl:87 — and still publishes): dataflow = chained = launched = the host plan =
+    the oracle's scalar loop, bitwise.  SOR against the oracle at 1e-13 (omega / d is a division on both sides, the
+    products' order is the same) and bitwise against the host plan."""
+    from test_bw_host import _short_rows
+    lib = AMG.hip_lib()
+    cases = [(AMG.poisson((20, 18, 16)), 64), (AMG.poisson((48, 40)), 64), (AMG.poisson((24, 24, 24)), 216),
+             (_short_rows(5000, 5, True, zero_diag=(0, 17, 4999)), 64)]
+    sm = [AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(), AMG.GaussSeidel(iter=3),
+          AMG.SOR(1.3), AMG.SOR(0.7, AMG.BackwardSweep())]
+    ran = 0
+    for A, rows in cases:
+        x0, bb = uniform(A.m, 31) - 0.5, uniform(A.m, 32)
+        for pre in sm:
+            ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre)
+            with tunables(lib, gs_bw=2, gs_bw_rows=rows, gs_lean=0):
+                dev = DeviceHierarchy(ml, 0, 1)
+                assert lib.amgh_debug_bw_mode(dev.h, 0) == 3, (A.m, repr(pre))      # really the dataflow sweep
+                x_flow = dev.smooth(0, False, x0, bb)
+                for rep in range(2):                                                    # epochs of the mailboxes
+                    assert np.array_equal(dev.smooth(0, False, x0, bb), x_flow)
+                with tunables(lib, gs_bw_flow=0):
+                    assert lib.amgh_debug_bw_mode(dev.h, 0) == 2
+                    x_chain = dev.smooth(0, False, x0, bb)
+                    with tunables(lib, gs_bw_chain=0):
+                        assert lib.amgh_debug_bw_mode(dev.h, 0) == 1
+                        x_launch = dev.smooth(0, False, x0, bb)
+                assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+            assert np.array_equal(x_flow, x_chain) and np.array_equal(x_flow, x_launch), (A.m, repr(pre))
+            assert np.array_equal(x_flow, _host_plan_sweeps(lib, A, pre, x0, bb, rows)), (A.m, repr(pre))
+            xo = O.smooth(pre, A, x0, bb, hermitian=True)
+            if isinstance(pre, AMG.SOR):
+                assert rel(x_flow, xo) <= 1e-13, (A.m, repr(pre))
+            else:
+                assert np.array_equal(x_flow, xo), (A.m, repr(pre))
+            ran += 1
+    assert ran == len(cases) * len(sm)
+
+
+def test_dataflow_default_footprint_keeps_only_its_own_layout_and_cycles_match_the_oracle():
+    """What a user gets without touching a tunable: levels swept as wavefronts of blocks hold the dataflow layout only
+    (no row-major records, no flags: the run-time switches have nothing to switch to), V / W / F cycles and the solve
+    are the oracle's at 1e-10 (multilevel.jl:200-239), PCG counts its iterations."""
+    lib = AMG.hip_lib()
+    A = AMG.poisson((40, 36, 32))
+    ml = AMG.ruge_stuben(A)
+    oh = O.OracleHierarchy(ml)
+    b = uniform(A.m, 5) - 0.4
+    with tunables(lib, gs_bw=2, gs_bw_rows=128):
+        dev = DeviceHierarchy(ml, 0, 1)
+    assert lib.amgh_debug_bw_mode(dev.h, 0) == 3
+    with tunables(lib, gs_bw_flow=0, gs_bw_chain=0):
+        assert lib.amgh_debug_bw_mode(dev.h, 0) == 3 and dev.gs_sweep_stats(0, False)["launches"] == 1
+    for cyc in (0, 1, 2):
+        assert rel(dev.precond_apply(b, cyc), oh.precond(b, cycle=cyc)) <= 1e-10
+    x, hist, its = dev.solve(b, np.zeros(A.m), 0, 50, 0.0, 1e-9, True, True)
+    xo, ho, ito = oh.solve(b, reltol=1e-9, maxiter=50)
+    assert its == ito and rel(x, xo) <= 1e-10 and rel(hist, ho) <= 1e-8
+    assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+
+
+def test_dataflow_declines_structurally_nonsymmetric_patterns():
+    """A block reads its far-side x when it starts; what keeps a later block from overwriting those rows first is, in the
+    dataflow sweep, only the data that block waits for — so the pattern must carry every dependency both ways.  A
+    structurally non-symmetric operator keeps the chained sweep (whose block-level flags order symmetrised edges)."""
+    from test_bw_host import _short_rows
+    lib = AMG.hip_lib()
+    A = _short_rows(6000, 6, False)
+    pre = AMG.GaussSeidel()
+    ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre)
+    x0, bb = uniform(A.m, 41) - 0.5, uniform(A.m, 42)
+    with tunables(lib, gs_bw=2, gs_bw_rows=64):
+        dev = DeviceHierarchy(ml, 0, 1)
+        assert lib.amgh_debug_bw_mode(dev.h, 0) == 2
+        x_dev = dev.smooth(0, False, x0, bb)
+    assert np.array_equal(x_dev, _host_plan_sweeps(lib, A, pre, x0, bb, 64))
+
+
+def test_a_forced_protocol_error_is_an_error_code_not_numbers():
+    """One block of the sweep publishes nothing (test hook gs_bw_skip_pub): its readers' polls give up after gs_bw_spin
+    tries, the sweep runs to its end on stale values — and every entry point that hands results out returns AMGH_ESTATE
+    instead of them.  The word is lowered by the report: the next call on the same handle is clean and right."""
+    lib = AMG.hip_lib()
+    A = AMG.poisson((32, 32, 32))
+    ml = AMG.ruge_stuben(A)
+    b = uniform(A.m, 9)
+    with tunables(lib, gs_bw=2, gs_bw_rows=64):
+        dev = DeviceHierarchy(ml, 0, 1)
+    assert lib.amgh_debug_bw_mode(dev.h, 0) == 3
+    z_ref = dev.precond_apply(b)
+    nblocks = dev.gs_sweep_stats(0, False)["rows"] // 64
+    with tunables(lib, gs_bw_skip_pub=nblocks // 2, gs_bw_spin=3000):
+        with pytest.raises(AMG.AMGError, match="rc=-3"):
+            dev.precond_apply(b)
+        with pytest.raises(AMG.AMGError, match="rc=-3"):
+            dev.solve(b, np.zeros(A.m), 0, 2, 0.0, 1e-8, True, True)
+        with pytest.raises(AMG.AMGError, match="rc=-3"):
+            dev.smooth(0, False, np.zeros(A.m), b)
+        with pytest.raises(AMG.AMGError, match="rc=-3"):
+            dev.pcg(b, maxiter=2)
+    assert np.array_equal(dev.precond_apply(b), z_ref)
+    assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+
+
+@pytest.fixture(scope="module")
+def soak_fixture():
+    A = AMG.poisson((256, 256, 256))
+    ml = AMG.ruge_stuben(A, setup="gpu", device=0)
+    dev = DeviceHierarchy(ml, 0, 1)
+    return A, ml, dev
+
+
+def test_soak_2000_sweeps_under_memory_load_eager_and_graph_replayed(soak_fixture):
+    """250 V-cycles at 256^3 = 2000 dataflow sweeps of the two finest levels (16.7 M and 8.4 M rows, ~50 000 blocks,
+    ~10 M mailboxes), the same right-hand side every time: every result equals the first BIT FOR BIT — eager, then
+    replayed from a hipGraph — while a second stream hammers HBM with SpMVs of a 117 M-entry operator from another host
+    thread (hand-offs under uneven load: stale lines, torn granules or an overtaken tag would show as a different bit
+    or a raised error word).  Give-ups 0."""
+    A, ml, dev = soak_fixture
+    lib = AMG.hip_lib()
+    assert lib.amgh_debug_bw_mode(dev.h, 0) == 3 and lib.amgh_debug_bw_mode(dev.h, 1) == 3
+    n = A.m
+    b = uniform(n, 3) - 0.5
+    # the load: a stand-alone copy of the fine operator multiplied over and over on its own stream
+    rp, ci, va = A.csr_arrays()
+    rp, ci, va = np.ascontiguousarray(rp, np.int32), np.ascontiguousarray(ci, np.int32), np.ascontiguousarray(va)
+    op = ctypes.c_void_p()
+    assert lib.amgh_csr_create(ctypes.byref(op), 0, n, n, rp.ctypes.data, ci.ctypes.data, va.ctypes.data) == 0
+    xd, yd, sd = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.amgh_dev_alloc(0, 8 * n, ctypes.byref(xd)) == 0 and lib.amgh_dev_alloc(0, 8 * n, ctypes.byref(yd)) == 0
+    assert lib.amgh_dev_alloc(0, 8 * 4096, ctypes.byref(sd)) == 0
+    assert lib.amgh_dev_upload(0, xd, b.ctypes.data, 8 * n) == 0
+    h2 = ctypes.c_void_p()
+    assert lib.amgh_create(ctypes.byref(h2), 0, 1) == 0     # (a second handle: its non-blocking stream carries the load)
+    st2 = lib.amgh_stream(h2)
+    stop = threading.Event()
+    launched, raised = [0], []
+
+    def hammer():
+        while not stop.is_set():
+            for _ in range(8):
+                if lib.amgh_csr_spmv_d(op, xd, yd, st2) != 0:
+                    return
+                launched[0] += 1
+            out = ctypes.c_double(0)        # (a dot product: the call waits for ITS stream only — a device-wide wait from
+            rc = lib.amgh_dot_d(0, 1024, yd, yd, sd, ctypes.byref(out), st2)   # another thread would break a graph capture)
+            if rc != 0:
+                raised.append(rc)
+
+    z1 = dev.precond_apply(b)
+    assert rel(z1, O.OracleHierarchy(ml).precond(b)) <= 1e-10
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        for graph in (0, 1):
+            assert lib.amgh_set_use_graph(dev.h, graph) == 0
+            for k in range(125):
+                z = dev.precond_apply(b)
+                assert np.array_equal(z, z1), (graph, k)
+    finally:
+        stop.set()
+        th.join()
+        lib.amgh_set_use_graph(dev.h, 0)
+        lib.amgh_csr_destroy(op)
+        lib.amgh_dev_free(0, xd); lib.amgh_dev_free(0, yd); lib.amgh_dev_free(0, sd)
+        lib.amgh_destroy(h2)
+    assert launched[0] > 200 and not raised     # the load really ran beside the cycles
+    assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0 and lib.amgh_dev_sync(0) == 0

@@ -9,7 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include "../algebraicmultigrid.jl_amd/csrc/hip/gs_blocks.hpp"
+#include "../algebraicmultigrid.jl_amd/csrc/hip/gs_flow.hpp"
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 using namespace amgh;
@@ -201,6 +201,87 @@ int main(int argc, char** argv) {
     for (int l = 0; l < nl; l += std::max(1, nl / 12)) {
       long long te = 0, ts = -1; for (int b = P.launch_ptr[l]; b < P.launch_ptr[l + 1]; ++b) { te = std::max(te, tim[5 * (size_t)b + 4]); if (ts < 0 || tim[5 * (size_t)b] < ts) ts = tim[5 * (size_t)b]; }
       printf("  depth %3d: %4d blocks, first start %8.1f us, last end %8.1f us\n", l, P.launch_ptr[l + 1] - P.launch_ptr[l], (ts - tmin) * 0.01, (te - tmin) * 0.01);
+    }
+  }
+  // ---- the same sweeps as a DATAFLOW (gs_flow.hpp): rows published as they are computed, records streamed into registers ----
+  if (!getenv("BW_NO_FLOW")) {
+    const auto tf0 = std::chrono::steady_clock::now();
+    const bool sym = bw::structurally_symmetric(n, A.rp.data(), A.ci.data(), 8);
+    bw::Flow F;
+    const bool fok = bw::flow_build<double>(P, 8, &F);
+    const double tflow = std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
+    printf("== dataflow: structurally symmetric %d, flow build %.2f s (ok %d), %lld mailboxes (%.1f MB), LDS %.1f KB per block, depth %d\n", (int)sym, tflow, (int)fok,
+           (long long)F.nmail, F.nmail * 16e-6, F.lds_max / 1024.0, BW_FLOW_DEPTH);
+    if (sym && fok) {
+      const int32_t B = (int32_t)P.blocks.size();
+      bw::FlowDesc* d_fd; unsigned char* d_srec; uint32_t* d_aux; uint16_t* d_fs; int32_t *d_fm, *d_err; void* d_mbox; unsigned long long* d_head; long long* d_tim;
+      CHECK(hipMalloc(&d_fd, sizeof(bw::FlowDesc) * (size_t)B)); CHECK(hipMalloc(&d_srec, F.srec.size())); CHECK(hipMalloc(&d_aux, 4 * std::max<size_t>(1, F.aux.size())));
+      CHECK(hipMalloc(&d_fs, 2 * F.fl_slot.size())); CHECK(hipMalloc(&d_fm, 4 * F.fl_mb.size()));
+      CHECK(hipMalloc(&d_mbox, 16 * (size_t)(F.nmail + 1024))); CHECK(hipMalloc(&d_head, 8)); CHECK(hipMalloc(&d_err, 4)); CHECK(hipMalloc(&d_tim, 32 * (size_t)B));
+      CHECK(hipMemcpy(d_fd, F.fd.data(), sizeof(bw::FlowDesc) * (size_t)B, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_srec, F.srec.data(), F.srec.size(), hipMemcpyHostToDevice));
+      CHECK(hipMemcpy(d_aux, F.aux.data(), 4 * F.aux.size(), hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_fs, F.fl_slot.data(), 2 * F.fl_slot.size(), hipMemcpyHostToDevice));
+      CHECK(hipMemcpy(d_fm, F.fl_mb.data(), 4 * F.fl_mb.size(), hipMemcpyHostToDevice));
+      CHECK(hipMemset(d_mbox, 0, 16 * (size_t)(F.nmail + 1024))); CHECK(hipMemset(d_head, 0, 8)); CHECK(hipMemset(d_err, 0, 4));
+      bw::FlowArgs<double> fa{d_blocks, d_fd, d_srec, d_aux, d_ext, d_fm, d_fs, d_mbox, d_b, d_x, 1.0, d_head, B, (int32_t)F.nmail, d_err, nullptr, 0u, -1};
+      const int mk = P.blocks[0].maxk;
+      CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+      CHECK(bw::sweep_flow<double>(fa, mk, F.lds_max, false, false, st));
+      CHECK(bw::sweep_flow<double>(fa, mk, F.lds_max, false, true, st));
+      CHECK(hipStreamSynchronize(st));
+      CHECK(hipMemcpy(xg.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+      int err = 0; CHECK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+      xr = x0; scalar(false); scalar(true);
+      diff = 0; maxd = 0.0;
+      for (int64_t p = 0; p < n; ++p) { const double e = std::fabs(xg[p] - xr[P.perm[p]]); if (xg[p] != xr[P.perm[p]]) ++diff; maxd = std::max(maxd, e); }
+      printf("dataflow forward + backward vs the scalar loops: %lld values differ (max |diff| %.3e), give-ups %d\n", (long long)diff, maxd, err);
+      const double fbytes = (double)F.srec.size() + n * 28.0 + P.ext_total * 22.0;
+      for (int bwd = 0; bwd < 2; ++bwd) {
+        CHECK(bw::sweep_flow<double>(fa, mk, F.lds_max, false, bwd, st)); CHECK(hipStreamSynchronize(st));
+        const int reps = 5;
+        CHECK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r) CHECK(bw::sweep_flow<double>(fa, mk, F.lds_max, false, bwd, st));
+        CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("dataflow %s sweep: %.3f ms (%.0f GB/s)\n", bwd ? "backward" : "forward ", ms / reps, fbytes / (ms / reps * 1e-3) / 1e9);
+      }
+      {   // repeated alternating sweeps against the launched ones
+        std::vector<double> xc(n), xl2(n);
+        CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+        for (int r = 0; r < 20; ++r) CHECK(bw::sweep_flow<double>(fa, mk, F.lds_max, false, r & 1, st));
+        CHECK(hipStreamSynchronize(st)); CHECK(hipMemcpy(xc.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+        a.tim = nullptr;
+        for (int r = 0; r < 20; ++r) CHECK(bw::sweep<double>(a, mk, P.launch_ptr, P.lds_max, false, r & 1, 1, st));
+        CHECK(hipStreamSynchronize(st)); CHECK(hipMemcpy(xl2.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+        int64_t dd = 0; for (int64_t p = 0; p < n; ++p) dd += xc[p] != xl2[p];
+        CHECK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+        printf("20 alternating sweeps, dataflow vs launched: %lld values differ, give-ups %d\n", (long long)dd, err);
+      }
+      fa.tim = d_tim;
+      for (int bwd = 0; bwd < 2; ++bwd) {
+        CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+        if (bwd) { fa.tim = nullptr; CHECK(bw::sweep_flow<double>(fa, mk, F.lds_max, false, false, st)); fa.tim = d_tim; }
+        CHECK(bw::sweep_flow<double>(fa, mk, F.lds_max, false, bwd, st)); CHECK(hipStreamSynchronize(st));
+        std::vector<long long> tim(4 * (size_t)B);
+        CHECK(hipMemcpy(tim.data(), d_tim, 32 * (size_t)B, hipMemcpyDeviceToHost));
+        long long tmin = tim[0], tmax = 0; double ld = 0, wk = 0;
+        for (int32_t bq = 0; bq < B; ++bq) {
+          const long long* t = &tim[4 * (size_t)bq];
+          tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[2]);
+          ld += (t[1] - t[0]) * 0.01; wk += (t[2] - t[1]) * 0.01;
+        }
+        printf("dataflow %s sweep, stamps: first start -> last end %.1f us; mean per block: ticket + load %.2f, walk (with its waits) %.2f us\n", bwd ? "backward" : "forward", (tmax - tmin) * 0.01, ld / B, wk / B);
+        for (int l0 = 0; l0 < nl; l0 += std::max(1, nl / 12)) {
+          const int l = bwd ? nl - 1 - l0 : l0;
+          long long te = 0, ts = -1, tw = -1; double w = 0; const int nbk = P.launch_ptr[l + 1] - P.launch_ptr[l];
+          for (int bq = P.launch_ptr[l]; bq < P.launch_ptr[l + 1]; ++bq) {
+            te = std::max(te, tim[4 * (size_t)bq + 2]); if (ts < 0 || tim[4 * (size_t)bq] < ts) ts = tim[4 * (size_t)bq];
+            if (tw < 0 || tim[4 * (size_t)bq + 1] < tw) tw = tim[4 * (size_t)bq + 1];
+            w += (tim[4 * (size_t)bq + 2] - tim[4 * (size_t)bq + 1]) * 0.01;
+          }
+          printf("  depth %3d: %4d blocks, first start %8.1f us, first walk %8.1f us, last end %8.1f us, mean walk %6.2f us\n", l, nbk, (ts - tmin) * 0.01, (tw - tmin) * 0.01, (te - tmin) * 0.01, w / nbk);
+        }
+      }
     }
   }
   return 0;

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""HBM-side counters of the fine-level Gauss-Seidel sweep kernels of tools/block_wave_bench (launched per depth, chained by
+flags, dataflow): one `rocprofv3 --kernel-trace --pmc <counter>` pass per counter (counters + kernel trace only).
+FETCH_SIZE is doubled on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM); request counters are printed raw."""
+import csv, glob, os, shutil, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+args = sys.argv[1:] or ["poisson", "256"]
+binary = os.environ.get("BW_BENCH", os.path.join(ROOT, "tools", "block_wave_bench"))
+counters = os.environ.get("PMC", "FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum").split()
+kinds = {"gs_bw_flow_kernel": "dataflow", "gs_bw_chain_kernel": "chained", "gs_bw_packed_kernel": "per depth"}
+
+def one(counter):
+    tmp = tempfile.mkdtemp(prefix="amgh_pmc_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", binary] + args
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        if r.returncode != 0:
+            return None, r.stdout.decode(errors="replace")[-300:]
+        tot, cnt = {}, {}
+        for f in glob.glob(tmp + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") != counter: continue
+                name = row.get("Kernel_Name", "")
+                for sub, key in kinds.items():
+                    if sub in name:
+                        tot[key] = tot.get(key, 0.0) + float(row["Counter_Value"]); cnt[key] = cnt.get(key, 0) + 1
+        return tot, cnt
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+print("counters per DISPATCH (mean over the tool's dispatches of each kernel kind), " + " ".join(args))
+for c in counters:
+    tot, cnt = one(c)
+    if tot is None:
+        print(f"{c}: failed: {cnt}"); continue
+    line = []
+    for key in ("per depth", "chained", "dataflow"):
+        if key not in tot: continue
+        per = tot[key] / cnt[key] * (94 if key == "per depth" and args[:2] == ["poisson", "256"] else 1)
+        if c == "FETCH_SIZE": line.append(f"{key}: {per * 1024 * 2 / 1e9:.3f} GB (x2 applied)")
+        elif c == "WRITE_SIZE": line.append(f"{key}: {per * 1024 / 1e9:.3f} GB")
+        else: line.append(f"{key}: {per / 1e6:.3f} M")
+    print(f"{c:>24}: " + " | ".join(line), flush=True)
