@@ -1562,7 +1562,11 @@ int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t
   prm.target_rows = target_rows;
   prm.threads = 2;
   bw::Plan P;
-  if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_EUNSUPPORTED;
+  try {
+    if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_EUNSUPPORTED;
+  } catch (const std::exception&) {
+    return AMGH_ENOMEM;
+  }
   if (stats4) { stats4[0] = (int64_t)P.blocks.size(); stats4[1] = (int64_t)P.launch_ptr.size() - 1; stats4[2] = P.sum_depth; stats4[3] = P.ext_total; }
   // every row exactly once
   {

@@ -813,6 +813,10 @@ void amgh_dist_destroy(amgh_dist_t* d) {
   if (!d) return;
   if (!d->host_only) hipSetDevice(d->device);
   if (d->stream) d->tr->wait_stream(d->stream);
+  // a transport whose peers read this rank's send buffers in place (IPC): a slower peer may still have copies of the last
+  // exchanges queued — nobody unmaps or frees before everybody's stream has drained (a broken transport returns at once;
+  // a peer that never arrives ends the wait with the transport's timeout and breaks it for everybody)
+  if (d->tr && d->tr->async() && !d->host_only) (void)d->tr->barrier();
   if (d->tail && d->tail->stream == d->stream) {  // the borrowed tail goes back to its own stream (ours is about to die)
     d->tail->stream = d->tail->own_stream;
     d->tail->own_stream = nullptr;

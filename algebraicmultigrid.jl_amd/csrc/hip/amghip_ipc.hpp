@@ -314,6 +314,10 @@ struct IpcTransport : Transport {
     if (rc == AMGH_OK) rc = ev_create(&ps.ev_ready);
     if (rc == AMGH_OK) rc = ev_create(&ps.ev_done);
     if (rc != AMGH_OK) { give_up(); return rc; }
+    // (the flags this rank writes for the plan start from zero with its sequence numbers: a plan id attached a second time
+    // on the same segment would otherwise pass its waits on the flags of its first life)
+    host_flag(ready_index(pl.id, rank))->store(0, std::memory_order_release);
+    for (int p = 0; p < nranks; ++p) host_flag(done_index(pl.id, rank, p))->store(0, std::memory_order_release);
     RC_TRY(barrier());
     for (int p = 0; p < nranks; ++p) {
       if (p == rank || pl.recv[p].cnt <= 0) continue;

@@ -34,6 +34,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -115,13 +116,18 @@ struct Plan {
   int32_t cells[3] = {1, 1, 1};
 };
 
+// (an exception in a worker — the plans allocate gigabytes — is carried to the calling thread, which lets the caller fall
+// back to another schedule instead of std::terminate taking the process down)
 template <class F>
 inline void parallel_for(int T, F fn) {
   if (T <= 1) { fn(0, 1); return; }
   std::vector<std::thread> th;
-  for (int t = 1; t < T; ++t) th.emplace_back([=] { fn(t, T); });
-  fn(0, T);
+  std::vector<std::exception_ptr> err((size_t)T);
+  for (int t = 1; t < T; ++t)
+    th.emplace_back([=, &err] { try { fn(t, T); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+  try { fn(0, T); } catch (...) { err[0] = std::current_exception(); }
   for (auto& x : th) x.join();
+  for (auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 struct Params {

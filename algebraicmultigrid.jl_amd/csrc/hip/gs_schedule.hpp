@@ -1012,7 +1012,12 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   if (const char* e = getenv("AMGH_BW_THREADS")) prm.threads = std::max(1, atoi(e));   // (measurement hook)
   prm.require_three = g_gs_bw != 2;   // (the cost-model branch below insists on three offset classes)
   bw::Plan P;
-  if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_OK;
+  try {   // (gigabytes of host memory: out of it, the level keeps the level schedules — nothing crosses the C ABI)
+    if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_OK;
+  } catch (const std::exception&) {
+    if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] n=%lld wavefront of blocks: the plan ran out of host memory, level schedules kept\n", (long long)n);
+    return AMGH_OK;
+  }
   tm.lap("block partition + records", n);
   const int64_t nnz = rowptr[n];
   const int nlaunch = (int)P.launch_ptr.size() - 1;
@@ -1060,7 +1065,9 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   // the sweep as a dataflow (gs_flow.hpp) where the data dependencies carry the anti-dependencies: structurally symmetric patterns
   if (g_gs_bw_flow && ncols <= n && bw::structurally_symmetric(n, rowptr, col, prm.threads)) {
     bw::Flow F;
-    if (bw::flow_build<real>(P, prm.threads, &F) && F.lds_max <= 64 * 1024 && (F.nmail + 1024) * (int64_t)bw::Mail<real>::kBytes < 0x7ffffff0ll) {
+    bool fok = false;
+    try { fok = bw::flow_build<real>(P, prm.threads, &F); } catch (const std::exception&) { fok = false; }
+    if (fok && F.lds_max <= 64 * 1024 && (F.nmail + 1024) * (int64_t)bw::Mail<real>::kBytes < 0x7ffffff0ll) {
       tm.lap("dataflow layout", n);
       GsSchedule::Bw::FlowDev& fl = g->bw.flow;
       RC_TRY(dev_upload(&fl.fd, F.fd.data(), (int64_t)F.fd.size()));

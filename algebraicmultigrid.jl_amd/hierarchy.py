@@ -729,15 +729,19 @@ def _smoothed_aggregation_gpu(A, B, theta, omega, improve_iters, hermitian, max_
                 side.submit(improve, A_host, Bf, nB, failed, share)
                 side.submit(done.set)
                 L.amgs_set_threads_here(threads_all - share)
-            S, _ = strength(A_host if hermitian else A_host.transpose(), bsr_flag)
-            tick("symmetric strength (host)")
-            AggOp = SparseMatrixCSC(L.amgs_standard_aggregation(S._h))
-            tick("aggregation (host)")
+            try:    # (whatever strength or aggregation raise, this thread gets its full thread count back)
+                S, _ = strength(A_host if hermitian else A_host.transpose(), bsr_flag)
+                tick("symmetric strength (host)")
+                AggOp = SparseMatrixCSC(L.amgs_standard_aggregation(S._h))
+                tick("aggregation (host)")
+                if share:
+                    while not done.wait(0.05):
+                        if side.exc is not None:
+                            break
+            finally:
+                if share:
+                    L.amgs_set_threads_here(threads_all)
             if share:
-                while not done.wait(0.05):
-                    if side.exc is not None:
-                        break
-                L.amgs_set_threads_here(threads_all)
                 if side.exc is not None:
                     raise side.exc
             else:

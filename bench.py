@@ -193,8 +193,12 @@ def main():
     sweeps = []
     launches = stored = composite = tri = 0
     alg_sweeps = 0
+    streamed_bytes = 0
+    bw_modes = []
     for l, lev in enumerate(ml.levels):
         per = {}
+        mode = int(lib.amgh_debug_bw_mode(dev.h, l))       # 0 level schedules, 1 / 2 / 3 wavefront of blocks (launched / chained / dataflow)
+        bw_modes.append(mode)
         for bwd in (False, True):
             st = dev.gs_sweep_stats(l, bwd)
             per["bwd" if bwd else "fwd"] = st
@@ -202,6 +206,14 @@ def main():
             stored += 2 * max(st["slot_entries"], st["entries"])
             composite += 2 * st["entries"]
             tri += 2 * st["tri_entries"]
+            if mode > 0:
+                # a block level streams its packed records: per row 16-byte chunks [values, diagonal, reciprocal | uint16
+                # columns, publish word] (csrc/hip/gs_blocks.hpp Packed::chunks), not 12 bytes per entry
+                maxk = st["slot_entries"] // max(1, st["rows"])
+                chunks = ((maxk + 2 + 1) // 2 + (maxk + 7) // 8) | 1
+                streamed_bytes += 2 * st["rows"] * (16 * chunks + 24)
+            else:
+                streamed_bytes += 2 * (12 * (max(st["slot_entries"], st["entries"]) + st["tri_entries"]) + 24 * st["rows"])
         alg_sweeps += 4 * (lev.A.nnz * 12 + (lev.A.m + 1) * 4 + 24 * lev.A.m)
         sweeps.append(per)
     smooth_ms = None
@@ -246,16 +258,20 @@ def main():
         # second roofline entry: the kernels that dominate the CYCLE (Gauss-Seidel sweeps: gs_slot / gs_bigslot /
         # chain / block launches + pre-pass), latency-bound — one launch per merged group of dependency levels
         "sweep_roofline": {
-            "bound": "hbm", "kernel": "gs_bw_chain_kernel (two finest levels: wavefront of blocks, one launch per sweep) + gs_slot_kernel / gs_bigslot_kernel "
-                                      "(merged dependency-level groups), all levels, pre + post smoother, both directions",
+            "bound": "hbm", "kernel": "gs_bw_flow_kernel (levels %s: wavefront of blocks as a dataflow, one launch per sweep) + gs_slot_kernel / gs_bigslot_kernel "
+                                      "(merged dependency-level groups), all levels, pre + post smoother, both directions" % [l for l, m in enumerate(bw_modes) if m == 3],
+            "block_wavefront_mode_by_level": bw_modes,
             "launches_per_cycle": launches, "entries_streamed_per_cycle": stored, "composite_entries_per_cycle": composite,
             "prepass_entries_per_cycle": tri,
-            "bytes_streamed_per_cycle": 12 * (stored + tri), "algorithmic_bytes_per_cycle": alg_sweeps,
-            "inflation": 12 * (stored + tri) / alg_sweeps,
+            # (as laid out: block levels their packed records — 80 / 208 bytes per 7- / 19-point row — merged levels 12 bytes per
+            # padded composite entry + pre-pass triangle; both sides of the ratio carry b, x in and x out, 24 bytes per row.
+            # Measured HBM traffic of the fine-level sweep: profiles/r04_pmc_flow.log)
+            "bytes_streamed_per_cycle": streamed_bytes, "algorithmic_bytes_per_cycle": alg_sweeps,
+            "inflation": streamed_bytes / alg_sweeps,
             "smoother_ms_per_cycle": smooth_ms, "cycle_ms_by_label": cycle_breakdown,
             "avg_launch_us": None if smooth_ms is None else 1e3 * smooth_ms / max(1, launches),
             "achieved": None if smooth_ms is None else alg_sweeps / (smooth_ms * 1e-3) / 1e9,
-            "streamed_GBs": None if smooth_ms is None else 12 * (stored + tri) / (smooth_ms * 1e-3) / 1e9,
+            "streamed_GBs": None if smooth_ms is None else streamed_bytes / (smooth_ms * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if smooth_ms is None else alg_sweeps / (smooth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "per_level": [{"fwd": p["fwd"], "bwd": p["bwd"]} for p in sweeps[:6]]},
