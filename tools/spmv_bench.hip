@@ -37,6 +37,7 @@ __global__ void csr_scalar_kernel(int n, const int* __restrict__ rowptr, const i
   y[r] = acc;
 }
 
+__device__ int dummy_;
 struct Variant { std::string name; void (*launch)(const StreamArgs&, hipStream_t); };
 
 template <class CFG>
@@ -46,6 +47,165 @@ void launch_cfg(const StreamArgs& a, hipStream_t st) {
   const int grid = CFG::XCD ? ((nb + kNumXcd - 1) / kNumXcd) * kNumXcd : nb;
   hipLaunchKernelGGL((csr_stream_kernel<M_SPMV, CFG>), dim3(grid), dim3(CFG::THREADS), 0, st, a);
 }
+
+// ---- experiment (round 4): col / val staged by LDS-DMA (global_load_lds_dwordx4: HBM -> LDS without passing registers),
+// a lane per row walking its entries out of LDS in stored order (the scalar loop's sum), x gathered row-aligned: for a
+// banded operator the 64 lanes of a gather read consecutive x (8 lines per instruction instead of ~35 when lanes hold
+// consecutive ENTRIES).  Persistent workgroups, two staging buffers: the next tile's DMA flies during this tile's gathers.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma16_nt(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int T, int ROWS, int EMAX, bool NT>
+__global__ __launch_bounds__(T) void csr_dma_kernel(StreamArgs a, int ntiles, long nnz) {
+  static_assert(ROWS == T, "a lane per row");
+  constexpr int NW = T / 64;
+  constexpr int NVI = EMAX * 8 / 1024 / NW, NCI = EMAX * 4 / 1024 / NW;   // DMA instructions per wave and tile
+  static_assert(NVI * NW * 1024 == EMAX * 8 && NCI * NW * 1024 == EMAX * 4, "EMAX: whole instructions per wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  double* val_s = (double*)lds;                          // [2][EMAX]
+  int* col_s = (int*)(lds + 2 * EMAX * 8);               // [2][EMAX]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds_base = 0;   // dynamic LDS starts at 0 (no static LDS in this kernel)
+  auto issue = [&](int tile, int buf) {
+    const int r0 = tile * ROWS;
+    const int p0 = __builtin_amdgcn_readfirstlane(a.rowptr[r0]);
+    const long a0 = p0 & ~3;
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+      const int inst = wave * NVI + i;
+      long e = a0 + ((long)inst * 64 + lane) * 2;          // entry index of this lane's 16 bytes
+      if (e > nnz - 2) e = (nnz - 2) & ~1l;                  // (the tail of the arrays: a harmless re-read)
+      const unsigned dst = lds_base + (unsigned)buf * (EMAX * 8) + (unsigned)inst * 1024u;
+      if (NT) lds_dma16_nt(a.val + e, dst); else lds_dma16(a.val + e, dst);
+    }
+#pragma unroll
+    for (int i = 0; i < NCI; ++i) {
+      const int inst = wave * NCI + i;
+      long e = a0 + ((long)inst * 64 + lane) * 4;
+      if (e > nnz - 4) e = (nnz - 4) & ~3l;
+      const unsigned dst = lds_base + 2u * EMAX * 8 + (unsigned)buf * (EMAX * 4) + (unsigned)inst * 1024u;
+      if (NT) lds_dma16_nt(a.col + e, dst); else lds_dma16(a.col + e, dst);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  issue(tile, 0);
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    const int r = tile * ROWS + tid;
+    const bool act = r < a.row_end;
+    const int rs = act ? a.rowptr[r] : 0, re = act ? a.rowptr[r + 1] : 0;
+    const int p0 = __builtin_amdgcn_readfirstlane(a.rowptr[tile * ROWS]);
+    const int a0 = p0 & ~3;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                          // this tile has landed; everybody is done with the other buffer
+    if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, buf ^ 1);
+    const double* vs = val_s + buf * EMAX;
+    const int* cs = col_s + buf * EMAX;
+    double acc = 0.0;
+    for (int j0 = rs; j0 < re; j0 += 8) {
+      int c[8]; double v[8], xv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const int j = min(j0 + e, re - 1) - a0; c[e] = cs[j]; v[e] = vs[j]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[e] = a.x[c[e]];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (j0 + e < re) acc += v[e] * xv[e];
+    }
+    if (act) a.y[r] = acc;
+  }
+}
+template <int T, int EMAX, bool NT, int WGPC>
+void launch_dma(const StreamArgs& a, hipStream_t st) {
+  const int nrows = a.row_end - a.row_begin;
+  const int ntiles = (nrows + T - 1) / T;
+  const int grid = std::min(ntiles, 256 * WGPC);
+  static long nnz = -1;
+  if (nnz < 0) { int v; hipMemcpy(&v, a.rowptr + nrows, 4, hipMemcpyDeviceToHost); nnz = v; }
+  const size_t lds = (size_t)2 * EMAX * 12;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)csr_dma_kernel<T, T, EMAX, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((csr_dma_kernel<T, T, EMAX, NT>), dim3(grid), dim3(T), lds, st, a, ntiles, nnz);
+}
+#define VD(T, E, NT, W) {"DMA T" #T " EMAX" #E " NT" #NT " WG/CU" #W, launch_dma<T, E, NT, W>}
+
+// variant A: one tile per workgroup (no persistence, one staging buffer): the overlap comes from the other workgroups of the CU
+template <int T, int RPT, int EMAX, bool NT>
+__global__ __launch_bounds__(T) void csr_dma1_kernel(StreamArgs a, long nnz) {
+  constexpr int NW = T / 64, ROWS = T * RPT;
+  constexpr int NVI = EMAX * 8 / 1024 / NW, NCI = (EMAX * 4 / 1024 + NW - 1) / NW;
+  static_assert(NVI * NW * 1024 == EMAX * 8, "EMAX: whole instructions per wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const double* vs = (const double*)lds;
+  const int* cs = (const int*)(lds + EMAX * 8);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = blockIdx.x * ROWS;
+  const int p0 = __builtin_amdgcn_readfirstlane(a.rowptr[r0]);
+  const long a0 = p0 & ~3;
+#pragma unroll
+  for (int i = 0; i < NVI; ++i) {
+    const int inst = wave * NVI + i;
+    long e = a0 + ((long)inst * 64 + lane) * 2;
+    if (e > nnz - 2) e = (nnz - 2) & ~1l;
+    if (NT) lds_dma16_nt(a.val + e, (unsigned)inst * 1024u); else lds_dma16(a.val + e, (unsigned)inst * 1024u);
+  }
+#pragma unroll
+  for (int i = 0; i < NCI; ++i) {
+    const int inst = wave * NCI + i;
+    if (inst * 1024 < EMAX * 4) {
+      long e = a0 + ((long)inst * 64 + lane) * 4;
+      if (e > nnz - 4) e = (nnz - 4) & ~3l;
+      if (NT) lds_dma16_nt(a.col + e, (unsigned)(EMAX * 8) + (unsigned)inst * 1024u); else lds_dma16(a.col + e, (unsigned)(EMAX * 8) + (unsigned)inst * 1024u);
+    }
+  }
+  int rs[RPT], re[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) { const int r = r0 + tid + q * T; const bool act = r < a.row_end; rs[q] = act ? a.rowptr[r] : 0; re[q] = act ? a.rowptr[r + 1] : 0; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  double acc[RPT];
+  int c[RPT][8]; double v[RPT][8], xv[RPT][8];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    acc[q] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const int j = max(min(rs[q] + e, re[q] - 1), (int)a0) - (int)a0; c[q][e] = cs[j]; v[q][e] = vs[j]; }
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xv[q][e] = a.x[c[q][e]];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (rs[q] + e < re[q]) acc[q] += v[q][e] * xv[q][e];
+    for (int j0 = rs[q] + 8; j0 < re[q]; j0 += 8)       // (rows longer than 8: the rest, batch by batch)
+      for (int e = 0; e < 8 && j0 + e < re[q]; ++e) acc[q] += vs[j0 + e - a0] * a.x[cs[j0 + e - a0]];
+    const int r = r0 + tid + q * T;
+    if (r < a.row_end) a.y[r] = acc[q];
+  }
+}
+template <int T, int RPT, int EMAX, bool NT>
+void launch_dma1(const StreamArgs& a, hipStream_t st) {
+  const int nrows = a.row_end - a.row_begin;
+  const int ntiles = (nrows + T * RPT - 1) / (T * RPT);
+  static long nnz = -1;
+  if (nnz < 0) { int v; hipMemcpy(&v, a.rowptr + nrows, 4, hipMemcpyDeviceToHost); nnz = v; }
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)csr_dma1_kernel<T, RPT, EMAX, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((csr_dma1_kernel<T, RPT, EMAX, NT>), dim3(ntiles), dim3(T), (size_t)EMAX * 12, st, a, nnz);
+}
+#define VA(T, R, E, NT) {"DMA1 T" #T " RPT" #R " EMAX" #E " NT" #NT, launch_dma1<T, R, E, NT>}
+
 #define V(T, R, L, VEC, NT, XCD) {"T" #T " RPT" #R " LDS" #L " VEC" #VEC " NT" #NT " XCD" #XCD, launch_cfg<StreamCfg<T, (T) * (R), L, VEC, NT, XCD>>}
 
 int main(int argc, char** argv) {
@@ -135,6 +295,9 @@ int main(int argc, char** argv) {
       V(128, 1, 1024, 2, true, false),
       V(128, 1, 1024, 4, false, false),
       V(128, 2, 2048, 4, false, false),
+      VA(256, 1, 2048, false), VA(256, 1, 2048, true), VA(128, 1, 1024, false), VA(256, 2, 4096, false), VA(512, 1, 4096, false), VA(512, 1, 4096, true), VA(1024, 1, 8192, false), VA(128, 2, 2048, false),
+      VD(256, 2048, false, 2), VD(256, 2048, false, 3), VD(256, 2048, true, 3), VD(256, 2048, false, 4), VD(256, 2048, true, 4),
+      VD(512, 4096, false, 1), VD(512, 4096, false, 2), VD(512, 4096, true, 2),
   };
   if (ship_only) vs = {V(1024, 1, 8192, 4, false, false)};
   StreamArgs a{};
