@@ -221,3 +221,4 @@ def test_soak_2000_sweeps_under_memory_load_eager_and_graph_replayed(soak_fixtur
         lib.amgh_destroy(h2)
     assert launched[0] > 200 and not raised     # the load really ran beside the cycles
     assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0 and lib.amgh_dev_sync(0) == 0
+
