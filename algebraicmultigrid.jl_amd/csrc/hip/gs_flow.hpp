@@ -32,7 +32,7 @@ namespace amgh {
 namespace bw {
 
 constexpr int kFlowThreads = 128;       // wave 0 walks, wave 1 fetches
-constexpr int32_t kPubFwd = 1 << 30;    // pub word: mailbox index | directions in which the row is published
+constexpr int32_t kPubFwd = 1 << 30;    // pub word: forward mailbox | backward mailbox << 11 (relative to the block's first) | directions in which the row is published
 constexpr int32_t kPubBwd = (int32_t)(1u << 31);
 constexpr int32_t kPubMask = (1 << 30) - 1;
 #ifndef BW_FLOW_WAVES
@@ -45,7 +45,7 @@ constexpr int32_t kPubMask = (1 << 30) - 1;
 struct FlowDesc {      // per block, beside Desc (16 bytes)
   int32_t aux;         // offset into the aux array: step words of the forward walk [nlev + 1], then of the backward walk [nlev + 1]
   int32_t npost;       // external columns behind the block that are rows (not halo columns of a sharded operator)
-  int32_t pad0, pad1;
+  int32_t pad0, pad1;  // pad0: the block's first mailbox
 };
 // step word k of a walk (in walking order): first row | rows << 11 | near-side values the step needs in LDS << 18; word nlev: 0 | 0 | all
 constexpr int kStepRowBits = 11, kStepCntBits = 7, kStepNeedMax = (1 << 14) - 1;
@@ -86,33 +86,32 @@ bool flow_build(const Plan& P, int threads, Flow* out) {
   const int64_t n = P.n;
   const int32_t B = (int32_t)P.blocks.size();
   typedef Packed<R> Pk;
-  // rows other blocks read, in which sweep direction they read them as NEW values, and which block reads them first
-  F.pub.assign(n, 0);
-  std::vector<int32_t> reader(n, -1);   // forward: the first block behind that reads the row; rows only read backward: the last block before
+  // rows other blocks read: in which sweep direction they read them as NEW values, and which block reads them first
+  std::vector<int32_t> cell_f(n, -1), cell_b(n, -1);   // the row's mailbox in forward / backward sweeps (first: the reading block)
   for (int32_t ob = 0; ob < B; ++ob) {
     const Desc& d = P.blocks[ob];
     for (int32_t e = 0; e < d.next; ++e) {
       const int32_t q = P.ext_col[d.ext0 + e];
       if (q >= n) continue;                                 // halo column: never written
-      if (e < d.npre) {                                     // before the block: a new value of the forward sweep
-        if (!(F.pub[q] & kPubFwd) || ob < reader[q]) reader[q] = ob;
-        F.pub[q] |= kPubFwd;
-      } else {
-        if (!(F.pub[q] & kPubFwd)) reader[q] = std::max(reader[q], ob);
-        F.pub[q] |= kPubBwd;
-      }
+      if (e < d.npre) { if (cell_f[q] < 0 || ob < cell_f[q]) cell_f[q] = ob; }   // before the block: a new value of the forward sweep
+      else cell_b[q] = std::max(cell_b[q], ob);
     }
   }
-  // mailboxes: a block's published rows grouped by (direction, reading block), in block order inside a group — what one
-  // reader fetches from one block is then a run of consecutive cells in the order it needs them (coalesced polls), and what
-  // a step publishes towards one reader is a run as well (merged write-through stores)
+  // mailboxes, block by block: first the rows published forward grouped by reading block, then the rows published backward
+  // likewise (a row read in both directions has one cell in each part), in block order inside a group — what one reader
+  // fetches from one block is then a run of consecutive cells in the order it needs them (coalesced polls), and what a step
+  // publishes towards one reader is a run as well (merged write-through stores).  The publish word of a row: its forward
+  // cell | backward cell << 11 (both relative to the block's first cell) | the directions
   int64_t nm = 0;
+  F.pub.assign(n, 0);
+  F.fd.resize(B);
   {
     std::vector<int64_t> base(B + 1, 0);
     for (int32_t ob = 0; ob < B; ++ob) {
       const Desc& d = P.blocks[ob];
       int64_t c = 0;
-      for (int32_t p = 0; p < d.nrows; ++p) c += F.pub[d.row0 + p] != 0;
+      for (int32_t p = 0; p < d.nrows; ++p) c += (cell_f[d.row0 + p] >= 0) + (cell_b[d.row0 + p] >= 0);
+      if (c >= (1 << 11)) return false;
       base[ob + 1] = base[ob] + c;
     }
     nm = base[B];
@@ -121,20 +120,23 @@ bool flow_build(const Plan& P, int threads, Flow* out) {
       std::vector<int32_t> rows;
       for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
         const Desc& d = P.blocks[ob];
-        rows.clear();
-        for (int32_t p = 0; p < d.nrows; ++p) if (F.pub[d.row0 + p] != 0) rows.push_back(d.row0 + p);
-        std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) {
-          const int fx = (F.pub[x] & kPubFwd) ? 0 : 1, fy = (F.pub[y] & kPubFwd) ? 0 : 1;
-          if (fx != fy) return fx < fy;
-          return reader[x] < reader[y];
-        });
-        for (size_t i = 0; i < rows.size(); ++i) F.pub[rows[i]] |= (int32_t)(base[ob] + (int64_t)i);
+        F.fd[ob].pad0 = (int32_t)base[ob];   // (mail0: the block's first cell)
+        int32_t local = 0;
+        for (int dir = 0; dir < 2; ++dir) {
+          std::vector<int32_t>& cl = dir ? cell_b : cell_f;
+          rows.clear();
+          for (int32_t p = 0; p < d.nrows; ++p) if (cl[d.row0 + p] >= 0) rows.push_back(d.row0 + p);
+          std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) { return cl[x] < cl[y]; });
+          for (int32_t q : rows) {
+            F.pub[q] |= dir ? ((local << 11) | kPubBwd) : (local | kPubFwd);
+            cl[q] = (int32_t)base[ob] + local;    // (from here on: the absolute cell)
+            ++local;
+          }
+        }
       }
     });
-    for (int64_t q = 0; q < n; ++q) if (F.pub[q] == 0) F.pub[q] = kPubMask;   // (no direction bits: never published)
   }
   F.nmail = nm;
-  F.fd.resize(B);
   int64_t aux_total = 0;
   for (int32_t ob = 0; ob < B; ++ob) {
     F.fd[ob].aux = (int32_t)aux_total;
@@ -174,7 +176,7 @@ bool flow_build(const Plan& P, int threads, Flow* out) {
         }
       int32_t npost = 0;
       for (int32_t e = d.npre; e < d.next; ++e) if (P.ext_col[d.ext0 + e] < n) ++npost;
-      f.npost = npost; f.pad0 = f.pad1 = 0;
+      f.npost = npost; f.pad1 = 0;
       // forward list: near side = columns before the block, by first use; need_fwd[k] = entries step k needs complete
       order.resize(d.npre);
       for (int32_t e = 0; e < d.npre; ++e) order[e] = e;
@@ -188,7 +190,7 @@ bool flow_build(const Plan& P, int threads, Flow* out) {
         ax[ns] = step_word(0, 0, d.npre);
         for (int32_t i = 0; i < d.npre; ++i) {
           const int32_t e = order[i];
-          F.fl_mb[d.ext0 + i] = F.pub[P.ext_col[d.ext0 + e]] & kPubMask;
+          F.fl_mb[d.ext0 + i] = cell_f[P.ext_col[d.ext0 + e]];
           F.fl_slot[d.ext0 + i] = (uint16_t)(d.nrows + e);
         }
       }
@@ -205,7 +207,7 @@ bool flow_build(const Plan& P, int threads, Flow* out) {
         ax[2 * ns + 1] = step_word(0, 0, npost);
         for (int32_t i = 0; i < npost; ++i) {
           const int32_t e = order[i];
-          F.fl_mb[d.ext0 + d.npre + i] = F.pub[P.ext_col[d.ext0 + e]] & kPubMask;
+          F.fl_mb[d.ext0 + d.npre + i] = cell_b[P.ext_col[d.ext0 + e]];
           F.fl_slot[d.ext0 + d.npre + i] = (uint16_t)(d.nrows + e);
         }
       }
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(kFlowThreads, (MAXK <= 6 ? BW_FLOW_WAVES : 2)) void
     // a row another block reads: into its mailbox at once, tagged with the sweep's epoch; every other lane into the block's
     // spare cell (one more line per step instead of a branch around the store)
     const int32_t pw = o.pub();
-    const unsigned cell = ((pw & pubdir) && !mute) ? (unsigned)(pw & kPubMask) : spare;
+    const unsigned cell = ((pw & pubdir) && !mute) ? (unsigned)f.pad0 + (((unsigned)pw >> (BWD ? 11 : 0)) & 0x7ffu) : spare;
     if constexpr (sizeof(R) == 8) {
       const unsigned qlo = (unsigned)__double2loint(q), qhi = (unsigned)__double2hiint(q);
       u32x4 cv = {qlo, epoch, qhi, epoch};
