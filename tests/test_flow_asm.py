@@ -1,0 +1,23 @@
+"""The dataflow sweep kernel (csrc/hip/gs_flow.hpp) counts its memory pipeline by hand: loads are inline asm whose
+destination registers the compiler allocates but does not track, waited for by `s_waitcnt vmcnt((D - 1)(L + 2))`.  This
+test compiles all 24 instantiations (double / float x GS / SOR x forward / backward x rows of 6 / 12 / 18 entries) to gfx950
+assembly (hipcc cross-compiles without a GPU) and audits the steady loop of each (tools/flow_asm_audit.py): no instruction
+touches a register set between its loads and its wait, the loop holds the hand-written waits and no compiler-inserted
+one, every load carries a scalar offset, no waterfall.  A compiler update that changes any of this fails here, not as a
+wrong bit on the GPU."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_flow_kernel_pipeline_survives_the_compiler():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "flow_asm_audit.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    lines = [l for l in out.splitlines() if l.startswith(("ok", "FAIL"))]
+    assert r.returncode == 0 and len(lines) == 24 and all(l.startswith("ok") for l in lines), out

@@ -1,0 +1,7 @@
+// The dataflow sweep kernels (csrc/hip/gs_flow.hpp) for both value types, and nothing else: what tools/flow_asm_audit.py
+// compiles to assembly (tests/test_flow_asm.py).
+#include "../algebraicmultigrid.jl_amd/csrc/hip/gs_flow.hpp"
+namespace amgh { namespace bw {
+template hipError_t sweep_flow<double>(const FlowArgs<double>&, int, size_t, bool, bool, hipStream_t);
+template hipError_t sweep_flow<float>(const FlowArgs<float>&, int, size_t, bool, bool, hipStream_t);
+} }
