@@ -1063,7 +1063,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   if (hipMemset(g->bw.head, 0, 8) != hipSuccess) return -1001;
   g->bw.nblocks = (int32_t)B;
   // the sweep as a dataflow (gs_flow.hpp) where the data dependencies carry the anti-dependencies: structurally symmetric patterns
-  if (g_gs_bw_flow && ncols <= n && bw::structurally_symmetric(n, rowptr, col, prm.threads)) {
+  if (g_gs_bw_flow && bw::structurally_symmetric(n, rowptr, col, prm.threads)) {   // (halo columns of a row-sharded operator: never written, read as they stand)
     bw::Flow F;
     bool fok = false;
     try { fok = bw::flow_build<real>(P, prm.threads, &F); } catch (const std::exception&) { fok = false; }

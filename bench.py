@@ -118,6 +118,7 @@ def main():
                     help="N > 1: halo transport of the primary measurement (default: AMGH_DIST_TRANSPORT or rccl)")
     ap.add_argument("--smoother", default="gs", choices=("gs", "jacobi"),
                     help="N > 1: smoother of the primary measurement (gs = ruge_stuben defaults; jacobi = Jacobi(2/3))")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the 32^3 two-cycle exchange that tries every transport before the timed problem")
     ap.add_argument("--no-secondary", action="store_true",
                     help="N > 1: skip the secondary measurements (Jacobi-smoothed hierarchy, IPC transport)")
     ap.add_argument("--setup", default="gpu", choices=("gpu", "host"), help="where the data-parallel half of ruge_stuben runs")

@@ -46,8 +46,11 @@ def node_levels(rank, world, bcast, build):
     tail = None
     levels = None
     ml = None
+    t_phase = {}
     if rank == 0:
+        t0 = time.perf_counter()
         ml = build()
+        t_phase["hierarchy_s"] = time.perf_counter() - t0
         A = ml.levels[0].A if ml.levels else ml.final_A
         sizes = [l.A.m for l in ml.levels] + [ml.final_A.m]
         lc = SH.num_sharded_levels(sizes, world)
@@ -65,13 +68,19 @@ def node_levels(rank, world, bcast, build):
             except OSError:
                 pass
             shm = tempfile.mkdtemp(prefix="amgh_levels_", dir=base)
+            t0 = time.perf_counter()
             SH.export_levels(levels, shm)
+            t_phase["export_s"] = time.perf_counter() - t0
+            t_phase["export_bytes"] = int(need)
         info["shm"] = shm
+        info["phases"] = t_phase
     else:
         info = None
     info = bcast(info)
     if rank != 0:
+        t0 = time.perf_counter()
         levels = SH.load_levels(info["shm"])
+        info = dict(info, load_s=time.perf_counter() - t0)
     info = dict(info, ml=ml)
     return levels, info, tail, shm
 
@@ -179,7 +188,16 @@ def main_distributed(args):
 
     import torch.distributed as dist  # rendezvous only (CPU / gloo)
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # (gloo announces its connections on stdout: rank 0's stdout is the ONE JSON line — the chatter goes to stderr)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     def bcast(obj):
         if world == 1:
@@ -250,6 +268,75 @@ def main_distributed(args):
 
     b = uniform(n, 0)
     notes = {}
+
+    def preflight(tkind):
+        """A 2-cycle exchange of a 32^3 Jacobi hierarchy over transport `tkind`, checked against the oracle on rank 0, before
+        the timed problem meets that transport for the first time (bounded: the IPC transport's own timeout is 30 s here; RCCL
+        has none of its own — a rank that cannot initialise it raises, a rank that hangs in it is the launcher's to kill)."""
+        t0 = time.perf_counter()
+        rec = {"transport": tkind, "ok": False}
+        old = os.environ.get("AMGH_IPC_TIMEOUT_S")
+        os.environ["AMGH_IPC_TIMEOUT_S"] = "30"
+        run = None
+        try:
+            small = AMG.ruge_stuben(AMG.poisson((32, 32, 32)), presmoother=jac, postsmoother=jac) if rank == 0 else None
+            lv_s, info_s, tail_s, shm_s = node_levels(rank, world, bcast, lambda: small)
+            ctx_s = dict(ctx, info=info_s)
+            err = None
+            try:
+                run = Run(ctx_s, "preflight", lv_s, tail_s, transport_spec(tkind))
+            except AMG.AMGError as e:
+                err = str(e)[:200]
+            if not all_ok(run is not None):
+                rec["error"] = err or "another rank failed to create the handle"
+            else:
+                nb = 32 ** 3
+                bs = uniform(nb, 7)
+                res, z_loc = run.measure(bs, 2, 0)
+                z = assemble_on_rank0(ctx_s, "preflight_" + tkind, z_loc)
+                good = True
+                if rank == 0:
+                    from oracle import oracle as O
+                    want = O.OracleHierarchy(info_s["ml"]).precond(bs)
+                    rel = float(np.linalg.norm(z - want) / np.linalg.norm(want))
+                    rec["rel_err_vs_oracle"] = rel
+                    good = rel <= PARITY_TOL
+                rec["ok"] = bool(bcast(good if rank == 0 else None))
+                if not rec["ok"]:
+                    rec["error"] = "the exchanged cycle differs from the oracle"
+            if rank == 0 and shm_s:
+                shutil.rmtree(shm_s, ignore_errors=True)
+        except Exception as ex:  # noqa: BLE001
+            rec["error"] = f"{type(ex).__name__}: {str(ex)[:200]}"
+        finally:
+            if run is not None:
+                try:
+                    run.sh.close()
+                except Exception:  # noqa: BLE001
+                    pass
+            if old is None:
+                os.environ.pop("AMGH_IPC_TIMEOUT_S", None)
+            else:
+                os.environ["AMGH_IPC_TIMEOUT_S"] = old
+        rec["ok"] = all_ok(rec["ok"])
+        rec["seconds"] = round(time.perf_counter() - t0, 2)
+        return rec
+
+    preflights = []
+    if world > 1 and not getattr(args, "no_preflight", False):
+        order = [transport] + [t for t in ("rccl", "ipc") if t != transport and not (one_gpu and t == "rccl")]
+        chosen = None
+        for tk in order:
+            rec = preflight(tk)
+            preflights.append(rec)
+            if rec["ok"] and chosen is None:
+                chosen = tk
+        if chosen is None:
+            raise SystemExit(f"bench_dist.py: no transport passed the preflight exchange: {preflights}")
+        if chosen != transport:
+            notes["transport_requested"] = transport
+            notes["transport_fallback_reason"] = next((r.get("error", "preflight failed") for r in preflights if r["transport"] == transport), "preflight failed")
+            transport = chosen
 
     def run_config(label, kind, tkind, want_spmv=False):
         lv, tl, ml_k = variant(kind)
@@ -327,6 +414,11 @@ def main_distributed(args):
                        "halo_bytes_sent_per_cycle_max_rank": primary["halo_bytes_sent_per_cycle_max_rank"],
                        "halo_bytes_sent_per_cycle_all_ranks": primary["halo_bytes_sent_per_cycle_all_ranks"],
                        "all_ranks_on_one_gpu": bool(one_gpu and world > 1),
+                       # lexicographic Gauss-Seidel is a dependency chain through the whole grid: a row-sharded sweep keeps
+                       # 256 + 256 + 256/N - 2 dependency levels per shard (exact inside a shard), so its time is bound by that
+                       # chain, not by the rows per GPU — the curve that CAN scale with N is secondary["jacobi"] (same hierarchy)
+                       "gauss_seidel_is_critical_path_bound": smoother == "gs",
+                       "scaling_curve": "secondary.jacobi" if (smoother == "gs" and "jacobi" in extra) else "value",
                        "parallelism": f"row-shard x{world} ({primary['transport']} halos, libamghip amgh_dist_*)"},
             "roofline": None if spmv_ms is None else {
                 "bound": "hbm", "kernel": "csr_stream_kernel<SPMV> on n/N local rows + neighbour halo exchange",
@@ -337,6 +429,13 @@ def main_distributed(args):
             "parity": primary["parity"],
             "cpu_baseline": cpu,
             "setup_s": t_setup, "shard_s": primary["shard_s"],
+            "setup_breakdown": {"hierarchy_s_rank0": info.get("phases", {}).get("hierarchy_s"),
+                                "export_s_rank0": info.get("phases", {}).get("export_s"),
+                                "export_bytes": info.get("phases", {}).get("export_bytes"),
+                                "per_rank_plans_and_upload_s": primary["shard_s"],
+                                "note": "rank 0 builds the hierarchy while the other ranks wait; every rank then lays out its own shard "
+                                        "(halo plans, smoother schedules, block plans) in per_rank_plans_and_upload_s"},
+            "preflight": preflights, "transport_used": primary["transport"],
             **({"secondary": {k: strip(v) for k, v in extra.items()}} if extra else {}),
             **notes,
         }
