@@ -27,6 +27,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -158,15 +159,27 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   int64_t hist[32] = {0};
   int maxlen = 0;
   int64_t cmax = n - 1;   // largest column (halo columns of a row-sharded operator lie behind the rows)
-  for (int64_t i = 0; i < n; ++i) {
-    int off = 0;
-    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-      cmax = std::max<int64_t>(cmax, col[j]);
-      const int64_t d = (int64_t)i - col[j];
-      if (d != 0) ++off;                                   // (halo columns of a row-sharded operator count as entries of the row)
-      if (d != 0 && col[j] < n) hist[31 - __builtin_clz((unsigned)(d < 0 ? -d : d))]++;
+  {
+    const int TH = std::max(1, prm.threads);
+    std::vector<std::array<int64_t, 34>> part((size_t)TH);   // per thread: the histogram, the longest row, the largest column
+    parallel_for(TH, [&](int t, int TT) {
+      std::array<int64_t, 34>& h = part[(size_t)t];
+      h.fill(0); h[33] = n - 1;
+      for (int64_t i = n * t / TT; i < n * (t + 1) / TT; ++i) {
+        int off = 0;
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+          h[33] = std::max<int64_t>(h[33], col[j]);
+          const int64_t d = (int64_t)i - col[j];
+          if (d != 0) ++off;                                   // (halo columns of a row-sharded operator count as entries of the row)
+          if (d != 0 && col[j] < n) h[31 - __builtin_clz((unsigned)(d < 0 ? -d : d))]++;
+        }
+        h[32] = std::max<int64_t>(h[32], off);   // off-diagonal entries of the longest row
+      }
+    });
+    for (const auto& h : part) {
+      for (int b = 0; b < 32; ++b) hist[b] += h[b];
+      maxlen = std::max(maxlen, (int)h[32]); cmax = std::max(cmax, h[33]);
     }
-    maxlen = std::max(maxlen, off);   // off-diagonal entries of the longest row
   }
   const int maxk = ((std::max(1, maxlen) + kChunk - 1) / kChunk) * kChunk;
   if (maxk > kPlanMaxK) return false;   // (kMaxK: the kernels' register sets; longer rows make the walk instruction-bound, profiles/r03_block_wave.log)
@@ -230,10 +243,19 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     if (ncell > ((int64_t)1 << 28)) { if (it == 0) return false; break; }
     for (int k = 0; k < 3; ++k) { h[k] = ht[k]; nb[k] = nt[k]; }
     count.assign((size_t)ncell, 0);
-    for (int64_t i = 0; i < n; ++i) {
-      const int32_t q = (phi[0][i] / h[0]) + nb[0] * ((phi[1][i] / h[1]) + nb[1] * (phi[2][i] / h[2]));
-      cell[i] = q;
-      count[q]++;
+    {
+      const int TH = std::max(1, prm.threads);
+      std::vector<std::vector<int32_t>> pc((size_t)TH);
+      parallel_for(TH, [&](int t, int TT) {
+        std::vector<int32_t>& c = pc[(size_t)t];
+        c.assign((size_t)ncell, 0);
+        for (int64_t i = n * t / TT; i < n * (t + 1) / TT; ++i) {
+          const int32_t q = (phi[0][i] / h[0]) + nb[0] * ((phi[1][i] / h[1]) + nb[1] * (phi[2][i] / h[2]));
+          cell[i] = q;
+          c[q]++;
+        }
+      });
+      for (const auto& c : pc) for (int64_t q = 0; q < ncell; ++q) count[(size_t)q] += c[(size_t)q];
     }
     int64_t over = 0;
     for (int32_t cnt : count) if (cnt > cap) over += cnt;
@@ -290,21 +312,29 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   std::vector<int64_t> eptr(B + 1, 0);   // edges (block of c) -> (block of i) for c < i adjacent, collected per target block (pre-order)
   std::vector<int32_t> esrc;
   {
-    for (int64_t i = 0; i < n; ++i)
-      for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-        const int32_t c = col[j];
-        if (c >= n || c == i || blk[c] == blk[i]) continue;
-        eptr[(c < i ? blk[i] : blk[c]) + 1]++;
-      }
+    // (counted and filled by all threads at once: the order of a block's list is whatever the threads make it — only its
+    // maximum and, sorted and made unique below, its set are used)
+    const int TH = std::max(1, prm.threads);
+    parallel_for(TH, [&](int t, int TT) {
+      for (int64_t i = n * t / TT; i < n * (t + 1) / TT; ++i)
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+          const int32_t c = col[j];
+          if (c >= n || c == i || blk[c] == blk[i]) continue;
+          __atomic_fetch_add(&eptr[(c < i ? blk[i] : blk[c]) + 1], (int64_t)1, __ATOMIC_RELAXED);
+        }
+    });
     for (int32_t b = 0; b < B; ++b) eptr[b + 1] += eptr[b];
     esrc.resize(eptr[B]);
     std::vector<int64_t> next(eptr.begin(), eptr.end() - 1);
-    for (int64_t i = 0; i < n; ++i)
-      for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-        const int32_t c = col[j];
-        if (c >= n || c == i || blk[c] == blk[i]) continue;
-        if (c < i) esrc[next[blk[i]]++] = blk[c]; else esrc[next[blk[c]]++] = blk[i];
-      }
+    parallel_for(TH, [&](int t, int TT) {
+      for (int64_t i = n * t / TT; i < n * (t + 1) / TT; ++i)
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+          const int32_t c = col[j];
+          if (c >= n || c == i || blk[c] == blk[i]) continue;
+          const int32_t tgt = c < i ? blk[i] : blk[c], src = c < i ? blk[c] : blk[i];
+          esrc[__atomic_fetch_add(&next[tgt], (int64_t)1, __ATOMIC_RELAXED)] = src;
+        }
+    });
     // pre-order is a topological order: cells by coordinate sum would be one, and so is (cell index, window) — a cell
     // only depends on cells with smaller-or-equal coordinates, i.e. smaller cell index, and inside a cell on earlier windows
     for (int32_t b = 0; b < B; ++b) {
@@ -326,12 +356,19 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   }
   // ---- in-block dependency levels (index order is a topological order) ----
   std::vector<int32_t> ilev(n, 0);
-  for (int64_t i = 0; i < n; ++i) {
-    int32_t l = ilev[i];
-    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) { const int32_t c = col[j]; if (c < i && blk[c] == blk[i]) l = std::max(l, ilev[c] + 1); }
-    ilev[i] = l;
-    for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) { const int32_t c = col[j]; if (c > i && c < n && blk[c] == blk[i]) ilev[c] = std::max(ilev[c], l + 1); }
-  }
+  parallel_for(T, [&](int t, int TT) {   // (block by block: the recurrence only couples rows of one block)
+    std::vector<int32_t> rows;
+    for (int32_t b = (int32_t)(B * (int64_t)t / TT); b < (int32_t)(B * (int64_t)(t + 1) / TT); ++b) {
+      rows.assign(crow.begin() + bptr[b], crow.begin() + bptr[b + 1]);
+      std::sort(rows.begin(), rows.end());
+      for (int32_t i : rows) {
+        int32_t l = ilev[i];
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) { const int32_t c = col[j]; if (c < i && blk[c] == b) l = std::max(l, ilev[c] + 1); }
+        ilev[i] = l;
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) { const int32_t c = col[j]; if (c > i && c < n && blk[c] == b) ilev[c] = std::max(ilev[c], l + 1); }
+      }
+    }
+  });
   lap("in-block levels");
   // ---- rows in block order ----
   P.blocks.resize(B);

@@ -79,8 +79,10 @@ inline bool structurally_symmetric(int64_t n, const int32_t* rowptr, const int32
 }
 
 // The dataflow view of a plan: mailboxes, fetch lists in order of use, the records transposed for coalesced streaming.
+// inplace: the plan's row-major records are turned into the chunk-major ones where they lie (F.srec stays empty; P.rec is
+// then what the dataflow kernel streams, and no longer what the chained / launched kernels or the host execution read)
 template <typename R>
-bool flow_build(const Plan& P, int threads, Flow* out) {
+bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false) {
   Flow& F = *out;
   F = Flow();
   const int64_t n = P.n;
@@ -112,10 +114,11 @@ bool flow_build(const Plan& P, int threads, Flow* out) {
       int64_t c = 0;
       for (int32_t p = 0; p < d.nrows; ++p) c += (cell_f[d.row0 + p] >= 0) + (cell_b[d.row0 + p] >= 0);
       if (c >= (1 << 11)) return false;
+      if ((((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15) + 16 > 64 * 1024) return false;   // (the kernel's LDS: x of the block)
       base[ob + 1] = base[ob] + c;
     }
     nm = base[B];
-    if (nm >= kPubMask) return false;
+    if (nm >= kPubMask || (nm + 1024) * (int64_t)(2 * sizeof(R)) >= 0x7ffffff0ll) return false;   // (the mailboxes: one buffer descriptor)
     parallel_for(std::max(1, threads), [&](int t, int TT) {
       std::vector<int32_t> rows;
       for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
@@ -146,16 +149,19 @@ bool flow_build(const Plan& P, int threads, Flow* out) {
   F.aux.assign((size_t)aux_total, 0);
   F.fl_mb.assign(std::max<size_t>(1, P.ext_col.size()), 0);
   F.fl_slot.assign(std::max<size_t>(1, P.ext_col.size()), 0);
-  F.srec.resize(P.rec.size());
+  if (!inplace) F.srec.resize(P.rec.size());
   std::atomic<size_t> lds_max{0};
   parallel_for(std::max(1, threads), [&](int t, int TT) {
     std::vector<int32_t> use, order;
+    std::vector<unsigned char> tmp;   // (in place: one block's rows, transposed, before they go back)
     size_t my_lds = 0;
     for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
       const Desc& d = P.blocks[ob];
       FlowDesc& f = F.fd[ob];
       const unsigned char* rec = P.rec.data() + (size_t)d.rec * 16;
-      unsigned char* srec = F.srec.data() + (size_t)d.rec * 16;
+      const size_t rows_bytes = (size_t)d.nrows * Pk::row_bytes(d.maxk);
+      if (inplace) tmp.resize(rows_bytes);
+      unsigned char* srec = inplace ? tmp.data() : F.srec.data() + (size_t)d.rec * 16;
       const size_t rs = Pk::row_bytes(d.maxk);
       const int kch = Pk::chunks(d.maxk), nvc = Pk::nvc(d.maxk);
       const uint16_t* stp = (const uint16_t*)(rec + (size_t)d.nrows * rs);
@@ -227,7 +233,8 @@ bool flow_build(const Plan& P, int threads, Flow* out) {
             std::memcpy(srec + ((size_t)kch * r0 + (size_t)(nvc + Pk::ncc(d.maxk) - 1) * nr + q) * 16 + 4 * cdw, &F.pub[d.row0 + r0 + q], 4);
         }
       }
-      std::memcpy(srec + (size_t)d.nrows * rs, rec + (size_t)d.nrows * rs, Pk::rec_bytes(d.nrows, d.maxk, d.nlev) - (size_t)d.nrows * rs);
+      if (inplace) std::memcpy(P.rec.data() + (size_t)d.rec * 16, tmp.data(), rows_bytes);   // (the step pointers behind the rows stay)
+      else std::memcpy(srec + (size_t)d.nrows * rs, rec + (size_t)d.nrows * rs, Pk::rec_bytes(d.nrows, d.maxk, d.nlev) - (size_t)d.nrows * rs);
       my_lds = std::max(my_lds, (((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15) + 16);
     }
     size_t cur = lds_max.load();

@@ -1066,12 +1066,21 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   if (g_gs_bw_flow && bw::structurally_symmetric(n, rowptr, col, prm.threads)) {   // (halo columns of a row-sharded operator: never written, read as they stand)
     bw::Flow F;
     bool fok = false;
-    try { fok = bw::flow_build<real>(P, prm.threads, &F); } catch (const std::exception&) { fok = false; }
-    if (fok && F.lds_max <= 64 * 1024 && (F.nmail + 1024) * (int64_t)bw::Mail<real>::kBytes < 0x7ffffff0ll) {
+    // (the default footprint keeps the dataflow layout only: its records are made from the plan's where they lie)
+    const bool inplace = gs_trim();
+    // (every limit is checked before a record is touched: `false` leaves the plan as it was; an exception — memory — with the
+    // records half rewritten leaves no block layout at all: the level schedules take the level)
+    try { fok = bw::flow_build<real>(P, prm.threads, &F, inplace); }
+    catch (const std::exception&) {
+      fok = false;
+      if (inplace) { g->free_dev(); return AMGH_OK; }
+    }
+    if (fok) {
       tm.lap("dataflow layout", n);
       GsSchedule::Bw::FlowDev& fl = g->bw.flow;
       RC_TRY(dev_upload(&fl.fd, F.fd.data(), (int64_t)F.fd.size()));
-      RC_TRY(dev_upload(&fl.srec, F.srec.data(), (int64_t)F.srec.size()));
+      if (inplace) RC_TRY(dev_upload(&fl.srec, P.rec.data(), (int64_t)P.rec.size()));
+      else RC_TRY(dev_upload(&fl.srec, F.srec.data(), (int64_t)F.srec.size()));
       if (F.aux.empty()) F.aux.push_back(0);
       RC_TRY(dev_upload(&fl.aux, F.aux.data(), (int64_t)F.aux.size()));
       RC_TRY(dev_upload(&fl.fl_mb, F.fl_mb.data(), (int64_t)F.fl_mb.size()));
@@ -1080,7 +1089,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
       if (hipMalloc(&fl.mbox, mbytes) != hipSuccess) { (void)hipGetLastError(); return AMGH_ENOMEM; }
       if (hipMemset(fl.mbox, 0, mbytes) != hipSuccess) return -1001;   // (epoch 0 is never a sweep's)
       fl.nmail = F.nmail; fl.lds_max = F.lds_max;
-      fl.bytes = (int64_t)F.fd.size() * (int64_t)sizeof(bw::FlowDesc) + (int64_t)F.srec.size() + (int64_t)F.aux.size() * 4 + (int64_t)F.fl_mb.size() * 6 + (int64_t)mbytes;
+      fl.bytes = (int64_t)F.fd.size() * (int64_t)sizeof(bw::FlowDesc) + (int64_t)P.rec.size() + (int64_t)F.aux.size() * 4 + (int64_t)F.fl_mb.size() * 6 + (int64_t)mbytes;
       fl.on = true;
       g->bytes += fl.bytes;
       tm.lap("dataflow upload", n);
