@@ -400,6 +400,7 @@ struct amgh_dist {
   amgh_t* tail = nullptr;              // the collapsed levels (on the rank that owns them), not owned
   bool finalized = false;
   bool host_only = false;              // device < 0: halo plans in host memory only, no GPU call anywhere
+  bool gs_exact = true;                // Gauss-Seidel / SOR across the shards: exact lexicographic order (ranks in turn) or the hybrid (amgh_dist_set_gs_mode)
   int nplans = 0;
   real *partial = nullptr, *scal = nullptr;
   int64_t ex_count = 0, ex_bytes = 0;  // halo exchanges / bytes sent by this rank since the last reset
@@ -585,8 +586,22 @@ int dist_smooth(amgh_dist* d, int l, const amgh_smoother_t& s, bool xzero, bool*
         if (!run) continue;
         if (!fresh) RC_TRY(halo_exchange(d, pl, L->x));
         fresh = false;
-        if (n > 0)
-          RC_TRY(csr_gs_sweep(&M->op, dir == 1, sor, s.omega, L->x, L->b, d->stream, true, true, 1, false, *b_kept));
+        if (!d->gs_exact || d->tr->nranks == 1) {
+          // processor-block hybrid: every shard sweeps at once, exact inside, the halo frozen for this directional sweep
+          if (n > 0)
+            RC_TRY(csr_gs_sweep(&M->op, dir == 1, sor, s.omega, L->x, L->b, d->stream, true, true, 1, false, *b_kept));
+        } else {
+          // exact lexicographic order across the shards (smoother.jl:61-90 on the whole level): the ranks sweep IN TURN —
+          // upward going forward, downward going backward — and every turn's boundary values travel before the next turn,
+          // so that a shard reads new values of everything before it in the sweep and old values of everything behind it
+          const int P = d->tr->nranks;
+          for (int turn = 0; turn < P; ++turn) {
+            const int q = dir == 0 ? turn : P - 1 - turn;
+            if (q == d->tr->rank && n > 0)
+              RC_TRY(csr_gs_sweep(&M->op, dir == 1, sor, s.omega, L->x, L->b, d->stream, true, true, 1, false, *b_kept));
+            if (turn + 1 < P) RC_TRY(halo_exchange(d, pl, L->x));
+          }
+        }
         *b_kept = true;
       }
     } else if (s.kind != AMGH_SMOOTH_NONE) {
@@ -807,6 +822,12 @@ int amgh_dist_create_ipc(amgh_dist_t** dp, int device, int rank, int nranks, con
   const int rc = tr->init(shm_name, rank, nranks, device < 0 ? -1 : device);
   if (rc != AMGH_OK) { delete tr; return rc; }
   return dist_new(dp, device < 0 ? -1 : device, tr);
+}
+
+int amgh_dist_set_gs_mode(amgh_dist_t* d, int exact) {
+  if (!d || exact < 0 || exact > 1) return AMGH_EINVAL;
+  d->gs_exact = exact != 0;
+  return AMGH_OK;
 }
 
 void amgh_dist_destroy(amgh_dist_t* d) {

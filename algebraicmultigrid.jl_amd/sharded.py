@@ -139,11 +139,12 @@ class ShardedHierarchy:
     transport : ("rccl", id_bytes), ("ipc", "/fresh_shm_name") or ("local", LocalGroup)
     device < 0 (IPC transport only): plans only — the collective setup in host memory, no GPU anywhere; the solve
     entry points are unavailable, `plan_info` is what such a handle is for.
+    gs_mode : "exact" (default) or "hybrid", see set_gs_mode
     dtype : float64 (default) or float32 = the Float32 instance of the library (the hierarchy's values are rounded
     once, every vector and every operation of the sharded cycle is Float32).
     """
 
-    def __init__(self, levels, n_tail, tail, rank, nranks, device, transport, dtype=np.float64):
+    def __init__(self, levels, n_tail, tail, rank, nranks, device, transport, dtype=np.float64, gs_mode="exact"):
         self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
         self.plans_only = self.device < 0
         self.dtype = np.dtype(np.float32 if np.dtype(dtype).itemsize == 4 else np.float64)
@@ -189,6 +190,7 @@ class ShardedHierarchy:
             self.tail = DeviceHierarchy(tail, self.device, 1, self.dtype)
             hip_check(self.lib.amgh_dist_set_tail(self.h, self.tail.h), "dist_set_tail")
         hip_check(self.lib.amgh_dist_finalize(self.h), "dist_finalize")
+        self.set_gs_mode(gs_mode)
         r0, r1 = C.c_int64(0), C.c_int64(0)
         hip_check(self.lib.amgh_dist_local_range(self.h, 0, C.byref(r0), C.byref(r1)), "dist_local_range")
         self.r0, self.r1 = r0.value, r1.value
@@ -198,7 +200,7 @@ class ShardedHierarchy:
             self._x = DeviceBuffer(max(self.nloc, 1), self.device, dtype=self.dtype)
 
     @classmethod
-    def from_multilevel(cls, ml, rank, nranks, device, transport, shard_min_rows=200_000, dtype=np.float64):
+    def from_multilevel(cls, ml, rank, nranks, device, transport, shard_min_rows=200_000, dtype=np.float64, gs_mode="exact"):
         """Every rank holds (or maps) the whole host hierarchy; only rank 0 needs the collapsed levels."""
         if not isinstance(ml, MultiLevel):
             raise AMGError("ml must be a MultiLevel")
@@ -208,7 +210,15 @@ class ShardedHierarchy:
         if rank == 0:
             tail = MultiLevel(ml.levels[lc:], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
                               ml.symmetry, method=ml.method)
-        return cls(level_arrays(ml, lc), sizes[lc], tail, rank, nranks, device, transport, dtype)
+        return cls(level_arrays(ml, lc), sizes[lc], tail, rank, nranks, device, transport, dtype, gs_mode)
+
+    def set_gs_mode(self, mode):
+        """Gauss-Seidel / SOR across the shards: "exact" (lexicographic order over the whole level: the ranks sweep in turn —
+        the reference's iterate) or "hybrid" (every shard at once, halo frozen per directional sweep).  The same on every rank."""
+        if mode not in ("exact", "hybrid"):
+            raise AMGError(f"gs_mode must be 'exact' or 'hybrid', not {mode!r}")
+        self.gs_mode = mode
+        hip_check(self.lib.amgh_dist_set_gs_mode(self.h, 1 if mode == "exact" else 0), "dist_set_gs_mode")
 
     def close(self):
         """Destroy the sharded handle first (it borrows the collapsed levels' handle), then the tail."""

@@ -348,6 +348,13 @@ int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail);
 /* Collective.  Exchanges the halo needs, builds the send / receive plans, uploads the local blocks
  * (columns renumbered to [local | halo]) and builds the smoother schedules of the shards.            */
 int amgh_dist_finalize(amgh_dist_t* d);
+/* Gauss-Seidel / SOR on the sharded levels (smoother.jl:61-90, :193-221; collective in effect: the same mode on every rank).
+ * exact = 1 (default): the whole level is swept in exact lexicographic order — the ranks sweep in turn (upward in a forward
+ * sweep, downward in a backward one) and every turn's boundary values travel before the next turn; the cycle is the
+ * reference's (1e-10) and a directional sweep costs the sum of the shards' sweeps plus nranks - 1 exchanges.
+ * exact = 0: the processor-block hybrid — every shard sweeps at once, exact inside, halo frozen per directional sweep:
+ * a different (convergent) iteration that scales with the ranks.  Jacobi is exact across shards in either mode.        */
+int amgh_dist_set_gs_mode(amgh_dist_t* d, int exact);
 int amgh_dist_num_sharded_levels(const amgh_dist_t* d);
 int amgh_dist_local_range(const amgh_dist_t* d, int level, int64_t* r0, int64_t* r1);
 /* ldiv! / _solve! on this rank's rows of the fine vectors (device pointers; collective).

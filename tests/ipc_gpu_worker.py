@@ -39,7 +39,7 @@ def main():
         transport, device = ("rccl", open(path, "rb").read()), rank
     else:
         transport, device = ("ipc", name), int(os.environ.get("AMG_IPC_DEVICE_OF_RANK", "0").split(",")[rank % len(os.environ.get("AMG_IPC_DEVICE_OF_RANK", "0").split(","))])
-    sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, device, transport, shard_min_rows)
+    sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, device, transport, shard_min_rows, gs_mode=os.environ.get("AMG_DIST_GS_MODE", "hybrid"))
     bl = b[sh.r0:sh.r1]
     out = {"r0": sh.r0, "r1": sh.r1, "lc": sh.lc}
     if case == "die":

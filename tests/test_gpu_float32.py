@@ -196,7 +196,7 @@ def test_row_sharded_cycle_in_float32():
     ml = AMG.ruge_stuben(A32, presmoother=jac, postsmoother=jac)
     for nranks in (2, 4):
         def work(rank, group):
-            sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, 0, ("local", group), 500, dtype=F32)
+            sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, 0, ("local", group), 500, dtype=F32, gs_mode="hybrid")
             x, hist = sh.solve(b[sh.r0:sh.r1], maxiter=4, calculate_residual=True, reltol=1e-30)
             z = sh.precond_apply(b[sh.r0:sh.r1])
             return x, hist, z, sh.lc
@@ -213,7 +213,7 @@ def test_row_sharded_cycle_in_float32():
     out = {}
     for dt in (F32, np.float64):
         def work(rank, group, dt=dt):
-            sh = SH.ShardedHierarchy.from_multilevel(ml_gs, rank, 2, 0, ("local", group), 500, dtype=dt)
+            sh = SH.ShardedHierarchy.from_multilevel(ml_gs, rank, 2, 0, ("local", group), 500, dtype=dt, gs_mode="hybrid")
             return sh.precond_apply(b[sh.r0:sh.r1].astype(dt))
         out[np.dtype(dt).name] = np.concatenate(SH.run_local_ranks(2, work, dtype=dt))
     assert out["float32"].dtype == F32 and rel(out["float32"], out["float64"]) <= F32_TOL

@@ -101,11 +101,11 @@ def test_c3_poisson_256cubed_rs_gauss_seidel_full_size(c3):
 
 
 # ---- C4: 256^3 row-sharded (virtual ranks on the one GPU of the box; the RCCL transport needs more GPUs) --------------
-def _sharded(ml, nranks, fn):
+def _sharded(ml, nranks, fn, gs_mode="hybrid"):
     from amg_amd import sharded as SH
 
     def work(rank, group):
-        sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, 0, ("local", group))
+        sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, 0, ("local", group), gs_mode=gs_mode)
         try:
             return fn(sh)
         finally:
@@ -169,6 +169,18 @@ def test_c4_256cubed_row_sharded_gauss_seidel_matches_the_frozen_halo_emulation_
         assert rel(x, want[k]) <= 1e-10, k
         xo, _, _ = oh.solve(b, maxiter=k + 1, calculate_residual=False)
         assert rel(x, xo) <= 5e-2            # hybrid vs exact sweep: same cycle up to the 3 interfaces per level
+
+
+def test_c4_256cubed_row_sharded_exact_gauss_seidel_is_the_oracle_cycle(c3):
+    """Config C4 with the library's default across shards — lexicographic Gauss-Seidel over the whole level, the ranks
+    sweeping in turn: one V-cycle of the default hierarchy on 2 and 4 shards IS the single-process oracle's cycle at the
+    north-star tolerance (/root/reference/src/smoother.jl:61-90, multilevel.jl:214-239)."""
+    A, ml = c3
+    b = uniform(A.m, 0)
+    want = O.OracleHierarchy(ml).precond(b)
+    for nranks in (2, 4):
+        res = _sharded(ml, nranks, lambda sh: sh.solve(b[sh.r0:sh.r1], maxiter=1, calculate_residual=False)[0], gs_mode="exact")
+        assert rel(np.concatenate(res), want) <= 1e-10, nranks
 
 
 def test_c4_two_processes_over_the_ipc_transport_full_size(c3):

@@ -22,16 +22,17 @@ def rel(x, y):
     return np.linalg.norm(np.asarray(x) - np.asarray(y)) / max(np.linalg.norm(y), 1e-300)
 
 
-def sharded_run(ml, nranks, shard_min_rows, fn):
-    """fn(sh) on every rank; returns the per-rank results."""
+def sharded_run(ml, nranks, shard_min_rows, fn, gs_mode="hybrid"):
+    """fn(sh) on every rank; returns the per-rank results.  gs_mode: "hybrid" (every shard sweeps at once, halo frozen per
+    directional sweep — what the emulations below restate) or "exact" (the library's default: the ranks sweep in turn)."""
     def work(rank, group):
-        sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, 0, ("local", group), shard_min_rows)
+        sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, 0, ("local", group), shard_min_rows, gs_mode=gs_mode)
         return fn(sh)
     return SH.run_local_ranks(nranks, work)
 
 
-def sharded_solve(ml, b, nranks, shard_min_rows, **kw):
-    res = sharded_run(ml, nranks, shard_min_rows, lambda sh: (*sh.solve(b[sh.r0:sh.r1], **kw), sh.lc, sh.stats()))
+def sharded_solve(ml, b, nranks, shard_min_rows, gs_mode="hybrid", **kw):
+    res = sharded_run(ml, nranks, shard_min_rows, lambda sh: (*sh.solve(b[sh.r0:sh.r1], **kw), sh.lc, sh.stats()), gs_mode)
     return np.concatenate([r[0] for r in res]), res[0][1], res[0][2], [r[3] for r in res]
 
 
@@ -51,15 +52,39 @@ def emulated_cycles(ml, b, nranks, shard_min_rows, cycles, cyc=0):
     return [np.concatenate([r[k] for r in res]) for k in range(cycles)]
 
 
-def sharded_cycles(ml, b, nranks, shard_min_rows, cycles, cyc=0):
+def sharded_cycles(ml, b, nranks, shard_min_rows, cycles, cyc=0, gs_mode="hybrid"):
     def fn(sh):
         out = []
         for k in range(1, cycles + 1):   # exactly k cycles from x0 = 0 (calculate_residual = False)
             x, _ = sh.solve(b[sh.r0:sh.r1], cycle=cyc, maxiter=k, calculate_residual=False)
             out.append(x)
         return out
-    res = sharded_run(ml, nranks, shard_min_rows, fn)
+    res = sharded_run(ml, nranks, shard_min_rows, fn, gs_mode)
     return [np.concatenate([r[k] for r in res]) for k in range(cycles)]
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+def test_exact_gauss_seidel_across_shards_is_the_oracle_cycle_for_cycle(nranks):
+    """The library's default on sharded levels: lexicographic Gauss-Seidel / SOR over the WHOLE level (smoother.jl:61-90,
+    :193-221) — the ranks sweep in turn, every turn's boundary values travel before the next — so every cycle's iterate is
+    the single-process oracle's at the north-star tolerance: symmetric, directional and repeated sweeps, SOR, V / W / F."""
+    A = AMG.poisson((40, 36, 48))
+    b = uniform(A.m, 6) - 0.3
+    cases = [(AMG.GaussSeidel(), AMG.GaussSeidel()),
+             (AMG.GaussSeidel(AMG.ForwardSweep(), iter=2), AMG.GaussSeidel(AMG.BackwardSweep())),
+             (AMG.SOR(1.2), AMG.SOR(0.9, AMG.ForwardSweep()))]
+    for pre, post in cases:
+        ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=post)
+        oh = O.OracleHierarchy(ml)
+        for cyc in ((0, 1, 2) if pre is cases[0][0] else (0,)):
+            got = sharded_cycles(ml, b, nranks, 4000, 2, cyc=cyc, gs_mode="exact")
+            for k in range(2):
+                xo, _, _ = oh.solve(b, cycle=cyc, maxiter=k + 1, calculate_residual=False)
+                assert rel(got[k], xo) <= 1e-10, (nranks, repr(pre), cyc, k)
+    ml = AMG.ruge_stuben(A)
+    x, hist, lc, stats = sharded_solve(ml, b, nranks, 4000, gs_mode="exact", reltol=1e-9, maxiter=60)
+    xo, ho, _ = O.OracleHierarchy(ml).solve(b, reltol=1e-9, maxiter=60)
+    assert lc >= 2 and len(hist) == len(ho) and np.allclose(hist, ho, rtol=1e-8) and rel(x, xo) <= 1e-10
 
 
 @pytest.mark.parametrize("nranks", [2, 4])
