@@ -1731,6 +1731,8 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_bw_chain")) g_gs_bw_chain = value;
   else if (!strcmp(name, "gs_bw_flow")) g_gs_bw_flow = value;
   else if (!strcmp(name, "gs_bw_spin")) g_gs_bw_spin = value;
+  else if (!strcmp(name, "gs_bw_nc")) g_gs_bw_nc = value;
+  else if (!strcmp(name, "gs_bw_nrhs")) g_gs_bw_nrhs = value;
   else if (!strcmp(name, "gs_bw_skip_pub")) g_gs_bw_skip_pub = value;
   else if (!strcmp(name, "gs_bw_min_rows")) g_gs_bw_min_rows = value;
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;

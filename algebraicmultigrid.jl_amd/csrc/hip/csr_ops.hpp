@@ -328,6 +328,16 @@ int gs_ensure_cols(amgh_csr* op, int ncolv, hipStream_t st) {
     RC_TRY(dev_alloc(&g->blk_s, g->n * ncolv));
     grown += 8 * g->n * (ncolv - g->cols_alloc);
   }
+  if (g->bw.flow.on && ncolv > g->bw.flow.mcols) {   // every column has its own mailboxes (epoch 0 is never a sweep's)
+    const size_t mb = (size_t)g->bw.flow.mail_stride * (size_t)ncolv;
+    (void)hipFree(g->bw.flow.mbox); g->bw.flow.mbox = nullptr;
+    if (hipMalloc(&g->bw.flow.mbox, mb) != hipSuccess) { (void)hipGetLastError(); g->bw.flow.mcols = 0; return AMGH_ENOMEM; }
+    if (hipMemset(g->bw.flow.mbox, 0, mb) != hipSuccess) return -1001;
+    const int64_t more = g->bw.flow.mail_stride * (int64_t)(ncolv - g->bw.flow.mcols);
+    g->bw.flow.bytes += more; g->bw.rec_bytes += more; g->slot_bytes += more;
+    grown += more;
+    g->bw.flow.mcols = ncolv;
+  }
   g->bytes += grown;
   op->bytes += grown;
   g->cols_alloc = ncolv;
@@ -504,13 +514,14 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
   if (g->bw.on) {   // wavefront of blocks
     hipError_t e = hipSuccess;
     const bool flow = g->bw.flow.on && (g_gs_bw_flow || !g->bw.rec);
-    if (flow) {   // as a dataflow: rows published as they are computed, blocks start on finished faces (one launch per column)
-      for (int c = 0; c < ncolv && e == hipSuccess; ++c) {
-        bw::FlowArgs<real> fa{g->bw.blocks, g->bw.flow.fd, g->bw.flow.srec, g->bw.flow.aux, g->bw.ext_col, g->bw.flow.fl_mb, g->bw.flow.fl_slot,
-                              g->bw.flow.mbox, rhs + (int64_t)c * ldb, xp + (int64_t)c * xs, omega, g->bw.head, g->bw.nblocks, (int32_t)g->bw.flow.nmail,
-                              g->bw.err, nullptr, (unsigned)g_gs_bw_spin, (int32_t)g_gs_bw_skip_pub};
-        e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st);
-      }
+    if (flow) {   // as a dataflow: rows published as they are computed, blocks start on finished faces; a block of right-hand
+                  // sides in launches of up to 8 columns (a walker / fetcher pair of waves per column in one workgroup)
+      bw::FlowArgs<real> fa{g->bw.blocks, g->bw.flow.fd, g->bw.flow.srec, g->bw.flow.aux, g->bw.ext_col, g->bw.flow.fl_mb, g->bw.flow.fl_slot,
+                            g->bw.flow.mbox, rhs, xp, omega, g->bw.head, g->bw.nblocks, (int32_t)g->bw.flow.nmail,
+                            g->bw.err, nullptr, (unsigned)g_gs_bw_spin, (int32_t)g_gs_bw_skip_pub};
+      fa.ldb = ldb; fa.ldx = xs; fa.mail_stride = g->bw.flow.mail_stride;
+      if (ncolv > g->bw.flow.mcols) return AMGH_ESTATE;   // (gs_ensure_cols sized the mailboxes)
+      e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);
     } else {
       bw::Args<real> ba{g->bw.blocks, g->bw.rec, g->bw.ext_col, rhs, xp, ldb, xs, omega, 0, nullptr};
       if (g_gs_bw_chain && ncolv == 1 && g->bw.flags) {   // one launch, blocks chained by flags

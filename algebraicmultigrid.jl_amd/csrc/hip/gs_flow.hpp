@@ -38,6 +38,9 @@ constexpr int32_t kPubMask = (1 << 30) - 1;
 #ifndef BW_FLOW_WAVES
 #define BW_FLOW_WAVES 4                 // waves per SIMD the kernel is compiled for (128 registers per lane: 8 blocks per CU)
 #endif
+#ifndef BW_FLOW_POLL_SLEEP_MC
+#define BW_FLOW_POLL_SLEEP_MC 4        // x 64 clocks between two polls of a fetcher whose window did not move, blocks of right-hand sides
+#endif
 #ifndef BW_FLOW_DEPTH
 #define BW_FLOW_DEPTH 4                 // steps whose operands are in flight ahead of the walk
 #endif
@@ -262,6 +265,11 @@ struct FlowArgs {
   long long* tim;                    // measurement hook: 4 stamps per block, then 128 step stamps per block, or null
   unsigned int spin_limit;           // polls before a wait gives up (0: the default)
   int32_t skip_pub;                  // test hook: the block of this ticket publishes nothing (a forced protocol error), -1: none
+  // blocks of right-hand sides (kernel template NC > 1: one walker / fetcher pair of waves per column in ONE workgroup, all
+  // pairs streaming the same record — the first one's loads bring it into the CU's cache): column c's b, x and mailboxes
+  // lie c * ldb, c * ldx entries and c * mail_stride bytes behind the first column's, its LDS x c * lds_stride bytes
+  int64_t ldb = 0, ldx = 0, mail_stride = 0;
+  int32_t lds_stride = 0;
 };
 
 template <typename R> struct Mail;
@@ -396,23 +404,32 @@ template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p) {
 template <int MAXK> struct FlowDepth { static constexpr int value = MAXK <= 6 ? BW_FLOW_DEPTH : MAXK <= 12 ? (BW_FLOW_DEPTH < 4 ? BW_FLOW_DEPTH : 4) : 3; };
 static_assert(BW_FLOW_DEPTH >= 2 && BW_FLOW_DEPTH <= 6, "the first round of the pipeline is written out for up to six sets");
 
-template <typename R, bool SOR, bool BWD, int MAXK>
-__global__ __launch_bounds__(kFlowThreads, (MAXK <= 6 ? BW_FLOW_WAVES : 2)) void gs_bw_flow_kernel(FlowArgs<R> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+template <typename R, bool SOR, bool BWD, int MAXK, int NC = 1>
+__global__ __launch_bounds__(kFlowThreads * NC, (MAXK <= 6 ? BW_FLOW_WAVES : 2)) void gs_bw_flow_kernel(FlowArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+  static_assert(2 * NC <= 4 * (MAXK <= 6 ? BW_FLOW_WAVES : 2), "the workgroup's waves must fit the registers the kernel is compiled for");
   typedef FlowOps<R, MAXK> O;
   typedef Mail<R> M;
   constexpr int D = FlowDepth<MAXK>::value;
   constexpr int RB = (int)sizeof(R);
-  const int tid = threadIdx.x;
+  // (NC > 1: pair c of waves — walker 2c, fetcher 2c + 1 — sweeps column c of the block of right-hand sides; the pairs share
+  // the ticket and the two barriers of the block's start, nothing else)
+  const int pair = NC > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
+  const int tid = NC > 1 ? (int)(threadIdx.x & 127u) : (int)threadIdx.x;
   const int lane = tid & 63;
+  unsigned char* lds = lds_all + (NC > 1 ? (size_t)pair * (size_t)a.lds_stride : 0);
+  if constexpr (NC > 1) {
+    a.b += (int64_t)pair * a.ldb; a.x += (int64_t)pair * a.ldx;
+    a.mbox = (void*)((unsigned char*)a.mbox + (int64_t)pair * a.mail_stride);
+  }
   const long long t_start = a.tim ? wall_clock64() : 0;
   // (the ticket travels through the first word of the dynamic LDS — no static LDS: the base stays 16-byte aligned)
-  unsigned long long* s_ticket = (unsigned long long*)lds;
+  unsigned long long* s_ticket = (unsigned long long*)lds_all;
   // (a launch starts with every resident workgroup at this line at once; one word takes ~88 atomics per microsecond, and the
   // first blocks' loads queue behind the burst — so the first workgroups stagger their draw, 12 ns apart: far less than the
   // time before their blocks can run.  A pure delay: tickets are still drawn by whoever comes)
   if (blockIdx.x < 2048u) for (unsigned i = 0; i < (blockIdx.x >> 5); ++i) __builtin_amdgcn_s_sleep(14);
-  if (tid == 0) *s_ticket = atomicAdd(a.head, 1ull);
+  if (threadIdx.x == 0) *s_ticket = atomicAdd(a.head, 1ull);
   __syncthreads();
   // (made wave-uniform by hand: everything derived from it — descriptors, step words, buffer offsets — then lives in scalar
   // registers; left to the compiler, a value read from LDS counts as divergent and every buffer access becomes a waterfall loop)
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(kFlowThreads, (MAXK <= 6 ? BW_FLOW_WAVES : 2)) void
         const bool moved = nfirst != first;
         first = nfirst;
         if (first == 64 * U) break;
-        if (!moved) __builtin_amdgcn_s_sleep(4);
+        if (!moved) __builtin_amdgcn_s_sleep(NC > 1 ? BW_FLOW_POLL_SLEEP_MC : 4);
         if (++total_spins > spin_limit) { fail = true; break; }
       }
     }
@@ -650,27 +667,67 @@ __global__ __launch_bounds__(kFlowThreads, (MAXK <= 6 ? BW_FLOW_WAVES : 2)) void
   for (int j = 0; j < D - 1; ++j)
     if (k + j < ns) { flow_wait<0>(ops[j]); step(ops[j], k + j); }
   if (gave_up && lane == 0) *a.err = 2;
-  if (a.tim && lane == 0) {
+  if (a.tim && lane == 0 && pair == 0) {
     long long* tt = a.tim + 4 * (int64_t)ob;
     tt[0] = t_start; tt[1] = t_loaded; tt[2] = wall_clock64(); tt[3] = 0;
   }
 }
 
+// columns one workgroup sweeps: bounded by the registers the kernel is compiled for (2 NC waves on 4 SIMDs) and by LDS
+template <int MAXK> struct FlowMaxNc { static constexpr int value = MAXK <= 6 ? 2 * BW_FLOW_WAVES : 4; };
+constexpr size_t kFlowLdsCap = 152 * 1024;
+
+template <typename R, bool SOR, bool BWD, int MAXK, int NC>
+inline hipError_t sweep_flow_launch(const FlowArgs<R>& a, size_t lds, hipStream_t st) {
+  if constexpr (NC > FlowMaxNc<MAXK>::value) return hipErrorInvalidValue;
+  else {
+    auto* fn = gs_bw_flow_kernel<R, SOR, BWD, MAXK, NC>;
+    if (lds > 64 * 1024) {   // (beyond the default limit: asked for once per kernel)
+      static hipError_t once = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlowLdsCap);
+      if (once != hipSuccess) return once;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)a.nblocks), dim3(kFlowThreads * NC), lds, st, a);
+    return hipGetLastError();
+  }
+}
+template <typename R, int MAXK, int NC>
+inline hipError_t sweep_flow_k(const FlowArgs<R>& a, size_t lds, bool sor, bool backward, hipStream_t st) {
+  if (sor) return backward ? sweep_flow_launch<R, true, true, MAXK, NC>(a, lds, st) : sweep_flow_launch<R, true, false, MAXK, NC>(a, lds, st);
+  return backward ? sweep_flow_launch<R, false, true, MAXK, NC>(a, lds, st) : sweep_flow_launch<R, false, false, MAXK, NC>(a, lds, st);
+}
+// ncols columns (a.ldb / a.ldx / a.mail_stride apart), at most nc_max per workgroup: launches of 8 / 4 / 2 / 1 columns
 template <typename R, int MAXK>
-inline hipError_t sweep_flow_k(const FlowArgs<R>& a, size_t lds_max, bool sor, bool backward, hipStream_t st) {
-  const dim3 grid((unsigned)a.nblocks);
-  if (lds_max > 64 * 1024) return hipErrorInvalidValue;
-  if (sor) { if (backward) hipLaunchKernelGGL((gs_bw_flow_kernel<R, true, true, MAXK>), grid, dim3(kFlowThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_flow_kernel<R, true, false, MAXK>), grid, dim3(kFlowThreads), lds_max, st, a); }
-  else { if (backward) hipLaunchKernelGGL((gs_bw_flow_kernel<R, false, true, MAXK>), grid, dim3(kFlowThreads), lds_max, st, a); else hipLaunchKernelGGL((gs_bw_flow_kernel<R, false, false, MAXK>), grid, dim3(kFlowThreads), lds_max, st, a); }
-  return hipGetLastError();
+inline hipError_t sweep_flow_cols(FlowArgs<R> a, size_t lds_max, bool sor, bool backward, int ncols, int nc_max, hipStream_t st) {
+  const size_t stride = (lds_max + 15) & ~(size_t)15;
+  if (stride > 64 * 1024) return hipErrorInvalidValue;
+  a.lds_stride = (int32_t)stride;
+  int cap = FlowMaxNc<MAXK>::value;
+  if (nc_max > 0 && nc_max < cap) cap = nc_max;
+  while (cap > 1 && (size_t)cap * stride > kFlowLdsCap) cap >>= 1;
+  for (int c = 0; c < ncols;) {
+    int nc = 1;
+    while (nc * 2 <= cap && c + nc * 2 <= ncols) nc *= 2;
+    hipError_t e;
+    switch (nc) {
+      case 8: e = sweep_flow_k<R, MAXK, 8>(a, stride * 8, sor, backward, st); break;
+      case 4: e = sweep_flow_k<R, MAXK, 4>(a, stride * 4, sor, backward, st); break;
+      case 2: e = sweep_flow_k<R, MAXK, 2>(a, stride * 2, sor, backward, st); break;
+      default: e = sweep_flow_k<R, MAXK, 1>(a, lds_max, sor, backward, st); break;
+    }
+    if (e != hipSuccess) return e;
+    a.b += (int64_t)nc * a.ldb; a.x += (int64_t)nc * a.ldx;
+    a.mbox = (void*)((unsigned char*)a.mbox + (int64_t)nc * a.mail_stride);
+    c += nc;
+  }
+  return hipSuccess;
 }
 template <typename R>
-inline hipError_t sweep_flow(const FlowArgs<R>& a, int maxk, size_t lds_max, bool sor, bool backward, hipStream_t st) {
+inline hipError_t sweep_flow(const FlowArgs<R>& a, int maxk, size_t lds_max, bool sor, bool backward, hipStream_t st, int ncols = 1, int nc_max = 0) {
   switch (maxk) {
-    case 6: return sweep_flow_k<R, 6>(a, lds_max, sor, backward, st);
-    case 12: return sweep_flow_k<R, 12>(a, lds_max, sor, backward, st);
+    case 6: return sweep_flow_cols<R, 6>(a, lds_max, sor, backward, ncols, nc_max, st);
+    case 12: return sweep_flow_cols<R, 12>(a, lds_max, sor, backward, ncols, nc_max, st);
 #if BW_PLAN_MAXK >= 18
-    case 18: return sweep_flow_k<R, 18>(a, lds_max, sor, backward, st);
+    case 18: return sweep_flow_cols<R, 18>(a, lds_max, sor, backward, ncols, nc_max, st);
 #endif
   }
   return hipErrorInvalidValue;

@@ -1003,7 +1003,7 @@ inline int bw_err_check() {
 // a launch per depth of the quotient DAG, one wave walking each block — no substitution, the scalar loop's arithmetic.
 // Sets g->bw (and everything the level-ordered cycle needs: perm, the permuted CSR copy, bp / xp) or leaves g untouched
 // when the operator is not eligible / the cost model says no.
-int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val, BuildTimer& tm) {
+int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val, BuildTimer& tm, int nrhs_hint = 1) {
   bw::Params prm;
   prm.target_rows = std::max(64, g_gs_bw_rows);
   // (few host threads: the plan is off the setup's critical path, which is a host thread of its own — the sequential C/F
@@ -1019,6 +1019,11 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
     return AMGH_OK;
   }
   tm.lap("block partition + records", n);
+  // the sweep as a dataflow (gs_flow.hpp) where the data dependencies carry the anti-dependencies: structurally symmetric
+  // patterns (halo columns of a row-sharded operator: never written, read as they stand).  Blocks of right-hand sides only
+  // have that execution (the chained kernel is a single-column one): other patterns keep the level schedules
+  const bool flow_ok = g_gs_bw_flow && bw::structurally_symmetric(n, rowptr, col, prm.threads);
+  if (nrhs_hint > 1 && !flow_ok) return AMGH_OK;
   const int64_t nnz = rowptr[n];
   const int nlaunch = (int)P.launch_ptr.size() - 1;
   if (g_gs_bw != 2) {
@@ -1062,8 +1067,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   RC_TRY(dev_alloc(&g->bw.head, 1));
   if (hipMemset(g->bw.head, 0, 8) != hipSuccess) return -1001;
   g->bw.nblocks = (int32_t)B;
-  // the sweep as a dataflow (gs_flow.hpp) where the data dependencies carry the anti-dependencies: structurally symmetric patterns
-  if (g_gs_bw_flow && bw::structurally_symmetric(n, rowptr, col, prm.threads)) {   // (halo columns of a row-sharded operator: never written, read as they stand)
+  if (flow_ok) {
     bw::Flow F;
     bool fok = false;
     // (the default footprint keeps the dataflow layout only: its records are made from the plan's where they lie)
@@ -1088,13 +1092,14 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
       const size_t mbytes = (size_t)(F.nmail + 1024) * bw::Mail<real>::kBytes;
       if (hipMalloc(&fl.mbox, mbytes) != hipSuccess) { (void)hipGetLastError(); return AMGH_ENOMEM; }
       if (hipMemset(fl.mbox, 0, mbytes) != hipSuccess) return -1001;   // (epoch 0 is never a sweep's)
-      fl.nmail = F.nmail; fl.lds_max = F.lds_max;
+      fl.nmail = F.nmail; fl.lds_max = F.lds_max; fl.mail_stride = (int64_t)mbytes; fl.mcols = 1;
       fl.bytes = (int64_t)F.fd.size() * (int64_t)sizeof(bw::FlowDesc) + (int64_t)P.rec.size() + (int64_t)F.aux.size() * 4 + (int64_t)F.fl_mb.size() * 6 + (int64_t)mbytes;
       fl.on = true;
       g->bytes += fl.bytes;
       tm.lap("dataflow upload", n);
     }
   }
+  if (nrhs_hint > 1 && !g->bw.flow.on) { g->free_dev(); return AMGH_OK; }   // (a limit of the dataflow layout: the level schedules)
   // the row-major records, the quotient graph and the flags of the launched / chained sweeps: all of it where the dataflow
   // layout is absent, and under the `full` footprint (run-time tunables then switch between the three executions)
   const bool keep_rec = !g->bw.flow.on || !gs_trim();
@@ -1130,8 +1135,9 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   return AMGH_OK;
 }
 
-// nrhs_hint: right-hand-side columns the sweeps of this schedule will carry (0 = unknown): the wavefront of blocks is a
-// single-column layout (its records would be re-read per column), chosen only for nrhs_hint == 1
+// nrhs_hint: right-hand-side columns the sweeps of this schedule will carry (0 = unknown: the level schedules, which serve
+// any block size at its best known cost); the wavefront of blocks is chosen for single columns and — as a dataflow, whose
+// workgroups carry up to 8 columns past one record stream — for blocks of right-hand sides
 int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr, const int32_t* col,
              const real* val, int nrhs_hint = 0) {
   const int64_t n = nrows;
@@ -1141,8 +1147,8 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   // 7.38 -> 7.22 ms per cycle, 96^3: 4.40 -> 4.52 —, 19-point rows from ~3 M — the 2.0 M-row second level of 160^3: 9.95 -> 10.51 ms)
   bool bw_size_ok = n >= g_gs_bw_min_rows;
   if (!bw_size_ok && n >= g_gs_bw_min_rows / 2 && n > 0 && rowptr[n] <= 7 * n) bw_size_ok = true;
-  if (g_gs_bw > 0 && nrhs_hint == 1 && n > 0 && (g_gs_bw == 2 || bw_size_ok)) {
-    const int rcb = bw_build(g, n, ncols, rowptr, col, val, tm);
+  if (g_gs_bw > 0 && (nrhs_hint == 1 || (nrhs_hint > 1 && g_gs_bw_nrhs)) && n > 0 && (g_gs_bw == 2 || bw_size_ok)) {
+    const int rcb = bw_build(g, n, ncols, rowptr, col, val, tm, nrhs_hint);
     if (rcb != AMGH_OK) return rcb;
     if (g->bw.on) return AMGH_OK;
   }

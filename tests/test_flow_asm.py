@@ -1,6 +1,7 @@
 """The dataflow sweep kernel (csrc/hip/gs_flow.hpp) counts its memory pipeline by hand: loads are inline asm whose
 destination registers the compiler allocates but does not track, waited for by `s_waitcnt vmcnt((D - 1)(L + 2))`.  This
-test compiles all 24 instantiations (double / float x GS / SOR x forward / backward x rows of 6 / 12 / 18 entries) to gfx950
+test compiles all 80 instantiations (double / float x GS / SOR x forward / backward x rows of 6 / 12 / 18 entries x
+1 / 2 / 4 [/ 8] right-hand-side columns per workgroup) to gfx950
 assembly (hipcc cross-compiles without a GPU) and audits the steady loop of each (tools/flow_asm_audit.py): no instruction
 touches a register set between its loads and its wait, the loop holds the hand-written waits and no compiler-inserted
 one, every load carries a scalar offset, no waterfall.  A compiler update that changes any of this fails here, not as a
@@ -20,4 +21,4 @@ def test_flow_kernel_pipeline_survives_the_compiler():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "flow_asm_audit.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     lines = [l for l in out.splitlines() if l.startswith(("ok", "FAIL"))]
-    assert r.returncode == 0 and len(lines) == 24 and all(l.startswith("ok") for l in lines), out
+    assert r.returncode == 0 and len(lines) == 80 and all(l.startswith("ok") for l in lines), out

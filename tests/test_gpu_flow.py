@@ -25,7 +25,8 @@ def rel(x, y):
 
 class tunables:
     """amgh_debug_set_tunable for the duration of a with block (values restored to the given defaults)."""
-    DEFAULTS = {"gs_bw": 1, "gs_bw_rows": 512, "gs_bw_chain": 1, "gs_bw_flow": 1, "gs_lean": -1, "gs_bw_spin": 0, "gs_bw_skip_pub": -1}
+    DEFAULTS = {"gs_bw": 1, "gs_bw_rows": 512, "gs_bw_chain": 1, "gs_bw_flow": 1, "gs_lean": -1, "gs_bw_spin": 0, "gs_bw_skip_pub": -1,
+                "gs_lpr": 0, "gs_ept": 0, "gs_bw_nc": 0, "gs_bw_nrhs": 1}
 
     def __init__(self, lib, **kw):
         self.lib, self.kw = lib, kw
@@ -155,6 +156,45 @@ def test_a_forced_protocol_error_is_an_error_code_not_numbers():
             dev.pcg(b, maxiter=2)
     assert np.array_equal(dev.precond_apply(b), z_ref)
     assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+
+
+@pytest.mark.parametrize("case,bs", [("poisson", 8), ("poisson", 3), ("poisson", 5), ("galerkin", 4), ("galerkin", 7), ("galerkin", 2)])
+def test_blocks_of_right_hand_sides_on_the_dataflow_layout_equal_the_single_columns_bit_for_bit(case, bs):
+    """bs > 1 (`MultiLevelWorkspace{TX,bs}`, /root/reference/src/multilevel.jl:28-59; the reference loops the columns inside
+    gs!, smoother.jl:77): a workgroup of the dataflow sweep carries up to 8 columns — one walker / fetcher pair of waves,
+    one LDS x and one set of mailboxes per column, all pairs streaming the same records (launches of 8 / 4 / 2 / 1 columns
+    for odd block sizes).  Per column the arithmetic is the single-column kernel's: the block's cycle equals the cycles of
+    its columns bit for bit (7-point rows: 8 columns per workgroup; 19-point-like Galerkin rows: 4), with every cap on the
+    columns per workgroup, and the oracle's at 1e-10."""
+    lib = AMG.hip_lib()
+    if case == "poisson":
+        A = AMG.poisson((32, 28, 24))
+    else:
+        A = AMG.ruge_stuben(AMG.poisson((40, 40, 40)), max_levels=3).levels[1].A
+    ml = AMG.ruge_stuben(A)
+    n = A.m
+    B = np.stack([uniform(n, 60 + c) - 0.2 * c for c in range(bs)], axis=1)
+    # (single columns sum the long rows of merged slot launches with several lanes per row — another order of additions:
+    #  one thread per row on both sides, as in test_gpu_parity's block tests)
+    with tunables(lib, gs_bw=2, gs_bw_rows=128, gs_lpr=1, gs_ept=1):
+        dev1 = DeviceHierarchy(ml, 0, 1)
+        devb = DeviceHierarchy(ml, 0, bs)
+        assert lib.amgh_debug_bw_mode(devb.h, 0) == 3 and lib.amgh_debug_bw_mode(dev1.h, 0) == 3
+        Z = devb.precond_apply(B)
+        for nc in (1, 2, 4):
+            with tunables(lib, gs_bw_nc=nc):
+                assert np.array_equal(devb.precond_apply(B), Z), nc
+        X, _, its = devb.solve(B, np.zeros_like(B), 0, 3, 0.0, 0.0, False, False)
+        singles = [dev1.precond_apply(B[:, c].copy()) for c in range(bs)]
+        x0 = dev1.solve(B[:, 0].copy(), np.zeros(n), 0, 3, 0.0, 0.0, False, False)[0]
+        assert lib.amgh_debug_bw_poll_giveups(devb.h, 0) == 0
+        with tunables(lib, gs_bw_nrhs=0):                  # the switch: blocks of right-hand sides on the level schedules
+            assert lib.amgh_debug_bw_mode(DeviceHierarchy(ml, 0, bs).h, 0) == 0
+    oh = O.OracleHierarchy(ml)
+    for c in range(bs):
+        assert np.array_equal(Z[:, c], singles[c]), (c, rel(Z[:, c], singles[c]))
+    assert np.array_equal(X[:, 0], x0)
+    assert rel(Z[:, bs - 1], oh.precond(B[:, bs - 1])) <= 1e-10
 
 
 @pytest.fixture(scope="module")

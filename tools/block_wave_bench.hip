@@ -282,6 +282,58 @@ int main(int argc, char** argv) {
           printf("  depth %3d: %4d blocks, first start %8.1f us, first walk %8.1f us, last end %8.1f us, mean walk %6.2f us\n", l, nbk, (ts - tmin) * 0.01, (tw - tmin) * 0.01, (te - tmin) * 0.01, w / nbk);
         }
       }
+      // ---- blocks of right-hand sides: up to 8 columns per workgroup (one walker / fetcher pair of waves per column, one
+      // record stream); every column carries the same b and x here, so each must come out as the single-column sweep ----
+      if (const char* ec = getenv("BW_COLS")) {
+        const int cols = std::max(1, atoi(ec));
+        double *d_xm, *d_bm; void* d_mm;
+        const size_t mstride = 16 * (size_t)(F.nmail + 1024);
+        CHECK(hipMalloc(&d_xm, 8 * (size_t)n * cols)); CHECK(hipMalloc(&d_bm, 8 * (size_t)n * cols)); CHECK(hipMalloc(&d_mm, mstride * cols));
+        CHECK(hipMemset(d_mm, 0, mstride * cols));
+        for (int c = 0; c < cols; ++c) CHECK(hipMemcpy(d_bm + (size_t)n * c, d_b, 8 * n, hipMemcpyDeviceToDevice));
+        bw::FlowArgs<double> fm = fa;
+        fm.tim = nullptr; fm.b = d_bm; fm.x = d_xm; fm.mbox = d_mm; fm.ldb = n; fm.ldx = n; fm.mail_stride = (int64_t)mstride;
+        std::vector<double> xm((size_t)n * cols);
+        printf("== blocks of %d right-hand sides on the dataflow layout (algorithmic bytes per sweep: records %.2f GB + %d x %.2f GB of b, x, mail)\n", cols,
+               F.srec.size() / 1e9, cols, (n * 28.0 + P.ext_total * 22.0) / 1e9);
+        for (int cap : {1, 2, 4, 8}) {
+          if (cap > cols) break;
+          for (int c = 0; c < cols; ++c) CHECK(hipMemcpy(d_xm + (size_t)n * c, xb.data(), 8 * n, hipMemcpyHostToDevice));
+          CHECK(bw::sweep_flow<double>(fm, mk, F.lds_max, false, false, st, cols, cap));
+          CHECK(bw::sweep_flow<double>(fm, mk, F.lds_max, false, true, st, cols, cap));
+          CHECK(hipStreamSynchronize(st));
+          CHECK(hipMemcpy(xm.data(), d_xm, 8 * (size_t)n * cols, hipMemcpyDeviceToHost));
+          int64_t dd = 0;
+          for (int c = 0; c < cols; ++c) for (int64_t p = 0; p < n; ++p) dd += xm[(size_t)n * c + p] != xg[p];
+          CHECK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+          float msd[2];
+          for (int bwd = 0; bwd < 2; ++bwd) {
+            const int reps = 5;
+            CHECK(hipEventRecord(e0, st));
+            for (int r = 0; r < reps; ++r) CHECK(bw::sweep_flow<double>(fm, mk, F.lds_max, false, bwd, st, cols, cap));
+            CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&msd[bwd], e0, e1)); msd[bwd] /= reps;
+          }
+          printf("columns per workgroup <= %d: forward %.3f ms, backward %.3f ms (%.3f / %.3f per column); %lld values differ from the single-column sweeps, give-ups %d\n",
+                 cap, msd[0], msd[1], msd[0] / cols, msd[1] / cols, (long long)dd, err);
+        }
+        // stamps of the widest launch (first column's pair)
+        fm.tim = d_tim;
+        CHECK(bw::sweep_flow<double>(fm, mk, F.lds_max, false, false, st, cols, 0)); CHECK(hipStreamSynchronize(st));
+        std::vector<long long> tim(4 * (size_t)B);
+        CHECK(hipMemcpy(tim.data(), d_tim, 32 * (size_t)B, hipMemcpyDeviceToHost));
+        long long tmin = tim[0], tmax = 0; double ld = 0, wk = 0;
+        for (int32_t bq = 0; bq < B; ++bq) { const long long* t = &tim[4 * (size_t)bq]; tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[2]); ld += (t[1] - t[0]) * 0.01; wk += (t[2] - t[1]) * 0.01; }
+        printf("forward sweep of the first launch's columns, stamps: first start -> last end %.1f us; mean per block: ticket + load %.2f, walk %.2f us\n", (tmax - tmin) * 0.01, ld / B, wk / B);
+        for (int l = 0; l < nl; l += std::max(1, nl / 12)) {
+          long long te = 0, ts = -1; double w = 0; const int nbk = P.launch_ptr[l + 1] - P.launch_ptr[l];
+          for (int bq = P.launch_ptr[l]; bq < P.launch_ptr[l + 1]; ++bq) {
+            te = std::max(te, tim[4 * (size_t)bq + 2]); if (ts < 0 || tim[4 * (size_t)bq] < ts) ts = tim[4 * (size_t)bq];
+            w += (tim[4 * (size_t)bq + 2] - tim[4 * (size_t)bq + 1]) * 0.01;
+          }
+          printf("  depth %3d: %4d blocks, first start %8.1f us, last end %8.1f us, mean walk %6.2f us\n", l, nbk, (ts - tmin) * 0.01, (te - tmin) * 0.01, w / nbk);
+        }
+      }
     }
   }
   return 0;

@@ -9,7 +9,8 @@ checks, for every instantiation it finds:
   2. the steady-state loop holds exactly the hand-written waits: D of them, all vmcnt((D-1)(L+2)), and no other vmcnt wait
      (a compiler-inserted one would mean it tracks a load of its own inside the pipeline);
   3. every asm buffer load of the loop carries an SGPR offset and the loop has no waterfall (v_readfirstlane) — the
-     descriptors stayed wave-uniform.
+     descriptors stayed wave-uniform;
+  4. the kernel does not spill (scratch accesses are memory operations the hand-written counts do not know).
 usage: python tools/flow_asm_audit.py [source.hip]     exit code 0 = clean; prints one line per kernel."""
 import os
 import re
@@ -127,6 +128,8 @@ def main():
             print(r.stdout.decode(errors="replace")[-2000:])
             return 2
         text = open(out).read().split("\n")
+    # no kernel may spill: scratch accesses are memory operations the hand-written counts do not know
+    scratch = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.amdhsa_kernel (\S+).*?\.amdhsa_private_segment_fixed_size (\d+)", "\n".join(text), re.S)}
     kernels = {}
     cur = None
     for l in text:
@@ -144,6 +147,8 @@ def main():
     rc = 0
     for name, lines in sorted(kernels.items()):
         ok, msg = audit_kernel(name, lines)
+        if scratch.get(name, 0) != 0 or any("scratch_" in l for l in lines):
+            ok, msg = False, f"spills ({scratch.get(name, 0)} bytes of scratch): uncounted memory operations; " + msg
         short = re.sub(r"^_ZN4amgh2bw17gs_bw_flow_kernelI", "", name)[:24]
         print(f"{'ok  ' if ok else 'FAIL'} {short:24s} {msg}")
         rc |= 0 if ok else 1

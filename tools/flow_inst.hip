@@ -2,6 +2,6 @@
 // compiles to assembly (tests/test_flow_asm.py).
 #include "../algebraicmultigrid.jl_amd/csrc/hip/gs_flow.hpp"
 namespace amgh { namespace bw {
-template hipError_t sweep_flow<double>(const FlowArgs<double>&, int, size_t, bool, bool, hipStream_t);
-template hipError_t sweep_flow<float>(const FlowArgs<float>&, int, size_t, bool, bool, hipStream_t);
+template hipError_t sweep_flow<double>(const FlowArgs<double>&, int, size_t, bool, bool, hipStream_t, int, int);
+template hipError_t sweep_flow<float>(const FlowArgs<float>&, int, size_t, bool, bool, hipStream_t, int, int);
 } }

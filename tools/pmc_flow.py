@@ -2,7 +2,7 @@
 """HBM-side counters of the fine-level Gauss-Seidel sweep kernels of tools/block_wave_bench (launched per depth, chained by
 flags, dataflow): one `rocprofv3 --kernel-trace --pmc <counter>` pass per counter (counters + kernel trace only).
 FETCH_SIZE is doubled on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM); request counters are printed raw."""
-import csv, glob, os, shutil, subprocess, sys, tempfile
+import csv, glob, os, re, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:] or ["poisson", "256"]
 binary = os.environ.get("BW_BENCH", os.path.join(ROOT, "tools", "block_wave_bench"))
@@ -13,7 +13,7 @@ def one(counter):
     tmp = tempfile.mkdtemp(prefix="amgh_pmc_", dir="/tmp")
     try:
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", binary] + args
-        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
         if r.returncode != 0:
             return None, r.stdout.decode(errors="replace")[-300:]
         tot, cnt = {}, {}
@@ -23,6 +23,9 @@ def one(counter):
                 name = row.get("Kernel_Name", "")
                 for sub, key in kinds.items():
                     if sub in name:
+                        if key == "dataflow":    # (the last template argument: right-hand-side columns per workgroup)
+                            m = re.search(r"(\d+)>", name)
+                            if m and int(m.group(1)) > 1 and name.count(",") >= 4: key = f"dataflow x{m.group(1)}"
                         tot[key] = tot.get(key, 0.0) + float(row["Counter_Value"]); cnt[key] = cnt.get(key, 0) + 1
         return tot, cnt
     finally:
@@ -34,10 +37,11 @@ for c in counters:
     if tot is None:
         print(f"{c}: failed: {cnt}"); continue
     line = []
-    for key in ("per depth", "chained", "dataflow"):
+    for key in ("per depth", "chained", "dataflow", "dataflow x2", "dataflow x4", "dataflow x8"):
         if key not in tot: continue
         per = tot[key] / cnt[key] * (94 if key == "per depth" and args[:2] == ["poisson", "256"] else 1)
         if c == "FETCH_SIZE": line.append(f"{key}: {per * 1024 * 2 / 1e9:.3f} GB (x2 applied)")
         elif c == "WRITE_SIZE": line.append(f"{key}: {per * 1024 / 1e9:.3f} GB")
+        elif per < 1e4: line.append(f"{key}: {per:.2f}")
         else: line.append(f"{key}: {per / 1e6:.3f} M")
     print(f"{c:>24}: " + " | ".join(line), flush=True)
