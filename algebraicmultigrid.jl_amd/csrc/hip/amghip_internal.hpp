@@ -388,7 +388,7 @@ int g_gs_bw_rows = 512;         // ... rows per block aimed at
 int g_gs_bw_flow = 1;           // the wavefront of blocks as a dataflow (gs_flow.hpp) where the pattern is structurally symmetric: 1 = on, 0 = off (chained / launched sweeps); build: the layout is only built when on; read at every sweep too
 int g_gs_bw_spin = 0;           // polls before a wait of the dataflow / chained sweep gives up (0 = the default, ~seconds); test hook
 int g_gs_bw_skip_pub = -1;      // test hook: the block with this ticket publishes nothing in dataflow sweeps (a forced protocol error); -1 = none
-int g_gs_bw_nc = 0;             // columns of a block of right-hand sides one workgroup of the dataflow sweep carries (0 = as many as registers and LDS allow: 8 / 4); read at every sweep
+int g_gs_bw_nc = 2;             // columns of a block of right-hand sides one workgroup of the dataflow sweep carries (walker waves beside its one fetcher; 0 = as many as are instantiated: 4 for rows of <= 6 entries, else 3); 256^3, bs = 8, smoothers of the two block-ordered levels: 1: 16.3 + 10.0, 2: 12.0 + 10.1, 3: 12.0 + 10.4, 4: 13.0 + 10.4 ms; read at every sweep
 int g_gs_bw_nrhs = 1;           // hierarchies built for blocks of right-hand sides get the dataflow layout too (0 = single-column hierarchies only); read at schedule build
 int g_gs_bw_chain = 1;          // the wavefront of blocks as one launch per sweep, blocks chained by flags (0: one launch per depth of the quotient graph)
 int g_gs_bw_min_rows = 3000000; // ... operators below this many rows keep the level schedules in mode 1 (half as many for rows of at most 7 entries: tools/bw_threshold.py, profiles/r03_bw_threshold.log)

@@ -517,7 +517,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
     if (flow) {   // as a dataflow: rows published as they are computed, blocks start on finished faces; a block of right-hand
                   // sides in launches of up to 8 columns (a walker / fetcher pair of waves per column in one workgroup)
       bw::FlowArgs<real> fa{g->bw.blocks, g->bw.flow.fd, g->bw.flow.srec, g->bw.flow.aux, g->bw.ext_col, g->bw.flow.fl_mb, g->bw.flow.fl_slot,
-                            g->bw.flow.mbox, rhs, xp, omega, g->bw.head, g->bw.nblocks, (int32_t)g->bw.flow.nmail,
+                            g->bw.flow.mbox, rhs, xp, omega, g->bw.head + 1, g->bw.nblocks, (int32_t)g->bw.flow.nmail,
                             g->bw.err, nullptr, (unsigned)g_gs_bw_spin, (int32_t)g_gs_bw_skip_pub};
       fa.ldb = ldb; fa.ldx = xs; fa.mail_stride = g->bw.flow.mail_stride;
       if (ncolv > g->bw.flow.mcols) return AMGH_ESTATE;   // (gs_ensure_cols sized the mailboxes)

@@ -31,15 +31,11 @@
 namespace amgh {
 namespace bw {
 
-constexpr int kFlowThreads = 128;       // wave 0 walks, wave 1 fetches
 constexpr int32_t kPubFwd = 1 << 30;    // pub word: forward mailbox | backward mailbox << 11 (relative to the block's first) | directions in which the row is published
 constexpr int32_t kPubBwd = (int32_t)(1u << 31);
 constexpr int32_t kPubMask = (1 << 30) - 1;
 #ifndef BW_FLOW_WAVES
 #define BW_FLOW_WAVES 4                 // waves per SIMD the kernel is compiled for (128 registers per lane: 8 blocks per CU)
-#endif
-#ifndef BW_FLOW_POLL_SLEEP_MC
-#define BW_FLOW_POLL_SLEEP_MC 4        // x 64 clocks between two polls of a fetcher whose window did not move, blocks of right-hand sides
 #endif
 #ifndef BW_FLOW_DEPTH
 #define BW_FLOW_DEPTH 4                 // steps whose operands are in flight ahead of the walk
@@ -258,18 +254,20 @@ struct FlowArgs {
   const int32_t* ext_col; const int32_t* fl_mb; const uint16_t* fl_slot;
   void* mbox;                        // 16 bytes per mailbox (double: {lo, epoch, hi, epoch}); 8 (float: {value, epoch})
   const R* b; R* x; R omega;
-  unsigned long long* head;          // ticket counter (never reset): epoch = ticket / nblocks + 1
+  unsigned long long* head;          // {sweeps so far << 32 | tickets drawn in the running one}: epoch = sweeps + 1
   int32_t nblocks;
   int32_t nmail;                     // mailboxes (1024 spare cells behind them)
   int32_t* err;
   long long* tim;                    // measurement hook: 4 stamps per block, then 128 step stamps per block, or null
   unsigned int spin_limit;           // polls before a wait gives up (0: the default)
   int32_t skip_pub;                  // test hook: the block of this ticket publishes nothing (a forced protocol error), -1: none
-  // blocks of right-hand sides (kernel template NC > 1: one walker / fetcher pair of waves per column in ONE workgroup, all
-  // pairs streaming the same record — the first one's loads bring it into the CU's cache): column c's b, x and mailboxes
-  // lie c * ldb, c * ldx entries and c * mail_stride bytes behind the first column's, its LDS x c * lds_stride bytes
+  // blocks of right-hand sides (kernel template NC > 1: a workgroup sweeps one block for a GROUP of up to NC columns — one
+  // walker wave per column, one fetcher wave for all of them, every walker streaming the same record): column c's b, x and
+  // mailboxes lie c * ldb, c * ldx entries and c * mail_stride bytes behind the first column's; inside the workgroup its
+  // LDS x lies (c - first column of the group) * lds_stride bytes behind the first one's
   int64_t ldb = 0, ldx = 0, mail_stride = 0;
   int32_t lds_stride = 0;
+  int32_t ncols = 1, ngroups = 1;    // columns of the launch, groups of <= NC columns they are swept in (grid = blocks x groups)
 };
 
 template <typename R> struct Mail;
@@ -401,27 +399,28 @@ template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p) {
   const unsigned long long u = (unsigned long long)p;
   return (T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)u));
 }
-template <int MAXK> struct FlowDepth { static constexpr int value = MAXK <= 6 ? BW_FLOW_DEPTH : MAXK <= 12 ? (BW_FLOW_DEPTH < 4 ? BW_FLOW_DEPTH : 4) : 3; };
+// (blocks of right-hand sides: the fetcher's column arrays share the 128 registers of the short-row kernels — one set less)
+template <int MAXK, int NC = 1> struct FlowDepth {
+  static constexpr int value = MAXK <= 6 ? (NC > 1 && BW_FLOW_DEPTH > 3 ? 3 : BW_FLOW_DEPTH) : MAXK <= 12 ? (BW_FLOW_DEPTH < 4 ? BW_FLOW_DEPTH : 4) : 3;
+};
 static_assert(BW_FLOW_DEPTH >= 2 && BW_FLOW_DEPTH <= 6, "the first round of the pipeline is written out for up to six sets");
 
+template <int MAXK> struct FlowWaves { static constexpr int value = MAXK <= 6 ? BW_FLOW_WAVES : 2; };   // waves per SIMD the kernel is compiled for
+
+// One workgroup = one block of the partition x one group of up to NC right-hand-side columns: waves 0 .. NC - 1 WALK the block,
+// one column each (own LDS x, own mailboxes, all of them streaming the same record: the first wave's loads bring it into the
+// CU's cache), wave NC FETCHES for all of them.  NC = 1 is the single-column sweep.
 template <typename R, bool SOR, bool BWD, int MAXK, int NC = 1>
-__global__ __launch_bounds__(kFlowThreads * NC, (MAXK <= 6 ? BW_FLOW_WAVES : 2)) void gs_bw_flow_kernel(FlowArgs<R> a) {
+__global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_flow_kernel(FlowArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
-  static_assert(2 * NC <= 4 * (MAXK <= 6 ? BW_FLOW_WAVES : 2), "the workgroup's waves must fit the registers the kernel is compiled for");
+  static_assert(NC >= 1 && NC + 1 <= 4 * FlowWaves<MAXK>::value, "the workgroup's waves must fit the registers the kernel is compiled for");
   typedef FlowOps<R, MAXK> O;
   typedef Mail<R> M;
-  constexpr int D = FlowDepth<MAXK>::value;
+  constexpr int D = FlowDepth<MAXK, NC>::value;
   constexpr int RB = (int)sizeof(R);
-  // (NC > 1: pair c of waves — walker 2c, fetcher 2c + 1 — sweeps column c of the block of right-hand sides; the pairs share
-  // the ticket and the two barriers of the block's start, nothing else)
-  const int pair = NC > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
-  const int tid = NC > 1 ? (int)(threadIdx.x & 127u) : (int)threadIdx.x;
-  const int lane = tid & 63;
-  unsigned char* lds = lds_all + (NC > 1 ? (size_t)pair * (size_t)a.lds_stride : 0);
-  if constexpr (NC > 1) {
-    a.b += (int64_t)pair * a.ldb; a.x += (int64_t)pair * a.ldx;
-    a.mbox = (void*)((unsigned char*)a.mbox + (int64_t)pair * a.mail_stride);
-  }
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63u);
+  const bool fetcher = wv == NC;
   const long long t_start = a.tim ? wall_clock64() : 0;
   // (the ticket travels through the first word of the dynamic LDS — no static LDS: the base stays 16-byte aligned)
   unsigned long long* s_ticket = (unsigned long long*)lds_all;
@@ -435,19 +434,77 @@ __global__ __launch_bounds__(kFlowThreads * NC, (MAXK <= 6 ? BW_FLOW_WAVES : 2))
   // registers; left to the compiler, a value read from LDS counts as divergent and every buffer access becomes a waterfall loop)
   const unsigned long long tv = *s_ticket;
   const unsigned long long ticket = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
-  __syncthreads();   // (the word is x[0] from here on)
-  const unsigned int epoch = (unsigned int)(ticket / (unsigned long long)a.nblocks) + 1u;
-  const int tk = (int)(ticket % (unsigned long long)a.nblocks);
+  __syncthreads();   // (the word is x[0] of the first column from here on)
+  // tickets run over (block, column group), the groups of a block side by side: a unit only ever waits for units of its own
+  // group with smaller tickets.  The word holds {sweeps so far, units drawn}; whoever draws the launch's last ticket starts
+  // the next sweep's count (every other draw of this launch has happened by then; launches of different shapes may follow
+  // each other on the same word)
+  const unsigned int units = (unsigned int)a.nblocks * (unsigned int)a.ngroups;
+  const unsigned int ut = (unsigned int)ticket, sweeps = (unsigned int)(ticket >> 32);
+  const unsigned int epoch = sweeps + 1u;
+  if (threadIdx.x == 0 && ut == units - 1u)
+    __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u == 0u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int tk = (int)(ut / (unsigned)a.ngroups);
+  const int c0 = (int)(ut % (unsigned)a.ngroups) * NC;
+  const int nch = a.ncols - c0 < NC ? a.ncols - c0 : NC;   // columns of this group
   const int ob = __builtin_amdgcn_readfirstlane(BWD ? a.nblocks - 1 - tk : tk);
   const Desc d = a.blocks[ob];
   const FlowDesc f = a.fd[ob];
   const int ns = d.nlev;
   const int nxb = (int)(((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15);
+  const unsigned spin_limit = a.spin_limit ? a.spin_limit : (1u << 22);
+  // column c of the group: b, x, mailboxes and LDS x
+  auto col_x = [&](int c) { return a.x + (int64_t)(c0 + c) * a.ldx; };
+  auto col_mail = [&](int c) { return (void*)((unsigned char*)a.mbox + (int64_t)(c0 + c) * a.mail_stride); };
+  auto col_lds = [&](int c) { return lds_all + (size_t)c * (size_t)a.lds_stride; };
+  if (fetcher) {
+    // ---- load phase, the fetcher's half (the walkers bring their own rows, below): for every column of the group the
+    // external columns of the far side as they stand (the columns the sweep has not reached — behind the block going
+    // forward, before it going backward — and halo columns; the near side arrives through the mailboxes).  The positions
+    // are the same for every column: read once, then the gathers of all columns of a batch in flight at once ----
+    constexpr int EU = 4;
+    const R* xc[NC]; R* xlc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { xc[c] = uniform_ptr(col_x(c < nch ? c : 0)); xlc[c] = (R*)col_lds(c); }
+    const int nfar = BWD ? d.npre + (d.next - d.npre - f.npost) : d.next - d.npre;
+    for (int e0 = 0; e0 < nfar; e0 += 64 * EU) {
+      int32_t ec[EU]; int es[EU];
+#pragma unroll
+      for (int k = 0; k < EU; ++k) {
+        const int i = e0 + lane + 64 * k;
+        es[k] = BWD ? (i < d.npre ? i : i + f.npost) : d.npre + i;   // slot in the external list
+        ec[k] = a.ext_col[i < nfar ? d.ext0 + es[k] : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < EU; ++k) pin(ec[k]);
+      R xe[NC][EU];
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int k = 0; k < EU; ++k) xe[c][k] = xc[c][ec[k]];
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int k = 0; k < EU; ++k) pin(xe[c][k]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int k = 0; k < EU; ++k) { const int i = e0 + lane + 64 * k; if (i < nfar && c < nch) xlc[c][d.nrows + es[k]] = xe[c][k]; }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) if (c < nch) { xlc[c][d.nrows + d.next] = (R)0; *(unsigned int*)(col_lds(c) + nxb) = 0u; }
+    }
+  }
+  // (walkers of columns the group does not have leave behind the block's barrier)
+  const bool walker = !fetcher && wv < nch;
+  const int wc = walker ? wv : 0;
+  unsigned char* lds = col_lds(wc);
   R* xl = (R*)lds;
   unsigned int* progress = (unsigned int*)(lds + nxb);
-  R* x = a.x;
-  const unsigned spin_limit = a.spin_limit ? a.spin_limit : (1u << 22);
-  __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.mbox), 0, 0x7ffffff0, 0x00020000);
+  R* x = col_x(wc);
+  const R* bcol = a.b + (int64_t)(c0 + wc) * a.ldb;
+  void* mcol = col_mail(wc);
   // the walker's pipeline starts ahead of the block's load phase: step words, then the operands of the first D steps
   const uint32_t* ax = a.aux + f.aux + (BWD ? ns + 1 : 0);
   // (step words by scalar loads, one issue ahead: a vector-loaded register read inside the main loop makes the compiler
@@ -456,9 +513,9 @@ __global__ __launch_bounds__(kFlowThreads * NC, (MAXK <= 6 ? BW_FLOW_WAVES : 2))
   const cu32* axc = (const cu32*)(unsigned long long)uniform_ptr(ax);
   unsigned sw_next = axc[0];
   const i32x4 rs_rec = make_rsrc(a.srec + (size_t)(uint32_t)d.rec * 16);
-  const i32x4 rs_b = make_rsrc(a.b + d.row0);
+  const i32x4 rs_b = make_rsrc(bcol + d.row0);
   const i32x4 rs_x = make_rsrc(x + d.row0);
-  const i32x4 rs_mst = make_rsrc(a.mbox);
+  const i32x4 rs_mst = make_rsrc(mcol);
   // operands of walking step kk into o (steps behind the last one: a harmless re-read of the block's first chunk);
   // O::NLOAD loads, always
   auto issue = [&](O& o, int kk) {
@@ -480,91 +537,91 @@ __global__ __launch_bounds__(kFlowThreads * NC, (MAXK <= 6 ? BW_FLOW_WAVES : 2))
     asm_load<RB / 4>(o.bb, (unsigned)tt * RB, rs_b, (unsigned)r0 * RB);
   };
   O ops[D];
-  if (tid < 64) {
+  if (walker) {
+    // the walker's half of the load phase: its column's own rows into LDS (one batch of loads for blocks of up to 512 rows),
+    // finished — the compiler waits for them before the LDS writes — before the hand-counted pipeline starts
+    constexpr int XW = 8;
+    for (int p0 = 0; p0 < d.nrows; p0 += 64 * XW) {
+      R xv[XW];
+#pragma unroll
+      for (int k = 0; k < XW; ++k) { const int p = p0 + lane + 64 * k; xv[k] = x[d.row0 + (p < d.nrows ? p : 0)]; }
+#pragma unroll
+      for (int k = 0; k < XW; ++k) pin(xv[k]);
+#pragma unroll
+      for (int k = 0; k < XW; ++k) { const int p = p0 + lane + 64 * k; if (p < d.nrows) xl[p] = xv[k]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the compiler's in flight when the counted loads start)
 #pragma unroll
     for (int j = 0; j < D; ++j) issue(ops[j], j);
   }
-  // ---- load phase (the fetcher wave; the walker's operand loads are already in flight): own x, every external column as
-  // it stands ----
-  if (tid >= 64) {
-    constexpr int XU = 5, EU = 4;   // (batches: every load of a batch in flight at once)
-    for (int p0 = 0; p0 < d.nrows; p0 += 64 * XU) {
-      R xv[XU];
-#pragma unroll
-      for (int k = 0; k < XU; ++k) { const int p = p0 + lane + 64 * k; xv[k] = x[d.row0 + (p < d.nrows ? p : 0)]; }
-#pragma unroll
-      for (int k = 0; k < XU; ++k) pin(xv[k]);
-#pragma unroll
-      for (int k = 0; k < XU; ++k) { const int p = p0 + lane + 64 * k; if (p < d.nrows) xl[p] = xv[k]; }
-    }
-    // (far side: the columns the sweep has not reached — behind the block going forward, before it going backward — and halo
-    // columns; the near side arrives through the mailboxes)
-    const int nfar = BWD ? d.npre + (d.next - d.npre - f.npost) : d.next - d.npre;
-    for (int e0 = 0; e0 < nfar; e0 += 64 * EU) {
-      int32_t ec[EU]; int es[EU];
-#pragma unroll
-      for (int k = 0; k < EU; ++k) {
-        const int i = e0 + lane + 64 * k;
-        es[k] = BWD ? (i < d.npre ? i : i + f.npost) : d.npre + i;   // slot in the external list
-        ec[k] = a.ext_col[i < nfar ? d.ext0 + es[k] : 0];
-      }
-#pragma unroll
-      for (int k = 0; k < EU; ++k) pin(ec[k]);
-      R xe[EU];
-#pragma unroll
-      for (int k = 0; k < EU; ++k) xe[k] = x[ec[k]];
-#pragma unroll
-      for (int k = 0; k < EU; ++k) pin(xe[k]);
-#pragma unroll
-      for (int k = 0; k < EU; ++k) { const int i = e0 + lane + 64 * k; if (i < nfar) xl[d.nrows + es[k]] = xe[k]; }
-    }
-    if (lane == 0) { xl[d.nrows + d.next] = (R)0; *progress = 0u; }
-  }
   __syncthreads();
-  if (tid >= 64) {
-    // ---- the fetcher: near-side values out of their mailboxes, in the order the walk needs them.  A window of U x 64 list
-    // entries is polled (only the groups up to the one behind the first missing entry); the progress word counts the LEADING
-    // entries that have arrived, so the walker goes on as soon as what its next step reads is there ----
-    constexpr int U = 3;
+  if (fetcher) {
+    // ---- the fetcher: near-side values out of their mailboxes, in the order the walk needs them, for every column of the
+    // group.  A window of U x 64 list entries is polled (per column only the groups up to the one behind its first missing
+    // entry); a column's progress word counts the LEADING entries that have arrived, so its walker goes on as soon as
+    // what its next step reads is there ----
+    constexpr int U = NC <= 2 ? 3 : 2;
     const int nf = BWD ? f.npost : d.npre;
     const int f0 = d.ext0 + (BWD ? d.npre : 0);
+    __amdgpu_buffer_rsrc_t rs_mail[NC];
+    R* xlc[NC]; unsigned int* prog[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      rs_mail[c] = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(col_mail(c < nch ? c : 0)), 0, 0x7ffffff0, 0x00020000);
+      xlc[c] = (R*)col_lds(c); prog[c] = (unsigned int*)(col_lds(c) + nxb);
+    }
     unsigned total_spins = 0;
     bool fail = false;
     for (int w0 = 0; w0 < nf && !fail; w0 += 64 * U) {
-      int32_t mb[U]; int slot[U]; bool ok[U];
+      int32_t mb[U]; int slot[U]; bool ok[NC][U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = w0 + 64 * u + lane;
         mb[u] = a.fl_mb[e < nf ? f0 + e : f0];
         slot[u] = a.fl_slot[e < nf ? f0 + e : f0];
-        ok[u] = !(e < nf);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ok[c][u] = !(e < nf) || !(c < nch);
       }
-      int first = 0;   // leading entries of the window that have arrived
+      int first[NC];   // leading entries of the window that have arrived, per column
+#pragma unroll
+      for (int c = 0; c < NC; ++c) first[c] = c < nch ? 0 : 64 * U;
       for (;;) {
-        typename M::cell c[U];
+        typename M::cell cl[NC][U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) if (!ok[u] && 64 * u <= first + 64) c[u] = M::load(rs_mail, (unsigned)mb[u] * (unsigned)M::kBytes);
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (!ok[u] && 64 * u <= first + 64 && M::valid(c[u], epoch)) { xl[slot[u]] = M::value(c[u]); ok[u] = true; }
-        int nfirst = 64 * U;
+          for (int u = 0; u < U; ++u) if (!ok[c][u] && 64 * u <= first[c] + 64) cl[c][u] = M::load(rs_mail[c], (unsigned)mb[u] * (unsigned)M::kBytes);
+        bool moved = false, done = true;
 #pragma unroll
-        for (int u = U - 1; u >= 0; --u) {
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(!ok[u]);
-          if (m) nfirst = 64 * u + (int)__builtin_ctzll(m);
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (!ok[c][u] && 64 * u <= first[c] + 64 && M::valid(cl[c][u], epoch)) { xlc[c][slot[u]] = M::value(cl[c][u]); ok[c][u] = true; }
+          int nfirst = 64 * U;
+#pragma unroll
+          for (int u = U - 1; u >= 0; --u) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(!ok[c][u]);
+            if (m) nfirst = 64 * u + (int)__builtin_ctzll(m);
+          }
+          // (LDS operations of one wave execute in program order: the values are in place before the progress word moves)
+          if (nfirst != first[c] && lane == 0) __hip_atomic_store(prog[c], (unsigned)(w0 + nfirst < nf ? w0 + nfirst : nf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          moved |= nfirst != first[c];
+          first[c] = nfirst;
+          done &= nfirst == 64 * U;
         }
-        // (LDS operations of one wave execute in program order: the values are in place before the progress word moves)
-        if (nfirst != first && lane == 0) __hip_atomic_store(progress, (unsigned)(w0 + nfirst < nf ? w0 + nfirst : nf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const bool moved = nfirst != first;
-        first = nfirst;
-        if (first == 64 * U) break;
-        if (!moved) __builtin_amdgcn_s_sleep(NC > 1 ? BW_FLOW_POLL_SLEEP_MC : 4);
+        if (done) break;
+        if (!moved) __builtin_amdgcn_s_sleep(4);
         if (++total_spins > spin_limit) { fail = true; break; }
       }
     }
-    if (fail && lane == 0) { *a.err = 1; __hip_atomic_store(progress, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    if (fail && lane == 0) {
+      *a.err = 1;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) if (c < nch) __hip_atomic_store(prog[c], 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     return;
   }
+  if (!walker) return;
   // ---- the walker ----
   __builtin_amdgcn_s_setprio(2);
   const long long t_loaded = a.tim ? wall_clock64() : 0;
@@ -667,14 +724,15 @@ __global__ __launch_bounds__(kFlowThreads * NC, (MAXK <= 6 ? BW_FLOW_WAVES : 2))
   for (int j = 0; j < D - 1; ++j)
     if (k + j < ns) { flow_wait<0>(ops[j]); step(ops[j], k + j); }
   if (gave_up && lane == 0) *a.err = 2;
-  if (a.tim && lane == 0 && pair == 0) {
+  if (a.tim && lane == 0 && wv == 0 && c0 == 0) {
     long long* tt = a.tim + 4 * (int64_t)ob;
     tt[0] = t_start; tt[1] = t_loaded; tt[2] = wall_clock64(); tt[3] = 0;
   }
 }
 
-// columns one workgroup sweeps: bounded by the registers the kernel is compiled for (2 NC waves on 4 SIMDs) and by LDS
-template <int MAXK> struct FlowMaxNc { static constexpr int value = MAXK <= 6 ? 2 * BW_FLOW_WAVES : 4; };
+// columns one workgroup sweeps (walker waves beside the one fetcher): as many as leave three (rows of <= 6 entries: 128
+// registers per lane, 16 waves per CU) / two (longer rows: 256 registers, 8 waves) workgroups resident per CU
+template <int MAXK> struct FlowMaxNc { static constexpr int value = MAXK <= 6 ? 4 : 3; };
 constexpr size_t kFlowLdsCap = 152 * 1024;
 
 template <typename R, bool SOR, bool BWD, int MAXK, int NC>
@@ -686,7 +744,7 @@ inline hipError_t sweep_flow_launch(const FlowArgs<R>& a, size_t lds, hipStream_
       static hipError_t once = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlowLdsCap);
       if (once != hipSuccess) return once;
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)a.nblocks), dim3(kFlowThreads * NC), lds, st, a);
+    hipLaunchKernelGGL(fn, dim3((unsigned)a.nblocks * (unsigned)a.ngroups), dim3(64 * (NC + 1)), lds, st, a);
     return hipGetLastError();
   }
 }
@@ -695,31 +753,23 @@ inline hipError_t sweep_flow_k(const FlowArgs<R>& a, size_t lds, bool sor, bool 
   if (sor) return backward ? sweep_flow_launch<R, true, true, MAXK, NC>(a, lds, st) : sweep_flow_launch<R, true, false, MAXK, NC>(a, lds, st);
   return backward ? sweep_flow_launch<R, false, true, MAXK, NC>(a, lds, st) : sweep_flow_launch<R, false, false, MAXK, NC>(a, lds, st);
 }
-// ncols columns (a.ldb / a.ldx / a.mail_stride apart), at most nc_max per workgroup: launches of 8 / 4 / 2 / 1 columns
+// ncols columns (a.ldb / a.ldx / a.mail_stride apart) in ONE launch: groups of equal size, at most nc_max columns each
 template <typename R, int MAXK>
 inline hipError_t sweep_flow_cols(FlowArgs<R> a, size_t lds_max, bool sor, bool backward, int ncols, int nc_max, hipStream_t st) {
   const size_t stride = (lds_max + 15) & ~(size_t)15;
-  if (stride > 64 * 1024) return hipErrorInvalidValue;
-  a.lds_stride = (int32_t)stride;
+  if (stride > 64 * 1024 || ncols < 1) return hipErrorInvalidValue;
+  if ((unsigned long long)a.nblocks * (unsigned long long)ncols > 0x7fffffffull) return hipErrorInvalidValue;
   int cap = FlowMaxNc<MAXK>::value;
   if (nc_max > 0 && nc_max < cap) cap = nc_max;
-  while (cap > 1 && (size_t)cap * stride > kFlowLdsCap) cap >>= 1;
-  for (int c = 0; c < ncols;) {
-    int nc = 1;
-    while (nc * 2 <= cap && c + nc * 2 <= ncols) nc *= 2;
-    hipError_t e;
-    switch (nc) {
-      case 8: e = sweep_flow_k<R, MAXK, 8>(a, stride * 8, sor, backward, st); break;
-      case 4: e = sweep_flow_k<R, MAXK, 4>(a, stride * 4, sor, backward, st); break;
-      case 2: e = sweep_flow_k<R, MAXK, 2>(a, stride * 2, sor, backward, st); break;
-      default: e = sweep_flow_k<R, MAXK, 1>(a, lds_max, sor, backward, st); break;
-    }
-    if (e != hipSuccess) return e;
-    a.b += (int64_t)nc * a.ldb; a.x += (int64_t)nc * a.ldx;
-    a.mbox = (void*)((unsigned char*)a.mbox + (int64_t)nc * a.mail_stride);
-    c += nc;
+  while (cap > 1 && (size_t)cap * stride > kFlowLdsCap) --cap;
+  const int groups = (ncols + cap - 1) / cap, nc = (ncols + groups - 1) / groups;
+  a.lds_stride = (int32_t)stride; a.ncols = ncols; a.ngroups = groups;
+  switch (nc) {
+    case 4: return sweep_flow_k<R, MAXK, 4>(a, stride * 4, sor, backward, st);
+    case 3: return sweep_flow_k<R, MAXK, 3>(a, stride * 3, sor, backward, st);
+    case 2: return sweep_flow_k<R, MAXK, 2>(a, stride * 2, sor, backward, st);
+    default: return sweep_flow_k<R, MAXK, 1>(a, lds_max, sor, backward, st);
   }
-  return hipSuccess;
 }
 template <typename R>
 inline hipError_t sweep_flow(const FlowArgs<R>& a, int maxk, size_t lds_max, bool sor, bool backward, hipStream_t st, int ncols = 1, int nc_max = 0) {

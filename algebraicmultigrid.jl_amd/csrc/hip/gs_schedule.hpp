@@ -1064,8 +1064,8 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   g->bw.err = bw_err_word();
   if (!g->bw.err) return -1001;
   const int64_t B = (int64_t)P.blocks.size();
-  RC_TRY(dev_alloc(&g->bw.head, 1));
-  if (hipMemset(g->bw.head, 0, 8) != hipSuccess) return -1001;
+  RC_TRY(dev_alloc(&g->bw.head, 2));   // ([0]: the chained sweep's ticket counter, [1]: the dataflow sweep's {sweeps, tickets})
+  if (hipMemset(g->bw.head, 0, 16) != hipSuccess) return -1001;
   g->bw.nblocks = (int32_t)B;
   if (flow_ok) {
     bw::Flow F;

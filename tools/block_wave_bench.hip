@@ -296,7 +296,7 @@ int main(int argc, char** argv) {
         std::vector<double> xm((size_t)n * cols);
         printf("== blocks of %d right-hand sides on the dataflow layout (algorithmic bytes per sweep: records %.2f GB + %d x %.2f GB of b, x, mail)\n", cols,
                F.srec.size() / 1e9, cols, (n * 28.0 + P.ext_total * 22.0) / 1e9);
-        for (int cap : {1, 2, 4, 8}) {
+        for (int cap : {1, 2, 3, 4}) {
           if (cap > cols) break;
           for (int c = 0; c < cols; ++c) CHECK(hipMemcpy(d_xm + (size_t)n * c, xb.data(), 8 * n, hipMemcpyHostToDevice));
           CHECK(bw::sweep_flow<double>(fm, mk, F.lds_max, false, false, st, cols, cap));

@@ -50,14 +50,15 @@ def audit_kernel(name, lines):
         return False, "no vmcnt waits found"
     # the steady wait follows from the instantiation: L = value chunks + column chunks + b loads per step, S = 2 stores,
     # D register sets (gs_flow.hpp FlowOps / FlowDepth) -> vmcnt((D - 1)(L + S))
-    m = re.search(r"gs_bw_flow_kernelI([df])Lb[01]ELb[01]ELi(\d+)E", name)
+    m = re.search(r"gs_bw_flow_kernelI([df])Lb[01]ELb[01]ELi(\d+)ELi(\d+)E", name)
     if not m:
         return False, "cannot read the instantiation from the name"
     rb, maxk = (8 if m.group(1) == "d" else 4), int(m.group(2))
     vpc = 16 // rb
     L = (maxk + 2 + vpc - 1) // vpc + (maxk + 7) // 8 + 1
     depth = int(os.environ.get("BW_FLOW_DEPTH", "4"))
-    D = depth if maxk <= 6 else (min(depth, 4) if maxk <= 12 else 3)
+    nc = int(m.group(3))
+    D = (min(depth, 3) if nc > 1 else depth) if maxk <= 6 else (min(depth, 4) if maxk <= 12 else 3)
     steady = (D - 1) * (L + 2)
     idx = [i for i, n in waits if n == steady]
     loads = [i for i, l in enumerate(code) if re.match(r"buffer_load_dword", l)]

@@ -7,7 +7,7 @@ import amg_amd as AMG
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-caps = [int(a) for a in sys.argv[3:]] or [1, 2, 4, 8]
+caps = [int(a) for a in sys.argv[3:]] or [1, 2, 3, 4]
 A = AMG.poisson((N, N, N))
 ml = AMG.ruge_stuben(A, setup="gpu", device=0)
 n = A.m
