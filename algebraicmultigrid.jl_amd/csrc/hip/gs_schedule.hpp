@@ -1010,7 +1010,8 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   // splitting — sharing a CPU quota with it: 16 threads here cost the 256^3 setup 0.3 s, 4 do not)
   prm.threads = std::max(1, std::min<int>(merge_threads(), 4));
   if (const char* e = getenv("AMGH_BW_THREADS")) prm.threads = std::max(1, atoi(e));   // (measurement hook)
-  prm.require_three = g_gs_bw != 2;   // (the cost-model branch below insists on three offset classes)
+  // (the cost-model branch below insists on three offset classes, or two on operators of >= gs_bw_two_min_rows rows)
+  prm.require_three = g_gs_bw != 2 && !(g_gs_bw_two_min_rows > 0 && n >= g_gs_bw_two_min_rows);
   bw::Plan P;
   try {   // (gigabytes of host memory: out of it, the level keeps the level schedules — nothing crosses the C ABI)
     if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_OK;
@@ -1026,17 +1027,27 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   if (nrhs_hint > 1 && !flow_ok) return AMGH_OK;
   const int64_t nnz = rowptr[n];
   const int nlaunch = (int)P.launch_ptr.size() - 1;
+  if (g_gs_bw == 2 && getenv("AMGH_VERBOSE")) {
+    const double merged = merge_cost((P.nlevels + 2) / 3, (int64_t)(1.8 * (double)nnz));
+    fprintf(stderr, "[amghip] n=%lld wavefront of blocks (forced): %zu blocks, %d depths (dependency levels %d), ranges %d x %d x %d, model %.3f ms (%.3f as one launch per depth) vs %.3f ms merged\n",
+            (long long)n, P.blocks.size(), nlaunch, P.nlevels, P.range[0], P.range[1], P.range[2], P.est_chain_seconds * 1e3, P.est_seconds * 1e3, merged * 1e3);
+  }
   if (g_gs_bw != 2) {
     // three independent directions (a stencil-like operator: with fewer the blocks are slabs and their walk is long), and
-    // clearly cheaper than groups of ~3 merged levels with ~1.8 x the entries (what such operators get otherwise)
+    // clearly cheaper than groups of ~3 merged levels with ~1.8 x the entries (what such operators get otherwise).
+    // Two directions (2-D grids): the wavefront is a line of at most sqrt(n) blocks' worth of rows and both models
+    // overprice it alike; measured on the 4096^2 Poisson hierarchy (profiles/r04_2d_blocks.log): the 16.8 M-row level
+    // 8.5 -> 6.3 ms per smoother, the 8.4 M-row level 7.9 -> 7.4, the 2.1 M-row level 3.7 -> 4.9 — large operators only
     const bool three = P.range[0] > 1 && P.range[1] > 1 && P.range[2] > 1;
+    const int ndir = (P.range[0] > 1) + (P.range[1] > 1) + (P.range[2] > 1);
+    const bool two = ndir == 2 && g_gs_bw_two_min_rows > 0 && n >= g_gs_bw_two_min_rows;
     const double merged = merge_cost((P.nlevels + 2) / 3, (int64_t)(1.8 * (double)nnz));
     const double est = g_gs_bw_chain ? P.est_chain_seconds : P.est_seconds;
+    const bool used = (three && est < 0.8 * merged) || (two && est < 0.6 * merged);
     if (getenv("AMGH_VERBOSE"))
-      fprintf(stderr, "[amghip] n=%lld wavefront of blocks: %zu blocks, %d depths (dependency levels %d), model %.3f ms (%.3f as one launch per depth) vs %.3f ms merged -> %s\n",
-              (long long)n, P.blocks.size(), nlaunch, P.nlevels, est * 1e3, P.est_seconds * 1e3, merged * 1e3,
-              (three && est < 0.8 * merged) ? "used" : "not used");
-    if (!three || !(est < 0.8 * merged)) return AMGH_OK;
+      fprintf(stderr, "[amghip] n=%lld wavefront of blocks: %zu blocks, %d depths (dependency levels %d), %d directions, model %.3f ms (%.3f as one launch per depth) vs %.3f ms merged -> %s\n",
+              (long long)n, P.blocks.size(), nlaunch, P.nlevels, ndir, est * 1e3, P.est_seconds * 1e3, merged * 1e3, used ? "used" : "not used");
+    if (!used) return AMGH_OK;
   }
   HostLevelCsr base;
   permuted_matrix(n, ncols, rowptr, col, val, P.perm, base);
