@@ -535,7 +535,10 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
     if (e != hipSuccess) return -(1000 + (int)e);
   }
   const int ns = (int)lay->segs.size();
-  for (int k = 0; k < ns; ++k) {
+  // (g_gs_dup_launch: measurement hook — every group launched 1 + that many times: a group's launch is idempotent, the
+  // repeats find its arrays in cache: what a prefetch of the next group's arrays could win at most)
+  for (int kk = 0; kk < ns * (1 + g_gs_dup_launch); ++kk) {
+    const int k = kk / (1 + g_gs_dup_launch);
     const GsSchedule::Seg& s = lay->segs[backward ? ns - 1 - k : k];
     if (s.chain) {
       ChainArgs c{};
