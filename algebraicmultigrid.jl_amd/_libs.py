@@ -55,6 +55,8 @@ def setup_lib():
     L.amgs_set_threads_here.argtypes = [C.c_int]
     L.amgs_mat_create.restype = vp
     L.amgs_mat_create.argtypes = [i64, i64, vp, vp, vp]
+    L.amgs_mat_alloc.restype = vp
+    L.amgs_mat_alloc.argtypes = [i64, i64, i64]
     L.amgs_mat_free.argtypes = [vp]
     for f in ("amgs_mat_rows", "amgs_mat_cols", "amgs_mat_nnz"):
         getattr(L, f).restype = i64
@@ -237,6 +239,8 @@ def hip_lib(dtype=None):
     L.amgh_setup_transpose.argtypes = [vp, C.POINTER(vp)]
     L.amgh_dmat_equal.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.amgh_setup_classical_strength.argtypes = [vp, C.c_double, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.amgh_setup_symmetric_strength.restype = C.c_int
+    L.amgh_setup_symmetric_strength.argtypes = [vp, C.c_double, C.c_int, C.POINTER(vp)]
     L.amgh_setup_direct_interpolation.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     L.amgh_setup_spgemm.argtypes = [vp, vp, C.POINTER(vp)]
     L.amgh_setup_jacobi_prolongation.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]

@@ -495,6 +495,94 @@ int amgh_setup_classical_strength(const amgh_dmat_t* At, double theta, amgh_dmat
   return AMGH_OK;
 }
 
+// ---- strength.jl:77-122 : S = SymmetricStrength(theta)(A, bsr_flag) --------------------------------------------------------
+// diags[i] = |sum of the stored diagonal entries of column i|  (strength.jl:94-104)
+__global__ void sym_diag_kernel(const int32_t* ap, const int32_t* ai, const double* av, int64_t n, double* diags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double d = 0.0;
+  for (int32_t j = ap[i]; j < ap[i + 1]; ++j)
+    if (ai[j] == i) d += av[j];
+  diags[i] = fabs(d);
+}
+// value an entry of column i takes before dropzeros!: 0 for an off-diagonal entry with v * v < theta^2 |a_ii| |a_rr|
+// (strength.jl:106-117), |v| otherwise (:121; stored zeros go with the dropped ones)
+__device__ __forceinline__ double sym_strength_value(int32_t row, int i, double v, double eps_aii, const double* diags) {
+  if (row != i && v * v < eps_aii * diags[row]) return 0.0;
+  return fabs(v);
+}
+__global__ void sym_strength_kernel(const int32_t* ap, const int32_t* ai, const double* av, int64_t n, double theta, const double* diags,
+                                    const int32_t* sp, int32_t* si, double* sv, int32_t* cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t a0 = ap[i], a1 = ap[i + 1];
+  const double eps_aii = theta * theta * diags[i];
+  if (!sp) {  // count pass
+    int32_t c = 0;
+    for (int32_t j = a0; j < a1; ++j) c += (sym_strength_value(ai[j], i, av[j], eps_aii, diags) != 0.0);
+    cnt[i] = c;
+    return;
+  }
+  // fill pass: kept entries, then scale_cols_by_largest_entry! (strength.jl:61-70: max over the stored values, from 0)
+  int32_t o = sp[i];
+  double big = 0.0;
+  for (int32_t j = a0; j < a1; ++j) {
+    const double nv = sym_strength_value(ai[j], i, av[j], eps_aii, diags);
+    if (nv != 0.0) { si[o] = ai[j]; sv[o] = nv; big = fmax(big, nv); ++o; }
+  }
+  for (int32_t q = sp[i]; q < o; ++q) sv[q] = sv[q] / big;
+}
+__global__ void fill_ones_kernel(double* v, int64_t n) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) v[k] = 1.0;
+}
+
+int amgh_setup_symmetric_strength(const amgh_dmat_t* A, double theta, int bsr_flag, amgh_dmat_t** S) {
+  RC_TRY(dmat_check(A));
+  if (!S || A->m != A->n) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(A->device));
+  const int64_t n = A->n;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, (n + 255) / 256);
+  amgh_dmat* Sm = nullptr;
+  if (bsr_flag && theta == 0.0) {   // strength.jl:81-84: the pattern of A, every value one
+    RC_TRY(dmat_alloc(&Sm, A->device, n, n, A->nnz));
+    int rc = AMGH_OK;
+    if (hipMemcpyAsync(Sm->ptr, A->ptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = -1001;
+    if (rc == AMGH_OK && A->nnz > 0 && hipMemcpyAsync(Sm->idx, A->idx, sizeof(int32_t) * (size_t)A->nnz, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) rc = -1001;
+    if (rc == AMGH_OK && A->nnz > 0)
+      hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)std::min<int64_t>(65535, (A->nnz + 255) / 256)), dim3(256), 0, nullptr, Sm->val, A->nnz);
+    if (rc == AMGH_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = -1001;
+    if (rc != AMGH_OK) { dmat_free(Sm); return rc; }
+    *S = Sm;
+    return AMGH_OK;
+  }
+  double* diags = nullptr;
+  int32_t *cnt = nullptr, *sp = nullptr;
+  int rc = dev_alloc(&diags, n + 1);
+  if (rc == AMGH_OK) rc = dev_alloc(&cnt, n + 1);
+  if (rc == AMGH_OK) rc = dev_alloc(&sp, n + 1);
+  int64_t total = 0;
+  if (rc == AMGH_OK && n > 0) {
+    hipLaunchKernelGGL(sym_diag_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)A->ptr, (const int32_t*)A->idx, (const double*)A->val, n, diags);
+    hipLaunchKernelGGL(sym_strength_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)A->ptr, (const int32_t*)A->idx, (const double*)A->val, n,
+                       theta, (const double*)diags, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, cnt);
+  }
+  if (rc == AMGH_OK) rc = dev_exclusive_scan(cnt, sp, n, &total, nullptr);
+  if (rc == AMGH_OK) rc = dmat_alloc(&Sm, A->device, n, n, total);
+  if (rc == AMGH_OK) {
+    hipFree(Sm->ptr);
+    Sm->ptr = sp;
+    sp = nullptr;
+    if (n > 0)
+      hipLaunchKernelGGL(sym_strength_kernel, dim3(grid), dim3(256), 0, nullptr, (const int32_t*)A->ptr, (const int32_t*)A->idx, (const double*)A->val, n,
+                         theta, (const double*)diags, (const int32_t*)Sm->ptr, Sm->idx, Sm->val, (int32_t*)nullptr);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) rc = -1001;
+  }
+  hipFree(diags); hipFree(cnt); hipFree(sp);
+  if (rc != AMGH_OK) { dmat_free(Sm); return rc; }
+  *S = Sm;
+  return AMGH_OK;
+}
+
 // P, R = direct_interpolation(At, T, splitting)  (classical.jl:57-189): R is nc x n in CSC (one column per fine node,
 // = the CSR arrays of P), P = R' (copy).  splitting: host array, 1 = C node, 0 = F node.
 int amgh_setup_direct_interpolation(const amgh_dmat_t* At, const amgh_dmat_t* T, const int32_t* splitting,

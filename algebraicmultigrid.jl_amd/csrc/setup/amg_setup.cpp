@@ -1405,6 +1405,17 @@ amgs_mat* amgs_mat_create(int64_t m, int64_t n, const int32_t* colptr, const int
     return A.release();
   });
 }
+// an m x n matrix with room for nnz stored entries whose arrays the CALLER fills in place (amgs_mat_colptr / _rowval /
+// _nzval): what the GPU half of the setup downloads into, without a staging copy.  The caller owns their consistency.
+amgs_mat* amgs_mat_alloc(int64_t m, int64_t n, int64_t nnz) {
+  return Guard::ptr([&]() -> amgs_mat* {
+    if (m < 0 || n < 0 || nnz < 0 || nnz > (int64_t)INT32_MAX) throw std::runtime_error("amgs_mat_alloc: bad argument");
+    MatP A = make(m, n);
+    A->rowval.resize((size_t)nnz);
+    A->nzval.resize((size_t)nnz);
+    return A.release();
+  });
+}
 void amgs_mat_free(amgs_mat* A) { delete A; }
 int64_t amgs_mat_rows(const amgs_mat* A) { return A->m; }
 int64_t amgs_mat_cols(const amgs_mat* A) { return A->n; }

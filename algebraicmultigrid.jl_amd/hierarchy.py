@@ -404,8 +404,15 @@ class _DMat:
         return cp, rv, nz
 
     def to_host(self):
-        cp, rv, nz = self.download()
-        return SparseMatrixCSC.from_arrays(self.m, self.n, cp, rv, nz)
+        # straight into the host library's arrays (no staging copy; the device arrays are a valid CSC by construction)
+        from ._libs import hip_check
+        h = setup_lib().amgs_mat_alloc(self.m, self.n, self.nnz)
+        if not h:
+            raise AMGError(setup_lib().amgs_last_error().decode())
+        out = SparseMatrixCSC(h)
+        hip_check(self.lib.amgh_dmat_download(self.h, out.colptr.ctypes.data, out.rowval.ctypes.data if self.nnz else None,
+                                              out.nzval.ctypes.data if self.nnz else None), "dmat_download")
+        return out
 
     def __del__(self):
         try:
@@ -664,7 +671,7 @@ def _ruge_stuben_gpu(A, theta, max_levels, max_coarse, hermitian, device=0, buil
 def _smoothed_aggregation_gpu(A, B, theta, omega, improve_iters, hermitian, max_levels, max_coarse, device=0):
     """extend_hierarchy_sa! (aggregation.jl:116-157) with its two heavy steps on the GPU: the prolongation smoothing
     P = T - (omega D^-1 A) T (amgh_setup_jacobi_prolongation: row sums, scaling, SpGEMM, subtraction) and R*A*P
-    (transpose + two SpGEMMs).  Strength, the sequential aggregation, improve_candidates (Gauss-Seidel on the
+    (transpose + two SpGEMMs), and SymmetricStrength.  The sequential aggregation, improve_candidates (Gauss-Seidel on the
     candidates) and fit_candidates (a QR per aggregate) run in the host library on the level matrix, which is
     downloaded anyway.  improve_candidates needs only A and B, strength + aggregation only A: the two chains run side
     by side on two host threads (half the OpenMP threads each), and a third thread downloads P and R — nothing on the
@@ -730,8 +737,21 @@ def _smoothed_aggregation_gpu(A, B, theta, omega, improve_iters, hermitian, max_
                 side.submit(done.set)
                 L.amgs_set_threads_here(threads_all - share)
             try:    # (whatever strength or aggregation raise, this thread gets its full thread count back)
-                S, _ = strength(A_host if hermitian else A_host.transpose(), bsr_flag)
-                tick("symmetric strength (host)")
+                # SymmetricStrength on the GPU (strength.jl:77-122, amgh_setup_symmetric_strength: bitwise the host
+                # library's); the sequential aggregation reads pattern and values on the host
+                if hermitian:
+                    dAs = dA
+                else:
+                    t_ = C.c_void_p()
+                    hip_check(lib.amgh_setup_transpose(dA.h, C.byref(t_)), "setup_transpose")
+                    dAs = _DMat(t_.value, lib)
+                s_ = C.c_void_p()
+                hip_check(lib.amgh_setup_symmetric_strength(dAs.h, theta, int(bool(bsr_flag)), C.byref(s_)), "setup_symmetric_strength")
+                dS = _DMat(s_.value, lib)
+                tick("symmetric strength (GPU)")
+                S = dS.to_host()
+                del dS, dAs
+                tick("download S")
                 AggOp = SparseMatrixCSC(L.amgs_standard_aggregation(S._h))
                 tick("aggregation (host)")
                 if share:

@@ -410,6 +410,10 @@ int amgh_dmat_equal(const amgh_dmat_t* A, const amgh_dmat_t* B, int* same);
  * diagonal (remove_diag, splitting.jl:8-18) and its transpose — so the host needs no matrix work of its own. */
 int amgh_setup_classical_strength(const amgh_dmat_t* At, double theta, amgh_dmat_t** S, amgh_dmat_t** T,
                                   amgh_dmat_t** Sn, amgh_dmat_t** Tn);
+/* S = SymmetricStrength(theta)(A, bsr_flag)  (strength.jl:77-122): off-diagonal entries with a_ij^2 < theta^2 |a_ii| |a_jj|
+ * and stored zeros dropped, |.| of the rest scaled by the column maxima (bsr_flag with theta = 0: the pattern of A with
+ * ones) — the strength of smoothed_aggregation, bitwise the host library's.                                     */
+int amgh_setup_symmetric_strength(const amgh_dmat_t* A, double theta, int bsr_flag, amgh_dmat_t** S);
 /* P, R = direct_interpolation(At, T, splitting)  (classical.jl:57-189); splitting is a HOST array
  * (1 = C node, 0 = F node).  R: nc x n, P = R': n x nc.                                                        */
 int amgh_setup_direct_interpolation(const amgh_dmat_t* At, const amgh_dmat_t* T, const int32_t* splitting,

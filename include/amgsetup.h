@@ -48,6 +48,9 @@ int amgs_set_threads_here(int nthreads);
 /* ---- matrices ---------------------------------------------------------- */
 amgs_mat* amgs_mat_create(int64_t m, int64_t n, const int32_t* colptr,
                           const int32_t* rowval, const double* nzval);
+/* an m x n matrix with room for nnz stored entries; the caller fills the three arrays in place (the GPU half of the
+ * setup downloads into them) and answers for their consistency */
+amgs_mat* amgs_mat_alloc(int64_t m, int64_t n, int64_t nnz);
 void amgs_mat_free(amgs_mat*);
 int64_t amgs_mat_rows(const amgs_mat*);
 int64_t amgs_mat_cols(const amgs_mat*);

@@ -145,3 +145,30 @@ def test_gpu_smoothed_aggregation_with_candidates_and_other_options():
     check_sa_hierarchy(AMG.poisson(500), B=np.linspace(1.0, 2.0, 500))
     check_sa_hierarchy(load_csc("randlap"))
     check_sa_hierarchy(AMG.poisson((20, 20)), symmetry=AMG.NoSymmetry())
+
+
+@pytest.mark.parametrize("theta", [0.0, 0.1, 0.25, 0.9])
+def test_gpu_symmetric_strength_is_the_host_librarys_bit_for_bit(theta):
+    """amgh_setup_symmetric_strength (strength.jl:77-122): entries with a_ij^2 < theta^2 |a_ii| |a_jj| and stored zeros
+    dropped, |.| scaled by the column maxima — structure and values of the host library's S, on grids, on an irregular
+    graph, on a non-symmetric operator with stored zeros and a zero diagonal, and the bsr_flag shortcut (:81-84)."""
+    from amg_amd.hierarchy import _DMat
+    import scipy.sparse as sp
+    lib = AMG.hip_lib()
+    rng = np.random.default_rng(11)
+    n = 400
+    M = sp.random(n, n, density=0.02, random_state=3, format="lil")
+    M.setdiag(rng.random(n) + 0.5)
+    M[5, 5] = 0.0                                   # a stored zero on the diagonal
+    M[7, 9] = 0.0                                   # a stored zero off the diagonal
+    M = M.tocsc()
+    M.data[::17] *= -1.0
+    cases = [AMG.poisson((30, 20)), AMG.poisson((12, 11, 10)), load_csc("randlap"), AMG.SparseMatrixCSC.from_scipy(M)]
+    for A in cases:
+        dA = _DMat.upload(A, lib)
+        for bsr in (0, 1):
+            s_ = C.c_void_p()
+            assert lib.amgh_setup_symmetric_strength(dA.h, theta, bsr, C.byref(s_)) == 0
+            S_dev = _DMat(s_.value, lib).to_host()
+            S_host, _ = AMG.SymmetricStrength(theta)(A, bool(bsr))
+            assert same(S_dev, S_host), (A.shape, theta, bsr)
