@@ -235,7 +235,7 @@ function localrows(M::SparseMatrixCSC, r0, r1)      # rows [r0, r1) of M' as CSR
 end
 
 """
-    hip_sharded(ml, rank, nranks, id; device = rank, shard_min_rows = 200_000) -> HipSharded
+    hip_sharded(ml, rank, nranks, id; device = rank, shard_min_rows = 200_000, gs_exact = true) -> HipSharded
 
 Levels with at least `shard_min_rows` rows are partitioned by contiguous row ranges; the rest is uploaded on rank 0
 (`hip`) and handed over with amgh_dist_set_tail.  Assumes symmetric level operators (A' = A), as the sharded
@@ -244,10 +244,12 @@ Python driver does.
 `id::Vector{UInt8}` (the 128 bytes of `amgh_dist_unique_id`, broadcast from rank 0) selects the RCCL transport;
 `id::AbstractString` (a fresh shared-memory name in `shm_open` syntax, e.g. "/amgh_1234", the same on every rank)
 selects the IPC transport: one process per rank, hipIpc peer-mapped send buffers, hand-off by flags the streams write
-and wait on — ranks may then share a GPU, which RCCL refuses.
+and wait on — ranks may then share a GPU, which RCCL refuses.  `gs_exact = true`: Gauss-Seidel / SOR sweep the whole
+level in lexicographic order (the ranks in turn: the reference's iterate); `false`: every shard at once, halo frozen
+per directional sweep (`amgh_dist_set_gs_mode`).
 """
 function hip_sharded(ml::MultiLevel, rank::Integer, nranks::Integer, id::Union{Vector{UInt8},AbstractString};
-                     device::Integer = rank, shard_min_rows::Integer = 200_000)
+                     device::Integer = rank, shard_min_rows::Integer = 200_000, gs_exact::Bool = true)
     d = Ref{Ptr{Cvoid}}(C_NULL)
     if id isa AbstractString
         check(ccall((:amgh_dist_create_ipc, libamghip), Cint, (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cstring),
@@ -284,6 +286,8 @@ function hip_sharded(ml::MultiLevel, rank::Integer, nranks::Integer, id::Union{V
         check(ccall((:amgh_dist_set_tail, libamghip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), d[], tail.workspace.handle))
     end
     check(ccall((:amgh_dist_finalize, libamghip), Cint, (Ptr{Cvoid},), d[]))
+    # Gauss-Seidel / SOR across shards: exact lexicographic order (the reference's iterate; default) or the frozen-halo hybrid
+    gs_exact || check(ccall((:amgh_dist_set_gs_mode, libamghip), Cint, (Ptr{Cvoid}, Cint), d[], 0))
     cuts0 = rowcuts(sizes[1], nranks)
     s = HipSharded(d[], tail, lc > 0 ? cuts0[rank + 1] : (rank == 0 ? 0 : sizes[1]), lc > 0 ? cuts0[rank + 2] : sizes[1])
     finalizer(s -> ccall((:amgh_dist_destroy, libamghip), Cvoid, (Ptr{Cvoid},), s.handle), s)
