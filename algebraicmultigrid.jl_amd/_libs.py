@@ -241,6 +241,8 @@ def hip_lib(dtype=None):
     L.amgh_setup_classical_strength.argtypes = [vp, C.c_double, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.amgh_setup_symmetric_strength.restype = C.c_int
     L.amgh_setup_symmetric_strength.argtypes = [vp, C.c_double, C.c_int, C.POINTER(vp)]
+    L.amgh_setup_fit_candidates_vector.restype = C.c_int
+    L.amgh_setup_fit_candidates_vector.argtypes = [vp, vp, C.c_double, C.POINTER(vp), vp]
     L.amgh_setup_direct_interpolation.argtypes = [vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     L.amgh_setup_spgemm.argtypes = [vp, vp, C.POINTER(vp)]
     L.amgh_setup_jacobi_prolongation.argtypes = [vp, vp, C.c_double, C.POINTER(vp)]

@@ -583,6 +583,44 @@ int amgh_setup_symmetric_strength(const amgh_dmat_t* A, double theta, int bsr_fl
   return AMGH_OK;
 }
 
+// ---- aggregation.jl:161-193 : T, Bc = fit_candidates(AggOp, B::Vector) --------------------------------------------------------
+// column i of A = AggOp' lists the fine nodes of aggregate i (ascending); one thread walks it twice, in stored order: the
+// sum of squares (norm_col, aggregation.jl:232-240), then B[row] * (1 / norm) — the host library's operations in its order
+__global__ void fit_vector_kernel(const int32_t* ap, const int32_t* ai, double* av, int64_t ncol, const double* B, double tol, double* Bc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncol) return;
+  double s = 0.0;
+  for (int32_t j = ap[i]; j < ap[i + 1]; ++j) { const double v = B[ai[j]]; s += v * v; }
+  const double norm_i = sqrt(s);
+  const double threshold_i = tol * norm_i;
+  double scale = 0.0, r = 0.0;
+  if (norm_i > threshold_i) { scale = 1.0 / norm_i; r = norm_i; }
+  Bc[i] = r;
+  for (int32_t j = ap[i]; j < ap[i + 1]; ++j) av[j] = B[ai[j]] * scale;
+}
+int amgh_setup_fit_candidates_vector(const amgh_dmat_t* AggOp, const double* B, double tol, amgh_dmat_t** T, double* Bc) {
+  RC_TRY(dmat_check(AggOp));
+  if (!T || !B || !Bc) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(AggOp->device));
+  const int64_t n_fine = AggOp->n, n_coarse = AggOp->m;
+  amgh_dmat* A = nullptr;
+  RC_TRY(dmat_transpose(AggOp, &A, true, nullptr));   // n_fine x n_coarse, rows ascending inside a column
+  double *dB = nullptr, *dBc = nullptr;
+  int rc = dev_alloc(&dB, std::max<int64_t>(n_fine, 1));
+  if (rc == AMGH_OK) rc = dev_alloc(&dBc, std::max<int64_t>(n_coarse, 1));
+  if (rc == AMGH_OK && n_fine > 0 && staged_copy(dB, B, sizeof(double) * (size_t)n_fine, hipMemcpyHostToDevice) != hipSuccess) rc = -1001;
+  if (rc == AMGH_OK && n_coarse > 0) {
+    hipLaunchKernelGGL(fit_vector_kernel, dim3((unsigned)((n_coarse + 255) / 256)), dim3(256), 0, nullptr, (const int32_t*)A->ptr, (const int32_t*)A->idx,
+                       A->val, n_coarse, (const double*)dB, tol, dBc);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) rc = -1001;
+    if (rc == AMGH_OK && hipMemcpy(Bc, dBc, sizeof(double) * (size_t)n_coarse, hipMemcpyDeviceToHost) != hipSuccess) rc = -1001;
+  }
+  hipFree(dB); hipFree(dBc);
+  if (rc != AMGH_OK) { dmat_free(A); return rc; }
+  *T = A;
+  return AMGH_OK;
+}
+
 // P, R = direct_interpolation(At, T, splitting)  (classical.jl:57-189): R is nc x n in CSC (one column per fine node,
 // = the CSR arrays of P), P = R' (copy).  splitting: host array, 1 = C node, 0 = F node.
 int amgh_setup_direct_interpolation(const amgh_dmat_t* At, const amgh_dmat_t* T, const int32_t* splitting,

@@ -1411,7 +1411,17 @@ amgs_mat* amgs_mat_alloc(int64_t m, int64_t n, int64_t nnz) {
   return Guard::ptr([&]() -> amgs_mat* {
     if (m < 0 || n < 0 || nnz < 0 || nnz > (int64_t)INT32_MAX) throw std::runtime_error("amgs_mat_alloc: bad argument");
     MatP A = make(m, n);
+    // (hundreds of megabytes that are written once, front to back: on 2 MiB pages — transparent huge pages are in `madvise`
+    // mode on the target hosts — the first touch costs a page fault per 512 x as many bytes)
+    auto huge = [](void* p, size_t bytes) {
+      const uintptr_t a = ((uintptr_t)p + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), e = ((uintptr_t)p + bytes) & ~(((uintptr_t)2 << 20) - 1);
+      if (e > a && !std::getenv("AMGS_NO_HUGEPAGES")) madvise((void*)a, e - a, MADV_HUGEPAGE);   // advice only
+    };
+    A->rowval.reserve((size_t)nnz);
+    huge(A->rowval.data(), sizeof(int32_t) * (size_t)nnz);
     A->rowval.resize((size_t)nnz);
+    A->nzval.reserve((size_t)nnz);
+    huge(A->nzval.data(), sizeof(double) * (size_t)nnz);
     A->nzval.resize((size_t)nnz);
     return A.release();
   });

@@ -9,6 +9,7 @@ Names, argument meaning and error behaviour follow the reference
 The heavy lifting is libamgsetup (C++); the solve phase is libamghip (HIP).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -378,6 +379,22 @@ def _unwrap(A, symmetry):
     return SparseMatrixCSC.coerce(A), symmetry
 
 
+def _huge_empty(count, dtype):
+    """np.empty whose pages — untouched so far — are advised to be 2 MiB ones (transparent huge pages are in `madvise`
+    mode on the target hosts): a download writes hundreds of megabytes front to back, and the sequential C/F splitting
+    then chases through them at random; with 4 KiB pages both pay a page fault / a TLB miss per 512 x fewer bytes."""
+    a = np.empty(int(count), dtype=dtype)
+    if a.nbytes >= (8 << 20) and not os.environ.get("AMGS_NO_HUGEPAGES"):
+        try:
+            lo = (a.ctypes.data + (2 << 20) - 1) & ~((2 << 20) - 1)
+            hi = (a.ctypes.data + a.nbytes) & ~((2 << 20) - 1)
+            if hi > lo:
+                C.CDLL(None, use_errno=True).madvise(C.c_void_p(lo), C.c_size_t(hi - lo), 14)   # MADV_HUGEPAGE: advice only
+        except Exception:   # noqa: BLE001 - no libc / no madvise: plain pages
+            pass
+    return a
+
+
 class _DMat:
     """SparseMatrixCSC on HBM (amgh_dmat_*): the operand type of the GPU half of the setup phase."""
 
@@ -396,9 +413,9 @@ class _DMat:
 
     def download(self, values=True):
         from ._libs import hip_check
-        cp = np.empty(self.n + 1, dtype=np.int32)
-        rv = np.empty(self.nnz, dtype=np.int32)
-        nz = np.empty(self.nnz, dtype=np.float64) if values else None
+        cp = _huge_empty(self.n + 1, np.int32)
+        rv = _huge_empty(self.nnz, np.int32)
+        nz = _huge_empty(self.nnz, np.float64) if values else None
         hip_check(self.lib.amgh_dmat_download(self.h, cp.ctypes.data, rv.ctypes.data, nz.ctypes.data if values else None),
                   "dmat_download")
         return cp, rv, nz
@@ -771,13 +788,27 @@ def _smoothed_aggregation_gpu(A, B, theta, omega, improve_iters, hermitian, max_
             tick("improve_candidates (host)")
             if AggOp.m == 0:
                 break
-            T, Bc = fit_candidates(AggOp, Bf[:, 0] if vector else Bf)
-            tick("fit_candidates (host)")
-            dT = _DMat.upload(T, lib, device)
-            tick("upload T")
+            if vector:
+                # one candidate: the tentative prolongator on the GPU (aggregation.jl:161-193, bitwise the host library's)
+                dAgg = _DMat.upload(AggOp, lib, device)
+                b1 = np.ascontiguousarray(Bf[:, 0])
+                Bc = np.empty(AggOp.m, dtype=np.float64)
+                t_ = C.c_void_p()
+                hip_check(lib.amgh_setup_fit_candidates_vector(dAgg.h, b1.ctypes.data, 1e-10, C.byref(t_), Bc.ctypes.data),
+                          "setup_fit_candidates_vector")
+                dT, T = _DMat(t_.value, lib), None
+                del dAgg
+                tick("fit_candidates (GPU)")
+            else:
+                T, Bc = fit_candidates(AggOp, Bf)
+                tick("fit_candidates (host)")
+                dT = _DMat.upload(T, lib, device)
+                tick("upload T")
             p = C.c_void_p()
             rc = lib.amgh_setup_jacobi_prolongation(dA.h, dT.h, omega, C.byref(p))
             if rc == -5:
+                if T is None:
+                    T = dT.to_host()
                 dP = _DMat.upload(SparseMatrixCSC(L.amgs_jacobi_prolongation(A_host._h, T._h, omega)), lib, device)
             else:
                 hip_check(rc, "setup_jacobi_prolongation")

@@ -414,6 +414,11 @@ int amgh_setup_classical_strength(const amgh_dmat_t* At, double theta, amgh_dmat
  * and stored zeros dropped, |.| of the rest scaled by the column maxima (bsr_flag with theta = 0: the pattern of A with
  * ones) — the strength of smoothed_aggregation, bitwise the host library's.                                     */
 int amgh_setup_symmetric_strength(const amgh_dmat_t* A, double theta, int bsr_flag, amgh_dmat_t** S);
+/* T, Bc = fit_candidates(AggOp, B::Vector; tol)  (aggregation.jl:161-193): AggOp is n_coarse x n_fine (one entry per aggregated
+ * fine node), B and Bc HOST vectors of n_fine / n_coarse entries; T = AggOp' with column i = B restricted to aggregate i,
+ * normalised (Bc[i] its norm) — the tentative prolongator, bitwise the host library's.  (Blocks of candidates take the QR
+ * per aggregate of the host library, amgs_fit_candidates.)                                                        */
+int amgh_setup_fit_candidates_vector(const amgh_dmat_t* AggOp, const double* B, double tol, amgh_dmat_t** T, double* Bc);
 /* P, R = direct_interpolation(At, T, splitting)  (classical.jl:57-189); splitting is a HOST array
  * (1 = C node, 0 = F node).  R: nc x n, P = R': n x nc.                                                        */
 int amgh_setup_direct_interpolation(const amgh_dmat_t* At, const amgh_dmat_t* T, const int32_t* splitting,

@@ -172,3 +172,25 @@ def test_gpu_symmetric_strength_is_the_host_librarys_bit_for_bit(theta):
             S_dev = _DMat(s_.value, lib).to_host()
             S_host, _ = AMG.SymmetricStrength(theta)(A, bool(bsr))
             assert same(S_dev, S_host), (A.shape, theta, bsr)
+
+
+def test_gpu_fit_candidates_vector_is_the_host_librarys_bit_for_bit():
+    """amgh_setup_fit_candidates_vector (aggregation.jl:161-193): T = AggOp' carrying the candidate restricted to every
+    aggregate, normalised, and the aggregates' norms — structure and values of the host library's, with aggregates of
+    one node, nodes in no aggregate, and a candidate that vanishes on a whole aggregate (norm 0: column of zeros)."""
+    from amg_amd.hierarchy import _DMat, fit_candidates
+    lib = AMG.hip_lib()
+    for A, seed in ((AMG.poisson((40, 30)), 1), (AMG.poisson((14, 12, 10)), 2), (load_csc("randlap"), 3)):
+        S, _ = AMG.SymmetricStrength(0.0)(A)
+        AggOp = AMG.StandardAggregation()(S)
+        n = A.m
+        B = uniform(n, seed) + 0.5
+        first = AggOp.transpose().rowval[: AggOp.transpose().colptr[1]]     # the fine nodes of aggregate 0
+        B[first] = 0.0
+        T_host, Bc_host = fit_candidates(AggOp, B)
+        dAgg = _DMat.upload(AggOp, lib)
+        t_ = C.c_void_p()
+        Bc = np.empty(AggOp.m)
+        assert lib.amgh_setup_fit_candidates_vector(dAgg.h, B.ctypes.data, 1e-10, C.byref(t_), Bc.ctypes.data) == 0
+        T_dev = _DMat(t_.value, lib).to_host()
+        assert same(T_dev, T_host) and np.array_equal(Bc, Bc_host) and Bc[0] == 0.0
