@@ -158,7 +158,8 @@ def test_a_forced_protocol_error_is_an_error_code_not_numbers():
     assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
 
 
-@pytest.mark.parametrize("case,bs", [("poisson", 8), ("poisson", 3), ("poisson", 5), ("galerkin", 4), ("galerkin", 7), ("galerkin", 2)])
+@pytest.mark.parametrize("case,bs", [("poisson", 8), ("poisson", 3), ("poisson", 5), ("galerkin", 4), ("galerkin", 7), ("galerkin", 2),
+                                     ("poisson-sor", 4), ("galerkin-sor", 3)])
 def test_blocks_of_right_hand_sides_on_the_dataflow_layout_equal_the_single_columns_bit_for_bit(case, bs):
     """bs > 1 (`MultiLevelWorkspace{TX,bs}`, /root/reference/src/multilevel.jl:28-59; the reference loops the columns inside
     gs!, smoother.jl:77): ONE launch sweeps all columns, a workgroup taking one block for a group of up to 4 (7-point rows) /
@@ -167,11 +168,13 @@ def test_blocks_of_right_hand_sides_on_the_dataflow_layout_equal_the_single_colu
     arithmetic is the single-column kernel's: the block's cycle equals the cycles of its columns bit for bit, with every
     cap on the columns per workgroup, and the oracle's at 1e-10."""
     lib = AMG.hip_lib()
-    if case == "poisson":
+    if case.startswith("poisson"):
         A = AMG.poisson((32, 28, 24))
     else:
         A = AMG.ruge_stuben(AMG.poisson((40, 40, 40)), max_levels=3).levels[1].A
-    ml = AMG.ruge_stuben(A)
+    # (SOR, sor_step! smoother.jl:193-221: forward-only before, backward-only after the coarse correction)
+    ml = (AMG.ruge_stuben(A, presmoother=AMG.SOR(1.2, AMG.ForwardSweep()), postsmoother=AMG.SOR(0.9, AMG.BackwardSweep(), iter=2))
+          if case.endswith("-sor") else AMG.ruge_stuben(A))
     n = A.m
     B = np.stack([uniform(n, 60 + c) - 0.2 * c for c in range(bs)], axis=1)
     # (single columns sum the long rows of merged slot launches with several lanes per row — another order of additions:
