@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import amg_amd as AMG
-from amg_amd.device import DeviceCSR, smooth_standalone
+from amg_amd.device import DeviceCSR, DeviceHierarchy, smooth_standalone
 from conftest import load_csc, uniform
 from oracle import oracle as O
 
@@ -217,3 +217,32 @@ def test_row_sharded_cycle_in_float32():
             return sh.precond_apply(b[sh.r0:sh.r1].astype(dt))
         out[np.dtype(dt).name] = np.concatenate(SH.run_local_ranks(2, work, dtype=dt))
     assert out["float32"].dtype == F32 and rel(out["float32"], out["float64"]) <= F32_TOL
+
+
+@pytest.mark.parametrize("bs", [1, 3, 4])
+def test_float32_dataflow_sweeps_single_columns_and_blocks_of_right_hand_sides(bs):
+    """The Float32 instance of the dataflow sweep (gs_flow.hpp with R = float: 8-byte mailboxes {value, epoch}, 4 values per
+    16-byte chunk), forced onto a small hierarchy: levels really run it (mode 3), blocks of right-hand sides (one walker
+    wave per column) equal their single columns bit for bit, and the cycle is the Float32 oracle's within Float32 rounding
+    (multilevel.jl:28-59, smoother.jl:61-90)."""
+    lib = AMG.hip_lib(F32)
+    A = as_f32_matrix(AMG.poisson((24, 20, 16)))
+    ml = AMG.ruge_stuben(A)
+    n = ml.levels[0].A.m
+    B = np.stack([uniform(n, 10 + c) - 0.3 * c for c in range(bs)], axis=1).astype(F32)
+    for name, v in ((b"gs_bw", 2), (b"gs_bw_rows", 128), (b"gs_lpr", 1), (b"gs_ept", 1)):
+        assert lib.amgh_debug_set_tunable(name, v) == 0
+    try:
+        dev1, devb = DeviceHierarchy(ml, 0, 1, dtype=F32), DeviceHierarchy(ml, 0, bs, dtype=F32)
+        assert lib.amgh_debug_bw_mode(devb.h, 0) == 3 and lib.amgh_debug_bw_mode(dev1.h, 0) == 3
+        Z = devb.precond_apply(B if bs > 1 else B[:, 0].copy())
+        Z = Z.reshape(n, bs)
+        singles = [dev1.precond_apply(B[:, c].copy()) for c in range(bs)]
+        assert lib.amgh_debug_bw_poll_giveups(devb.h, 0) == 0
+    finally:
+        for name, v in ((b"gs_bw", 1), (b"gs_bw_rows", 512), (b"gs_lpr", 0), (b"gs_ept", 0)):
+            lib.amgh_debug_set_tunable(name, v)
+    oh = O.OracleHierarchy(ml, dtype=F32)
+    for c in range(bs):
+        assert np.array_equal(Z[:, c], singles[c]), c
+    assert Z.dtype == F32 and rel(Z[:, bs - 1], oh.precond(np.ascontiguousarray(B[:, bs - 1]))) <= F32_TOL
