@@ -138,6 +138,7 @@ struct Params {
   int threads = 8;
   bool require_three = false;   // give up right after the offset histogram unless it shows three classes (a caller that would
                                 // reject such a plan anyway: saves the passes over the matrix)
+  bool require_two = false;     // ... or at least two (operators large enough for a line-shaped wavefront to pay)
 };
 
 // Returns false when the operator cannot be laid out (rows too long for the LDS budget, local index overflow).
@@ -193,6 +194,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     if (P.cuts[0] > P.cuts[1]) std::swap(P.cuts[0], P.cuts[1]);
   }
   if (prm.require_three && (P.cuts[0] == 99 || P.cuts[1] == 99)) return false;
+  if (prm.require_two && P.cuts[0] == 99 && P.cuts[1] == 99) return false;   // (one class: a chain of slabs)
   lap("offset histogram");
   const int cut0 = P.cuts[0], cut1 = P.cuts[1];
   auto cls = [cut0, cut1](int64_t d) { const int b = 31 - __builtin_clz((unsigned)d); return b <= cut0 ? 0 : b <= cut1 ? 1 : 2; };

@@ -1012,6 +1012,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   if (const char* e = getenv("AMGH_BW_THREADS")) prm.threads = std::max(1, atoi(e));   // (measurement hook)
   // (the cost-model branch below insists on three offset classes, or two on operators of >= gs_bw_two_min_rows rows)
   prm.require_three = g_gs_bw != 2 && !(g_gs_bw_two_min_rows > 0 && n >= g_gs_bw_two_min_rows);
+  prm.require_two = g_gs_bw != 2;
   bw::Plan P;
   try {   // (gigabytes of host memory: out of it, the level keeps the level schedules — nothing crosses the C ABI)
     if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_OK;
