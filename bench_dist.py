@@ -95,11 +95,12 @@ def with_smoother(ml, sm):
 class Run:
     """One measured configuration: a sharded handle, K timed cycles, the assembled result on rank 0."""
 
-    def __init__(self, ctx, label, levels, tail, transport, gs_mode="exact"):
+    def __init__(self, ctx, label, levels, tail, transport, gs_mode="exact", n_tail=None):
         from amg_amd import sharded as SH
         self.ctx, self.label = ctx, label
         t0 = time.perf_counter()
-        self.sh = SH.ShardedHierarchy(levels, ctx["info"]["n_tail"], tail, ctx["rank"], ctx["world"], ctx["device"], transport, gs_mode=gs_mode)
+        self.sh = SH.ShardedHierarchy(levels, ctx["info"]["n_tail"] if n_tail is None else n_tail, tail, ctx["rank"], ctx["world"], ctx["device"],
+                                      transport, gs_mode=gs_mode)
         self.shard_s = time.perf_counter() - t0
         self.transport = transport[0]
 
@@ -339,11 +340,25 @@ def main_distributed(args):
             notes["transport_fallback_reason"] = next((r.get("error", "preflight failed") for r in preflights if r["transport"] == transport), "preflight failed")
             transport = chosen
 
-    def run_config(label, kind, tkind, want_spmv=False, gs_mode="exact"):
+    # Gauss-Seidel in exact lexicographic order sweeps the shards of a level ONE AFTER THE OTHER (one dependency chain through
+    # the grid): every further sharded level adds N turns and N exchanges per sweep and wins nothing — a level that is not
+    # sharded is swept at single-GPU speed on rank 0.  The exact curve therefore shards the finest level only (its operators,
+    # residuals and transfers do scale, and it is the level that has to fit N x 288 GB); what it costs to shard every level of
+    # >= 200 000 rows in exact order is the secondary "gs_exact_all_levels".
+    lc_all = info["lc"]
+    lc_exact = min(1, lc_all)
+    tail_exact = None
+    if rank == 0 and ml is not None and lc_exact < lc_all:
+        tail_exact = AMG.MultiLevel(ml.levels[lc_exact:], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother, ml.symmetry, method=ml.method)
+
+    def run_config(label, kind, tkind, want_spmv=False, gs_mode="exact", all_levels=False):
         lv, tl, ml_k = variant(kind)
+        n_tail = None
+        if kind == "gs" and gs_mode == "exact" and not all_levels and lc_exact < lc_all:
+            lv, tl, n_tail = lv[:lc_exact], tail_exact, info["sizes"][lc_exact]
         run, err = None, None
         try:
-            run = Run(ctx, label, lv, tl, transport_spec(tkind), gs_mode)
+            run = Run(ctx, label, lv, tl, transport_spec(tkind), gs_mode, n_tail=n_tail)
         except AMG.AMGError as e:
             err = str(e)
         if not all_ok(run is not None):
@@ -357,6 +372,7 @@ def main_distributed(args):
         if rank == 0:
             res["parity"] = check_parity(ctx, ml_k, b, z, kind, gs_mode)
         res["gs_mode"] = gs_mode if kind == "gs" else None
+        res["sharded_levels"] = len(lv)
         run.close()
         res["value"] = n * args.steps / res["elapsed"]
         ok = bcast(res["parity"]["ok"] if rank == 0 else None)
@@ -381,11 +397,13 @@ def main_distributed(args):
         if smoother != "jacobi":
             todo.append(("jacobi", "jacobi", transport, "exact"))
             todo.append(("gs_hybrid", "gs", transport, "hybrid"))   # every shard sweeps at once, halo frozen per directional sweep
+            if lc_exact < lc_all:
+                todo.append(("gs_exact_all_levels", "gs", transport, "exact-all"))   # exact order with every large level sharded
         if transport != "ipc":
             todo.append(("ipc", smoother, "ipc", "exact"))
         for label, kind, tkind, mode in todo:
             try:
-                res, e2 = run_config(label, kind, tkind, gs_mode=mode)
+                res, e2 = run_config(label, kind, tkind, gs_mode="exact" if mode == "exact-all" else mode, all_levels=mode == "exact-all")
                 extra[label] = {"error": e2} if res is None else dict(res, **({"error": e2} if e2 else {}))
             except Exception as ex:  # noqa: BLE001
                 extra[label] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
@@ -399,7 +417,8 @@ def main_distributed(args):
         alg = spmv_bytes(info["nnz"], n, n)
         spmv_ms = primary.get("spmv_ms")
         smooth_txt = ("ruge_stuben defaults (symmetric Gauss-Seidel pre+post in exact lexicographic order over the whole level: "
-                      "the ranks sweep in turn, boundary values exchanged between turns — the reference's iterate)"
+                      "the ranks sweep in turn, boundary values exchanged between turns — the reference's iterate; only the finest "
+                      "level is sharded on this curve: a level swept in turns gains nothing from more shards)"
                       if smoother == "gs" else "Jacobi(2/3) pre+post (exact across shards)")
         tr_txt = {"rccl": "RCCL send/recv called by libamghip", "ipc": "hipIpc peer-mapped send buffers + stream-written "
                   "flags in shared memory (libamghip's IPC transport)"}[primary["transport"]]
@@ -409,10 +428,11 @@ def main_distributed(args):
             "value": primary["value"], "unit": "unknowns/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": primary["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "poisson((%d,%d,%d)) 7-point, %s, one V-cycle per step (ldiv!), levels of >= 200000 rows "
+            "config": {"workload": "poisson((%d,%d,%d)) 7-point, %s, one V-cycle per step (ldiv!), large levels "
                                    "1-D row-sharded, neighbour exchange of halo entries before every operator (%s, interior "
                                    "rows overlapped), coarser levels collapsed to rank 0" % (N, N, N, smooth_txt, tr_txt),
-                       "unknowns": n, "nnz": info["nnz"], "levels": info["nlev"], "sharded_levels": info["lc"],
+                       "unknowns": n, "nnz": info["nnz"], "levels": info["nlev"], "sharded_levels": primary.get("sharded_levels", info["lc"]),
+                       "sharded_levels_of_the_secondaries": info["lc"],
                        "smoother": smoother, "transport": primary["transport"],
                        "halo_exchanges_per_cycle": primary["halo_exchanges_per_cycle"],
                        "halo_bytes_sent_per_cycle_max_rank": primary["halo_bytes_sent_per_cycle_max_rank"],
