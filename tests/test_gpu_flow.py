@@ -159,7 +159,7 @@ def test_a_forced_protocol_error_is_an_error_code_not_numbers():
 
 
 @pytest.mark.parametrize("case,bs", [("poisson", 8), ("poisson", 3), ("poisson", 5), ("galerkin", 4), ("galerkin", 7), ("galerkin", 2),
-                                     ("poisson-sor", 4), ("galerkin-sor", 3)])
+                                     ("poisson-sor", 4), ("galerkin-sor", 3), ("poisson", 33)])
 def test_blocks_of_right_hand_sides_on_the_dataflow_layout_equal_the_single_columns_bit_for_bit(case, bs):
     """bs > 1 (`MultiLevelWorkspace{TX,bs}`, /root/reference/src/multilevel.jl:28-59; the reference loops the columns inside
     gs!, smoother.jl:77): ONE launch sweeps all columns, a workgroup taking one block for a group of up to 4 (7-point rows) /
