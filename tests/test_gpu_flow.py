@@ -265,3 +265,29 @@ def test_soak_2000_sweeps_under_memory_load_eager_and_graph_replayed(soak_fixtur
     assert launched[0] > 200 and not raised     # the load really ran beside the cycles
     assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0 and lib.amgh_dev_sync(0) == 0
 
+
+
+def test_soak_blocks_of_eight_right_hand_sides_at_full_size(soak_fixture):
+    """The 256^3 hierarchy with workspace block size 8: 80 V-cycles (eager, then replayed from a hipGraph) = 640 dataflow
+    launches of 4 column groups x 32 768 / 16 559 blocks, the same block of right-hand sides every time: every result equals
+    the first bit for bit, its columns equal the single-column cycles bit for bit, give-ups 0."""
+    A, ml, dev1 = soak_fixture
+    lib = AMG.hip_lib()
+    n, bs = A.m, 8
+    B = np.stack([uniform(n, 20 + c) - 0.1 * c for c in range(bs)], axis=1)
+    dev = DeviceHierarchy(ml, 0, bs)
+    assert lib.amgh_debug_bw_mode(dev.h, 0) == 3 and lib.amgh_debug_bw_mode(dev.h, 1) == 3
+    Z1 = dev.precond_apply(B)
+    # (levels 2-3: single columns sum long composite rows with several lanes per row — compare like with like)
+    with tunables(lib, gs_lpr=1, gs_ept=1):
+        Zl = dev.precond_apply(B)
+        for c in (0, 5, 7):
+            assert np.array_equal(Zl[:, c], dev1.precond_apply(B[:, c].copy())), c
+    try:
+        for graph in (0, 1):
+            assert lib.amgh_set_use_graph(dev.h, graph) == 0
+            for k in range(40):
+                assert np.array_equal(dev.precond_apply(B), Z1), (graph, k)
+    finally:
+        lib.amgh_set_use_graph(dev.h, 0)
+    assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0 and lib.amgh_dev_sync(0) == 0
