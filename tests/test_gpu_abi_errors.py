@@ -240,3 +240,28 @@ def test_sharded_abi_error_codes():
     assert lib.amgh_strerror(-2005).decode().startswith("RCCL error 5")
     lib.amgh_dist_destroy(d)
     lib.amgh_local_group_destroy(g)
+
+
+def test_setup_entry_points_reject_bad_arguments():
+    """The GPU half of the setup (amgh_setup_*): non-square operators, null outputs and null inputs are AMGH_EINVAL (-2),
+    never a crash; a sweep of more right-hand-side columns than a handle was created for cannot be asked for at all
+    (amgh_create fixes the block size: multilevel.jl:28-59)."""
+    import ctypes as C
+    from amg_amd.hierarchy import _DMat
+    lib = AMG.hip_lib()
+    A = AMG.poisson((12, 10))
+    dA = _DMat.upload(A, lib)
+    R = AMG.ruge_stuben(A).levels[0].R                       # nc x n: not square
+    dR = _DMat.upload(R, lib)
+    out = C.c_void_p()
+    assert lib.amgh_setup_symmetric_strength(dR.h, 0.0, 0, C.byref(out)) == -2
+    assert lib.amgh_setup_symmetric_strength(dA.h, 0.0, 0, None) == -2
+    assert lib.amgh_setup_symmetric_strength(None, 0.0, 0, C.byref(out)) == -2
+    b = np.ones(A.m)
+    bc = np.zeros(A.m)
+    assert lib.amgh_setup_fit_candidates_vector(dA.h, None, 1e-10, C.byref(out), bc.ctypes.data) == -2
+    assert lib.amgh_setup_fit_candidates_vector(dA.h, b.ctypes.data, 1e-10, None, bc.ctypes.data) == -2
+    assert lib.amgh_setup_fit_candidates_vector(None, b.ctypes.data, 1e-10, C.byref(out), bc.ctypes.data) == -2
+    assert lib.amgh_debug_set_tunable(b"gs_bw_nc", 2) == 0 and lib.amgh_debug_set_tunable(b"no_such_tunable", 1) == -2
+    h = C.c_void_p()
+    assert lib.amgh_create(C.byref(h), 0, 65) != 0 and lib.amgh_create(C.byref(h), 0, 0) != 0      # 1 <= nrhs <= 64
