@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--light", action="store_true", help="profiling runs: skip the extra smoother timing")
+    ap.add_argument("--no-block-rhs", action="store_true", help="skip the secondary measurement on a block of 8 right-hand sides")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--force-dist", action="store_true", help="run the row-sharded driver even with one rank")
     ap.add_argument("--transport", default=None, choices=("rccl", "ipc"),
@@ -280,6 +281,38 @@ def main():
         **({"overlap_error": overlap_error} if overlap_error else {}),
         "hbm_bytes": dev.device_bytes(), "hbm_bytes_by_category": dev.device_bytes_detail(),
     }
+    if not args.light and not args.no_block_rhs:
+        # secondary (never `value`): the same cycle on a block of 8 right-hand sides (workspace block size 8,
+        # multilevel.jl:28-59) — one launch per sweep carries all columns; first column checked bitwise against the timed
+        # single-column result above (same b in column 0).  A failure here never costs the primary line.
+        try:
+            bs = 8
+            t0 = time.perf_counter()
+            devb = ml.device(0, bs)
+            t_layout = time.perf_counter() - t0
+            Bh = np.stack([b] + [uniform(n, 100 + c) for c in range(1, bs)], axis=1)
+            Bd = AMG.DeviceBuffer(n * bs, 0, np.asfortranarray(Bh).ravel(order="F"))
+            Zd = AMG.DeviceBuffer(n * bs, 0)
+            for _ in range(2):
+                if lib.amgh_precond_apply_d(devb.h, Bd.ptr, Zd.ptr, 0) != 0:
+                    raise RuntimeError("precond_apply on the block failed")
+            lib.amgh_dev_sync(0)
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                lib.amgh_precond_apply_d(devb.h, Bd.ptr, Zd.ptr, 0)
+            lib.amgh_dev_sync(0)
+            ms8 = 1e3 * (time.perf_counter() - t0) / reps
+            z8 = Zd.download()[:n]
+            out["block_of_right_hand_sides"] = {
+                "bs": bs, "ms_per_cycle": ms8, "unknowns_per_s": n * bs / (ms8 * 1e-3), "speedup_vs_columns_one_by_one": bs * ms_per_step / ms8,
+                "layout_s": t_layout, "hbm_bytes": devb.device_bytes(),
+                "first_column_rel_diff_vs_single_column_cycle": float(np.linalg.norm(z8 - z_timed) / np.linalg.norm(z_timed)),
+                "block_wavefront_mode_by_level": [int(lib.amgh_debug_bw_mode(devb.h, l)) for l in range(len(ml.levels))]}
+            del Bd, Zd, devb
+            ml._dev.pop((0, bs), None) if hasattr(ml, "_dev") else None
+        except Exception as ex:  # noqa: BLE001
+            out["block_of_right_hand_sides"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"], z_oracle = cpu_baseline(ml, b, args.cpu_budget)
         # parity of the TIMED result (checked outside the timed region): the last V-cycle's output against the oracle
