@@ -461,8 +461,13 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
     if (x_resident) {
       // nothing: g->xp holds x
     } else if (xzero) {
-      const int64_t cnt = xs * ncolv;  // (a fill kernel: hipMemsetAsync of a small buffer costs far more than a launch)
-      hipLaunchKernelGGL(fill_kernel, dim3(grid_for(cnt)), dim3(256), 0, st, g->xp, cnt, 0.0);
+      // (a dataflow sweep of a square operator from x = 0 needs no x in memory at all: every block starts from zeros in LDS
+      // and writes all its rows — see flow_xzero below)
+      const bool flow_zero = g_gs_flow_xzero && g->bw.on && g->bw.flow.on && (g_gs_bw_flow || !g->bw.rec) && g->ncols == g->n && lay == g;
+      if (!flow_zero) {
+        const int64_t cnt = xs * ncolv;  // (a fill kernel: hipMemsetAsync of a small buffer costs far more than a launch)
+        hipLaunchKernelGGL(fill_kernel, dim3(grid_for(cnt)), dim3(256), 0, st, g->xp, cnt, 0.0);
+      }
     } else {
       hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const real*)x, g->permx,
                          g->xp, (int)g->ncols, (int64_t)g->ncols, xs);
@@ -520,6 +525,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
                             g->bw.flow.mbox, rhs, xp, omega, g->bw.head + 1, g->bw.nblocks, (int32_t)g->bw.flow.nmail,
                             g->bw.err, nullptr, (unsigned)g_gs_bw_spin, (int32_t)g_gs_bw_skip_pub};
       fa.ldb = ldb; fa.ldx = xs; fa.mail_stride = g->bw.flow.mail_stride;
+      fa.xzero = (g_gs_flow_xzero && first && xzero && !x_resident && g->ncols == g->n) ? 1 : 0;   // the sweep that starts a smooth! call on x = 0
       if (ncolv > g->bw.flow.mcols) return AMGH_ESTATE;   // (gs_ensure_cols sized the mailboxes)
       e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);
     } else {

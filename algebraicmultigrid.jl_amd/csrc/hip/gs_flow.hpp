@@ -268,6 +268,7 @@ struct FlowArgs {
   int64_t ldb = 0, ldx = 0, mail_stride = 0;
   int32_t lds_stride = 0;
   int32_t ncols = 1, ngroups = 1;    // columns of the launch, groups of <= NC columns they are swept in (grid = blocks x groups)
+  int32_t xzero = 0;                 // x is zero on entry and need not be read: every block starts from zeros in LDS (the x in memory may hold anything)
 };
 
 template <typename R> struct Mail;
@@ -467,6 +468,13 @@ __global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_f
 #pragma unroll
     for (int c = 0; c < NC; ++c) { xc[c] = uniform_ptr(col_x(c < nch ? c : 0)); xlc[c] = (R*)col_lds(c); }
     const int nfar = BWD ? d.npre + (d.next - d.npre - f.npost) : d.next - d.npre;
+    if (a.xzero) {   // (x = 0 everywhere: the far side is zeros, nothing to gather)
+      for (int e0 = 0; e0 < d.next; e0 += 64) {
+        const int i = e0 + lane;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (i < d.next && c < nch) xlc[c][d.nrows + i] = (R)0;
+      }
+    } else
     for (int e0 = 0; e0 < nfar; e0 += 64 * EU) {
       int32_t ec[EU]; int es[EU];
 #pragma unroll
@@ -541,6 +549,9 @@ __global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_f
     // the walker's half of the load phase: its column's own rows into LDS (one batch of loads for blocks of up to 512 rows),
     // finished — the compiler waits for them before the LDS writes — before the hand-counted pipeline starts
     constexpr int XW = 8;
+    if (a.xzero) {
+      for (int p = lane; p < d.nrows; p += 64) xl[p] = (R)0;
+    } else
     for (int p0 = 0; p0 < d.nrows; p0 += 64 * XW) {
       R xv[XW];
 #pragma unroll

@@ -514,7 +514,8 @@ int amgh_debug_bw_mode(const amgh_t* h, int l);
  * wavefront of blocks as ONE launch per sweep, blocks chained by flags; 0: one launch per depth of the quotient graph —
  * bitwise the same sweep), "gs_bw_nc" (columns of a block of right-hand sides one workgroup of the dataflow sweep carries: 2;
  * 0 = as many as are instantiated), "gs_bw_spin" / "gs_bw_skip_pub" (test hooks: bound of a poll, a block that publishes
- * nothing), "gs_dup_launch" (measurement hook: every merged-group launch issued 1 + that many times).
+ * nothing), "gs_flow_xzero" (1: a dataflow sweep that starts a smooth! call on x = 0 reads no x — bitwise the same),
+ * "gs_dup_launch" (measurement hook: every merged-group launch issued 1 + that many times).
  * Returns AMGH_EINVAL for an unknown name.                                                                       */
 int amgh_debug_set_tunable(const char* name, int value);
 

@@ -26,7 +26,7 @@ def rel(x, y):
 class tunables:
     """amgh_debug_set_tunable for the duration of a with block (values restored to the given defaults)."""
     DEFAULTS = {"gs_bw": 1, "gs_bw_rows": 512, "gs_bw_chain": 1, "gs_bw_flow": 1, "gs_lean": -1, "gs_bw_spin": 0, "gs_bw_skip_pub": -1,
-                "gs_lpr": 0, "gs_ept": 0, "gs_bw_nc": 2, "gs_bw_nrhs": 1}
+                "gs_lpr": 0, "gs_ept": 0, "gs_bw_nc": 2, "gs_bw_nrhs": 1, "gs_flow_xzero": 1}
 
     def __init__(self, lib, **kw):
         self.lib, self.kw = lib, kw
@@ -113,6 +113,29 @@ def test_dataflow_default_footprint_keeps_only_its_own_layout_and_cycles_match_t
     xo, ho, ito = oh.solve(b, reltol=1e-9, maxiter=50)
     assert its == ito and rel(x, xo) <= 1e-10 and rel(hist, ho) <= 1e-8
     assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+def test_sweeps_that_start_from_zero_read_no_x_and_give_the_same_bits(bs):
+    """Every pre-smoother of a cycle below the fine level, and the fine one of ldiv!, starts from x = 0
+    (multilevel.jl:214-221): the dataflow sweep then fills its blocks' LDS with zeros instead of reading x (and nothing
+    zeroes x in memory first) — the same arithmetic on the same values: bit for bit the cycle that reads x, for V / W / F
+    cycles (W and F revisit levels with x != 0: those sweeps read x as ever), SOR included."""
+    lib = AMG.hip_lib()
+    A = AMG.poisson((30, 28, 26))
+    n = A.m
+    B = np.stack([uniform(n, 40 + c) - 0.2 for c in range(bs)], axis=1)
+    for kw in (dict(), dict(presmoother=AMG.SOR(1.3), postsmoother=AMG.SOR(0.8, AMG.BackwardSweep()))):
+        ml = AMG.ruge_stuben(A, **kw)
+        with tunables(lib, gs_bw=2, gs_bw_rows=128):
+            dev = DeviceHierarchy(ml, 0, bs)
+            assert lib.amgh_debug_bw_mode(dev.h, 0) == 3
+            rhs = B if bs > 1 else B[:, 0].copy()
+            for cyc in (0, 1, 2):
+                z_fast = dev.precond_apply(rhs, cyc)
+                with tunables(lib, gs_flow_xzero=0):
+                    assert np.array_equal(dev.precond_apply(rhs, cyc), z_fast), (cyc, kw)
+        assert rel(z_fast.reshape(n, bs)[:, 0], O.OracleHierarchy(ml).precond(B[:, 0].copy(), cycle=2)) <= 1e-10
 
 
 def test_dataflow_declines_structurally_nonsymmetric_patterns():
