@@ -1009,9 +1009,11 @@ int amgh_device_bytes_detail(const amgh_t* h, int64_t* out8) {
   out8[7] = h->ws_bytes + ((h->ncoarse > 0 && h->coarse_op) ? h->ncoarse * h->ncoarse * kRealB : 0);
   return AMGH_OK;
 }
-// Diagnostics of the chained wavefront of blocks (gs_bw_chain_kernel): how many flag polls gave up (always 0: a block
-// only waits for blocks with smaller tickets; the bound turns a protocol error into wrong numbers instead of a hang).
-// -1 when level l has no such schedule.  Synchronises the device.
+// Diagnostics of the chained / dataflow wavefront of blocks: the poll give-up word (always 0: a block only waits for
+// blocks with smaller tickets).  The bound turns a protocol error into an ERROR instead of a hang: a give-up raises this
+// word and the next synchronising entry point (amgh_solve, amgh_precond_apply, amgh_pcg, amgh_dev_sync, amgh_dist_*)
+// returns AMGH_ESTATE — the values of that sweep are not to be used.  -1 when level l has no such schedule.
+// Synchronises the device; reads the word without clearing it.
 int amgh_debug_bw_poll_giveups(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
   amgh_csr* M = h->levels[l]->smat();
@@ -1736,7 +1738,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_bw_skip_pub")) g_gs_bw_skip_pub = value;
   else if (!strcmp(name, "gs_bw_min_rows")) g_gs_bw_min_rows = value;
   else if (!strcmp(name, "gs_bw_two_min_rows")) g_gs_bw_two_min_rows = value;
-  else if (!strcmp(name, "gs_dup_launch")) g_gs_dup_launch = value;
+  else if (!strcmp(name, "gs_dup_launch")) g_gs_dup_launch = value < 0 ? 0 : value > 16 ? 16 : value;   // (a repeat count: never negative)
   else if (!strcmp(name, "gs_flow_xzero")) g_gs_flow_xzero = value;
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;
   else if (!strcmp(name, "jacobi_zero")) g_jacobi_zero = value;

@@ -1063,7 +1063,8 @@ int amgh_dist_solve_d(amgh_dist_t* d, const real* b_loc_d, real* x_loc_d, int cy
   }
   if (iters) *iters = itr - 1;
   if (n > 0) HIP_TRY(hipMemcpyAsync(x_loc_d, dist_x0(d), sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
-  return d->tr->wait_stream(d->stream);
+  RC_TRY(d->tr->wait_stream(d->stream));
+  return bw_err_check();   // (sharded levels and the tail sweep by dataflow kernels too: a poll give-up is this call's error)
 }
 
 // y_loc = A_level x_loc with the halo exchange in front (roofline hook of the sharded SpMV).  Enqueue only.
@@ -1084,7 +1085,8 @@ int amgh_dist_sync(amgh_dist_t* d) {
   if (!d) return AMGH_EINVAL;
   if (d->host_only) return AMGH_OK;
   HIP_TRY(hipSetDevice(d->device));
-  return d->tr->wait_stream(d->stream);
+  RC_TRY(d->tr->wait_stream(d->stream));
+  return bw_err_check();   // (what amgh_dist_precond_apply_d enqueued has run: a sweep that gave up a poll is reported here)
 }
 int amgh_dist_barrier(amgh_dist_t* d) {
   if (!d) return AMGH_EINVAL;

@@ -329,10 +329,14 @@ int gs_ensure_cols(amgh_csr* op, int ncolv, hipStream_t st) {
     grown += 8 * g->n * (ncolv - g->cols_alloc);
   }
   if (g->bw.flow.on && ncolv > g->bw.flow.mcols) {   // every column has its own mailboxes (epoch 0 is never a sweep's)
+    // (the new buffer is allocated and zeroed BEFORE the old one goes: a failure here leaves the old mailboxes and their
+    // column count in place, so that sweeps of fewer columns keep working)
     const size_t mb = (size_t)g->bw.flow.mail_stride * (size_t)ncolv;
-    (void)hipFree(g->bw.flow.mbox); g->bw.flow.mbox = nullptr;
-    if (hipMalloc(&g->bw.flow.mbox, mb) != hipSuccess) { (void)hipGetLastError(); g->bw.flow.mcols = 0; return AMGH_ENOMEM; }
-    if (hipMemset(g->bw.flow.mbox, 0, mb) != hipSuccess) return -1001;
+    void* fresh = nullptr;
+    if (hipMalloc(&fresh, mb) != hipSuccess) { (void)hipGetLastError(); return AMGH_ENOMEM; }
+    if (hipMemset(fresh, 0, mb) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(fresh); return -1001; }
+    (void)hipFree(g->bw.flow.mbox);
+    g->bw.flow.mbox = fresh;
     const int64_t more = g->bw.flow.mail_stride * (int64_t)(ncolv - g->bw.flow.mcols);
     g->bw.flow.bytes += more; g->bw.rec_bytes += more; g->slot_bytes += more;
     grown += more;

@@ -124,8 +124,13 @@ inline void parallel_for(int T, F fn) {
   if (T <= 1) { fn(0, 1); return; }
   std::vector<std::thread> th;
   std::vector<std::exception_ptr> err((size_t)T);
-  for (int t = 1; t < T; ++t)
-    th.emplace_back([=, &err] { try { fn(t, T); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+  try {
+    for (int t = 1; t < T; ++t)
+      th.emplace_back([=, &err] { try { fn(t, T); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+  } catch (...) {   // (a thread could not be created: the ones that run are joined before the exception travels on — a
+    for (auto& x : th) x.join();   // joinable std::thread destroyed would be std::terminate)
+    throw;
+  }
   try { fn(0, T); } catch (...) { err[0] = std::current_exception(); }
   for (auto& x : th) x.join();
   for (auto& e : err) if (e) std::rethrow_exception(e);
@@ -139,6 +144,8 @@ struct Params {
   bool require_three = false;   // give up right after the offset histogram unless it shows three classes (a caller that would
                                 // reject such a plan anyway: saves the passes over the matrix)
   bool require_two = false;     // ... or at least two (operators large enough for a line-shaped wavefront to pay)
+  bool flow_only = false;       // the plan will only be executed by the dataflow kernel (gs_flow.hpp): a block's LDS holds its x,
+                                // not its record — the record's bytes do not bound the rows of a block (long rows: levels 2+)
 };
 
 // Returns false when the operator cannot be laid out (rows too long for the LDS budget, local index overflow).
@@ -223,7 +230,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   lap("potentials + levels");
   P.nlevels = *std::max_element(lev.begin(), lev.end()) + 1;
   // ---- rows per block from the LDS budget ----
-  const size_t per_row = Packed<R>::row_bytes(maxk) + 2 * sizeof(R) + 2 * sizeof(R);   // packed row + b + x + ~2 external values
+  const size_t per_row = (prm.flow_only ? 0 : Packed<R>::row_bytes(maxk)) + 2 * sizeof(R) + 2 * sizeof(R);   // packed row + b + x + ~2 external values
   int cap = (int)std::min<size_t>(prm.max_rows, prm.lds_limit / per_row);
   cap = (cap / 64) * 64;
   if (cap < 64) return false;
@@ -460,7 +467,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     if (rec_total / 16 > (size_t)INT32_MAX) fits = false;
     d.rec = (int32_t)(rec_total / 16);
     rec_total += Packed<R>::rec_bytes(d.nrows, d.maxk, d.nlev);
-    const size_t l = Packed<R>::lds_bytes(d);
+    const size_t l = prm.flow_only ? (((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15) + 16 : Packed<R>::lds_bytes(d);
     P.lds_max = std::max(P.lds_max, l);
     if (d.nrows + d.next + 1 > 65535 || d.nlev > 65534 || l > 160 * 1024 - 64) fits = false;   // (- 64: the chained kernel's static LDS)
     if ((size_t)(d.nrows + d.next + 1) * sizeof(R) > 65535) fits = false;   // byte offsets in 16 bits

@@ -1,0 +1,439 @@
+// gs_relay.hpp — the dataflow sweep of gs_flow.hpp with a block's walk RELAYED between several waves.
+// Included by gs_schedule.hpp (single-column sweeps of block-ordered levels) and tools/block_wave_bench.hip.
+//
+// smoother.jl:61-90 (gs!) / :193-221 (sor_step!) in exact lexicographic order: the same plan, records, mailboxes, fetcher
+// and arithmetic as gs_bw_flow_kernel — what changes is WHO walks.  A single wave64 pays ~3 ns per instruction whatever it
+// is (tools/wave_chain_probe), and a step of the walk is ~110 (7-point rows) to ~250 (19-point rows) instructions of which
+// only the tail — gather the x of the rows just computed, the ordered sum, the quotient, the LDS store — depends on the
+// previous step: the walk of gs_bw_flow_kernel is bound by what one wave can ISSUE (0.24 / 0.38 us per step with the
+// operands in LDS, 0.40 / 0.50 us streamed), not by the chain of dependent operations (~0.07 us).  Here W walker waves take
+// the steps of a block in turn (step k belongs to wave k mod W): a wave unpacks its step's record, computes its LDS
+// addresses and its mailbox address, issues the loads of its step after next, all of it while the W - 1 steps in front of
+// its own are being computed by the other waves (each on its own SIMD's issue port); then it waits for the block's DONE word
+// in LDS (steps finished so far, written behind the x of a step by the wave that computed it — LDS operations of one
+// wave execute in program order, so whoever reads the word sees the values), runs the dependent tail, stores x and the word.
+// Per step the critical path is the hand-over (one LDS round trip) + the tail.  W x D steps of records are in flight in
+// registers (D sets per wave), which also covers the HBM latency the single walker's D = 3-4 steps did not.
+// Everything else — tickets in depth order, publish-as-computed mailboxes, the fetcher wave, bounded polls that raise
+// *err — is gs_flow.hpp's.  Per row the arithmetic is unchanged: bitwise the scalar loop.
+#pragma once
+#include "gs_flow.hpp"
+
+namespace amgh {
+namespace bw {
+
+#ifndef BW_RELAY_W
+#define BW_RELAY_W 4                    // default walker waves per block
+#endif
+
+// walker waves / register sets per wave / waves per SIMD the kernel is compiled for
+#ifndef BW_RELAY_DEPTH_SHORT
+#define BW_RELAY_DEPTH_SHORT 3          // register sets per walker wave, rows of <= 12 entries ...
+#endif
+#ifndef BW_RELAY_DEPTH_LONG
+#define BW_RELAY_DEPTH_LONG 2           // ... and of up to 18
+#endif
+template <int MAXK> struct RelayDepth { static constexpr int value = MAXK <= 12 ? BW_RELAY_DEPTH_SHORT : BW_RELAY_DEPTH_LONG; };
+template <int MAXK> struct RelayWaves { static constexpr int value = MAXK <= 6 ? 4 : 2; };
+
+// LDS by its 32-bit address (the walkers keep absolute LDS addresses in registers: nothing is added behind the hand-over)
+template <typename T> __device__ __forceinline__ T lds_get(unsigned addr) { return *(const __attribute__((address_space(3))) T*)(unsigned long long)addr; }
+template <typename T> __device__ __forceinline__ void lds_put(unsigned addr, T v) { *(__attribute__((address_space(3))) T*)(unsigned long long)addr = v; }
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) unsigned char*)p; }
+
+// control words of a block, behind its x in LDS (16 bytes, 16-byte aligned): one ds_read_b128 polls them all
+//   [0] progress: leading entries of the fetch list that have arrived (the fetcher)   [1] done: steps finished (the walkers)
+//   [2] bail: somebody gave up a poll — nobody waits any more                          [3] unused
+template <typename R, bool SOR, bool BWD, int MAXK, int W>
+__global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_relay_kernel(FlowArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+  static_assert(W >= 2 && W <= 7, "walker waves per block");
+  typedef FlowOps<R, MAXK> O;
+  typedef Mail<R> M;
+  constexpr int D = RelayDepth<MAXK>::value;
+  constexpr int RB = (int)sizeof(R);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63u);
+  const bool fetcher = wv == W;
+  const long long t_start = a.tim ? wall_clock64() : 0;
+  unsigned long long* s_ticket = (unsigned long long*)lds_all;
+  if (blockIdx.x < 2048u) for (unsigned i = 0; i < (blockIdx.x >> 5); ++i) __builtin_amdgcn_s_sleep(14);   // (staggered draws: gs_flow.hpp)
+  if (threadIdx.x == 0) *s_ticket = atomicAdd(a.head, 1ull);
+  __syncthreads();
+  const unsigned long long tv = *s_ticket;
+  const unsigned long long ticket = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
+  __syncthreads();   // (the word is x[0] from here on)
+  const unsigned int units = (unsigned int)a.nblocks;
+  const unsigned int ut = (unsigned int)ticket, sweeps = (unsigned int)(ticket >> 32);
+  const unsigned int epoch = sweeps + 1u;
+  if (threadIdx.x == 0 && ut == units - 1u)
+    __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u == 0u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int tk = (int)ut;
+  const int ob = __builtin_amdgcn_readfirstlane(BWD ? a.nblocks - 1 - tk : tk);
+  const Desc d = a.blocks[ob];
+  const FlowDesc f = a.fd[ob];
+  const int ns = d.nlev;
+  const int nxb = (int)(((size_t)(d.nrows + d.next + 1) * sizeof(R) + 15) & ~(size_t)15);
+  const unsigned spin_limit = a.spin_limit ? a.spin_limit : (1u << 22);
+  unsigned char* lds = lds_all;
+  R* xl = (R*)lds;
+  unsigned int* ctl = (unsigned int*)(lds + nxb);
+  R* x = a.x;
+  if (fetcher) {
+    // ---- load phase, the fetcher's half: the external columns of the far side as they stand (gs_flow.hpp) ----
+    constexpr int EU = 4;
+    const R* xc = uniform_ptr(x);
+    const int nfar = BWD ? d.npre + (d.next - d.npre - f.npost) : d.next - d.npre;
+    if (a.xzero) {
+      for (int e0 = 0; e0 < d.next; e0 += 64) { const int i = e0 + lane; if (i < d.next) xl[d.nrows + i] = (R)0; }
+    } else
+    for (int e0 = 0; e0 < nfar; e0 += 64 * EU) {
+      int32_t ec[EU]; int es[EU];
+#pragma unroll
+      for (int k = 0; k < EU; ++k) {
+        const int i = e0 + lane + 64 * k;
+        es[k] = BWD ? (i < d.npre ? i : i + f.npost) : d.npre + i;
+        ec[k] = a.ext_col[i < nfar ? d.ext0 + es[k] : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < EU; ++k) pin(ec[k]);
+      R xe[EU];
+#pragma unroll
+      for (int k = 0; k < EU; ++k) xe[k] = xc[ec[k]];
+#pragma unroll
+      for (int k = 0; k < EU; ++k) pin(xe[k]);
+#pragma unroll
+      for (int k = 0; k < EU; ++k) { const int i = e0 + lane + 64 * k; if (i < nfar) xl[d.nrows + es[k]] = xe[k]; }
+    }
+    if (lane == 0) { xl[d.nrows + d.next] = (R)0; ctl[0] = 0u; ctl[1] = 0u; ctl[2] = 0u; ctl[3] = 0u; }
+  }
+  const bool walker = !fetcher;
+  // my steps: wv, wv + W, ...; step words by scalar loads one issue ahead (gs_flow.hpp)
+  const uint32_t* ax = a.aux + f.aux + (BWD ? ns + 1 : 0);
+  typedef const uint32_t __attribute__((address_space(4))) cu32;
+  const cu32* axc = (const cu32*)(unsigned long long)uniform_ptr(ax);
+  unsigned sw_next = axc[wv < ns ? wv : ns];
+  const i32x4 rs_rec = make_rsrc(a.srec + (size_t)(uint32_t)d.rec * 16);
+  const i32x4 rs_b = make_rsrc(a.b + d.row0);
+  const i32x4 rs_x = make_rsrc(x + d.row0);
+  const i32x4 rs_mst = make_rsrc(a.mbox);
+  // operands of walking step kk (one of mine) into o; steps behind the last one: a harmless re-read of the block's first chunk
+  auto issue = [&](O& o, int kk) {
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)sw_next);
+    sw_next = axc[kk + W < ns ? kk + W : ns];
+    const int r0 = (int)(w & ((1u << kStepRowBits) - 1)), nr = (int)((w >> kStepRowBits) & ((1u << kStepCntBits) - 1));
+    o.need = (int)(w >> (kStepRowBits + kStepCntBits));
+    const int tt = lane < nr ? lane : 0;
+    o.p = r0 + tt;
+    const unsigned voff = (unsigned)tt * 16u;
+    const unsigned s0 = (unsigned)r0 * (16u * O::KCH), sd = (unsigned)nr * 16u;
+#pragma unroll
+    for (int c = 0; c < O::NVC - 1; ++c) asm_load<4>(o.vf[c], voff, rs_rec, s0 + (unsigned)c * sd);
+    asm_load<O::VTAIL>(o.vt, voff, rs_rec, s0 + (unsigned)(O::NVC - 1) * sd);
+#pragma unroll
+    for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)(O::NVC + c) * sd);
+    asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NVC + O::NCC - 1) * sd);
+    asm_load<RB / 4>(o.bb, (unsigned)tt * RB, rs_b, (unsigned)r0 * RB);
+  };
+  O ops[D];
+  if (walker) {
+    // the walkers' half of the load phase: the block's own rows into LDS, a share each
+    constexpr int XW = W >= 4 ? 2 : 4;
+    if (a.xzero) {
+      for (int p = wv * 64 + lane; p < d.nrows; p += 64 * W) xl[p] = (R)0;
+    } else
+    for (int p0 = wv * 64 * XW; p0 < d.nrows; p0 += 64 * XW * W) {
+      R xv[XW];
+#pragma unroll
+      for (int k = 0; k < XW; ++k) { const int p = p0 + lane + 64 * k; xv[k] = x[d.row0 + (p < d.nrows ? p : 0)]; }
+#pragma unroll
+      for (int k = 0; k < XW; ++k) pin(xv[k]);
+#pragma unroll
+      for (int k = 0; k < XW; ++k) { const int p = p0 + lane + 64 * k; if (p < d.nrows) xl[p] = xv[k]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the compiler's in flight when the counted loads start)
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(ops[j], wv + j * W);
+  }
+  __syncthreads();
+  if (fetcher) {
+    // ---- the fetcher: near-side values out of their mailboxes in the order the walk needs them (gs_flow.hpp, one column) ----
+    constexpr int U = 3;
+    const int nf = BWD ? f.npost : d.npre;
+    const int f0 = d.ext0 + (BWD ? d.npre : 0);
+    const __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.mbox), 0, 0x7ffffff0, 0x00020000);
+    unsigned total_spins = 0;
+    bool fail = false;
+#ifdef BW_RELAY_STAMPS
+    long long* t_seen = a.tim + 4 * (int64_t)a.nblocks + 384 * (int64_t)a.nblocks + ((int64_t)a.nmail + 1024);
+    long long poll_sum = 0, poll_max = 0, npoll = 0;
+#endif
+    for (int w0 = 0; w0 < nf && !fail; w0 += 64 * U) {
+      int32_t mb[U]; int slot[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = w0 + 64 * u + lane;
+        mb[u] = a.fl_mb[e < nf ? f0 + e : f0];
+        slot[u] = a.fl_slot[e < nf ? f0 + e : f0];
+        ok[u] = !(e < nf);
+      }
+      int first = 0;
+      for (;;) {
+        typename M::cell cl[U];
+#ifdef BW_RELAY_STAMPS
+        const long long tp0 = wall_clock64();
+#endif
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (!ok[u] && 64 * u <= first + 64) cl[u] = M::load(rs_mail, (unsigned)mb[u] * (unsigned)M::kBytes);
+#ifdef BW_RELAY_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long tp1 = wall_clock64();
+        poll_sum += tp1 - tp0; poll_max = poll_max > tp1 - tp0 ? poll_max : tp1 - tp0; ++npoll;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (a.tim && !ok[u] && 64 * u <= first + 64 && M::valid(cl[u], epoch)) t_seen[mb[u]] = tp1;
+#endif
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (!ok[u] && 64 * u <= first + 64 && M::valid(cl[u], epoch)) { xl[slot[u]] = M::value(cl[u]); ok[u] = true; }
+        int nfirst = 64 * U;
+#pragma unroll
+        for (int u = U - 1; u >= 0; --u) {
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(!ok[u]);
+          if (m) nfirst = 64 * u + (int)__builtin_ctzll(m);
+        }
+        const bool moved = nfirst != first;
+        if (moved && lane == 0) __hip_atomic_store(ctl, (unsigned)(w0 + nfirst < nf ? w0 + nfirst : nf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        first = nfirst;
+        if (nfirst == 64 * U) break;
+        if (!moved) __builtin_amdgcn_s_sleep(4);
+        if (++total_spins > spin_limit) { fail = true; break; }
+      }
+    }
+    if (fail && lane == 0) {
+      *a.err = 1;
+      __hip_atomic_store(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#ifdef BW_RELAY_STAMPS
+    if (a.tim && lane == 0) {
+      long long* q = a.tim + 4 * (int64_t)a.nblocks + 384 * (int64_t)a.nblocks + 2 * ((int64_t)a.nmail + 1024) + 4 * (int64_t)ob;
+      q[0] = npoll; q[1] = poll_sum; q[2] = poll_max; q[3] = 0;
+    }
+#endif
+    return;
+  }
+  // ---- a walker ----
+  __builtin_amdgcn_s_setprio(2);
+  const long long t_loaded = a.tim ? wall_clock64() : 0;
+  const int32_t pubdir = BWD ? kPubBwd : kPubFwd;
+  const bool mute = a.skip_pub == tk;
+  const unsigned spare = (unsigned)a.nmail + (unsigned)(ob & 1023);
+  bool gave_up = false, bail = false;
+  const unsigned xl_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(xl));
+  const unsigned ctl_off = xl_base + (unsigned)nxb;   // (LDS address of the control words)
+#ifdef BW_RELAY_STAMPS   // (measurement builds: three wall-clock stamps per step in LDS behind the control words, dumped at the end;
+  // per mailbox the time its row was published (a counted third store of the step) and the time its reader's fetcher saw it)
+  const unsigned stamp_base = xl_base + (unsigned)nxb + 16u;
+  i32x4 rs_pub = make_rsrc(a.tim + 4 * (int64_t)a.nblocks + 384 * (int64_t)a.nblocks);
+  if (!a.tim) rs_pub.z = 0;   // (no stamps asked for: zero records, the stores fall out of range and are dropped)
+#endif
+  auto step = [&](const O& o, int kk) {
+#ifdef BW_RELAY_STAMPS
+    const long long t_rec = wall_clock64();   // the step's record has landed
+#endif
+    // ---- off the critical path: everything the record alone determines ----
+    unsigned off[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const u32x4 cw = o.cchunk(k >> 3);
+      const unsigned w = ((k >> 1) & 3) == 0 ? cw.x : ((k >> 1) & 3) == 1 ? cw.y : ((k >> 1) & 3) == 2 ? cw.z : cw.w;
+      off[k] = xl_base + ((k & 1) ? (w >> 16) : (w & 0xffffu));
+    }
+    const int32_t pw = o.pub();
+    unsigned cell = ((pw & pubdir) && !mute) ? (unsigned)f.pad0 + (((unsigned)pw >> (BWD ? 11 : 0)) & 0x7ffu) : spare;
+    cell *= (unsigned)M::kBytes;
+    unsigned xoff = (unsigned)o.p * (unsigned)RB;   // (the row's x: byte offset in the block, in LDS and in memory alike)
+    unsigned xadr = xl_base + xoff;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) asm volatile("" : "+v"(off[k]));
+    asm volatile("" : "+v"(cell), "+v"(xoff), "+v"(xadr));
+    // ---- the hand-over: every step before kk is finished and the near-side values this step reads are in LDS ----
+    if (!bail) {
+      // (a sibling's step arrives within a few polls: spin; a predecessor BLOCK's values may take the rest of the sweep: after
+      // a few dozen polls the wave sleeps between them and gives its issue slots to the waves that have work)
+      unsigned spins = 0;
+      for (;;) {
+        u32x4 cw;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cw) : "v"(ctl_off) : "memory");
+        const unsigned pr = (unsigned)__builtin_amdgcn_readfirstlane((int)cw.x), dn = (unsigned)__builtin_amdgcn_readfirstlane((int)cw.y);
+        const unsigned bl = (unsigned)__builtin_amdgcn_readfirstlane((int)cw.z);
+        if (((pr >= (unsigned)o.need) & (dn >= (unsigned)kk)) | (bl != 0u)) { bail = bl != 0u; break; }
+        if (++spins > 48u) {
+          if (spins == 49u) __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_s_sleep(1);
+          if (spins > 4u * spin_limit) { gave_up = true; bail = true; break; }
+        }
+      }
+      if (spins > 48u) __builtin_amdgcn_s_setprio(2);
+    }
+#ifdef BW_RELAY_STAMPS
+    const long long t_go = wall_clock64();    // the hand-over has arrived
+#endif
+    asm volatile("" ::: "memory");   // the gathers stay below the hand-over
+    // ---- the dependent tail ----
+    R xv[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) xv[k] = lds_get<R>(off[k]);
+    const R xo = lds_get<R>(xadr);
+    R acc = (R)0;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) acc += chunk_value<R>(o, k) * xv[k];
+    const R dg = chunk_value<R>(o, MAXK), rc = chunk_value<R>(o, MAXK + 1);
+    R bbv;
+    if constexpr (sizeof(R) == 8) bbv = __hiloint2double((int)o.bb.y, (int)o.bb.x); else bbv = __uint_as_float(o.bb);
+    const R nn = bbv - acc;
+    R q;
+    if (SOR) q = ((R)1 - a.omega) * xo + (a.omega / dg) * nn;
+    else {
+      // (bb - acc) / dg from rc = RN(1 / dg): the correctly rounded quotient (Markstein) inside the normal range — packed_row
+      q = nn * rc;
+      const R rem = __builtin_fma(-dg, q, nn);
+      q = __builtin_fma(rem, rc, q);
+      const R an = __builtin_fabs(nn);
+      const bool safe = sizeof(R) == 8 ? (an > (R)1e-200 && an < (R)1e200) : (an > (R)1e-25 && an < (R)1e25);
+      if (__builtin_amdgcn_ballot_w64(!(rc != (R)0 && safe) && dg != (R)0) != 0) {
+        asm volatile("; rows outside the normal range: the division itself" ::: "memory");
+        if (!(rc != (R)0 && safe)) q = nn / dg;
+      }
+    }
+    q = dg != (R)0 ? q : xo;   // a zero diagonal: the row keeps its value (smoother.jl:87) — and publishes it
+    lds_put<R>(xadr, q);
+    // (LDS operations of one wave execute in program order: the values are in place before the word moves)
+    __hip_atomic_store(ctl + 1, (unsigned)(kk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (gave_up) __hip_atomic_store(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef BW_RELAY_STAMPS
+    const long long t_done = wall_clock64();   // x and the word are on their way
+    if (a.tim && kk < 128) {
+      lds_put<long long>(stamp_base + 24u * (unsigned)kk, t_rec);
+      lds_put<long long>(stamp_base + 24u * (unsigned)kk + 8u, t_go);
+      lds_put<long long>(stamp_base + 24u * (unsigned)kk + 16u, t_done);
+    }
+    { u32x2 tv2 = {(unsigned)t_done, (unsigned)(t_done >> 32)}; asm_store(tv2, (cell / (unsigned)M::kBytes) * 8u, rs_pub); }
+#endif
+    // ---- behind the hand-over: the row into its mailbox (tagged with the sweep's epoch) and into x ----
+    if constexpr (sizeof(R) == 8) {
+      const unsigned qlo = (unsigned)__double2loint(q), qhi = (unsigned)__double2hiint(q);
+      u32x4 cv = {qlo, epoch, qhi, epoch};
+      asm_store_sc1(cv, cell, rs_mst);
+      u32x2 xv2 = {qlo, qhi};
+      asm_store(xv2, xoff, rs_x);
+    } else {
+      u32x2 cv = {__float_as_uint(q), epoch};
+      asm_store_sc1(cv, cell, rs_mst);
+      asm_store(__float_as_uint(q), xoff, rs_x);
+    }
+#ifdef BW_FLOW_STEP_STAMPS
+    if (a.tim && lane == 0) a.tim[4 * (int64_t)a.nblocks + 128 * (int64_t)ob + kk] = wall_clock64();
+#endif
+  };
+  // The pipeline of gs_flow.hpp over MY steps (j-th one: wv + j W): D register sets, vmcnt counted exactly per wave
+#ifdef BW_RELAY_STAMPS
+  constexpr int L = O::NLOAD, S = 3;
+#else
+  constexpr int L = O::NLOAD, S = 2;
+#endif
+  const int nsw = ns > wv ? (ns - wv + W - 1) / W : 0;
+  int k = 0;
+  if (nsw >= D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {   // the first round: set j was followed by D - 1 - j more sets and j whole steps
+      if (j == 0) flow_wait<(D - 1) * L>(ops[0]);
+      else if (j == 1) flow_wait<(D - 2) * L + 1 * (L + S)>(ops[1 < D ? 1 : 0]);
+      else if (j == 2) flow_wait<(D > 2 ? D - 3 : 0) * L + 2 * (L + S)>(ops[2 < D ? 2 : 0]);
+      else flow_wait<(D > 3 ? D - 4 : 0) * L + 3 * (L + S)>(ops[3 < D ? 3 : 0]);
+      step(ops[j], wv + j * W);
+      issue(ops[j], wv + (j + D) * W);
+    }
+    for (k = D; k + D <= nsw; k += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        flow_wait<(D - 1) * (L + S)>(ops[j]);
+        step(ops[j], wv + (k + j) * W);
+        issue(ops[j], wv + (k + j + D) * W);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j)
+    if (k + j < nsw) { flow_wait<0>(ops[j]); step(ops[j], wv + (k + j) * W); }
+  if (gave_up && lane == 0) *a.err = 2;
+#ifdef BW_RELAY_STAMPS
+  if (a.tim) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int kk = wv; kk < ns && kk < 128; kk += W)
+      if (lane < 3) a.tim[4 * (int64_t)a.nblocks + 384 * (int64_t)ob + 3 * kk + lane] = lds_get<long long>(stamp_base + 24u * (unsigned)kk + 8u * (unsigned)lane);
+  }
+#endif
+  if (a.tim && lane == 0) {
+    long long* tt = a.tim + 4 * (int64_t)ob;
+    if (wv == 0) { tt[0] = t_start; tt[1] = t_loaded; tt[3] = 0; }
+    if (wv == (ns - 1) % W) tt[2] = wall_clock64();
+  }
+}
+static_assert(RelayDepth<6>::value <= 4 && RelayDepth<12>::value <= 4 && RelayDepth<18>::value <= 4, "the first round of the relay's pipeline is written out for up to four sets");
+
+// measurement knob: extra dynamic LDS per workgroup (bounds the blocks resident per CU)
+inline size_t& relay_lds_pad() { static size_t pad = 0; return pad; }
+
+template <typename R, bool SOR, bool BWD, int MAXK, int W>
+inline hipError_t sweep_relay_launch(const FlowArgs<R>& a, size_t lds, hipStream_t st) {
+  auto* fn = gs_bw_relay_kernel<R, SOR, BWD, MAXK, W>;
+  if (relay_lds_pad()) {
+    lds += relay_lds_pad();
+    static hipError_t once = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (once != hipSuccess) return once;
+    hipLaunchKernelGGL(fn, dim3((unsigned)a.nblocks), dim3(64 * (W + 1)), lds, st, a);
+    return hipGetLastError();
+  }
+#ifdef BW_RELAY_STAMPS
+  lds += 128 * 24;
+#endif
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3((unsigned)a.nblocks), dim3(64 * (W + 1)), lds, st, a);
+  return hipGetLastError();
+}
+template <typename R, int MAXK, int W>
+inline hipError_t sweep_relay_k(const FlowArgs<R>& a, size_t lds, bool sor, bool backward, hipStream_t st) {
+  if (sor) return backward ? sweep_relay_launch<R, true, true, MAXK, W>(a, lds, st) : sweep_relay_launch<R, true, false, MAXK, W>(a, lds, st);
+  return backward ? sweep_relay_launch<R, false, true, MAXK, W>(a, lds, st) : sweep_relay_launch<R, false, false, MAXK, W>(a, lds, st);
+}
+// one column, W walker waves per block (the kernels instantiated: BW_RELAY_W, or the set a tool asks for with BW_RELAY_ALL_W)
+template <typename R, int MAXK>
+inline hipError_t sweep_relay_w(FlowArgs<R> a, size_t lds_max, bool sor, bool backward, int w, hipStream_t st) {
+  a.ncols = 1; a.ngroups = 1; a.lds_stride = 0;
+  switch (w) {
+#ifdef BW_RELAY_ALL_W
+    case 2: return sweep_relay_k<R, MAXK, 2>(a, lds_max, sor, backward, st);
+    case 3: return sweep_relay_k<R, MAXK, 3>(a, lds_max, sor, backward, st);
+    case 4: return sweep_relay_k<R, MAXK, 4>(a, lds_max, sor, backward, st);
+#else
+    case BW_RELAY_W: return sweep_relay_k<R, MAXK, BW_RELAY_W>(a, lds_max, sor, backward, st);
+#endif
+  }
+  return hipErrorInvalidValue;
+}
+template <typename R>
+inline hipError_t sweep_relay(const FlowArgs<R>& a, int maxk, size_t lds_max, bool sor, bool backward, hipStream_t st, int w = BW_RELAY_W) {
+  switch (maxk) {
+    case 6: return sweep_relay_w<R, 6>(a, lds_max, sor, backward, w, st);
+    case 12: return sweep_relay_w<R, 12>(a, lds_max, sor, backward, w, st);
+#if BW_PLAN_MAXK >= 18
+    case 18: return sweep_relay_w<R, 18>(a, lds_max, sor, backward, w, st);
+#endif
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace bw
+}  // namespace amgh

@@ -992,9 +992,11 @@ inline int32_t* bw_err_word() {
 inline int bw_err_check() {
   int32_t* w = bw_err_word();
   if (!w) return AMGH_OK;
-  const int32_t v = *(volatile int32_t*)w;
+  if (*(volatile int32_t*)w == 0) return AMGH_OK;
+  // (read and lowered in ONE atomic exchange: of two threads that synchronise at once exactly one reports the give-up,
+  // and a word raised between a plain read and a plain store of 0 cannot get lost)
+  const int32_t v = __atomic_exchange_n(w, 0, __ATOMIC_ACQ_REL);
   if (v == 0) return AMGH_OK;
-  *(volatile int32_t*)w = 0;
   if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] a block sweep gave up a poll (code %d): AMGH_ESTATE\n", (int)v);
   return AMGH_ESTATE;
 }

@@ -70,6 +70,42 @@ def pmc_traffic(N, enabled=True):
         return None, f"unavailable: {type(e).__name__}: {str(e)[:160]}"
 
 
+def read_ceiling(N):
+    """What this chip, on this box, in this run, READS: tools/spmv_bench's known-size kernels (2 GiB 16-B/lane read, 1 GiB
+    copy), timed with HIP events outside any profiler.  The roofline fraction against the datasheet's 8 TB/s moves ~8 %
+    from box to box; the fraction of this ceiling is what the kernel makes of the memory system it was given."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "spmv_bench")
+    try:
+        r = subprocess.run([exe, str(N), "5", "1", "ship"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=180)
+        txt = r.stdout.decode(errors="replace")
+        rd = re.search(r"read16\s+2GiB:\s+([0-9.]+) ms\s+([0-9.]+) GB/s", txt)
+        cp = re.search(r"copy16\s+1GiB->1GiB:\s+([0-9.]+) ms\s+([0-9.]+) GB/s", txt)
+        return (float(rd.group(2)) if rd else None), (float(cp.group(2)) if cp else None)
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def smi_state():
+    """Clock / power state of GPU 0 as rocm-smi reports it (best effort; None when the tool is missing)."""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showperflevel", "--showtemp", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=30)
+        d = json.loads(r.stdout.decode(errors="replace"))
+        card = d.get("card0") or next(iter(d.values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "socclk", "power", "performance level", "temperature (sensor junction)",
+                                     "temperature (sensor memory)", "temperature (sensor hbm")):
+                keep[k] = v
+        return keep or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -170,14 +206,23 @@ def main():
         if rc != 0:
             raise RuntimeError(lib.amgh_strerror(rc).decode())
 
+    def sync():
+        # the synchronising entry point is where a give-up of the dataflow sweeps' bounded polls surfaces (AMGH_ESTATE):
+        # a timed region that ran on stale values fails the run here, before anything is reported
+        rc = lib.amgh_dev_sync(0)
+        if rc != 0:
+            raise SystemExit("bench.py: amgh_dev_sync: " + lib.amgh_strerror(rc).decode())
+
+    clocks_before = smi_state()
     for _ in range(args.warmup):
         step()
-    lib.amgh_dev_sync(0)
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    lib.amgh_dev_sync(0)
+    sync()
     elapsed = time.perf_counter() - t0
+    clocks_after = smi_state()
     ms_per_step = 1e3 * elapsed / args.steps
     value = n * args.steps / elapsed
     z_timed = zd.download()      # what the LAST timed V-cycle produced (checked against the oracle below)
@@ -187,6 +232,7 @@ def main():
     resid_ms = dev.bench_op(0, 3, reps=50, warmup=5)
     alg = spmv_bytes(A.nnz, n, n)
     achieved = alg / (spmv_ms * 1e-3) / 1e9
+    read_GBs, copy_GBs = (None, None) if args.light else read_ceiling(N)
     # one presmoother application (fwd+bwd GS) on the fine level; skipped with --light because every
     # dependency level is a launch and rocprofv3's kernel tracing costs ~10 ms per dispatch
     sweep_ms = None if args.light else dev.bench_op(0, 4, reps=3, warmup=1)
@@ -226,7 +272,7 @@ def main():
         dev.profile(True)
         for _ in range(3):
             step()
-        lib.amgh_dev_sync(0)
+        sync()
         prof = dev.profile_read()
         dev.profile(False)
         smooth_ms = float(sum(prof[k].sum() for k in prof if k in ("Presmoother", "Postsmoother"))) / 3.0
@@ -252,6 +298,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "csr_stream_kernel<SPMV, StreamCfg<1024,1024,8192,4>> (fine-level A, %d rows, %d nnz)" % (n, A.nnz),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_how, "algorithmic_bytes": alg, "avg_launch_ms": spmv_ms,
+                     # self-normalisation: the pure-read / copy rate of THIS box measured in this run, and the
+                     # kernel against it — the datasheet fraction moves with the box, this one should not
+                     "read_ceiling_GBs": read_GBs, "copy_ceiling_GBs": copy_GBs,
+                     "frac_of_read_ceiling": None if not read_GBs else achieved / read_GBs,
+                     "gpu_state_before_timed_region": clocks_before, "gpu_state_after_timed_region": clocks_after,
                      "fused_residual_ms": resid_ms,
                      "fused_residual_GBs": (alg + 8 * n) / (resid_ms * 1e-3) / 1e9},
         "vcycle": {"algorithmic_bytes": vb, "achieved_GBs": vb / (ms_per_step * 1e-3) / 1e9,
@@ -296,12 +347,15 @@ def main():
             for _ in range(2):
                 if lib.amgh_precond_apply_d(devb.h, Bd.ptr, Zd.ptr, 0) != 0:
                     raise RuntimeError("precond_apply on the block failed")
-            lib.amgh_dev_sync(0)
+            if lib.amgh_dev_sync(0) != 0:
+                raise RuntimeError("amgh_dev_sync after the warm-up cycles on the block failed")
             t0 = time.perf_counter()
             reps = 5
             for _ in range(reps):
-                lib.amgh_precond_apply_d(devb.h, Bd.ptr, Zd.ptr, 0)
-            lib.amgh_dev_sync(0)
+                if lib.amgh_precond_apply_d(devb.h, Bd.ptr, Zd.ptr, 0) != 0:
+                    raise RuntimeError("precond_apply on the block failed")
+            if lib.amgh_dev_sync(0) != 0:
+                raise RuntimeError("amgh_dev_sync after the timed cycles on the block failed")
             ms8 = 1e3 * (time.perf_counter() - t0) / reps
             z8 = Zd.download()[:n]
             out["block_of_right_hand_sides"] = {

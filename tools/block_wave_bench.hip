@@ -9,7 +9,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include "../algebraicmultigrid.jl_amd/csrc/hip/gs_flow.hpp"
+#define BW_RELAY_ALL_W 1
+#include "../algebraicmultigrid.jl_amd/csrc/hip/gs_relay.hpp"
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 using namespace amgh;
@@ -217,7 +218,8 @@ int main(int argc, char** argv) {
       bw::FlowDesc* d_fd; unsigned char* d_srec; uint32_t* d_aux; uint16_t* d_fs; int32_t *d_fm, *d_err; void* d_mbox; unsigned long long* d_head; long long* d_tim;
       CHECK(hipMalloc(&d_fd, sizeof(bw::FlowDesc) * (size_t)B)); CHECK(hipMalloc(&d_srec, F.srec.size())); CHECK(hipMalloc(&d_aux, 4 * std::max<size_t>(1, F.aux.size())));
       CHECK(hipMalloc(&d_fs, 2 * F.fl_slot.size())); CHECK(hipMalloc(&d_fm, 4 * F.fl_mb.size()));
-      CHECK(hipMalloc(&d_mbox, 16 * (size_t)(F.nmail + 1024))); CHECK(hipMalloc(&d_head, 8)); CHECK(hipMalloc(&d_err, 4)); CHECK(hipMalloc(&d_tim, 32 * (size_t)B));
+      CHECK(hipMalloc(&d_mbox, 16 * (size_t)(F.nmail + 1024))); CHECK(hipMalloc(&d_head, 8)); CHECK(hipMalloc(&d_err, 4)); const size_t tim_bytes = (32 + 8 * 384 + 32) * (size_t)B + 16 * (size_t)(F.nmail + 1024);
+      CHECK(hipMalloc(&d_tim, tim_bytes)); CHECK(hipMemset(d_tim, 0, tim_bytes));
       CHECK(hipMemcpy(d_fd, F.fd.data(), sizeof(bw::FlowDesc) * (size_t)B, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_srec, F.srec.data(), F.srec.size(), hipMemcpyHostToDevice));
       CHECK(hipMemcpy(d_aux, F.aux.data(), 4 * F.aux.size(), hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_fs, F.fl_slot.data(), 2 * F.fl_slot.size(), hipMemcpyHostToDevice));
       CHECK(hipMemcpy(d_fm, F.fl_mb.data(), 4 * F.fl_mb.size(), hipMemcpyHostToDevice));
@@ -280,6 +282,114 @@ int main(int argc, char** argv) {
             w += (tim[4 * (size_t)bq + 2] - tim[4 * (size_t)bq + 1]) * 0.01;
           }
           printf("  depth %3d: %4d blocks, first start %8.1f us, first walk %8.1f us, last end %8.1f us, mean walk %6.2f us\n", l, nbk, (ts - tmin) * 0.01, (tw - tmin) * 0.01, (te - tmin) * 0.01, w / nbk);
+        }
+      }
+      // ---- the same dataflow with the walk of a block RELAYED between W waves (gs_relay.hpp) ----
+      if (!getenv("BW_NO_RELAY")) {
+        std::vector<double> xq(n);
+        if (const char* ep = getenv("BW_RELAY_LDS_PAD")) { bw::relay_lds_pad() = (size_t)atoi(ep) * 1024; printf("relay: %d KB of LDS padding per workgroup\n", atoi(ep)); }
+        for (int W : {2, 3, 4}) {
+          if (const char* ew = getenv("BW_RELAY_ONLY")) if (atoi(ew) != W) continue;
+          fa.tim = nullptr;
+          fa.spin_limit = 1u << 18;   // (a protocol error of a kernel under development ends in seconds)
+          CHECK(hipMemset(d_err, 0, 4));
+          CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+          CHECK(bw::sweep_relay<double>(fa, mk, F.lds_max, false, false, st, W));
+          CHECK(bw::sweep_relay<double>(fa, mk, F.lds_max, false, true, st, W));
+          CHECK(hipStreamSynchronize(st));
+          CHECK(hipMemcpy(xq.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+          CHECK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+          int64_t dd = 0; double md = 0.0;
+          for (int64_t p = 0; p < n; ++p) { if (xq[p] != xg[p]) ++dd; md = std::max(md, std::fabs(xq[p] - xg[p])); }
+          printf("== relay, %d walker waves per block: forward + backward vs the dataflow sweeps (= the scalar loops): %lld values differ (max |diff| %.3e), give-ups %d\n", W, (long long)dd, md, err);
+          float msd[2];
+          for (int bwd = 0; bwd < 2; ++bwd) {
+            CHECK(bw::sweep_relay<double>(fa, mk, F.lds_max, false, bwd, st, W)); CHECK(hipStreamSynchronize(st));
+            const int reps = 5;
+            CHECK(hipEventRecord(e0, st));
+            for (int r = 0; r < reps; ++r) CHECK(bw::sweep_relay<double>(fa, mk, F.lds_max, false, bwd, st, W));
+            CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&msd[bwd], e0, e1)); msd[bwd] /= reps;
+          }
+          printf("relay W = %d forward  sweep: %.3f ms (%.0f GB/s)\nrelay W = %d backward sweep: %.3f ms (%.0f GB/s)\n", W, msd[0], fbytes / (msd[0] * 1e-3) / 1e9, W, msd[1], fbytes / (msd[1] * 1e-3) / 1e9);
+          {   // 20 alternating sweeps against the single-walker dataflow
+            std::vector<double> xc(n), xl2(n);
+            CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+            for (int r = 0; r < 20; ++r) CHECK(bw::sweep_relay<double>(fa, mk, F.lds_max, false, r & 1, st, W));
+            CHECK(hipStreamSynchronize(st)); CHECK(hipMemcpy(xc.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+            for (int r = 0; r < 20; ++r) CHECK(bw::sweep_flow<double>(fa, mk, F.lds_max, false, r & 1, st));
+            CHECK(hipStreamSynchronize(st)); CHECK(hipMemcpy(xl2.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
+            int64_t d2 = 0; for (int64_t p = 0; p < n; ++p) d2 += xc[p] != xl2[p];
+            CHECK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+            printf("20 alternating sweeps, relay W = %d vs dataflow: %lld values differ, give-ups %d\n", W, (long long)d2, err);
+          }
+          fa.tim = d_tim;
+          for (int bwd = 0; bwd < 1; ++bwd) {
+            CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
+            CHECK(bw::sweep_relay<double>(fa, mk, F.lds_max, false, bwd, st, W)); CHECK(hipStreamSynchronize(st));
+            std::vector<long long> tim(4 * (size_t)B);
+            CHECK(hipMemcpy(tim.data(), d_tim, 32 * (size_t)B, hipMemcpyDeviceToHost));
+            long long tmin = tim[0], tmax = 0; double ld = 0, wk = 0;
+            for (int32_t bq = 0; bq < B; ++bq) { const long long* t = &tim[4 * (size_t)bq]; tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[2]); ld += (t[1] - t[0]) * 0.01; wk += (t[2] - t[1]) * 0.01; }
+            printf("relay W = %d forward sweep, stamps: first start -> last end %.1f us; mean per block: ticket + load %.2f, walk (with its waits) %.2f us\n", W, (tmax - tmin) * 0.01, ld / B, wk / B);
+            for (int l = 0; l < nl; l += std::max(1, nl / 12)) {
+              long long te = 0, ts = -1, tw = -1; double w = 0; const int nbk = P.launch_ptr[l + 1] - P.launch_ptr[l];
+              for (int bq = P.launch_ptr[l]; bq < P.launch_ptr[l + 1]; ++bq) {
+                te = std::max(te, tim[4 * (size_t)bq + 2]); if (ts < 0 || tim[4 * (size_t)bq] < ts) ts = tim[4 * (size_t)bq];
+                if (tw < 0 || tim[4 * (size_t)bq + 1] < tw) tw = tim[4 * (size_t)bq + 1];
+                w += (tim[4 * (size_t)bq + 2] - tim[4 * (size_t)bq + 1]) * 0.01;
+              }
+              printf("  depth %3d: %4d blocks, first start %8.1f us, first walk %8.1f us, last end %8.1f us, mean walk %6.2f us\n", l, nbk, (ts - tmin) * 0.01, (tw - tmin) * 0.01, (te - tmin) * 0.01, w / nbk);
+            }
+#ifdef BW_RELAY_STAMPS
+          {   // per-step stamps: record landed | hand-over arrived | x + word written — a chain of blocks through the first depths, and the medians of the ramp
+            std::vector<long long> stp((size_t)384 * B);
+            CHECK(hipMemcpy(stp.data(), d_tim + 4 * (size_t)B, 8 * 384 * (size_t)B, hipMemcpyDeviceToHost));
+            long long tmin2 = tim[0]; for (int32_t bq = 0; bq < B; ++bq) tmin2 = std::min(tmin2, tim[4 * (size_t)bq]);
+            for (int l : {0, 1, 2, 3, nl / 2}) {
+              if (l >= nl) continue;
+              const int bq = P.launch_ptr[l] + (l == nl / 2 ? (P.launch_ptr[l + 1] - P.launch_ptr[l]) / 2 : 0);
+              const int nsb = std::min(128, (int)P.blocks[bq].nlev);
+              printf("  block %d (depth %d, %d steps): per step [us since launch] record landed | go | done  (go - previous done | done - go)\n", bq, l, nsb);
+              for (int k2 = 0; k2 < nsb; ++k2) {
+                const long long* q = &stp[(size_t)384 * bq + 3 * k2];
+                const long long pd = k2 ? stp[(size_t)384 * bq + 3 * (k2 - 1) + 2] : q[1];
+                printf("    step %2d: %8.2f | %8.2f | %8.2f   (%5.2f | %5.2f)\n", k2, (q[0] - tmin2) * 0.01, (q[1] - tmin2) * 0.01, (q[2] - tmin2) * 0.01, (q[1] - pd) * 0.01, (q[2] - q[1]) * 0.01);
+              }
+            }
+            // medians over all steps of all blocks: step period (done - previous done), hand-over (go - previous done), tail (done - go), record slack (go - record landed)
+            std::vector<double> per, hand, tail, slack;
+            for (int32_t bq = 0; bq < B; ++bq) {
+              const int nsb = std::min(128, (int)P.blocks[bq].nlev);
+              for (int k2 = 1; k2 < nsb; ++k2) {
+                const long long* q = &stp[(size_t)384 * bq + 3 * k2];
+                const long long pd = stp[(size_t)384 * bq + 3 * (k2 - 1) + 2];
+                per.push_back((q[2] - pd) * 0.01); hand.push_back((q[1] - pd) * 0.01); tail.push_back((q[2] - q[1]) * 0.01); slack.push_back((q[1] - q[0]) * 0.01);
+              }
+            }
+            auto med = [](std::vector<double>& v, double f) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(f * (v.size() - 1))]; };
+            {   // hand-offs: row published (the producing step's done stamp) -> seen by the reading block's fetcher; the fetchers' polls
+              const size_t NM = (size_t)F.nmail + 1024;
+              std::vector<long long> tp(NM), tsn(NM), fq(4 * (size_t)B);
+              CHECK(hipMemcpy(tp.data(), d_tim + (4 + 384) * (size_t)B, 8 * NM, hipMemcpyDeviceToHost));
+              CHECK(hipMemcpy(tsn.data(), d_tim + (4 + 384) * (size_t)B + NM, 8 * NM, hipMemcpyDeviceToHost));
+              CHECK(hipMemcpy(fq.data(), d_tim + (4 + 384) * (size_t)B + 2 * NM, 32 * (size_t)B, hipMemcpyDeviceToHost));
+              std::vector<double> ho;
+              for (size_t m = 0; m < (size_t)F.nmail; ++m) if (tp[m] && tsn[m]) ho.push_back((tsn[m] - tp[m]) * 0.01);
+              double np = 0, ps = 0, pm = 0;
+              for (int32_t bq = 0; bq < B; ++bq) { np += fq[4 * (size_t)bq]; ps += fq[4 * (size_t)bq + 1] * 0.01; pm = std::max(pm, fq[4 * (size_t)bq + 2] * 0.01); }
+              auto pct = [](std::vector<double>& v, double f) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(f * (v.size() - 1))]; };
+              printf("  hand-offs (row published -> seen by the reader's fetcher), %zu forward mailboxes: p10 %.2f median %.2f p90 %.2f p99 %.2f us; fetcher polls: %.1f per block, mean round trip %.2f us, longest %.2f us\n",
+                     ho.size(), pct(ho, 0.1), pct(ho, 0.5), pct(ho, 0.9), pct(ho, 0.99), np / B, np ? ps / np : 0.0, pm);
+              // by depth of the reading... (the producing block's depth: early ramp vs the wide middle)
+            }
+            printf("  all steps: period p10 %.2f median %.2f p90 %.2f | hand-over (go - previous done) p10 %.2f median %.2f p90 %.2f | tail (done - go) p10 %.2f median %.2f p90 %.2f | go - record landed p10 %.2f median %.2f us\n",
+                   med(per, 0.1), med(per, 0.5), med(per, 0.9), med(hand, 0.1), med(hand, 0.5), med(hand, 0.9), med(tail, 0.1), med(tail, 0.5), med(tail, 0.9), med(slack, 0.1), med(slack, 0.5));
+          }
+#endif
+          }
+          fa.tim = nullptr; fa.spin_limit = 0u;
         }
       }
       // ---- blocks of right-hand sides: up to 8 columns per workgroup (one walker / fetcher pair of waves per column, one
