@@ -391,6 +391,7 @@ int g_gs_bw_skip_pub = -1;      // test hook: the block with this ticket publish
 int g_gs_bw_nc = 2;             // columns of a block of right-hand sides one workgroup of the dataflow sweep carries (walker waves beside its one fetcher; 0 = as many as are instantiated: 4 for rows of <= 6 entries, else 3); 256^3, bs = 8, smoothers of the two block-ordered levels: 1: 16.3 + 10.0, 2: 12.0 + 10.1, 3: 12.0 + 10.4, 4: 13.0 + 10.4 ms; read at every sweep
 int g_gs_bw_nrhs = 1;           // hierarchies built for blocks of right-hand sides get the dataflow layout too (0 = single-column hierarchies only); read at schedule build
 int g_gs_bw_chain = 1;          // the wavefront of blocks as one launch per sweep, blocks chained by flags (0: one launch per depth of the quotient graph)
+int g_gs_bw_relay = 3;          // walker waves a single-column dataflow sweep relays a block's walk between (gs_relay.hpp: the one instantiated count, BW_RELAY_W; 0: one walker, gs_bw_flow_kernel — bitwise the same); read at every sweep
 int g_gs_flow_xzero = 1;        // a dataflow sweep that starts a smooth! call on x = 0 reads no x (0: fill + read as any other sweep — bitwise the same); read at every sweep
 int g_gs_dup_launch = 0;        // measurement hook: every merged-group / level launch of a sweep issued 1 + this many times (idempotent); read at every sweep
 int g_gs_bw_two_min_rows = 6000000; // ... operators with TWO offset classes (2-D grids) take the wavefront of blocks from this many rows (0 = never); read at schedule build

@@ -531,7 +531,9 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       fa.ldb = ldb; fa.ldx = xs; fa.mail_stride = g->bw.flow.mail_stride;
       fa.xzero = (g_gs_flow_xzero && first && xzero && !x_resident && g->ncols == g->n) ? 1 : 0;   // the sweep that starts a smooth! call on x = 0
       if (ncolv > g->bw.flow.mcols) return AMGH_ESTATE;   // (gs_ensure_cols sized the mailboxes)
-      e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);
+      // a single column: the block's walk relayed between walker waves (gs_relay.hpp) — the same layout, the same bits
+      if (ncolv == 1 && g_gs_bw_relay > 0) e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
+      else e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);
     } else {
       bw::Args<real> ba{g->bw.blocks, g->bw.rec, g->bw.ext_col, rhs, xp, ldb, xs, omega, 0, nullptr};
       if (g_gs_bw_chain && ncolv == 1 && g->bw.flags) {   // one launch, blocks chained by flags

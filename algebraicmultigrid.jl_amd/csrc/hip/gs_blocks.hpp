@@ -199,6 +199,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
     std::stable_sort(gaps.begin(), gaps.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
     for (int g = 0; g < 2 && g < (int)gaps.size(); ++g) if (gaps[g].first >= 2) P.cuts[g] = gaps[g].second;
     if (P.cuts[0] > P.cuts[1]) std::swap(P.cuts[0], P.cuts[1]);
+    if (const char* e = getenv("BW_PLAN_CUTS")) { int a = 99, b = 99; if (sscanf(e, "%d,%d", &a, &b) >= 1) { P.cuts[0] = a; P.cuts[1] = b; } }   // (measurement hook: the offset classes by hand)
   }
   if (prm.require_three && (P.cuts[0] == 99 || P.cuts[1] == 99)) return false;
   if (prm.require_two && P.cuts[0] == 99 && P.cuts[1] == 99) return false;   // (one class: a chain of slabs)

@@ -23,10 +23,13 @@ namespace amgh {
 namespace bw {
 
 #ifndef BW_RELAY_W
-#define BW_RELAY_W 4                    // default walker waves per block
+#define BW_RELAY_W 3                    // walker waves per block (256^3, levels 0 / 1, ms per sweep: 2: 0.625 / 0.96, 3: 0.610 / 0.93, 4: 0.73 / 1.00; one walker: 0.66 / 0.98)
 #endif
 
 // walker waves / register sets per wave / waves per SIMD the kernel is compiled for
+#ifndef BW_RELAY_SPIN
+#define BW_RELAY_SPIN 48u               // polls of the hand-over before a walker sleeps between them
+#endif
 #ifndef BW_RELAY_DEPTH_SHORT
 #define BW_RELAY_DEPTH_SHORT 3          // register sets per walker wave, rows of <= 12 entries ...
 #endif
@@ -34,7 +37,7 @@ namespace bw {
 #define BW_RELAY_DEPTH_LONG 2           // ... and of up to 18
 #endif
 template <int MAXK> struct RelayDepth { static constexpr int value = MAXK <= 12 ? BW_RELAY_DEPTH_SHORT : BW_RELAY_DEPTH_LONG; };
-template <int MAXK> struct RelayWaves { static constexpr int value = MAXK <= 6 ? 4 : 2; };
+template <int MAXK> struct RelayWaves { static constexpr int value = MAXK <= 6 ? 4 : MAXK <= 18 ? 2 : 1; };
 
 // LDS by its 32-bit address (the walkers keep absolute LDS addresses in registers: nothing is added behind the hand-over)
 template <typename T> __device__ __forceinline__ T lds_get(unsigned addr) { return *(const __attribute__((address_space(3))) T*)(unsigned long long)addr; }
@@ -106,57 +109,9 @@ __global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_r
       for (int k = 0; k < EU; ++k) { const int i = e0 + lane + 64 * k; if (i < nfar) xl[d.nrows + es[k]] = xe[k]; }
     }
     if (lane == 0) { xl[d.nrows + d.next] = (R)0; ctl[0] = 0u; ctl[1] = 0u; ctl[2] = 0u; ctl[3] = 0u; }
-  }
-  const bool walker = !fetcher;
-  // my steps: wv, wv + W, ...; step words by scalar loads one issue ahead (gs_flow.hpp)
-  const uint32_t* ax = a.aux + f.aux + (BWD ? ns + 1 : 0);
-  typedef const uint32_t __attribute__((address_space(4))) cu32;
-  const cu32* axc = (const cu32*)(unsigned long long)uniform_ptr(ax);
-  unsigned sw_next = axc[wv < ns ? wv : ns];
-  const i32x4 rs_rec = make_rsrc(a.srec + (size_t)(uint32_t)d.rec * 16);
-  const i32x4 rs_b = make_rsrc(a.b + d.row0);
-  const i32x4 rs_x = make_rsrc(x + d.row0);
-  const i32x4 rs_mst = make_rsrc(a.mbox);
-  // operands of walking step kk (one of mine) into o; steps behind the last one: a harmless re-read of the block's first chunk
-  auto issue = [&](O& o, int kk) {
-    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)sw_next);
-    sw_next = axc[kk + W < ns ? kk + W : ns];
-    const int r0 = (int)(w & ((1u << kStepRowBits) - 1)), nr = (int)((w >> kStepRowBits) & ((1u << kStepCntBits) - 1));
-    o.need = (int)(w >> (kStepRowBits + kStepCntBits));
-    const int tt = lane < nr ? lane : 0;
-    o.p = r0 + tt;
-    const unsigned voff = (unsigned)tt * 16u;
-    const unsigned s0 = (unsigned)r0 * (16u * O::KCH), sd = (unsigned)nr * 16u;
-#pragma unroll
-    for (int c = 0; c < O::NVC - 1; ++c) asm_load<4>(o.vf[c], voff, rs_rec, s0 + (unsigned)c * sd);
-    asm_load<O::VTAIL>(o.vt, voff, rs_rec, s0 + (unsigned)(O::NVC - 1) * sd);
-#pragma unroll
-    for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)(O::NVC + c) * sd);
-    asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NVC + O::NCC - 1) * sd);
-    asm_load<RB / 4>(o.bb, (unsigned)tt * RB, rs_b, (unsigned)r0 * RB);
-  };
-  O ops[D];
-  if (walker) {
-    // the walkers' half of the load phase: the block's own rows into LDS, a share each
-    constexpr int XW = W >= 4 ? 2 : 4;
-    if (a.xzero) {
-      for (int p = wv * 64 + lane; p < d.nrows; p += 64 * W) xl[p] = (R)0;
-    } else
-    for (int p0 = wv * 64 * XW; p0 < d.nrows; p0 += 64 * XW * W) {
-      R xv[XW];
-#pragma unroll
-      for (int k = 0; k < XW; ++k) { const int p = p0 + lane + 64 * k; xv[k] = x[d.row0 + (p < d.nrows ? p : 0)]; }
-#pragma unroll
-      for (int k = 0; k < XW; ++k) pin(xv[k]);
-#pragma unroll
-      for (int k = 0; k < XW; ++k) { const int p = p0 + lane + 64 * k; if (p < d.nrows) xl[p] = xv[k]; }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the compiler's in flight when the counted loads start)
-#pragma unroll
-    for (int j = 0; j < D; ++j) issue(ops[j], wv + j * W);
-  }
-  __syncthreads();
-  if (fetcher) {
+    // (the fetcher's whole life is this branch — its own barrier, its own return: no path of the control-flow graph leads from the
+    // walkers' hand-issued loads into it, which is what tools/flow_asm_linear.py can then verify)
+    __syncthreads();
     // ---- the fetcher: near-side values out of their mailboxes in the order the walk needs them (gs_flow.hpp, one column) ----
     constexpr int U = 3;
     const int nf = BWD ? f.npost : d.npre;
@@ -206,7 +161,9 @@ __global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_r
         if (moved && lane == 0) __hip_atomic_store(ctl, (unsigned)(w0 + nfirst < nf ? w0 + nfirst : nf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         first = nfirst;
         if (nfirst == 64 * U) break;
+#ifndef BW_RELAY_FETCH_NOSLEEP
         if (!moved) __builtin_amdgcn_s_sleep(4);
+#endif
         if (++total_spins > spin_limit) { fail = true; break; }
       }
     }
@@ -221,7 +178,56 @@ __global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_r
     }
 #endif
     return;
+    }
+  // ---- the walkers ----
+  // my steps: wv, wv + W, ...; step words by scalar loads one issue ahead (gs_flow.hpp)
+  const uint32_t* ax = a.aux + f.aux + (BWD ? ns + 1 : 0);
+  typedef const uint32_t __attribute__((address_space(4))) cu32;
+  const cu32* axc = (const cu32*)(unsigned long long)uniform_ptr(ax);
+  unsigned sw_next = axc[wv < ns ? wv : ns];
+  const i32x4 rs_rec = make_rsrc(a.srec + (size_t)(uint32_t)d.rec * 16);
+  const i32x4 rs_b = make_rsrc(a.b + d.row0);
+  const i32x4 rs_x = make_rsrc(x + d.row0);
+  const i32x4 rs_mst = make_rsrc(a.mbox);
+  // operands of walking step kk (one of mine) into o; steps behind the last one: a harmless re-read of the block's first chunk
+  auto issue = [&](O& o, int kk) {
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)sw_next);
+    sw_next = axc[kk + W < ns ? kk + W : ns];
+    const int r0 = (int)(w & ((1u << kStepRowBits) - 1)), nr = (int)((w >> kStepRowBits) & ((1u << kStepCntBits) - 1));
+    o.need = (int)(w >> (kStepRowBits + kStepCntBits));
+    const int tt = lane < nr ? lane : 0;
+    o.p = r0 + tt;
+    const unsigned voff = (unsigned)tt * 16u;
+    const unsigned s0 = (unsigned)r0 * (16u * O::KCH), sd = (unsigned)nr * 16u;
+#pragma unroll
+    for (int c = 0; c < O::NVC - 1; ++c) asm_load<4>(o.vf[c], voff, rs_rec, s0 + (unsigned)c * sd);
+    asm_load<O::VTAIL>(o.vt, voff, rs_rec, s0 + (unsigned)(O::NVC - 1) * sd);
+#pragma unroll
+    for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)(O::NVC + c) * sd);
+    asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NVC + O::NCC - 1) * sd);
+    asm_load<RB / 4>(o.bb, (unsigned)tt * RB, rs_b, (unsigned)r0 * RB);
+  };
+  O ops[D];
+  {
+    // the walkers' half of the load phase: the block's own rows into LDS, a share each
+    constexpr int XW = W >= 4 ? 2 : 4;
+    if (a.xzero) {
+      for (int p = wv * 64 + lane; p < d.nrows; p += 64 * W) xl[p] = (R)0;
+    } else
+    for (int p0 = wv * 64 * XW; p0 < d.nrows; p0 += 64 * XW * W) {
+      R xv[XW];
+#pragma unroll
+      for (int k = 0; k < XW; ++k) { const int p = p0 + lane + 64 * k; xv[k] = x[d.row0 + (p < d.nrows ? p : 0)]; }
+#pragma unroll
+      for (int k = 0; k < XW; ++k) pin(xv[k]);
+#pragma unroll
+      for (int k = 0; k < XW; ++k) { const int p = p0 + lane + 64 * k; if (p < d.nrows) xl[p] = xv[k]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the compiler's in flight when the counted loads start)
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(ops[j], wv + j * W);
   }
+  __syncthreads();
   // ---- a walker ----
   __builtin_amdgcn_s_setprio(2);
   const long long t_loaded = a.tim ? wall_clock64() : 0;
@@ -242,20 +248,25 @@ __global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_r
     const long long t_rec = wall_clock64();   // the step's record has landed
 #endif
     // ---- off the critical path: everything the record alone determines ----
-    unsigned off[MAXK];
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
+    // (rows of more than 18 entries: the addresses are made behind the hand-over, batch by batch — D sets of such rows leave
+    // no registers for them, and a compiler short of registers moves sets that are still in flight)
+    constexpr bool PRE = MAXK <= 18;
+    constexpr int NOFF = PRE ? MAXK : 1;
+    auto col_addr = [&](int k) {
       const u32x4 cw = o.cchunk(k >> 3);
       const unsigned w = ((k >> 1) & 3) == 0 ? cw.x : ((k >> 1) & 3) == 1 ? cw.y : ((k >> 1) & 3) == 2 ? cw.z : cw.w;
-      off[k] = xl_base + ((k & 1) ? (w >> 16) : (w & 0xffffu));
-    }
+      return xl_base + ((k & 1) ? (w >> 16) : (w & 0xffffu));
+    };
+    unsigned off[NOFF];
+#pragma unroll
+    for (int k = 0; k < NOFF; ++k) off[k] = col_addr(k);
     const int32_t pw = o.pub();
     unsigned cell = ((pw & pubdir) && !mute) ? (unsigned)f.pad0 + (((unsigned)pw >> (BWD ? 11 : 0)) & 0x7ffu) : spare;
     cell *= (unsigned)M::kBytes;
     unsigned xoff = (unsigned)o.p * (unsigned)RB;   // (the row's x: byte offset in the block, in LDS and in memory alike)
     unsigned xadr = xl_base + xoff;
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) asm volatile("" : "+v"(off[k]));
+    for (int k = 0; k < NOFF; ++k) asm volatile("" : "+v"(off[k]));
     asm volatile("" : "+v"(cell), "+v"(xoff), "+v"(xadr));
     // ---- the hand-over: every step before kk is finished and the near-side values this step reads are in LDS ----
     if (!bail) {
@@ -265,29 +276,55 @@ __global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_r
       for (;;) {
         u32x4 cw;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cw) : "v"(ctl_off) : "memory");
+#ifdef BW_RELAY_POLL_V2
+        // (every lane holds the same words: compared in the vector unit, one ballot for the branch)
+        const bool okv = ((cw.x >= (unsigned)o.need) & (cw.y >= (unsigned)kk)) | (cw.z != 0u);
+        if (__builtin_amdgcn_ballot_w64(okv) != 0ull) { bail = (unsigned)__builtin_amdgcn_readfirstlane((int)cw.z) != 0u; break; }
+#else
         const unsigned pr = (unsigned)__builtin_amdgcn_readfirstlane((int)cw.x), dn = (unsigned)__builtin_amdgcn_readfirstlane((int)cw.y);
         const unsigned bl = (unsigned)__builtin_amdgcn_readfirstlane((int)cw.z);
         if (((pr >= (unsigned)o.need) & (dn >= (unsigned)kk)) | (bl != 0u)) { bail = bl != 0u; break; }
-        if (++spins > 48u) {
-          if (spins == 49u) __builtin_amdgcn_s_setprio(0);
+#endif
+        if (++spins > BW_RELAY_SPIN) {
+#ifndef BW_RELAY_NOSLEEP
+          if (spins == BW_RELAY_SPIN + 1u) __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_s_sleep(1);
+#endif
           if (spins > 4u * spin_limit) { gave_up = true; bail = true; break; }
         }
       }
-      if (spins > 48u) __builtin_amdgcn_s_setprio(2);
+#ifndef BW_RELAY_NOSLEEP
+      if (spins > BW_RELAY_SPIN) __builtin_amdgcn_s_setprio(2);
+#endif
     }
 #ifdef BW_RELAY_STAMPS
     const long long t_go = wall_clock64();    // the hand-over has arrived
 #endif
     asm volatile("" ::: "memory");   // the gathers stay below the hand-over
     // ---- the dependent tail ----
-    R xv[MAXK];
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) xv[k] = lds_get<R>(off[k]);
-    const R xo = lds_get<R>(xadr);
     R acc = (R)0;
+    R xo;
+    if constexpr (PRE) {
+      R xv[MAXK];
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) acc += chunk_value<R>(o, k) * xv[k];
+      for (int k = 0; k < MAXK; ++k) xv[k] = lds_get<R>(off[k]);
+      xo = lds_get<R>(xadr);
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k) acc += chunk_value<R>(o, k) * xv[k];
+    } else {
+      constexpr int GB = 12;   // gathers per batch
+      xo = lds_get<R>(xadr);
+#pragma unroll
+      for (int k0 = 0; k0 < MAXK; k0 += GB) {
+        R xv[GB];
+#pragma unroll
+        for (int k = 0; k < GB; ++k) if (k0 + k < MAXK) xv[k] = lds_get<R>(col_addr(k0 + k));
+#pragma unroll
+        for (int k = 0; k < GB; ++k) if (k0 + k < MAXK) pin(xv[k]);
+#pragma unroll
+        for (int k = 0; k < GB; ++k) if (k0 + k < MAXK) acc += chunk_value<R>(o, k0 + k) * xv[k];
+      }
+    }
     const R dg = chunk_value<R>(o, MAXK), rc = chunk_value<R>(o, MAXK + 1);
     R bbv;
     if constexpr (sizeof(R) == 8) bbv = __hiloint2double((int)o.bb.y, (int)o.bb.x); else bbv = __uint_as_float(o.bb);
@@ -430,6 +467,9 @@ inline hipError_t sweep_relay(const FlowArgs<R>& a, int maxk, size_t lds_max, bo
     case 12: return sweep_relay_w<R, 12>(a, lds_max, sor, backward, w, st);
 #if BW_PLAN_MAXK >= 18
     case 18: return sweep_relay_w<R, 18>(a, lds_max, sor, backward, w, st);
+#endif
+#ifdef BW_EXTRA_MAXK   // (tools: one more row length, e.g. the 35-entry rows of the third level of the 256^3 hierarchy)
+    case BW_EXTRA_MAXK: return sweep_relay_w<R, BW_EXTRA_MAXK>(a, lds_max, sor, backward, w, st);
 #endif
   }
   return hipErrorInvalidValue;

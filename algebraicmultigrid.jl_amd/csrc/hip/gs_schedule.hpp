@@ -886,7 +886,7 @@ double merge_cost(int64_t ngroups, int64_t nnz) { return ngroups * 3.8e-6 + 12.0
 
 }  // namespace
 #include "gs_merge_dev.hpp"
-#include "gs_flow.hpp"
+#include "gs_relay.hpp"
 namespace {
 
 // Build the dependency-level schedule from HOST arrays of the smoother matrix.

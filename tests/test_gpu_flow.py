@@ -26,7 +26,7 @@ def rel(x, y):
 class tunables:
     """amgh_debug_set_tunable for the duration of a with block (values restored to the given defaults)."""
     DEFAULTS = {"gs_bw": 1, "gs_bw_rows": 512, "gs_bw_chain": 1, "gs_bw_flow": 1, "gs_lean": -1, "gs_bw_spin": 0, "gs_bw_skip_pub": -1,
-                "gs_lpr": 0, "gs_ept": 0, "gs_bw_nc": 2, "gs_bw_nrhs": 1, "gs_flow_xzero": 1}
+                "gs_lpr": 0, "gs_ept": 0, "gs_bw_nc": 2, "gs_bw_nrhs": 1, "gs_flow_xzero": 1, "gs_bw_relay": 3}
 
     def __init__(self, lib, **kw):
         self.lib, self.kw = lib, kw
@@ -75,6 +75,9 @@ def test_dataflow_sweep_is_the_scalar_loop_bit_for_bit():
                 x_flow = dev.smooth(0, False, x0, bb)
                 for rep in range(2):                                                    # epochs of the mailboxes
                     assert np.array_equal(dev.smooth(0, False, x0, bb), x_flow)
+                with tunables(lib, gs_bw_relay=0):                                      # one walker per block (gs_bw_flow_kernel) instead of the relay
+                    assert np.array_equal(dev.smooth(0, False, x0, bb), x_flow), (A.m, repr(pre))
+                assert np.array_equal(dev.smooth(0, False, x0, bb), x_flow)             # ... and back: the two share mailboxes and epochs
                 with tunables(lib, gs_bw_flow=0):
                     assert lib.amgh_debug_bw_mode(dev.h, 0) == 2
                     x_chain = dev.smooth(0, False, x0, bb)

@@ -50,15 +50,19 @@ def audit_kernel(name, lines):
         return False, "no vmcnt waits found"
     # the steady wait follows from the instantiation: L = value chunks + column chunks + b loads per step, S = 2 stores,
     # D register sets (gs_flow.hpp FlowOps / FlowDepth) -> vmcnt((D - 1)(L + S))
-    m = re.search(r"gs_bw_flow_kernelI([df])Lb[01]ELb[01]ELi(\d+)ELi(\d+)E", name)
+    m = re.search(r"gs_bw_(flow|relay)_kernelI([df])Lb[01]ELb[01]ELi(\d+)ELi(\d+)E", name)
     if not m:
         return False, "cannot read the instantiation from the name"
-    rb, maxk = (8 if m.group(1) == "d" else 4), int(m.group(2))
+    relay = m.group(1) == "relay"
+    rb, maxk = (8 if m.group(2) == "d" else 4), int(m.group(3))
     vpc = 16 // rb
     L = (maxk + 2 + vpc - 1) // vpc + (maxk + 7) // 8 + 1
     depth = int(os.environ.get("BW_FLOW_DEPTH", "4"))
-    nc = int(m.group(3))
-    D = (min(depth, 3) if nc > 1 else depth) if maxk <= 6 else (min(depth, 4) if maxk <= 12 else 3)
+    nc = int(m.group(4))   # (relay kernels: the walker waves per block)
+    if relay:   # gs_relay.hpp RelayDepth
+        D = int(os.environ.get("BW_RELAY_DEPTH_SHORT", "3")) if maxk <= 12 else int(os.environ.get("BW_RELAY_DEPTH_LONG", "2"))
+    else:
+        D = (min(depth, 3) if nc > 1 else depth) if maxk <= 6 else (min(depth, 4) if maxk <= 12 else 3)
     steady = (D - 1) * (L + 2)
     idx = [i for i, n in waits if n == steady]
     loads = [i for i, l in enumerate(code) if re.match(r"buffer_load_dword", l)]
@@ -86,7 +90,8 @@ def audit_kernel(name, lines):
     if len(bw) != D or any(int(x) != steady for x in bw):
         msgs.append(f"vmcnt waits in the loop: {bw} (expected {D} x {steady})")
     # 3. uniform descriptors
-    if any("v_readfirstlane" in l for l in body):
+    # (the relay's hand-over polls read their LDS words through v_readfirstlane: not a waterfall — its buffer accesses are checked below)
+    if not relay and any("v_readfirstlane" in l for l in body):
         msgs.append("waterfall (v_readfirstlane) inside the loop")
     bl = [l for l in body if l.startswith("buffer_load")]
     if not bl or any(not re.search(r", s\d+ offen$|, s\[\d+:\d+\], s\d+ offen", l) for l in bl):
@@ -123,7 +128,7 @@ def main():
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "flow_inst.hip")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S", "-o", out, src]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S", "-o", out, src] + os.environ.get("AUDIT_HIP_FLAGS", "").split()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             print(r.stdout.decode(errors="replace")[-2000:])
@@ -134,7 +139,7 @@ def main():
     kernels = {}
     cur = None
     for l in text:
-        m = re.match(r"^(_ZN4amgh2bw17gs_bw_flow_kernel\w+):", l)
+        m = re.match(r"^(_ZN4amgh2bw1[78]gs_bw_(?:flow|relay)_kernel\w+):", l)
         if m:
             cur = m.group(1)
             kernels[cur] = []
@@ -150,8 +155,8 @@ def main():
         ok, msg = audit_kernel(name, lines)
         if scratch.get(name, 0) != 0 or any("scratch_" in l for l in lines):
             ok, msg = False, f"spills ({scratch.get(name, 0)} bytes of scratch): uncounted memory operations; " + msg
-        short = re.sub(r"^_ZN4amgh2bw17gs_bw_flow_kernelI", "", name)[:24]
-        print(f"{'ok  ' if ok else 'FAIL'} {short:24s} {msg}")
+        short = re.sub(r"^_ZN4amgh2bw1[78]gs_bw_(flow|relay)_kernelI", r"\1 ", name)[:30]
+        print(f"{'ok  ' if ok else 'FAIL'} {short:30s} {msg}")
         rc |= 0 if ok else 1
     return rc
 

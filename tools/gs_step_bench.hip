@@ -23,6 +23,7 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 struct Args {
   const int32_t* wcol; const double* wval; const int32_t* slot_row; const i4_t* wmeta; const double* diag; const double* bp;
   double* x; long long ent0; int nslots; int slot0; int xcd;
+  const i4_t* smeta; const double* sdiag; int rmax;   // in-slot row descriptors (round 5): per slot rmax x {start, end, row, 0} and the diagonals, found from blockIdx alone
 };
 
 __device__ __forceinline__ int xcd_block(int b, int nb) { const int per = (nb + 7) / 8; return (b % 8) * per + b / 8; }
@@ -78,6 +79,42 @@ __global__ __launch_bounds__(T) void slot_kernel(Args a) {
     const int lo = (int)(m.x - base), hi = (int)(m.y - base);
     for (int j = lo; j < hi; ++j) acc += s_prod[j];
     if (d != 0.0) a.x[r0 + t] = (bb - acc) / d;
+  }
+}
+
+// The slot kernel with the row descriptors INSIDE the slot (round-5 verdict, task 1a): the launch's first round trip carries
+// the (col, val) entries AND the rows' {start, end, row} + diagonals (their addresses follow from blockIdx), the second one
+// only the x gathers and b — instead of slot_row first, then wmeta / diag / b behind it.
+template <int T, int EPT>
+__global__ __launch_bounds__(T) void slot_inslot_kernel(Args a) {
+  constexpr int S = T * EPT;
+  __shared__ double s_prod[S];
+  const int tid = threadIdx.x;
+  int lb = blockIdx.x;
+  if (a.xcd) lb = xcd_block(lb, a.nslots);
+  if (lb >= a.nslots) return;
+  const int s = a.slot0 + lb;
+  const long long base = a.ent0 + (long long)lb * S;
+  double v[EPT]; int c[EPT];
+  if (EPT == 1) { v[0] = a.wval[base + tid]; c[0] = a.wcol[base + tid]; }
+  else {
+    const d2_t vv = *(const d2_t*)(a.wval + base + 2 * tid); const i2_t cc = *(const i2_t*)(a.wcol + base + 2 * tid);
+    v[0] = vv.x; v[EPT - 1] = vv.y; c[0] = cc.x; c[EPT - 1] = cc.y;
+  }
+  i4_t m = i4_t{0, 0, -1, 0}; double d = 0.0;
+  if (tid < a.rmax) { m = a.smeta[(long long)s * a.rmax + tid]; d = a.sdiag[(long long)s * a.rmax + tid]; }
+  double xv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) xv[e] = a.x[c[e]];
+  const double bb = m.z >= 0 ? a.bp[m.z] : 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) s_prod[EPT * tid + e] = v[e] * xv[e];
+  __syncthreads();
+  if (m.z >= 0) {
+    double acc = 0.0;
+    const int lo = (int)(m.x - base), hi = (int)(m.y - base);
+    for (int j = lo; j < hi; ++j) acc += s_prod[j];
+    if (d != 0.0) a.x[m.z] = (bb - acc) / d;
   }
 }
 
@@ -532,6 +569,44 @@ double run(const Layout& L, Args a, int K, bool graph, int xcd, hipStream_t st, 
   return 1e3 * best / K;
 }
 
+template <int T, int EPT>
+double run_inslot(const Layout& L, Args a, int K, bool graph, hipStream_t st, std::vector<double>* out, long long n, const std::vector<double>& x0, const std::vector<double>& diag) {
+  // the in-slot descriptors from the layout's per-row ones
+  const size_t nslot = L.slot_row.size() / 2;
+  int rmax = 1;
+  for (size_t q = 0; q < nslot; ++q) rmax = std::max(rmax, L.slot_row[2 * q + 1] - L.slot_row[2 * q]);
+  if (rmax > T) { printf("  in-slot: %d rows in a slot > %d threads\n", rmax, T); return 0.0; }
+  std::vector<i4_t> sm(nslot * rmax, i4_t{0, 0, -1, 0}); std::vector<double> sd(nslot * rmax, 0.0);
+  for (size_t q = 0; q < nslot; ++q)
+    for (int r = L.slot_row[2 * q]; r < L.slot_row[2 * q + 1]; ++r) {
+      const i4_t w = L.wmeta[r];
+      sm[q * rmax + (r - L.slot_row[2 * q])] = i4_t{w.x, w.y, r, 0}; sd[q * rmax + (r - L.slot_row[2 * q])] = diag[r];
+    }
+  i4_t* dsm; double* dsd; CHECK(hipMalloc(&dsm, sizeof(i4_t) * sm.size())); CHECK(hipMalloc(&dsd, 8 * sd.size()));
+  CHECK(hipMemcpy(dsm, sm.data(), sizeof(i4_t) * sm.size(), hipMemcpyHostToDevice)); CHECK(hipMemcpy(dsd, sd.data(), 8 * sd.size(), hipMemcpyHostToDevice));
+  a.smeta = dsm; a.sdiag = dsd; a.rmax = rmax;
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  float best = 1e30f;
+  hipGraphExec_t exec = nullptr;
+  auto enqueue = [&]() {
+    for (int k = 0; k < K; ++k) {
+      Args b = a; b.ent0 = L.ent0[k]; b.nslots = L.nslots[k]; b.slot0 = L.slot0[k]; b.xcd = 1;
+      hipLaunchKernelGGL((slot_inslot_kernel<T, EPT>), dim3(((b.nslots + 7) / 8) * 8), dim3(T), 0, st, b);
+    }
+  };
+  if (graph) { hipGraph_t g; CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); enqueue(); CHECK(hipStreamEndCapture(st, &g));
+    CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0)); CHECK(hipGraphDestroy(g)); }
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipMemcpyAsync(a.x, x0.data(), 8 * n, hipMemcpyHostToDevice, st)); CHECK(hipStreamSynchronize(st));
+    CHECK(hipEventRecord(e0, st)); if (graph) CHECK(hipGraphLaunch(exec, st)); else enqueue(); CHECK(hipEventRecord(e1, st)); CHECK(hipStreamSynchronize(st));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+  }
+  if (exec) CHECK(hipGraphExecDestroy(exec));
+  if (out) { out->resize(n); CHECK(hipMemcpy(out->data(), a.x, 8 * n, hipMemcpyDeviceToHost)); }
+  CHECK(hipFree(dsm)); CHECK(hipFree(dsd));
+  return 1e3 * best / K;
+}
+
 template <int KL, int TMAX = 0, bool UNI = false>
 double run_sell(const Sell& S, SellArgs a, int K, int R, bool graph, hipStream_t st, std::vector<double>* out, long long n, const std::vector<double>& x0) {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -612,6 +687,9 @@ int main(int argc, char** argv) {
           const double t = run<512, 1, 0>(L, a, K, false, 1, st, &ref, n, x0); report("T512 E1 eager xcd", t, nullptr);
           report("T512 E1 graph xcd", run<512, 1, 0>(L, a, K, true, 1, st, &got, n, x0), &got);
           report("T256 E2 eager xcd", run<256, 2, 0>(L, a, K, false, 1, st, &got, n, x0), &got);
+          report("T512 E1 IN-SLOT descr.", run_inslot<512, 1>(L, a, K, false, st, &got, n, x0, diag), &got);
+          report("T256 E2 IN-SLOT descr.", run_inslot<256, 2>(L, a, K, false, st, &got, n, x0, diag), &got);
+          if (getenv("INSLOT_ONLY")) { hipFree((void*)a.wcol); hipFree((void*)a.wval); hipFree((void*)a.slot_row); hipFree((void*)a.wmeta); continue; }
           report("T512 E1 no-gather", run<512, 1, 1>(L, a, K, false, 1, st, nullptr, n, x0), nullptr);
           for (int G : {512, 768, 1024, 2048}) {
             char nm[64]; snprintf(nm, sizeof nm, "PIPE T512 grid %d", G);
