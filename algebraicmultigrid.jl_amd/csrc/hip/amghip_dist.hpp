@@ -26,6 +26,7 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <condition_variable>
 #include <mutex>
@@ -381,6 +382,14 @@ struct DistLevel {
   real *x = nullptr, *b = nullptr, *res = nullptr, *tmp = nullptr;  // x: [local | halo], res: [local | halo of R's input]
   VecPlan rplan;                       // halo plan of res (read by R)
   DistOp* smat() { return S.present ? &S : &A; }
+  // Gauss-Seidel / SOR PIPELINED across the ranks (dist_pipe_setup): the neighbours' mailboxes as this rank maps them
+  struct Pipe {
+    bool on = false;                   // every rank has the dataflow layout with extended lists on this level, each halo side comes from one neighbour
+    const void *rprev = nullptr, *rnext = nullptr;   // mailboxes of rank - 1 (polled in forward sweeps) / rank + 1 (backward sweeps)
+    void *ipc_prev = nullptr, *ipc_next = nullptr;   // ... when they were opened from IPC handles (closed at destroy)
+    int grid = 0;                      // workgroups per launch (ranks sharing one device: the persistent form, every rank's workgroups resident)
+    uint32_t epoch = 0;                // sweeps so far: the mailbox tag, the same on every rank
+  } pipe;
 };
 
 void sort_unique(std::vector<int64_t>& v) {
@@ -400,7 +409,8 @@ struct amgh_dist {
   amgh_t* tail = nullptr;              // the collapsed levels (on the rank that owns them), not owned
   bool finalized = false;
   bool host_only = false;              // device < 0: halo plans in host memory only, no GPU call anywhere
-  bool gs_exact = true;                // Gauss-Seidel / SOR across the shards: exact lexicographic order (ranks in turn) or the hybrid (amgh_dist_set_gs_mode)
+  bool gs_exact = true;                // Gauss-Seidel / SOR across the shards: exact lexicographic order or the hybrid (amgh_dist_set_gs_mode)
+  bool gs_pipe = true;                 // ... exact order as ONE pipelined sweep where the level allows it (DistLevel::Pipe::on), else the ranks in turn
   int nplans = 0;
   real *partial = nullptr, *scal = nullptr;
   int64_t ex_count = 0, ex_bytes = 0;  // halo exchanges / bytes sent by this rank since the last reset
@@ -590,6 +600,23 @@ int dist_smooth(amgh_dist* d, int l, const amgh_smoother_t& s, bool xzero, bool*
           // processor-block hybrid: every shard sweeps at once, exact inside, the halo frozen for this directional sweep
           if (n > 0)
             RC_TRY(csr_gs_sweep(&M->op, dir == 1, sor, s.omega, L->x, L->b, d->stream, true, true, 1, false, *b_kept));
+        } else if (d->gs_pipe && L->pipe.on) {
+          // exact lexicographic order across the shards as ONE sweep: every rank launches its dataflow sweep at once; a block
+          // whose rows read the halo of the near side (lower ranks going forward, higher ranks going backward) polls those
+          // rows' mailboxes in the neighbouring rank's array — they are published the moment they are computed, exactly as
+          // between the blocks of one rank — and starts on them: the wavefront runs through the shards as through one level.
+          // The far side's halo is what the exchange above delivered (old values, as the order demands)
+          if (n > 0) {
+            amgh_csr* op = &M->op;
+            ++L->pipe.epoch;
+            if ((L->pipe.epoch & 0x7fffffffu) == 0u) ++L->pipe.epoch;
+            op->pipe_epoch = 0x80000000u | (L->pipe.epoch & 0x7fffffffu);   // (tags of the launches' own counts stay below 2^31)
+            op->pipe_rmbox = dir == 0 ? L->pipe.rprev : L->pipe.rnext;
+            op->pipe_grid = L->pipe.grid;
+            const int rc = csr_gs_sweep(op, dir == 1, sor, s.omega, L->x, L->b, d->stream, true, true, 1, false, *b_kept);
+            op->pipe_epoch = 0; op->pipe_rmbox = nullptr; op->pipe_grid = 0;
+            RC_TRY(rc);
+          }
         } else {
           // exact lexicographic order across the shards (smoother.jl:61-90 on the whole level): the ranks sweep IN TURN —
           // upward going forward, downward going backward — and every turn's boundary values travel before the next turn,
@@ -712,6 +739,8 @@ void dist_free(amgh_dist* d) {
     if (!d->host_only) {
       for (DistOp* o : {&L->A, &L->S, &L->P, &L->R}) csr_free(&o->op);
       hipFree(L->x); hipFree(L->b); hipFree(L->res); hipFree(L->tmp);
+      if (L->pipe.ipc_prev) (void)hipIpcCloseMemHandle(L->pipe.ipc_prev);
+      if (L->pipe.ipc_next) (void)hipIpcCloseMemHandle(L->pipe.ipc_next);
       d->tr->plan_detach(L->rplan);
       L->rplan.free_dev();
     }
@@ -824,10 +853,16 @@ int amgh_dist_create_ipc(amgh_dist_t** dp, int device, int rank, int nranks, con
   return dist_new(dp, device < 0 ? -1 : device, tr);
 }
 
-int amgh_dist_set_gs_mode(amgh_dist_t* d, int exact) {
-  if (!d || exact < 0 || exact > 1) return AMGH_EINVAL;
-  d->gs_exact = exact != 0;
+int amgh_dist_set_gs_mode(amgh_dist_t* d, int mode) {
+  if (!d || mode < 0 || mode > 2) return AMGH_EINVAL;
+  d->gs_exact = mode != 0;
+  d->gs_pipe = mode != 2;   // 1: pipelined where the level allows it (the default), 2: the ranks strictly in turn
   return AMGH_OK;
+}
+// 1 when Gauss-Seidel / SOR sweeps of sharded level `level` run as one sweep pipelined across the ranks under mode 1
+int amgh_dist_gs_pipelined(const amgh_dist_t* d, int level) {
+  if (!d || !d->finalized || level < 0 || level >= (int)d->levels.size()) return -1;
+  return d->levels[level]->pipe.on ? 1 : 0;
 }
 
 void amgh_dist_destroy(amgh_dist_t* d) {
@@ -891,6 +926,134 @@ int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail) {
 }
 
 // Collective: every rank calls it after the same sequence of amgh_dist_push_level calls.
+namespace {
+uint64_t fnv1a(const char* s) { uint64_t h = 1469598103934665603ull; for (; *s; ++s) { h ^= (unsigned char)*s; h *= 1099511628211ull; } return h; }
+
+// Collective: which sharded levels sweep Gauss-Seidel / SOR as one pipeline across the ranks.  A level qualifies when EVERY
+// rank holds the dataflow layout with extended lists for its shard and reads its lower halo from rank - 1 only, its upper
+// halo from rank + 1 only.  The ranks then exchange, per level, the mailbox of every row a neighbour reads (in the order of
+// the halo exchange's send lists = the order of the receiver's halo) and a handle of their mailbox array; the halo entries
+// of the extended fetch lists are pointed at the neighbour's cells and the arrays are mapped (same process: the pointer;
+// another process: hipIpcOpenMemHandle).  Any failure anywhere switches the level back to the ranks sweeping in turn.
+int dist_pipe_setup(amgh_dist* d) {
+  Transport* tr = d->tr;
+  const int N = tr->nranks, me = tr->rank;
+  const int lc = (int)d->levels.size();
+  if (N < 2 || lc == 0) return AMGH_OK;
+  if (const char* e = getenv("AMGH_DIST_PIPE")) if (atoi(e) == 0) return AMGH_OK;   // (measurement hook; the same on every rank)
+  std::vector<double> bad((size_t)lc, 0.0);
+  for (int l = 0; l < lc; ++l) {
+    DistLevel* L = d->levels[l];
+    VecPlan& xp = d->xplan[l];
+    const amgh_csr* M = &L->smat()->op;
+    const bool gs = L->pre.kind == AMGH_SMOOTH_GS || L->pre.kind == AMGH_SMOOTH_SOR || L->post.kind == AMGH_SMOOTH_GS || L->post.kind == AMGH_SMOOTH_SOR;
+    bool ok = gs && xp.nloc() > 0 && M->gs && M->gs->bw.on && M->gs->bw.flow.on && M->gs->bw.flow.xon && M->gs->bw.flow.mbox;
+    for (int p = 0; p < N && ok; ++p) {
+      if (p == me) continue;
+      if ((p < me - 1 || p > me + 1) && (xp.recv[p].cnt > 0 || xp.send[p].cnt > 0)) ok = false;
+    }
+    bad[(size_t)l] = ok ? 0.0 : 1.0;
+  }
+  RC_TRY(tr->allreduce(bad.data(), lc, true));
+  char host[256] = {0}, bus[64] = {0};
+  (void)gethostname(host, sizeof host - 1);
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, d->device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", d->device); }
+  const int64_t where = (int64_t)((fnv1a(host) ^ (fnv1a(bus) * 31ull)) >> 1);
+  for (int l = 0; l < lc; ++l) {
+    DistLevel* L = d->levels[l];
+    VecPlan& xp = d->xplan[l];
+    std::vector<int64_t> mine;
+    double fail = 0.0;
+    GsSchedule* g = bad[(size_t)l] == 0.0 ? L->smat()->op.gs : nullptr;
+    if (g) {
+      GsSchedule::Bw::FlowDev& fl = g->bw.flow;
+      hipIpcMemHandle_t hnd;
+      std::memset(&hnd, 0, sizeof hnd);
+      if (hipIpcGetMemHandle(&hnd, fl.mbox) != hipSuccess) { (void)hipGetLastError(); std::memset(&hnd, 0, sizeof hnd); }   // (same-process peers do not need it)
+      mine.push_back((int64_t)getpid()); mine.push_back(where); mine.push_back((int64_t)(uintptr_t)fl.mbox);
+      int64_t hw[8]; static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+      std::memcpy(hw, &hnd, 64);
+      for (int k = 0; k < 8; ++k) mine.push_back(hw[k]);
+      // cells of the rows rank - 1 reads (backward cells), then of the rows rank + 1 reads (forward cells), each in send order
+      for (int side = 0; side < 2; ++side) {
+        const int p = side == 0 ? me - 1 : me + 1;
+        const int64_t cnt = (p >= 0 && p < N) ? xp.send[p].cnt : 0;
+        mine.push_back(cnt);
+        for (int64_t i = 0; i < cnt; ++i) {
+          const int32_t row = xp.h_send_idx[(size_t)(xp.send[p].off + i)];
+          mine.push_back(side == 0 ? fl.h_row_cell_b[(size_t)row] : fl.h_row_cell_f[(size_t)row]);
+        }
+      }
+    }
+    std::vector<std::vector<int64_t>> all;
+    RC_TRY(tr->allgatherv_host(mine, all));
+    if (g) {
+      GsSchedule::Bw::FlowDev& fl = g->bw.flow;
+      int64_t nlo = 0;
+      for (int p = 0; p < me; ++p) nlo += xp.recv[p].cnt;
+      const int64_t nhi = xp.nhalo() - nlo;
+      // the neighbours' lists: [pid, where, ptr, handle x 8, n_prev, cells..., n_next, cells...]
+      auto side_cells = [&](int p, int side, const int64_t** cells, int64_t* cnt) -> bool {
+        const std::vector<int64_t>& v = all[(size_t)p];
+        if (v.size() < 12) return false;
+        size_t pos = 11;
+        for (int sd = 0; sd < 2; ++sd) {
+          if (pos >= v.size()) return false;
+          const int64_t c = v[pos++];
+          if (c < 0 || pos + (size_t)c > v.size()) return false;
+          if (sd == side) { *cells = v.data() + pos; *cnt = c; return true; }
+          pos += (size_t)c;
+        }
+        return false;
+      };
+      const int64_t *lowc = nullptr, *upc = nullptr;
+      int64_t nl = 0, nu = 0;
+      if (nlo > 0 && !(me > 0 && side_cells(me - 1, 1, &lowc, &nl) && nl == nlo)) fail = 1.0;    // rank - 1's forward cells of what it sends up
+      if (nhi > 0 && !(me + 1 < N && side_cells(me + 1, 0, &upc, &nu) && nu == nhi)) fail = 1.0;   // rank + 1's backward cells of what it sends down
+      if (fail == 0.0) {
+        for (int32_t& e : fl.h_xfl_mb) {
+          if (e >= 0) continue;
+          const int64_t h = (int64_t)(e & 0x7fffffff);
+          const int64_t c = h < nlo ? lowc[h] : (h - nlo < nhi ? upc[h - nlo] : -1);
+          if (c < 0 || c >= (int64_t)0x3fffffff) { fail = 1.0; break; }
+          e = bw::kRemoteCell | (int32_t)c;
+        }
+      }
+      if (fail == 0.0 && hipMemcpy(fl.xfl_mb, fl.h_xfl_mb.data(), sizeof(int32_t) * fl.h_xfl_mb.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); fail = 1.0; }
+      // the neighbours' mailbox arrays
+      int nshare = 0;
+      for (int p = 0; p < N; ++p) if (all[(size_t)p].size() >= 2 && all[(size_t)p][1] == where) ++nshare;
+      for (int side = 0; side < 2 && fail == 0.0; ++side) {
+        const int p = side == 0 ? me - 1 : me + 1;
+        if (p < 0 || p >= N || (side == 0 ? nlo : nhi) == 0) continue;
+        const std::vector<int64_t>& v = all[(size_t)p];
+        if (v.size() < 12) { fail = 1.0; break; }
+        const void* ptr = nullptr; void* opened = nullptr;
+        if (v[0] == (int64_t)getpid()) ptr = (const void*)(uintptr_t)v[2];
+        else {
+          hipIpcMemHandle_t hnd;
+          std::memcpy(&hnd, v.data() + 3, 64);
+          if (hipIpcOpenMemHandle(&opened, hnd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); fail = 1.0; break; }
+          ptr = opened;
+        }
+        if (side == 0) { L->pipe.rprev = ptr; L->pipe.ipc_prev = opened; } else { L->pipe.rnext = ptr; L->pipe.ipc_next = opened; }
+      }
+      // ranks sharing this device: every rank's workgroups must be resident at once (a rank waits for its neighbour's)
+      if (fail == 0.0 && nshare > 1) {
+        const int cap = bw::relay_resident_blocks<real>(g->bw.maxk, g->bw.flow.lds_max);
+        L->pipe.grid = std::max(1, cap / nshare);
+        if (cap <= 0) fail = 1.0;
+      }
+    } else fail = bad[(size_t)l];
+    RC_TRY(tr->allreduce(&fail, 1, true));
+    L->pipe.on = fail == 0.0;
+    if (getenv("AMGH_VERBOSE") && me == 0)
+      fprintf(stderr, "[amghip] sharded level %d: Gauss-Seidel across the ranks %s\n", l, L->pipe.on ? "as one pipelined sweep" : "in turns");
+  }
+  return AMGH_OK;
+}
+}  // namespace
+
 int amgh_dist_finalize(amgh_dist_t* d) {
   if (!d) return AMGH_EINVAL;
   if (d->finalized) return AMGH_ESTATE;
@@ -956,8 +1119,24 @@ int amgh_dist_finalize(amgh_dist_t* d) {
     amgh_csr* M = &L->smat()->op;
     if (nloc > 0 && jac) RC_TRY(csr_ensure_diag(M, d->stream));
     M->gs_nrhs_hint = 1;   // (the sharded cycle carries one right-hand side)
-    if (nloc > 0 && gs) RC_TRY(csr_ensure_gs(M));
+    if (nloc > 0 && gs) {
+      // the rows the neighbours read get mailboxes, the halo columns places in the fetch lists: what a sweep pipelined across
+      // the ranks needs (dist_pipe_setup decides, collectively, whether the level gets one)
+      std::vector<unsigned char> pub_f((size_t)nloc, 0), pub_b((size_t)nloc, 0);
+      int64_t nlo = 0;
+      for (int p = 0; p < N; ++p) {
+        if (p == me) continue;
+        if (p < me) nlo += xp.recv[p].cnt;
+        for (int64_t i = 0; i < xp.send[p].cnt; ++i) (p > me ? pub_f : pub_b)[(size_t)xp.h_send_idx[(size_t)(xp.send[p].off + i)]] = 1;
+      }
+      bw::FlowHalo fh; fh.nlo = nlo; fh.pub_f = pub_f.data(); fh.pub_b = pub_b.data();
+      tl_flow_halo = N > 1 ? &fh : nullptr;
+      const int rcg = csr_ensure_gs(M);
+      tl_flow_halo = nullptr;
+      RC_TRY(rcg);
+    }
   }
+  if (!d->host_only) RC_TRY(dist_pipe_setup(d));
   if (d->host_only) {
     RC_TRY(tr->barrier());
     d->finalized = true;

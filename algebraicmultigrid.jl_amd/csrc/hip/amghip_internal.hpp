@@ -227,6 +227,10 @@ struct GsSchedule {
       int64_t mail_stride = 0;   // bytes of one right-hand-side column's mailboxes (the spare cells included)
       int mcols = 0;             // columns mbox holds
       bool on = false;
+      // a row-sharded operator's extended fetch lists (bw::FlowX): what a sweep pipelined across the ranks reads
+      uint32_t* xaux = nullptr; int32_t* xfl_mb = nullptr; uint16_t* xfl_slot = nullptr; int32_t* xlist = nullptr;
+      std::vector<int32_t> h_xfl_mb, h_row_cell_f, h_row_cell_b;   // host copies: the halo entries are patched with the neighbours' cells
+      bool xon = false;
     } flow;
   } bw;
   // the same operator as one record walked by a single wave (gs_wave_kernel): built when it fits (rows of at most
@@ -333,6 +337,7 @@ struct GsSchedule {
     hipFree(bw.blocks); hipFree(bw.rec); hipFree(bw.ext_col);
     hipFree(bw.dep_ptr); hipFree(bw.dep); hipFree(bw.sdep_ptr); hipFree(bw.sdep); hipFree(bw.flags); hipFree(bw.head);
     hipFree(bw.flow.fd); hipFree(bw.flow.srec); hipFree(bw.flow.aux); hipFree(bw.flow.fl_mb); hipFree(bw.flow.fl_slot); hipFree(bw.flow.mbox);
+    hipFree(bw.flow.xaux); hipFree(bw.flow.xfl_mb); hipFree(bw.flow.xfl_slot); hipFree(bw.flow.xlist);
     bw = Bw();
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
     hipFree(perm); hipFree(dpos); if (!diag_shared) hipFree(diag);
@@ -356,6 +361,9 @@ struct amgh_csr {
   real* diag = nullptr;
   GsSchedule* gs = nullptr;
   int gs_nrhs_hint = 0;   // right-hand-side columns the sweeps over this operator will carry (0 = unknown), see gs_build
+  // a sweep pipelined across the ranks of a row-sharded level (amghip_dist.hpp), set around a csr_gs_sweep call: the sweep's
+  // mailbox tag (0 = not pipelined), the neighbouring rank's mailboxes, the workgroups to launch (0 = one per block)
+  uint32_t pipe_epoch = 0; const void* pipe_rmbox = nullptr; int pipe_grid = 0;
   int64_t bytes = 0;
 };
 
@@ -392,6 +400,7 @@ int g_gs_bw_nc = 2;             // columns of a block of right-hand sides one wo
 int g_gs_bw_nrhs = 1;           // hierarchies built for blocks of right-hand sides get the dataflow layout too (0 = single-column hierarchies only); read at schedule build
 int g_gs_bw_chain = 1;          // the wavefront of blocks as one launch per sweep, blocks chained by flags (0: one launch per depth of the quotient graph)
 int g_gs_bw_relay = 3;          // walker waves a single-column dataflow sweep relays a block's walk between (gs_relay.hpp: the one instantiated count, BW_RELAY_W; 0: one walker, gs_bw_flow_kernel — bitwise the same); read at every sweep
+int g_gs_bw_grid = 0;           // workgroups of a relayed single-column sweep (fewer than blocks: the persistent form of gs_relay.hpp; 0: one per block); read at every sweep
 int g_gs_flow_xzero = 1;        // a dataflow sweep that starts a smooth! call on x = 0 reads no x (0: fill + read as any other sweep — bitwise the same); read at every sweep
 int g_gs_dup_launch = 0;        // measurement hook: every merged-group / level launch of a sweep issued 1 + this many times (idempotent); read at every sweep
 int g_gs_bw_two_min_rows = 6000000; // ... operators with TWO offset classes (2-D grids) take the wavefront of blocks from this many rows (0 = never); read at schedule build

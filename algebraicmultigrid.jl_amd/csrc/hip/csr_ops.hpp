@@ -532,7 +532,15 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       fa.xzero = (g_gs_flow_xzero && first && xzero && !x_resident && g->ncols == g->n) ? 1 : 0;   // the sweep that starts a smooth! call on x = 0
       if (ncolv > g->bw.flow.mcols) return AMGH_ESTATE;   // (gs_ensure_cols sized the mailboxes)
       // a single column: the block's walk relayed between walker waves (gs_relay.hpp) — the same layout, the same bits
-      if (ncolv == 1 && g_gs_bw_relay > 0) e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
+      if (op->pipe_epoch) {   // one sweep of a row-sharded level pipelined across the ranks: the relayed kernel on the extended lists
+        if (ncolv != 1 || !g->bw.flow.xon) return AMGH_ESTATE;
+        fa.aux = g->bw.flow.xaux; fa.fl_mb = g->bw.flow.xfl_mb; fa.fl_slot = g->bw.flow.xfl_slot; fa.xlist = g->bw.flow.xlist;
+        fa.epoch = op->pipe_epoch; fa.rmbox = op->pipe_rmbox; fa.grid = op->pipe_grid;
+        e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
+      } else if (ncolv == 1 && g_gs_bw_relay > 0) {
+        fa.grid = g_gs_bw_grid;
+        e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
+      }
       else e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);
     } else {
       bw::Args<real> ba{g->bw.blocks, g->bw.rec, g->bw.ext_col, rhs, xp, ldb, xs, omega, 0, nullptr};

@@ -50,7 +50,29 @@ struct FlowDesc {      // per block, beside Desc (16 bytes)
 constexpr int kStepRowBits = 11, kStepCntBits = 7, kStepNeedMax = (1 << 14) - 1;
 inline uint32_t step_word(int r0, int nr, int need) { return (uint32_t)r0 | ((uint32_t)nr << kStepRowBits) | ((uint32_t)need << (kStepRowBits + kStepCntBits)); }
 
+constexpr int32_t kRemoteCell = (int32_t)(1u << 31);   // fetch-list entry: a mailbox of the NEIGHBOURING rank's array (FlowArgs::rmbox), not of this one
+
+// A row-sharded operator (amghip_dist.hpp): rows = this rank's rows, columns [n, n + nlo) = halo entries owned by lower
+// ranks, [n + nlo, ncols) by higher ranks.  For a sweep PIPELINED across the ranks the rows a higher rank reads get a
+// forward mailbox (pub_f), the rows a lower rank reads a backward one (pub_b) — the neighbour's fetchers poll them
+// through a peer mapping —, and this rank's blocks get fetch lists that hold their lower (forward sweep) / upper
+// (backward sweep) halo columns beside the columns of predecessor blocks: the extended lists of FlowX.
+struct FlowHalo {
+  int64_t nlo = 0;                       // halo columns owned by lower ranks (they come first)
+  const unsigned char* pub_f = nullptr;  // per natural local row: read by a higher rank
+  const unsigned char* pub_b = nullptr;  // ... by a lower rank
+};
+struct FlowX {
+  bool on = false;
+  std::vector<uint32_t> aux;        // step words with the extended lists' counts (same offsets as Flow::aux)
+  std::vector<int32_t> fl_mb;       // per block: forward list, then backward list; a halo entry holds kRemoteCell | halo index until the neighbour's cells are known
+  std::vector<uint16_t> fl_slot;
+  std::vector<int32_t> list;        // per block {first entry, forward entries, backward entries, 0}
+  std::vector<int32_t> row_cell_f, row_cell_b;   // per natural local row: its forward / backward mailbox (-1: none)
+};
+
 struct Flow {
+  FlowX x;
   std::vector<FlowDesc> fd;
   std::vector<uint32_t> aux;
   std::vector<int32_t> fl_mb;       // per block at ext0: mailboxes of the forward fetch list (npre entries, in the order of
@@ -81,7 +103,7 @@ inline bool structurally_symmetric(int64_t n, const int32_t* rowptr, const int32
 // inplace: the plan's row-major records are turned into the chunk-major ones where they lie (F.srec stays empty; P.rec is
 // then what the dataflow kernel streams, and no longer what the chained / launched kernels or the host execution read)
 template <typename R>
-bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false) {
+bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false, const FlowHalo* hx = nullptr) {
   Flow& F = *out;
   F = Flow();
   const int64_t n = P.n;
@@ -96,6 +118,13 @@ bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false) {
       if (q >= n) continue;                                 // halo column: never written
       if (e < d.npre) { if (cell_f[q] < 0 || ob < cell_f[q]) cell_f[q] = ob; }   // before the block: a new value of the forward sweep
       else cell_b[q] = std::max(cell_b[q], ob);
+    }
+  }
+  if (hx) {   // rows a neighbouring rank reads: a reader behind every block (forward) / before every block (backward)
+    for (int64_t q = 0; q < n; ++q) {
+      const int32_t i = P.perm[q];
+      if (hx->pub_f && hx->pub_f[i] && cell_f[q] < 0) cell_f[q] = B;
+      if (hx->pub_b && hx->pub_b[i] && cell_b[q] < 0) cell_b[q] = B;
     }
   }
   // mailboxes, block by block: first the rows published forward grouped by reading block, then the rows published backward
@@ -149,6 +178,12 @@ bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false) {
   F.fl_mb.assign(std::max<size_t>(1, P.ext_col.size()), 0);
   F.fl_slot.assign(std::max<size_t>(1, P.ext_col.size()), 0);
   if (!inplace) F.srec.resize(P.rec.size());
+  // the extended lists of a row-sharded operator (FlowX): collected per block, laid out behind the loop
+  std::vector<std::vector<int32_t>> xl_mb(hx ? (size_t)B : 0);
+  std::vector<std::vector<uint16_t>> xl_slot(hx ? (size_t)B : 0);
+  std::vector<int32_t> xl_nf(hx ? (size_t)B : 0, 0);
+  std::atomic<int> bad_x{0};
+  if (hx) F.x.aux.assign((size_t)aux_total, 0);
   std::atomic<size_t> lds_max{0};
   parallel_for(std::max(1, threads), [&](int t, int TT) {
     std::vector<int32_t> use, order;
@@ -216,6 +251,48 @@ bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false) {
           F.fl_slot[d.ext0 + d.npre + i] = (uint16_t)(d.nrows + e);
         }
       }
+      if (hx) {
+        // the same two lists with the halo columns of the near side in them: lower ranks' entries are new values of a forward
+        // sweep (they lie before every row of this rank), higher ranks' entries of a backward one
+        uint32_t* axx = F.x.aux.data() + f.aux;
+        std::vector<int32_t>& lm = xl_mb[(size_t)ob];
+        std::vector<uint16_t>& ls = xl_slot[(size_t)ob];
+        auto entry_mb = [&](int32_t e, bool fwd) -> int32_t {
+          const int32_t q = P.ext_col[d.ext0 + e];
+          if (q >= n) return kRemoteCell | (int32_t)(q - n);
+          return fwd ? cell_f[q] : cell_b[q];
+        };
+        order.clear();
+        for (int32_t e = 0; e < d.npre; ++e) order.push_back(e);
+        for (int32_t e = d.npre + npost; e < d.next; ++e) if (P.ext_col[d.ext0 + e] < n + hx->nlo && use[2 * e + 1] >= 0) order.push_back(e);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return use[2 * a] < use[2 * b]; });
+        {
+          int32_t done = 0;
+          const int32_t cnt = (int32_t)order.size();
+          for (int k = 0; k < ns; ++k) {
+            while (done < cnt && use[2 * order[done]] <= k) ++done;
+            axx[k] = step_word(stp[k], stp[k + 1] - stp[k], done);
+          }
+          axx[ns] = step_word(0, 0, cnt);
+          for (int32_t e : order) { lm.push_back(entry_mb(e, true)); ls.push_back((uint16_t)(d.nrows + e)); }
+          xl_nf[(size_t)ob] = cnt;
+        }
+        order.clear();
+        for (int32_t i = 0; i < npost; ++i) order.push_back(d.npre + i);
+        for (int32_t e = d.npre + npost; e < d.next; ++e) if (P.ext_col[d.ext0 + e] >= n + hx->nlo && use[2 * e + 1] >= 0) order.push_back(e);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return use[2 * a + 1] > use[2 * b + 1]; });
+        {
+          int32_t done = 0;
+          const int32_t cnt = (int32_t)order.size();
+          for (int k = 0; k < ns; ++k) {
+            while (done < cnt && ns - 1 - use[2 * order[done] + 1] <= k) ++done;
+            axx[ns + 1 + k] = step_word(stp[ns - 1 - k], stp[ns - k] - stp[ns - 1 - k], done);
+          }
+          axx[2 * ns + 1] = step_word(0, 0, cnt);
+          for (int32_t e : order) { lm.push_back(entry_mb(e, false)); ls.push_back((uint16_t)(d.nrows + e)); }
+        }
+        if (lm.size() > (size_t)kStepNeedMax) bad_x.store(1);
+      }
       // the record, chunk-major per step: chunk c of the step's row t at 16 (kch stp[s] + c nr + t)
       for (int s = 0; s < ns; ++s) {
         const int32_t r0 = stp[s], nr = stp[s + 1] - stp[s];
@@ -240,6 +317,26 @@ bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false) {
     while (my_lds > cur && !lds_max.compare_exchange_weak(cur, my_lds)) {}
   });
   F.lds_max = lds_max.load();
+  if (hx && bad_x.load() == 0) {
+    FlowX& X = F.x;
+    X.list.assign((size_t)B * 4, 0);
+    size_t tot = 0;
+    for (int32_t ob = 0; ob < B; ++ob) tot += xl_mb[(size_t)ob].size();
+    if (tot < (size_t)INT32_MAX) {
+      X.fl_mb.reserve(tot + 1); X.fl_slot.reserve(tot + 1);
+      for (int32_t ob = 0; ob < B; ++ob) {
+        X.list[4 * (size_t)ob] = (int32_t)X.fl_mb.size();
+        X.list[4 * (size_t)ob + 1] = xl_nf[(size_t)ob];
+        X.list[4 * (size_t)ob + 2] = (int32_t)xl_mb[(size_t)ob].size() - xl_nf[(size_t)ob];
+        X.fl_mb.insert(X.fl_mb.end(), xl_mb[(size_t)ob].begin(), xl_mb[(size_t)ob].end());
+        X.fl_slot.insert(X.fl_slot.end(), xl_slot[(size_t)ob].begin(), xl_slot[(size_t)ob].end());
+      }
+      if (X.fl_mb.empty()) { X.fl_mb.push_back(0); X.fl_slot.push_back(0); }
+      X.row_cell_f.assign((size_t)n, -1); X.row_cell_b.assign((size_t)n, -1);
+      for (int64_t q = 0; q < n; ++q) { X.row_cell_f[(size_t)P.perm[q]] = cell_f[q]; X.row_cell_b[(size_t)P.perm[q]] = cell_b[q]; }
+      X.on = true;
+    }
+  }
   return true;
 }
 
@@ -269,6 +366,11 @@ struct FlowArgs {
   int32_t lds_stride = 0;
   int32_t ncols = 1, ngroups = 1;    // columns of the launch, groups of <= NC columns they are swept in (grid = blocks x groups)
   int32_t xzero = 0;                 // x is zero on entry and need not be read: every block starts from zeros in LDS (the x in memory may hold anything)
+  // (the relayed kernel of gs_relay.hpp only)
+  uint32_t epoch = 0;                // the mailbox tag of this sweep when several launches share it (the ranks of a row-sharded level: every rank the same; 0: the launch's own count)
+  const int32_t* xlist = nullptr;    // the extended fetch lists of a row-sharded operator (FlowX::list; aux / fl_mb / fl_slot are then FlowX's)
+  const void* rmbox = nullptr;       // mailboxes of the neighbouring rank this sweep's halo entries come from (peer-mapped; fetch-list entries with kRemoteCell set)
+  int32_t grid = 0;                  // workgroups to launch: fewer than blocks = the persistent form (host side only; 0: one per block)
 };
 
 template <typename R> struct Mail;
@@ -276,6 +378,7 @@ template <> struct Mail<double> {
   static constexpr int kBytes = 16;
   typedef u32x4 cell;
   static __device__ __forceinline__ cell load(__amdgpu_buffer_rsrc_t rs, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16); }   // sc1: past this CU's L1
+  static __device__ __forceinline__ cell load_sys(__amdgpu_buffer_rsrc_t rs, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 17); }   // sc0 sc1: system scope (another device's memory)
   static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned off, double v, unsigned epoch) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
     cell c; c.x = (unsigned)u; c.y = epoch; c.z = (unsigned)(u >> 32); c.w = epoch;
@@ -288,6 +391,7 @@ template <> struct Mail<float> {
   static constexpr int kBytes = 8;
   typedef u32x2 cell;
   static __device__ __forceinline__ cell load(__amdgpu_buffer_rsrc_t rs, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 16); }
+  static __device__ __forceinline__ cell load_sys(__amdgpu_buffer_rsrc_t rs, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 17); }
   static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, unsigned off, float v, unsigned epoch) {
     cell c; c.x = __float_as_uint(v); c.y = epoch;
     __builtin_amdgcn_raw_buffer_store_b64(c, rs, off, 0, 16);

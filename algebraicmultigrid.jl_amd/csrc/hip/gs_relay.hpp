@@ -47,30 +47,16 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // control words of a block, behind its x in LDS (16 bytes, 16-byte aligned): one ds_read_b128 polls them all
 //   [0] progress: leading entries of the fetch list that have arrived (the fetcher)   [1] done: steps finished (the walkers)
 //   [2] bail: somebody gave up a poll — nobody waits any more                          [3] unused
+// One block of the sweep: ticket ut of the launch, mailbox tag `epoch`.  All waves of the workgroup enter; the fetcher wave
+// leaves when its list is done, the walkers behind their last step.
 template <typename R, bool SOR, bool BWD, int MAXK, int W>
-__global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_relay_kernel(FlowArgs<R> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
-  static_assert(W >= 2 && W <= 7, "walker waves per block");
+__device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char* lds_all, const int wv, const int lane, const unsigned int ut,
+                                            const unsigned int epoch, const long long t_start) {
   typedef FlowOps<R, MAXK> O;
   typedef Mail<R> M;
   constexpr int D = RelayDepth<MAXK>::value;
   constexpr int RB = (int)sizeof(R);
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = (int)(threadIdx.x & 63u);
   const bool fetcher = wv == W;
-  const long long t_start = a.tim ? wall_clock64() : 0;
-  unsigned long long* s_ticket = (unsigned long long*)lds_all;
-  if (blockIdx.x < 2048u) for (unsigned i = 0; i < (blockIdx.x >> 5); ++i) __builtin_amdgcn_s_sleep(14);   // (staggered draws: gs_flow.hpp)
-  if (threadIdx.x == 0) *s_ticket = atomicAdd(a.head, 1ull);
-  __syncthreads();
-  const unsigned long long tv = *s_ticket;
-  const unsigned long long ticket = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
-  __syncthreads();   // (the word is x[0] from here on)
-  const unsigned int units = (unsigned int)a.nblocks;
-  const unsigned int ut = (unsigned int)ticket, sweeps = (unsigned int)(ticket >> 32);
-  const unsigned int epoch = sweeps + 1u;
-  if (threadIdx.x == 0 && ut == units - 1u)
-    __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u == 0u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int tk = (int)ut;
   const int ob = __builtin_amdgcn_readfirstlane(BWD ? a.nblocks - 1 - tk : tk);
   const Desc d = a.blocks[ob];
@@ -114,9 +100,17 @@ __global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_r
     __syncthreads();
     // ---- the fetcher: near-side values out of their mailboxes in the order the walk needs them (gs_flow.hpp, one column) ----
     constexpr int U = 3;
-    const int nf = BWD ? f.npost : d.npre;
-    const int f0 = d.ext0 + (BWD ? d.npre : 0);
+    // (a row-sharded operator swept in a pipeline across the ranks: the extended lists — the near side's halo columns among them,
+    // polled in the neighbouring rank's mailboxes)
+    int nf = BWD ? f.npost : d.npre;
+    int f0 = d.ext0 + (BWD ? d.npre : 0);
+    if (a.xlist) {
+      const int l0 = a.xlist[4 * (int64_t)ob], lf = a.xlist[4 * (int64_t)ob + 1], lb = a.xlist[4 * (int64_t)ob + 2];
+      nf = __builtin_amdgcn_readfirstlane(BWD ? lb : lf);
+      f0 = __builtin_amdgcn_readfirstlane(BWD ? l0 + lf : l0);
+    }
     const __amdgpu_buffer_rsrc_t rs_mail = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.mbox), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rmail = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<void*>(a.rmbox ? a.rmbox : (const void*)a.mbox)), 0, 0x7ffffff0, 0x00020000);
     unsigned total_spins = 0;
     bool fail = false;
 #ifdef BW_RELAY_STAMPS
@@ -139,14 +133,18 @@ __global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_r
         const long long tp0 = wall_clock64();
 #endif
 #pragma unroll
-        for (int u = 0; u < U; ++u) if (!ok[u] && 64 * u <= first + 64) cl[u] = M::load(rs_mail, (unsigned)mb[u] * (unsigned)M::kBytes);
+        for (int u = 0; u < U; ++u)
+          if (!ok[u] && 64 * u <= first + 64) {
+            if (mb[u] < 0) cl[u] = M::load_sys(rs_rmail, (unsigned)(mb[u] & 0x7fffffff) * (unsigned)M::kBytes);   // (kRemoteCell)
+            else cl[u] = M::load(rs_mail, (unsigned)mb[u] * (unsigned)M::kBytes);
+          }
 #ifdef BW_RELAY_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const long long tp1 = wall_clock64();
         poll_sum += tp1 - tp0; poll_max = poll_max > tp1 - tp0 ? poll_max : tp1 - tp0; ++npoll;
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (a.tim && !ok[u] && 64 * u <= first + 64 && M::valid(cl[u], epoch)) t_seen[mb[u]] = tp1;
+          if (a.tim && mb[u] >= 0 && !ok[u] && 64 * u <= first + 64 && M::valid(cl[u], epoch)) t_seen[mb[u]] = tp1;
 #endif
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -418,6 +416,40 @@ __global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_r
     if (wv == (ns - 1) % W) tt[2] = wall_clock64();
   }
 }
+
+// PERSISTENT form: a launch of fewer workgroups than blocks keeps every workgroup resident for the whole sweep — each draws
+// tickets until they run out.  That is what several sweeps sharing one device need (the ranks of a row-sharded level on a
+// single GPU: a workgroup of rank p may wait for values of rank p - 1, whose workgroups must then BE resident, not queued
+// behind it), and what bounds the resident workgroups of a launch.  A launch of one workgroup per block is the plain form.
+template <typename R, bool SOR, bool BWD, int MAXK, int W>
+__global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_relay_kernel(FlowArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+  static_assert(W >= 2 && W <= 7, "walker waves per block");
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63u);
+  const unsigned int units = (unsigned int)a.nblocks;
+  const bool persistent = gridDim.x < units;
+  const unsigned int draws = units + (persistent ? gridDim.x : 0u);   // (every persistent workgroup draws one ticket past the last block)
+  unsigned long long* s_ticket = (unsigned long long*)lds_all;
+  if (blockIdx.x < 2048u) for (unsigned i = 0; i < (blockIdx.x >> 5); ++i) __builtin_amdgcn_s_sleep(14);   // (staggered draws: gs_flow.hpp)
+  for (;;) {
+    const long long t_start = a.tim ? wall_clock64() : 0;
+    if (threadIdx.x == 0) *s_ticket = atomicAdd(a.head, 1ull);
+    __syncthreads();
+    const unsigned long long tv = *s_ticket;
+    const unsigned long long ticket = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(tv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)tv);
+    __syncthreads();   // (the word is x[0] from here on)
+    const unsigned int ut = (unsigned int)ticket, sweeps = (unsigned int)(ticket >> 32);
+    // whoever draws the launch's last ticket starts the next sweep's count (every other draw of this launch has happened by then)
+    if (threadIdx.x == 0 && ut == draws - 1u)
+      __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u == 0u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ut >= units) return;
+    const unsigned int epoch = a.epoch ? a.epoch : sweeps + 1u;   // (a.epoch: the tag of a sweep that several launches share, amghip_dist.hpp)
+    relay_block<R, SOR, BWD, MAXK, W>(a, lds_all, wv, lane, ut, epoch, t_start);
+    if (!persistent) return;
+    __syncthreads();   // (everybody is done with this block's LDS)
+  }
+}
 static_assert(RelayDepth<6>::value <= 4 && RelayDepth<12>::value <= 4 && RelayDepth<18>::value <= 4, "the first round of the relay's pipeline is written out for up to four sets");
 
 // measurement knob: extra dynamic LDS per workgroup (bounds the blocks resident per CU)
@@ -430,16 +462,37 @@ inline hipError_t sweep_relay_launch(const FlowArgs<R>& a, size_t lds, hipStream
     lds += relay_lds_pad();
     static hipError_t once = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (once != hipSuccess) return once;
-    hipLaunchKernelGGL(fn, dim3((unsigned)a.nblocks), dim3(64 * (W + 1)), lds, st, a);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(a.grid > 0 && a.grid < a.nblocks ? a.grid : a.nblocks)), dim3(64 * (W + 1)), lds, st, a);
     return hipGetLastError();
   }
 #ifdef BW_RELAY_STAMPS
   lds += 128 * 24;
 #endif
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fn, dim3((unsigned)a.nblocks), dim3(64 * (W + 1)), lds, st, a);
+  hipLaunchKernelGGL(fn, dim3((unsigned)(a.grid > 0 && a.grid < a.nblocks ? a.grid : a.nblocks)), dim3(64 * (W + 1)), lds, st, a);
   return hipGetLastError();
 }
+// workgroups of the relayed kernel one device keeps resident at once (what a persistent launch may ask for)
+template <typename R, int MAXK, int W>
+inline int relay_resident(size_t lds) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gs_bw_relay_kernel<R, false, false, MAXK, W>, 64 * (W + 1), lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return per_cu * prop.multiProcessorCount;
+}
+template <typename R>
+inline int relay_resident_blocks(int maxk, size_t lds) {
+  switch (maxk) {
+    case 6: return relay_resident<R, 6, BW_RELAY_W>(lds);
+    case 12: return relay_resident<R, 12, BW_RELAY_W>(lds);
+#if BW_PLAN_MAXK >= 18
+    case 18: return relay_resident<R, 18, BW_RELAY_W>(lds);
+#endif
+  }
+  return 0;
+}
+
 template <typename R, int MAXK, int W>
 inline hipError_t sweep_relay_k(const FlowArgs<R>& a, size_t lds, bool sor, bool backward, hipStream_t st) {
   if (sor) return backward ? sweep_relay_launch<R, true, true, MAXK, W>(a, lds, st) : sweep_relay_launch<R, true, false, MAXK, W>(a, lds, st);

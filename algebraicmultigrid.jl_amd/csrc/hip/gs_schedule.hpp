@@ -1005,6 +1005,9 @@ inline int bw_err_check() {
 // a launch per depth of the quotient DAG, one wave walking each block — no substitution, the scalar loop's arithmetic.
 // Sets g->bw (and everything the level-ordered cycle needs: perm, the permuted CSR copy, bp / xp) or leaves g untouched
 // when the operator is not eligible / the cost model says no.
+// (set by amghip_dist.hpp around the schedule build of a row-sharded operator whose sweeps may be pipelined across the ranks)
+thread_local const bw::FlowHalo* tl_flow_halo = nullptr;
+
 int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val, BuildTimer& tm, int nrhs_hint = 1) {
   bw::Params prm;
   prm.target_rows = std::max(64, g_gs_bw_rows);
@@ -1088,7 +1091,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
     const bool inplace = gs_trim();
     // (every limit is checked before a record is touched: `false` leaves the plan as it was; an exception — memory — with the
     // records half rewritten leaves no block layout at all: the level schedules take the level)
-    try { fok = bw::flow_build<real>(P, prm.threads, &F, inplace); }
+    try { fok = bw::flow_build<real>(P, prm.threads, &F, inplace, tl_flow_halo); }
     catch (const std::exception&) {
       fok = false;
       if (inplace) { g->free_dev(); return AMGH_OK; }
@@ -1109,6 +1112,15 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
       fl.nmail = F.nmail; fl.lds_max = F.lds_max; fl.mail_stride = (int64_t)mbytes; fl.mcols = 1;
       fl.bytes = (int64_t)F.fd.size() * (int64_t)sizeof(bw::FlowDesc) + (int64_t)P.rec.size() + (int64_t)F.aux.size() * 4 + (int64_t)F.fl_mb.size() * 6 + (int64_t)mbytes;
       fl.on = true;
+      if (F.x.on) {   // the extended lists; their halo entries wait for the neighbours' cells (amgh_dist_finalize patches and uploads xfl_mb)
+        RC_TRY(dev_upload(&fl.xaux, F.x.aux.data(), (int64_t)F.x.aux.size()));
+        RC_TRY(dev_upload(&fl.xfl_slot, F.x.fl_slot.data(), (int64_t)F.x.fl_slot.size()));
+        RC_TRY(dev_upload(&fl.xlist, F.x.list.data(), (int64_t)F.x.list.size()));
+        RC_TRY(dev_alloc(&fl.xfl_mb, (int64_t)F.x.fl_mb.size()));
+        fl.h_xfl_mb = std::move(F.x.fl_mb); fl.h_row_cell_f = std::move(F.x.row_cell_f); fl.h_row_cell_b = std::move(F.x.row_cell_b);
+        fl.xon = true;
+        fl.bytes += (int64_t)F.x.aux.size() * 4 + (int64_t)fl.h_xfl_mb.size() * 6 + (int64_t)F.x.list.size() * 4;
+      }
       g->bytes += fl.bytes;
       tm.lap("dataflow upload", n);
     }

@@ -139,7 +139,7 @@ class ShardedHierarchy:
     transport : ("rccl", id_bytes), ("ipc", "/fresh_shm_name") or ("local", LocalGroup)
     device < 0 (IPC transport only): plans only — the collective setup in host memory, no GPU anywhere; the solve
     entry points are unavailable, `plan_info` is what such a handle is for.
-    gs_mode : "exact" (default) or "hybrid", see set_gs_mode
+    gs_mode : "exact" (default), "exact-turns" or "hybrid", see set_gs_mode
     dtype : float64 (default) or float32 = the Float32 instance of the library (the hierarchy's values are rounded
     once, every vector and every operation of the sharded cycle is Float32).
     """
@@ -212,13 +212,21 @@ class ShardedHierarchy:
                               ml.symmetry, method=ml.method)
         return cls(level_arrays(ml, lc), sizes[lc], tail, rank, nranks, device, transport, dtype, gs_mode)
 
+    GS_MODES = {"hybrid": 0, "exact": 1, "exact-turns": 2}
+
     def set_gs_mode(self, mode):
-        """Gauss-Seidel / SOR across the shards: "exact" (lexicographic order over the whole level: the ranks sweep in turn —
-        the reference's iterate) or "hybrid" (every shard at once, halo frozen per directional sweep).  The same on every rank."""
-        if mode not in ("exact", "hybrid"):
-            raise AMGError(f"gs_mode must be 'exact' or 'hybrid', not {mode!r}")
+        """Gauss-Seidel / SOR across the shards.  "exact": lexicographic order over the whole level (the reference's iterate) —
+        as ONE sweep pipelined across the ranks where every rank holds the dataflow layout of its shard (`gs_pipelined`), else
+        with the ranks in turn; "exact-turns": always in turn; "hybrid": every shard at once, halo frozen per directional
+        sweep (another convergent iteration).  The same on every rank."""
+        if mode not in self.GS_MODES:
+            raise AMGError(f"gs_mode must be one of {sorted(self.GS_MODES)}, not {mode!r}")
         self.gs_mode = mode
-        hip_check(self.lib.amgh_dist_set_gs_mode(self.h, 1 if mode == "exact" else 0), "dist_set_gs_mode")
+        hip_check(self.lib.amgh_dist_set_gs_mode(self.h, self.GS_MODES[mode]), "dist_set_gs_mode")
+
+    def gs_pipelined(self):
+        """Per sharded level: do its Gauss-Seidel / SOR sweeps run as one sweep pipelined across the ranks under "exact"?"""
+        return [int(self.lib.amgh_dist_gs_pipelined(self.h, l)) == 1 for l in range(int(self.lib.amgh_dist_num_sharded_levels(self.h)))] if not self.plans_only else []
 
     def close(self):
         """Destroy the sharded handle first (it borrows the collapsed levels' handle), then the tail."""

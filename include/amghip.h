@@ -349,12 +349,18 @@ int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail);
  * (columns renumbered to [local | halo]) and builds the smoother schedules of the shards.            */
 int amgh_dist_finalize(amgh_dist_t* d);
 /* Gauss-Seidel / SOR on the sharded levels (smoother.jl:61-90, :193-221; collective in effect: the same mode on every rank).
- * exact = 1 (default): the whole level is swept in exact lexicographic order — the ranks sweep in turn (upward in a forward
- * sweep, downward in a backward one) and every turn's boundary values travel before the next turn; the cycle is the
- * reference's (1e-10) and a directional sweep costs the sum of the shards' sweeps plus nranks - 1 exchanges.
- * exact = 0: the processor-block hybrid — every shard sweeps at once, exact inside, halo frozen per directional sweep:
- * a different (convergent) iteration that scales with the ranks.  Jacobi is exact across shards in either mode.        */
-int amgh_dist_set_gs_mode(amgh_dist_t* d, int exact);
+ * mode = 1 (default): the whole level is swept in exact lexicographic order, the cycle is the reference's (1e-10).  Where every
+ *   rank holds the dataflow layout of its shard (amgh_dist_gs_pipelined) it is ONE sweep pipelined across the ranks: all
+ *   ranks launch at once, a block that reads rows of the neighbouring rank polls their mailboxes in that rank's memory
+ *   (peer-mapped) and starts on them as it starts on rows of its own rank's blocks — one dependency chain through the level,
+ *   one exchange per directional sweep.  Elsewhere the ranks sweep in turn (mode 2).
+ * mode = 2: exact order with the ranks strictly in turn (upward in a forward sweep, downward in a backward one), every
+ *   turn's boundary values travelling before the next: the sum of the shards' sweeps plus nranks - 1 exchanges.
+ * mode = 0: the processor-block hybrid — every shard sweeps at once, exact inside, halo frozen per directional sweep:
+ *   a different (convergent) iteration that scales with the ranks.  Jacobi is exact across shards in every mode.        */
+int amgh_dist_set_gs_mode(amgh_dist_t* d, int mode);
+/* 1 when level `level`'s Gauss-Seidel / SOR sweeps run as one pipelined sweep under mode 1, 0 when in turns, < 0: no such level */
+int amgh_dist_gs_pipelined(const amgh_dist_t* d, int level);
 int amgh_dist_num_sharded_levels(const amgh_dist_t* d);
 int amgh_dist_local_range(const amgh_dist_t* d, int level, int64_t* r0, int64_t* r1);
 /* ldiv! / _solve! on this rank's rows of the fine vectors (device pointers; collective).

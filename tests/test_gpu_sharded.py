@@ -87,6 +87,36 @@ def test_exact_gauss_seidel_across_shards_is_the_oracle_cycle_for_cycle(nranks):
     assert lc >= 2 and len(hist) == len(ho) and np.allclose(hist, ho, rtol=1e-8) and rel(x, xo) <= 1e-10
 
 
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+def test_gauss_seidel_pipelined_across_the_ranks_is_the_oracle_and_the_turns_bit_for_bit(nranks):
+    """Exact order as ONE sweep (amgh_dist_set_gs_mode 1 where every rank holds the dataflow layout of its shard — forced here on
+    small shards): all ranks launch at once, a block polls the rows it reads of the neighbouring rank in that rank's mailboxes.
+    Every cycle's iterate is the oracle's (1e-10) and, row for row the same arithmetic, BITWISE the iterate of the ranks
+    sweeping in turn; GS forward / backward / symmetric, SOR, V and W cycles; the ranks share this box's one GPU, so every
+    launch is the persistent form with all ranks' workgroups resident."""
+    from test_gpu_flow import tunables
+    lib = AMG.hip_lib()
+    A = AMG.poisson((40, 36, 48))
+    b = uniform(A.m, 6) - 0.3
+    cases = [(AMG.GaussSeidel(), AMG.GaussSeidel(), (0, 1)),
+             (AMG.GaussSeidel(AMG.ForwardSweep(), iter=2), AMG.GaussSeidel(AMG.BackwardSweep()), (0,)),
+             (AMG.SOR(1.2), AMG.SOR(0.9, AMG.ForwardSweep()), (0,))]
+    with tunables(lib, gs_bw=2, gs_bw_rows=64):
+        for pre, post, cycs in cases:
+            ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=post)
+            oh = O.OracleHierarchy(ml)
+            piped = sharded_run(ml, nranks, 4000, lambda sh: sh.gs_pipelined(), "exact")
+            assert all(len(p) >= 2 and p[0] and p[1] for p in piped), piped   # the two large levels, on every rank (a third, of ~2 900 rows, is too small for blocks: in turns)
+            for cyc in cycs:
+                got = sharded_cycles(ml, b, nranks, 4000, 2, cyc=cyc, gs_mode="exact")
+                turns = sharded_cycles(ml, b, nranks, 4000, 2, cyc=cyc, gs_mode="exact-turns")
+                for k in range(2):
+                    xo, _, _ = oh.solve(b, cycle=cyc, maxiter=k + 1, calculate_residual=False)
+                    assert rel(got[k], xo) <= 1e-10, (nranks, repr(pre), cyc, k)
+                    assert np.array_equal(got[k], turns[k]), (nranks, repr(pre), cyc, k)
+        assert lib.amgh_dev_sync(0) == 0
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_sharded_jacobi_equals_the_oracle_cycle_for_cycle(nranks):
     A = AMG.poisson((32, 24, 20))

@@ -288,6 +288,7 @@ int main(int argc, char** argv) {
       if (!getenv("BW_NO_RELAY")) {
         std::vector<double> xq(n);
         if (const char* ep = getenv("BW_RELAY_LDS_PAD")) { bw::relay_lds_pad() = (size_t)atoi(ep) * 1024; printf("relay: %d KB of LDS padding per workgroup\n", atoi(ep)); }
+        if (const char* eg = getenv("BW_RELAY_GRID")) { fa.grid = atoi(eg); printf("relay: persistent launches of %d workgroups (resident capacity at W = 3: %d)\n", fa.grid, bw::relay_resident_blocks<double>(mk, F.lds_max)); }
         for (int W : {2, 3, 4}) {
           if (const char* ew = getenv("BW_RELAY_ONLY")) if (atoi(ew) != W) continue;
           fa.tim = nullptr;
