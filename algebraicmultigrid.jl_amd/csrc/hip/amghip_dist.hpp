@@ -1131,8 +1131,9 @@ int amgh_dist_finalize(amgh_dist_t* d) {
       }
       bw::FlowHalo fh; fh.nlo = nlo; fh.pub_f = pub_f.data(); fh.pub_b = pub_b.data();
       tl_flow_halo = N > 1 ? &fh : nullptr;
+      tl_gs_level_rows = N > 1 ? L->n_glob : 0;
       const int rcg = csr_ensure_gs(M);
-      tl_flow_halo = nullptr;
+      tl_flow_halo = nullptr; tl_gs_level_rows = 0;
       RC_TRY(rcg);
     }
   }

@@ -1007,6 +1007,9 @@ inline int bw_err_check() {
 // when the operator is not eligible / the cost model says no.
 // (set by amghip_dist.hpp around the schedule build of a row-sharded operator whose sweeps may be pipelined across the ranks)
 thread_local const bw::FlowHalo* tl_flow_halo = nullptr;
+// (... and the rows of the whole level the operator is a shard of: the size thresholds of the block layouts are about the level —
+// a shard below them that keeps the level schedules would be swept in turns instead of in the pipeline)
+thread_local int64_t tl_gs_level_rows = 0;
 
 int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, const int32_t* col, const real* val, BuildTimer& tm, int nrhs_hint = 1) {
   bw::Params prm;
@@ -1049,7 +1052,9 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
     const bool two = ndir == 2 && g_gs_bw_two_min_rows > 0 && n >= g_gs_bw_two_min_rows;
     const double merged = merge_cost((P.nlevels + 2) / 3, (int64_t)(1.8 * (double)nnz));
     const double est = g_gs_bw_chain ? P.est_chain_seconds : P.est_seconds;
-    const bool used = (three && est < 0.8 * merged) || (two && est < 0.6 * merged);
+    // (a shard of a row-sharded level that can be swept in the pipeline across the ranks: the alternative to the block layout is
+    // not the merged groups but the ranks sweeping in turn)
+    const bool used = (three && est < 0.8 * merged) || (two && est < 0.6 * merged) || (three && tl_flow_halo != nullptr);
     if (getenv("AMGH_VERBOSE"))
       fprintf(stderr, "[amghip] n=%lld wavefront of blocks: %zu blocks, %d depths (dependency levels %d), %d directions, model %.3f ms (%.3f as one launch per depth) vs %.3f ms merged -> %s\n",
               (long long)n, P.blocks.size(), nlaunch, P.nlevels, ndir, est * 1e3, P.est_seconds * 1e3, merged * 1e3, used ? "used" : "not used");
@@ -1171,8 +1176,9 @@ int gs_build(GsSchedule* g, int64_t nrows, int64_t ncols, const int32_t* rowptr,
   g->bytes = 0;
   // (size thresholds measured with the chained kernel, profiles/r03_bw_threshold.log: 7-point rows pay from ~1.5 M rows — 128^3:
   // 7.38 -> 7.22 ms per cycle, 96^3: 4.40 -> 4.52 —, 19-point rows from ~3 M — the 2.0 M-row second level of 160^3: 9.95 -> 10.51 ms)
-  bool bw_size_ok = n >= g_gs_bw_min_rows;
-  if (!bw_size_ok && n >= g_gs_bw_min_rows / 2 && n > 0 && rowptr[n] <= 7 * n) bw_size_ok = true;
+  const int64_t n_level = std::max<int64_t>(n, tl_gs_level_rows);
+  bool bw_size_ok = n_level >= g_gs_bw_min_rows;
+  if (!bw_size_ok && n_level >= g_gs_bw_min_rows / 2 && n > 0 && rowptr[n] <= 7 * n) bw_size_ok = true;
   if (g_gs_bw > 0 && (nrhs_hint == 1 || (nrhs_hint > 1 && g_gs_bw_nrhs)) && n > 0 && (g_gs_bw == 2 || bw_size_ok)) {
     const int rcb = bw_build(g, n, ncols, rowptr, col, val, tm, nrhs_hint);
     if (rcb != AMGH_OK) return rcb;

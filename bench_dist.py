@@ -57,7 +57,7 @@ def node_levels(rank, world, bcast, build):
         levels = SH.level_arrays(ml, lc)
         tail = AMG.MultiLevel(ml.levels[lc:], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
                               ml.symmetry, method=ml.method)
-        info = dict(n_tail=sizes[lc], nnz=A.nnz, nlev=len(ml), lc=lc, sizes=sizes)
+        info = dict(n_tail=sizes[lc], nnz=A.nnz, nlev=len(ml), lc=lc, sizes=sizes, level_nnz=[l.A.nnz for l in ml.levels])
         if world > 1:
             # shared memory if it has the room (a container's /dev/shm can be as small as 64 MB), else the temp directory
             need = sum(a.nbytes for d in levels for key in ("A", "S", "P", "R") if d[key] is not None for a in d[key])
@@ -103,6 +103,7 @@ class Run:
                                       transport, gs_mode=gs_mode)
         self.shard_s = time.perf_counter() - t0
         self.transport = transport[0]
+        self.pipelined = self.sh.gs_pipelined()
 
     def measure(self, b, steps, warmup):
         sh = self.sh
@@ -161,7 +162,7 @@ def assemble_on_rank0(ctx, tag, z_loc):
 def check_parity(ctx, ml, b, z, kind, gs_mode="exact"):
     """rank 0: the assembled result of one cycle from x = 0 against the checker (never part of the timed region)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
-    if kind == "jacobi" or gs_mode == "exact":
+    if kind == "jacobi" or gs_mode in ("exact", "exact-turns"):
         from oracle import oracle as O
         want = O.OracleHierarchy(ml).precond(b)
         what = ("||z - z_oracle|| / ||z_oracle||, oracle V-cycle (" + ("Jacobi smoothers are exact across shards" if kind == "jacobi" else
@@ -340,13 +341,22 @@ def main_distributed(args):
             notes["transport_fallback_reason"] = next((r.get("error", "preflight failed") for r in preflights if r["transport"] == transport), "preflight failed")
             transport = chosen
 
-    # Gauss-Seidel in exact lexicographic order sweeps the shards of a level ONE AFTER THE OTHER (one dependency chain through
-    # the grid): every further sharded level adds N turns and N exchanges per sweep and wins nothing — a level that is not
-    # sharded is swept at single-GPU speed on rank 0.  The exact curve therefore shards the finest level only (its operators,
-    # residuals and transfers do scale, and it is the level that has to fit N x 288 GB); what it costs to shard every level of
-    # >= 200 000 rows in exact order is the secondary "gs_exact_all_levels".
+    # Gauss-Seidel in exact lexicographic order is ONE dependency chain through the grid.  Where every rank holds the block
+    # (dataflow) layout of its shard, the library sweeps the level as one pipeline across the ranks (amgh_dist_set_gs_mode 1):
+    # all ranks launch at once, blocks poll the rows they read of the neighbouring rank in that rank's mailboxes — the chain
+    # is paid once, the bandwidth-bound middle of the wavefront is shared by the ranks.  Levels without that layout (rows too
+    # long, or too few: the merged-group schedules) would be swept with the ranks IN TURN — N turns and N exchanges per sweep
+    # for nothing — so the exact curve shards the levels that pipeline (the library's own size rule for block layouts, applied
+    # to the whole level) and sweeps the ones below at single-GPU speed on rank 0.  Sharding every level of >= 200 000 rows in
+    # exact order is the secondary "gs_exact_all_levels".
     lc_all = info["lc"]
-    lc_exact = min(1, lc_all)
+    def pipelines(l):
+        rows, nnz = info["sizes"][l], info["level_nnz"][l]
+        return rows >= 3_000_000 or (rows >= 1_500_000 and nnz <= 7 * rows)
+    lc_exact = 0
+    while lc_exact < lc_all and pipelines(lc_exact):
+        lc_exact += 1
+    lc_exact = max(min(1, lc_all), lc_exact)
     tail_exact = None
     if rank == 0 and ml is not None and lc_exact < lc_all:
         tail_exact = AMG.MultiLevel(ml.levels[lc_exact:], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother, ml.symmetry, method=ml.method)
@@ -354,7 +364,7 @@ def main_distributed(args):
     def run_config(label, kind, tkind, want_spmv=False, gs_mode="exact", all_levels=False):
         lv, tl, ml_k = variant(kind)
         n_tail = None
-        if kind == "gs" and gs_mode == "exact" and not all_levels and lc_exact < lc_all:
+        if kind == "gs" and gs_mode in ("exact", "exact-turns") and not all_levels and lc_exact < lc_all:
             lv, tl, n_tail = lv[:lc_exact], tail_exact, info["sizes"][lc_exact]
         run, err = None, None
         try:
@@ -373,6 +383,7 @@ def main_distributed(args):
             res["parity"] = check_parity(ctx, ml_k, b, z, kind, gs_mode)
         res["gs_mode"] = gs_mode if kind == "gs" else None
         res["sharded_levels"] = len(lv)
+        res["gs_pipelined_by_level"] = run.pipelined if (kind == "gs" and gs_mode == "exact") else None
         run.close()
         res["value"] = n * args.steps / res["elapsed"]
         ok = bcast(res["parity"]["ok"] if rank == 0 else None)
@@ -397,6 +408,7 @@ def main_distributed(args):
         if smoother != "jacobi":
             todo.append(("jacobi", "jacobi", transport, "exact"))
             todo.append(("gs_hybrid", "gs", transport, "hybrid"))   # every shard sweeps at once, halo frozen per directional sweep
+            todo.append(("gs_exact_turns", "gs", transport, "exact-turns"))   # the same levels with the ranks strictly in turn (what round 4 shipped)
             if lc_exact < lc_all:
                 todo.append(("gs_exact_all_levels", "gs", transport, "exact-all"))   # exact order with every large level sharded
         if transport != "ipc":
@@ -416,9 +428,10 @@ def main_distributed(args):
     if rank == 0:
         alg = spmv_bytes(info["nnz"], n, n)
         spmv_ms = primary.get("spmv_ms")
-        smooth_txt = ("ruge_stuben defaults (symmetric Gauss-Seidel pre+post in exact lexicographic order over the whole level: "
-                      "the ranks sweep in turn, boundary values exchanged between turns — the reference's iterate; only the finest "
-                      "level is sharded on this curve: a level swept in turns gains nothing from more shards)"
+        smooth_txt = ("ruge_stuben defaults (symmetric Gauss-Seidel pre+post in exact lexicographic order over the whole level — the "
+                      "reference's iterate — as ONE sweep pipelined across the ranks: all ranks launch at once, a block polls the rows "
+                      "it reads of the neighbouring rank in that rank's peer-mapped mailboxes; the levels with block layouts are "
+                      "sharded on this curve (gs_pipelined_by_level), the ones below are swept on rank 0)"
                       if smoother == "gs" else "Jacobi(2/3) pre+post (exact across shards)")
         tr_txt = {"rccl": "RCCL send/recv called by libamghip", "ipc": "hipIpc peer-mapped send buffers + stream-written "
                   "flags in shared memory (libamghip's IPC transport)"}[primary["transport"]]
@@ -443,7 +456,7 @@ def main_distributed(args):
                        # curves that CAN scale are secondary["gs_hybrid"] (every shard at once, halo frozen per directional sweep:
                        # another convergent iteration, checked against its own emulation) and secondary["jacobi"] (exact across shards)
                        "gauss_seidel_is_critical_path_bound": smoother == "gs",
-                       "gs_mode": primary.get("gs_mode"),
+                       "gs_mode": primary.get("gs_mode"), "gs_pipelined_by_level": primary.get("gs_pipelined_by_level"),
                        "scaling_curve": "secondary.gs_hybrid / secondary.jacobi" if smoother == "gs" else "value",
                        "parallelism": f"row-shard x{world} ({primary['transport']} halos, libamghip amgh_dist_*)"},
             "roofline": None if spmv_ms is None else {

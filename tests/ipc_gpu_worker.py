@@ -39,9 +39,12 @@ def main():
         transport, device = ("rccl", open(path, "rb").read()), rank
     else:
         transport, device = ("ipc", name), int(os.environ.get("AMG_IPC_DEVICE_OF_RANK", "0").split(",")[rank % len(os.environ.get("AMG_IPC_DEVICE_OF_RANK", "0").split(","))])
+    for kv in filter(None, os.environ.get("AMG_TUNABLES", "").split(",")):   # e.g. gs_bw=2,gs_bw_rows=64: block layouts on small shards
+        k, v = kv.split("=")
+        assert AMG.hip_lib().amgh_debug_set_tunable(k.encode(), int(v)) == 0
     sh = SH.ShardedHierarchy.from_multilevel(ml, rank, nranks, device, transport, shard_min_rows, gs_mode=os.environ.get("AMG_DIST_GS_MODE", "hybrid"))
     bl = b[sh.r0:sh.r1]
-    out = {"r0": sh.r0, "r1": sh.r1, "lc": sh.lc}
+    out = {"r0": sh.r0, "r1": sh.r1, "lc": sh.lc, "pipelined": np.array(sh.gs_pipelined(), dtype=np.int32)}
     if case == "die":
         # rank nranks-1 vanishes after one cycle; the others are inside a 40-cycle solve whose streams wait for flags
         # only the dead rank would write: they must come back with AMGH_ESTATE, not hang

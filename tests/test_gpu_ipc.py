@@ -111,6 +111,25 @@ def test_ipc_processes_exact_gauss_seidel_is_the_oracle_cycle(nranks):
     assert rel(assemble(parts, "solve_v_x"), xo) <= 1e-10
 
 
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+def test_ipc_processes_pipelined_gauss_seidel_is_the_oracle_cycle(nranks):
+    """REAL processes, exact order as ONE sweep pipelined across the ranks: every process maps its neighbours' mailbox arrays
+    with hipIpc handles, its blocks poll the neighbour's cells through that mapping while all the ranks' (persistent) launches
+    share the one GPU.  Every cycle and the solve equal the single-process oracle's."""
+    ml, b, smr, _ = build_case("gs")
+    parts = run_ipc("gs", nranks, env_extra={"AMG_DIST_GS_MODE": "exact", "AMG_TUNABLES": "gs_bw=2,gs_bw_rows=64"})
+    assert all(p["pipelined"][0] == 1 for p in parts), [p["pipelined"] for p in parts]
+    oh = O.OracleHierarchy(ml)
+    got = assemble(parts, "cycles")
+    for k in range(3):
+        xo, _, _ = oh.solve(b, maxiter=k + 1, calculate_residual=False)
+        assert rel(got[k], xo) <= 1e-10, (nranks, k)
+    xo, ho, _ = oh.solve(b, reltol=1e-10, maxiter=60)
+    hist = parts[0]["solve_v_hist"]
+    assert len(hist) == len(ho) and np.allclose(hist, ho, rtol=1e-8)
+    assert rel(assemble(parts, "solve_v_x"), xo) <= 1e-10
+
+
 def test_ipc_processes_sor_w_cycle():
     ml, b, smr, _ = build_case("sor_w")
     lc = SH.num_sharded_levels([l.A.m for l in ml.levels] + [ml.final_A.m], 4, smr)
