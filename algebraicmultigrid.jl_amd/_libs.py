@@ -194,6 +194,7 @@ def _bind_dist(L):
     L.amgh_dist_push_level.argtypes = [vp, i64, i64, vp, vp] + [vp] * 12 + [C.POINTER(amgh_smoother_t),
                                                                             C.POINTER(amgh_smoother_t)]
     L.amgh_dist_set_tail.argtypes = [vp, vp]
+    L.amgh_dist_set_host_tail.argtypes = [vp, vp, vp]
     L.amgh_dist_finalize.argtypes = [vp]
     L.amgh_dist_set_gs_mode.argtypes = [vp, C.c_int]
     L.amgh_dist_gs_pipelined.argtypes = [vp, C.c_int]

@@ -1741,6 +1741,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_dup_launch")) g_gs_dup_launch = value < 0 ? 0 : value > 16 ? 16 : value;   // (a repeat count: never negative)
   else if (!strcmp(name, "gs_flow_xzero")) g_gs_flow_xzero = value;
   else if (!strcmp(name, "gs_bw_grid")) g_gs_bw_grid = value < 0 ? 0 : value;
+  else if (!strcmp(name, "gs_bw_grid_long")) g_gs_bw_grid_long = value < 0 ? 0 : value;
   else if (!strcmp(name, "gs_bw_relay")) g_gs_bw_relay = value == 0 ? 0 : BW_RELAY_W;   // (one count is instantiated)
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;
   else if (!strcmp(name, "jacobi_zero")) g_jacobi_zero = value;

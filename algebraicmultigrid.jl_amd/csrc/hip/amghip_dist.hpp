@@ -77,6 +77,26 @@ struct Transport {
   virtual int pack_target(VecPlan& pl, hipStream_t, real** sendbuf) { *sendbuf = pl.d_sendbuf; return AMGH_OK; }
   virtual int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st, bool overlap) = 0;
   virtual int exchange_finish(VecPlan& pl, hipStream_t st) = 0;
+  // the same exchange on HOST buffers (device = -1 with a host tail: the C code's cycle executed in host memory — the CPU
+  // multi-process test): every rank's packed entries travel through allgatherv_host as bit patterns, prefixed by the
+  // offsets and counts of its per-peer spans (slow, exact)
+  virtual int exchange_host(VecPlan& pl, const real* sendbuf, real* recvbuf) {
+    const size_t N = (size_t)nranks;
+    std::vector<int64_t> mine(2 * N + (size_t)pl.nsend);
+    for (size_t p = 0; p < N; ++p) { mine[p] = pl.send[p].off; mine[N + p] = pl.send[p].cnt; }
+    for (int64_t i = 0; i < pl.nsend; ++i) { const double v = (double)sendbuf[i]; std::memcpy(&mine[2 * N + (size_t)i], &v, 8); }
+    std::vector<std::vector<int64_t>> all;
+    RC_TRY(allgatherv_host(mine, all));
+    for (size_t p = 0; p < N; ++p) {
+      if ((int)p == rank || pl.recv[p].cnt <= 0) continue;
+      const std::vector<int64_t>& v = all[p];
+      if (v.size() < 2 * N) return AMGH_ESTATE;
+      const int64_t off = v[(size_t)rank], cnt = v[N + (size_t)rank];
+      if (cnt != pl.recv[p].cnt || off < 0 || 2 * N + (size_t)(off + cnt) > v.size()) return AMGH_ESTATE;
+      for (int64_t i = 0; i < cnt; ++i) { double x; std::memcpy(&x, &v[2 * N + (size_t)(off + i)], 8); recvbuf[pl.recv[p].off + i] = (real)x; }
+    }
+    return AMGH_OK;
+  }
   virtual int allreduce(double* v, int n, bool max_op) = 0;  // host values, in place
   virtual int barrier() = 0;
   // host wait for a stream whose work may depend on other ranks (a transport that can, bounds the wait)
@@ -362,6 +382,9 @@ struct LocalTransport : Transport {
 // one local operator block: rows = my rows, columns = [my entries of the input vector | its halo]
 struct DistOp {
   amgh_csr op;
+  std::vector<int32_t> h_rowptr, h_col;   // host execution (device = -1): the block in host memory, columns in [local | halo]
+  std::vector<real> h_val;
+  int64_t h_ncols = 0;
   bool present = false;
   int32_t i0 = 0, i1 = 0;  // rows [i0, i1) read no halo column (interior): they can run while the halo is in flight
 };
@@ -409,6 +432,10 @@ struct amgh_dist {
   amgh_t* tail = nullptr;              // the collapsed levels (on the rank that owns them), not owned
   bool finalized = false;
   bool host_only = false;              // device < 0: halo plans in host memory only, no GPU call anywhere
+  amgh_coarse_fn host_tail = nullptr;  // ... unless the collapsed levels are given as a host callback (amgh_dist_set_host_tail): then the
+  void* host_tail_user = nullptr;      // whole sharded cycle EXECUTES in host memory (vectors, exchanges, sweeps: plain loops)
+  bool host_exec = false;
+  std::vector<real> h_pack;            // host execution: the packed send entries of the exchange under way
   bool gs_exact = true;                // Gauss-Seidel / SOR across the shards: exact lexicographic order or the hybrid (amgh_dist_set_gs_mode)
   bool gs_pipe = true;                 // ... exact order as ONE pipelined sweep where the level allows it (DistLevel::Pipe::on), else the ranks in turn
   int nplans = 0;
@@ -493,6 +520,10 @@ int block_upload(amgh_dist* d, DistOp& dop, HostBlock& hb, const VecPlan& pl) {
   dop.i0 = std::min(i0, i1); dop.i1 = i1;
   if (!d->host_only)
     RC_TRY(csr_upload(&dop.op, d->device, n, nloc + pl.nhalo(), hb.rowptr.data(), lc.data(), hb.val.data()));
+  else if (d->host_exec) {
+    dop.h_rowptr = hb.rowptr; dop.h_col = lc; dop.h_val = hb.val; dop.h_ncols = nloc + pl.nhalo();
+    dop.op.nrows = n; dop.op.ncols = nloc + pl.nhalo(); dop.op.nnz = (int64_t)hb.val.size();
+  }
   dop.present = true;
   hb = HostBlock();
   return AMGH_OK;
@@ -514,6 +545,13 @@ int take_block(HostBlock& hb, int64_t nrows, const int32_t* rowptr, const int32_
 // ---- data path ---------------------------------------------------------------------------------------------------
 int halo_begin(amgh_dist* d, VecPlan& pl, real* vec, bool overlap = false) {
   if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
+  if (d->host_exec) {   // host execution: pack, exchange, done (nothing is in flight behind this call)
+    d->h_pack.resize((size_t)std::max<int64_t>(1, pl.nsend));
+    for (int64_t i = 0; i < pl.nsend; ++i) d->h_pack[(size_t)i] = vec[pl.h_send_idx[(size_t)i]];
+    ++d->ex_count;
+    d->ex_bytes += (int64_t)sizeof(real) * pl.nsend;
+    return d->tr->exchange_host(pl, d->h_pack.data(), vec + pl.nloc());
+  }
   real* sendbuf = nullptr;
   RC_TRY(d->tr->pack_target(pl, d->stream, &sendbuf));
   if (pl.nsend > 0) {
@@ -526,7 +564,7 @@ int halo_begin(amgh_dist* d, VecPlan& pl, real* vec, bool overlap = false) {
   return d->tr->exchange_begin(pl, sendbuf, vec + pl.nloc(), d->stream, overlap);
 }
 int halo_finish(amgh_dist* d, VecPlan& pl) {
-  if (!pl.any || d->tr->nranks == 1) return AMGH_OK;
+  if (!pl.any || d->tr->nranks == 1 || d->host_exec) return AMGH_OK;
   return d->tr->exchange_finish(pl, d->stream);
 }
 int halo_exchange(amgh_dist* d, VecPlan& pl, real* vec) {
@@ -551,12 +589,52 @@ int rows_apply(const amgh_csr* op, int mode, const real* x, const real* b, real*
   return AMGH_EINVAL;
 }
 
+// ---- host execution (device = -1 + amgh_dist_set_host_tail): the operators as plain loops over the block in host memory, sums in
+// stored entry order (the order of the stream kernels and of the scalar loops) ----
+int rows_apply_host(const DistOp& dop, int mode, const real* x, const real* b, real* y, real omega) {
+  const int64_t n = (int64_t)dop.h_rowptr.size() - 1;
+  for (int64_t i = 0; i < n; ++i) {
+    real acc = 0, dg = 0;
+    for (int32_t j = dop.h_rowptr[(size_t)i]; j < dop.h_rowptr[(size_t)i + 1]; ++j) {
+      const int32_t c = dop.h_col[(size_t)j];
+      if (mode == M_JACOBI && c == i) { dg = dop.h_val[(size_t)j]; continue; }
+      acc += dop.h_val[(size_t)j] * x[c];
+    }
+    switch (mode) {
+      case M_SPMV: y[i] = acc; break;
+      case M_RESID: y[i] = b[i] - acc; break;
+      case M_ADD: y[i] += acc; break;
+      case M_JACOBI: y[i] = dg != (real)0 ? ((real)1 - omega) * x[i] + omega * ((b[i] - acc) / dg) : x[i]; break;   // smoother.jl:113-141
+      default: return AMGH_EINVAL;
+    }
+  }
+  return AMGH_OK;
+}
+// one directional Gauss-Seidel / SOR sweep over the local rows in index order (smoother.jl:61-90, :193-221), halo entries as they stand
+void gs_sweep_host(const DistOp& dop, bool backward, bool sor, real omega, real* x, const real* b) {
+  const int64_t n = (int64_t)dop.h_rowptr.size() - 1;
+  for (int64_t s = 0; s < n; ++s) {
+    const int64_t i = backward ? n - 1 - s : s;
+    real acc = 0, dg = 0;
+    for (int32_t j = dop.h_rowptr[(size_t)i]; j < dop.h_rowptr[(size_t)i + 1]; ++j) {
+      const int32_t c = dop.h_col[(size_t)j];
+      if (c == i) dg = dop.h_val[(size_t)j]; else acc += dop.h_val[(size_t)j] * x[c];
+    }
+    if (dg == (real)0) continue;
+    x[i] = sor ? ((real)1 - omega) * x[i] + (omega / dg) * (b[i] - acc) : (b[i] - acc) / dg;
+  }
+}
+
 // y = op(vec) with the halo of vec exchanged first; interior rows run while the halo is in flight when the transport
 // is asynchronous and the block is big enough for three launches to pay
 int dist_apply(amgh_dist* d, DistOp& dop, int mode, VecPlan& pl, real* vec, const real* b, real* y, real omega,
                bool skip_exchange = false) {
   const amgh_csr* op = &dop.op;
   const int32_t n = (int32_t)op->nrows;
+  if (d->host_exec) {
+    if (!skip_exchange) RC_TRY(halo_exchange(d, pl, vec));
+    return dop.present ? rows_apply_host(dop, mode, vec, b, y, omega) : AMGH_OK;
+  }
   if (skip_exchange) return rows_apply(op, mode, vec, b, y, omega, 0, n, d->stream);
   const bool split = d->overlap && d->tr->async() && pl.any && d->tr->nranks > 1 && (dop.i1 - dop.i0) >= 65536;
   RC_TRY(halo_begin(d, pl, vec, split));
@@ -578,6 +656,38 @@ int dist_smooth(amgh_dist* d, int l, const amgh_smoother_t& s, bool xzero, bool*
   DistOp* M = L->smat();
   const int64_t n = pl.nloc();
   bool fresh = xzero;
+  if (d->host_exec) {   // host execution: the same control flow — exchanges, turns — over plain loops
+    for (int it = 0; it < s.iter; ++it) {
+      if (s.kind == AMGH_SMOOTH_JACOBI) {
+        if (!fresh) RC_TRY(halo_exchange(d, pl, L->x));
+        fresh = false;
+        if (n > 0) { RC_TRY(rows_apply_host(*M, M_JACOBI, L->x, L->b, L->tmp, s.omega)); std::memcpy(L->x, L->tmp, sizeof(real) * (size_t)n); }
+      } else if (s.kind == AMGH_SMOOTH_GS || s.kind == AMGH_SMOOTH_SOR) {
+        const bool sor = s.kind == AMGH_SMOOTH_SOR;
+        for (int dir = 0; dir < 2; ++dir) {
+          const bool run = dir == 0 ? (s.sweep == AMGH_SWEEP_FORWARD || s.sweep == AMGH_SWEEP_SYMMETRIC)
+                                    : (s.sweep == AMGH_SWEEP_BACKWARD || s.sweep == AMGH_SWEEP_SYMMETRIC);
+          if (!run) continue;
+          if (!fresh) RC_TRY(halo_exchange(d, pl, L->x));
+          fresh = false;
+          if (!d->gs_exact || d->tr->nranks == 1) {
+            if (n > 0) gs_sweep_host(*M, dir == 1, sor, s.omega, L->x, L->b);
+          } else {
+            const int P = d->tr->nranks;
+            for (int turn = 0; turn < P; ++turn) {
+              const int q = dir == 0 ? turn : P - 1 - turn;
+              if (q == d->tr->rank && n > 0) gs_sweep_host(*M, dir == 1, sor, s.omega, L->x, L->b);
+              if (turn + 1 < P) RC_TRY(halo_exchange(d, pl, L->x));
+            }
+          }
+        }
+      } else if (s.kind != AMGH_SMOOTH_NONE) {
+        return AMGH_EINVAL;
+      }
+    }
+    *b_kept = false;
+    return AMGH_OK;
+  }
   for (int it = 0; it < s.iter; ++it) {
     if (s.kind == AMGH_SMOOTH_JACOBI) {
       if (n > 0) RC_TRY(csr_ensure_diag(&M->op, d->stream));
@@ -652,6 +762,11 @@ int dist_cycle_next(amgh_dist* d, int l, int cyc) {  // __solve_next! (multileve
 int dist_cycle(amgh_dist* d, int l, int cyc, bool xzero) {
   const int lc = (int)d->levels.size();
   if (l == lc) {  // the collapsed levels: single-GPU cycle on their owner, nothing elsewhere
+    if (d->host_exec) {   // host execution: the owner's callback IS the collapsed levels (x = 0 on entry, one application per visit)
+      const int64_t nt = d->xplan[lc].nloc();
+      if (nt > 0 && d->host_tail && d->host_tail(d->host_tail_user, d->bt, d->xt, nt) != 0) return AMGH_ESTATE;
+      return AMGH_OK;
+    }
     if (!d->tail) return AMGH_OK;
     if (d->tail->levels.empty()) return coarse_solve(d->tail, d->xt, d->bt);
     return cycle(d->tail, 0, d->xt, d->bt, cyc, xzero);
@@ -666,7 +781,8 @@ int dist_cycle(amgh_dist* d, int l, int cyc, bool xzero) {
   RC_TRY(dist_apply(d, L->A, M_RESID, xp, L->x, L->b, L->res, 0.0));                                // res = b - A x
   RC_TRY(dist_apply(d, L->R, M_SPMV, L->rplan, L->res, nullptr, bc, 0.0));                          // b_c = R res
   const int64_t ncx = xpc.nloc() + xpc.nhalo();
-  if (ncx > 0) HIP_TRY(hipMemsetAsync(xc, 0, sizeof(real) * ncx, d->stream));                                  // coarse_x .= 0
+  if (ncx > 0 && d->host_exec) std::memset(xc, 0, sizeof(real) * (size_t)ncx);
+  else if (ncx > 0) HIP_TRY(hipMemsetAsync(xc, 0, sizeof(real) * ncx, d->stream));                             // coarse_x .= 0
   RC_TRY(dist_cycle_next(d, l + 1, cyc));
   RC_TRY(dist_apply(d, L->P, M_ADD, xpc, xc, nullptr, L->x, 0.0));                                   // x += P x_c
   RC_TRY(dist_smooth(d, l, L->post, false, &b_kept));
@@ -674,6 +790,7 @@ int dist_cycle(amgh_dist* d, int l, int cyc, bool xzero) {
 }
 
 int dist_apply_cycle(amgh_dist* d, int cyc, bool xzero) {
+  if (d->levels.empty() && d->host_exec) return dist_cycle(d, 0, cyc, xzero);
   if (d->levels.empty()) {
     if (!d->tail) return AMGH_OK;
     if (d->tail->levels.empty()) return coarse_solve(d->tail, d->xt, d->bt);
@@ -688,6 +805,13 @@ real* dist_b0(amgh_dist* d) { return d->levels.empty() ? d->bt : d->levels[0]->b
 // sum over all ranks of x . y over the local entries (host result, same bits on every rank)
 int dist_dot(amgh_dist* d, const real* x, const real* y, int64_t n, real* out) {
   real v = 0.0;
+  if (d->host_exec) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) acc += (double)x[i] * (double)y[i];
+    RC_TRY(d->tr->allreduce(&acc, 1, false));
+    *out = (real)acc;
+    return AMGH_OK;
+  }
   if (n > 0) {
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kThreads - 1) / kThreads));
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, d->stream, x, y, n, d->partial);
@@ -705,6 +829,7 @@ int dist_dot(amgh_dist* d, const real* x, const real* y, int64_t n, real* out) {
 // || b - A x || over all ranks (multilevel.jl:188-190); res of level 0 is the scratch, as in the reference
 int dist_resnorm(amgh_dist* d, real* out) {
   real s = 0.0;
+  if (d->levels.empty() && d->host_exec) return AMGH_EUNSUPPORTED;   // (host execution is for sharded levels over a host tail)
   if (d->levels.empty()) {
     real v = 0.0;
     if (d->tail) {
@@ -730,12 +855,13 @@ int dist_resnorm(amgh_dist* d, real* out) {
 int dist_check(const amgh_dist* d) {
   if (!d) return AMGH_EINVAL;
   if (!d->finalized) return AMGH_ESTATE;
-  if (d->host_only) return AMGH_EUNSUPPORTED;  // plans only: there is no data path without a device
+  if (d->host_only && !d->host_exec) return AMGH_EUNSUPPORTED;  // plans only: there is no data path without a device or a host tail
   return AMGH_OK;
 }
 
 void dist_free(amgh_dist* d) {
   for (DistLevel* L : d->levels) {
+    if (d->host_exec) { free(L->x); free(L->b); free(L->res); free(L->tmp); }
     if (!d->host_only) {
       for (DistOp* o : {&L->A, &L->S, &L->P, &L->R}) csr_free(&o->op);
       hipFree(L->x); hipFree(L->b); hipFree(L->res); hipFree(L->tmp);
@@ -752,6 +878,7 @@ void dist_free(amgh_dist* d) {
     hipFree(d->xt); hipFree(d->bt); hipFree(d->partial); hipFree(d->scal);
     if (d->stream) hipStreamDestroy(d->stream);
   }
+  if (d->host_exec) { free(d->xt); free(d->bt); }
   delete d->tr;
   delete d;
 }
@@ -922,6 +1049,17 @@ int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail) {
   if (d->finalized) return AMGH_ESTATE;
   if (tail && (d->host_only || !tail->finalized || tail->nrhs != 1 || tail->device != d->device)) return AMGH_EINVAL;
   d->tail = tail;
+  return AMGH_OK;
+}
+
+// The collapsed levels as a HOST callback (device = -1 handles; before amgh_dist_finalize, on every rank — the owner's fn is the
+// one that gets called, with x = 0 semantics of one visit: x = fn(b)).  With it the handle EXECUTES the sharded cycle in host
+// memory: amgh_dist_precond_apply_d / amgh_dist_solve_d then take host pointers.
+int amgh_dist_set_host_tail(amgh_dist_t* d, amgh_coarse_fn fn, void* user) {
+  if (!d || !d->host_only) return AMGH_EINVAL;
+  if (d->finalized) return AMGH_ESTATE;
+  d->host_tail = fn; d->host_tail_user = user;
+  d->host_exec = true;
   return AMGH_OK;
 }
 
@@ -1104,6 +1242,12 @@ int amgh_dist_finalize(amgh_dist_t* d) {
     RC_TRY(block_upload(d, L->S, L->hS, xp));
     RC_TRY(block_upload(d, L->P, L->hP, d->xplan[l + 1]));
     RC_TRY(block_upload(d, L->R, L->hR, L->rplan));
+    if (d->host_exec) {   // host execution: the level's vectors in host memory
+      const int64_t nl = xp.nloc();
+      auto zalloc = [](int64_t k) { return (real*)calloc((size_t)std::max<int64_t>(1, k), sizeof(real)); };
+      L->x = zalloc(nl + xp.nhalo()); L->b = zalloc(nl); L->res = zalloc(nl + L->rplan.nhalo()); L->tmp = zalloc(nl);
+      if (!L->x || !L->b || !L->res || !L->tmp) return AMGH_ENOMEM;
+    }
     if (d->host_only) continue;
     const int64_t nloc = xp.nloc();
     RC_TRY(dev_alloc(&L->x, nloc + xp.nhalo()));
@@ -1139,6 +1283,12 @@ int amgh_dist_finalize(amgh_dist_t* d) {
   }
   if (!d->host_only) RC_TRY(dist_pipe_setup(d));
   if (d->host_only) {
+    if (d->host_exec) {
+      VecPlan& tp = d->xplan[lc];
+      d->xt = (real*)calloc((size_t)std::max<int64_t>(1, tp.nloc() + tp.nhalo()), sizeof(real));
+      d->bt = (real*)calloc((size_t)std::max<int64_t>(1, tp.nloc()), sizeof(real));
+      if (!d->xt || !d->bt) return AMGH_ENOMEM;
+    }
     RC_TRY(tr->barrier());
     d->finalized = true;
     return AMGH_OK;
@@ -1197,20 +1347,40 @@ int amgh_dist_plan_info(const amgh_dist_t* d, int level, int64_t* out_counts, in
   return amgh_dist_plan_info2(d, level, 0, out_counts, halo_globals, send_idx, send_cnt_per_peer, recv_cnt_per_peer);
 }
 
+namespace {
+// (host execution: the "device pointers" of the entry points are host pointers, copies are memcpy, nothing is enqueued)
+int dist_copy(amgh_dist* d, real* dst, const real* src, int64_t n) {
+  if (n <= 0) return AMGH_OK;
+  if (d->host_exec) { std::memmove(dst, src, sizeof(real) * (size_t)n); return AMGH_OK; }
+  HIP_TRY(hipMemcpyAsync(dst, src, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
+  return AMGH_OK;
+}
+int dist_zero(amgh_dist* d, real* p, int64_t n) {
+  if (n <= 0) return AMGH_OK;
+  if (d->host_exec) { std::memset(p, 0, sizeof(real) * (size_t)n); return AMGH_OK; }
+  HIP_TRY(hipMemsetAsync(p, 0, sizeof(real) * n, d->stream));
+  return AMGH_OK;
+}
+int dist_setdev(amgh_dist* d) {
+  if (d->host_exec) return AMGH_OK;
+  HIP_TRY(hipSetDevice(d->device));
+  return AMGH_OK;
+}
+}  // namespace
+
 // ldiv!(x, p, b) on the sharded hierarchy: r_loc_d / z_loc_d hold this rank's rows of level 0 (device pointers).
 // Enqueues on the handle's stream; amgh_dist_sync waits for it.
 int amgh_dist_precond_apply_d(amgh_dist_t* d, const real* r_loc_d, real* z_loc_d, int cycle_) {
   RC_TRY(dist_check(d));
   if (cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
-  HIP_TRY(hipSetDevice(d->device));
+  RC_TRY(dist_setdev(d));
   const VecPlan& p0 = d->xplan[0];
   const int64_t n = p0.nloc();
   if (n > 0 && (!r_loc_d || !z_loc_d)) return AMGH_EINVAL;
-  if (n > 0) HIP_TRY(hipMemcpyAsync(dist_b0(d), r_loc_d, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
-  if (n + p0.nhalo() > 0) HIP_TRY(hipMemsetAsync(dist_x0(d), 0, sizeof(real) * (n + p0.nhalo()), d->stream));
+  RC_TRY(dist_copy(d, dist_b0(d), r_loc_d, n));
+  RC_TRY(dist_zero(d, dist_x0(d), n + p0.nhalo()));
   RC_TRY(dist_apply_cycle(d, cycle_, true));
-  if (n > 0) HIP_TRY(hipMemcpyAsync(z_loc_d, dist_x0(d), sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
-  return AMGH_OK;
+  return dist_copy(d, z_loc_d, dist_x0(d), n);
 }
 
 // _solve!(x, ml, b, cycle; ...) (multilevel.jl:158-198) on the sharded hierarchy: x_loc_d in/out (initial guess).
@@ -1218,14 +1388,12 @@ int amgh_dist_solve_d(amgh_dist_t* d, const real* b_loc_d, real* x_loc_d, int cy
                       double reltol, int calculate_residual, real* resid_hist, int* iters) {
   RC_TRY(dist_check(d));
   if (cycle_ < 0 || cycle_ > 2 || maxiter < 0) return AMGH_EINVAL;
-  HIP_TRY(hipSetDevice(d->device));
+  RC_TRY(dist_setdev(d));
   const VecPlan& p0 = d->xplan[0];
   const int64_t n = p0.nloc();
   if (n > 0 && (!b_loc_d || !x_loc_d)) return AMGH_EINVAL;
-  if (n > 0) {
-    HIP_TRY(hipMemcpyAsync(dist_b0(d), b_loc_d, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
-    HIP_TRY(hipMemcpyAsync(dist_x0(d), x_loc_d, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
-  }
+  RC_TRY(dist_copy(d, dist_b0(d), b_loc_d, n));
+  RC_TRY(dist_copy(d, dist_x0(d), x_loc_d, n));
   real nb2 = 0.0;
   RC_TRY(dist_dot(d, dist_b0(d), dist_b0(d), n, &nb2));
   const real normb = std::sqrt(nb2);
@@ -1242,7 +1410,8 @@ int amgh_dist_solve_d(amgh_dist_t* d, const real* b_loc_d, real* x_loc_d, int cy
     ++itr;
   }
   if (iters) *iters = itr - 1;
-  if (n > 0) HIP_TRY(hipMemcpyAsync(x_loc_d, dist_x0(d), sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
+  RC_TRY(dist_copy(d, x_loc_d, dist_x0(d), n));
+  if (d->host_exec) return AMGH_OK;
   RC_TRY(d->tr->wait_stream(d->stream));
   return bw_err_check();   // (sharded levels and the tail sweep by dataflow kernels too: a poll give-up is this call's error)
 }
@@ -1251,13 +1420,13 @@ int amgh_dist_solve_d(amgh_dist_t* d, const real* b_loc_d, real* x_loc_d, int cy
 int amgh_dist_spmv_d(amgh_dist_t* d, int level, const real* x_loc_d, real* y_loc_d) {
   RC_TRY(dist_check(d));
   if (level < 0 || level >= (int)d->levels.size()) return AMGH_EINVAL;
-  HIP_TRY(hipSetDevice(d->device));
+  RC_TRY(dist_setdev(d));
   DistLevel* L = d->levels[level];
   VecPlan& pl = d->xplan[level];
   const int64_t n = pl.nloc();
   if (n > 0 && !y_loc_d) return AMGH_EINVAL;
   // x_loc_d == NULL: multiply the level's own x (what the last cycle left there) — no copy in front of the exchange
-  if (n > 0 && x_loc_d && x_loc_d != L->x) HIP_TRY(hipMemcpyAsync(L->x, x_loc_d, sizeof(real) * n, hipMemcpyDeviceToDevice, d->stream));
+  if (n > 0 && x_loc_d && x_loc_d != L->x) RC_TRY(dist_copy(d, L->x, x_loc_d, n));
   return dist_apply(d, L->A, M_SPMV, pl, L->x, nullptr, n > 0 ? y_loc_d : L->tmp, 0.0);
 }
 

@@ -538,7 +538,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
         fa.epoch = op->pipe_epoch; fa.rmbox = op->pipe_rmbox; fa.grid = op->pipe_grid;
         e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
       } else if (ncolv == 1 && g_gs_bw_relay > 0) {
-        fa.grid = g_gs_bw_grid;
+        fa.grid = g->bw.maxk > 6 ? g_gs_bw_grid_long : g_gs_bw_grid;
         e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
       }
       else e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);

@@ -130,6 +130,14 @@ def rccl_unique_id():
     return bytes(buf)
 
 
+class _HostBuffer:
+    """A vector of the host-executed sharded cycle (device < 0 with a host tail): numpy memory behind the same .ptr as a DeviceBuffer."""
+
+    def __init__(self, n, dtype):
+        self.a = np.zeros(int(n), dtype=dtype)
+        self.ptr = self.a.ctypes.data
+
+
 class ShardedHierarchy:
     """One rank of the row-sharded MultiLevel.
 
@@ -144,15 +152,18 @@ class ShardedHierarchy:
     once, every vector and every operation of the sharded cycle is Float32).
     """
 
-    def __init__(self, levels, n_tail, tail, rank, nranks, device, transport, dtype=np.float64, gs_mode="exact"):
+    def __init__(self, levels, n_tail, tail, rank, nranks, device, transport, dtype=np.float64, gs_mode="exact", host_tail=None):
         self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
-        self.plans_only = self.device < 0
+        # device < 0: plans only — unless the collapsed levels come as a host function (host_tail: b -> x, one visit from x = 0,
+        # on the owner; anything callable or None elsewhere): the library then EXECUTES the sharded cycle in host memory
+        self.host_exec = self.device < 0 and host_tail is not None
+        self.plans_only = self.device < 0 and not self.host_exec
         self.dtype = np.dtype(np.float32 if np.dtype(dtype).itemsize == 4 else np.float64)
-        self.lib = hip_lib(self.dtype) if self.plans_only else require_gpu(self.dtype)
+        self.lib = hip_lib(self.dtype) if self.device < 0 else require_gpu(self.dtype)
         h = C.c_void_p()
         kind, arg = transport
-        if self.plans_only and kind != "ipc":
-            raise AMGError("device < 0 (plans only) needs the IPC transport")
+        if self.device < 0 and kind != "ipc":
+            raise AMGError("device < 0 (plans only / host execution) needs the IPC transport")
         if kind == "ipc":
             hip_check(self.lib.amgh_dist_create_ipc(C.byref(h), self.device, self.rank, self.nranks,
                                                     str(arg).encode()), "dist_create_ipc")
@@ -186,7 +197,21 @@ class ShardedHierarchy:
                 ptr(S[0]), ptr(S[1]), ptr(S[2]), ptr(P[0]), ptr(P[1]), ptr(P[2]), ptr(R[0]), ptr(R[1]), ptr(R[2]),
                 C.byref(pre), C.byref(post)), "dist_push_level")
         self.tail = None
-        if tail is not None and not self.plans_only:
+        if self.host_exec:
+            from ._libs import COARSE_FN, COARSE_FN_F32
+            fn = host_tail if callable(host_tail) else None
+            dt = self.dtype
+
+            def _cb(_user, b_ptr, x_ptr, n):
+                try:
+                    bb = np.ctypeslib.as_array(b_ptr, shape=(n,)).astype(np.float64)
+                    np.ctypeslib.as_array(x_ptr, shape=(n,))[:] = np.asarray(fn(bb), dtype=dt)
+                    return 0
+                except Exception:  # noqa: BLE001
+                    return -1
+            self._host_tail_cb = (COARSE_FN if dt.itemsize == 8 else COARSE_FN_F32)(_cb)
+            hip_check(self.lib.amgh_dist_set_host_tail(self.h, C.cast(self._host_tail_cb, C.c_void_p), None), "dist_set_host_tail")
+        if tail is not None and not self.plans_only and not self.host_exec:
             self.tail = DeviceHierarchy(tail, self.device, 1, self.dtype)
             hip_check(self.lib.amgh_dist_set_tail(self.h, self.tail.h), "dist_set_tail")
         hip_check(self.lib.amgh_dist_finalize(self.h), "dist_finalize")
@@ -195,12 +220,14 @@ class ShardedHierarchy:
         hip_check(self.lib.amgh_dist_local_range(self.h, 0, C.byref(r0), C.byref(r1)), "dist_local_range")
         self.r0, self.r1 = r0.value, r1.value
         self.nloc = self.r1 - self.r0
-        if not self.plans_only:
+        if self.host_exec:
+            self._b, self._x = _HostBuffer(max(self.nloc, 1), self.dtype), _HostBuffer(max(self.nloc, 1), self.dtype)
+        elif not self.plans_only:
             self._b = DeviceBuffer(max(self.nloc, 1), self.device, dtype=self.dtype)
             self._x = DeviceBuffer(max(self.nloc, 1), self.device, dtype=self.dtype)
 
     @classmethod
-    def from_multilevel(cls, ml, rank, nranks, device, transport, shard_min_rows=200_000, dtype=np.float64, gs_mode="exact"):
+    def from_multilevel(cls, ml, rank, nranks, device, transport, shard_min_rows=200_000, dtype=np.float64, gs_mode="exact", host_tail=None):
         """Every rank holds (or maps) the whole host hierarchy; only rank 0 needs the collapsed levels."""
         if not isinstance(ml, MultiLevel):
             raise AMGError("ml must be a MultiLevel")
@@ -210,7 +237,9 @@ class ShardedHierarchy:
         if rank == 0:
             tail = MultiLevel(ml.levels[lc:], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
                               ml.symmetry, method=ml.method)
-        return cls(level_arrays(ml, lc), sizes[lc], tail, rank, nranks, device, transport, dtype, gs_mode)
+        # host_tail (device < 0): a factory — called on rank 0 with the collapsed levels' MultiLevel, returns the function b -> x
+        ht = None if host_tail is None else (host_tail(tail) if rank == 0 else True)
+        return cls(level_arrays(ml, lc), sizes[lc], tail, rank, nranks, device, transport, dtype, gs_mode, host_tail=ht)
 
     GS_MODES = {"hybrid": 0, "exact": 1, "exact-turns": 2}
 
@@ -226,7 +255,7 @@ class ShardedHierarchy:
 
     def gs_pipelined(self):
         """Per sharded level: do its Gauss-Seidel / SOR sweeps run as one sweep pipelined across the ranks under "exact"?"""
-        return [int(self.lib.amgh_dist_gs_pipelined(self.h, l)) == 1 for l in range(int(self.lib.amgh_dist_num_sharded_levels(self.h)))] if not self.plans_only else []
+        return [int(self.lib.amgh_dist_gs_pipelined(self.h, l)) == 1 for l in range(int(self.lib.amgh_dist_num_sharded_levels(self.h)))] if self.device >= 0 else []
 
     def close(self):
         """Destroy the sharded handle first (it borrows the collapsed levels' handle), then the tail."""
@@ -251,12 +280,16 @@ class ShardedHierarchy:
         host = np.ascontiguousarray(host, dtype=self.dtype)
         if host.size != self.nloc:
             raise AMGError(f"expected {self.nloc} local entries, got {host.size}")
-        if self.nloc:
+        if self.nloc and self.host_exec:
+            buf.a[:self.nloc] = host
+        elif self.nloc:
             hip_check(self.lib.amgh_dev_upload(self.device, buf.ptr, host.ctypes.data, self.dtype.itemsize * self.nloc), "upload")
 
     def _down(self, buf):
         out = np.empty(self.nloc, dtype=self.dtype)
-        if self.nloc:
+        if self.nloc and self.host_exec:
+            out[:] = buf.a[:self.nloc]
+        elif self.nloc:
             hip_check(self.lib.amgh_dev_download(self.device, out.ctypes.data, buf.ptr, self.dtype.itemsize * self.nloc), "download")
         return out
 
@@ -290,6 +323,11 @@ class ShardedHierarchy:
         """y = A_level x on this rank's rows (halo exchange included)."""
         r0, r1 = self.local_range(level)
         n = r1 - r0
+        if self.host_exec:
+            xd, yd = _HostBuffer(max(n, 1), self.dtype), _HostBuffer(max(n, 1), self.dtype)
+            xd.a[:n] = np.asarray(x_local, dtype=self.dtype)
+            hip_check(self.lib.amgh_dist_spmv_d(self.h, level, xd.ptr, yd.ptr), "dist_spmv")
+            return yd.a[:n].copy()
         xd = DeviceBuffer(max(n, 1), self.device, dtype=self.dtype)
         yd = DeviceBuffer(max(n, 1), self.device, dtype=self.dtype)
         isz = self.dtype.itemsize

@@ -345,6 +345,13 @@ int amgh_dist_push_level(amgh_dist_t* d, int64_t n_global, int64_t nc_global,
  * the coarse solver, on the rank that owns them; NULL elsewhere.  Borrowed, not owned; its stream
  * becomes the sharded handle's.                                                                      */
 int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail);
+/* device = -1 handles: the collapsed levels as a HOST callback (x = fn(b): one visit of __solve! at level lc, multilevel.jl:214-239;
+ * set on every rank before amgh_dist_finalize, called on the owner).  With it the handle EXECUTES the sharded cycle in host
+ * memory — the same C code: halo plans, exchange ordering, turns of the exact Gauss-Seidel, collapse, all-reduces — with the
+ * operators as plain loops; amgh_dist_precond_apply_d / amgh_dist_solve_d / amgh_dist_spmv_d then take HOST pointers.  What the
+ * CPU multi-process test (gloo-launched, no GPU) runs against the oracle.  V cycles (a W / F cycle's second visit of the
+ * collapsed levels would need their previous x).                                                                          */
+int amgh_dist_set_host_tail(amgh_dist_t* d, amgh_coarse_fn fn, void* user);
 /* Collective.  Exchanges the halo needs, builds the send / receive plans, uploads the local blocks
  * (columns renumbered to [local | halo]) and builds the smoother schedules of the shards.            */
 int amgh_dist_finalize(amgh_dist_t* d);

@@ -37,6 +37,20 @@ def test_gloo_world_size_2():
     assert r.returncode == 0 and "DIST_WORKER_OK" in out, out[-3000:]
 
 
+def test_gloo_drives_the_library_sharded_cycle_on_the_host():
+    """`amgh_dist_*` ITSELF — not a mirror of it — through whole V-cycles without a GPU: world_size 2 and 3 launched over gloo,
+    the library executing its sharded cycle in host memory (device = -1 with a host tail): halo plans, exchange ordering,
+    exact Gauss-Seidel in turns, the hybrid, Jacobi, collapse onto rank 0, the all-reduced residual norms — against the
+    oracle at 1e-10 (tests/dist_host_worker.py)."""
+    for nranks, port in ((2, "29541"), (3, "29543")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", AMGH_IPC_TIMEOUT_S="120")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "dist_host_worker.py")]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, cwd=ROOT)
+        out = r.stdout.decode()
+        assert r.returncode == 0 and "DIST_HOST_WORKER_OK" in out, (nranks, out[-4000:])
+
+
 def test_node_levels_gloo():
     """bench_dist.py's once-per-node hand-over of the host hierarchy (export on rank 0, memory-mapped row slices on the
     others), world_size 2 over gloo."""
