@@ -35,7 +35,7 @@ import numpy as np
 PARITY_TOL = 1e-10
 
 
-def node_levels(rank, world, bcast, build):
+def node_levels(rank, world, bcast, build, shard_min_rows=200_000):
     """The host hierarchy ONCE per node: rank 0 runs `build()` (-> MultiLevel), decides how many levels are sharded,
     and — for world > 1 — exports the sharded levels' matrices as .npy files; every other rank maps them and will read
     only its own rows.  `bcast(obj)` broadcasts a small Python object from rank 0.  Returns (levels, info, tail, dir):
@@ -53,11 +53,11 @@ def node_levels(rank, world, bcast, build):
         t_phase["hierarchy_s"] = time.perf_counter() - t0
         A = ml.levels[0].A if ml.levels else ml.final_A
         sizes = [l.A.m for l in ml.levels] + [ml.final_A.m]
-        lc = SH.num_sharded_levels(sizes, world)
+        lc = SH.num_sharded_levels(sizes, world, shard_min_rows)
         levels = SH.level_arrays(ml, lc)
         tail = AMG.MultiLevel(ml.levels[lc:], ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
                               ml.symmetry, method=ml.method)
-        info = dict(n_tail=sizes[lc], nnz=A.nnz, nlev=len(ml), lc=lc, sizes=sizes, level_nnz=[l.A.nnz for l in ml.levels])
+        info = dict(n_tail=sizes[lc], nnz=A.nnz, nlev=len(ml), lc=lc, sizes=sizes, level_nnz=[l.A.nnz for l in ml.levels], shard_min_rows=shard_min_rows)
         if world > 1:
             # shared memory if it has the room (a container's /dev/shm can be as small as 64 MB), else the temp directory
             need = sum(a.nbytes for d in levels for key in ("A", "S", "P", "R") if d[key] is not None for a in d[key])
@@ -272,18 +272,28 @@ def main_distributed(args):
     b = uniform(n, 0)
     notes = {}
 
-    def preflight(tkind):
-        """A 2-cycle exchange of a 32^3 Jacobi hierarchy over transport `tkind`, checked against the oracle on rank 0, before
-        the timed problem meets that transport for the first time (bounded: the IPC transport's own timeout is 30 s here; RCCL
-        has none of its own — a rank that cannot initialise it raises, a rank that hangs in it is the launcher's to kill)."""
+    def preflight(tkind, pipe=False):
+        """A 2-cycle exchange of a small hierarchy with SHARDED levels (shard_min_rows 500) over transport `tkind`, checked against
+        the oracle on rank 0, before the timed problem meets that transport for the first time (bounded: the IPC transport's own
+        timeout is 30 s here; RCCL has none of its own — a rank that cannot initialise it raises, a rank that hangs in it is the
+        launcher's to kill).  pipe = False: 32^3, Jacobi smoothers (the halo exchanges).  pipe = True: 40^3, the default
+        Gauss-Seidel smoothers with block layouts forced on the small shards, exact order as ONE sweep pipelined across the ranks:
+        the neighbours' mailbox arrays mapped across processes / devices and polled from inside the sweeps — on this hardware,
+        before the timed problem depends on it."""
         t0 = time.perf_counter()
-        rec = {"transport": tkind, "ok": False}
+        rec = {"transport": tkind, "ok": False, "what": "gs_pipelined" if pipe else "jacobi_exchange"}
+        lib = AMG.hip_lib()
+        if pipe:
+            lib.amgh_debug_set_tunable(b"gs_bw", 2); lib.amgh_debug_set_tunable(b"gs_bw_rows", 64)
         old = os.environ.get("AMGH_IPC_TIMEOUT_S")
         os.environ["AMGH_IPC_TIMEOUT_S"] = "30"
         run = None
         try:
-            small = AMG.ruge_stuben(AMG.poisson((32, 32, 32)), presmoother=jac, postsmoother=jac) if rank == 0 else None
-            lv_s, info_s, tail_s, shm_s = node_levels(rank, world, bcast, lambda: small)
+            ns = 40 if pipe else 32
+            small = None
+            if rank == 0:
+                small = AMG.ruge_stuben(AMG.poisson((ns, ns, ns))) if pipe else AMG.ruge_stuben(AMG.poisson((ns, ns, ns)), presmoother=jac, postsmoother=jac)
+            lv_s, info_s, tail_s, shm_s = node_levels(rank, world, bcast, lambda: small, shard_min_rows=4000 if pipe else 500)
             ctx_s = dict(ctx, info=info_s)
             err = None
             try:
@@ -293,8 +303,10 @@ def main_distributed(args):
             if not all_ok(run is not None):
                 rec["error"] = err or "another rank failed to create the handle"
             else:
-                nb = 32 ** 3
+                nb = ns ** 3
                 bs = uniform(nb, 7)
+                if pipe:
+                    rec["pipelined_by_level"] = run.pipelined
                 res, z_loc = run.measure(bs, 2, 0)
                 z = assemble_on_rank0(ctx_s, "preflight_" + tkind, z_loc)
                 good = True
@@ -307,6 +319,8 @@ def main_distributed(args):
                 rec["ok"] = bool(bcast(good if rank == 0 else None))
                 if not rec["ok"]:
                     rec["error"] = "the exchanged cycle differs from the oracle"
+                if pipe and rec["ok"] and not (run.pipelined and run.pipelined[0]):
+                    rec["ok"], rec["error"] = False, "the small shards did not get a pipelined sweep"
             if rank == 0 and shm_s:
                 shutil.rmtree(shm_s, ignore_errors=True)
         except Exception as ex:  # noqa: BLE001
@@ -321,6 +335,8 @@ def main_distributed(args):
                 os.environ.pop("AMGH_IPC_TIMEOUT_S", None)
             else:
                 os.environ["AMGH_IPC_TIMEOUT_S"] = old
+            if pipe:
+                lib.amgh_debug_set_tunable(b"gs_bw", 1); lib.amgh_debug_set_tunable(b"gs_bw_rows", 512)
         rec["ok"] = all_ok(rec["ok"])
         rec["seconds"] = round(time.perf_counter() - t0, 2)
         return rec
@@ -336,6 +352,14 @@ def main_distributed(args):
                 chosen = tk
         if chosen is None:
             raise SystemExit(f"bench_dist.py: no transport passed the preflight exchange: {preflights}")
+        if smoother == "gs":
+            # the pipelined exact sweep maps memory across processes / devices and polls it from inside kernels: tried on a small
+            # problem first; if it does not come back right on this hardware, the timed problem sweeps with the ranks in turn
+            rec = preflight(chosen, pipe=True)
+            preflights.append(rec)
+            if not rec["ok"]:
+                os.environ["AMGH_DIST_PIPE"] = "0"
+                notes["gs_pipeline_disabled"] = rec.get("error", "preflight failed")
         if chosen != transport:
             notes["transport_requested"] = transport
             notes["transport_fallback_reason"] = next((r.get("error", "preflight failed") for r in preflights if r["transport"] == transport), "preflight failed")
