@@ -17,16 +17,24 @@ def one(counter):
         if r.returncode != 0:
             return None, r.stdout.decode(errors="replace")[-300:]
         tot, cnt = {}, {}
+        relay = []   # (dispatch id, value) of the relayed kernels: the tool's LAST alternating loop is what is reported for them
         for f in glob.glob(tmp + "/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(f)):
                 if row.get("Counter_Name") != counter: continue
                 name = row.get("Kernel_Name", "")
+                if "gs_bw_relay_kernel" in name:
+                    relay.append((int(row.get("Dispatch_Id", len(relay))), float(row["Counter_Value"])))
+                    continue
                 for sub, key in kinds.items():
                     if sub in name:
                         if key == "dataflow":    # (the last template argument: right-hand-side columns per workgroup)
                             m = re.search(r"(\d+)>", name)
                             if m and int(m.group(1)) > 1 and name.count(",") >= 4: key = f"dataflow x{m.group(1)}"
                         tot[key] = tot.get(key, 0.0) + float(row["Counter_Value"]); cnt[key] = cnt.get(key, 0) + 1
+        if len(relay) >= 22:   # ... 20 alternating sweeps + the stamped one behind them
+            relay.sort()
+            vals = [v for _, v in relay[-21:-1]]
+            tot["relay, alternating"] = sum(vals); cnt["relay, alternating"] = len(vals)
         return tot, cnt
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -37,7 +45,7 @@ for c in counters:
     if tot is None:
         print(f"{c}: failed: {cnt}"); continue
     line = []
-    for key in ("per depth", "chained", "dataflow", "dataflow x2", "dataflow x4", "dataflow x8"):
+    for key in ("per depth", "chained", "dataflow", "relay, alternating", "dataflow x2", "dataflow x4", "dataflow x8"):
         if key not in tot: continue
         per = tot[key] / cnt[key] * (94 if key == "per depth" and args[:2] == ["poisson", "256"] else 1)
         if c == "FETCH_SIZE": line.append(f"{key}: {per * 1024 * 2 / 1e9:.3f} GB (x2 applied)")
