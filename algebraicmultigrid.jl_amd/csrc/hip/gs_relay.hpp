@@ -99,6 +99,9 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     // walkers' hand-issued loads into it, which is what tools/flow_asm_linear.py can then verify)
     __syncthreads();
     // ---- the fetcher: near-side values out of their mailboxes in the order the walk needs them (gs_flow.hpp, one column) ----
+#ifdef BW_RELAY_FETCH_PRIO
+    __builtin_amdgcn_s_setprio(BW_RELAY_FETCH_PRIO);   // (measurement: the fetcher's few instructions ahead of the walkers' many on a shared SIMD)
+#endif
     constexpr int U = 3;
     // (a row-sharded operator swept in a pipeline across the ranks: the extended lists — the near side's halo columns among them,
     // polled in the neighbouring rank's mailboxes)

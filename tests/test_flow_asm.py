@@ -1,7 +1,7 @@
 """The dataflow sweep kernel (csrc/hip/gs_flow.hpp) counts its memory pipeline by hand: loads are inline asm whose
 destination registers the compiler allocates but does not track, waited for by `s_waitcnt vmcnt((D - 1)(L + 2))`.  This
 test compiles all 80 instantiations (double / float x GS / SOR x forward / backward x rows of 6 / 12 / 18 entries x
-1 / 2 / 4 [/ 8] right-hand-side columns per workgroup) to gfx950
+1 / 2 / 3 [/ 4 for rows of 6 entries] right-hand-side columns per workgroup) to gfx950
 assembly (hipcc cross-compiles without a GPU) and audits the steady loop of each (tools/flow_asm_audit.py): no instruction
 touches a register set between its loads and its wait, the loop holds the hand-written waits and no compiler-inserted
 one, every load carries a scalar offset, no waterfall.  The 24 relayed kernels (csrc/hip/gs_relay.hpp: the same pipeline per
