@@ -1079,6 +1079,7 @@ int dist_pipe_setup(amgh_dist* d) {
   const int lc = (int)d->levels.size();
   if (N < 2 || lc == 0) return AMGH_OK;
   if (const char* e = getenv("AMGH_DIST_PIPE")) if (atoi(e) == 0) return AMGH_OK;   // (measurement hook; the same on every rank)
+  if (const char* e = getenv("AMGH_IPC_STAGED")) if (atoi(e) != 0) return AMGH_OK;  // (no peer mappings wanted at all)
   std::vector<double> bad((size_t)lc, 0.0);
   for (int l = 0; l < lc; ++l) {
     DistLevel* L = d->levels[l];

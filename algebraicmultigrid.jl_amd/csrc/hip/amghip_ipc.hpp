@@ -81,7 +81,12 @@ struct IpcTransport : Transport {
     if (base) munmap(base, map_bytes);
     if (creator) shm_unlink(name.c_str());
   }
-  bool async() const override { return true; }
+  bool async() const override { return !staged; }
+  // AMGH_IPC_STAGED=1 (the same on every rank): no peer mapping at all — an exchange is packed on the device, copied to the host,
+  // carried by the shared-memory rendezvous (exchange_host) and copied back.  Slow and synchronous; what is left when neither
+  // RCCL nor hipIpc peer mappings work between the devices of a node (bench_dist.py's last preflight candidate).
+  bool staged = false;
+  std::vector<real> st_send, st_recv;
   int send_copies() const override { return 2; }
 
   // ---- flags ----------------------------------------------------------------------------------------------------
@@ -149,6 +154,7 @@ struct IpcTransport : Transport {
     rank = rank_; nranks = nranks_; device = device_; host_only = device_ < 0;
     name = shm_name;
     if (const char* ev = getenv("AMGH_IPC_TIMEOUT_S")) timeout_s = std::max(1.0, atof(ev));
+    if (const char* ev = getenv("AMGH_IPC_STAGED")) staged = atoi(ev) != 0 && !host_only;
     flag_off = ipc_page_round(sizeof(IpcHeader));
     flag_bytes = ipc_page_round(((size_t)kIpcMaxPlans * nranks + (size_t)kIpcMaxPlans * nranks * nranks) * kIpcFlagStride);
     map_bytes = flag_off + flag_bytes;
@@ -301,6 +307,7 @@ struct IpcTransport : Transport {
     if (pl.id < 0 || pl.id >= kIpcMaxPlans) return AMGH_EUNSUPPORTED;
     PlanState& ps = plans[pl.id];
     ps.seq = 0;
+    if (staged) { ps.attached = true; return barrier(); }
     ps.peer.assign(nranks, nullptr);
     ps.peer_nsend.assign(nranks, 0);
     ps.peer_off.assign(nranks, 0);
@@ -344,6 +351,7 @@ struct IpcTransport : Transport {
   int pack_target(VecPlan& pl, hipStream_t st, real** sendbuf) override {
     if (broken) return AMGH_ESTATE;
     PlanState& ps = plans[pl.id];
+    if (staged) { *sendbuf = pl.d_sendbuf; return AMGH_OK; }
     const uint64_t k = ++ps.seq;
     *sendbuf = pl.d_sendbuf + (k & 1) * pl.nsend;
     if (k > 2)  // the readers of exchange k - 2 are done with this copy of the buffer
@@ -352,8 +360,17 @@ struct IpcTransport : Transport {
           HIP_TRY(hipStreamWaitValue64(st, dev_flag(done_index(pl.id, q, rank)), k - 2, hipStreamWaitValueGte, ~0ull));
     return AMGH_OK;
   }
-  int exchange_begin(VecPlan& pl, const real*, real* recvbuf, hipStream_t st, bool overlap) override {
+  int exchange_begin(VecPlan& pl, const real* sendbuf, real* recvbuf, hipStream_t st, bool overlap) override {
     if (broken) return AMGH_ESTATE;
+    if (staged) {
+      HIP_TRY(hipStreamSynchronize(st));
+      st_send.resize((size_t)std::max<int64_t>(1, pl.nsend)); st_recv.assign((size_t)std::max<int64_t>(1, pl.nhalo()), (real)0);
+      if (pl.nsend > 0) HIP_TRY(hipMemcpy(st_send.data(), sendbuf, sizeof(real) * (size_t)pl.nsend, hipMemcpyDeviceToHost));
+      RC_TRY(exchange_host(pl, st_send.data(), st_recv.data()));
+      if (pl.nhalo() > 0) HIP_TRY(hipMemcpy(recvbuf, st_recv.data(), sizeof(real) * (size_t)pl.nhalo(), hipMemcpyHostToDevice));
+      plans[pl.id].on_cs = false;
+      return AMGH_OK;
+    }
     PlanState& ps = plans[pl.id];
     const uint64_t k = ps.seq;
     if (pl.nsend > 0) HIP_TRY(hipStreamWriteValue64(st, dev_flag(ready_index(pl.id, rank)), k, 0));

@@ -151,7 +151,7 @@ def main():
     ap.add_argument("--no-block-rhs", action="store_true", help="skip the secondary measurement on a block of 8 right-hand sides")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--force-dist", action="store_true", help="run the row-sharded driver even with one rank")
-    ap.add_argument("--transport", default=None, choices=("rccl", "ipc"),
+    ap.add_argument("--transport", default=None, choices=("rccl", "ipc", "ipc-staged"),
                     help="N > 1: halo transport of the primary measurement (default: AMGH_DIST_TRANSPORT or rccl)")
     ap.add_argument("--smoother", default="gs", choices=("gs", "jacobi"),
                     help="N > 1: smoother of the primary measurement (gs = ruge_stuben defaults; jacobi = Jacobi(2/3))")

@@ -266,7 +266,14 @@ def main_distributed(args):
 
     def transport_spec(kind):
         if kind == "rccl":
+            os.environ.pop("AMGH_IPC_STAGED", None)
             return ("rccl", bcast(SH.rccl_unique_id() if rank == 0 else None))
+        # "ipc-staged": the IPC transport without any peer mapping — exchanges staged through host memory and the shared-memory
+        # rendezvous (slow, synchronous): the last resort when neither RCCL nor hipIpc mappings work between the node's devices
+        if kind == "ipc-staged":
+            os.environ["AMGH_IPC_STAGED"] = "1"
+        else:
+            os.environ.pop("AMGH_IPC_STAGED", None)
         return ("ipc", bcast("/amgh_b_%d_%s" % (os.getpid(), os.urandom(4).hex()) if rank == 0 else None))
 
     b = uniform(n, 0)
@@ -343,16 +350,20 @@ def main_distributed(args):
 
     preflights = []
     if world > 1 and not getattr(args, "no_preflight", False):
-        order = [transport] + [t for t in ("rccl", "ipc") if t != transport and not (one_gpu and t == "rccl")]
+        order = [transport] + [t for t in ("rccl", "ipc", "ipc-staged") if t != transport and not (one_gpu and t == "rccl")]
         chosen = None
         for tk in order:
+            if tk == "ipc-staged" and chosen is not None:
+                continue                                   # (the last resort is only tried when nothing else came back right)
             rec = preflight(tk)
             preflights.append(rec)
             if rec["ok"] and chosen is None:
                 chosen = tk
         if chosen is None:
             raise SystemExit(f"bench_dist.py: no transport passed the preflight exchange: {preflights}")
-        if smoother == "gs":
+        if chosen == "ipc-staged":
+            notes["ipc_staged"] = "exchanges staged through host memory (no peer mapping worked between the devices): a functional number, not the transport's speed"
+        if smoother == "gs" and chosen != "ipc-staged":
             # the pipelined exact sweep maps memory across processes / devices and polls it from inside kernels: tried on a small
             # problem first; if it does not come back right on this hardware, the timed problem sweeps with the ranks in turn
             rec = preflight(chosen, pipe=True)
