@@ -53,6 +53,55 @@ def _host_plan_sweeps(lib, A, pre, x0, bb, rows):
     return xh
 
 
+def _irregular_long_rows(n, seed, cap=18, tries=14):
+    """random structurally symmetric operator whose rows hold up to `cap` off-diagonal entries (the 18-entry records): an edge is
+    kept only while both of its rows have room; mostly short-range edges + a few long ones (blocks with many external columns)"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    deg = np.zeros(n, dtype=np.int64)
+    rows, cols, vals = [], [], []
+    seen = set()
+    for i in range(n):
+        for t in range(tries):
+            j = int(i + rng.integers(-40, 41)) if t < tries - 2 else int(rng.integers(0, n))
+            if j < 0 or j >= n or j == i or (min(i, j), max(i, j)) in seen or deg[i] >= cap or deg[j] >= cap:
+                continue
+            seen.add((min(i, j), max(i, j)))
+            v = -float(rng.random()) - 0.1
+            rows += [i, j]; cols += [j, i]; vals += [v, v * (0.5 + float(rng.random()))]   # (values not symmetric: only the pattern has to be)
+            deg[i] += 1; deg[j] += 1
+    M = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    d = np.asarray(abs(M).sum(axis=1)).ravel() + 1.0
+    K = (M + sp.diags(d)).tocsc()
+    assert int(np.diff(K.tocsr().indptr).max()) - 1 > 12          # really rows of the 18-entry kernels
+    return AMG.SparseMatrixCSC.from_scipy(K)
+
+
+def test_relayed_sweep_on_irregular_long_rows_is_the_scalar_loop_bit_for_bit():
+    """Rows of up to 18 entries on an irregular (random, structurally symmetric, unsymmetric values) pattern: the relayed dataflow
+    sweep of the 18-entry records = the single walker = the chained and launched kernels = the host plan = the oracle's scalar
+    loop, bitwise — forward, backward, symmetric; SOR at 1e-13.  (The S matrix path: the smoother sweeps the transpose's rows.)"""
+    lib = AMG.hip_lib()
+    A = _irregular_long_rows(6000, 3)
+    x0, bb = uniform(A.m, 41) - 0.5, uniform(A.m, 42)
+    for pre in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2), AMG.SOR(1.1)):
+        ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre)
+        with tunables(lib, gs_bw=2, gs_bw_rows=64, gs_lean=0):
+            dev = DeviceHierarchy(ml, 0, 1)
+            assert lib.amgh_debug_bw_mode(dev.h, 0) == 3 and dev.gs_sweep_stats(0, False)["slot_entries"] // A.m == 18, repr(pre)
+            x_relay = dev.smooth(0, False, x0, bb)
+            with tunables(lib, gs_bw_relay=0):
+                assert np.array_equal(dev.smooth(0, False, x0, bb), x_relay), repr(pre)
+            with tunables(lib, gs_bw_flow=0):
+                assert np.array_equal(dev.smooth(0, False, x0, bb), x_relay), repr(pre)
+            assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+        xo = O.smooth(pre, A, x0, bb, hermitian=True)
+        if isinstance(pre, AMG.SOR):
+            assert rel(x_relay, xo) <= 1e-13, repr(pre)
+        else:
+            assert np.array_equal(x_relay, xo), repr(pre)
+
+
 def test_dataflow_sweep_is_the_scalar_loop_bit_for_bit():
     """Gauss-Seidel forward / backward / symmetric / repeated, on grids and on an irregular symmetric pattern with zero
     diagonals (rows the sweep skips, smoother.jl:87 — and still publishes): dataflow = chained = launched = the host plan =
