@@ -856,6 +856,7 @@ int dist_check(const amgh_dist* d) {
   if (!d) return AMGH_EINVAL;
   if (!d->finalized) return AMGH_ESTATE;
   if (d->host_only && !d->host_exec) return AMGH_EUNSUPPORTED;  // plans only: there is no data path without a device or a host tail
+  if (!d->host_only && !d->tail && d->xplan.back().nloc() > 0) return AMGH_ESTATE;   // the owner of the collapsed levels has not passed them yet
   return AMGH_OK;
 }
 
@@ -1046,8 +1047,17 @@ int amgh_dist_push_level(amgh_dist_t* d, int64_t n_global, int64_t nc_global, co
 
 int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail) {
   if (!d) return AMGH_EINVAL;
-  if (d->finalized) return AMGH_ESTATE;
   if (tail && (d->host_only || !tail->finalized || tail->nrhs != 1 || tail->device != d->device)) return AMGH_EINVAL;
+  if (d->finalized) {
+    // late binding (not collective): the owner built the collapsed levels beside amgh_dist_finalize — the shards' plans and
+    // schedules and the tail's schedules are seconds of independent work — and passes them now, once
+    if (!tail || d->tail || d->xplan.back().nloc() != fine_n(tail)) return AMGH_ESTATE;
+    d->tail = tail;
+    d->tail->ext_stream = true;
+    d->tail->own_stream = d->tail->own_stream ? d->tail->own_stream : d->tail->stream;
+    d->tail->stream = d->stream;
+    return AMGH_OK;
+  }
   d->tail = tail;
   return AMGH_OK;
 }
@@ -1214,7 +1224,8 @@ int amgh_dist_finalize(amgh_dist_t* d) {
   {
     const int64_t nt = tcuts[me + 1] - tcuts[me];
     // (plans only: the owner has no GPU handle to pass, the partition alone says who it is)
-    const bool owner_ok = nt == 0 ? true : nt == tcuts[N] && (d->host_only || (d->tail && fine_n(d->tail) == nt));
+    // (a tail that is still being built — its schedules take seconds — may follow: amgh_dist_set_tail after finalize)
+    const bool owner_ok = nt == 0 ? true : nt == tcuts[N] && (d->host_only || !d->tail || fine_n(d->tail) == nt);
     double bad = owner_ok ? 0.0 : 1.0;
     RC_TRY(tr->allreduce(&bad, 1, true));
     if (bad != 0.0) DIST_EINVAL("the collapsed levels must live on exactly one rank, which passes the tail");

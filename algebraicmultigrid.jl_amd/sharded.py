@@ -211,10 +211,34 @@ class ShardedHierarchy:
                     return -1
             self._host_tail_cb = (COARSE_FN if dt.itemsize == 8 else COARSE_FN_F32)(_cb)
             hip_check(self.lib.amgh_dist_set_host_tail(self.h, C.cast(self._host_tail_cb, C.c_void_p), None), "dist_set_host_tail")
+        tail_job = None
         if tail is not None and not self.plans_only and not self.host_exec:
-            self.tail = DeviceHierarchy(tail, self.device, 1, self.dtype)
+            if isinstance(tail, DeviceHierarchy) or self.lc == 0:   # built by the caller already / nothing is sharded: the tail's size IS the partition
+                self.tail = tail if isinstance(tail, DeviceHierarchy) else DeviceHierarchy(tail, self.device, 1, self.dtype)
+                hip_check(self.lib.amgh_dist_set_tail(self.h, self.tail.h), "dist_set_tail")
+            else:
+                # the collapsed levels' device hierarchy (seconds of smoother schedules) beside amgh_dist_finalize (seconds of
+                # halo plans and shard schedules): independent work — the tail is passed once both are done
+                import threading
+                box = {}
+
+                def _build():
+                    try:
+                        box["tail"] = DeviceHierarchy(tail, self.device, 1, self.dtype)
+                    except BaseException as e:  # noqa: BLE001
+                        box["err"] = e
+                tail_job = threading.Thread(target=_build)
+                tail_job.start()
+        try:
+            hip_check(self.lib.amgh_dist_finalize(self.h), "dist_finalize")
+        finally:
+            if tail_job is not None:
+                tail_job.join()
+        if tail_job is not None:
+            if "err" in box:
+                raise box["err"]
+            self.tail = box["tail"]
             hip_check(self.lib.amgh_dist_set_tail(self.h, self.tail.h), "dist_set_tail")
-        hip_check(self.lib.amgh_dist_finalize(self.h), "dist_finalize")
         self.set_gs_mode(gs_mode)
         r0, r1 = C.c_int64(0), C.c_int64(0)
         hip_check(self.lib.amgh_dist_local_range(self.h, 0, C.byref(r0), C.byref(r1)), "dist_local_range")

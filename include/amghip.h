@@ -343,7 +343,9 @@ int amgh_dist_push_level(amgh_dist_t* d, int64_t n_global, int64_t nc_global,
                          const amgh_smoother_t* pre, const amgh_smoother_t* post);
 /* The collapsed levels: a finalized single-GPU handle (nrhs = 1, same device) holding levels lc.. and
  * the coarse solver, on the rank that owns them; NULL elsewhere.  Borrowed, not owned; its stream
- * becomes the sharded handle's.                                                                      */
+ * becomes the sharded handle's.  Before amgh_dist_finalize — or, on the owner, once AFTER it (the tail's
+ * smoother schedules and the shards' plans are independent work: build them side by side); the solve
+ * entry points return AMGH_ESTATE on an owner that has not passed its tail yet.                          */
 int amgh_dist_set_tail(amgh_dist_t* d, amgh_t* tail);
 /* device = -1 handles: the collapsed levels as a HOST callback (x = fn(b): one visit of __solve! at level lc, multilevel.jl:214-239;
  * set on every rank before amgh_dist_finalize, called on the owner).  With it the handle EXECUTES the sharded cycle in host
