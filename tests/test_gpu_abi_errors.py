@@ -231,8 +231,21 @@ def test_sharded_abi_error_codes():
     assert lib.amgh_dist_set_tail(d, h) == -2
     lib.amgh_destroy(h)
     # finalize without levels and without a tail: a hierarchy of size 0 is fine, solve on it is a no-op
+    # round 5: the modes of the exact sweep, the pipeline query, host tails only on device = -1 handles
+    assert lib.amgh_dist_set_gs_mode(d, 3) == -2 and lib.amgh_dist_set_gs_mode(d, -1) == -2
+    assert all(lib.amgh_dist_set_gs_mode(d, m) == 0 for m in (0, 2, 1))
+    assert lib.amgh_dist_gs_pipelined(d, 0) == -1                            # not finalized
+    assert lib.amgh_dist_set_host_tail(d, None, None) == -2                  # a GPU handle executes on the GPU
+    assert lib.amgh_dist_set_host_tail(None, None, None) == -2
     assert lib.amgh_dist_finalize(d) == 0
     assert lib.amgh_dist_finalize(d) == -3
+    assert lib.amgh_dist_gs_pipelined(d, 0) == -1                            # no such level
+    # a tail after finalize: once, on the owner, of the right size — here nothing is collapsed onto this rank (size 0): refused
+    h2 = vp()
+    assert lib.amgh_create(C.byref(h2), 0, 1) == 0
+    assert lib.amgh_dist_set_tail(d, h2) == -2                               # (not finalized itself)
+    lib.amgh_destroy(h2)
+    assert lib.amgh_dist_set_tail(d, None) == -3
     assert lib.amgh_dist_precond_apply_d(d, None, None, 7) == -2
     assert lib.amgh_dist_spmv_d(d, 0, None, None) == -2                      # no sharded level
     out2 = np.zeros(2, dtype=np.int64)
