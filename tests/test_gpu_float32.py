@@ -219,6 +219,35 @@ def test_row_sharded_cycle_in_float32():
     assert out["float32"].dtype == F32 and rel(out["float32"], out["float64"]) <= F32_TOL
 
 
+def test_float32_gauss_seidel_pipelined_across_the_ranks():
+    """The Float32 instance of the exact sweep pipelined across the ranks (8-byte mailboxes {value, tag} polled in the neighbour's
+    array): 3 virtual ranks, block layouts forced on the small shards — the pipeline really runs (gs_pipelined), equals the ranks
+    sweeping in turn bit for bit, and is the Float32 oracle's cycle within Float32 rounding."""
+    from amg_amd import sharded as SH
+    lib = AMG.hip_lib(F32)
+    A32 = as_f32_matrix(AMG.poisson((32, 28, 36)))
+    b = (uniform(A32.m, 8) - 0.4).astype(F32)
+    ml = AMG.ruge_stuben(A32)
+    for name, v in ((b"gs_bw", 2), (b"gs_bw_rows", 64)):
+        assert lib.amgh_debug_set_tunable(name, v) == 0
+    try:
+        out = {}
+        for mode in ("exact", "exact-turns"):
+            def work(rank, group, mode=mode):
+                sh = SH.ShardedHierarchy.from_multilevel(ml, rank, 3, 0, ("local", group), 4000, dtype=F32, gs_mode=mode)
+                x, _ = sh.solve(b[sh.r0:sh.r1], maxiter=2, calculate_residual=False)
+                return x, sh.gs_pipelined()
+            res = SH.run_local_ranks(3, work, dtype=F32)
+            out[mode] = np.concatenate([r[0] for r in res])
+            assert all(r[1] and r[1][0] for r in res), [r[1] for r in res]
+    finally:
+        for name, v in ((b"gs_bw", 1), (b"gs_bw_rows", 512)):
+            lib.amgh_debug_set_tunable(name, v)
+    assert out["exact"].dtype == F32 and np.array_equal(out["exact"], out["exact-turns"])
+    xo, _, _ = O.OracleHierarchy(ml, dtype=F32).solve(b, maxiter=2, calculate_residual=False)
+    assert rel(out["exact"], xo) <= F32_TOL
+
+
 @pytest.mark.parametrize("bs", [1, 3, 4])
 def test_float32_dataflow_sweeps_single_columns_and_blocks_of_right_hand_sides(bs):
     """The Float32 instance of the dataflow sweep (gs_flow.hpp with R = float: 8-byte mailboxes {value, epoch}, 4 values per
