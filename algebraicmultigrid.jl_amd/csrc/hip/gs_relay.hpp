@@ -415,7 +415,14 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
 #endif
   if (a.tim && lane == 0) {
     long long* tt = a.tim + 4 * (int64_t)ob;
-    if (wv == 0) { tt[0] = t_start; tt[1] = t_loaded; tt[3] = 0; }
+    if (wv == 0) {
+      tt[0] = t_start; tt[1] = t_loaded;
+      unsigned xcc = 0;
+#ifdef BW_RELAY_STAMPS
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));   // (which XCD the block ran on: hand-offs inside / across XCDs)
+#endif
+      tt[3] = (long long)(xcc & 15u);
+    }
     if (wv == (ns - 1) % W) tt[2] = wall_clock64();
   }
 }

@@ -381,6 +381,24 @@ int main(int argc, char** argv) {
               double np = 0, ps = 0, pm = 0;
               for (int32_t bq = 0; bq < B; ++bq) { np += fq[4 * (size_t)bq]; ps += fq[4 * (size_t)bq + 1] * 0.01; pm = std::max(pm, fq[4 * (size_t)bq + 2] * 0.01); }
               auto pct = [](std::vector<double>& v, double f) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(f * (v.size() - 1))]; };
+              {   // the same by placement: the producing block and the reading block on one XCD (one L2) or on two
+                std::vector<double> same, cross;
+                std::vector<int32_t> row0s(B); for (int32_t bq = 0; bq < B; ++bq) row0s[bq] = P.blocks[bq].row0;
+                // blocks are in launch order, their row ranges ascending with it
+                for (int32_t bq = 0; bq < B; ++bq) {
+                  const bw::Desc& dd = P.blocks[bq];
+                  for (int32_t i2 = 0; i2 < dd.npre; ++i2) {
+                    const int32_t cellm = F.fl_mb[(size_t)dd.ext0 + i2];
+                    const int32_t q2 = P.ext_col[(size_t)dd.ext0 + (F.fl_slot[(size_t)dd.ext0 + i2] - dd.nrows)];
+                    const int32_t pb = (int32_t)(std::upper_bound(row0s.begin(), row0s.end(), q2) - row0s.begin()) - 1;
+                    if (pb < 0 || !tp[(size_t)cellm] || !tsn[(size_t)cellm]) continue;
+                    const double dt = (tsn[(size_t)cellm] - tp[(size_t)cellm]) * 0.01;
+                    (tim[4 * (size_t)pb + 3] == tim[4 * (size_t)bq + 3] ? same : cross).push_back(dt);
+                  }
+                }
+                printf("  hand-offs by placement: producer and reader on ONE XCD: %zu, p10 %.2f median %.2f us | on TWO XCDs: %zu, p10 %.2f median %.2f us\n",
+                       same.size(), pct(same, 0.1), pct(same, 0.5), cross.size(), pct(cross, 0.1), pct(cross, 0.5));
+              }
               printf("  hand-offs (row published -> seen by the reader's fetcher), %zu forward mailboxes: p10 %.2f median %.2f p90 %.2f p99 %.2f us; fetcher polls: %.1f per block, mean round trip %.2f us, longest %.2f us\n",
                      ho.size(), pct(ho, 0.1), pct(ho, 0.5), pct(ho, 0.9), pct(ho, 0.99), np / B, np ? ps / np : 0.0, pm);
               // by depth of the reading... (the producing block's depth: early ramp vs the wide middle)
