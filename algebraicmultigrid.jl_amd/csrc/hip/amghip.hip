@@ -1030,6 +1030,11 @@ int amgh_debug_bw_mode(const amgh_t* h, int l) {
   if (g->bw.flow.on && (g_gs_bw_flow || !g->bw.rec)) return 3;
   return (g_gs_bw_chain && g->bw.flags) ? 2 : 1;
 }
+int amgh_debug_bw_dict(const amgh_t* h, int l) {
+  if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
+  const GsSchedule* g = h->levels[l]->smat()->gs;
+  return g && g->bw.on && g->bw.flow.on && g->bw.flow.dict_on && g_gs_bw_dict && g_gs_bw_relay > 0 && (g_gs_bw_flow || !g->bw.rec) ? 1 : 0;
+}
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
   amgh_csr* M = h->levels[l]->smat();
@@ -1742,6 +1747,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_flow_xzero")) g_gs_flow_xzero = value;
   else if (!strcmp(name, "gs_bw_grid")) g_gs_bw_grid = value < 0 ? 0 : value;
   else if (!strcmp(name, "gs_bw_grid_long")) g_gs_bw_grid_long = value < 0 ? 0 : value;
+  else if (!strcmp(name, "gs_bw_dict")) g_gs_bw_dict = value != 0;
   else if (!strcmp(name, "gs_bw_relay")) g_gs_bw_relay = value == 0 ? 0 : BW_RELAY_W;   // (one count is instantiated)
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;
   else if (!strcmp(name, "jacobi_zero")) g_jacobi_zero = value;

@@ -231,6 +231,10 @@ struct GsSchedule {
       uint32_t* xaux = nullptr; int32_t* xfl_mb = nullptr; uint16_t* xfl_slot = nullptr; int32_t* xlist = nullptr;
       std::vector<int32_t> h_xfl_mb, h_row_cell_f, h_row_cell_b;   // host copies: the halo entries are patched with the neighbours' cells
       bool xon = false;
+      // the DICTIONARY layout (bw::FlowDict): column records + every block's distinct value rows — what the relayed
+      // single-column sweep streams instead of srec where the operator's rows repeat (stencils and their Galerkin products)
+      unsigned char* crec = nullptr; unsigned char* dict = nullptr; int32_t* dict_ent = nullptr;
+      size_t dict_lds = 0; bool dict_on = false;
     } flow;
   } bw;
   // the same operator as one record walked by a single wave (gs_wave_kernel): built when it fits (rows of at most
@@ -338,6 +342,7 @@ struct GsSchedule {
     hipFree(bw.dep_ptr); hipFree(bw.dep); hipFree(bw.sdep_ptr); hipFree(bw.sdep); hipFree(bw.flags); hipFree(bw.head);
     hipFree(bw.flow.fd); hipFree(bw.flow.srec); hipFree(bw.flow.aux); hipFree(bw.flow.fl_mb); hipFree(bw.flow.fl_slot); hipFree(bw.flow.mbox);
     hipFree(bw.flow.xaux); hipFree(bw.flow.xfl_mb); hipFree(bw.flow.xfl_slot); hipFree(bw.flow.xlist);
+    hipFree(bw.flow.crec); hipFree(bw.flow.dict); hipFree(bw.flow.dict_ent);
     bw = Bw();
     hipFree(d_lvl_ptr); hipFree(rowptr); hipFree(col); hipFree(val);
     hipFree(perm); hipFree(dpos); if (!diag_shared) hipFree(diag);
@@ -399,6 +404,7 @@ int g_gs_bw_skip_pub = -1;      // test hook: the block with this ticket publish
 int g_gs_bw_nc = 2;             // columns of a block of right-hand sides one workgroup of the dataflow sweep carries (walker waves beside its one fetcher; 0 = as many as are instantiated: 4 for rows of <= 6 entries, else 3); 256^3, bs = 8, smoothers of the two block-ordered levels: 1: 16.3 + 10.0, 2: 12.0 + 10.1, 3: 12.0 + 10.4, 4: 13.0 + 10.4 ms; read at every sweep
 int g_gs_bw_nrhs = 1;           // hierarchies built for blocks of right-hand sides get the dataflow layout too (0 = single-column hierarchies only); read at schedule build
 int g_gs_bw_chain = 1;          // the wavefront of blocks as one launch per sweep, blocks chained by flags (0: one launch per depth of the quotient graph)
+int g_gs_bw_dict = 1;           // the relayed single-column sweep reads the dictionary layout where a schedule carries one (bw::FlowDict: half the bytes of a 7-point level's sweep; bitwise the same); read at schedule build (0: not built) and at every sweep
 int g_gs_bw_relay = 3;          // walker waves a single-column dataflow sweep relays a block's walk between (gs_relay.hpp: the one instantiated count, BW_RELAY_W; 0: one walker, gs_bw_flow_kernel — bitwise the same); read at every sweep
 int g_gs_bw_grid = 0;           // workgroups of a relayed single-column sweep (fewer than blocks: the persistent form of gs_relay.hpp; 0: one per block); read at every sweep
 int g_gs_bw_grid_long = 512;      // ... of levels with rows of more than 6 entries (critical-path bound: fewer resident blocks, faster hand-offs); read at every sweep

@@ -539,7 +539,9 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
         e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
       } else if (ncolv == 1 && g_gs_bw_relay > 0) {
         fa.grid = g->bw.maxk > 6 ? g_gs_bw_grid_long : g_gs_bw_grid;
-        e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
+        const bool dict = g->bw.flow.dict_on && g_gs_bw_dict;   // (column records + the blocks' dictionaries of value rows)
+        if (dict) { fa.crec = g->bw.flow.crec; fa.dict = g->bw.flow.dict; fa.dict_ent = g->bw.flow.dict_ent; }
+        e = bw::sweep_relay<real>(fa, g->bw.maxk, dict ? g->bw.flow.dict_lds : g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
       }
       else e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);
     } else {

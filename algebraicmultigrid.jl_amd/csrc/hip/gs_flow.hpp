@@ -71,8 +71,25 @@ struct FlowX {
   std::vector<int32_t> row_cell_f, row_cell_b;   // per natural local row: its forward / backward mailbox (-1: none)
 };
 
+// The DICTIONARY layout of the records (round 5): rows whose values (entries, diagonal, reciprocal: the row's value chunks,
+// bit for bit) are equal share ONE copy per block — a block's distinct value rows form its dictionary (loaded into LDS with
+// the block), a row's streamed record shrinks to its column chunks, the dictionary index riding in bits 22-29 of the publish
+// word: 16 instead of 80 bytes per 7-point row, 48 instead of 208 per 19-point row.  Lossless and general (a constant-
+// coefficient stencil has a handful of value rows, its Galerkin coarse operators a few dozen per block); a level with a block of
+// more than 256 distinct rows, or a dictionary beyond kDictLdsMax, keeps the plain records.
+constexpr int kDictIdxShift = 22, kDictMaxRows = 256;
+constexpr size_t kDictLdsMax = 24 * 1024;
+struct FlowDict {
+  bool on = false;
+  std::vector<unsigned char, NoInit<unsigned char>> crec;   // per row its column chunks, chunk-major per step; block ob's rows start at 16 * ncc * row0
+  std::vector<unsigned char> dict;                            // the blocks' dictionaries, back to back (value chunks of each distinct row)
+  std::vector<int32_t> ent;                                   // per block: offset into dict in 16-byte units | (rows - 1) << 24
+  size_t lds_max = 0;                                         // x + control words + the largest dictionary
+};
+
 struct Flow {
   FlowX x;
+  FlowDict dc;
   std::vector<FlowDesc> fd;
   std::vector<uint32_t> aux;
   std::vector<int32_t> fl_mb;       // per block at ext0: mailboxes of the forward fetch list (npre entries, in the order of
@@ -103,7 +120,7 @@ inline bool structurally_symmetric(int64_t n, const int32_t* rowptr, const int32
 // inplace: the plan's row-major records are turned into the chunk-major ones where they lie (F.srec stays empty; P.rec is
 // then what the dataflow kernel streams, and no longer what the chained / launched kernels or the host execution read)
 template <typename R>
-bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false, const FlowHalo* hx = nullptr) {
+bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false, const FlowHalo* hx = nullptr, bool want_dict = true) {
   Flow& F = *out;
   F = Flow();
   const int64_t n = P.n;
@@ -183,6 +200,13 @@ bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false, const Flo
   std::vector<std::vector<uint16_t>> xl_slot(hx ? (size_t)B : 0);
   std::vector<int32_t> xl_nf(hx ? (size_t)B : 0, 0);
   std::atomic<int> bad_x{0};
+  // the dictionary layout: built for every block beside the plain record (dropped again if any block does not qualify)
+  const int ncc_all = B > 0 ? Pk::ncc(P.blocks[0].maxk) : 1;
+  std::vector<std::vector<unsigned char>> dict_of(want_dict ? (size_t)B : 0);
+  std::atomic<int> bad_dict{0};
+  std::atomic<size_t> lds_dict_max{0};
+  if (!want_dict) bad_dict.store(1);
+  else if (n * (int64_t)ncc_all * 16 < (int64_t)0x7ffffff0ll) F.dc.crec.resize((size_t)n * (size_t)ncc_all * 16); else bad_dict.store(1);
   if (hx) F.x.aux.assign((size_t)aux_total, 0);
   std::atomic<size_t> lds_max{0};
   parallel_for(std::max(1, threads), [&](int t, int TT) {
@@ -293,6 +317,50 @@ bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false, const Flo
         }
         if (lm.size() > (size_t)kStepNeedMax) bad_x.store(1);
       }
+      if (bad_dict.load(std::memory_order_relaxed) == 0) {
+        // distinct value rows of the block (raw bytes of the value chunks), in order of first appearance
+        const size_t vb = (size_t)16 * nvc;
+        const int ncc = Pk::ncc(d.maxk);
+        std::vector<unsigned char>& dv = dict_of[(size_t)ob];
+        std::vector<int32_t> idx_of((size_t)d.nrows);
+        {
+          std::vector<std::pair<uint64_t, int32_t>> seen;   // (hash, dictionary row): a block has few distinct rows — a short list
+          for (int32_t pr = 0; pr < d.nrows; ++pr) {
+            const unsigned char* vrow = rec + (size_t)pr * rs;
+            uint64_t h = 1469598103934665603ull;
+            for (size_t q = 0; q < vb; q += 8) { uint64_t w; std::memcpy(&w, vrow + q, 8); h = (h ^ w) * 1099511628211ull; }
+            int32_t found = -1;
+            for (const auto& e : seen)
+              if (e.first == h && std::memcmp(dv.data() + (size_t)e.second * vb, vrow, vb) == 0) { found = e.second; break; }
+            if (found < 0) {
+              found = (int32_t)(dv.size() / vb);
+              if (found >= kDictMaxRows) { bad_dict.store(1); break; }
+              dv.insert(dv.end(), vrow, vrow + vb);
+              seen.push_back({h, found});
+            }
+            idx_of[(size_t)pr] = found;
+          }
+        }
+        if (bad_dict.load(std::memory_order_relaxed) == 0) {
+          if (dv.size() > kDictLdsMax) bad_dict.store(1);
+          unsigned char* crec = F.dc.crec.data() + (size_t)d.row0 * (size_t)ncc * 16;
+          const int cdw = ((d.maxk + 1) / 2 - 1) % 4 + 1;
+          for (int sx = 0; sx < ns; ++sx) {
+            const int32_t r0 = stp[sx], nr = stp[sx + 1] - stp[sx];
+            for (int c = 0; c < ncc; ++c)
+              for (int32_t q = 0; q < nr; ++q) {
+                unsigned char* dst = crec + ((size_t)ncc * r0 + (size_t)c * nr + q) * 16;
+                std::memcpy(dst, rec + (size_t)(r0 + q) * rs + (size_t)16 * (nvc + c), 16);
+                if (c == ncc - 1) {
+                  const int32_t pw = F.pub[d.row0 + r0 + q] | (idx_of[(size_t)(r0 + q)] << kDictIdxShift);
+                  std::memcpy(dst + 4 * cdw, &pw, 4);
+                }
+              }
+          }
+          size_t cur = lds_dict_max.load();
+          while (dv.size() > cur && !lds_dict_max.compare_exchange_weak(cur, dv.size())) {}
+        }
+      }
       // the record, chunk-major per step: chunk c of the step's row t at 16 (kch stp[s] + c nr + t)
       for (int s = 0; s < ns; ++s) {
         const int32_t r0 = stp[s], nr = stp[s + 1] - stp[s];
@@ -317,6 +385,27 @@ bool flow_build(Plan& P, int threads, Flow* out, bool inplace = false, const Flo
     while (my_lds > cur && !lds_max.compare_exchange_weak(cur, my_lds)) {}
   });
   F.lds_max = lds_max.load();
+  if (bad_dict.load() == 0 && B > 0) {
+    FlowDict& D = F.dc;
+    D.ent.assign((size_t)B, 0);
+    size_t tot = 0;
+    for (int32_t ob = 0; ob < B; ++ob) tot += dict_of[(size_t)ob].size();
+    size_t drows = 0;
+    for (int32_t ob = 0; ob < B; ++ob) drows += dict_of[(size_t)ob].size() / ((size_t)16 * Pk::nvc(P.blocks[ob].maxk));
+    // (worth it where the rows repeat: a dictionary of at most a quarter of the rows — stencils, and Galerkin products of them)
+    if (tot / 16 < ((size_t)1 << 24) && drows * 4 <= (size_t)n) {
+      D.dict.reserve(tot + 16);
+      for (int32_t ob = 0; ob < B; ++ob) {
+        const std::vector<unsigned char>& dv = dict_of[(size_t)ob];
+        const size_t vb = (size_t)16 * Pk::nvc(P.blocks[ob].maxk);
+        D.ent[(size_t)ob] = (int32_t)(D.dict.size() / 16) | (int32_t)((dv.size() / vb - 1) << 24);
+        D.dict.insert(D.dict.end(), dv.begin(), dv.end());
+      }
+      D.lds_max = F.lds_max + lds_dict_max.load();
+      D.on = D.lds_max <= 64 * 1024;
+    }
+  }
+  if (!F.dc.on) { F.dc.crec.clear(); F.dc.crec.shrink_to_fit(); }
   if (hx && bad_x.load() == 0) {
     FlowX& X = F.x;
     X.list.assign((size_t)B * 4, 0);
@@ -368,6 +457,7 @@ struct FlowArgs {
   int32_t xzero = 0;                 // x is zero on entry and need not be read: every block starts from zeros in LDS (the x in memory may hold anything)
   // (the relayed kernel of gs_relay.hpp only)
   uint32_t epoch = 0;                // the mailbox tag of this sweep when several launches share it (the ranks of a row-sharded level: every rank the same; 0: the launch's own count)
+  const unsigned char* crec = nullptr; const unsigned char* dict = nullptr; const int32_t* dict_ent = nullptr;   // the dictionary layout (FlowDict), or null
   const int32_t* xlist = nullptr;    // the extended fetch lists of a row-sharded operator (FlowX::list; aux / fl_mb / fl_slot are then FlowX's)
   const void* rmbox = nullptr;       // mailboxes of the neighbouring rank this sweep's halo entries come from (peer-mapped; fetch-list entries with kRemoteCell set)
   int32_t grid = 0;                  // workgroups to launch: fewer than blocks = the persistent form (host side only; 0: one per block)

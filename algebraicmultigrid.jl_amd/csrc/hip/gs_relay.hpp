@@ -37,7 +37,13 @@ namespace bw {
 #define BW_RELAY_DEPTH_LONG 2           // ... and of up to 18
 #endif
 template <int MAXK> struct RelayDepth { static constexpr int value = MAXK <= 12 ? BW_RELAY_DEPTH_SHORT : BW_RELAY_DEPTH_LONG; };
+#ifndef BW_RELAY_DICT_DEPTH
+#define BW_RELAY_DICT_DEPTH 3
+#endif
+template <int MAXK> struct RelayDepthD { static constexpr int value = BW_RELAY_DICT_DEPTH; };   // the dictionary layout: a set is a handful of registers
 template <int MAXK> struct RelayWaves { static constexpr int value = MAXK <= 6 ? 4 : MAXK <= 18 ? 2 : 1; };
+// (the dictionary layout: a set in flight is a column chunk or three and b — 74 / 139 registers at 6 / 18 entries a row against 109 / 165)
+template <int MAXK> struct RelayWavesD { static constexpr int value = MAXK <= 6 ? 5 : MAXK <= 18 ? 3 : 1; };
 
 // LDS by its 32-bit address (the walkers keep absolute LDS addresses in registers: nothing is added behind the hand-over)
 template <typename T> __device__ __forceinline__ T lds_get(unsigned addr) { return *(const __attribute__((address_space(3))) T*)(unsigned long long)addr; }
@@ -47,15 +53,49 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // control words of a block, behind its x in LDS (16 bytes, 16-byte aligned): one ds_read_b128 polls them all
 //   [0] progress: leading entries of the fetch list that have arrived (the fetcher)   [1] done: steps finished (the walkers)
 //   [2] bail: somebody gave up a poll — nobody waits any more                          [3] unused
+// a step's operands on the DICTIONARY layout (FlowDict): column chunks and b only — the values come out of the block's
+// dictionary in LDS, by the index that rides in the publish word
+template <typename R, int MAXK>
+struct FlowOpsD {
+  static constexpr int VPC = 16 / (int)sizeof(R), NVC = (MAXK + 2 + VPC - 1) / VPC, NCC = (MAXK + 7) / 8, KCH = NCC;
+  static constexpr int CTAIL = ((MAXK + 1) / 2 - 1) % 4 + 1;
+  static constexpr int NLOAD = NCC + 1;
+  u32x4 cf[NCC > 1 ? NCC - 1 : 1];
+  typename Dw<CTAIL + 1>::type ct;
+  typename Dw<(int)sizeof(R) / 4>::type bb;
+  int p; int need;
+  __device__ __forceinline__ u32x4 cchunk(int c) const { return c < NCC - 1 ? cf[c] : widen(ct); }
+  __device__ __forceinline__ int32_t pub() const { const u32x4 c = widen(ct); return (int32_t)(CTAIL == 1 ? c.y : CTAIL == 2 ? c.z : c.w); }
+};
+template <int N, typename R, int MAXK>
+__device__ __forceinline__ void flow_wait(FlowOpsD<R, MAXK>& o) {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
+#pragma unroll
+  for (int c = 0; c < FlowOpsD<R, MAXK>::NCC - 1; ++c) asm volatile("" : "+v"(o.cf[c]));
+  asm volatile("" : "+v"(o.ct));
+  asm volatile("" : "+v"(o.bb));
+}
+template <typename R> __device__ __forceinline__ R value_of(const u32x4* vv, int k) {   // value k of a row out of its value chunks
+  if constexpr (sizeof(R) == 8) {
+    const u32x4 c = vv[k >> 1];
+    return (k & 1) ? __hiloint2double((int)c.w, (int)c.z) : __hiloint2double((int)c.y, (int)c.x);
+  } else {
+    const u32x4 c = vv[k >> 2];
+    const unsigned w = (k & 3) == 0 ? c.x : (k & 3) == 1 ? c.y : (k & 3) == 2 ? c.z : c.w;
+    return __uint_as_float(w);
+  }
+}
+
 // One block of the sweep: ticket ut of the launch, mailbox tag `epoch`.  All waves of the workgroup enter; the fetcher wave
 // leaves when its list is done, the walkers behind their last step.
-template <typename R, bool SOR, bool BWD, int MAXK, int W>
+template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT>
 __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char* lds_all, const int wv, const int lane, const unsigned int ut,
                                             const unsigned int epoch, const long long t_start) {
-  typedef FlowOps<R, MAXK> O;
+  typedef typename std::conditional<DICT, FlowOpsD<R, MAXK>, FlowOps<R, MAXK>>::type O;
   typedef Mail<R> M;
-  constexpr int D = RelayDepth<MAXK>::value;
+  constexpr int D = DICT ? RelayDepthD<MAXK>::value : RelayDepth<MAXK>::value;
   constexpr int RB = (int)sizeof(R);
+  constexpr int NVC = FlowOps<R, MAXK>::NVC;
   const bool fetcher = wv == W;
   const int tk = (int)ut;
   const int ob = __builtin_amdgcn_readfirstlane(BWD ? a.nblocks - 1 - tk : tk);
@@ -186,7 +226,7 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
   typedef const uint32_t __attribute__((address_space(4))) cu32;
   const cu32* axc = (const cu32*)(unsigned long long)uniform_ptr(ax);
   unsigned sw_next = axc[wv < ns ? wv : ns];
-  const i32x4 rs_rec = make_rsrc(a.srec + (size_t)(uint32_t)d.rec * 16);
+  const i32x4 rs_rec = DICT ? make_rsrc(a.crec + (size_t)(uint32_t)d.row0 * (size_t)(16 * O::NCC)) : make_rsrc(a.srec + (size_t)(uint32_t)d.rec * 16);
   const i32x4 rs_b = make_rsrc(a.b + d.row0);
   const i32x4 rs_x = make_rsrc(x + d.row0);
   const i32x4 rs_mst = make_rsrc(a.mbox);
@@ -200,12 +240,18 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     o.p = r0 + tt;
     const unsigned voff = (unsigned)tt * 16u;
     const unsigned s0 = (unsigned)r0 * (16u * O::KCH), sd = (unsigned)nr * 16u;
+    if constexpr (DICT) {
 #pragma unroll
-    for (int c = 0; c < O::NVC - 1; ++c) asm_load<4>(o.vf[c], voff, rs_rec, s0 + (unsigned)c * sd);
-    asm_load<O::VTAIL>(o.vt, voff, rs_rec, s0 + (unsigned)(O::NVC - 1) * sd);
+      for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)c * sd);
+      asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NCC - 1) * sd);
+    } else {
 #pragma unroll
-    for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)(O::NVC + c) * sd);
-    asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NVC + O::NCC - 1) * sd);
+      for (int c = 0; c < O::NVC - 1; ++c) asm_load<4>(o.vf[c], voff, rs_rec, s0 + (unsigned)c * sd);
+      asm_load<O::VTAIL>(o.vt, voff, rs_rec, s0 + (unsigned)(O::NVC - 1) * sd);
+#pragma unroll
+      for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)(O::NVC + c) * sd);
+      asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NVC + O::NCC - 1) * sd);
+    }
     asm_load<RB / 4>(o.bb, (unsigned)tt * RB, rs_b, (unsigned)r0 * RB);
   };
   O ops[D];
@@ -224,6 +270,13 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
 #pragma unroll
       for (int k = 0; k < XW; ++k) { const int p = p0 + lane + 64 * k; if (p < d.nrows) xl[p] = xv[k]; }
     }
+    if constexpr (DICT) {   // the block's dictionary (its distinct value rows) behind the control words
+      const int32_t de = a.dict_ent[ob];
+      const int nchunk = (((unsigned)de >> 24) + 1) * NVC;
+      const u32x4* dg = (const u32x4*)(a.dict + (size_t)(de & 0xffffff) * 16);
+      u32x4* dl = (u32x4*)(lds + nxb + 16);
+      for (int i = wv * 64 + lane; i < nchunk; i += 64 * W) dl[i] = dg[i];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (nothing of the compiler's in flight when the counted loads start)
 #pragma unroll
     for (int j = 0; j < D; ++j) issue(ops[j], wv + j * W);
@@ -238,6 +291,7 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
   bool gave_up = false, bail = false;
   const unsigned xl_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(xl));
   const unsigned ctl_off = xl_base + (unsigned)nxb;   // (LDS address of the control words)
+  const unsigned dict_base = ctl_off + 16u;            // (the dictionary layout: the block's distinct value rows)
 #ifdef BW_RELAY_STAMPS   // (measurement builds: three wall-clock stamps per step in LDS behind the control words, dumped at the end;
   // per mailbox the time its row was published (a counted third store of the step) and the time its reader's fetcher saw it)
   const unsigned stamp_base = xl_base + (unsigned)nxb + 16u;
@@ -264,6 +318,15 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     const int32_t pw = o.pub();
     unsigned cell = ((pw & pubdir) && !mute) ? (unsigned)f.pad0 + (((unsigned)pw >> (BWD ? 11 : 0)) & 0x7ffu) : spare;
     cell *= (unsigned)M::kBytes;
+    u32x4 vv[NVC];   // (the dictionary layout: the row's values out of LDS, ahead of the hand-over)
+    if constexpr (DICT) {
+      const unsigned da = dict_base + (((unsigned)pw >> kDictIdxShift) & 0xffu) * (unsigned)(16 * NVC);
+#pragma unroll
+      for (int c = 0; c < NVC; ++c) vv[c] = lds_get<u32x4>(da + 16u * (unsigned)c);
+#pragma unroll
+      for (int c = 0; c < NVC; ++c) asm volatile("" : "+v"(vv[c]));
+    }
+    auto val = [&](int k) -> R { if constexpr (DICT) return value_of<R>(vv, k); else return chunk_value<R>(o, k); };
     unsigned xoff = (unsigned)o.p * (unsigned)RB;   // (the row's x: byte offset in the block, in LDS and in memory alike)
     unsigned xadr = xl_base + xoff;
 #pragma unroll
@@ -311,7 +374,7 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
       for (int k = 0; k < MAXK; ++k) xv[k] = lds_get<R>(off[k]);
       xo = lds_get<R>(xadr);
 #pragma unroll
-      for (int k = 0; k < MAXK; ++k) acc += chunk_value<R>(o, k) * xv[k];
+      for (int k = 0; k < MAXK; ++k) acc += val(k) * xv[k];
     } else {
       constexpr int GB = 12;   // gathers per batch
       xo = lds_get<R>(xadr);
@@ -323,10 +386,10 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
 #pragma unroll
         for (int k = 0; k < GB; ++k) if (k0 + k < MAXK) pin(xv[k]);
 #pragma unroll
-        for (int k = 0; k < GB; ++k) if (k0 + k < MAXK) acc += chunk_value<R>(o, k0 + k) * xv[k];
+        for (int k = 0; k < GB; ++k) if (k0 + k < MAXK) acc += val(k0 + k) * xv[k];
       }
     }
-    const R dg = chunk_value<R>(o, MAXK), rc = chunk_value<R>(o, MAXK + 1);
+    const R dg = val(MAXK), rc = val(MAXK + 1);
     R bbv;
     if constexpr (sizeof(R) == 8) bbv = __hiloint2double((int)o.bb.y, (int)o.bb.x); else bbv = __uint_as_float(o.bb);
     const R nn = bbv - acc;
@@ -431,8 +494,8 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
 // tickets until they run out.  That is what several sweeps sharing one device need (the ranks of a row-sharded level on a
 // single GPU: a workgroup of rank p may wait for values of rank p - 1, whose workgroups must then BE resident, not queued
 // behind it), and what bounds the resident workgroups of a launch.  A launch of one workgroup per block is the plain form.
-template <typename R, bool SOR, bool BWD, int MAXK, int W>
-__global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_relay_kernel(FlowArgs<R> a) {
+template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT = false>
+__global__ __launch_bounds__(64 * (W + 1), DICT ? RelayWavesD<MAXK>::value : RelayWaves<MAXK>::value) void gs_bw_relay_kernel(FlowArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
   static_assert(W >= 2 && W <= 7, "walker waves per block");
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -455,7 +518,7 @@ __global__ __launch_bounds__(64 * (W + 1), RelayWaves<MAXK>::value) void gs_bw_r
       __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u == 0u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ut >= units) return;
     const unsigned int epoch = a.epoch ? a.epoch : sweeps + 1u;   // (a.epoch: the tag of a sweep that several launches share, amghip_dist.hpp)
-    relay_block<R, SOR, BWD, MAXK, W>(a, lds_all, wv, lane, ut, epoch, t_start);
+    relay_block<R, SOR, BWD, MAXK, W, DICT>(a, lds_all, wv, lane, ut, epoch, t_start);
     if (!persistent) return;
     __syncthreads();   // (everybody is done with this block's LDS)
   }
@@ -465,9 +528,9 @@ static_assert(RelayDepth<6>::value <= 4 && RelayDepth<12>::value <= 4 && RelayDe
 // measurement knob: extra dynamic LDS per workgroup (bounds the blocks resident per CU)
 inline size_t& relay_lds_pad() { static size_t pad = 0; return pad; }
 
-template <typename R, bool SOR, bool BWD, int MAXK, int W>
+template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT = false>
 inline hipError_t sweep_relay_launch(const FlowArgs<R>& a, size_t lds, hipStream_t st) {
-  auto* fn = gs_bw_relay_kernel<R, SOR, BWD, MAXK, W>;
+  auto* fn = gs_bw_relay_kernel<R, SOR, BWD, MAXK, W, DICT>;
   if (relay_lds_pad()) {
     lds += relay_lds_pad();
     static hipError_t once = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -476,7 +539,7 @@ inline hipError_t sweep_relay_launch(const FlowArgs<R>& a, size_t lds, hipStream
     return hipGetLastError();
   }
 #ifdef BW_RELAY_STAMPS
-  lds += 128 * 24;
+  lds += 128 * 24 + (DICT ? kDictLdsMax : 0);
 #endif
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(fn, dim3((unsigned)(a.grid > 0 && a.grid < a.nblocks ? a.grid : a.nblocks)), dim3(64 * (W + 1)), lds, st, a);
@@ -505,6 +568,11 @@ inline int relay_resident_blocks(int maxk, size_t lds) {
 
 template <typename R, int MAXK, int W>
 inline hipError_t sweep_relay_k(const FlowArgs<R>& a, size_t lds, bool sor, bool backward, hipStream_t st) {
+  if constexpr (MAXK <= 18)   // (the dictionary layout, where the schedule carries one: FlowDict)
+    if (a.crec) {
+      if (sor) return backward ? sweep_relay_launch<R, true, true, MAXK, W, true>(a, lds, st) : sweep_relay_launch<R, true, false, MAXK, W, true>(a, lds, st);
+      return backward ? sweep_relay_launch<R, false, true, MAXK, W, true>(a, lds, st) : sweep_relay_launch<R, false, false, MAXK, W, true>(a, lds, st);
+    }
   if (sor) return backward ? sweep_relay_launch<R, true, true, MAXK, W>(a, lds, st) : sweep_relay_launch<R, true, false, MAXK, W>(a, lds, st);
   return backward ? sweep_relay_launch<R, false, true, MAXK, W>(a, lds, st) : sweep_relay_launch<R, false, false, MAXK, W>(a, lds, st);
 }

@@ -510,6 +510,9 @@ int amgh_debug_bw_poll_giveups(const amgh_t* h, int l);
  * launch as a dataflow (rows published into mailboxes as they are computed; structurally symmetric patterns).  -1: no
  * such level.                                                                                                         */
 int amgh_debug_bw_mode(const amgh_t* h, int l);
+/* ... and whether the single-column dataflow sweep of level l reads the DICTIONARY layout (column records + every block's
+ * distinct value rows, held in LDS; tunable "gs_bw_dict"): 1 / 0, -1: no such level.                                */
+int amgh_debug_bw_dict(const amgh_t* h, int l);
 
 /* Diagnostics: tunables of the Gauss-Seidel execution (process-wide; used by tools/ to pick the defaults and by
  * tests to force every path).  Read at every sweep: "gs_xcd_map", "gs_block_pipe", "gs_flip", "gs_keep_lo",
@@ -530,6 +533,8 @@ int amgh_debug_bw_mode(const amgh_t* h, int l);
  * bitwise the same sweep), "gs_bw_nc" (columns of a block of right-hand sides one workgroup of the dataflow sweep carries: 2;
  * 0 = as many as are instantiated), "gs_bw_spin" / "gs_bw_skip_pub" (test hooks: bound of a poll, a block that publishes
  * nothing), "gs_flow_xzero" (1: a dataflow sweep that starts a smooth! call on x = 0 reads no x — bitwise the same),
+ * "gs_bw_dict" (1: single-column schedules carry the dictionary layout where every block has at most 256 distinct value
+ * rows, and the relayed sweep reads it — bitwise the same; read at build and at every sweep),
  * "gs_dup_launch" (measurement hook: every merged-group launch issued 1 + that many times).
  * Returns AMGH_EINVAL for an unknown name.                                                                       */
 int amgh_debug_set_tunable(const char* name, int value);

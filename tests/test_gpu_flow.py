@@ -26,7 +26,7 @@ def rel(x, y):
 class tunables:
     """amgh_debug_set_tunable for the duration of a with block (values restored to the given defaults)."""
     DEFAULTS = {"gs_bw": 1, "gs_bw_rows": 512, "gs_bw_chain": 1, "gs_bw_flow": 1, "gs_lean": -1, "gs_bw_spin": 0, "gs_bw_skip_pub": -1,
-                "gs_lpr": 0, "gs_ept": 0, "gs_bw_nc": 2, "gs_bw_nrhs": 1, "gs_flow_xzero": 1, "gs_bw_relay": 3}
+                "gs_lpr": 0, "gs_ept": 0, "gs_bw_nc": 2, "gs_bw_nrhs": 1, "gs_flow_xzero": 1, "gs_bw_relay": 3, "gs_bw_dict": 1}
 
     def __init__(self, lib, **kw):
         self.lib, self.kw = lib, kw
@@ -92,6 +92,8 @@ def test_relayed_sweep_on_irregular_long_rows_is_the_scalar_loop_bit_for_bit():
             x_relay = dev.smooth(0, False, x0, bb)
             with tunables(lib, gs_bw_relay=0):
                 assert np.array_equal(dev.smooth(0, False, x0, bb), x_relay), repr(pre)
+            # (random values: every row its own dictionary entry — nothing to gain, no dictionary layout for this operator)
+            assert lib.amgh_debug_bw_dict(dev.h, 0) == 0
             with tunables(lib, gs_bw_flow=0):
                 assert np.array_equal(dev.smooth(0, False, x0, bb), x_relay), repr(pre)
             assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
@@ -125,6 +127,11 @@ def test_dataflow_sweep_is_the_scalar_loop_bit_for_bit():
                 for rep in range(2):                                                    # epochs of the mailboxes
                     assert np.array_equal(dev.smooth(0, False, x0, bb), x_flow)
                 with tunables(lib, gs_bw_relay=0):                                      # one walker per block (gs_bw_flow_kernel) instead of the relay
+                    assert np.array_equal(dev.smooth(0, False, x0, bb), x_flow), (A.m, repr(pre))
+                if A.m != 5000:                                                         # grids: the relay read the dictionary layout
+                    assert lib.amgh_debug_bw_dict(dev.h, 0) == 1, (A.m, repr(pre))
+                with tunables(lib, gs_bw_dict=0):                                       # ... and here the plain records
+                    assert lib.amgh_debug_bw_dict(dev.h, 0) == 0
                     assert np.array_equal(dev.smooth(0, False, x0, bb), x_flow), (A.m, repr(pre))
                 assert np.array_equal(dev.smooth(0, False, x0, bb), x_flow)             # ... and back: the two share mailboxes and epochs
                 with tunables(lib, gs_bw_flow=0):
@@ -366,3 +373,41 @@ def test_soak_blocks_of_eight_right_hand_sides_at_full_size(soak_fixture):
     finally:
         lib.amgh_set_use_graph(dev.h, 0)
     assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0 and lib.amgh_dev_sync(0) == 0
+
+
+def test_dictionary_layout_rows_that_repeat_and_rows_that_do_not():
+    """The dictionary layout of the dataflow records (gs_flow.hpp FlowDict: a block's distinct value rows in LDS, the record
+    carries the columns and a dictionary index): a 19-point operator (Galerkin product of the 7-point grid: rows of up to 18
+    entries), a grid with a few perturbed rows per block — the relayed sweep on it = on the plain records = the oracle's
+    scalar loop, bitwise; an operator whose rows all differ (a dictionary as large as the records) keeps the plain records."""
+    import scipy.sparse as sp
+    lib = AMG.hip_lib()
+    S = AMG.poisson((20, 20, 20)).to_scipy().tocsr()
+    # the 19-point operator of a 16^3 grid: the 6 face and the 12 edge neighbours (rows of up to 18 entries)
+    E, N = sp.identity(16, format="csr"), sp.diags([np.ones(15), np.ones(15)], [-1, 1], format="csr")
+    k3 = lambda a, b, c: sp.kron(sp.kron(a, b), c, format="csr")
+    K19 = 25.0 * sp.identity(16 ** 3) - 2.0 * (k3(N, E, E) + k3(E, N, E) + k3(E, E, N)) - (k3(N, N, E) + k3(N, E, N) + k3(E, N, N))
+    A19 = AMG.SparseMatrixCSC.from_scipy(K19.tocsc())
+    assert int(np.diff(K19.tocsr().indptr).max()) == 19
+    P = S.copy().tolil()
+    rng = np.random.default_rng(5)
+    for i in rng.integers(0, S.shape[0], 300):
+        P[i, i] = 6.0 + rng.random()
+    Ap = AMG.SparseMatrixCSC.from_scipy(P.tocsc())
+    R = S.copy()
+    R.data = R.data * (1.0 + 0.01 * rng.random(R.data.size))
+    R = (R + R.T) * 0.5                       # every row its own values: no dictionary (but the pattern stays symmetric)
+    Ar = AMG.SparseMatrixCSC.from_scipy(sp.csc_matrix(R))
+    pre = AMG.GaussSeidel()
+    for A, want, rows in ((A19, 1, 128), (Ap, 1, 216), (Ar, 0, 512)):
+        x0, bb = uniform(A.m, 51) - 0.5, uniform(A.m, 52)
+        ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre)
+        with tunables(lib, gs_bw=2, gs_bw_rows=rows, gs_lean=0):
+            dev = DeviceHierarchy(ml, 0, 1)
+            assert lib.amgh_debug_bw_mode(dev.h, 0) == 3
+            assert lib.amgh_debug_bw_dict(dev.h, 0) == want, (A.m, A.nnz)
+            xd = dev.smooth(0, False, x0, bb)
+            with tunables(lib, gs_bw_dict=0):
+                assert np.array_equal(dev.smooth(0, False, x0, bb), xd)
+            assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+        assert np.array_equal(xd, O.smooth(pre, A, x0, bb, hermitian=True)), (A.m, A.nnz)

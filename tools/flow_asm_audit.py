@@ -50,17 +50,22 @@ def audit_kernel(name, lines):
         return False, "no vmcnt waits found"
     # the steady wait follows from the instantiation: L = value chunks + column chunks + b loads per step, S = 2 stores,
     # D register sets (gs_flow.hpp FlowOps / FlowDepth) -> vmcnt((D - 1)(L + S))
-    m = re.search(r"gs_bw_(flow|relay)_kernelI([df])Lb[01]ELb[01]ELi(\d+)ELi(\d+)E", name)
+    m = re.search(r"gs_bw_(flow|relay)_kernelI([df])Lb[01]ELb[01]ELi(\d+)ELi(\d+)E(?:Lb([01])E)?", name)
     if not m:
         return False, "cannot read the instantiation from the name"
     relay = m.group(1) == "relay"
     rb, maxk = (8 if m.group(2) == "d" else 4), int(m.group(3))
     vpc = 16 // rb
     L = (maxk + 2 + vpc - 1) // vpc + (maxk + 7) // 8 + 1
+    dic = relay and m.group(5) == "1"   # (gs_relay.hpp FlowOpsD: the values come out of the block's dictionary in LDS)
+    if dic:
+        L = (maxk + 7) // 8 + 1
     depth = int(os.environ.get("BW_FLOW_DEPTH", "4"))
     nc = int(m.group(4))   # (relay kernels: the walker waves per block)
     if relay:   # gs_relay.hpp RelayDepth
         D = int(os.environ.get("BW_RELAY_DEPTH_SHORT", "3")) if maxk <= 12 else int(os.environ.get("BW_RELAY_DEPTH_LONG", "2"))
+        if dic:
+            D = int(os.environ.get("BW_RELAY_DICT_DEPTH", "3"))
     else:
         D = (min(depth, 3) if nc > 1 else depth) if maxk <= 6 else (min(depth, 4) if maxk <= 12 else 3)
     steady = (D - 1) * (L + 2)

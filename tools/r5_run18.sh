@@ -1,10 +1,23 @@
 mkdir -p gpurun_out/r5
-export AMG_DIST_ONE_GPU=1
-(timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 2 --steps 2 --warmup 1 --transport ipc-staged --no-secondary --no-cpu-baseline --size 128 > gpurun_out/r5/dist2s.json 2> gpurun_out/r5/dist2s.err; echo rc=$? >> gpurun_out/r5/dist2s.err)
-tail -3 gpurun_out/r5/dist2s.err | cut -c1-300
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r5/dist2s.json').read().strip().splitlines()[-1])
-print("primary ms", d['ms_per_step'], d['parity']['rel_err'], d['config'].get('gs_pipelined_by_level'), d['config']['sharded_levels'], d.get('ipc_staged'))
-for r in d['preflight']: print(r)
+cat > /tmp/dump1.py <<'PY'
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import amg_amd as AMG
+ml = AMG.ruge_stuben(AMG.poisson((256, 256, 256)), setup="gpu")
+for li in (0, 1):
+    M = ml.levels[li].A
+    with open(f"/tmp/bw_L{li}.bin", "wb") as f:
+        np.array([M.m, M.nnz], dtype=np.int64).tofile(f)
+        np.asarray(M.colptr, dtype=np.int32).tofile(f); np.asarray(M.rowval, dtype=np.int32).tofile(f); np.asarray(M.nzval, dtype=np.float64).tofile(f)
 PY
+python /tmp/dump1.py
+export BW_RELAY_ONLY=3
+for v in d63 d54 d72; do
+  for L in 0 1; do
+    for g in 0 512; do
+      (BW_RELAY_GRID=$g timeout 300 tools/relay_bench_$v /tmp/bw_L$L.bin 512 1024 > gpurun_out/r5/dict_${v}_L${L}_g$g.log 2>&1; echo rc=$? >> gpurun_out/r5/dict_${v}_L${L}_g$g.log)
+      echo "== $v L$L grid $g"; grep -E "^n =|dictionary|relay W|rc=|----" gpurun_out/r5/dict_${v}_L${L}_g$g.log | cut -c1-260
+    done
+  done
+done

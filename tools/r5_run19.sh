@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r5
-(timeout 2700 python -m pytest tests -x -q -m gpu > gpurun_out/r5/pytest_gpu3.log 2>&1; echo rc=$? >> gpurun_out/r5/pytest_gpu3.log)
-tail -6 gpurun_out/r5/pytest_gpu3.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 1500 python -m pytest tests/test_gpu_flow.py tests/test_gpu_float32.py -x -q -m gpu 2>&1 | tail -8
+timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/r5/bench_dict.json 2> gpurun_out/r5/bench_dict.err; tail -3 gpurun_out/r5/bench_dict.err; cat gpurun_out/r5/bench_dict.json | cut -c1-1500

@@ -59,14 +59,31 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   bw::FlowArgs<double> fa{d_blocks, d_fd, d_srec, d_aux, d_ext, d_fm, d_fs, d_mbox, d_b, d_x, 1.0, d_head, B, (int32_t)F.nmail, d_err, nullptr, 1u << 18, -1};
   const int mk = P.blocks[0].maxk;
-  const double fbytes = (double)F.srec.size() + n * 28.0 + P.ext_total * 22.0;
+  // the dictionary layout (FlowDict): distinct value rows per block in LDS, the record carries columns only
+  unsigned char *d_crec = nullptr, *d_dict = nullptr; int32_t* d_dent = nullptr;
+  if (F.dc.on) {
+    int64_t drows = 0; int dmax = 0;
+    for (int32_t e : F.dc.ent) { drows += ((uint32_t)e >> 24) + 1; dmax = std::max(dmax, (int)((uint32_t)e >> 24) + 1); }
+    printf("dictionary layout: %.3f GB column records (%.1f B per row), %.1f distinct value rows per block (max %d), %.3f MB of dictionaries, LDS %.1f KB per block\n",
+           F.dc.crec.size() / 1e9, (double)F.dc.crec.size() / n, (double)drows / B, dmax, F.dc.dict.size() / 1e6, F.dc.lds_max / 1024.0);
+    CHECK(hipMalloc(&d_crec, F.dc.crec.size())); CHECK(hipMalloc(&d_dict, F.dc.dict.size() + 16)); CHECK(hipMalloc(&d_dent, 4 * (size_t)B));
+    CHECK(hipMemcpy(d_crec, F.dc.crec.data(), F.dc.crec.size(), hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_dict, F.dc.dict.data(), F.dc.dict.size(), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_dent, F.dc.ent.data(), 4 * (size_t)B, hipMemcpyHostToDevice));
+  } else printf("no dictionary layout for this operator\n");
+  if (const char* eg = getenv("BW_RELAY_GRID")) fa.grid = atoi(eg);
+  for (int dict = 0; dict < (F.dc.on ? 2 : 1); ++dict) {
+  fa.crec = dict ? d_crec : nullptr; fa.dict = dict ? d_dict : nullptr; fa.dict_ent = dict ? d_dent : nullptr;
+  const size_t lds_use = dict ? F.dc.lds_max : F.lds_max;
+  if (const char* ed = getenv("BW_RELAY_DICT")) if (atoi(ed) != dict) continue;
+  printf("---- %s records ----\n", dict ? "dictionary" : "plain");
+  const double fbytes = (double)(dict ? F.dc.crec.size() + F.dc.dict.size() : F.srec.size()) + n * 28.0 + P.ext_total * 22.0;
   for (int W : {2, 3, 4}) {
     if (const char* ew = getenv("BW_RELAY_ONLY")) if (atoi(ew) != W) continue;
     CHECK(hipMemset(d_err, 0, 4));
     CHECK(hipMemcpy(d_x, xb.data(), 8 * n, hipMemcpyHostToDevice));
-    hipError_t e = bw::sweep_relay<double>(fa, mk, F.lds_max, false, false, st, W);
+    hipError_t e = bw::sweep_relay<double>(fa, mk, lds_use, false, false, st, W);
     if (e != hipSuccess) { printf("relay W = %d: launch failed: %s\n", W, hipGetErrorString(e)); (void)hipGetLastError(); continue; }
-    CHECK(bw::sweep_relay<double>(fa, mk, F.lds_max, false, true, st, W));
+    CHECK(bw::sweep_relay<double>(fa, mk, lds_use, false, true, st, W));
     CHECK(hipStreamSynchronize(st));
     CHECK(hipMemcpy(xg.data(), d_x, 8 * n, hipMemcpyDeviceToHost));
     int err = 0; CHECK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
@@ -74,14 +91,15 @@ int main(int argc, char** argv) {
     for (int64_t p = 0; p < n; ++p) { const double v = xr[P.perm[p]]; if (xg[p] != v) ++dd; md = std::max(md, std::fabs(xg[p] - v)); }
     printf("relay W = %d: forward + backward vs the scalar loops: %lld values differ (max |diff| %.3e), give-ups %d\n", W, (long long)dd, md, err);
     for (int bwd = 0; bwd < 2; ++bwd) {
-      CHECK(bw::sweep_relay<double>(fa, mk, F.lds_max, false, bwd, st, W)); CHECK(hipStreamSynchronize(st));
+      CHECK(bw::sweep_relay<double>(fa, mk, lds_use, false, bwd, st, W)); CHECK(hipStreamSynchronize(st));
       const int reps = 5;
       CHECK(hipEventRecord(e0, st));
-      for (int r = 0; r < reps; ++r) CHECK(bw::sweep_relay<double>(fa, mk, F.lds_max, false, bwd, st, W));
+      for (int r = 0; r < reps; ++r) CHECK(bw::sweep_relay<double>(fa, mk, lds_use, false, bwd, st, W));
       CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
       printf("relay W = %d %s sweep: %.3f ms (%.0f GB/s)\n", W, bwd ? "backward" : "forward ", ms / reps, fbytes / (ms / reps * 1e-3) / 1e9);
     }
+  }
   }
   return 0;
 }
