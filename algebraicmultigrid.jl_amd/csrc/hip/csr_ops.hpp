@@ -531,6 +531,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       fa.ldb = ldb; fa.ldx = xs; fa.mail_stride = g->bw.flow.mail_stride;
       fa.xzero = (g_gs_flow_xzero && first && xzero && !x_resident && g->ncols == g->n) ? 1 : 0;   // the sweep that starts a smooth! call on x = 0
       if (ncolv > g->bw.flow.mcols) return AMGH_ESTATE;   // (gs_ensure_cols sized the mailboxes)
+      const bool dict = g->bw.flow.dict_on && g_gs_bw_dict;   // (column records + the blocks' dictionaries of value rows)
       // a single column: the block's walk relayed between walker waves (gs_relay.hpp) — the same layout, the same bits
       if (op->pipe_epoch) {   // one sweep of a row-sharded level pipelined across the ranks: the relayed kernel on the extended lists
         if (ncolv != 1 || !g->bw.flow.xon) return AMGH_ESTATE;
@@ -539,11 +540,15 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
         e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
       } else if (ncolv == 1 && g_gs_bw_relay > 0) {
         fa.grid = g->bw.maxk > 6 ? g_gs_bw_grid_long : g_gs_bw_grid;
-        const bool dict = g->bw.flow.dict_on && g_gs_bw_dict;   // (column records + the blocks' dictionaries of value rows)
         if (dict) { fa.crec = g->bw.flow.crec; fa.dict = g->bw.flow.dict; fa.dict_ent = g->bw.flow.dict_ent; }
         e = bw::sweep_relay<real>(fa, g->bw.maxk, dict ? g->bw.flow.dict_lds : g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
+      } else {
+        if (dict && ncolv > 1) {
+          fa.crec = g->bw.flow.crec; fa.dict = g->bw.flow.dict; fa.dict_ent = g->bw.flow.dict_ent;
+          fa.dict_lds = (int32_t)(g->bw.flow.dict_lds - g->bw.flow.lds_max);
+        }
+        e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);
       }
-      else e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);
     } else {
       bw::Args<real> ba{g->bw.blocks, g->bw.rec, g->bw.ext_col, rhs, xp, ldb, xs, omega, 0, nullptr};
       if (g_gs_bw_chain && ncolv == 1 && g->bw.flags) {   // one launch, blocks chained by flags

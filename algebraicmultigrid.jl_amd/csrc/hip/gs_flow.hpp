@@ -458,6 +458,7 @@ struct FlowArgs {
   // (the relayed kernel of gs_relay.hpp only)
   uint32_t epoch = 0;                // the mailbox tag of this sweep when several launches share it (the ranks of a row-sharded level: every rank the same; 0: the launch's own count)
   const unsigned char* crec = nullptr; const unsigned char* dict = nullptr; const int32_t* dict_ent = nullptr;   // the dictionary layout (FlowDict), or null
+  int32_t dict_lds = 0;              // ... and the bytes of its largest dictionary (host side only: LDS behind the columns' x)
   const int32_t* xlist = nullptr;    // the extended fetch lists of a row-sharded operator (FlowX::list; aux / fl_mb / fl_slot are then FlowX's)
   const void* rmbox = nullptr;       // mailboxes of the neighbouring rank this sweep's halo entries come from (peer-mapped; fetch-list entries with kRemoteCell set)
   int32_t grid = 0;                  // workgroups to launch: fewer than blocks = the persistent form (host side only; 0: one per block)
@@ -572,6 +573,39 @@ template <typename R, typename O> __device__ __forceinline__ R chunk_value(const
     return __uint_as_float(w);
   }
 }
+// a step's operands on the DICTIONARY layout (FlowDict): column chunks and b only — the values come out of the block's
+// dictionary in LDS, by the index that rides in the publish word
+template <typename R, int MAXK>
+struct FlowOpsD {
+  static constexpr int VPC = 16 / (int)sizeof(R), NVC = (MAXK + 2 + VPC - 1) / VPC, NCC = (MAXK + 7) / 8, KCH = NCC;
+  static constexpr int CTAIL = ((MAXK + 1) / 2 - 1) % 4 + 1;
+  static constexpr int NLOAD = NCC + 1;
+  u32x4 cf[NCC > 1 ? NCC - 1 : 1];
+  typename Dw<CTAIL + 1>::type ct;
+  typename Dw<(int)sizeof(R) / 4>::type bb;
+  int p; int need;
+  __device__ __forceinline__ u32x4 cchunk(int c) const { return c < NCC - 1 ? cf[c] : widen(ct); }
+  __device__ __forceinline__ int32_t pub() const { const u32x4 c = widen(ct); return (int32_t)(CTAIL == 1 ? c.y : CTAIL == 2 ? c.z : c.w); }
+};
+template <int N, typename R, int MAXK>
+__device__ __forceinline__ void flow_wait(FlowOpsD<R, MAXK>& o) {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
+#pragma unroll
+  for (int c = 0; c < FlowOpsD<R, MAXK>::NCC - 1; ++c) asm volatile("" : "+v"(o.cf[c]));
+  asm volatile("" : "+v"(o.ct));
+  asm volatile("" : "+v"(o.bb));
+}
+template <typename R> __device__ __forceinline__ R value_of(const u32x4* vv, int k) {   // value k of a row out of its value chunks
+  if constexpr (sizeof(R) == 8) {
+    const u32x4 c = vv[k >> 1];
+    return (k & 1) ? __hiloint2double((int)c.w, (int)c.z) : __hiloint2double((int)c.y, (int)c.x);
+  } else {
+    const u32x4 c = vv[k >> 2];
+    const unsigned w = (k & 3) == 0 ? c.x : (k & 3) == 1 ? c.y : (k & 3) == 2 ? c.z : c.w;
+    return __uint_as_float(w);
+  }
+}
+
 template <typename R> __device__ __forceinline__ R load_real(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff);
 template <> __device__ __forceinline__ double load_real<double>(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
   const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
@@ -594,6 +628,16 @@ template <typename T> __device__ __forceinline__ T* uniform_ptr(T* p) {
   const unsigned long long u = (unsigned long long)p;
   return (T*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)u));
 }
+// The fetcher's arrival at the workgroup's barrier, as an instruction of its own: written as __syncthreads() the compiler
+// sinks it into ONE barrier block shared with the walkers' — correct, but every path through the fetcher's code then starts
+// in a block the walkers' hand-issued loads flow through, and the whole-kernel audit (tools/flow_asm_linear.py) can no longer
+// tell the two apart.  (LDS writes done, then the barrier; the fetcher has no stores to memory before it.)
+__device__ __forceinline__ void fetcher_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\t; (the fetcher's arrival)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // (blocks of right-hand sides: the fetcher's column arrays share the 128 registers of the short-row kernels — one set less)
 template <int MAXK, int NC = 1> struct FlowDepth {
   static constexpr int value = MAXK <= 6 ? (NC > 1 && BW_FLOW_DEPTH > 3 ? 3 : BW_FLOW_DEPTH) : MAXK <= 12 ? (BW_FLOW_DEPTH < 4 ? BW_FLOW_DEPTH : 4) : 3;
@@ -601,17 +645,23 @@ template <int MAXK, int NC = 1> struct FlowDepth {
 static_assert(BW_FLOW_DEPTH >= 2 && BW_FLOW_DEPTH <= 6, "the first round of the pipeline is written out for up to six sets");
 
 template <int MAXK> struct FlowWaves { static constexpr int value = MAXK <= 6 ? BW_FLOW_WAVES : 2; };   // waves per SIMD the kernel is compiled for
+// (the dictionary layout: a set in flight is a column chunk or three and b)
+#ifndef BW_FLOW_DICT_DEPTH
+#define BW_FLOW_DICT_DEPTH 3
+#endif
+template <int MAXK> struct FlowWavesD { static constexpr int value = MAXK <= 6 ? 5 : 3; };
 
 // One workgroup = one block of the partition x one group of up to NC right-hand-side columns: waves 0 .. NC - 1 WALK the block,
 // one column each (own LDS x, own mailboxes, all of them streaming the same record: the first wave's loads bring it into the
 // CU's cache), wave NC FETCHES for all of them.  NC = 1 is the single-column sweep.
-template <typename R, bool SOR, bool BWD, int MAXK, int NC = 1>
-__global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_flow_kernel(FlowArgs<R> a) {
+template <typename R, bool SOR, bool BWD, int MAXK, int NC = 1, bool DICT = false>
+__global__ __launch_bounds__(64 * (NC + 1), DICT ? FlowWavesD<MAXK>::value : FlowWaves<MAXK>::value) void gs_bw_flow_kernel(FlowArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
   static_assert(NC >= 1 && NC + 1 <= 4 * FlowWaves<MAXK>::value, "the workgroup's waves must fit the registers the kernel is compiled for");
-  typedef FlowOps<R, MAXK> O;
+  typedef typename std::conditional<DICT, FlowOpsD<R, MAXK>, FlowOps<R, MAXK>>::type O;
   typedef Mail<R> M;
-  constexpr int D = FlowDepth<MAXK, NC>::value;
+  constexpr int D = DICT ? BW_FLOW_DICT_DEPTH : FlowDepth<MAXK, NC>::value;
+  constexpr int NVC = FlowOps<R, MAXK>::NVC;
   constexpr int RB = (int)sizeof(R);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63u);
@@ -697,10 +747,80 @@ __global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_f
 #pragma unroll
       for (int c = 0; c < NC; ++c) if (c < nch) { xlc[c][d.nrows + d.next] = (R)0; *(unsigned int*)(col_lds(c) + nxb) = 0u; }
     }
+    // (the fetcher's path is its own from here to its end — its own arrival at the block's barrier: nothing of the walkers'
+    // hand-counted loads is in flight on any path through it, which is what tools/flow_asm_linear.py can then see)
+    fetcher_barrier();
+    {
+      // ---- the fetcher: near-side values out of their mailboxes, in the order the walk needs them, for every column of the
+      // group.  A window of U x 64 list entries is polled (per column only the groups up to the one behind its first missing
+      // entry); a column's progress word counts the LEADING entries that have arrived, so its walker goes on as soon as
+      // what its next step reads is there ----
+      constexpr int U = NC <= 2 ? 3 : 2;
+      const int nf = BWD ? f.npost : d.npre;
+      const int f0 = d.ext0 + (BWD ? d.npre : 0);
+      __amdgpu_buffer_rsrc_t rs_mail[NC];
+      R* xlc[NC]; unsigned int* prog[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        rs_mail[c] = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(col_mail(c < nch ? c : 0)), 0, 0x7ffffff0, 0x00020000);
+        xlc[c] = (R*)col_lds(c); prog[c] = (unsigned int*)(col_lds(c) + nxb);
+      }
+      unsigned total_spins = 0;
+      bool fail = false;
+      for (int w0 = 0; w0 < nf && !fail; w0 += 64 * U) {
+        int32_t mb[U]; int slot[U]; bool ok[NC][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = w0 + 64 * u + lane;
+          mb[u] = a.fl_mb[e < nf ? f0 + e : f0];
+          slot[u] = a.fl_slot[e < nf ? f0 + e : f0];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) ok[c][u] = !(e < nf) || !(c < nch);
+        }
+        int first[NC];   // leading entries of the window that have arrived, per column
+#pragma unroll
+        for (int c = 0; c < NC; ++c) first[c] = c < nch ? 0 : 64 * U;
+        for (;;) {
+          typename M::cell cl[NC][U];
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (!ok[c][u] && 64 * u <= first[c] + 64) cl[c][u] = M::load(rs_mail[c], (unsigned)mb[u] * (unsigned)M::kBytes);
+          bool moved = false, done = true;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (!ok[c][u] && 64 * u <= first[c] + 64 && M::valid(cl[c][u], epoch)) { xlc[c][slot[u]] = M::value(cl[c][u]); ok[c][u] = true; }
+            int nfirst = 64 * U;
+#pragma unroll
+            for (int u = U - 1; u >= 0; --u) {
+              const unsigned long long m = __builtin_amdgcn_ballot_w64(!ok[c][u]);
+              if (m) nfirst = 64 * u + (int)__builtin_ctzll(m);
+            }
+            // (LDS operations of one wave execute in program order: the values are in place before the progress word moves)
+            if (nfirst != first[c] && lane == 0) __hip_atomic_store(prog[c], (unsigned)(w0 + nfirst < nf ? w0 + nfirst : nf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            moved |= nfirst != first[c];
+            first[c] = nfirst;
+            done &= nfirst == 64 * U;
+          }
+          if (done) break;
+          if (!moved) __builtin_amdgcn_s_sleep(4);
+          if (++total_spins > spin_limit) { fail = true; break; }
+        }
+      }
+      if (fail && lane == 0) {
+        *a.err = 1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (c < nch) __hip_atomic_store(prog[c], 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      return;
+    }
   }
   // (walkers of columns the group does not have leave behind the block's barrier)
-  const bool walker = !fetcher && wv < nch;
-  const int wc = walker ? wv : 0;
+  // (... by a path of their own, like the fetcher: every path below this line is a walker's)
+  if (wv >= nch) { fetcher_barrier(); return; }
+  const int wc = wv;
   unsigned char* lds = col_lds(wc);
   R* xl = (R*)lds;
   unsigned int* progress = (unsigned int*)(lds + nxb);
@@ -714,7 +834,7 @@ __global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_f
   typedef const uint32_t __attribute__((address_space(4))) cu32;   // (constant address space: read-only for the kernel's lifetime, so a uniform index is a scalar load)
   const cu32* axc = (const cu32*)(unsigned long long)uniform_ptr(ax);
   unsigned sw_next = axc[0];
-  const i32x4 rs_rec = make_rsrc(a.srec + (size_t)(uint32_t)d.rec * 16);
+  const i32x4 rs_rec = DICT ? make_rsrc(a.crec + (size_t)(uint32_t)d.row0 * (size_t)(16 * O::NCC)) : make_rsrc(a.srec + (size_t)(uint32_t)d.rec * 16);
   const i32x4 rs_b = make_rsrc(bcol + d.row0);
   const i32x4 rs_x = make_rsrc(x + d.row0);
   const i32x4 rs_mst = make_rsrc(mcol);
@@ -730,16 +850,31 @@ __global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_f
     o.p = r0 + tt;
     const unsigned voff = (unsigned)tt * 16u;
     const unsigned s0 = (unsigned)r0 * (16u * O::KCH), sd = (unsigned)nr * 16u;
+    if constexpr (DICT) {
 #pragma unroll
-    for (int c = 0; c < O::NVC - 1; ++c) asm_load<4>(o.vf[c], voff, rs_rec, s0 + (unsigned)c * sd);
-    asm_load<O::VTAIL>(o.vt, voff, rs_rec, s0 + (unsigned)(O::NVC - 1) * sd);
+      for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)c * sd);
+      asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NCC - 1) * sd);
+    } else {
 #pragma unroll
-    for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)(O::NVC + c) * sd);
-    asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NVC + O::NCC - 1) * sd);
+      for (int c = 0; c < O::NVC - 1; ++c) asm_load<4>(o.vf[c], voff, rs_rec, s0 + (unsigned)c * sd);
+      asm_load<O::VTAIL>(o.vt, voff, rs_rec, s0 + (unsigned)(O::NVC - 1) * sd);
+#pragma unroll
+      for (int c = 0; c < O::NCC - 1; ++c) asm_load<4>(o.cf[c], voff, rs_rec, s0 + (unsigned)(O::NVC + c) * sd);
+      asm_load<O::CTAIL + 1>(o.ct, voff, rs_rec, s0 + (unsigned)(O::NVC + O::NCC - 1) * sd);
+    }
     asm_load<RB / 4>(o.bb, (unsigned)tt * RB, rs_b, (unsigned)r0 * RB);
   };
   O ops[D];
-  if (walker) {
+  // (the dictionary layout: the block's distinct value rows, behind the columns' LDS; every walker brings a share)
+  const u32x4* dict_lds = (const u32x4*)(lds_all + (size_t)NC * (size_t)a.lds_stride);
+  {
+    if constexpr (DICT) {
+      const int32_t de = a.dict_ent[ob];
+      const int nchunk = (int)(((unsigned)de >> 24) + 1u) * NVC;
+      const u32x4* dg = (const u32x4*)(a.dict + (size_t)(de & 0xffffff) * 16);
+      u32x4* dl = (u32x4*)(lds_all + (size_t)NC * (size_t)a.lds_stride);
+      for (int i = wv * 64 + lane; i < nchunk; i += 64 * nch) dl[i] = dg[i];
+    }
     // the walker's half of the load phase: its column's own rows into LDS (one batch of loads for blocks of up to 512 rows),
     // finished — the compiler waits for them before the LDS writes — before the hand-counted pipeline starts
     constexpr int XW = 8;
@@ -760,73 +895,6 @@ __global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_f
     for (int j = 0; j < D; ++j) issue(ops[j], j);
   }
   __syncthreads();
-  if (fetcher) {
-    // ---- the fetcher: near-side values out of their mailboxes, in the order the walk needs them, for every column of the
-    // group.  A window of U x 64 list entries is polled (per column only the groups up to the one behind its first missing
-    // entry); a column's progress word counts the LEADING entries that have arrived, so its walker goes on as soon as
-    // what its next step reads is there ----
-    constexpr int U = NC <= 2 ? 3 : 2;
-    const int nf = BWD ? f.npost : d.npre;
-    const int f0 = d.ext0 + (BWD ? d.npre : 0);
-    __amdgpu_buffer_rsrc_t rs_mail[NC];
-    R* xlc[NC]; unsigned int* prog[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      rs_mail[c] = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(col_mail(c < nch ? c : 0)), 0, 0x7ffffff0, 0x00020000);
-      xlc[c] = (R*)col_lds(c); prog[c] = (unsigned int*)(col_lds(c) + nxb);
-    }
-    unsigned total_spins = 0;
-    bool fail = false;
-    for (int w0 = 0; w0 < nf && !fail; w0 += 64 * U) {
-      int32_t mb[U]; int slot[U]; bool ok[NC][U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = w0 + 64 * u + lane;
-        mb[u] = a.fl_mb[e < nf ? f0 + e : f0];
-        slot[u] = a.fl_slot[e < nf ? f0 + e : f0];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) ok[c][u] = !(e < nf) || !(c < nch);
-      }
-      int first[NC];   // leading entries of the window that have arrived, per column
-#pragma unroll
-      for (int c = 0; c < NC; ++c) first[c] = c < nch ? 0 : 64 * U;
-      for (;;) {
-        typename M::cell cl[NC][U];
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-          for (int u = 0; u < U; ++u) if (!ok[c][u] && 64 * u <= first[c] + 64) cl[c][u] = M::load(rs_mail[c], (unsigned)mb[u] * (unsigned)M::kBytes);
-        bool moved = false, done = true;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (!ok[c][u] && 64 * u <= first[c] + 64 && M::valid(cl[c][u], epoch)) { xlc[c][slot[u]] = M::value(cl[c][u]); ok[c][u] = true; }
-          int nfirst = 64 * U;
-#pragma unroll
-          for (int u = U - 1; u >= 0; --u) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(!ok[c][u]);
-            if (m) nfirst = 64 * u + (int)__builtin_ctzll(m);
-          }
-          // (LDS operations of one wave execute in program order: the values are in place before the progress word moves)
-          if (nfirst != first[c] && lane == 0) __hip_atomic_store(prog[c], (unsigned)(w0 + nfirst < nf ? w0 + nfirst : nf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          moved |= nfirst != first[c];
-          first[c] = nfirst;
-          done &= nfirst == 64 * U;
-        }
-        if (done) break;
-        if (!moved) __builtin_amdgcn_s_sleep(4);
-        if (++total_spins > spin_limit) { fail = true; break; }
-      }
-    }
-    if (fail && lane == 0) {
-      *a.err = 1;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) if (c < nch) __hip_atomic_store(prog[c], 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    return;
-  }
-  if (!walker) return;
   // ---- the walker ----
   __builtin_amdgcn_s_setprio(2);
   const long long t_loaded = a.tim ? wall_clock64() : 0;
@@ -856,10 +924,17 @@ __global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_f
       xv[k] = *(const R*)((const char*)xl + off);
     }
     const R xo = xl[o.p];
+    u32x4 vv[NVC];
+    if constexpr (DICT) {
+      const u32x4* dr = dict_lds + (((unsigned)o.pub() >> kDictIdxShift) & 0xffu) * (unsigned)NVC;
+#pragma unroll
+      for (int c = 0; c < NVC; ++c) vv[c] = dr[c];
+    }
+    auto val = [&](int k) -> R { if constexpr (DICT) return value_of<R>(vv, k); else return chunk_value<R>(o, k); };
     R acc = (R)0;
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) acc += chunk_value<R>(o, k) * xv[k];
-    const R dg = chunk_value<R>(o, MAXK), rc = chunk_value<R>(o, MAXK + 1);
+    for (int k = 0; k < MAXK; ++k) acc += val(k) * xv[k];
+    const R dg = val(MAXK), rc = val(MAXK + 1);
     R bbv;
     if constexpr (sizeof(R) == 8) bbv = __hiloint2double((int)o.bb.y, (int)o.bb.x); else bbv = __uint_as_float(o.bb);
     const R nn = bbv - acc;
@@ -940,11 +1015,11 @@ __global__ __launch_bounds__(64 * (NC + 1), FlowWaves<MAXK>::value) void gs_bw_f
 template <int MAXK> struct FlowMaxNc { static constexpr int value = MAXK <= 6 ? 4 : 3; };
 constexpr size_t kFlowLdsCap = 152 * 1024;
 
-template <typename R, bool SOR, bool BWD, int MAXK, int NC>
+template <typename R, bool SOR, bool BWD, int MAXK, int NC, bool DICT = false>
 inline hipError_t sweep_flow_launch(const FlowArgs<R>& a, size_t lds, hipStream_t st) {
   if constexpr (NC > FlowMaxNc<MAXK>::value) return hipErrorInvalidValue;
   else {
-    auto* fn = gs_bw_flow_kernel<R, SOR, BWD, MAXK, NC>;
+    auto* fn = gs_bw_flow_kernel<R, SOR, BWD, MAXK, NC, DICT>;
     if (lds > 64 * 1024) {   // (beyond the default limit: asked for once per kernel)
       static hipError_t once = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFlowLdsCap);
       if (once != hipSuccess) return once;
@@ -955,6 +1030,11 @@ inline hipError_t sweep_flow_launch(const FlowArgs<R>& a, size_t lds, hipStream_
 }
 template <typename R, int MAXK, int NC>
 inline hipError_t sweep_flow_k(const FlowArgs<R>& a, size_t lds, bool sor, bool backward, hipStream_t st) {
+  if constexpr (NC > 1)   // (the dictionary layout, where the schedule carries one — a single column on it is the relayed sweep's, gs_relay.hpp)
+    if (a.crec) {
+      if (sor) return backward ? sweep_flow_launch<R, true, true, MAXK, NC, true>(a, lds, st) : sweep_flow_launch<R, true, false, MAXK, NC, true>(a, lds, st);
+      return backward ? sweep_flow_launch<R, false, true, MAXK, NC, true>(a, lds, st) : sweep_flow_launch<R, false, false, MAXK, NC, true>(a, lds, st);
+    }
   if (sor) return backward ? sweep_flow_launch<R, true, true, MAXK, NC>(a, lds, st) : sweep_flow_launch<R, true, false, MAXK, NC>(a, lds, st);
   return backward ? sweep_flow_launch<R, false, true, MAXK, NC>(a, lds, st) : sweep_flow_launch<R, false, false, MAXK, NC>(a, lds, st);
 }
@@ -966,13 +1046,14 @@ inline hipError_t sweep_flow_cols(FlowArgs<R> a, size_t lds_max, bool sor, bool 
   if ((unsigned long long)a.nblocks * (unsigned long long)ncols > 0x7fffffffull) return hipErrorInvalidValue;
   int cap = FlowMaxNc<MAXK>::value;
   if (nc_max > 0 && nc_max < cap) cap = nc_max;
-  while (cap > 1 && (size_t)cap * stride > kFlowLdsCap) --cap;
+  const size_t dl = a.crec ? (size_t)a.dict_lds : 0;   // (the block's dictionary behind the columns)
+  while (cap > 1 && (size_t)cap * stride + dl > kFlowLdsCap) --cap;
   const int groups = (ncols + cap - 1) / cap, nc = (ncols + groups - 1) / groups;
   a.lds_stride = (int32_t)stride; a.ncols = ncols; a.ngroups = groups;
   switch (nc) {
-    case 4: return sweep_flow_k<R, MAXK, 4>(a, stride * 4, sor, backward, st);
-    case 3: return sweep_flow_k<R, MAXK, 3>(a, stride * 3, sor, backward, st);
-    case 2: return sweep_flow_k<R, MAXK, 2>(a, stride * 2, sor, backward, st);
+    case 4: return sweep_flow_k<R, MAXK, 4>(a, stride * 4 + dl, sor, backward, st);
+    case 3: return sweep_flow_k<R, MAXK, 3>(a, stride * 3 + dl, sor, backward, st);
+    case 2: return sweep_flow_k<R, MAXK, 2>(a, stride * 2 + dl, sor, backward, st);
     default: return sweep_flow_k<R, MAXK, 1>(a, lds_max, sor, backward, st);
   }
 }

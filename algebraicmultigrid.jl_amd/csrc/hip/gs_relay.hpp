@@ -53,39 +53,6 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // control words of a block, behind its x in LDS (16 bytes, 16-byte aligned): one ds_read_b128 polls them all
 //   [0] progress: leading entries of the fetch list that have arrived (the fetcher)   [1] done: steps finished (the walkers)
 //   [2] bail: somebody gave up a poll — nobody waits any more                          [3] unused
-// a step's operands on the DICTIONARY layout (FlowDict): column chunks and b only — the values come out of the block's
-// dictionary in LDS, by the index that rides in the publish word
-template <typename R, int MAXK>
-struct FlowOpsD {
-  static constexpr int VPC = 16 / (int)sizeof(R), NVC = (MAXK + 2 + VPC - 1) / VPC, NCC = (MAXK + 7) / 8, KCH = NCC;
-  static constexpr int CTAIL = ((MAXK + 1) / 2 - 1) % 4 + 1;
-  static constexpr int NLOAD = NCC + 1;
-  u32x4 cf[NCC > 1 ? NCC - 1 : 1];
-  typename Dw<CTAIL + 1>::type ct;
-  typename Dw<(int)sizeof(R) / 4>::type bb;
-  int p; int need;
-  __device__ __forceinline__ u32x4 cchunk(int c) const { return c < NCC - 1 ? cf[c] : widen(ct); }
-  __device__ __forceinline__ int32_t pub() const { const u32x4 c = widen(ct); return (int32_t)(CTAIL == 1 ? c.y : CTAIL == 2 ? c.z : c.w); }
-};
-template <int N, typename R, int MAXK>
-__device__ __forceinline__ void flow_wait(FlowOpsD<R, MAXK>& o) {
-  asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory");
-#pragma unroll
-  for (int c = 0; c < FlowOpsD<R, MAXK>::NCC - 1; ++c) asm volatile("" : "+v"(o.cf[c]));
-  asm volatile("" : "+v"(o.ct));
-  asm volatile("" : "+v"(o.bb));
-}
-template <typename R> __device__ __forceinline__ R value_of(const u32x4* vv, int k) {   // value k of a row out of its value chunks
-  if constexpr (sizeof(R) == 8) {
-    const u32x4 c = vv[k >> 1];
-    return (k & 1) ? __hiloint2double((int)c.w, (int)c.z) : __hiloint2double((int)c.y, (int)c.x);
-  } else {
-    const u32x4 c = vv[k >> 2];
-    const unsigned w = (k & 3) == 0 ? c.x : (k & 3) == 1 ? c.y : (k & 3) == 2 ? c.z : c.w;
-    return __uint_as_float(w);
-  }
-}
-
 // One block of the sweep: ticket ut of the launch, mailbox tag `epoch`.  All waves of the workgroup enter; the fetcher wave
 // leaves when its list is done, the walkers behind their last step.
 template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT>
@@ -137,7 +104,7 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     if (lane == 0) { xl[d.nrows + d.next] = (R)0; ctl[0] = 0u; ctl[1] = 0u; ctl[2] = 0u; ctl[3] = 0u; }
     // (the fetcher's whole life is this branch — its own barrier, its own return: no path of the control-flow graph leads from the
     // walkers' hand-issued loads into it, which is what tools/flow_asm_linear.py can then verify)
-    __syncthreads();
+    fetcher_barrier();
     // ---- the fetcher: near-side values out of their mailboxes in the order the walk needs them (gs_flow.hpp, one column) ----
 #ifdef BW_RELAY_FETCH_PRIO
     __builtin_amdgcn_s_setprio(BW_RELAY_FETCH_PRIO);   // (measurement: the fetcher's few instructions ahead of the walkers' many on a shared SIMD)

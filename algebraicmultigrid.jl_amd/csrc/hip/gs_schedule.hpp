@@ -1096,7 +1096,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
     const bool inplace = gs_trim();
     // (every limit is checked before a record is touched: `false` leaves the plan as it was; an exception — memory — with the
     // records half rewritten leaves no block layout at all: the level schedules take the level)
-    try { fok = bw::flow_build<real>(P, prm.threads, &F, inplace, tl_flow_halo, g_gs_bw_dict != 0 && nrhs_hint <= 1 && !tl_flow_halo); }
+    try { fok = bw::flow_build<real>(P, prm.threads, &F, inplace, tl_flow_halo, g_gs_bw_dict != 0 && !tl_flow_halo); }
     catch (const std::exception&) {
       fok = false;
       if (inplace) { g->free_dev(); return AMGH_OK; }
@@ -1126,7 +1126,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
         fl.xon = true;
         fl.bytes += (int64_t)F.x.aux.size() * 4 + (int64_t)fl.h_xfl_mb.size() * 6 + (int64_t)F.x.list.size() * 4;
       }
-      if (F.dc.on) {   // (blocks of right-hand sides are swept by the multi-column kernels: srec)
+      if (F.dc.on) {   // the dictionary layout beside the plain records (a schedule serves one column and blocks of them)
         RC_TRY(dev_upload(&fl.crec, F.dc.crec.data(), (int64_t)F.dc.crec.size()));
         F.dc.dict.resize(F.dc.dict.size() + 16, 0);
         RC_TRY(dev_upload(&fl.dict, F.dc.dict.data(), (int64_t)F.dc.dict.size()));

@@ -57,7 +57,7 @@ def audit_kernel(name, lines):
     rb, maxk = (8 if m.group(2) == "d" else 4), int(m.group(3))
     vpc = 16 // rb
     L = (maxk + 2 + vpc - 1) // vpc + (maxk + 7) // 8 + 1
-    dic = relay and m.group(5) == "1"   # (gs_relay.hpp FlowOpsD: the values come out of the block's dictionary in LDS)
+    dic = m.group(5) == "1"   # (FlowOpsD: the values come out of the block's dictionary in LDS)
     if dic:
         L = (maxk + 7) // 8 + 1
     depth = int(os.environ.get("BW_FLOW_DEPTH", "4"))
@@ -68,6 +68,8 @@ def audit_kernel(name, lines):
             D = int(os.environ.get("BW_RELAY_DICT_DEPTH", "3"))
     else:
         D = (min(depth, 3) if nc > 1 else depth) if maxk <= 6 else (min(depth, 4) if maxk <= 12 else 3)
+        if dic:
+            D = int(os.environ.get("BW_FLOW_DICT_DEPTH", "3"))
     steady = (D - 1) * (L + 2)
     idx = [i for i, n in waits if n == steady]
     loads = [i for i, l in enumerate(code) if re.match(r"buffer_load_dword", l)]

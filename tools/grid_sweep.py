@@ -18,11 +18,12 @@ def cyc(reps=10):
     assert lib.amgh_dev_sync(0) == 0
     return 1e3 * (time.perf_counter() - t0) / reps
 z0 = None
-for name, vals in ((b"gs_bw_grid_long", (0, 256, 384, 448, 512, 576, 640, 0)), (b"gs_bw_grid", (0, 768, 896, 1024, 0))):
+DEF = {b"gs_bw_grid_long": 512, b"gs_bw_grid": 0, b"gs_bw_dict": 1}
+for name, vals in ((b"gs_bw_dict", (1, 0, 1)), (b"gs_bw_grid_long", (0, 256, 384, 512, 640, 768, 1024)), (b"gs_bw_grid", (0, 768, 1024, 1280, 1536))):
     for v in vals:
         lib.amgh_debug_set_tunable(name, v)
         t = cyc()
         z = zd.download()
         if z0 is None: z0 = z
         print(f"{name.decode()} = {v:5d}: {t:7.3f} ms per V-cycle, L0 / L1 presmooth {dev.bench_op(0, 4, 3, 1):.3f} / {dev.bench_op(1, 4, 3, 1):.3f} ms, bitwise the first {bool((z == z0).all())}", flush=True)
-    lib.amgh_debug_set_tunable(name, 0)
+    lib.amgh_debug_set_tunable(name, DEF[name])
