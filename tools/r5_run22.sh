@@ -1,3 +1,3 @@
 mkdir -p gpurun_out/r5
-(timeout 1500 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_ipc.py tests/test_gpu_dist.py tests/test_gpu_float32.py tests/test_gpu_fullsize.py -x -q -m gpu > gpurun_out/r5/pytest_dist.log 2>&1; echo rc=$? >> gpurun_out/r5/pytest_dist.log)
-tail -5 gpurun_out/r5/pytest_dist.log | cut -c1-300
+timeout 2400 python -m pytest tests/test_gpu_flow.py -x -q -m gpu 2>&1 | tail -8
+timeout 1200 python tools/bs_sweep.py 256 8 2>&1 | tee gpurun_out/r5/bs_sweep_il.log | tail -30
