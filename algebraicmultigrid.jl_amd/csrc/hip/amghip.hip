@@ -32,6 +32,7 @@ struct Level {
   amgh_csr Pp, Rp;
   bool lo_ok = false;
   real* lo_val = nullptr;  // S != A with the same pattern: values of A in the order of the schedule's level-ordered copy of S
+  CodedCols lo_cc;         // value-coded columns of the level-ordered A (the schedule's copy with lo_val or its own values)
   bool lo_want = false;    // between amgh_push_level_begin and _end: the level-ordered P / R are to be built
   // the COARSE side in the next level's dependency-level order too (set when the next level is pushed and runs the
   // level-ordered cycle): Rp's rows and Pp's columns are renumbered to it, the restricted residual is written straight
@@ -249,15 +250,15 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo
       ProfScope p(h, AMGH_T_RESIDUAL, l);  // r = b - A x, everything in level order (bp was gathered by the pre-smoother)
       // (A itself in level order: the schedule's copy, or — when the smoother sweeps S = A' — A's values on S's pattern)
       if (il_block(bs) && g_rhs_il >= 2)   // (2: the block residual reads the matrix once; measured)
-        RC_TRY(resid_cols(bs, g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, n, g->xp, xs, g->bp, n, L->res, n, h->stream));
+        RC_TRY(resid_cols(bs, g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, n, g->xp, xs, g->bp, n, L->res, n, h->stream, &L->lo_cc));
       else
         RC_TRY(raw_apply(M_RESID, g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, n, g->xp, xs, g->bp, n, L->res, n,
-                         h->stream, bs));
+                         h->stream, bs, &L->lo_cc));
     }
     {
       ProfScope p(h, AMGH_T_RESTRICT, l);
       if (L->il && il_block(bs))
-        RC_TRY(il_apply(bs, false, L->Rp.rowptr, L->Rp.col, L->Rp.val, nc, L->res, n, n, L->il, C ? cg->bp : L->cb, nc, h->stream));
+        RC_TRY(il_apply(bs, false, L->Rp.rowptr, L->Rp.col, L->Rp.val, nc, L->res, n, n, L->il, C ? cg->bp : L->cb, nc, h->stream, &L->Rp.cc));
       else
         RC_TRY(csr_apply(&L->Rp, M_SPMV, L->res, nullptr, C ? cg->bp : L->cb, h->stream, bs));
       if (C) cg->bp_cols = bs;          // the next level's level-ordered right-hand side is in place
@@ -273,10 +274,10 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo
       ProfScope p(h, AMGH_T_PROLONG, l);  // x += P e on the level-ordered x
       if (L->il && il_block(bs))
         RC_TRY(il_apply(bs, true, L->Pp.rowptr, L->Pp.col, L->Pp.val, n, C ? cg->xp : L->cx, nc, C ? cg->xstride : nc, L->il,
-                        g->xp, xs, h->stream));
+                        g->xp, xs, h->stream, &L->Pp.cc));
       else
         RC_TRY(raw_apply(M_ADD, L->Pp.rowptr, L->Pp.col, L->Pp.val, n, C ? cg->xp : L->cx, C ? cg->xstride : nc, nullptr, 0, g->xp,
-                         xs, h->stream, bs));
+                         xs, h->stream, bs, &L->Pp.cc));
     }
     {
       ProfScope p(h, AMGH_T_POSTSMOOTH, l);
@@ -567,6 +568,7 @@ void amgh_destroy(amgh_t* h) {
   for (Level* L : h->levels) {
     csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
     hipFree(L->res); hipFree(L->cx); hipFree(L->cb); hipFree(L->tmp); hipFree(L->lo_val); hipFree(L->il);
+    L->lo_cc.free_dev();
     delete L;
   }
   csr_free(&h->finalA);
@@ -584,6 +586,7 @@ void amgh_destroy(amgh_t* h) {
 static void level_discard(Level* L) {
   csr_free(&L->A); csr_free(&L->S); csr_free(&L->P); csr_free(&L->R); csr_free(&L->Pp); csr_free(&L->Rp);
   hipFree(L->lo_val);
+  L->lo_cc.free_dev();
   delete L;
 }
 
@@ -946,6 +949,16 @@ int amgh_finalize(amgh_t* h) {
       RC_TRY(csr_ensure_diag(L->smat(), h->stream));
     }
   }
+  // value-coded columns of the big operators the level-ordered cycle streams (its A, Rp, Pp: everything is in its final order
+  // by now), where they hold few distinct values
+  for (Level* L : h->levels) {
+    GsSchedule* g = L->smat()->gs;
+    if (!L->lo_ok || !g || g->nblk != 0 || !g->rowptr || g->compacted) continue;
+    RC_TRY(code_values(g->col, L->lo_val ? L->lo_val : g->val, L->n, g->ncols, g->nnz, &L->lo_cc, h->stream));
+    RC_TRY(code_values(L->Rp.col, L->Rp.val, L->Rp.nrows, L->Rp.ncols, L->Rp.nnz, &L->Rp.cc, h->stream));
+    RC_TRY(code_values(L->Pp.col, L->Pp.val, L->Pp.nrows, L->Pp.ncols, L->Pp.nnz, &L->Pp.cc, h->stream));
+    ws += L->lo_cc.bytes + L->Rp.cc.bytes + L->Pp.cc.bytes;
+  }
   // a level that receives its right-hand side in level order gets it written into its schedule's own vector by the
   // level above: sized for the block of right-hand sides before the first cycle
   for (size_t l = 0; l + 1 < h->levels.size(); ++l)
@@ -1034,6 +1047,12 @@ int amgh_debug_bw_dict(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
   const GsSchedule* g = h->levels[l]->smat()->gs;
   return g && g->bw.on && g->bw.flow.on && g->bw.flow.dict_on && g_gs_bw_dict && g_gs_bw_relay > 0 && (g_gs_bw_flow || !g->bw.rec) ? 1 : 0;
+}
+int amgh_debug_coded_ops(const amgh_t* h, int l) {
+  if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
+  const Level* L = h->levels[l];
+  if (!g_stream_code) return 0;
+  return (L->lo_cc.ccol ? 1 : 0) | (L->Rp.cc.ccol ? 2 : 0) | (L->Pp.cc.ccol ? 4 : 0);
 }
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
@@ -1748,6 +1767,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_bw_grid")) g_gs_bw_grid = value < 0 ? 0 : value;
   else if (!strcmp(name, "gs_bw_grid_long")) g_gs_bw_grid_long = value < 0 ? 0 : value;
   else if (!strcmp(name, "gs_bw_dict")) g_gs_bw_dict = value != 0;
+  else if (!strcmp(name, "stream_code")) g_stream_code = value != 0;
   else if (!strcmp(name, "gs_bw_relay")) g_gs_bw_relay = value == 0 ? 0 : BW_RELAY_W;   // (one count is instantiated)
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;
   else if (!strcmp(name, "jacobi_zero")) g_jacobi_zero = value;

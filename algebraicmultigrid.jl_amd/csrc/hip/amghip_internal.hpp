@@ -355,7 +355,16 @@ struct GsSchedule {
 
 #include "dev_scan.hpp"
 
+// Value-coded columns of an operator (StreamArgs::ccol): built once where the operator has at most 256 distinct values and
+// fewer than 2^24 columns (code_values, csr_ops.hpp); the SpMV-type launches of big operators then stream 4 bytes per entry.
+struct CodedCols {
+  uint32_t* ccol = nullptr; real* vtab = nullptr; int n = 0;
+  int64_t bytes = 0;
+  void free_dev() { hipFree(ccol); hipFree(vtab); ccol = nullptr; vtab = nullptr; n = 0; bytes = 0; }
+};
+
 struct amgh_csr {
+  CodedCols cc;
   int device = 0;
   int64_t nrows = 0, ncols = 0, nnz = 0;
   int32_t* rowptr = nullptr;
@@ -401,9 +410,10 @@ int g_gs_bw_rows = 512;         // ... rows per block aimed at
 int g_gs_bw_flow = 1;           // the wavefront of blocks as a dataflow (gs_flow.hpp) where the pattern is structurally symmetric: 1 = on, 0 = off (chained / launched sweeps); build: the layout is only built when on; read at every sweep too
 int g_gs_bw_spin = 0;           // polls before a wait of the dataflow / chained sweep gives up (0 = the default, ~seconds); test hook
 int g_gs_bw_skip_pub = -1;      // test hook: the block with this ticket publishes nothing in dataflow sweeps (a forced protocol error); -1 = none
-int g_gs_bw_nc = 2;             // columns of a block of right-hand sides one workgroup of the dataflow sweep carries (walker waves beside its one fetcher; 0 = as many as are instantiated: 4 for rows of <= 6 entries, else 3); 256^3, bs = 8, smoothers of the two block-ordered levels: 1: 16.3 + 10.0, 2: 12.0 + 10.1, 3: 12.0 + 10.4, 4: 13.0 + 10.4 ms; read at every sweep
+int g_gs_bw_nc = -1;            // columns of a block of right-hand sides one workgroup of the dataflow sweep carries (walker waves beside its one fetcher; -1 = 3 on the dictionary layout — records a quarter the size: the fetcher's shared polls count for more than a second record stream —, 2 on plain records: bs = 8 at 256^3 46.5 / 47.4 / 46.8 ms with 3 / 2 / 4 columns on the dictionary, 52.8 / 52.5 / 52.9 on plain records; 0 = as many as are instantiated: 4 for rows of <= 6 entries, else 3); 256^3, bs = 8, smoothers of the two block-ordered levels: 1: 16.3 + 10.0, 2: 12.0 + 10.1, 3: 12.0 + 10.4, 4: 13.0 + 10.4 ms; read at every sweep
 int g_gs_bw_nrhs = 1;           // hierarchies built for blocks of right-hand sides get the dataflow layout too (0 = single-column hierarchies only); read at schedule build
 int g_gs_bw_chain = 1;          // the wavefront of blocks as one launch per sweep, blocks chained by flags (0: one launch per depth of the quotient graph)
+int g_stream_code = 1;          // SpMV-type launches (residual, restriction, prolongation of the level-ordered cycle) of operators of >= 2^18 rows stream value-coded columns where the operator has <= 256 distinct values (CodedCols; bitwise the same sums); read at amgh_finalize (0: not built) and at every launch
 int g_gs_bw_dict = 1;           // the relayed single-column sweep reads the dictionary layout where a schedule carries one (bw::FlowDict: half the bytes of a 7-point level's sweep; bitwise the same); read at schedule build (0: not built) and at every sweep
 int g_gs_bw_relay = 3;          // walker waves a single-column dataflow sweep relays a block's walk between (gs_relay.hpp: the one instantiated count, BW_RELAY_W; 0: one walker, gs_bw_flow_kernel — bitwise the same); read at every sweep
 int g_gs_bw_grid = 0;           // workgroups of a relayed single-column sweep (fewer than blocks: the persistent form of gs_relay.hpp; 0: one per block); read at every sweep
@@ -464,6 +474,7 @@ void csr_free(amgh_csr* op) {
   if (!op) return;
   hipFree(op->rowptr); hipFree(op->col); hipFree(op->val);
   hipFree(op->dpos); hipFree(op->diag);
+  op->cc.free_dev();
   if (op->gs) { op->gs->free_dev(); delete op->gs; }
   op->rowptr = op->col = op->dpos = nullptr; op->val = op->diag = nullptr; op->gs = nullptr;
 }

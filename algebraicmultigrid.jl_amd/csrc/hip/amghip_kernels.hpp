@@ -57,7 +57,15 @@ struct StreamArgs {
   // the grid is (row tiles padded to a multiple of 8) x ncolv workgroups, see multi_column_block()
   int64_t ldx, ldy, ldb;
   int32_t ncolv;
+  // VALUE-CODED columns (CodedCols): entry k as one word, column | code << 24, the code an index into vtab (the operator's
+  // distinct values, at most 256 of them: a constant-coefficient stencil has two, its first Galerkin product eight, their
+  // interpolation weights a few dozen) — 4 bytes per entry instead of 12; the products and their order are the same
+  const uint32_t* ccol;
+  const real* vtab;
+  int32_t vtab_n;
 };
+constexpr int kCodeBits = 24, kCodeMax = 256;
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
 // LDS index skew: breaks the power-of-two strides of rows with 8/16/32 entries
 // (ds_read_b64 banks = (addr/4) mod 64; one pad slot per 32 keeps a 32-lane
@@ -168,10 +176,16 @@ __device__ __forceinline__ real seq_sum(const real* s_prod, int lo, int hi, int 
 // products val*x[col] are staged in LDS; each thread then sums its own rows'
 // segments sequentially in index order.  Row ranges with more products than fit
 // in LDS are processed in several passes (any row length is handled).
-template <int MODE, class CFG>
+template <int MODE, class CFG, bool CODED = false>
 __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) {
   constexpr int T = CFG::THREADS, RPT = CFG::RPT, LDSN = CFG::LDS_NNZ, VEC = CFG::VEC;
   constexpr bool NT = CFG::NT;
+  static_assert(!CODED || (VEC == 4 && T >= kCodeMax), "the value-coded variant is the big-operator configuration's");
+  __shared__ real s_tab[CODED ? kCodeMax : 1];
+  if (CODED) {
+    if ((int)threadIdx.x < a.vtab_n) s_tab[threadIdx.x] = a.vtab[threadIdx.x];
+    __syncthreads();
+  }
   // few rows per workgroup (latency-bound GS launches): plain LDS indices + the pipelined in-order
   // sum; many rows per workgroup (SpMV): skewed indices keep the row-strided reads conflict-free
   constexpr bool SK = CFG::ROWS > 64;
@@ -234,6 +248,12 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
             const d2_t vv = ld_stream<NT>((const d2_t*)(a.val + k));
             const i2_t cc = ld_stream<NT>((const i2_t*)(a.col + k));
             v[0] = vv.x; v[1] = vv.y; c[0] = cc.x; c[1] = cc.y;
+          } else if (CODED) {
+            const u4_t cc = ld_stream<NT>((const u4_t*)(a.ccol + k));
+            c[0] = (int)(cc.x & ((1u << kCodeBits) - 1)); c[1] = (int)(cc.y & ((1u << kCodeBits) - 1));
+            c[VEC - 2] = (int)(cc.z & ((1u << kCodeBits) - 1)); c[VEC - 1] = (int)(cc.w & ((1u << kCodeBits) - 1));
+            v[0] = s_tab[cc.x >> kCodeBits]; v[1] = s_tab[cc.y >> kCodeBits];
+            v[VEC - 2] = s_tab[cc.z >> kCodeBits]; v[VEC - 1] = s_tab[cc.w >> kCodeBits];
           } else {
             const d2_t v0 = ld_stream<NT>((const d2_t*)(a.val + k));
             const d2_t v1 = ld_stream<NT>((const d2_t*)(a.val + k + 2));
@@ -250,6 +270,9 @@ __global__ __launch_bounds__(CFG::THREADS) void csr_stream_kernel(StreamArgs a) 
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const int kk = k + e;
+            if (CODED) {
+              if (kk >= c0 && kk < c1) { const unsigned w = a.ccol[kk]; s_prod[lidx<SK>(kk - c0)] = s_tab[w >> kCodeBits] * a.x[w & ((1u << kCodeBits) - 1)]; }
+            } else
             if (kk >= c0 && kk < c1) s_prod[lidx<SK>(kk - c0)] = a.val[kk] * a.x[a.col[kk]];
           }
         }
@@ -833,10 +856,16 @@ __global__ __launch_bounds__(256) void to_interleaved_kernel(const real* __restr
   }
 }
 // y[:, q] = M xil[:, q] (ADD = false) or y[:, q] += M xil[:, q]: xil interleaved (ncols x BS), y column-major (ldy apart)
-template <bool ADD, int BS>
+// (CODED: value-coded columns, StreamArgs::ccol — col holds the words, val the table of vtab_n distinct values)
+template <bool ADD, int BS, bool CODED = false>
 __global__ __launch_bounds__(256) void csr_il_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                      const real* __restrict__ val, int64_t nrows, const real* __restrict__ xil,
-                                                     real* __restrict__ y, int64_t ldy) {
+                                                     real* __restrict__ y, int64_t ldy, int vtab_n = 0) {
+  __shared__ real s_tab[CODED ? kCodeMax : 1];
+  if (CODED) {
+    if ((int)threadIdx.x < vtab_n) s_tab[threadIdx.x] = val[threadIdx.x];
+    __syncthreads();
+  }
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = t / BS;
   const int q = (int)(t % BS);
@@ -847,13 +876,19 @@ __global__ __launch_bounds__(256) void csr_il_kernel(const int32_t* __restrict__
   for (; j + 4 <= j1; j += 4) {   // four entries' loads in flight, adds in index order
     int32_t c[4]; real v[4], xv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { c[e] = col[j + e]; v[e] = val[j + e]; }
+    for (int e = 0; e < 4; ++e) {
+      if (CODED) { const unsigned w = (unsigned)col[j + e]; c[e] = (int32_t)(w & ((1u << kCodeBits) - 1)); v[e] = s_tab[w >> kCodeBits]; }
+      else { c[e] = col[j + e]; v[e] = val[j + e]; }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) xv[e] = xil[(int64_t)c[e] * BS + q];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc += v[e] * xv[e];
   }
-  for (; j < j1; ++j) acc += val[j] * xil[(int64_t)col[j] * BS + q];
+  for (; j < j1; ++j) {
+    if (CODED) { const unsigned w = (unsigned)col[j]; acc += s_tab[w >> kCodeBits] * xil[(int64_t)(w & ((1u << kCodeBits) - 1)) * BS + q]; }
+    else acc += val[j] * xil[(int64_t)col[j] * BS + q];
+  }
   real* yp = y + row + (int64_t)q * ldy;
   *yp = ADD ? *yp + acc : acc;
 }
@@ -862,11 +897,16 @@ __global__ __launch_bounds__(256) void csr_il_kernel(const int32_t* __restrict__
 // kernel re-reads the matrix tile per column, from L2 at best); lane q gathers column q — neighbouring rows of a wave
 // gather neighbouring x, sector sharing is per column as in the single-column kernel.  In-order sums: bitwise the
 // stream kernel's residual.
-template <int BS>
+template <int BS, bool CODED = false>
 __global__ __launch_bounds__(256) void csr_resid_cols_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                              const real* __restrict__ val, int64_t nrows,
                                                              const real* __restrict__ x, int64_t ldx, const real* __restrict__ b,
-                                                             int64_t ldb, real* __restrict__ y, int64_t ldy) {
+                                                             int64_t ldb, real* __restrict__ y, int64_t ldy, int vtab_n = 0) {
+  __shared__ real s_tab[CODED ? kCodeMax : 1];
+  if (CODED) {
+    if ((int)threadIdx.x < vtab_n) s_tab[threadIdx.x] = val[threadIdx.x];
+    __syncthreads();
+  }
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = t / BS;
   const int q = (int)(t % BS);
@@ -878,13 +918,19 @@ __global__ __launch_bounds__(256) void csr_resid_cols_kernel(const int32_t* __re
   for (; j + 4 <= j1; j += 4) {
     int32_t c[4]; real v[4], xv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { c[e] = col[j + e]; v[e] = val[j + e]; }
+    for (int e = 0; e < 4; ++e) {
+      if (CODED) { const unsigned w = (unsigned)col[j + e]; c[e] = (int32_t)(w & ((1u << kCodeBits) - 1)); v[e] = s_tab[w >> kCodeBits]; }
+      else { c[e] = col[j + e]; v[e] = val[j + e]; }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) xv[e] = xq[c[e]];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc += v[e] * xv[e];
   }
-  for (; j < j1; ++j) acc += val[j] * xq[col[j]];
+  for (; j < j1; ++j) {
+    if (CODED) { const unsigned w = (unsigned)col[j]; acc += s_tab[w >> kCodeBits] * xq[w & ((1u << kCodeBits) - 1)]; }
+    else acc += val[j] * xq[col[j]];
+  }
   y[row + (int64_t)q * ldy] = b[row + (int64_t)q * ldb] - acc;
 }
 

@@ -6,7 +6,7 @@
 namespace {
 
 
-template <int MODE, class CFG = DefaultCfg>
+template <int MODE, class CFG = DefaultCfg, bool CODED = false>
 int launch_stream(const StreamArgs& a0, hipStream_t st, int ncolv = 1) {
   const int nrows = a0.row_end - a0.row_begin;
   if (nrows <= 0) return AMGH_OK;
@@ -15,7 +15,7 @@ int launch_stream(const StreamArgs& a0, hipStream_t st, int ncolv = 1) {
   const int nb = (nrows + CFG::ROWS - 1) / CFG::ROWS;
   // multi-column launches: tiles padded to a multiple of 8, times ncolv (multi_column_block)
   const int64_t grid = (CFG::XCD || ncolv > 1) ? (int64_t)((nb + kNumXcd - 1) / kNumXcd) * kNumXcd * ncolv : nb;
-  hipLaunchKernelGGL((csr_stream_kernel<MODE, CFG>), dim3((unsigned)grid), dim3(CFG::THREADS), 0, st, a);
+  hipLaunchKernelGGL((csr_stream_kernel<MODE, CFG, CODED>), dim3((unsigned)grid), dim3(CFG::THREADS), 0, st, a);
   HIP_TRY(hipGetLastError());
   return AMGH_OK;
 }
@@ -62,7 +62,92 @@ using SmallCfg = StreamCfg<256, 64, 4096, 2, false, false>;
 template <int MODE>
 int launch_stream_sized(const StreamArgs& a, hipStream_t st, int ncolv) {
   if (a.row_end - a.row_begin < (1 << 18)) return launch_stream<MODE, SmallCfg>(a, st, ncolv);
+  if (a.ccol && g_stream_code) return launch_stream<MODE, DefaultCfg, true>(a, st, ncolv);   // value-coded columns: 4 bytes per entry
   return launch_stream<MODE>(a, st, ncolv);
+}
+
+// ---- value-coded columns (CodedCols) ----------------------------------------------------------------------------------
+typedef std::conditional<sizeof(real) == 8, unsigned long long, unsigned int>::type rbits_t;
+__device__ __forceinline__ rbits_t real_bits(real v) { rbits_t b; __builtin_memcpy(&b, &v, sizeof(real)); return b; }
+constexpr int kCodeMiss = 4096;
+// position of v in the sorted table (by bit pattern), or -1
+__device__ __forceinline__ int code_find(const rbits_t* tab, int ntab, rbits_t v) {
+  int lo = 0, hi = ntab;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (tab[mid] < v) lo = mid + 1; else hi = mid; }
+  return (lo < ntab && tab[lo] == v) ? lo : -1;
+}
+// values of val[0, nnz) that are not in the table: counted, the first kCodeMiss of them recorded
+__global__ void code_probe_kernel(const real* val, int64_t nnz, const real* tab, int ntab, unsigned* miss_cnt, real* miss) {
+  __shared__ rbits_t s_tab[kCodeMax];
+  if ((int)threadIdx.x < ntab) s_tab[threadIdx.x] = real_bits(tab[threadIdx.x]);
+  __syncthreads();
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+    const real v = val[k];
+    if (code_find(s_tab, ntab, real_bits(v)) >= 0) continue;
+    // (a table that is far from complete: the list fills within the first few thousand entries and the rest only look)
+    if (__hip_atomic_load(miss_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)kCodeMiss) continue;
+    const unsigned i = atomicAdd(miss_cnt, 1u);
+    if (i < (unsigned)kCodeMiss) miss[i] = v;
+  }
+}
+__global__ void code_encode_kernel(const int32_t* col, const real* val, int64_t nnz, const real* tab, int ntab, uint32_t* ccol) {
+  __shared__ rbits_t s_tab[kCodeMax];
+  if ((int)threadIdx.x < ntab) s_tab[threadIdx.x] = real_bits(tab[threadIdx.x]);
+  __syncthreads();
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x)
+    ccol[k] = (uint32_t)col[k] | ((uint32_t)code_find(s_tab, ntab, real_bits(val[k])) << kCodeBits);
+}
+// out: the coded columns of (col, val), or left empty where the operator does not qualify (more than 256 distinct values —
+// by bit pattern —, 2^24 columns or more, nothing to gain below 2^18 rows).  A few passes over val on the device.
+int code_values(const int32_t* col, const real* val, int64_t nrows, int64_t ncols, int64_t nnz, CodedCols* out, hipStream_t st) {
+  if (!g_stream_code || out->ccol || nrows < (1 << 18) || ncols > ((int64_t)1 << kCodeBits) || nnz <= 0 || !col || !val) return AMGH_OK;
+  unsigned* d_cnt = nullptr; real *d_miss = nullptr, *d_tab = nullptr;
+  RC_TRY(dev_alloc(&d_cnt, 1));
+  int rc = dev_alloc(&d_miss, kCodeMiss);
+  if (rc == AMGH_OK) rc = dev_alloc(&d_tab, kCodeMax);
+  std::vector<rbits_t> tab;
+  std::vector<real> miss((size_t)kCodeMiss);
+  bool ok = rc == AMGH_OK;
+  // (the first pass looks at a sample: with an empty table every entry is a miss)
+  for (int pass = 0; ok && pass < 8; ++pass) {
+    const int64_t span = pass == 0 ? std::min<int64_t>(nnz, 1 << 20) : nnz;
+    const int ntab = (int)tab.size();
+    if (hipMemsetAsync(d_cnt, 0, 4, st) != hipSuccess) { rc = -1001; break; }
+    if (ntab > 0) {
+      std::vector<real> tv((size_t)ntab);
+      for (int i = 0; i < ntab; ++i) std::memcpy(&tv[(size_t)i], &tab[(size_t)i], sizeof(real));
+      if (hipMemcpyAsync(d_tab, tv.data(), sizeof(real) * (size_t)ntab, hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1001; break; }
+      if (hipStreamSynchronize(st) != hipSuccess) { rc = -1001; break; }   // (tv goes out of scope)
+    }
+    hipLaunchKernelGGL(code_probe_kernel, dim3((unsigned)std::min<int64_t>((span + 255) / 256, 8192)), dim3(256), 0, st, val, span, (const real*)d_tab, ntab, d_cnt, d_miss);
+    unsigned cnt = 0;
+    if (hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = -1001; break; }
+    if (cnt == 0) { if (pass > 0) break; else continue; }
+    const unsigned got = std::min<unsigned>(cnt, (unsigned)kCodeMiss);
+    if (hipMemcpy(miss.data(), d_miss, sizeof(real) * got, hipMemcpyDeviceToHost) != hipSuccess) { rc = -1001; break; }
+    for (unsigned i = 0; i < got; ++i) { rbits_t b; std::memcpy(&b, &miss[i], sizeof(real)); tab.push_back(b); }
+    std::sort(tab.begin(), tab.end());
+    tab.erase(std::unique(tab.begin(), tab.end()), tab.end());
+    if ((int)tab.size() > kCodeMax) ok = false;
+    if (pass == 7) ok = false;   // (still missing after eight passes: not an operator of few values)
+  }
+  if (rc == AMGH_OK && ok && !tab.empty()) {
+    std::vector<real> tv(tab.size());
+    for (size_t i = 0; i < tab.size(); ++i) std::memcpy(&tv[i], &tab[i], sizeof(real));
+    rc = dev_alloc(&out->ccol, nnz + 4);   // (the kernel's 16-byte loads may start up to 3 entries before / end 3 behind a range)
+    if (rc == AMGH_OK) rc = dev_alloc(&out->vtab, kCodeMax);
+    if (rc == AMGH_OK && hipMemcpyAsync(d_tab, tv.data(), sizeof(real) * tv.size(), hipMemcpyHostToDevice, st) != hipSuccess) rc = -1001;
+    if (rc == AMGH_OK && hipMemcpyAsync(out->vtab, tv.data(), sizeof(real) * tv.size(), hipMemcpyHostToDevice, st) != hipSuccess) rc = -1001;
+    if (rc == AMGH_OK) {
+      hipLaunchKernelGGL(code_encode_kernel, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 8192)), dim3(256), 0, st, col, val, nnz, (const real*)d_tab, (int)tab.size(), out->ccol);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = -1001;
+    }
+    if (rc == AMGH_OK) { out->n = (int)tab.size(); out->bytes = nnz * 4 + kCodeMax * kRealB; }
+    else out->free_dev();
+  }
+  hipFree(d_cnt); hipFree(d_miss); hipFree(d_tab);
+  if (rc == AMGH_ENOMEM) { (void)hipGetLastError(); out->free_dev(); return AMGH_OK; }   // (out of memory: the plain columns stay)
+  return rc;
 }
 
 // ncolv right-hand-side columns (x: ncols apart, y and b: nrows apart) in one launch
@@ -70,6 +155,7 @@ int csr_apply(const amgh_csr* op, int mode, const real* x, const real* b, real* 
               int ncolv = 1) {
   StreamArgs a{};
   a.rowptr = op->rowptr; a.col = op->col; a.val = op->val;
+  a.ccol = op->cc.ccol; a.vtab = op->cc.vtab; a.vtab_n = op->cc.n;
   a.x = x; a.y = y; a.b = b;
   a.row_begin = 0; a.row_end = (int32_t)op->nrows;
   a.ldx = op->ncols; a.ldy = op->nrows; a.ldb = op->nrows;
@@ -180,9 +266,10 @@ int launch_chain(const ChainArgs& c, bool sor, bool ldsx, int threads, int nx, h
 
 // SpMV-type launch on raw CSR arrays with explicit column strides (operators and vectors in level order)
 int raw_apply(int mode, const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x,
-              int64_t ldx, const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st, int ncolv) {
+              int64_t ldx, const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st, int ncolv, const CodedCols* cc = nullptr) {
   StreamArgs a{};
   a.rowptr = rowptr; a.col = col; a.val = val;
+  if (cc) { a.ccol = cc->ccol; a.vtab = cc->vtab; a.vtab_n = cc->n; }
   a.x = x; a.y = y; a.b = b;
   a.row_begin = 0; a.row_end = (int32_t)nrows;
   a.ldx = ldx; a.ldy = ldy; a.ldb = ldb;
@@ -198,12 +285,16 @@ int raw_apply(int mode, const int32_t* rowptr, const int32_t* col, const real* v
 // x: nx rows, ldx apart, column-major; il: scratch of nx * bs reals.  Returns AMGH_EUNSUPPORTED for other block sizes.
 template <int BS>
 int il_apply_t(bool add, const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x, int64_t nx,
-               int64_t ldx, real* il, real* y, int64_t ldy, hipStream_t st) {
+               int64_t ldx, real* il, real* y, int64_t ldy, hipStream_t st, const CodedCols* cc) {
   if (nx > 0)
     hipLaunchKernelGGL((to_interleaved_kernel<BS>), dim3((unsigned)((nx + 63) / 64)), dim3(256), 0, st, x, ldx, il, nx);
   const int64_t threads = nrows * BS;
   if (threads > 0) {
     const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (cc && cc->ccol && g_stream_code) {   // value-coded columns: the words in place of the columns, the table in place of the values
+      if (add) hipLaunchKernelGGL((csr_il_kernel<true, BS, true>), dim3(grid), dim3(256), 0, st, rowptr, (const int32_t*)cc->ccol, (const real*)cc->vtab, nrows, (const real*)il, y, ldy, cc->n);
+      else hipLaunchKernelGGL((csr_il_kernel<false, BS, true>), dim3(grid), dim3(256), 0, st, rowptr, (const int32_t*)cc->ccol, (const real*)cc->vtab, nrows, (const real*)il, y, ldy, cc->n);
+    } else
     if (add) hipLaunchKernelGGL((csr_il_kernel<true, BS>), dim3(grid), dim3(256), 0, st, rowptr, col, val, nrows, (const real*)il, y, ldy);
     else hipLaunchKernelGGL((csr_il_kernel<false, BS>), dim3(grid), dim3(256), 0, st, rowptr, col, val, nrows, (const real*)il, y, ldy);
   }
@@ -211,12 +302,12 @@ int il_apply_t(bool add, const int32_t* rowptr, const int32_t* col, const real* 
   return AMGH_OK;
 }
 int il_apply(int bs, bool add, const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x,
-             int64_t nx, int64_t ldx, real* il, real* y, int64_t ldy, hipStream_t st) {
+             int64_t nx, int64_t ldx, real* il, real* y, int64_t ldy, hipStream_t st, const CodedCols* cc = nullptr) {
   switch (bs) {
-    case 2: return il_apply_t<2>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st);
-    case 4: return il_apply_t<4>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st);
-    case 8: return il_apply_t<8>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st);
-    case 16: return il_apply_t<16>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st);
+    case 2: return il_apply_t<2>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st, cc);
+    case 4: return il_apply_t<4>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st, cc);
+    case 8: return il_apply_t<8>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st, cc);
+    case 16: return il_apply_t<16>(add, rowptr, col, val, nrows, x, nx, ldx, il, y, ldy, st, cc);
   }
   return AMGH_EUNSUPPORTED;
 }
@@ -224,8 +315,12 @@ inline bool il_block(int bs) { return g_rhs_il && (bs == 2 || bs == 4 || bs == 8
 // r = b - A x for a block of bs in {2, 4, 8, 16} right-hand sides, the matrix read once (csr_resid_cols_kernel)
 template <int BS>
 int resid_cols_t(const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x, int64_t ldx,
-                 const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st) {
+                 const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st, const CodedCols* cc) {
   const int64_t threads = nrows * BS;
+  if (threads > 0 && cc && cc->ccol && g_stream_code)
+    hipLaunchKernelGGL((csr_resid_cols_kernel<BS, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, rowptr, (const int32_t*)cc->ccol,
+                       (const real*)cc->vtab, nrows, x, ldx, b, ldb, y, ldy, cc->n);
+  else
   if (threads > 0)
     hipLaunchKernelGGL((csr_resid_cols_kernel<BS>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, rowptr, col, val, nrows,
                        x, ldx, b, ldb, y, ldy);
@@ -233,12 +328,12 @@ int resid_cols_t(const int32_t* rowptr, const int32_t* col, const real* val, int
   return AMGH_OK;
 }
 int resid_cols(int bs, const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x, int64_t ldx,
-               const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st) {
+               const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st, const CodedCols* cc = nullptr) {
   switch (bs) {
-    case 2: return resid_cols_t<2>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st);
-    case 4: return resid_cols_t<4>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st);
-    case 8: return resid_cols_t<8>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st);
-    case 16: return resid_cols_t<16>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st);
+    case 2: return resid_cols_t<2>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st, cc);
+    case 4: return resid_cols_t<4>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st, cc);
+    case 8: return resid_cols_t<8>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st, cc);
+    case 16: return resid_cols_t<16>(rowptr, col, val, nrows, x, ldx, b, ldb, y, ldy, st, cc);
   }
   return AMGH_EUNSUPPORTED;
 }
@@ -547,7 +642,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
           fa.crec = g->bw.flow.crec; fa.dict = g->bw.flow.dict; fa.dict_ent = g->bw.flow.dict_ent;
           fa.dict_lds = (int32_t)(g->bw.flow.dict_lds - g->bw.flow.lds_max);
         }
-        e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc);
+        e = bw::sweep_flow<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, ncolv, g_gs_bw_nc >= 0 ? g_gs_bw_nc : (fa.crec ? 3 : 2));
       }
     } else {
       bw::Args<real> ba{g->bw.blocks, g->bw.rec, g->bw.ext_col, rhs, xp, ldb, xs, omega, 0, nullptr};

@@ -513,6 +513,12 @@ int amgh_debug_bw_mode(const amgh_t* h, int l);
 /* ... and whether the single-column dataflow sweep of level l reads the DICTIONARY layout (column records + every block's
  * distinct value rows, held in LDS; tunable "gs_bw_dict"): 1 / 0, -1: no such level.                                */
 int amgh_debug_bw_dict(const amgh_t* h, int l);
+/* Diagnostics: which operators of level l the level-ordered cycle streams as VALUE-CODED columns (one 32-bit word per
+ * entry: column | code << 24, the code an index into the operator's table of distinct values — built at amgh_finalize for
+ * operators of >= 2^18 rows, fewer than 2^24 columns and at most 256 distinct values; the sums are the plain kernel's, bit
+ * for bit; tunable "stream_code"): bit 0 = A (residual, multilevel.jl:219-220), bit 1 = R (restriction, :221), bit 2 = P
+ * (prolongation, :233-234).  -1: no such level.                                                                       */
+int amgh_debug_coded_ops(const amgh_t* h, int l);
 
 /* Diagnostics: tunables of the Gauss-Seidel execution (process-wide; used by tools/ to pick the defaults and by
  * tests to force every path).  Read at every sweep: "gs_xcd_map", "gs_block_pipe", "gs_flip", "gs_keep_lo",
@@ -530,11 +536,13 @@ int amgh_debug_bw_dict(const amgh_t* h, int l);
  * levels), "gs_bw_flow" (1: the dataflow layout of the wavefront is built where the pattern is structurally symmetric);
  * read at every sweep: "gs_bw_flow" (0: the chained / launched execution where its layout was kept), "gs_bw_chain" (1: the
  * wavefront of blocks as ONE launch per sweep, blocks chained by flags; 0: one launch per depth of the quotient graph —
- * bitwise the same sweep), "gs_bw_nc" (columns of a block of right-hand sides one workgroup of the dataflow sweep carries: 2;
+ * bitwise the same sweep), "gs_bw_nc" (columns of a block of right-hand sides one workgroup of the dataflow sweep carries: -1 = 3 on the dictionary layout, 2 on plain records;
  * 0 = as many as are instantiated), "gs_bw_spin" / "gs_bw_skip_pub" (test hooks: bound of a poll, a block that publishes
  * nothing), "gs_flow_xzero" (1: a dataflow sweep that starts a smooth! call on x = 0 reads no x — bitwise the same),
- * "gs_bw_dict" (1: single-column schedules carry the dictionary layout where every block has at most 256 distinct value
- * rows, and the relayed sweep reads it — bitwise the same; read at build and at every sweep),
+ * "gs_bw_dict" (1: dataflow schedules carry the dictionary layout where the rows' values repeat — at most 256 distinct
+ * value rows per block, a quarter of the rows overall — and the relayed and the multi-column sweeps read it, bitwise the
+ * same; read at build and at every sweep),
+ * "stream_code" (1: value-coded columns, see amgh_debug_coded_ops; read at amgh_finalize and at every launch),
  * "gs_dup_launch" (measurement hook: every merged-group launch issued 1 + that many times).
  * Returns AMGH_EINVAL for an unknown name.                                                                       */
 int amgh_debug_set_tunable(const char* name, int value);

@@ -275,6 +275,6 @@ def test_setup_entry_points_reject_bad_arguments():
     assert lib.amgh_setup_fit_candidates_vector(dA.h, None, 1e-10, C.byref(out), bc.ctypes.data) == -2
     assert lib.amgh_setup_fit_candidates_vector(dA.h, b.ctypes.data, 1e-10, None, bc.ctypes.data) == -2
     assert lib.amgh_setup_fit_candidates_vector(None, b.ctypes.data, 1e-10, C.byref(out), bc.ctypes.data) == -2
-    assert lib.amgh_debug_set_tunable(b"gs_bw_nc", 2) == 0 and lib.amgh_debug_set_tunable(b"no_such_tunable", 1) == -2
+    assert lib.amgh_debug_set_tunable(b"gs_bw_nc", -1) == 0 and lib.amgh_debug_set_tunable(b"no_such_tunable", 1) == -2
     h = C.c_void_p()
     assert lib.amgh_create(C.byref(h), 0, 65) != 0 and lib.amgh_create(C.byref(h), 0, 0) != 0      # 1 <= nrhs <= 64

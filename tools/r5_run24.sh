@@ -1,19 +1,5 @@
 mkdir -p gpurun_out/r5
-cat > /tmp/dump1.py <<'PY'
-import os, sys
-sys.path.insert(0, os.getcwd())
-import numpy as np
-import amg_amd as AMG
-ml = AMG.ruge_stuben(AMG.poisson((256, 256, 256)), setup="gpu")
-M = ml.levels[1].A
-with open("/tmp/bw_L1.bin", "wb") as f:
-    np.array([M.m, M.nnz], dtype=np.int64).tofile(f)
-    np.asarray(M.colptr, dtype=np.int32).tofile(f); np.asarray(M.rowval, dtype=np.int32).tofile(f); np.asarray(M.nzval, dtype=np.float64).tofile(f)
-PY
-python /tmp/dump1.py
-for v in "" _fake; do
-  (BW_RELAY_ONLY=3 timeout 300 tools/block_wave_bench$v poisson 256 > gpurun_out/r5/fake${v}_L0.log 2>&1)
-  (BW_RELAY_ONLY=3 timeout 300 tools/block_wave_bench$v file /tmp/bw_L1.bin 512 > gpurun_out/r5/fake${v}_L1.log 2>&1)
-  (BW_RELAY_ONLY=3 BW_RELAY_GRID=512 timeout 300 tools/block_wave_bench$v file /tmp/bw_L1.bin 512 > gpurun_out/r5/fake${v}_g512_L1.log 2>&1)
-  echo "== variant '$v'"; grep -E "^relay W = 3 (forward|backward)" gpurun_out/r5/fake${v}_L0.log gpurun_out/r5/fake${v}_L1.log gpurun_out/r5/fake${v}_g512_L1.log | grep -v stamps | cut -c1-140
-done
+timeout 1500 python -m pytest tests/test_gpu_coded.py tests/test_gpu_parity.py tests/test_gpu_float32.py -x -q -m gpu 2>&1 | tail -5
+timeout 600 python bench.py --steps 20 --warmup 3 > gpurun_out/r5/bench_code2.json 2> gpurun_out/r5/bench_code2.err; tail -3 gpurun_out/r5/bench_code2.err
+python -c "
+import json; d=json.load(open('gpurun_out/r5/bench_code2.json')); print(d['ms_per_step'], d['setup_s'], d['parity'], d['block_of_right_hand_sides']['ms_per_cycle'], d['block_of_right_hand_sides']['first_column_rel_diff_vs_single_column_cycle'], d['hbm_bytes'])"
