@@ -1021,6 +1021,14 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   // (the cost-model branch below insists on three offset classes, or two on operators of >= gs_bw_two_min_rows rows)
   prm.require_three = g_gs_bw != 2 && !(g_gs_bw_two_min_rows > 0 && n >= g_gs_bw_two_min_rows);
   prm.require_two = g_gs_bw != 2;
+  // the sweep as a dataflow (gs_flow.hpp) where the data dependencies carry the anti-dependencies: structurally symmetric
+  // patterns (halo columns of a row-sharded operator: never written, read as they stand).  Blocks of right-hand sides only
+  // have that execution (the chained kernel is a single-column one): other patterns keep the level schedules
+  const bool flow_ok = g_gs_bw_flow && bw::structurally_symmetric(n, rowptr, col, prm.threads);
+  if (nrhs_hint > 1 && !flow_ok) return AMGH_OK;
+  // (the default footprint keeps the dataflow layout only: a block's LDS then holds its x, never its record, and the record's
+  // bytes do not bound the rows of a block)
+  prm.flow_only = flow_ok && gs_trim();
   bw::Plan P;
   try {   // (gigabytes of host memory: out of it, the level keeps the level schedules — nothing crosses the C ABI)
     if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_OK;
@@ -1029,11 +1037,6 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
     return AMGH_OK;
   }
   tm.lap("block partition + records", n);
-  // the sweep as a dataflow (gs_flow.hpp) where the data dependencies carry the anti-dependencies: structurally symmetric
-  // patterns (halo columns of a row-sharded operator: never written, read as they stand).  Blocks of right-hand sides only
-  // have that execution (the chained kernel is a single-column one): other patterns keep the level schedules
-  const bool flow_ok = g_gs_bw_flow && bw::structurally_symmetric(n, rowptr, col, prm.threads);
-  if (nrhs_hint > 1 && !flow_ok) return AMGH_OK;
   const int64_t nnz = rowptr[n];
   const int nlaunch = (int)P.launch_ptr.size() - 1;
   if (g_gs_bw == 2 && getenv("AMGH_VERBOSE")) {
@@ -1101,6 +1104,8 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
       fok = false;
       if (inplace) { g->free_dev(); return AMGH_OK; }
     }
+    // (a plan made for the dataflow kernel alone has blocks whose records need not fit LDS: without that layout, the level schedules)
+    if (!fok && prm.flow_only) { g->free_dev(); return AMGH_OK; }
     if (fok) {
       tm.lap("dataflow layout", n);
       GsSchedule::Bw::FlowDev& fl = g->bw.flow;

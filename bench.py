@@ -256,9 +256,12 @@ def main():
             tri += 2 * st["tri_entries"]
             if mode > 0:
                 # a block level streams its packed records: per row 16-byte chunks [values, diagonal, reciprocal | uint16
-                # columns, publish word] (csrc/hip/gs_blocks.hpp Packed::chunks), not 12 bytes per entry
+                # columns, publish word] (csrc/hip/gs_blocks.hpp Packed::chunks), not 12 bytes per entry — on the dictionary
+                # layout (gs_flow.hpp FlowDict: the value chunks once per block, in LDS) the column chunks only
                 maxk = st["slot_entries"] // max(1, st["rows"])
                 chunks = ((maxk + 2 + 1) // 2 + (maxk + 7) // 8) | 1
+                if int(lib.amgh_debug_bw_dict(dev.h, l)) == 1:
+                    chunks = (maxk + 7) // 8
                 streamed_bytes += 2 * st["rows"] * (16 * chunks + 24)
             else:
                 streamed_bytes += 2 * (12 * (max(st["slot_entries"], st["entries"]) + st["tri_entries"]) + 24 * st["rows"])
@@ -311,12 +314,17 @@ def main():
         # second roofline entry: the kernels that dominate the CYCLE (Gauss-Seidel sweeps: gs_slot / gs_bigslot /
         # chain / block launches + pre-pass), latency-bound — one launch per merged group of dependency levels
         "sweep_roofline": {
-            "bound": "hbm", "kernel": "gs_bw_flow_kernel (levels %s: wavefront of blocks as a dataflow, one launch per sweep) + gs_slot_kernel / gs_bigslot_kernel "
-                                      "(merged dependency-level groups), all levels, pre + post smoother, both directions" % [l for l, m in enumerate(bw_modes) if m == 3],
+            "bound": "hbm", "kernel": "gs_bw_relay_kernel (levels %s: wavefront of blocks as a dataflow, one launch per sweep, a block's walk relayed between 3 waves; "
+                                      "dictionary layout of the records on levels %s) + gs_slot_kernel / gs_bigslot_kernel "
+                                      "(merged dependency-level groups), all levels, pre + post smoother, both directions"
+                                      % ([l for l, m in enumerate(bw_modes) if m == 3], [l for l in range(len(bw_modes)) if int(lib.amgh_debug_bw_dict(dev.h, l)) == 1]),
             "block_wavefront_mode_by_level": bw_modes,
+            "dictionary_layout_by_level": [int(lib.amgh_debug_bw_dict(dev.h, l)) for l in range(len(bw_modes))],
+            # (bit 0 / 1 / 2: the level-ordered cycle streams A / R / P of the level as value-coded columns, 4 bytes per entry)
+            "value_coded_operators_by_level": [int(lib.amgh_debug_coded_ops(dev.h, l)) for l in range(len(bw_modes))],
             "launches_per_cycle": launches, "entries_streamed_per_cycle": stored, "composite_entries_per_cycle": composite,
             "prepass_entries_per_cycle": tri,
-            # (as laid out: block levels their packed records — 80 / 208 bytes per 7- / 19-point row — merged levels 12 bytes per
+            # (as laid out: block levels their packed records — 80 / 208 bytes per 7- / 19-point row, 16 / 48 on the dictionary layout — merged levels 12 bytes per
             # padded composite entry + pre-pass triangle; both sides of the ratio carry b, x in and x out, 24 bytes per row.
             # Measured HBM traffic of the fine-level sweep: profiles/r04_pmc_flow.log)
             "bytes_streamed_per_cycle": streamed_bytes, "algorithmic_bytes_per_cycle": alg_sweeps,
