@@ -437,6 +437,7 @@ struct amgh_dist {
   bool host_exec = false;
   std::vector<real> h_pack;            // host execution: the packed send entries of the exchange under way
   bool gs_exact = true;                // Gauss-Seidel / SOR across the shards: exact lexicographic order or the hybrid (amgh_dist_set_gs_mode)
+  bool pipe_serial = false;            // ranks of this process sharing the device were found NOT to run concurrently (dist_pipe_probe): the levels sweep in turns
   bool gs_pipe = true;                 // ... exact order as ONE pipelined sweep where the level allows it (DistLevel::Pipe::on), else the ranks in turn
   int nplans = 0;
   real *partial = nullptr, *scal = nullptr;
@@ -992,6 +993,9 @@ int amgh_dist_gs_pipelined(const amgh_dist_t* d, int level) {
   if (!d || !d->finalized || level < 0 || level >= (int)d->levels.size()) return -1;
   return d->levels[level]->pipe.on ? 1 : 0;
 }
+// 1 when levels that could have been pipelined sweep in turns because the ranks sharing this device inside one process do not
+// run concurrently (their streams share a hardware queue)
+int amgh_dist_pipe_serialized(const amgh_dist_t* d) { return (d && d->finalized) ? (d->pipe_serial ? 1 : 0) : -1; }
 
 void amgh_dist_destroy(amgh_dist_t* d) {
   if (!d) return;
@@ -1083,6 +1087,59 @@ uint64_t fnv1a(const char* s) { uint64_t h = 1469598103934665603ull; for (; *s; 
 // the halo exchange's send lists = the order of the receiver's halo) and a handle of their mailbox array; the halo entries
 // of the extended fetch lists are pointed at the neighbour's cells and the arrays are mapped (same process: the pointer;
 // another process: hipIpcOpenMemHandle).  Any failure anywhere switches the level back to the ranks sweeping in turn.
+// Do the sweep streams of the ranks that share this device AND this process really run side by side?  A process's streams are
+// spread over a handful of hardware queues; two ranks whose streams landed on one queue run their kernels one after the other,
+// and a pipelined sweep — every rank's workgroups waiting for the neighbour's — would only end in its bounded polls.  Every such
+// rank raises a flag from a kernel on its sweep stream and waits (bounded: ~50 ms) for its neighbours' flags.
+__global__ void pipe_probe_kernel(unsigned* mine, const unsigned* prev, const unsigned* next, unsigned tag, long long ticks, unsigned* result) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __hip_atomic_store(mine, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const long long t0 = wall_clock64();
+  bool ok = false;
+  for (;;) {
+    const bool a = !prev || __hip_atomic_load(prev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == tag;
+    const bool b = !next || __hip_atomic_load(next, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == tag;
+    if (a && b) { ok = true; break; }
+    if (wall_clock64() - t0 > ticks) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  *result = ok ? 1u : 2u;
+}
+// collective (every rank calls it); *ok = 0 where some pair of same-process ranks on one device does not run concurrently
+int dist_pipe_probe(amgh_dist* d, int64_t where, bool* ok) {
+  Transport* tr = d->tr;
+  const int N = tr->nranks, me = tr->rank;
+  *ok = true;
+  unsigned* flag = nullptr;   // [0]: my flag, [1]: the result
+  RC_TRY(dev_alloc(&flag, 2));
+  int rc = hipMemset(flag, 0, 8) == hipSuccess ? AMGH_OK : -1001;
+  std::vector<int64_t> mine{(int64_t)getpid(), where, (int64_t)(uintptr_t)flag};
+  std::vector<std::vector<int64_t>> all;
+  if (rc == AMGH_OK) rc = tr->allgatherv_host(mine, all);
+  double fail = rc == AMGH_OK ? 0.0 : 1.0;
+  if (rc == AMGH_OK) {
+    auto peer = [&](int p) -> const unsigned* {
+      if (p < 0 || p >= N || all[(size_t)p].size() < 3 || all[(size_t)p][0] != mine[0] || all[(size_t)p][1] != where) return nullptr;
+      return (const unsigned*)(uintptr_t)all[(size_t)p][2];
+    };
+    const unsigned *pv = peer(me - 1), *nx = peer(me + 1);
+    rc = tr->barrier();   // (every rank's flag is zeroed and known; the launches below leave the hosts within microseconds of each other)
+    if (rc == AMGH_OK && (pv || nx)) {
+      hipLaunchKernelGGL(pipe_probe_kernel, dim3(1), dim3(64), 0, d->stream, flag, pv, nx, 0x50495045u, (long long)5000000, flag + 1);   // 50 ms of the 100 MHz clock
+      unsigned res = 0;
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess ||
+          hipMemcpy(&res, flag + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); fail = 1.0; }
+      else if (res != 1u) fail = 1.0;
+    }
+    if (rc != AMGH_OK) fail = 1.0;
+  }
+  const int rc2 = tr->allreduce(&fail, 1, true);   // (also: nobody frees a flag a neighbour's kernel may still read)
+  hipFree(flag);
+  if (rc2 != AMGH_OK) return rc2;
+  *ok = fail == 0.0;
+  return AMGH_OK;
+}
+
 int dist_pipe_setup(amgh_dist* d) {
   Transport* tr = d->tr;
   const int N = tr->nranks, me = tr->rank;
@@ -1189,16 +1246,32 @@ int dist_pipe_setup(amgh_dist* d) {
       }
       // ranks sharing this device: every rank's workgroups must be resident at once (a rank waits for its neighbour's)
       if (fail == 0.0 && nshare > 1) {
-        const int cap = bw::relay_resident_blocks<real>(g->bw.maxk, g->bw.flow.lds_max);
+        // (both record layouts — the tunable gs_bw_dict switches between them at every sweep — must fit the grid)
+        int cap = bw::relay_resident_blocks<real>(g->bw.maxk, g->bw.flow.lds_max);
+        if (g->bw.flow.dict_on) cap = std::min(cap, bw::relay_resident_blocks<real>(g->bw.maxk, g->bw.flow.dict_lds, true));
         L->pipe.grid = std::max(1, cap / nshare);
         if (cap <= 0) fail = 1.0;
       }
     } else fail = bad[(size_t)l];
     RC_TRY(tr->allreduce(&fail, 1, true));
     L->pipe.on = fail == 0.0;
-    if (getenv("AMGH_VERBOSE") && me == 0)
-      fprintf(stderr, "[amghip] sharded level %d: Gauss-Seidel across the ranks %s\n", l, L->pipe.on ? "as one pipelined sweep" : "in turns");
   }
+  // ranks of one process on one device: only if their sweep streams really run concurrently
+  bool any = false;
+  for (int l = 0; l < lc; ++l) any = any || d->levels[l]->pipe.on;
+  if (any) {
+    bool concurrent = true;
+    RC_TRY(dist_pipe_probe(d, where, &concurrent));
+    if (!concurrent) {
+      d->pipe_serial = true;
+      for (int l = 0; l < lc; ++l) d->levels[l]->pipe.on = false;
+      if (getenv("AMGH_VERBOSE") && me == 0)
+        fprintf(stderr, "[amghip] ranks sharing a device do not run concurrently (their streams share a hardware queue): Gauss-Seidel across the ranks in turns\n");
+    }
+  }
+  if (getenv("AMGH_VERBOSE") && me == 0)
+    for (int l = 0; l < lc; ++l)
+      fprintf(stderr, "[amghip] sharded level %d: Gauss-Seidel across the ranks %s\n", l, d->levels[l]->pipe.on ? "as one pipelined sweep" : "in turns");
   return AMGH_OK;
 }
 }  // namespace

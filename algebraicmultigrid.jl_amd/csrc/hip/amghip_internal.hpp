@@ -417,7 +417,7 @@ int g_stream_code = 1;          // SpMV-type launches (residual, restriction, pr
 int g_gs_bw_dict = 1;           // the relayed single-column sweep reads the dictionary layout where a schedule carries one (bw::FlowDict: half the bytes of a 7-point level's sweep; bitwise the same); read at schedule build (0: not built) and at every sweep
 int g_gs_bw_relay = 3;          // walker waves a single-column dataflow sweep relays a block's walk between (gs_relay.hpp: the one instantiated count, BW_RELAY_W; 0: one walker, gs_bw_flow_kernel — bitwise the same); read at every sweep
 int g_gs_bw_grid = 0;           // workgroups of a relayed single-column sweep (fewer than blocks: the persistent form of gs_relay.hpp; 0: one per block); read at every sweep
-int g_gs_bw_grid_long = 512;      // ... of levels with rows of more than 6 entries (critical-path bound: fewer resident blocks, faster hand-offs); read at every sweep
+int g_gs_bw_grid_long = 512;      // ... of levels with rows of more than 6 entries ON PLAIN RECORDS (critical-path bound: fewer resident blocks, faster hand-offs; the dictionary layout launches a workgroup per block); read at every sweep
 int g_gs_flow_xzero = 1;        // a dataflow sweep that starts a smooth! call on x = 0 reads no x (0: fill + read as any other sweep — bitwise the same); read at every sweep
 int g_gs_dup_launch = 0;        // measurement hook: every merged-group / level launch of a sweep issued 1 + this many times (idempotent); read at every sweep
 int g_gs_bw_two_min_rows = 6000000; // ... operators with TWO offset classes (2-D grids) take the wavefront of blocks from this many rows (0 = never); read at schedule build

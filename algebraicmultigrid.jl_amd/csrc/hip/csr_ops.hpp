@@ -632,9 +632,11 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
         if (ncolv != 1 || !g->bw.flow.xon) return AMGH_ESTATE;
         fa.aux = g->bw.flow.xaux; fa.fl_mb = g->bw.flow.xfl_mb; fa.fl_slot = g->bw.flow.xfl_slot; fa.xlist = g->bw.flow.xlist;
         fa.epoch = op->pipe_epoch; fa.rmbox = op->pipe_rmbox; fa.grid = op->pipe_grid;
-        e = bw::sweep_relay<real>(fa, g->bw.maxk, g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
+        if (dict) { fa.crec = g->bw.flow.crec; fa.dict = g->bw.flow.dict; fa.dict_ent = g->bw.flow.dict_ent; }
+        e = bw::sweep_relay<real>(fa, g->bw.maxk, dict ? g->bw.flow.dict_lds : g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
       } else if (ncolv == 1 && g_gs_bw_relay > 0) {
-        fa.grid = g->bw.maxk > 6 ? g_gs_bw_grid_long : g_gs_bw_grid;
+        // (the persistent grid pays on the plain 19-point records only: 0.98 -> 0.87 ms there, 0.776 -> 0.787 on the dictionary layout)
+        fa.grid = g->bw.maxk > 6 ? (dict ? 0 : g_gs_bw_grid_long) : g_gs_bw_grid;
         if (dict) { fa.crec = g->bw.flow.crec; fa.dict = g->bw.flow.dict; fa.dict_ent = g->bw.flow.dict_ent; }
         e = bw::sweep_relay<real>(fa, g->bw.maxk, dict ? g->bw.flow.dict_lds : g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
       } else {

@@ -513,21 +513,21 @@ inline hipError_t sweep_relay_launch(const FlowArgs<R>& a, size_t lds, hipStream
   return hipGetLastError();
 }
 // workgroups of the relayed kernel one device keeps resident at once (what a persistent launch may ask for)
-template <typename R, int MAXK, int W>
+template <typename R, int MAXK, int W, bool DICT = false>
 inline int relay_resident(size_t lds) {
   int per_cu = 0, dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gs_bw_relay_kernel<R, false, false, MAXK, W>, 64 * (W + 1), lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gs_bw_relay_kernel<R, false, false, MAXK, W, DICT>, 64 * (W + 1), lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return per_cu * prop.multiProcessorCount;
 }
 template <typename R>
-inline int relay_resident_blocks(int maxk, size_t lds) {
+inline int relay_resident_blocks(int maxk, size_t lds, bool dict = false) {   // (dict: the kernel on the dictionary layout, lds with its dictionary)
   switch (maxk) {
-    case 6: return relay_resident<R, 6, BW_RELAY_W>(lds);
-    case 12: return relay_resident<R, 12, BW_RELAY_W>(lds);
+    case 6: return dict ? relay_resident<R, 6, BW_RELAY_W, true>(lds) : relay_resident<R, 6, BW_RELAY_W>(lds);
+    case 12: return dict ? relay_resident<R, 12, BW_RELAY_W, true>(lds) : relay_resident<R, 12, BW_RELAY_W>(lds);
 #if BW_PLAN_MAXK >= 18
-    case 18: return relay_resident<R, 18, BW_RELAY_W>(lds);
+    case 18: return dict ? relay_resident<R, 18, BW_RELAY_W, true>(lds) : relay_resident<R, 18, BW_RELAY_W>(lds);
 #endif
   }
   return 0;

@@ -1099,7 +1099,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
     const bool inplace = gs_trim();
     // (every limit is checked before a record is touched: `false` leaves the plan as it was; an exception — memory — with the
     // records half rewritten leaves no block layout at all: the level schedules take the level)
-    try { fok = bw::flow_build<real>(P, prm.threads, &F, inplace, tl_flow_halo, g_gs_bw_dict != 0 && !tl_flow_halo); }
+    try { fok = bw::flow_build<real>(P, prm.threads, &F, inplace, tl_flow_halo, g_gs_bw_dict != 0); }
     catch (const std::exception&) {
       fok = false;
       if (inplace) { g->free_dev(); return AMGH_OK; }

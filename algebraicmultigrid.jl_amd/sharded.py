@@ -281,6 +281,11 @@ class ShardedHierarchy:
         """Per sharded level: do its Gauss-Seidel / SOR sweeps run as one sweep pipelined across the ranks under "exact"?"""
         return [int(self.lib.amgh_dist_gs_pipelined(self.h, l)) == 1 for l in range(int(self.lib.amgh_dist_num_sharded_levels(self.h)))] if self.device >= 0 else []
 
+    def pipe_serialized(self):
+        """True when ranks of one process sharing one device were found not to run concurrently (their streams share a hardware
+        queue) and every level was therefore left to the turn loop (`amgh_dist_pipe_serialized`)."""
+        return self.device >= 0 and int(self.lib.amgh_dist_pipe_serialized(self.h)) == 1
+
     def close(self):
         """Destroy the sharded handle first (it borrows the collapsed levels' handle), then the tail."""
         if getattr(self, "h", None):

@@ -370,6 +370,11 @@ int amgh_dist_finalize(amgh_dist_t* d);
 int amgh_dist_set_gs_mode(amgh_dist_t* d, int mode);
 /* 1 when level `level`'s Gauss-Seidel / SOR sweeps run as one pipelined sweep under mode 1, 0 when in turns, < 0: no such level */
 int amgh_dist_gs_pipelined(const amgh_dist_t* d, int level);
+/* 1 when amgh_dist_finalize found that ranks of ONE process sharing ONE device (virtual ranks: a test and measurement
+ * arrangement) do not run their sweep streams concurrently — a process's streams are spread over a few hardware queues, two on
+ * the same queue run one after the other — and therefore left every level to the turn loop (a pipelined sweep would wait for a
+ * neighbour that cannot start); 0 otherwise, -1 before finalize.  Probed with a bounded flag exchange between the streams. */
+int amgh_dist_pipe_serialized(const amgh_dist_t* d);
 int amgh_dist_num_sharded_levels(const amgh_dist_t* d);
 int amgh_dist_local_range(const amgh_dist_t* d, int level, int64_t* r0, int64_t* r1);
 /* ldiv! / _solve! on this rank's rows of the fine vectors (device pointers; collective).

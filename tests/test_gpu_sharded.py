@@ -101,12 +101,18 @@ def test_gauss_seidel_pipelined_across_the_ranks_is_the_oracle_and_the_turns_bit
     cases = [(AMG.GaussSeidel(), AMG.GaussSeidel(), (0, 1)),
              (AMG.GaussSeidel(AMG.ForwardSweep(), iter=2), AMG.GaussSeidel(AMG.BackwardSweep()), (0,)),
              (AMG.SOR(1.2), AMG.SOR(0.9, AMG.ForwardSweep()), (0,))]
+    serialized = False
     with tunables(lib, gs_bw=2, gs_bw_rows=64):
         for pre, post, cycs in cases:
             ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=post)
             oh = O.OracleHierarchy(ml)
-            piped = sharded_run(ml, nranks, 4000, lambda sh: sh.gs_pipelined(), "exact")
-            assert all(len(p) >= 2 and p[0] and p[1] for p in piped), piped   # the two large levels, on every rank (a third, of ~2 900 rows, is too small for blocks: in turns)
+            piped = sharded_run(ml, nranks, 4000, lambda sh: (sh.gs_pipelined(), sh.pipe_serialized()), "exact")
+            # (virtual ranks are threads of ONE process: where two of their streams share a hardware queue the library finds out at
+            # finalize — a bounded probe — and sweeps in turns; everything below still holds, the pipeline itself then is what the
+            # IPC-process tests of test_gpu_ipc.py run)
+            serialized = serialized or any(p[1] for p in piped)
+            if not serialized:
+                assert all(len(p[0]) >= 2 and p[0][0] and p[0][1] for p in piped), piped   # the two large levels, on every rank (a third, of ~2 900 rows, is too small for blocks: in turns)
             for cyc in cycs:
                 got = sharded_cycles(ml, b, nranks, 4000, 2, cyc=cyc, gs_mode="exact")
                 turns = sharded_cycles(ml, b, nranks, 4000, 2, cyc=cyc, gs_mode="exact-turns")
@@ -115,6 +121,8 @@ def test_gauss_seidel_pipelined_across_the_ranks_is_the_oracle_and_the_turns_bit
                     assert rel(got[k], xo) <= 1e-10, (nranks, repr(pre), cyc, k)
                     assert np.array_equal(got[k], turns[k]), (nranks, repr(pre), cyc, k)
         assert lib.amgh_dev_sync(0) == 0
+    if serialized:
+        pytest.skip("the virtual ranks' streams shared a hardware queue in this process: swept in turns (oracle parity held); the pipelined sweep is covered by test_gpu_ipc.py")
 
 
 @pytest.mark.parametrize("nranks", [2, 4])
