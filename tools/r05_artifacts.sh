@@ -10,3 +10,5 @@ ls -la $O
 python -c "
 import json; d=json.load(open('$O/bench_256.json')); print(d['ms_per_step'], d['value'], d['setup_s'], d['roofline']['frac'], d['roofline']['frac_of_read_ceiling'], d['roofline']['traffic'], d['parity'], d['block_of_right_hand_sides'].get('ms_per_cycle'))"
 head -30 $O/rocprofv3_kernel_stats_bench256.txt | cut -c1-200
+# the bs = 8 cycle by columns per workgroup / record layout, with its per-level profile
+timeout 900 python tools/bs_sweep.py 256 8 > $O/bs_sweep.log 2>&1; tail -12 $O/bs_sweep.log
