@@ -1046,7 +1046,7 @@ int amgh_debug_bw_mode(const amgh_t* h, int l) {
 int amgh_debug_bw_dict(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
   const GsSchedule* g = h->levels[l]->smat()->gs;
-  return g && g->bw.on && g->bw.flow.on && g->bw.flow.dict_on && g_gs_bw_dict && g_gs_bw_relay > 0 && (g_gs_bw_flow || !g->bw.rec) ? 1 : 0;
+  return g && g->bw.on && g->bw.flow.on && g->bw.flow.dict_on && (g_gs_bw_dict || !g->bw.flow.srec) && (g_gs_bw_flow || !g->bw.rec) ? 1 : 0;
 }
 int amgh_debug_coded_ops(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;

@@ -1090,16 +1090,17 @@ uint64_t fnv1a(const char* s) { uint64_t h = 1469598103934665603ull; for (; *s; 
 // Do the sweep streams of the ranks that share this device AND this process really run side by side?  A process's streams are
 // spread over a handful of hardware queues; two ranks whose streams landed on one queue run their kernels one after the other,
 // and a pipelined sweep — every rank's workgroups waiting for the neighbour's — would only end in its bounded polls.  Every such
-// rank raises a flag from a kernel on its sweep stream and waits (bounded: ~50 ms) for its neighbours' flags.
-__global__ void pipe_probe_kernel(unsigned* mine, const unsigned* prev, const unsigned* next, unsigned tag, long long ticks, unsigned* result) {
+// rank raises a flag from a kernel on its sweep stream and waits (bounded: ~50 ms) for the flags of ALL the others — not only its
+// neighbours': the sweep is one dependency chain through the ranks, and rank 0 queued in front of rank 2 is as fatal going backward.
+__global__ void pipe_probe_kernel(unsigned* mine, const unsigned* const* peers, int npeers, unsigned tag, long long ticks, unsigned* result) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   __hip_atomic_store(mine, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   const long long t0 = wall_clock64();
   bool ok = false;
   for (;;) {
-    const bool a = !prev || __hip_atomic_load(prev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == tag;
-    const bool b = !next || __hip_atomic_load(next, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == tag;
-    if (a && b) { ok = true; break; }
+    bool all = true;
+    for (int p = 0; p < npeers; ++p) all = all && __hip_atomic_load(peers[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == tag;
+    if (all) { ok = true; break; }
     if (wall_clock64() - t0 > ticks) break;
     __builtin_amdgcn_s_sleep(32);
   }
@@ -1122,15 +1123,23 @@ int dist_pipe_probe(amgh_dist* d, int64_t where, bool* ok) {
       if (p < 0 || p >= N || all[(size_t)p].size() < 3 || all[(size_t)p][0] != mine[0] || all[(size_t)p][1] != where) return nullptr;
       return (const unsigned*)(uintptr_t)all[(size_t)p][2];
     };
-    const unsigned *pv = peer(me - 1), *nx = peer(me + 1);
+    std::vector<const unsigned*> peers;
+    for (int p = 0; p < N; ++p) if (p != me && peer(p)) peers.push_back(peer(p));
+    const unsigned** d_peers = nullptr;
+    if (!peers.empty()) {
+      if (hipMalloc((void**)&d_peers, sizeof(void*) * peers.size()) != hipSuccess ||
+          hipMemcpy((void*)d_peers, peers.data(), sizeof(void*) * peers.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); fail = 1.0; }
+    }
     rc = tr->barrier();   // (every rank's flag is zeroed and known; the launches below leave the hosts within microseconds of each other)
-    if (rc == AMGH_OK && (pv || nx)) {
-      hipLaunchKernelGGL(pipe_probe_kernel, dim3(1), dim3(64), 0, d->stream, flag, pv, nx, 0x50495045u, (long long)5000000, flag + 1);   // 50 ms of the 100 MHz clock
+    if (rc == AMGH_OK && !peers.empty() && fail == 0.0) {
+      hipLaunchKernelGGL(pipe_probe_kernel, dim3(1), dim3(64), 0, d->stream, flag, (const unsigned* const*)d_peers, (int)peers.size(), 0x50495045u,
+                         (long long)5000000, flag + 1);   // 50 ms of the 100 MHz clock
       unsigned res = 0;
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess ||
           hipMemcpy(&res, flag + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); fail = 1.0; }
       else if (res != 1u) fail = 1.0;
     }
+    if (d_peers) hipFree((void*)d_peers);
     if (rc != AMGH_OK) fail = 1.0;
   }
   const int rc2 = tr->allreduce(&fail, 1, true);   // (also: nobody frees a flag a neighbour's kernel may still read)

@@ -626,7 +626,8 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       fa.ldb = ldb; fa.ldx = xs; fa.mail_stride = g->bw.flow.mail_stride;
       fa.xzero = (g_gs_flow_xzero && first && xzero && !x_resident && g->ncols == g->n) ? 1 : 0;   // the sweep that starts a smooth! call on x = 0
       if (ncolv > g->bw.flow.mcols) return AMGH_ESTATE;   // (gs_ensure_cols sized the mailboxes)
-      const bool dict = g->bw.flow.dict_on && g_gs_bw_dict;   // (column records + the blocks' dictionaries of value rows)
+      // (column records + the blocks' dictionaries of value rows; the only layout a trimmed schedule holds where it has one)
+      const bool dict = g->bw.flow.dict_on && (g_gs_bw_dict || !g->bw.flow.srec);
       // a single column: the block's walk relayed between walker waves (gs_relay.hpp) — the same layout, the same bits
       if (op->pipe_epoch) {   // one sweep of a row-sharded level pipelined across the ranks: the relayed kernel on the extended lists
         if (ncolv != 1 || !g->bw.flow.xon) return AMGH_ESTATE;
@@ -640,7 +641,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
         if (dict) { fa.crec = g->bw.flow.crec; fa.dict = g->bw.flow.dict; fa.dict_ent = g->bw.flow.dict_ent; }
         e = bw::sweep_relay<real>(fa, g->bw.maxk, dict ? g->bw.flow.dict_lds : g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
       } else {
-        if (dict && ncolv > 1) {
+        if (dict) {
           fa.crec = g->bw.flow.crec; fa.dict = g->bw.flow.dict; fa.dict_ent = g->bw.flow.dict_ent;
           fa.dict_lds = (int32_t)(g->bw.flow.dict_lds - g->bw.flow.lds_max);
         }

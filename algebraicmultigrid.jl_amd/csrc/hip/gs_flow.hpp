@@ -1030,11 +1030,12 @@ inline hipError_t sweep_flow_launch(const FlowArgs<R>& a, size_t lds, hipStream_
 }
 template <typename R, int MAXK, int NC>
 inline hipError_t sweep_flow_k(const FlowArgs<R>& a, size_t lds, bool sor, bool backward, hipStream_t st) {
-  if constexpr (NC > 1)   // (the dictionary layout, where the schedule carries one — a single column on it is the relayed sweep's, gs_relay.hpp)
-    if (a.crec) {
+  if (a.crec) {   // (the dictionary layout, where the schedule carries one)
+    {
       if (sor) return backward ? sweep_flow_launch<R, true, true, MAXK, NC, true>(a, lds, st) : sweep_flow_launch<R, true, false, MAXK, NC, true>(a, lds, st);
       return backward ? sweep_flow_launch<R, false, true, MAXK, NC, true>(a, lds, st) : sweep_flow_launch<R, false, false, MAXK, NC, true>(a, lds, st);
     }
+  }
   if (sor) return backward ? sweep_flow_launch<R, true, true, MAXK, NC>(a, lds, st) : sweep_flow_launch<R, true, false, MAXK, NC>(a, lds, st);
   return backward ? sweep_flow_launch<R, false, true, MAXK, NC>(a, lds, st) : sweep_flow_launch<R, false, false, MAXK, NC>(a, lds, st);
 }
@@ -1054,7 +1055,7 @@ inline hipError_t sweep_flow_cols(FlowArgs<R> a, size_t lds_max, bool sor, bool 
     case 4: return sweep_flow_k<R, MAXK, 4>(a, stride * 4 + dl, sor, backward, st);
     case 3: return sweep_flow_k<R, MAXK, 3>(a, stride * 3 + dl, sor, backward, st);
     case 2: return sweep_flow_k<R, MAXK, 2>(a, stride * 2 + dl, sor, backward, st);
-    default: return sweep_flow_k<R, MAXK, 1>(a, lds_max, sor, backward, st);
+    default: return sweep_flow_k<R, MAXK, 1>(a, stride + dl, sor, backward, st);
   }
 }
 template <typename R>

@@ -4,6 +4,13 @@ import sys
 import numpy as np
 import pytest
 
+# Virtual ranks (tests of the row-sharded path with N ranks as threads of ONE process on ONE device) need the ranks' sweep
+# streams to run side by side: the HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (4 by
+# default), round-robin at creation, and two ranks on one queue run their kernels one after the other.  The library finds
+# that out at amgh_dist_finalize and sweeps in turns (amgh_dist_pipe_serialized; the tests then skip their pipelined part) —
+# with 8 queues the suite's streams do not collide and the pipelined sweeps really run.  Read when the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # torch bundles its own ROCm runtime (libamdhip64.so.7 / libhsa-runtime64): it has to be the first HIP
 # runtime loaded into a process that will use torch.cuda, otherwise torch's device init fails.  The
 # sharded-driver tests use torch tensors, so load it before libamghip.so pulls in /opt/rocm's copy.

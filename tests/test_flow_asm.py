@@ -26,7 +26,7 @@ def test_flow_kernel_pipeline_survives_the_compiler():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "flow_asm_audit.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     lines = [l for l in out.splitlines() if l.startswith(("ok", "FAIL"))]
-    assert r.returncode == 0 and len(lines) == 184 and all(l.startswith("ok") for l in lines), out
+    assert r.returncode == 0 and len(lines) == 208 and all(l.startswith("ok") for l in lines), out
     assert sum("relay" in l for l in lines) == 48, out
 
 
@@ -36,4 +36,4 @@ def test_no_set_in_flight_is_touched_anywhere_in_the_kernels():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     lines = [l for l in out.splitlines() if l.startswith(("ok", "FAIL"))]
-    assert r.returncode == 0 and len(lines) == 184 and all(l.startswith("ok") for l in lines), out
+    assert r.returncode == 0 and len(lines) == 208 and all(l.startswith("ok") for l in lines), out

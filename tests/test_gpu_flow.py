@@ -269,11 +269,17 @@ def test_blocks_of_right_hand_sides_on_the_dataflow_layout_equal_the_single_colu
         for nc in (1, 3, 0):
             with tunables(lib, gs_bw_nc=nc):
                 assert np.array_equal(devb.precond_apply(B), Z), nc
-        # (the multi-column kernels read the dictionary layout — column records + the blocks' value rows in LDS; here the plain records)
+        # (the multi-column kernels read the dictionary layout — column records + the blocks' value rows in LDS: the only record
+        # layout a schedule of the default footprint holds; here a hierarchy built without it, on the plain records)
         assert lib.amgh_debug_bw_dict(devb.h, 0) == 1
-        for nc in (2, 0):
-            with tunables(lib, gs_bw_dict=0, gs_bw_nc=nc):
-                assert np.array_equal(devb.precond_apply(B), Z), ("plain records", nc)
+        with tunables(lib, gs_bw_dict=0):
+            assert lib.amgh_debug_bw_dict(devb.h, 0) == 1      # (nothing to switch to)
+            devp = DeviceHierarchy(ml, 0, bs)
+            assert lib.amgh_debug_bw_dict(devp.h, 0) == 0
+            for nc in (2, 0):
+                with tunables(lib, gs_bw_nc=nc):
+                    assert np.array_equal(devp.precond_apply(B), Z), ("plain records", nc)
+            del devp
         X, _, its = devb.solve(B, np.zeros_like(B), 0, 3, 0.0, 0.0, False, False)
         singles = [dev1.precond_apply(B[:, c].copy()) for c in range(bs)]
         x0 = dev1.solve(B[:, 0].copy(), np.zeros(n), 0, 3, 0.0, 0.0, False, False)[0]

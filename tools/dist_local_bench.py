@@ -4,6 +4,7 @@ ranks' streams): ms per cycle by Gauss-Seidel mode, per number of sharded levels
 exact sweep without the cost of several processes sharing a device.
 usage: python tools/dist_local_bench.py [N=256] [nranks=4] [shard_min_rows=2000000]"""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (virtual ranks: every rank's stream on a hardware queue of its own, tests/conftest.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import amg_amd as AMG

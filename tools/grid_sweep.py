@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import amg_amd as AMG
 from bench import uniform
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+AMG.hip_lib().amgh_debug_set_tunable(b"gs_lean", 0)   # (the full footprint: both record layouts stay on the device, gs_bw_dict switches between them at run time)
 ml = AMG.ruge_stuben(AMG.poisson((N, N, N)), setup="gpu", device=0)
 dev = ml.device()
 lib = dev.lib
