@@ -16,6 +16,8 @@
 // registers (D sets per wave), which also covers the HBM latency the single walker's D = 3-4 steps did not.
 // Everything else — tickets in depth order, publish-as-computed mailboxes, the fetcher wave, bounded polls that raise
 // *err — is gs_flow.hpp's.  Per row the arithmetic is unchanged: bitwise the scalar loop.
+// Template flag DICT: the records on the dictionary layout (gs_flow.hpp FlowDict) — a set in flight is the row's column chunks
+// and b, the values come out of the block's dictionary in LDS ahead of the hand-over (256^3: 0.61 -> 0.56 / 0.93 -> 0.78 ms).
 #pragma once
 #include "gs_flow.hpp"
 
