@@ -172,6 +172,7 @@ def _bind_solve_phase(L, creal, coarse_fn):
     L.amgh_debug_bw_dict.argtypes = [vp, C.c_int]
     L.amgh_debug_coded_ops.argtypes = [vp, C.c_int]
     L.amgh_debug_bw_sweep_host.argtypes = [i64, vp, vp, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp]
+    L.amgh_debug_bw_dict_sweep_host.argtypes = [i64, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.amgh_debug_set_tunable.argtypes = [C.c_char_p, C.c_int]
     L.amgh_profile_enable.argtypes = [vp, C.c_int]
     L.amgh_profile_read.argtypes = [vp, vp, C.c_int]

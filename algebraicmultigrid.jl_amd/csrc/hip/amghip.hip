@@ -1686,6 +1686,93 @@ int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t
   return AMGH_OK;
 }
 
+// Host-only: one Gauss-Seidel sweep executed FROM THE DICTIONARY LAYOUT of the dataflow records (gs_flow.hpp FlowDict: column
+// records chunk-major per step, the dictionary index in the publish word, every block's distinct value rows) — the blocks in
+// ticket order, a block's steps in walking order, a row's values out of its block's dictionary.  CPU tests compare it bit for
+// bit with the scalar lexicographic sweep.  stats5 = {1 if the operator has the layout, dictionary rows in all, largest
+// dictionary, bytes of column records + dictionaries, bytes of the plain records}.  AMGH_EUNSUPPORTED: no block layout /
+// no dataflow layout (pattern not structurally symmetric); without the dictionary layout x is left untouched (stats5[0] = 0).
+int amgh_debug_bw_dict_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t* col, const real* val, int target_rows,
+                                  int backward, real* x, const real* b, int64_t* stats5) {
+  if (nrows <= 0 || !rowptr || !x || !b || target_rows < 1) return AMGH_EINVAL;
+  const int64_t n = nrows;
+  for (int32_t j = 0; j < rowptr[n]; ++j)
+    if (col[j] < 0 || col[j] >= n) return AMGH_EINVAL;
+  bw::Params prm;
+  prm.target_rows = target_rows;
+  prm.threads = 2;
+  bw::Plan P;
+  bw::Flow F;
+  try {
+    if (!bw::plan<real>(n, rowptr, col, val, prm, &P)) return AMGH_EUNSUPPORTED;
+    if (!bw::structurally_symmetric(n, rowptr, col, 2) || !bw::flow_build<real>(P, 2, &F)) return AMGH_EUNSUPPORTED;
+  } catch (const std::exception&) {
+    return AMGH_ENOMEM;
+  }
+  const int32_t B = (int32_t)P.blocks.size();
+  if (stats5) {
+    int64_t rows = 0, mx = 0;
+    if (F.dc.on) for (int32_t e : F.dc.ent) { const int64_t r = (int64_t)((uint32_t)e >> 24) + 1; rows += r; mx = std::max(mx, r); }
+    stats5[0] = F.dc.on ? 1 : 0; stats5[1] = rows; stats5[2] = mx;
+    stats5[3] = (int64_t)(F.dc.crec.size() + F.dc.dict.size()); stats5[4] = (int64_t)F.srec.size();
+  }
+  if (!F.dc.on) return AMGH_OK;
+  std::vector<real> xp(n), bp(n);
+  for (int64_t p = 0; p < n; ++p) { xp[p] = x[P.perm[p]]; bp[p] = b[P.perm[p]]; }
+  for (int32_t t = 0; t < B; ++t) {
+    const int32_t ob = backward ? B - 1 - t : t;
+    const bw::Desc& d = P.blocks[ob];
+    const bw::FlowDesc& f = F.fd[ob];
+    const int nvc = bw::Packed<real>::nvc(d.maxk), ncc = bw::Packed<real>::ncc(d.maxk), ns = d.nlev;
+    const int cdw = ((d.maxk + 1) / 2 - 1) % 4 + 1;
+    const unsigned char* crec = F.dc.crec.data() + (size_t)d.row0 * (size_t)ncc * 16;
+    const int32_t de = F.dc.ent[(size_t)ob];
+    const unsigned char* dict = F.dc.dict.data() + (size_t)(de & 0xffffff) * 16;
+    const int drows = (int)((uint32_t)de >> 24) + 1;
+    const uint32_t* ax = F.aux.data() + f.aux + (backward ? ns + 1 : 0);
+    std::vector<real> xl((size_t)d.nrows + d.next + 1);
+    for (int32_t p = 0; p < d.nrows; ++p) xl[p] = xp[d.row0 + p];
+    for (int32_t e = 0; e < d.next; ++e) xl[d.nrows + e] = xp[P.ext_col[d.ext0 + e]];
+    xl[(size_t)d.nrows + d.next] = 0.0;
+    for (int k = 0; k < ns; ++k) {
+      const uint32_t w = ax[k];
+      const int r0 = (int)(w & ((1u << bw::kStepRowBits) - 1)), nr = (int)((w >> bw::kStepRowBits) & ((1u << bw::kStepCntBits) - 1));
+      std::vector<real> xn((size_t)nr);
+      for (int q = 0; q < nr; ++q) {
+        uint16_t cc[64];
+        int32_t pw = 0;
+        for (int c = 0; c < ncc; ++c) {
+          const unsigned char* ch = crec + ((size_t)ncc * r0 + (size_t)c * nr + q) * 16;
+          std::memcpy(cc + 8 * c, ch, 16);
+          if (c == ncc - 1) std::memcpy(&pw, ch + 4 * cdw, 4);
+        }
+        const int idx = (int)(((uint32_t)pw >> bw::kDictIdxShift) & 0xffu);
+        if (idx >= drows) return AMGH_ESTATE;
+        if ((pw & ~(0xff << bw::kDictIdxShift)) != F.pub[(size_t)d.row0 + r0 + q]) return AMGH_ESTATE;   // the publish word rides unchanged
+        const real* v = (const real*)(dict + (size_t)idx * nvc * 16);
+        real acc = 0.0;
+        for (int e = 0; e < d.maxk; ++e) acc += v[e] * xl[cc[e] / sizeof(real)];
+        const real dg = v[d.maxk], rc = v[d.maxk + 1];
+        real qv = xl[(size_t)r0 + q];
+        if (dg != 0.0) {
+          const real nn = bp[d.row0 + r0 + q] - acc;
+          qv = nn * rc;
+          const real rem = std::fma(-dg, qv, nn);
+          qv = std::fma(rem, rc, qv);
+          const real an = nn < 0 ? -nn : nn;
+          const bool safe = sizeof(real) == 8 ? (an > (real)1e-200 && an < (real)1e200) : (an > (real)1e-25 && an < (real)1e25);
+          if (!(rc != 0.0 && safe)) qv = nn / dg;
+        }
+        xn[(size_t)q] = qv;
+      }
+      for (int q = 0; q < nr; ++q) xl[(size_t)r0 + q] = xn[(size_t)q];
+    }
+    for (int32_t p = 0; p < d.nrows; ++p) xp[d.row0 + p] = xl[p];
+  }
+  for (int64_t p = 0; p < n; ++p) x[P.perm[p]] = xp[p];
+  return AMGH_OK;
+}
+
 // Host-only emulation of ONE merged-level Gauss-Seidel sweep (no device work: usable without a GPU).  Runs the same
 // construction the device schedules use — dependency levels, level order, groups of m levels made independent by
 // substitution, pre-pass over the other triangle — and then applies the composite rows group by group on the host.

@@ -501,6 +501,15 @@ int amgh_debug_merged_sweep_host(int64_t nrows, int64_t ncols, const int32_t* ro
 int amgh_debug_bw_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t* col, const amgh_real* val, int target_rows,
                              int backward, double omega, amgh_real* x, const amgh_real* b, int64_t* stats4);
 
+/* Diagnostics: one Gauss-Seidel sweep executed on the host FROM THE DICTIONARY LAYOUT of the dataflow records (csrc/hip/
+ * gs_flow.hpp FlowDict: per row its column chunks and a dictionary index, per block its distinct value rows) — what the
+ * relayed and the multi-column kernels read where an operator's rows repeat.  x (in / out), b: nrows entries; stats5 = {1 if
+ * the operator has the layout (else x is left untouched), dictionary rows in all, rows of the largest dictionary, bytes of
+ * column records + dictionaries, bytes of the plain records} (may be NULL).  AMGH_EUNSUPPORTED: no block layout or a
+ * pattern that is not structurally symmetric.  CPU tests compare it bit for bit with the scalar loop (smoother.jl:61-90). */
+int amgh_debug_bw_dict_sweep_host(int64_t nrows, const int32_t* rowptr, const int32_t* col, const amgh_real* val, int target_rows,
+                                  int backward, amgh_real* x, const amgh_real* b, int64_t* stats5);
+
 /* Diagnostics of the single-launch wavefronts of blocks (blocks ordered by flags or by the data they wait for instead of
  * kernel boundaries): the process-wide word a bounded poll raises when it gives up, read behind a device
  * synchronisation — always 0 (a block only waits for blocks holding smaller tickets).  A raised word is what turns the

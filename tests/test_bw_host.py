@@ -139,3 +139,47 @@ def test_block_wave_plan_refuses_long_rows_and_counts_launches():
     rc, _, st = _bw_sweep(A, np.zeros(A.m), np.ones(A.m), 64, 0)
     assert rc == 0 and st["blocks"] == 64 and st["launches"] == 3 * 4 - 2        # 4^3 blocks of 4^3 rows: a wavefront of cubes
     assert st["sum_depth"] == st["launches"] * (3 * 4 - 2) and st["ext"] > 0
+
+
+def _dict_sweep(A, x, b, target_rows, backward, dtype=np.float64):
+    lib = AMG.hip_lib("float32" if dtype == np.float32 else "float64")
+    rp, ci, va = A.csr_arrays()
+    rp = np.ascontiguousarray(rp, dtype=np.int32)
+    ci = np.ascontiguousarray(ci, dtype=np.int32)
+    va = np.ascontiguousarray(va, dtype=dtype)
+    x = np.array(x, dtype=dtype, copy=True)
+    b = np.ascontiguousarray(b, dtype=dtype)
+    st = np.zeros(5, dtype=np.int64)
+    rc = lib.amgh_debug_bw_dict_sweep_host(A.m, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(target_rows), int(backward),
+                                           x.ctypes.data, b.ctypes.data, st.ctypes.data)
+    return rc, x, dict(zip(("on", "dict_rows", "dict_max", "dict_bytes", "plain_bytes"), map(int, st)))
+
+
+def test_dictionary_layout_executed_on_the_host_is_the_scalar_sweep_bit_for_bit():
+    """The dictionary layout of the dataflow records (csrc/hip/gs_flow.hpp FlowDict) without a GPU: a sweep executed on the
+    host from the column records, the dictionary indices in the publish words and the blocks' dictionaries of value rows
+    equals the scalar lexicographic sweep (smoother.jl:61-90) bit for bit — a 7-point grid (a handful of distinct value rows
+    per block: boundary rows differ from interior ones), a grid with perturbed rows (longer dictionaries), a 2-D grid,
+    Float32; an operator whose rows all differ has no such layout (the plain records stay)."""
+    cases = [("poisson 3-D", AMG.poisson((14, 12, 10)), 64), ("poisson 2-D", AMG.poisson((40, 30)), 64)]
+    S = AMG.poisson((12, 12, 12)).to_scipy().tolil()
+    rng = np.random.default_rng(4)
+    for i in rng.integers(0, S.shape[0], 200):
+        S[i, i] = 6.0 + rng.random()
+    cases.append(("perturbed rows", AMG.SparseMatrixCSC.from_scipy(S.tocsc()), 128))
+    for name, A, rows in cases:
+        x0, b = uniform(A.m, 3) - 0.5, uniform(A.m, 4)
+        for dtype in (np.float64, np.float32):
+            for backward in (False, True):
+                rc, xd, st = _dict_sweep(A, x0, b, rows, backward, dtype)
+                assert rc == 0 and st["on"] == 1, (name, st)
+                assert st["dict_bytes"] * 2 < st["plain_bytes"] and st["dict_rows"] * 4 <= A.m, (name, st)
+                assert np.array_equal(xd, _scalar_sweep(A, x0, b, backward, dtype=dtype)), (name, dtype, backward)
+        if name == "perturbed rows":
+            assert st["dict_max"] > 8, st
+    R = AMG.poisson((10, 10, 10)).to_scipy().tocsr()
+    R.data = R.data * (1.0 + 0.01 * np.random.default_rng(5).random(R.data.size))
+    Ar = AMG.SparseMatrixCSC.from_scipy(((R + R.T) * 0.5).tocsc())
+    x0 = uniform(Ar.m, 6)
+    rc, xd, st = _dict_sweep(Ar, x0, uniform(Ar.m, 7), 64, False)
+    assert rc == 0 and st["on"] == 0 and np.array_equal(xd, x0), st
