@@ -409,8 +409,15 @@ def test_dictionary_layout_rows_that_repeat_and_rows_that_do_not():
     R.data = R.data * (1.0 + 0.01 * rng.random(R.data.size))
     R = (R + R.T) * 0.5                       # every row its own values: no dictionary (but the pattern stays symmetric)
     Ar = AMG.SparseMatrixCSC.from_scipy(sp.csc_matrix(R))
+    # the 9-point operator of a 48 x 40 grid (rows of up to 8 entries: the 12-entry records)
+    E2a, E2b = sp.identity(48, format="csr"), sp.identity(40, format="csr")
+    N2a = sp.diags([np.ones(47), np.ones(47)], [-1, 1], format="csr")
+    N2b = sp.diags([np.ones(39), np.ones(39)], [-1, 1], format="csr")
+    K9 = 10.0 * sp.identity(48 * 40) - 1.5 * (sp.kron(N2a, E2b) + sp.kron(E2a, N2b)) - 0.5 * sp.kron(N2a, N2b)
+    A9 = AMG.SparseMatrixCSC.from_scipy(sp.csc_matrix(K9))
+    assert int(np.diff(sp.csr_matrix(K9).indptr).max()) == 9
     pre = AMG.GaussSeidel()
-    for A, want, rows in ((A19, 1, 128), (Ap, 1, 216), (Ar, 0, 512)):
+    for A, want, rows in ((A19, 1, 128), (Ap, 1, 216), (A9, 1, 64), (Ar, 0, 512)):
         x0, bb = uniform(A.m, 51) - 0.5, uniform(A.m, 52)
         ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre)
         with tunables(lib, gs_bw=2, gs_bw_rows=rows, gs_lean=0):
