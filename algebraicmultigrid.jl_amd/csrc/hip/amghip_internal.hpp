@@ -421,7 +421,7 @@ int g_gs_bw_grid_long = 512;      // ... of levels with rows of more than 6 entr
 int g_gs_flow_xzero = 1;        // a dataflow sweep that starts a smooth! call on x = 0 reads no x (0: fill + read as any other sweep — bitwise the same); read at every sweep
 int g_gs_dup_launch = 0;        // measurement hook: every merged-group / level launch of a sweep issued 1 + this many times (idempotent); read at every sweep
 int g_gs_bw_two_min_rows = 6000000; // ... operators with TWO offset classes (2-D grids) take the wavefront of blocks from this many rows (0 = never); read at schedule build
-int g_gs_bw_min_rows = 3000000; // ... operators below this many rows keep the level schedules in mode 1 (half as many for rows of at most 7 entries: tools/bw_threshold.py, profiles/r03_bw_threshold.log)
+int g_gs_bw_min_rows = 30000;   // ... operators below this many rows keep the level schedules in mode 1 (half as many for rows of at most 7 entries).  Round 3 (chained kernel): 3 000 000; with the relayed dataflow sweep and its own cost model (Plan::est_flow_seconds) the block layout wins wherever that model says so: 48^3 ... 160^3 Poisson hierarchies -19 ... -28 % per V-cycle with the second level on it too (tools/minrows_sweep.py, profiles/r05_block_layout_threshold.log)
 int g_gs_sample = 1;            // candidate group sizes of the merged sweeps from a sample of the groups (0 = every candidate built in full); read at schedule build
 int g_gs_sell = 1;              // merged groups from the SELL-like layout where it was built (0 = slot kernels); build: read at schedule build too
 int g_gs_lean = -1;             // footprint policy: -1 = AMGH_LEAN environment variable (unset: trim), 0 = full (every copy kept), 1 = lean, 2 = trim; read at schedule build

@@ -112,6 +112,7 @@ struct Plan {
   int max_rows = 0;
   double est_seconds = 0.0;         // modelled time of one directional sweep, one launch per depth ...
   double est_chain_seconds = 0.0;   // ... and as one launch, blocks chained by flags
+  double est_flow_seconds = 0.0;    // ... and as a dataflow with relayed walks (gs_flow.hpp / gs_relay.hpp)
   int cuts[2] = {99, 99};
   int32_t range[3] = {1, 1, 1};
   int32_t cells[3] = {1, 1, 1};
@@ -553,6 +554,15 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
       double walk_all = 0.0;
       for (const Desc& d : P.blocks) walk_all += 4.8e-6 + d.nlev * step;
       P.est_chain_seconds = (double)P.sum_depth * step + nlaunch * 2.3e-6 + 0.3 * walk_all / slots;
+      // as a dataflow (rows published as they are computed, a block's walk relayed between three waves; round 5): ONE chain through
+      // the operator's dependency levels — 0.31 + 0.0087 maxk us per level: hand-over + dependent tail — plus a hand-off per depth
+      // of the block graph (1.1 us: write-through cell, coherent poll), plus, where the wavefront is wide, half of what the resident
+      // workgroups (5 / 3 per CU) need for all blocks (6 us of load phase + the walk).  Measured (profiles/r05_dictionary_layout.log,
+      // tools/bwforce_sweep.py): 256^3 level 0 0.557 ms (model 0.567), level 1 0.78 (0.87); 128^3 level 0 0.19 (0.22), level 1 0.34 (0.35)
+      const double fstep = 0.31e-6 + 0.0087e-6 * maxk;
+      double occupy = 0.0;
+      for (const Desc& d : P.blocks) occupy += 6.0e-6 + d.nlev * fstep;
+      P.est_flow_seconds = P.nlevels * fstep + nlaunch * 1.1e-6 + 0.5 * occupy / (256.0 * (maxk <= 6 ? 5 : 3)) + 8.0e-6;
     }
   }
   return true;

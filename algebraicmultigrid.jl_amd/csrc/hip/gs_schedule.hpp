@@ -1021,6 +1021,12 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
   // (the cost-model branch below insists on three offset classes, or two on operators of >= gs_bw_two_min_rows rows)
   prm.require_three = g_gs_bw != 2 && !(g_gs_bw_two_min_rows > 0 && n >= g_gs_bw_two_min_rows);
   prm.require_two = g_gs_bw != 2;
+  // (rows beyond the records' 18 entries: not eligible — found from the row pointers alone, before any pass over the entries)
+  {
+    int32_t longest = 0;
+    for (int64_t i = 0; i < n; ++i) longest = std::max(longest, rowptr[i + 1] - rowptr[i]);
+    if (longest - 1 > bw::kPlanMaxK) return AMGH_OK;
+  }
   // the sweep as a dataflow (gs_flow.hpp) where the data dependencies carry the anti-dependencies: structurally symmetric
   // patterns (halo columns of a row-sharded operator: never written, read as they stand).  Blocks of right-hand sides only
   // have that execution (the chained kernel is a single-column one): other patterns keep the level schedules
@@ -1054,13 +1060,14 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
     const int ndir = (P.range[0] > 1) + (P.range[1] > 1) + (P.range[2] > 1);
     const bool two = ndir == 2 && g_gs_bw_two_min_rows > 0 && n >= g_gs_bw_two_min_rows;
     const double merged = merge_cost((P.nlevels + 2) / 3, (int64_t)(1.8 * (double)nnz));
-    const double est = g_gs_bw_chain ? P.est_chain_seconds : P.est_seconds;
+    // (the execution the level will get: the dataflow where the pattern allows it, else chained by flags / launched per depth)
+    const double est = flow_ok ? P.est_flow_seconds : g_gs_bw_chain ? P.est_chain_seconds : P.est_seconds;
     // (a shard of a row-sharded level that can be swept in the pipeline across the ranks: the alternative to the block layout is
     // not the merged groups but the ranks sweeping in turn)
     const bool used = (three && est < 0.8 * merged) || (two && est < 0.6 * merged) || (three && tl_flow_halo != nullptr);
     if (getenv("AMGH_VERBOSE"))
-      fprintf(stderr, "[amghip] n=%lld wavefront of blocks: %zu blocks, %d depths (dependency levels %d), %d directions, model %.3f ms (%.3f as one launch per depth) vs %.3f ms merged -> %s\n",
-              (long long)n, P.blocks.size(), nlaunch, P.nlevels, ndir, est * 1e3, P.est_seconds * 1e3, merged * 1e3, used ? "used" : "not used");
+      fprintf(stderr, "[amghip] n=%lld wavefront of blocks: %zu blocks, %d depths (dependency levels %d), %d directions, model %.3f ms (%s; %.3f as one launch per depth) vs %.3f ms merged -> %s\n",
+              (long long)n, P.blocks.size(), nlaunch, P.nlevels, ndir, est * 1e3, flow_ok ? "dataflow" : "chained", P.est_seconds * 1e3, merged * 1e3, used ? "used" : "not used");
     if (!used) return AMGH_OK;
   }
   HostLevelCsr base;
