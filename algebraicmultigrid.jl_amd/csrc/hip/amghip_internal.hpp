@@ -420,7 +420,7 @@ int g_gs_bw_grid = 0;           // workgroups of a relayed single-column sweep (
 int g_gs_bw_grid_long = 512;      // ... of levels with rows of more than 6 entries ON PLAIN RECORDS (critical-path bound: fewer resident blocks, faster hand-offs; the dictionary layout launches a workgroup per block); read at every sweep
 int g_gs_flow_xzero = 1;        // a dataflow sweep that starts a smooth! call on x = 0 reads no x (0: fill + read as any other sweep — bitwise the same); read at every sweep
 int g_gs_dup_launch = 0;        // measurement hook: every merged-group / level launch of a sweep issued 1 + this many times (idempotent); read at every sweep
-int g_gs_bw_two_min_rows = 6000000; // ... operators with TWO offset classes (2-D grids) take the wavefront of blocks from this many rows (0 = never); read at schedule build
+int g_gs_bw_two_min_rows = 200000;  // ... operators with TWO offset classes (2-D grids) take the wavefront of blocks from this many rows where the cost model agrees (0 = never); round 4: 6 000 000; with the relayed dataflow sweep 512^2 / 1024^2 / 2048^2 Poisson V-cycles 4.82 -> 3.92 / 9.35 -> 8.50 / 21.6 -> 18.3 ms, 4096^2 39.1 -> 39.9 (profiles/r05_block_layout_threshold.log); read at schedule build
 int g_gs_bw_min_rows = 30000;   // ... operators below this many rows keep the level schedules in mode 1 (half as many for rows of at most 7 entries).  Round 3 (chained kernel): 3 000 000; with the relayed dataflow sweep and its own cost model (Plan::est_flow_seconds) the block layout wins wherever that model says so: 48^3 ... 160^3 Poisson hierarchies -19 ... -28 % per V-cycle with the second level on it too (tools/minrows_sweep.py, profiles/r05_block_layout_threshold.log)
 int g_gs_sample = 1;            // candidate group sizes of the merged sweeps from a sample of the groups (0 = every candidate built in full); read at schedule build
 int g_gs_sell = 1;              // merged groups from the SELL-like layout where it was built (0 = slot kernels); build: read at schedule build too

@@ -545,7 +545,7 @@ int amgh_debug_coded_ops(const amgh_t* h, int l);
  * "gs_bigslot" (0 off, 1 cost model, 2 always), "gs_super" (blocks per superblock), "gs_block_inverse", "gs_bw" (the
  * wavefront-of-blocks layout of single-column hierarchies: 0 off, 1 where its cost model prefers it, 2 always),
  * "gs_bw_rows" (rows per block aimed at, 512), "gs_bw_min_rows" (smallest operator considered in mode 1: 30 000 rows, half of it for operators of at most 7 entries per row — above it the cost model decides);
- * "gs_bw_two_min_rows" (operators with TWO offset classes — 2-D grids — take that layout from this many rows: 6 000 000;
+ * "gs_bw_two_min_rows" (operators with TWO offset classes — 2-D grids — take that layout from this many rows: 200 000;
  * 0 never), "gs_bw_nrhs" (1: hierarchies created for blocks of right-hand sides get it too, on structurally symmetric
  * levels), "gs_bw_flow" (1: the dataflow layout of the wavefront is built where the pattern is structurally symmetric);
  * read at every sweep: "gs_bw_flow" (0: the chained / launched execution where its layout was kept), "gs_bw_chain" (1: the

@@ -36,17 +36,19 @@ def test_c2_poisson_1024x1024_sa_jacobi_full_size():
 
 
 def test_2d_gauss_seidel_hierarchy_large_levels_as_wavefronts_of_blocks():
-    """2-D grids have two offset classes: their wavefront of blocks is a line, and only operators of >= 6 M rows take it
-    (tunable gs_bw_two_min_rows; 4096^2: the 16.8 M-row level 8.5 -> 6.3 ms per smoother, profiles/r04_2d_blocks.log).
+    """2-D grids have two offset classes: their wavefront of blocks is a line; operators of >= 200 000 rows take it where the
+    cost model of the dataflow execution agrees (tunable gs_bw_two_min_rows; round 4: 6 M rows — 4096^2: the 16.8 M-row
+    level 8.5 -> 6.3 ms per smoother, profiles/r04_2d_blocks.log; round 5: profiles/r05_block_layout_threshold.log).
     A 3072 x 2048 Poisson hierarchy with the defaults (ruge_stuben, symmetric Gauss-Seidel, smoother.jl:61-90): the fine
-    level runs the dataflow sweep, the 3.1 M-row level below it keeps the merged groups, the cycle is the oracle's at
-    1e-10 and the fine-level smoother alone is the scalar loop bit for bit."""
+    level and the 3.1 M-row level below it run the dataflow sweep, small levels keep the merged groups, the cycle is the
+    oracle's at 1e-10 and the fine-level smoother alone is the scalar loop bit for bit."""
     lib = AMG.hip_lib()
     A = AMG.poisson((3072, 2048))
     n = A.m
     ml = AMG.ruge_stuben(A, setup="gpu", device=0)
     dev = ml.device(0, 1)
-    assert lib.amgh_debug_bw_mode(dev.h, 0) == 3 and lib.amgh_debug_bw_mode(dev.h, 1) == 0
+    assert lib.amgh_debug_bw_mode(dev.h, 0) == 3 and lib.amgh_debug_bw_mode(dev.h, 1) == 3
+    assert lib.amgh_debug_bw_mode(dev.h, len(ml.levels) - 1) == 0
     assert dev.gs_sweep_stats(0, False)["launches"] == 1
     b = uniform(n, 5) - 0.3
     oh = O.OracleHierarchy(ml)
