@@ -59,10 +59,15 @@ int launch_gs_level(const StreamArgs& a, int rows, hipStream_t st, int ncolv = 1
 // (5 195 rows of 124 entries: 6 workgroups, 0.18 ms for 8 MB).  Below 2^18 rows: 64 rows per 256-thread workgroup.
 // The per-row sums are the same in-order sums either way.
 using SmallCfg = StreamCfg<256, 64, 4096, 2, false, false>;
+// (the value-coded variant: a third of the bytes per row — measured shapes in profiles/r05_coded_cfg.log)
+#ifndef AMGH_CODED_CFG
+#define AMGH_CODED_CFG 1024, 1024, 8192, 4
+#endif
+using CodedCfg = StreamCfg<AMGH_CODED_CFG, false, false>;
 template <int MODE>
 int launch_stream_sized(const StreamArgs& a, hipStream_t st, int ncolv) {
   if (a.row_end - a.row_begin < (1 << 18)) return launch_stream<MODE, SmallCfg>(a, st, ncolv);
-  if (a.ccol && g_stream_code) return launch_stream<MODE, DefaultCfg, true>(a, st, ncolv);   // value-coded columns: 4 bytes per entry
+  if (a.ccol && g_stream_code) return launch_stream<MODE, CodedCfg, true>(a, st, ncolv);   // value-coded columns: 4 bytes per entry
   return launch_stream<MODE>(a, st, ncolv);
 }
 
