@@ -6,7 +6,8 @@ one `__solve!`, multilevel.jl:214-239) over the whole 16.7 M-unknown system, on 
 built by `ruge_stuben` defaults (symmetric Gauss-Seidel pre/post), with b already resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256]
-    python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...   (N > 1)
+    python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...   (N > 1, a launcher's RANK / WORLD_SIZE)
+    python bench.py --gpus N ...        (N > 1, no launcher: bench.py spawns its N ranks itself, `self_launch`)
 
 Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for the definitions.
 """
@@ -139,6 +140,64 @@ def cpu_baseline(ml, b, budget_s=20.0):
                       "CPU restatement of the reference's _solve cycle (Julia is not installed), gcc -O3 -march=native"}, z
 
 
+def self_launch(nranks):
+    """`python bench.py --gpus N` with N > 1 and no launcher's environment (RANK / WORLD_SIZE absent): spawn the N ranks — this
+    same command line, one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run
+    would — forward rank 0's ONE JSON line as this process's stdout and return the worst child's exit code.  A rank that dies
+    takes the others with it after a grace period (they would wait for it in a collective for ever); children are killed by PID."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                AMGH_BENCH_LAUNCHER="self")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(nranks):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout carries the line; the other ranks' stdout (nothing, by construction) joins stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), stderr=None))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    grace = float(os.environ.get("AMGH_BENCH_GRACE_S", "30"))
+    first_bad = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_bad is None:
+            first_bad = time.perf_counter()
+            print(f"bench.py: rank {procs.index(bad[0])} exited with code {bad[0].returncode}; the other ranks get {grace:.0f} s", file=sys.stderr, flush=True)
+        if first_bad is not None and time.perf_counter() - first_bad > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    reader.join(timeout=10)
+    rcs = [p.returncode for p in procs]
+    text = (out0[0] if out0 else b"").decode(errors="replace")
+    line = None
+    for ln in text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    for ln in text.splitlines():                      # anything else rank 0 wrote to stdout is not the line: stderr
+        if ln.strip() and ln.strip() != line:
+            print(ln, file=sys.stderr)
+    worst = max((abs(rc) if rc is not None else 1) for rc in rcs)
+    if line is not None and worst == 0:
+        print(line, flush=True)
+        return 0
+    print(f"bench.py: self-launched run failed: exit codes by rank {rcs}" + ("" if line else "; rank 0 printed no JSON line"), file=sys.stderr, flush=True)
+    return worst or 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,11 +218,16 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="N > 1: skip the secondary measurements (Jacobi-smoothed hierarchy, IPC transport)")
     ap.add_argument("--setup", default="gpu", choices=("gpu", "host"), help="where the data-parallel half of ruge_stuben runs")
+    ap.add_argument("--host-exec", action="store_true",
+                    help="N > 1 launcher self-test on a box without GPUs: the library's own sharded cycle (amgh_dist_*) executed in host "
+                         "memory over the shared-memory transport, checked against the oracle — functional, never a measurement")
     ap.add_argument("--no-overlap", action="store_true",
                     help="with --setup gpu: build the HBM hierarchy after ruge_stuben instead of level by level beside it")
     args = ap.parse_args()
 
-    if args.gpus > 1 or args.force_dist:
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)   # started the way `--gpus 1` is started: no launcher — be the launcher
+    if args.gpus > 1 or args.force_dist or args.host_exec:
         from bench_dist import main_distributed  # row-sharded path (torch.distributed over RCCL)
         return main_distributed(args)
 
@@ -386,4 +450,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -6,6 +6,9 @@ level.
 
 Launched by:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                   --master-port P bench.py --gpus N --steps K --warmup W [--transport rccl|ipc] [--smoother gs|jacobi]
+         or:  python bench.py --gpus N ...   (no launcher: bench.py spawns its N ranks itself, bench.self_launch)
+The rendezvous is bounded (AMGH_RENDEZVOUS_TIMEOUT_S, default 600): a rank whose peers never arrive fails with a message that
+names the launcher instead of waiting for ever.  `--host-exec` is the launcher's self-test on a box without GPUs.
 
 One run measures up to three configurations on the SAME hierarchy (A, P, R of every level are shared):
   primary    --smoother (default gs: ruge_stuben defaults, BASELINE.json C4) over --transport (default rccl: RCCL
@@ -100,7 +103,7 @@ class Run:
         self.ctx, self.label = ctx, label
         t0 = time.perf_counter()
         self.sh = SH.ShardedHierarchy(levels, ctx["info"]["n_tail"] if n_tail is None else n_tail, tail, ctx["rank"], ctx["world"], ctx["device"],
-                                      transport, gs_mode=gs_mode)
+                                      transport, gs_mode=gs_mode, host_tail=ctx.get("host_tail"))
         self.shard_s = time.perf_counter() - t0
         self.transport = transport[0]
         self.pipelined = self.sh.gs_pipelined()
@@ -130,7 +133,7 @@ class Run:
         """fine-level sharded SpMV (neighbour exchange + local rows) on the level's resident x, timed like the cycle"""
         import amg_amd as AMG
         sh = self.sh
-        if sh.lc == 0:
+        if sh.lc == 0 or sh.host_exec:
             return None
         y = AMG.DeviceBuffer(max(sh.nloc, 1), self.ctx["device"])
         for _ in range(3):
@@ -141,6 +144,28 @@ class Run:
             sh.lib.amgh_dist_spmv_d(sh.h, 0, None, y.ptr)
         sh.barrier()
         return 1e3 * float(sh.allreduce([time.perf_counter() - t0], "max")[0]) / reps
+
+    def tail_ms(self, reps=5):
+        """The part of the cycle that does NOT shard: one visit of the collapsed levels (everything below the sharded ones, coarse
+        solve included) on the rank that owns them, timed alone on the handle's stream — `serial_ms_on_rank0` of the line.  Not a
+        collective: the owner measures while the other ranks wait at the next barrier."""
+        import amg_amd as AMG
+        sh = self.sh
+        if sh.tail is None or sh.host_exec:
+            return None
+        nt = sh.tail.ml.levels[0].A.m if sh.tail.ml.levels else sh.tail.ml.final_A.m
+        bt = AMG.DeviceBuffer(nt, self.ctx["device"], np.linspace(0.1, 1.0, nt))
+        zt = AMG.DeviceBuffer(nt, self.ctx["device"])
+        lib = sh.lib
+        for _ in range(2):
+            if lib.amgh_precond_apply_d(sh.tail.h, bt.ptr, zt.ptr, 0) != 0:
+                return None
+        sh.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lib.amgh_precond_apply_d(sh.tail.h, bt.ptr, zt.ptr, 0)
+        sh.sync()
+        return 1e3 * (time.perf_counter() - t0) / reps
 
     def close(self):
         self.sh.barrier()
@@ -176,6 +201,35 @@ def check_parity(ctx, ml, b, z, kind, gs_mode="exact"):
     return {"rel_err": err, "tolerance": PARITY_TOL, "what": what, "ok": bool(err <= PARITY_TOL)}
 
 
+def amdahl(primary, info, world, N):
+    """What a reader of a flat curve needs: the levels below the sharded ones run on ONE rank (exact lexicographic Gauss-Seidel on
+    merged dependency-level groups does not shard), so the cycle cannot drop below that serial part whatever N is."""
+    serial = primary.get("tail_ms")
+    out = {"sharded_levels": primary.get("sharded_levels"), "collapsed_levels_rows": info["sizes"][primary.get("sharded_levels") or 0:],
+           "serial_ms_on_rank0": serial}
+    if serial is None:
+        return out
+    t1, src = None, None
+    try:   # the single-GPU cycle of the same problem as this repository last measured it (a run at N > 1 does not hold the unsharded layout)
+        here = os.path.dirname(os.path.abspath(__file__))
+        for name in ("r06_bench_256.json", "r05_bench_256.json"):
+            f = os.path.join(here, "profiles", name)
+            if N == 256 and os.path.exists(f):
+                t1, src = float(json.load(open(f))["ms_per_step"]), "profiles/" + name
+                break
+    except Exception:  # noqa: BLE001
+        pass
+    out["amdahl"] = {
+        "what": "levels >= sharded_levels (merged-group / dense Gauss-Seidel sweeps, coarse solve) run on rank 0 alone: ms_per_step >= "
+                "serial_ms_on_rank0 for every N; with the sharded part scaling perfectly the cycle is serial + (T1 - serial) / N",
+        "serial_ms_on_rank0": serial, "sharded_part_ms_this_run": primary["ms_per_step"] - serial,
+        "single_gpu_ms": t1, "single_gpu_ms_source": src,
+        "best_possible_ms_at_this_N": None if t1 is None else serial + max(0.0, t1 - serial) / world,
+        "max_speedup_at_this_N": None if t1 is None else t1 / (serial + max(0.0, t1 - serial) / world),
+        "max_speedup_any_N": None if t1 is None else t1 / serial}
+    return out
+
+
 def main_distributed(args):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("NCCL_DEBUG", "WARN")
@@ -195,8 +249,15 @@ def main_distributed(args):
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
+        rdv_s = float(os.environ.get("AMGH_RENDEZVOUS_TIMEOUT_S", "600"))
         try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            import datetime
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=rdv_s))
+        except Exception as ex:  # noqa: BLE001  (a rank that never arrives: say who was expected to start it, then fail — never wait for ever)
+            raise SystemExit(f"bench_dist.py: rank {rank} of {world} found no peers at {os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']} within "
+                             f"{rdv_s:.0f} s ({type(ex).__name__}: {str(ex)[:200]}). Launcher: {os.environ.get('AMGH_BENCH_LAUNCHER', 'external (RANK / WORLD_SIZE were set by the caller)')}; "
+                             f"start the ranks with `python bench.py --gpus {world}` (bench.py spawns them) or `python -m torch.distributed.run --nnodes=1 "
+                             f"--nproc-per-node {world} --master-addr 127.0.0.1 bench.py --gpus {world}`")
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
@@ -228,9 +289,12 @@ def main_distributed(args):
     from amg_amd import sharded as SH
     from bench import cpu_baseline, spmv_bytes, uniform
 
+    host_exec = bool(getattr(args, "host_exec", False))   # launcher self-test without GPUs: amgh_dist_* executed in host memory
     one_gpu = os.environ.get("AMG_DIST_ONE_GPU") == "1"   # functional check on a single-GPU box: every rank on device 0
-    ngpu = int(AMG.hip_lib().amgh_device_count())
-    if not one_gpu and ngpu < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+    ngpu = 0 if host_exec else int(AMG.hip_lib().amgh_device_count())
+    if host_exec:
+        one_gpu = False
+    elif not one_gpu and ngpu < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
         # more ranks than devices (every rank sees the same count): ranks that set a missing device would fail while the
         # others wait in a collective for ever — run the functional mode instead and say so in the line
         one_gpu = True
@@ -248,12 +312,28 @@ def main_distributed(args):
     n = N ** 3
     # ---- host hierarchy: once per node --------------------------------------------------------------------------
     t0 = time.perf_counter()
-    levels, info, tail, shm = node_levels(rank, world, bcast,
-                                          lambda: AMG.ruge_stuben(AMG.poisson((N, N, N)), setup=getattr(args, "setup", "gpu")))
+    if host_exec:
+        # three levels, both sparse ones sharded whatever their size: what is collapsed onto rank 0 is the coarse solve alone —
+        # the host mirror's own Pinv (coarse_solver.jl:9-16), so that nothing of this mode's cycle comes from the checker
+        transport, local_rank, secondary = "ipc", -1, False
+        levels, info, tail, shm = node_levels(rank, world, bcast,
+                                              lambda: AMG.ruge_stuben(AMG.poisson((N, N, N)), setup="host", max_levels=3, coarse_solver=AMG.Pinv),
+                                              shard_min_rows=1)
+    else:
+        levels, info, tail, shm = node_levels(rank, world, bcast,
+                                              lambda: AMG.ruge_stuben(AMG.poisson((N, N, N)), setup=getattr(args, "setup", "gpu")))
     t_setup = time.perf_counter() - t0
     ml = info["ml"]                                        # rank 0 only
     gdir = bcast(tempfile.mkdtemp(prefix="amgh_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) if rank == 0 else None)
     ctx = dict(rank=rank, world=world, device=local_rank, info=info, gdir=gdir, barrier=host_barrier)
+    if host_exec:
+        if rank == 0:
+            if tail.levels:
+                raise SystemExit("bench_dist.py --host-exec: the hierarchy left sparse levels unsharded (grid too small for this many ranks)")
+            pinv = tail.coarse_solver.dense_operator()
+            ctx["host_tail"] = lambda bb: pinv @ bb
+        else:
+            ctx["host_tail"] = True
     jac = AMG.Jacobi(2.0 / 3.0)
     jac_tuple = SH._smoother_tuple(jac)
 
@@ -349,7 +429,7 @@ def main_distributed(args):
         return rec
 
     preflights = []
-    if world > 1 and not getattr(args, "no_preflight", False):
+    if world > 1 and not getattr(args, "no_preflight", False) and not host_exec:
         order = [transport] + [t for t in ("rccl", "ipc", "ipc-staged") if t != transport and not (one_gpu and t == "rccl")]
         chosen = None
         for tk in order:
@@ -389,7 +469,7 @@ def main_distributed(args):
         rows, nnz = info["sizes"][l], info["level_nnz"][l]
         return rows >= 3_000_000 or (rows >= 1_500_000 and nnz <= 7 * rows)
     lc_exact = 0
-    while lc_exact < lc_all and pipelines(lc_exact):
+    while lc_exact < lc_all and (pipelines(lc_exact) or host_exec):
         lc_exact += 1
     lc_exact = max(min(1, lc_all), lc_exact)
     tail_exact = None
@@ -413,6 +493,7 @@ def main_distributed(args):
         res, z_loc = run.measure(b, args.steps, args.warmup)
         if want_spmv:
             res["spmv_ms"] = run.spmv_ms()
+            res["tail_ms"] = run.tail_ms()               # (the owner of the collapsed levels only; the others wait below)
         z = assemble_on_rank0(ctx, label, z_loc)
         if rank == 0:
             res["parity"] = check_parity(ctx, ml_k, b, z, kind, gs_mode)
@@ -463,13 +544,17 @@ def main_distributed(args):
     if rank == 0:
         alg = spmv_bytes(info["nnz"], n, n)
         spmv_ms = primary.get("spmv_ms")
+        piped = any(primary.get("gs_pipelined_by_level") or [])
         smooth_txt = ("ruge_stuben defaults (symmetric Gauss-Seidel pre+post in exact lexicographic order over the whole level — the "
-                      "reference's iterate — as ONE sweep pipelined across the ranks: all ranks launch at once, a block polls the rows "
+                      "reference's iterate — " + ("as ONE sweep pipelined across the ranks: all ranks launch at once, a block polls the rows "
                       "it reads of the neighbouring rank in that rank's peer-mapped mailboxes; the levels with block layouts are "
-                      "sharded on this curve (gs_pipelined_by_level), the ones below are swept on rank 0)"
+                      "sharded on this curve (gs_pipelined_by_level), the ones below are swept on rank 0)" if piped else
+                      "the ranks sweeping in turn (no level runs the pipelined sweep in this run: gs_pipelined_by_level))")
                       if smoother == "gs" else "Jacobi(2/3) pre+post (exact across shards)")
         tr_txt = {"rccl": "RCCL send/recv called by libamghip", "ipc": "hipIpc peer-mapped send buffers + stream-written "
                   "flags in shared memory (libamghip's IPC transport)"}[primary["transport"]]
+        if host_exec:
+            tr_txt = "host memory, shared-memory rendezvous of libamghip's IPC transport"
         strip = lambda r: {k: v for k, v in r.items() if k not in ("elapsed",)}  # noqa: E731
         out = {
             "metric": f"V-cycle unknowns/sec + fine-level SpMV GB/s (% HBM peak), 3-D Poisson {N}^3",
@@ -486,6 +571,8 @@ def main_distributed(args):
                        "halo_bytes_sent_per_cycle_max_rank": primary["halo_bytes_sent_per_cycle_max_rank"],
                        "halo_bytes_sent_per_cycle_all_ranks": primary["halo_bytes_sent_per_cycle_all_ranks"],
                        "all_ranks_on_one_gpu": bool(one_gpu and world > 1),
+                       "host_execution": ("launcher self-test: amgh_dist_* executed in host memory over the shared-memory transport, 3-level "
+                                          "hierarchy, Gauss-Seidel across the ranks in turns — functional, NOT a measurement") if host_exec else None,
                        # lexicographic Gauss-Seidel is ONE dependency chain through the whole grid: in exact order the shards of a
                        # level sweep one after the other (the value of this line: the reference's iterate, a flat curve in N); the
                        # curves that CAN scale are secondary["gs_hybrid"] (every shard at once, halo frozen per directional sweep:
@@ -510,6 +597,10 @@ def main_distributed(args):
                                 "note": "rank 0 builds the hierarchy while the other ranks wait; every rank then lays out its own shard "
                                         "(halo plans, smoother schedules, block plans) in per_rank_plans_and_upload_s"},
             "preflight": preflights, "transport_used": primary["transport"],
+            "launcher": os.environ.get("AMGH_BENCH_LAUNCHER", "external") + (" (bench.py spawned its ranks)" if os.environ.get("AMGH_BENCH_LAUNCHER") == "self"
+                                                                              else " (RANK / WORLD_SIZE set by the caller, e.g. torch.distributed.run)"),
+            "ranks": world, "devices_visible": ngpu,
+            **amdahl(primary, info, world, N),
             **({"secondary": {k: strip(v) for k, v in extra.items()}} if extra else {}),
             **notes,
         }

@@ -97,3 +97,72 @@ def test_ipc_dead_peer_does_not_hang_the_others():
     for r in (0, 1):
         rc, out = outs[r]
         assert rc == 0 and f"IPC_PLAN_RANK_{r}_SAW_DEAD_PEER" in out, (r, out[-3000:])
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra)
+    return env
+
+
+def test_bench_gpus_2_starts_by_itself_and_finishes():
+    """`python bench.py --gpus 2`, started the way the driver starts `--gpus 1` (no launcher, no RANK / WORLD_SIZE): bench.py
+    spawns its two ranks, they rendezvous over gloo, run the library's own sharded cycle (here in host memory: --host-exec, the
+    launcher's self-test on a box without GPUs), rank 0 checks the assembled result against the oracle, and the parent process
+    prints rank 0's ONE JSON line and returns 0 — no hang (multilevel.jl:214-239 is the cycle)."""
+    import json
+    import time
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "24", "--steps", "2", "--warmup", "1",
+                        "--host-exec", "--cpu-budget", "0.5"], env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                   # stdout is the line and nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["steps"] == 2 and d["launcher"].startswith("self")
+    assert d["parity"]["ok"] and d["parity"]["rel_err"] <= 1e-10
+    assert d["config"]["sharded_levels"] == 2 and d["config"]["host_execution"]
+    assert d["config"]["halo_exchanges_per_cycle"] > 0
+    assert time.perf_counter() - t0 < 300
+
+
+def test_bench_gpus_3_host_exec_three_ranks():
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--size", "20", "--steps", "1", "--warmup", "0",
+                        "--host-exec", "--no-cpu-baseline"], env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads(r.stdout.decode().strip())
+    assert d["n_gpus"] == 3 and d["parity"]["ok"]
+
+
+def test_bench_rendezvous_is_bounded_and_names_the_launcher():
+    """A rank whose peers never arrive (RANK / WORLD_SIZE set by a caller who launched nobody else) fails within the rendezvous
+    timeout with a message that says how to launch — it does not wait for ever."""
+    import socket
+    import time
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "16", "--host-exec"],
+                       env=_clean_env(RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AMGH_RENDEZVOUS_TIMEOUT_S="5"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+    assert time.perf_counter() - t0 < 120
+    err = r.stderr.decode()
+    assert "found no peers" in err and "python bench.py --gpus 2" in err, err[-2000:]
+    assert r.stdout.decode().strip() == ""
+
+
+def test_bench_self_launch_fails_fast_when_a_rank_dies():
+    """Without --host-exec on a box without GPUs every rank fails at its first look for a device: the parent returns non-zero
+    promptly (a rank that dies takes the others with it after the grace period) and prints no line."""
+    import time
+    if AMG.gpu_available():
+        import pytest
+        pytest.skip("a GPU is visible: the ranks would run")
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "16", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=_clean_env(AMGH_BENCH_GRACE_S="5"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and r.stdout.decode().strip() == ""
+    assert time.perf_counter() - t0 < 120

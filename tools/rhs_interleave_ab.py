@@ -1,6 +1,6 @@
 """bs = 8 cycle of the 256^3 hierarchy with restriction / prolongation through the interleaved copy (tunable rhs_il = 1; per operator the
 kernel amgh_finalize timed as faster) against column by column everywhere (rhs_il = 0), with the per-level times.  AMGH_VERBOSE=1 prints
-the timings behind the choice.   usage: python tools/il_test.py"""
+the timings behind the choice.   usage: python tools/rhs_interleave_ab.py"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
