@@ -202,6 +202,7 @@ def _bind_dist(L):
     L.amgh_dist_set_gs_mode.argtypes = [vp, C.c_int]
     L.amgh_dist_gs_pipelined.argtypes = [vp, C.c_int]
     L.amgh_dist_pipe_serialized.argtypes = [vp]
+    L.amgh_dist_pipe_protocol_failed.argtypes = [vp]
     L.amgh_dist_num_sharded_levels.argtypes = [vp]
     L.amgh_dist_local_range.argtypes = [vp, C.c_int, i64p, i64p]
     L.amgh_dist_precond_apply_d.argtypes = [vp, vp, vp, C.c_int]

@@ -969,7 +969,8 @@ int amgh_finalize(amgh_t* h) {
       const int64_t n = L->n, nc = L->nc;
       auto timed = [&](auto&& fn, double* ms) -> int {
         hipEvent_t e0, e1;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1001;
+        if (hipEventCreate(&e0) != hipSuccess) return -1001;
+        if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return -1001; }
         int rc = fn();
         if (rc == AMGH_OK && hipEventRecord(e0, h->stream) != hipSuccess) rc = -1001;
         for (int r = 0; r < 2 && rc == AMGH_OK; ++r) rc = fn();

@@ -437,6 +437,8 @@ struct amgh_dist {
   bool host_exec = false;
   std::vector<real> h_pack;            // host execution: the packed send entries of the exchange under way
   bool gs_exact = true;                // Gauss-Seidel / SOR across the shards: exact lexicographic order or the hybrid (amgh_dist_set_gs_mode)
+  bool tail_agreed = false;            // every rank has seen (collectively, at the first data-path call) that the owner holds the collapsed levels
+  bool pipe_mail_failed = false;       // the mailbox protocol probe between neighbouring ranks failed (dist_pipe_mail_probe): the levels sweep in turns
   bool pipe_serial = false;            // ranks of this process sharing the device were found NOT to run concurrently (dist_pipe_probe): the levels sweep in turns
   bool gs_pipe = true;                 // ... exact order as ONE pipelined sweep where the level allows it (DistLevel::Pipe::on), else the ranks in turn
   int nplans = 0;
@@ -853,11 +855,19 @@ int dist_resnorm(amgh_dist* d, real* out) {
   return AMGH_OK;
 }
 
-int dist_check(const amgh_dist* d) {
+int dist_check(amgh_dist* d) {
   if (!d) return AMGH_EINVAL;
   if (!d->finalized) return AMGH_ESTATE;
   if (d->host_only && !d->host_exec) return AMGH_EUNSUPPORTED;  // plans only: there is no data path without a device or a host tail
-  if (!d->host_only && !d->tail && d->xplan.back().nloc() > 0) return AMGH_ESTATE;   // the owner of the collapsed levels has not passed them yet
+  if (!d->tail_agreed) {
+    // The owner of the collapsed levels may pass them after amgh_dist_finalize (amgh_dist_set_tail, not collective).  Whether it
+    // HAS is settled collectively at the first data-path call: an owner without its tail fails this call on EVERY rank — alone it
+    // would return while the others enter the cycle's exchanges and wait for it (RCCL has no timeout).
+    double missing = (!d->host_only && !d->tail && d->xplan.back().nloc() > 0) ? 1.0 : 0.0;
+    RC_TRY(d->tr->allreduce(&missing, 1, true));
+    if (missing != 0.0) return AMGH_ESTATE;
+    d->tail_agreed = true;
+  }
   return AMGH_OK;
 }
 
@@ -996,6 +1006,7 @@ int amgh_dist_gs_pipelined(const amgh_dist_t* d, int level) {
 // 1 when levels that could have been pipelined sweep in turns because the ranks sharing this device inside one process do not
 // run concurrently (their streams share a hardware queue)
 int amgh_dist_pipe_serialized(const amgh_dist_t* d) { return (d && d->finalized) ? (d->pipe_serial ? 1 : 0) : -1; }
+int amgh_dist_pipe_protocol_failed(const amgh_dist_t* d) { return (d && d->finalized) ? (d->pipe_mail_failed ? 1 : 0) : -1; }
 
 void amgh_dist_destroy(amgh_dist_t* d) {
   if (!d) return;
@@ -1149,6 +1160,115 @@ int dist_pipe_probe(amgh_dist* d, int64_t where, bool* ok) {
   return AMGH_OK;
 }
 
+// The mailbox protocol ITSELF between neighbouring ranks, before any level depends on it: on memory allocated and mapped exactly
+// as the levels' mailbox arrays are (hipMalloc; the neighbour's through its pointer — same process, peer access enabled when it
+// lives on another device — or hipIpcOpenMemHandle) and with the instructions the sweeps use: a walker's write-through store
+// (Mail<real>::store, sc1) polled by the neighbour's fetcher (Mail<real>::load_sys, sc0 sc1).  Two ranks on two devices is the case
+// this exists for: an agent-scope store to coarse-grained memory is not PROMISED to become visible to another agent's system-scope
+// loads mid-kernel; where it does not (or the mapping fails), the polls below run into their bound and every level sweeps with the
+// ranks in turn.  kMailProbeRounds rounds in lockstep, a fresh cell per round (a cell is written once per epoch, as in the sweeps),
+// values checked.  One lane per rank.
+constexpr int kMailProbeRounds = 64;
+__global__ void pipe_mail_probe_kernel(void* mine, const void* prev, const void* next, int me, int rounds, long long ticks, unsigned* result, int mute) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  typedef bw::Mail<real> M;
+  const __amdgpu_buffer_rsrc_t rs_me = __builtin_amdgcn_make_buffer_rsrc(mine, 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_pv = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(prev ? prev : (const void*)mine), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_nx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(next ? next : (const void*)mine), 0, 0x7ffffff0, 0x00020000);
+  const long long t0 = wall_clock64();
+  unsigned res = 1u;
+  for (int r = 1; r <= rounds && res == 1u; ++r) {
+    // side 0: the cells rank - 1 reads, side 1: the cells rank + 1 reads
+    if (!mute) {
+      M::store(rs_me, (unsigned)((0 * rounds + (r - 1)) * M::kBytes), (real)(1000 * me + r), (unsigned)r);
+      M::store(rs_me, (unsigned)((1 * rounds + (r - 1)) * M::kBytes), (real)(1000 * me + r), (unsigned)r);
+    }
+    bool got_p = prev == nullptr, got_n = next == nullptr;
+    while (!(got_p && got_n)) {
+      if (!got_p) {
+        const typename M::cell c = M::load_sys(rs_pv, (unsigned)((1 * rounds + (r - 1)) * M::kBytes));
+        if (M::valid(c, (unsigned)r)) { got_p = true; if (M::value(c) != (real)(1000 * (me - 1) + r)) res = 3u; }
+      }
+      if (!got_n) {
+        const typename M::cell c = M::load_sys(rs_nx, (unsigned)((0 * rounds + (r - 1)) * M::kBytes));
+        if (M::valid(c, (unsigned)r)) { got_n = true; if (M::value(c) != (real)(1000 * (me + 1) + r)) res = 3u; }
+      }
+      if (wall_clock64() - t0 > ticks) { res = 2u; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  *result = res;
+}
+// collective; *ok = false when some pair of neighbouring ranks cannot run the protocol (mapping, peer access, visibility, bound)
+int dist_pipe_mail_probe(amgh_dist* d, int64_t where, bool* ok) {
+  Transport* tr = d->tr;
+  const int N = tr->nranks, me = tr->rank;
+  *ok = true;
+  const size_t bytes = (size_t)2 * kMailProbeRounds * bw::Mail<real>::kBytes + 16;
+  void* cells = nullptr;
+  double fail = 0.0;
+  if (hipMalloc(&cells, bytes) != hipSuccess || hipMemset(cells, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); fail = 1.0; }
+  hipIpcMemHandle_t hnd;
+  std::memset(&hnd, 0, sizeof hnd);
+  if (cells && hipIpcGetMemHandle(&hnd, cells) != hipSuccess) { (void)hipGetLastError(); std::memset(&hnd, 0, sizeof hnd); }
+  std::vector<int64_t> mine{(int64_t)getpid(), where, (int64_t)(uintptr_t)cells};
+  { int64_t hw[8]; std::memcpy(hw, &hnd, 64); for (int k = 0; k < 8; ++k) mine.push_back(hw[k]); }
+  mine.push_back((int64_t)d->device);
+  std::vector<std::vector<int64_t>> all;
+  RC_TRY(tr->allgatherv_host(mine, all));
+  const void* nb[2] = {nullptr, nullptr};
+  void* opened[2] = {nullptr, nullptr};
+  for (int side = 0; side < 2 && fail == 0.0; ++side) {
+    const int p = side == 0 ? me - 1 : me + 1;
+    if (p < 0 || p >= N) continue;
+    const std::vector<int64_t>& v = all[(size_t)p];
+    if (v.size() < 12 || v[2] == 0) { fail = 1.0; break; }
+    if (v[0] == (int64_t)getpid()) {
+      if (v[1] != where) {   // the same process, another device: the raw pointer is only usable with peer access
+        int can = 0;
+        const int pdev = (int)v[11];
+        if (hipDeviceCanAccessPeer(&can, d->device, pdev) != hipSuccess || !can) { (void)hipGetLastError(); fail = 1.0; break; }
+        const hipError_t e = hipDeviceEnablePeerAccess(pdev, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); fail = 1.0; break; }
+        (void)hipGetLastError();
+      }
+      nb[side] = (const void*)(uintptr_t)v[2];
+    } else {
+      hipIpcMemHandle_t h2;
+      std::memcpy(&h2, v.data() + 3, 64);
+      if (hipIpcOpenMemHandle(&opened[side], h2, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); opened[side] = nullptr; fail = 1.0; break; }
+      nb[side] = opened[side];
+    }
+  }
+  unsigned* result = nullptr;
+  if (dev_alloc(&result, 2) != AMGH_OK || hipMemset(result, 0, 8) != hipSuccess) fail = 1.0;
+  // (every rank launches or none does: a rank that could not map its neighbour would leave that neighbour polling into its bound)
+  RC_TRY(tr->allreduce(&fail, 1, true));
+  if (fail == 0.0) {
+    int rc = tr->barrier();
+    if (rc == AMGH_OK) {
+      long long ticks = 20000000;   // 200 ms of the 100 MHz clock
+      if (const char* e = getenv("AMGH_MAIL_PROBE_MS")) ticks = std::max(1ll, atoll(e)) * 100000ll;
+      int mute = 0;   // test hook: this rank publishes nothing — its neighbours run into the bound (a forced protocol failure)
+      if (const char* e = getenv("AMGH_MAIL_PROBE_MUTE")) mute = atoi(e) == me ? 1 : 0;
+      hipLaunchKernelGGL(pipe_mail_probe_kernel, dim3(1), dim3(64), 0, d->stream, cells, nb[0], nb[1], me, kMailProbeRounds, ticks, result, mute);
+      unsigned res = 0;
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess ||
+          hipMemcpy(&res, result, 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); fail = 1.0; }
+      else if (res != 1u) fail = 1.0;
+      if (getenv("AMGH_VERBOSE") && res != 1u) fprintf(stderr, "[amghip] rank %d: mailbox protocol probe with its neighbours: %s\n", me, res == 2u ? "no answer within the bound" : res == 3u ? "wrong value" : "not run");
+    } else fail = 1.0;
+    const int rc2 = tr->allreduce(&fail, 1, true);   // (also: nobody unmaps or frees cells a neighbour's kernel may still poll)
+    if (rc2 != AMGH_OK) fail = 1.0;
+  }
+  for (int side = 0; side < 2; ++side) if (opened[side]) (void)hipIpcCloseMemHandle(opened[side]);
+  (void)tr->barrier();
+  if (result) hipFree(result);
+  if (cells) hipFree(cells);
+  *ok = fail == 0.0;
+  return AMGH_OK;
+}
+
 int dist_pipe_setup(amgh_dist* d) {
   Transport* tr = d->tr;
   const int N = tr->nranks, me = tr->rank;
@@ -1174,6 +1294,50 @@ int dist_pipe_setup(amgh_dist* d) {
   (void)gethostname(host, sizeof host - 1);
   if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, d->device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", d->device); }
   const int64_t where = (int64_t)((fnv1a(host) ^ (fnv1a(bus) * 31ull)) >> 1);
+  {
+    // no level qualifies anywhere: nothing to map, nothing to probe
+    bool any_level = false;
+    for (int l = 0; l < lc; ++l) any_level = any_level || bad[(size_t)l] == 0.0;
+    if (!any_level) return AMGH_OK;
+    // ranks of one process: the sweep streams must run side by side for the protocol probe as for the sweeps (see below)
+    bool protocol = true;
+    bool concurrent = true;
+    RC_TRY(dist_pipe_probe(d, where, &concurrent));
+    // Two ranks of this process on one hardware queue: the runtime hands queues out round-robin at stream creation, so the ranks
+    // take fresh sweep streams ONE AFTER THE OTHER (rank order, a barrier between them: N consecutive creations land on N
+    // different queues while N <= GPU_MAX_HW_QUEUES) and the probe runs again.  Nothing has been enqueued on the old stream
+    // that a later call depends on (the collapsed levels are bound to the handle's stream after this), so it is simply replaced.
+    for (int attempt = 0; attempt < 3 && !concurrent; ++attempt) {
+      double bad_stream = 0.0;
+      for (int p = 0; p < N; ++p) {
+        if (p == me) {
+          hipStream_t fresh = nullptr;
+          if (hipStreamSynchronize(d->stream) != hipSuccess || hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); bad_stream = 1.0; }
+          else { (void)hipStreamDestroy(d->stream); d->stream = fresh; }
+        }
+        RC_TRY(tr->barrier());
+      }
+      RC_TRY(tr->allreduce(&bad_stream, 1, true));
+      if (bad_stream != 0.0) break;
+      RC_TRY(dist_pipe_probe(d, where, &concurrent));
+      if (getenv("AMGH_VERBOSE") && me == 0)
+        fprintf(stderr, "[amghip] sweep streams of the ranks sharing a device re-created in rank order (attempt %d): %s\n", attempt + 1, concurrent ? "concurrent" : "still serialised");
+    }
+    const bool side_by_side = concurrent;
+    if (!side_by_side) {
+      d->pipe_serial = true;
+      if (getenv("AMGH_VERBOSE") && me == 0)
+        fprintf(stderr, "[amghip] ranks sharing a device do not run concurrently (their streams share a hardware queue): Gauss-Seidel across the ranks in turns\n");
+      return AMGH_OK;
+    }
+    RC_TRY(dist_pipe_mail_probe(d, where, &protocol));
+    d->pipe_mail_failed = side_by_side && !protocol;
+    if (side_by_side && !protocol) {
+      if (getenv("AMGH_VERBOSE") && me == 0)
+        fprintf(stderr, "[amghip] the mailbox protocol did not come back right between neighbouring ranks (mapping / peer access / visibility): Gauss-Seidel across the ranks in turns\n");
+      return AMGH_OK;
+    }
+  }
   for (int l = 0; l < lc; ++l) {
     DistLevel* L = d->levels[l];
     VecPlan& xp = d->xplan[l];
@@ -1264,19 +1428,6 @@ int dist_pipe_setup(amgh_dist* d) {
     } else fail = bad[(size_t)l];
     RC_TRY(tr->allreduce(&fail, 1, true));
     L->pipe.on = fail == 0.0;
-  }
-  // ranks of one process on one device: only if their sweep streams really run concurrently
-  bool any = false;
-  for (int l = 0; l < lc; ++l) any = any || d->levels[l]->pipe.on;
-  if (any) {
-    bool concurrent = true;
-    RC_TRY(dist_pipe_probe(d, where, &concurrent));
-    if (!concurrent) {
-      d->pipe_serial = true;
-      for (int l = 0; l < lc; ++l) d->levels[l]->pipe.on = false;
-      if (getenv("AMGH_VERBOSE") && me == 0)
-        fprintf(stderr, "[amghip] ranks sharing a device do not run concurrently (their streams share a hardware queue): Gauss-Seidel across the ranks in turns\n");
-    }
   }
   if (getenv("AMGH_VERBOSE") && me == 0)
     for (int l = 0; l < lc; ++l)

@@ -620,6 +620,10 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
   } else {
     g->s_dir = -1;
   }
+  // a sweep marked as one of a row-sharded level pipelined across the ranks (amghip_dist.hpp) exists only as the relayed dataflow
+  // kernel on the extended lists: on any other path (a tunable switched the dataflow off, no block layout) the halo would stay
+  // frozen — a hybrid sweep executed silently under the exact mode.  Refuse.
+  if (op->pipe_epoch && !(g->bw.on && g->bw.flow.on && (g_gs_bw_flow || !g->bw.rec))) return AMGH_ESTATE;
   if (g->bw.on) {   // wavefront of blocks
     hipError_t e = hipSuccess;
     const bool flow = g->bw.flow.on && (g_gs_bw_flow || !g->bw.rec);

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64 * (NC + 1), DICT ? FlowWavesD<MAXK>::value : Flo
   const unsigned int ut = (unsigned int)ticket, sweeps = (unsigned int)(ticket >> 32);
   const unsigned int epoch = sweeps + 1u;
   if (threadIdx.x == 0 && ut == units - 1u)
-    __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u == 0u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u >= 0x80000000u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int tk = (int)(ut / (unsigned)a.ngroups);
   const int c0 = (int)(ut % (unsigned)a.ngroups) * NC;
   const int nch = a.ncols - c0 < NC ? a.ncols - c0 : NC;   // columns of this group

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64 * (W + 1), DICT ? RelayWavesD<MAXK>::value : Rel
     const unsigned int ut = (unsigned int)ticket, sweeps = (unsigned int)(ticket >> 32);
     // whoever draws the launch's last ticket starts the next sweep's count (every other draw of this launch has happened by then)
     if (threadIdx.x == 0 && ut == draws - 1u)
-      __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u == 0u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u >= 0x80000000u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ut >= units) return;
     const unsigned int epoch = a.epoch ? a.epoch : sweeps + 1u;   // (a.epoch: the tag of a sweep that several launches share, amghip_dist.hpp)
     relay_block<R, SOR, BWD, MAXK, W, DICT>(a, lds_all, wv, lane, ut, epoch, t_start);

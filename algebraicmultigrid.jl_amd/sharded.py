@@ -230,15 +230,24 @@ class ShardedHierarchy:
                 tail_job = threading.Thread(target=_build)
                 tail_job.start()
         try:
-            hip_check(self.lib.amgh_dist_finalize(self.h), "dist_finalize")
-        finally:
+            try:
+                hip_check(self.lib.amgh_dist_finalize(self.h), "dist_finalize")
+            finally:
+                if tail_job is not None:
+                    tail_job.join()
             if tail_job is not None:
-                tail_job.join()
-        if tail_job is not None:
-            if "err" in box:
-                raise box["err"]
-            self.tail = box["tail"]
-            hip_check(self.lib.amgh_dist_set_tail(self.h, self.tail.h), "dist_set_tail")
+                if "err" in box:
+                    raise box["err"]
+                self.tail = box["tail"]
+                hip_check(self.lib.amgh_dist_set_tail(self.h, self.tail.h), "dist_set_tail")
+        except BaseException:
+            # nothing of a half-built rank stays behind: the handle first (it may borrow the tail), then the collapsed levels
+            self.lib.amgh_dist_destroy(self.h)
+            self.h = None
+            if tail_job is not None:
+                box.pop("tail", None)      # (DeviceHierarchy.__del__ destroys the collapsed levels' handle)
+            self.tail = None
+            raise
         self.set_gs_mode(gs_mode)
         r0, r1 = C.c_int64(0), C.c_int64(0)
         hip_check(self.lib.amgh_dist_local_range(self.h, 0, C.byref(r0), C.byref(r1)), "dist_local_range")
@@ -285,6 +294,11 @@ class ShardedHierarchy:
         """True when ranks of one process sharing one device were found not to run concurrently (their streams share a hardware
         queue) and every level was therefore left to the turn loop (`amgh_dist_pipe_serialized`)."""
         return self.device >= 0 and int(self.lib.amgh_dist_pipe_serialized(self.h)) == 1
+
+    def pipe_protocol_failed(self):
+        """True when the mailbox protocol probe between neighbouring ranks (`amgh_dist_pipe_protocol_failed`) did not come back
+        right at finalize — mapping, peer access or visibility across devices — and every level was left to the turn loop."""
+        return self.device >= 0 and int(self.lib.amgh_dist_pipe_protocol_failed(self.h)) == 1
 
     def close(self):
         """Destroy the sharded handle first (it borrows the collapsed levels' handle), then the tail."""

@@ -375,6 +375,12 @@ int amgh_dist_gs_pipelined(const amgh_dist_t* d, int level);
  * the same queue run one after the other — and therefore left every level to the turn loop (a pipelined sweep would wait for a
  * neighbour that cannot start); 0 otherwise, -1 before finalize.  Probed with a bounded flag exchange between the streams. */
 int amgh_dist_pipe_serialized(const amgh_dist_t* d);
+/* 1 when amgh_dist_finalize ran the mailbox protocol itself between neighbouring ranks — kMailProbeRounds lockstep rounds of the
+ * sweeps' own write-through store / system-scope poll on memory allocated and mapped as the levels' mailbox arrays are (the
+ * neighbour's pointer with peer access enabled, or hipIpcOpenMemHandle) — and it did NOT come back right (mapping, peer access,
+ * visibility across devices, the bound): every level is then left to the turn loop; 0 when it passed or was not needed, -1
+ * before finalize.  (The reference is one process, multilevel.jl:214-239; this guards the pipelined sweep across devices.)       */
+int amgh_dist_pipe_protocol_failed(const amgh_dist_t* d);
 int amgh_dist_num_sharded_levels(const amgh_dist_t* d);
 int amgh_dist_local_range(const amgh_dist_t* d, int level, int64_t* r0, int64_t* r1);
 /* ldiv! / _solve! on this rank's rows of the fine vectors (device pointers; collective).

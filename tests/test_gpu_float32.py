@@ -8,6 +8,8 @@ differ at 1e-13 .. 1e-11 (merged dependency levels, lanes-per-row sums); scaled 
 5e-5 relative in the 2-norm — written below as F32_TOL."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -250,7 +252,12 @@ def test_float32_gauss_seidel_pipelined_across_the_ranks():
     xo, _, _ = O.OracleHierarchy(ml, dtype=F32).solve(b, maxiter=2, calculate_residual=False)
     assert rel(out["exact"], xo) <= F32_TOL
     if serialized:
-        pytest.skip("the virtual ranks' streams shared a hardware queue in this process: swept in turns (oracle parity held)")
+        # (the library re-creates the ranks' sweep streams in rank order and probes again, three times, before it settles for turns:
+        # with the 8 hardware queues tests/conftest.py asks for, 2-4 virtual ranks must end up side by side)
+        msg = "the virtual ranks' streams shared a hardware queue in this process: swept in turns (oracle parity held)"
+        if os.environ.get("GPU_MAX_HW_QUEUES") == "8":
+            pytest.fail(msg + " although GPU_MAX_HW_QUEUES=8 was requested and the streams were re-created: the pipelined sweep did not run")
+        pytest.skip(msg)
 
 
 @pytest.mark.parametrize("bs", [1, 3, 4])
