@@ -170,6 +170,7 @@ def _bind_solve_phase(L, creal, coarse_fn):
     L.amgh_debug_bw_poll_giveups.argtypes = [vp, C.c_int]
     L.amgh_debug_bw_mode.argtypes = [vp, C.c_int]
     L.amgh_debug_bw_dict.argtypes = [vp, C.c_int]
+    L.amgh_debug_bw_late.argtypes = [vp, C.c_int]
     L.amgh_debug_coded_ops.argtypes = [vp, C.c_int]
     L.amgh_debug_bw_sweep_host.argtypes = [i64, vp, vp, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp]
     L.amgh_debug_bw_dict_sweep_host.argtypes = [i64, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]

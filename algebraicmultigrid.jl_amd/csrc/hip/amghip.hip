@@ -1089,6 +1089,11 @@ int amgh_debug_bw_dict(const amgh_t* h, int l) {
   const GsSchedule* g = h->levels[l]->smat()->gs;
   return g && g->bw.on && g->bw.flow.on && g->bw.flow.dict_on && (g_gs_bw_dict || !g->bw.flow.srec) && (g_gs_bw_flow || !g->bw.rec) ? 1 : 0;
 }
+int amgh_debug_bw_late(const amgh_t* h, int l) {
+  if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
+  const GsSchedule* g = h->levels[l]->smat()->gs;
+  return g && g->bw.on && g->bw.flow.on && g->bw.flow.late_ok && !g_gs_bw_inorder && g_gs_bw_relay > 0 && h->nrhs == 1 && (g_gs_bw_flow || !g->bw.rec) ? 1 : 0;
+}
 int amgh_debug_coded_ops(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
   const Level* L = h->levels[l];
@@ -1895,6 +1900,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_bw_grid")) g_gs_bw_grid = value < 0 ? 0 : value;
   else if (!strcmp(name, "gs_bw_grid_long")) g_gs_bw_grid_long = value < 0 ? 0 : value;
   else if (!strcmp(name, "gs_bw_dict")) g_gs_bw_dict = value != 0;
+  else if (!strcmp(name, "gs_bw_inorder")) g_gs_bw_inorder = value != 0;
   else if (!strcmp(name, "stream_code")) g_stream_code = value != 0;
   else if (!strcmp(name, "gs_bw_relay")) g_gs_bw_relay = value == 0 ? 0 : BW_RELAY_W;   // (one count is instantiated)
   else if (!strcmp(name, "rhs_il")) g_rhs_il = value;

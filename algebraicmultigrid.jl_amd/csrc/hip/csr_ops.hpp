@@ -647,6 +647,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       } else if (ncolv == 1 && g_gs_bw_relay > 0) {
         // (the persistent grid pays on the plain 19-point records only: 0.98 -> 0.87 ms there, 0.776 -> 0.787 on the dictionary layout)
         fa.grid = g->bw.maxk > 6 ? (dict ? 0 : g_gs_bw_grid_long) : g_gs_bw_grid;
+        fa.late = (g->bw.flow.late_ok && !g_gs_bw_inorder) ? 1 : 0;   // the dependency-aware row sum (gs_relay.hpp, LATE)
         if (dict) { fa.crec = g->bw.flow.crec; fa.dict = g->bw.flow.dict; fa.dict_ent = g->bw.flow.dict_ent; }
         e = bw::sweep_relay<real>(fa, g->bw.maxk, dict ? g->bw.flow.dict_lds : g->bw.flow.lds_max, sor, backward, st, BW_RELAY_W);
       } else {

@@ -113,6 +113,7 @@ struct Plan {
   double est_seconds = 0.0;         // modelled time of one directional sweep, one launch per depth ...
   double est_chain_seconds = 0.0;   // ... and as one launch, blocks chained by flags
   double est_flow_seconds = 0.0;    // ... and as a dataflow with relayed walks (gs_flow.hpp / gs_relay.hpp)
+  bool late_ok = false;             // every row's entries lie split around the padding with at most maxk / 2 on either side (the records' fill)
   int cuts[2] = {99, 99};
   int32_t range[3] = {1, 1, 1};
   int32_t cells[3] = {1, 1, 1};
@@ -482,6 +483,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
   P.ext_col.resize(ext_ptr[B]);
   lap("descriptors");
   P.rec.resize(rec_total);
+  std::atomic<int> late_bad{0};
   parallel_for(T, [&](int t, int TT) {
     std::vector<int32_t> where((size_t)cmax + 1);      // per thread: index of a position in the current block's external list
     for (int32_t ob = B * (int64_t)t / TT; ob < B * (int64_t)(t + 1) / TT; ++ob) {
@@ -504,7 +506,23 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
         R* v = (R*)(rec + (size_t)p * rs);
         uint16_t* cc = (uint16_t*)(rec + (size_t)p * rs + (size_t)16 * nvc);
         for (int k = 0; k < 8 * Packed<R>::ncc(d.maxk); ++k) cc[k] = zoff;
-        int k = 0;
+        // Entries in stored order, the padding in the MIDDLE: the columns that precede the row (new values of a forward sweep)
+        // from slot 0 up, the columns behind it (new values of a backward sweep) ending at slot maxk - 1.  A sum over all
+        // slots in order is the scalar loop's, bit for bit, wherever the zeros sit (an accumulator that starts at +0 never
+        // becomes -0); what the split buys is that the entries whose x may still be on its way lie in one HALF of the
+        // slots per direction (Plan::late_ok: every row has at most maxk / 2 entries on either side — gs_relay.hpp sums the
+        // other half above the hand-over).  Rows of a row-sharded operator (halo columns) keep the plain order.
+        int nlow = 0, nupp = 0;
+        bool halo = false;
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+          const int32_t c = col[j];
+          if (c == i) continue;
+          if (c >= n) halo = true;
+          if (c < i) ++nlow; else ++nupp;
+        }
+        const bool split = !halo;
+        if (!split || 2 * nlow > d.maxk || 2 * nupp > d.maxk) late_bad.store(1, std::memory_order_relaxed);
+        int kl = 0, ku = split ? d.maxk - nupp : 0;
         R dg = 0;
         for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
           const int32_t c = col[j];
@@ -513,9 +531,9 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
           size_t lc;
           if (q >= d.row0 && q < d.row0 + d.nrows) lc = (size_t)(q - d.row0);
           else lc = (size_t)d.nrows + (size_t)where[q];
+          const int k = (!split || c < i) ? kl++ : ku++;
           v[k] = val[j];
           cc[k] = (uint16_t)(lc * sizeof(R));
-          ++k;
         }
         v[d.maxk] = dg;
         // reciprocal for the division-free quotient; 0 = "divide" (diagonals whose reciprocal or products may leave the normal range)
@@ -526,6 +544,7 @@ bool plan(int64_t n, const int32_t* rowptr, const int32_t* col, const R* val, co
       stp[nl] = (uint16_t)d.nrows;
     }
   });
+  P.late_ok = late_bad.load() == 0;
   lap("records");
   // ---- modelled time of one sweep: per launch a boundary + the latency chain of a block + its bytes + its deepest block ----
   {

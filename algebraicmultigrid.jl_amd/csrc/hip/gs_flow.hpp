@@ -461,6 +461,7 @@ struct FlowArgs {
   int32_t dict_lds = 0;              // ... and the bytes of its largest dictionary (host side only: LDS behind the columns' x)
   const int32_t* xlist = nullptr;    // the extended fetch lists of a row-sharded operator (FlowX::list; aux / fl_mb / fl_slot are then FlowX's)
   const void* rmbox = nullptr;       // mailboxes of the neighbouring rank this sweep's halo entries come from (peer-mapped; fetch-list entries with kRemoteCell set)
+  int32_t late = 0;                  // the relayed kernel sums the far half of every row above the hand-over (records with the split entry layout; host side only)
   int32_t grid = 0;                  // workgroups to launch: fewer than blocks = the persistent form (host side only; 0: one per block)
 };
 

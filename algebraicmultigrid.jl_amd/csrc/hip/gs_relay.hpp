@@ -57,7 +57,15 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 //   [2] bail: somebody gave up a poll — nobody waits any more                          [3] unused
 // One block of the sweep: ticket ut of the launch, mailbox tag `epoch`.  All waves of the workgroup enter; the fetcher wave
 // leaves when its list is done, the walkers behind their last step.
-template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT>
+// Template flag LATE (round 6): the dependency-aware row sum.  The records hold a row's entries split around the padding — the
+// columns that precede the row in slots [0, MAXK / 2), the columns behind it in [MAXK / 2, MAXK) (gs_blocks.hpp, Plan::late_ok) —
+// so the half of the sum that multiplies the sweep's FAR side (x values nobody writes before this row is done: rows behind it
+// in a forward sweep, before it in a backward one) is gathered and summed ABOVE the hand-over, and only the near half — the
+// rows the previous steps and the predecessor blocks produce — is gathered and added below it: MAXK / 2 gathers, products and
+// dependent adds in the tail instead of MAXK (a wave pays ~3 ns per instruction, whatever it is).  Per row: early = sum of
+// the far half in stored order, acc = early + the near half in stored order — deterministic, the same Gauss-Seidel iterate,
+// not the scalar loop's bits (tunable gs_bw_inorder = 1 keeps those).
+template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT, bool LATE>
 __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char* lds_all, const int wv, const int lane, const unsigned int ut,
                                             const unsigned int epoch, const long long t_start) {
   typedef typename std::conditional<DICT, FlowOpsD<R, MAXK>, FlowOps<R, MAXK>>::type O;
@@ -298,8 +306,24 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     auto val = [&](int k) -> R { if constexpr (DICT) return value_of<R>(vv, k); else return chunk_value<R>(o, k); };
     unsigned xoff = (unsigned)o.p * (unsigned)RB;   // (the row's x: byte offset in the block, in LDS and in memory alike)
     unsigned xadr = xl_base + xoff;
+    // (LATE) the far half of the row sum and the row's own old x: nothing writes them before this step is done
+    constexpr int H = MAXK / 2, E0 = BWD ? 0 : H, L0 = BWD ? H : 0;
+    R early = (R)0, xo_early = (R)0;
+    if constexpr (LATE) {
+      static_assert(!LATE || (PRE && MAXK % 2 == 0), "the split sum is written for the pre-addressed rows");
+      R xe[H];
 #pragma unroll
-    for (int k = 0; k < NOFF; ++k) asm volatile("" : "+v"(off[k]));
+      for (int k = 0; k < H; ++k) xe[k] = lds_get<R>(off[E0 + k]);
+      xo_early = lds_get<R>(xadr);
+#pragma unroll
+      for (int k = 0; k < H; ++k) early += val(E0 + k) * xe[k];
+      asm volatile("" : "+v"(early), "+v"(xo_early));
+#pragma unroll
+      for (int k = 0; k < H; ++k) asm volatile("" : "+v"(off[L0 + k]));
+    } else {
+#pragma unroll
+      for (int k = 0; k < NOFF; ++k) asm volatile("" : "+v"(off[k]));
+    }
     asm volatile("" : "+v"(cell), "+v"(xoff), "+v"(xadr));
     // ---- the hand-over: every step before kk is finished and the near-side values this step reads are in LDS ----
     if (!bail) {
@@ -337,7 +361,15 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     // ---- the dependent tail ----
     R acc = (R)0;
     R xo;
-    if constexpr (PRE) {
+    if constexpr (LATE) {
+      R xv[H];
+#pragma unroll
+      for (int k = 0; k < H; ++k) xv[k] = lds_get<R>(off[L0 + k]);
+      xo = xo_early;
+      acc = early;
+#pragma unroll
+      for (int k = 0; k < H; ++k) acc += val(L0 + k) * xv[k];
+    } else if constexpr (PRE) {
       R xv[MAXK];
 #pragma unroll
       for (int k = 0; k < MAXK; ++k) xv[k] = lds_get<R>(off[k]);
@@ -463,7 +495,7 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
 // tickets until they run out.  That is what several sweeps sharing one device need (the ranks of a row-sharded level on a
 // single GPU: a workgroup of rank p may wait for values of rank p - 1, whose workgroups must then BE resident, not queued
 // behind it), and what bounds the resident workgroups of a launch.  A launch of one workgroup per block is the plain form.
-template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT = false>
+template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT = false, bool LATE = false>
 __global__ __launch_bounds__(64 * (W + 1), DICT ? RelayWavesD<MAXK>::value : RelayWaves<MAXK>::value) void gs_bw_relay_kernel(FlowArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
   static_assert(W >= 2 && W <= 7, "walker waves per block");
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(64 * (W + 1), DICT ? RelayWavesD<MAXK>::value : Rel
       __hip_atomic_store(a.head, (unsigned long long)(sweeps + 2u >= 0x80000000u ? 0u : sweeps + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ut >= units) return;
     const unsigned int epoch = a.epoch ? a.epoch : sweeps + 1u;   // (a.epoch: the tag of a sweep that several launches share, amghip_dist.hpp)
-    relay_block<R, SOR, BWD, MAXK, W, DICT>(a, lds_all, wv, lane, ut, epoch, t_start);
+    relay_block<R, SOR, BWD, MAXK, W, DICT, LATE>(a, lds_all, wv, lane, ut, epoch, t_start);
     if (!persistent) return;
     __syncthreads();   // (everybody is done with this block's LDS)
   }
@@ -497,9 +529,9 @@ static_assert(RelayDepth<6>::value <= 4 && RelayDepth<12>::value <= 4 && RelayDe
 // measurement knob: extra dynamic LDS per workgroup (bounds the blocks resident per CU)
 inline size_t& relay_lds_pad() { static size_t pad = 0; return pad; }
 
-template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT = false>
+template <typename R, bool SOR, bool BWD, int MAXK, int W, bool DICT = false, bool LATE = false>
 inline hipError_t sweep_relay_launch(const FlowArgs<R>& a, size_t lds, hipStream_t st) {
-  auto* fn = gs_bw_relay_kernel<R, SOR, BWD, MAXK, W, DICT>;
+  auto* fn = gs_bw_relay_kernel<R, SOR, BWD, MAXK, W, DICT, LATE>;
   if (relay_lds_pad()) {
     lds += relay_lds_pad();
     static hipError_t once = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -535,15 +567,18 @@ inline int relay_resident_blocks(int maxk, size_t lds, bool dict = false) {   //
   return 0;
 }
 
+template <typename R, int MAXK, int W, bool DICT, bool LATE>
+inline hipError_t sweep_relay_d(const FlowArgs<R>& a, size_t lds, bool sor, bool backward, hipStream_t st) {
+  if (sor) return backward ? sweep_relay_launch<R, true, true, MAXK, W, DICT, LATE>(a, lds, st) : sweep_relay_launch<R, true, false, MAXK, W, DICT, LATE>(a, lds, st);
+  return backward ? sweep_relay_launch<R, false, true, MAXK, W, DICT, LATE>(a, lds, st) : sweep_relay_launch<R, false, false, MAXK, W, DICT, LATE>(a, lds, st);
+}
 template <typename R, int MAXK, int W>
 inline hipError_t sweep_relay_k(const FlowArgs<R>& a, size_t lds, bool sor, bool backward, hipStream_t st) {
-  if constexpr (MAXK <= 18)   // (the dictionary layout, where the schedule carries one: FlowDict)
-    if (a.crec) {
-      if (sor) return backward ? sweep_relay_launch<R, true, true, MAXK, W, true>(a, lds, st) : sweep_relay_launch<R, true, false, MAXK, W, true>(a, lds, st);
-      return backward ? sweep_relay_launch<R, false, true, MAXK, W, true>(a, lds, st) : sweep_relay_launch<R, false, false, MAXK, W, true>(a, lds, st);
-    }
-  if (sor) return backward ? sweep_relay_launch<R, true, true, MAXK, W>(a, lds, st) : sweep_relay_launch<R, true, false, MAXK, W>(a, lds, st);
-  return backward ? sweep_relay_launch<R, false, true, MAXK, W>(a, lds, st) : sweep_relay_launch<R, false, false, MAXK, W>(a, lds, st);
+  if constexpr (MAXK <= 18) {   // (the dictionary layout, where the schedule carries one: FlowDict; the split row sum where the records allow it: a.late)
+    if (a.crec) return a.late ? sweep_relay_d<R, MAXK, W, true, true>(a, lds, sor, backward, st) : sweep_relay_d<R, MAXK, W, true, false>(a, lds, sor, backward, st);
+    if (a.late) return sweep_relay_d<R, MAXK, W, false, true>(a, lds, sor, backward, st);
+  }
+  return sweep_relay_d<R, MAXK, W, false, false>(a, lds, sor, backward, st);
 }
 // one column, W walker waves per block (the kernels instantiated: BW_RELAY_W, or the set a tool asks for with BW_RELAY_ALL_W)
 template <typename R, int MAXK>

@@ -1133,6 +1133,7 @@ int bw_build(GsSchedule* g, int64_t n, int64_t ncols, const int32_t* rowptr, con
       fl.nmail = F.nmail; fl.lds_max = F.lds_max; fl.mail_stride = (int64_t)mbytes; fl.mcols = 1;
       fl.bytes = (int64_t)F.fd.size() * (int64_t)sizeof(bw::FlowDesc) + (only_dict ? 0 : (int64_t)P.rec.size()) + (int64_t)F.aux.size() * 4 + (int64_t)F.fl_mb.size() * 6 + (int64_t)mbytes;
       fl.on = true;
+      fl.late_ok = P.late_ok && g->ncols == n;
       if (F.x.on) {   // the extended lists; their halo entries wait for the neighbours' cells (amgh_dist_finalize patches and uploads xfl_mb)
         RC_TRY(dev_upload(&fl.xaux, F.x.aux.data(), (int64_t)F.x.aux.size()));
         RC_TRY(dev_upload(&fl.xfl_slot, F.x.fl_slot.data(), (int64_t)F.x.fl_slot.size()));

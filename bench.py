@@ -140,6 +140,121 @@ def cpu_baseline(ml, b, budget_s=20.0):
                       "CPU restatement of the reference's _solve cycle (Julia is not installed), gcc -O3 -march=native"}, z
 
 
+def uncompressed_cycle_ms(ml, lib, bd, zd, n, reps=3):
+    """What an operator WITHOUT repeating value rows / few distinct values gets (variable coefficients, elasticity): the same
+    hierarchy laid out a second time with the dictionary records (tunable gs_bw_dict) and the value-coded columns (stream_code)
+    switched off at build — the plain 80 / 208-byte records and 12-byte entries — timed over `reps` cycles.  Both layouts are
+    lossless; this is the round-4 data path under this round's kernels."""
+    import amg_amd as AMG
+    for name in (b"gs_bw_dict", b"stream_code"):
+        if lib.amgh_debug_set_tunable(name, 0) != 0:
+            raise RuntimeError("tunable %r not accepted" % name)
+    try:
+        t0 = time.perf_counter()
+        dev2 = AMG.DeviceHierarchy(ml, 0, 1)
+        t_layout = time.perf_counter() - t0
+        for _ in range(2):
+            if lib.amgh_precond_apply_d(dev2.h, bd.ptr, zd.ptr, 0) != 0:
+                raise RuntimeError("precond_apply failed")
+        if lib.amgh_dev_sync(0) != 0:
+            raise RuntimeError("amgh_dev_sync failed")
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lib.amgh_precond_apply_d(dev2.h, bd.ptr, zd.ptr, 0)
+        if lib.amgh_dev_sync(0) != 0:
+            raise RuntimeError("amgh_dev_sync failed")
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        z = zd.download()
+        out = {"ms_per_cycle": ms, "unknowns_per_s": n / (ms * 1e-3), "cycles_timed": reps, "layout_s": t_layout, "hbm_bytes": dev2.device_bytes(),
+               "dictionary_layout_by_level": [int(lib.amgh_debug_bw_dict(dev2.h, l)) for l in range(len(ml.levels))],
+               "value_coded_operators_by_level": [int(lib.amgh_debug_coded_ops(dev2.h, l)) for l in range(len(ml.levels))],
+               "what": "the same cycle with gs_bw_dict = 0 and stream_code = 0 at layout: plain records, 12-byte entries (what an operator "
+                       "whose value rows do not repeat gets); bitwise the compressed layouts"}
+        del dev2
+        return out, z
+    finally:
+        for name in (b"gs_bw_dict", b"stream_code"):
+            lib.amgh_debug_set_tunable(name, 1)
+
+
+def secondary_configs(check=True):
+    """The smaller BASELINE.json configurations on the same build, a few hundred milliseconds each: C1 (poisson(1000), ruge_stuben,
+    symmetric Gauss-Seidel), C2 at full size (poisson((1024,1024)), smoothed_aggregation, Jacobi(2/3)), C5 (lin_elastic_2d,
+    smoothed aggregation with near-null-space, aspreconditioner in CG).  With `check` (the run has its CPU leg: the oracle is
+    the checker there, never the thing timed) each cycle is compared with the oracle's (<= 1e-10) outside its timed loop."""
+    import amg_amd as AMG
+    lib = AMG.hip_lib()
+    out = {}
+
+    def cycles(ml, n, reps):
+        dev = ml.device()
+        b = uniform(n, 3)
+        bd = AMG.DeviceBuffer(n, 0, b)
+        zd = AMG.DeviceBuffer(n, 0)
+        best = 1e9
+        for _ in range(4):   # (tiny cycles: the clocks ramp up under load — best of a few rounds)
+            for _ in range(50 if n < 100000 else 3):
+                lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0)
+            lib.amgh_dev_sync(0)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0)
+            if lib.amgh_dev_sync(0) != 0:
+                raise RuntimeError("amgh_dev_sync failed")
+            best = min(best, 1e3 * (time.perf_counter() - t0) / reps)
+        err = None
+        if check:
+            from oracle import oracle as O
+            z = zd.download()
+            zo = O.OracleHierarchy(ml).precond(b)
+            err = float(np.linalg.norm(z - zo) / np.linalg.norm(zo))
+            if not err <= 1e-10:
+                raise RuntimeError(f"cycle differs from the oracle: {err:.3e}")
+        return best, err, dev
+
+    try:
+        A = AMG.poisson(1000)
+        ml = AMG.ruge_stuben(A)
+        ms, err, _ = cycles(ml, 1000, 50)
+        out["C1"] = {"workload": "poisson(1000), ruge_stuben defaults", "vcycle_ms": ms, "levels": len(ml), "rel_err_vs_oracle": err}
+    except Exception as ex:  # noqa: BLE001
+        out["C1"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+    try:
+        A = AMG.poisson((1024, 1024))
+        n = A.m
+        jac = AMG.Jacobi(2.0 / 3.0)
+        t0 = time.perf_counter()
+        ml = AMG.smoothed_aggregation(A, presmoother=jac, postsmoother=jac)
+        ts = time.perf_counter() - t0
+        ms, err, dev = cycles(ml, n, 20)
+        sp = dev.bench_op(0, 0, reps=50, warmup=5)
+        alg = spmv_bytes(A.nnz, n, n)
+        out["C2"] = {"workload": "poisson((1024,1024)), smoothed_aggregation, Jacobi(2/3) pre+post", "unknowns": n, "setup_s": ts,
+                     "vcycle_ms": ms, "unknowns_per_s": n / (ms * 1e-3), "levels": len(ml), "rel_err_vs_oracle": err,
+                     "fine_spmv_ms": sp, "fine_spmv_GBs": alg / (sp * 1e-3) / 1e9,
+                     "note": "the fine operator (%.0f MB) fits the 256 MB Infinity Cache: the SpMV rate is not an HBM figure" % (alg / 1e6)}
+    except Exception as ex:  # noqa: BLE001
+        out["C2"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+    try:
+        d = np.load(os.path.join(ROOT, "tests", "golden", "lin_elastic_2d.npz"))
+        A = AMG.SparseMatrixCSC.from_arrays(int(d["m"]), int(d["n"]), d["colptr"], d["rowval"], d["nzval"])
+        ml = AMG.smoothed_aggregation(A, B=d["B"])
+        pl = AMG.aspreconditioner(ml)
+        best, iters = 1e9, None
+        for _ in range(4):
+            t0 = time.perf_counter()
+            x, log = AMG.cg(A, d["b"], Pl=pl, reltol=1e-10, log=True)
+            best = min(best, 1e3 * (time.perf_counter() - t0))
+            iters = int(log["iters"])
+        ms, err, _ = cycles(ml, A.m, 50)
+        res = float(np.linalg.norm(d["b"] - A @ x) / np.linalg.norm(d["b"]))
+        out["C5"] = {"workload": "lin_elastic_2d (n = %d), smoothed_aggregation with B, aspreconditioner in cg, reltol 1e-10" % A.m,
+                     "pcg_ms": best, "pcg_iterations": iters, "final_rel_residual": res, "vcycle_ms": ms, "rel_err_vs_oracle": err}
+    except Exception as ex:  # noqa: BLE001
+        out["C5"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+    return out
+
+
 def self_launch(nranks):
     """`python bench.py --gpus N` with N > 1 and no launcher's environment (RANK / WORLD_SIZE absent): spawn the N ranks — this
     same command line, one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run
@@ -208,6 +323,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--light", action="store_true", help="profiling runs: skip the extra smoother timing")
     ap.add_argument("--no-block-rhs", action="store_true", help="skip the secondary measurement on a block of 8 right-hand sides")
+    ap.add_argument("--no-uncompressed", action="store_true", help="skip the secondary cycle on the uncompressed layouts (a second layout of the hierarchy: ~6 s, ~24 GB)")
+    ap.add_argument("--no-secondary-configs", action="store_true", help="skip the C1 / C2 / C5 cycles")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--force-dist", action="store_true", help="run the row-sharded driver even with one rank")
     ap.add_argument("--transport", default=None, choices=("rccl", "ipc", "ipc-staged"),
@@ -372,8 +489,11 @@ def main():
                      "gpu_state_before_timed_region": clocks_before, "gpu_state_after_timed_region": clocks_after,
                      "fused_residual_ms": resid_ms,
                      "fused_residual_GBs": (alg + 8 * n) / (resid_ms * 1e-3) / 1e9},
+        # (EFFECTIVE figures: the 12-bytes-per-entry count of BASELINE.md section 4 over the measured time — with the dictionary
+        # records and the value-coded columns the kernels MOVE fewer bytes than this count, sweep_roofline.bytes_streamed_per_cycle)
         "vcycle": {"algorithmic_bytes": vb, "achieved_GBs": vb / (ms_per_step * 1e-3) / 1e9,
                    "frac_of_hbm_peak": vb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "frac_of_hbm_peak_is": "effective (algorithmic 12-byte count / time), not bytes moved / time",
                    "fine_symmetric_gs_ms": sweep_ms},
         # second roofline entry: the kernels that dominate the CYCLE (Gauss-Seidel sweeps: gs_slot / gs_bigslot /
         # chain / block launches + pre-pass), latency-bound — one launch per merged group of dependency levels
@@ -439,6 +559,21 @@ def main():
             ml._dev.pop((0, bs), None) if hasattr(ml, "_dev") else None
         except Exception as ex:  # noqa: BLE001
             out["block_of_right_hand_sides"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+    if not args.light and not args.no_uncompressed:
+        # secondary (never `value`): the cycle a general operator gets — no dictionary records, no value-coded columns
+        try:
+            unc, z_unc = uncompressed_cycle_ms(ml, lib, bd, zd, n)
+            unc["rel_diff_vs_compressed_cycle"] = float(np.linalg.norm(z_unc - z_timed) / np.linalg.norm(z_timed))
+            out["vcycle_uncompressed_ms"] = unc["ms_per_cycle"]
+            out["vcycle_uncompressed"] = unc
+        except Exception as ex:  # noqa: BLE001
+            out["vcycle_uncompressed_ms"] = None
+            out["vcycle_uncompressed"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+    if not args.light and not args.no_secondary_configs:
+        try:
+            out["secondary_configs"] = secondary_configs(check=not args.no_cpu_baseline)
+        except Exception as ex:  # noqa: BLE001
+            out["secondary_configs"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"], z_oracle = cpu_baseline(ml, b, args.cpu_budget)
         # parity of the TIMED result (checked outside the timed region): the last V-cycle's output against the oracle

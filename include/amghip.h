@@ -533,6 +533,12 @@ int amgh_debug_bw_mode(const amgh_t* h, int l);
 /* ... and whether the single-column dataflow sweep of level l reads the DICTIONARY layout (column records + every block's
  * distinct value rows, held in LDS; tunable "gs_bw_dict"): 1 / 0, -1: no such level.                                */
 int amgh_debug_bw_dict(const amgh_t* h, int l);
+/* ... and whether its rows are summed with the sweep's FAR side above the hand-over (the relayed walk's dependency-aware row
+ * sum: the entries of smoother.jl:81-87's sum whose x cannot change any more are added first, the near half behind the
+ * hand-over — the same iterate, one reassociation per row; tunable "gs_bw_inorder" = 1 restores the stored-order sum, the
+ * scalar loop's bits): 1 / 0, -1: no such level.  Needs records whose entries lie split around the padding with at most
+ * half of the slots on either side (every non-sharded operator whose rows are that balanced).                         */
+int amgh_debug_bw_late(const amgh_t* h, int l);
 /* Diagnostics: which operators of level l the level-ordered cycle streams as VALUE-CODED columns (one 32-bit word per
  * entry: column | code << 24, the code an index into the operator's table of distinct values — built at amgh_finalize for
  * operators of >= 2^18 rows, fewer than 2^24 columns and at most 256 distinct values; the sums are the plain kernel's, bit

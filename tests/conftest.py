@@ -32,6 +32,18 @@ def _build_native():
     """Tests never compile in the timed path: make sure the in-tree .so files exist."""
     import __graft_entry__ as g
     g.build(only_missing=True)
+    # The library's default row sum in the relayed Gauss-Seidel walk is the DEPENDENCY-AWARE one (csrc/hip/gs_relay.hpp, LATE:
+    # the far half of a row summed above the hand-over — the same iterate, one reassociation per row).  Most of this suite pins
+    # more than the iterate: BITS — relayed = single walker = chained = launched kernels = host plan = the oracle's scalar loop,
+    # blocks of right-hand sides = their single columns, the pipelined sharded sweep = the turn loop.  Those comparisons need the
+    # stored-order sum on every path, so the suite runs with gs_bw_inorder = 1; tests/test_gpu_late.py (and bench.py, smoke())
+    # run the shipping default against the oracle.
+    import amg_amd as AMG
+    for dt in ("float64", "float32"):
+        try:
+            AMG.hip_lib(dt).amgh_debug_set_tunable(b"gs_bw_inorder", 1)
+        except Exception:  # noqa: BLE001  (no library: the tests that need it fail on their own)
+            pass
 
 
 def load_csc(name):

@@ -26,7 +26,8 @@ def rel(x, y):
 class tunables:
     """amgh_debug_set_tunable for the duration of a with block (values restored to the given defaults)."""
     DEFAULTS = {"gs_bw": 1, "gs_bw_rows": 512, "gs_bw_chain": 1, "gs_bw_flow": 1, "gs_lean": -1, "gs_bw_spin": 0, "gs_bw_skip_pub": -1,
-                "gs_lpr": 0, "gs_ept": 0, "gs_bw_nc": -1, "gs_bw_nrhs": 1, "gs_flow_xzero": 1, "gs_bw_relay": 3, "gs_bw_dict": 1}
+                "gs_lpr": 0, "gs_ept": 0, "gs_bw_nc": -1, "gs_bw_nrhs": 1, "gs_flow_xzero": 1, "gs_bw_relay": 3, "gs_bw_dict": 1,
+                "gs_bw_inorder": 1}   # (the suite's default, tests/conftest.py; the library's is 0)
 
     def __init__(self, lib, **kw):
         self.lib, self.kw = lib, kw
