@@ -39,13 +39,22 @@ namespace bw {
 #define BW_RELAY_DEPTH_LONG 2           // ... and of up to 18
 #endif
 template <int MAXK> struct RelayDepth { static constexpr int value = MAXK <= 12 ? BW_RELAY_DEPTH_SHORT : BW_RELAY_DEPTH_LONG; };
+#ifndef BW_RELAY_FETCH_SLEEP
+#define BW_RELAY_FETCH_SLEEP 4          // x 64 cycles between two polls of a fetcher that saw nothing new
+#endif
+#ifndef BW_RELAY_FETCH_PD
+#define BW_RELAY_FETCH_PD 1             // polls of a fetcher in flight at once (1: the round-5 loop — wait for a poll, then issue the next)
+#endif
+#ifndef BW_RELAY_FETCH_GAP
+#define BW_RELAY_FETCH_GAP 6            // ... issued this many x 64 cycles apart
+#endif
 #ifndef BW_RELAY_DICT_DEPTH
 #define BW_RELAY_DICT_DEPTH 3
 #endif
 template <int MAXK> struct RelayDepthD { static constexpr int value = BW_RELAY_DICT_DEPTH; };   // the dictionary layout: a set is a handful of registers
 template <int MAXK> struct RelayWaves { static constexpr int value = MAXK <= 6 ? 4 : MAXK <= 18 ? 2 : 1; };
 // (the dictionary layout: a set in flight is a column chunk or three and b — 74 / 139 registers at 6 / 18 entries a row against 109 / 165)
-template <int MAXK> struct RelayWavesD { static constexpr int value = MAXK <= 6 ? 5 : MAXK <= 18 ? 3 : 1; };
+template <int MAXK> struct RelayWavesD { static constexpr int value = MAXK <= 6 ? 5 : MAXK <= 18 ? 3 : 2; };
 
 // LDS by its 32-bit address (the walkers keep absolute LDS addresses in registers: nothing is added behind the hand-over)
 template <typename T> __device__ __forceinline__ T lds_get(unsigned addr) { return *(const __attribute__((address_space(3))) T*)(unsigned long long)addr; }
@@ -137,6 +146,68 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     long long* t_seen = a.tim + 4 * (int64_t)a.nblocks + 384 * (int64_t)a.nblocks + ((int64_t)a.nmail + 1024);
     long long poll_sum = 0, poll_max = 0, npoll = 0;
 #endif
+#if BW_RELAY_FETCH_PD > 1 && !defined(BW_RELAY_STAMPS)
+    // PIPELINED polls (round 6): a poll is a coherent load served by the memory side — ~1-2.5 us under the sweep's own traffic — and a
+    // loop that waits for one poll before it issues the next sees a value, on average, one and a half round trips after it was
+    // published (measured: 2.5 us at the median, profiles/r05_flow_phases.log).  Here BW_RELAY_FETCH_PD polls of the same cells are in
+    // flight, issued BW_RELAY_FETCH_GAP x 64 cycles apart: a published value is seen one round trip + half a gap later.  A cell
+    // that arrived is never polled again; a later poll of a lane that an earlier one already served is dropped (same value).
+    constexpr int PD = BW_RELAY_FETCH_PD;
+    for (int w0 = 0; w0 < nf && !fail; w0 += 64 * U) {
+      int32_t mb[U]; int slot[U]; bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = w0 + 64 * u + lane;
+        mb[u] = a.fl_mb[e < nf ? f0 + e : f0];
+        slot[u] = a.fl_slot[e < nf ? f0 + e : f0];
+        ok[u] = !(e < nf);
+      }
+      int first = 0;
+      typename M::cell q[PD][U];
+      bool is[PD][U];
+      auto issue = [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          is[r][u] = !ok[u] && 64 * u <= first + 64;
+          if (is[r][u]) {
+            if (mb[u] < 0) q[r][u] = M::load_sys(rs_rmail, (unsigned)(mb[u] & 0x7fffffff) * (unsigned)M::kBytes);   // (kRemoteCell)
+            else q[r][u] = M::load(rs_mail, (unsigned)mb[u] * (unsigned)M::kBytes);
+          }
+        }
+      };
+      auto process = [&](auto rc) -> bool {
+        constexpr int r = decltype(rc)::value;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (is[r][u] && !ok[u] && M::valid(q[r][u], epoch)) { xl[slot[u]] = M::value(q[r][u]); ok[u] = true; }
+        int nfirst = 64 * U;
+#pragma unroll
+        for (int u = U - 1; u >= 0; --u) {
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(!ok[u]);
+          if (m) nfirst = 64 * u + (int)__builtin_ctzll(m);
+        }
+        if (nfirst != first && lane == 0) __hip_atomic_store(ctl, (unsigned)(w0 + nfirst < nf ? w0 + nfirst : nf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        first = nfirst;
+        return nfirst == 64 * U;
+      };
+      issue(std::integral_constant<int, 0>());
+      if constexpr (PD > 1) { __builtin_amdgcn_s_sleep(BW_RELAY_FETCH_GAP); issue(std::integral_constant<int, 1>()); }
+      if constexpr (PD > 2) { __builtin_amdgcn_s_sleep(BW_RELAY_FETCH_GAP); issue(std::integral_constant<int, 2>()); }
+      if constexpr (PD > 3) { __builtin_amdgcn_s_sleep(BW_RELAY_FETCH_GAP); issue(std::integral_constant<int, 3>()); }
+      bool done = false;
+      while (!done && !fail) {
+        if (process(std::integral_constant<int, 0>())) { done = true; break; }
+        issue(std::integral_constant<int, 0>());
+        if constexpr (PD > 1) { __builtin_amdgcn_s_sleep(BW_RELAY_FETCH_GAP); if (process(std::integral_constant<int, 1>())) { done = true; break; } issue(std::integral_constant<int, 1>()); }
+        if constexpr (PD > 2) { __builtin_amdgcn_s_sleep(BW_RELAY_FETCH_GAP); if (process(std::integral_constant<int, 2>())) { done = true; break; } issue(std::integral_constant<int, 2>()); }
+        if constexpr (PD > 3) { __builtin_amdgcn_s_sleep(BW_RELAY_FETCH_GAP); if (process(std::integral_constant<int, 3>())) { done = true; break; } issue(std::integral_constant<int, 3>()); }
+        __builtin_amdgcn_s_sleep(BW_RELAY_FETCH_GAP);
+        total_spins += PD;
+        if (total_spins > spin_limit) fail = true;
+      }
+    }
+#else
     for (int w0 = 0; w0 < nf && !fail; w0 += 64 * U) {
       int32_t mb[U]; int slot[U]; bool ok[U];
 #pragma unroll
@@ -180,11 +251,12 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
         first = nfirst;
         if (nfirst == 64 * U) break;
 #ifndef BW_RELAY_FETCH_NOSLEEP
-        if (!moved) __builtin_amdgcn_s_sleep(4);
+        if (!moved) __builtin_amdgcn_s_sleep(BW_RELAY_FETCH_SLEEP);
 #endif
         if (++total_spins > spin_limit) { fail = true; break; }
       }
     }
+#endif
     if (fail && lane == 0) {
       *a.err = 1;
       __hip_atomic_store(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -283,7 +355,7 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     // (rows of more than 18 entries: the addresses are made behind the hand-over, batch by batch — D sets of such rows leave
     // no registers for them, and a compiler short of registers moves sets that are still in flight)
     constexpr bool PRE = MAXK <= 18;
-    constexpr int NOFF = PRE ? MAXK : 1;
+    constexpr int NOFF = (PRE && !LATE) ? MAXK : 1;   // (LATE keeps the near half's addresses only: offl below)
     auto col_addr = [&](int k) {
       const u32x4 cw = o.cchunk(k >> 3);
       const unsigned w = ((k >> 1) & 3) == 0 ? cw.x : ((k >> 1) & 3) == 1 ? cw.y : ((k >> 1) & 3) == 2 ? cw.z : cw.w;
@@ -296,8 +368,9 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     unsigned cell = ((pw & pubdir) && !mute) ? (unsigned)f.pad0 + (((unsigned)pw >> (BWD ? 11 : 0)) & 0x7ffu) : spare;
     cell *= (unsigned)M::kBytes;
     u32x4 vv[NVC];   // (the dictionary layout: the row's values out of LDS, ahead of the hand-over)
+    unsigned da = 0u;
     if constexpr (DICT) {
-      const unsigned da = dict_base + (((unsigned)pw >> kDictIdxShift) & 0xffu) * (unsigned)(16 * NVC);
+      da = dict_base + (((unsigned)pw >> kDictIdxShift) & 0xffu) * (unsigned)(16 * NVC);
 #pragma unroll
       for (int c = 0; c < NVC; ++c) vv[c] = lds_get<u32x4>(da + 16u * (unsigned)c);
 #pragma unroll
@@ -306,20 +379,50 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     auto val = [&](int k) -> R { if constexpr (DICT) return value_of<R>(vv, k); else return chunk_value<R>(o, k); };
     unsigned xoff = (unsigned)o.p * (unsigned)RB;   // (the row's x: byte offset in the block, in LDS and in memory alike)
     unsigned xadr = xl_base + xoff;
-    // (LATE) the far half of the row sum and the row's own old x: nothing writes them before this step is done
+    // (LATE) everything the far side and the record determine: the far half of the row sum, the row's own old x, and — so that
+    // the tail is nothing but the near half's multiply-adds — the row brought to the form x_i = q0 - sum_near nv[k] x[k]:
+    //   Gauss-Seidel: q0 = (b - early) rc, nv[k] = v[k] rc (rc = RN(1 / d) from the record);
+    //   SOR:          q0 = (1 - omega) x_i + (omega / d)(b - early), nv[k] = v[k] (omega / d).
+    // Rows whose record says "divide" (rc = 0: a diagonal outside [1e-100, 1e100]) and rows with a zero diagonal (the row keeps
+    // its value, smoother.jl:87) are told apart here too; the tail only selects.
     constexpr int H = MAXK / 2, E0 = BWD ? 0 : H, L0 = BWD ? H : 0;
-    R early = (R)0, xo_early = (R)0;
+    R q0 = (R)0, xo_early = (R)0, early = (R)0, bb_early = (R)0;
+    R nv[LATE ? H : 1];
+    unsigned offl[LATE ? H : 1];
+    bool keep_row = false, slow_row = false;
+    unsigned long long slow_any = 0ull;
     if constexpr (LATE) {
-      static_assert(!LATE || (PRE && MAXK % 2 == 0), "the split sum is written for the pre-addressed rows");
-      R xe[H];
+      static_assert(!LATE || MAXK % 2 == 0, "the split sum halves the slots");
 #pragma unroll
-      for (int k = 0; k < H; ++k) xe[k] = lds_get<R>(off[E0 + k]);
+      for (int k = 0; k < H; ++k) offl[k] = col_addr(L0 + k);
       xo_early = lds_get<R>(xadr);
+      constexpr int GE = 12;   // far-side gathers per batch (rows of 36 entries: 18 gathers in flight at once would cost their registers)
 #pragma unroll
-      for (int k = 0; k < H; ++k) early += val(E0 + k) * xe[k];
-      asm volatile("" : "+v"(early), "+v"(xo_early));
+      for (int k0 = 0; k0 < H; k0 += GE) {
+        R xe[GE];
 #pragma unroll
-      for (int k = 0; k < H; ++k) asm volatile("" : "+v"(off[L0 + k]));
+        for (int k = 0; k < GE; ++k) if (k0 + k < H) xe[k] = lds_get<R>(col_addr(E0 + k0 + k));
+#pragma unroll
+        for (int k = 0; k < GE; ++k) if (k0 + k < H) early = __builtin_fma(val(E0 + k0 + k), xe[k], early);
+      }
+      const R dg = val(MAXK), rc = val(MAXK + 1);
+      if constexpr (sizeof(R) == 8) bb_early = __hiloint2double((int)o.bb.y, (int)o.bb.x); else bb_early = __uint_as_float(o.bb);
+      keep_row = dg == (R)0;
+      if constexpr (SOR) {
+        const R w = a.omega / dg;
+        q0 = __builtin_fma(w, bb_early - early, ((R)1 - a.omega) * xo_early);
+#pragma unroll
+        for (int k = 0; k < H; ++k) nv[k] = -(val(L0 + k) * w);
+      } else {
+        slow_row = rc == (R)0 && !keep_row;
+        q0 = (bb_early - early) * rc;
+#pragma unroll
+        for (int k = 0; k < H; ++k) nv[k] = -(val(L0 + k) * rc);
+      }
+      slow_any = __builtin_amdgcn_ballot_w64(slow_row);
+      asm volatile("" : "+v"(q0), "+v"(xo_early));
+#pragma unroll
+      for (int k = 0; k < H; ++k) asm volatile("" : "+v"(nv[k]), "+v"(offl[k]));
     } else {
 #pragma unroll
       for (int k = 0; k < NOFF; ++k) asm volatile("" : "+v"(off[k]));
@@ -361,14 +464,29 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
     // ---- the dependent tail ----
     R acc = (R)0;
     R xo;
+    R q_late = (R)0;
     if constexpr (LATE) {
       R xv[H];
 #pragma unroll
-      for (int k = 0; k < H; ++k) xv[k] = lds_get<R>(off[L0 + k]);
+      for (int k = 0; k < H; ++k) xv[k] = lds_get<R>(offl[k]);
       xo = xo_early;
-      acc = early;
+      // two chains for the long rows: the dependent latency of H multiply-adds halves, one add joins them
+      R qa = q0, qb = (R)0;
 #pragma unroll
-      for (int k = 0; k < H; ++k) acc += val(L0 + k) * xv[k];
+      for (int k = 0; k < H; ++k) {
+        if (H >= 6 && (k & 1)) qb = __builtin_fma(nv[k], xv[k], qb);
+        else qa = __builtin_fma(nv[k], xv[k], qa);
+      }
+      q_late = H >= 6 ? qa + qb : qa;
+      if (slow_any != 0ull) {   // (wave-uniform, decided above the hand-over) rows that must divide: the plain sum and the division
+        asm volatile("; LATE: rows whose record asks for the division" ::: "memory");
+        // (cold: the values come back out of the dictionary / the record — nothing of them is kept alive across the hand-over for this)
+        auto val2 = [&](int k) -> R { if constexpr (DICT) return lds_get<R>(da + (unsigned)(RB * k)); else return chunk_value<R>(o, k); };
+        R s2 = early;
+#pragma unroll
+        for (int k = 0; k < H; ++k) s2 += val2(L0 + k) * xv[k];
+        if (slow_row) q_late = (bb_early - s2) / val2(MAXK);
+      }
     } else if constexpr (PRE) {
       R xv[MAXK];
 #pragma unroll
@@ -390,11 +508,13 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
         for (int k = 0; k < GB; ++k) if (k0 + k < MAXK) acc += val(k0 + k) * xv[k];
       }
     }
+    R q;
+    if constexpr (LATE) q = keep_row ? xo : q_late;
+    else {
     const R dg = val(MAXK), rc = val(MAXK + 1);
     R bbv;
     if constexpr (sizeof(R) == 8) bbv = __hiloint2double((int)o.bb.y, (int)o.bb.x); else bbv = __uint_as_float(o.bb);
     const R nn = bbv - acc;
-    R q;
     if (SOR) q = ((R)1 - a.omega) * xo + (a.omega / dg) * nn;
     else {
       // (bb - acc) / dg from rc = RN(1 / dg): the correctly rounded quotient (Markstein) inside the normal range — packed_row
@@ -409,6 +529,7 @@ __device__ __forceinline__ void relay_block(const FlowArgs<R>& a, unsigned char*
       }
     }
     q = dg != (R)0 ? q : xo;   // a zero diagonal: the row keeps its value (smoother.jl:87) — and publishes it
+    }
     lds_put<R>(xadr, q);
     // (LDS operations of one wave execute in program order: the values are in place before the word moves)
     __hip_atomic_store(ctl + 1, (unsigned)(kk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -574,9 +695,14 @@ inline hipError_t sweep_relay_d(const FlowArgs<R>& a, size_t lds, bool sor, bool
 }
 template <typename R, int MAXK, int W>
 inline hipError_t sweep_relay_k(const FlowArgs<R>& a, size_t lds, bool sor, bool backward, hipStream_t st) {
-  if constexpr (MAXK <= 18) {   // (the dictionary layout, where the schedule carries one: FlowDict; the split row sum where the records allow it: a.late)
+#ifdef BW_EXTRA_DICT
+  constexpr bool kDictOk = true;      // (tools: the dictionary layout and the split sum under the extra row length too)
+#else
+  constexpr bool kDictOk = MAXK <= 18;
+#endif
+  if constexpr (kDictOk) {   // (the dictionary layout, where the schedule carries one: FlowDict; the split row sum where the records allow it: a.late)
     if (a.crec) return a.late ? sweep_relay_d<R, MAXK, W, true, true>(a, lds, sor, backward, st) : sweep_relay_d<R, MAXK, W, true, false>(a, lds, sor, backward, st);
-    if (a.late) return sweep_relay_d<R, MAXK, W, false, true>(a, lds, sor, backward, st);
+    if constexpr (MAXK <= 18) if (a.late) return sweep_relay_d<R, MAXK, W, false, true>(a, lds, sor, backward, st);
   }
   return sweep_relay_d<R, MAXK, W, false, false>(a, lds, sor, backward, st);
 }

@@ -1,7 +1,8 @@
 // relay_bench — the dataflow sweep with relayed walkers (csrc/hip/gs_relay.hpp) on an operator file, rows of any length the
 // tool is compiled for: flow-only plan (a block's LDS holds x only), forward / backward sweeps checked bit for bit against
 // the scalar loops, timings per number of walker waves.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DBW_PLAN_MAXK=36 -DBW_EXTRA_MAXK=36 -o tools/relay_bench tools/relay_bench.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DBW_PLAN_MAXK=36 -DBW_EXTRA_MAXK=36 [-DBW_EXTRA_DICT] -o tools/relay_bench tools/relay_bench.hip
+//   environment: BW_RELAY_LATE=1 (the split row sum), BW_RELAY_DICT=0/1, BW_RELAY_ONLY=W, BW_RELAY_GRID=g, BW_PLAN_CUTS=a,b (offset classes by hand)
 // usage: relay_bench PATH [target_rows] [max_rows]     PATH: int64 n, int64 nnz, int32 rowptr[n+1], int32 col[nnz], double val[nnz]
 #include <chrono>
 #include <cstdio>
@@ -71,6 +72,8 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(d_dent, F.dc.ent.data(), 4 * (size_t)B, hipMemcpyHostToDevice));
   } else printf("no dictionary layout for this operator\n");
   if (const char* eg = getenv("BW_RELAY_GRID")) fa.grid = atoi(eg);
+  if (const char* el = getenv("BW_RELAY_LATE")) fa.late = (atoi(el) != 0 && P.late_ok) ? 1 : 0;   // the dependency-aware row sum (not the scalar loops' bits: max |diff| below)
+  printf("records split around the padding (late_ok): %d; row sum: %s\n", (int)P.late_ok, fa.late ? "far half above the hand-over (LATE)" : "stored order");
   for (int dict = 0; dict < (F.dc.on ? 2 : 1); ++dict) {
   fa.crec = dict ? d_crec : nullptr; fa.dict = dict ? d_dict : nullptr; fa.dict_ent = dict ? d_dent : nullptr;
   const size_t lds_use = dict ? F.dc.lds_max : F.lds_max;
