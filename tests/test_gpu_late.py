@@ -120,3 +120,32 @@ def test_c3_full_size_v_cycle_with_the_split_row_sum():
     assert rel(xs, xo) <= 1e-14
     z_in = dev.precond_apply(b)                      # the stored-order sum on the same handle
     assert rel(z_in, zo) <= 1e-12 and not np.array_equal(z_in, z)
+
+
+def test_float32_instance_split_row_sum():
+    """The Float32 instance of the LATE kernels (gs_relay.hpp with R = float: 4 values per chunk, the reciprocal in Float32): forced
+    onto a small hierarchy, both levels really run it; sweep and cycle are the Float32 oracle's within Float32 rounding, rerun
+    bitwise, and the stored-order sum on the same handle is the Float32 scalar loop bit for bit (smoother.jl:61-90)."""
+    from test_gpu_float32 import F32, F32_TOL, as_f32_matrix
+    lib = AMG.hip_lib(F32)
+    A = as_f32_matrix(AMG.poisson((24, 20, 16)))
+    ml = AMG.ruge_stuben(A)
+    n = A.m
+    b = (uniform(n, 10) - 0.3).astype(F32)
+    x0 = (uniform(n, 11) - 0.5).astype(F32)
+    with tunables(lib, gs_bw=2, gs_bw_rows=128, gs_lean=0):
+        dev = DeviceHierarchy(ml, 0, 1, dtype=F32)
+        assert lib.amgh_debug_bw_mode(dev.h, 0) == 3
+        x_in = dev.smooth(0, False, x0, b)
+        with tunables(lib, gs_bw_inorder=0):
+            assert lib.amgh_debug_bw_late(dev.h, 0) == 1
+            x_late = dev.smooth(0, False, x0, b)
+            assert np.array_equal(dev.smooth(0, False, x0, b), x_late)
+            z = dev.precond_apply(b)
+        assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+    xo = O.smooth(ml.levels[0].presmoother, A, x0, b, hermitian=True, dtype=F32)
+    assert np.array_equal(x_in, xo)
+    assert rel(x_late.astype(np.float64), xo.astype(np.float64)) <= 1e-6
+    assert x_late.dtype == F32 and rel(x_late.astype(np.float64), x_in.astype(np.float64)) <= 1e-6
+    zo = O.OracleHierarchy(ml, dtype=F32).precond(b)
+    assert rel(z.astype(np.float64), zo.astype(np.float64)) <= F32_TOL
