@@ -149,3 +149,43 @@ def test_float32_instance_split_row_sum():
     assert x_late.dtype == F32 and rel(x_late.astype(np.float64), x_in.astype(np.float64)) <= 1e-6
     zo = O.OracleHierarchy(ml, dtype=F32).precond(b)
     assert rel(z.astype(np.float64), zo.astype(np.float64)) <= F32_TOL
+
+
+def test_split_row_sum_zero_diagonals_and_rows_that_must_divide():
+    """Rows the pre-scaled form cannot take: a zero diagonal (the row keeps its value and still publishes it, smoother.jl:87) and a
+    diagonal outside [1e-100, 1e100] (the record's reciprocal is 0 = "divide": the LATE kernel's wave-uniform cold branch sums the
+    near half plainly and divides).  A 3-D grid whose records allow the split, with such rows planted in it: the sweep is the
+    oracle's to rounding, in every direction."""
+    import scipy.sparse as sp
+    lib = AMG.hip_lib()
+    M = AMG.poisson((20, 18, 16)).to_scipy().tolil()
+    n = M.shape[0]
+    for r in (0, 777, 3000, n - 1):
+        M[r, r] = 0.0                     # zero diagonals (stored as explicit zeros would be dropped: rows without a diagonal)
+    for r in (5, 1234, 4000):
+        M[r, r] = 6.0e120                 # the reciprocal would leave the range the record trusts
+    for r in (9, 2222):
+        M[r, r] = 3.0e-130
+    A = AMG.SparseMatrixCSC.from_scipy(sp.csc_matrix(M.tocsr()))
+    x0, bb = uniform(n, 51) - 0.5, uniform(n, 52)
+    for pre in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2), AMG.SOR(1.2)):
+        ml = AMG.ruge_stuben(A, presmoother=pre, postsmoother=pre, max_levels=2)
+        with tunables(lib, gs_bw=2, gs_bw_rows=64, gs_lean=0):
+            dev = DeviceHierarchy(ml, 0, 1)
+            assert lib.amgh_debug_bw_mode(dev.h, 0) == 3, repr(pre)
+            x_in = dev.smooth(0, False, x0, bb)
+            with tunables(lib, gs_bw_inorder=0):
+                assert lib.amgh_debug_bw_late(dev.h, 0) == 1
+                x_late = dev.smooth(0, False, x0, bb)
+            assert lib.amgh_debug_bw_poll_giveups(dev.h, 0) == 0
+        xo = O.smooth(pre, A, x0, bb, hermitian=True)
+        ok = np.isfinite(xo)
+        assert np.array_equal(np.isfinite(x_late), ok)
+        if not isinstance(pre, AMG.SOR):
+            assert np.array_equal(x_in[ok], xo[ok])
+        # entry by entry, relative to the entry (rows with a 3e-130 diagonal hold values of 1e129: a norm would hide everything else)
+        # with the typical magnitude of the ordinary entries as the floor
+        floor = 1e-3 * np.median(np.abs(xo[ok]))
+        assert np.max(np.abs(x_late[ok] - xo[ok]) / np.maximum(np.abs(xo[ok]), floor)) <= 1e-12, repr(pre)
+        for r in (0, 777, 3000, n - 1):
+            assert x_late[r] == x0[r]      # zero diagonal: untouched
