@@ -1881,6 +1881,8 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_slots")) g_gs_slots = value;
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
   else if (!strcmp(name, "gs_lpr")) g_gs_lpr = value;
+  else if (!strcmp(name, "gs_il")) g_gs_il = value;
+  else if (!strcmp(name, "gs_tri_rb")) g_gs_tri_rb = value;
   else if (!strcmp(name, "gs_lean")) g_gs_lean = value;
   else if (!strcmp(name, "gs_sell")) g_gs_sell = value;
   else if (!strcmp(name, "gs_sample")) g_gs_sample = value;

@@ -246,6 +246,9 @@ struct GsSchedule {
   real* bp = nullptr;     // right-hand side in dependency-level order (scratch)
   real* xp = nullptr;     // x in dependency-level order (scratch, ncols entries per right-hand-side column)
   int cols_alloc = 1;       // right-hand-side columns bp / xp currently hold
+  real* xil = nullptr;    // blocks of 2 / 4 / 8 right-hand sides on merged groups: [x ; s] INTERLEAVED (xstride positions x bs values), beside xp (gs_slot_il_kernel); allocated by the first such sweep
+  int64_t xil_cap = 0;      // ... doubles allocated
+  int xil_cols = 0;         // ... columns of the sweep that last wrote all of xil's x part (0: stale — something else wrote xp since)
   int bp_cols = 0;          // columns of b gathered into bp by the last level-ordered sweep (0: none)
   int32_t* permx = nullptr; // perm extended by the identity over halo columns
   std::vector<int32_t> h_perm;  // host copy of perm (level-ordered row -> original row), for level-ordered P / R copies
@@ -339,6 +342,7 @@ struct GsSchedule {
     hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
     hipFree(scol); hipFree(sval); hipFree(schunk); scol = nullptr; sval = nullptr; schunk = nullptr;
     hipFree(ww_rec); ww_rec = nullptr;
+    hipFree(xil); xil = nullptr; xil_cap = 0; xil_cols = 0;
     hipFree(bw.blocks); hipFree(bw.rec); hipFree(bw.ext_col);
     hipFree(bw.dep_ptr); hipFree(bw.dep); hipFree(bw.sdep_ptr); hipFree(bw.sdep); hipFree(bw.flags); hipFree(bw.head);
     hipFree(bw.flow.fd); hipFree(bw.flow.srec); hipFree(bw.flow.aux); hipFree(bw.flow.fl_mb); hipFree(bw.flow.fl_slot); hipFree(bw.flow.mbox);
@@ -429,6 +433,8 @@ int g_gs_sell = 1;              // merged groups from the SELL-like layout where
 int g_gs_lean = -1;             // footprint policy: -1 = AMGH_LEAN environment variable (unset: trim), 0 = full (every copy kept), 1 = lean, 2 = trim; read at schedule build
 int g_gs_ept = 0;               // entries per thread of merged slot launches (0 = 2 when a group has more than 1024 slots, else 1)
 int g_gs_lpr = 0;               // lanes per row in the row sums of merged slot launches (0 = by row length, 1 = one thread per row)
+int g_gs_il = 1;                // blocks of 2 / 4 / 8 right-hand sides: merged groups gather from an interleaved copy of the sweep's vector (gs_slot_il_kernel, gs_sell_il_kernel; 0 = one gather per column); read at every sweep
+int g_gs_tri_rb = 1;            // dense triangle inverses under a block of right-hand sides: 4 rows per workgroup (tri_gemm_kernel; 0 = one row, tri_gemv_kernel — bitwise the same); read at every sweep
 int g_gs_dense_blk = 4096;       // ... rows per dense block above kDenseTriMax rows; read at schedule build
 int g_gs_dense_tri = 1;          // small operators: sweeps through the dense inverse of the whole triangle (0 = block-inverse / exact order); build + sweep
 int g_gs_block_inverse = 1;     // block-inverse sweeps for small densely coupled operators (0 = exact order everywhere)        // workgroup size of the per-level launches (64 or 256)

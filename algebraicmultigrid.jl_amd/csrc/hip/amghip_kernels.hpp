@@ -413,6 +413,35 @@ __global__ void copy_cols_kernel(real* __restrict__ dst, const real* __restrict_
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) dst[r] = src[r];
 }
 
+// the two kernels above for a block of BS right-hand sides whose sweep also keeps [x ; s] interleaved (gs_slot_il_kernel):
+// a thread takes all columns of a row — the same expressions — and writes s to the column-major vector and, as one run of
+// BS values, to the interleaved one (sil = position of s[0] there)
+template <int BS>
+__global__ void gs_flip_rhs_il_kernel(const real* __restrict__ bp, const real* __restrict__ diag, const real* __restrict__ xp,
+                                      real* __restrict__ sp, int n, int64_t ldb, int64_t ldx, real scale, real* __restrict__ sil) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const real d = diag[r];
+#pragma unroll
+    for (int q = 0; q < BS; ++q) {
+      const real v = bp[r + q * ldb] - sp[r + q * ldx] + scale * (d * xp[r + q * ldx]);
+      sp[r + q * ldx] = v;
+      sil[(int64_t)r * BS + q] = v;
+    }
+  }
+}
+template <int BS>
+__global__ void copy_cols_il_kernel(real* __restrict__ dst, const real* __restrict__ src, int n, int64_t ld_dst, int64_t ld_src,
+                                    real* __restrict__ sil) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int q = 0; q < BS; ++q) {
+      const real v = src[r + q * ld_src];
+      dst[r + q * ld_dst] = v;
+      sil[(int64_t)r * BS + q] = v;
+    }
+  }
+}
+
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for outstanding
 // global loads (s_waitcnt vmcnt(0)), so prefetches issued before it stay in flight across it.  Only valid where
 // the data exchanged between the threads goes through LDS.
@@ -1131,42 +1160,39 @@ __global__ __launch_bounds__(256) void gs_sell_kernel(SellArgs a) {
 #pragma unroll
     for (int k = 0; k < NCV; ++k) bb[k] = bp[a.row0 + r + k * a.ldb];
   }
-  int t = 0;
-  for (; t + BATCH <= cd.y; t += BATCH) {
-    real v[BATCH], xv[BATCH][NCV];
-    int c[BATCH];
+  // entries t .. t + BATCH - 1 of every lane per round; the NEXT round's (col, val) are requested before this round's x
+  // gathers (round 6: with 8 columns per launch and 2 entries per round a 200-entry row was four dependent round trips —
+  // col / val, gather, col / val, gather — where the single column has two).  Per lane the products are added in entry
+  // order whatever BATCH is: the sums keep their bits.
+  const int nit = cd.y;   // (uniform over the wave: one chunk per wave)
+  int c[BATCH];
+  real v[BATCH];
 #pragma unroll
-    for (int e = 0; e < BATCH; ++e) c[e] = a.scol[base + (int64_t)(t + e) * kWave];
-#pragma unroll
-    for (int e = 0; e < BATCH; ++e) v[e] = a.sval[base + (int64_t)(t + e) * kWave];
-#pragma unroll
-    for (int e = 0; e < BATCH; ++e)
-#pragma unroll
-      for (int k = 0; k < NCV; ++k) xv[e][k] = c[e] >= 0 ? x[c[e] + k * a.ldx] : 0.0;
-#pragma unroll
-    for (int e = 0; e < BATCH; ++e)
-      if (c[e] >= 0) {
-#pragma unroll
-        for (int k = 0; k < NCV; ++k) acc[k] += v[e] * xv[e][k];
-      }
+  for (int e = 0; e < BATCH; ++e) {
+    c[e] = -1; v[e] = 0.0;
+    if (e < nit) { c[e] = a.scol[base + (int64_t)e * kWave]; v[e] = a.sval[base + (int64_t)e * kWave]; }
   }
-  if (t < cd.y) {  // tail of 1 .. BATCH-1 iterations, loads issued together
-    real v[BATCH], xv[BATCH][NCV];
-    int c[BATCH];
+  for (int t = 0; t < nit; t += BATCH) {
+    int cn[BATCH];
+    real vn[BATCH];
 #pragma unroll
-    for (int e = 0; e < BATCH - 1; ++e) c[e] = (t + e < cd.y) ? a.scol[base + (int64_t)(t + e) * kWave] : -1;
+    for (int e = 0; e < BATCH; ++e) {
+      cn[e] = -1; vn[e] = 0.0;
+      if (t + BATCH + e < nit) { cn[e] = a.scol[base + (int64_t)(t + BATCH + e) * kWave]; vn[e] = a.sval[base + (int64_t)(t + BATCH + e) * kWave]; }
+    }
+    real xv[BATCH][NCV];
 #pragma unroll
-    for (int e = 0; e < BATCH - 1; ++e) v[e] = (t + e < cd.y) ? a.sval[base + (int64_t)(t + e) * kWave] : 0.0;
-#pragma unroll
-    for (int e = 0; e < BATCH - 1; ++e)
+    for (int e = 0; e < BATCH; ++e)
 #pragma unroll
       for (int k = 0; k < NCV; ++k) xv[e][k] = c[e] >= 0 ? x[c[e] + k * a.ldx] : 0.0;
 #pragma unroll
-    for (int e = 0; e < BATCH - 1; ++e)
+    for (int e = 0; e < BATCH; ++e)
       if (c[e] >= 0) {
 #pragma unroll
         for (int k = 0; k < NCV; ++k) acc[k] += v[e] * xv[e][k];
       }
+#pragma unroll
+    for (int e = 0; e < BATCH; ++e) { c[e] = cn[e]; v[e] = vn[e]; }
   }
 #pragma unroll
   for (int k = 0; k < NCV; ++k) {
@@ -1197,6 +1223,175 @@ __global__ void sell_fill_kernel(const int32_t* prow, const int32_t* pcol, const
     const int e = t * K + sub;
     if (e < len) { scol[base + (int64_t)t * kWave] = pcol[a0 + e]; sval[base + (int64_t)t * kWave] = pval[a0 + e]; }
     else { scol[base + (int64_t)t * kWave] = -1; sval[base + (int64_t)t * kWave] = 0.0; }
+  }
+}
+
+// ---- merged groups for a block of right-hand sides from an INTERLEAVED vector (round 6) -----------------------------------
+// With the columns of a block ldx apart every matrix entry of a merged group costs one gather PER COLUMN, each its own
+// cache line: at bs = 8 the 62-entry rows of the 1.4 M-row level of the 256^3 hierarchy ran 13.6 us per launch against 5.4
+// for one column, and a what-if with one gather per entry said 4 of the 8 extra microseconds are those gathers (the L1 looks
+// up one line per lane and cycle).  Here the sweep's vector [x ; s] is ALSO kept interleaved (xil: the BS values of a
+// position side by side — one 64-byte sector at BS = 8); lane = (entry, column): the BS lanes of an entry read one sector,
+// a wave's gather touches 64 / BS lines instead of 64.  (col, val) are loaded once per entry and handed to the BS lanes by
+// wave shuffles.  Results go to xil AND to the column-major x (the rest of the cycle — residual, restriction, flip — reads
+// that one), so segments without an interleaved kernel (chains, long-row slots) run as before and only their rows are
+// copied over.  Exact Gauss-Seidel on the merged system; the order of a row's additions is the kernel's own (lanes per
+// row = 64 / BS), as with every several-lanes-per-row kernel of the merged groups.
+struct SlotIlArgs {
+  const int32_t* wcol;      // slot arrays (as SlotArgs)
+  const real* wval;
+  const int32_t* slot_row;
+  const i4_t* wmeta;
+  const real* diag;
+  real* xil;                // [x ; s] interleaved: position p, column q at p * BS + q
+  real* x;                  // the column-major x (columns ldx apart): written too
+  real omega;
+  int32_t slot0, nslots, xcd_map;
+  int32_t soff;             // position of s[0] in xil (= the operator's ncols)
+  int64_t ldx;
+};
+template <bool SOR, int BS>
+__global__ __launch_bounds__(kSlot) void gs_slot_il_kernel(SlotIlArgs a) {
+  static_assert(BS == 2 || BS == 4 || BS == 8 || BS == 16, "columns per block");
+  constexpr int EPW = kWave / BS;   // entries a wave handles per round = lanes per (row, column) sum
+  constexpr int NW = kSlot / kWave;
+  __shared__ real s_prod[kSlot * BS];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+  int lb = blockIdx.x;
+  if (a.xcd_map) lb = xcd_block(lb, a.nslots);
+  if (lb >= a.nslots) return;
+  const int s = a.slot0 + lb;
+  const int base = s * kSlot;
+  const real v = a.wval[base + tid];
+  const int c = a.wcol[base + tid];
+  const int r0 = a.slot_row[2 * s], nrows = a.slot_row[2 * s + 1] - r0;
+  const int q = lane % BS, sub = lane / BS;
+  real xv[BS], vv[BS];
+#pragma unroll
+  for (int k = 0; k < BS; ++k) {   // round k: entries w * 64 + k * EPW + (0 .. EPW - 1), BS lanes each
+    const int src = k * EPW + sub;
+    const int ck = __shfl(c, src, kWave);
+    vv[k] = __shfl(v, src, kWave);
+    xv[k] = a.xil[(int64_t)ck * BS + q];
+  }
+  // row data of this wave's first row, requested with the gathers
+  i4_t m = i4_t{0, 0, -1, 0};
+  real d = 0.0, bb = 0.0;
+  if (w < nrows) { m = a.wmeta[r0 + w]; d = a.diag[r0 + w]; bb = a.xil[(int64_t)(a.soff + r0 + w) * BS + q]; }
+#pragma unroll
+  for (int k = 0; k < BS; ++k) s_prod[(w * kWave + k * EPW) * BS + lane] = vv[k] * xv[k];   // entry e, column q at e * BS + q
+  __syncthreads();
+  for (int r = w; r < nrows; r += NW) {   // a wave per row: EPW lanes per column
+    if (r != w) { m = a.wmeta[r0 + r]; d = a.diag[r0 + r]; bb = a.xil[(int64_t)(a.soff + r0 + r) * BS + q]; }
+    const int dz = m.z - base, qe = m.y - base;
+    real acc = 0.0;
+    for (int e = m.x - base + sub; e < qe; e += EPW)
+      if (e != dz) acc += s_prod[e * BS + q];
+#pragma unroll
+    for (int o = BS; o < kWave; o <<= 1) acc += __shfl_xor(acc, o, kWave);
+    if (sub == 0 && d != 0.0) {
+      const int64_t i = r0 + r;
+      real* xi = a.xil + i * BS + q;
+      const real xn = SOR ? (1.0 - a.omega) * *xi + (a.omega / d) * (bb - acc) : (bb - acc) / d;
+      *xi = xn;
+      a.x[i + q * a.ldx] = xn;
+    }
+  }
+}
+
+// The SELL-like copy of a merged group the same way: the wave's 64 entry lanes of a storage iteration are taken EPW at a
+// time, BS column lanes each; BATCH iterations' gathers are in flight together and the next round's (col, val) are
+// requested before them.  Needs K >= EPW and K >= BS (a row's K entry lanes are whole rounds; other shapes keep
+// gs_sell_kernel and have their rows copied over).
+struct SellIlArgs {
+  const int32_t* scol;
+  const real* sval;
+  const i2_t* chunk;
+  const real* diag;
+  real* xil;
+  real* x;
+  real omega;
+  int32_t row0, nrows, chunk0, nchunks, xcd_map;
+  int32_t soff;
+  int64_t ldx;
+};
+template <bool SOR, int K, int BS, int BATCH>
+__global__ __launch_bounds__(256) void gs_sell_il_kernel(SellIlArgs a) {
+  constexpr int C = kWave / K;      // rows per chunk
+  constexpr int EPW = kWave / BS;   // entry lanes per round
+  constexpr int NR = BS;            // rounds per storage iteration
+  constexpr int G = K / EPW;        // rounds per row
+  static_assert(K >= EPW && K >= BS && K % EPW == 0, "a row's entry lanes are whole rounds");
+  const int nwg = (a.nchunks + 3) >> 2;
+  int wb = blockIdx.x;
+  if (a.xcd_map) wb = xcd_block(wb, nwg);
+  if (wb >= nwg) return;
+  const int ch = wb * 4 + (threadIdx.x >> 6);
+  if (ch >= a.nchunks) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const i2_t cd = a.chunk[a.chunk0 + ch];
+  const int64_t base = (int64_t)(uint32_t)cd.x * kWave + lane;
+  const int q = lane % BS, sub = lane / BS;
+  const int r = ch * C + sub;   // the row this lane writes (lanes sub < C)
+  const bool live = sub < C && r < a.nrows;
+  real d = 0.0, bb = 0.0;
+  if (live) { d = a.diag[a.row0 + r]; bb = a.xil[(int64_t)(a.soff + a.row0 + r) * BS + q]; }
+  real acc[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) acc[k] = 0.0;
+  const int nit = cd.y;
+  int c[BATCH];
+  real v[BATCH];
+#pragma unroll
+  for (int e = 0; e < BATCH; ++e) {
+    c[e] = -1; v[e] = 0.0;
+    if (e < nit) { c[e] = a.scol[base + (int64_t)e * kWave]; v[e] = a.sval[base + (int64_t)e * kWave]; }
+  }
+  for (int t = 0; t < nit; t += BATCH) {
+    int cn[BATCH];
+    real vn[BATCH];
+#pragma unroll
+    for (int e = 0; e < BATCH; ++e) {
+      cn[e] = -1; vn[e] = 0.0;
+      if (t + BATCH + e < nit) { cn[e] = a.scol[base + (int64_t)(t + BATCH + e) * kWave]; vn[e] = a.sval[base + (int64_t)(t + BATCH + e) * kWave]; }
+    }
+    int cc[BATCH][NR];
+    real vv[BATCH][NR], xv[BATCH][NR];
+#pragma unroll
+    for (int e = 0; e < BATCH; ++e)
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int src = k * EPW + sub;
+        cc[e][k] = __shfl(c[e], src, kWave);
+        vv[e][k] = __shfl(v[e], src, kWave);
+        xv[e][k] = cc[e][k] >= 0 ? a.xil[(int64_t)cc[e][k] * BS + q] : 0.0;
+      }
+#pragma unroll
+    for (int e = 0; e < BATCH; ++e)
+#pragma unroll
+      for (int k = 0; k < NR; ++k)
+        if (cc[e][k] >= 0) acc[k] += vv[e][k] * xv[e][k];
+#pragma unroll
+    for (int e = 0; e < BATCH; ++e) { c[e] = cn[e]; v[e] = vn[e]; }
+  }
+  // entry lane k * EPW + sub belongs to row (k * EPW + sub) / K = k / G of the chunk: the rounds of a row in this lane,
+  // then the EPW lanes of the column
+  real tot = 0.0;
+#pragma unroll
+  for (int mrow = 0; mrow < C; ++mrow) {
+    real ra = acc[mrow * G];
+#pragma unroll
+    for (int g2 = 1; g2 < G; ++g2) ra += acc[mrow * G + g2];
+#pragma unroll
+    for (int o = BS; o < kWave; o <<= 1) ra += __shfl_xor(ra, o, kWave);
+    if (sub == mrow) tot = ra;
+  }
+  if (live && d != 0.0) {
+    const int64_t i = a.row0 + r;
+    real* xi = a.xil + i * BS + q;
+    const real xn = SOR ? (1.0 - a.omega) * *xi + (a.omega / d) * (bb - tot) : (bb - tot) / d;
+    *xi = xn;
+    a.x[i + q * a.ldx] = xn;
   }
 }
 
@@ -1717,14 +1912,24 @@ __global__ __launch_bounds__(kThreads) void tri_gemv_kernel(const real* X, const
   const int i = blockIdx.x, tid = threadIdx.x;
   const real* sv = s + (int64_t)blockIdx.y * NC * lds;
   const real* row = X + (size_t)i * n;
-  const int lo = upper ? i : 0, hi = upper ? n : i + 1;
+  // a thread's entries are a function of the COLUMN alone — lower: j = tid, tid + 256, ... up to the diagonal; upper: j = n - 1 -
+  // tid, n - 1 - tid - 256, ... down to it — so that tri_gemm_kernel (several rows per workgroup sharing the loads of s) forms
+  // every sum from the same partial sums in the same order
   real acc[NC];
 #pragma unroll
   for (int q = 0; q < NC; ++q) acc[q] = 0.0;
-  for (int j = lo + tid; j < hi; j += kThreads) {
-    const real r = row[j];
+  if (!upper) {
+    for (int j = tid; j <= i; j += kThreads) {
+      const real r = row[j];
 #pragma unroll
-    for (int q = 0; q < NC; ++q) acc[q] += r * sv[j + q * lds];
+      for (int q = 0; q < NC; ++q) acc[q] += r * sv[j + q * lds];
+    }
+  } else {
+    for (int j = n - 1 - tid; j >= i; j -= kThreads) {
+      const real r = row[j];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) acc[q] += r * sv[j + q * lds];
+    }
   }
 #pragma unroll
   for (int q = 0; q < NC; ++q) {
@@ -1737,6 +1942,62 @@ __global__ __launch_bounds__(kThreads) void tri_gemv_kernel(const real* X, const
 #pragma unroll
     for (int w = 1; w < kThreads / kWave; ++w) t += s_part[tid][w];
     x[((int64_t)blockIdx.y * NC + tid) * ldx + i] = t;
+  }
+}
+
+// The same product for a block of NC right-hand sides with RB consecutive rows per workgroup (round 6): with one row per
+// workgroup every entry of X costs NC loads of s beside its own — 9 x the row's bytes through L2 at NC = 8, 38.6 us per launch
+// of a 4 096-row block where a single column takes 13.8.  RB rows share a thread's NC loads of s (registers): RB + NC loads per
+// RB * NC multiply-adds.  The partial sums, the tree and the order of the wave partials are tri_gemv_kernel's: bit for bit its
+// result per column.
+template <int NC, int RB>
+__global__ __launch_bounds__(kThreads) void tri_gemm_kernel(const real* X, const real* s, real* x, int n, int upper, int64_t lds,
+                                                              int64_t ldx) {
+  __shared__ real s_part[RB * NC][kThreads / kWave];
+  const int i0 = blockIdx.x * RB, tid = threadIdx.x;
+  const real* sv = s + (int64_t)blockIdx.y * NC * lds;
+  real acc[RB][NC];
+#pragma unroll
+  for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[rr][q] = 0.0;
+  const int ilast = min(i0 + RB, n) - 1;   // the last row of this workgroup
+  const int step = upper ? -kThreads : kThreads;
+  for (int j = upper ? n - 1 - tid : tid; upper ? j >= i0 : j <= ilast; j += step) {
+    real sq[NC], r[RB];
+    bool ok[RB];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) sq[q] = sv[j + q * lds];
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) {
+      const int i = i0 + rr;
+      ok[rr] = i < n && (upper ? j >= i : j <= i);
+      r[rr] = ok[rr] ? X[(size_t)i * n + j] : 0.0;
+    }
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr)
+      if (ok[rr]) {
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[rr][q] += r[rr] * sq[q];
+      }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      real v = acc[rr][q];
+      for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+      if (tid % kWave == 0) s_part[rr * NC + q][tid / kWave] = v;
+    }
+  __syncthreads();
+  if (tid < RB * NC) {
+    const int rr = tid / NC, q = tid % NC, i = i0 + rr;
+    if (i < n) {
+      real t = s_part[tid][0];
+#pragma unroll
+      for (int w = 1; w < kThreads / kWave; ++w) t += s_part[tid][w];
+      x[((int64_t)blockIdx.y * NC + q) * ldx + i] = t;
+    }
   }
 }
 

@@ -392,6 +392,62 @@ int launch_sell(const SellArgs& a, bool sor, int k, int grid, int ncolv, hipStre
     default: return launch_sell_k<64>(a, sor, grid, ncolv, st);
   }
 }
+// the interleaved kernels of a block of bs = 2 / 4 / 8 right-hand sides (gs_slot_il_kernel, gs_sell_il_kernel)
+int launch_slot_il(const SlotIlArgs& a, bool sor, int bs, int grid, hipStream_t st) {
+#define AMGH_SLOT_IL(BS_) \
+  do { if (sor) hipLaunchKernelGGL((gs_slot_il_kernel<true, BS_>), dim3(grid), dim3(kSlot), 0, st, a); \
+       else hipLaunchKernelGGL((gs_slot_il_kernel<false, BS_>), dim3(grid), dim3(kSlot), 0, st, a); } while (0)
+  switch (bs) {
+    case 8: AMGH_SLOT_IL(8); break;
+    case 4: AMGH_SLOT_IL(4); break;
+    case 2: AMGH_SLOT_IL(2); break;
+    default: return AMGH_EUNSUPPORTED;
+  }
+#undef AMGH_SLOT_IL
+  return AMGH_OK;
+}
+inline bool sell_il_shape(int k, int bs) { return (bs == 8 || bs == 4 || bs == 2) && k >= kWave / bs && k >= bs; }
+template <int K, int BS>
+int launch_sell_il_kb(const SellIlArgs& a, bool sor, int grid, hipStream_t st) {
+  if constexpr (K >= kWave / BS && K >= BS) {
+    constexpr int BATCH = BS >= 8 ? 2 : 4;   // (storage iterations in flight per lane; at BS = 8: 1: 7.57, 2: 6.13, 4: 6.16 ms on the 228 538-row level of the 256^3 hierarchy)
+    if (sor) hipLaunchKernelGGL((gs_sell_il_kernel<true, K, BS, BATCH>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gs_sell_il_kernel<false, K, BS, BATCH>), dim3(grid), dim3(256), 0, st, a);
+    return AMGH_OK;
+  } else {
+    return AMGH_EUNSUPPORTED;
+  }
+}
+template <int K>
+int launch_sell_il_k(const SellIlArgs& a, bool sor, int bs, int grid, hipStream_t st) {
+  switch (bs) {
+    case 8: return launch_sell_il_kb<K, 8>(a, sor, grid, st);
+    case 4: return launch_sell_il_kb<K, 4>(a, sor, grid, st);
+    case 2: return launch_sell_il_kb<K, 2>(a, sor, grid, st);
+  }
+  return AMGH_EUNSUPPORTED;
+}
+int launch_sell_il(const SellIlArgs& a, bool sor, int k, int bs, int grid, hipStream_t st) {
+  switch (k) {
+    case 8: return launch_sell_il_k<8>(a, sor, bs, grid, st);
+    case 16: return launch_sell_il_k<16>(a, sor, bs, grid, st);
+    case 32: return launch_sell_il_k<32>(a, sor, bs, grid, st);
+    default: return launch_sell_il_k<64>(a, sor, bs, grid, st);
+  }
+}
+// positions [p0, p0 + np) of the column-major xp (columns ld apart) into the interleaved copy
+int il_copy_rows(int bs, const real* xp, int64_t ld, real* xil, int64_t p0, int64_t np, hipStream_t st) {
+  if (np <= 0) return AMGH_OK;
+  const unsigned grid = (unsigned)((np + 63) / 64);
+  switch (bs) {
+    case 8: hipLaunchKernelGGL((to_interleaved_kernel<8>), dim3(grid), dim3(256), 0, st, xp + p0, ld, xil + p0 * 8, np); break;
+    case 4: hipLaunchKernelGGL((to_interleaved_kernel<4>), dim3(grid), dim3(256), 0, st, xp + p0, ld, xil + p0 * 4, np); break;
+    case 2: hipLaunchKernelGGL((to_interleaved_kernel<2>), dim3(grid), dim3(256), 0, st, xp + p0, ld, xil + p0 * 2, np); break;
+    default: return AMGH_EUNSUPPORTED;
+  }
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
 int launch_slot(const SlotArgs& sa, bool sor, int ncv, int grid, hipStream_t st) {
   switch (ncv) {
     case 8: return launch_slot_t<8>(sa, sor, grid, st);
@@ -478,7 +534,13 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       else RC_TRY((launch_stream<M_RESID, StreamCfg<256, 64, 4096, 2, false, false>>(ra, st, ncolv)));
       const real* Xk = (const real*)((backward ? g->dti_b : g->dti_f) + g->dti_off[k]);
       // columns per workgroup: the largest of 8 / 4 / 2 / 1 that divides the block of right-hand sides
-      if (ncolv % 8 == 0) hipLaunchKernelGGL(tri_gemv_kernel<8>, dim3((unsigned)rb, ncolv / 8), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      // (blocks of right-hand sides: 4 rows per workgroup share the loads of s — tri_gemm_kernel, bitwise tri_gemv_kernel; tunable gs_tri_rb)
+      constexpr int RB = 4;
+      const unsigned rgrid = (unsigned)((rb + RB - 1) / RB);
+      if (ncolv % 8 == 0 && g_gs_tri_rb) hipLaunchKernelGGL((tri_gemm_kernel<8, RB>), dim3(rgrid, ncolv / 8), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      else if (ncolv % 4 == 0 && g_gs_tri_rb) hipLaunchKernelGGL((tri_gemm_kernel<4, RB>), dim3(rgrid, ncolv / 4), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      else if (ncolv % 2 == 0 && g_gs_tri_rb) hipLaunchKernelGGL((tri_gemm_kernel<2, RB>), dim3(rgrid, ncolv / 2), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      else if (ncolv % 8 == 0) hipLaunchKernelGGL(tri_gemv_kernel<8>, dim3((unsigned)rb, ncolv / 8), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
       else if (ncolv % 4 == 0) hipLaunchKernelGGL(tri_gemv_kernel<4>, dim3((unsigned)rb, ncolv / 4), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
       else if (ncolv % 2 == 0) hipLaunchKernelGGL(tri_gemv_kernel<2>, dim3((unsigned)rb, ncolv / 2), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
       else hipLaunchKernelGGL(tri_gemv_kernel<1>, dim3((unsigned)rb, ncolv), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
@@ -557,6 +619,21 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
     }
   }
   const int64_t xs = g->xstride;  // doubles per column of xp
+  // blocks of 2 / 4 / 8 right-hand sides on merged groups: the groups gather from an interleaved copy of [x ; s] (one
+  // sector per entry for all columns instead of one line per column) and write both; xil's x part is current only from one
+  // sweep of a smooth! call to the next (prolongation, fills and gathers write xp alone)
+  const bool il = g_gs_il && g_gs_lpr != 1 && lay != g && !g->bw.on && (ncolv == 8 || ncolv == 4 || ncolv == 2);
+  if (first || !il) g->xil_cols = 0;
+  bool il_s_ok = false;   // the s part of xil was written by the kernel that produced s
+  if (il && g->xil_cap < xs * ncolv) {   // (the first cycle of every kind runs eagerly: never during a capture)
+    HIP_TRY(hipStreamSynchronize(st));
+    ++g_sched_epoch;
+    hipFree(g->xil); g->xil = nullptr; g->xil_cap = 0;
+    RC_TRY(dev_alloc(&g->xil, xs * ncolv));
+    g->xil_cap = xs * ncolv;
+    g->bytes += (int64_t)sizeof(real) * xs * ncolv; op->bytes += (int64_t)sizeof(real) * xs * ncolv;
+    g->xil_cols = 0;
+  }
   if (first) {
     if (!(reuse_b && g->bp_cols == ncolv))
       hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, b, g->perm, g->bp, (int)g->n,
@@ -571,6 +648,11 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       if (!flow_zero) {
         const int64_t cnt = xs * ncolv;  // (a fill kernel: hipMemsetAsync of a small buffer costs far more than a launch)
         hipLaunchKernelGGL(fill_kernel, dim3(grid_for(cnt)), dim3(256), 0, st, g->xp, cnt, 0.0);
+        if (il) {   // x = 0 in the interleaved copy too (no transposition pass)
+          const int64_t ci = g->ncols * ncolv;
+          hipLaunchKernelGGL(fill_kernel, dim3(grid_for(ci)), dim3(256), 0, st, g->xil, ci, 0.0);
+          g->xil_cols = ncolv;
+        }
       }
     } else {
       hipLaunchKernelGGL(gather_perm_kernel, dim3(grid_for(g->ncols), ncolv), dim3(256), 0, st, (const real*)x, g->permx,
@@ -588,11 +670,27 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
                       g->s_dir == (backward ? 0 : 1) && g->s_key == s_key;
     if (flip) {
       // the previous sweep of this smooth! call ran the other way on the same xp: s follows without a matrix pass
+      if (il) {   // (the same expression, all columns of a row by one thread: s goes to xp and, as whole sectors, to xil)
+        real* sil = g->xil + g->ncols * ncolv;
+#define AMGH_FLIP_IL(BS_) hipLaunchKernelGGL((gs_flip_rhs_il_kernel<BS_>), dim3(grid_for(g->n)), dim3(256), 0, st, (const real*)g->bp, \
+                         (const real*)lay->diag, (const real*)xp, xp + g->ncols, (int)g->n, (int64_t)g->n, xs, flip_scale, sil)
+        if (ncolv == 8) AMGH_FLIP_IL(8); else if (ncolv == 4) AMGH_FLIP_IL(4); else AMGH_FLIP_IL(2);
+#undef AMGH_FLIP_IL
+        il_s_ok = true;
+      } else
       hipLaunchKernelGGL(gs_flip_rhs_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, (const real*)g->bp,
                          (const real*)lay->diag, (const real*)xp, xp + g->ncols, (int)g->n, (int64_t)g->n, xs,
                          flip_scale);
       HIP_TRY(hipGetLastError());
     } else if (first && xzero) {  // s = b - T * 0
+      if (il) {
+        real* sil = g->xil + g->ncols * ncolv;
+#define AMGH_COPY_IL(BS_) hipLaunchKernelGGL((copy_cols_il_kernel<BS_>), dim3(grid_for(g->n)), dim3(256), 0, st, xp + g->ncols, \
+                         (const real*)g->bp, (int)g->n, xs, (int64_t)g->n, sil)
+        if (ncolv == 8) AMGH_COPY_IL(8); else if (ncolv == 4) AMGH_COPY_IL(4); else AMGH_COPY_IL(2);
+#undef AMGH_COPY_IL
+        il_s_ok = true;
+      } else
       hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(g->n), ncolv), dim3(256), 0, st, xp + g->ncols,
                          (const real*)g->bp, (int)g->n, xs, (int64_t)g->n);
       HIP_TRY(hipGetLastError());
@@ -669,6 +767,11 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
     }
     if (e != hipSuccess) return -(1000 + (int)e);
   }
+  if (il) {   // what of xil the producers above did not write
+    if (g->xil_cols != ncolv) RC_TRY(il_copy_rows(ncolv, xp, xs, g->xil, 0, il_s_ok ? g->ncols : xs, st));   // x (and s)
+    else if (!il_s_ok) RC_TRY(il_copy_rows(ncolv, xp, xs, g->xil, g->ncols, g->n, st));                      // s alone
+    g->xil_cols = ncolv;
+  }
   const int ns = (int)lay->segs.size();
   // (g_gs_dup_launch: measurement hook — every group launched 1 + that many times: a group's launch is idempotent, the
   // repeats find its arrays in cache: what a prefetch of the next group's arrays could win at most)
@@ -696,6 +799,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
         continue;
       }
       RC_TRY(launch_chain(c, sor, ldsx, s.rows, (int)nx, st, ncolv));
+      if (il) RC_TRY(il_copy_rows(ncolv, xp, xs, g->xil, lay->lvl_ptr[s.l0], lay->lvl_ptr[s.l1] - lay->lvl_ptr[s.l0], st));
     } else if (s.sell_k > 0 && lay->scol && g_gs_sell) {
       SellArgs la{};
       la.scol = lay->scol; la.sval = lay->sval; la.chunk = lay->schunk; la.diag = lay->diag; la.bp = rhs; la.x = xp;
@@ -707,8 +811,18 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       // to win and the mapping unbalances the XCDs (the 228 538-row level of the 256^3 hierarchy: 1.40 -> 1.29 ms per pass)
       la.xcd_map = (g_gs_xcd_map && nwg >= 768) ? 1 : 0;
       const int grid = la.xcd_map ? ((nwg + kNumXcd - 1) / kNumXcd) * kNumXcd : nwg;
+      if (il && sell_il_shape(s.sell_k, ncolv)) {
+        SellIlArgs ia{};
+        ia.scol = la.scol; ia.sval = la.sval; ia.chunk = la.chunk; ia.diag = la.diag; ia.xil = g->xil; ia.x = xp; ia.omega = omega;
+        ia.row0 = la.row0; ia.nrows = la.nrows; ia.chunk0 = la.chunk0; ia.nchunks = la.nchunks; ia.xcd_map = la.xcd_map;
+        ia.soff = (int32_t)g->ncols; ia.ldx = xs;
+        RC_TRY(launch_sell_il(ia, sor, s.sell_k, ncolv, grid, st));
+        HIP_TRY(hipGetLastError());
+        continue;
+      }
       RC_TRY(launch_sell(la, sor, s.sell_k, grid, ncolv, st));
       HIP_TRY(hipGetLastError());
+      if (il) RC_TRY(il_copy_rows(ncolv, xp, xs, g->xil, la.row0, la.nrows, st));
     } else if (s.nslots > 0 && (g_gs_slots || lay->compacted)) {
       SlotArgs sa{};
       sa.wcol = lay->wcol; sa.wval = lay->wval; sa.slot_row = lay->slot_row; sa.wmeta = lay->wmeta;
@@ -722,6 +836,18 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
         const int grid = ((xmap || ncolv > 1) ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots) * ncolv;
         if (sor) hipLaunchKernelGGL(gs_bigslot_kernel<true>, dim3(grid), dim3(kSlot), 0, st, sa);
         else hipLaunchKernelGGL(gs_bigslot_kernel<false>, dim3(grid), dim3(kSlot), 0, st, sa);
+        HIP_TRY(hipGetLastError());
+        if (il) RC_TRY(il_copy_rows(ncolv, xp, xs, g->xil, lay->lvl_ptr[s.l0], lay->lvl_ptr[s.l1] - lay->lvl_ptr[s.l0], st));
+        continue;
+      }
+      if (il) {
+        SlotIlArgs ia{};
+        ia.wcol = sa.wcol; ia.wval = sa.wval; ia.slot_row = sa.slot_row; ia.wmeta = sa.wmeta; ia.diag = sa.diag;
+        ia.xil = g->xil; ia.x = xp; ia.omega = omega; ia.slot0 = s.slot0; ia.nslots = s.nslots;
+        ia.xcd_map = (g_gs_xcd_map && s.nslots >= 768) ? 1 : 0;
+        ia.soff = (int32_t)g->ncols; ia.ldx = xs;
+        const int grid = ia.xcd_map ? ((s.nslots + kNumXcd - 1) / kNumXcd) * kNumXcd : s.nslots;
+        RC_TRY(launch_slot_il(ia, sor, ncolv, grid, st));
         HIP_TRY(hipGetLastError());
         continue;
       }
@@ -754,6 +880,7 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       a.row_begin = lay->lvl_ptr[s.l0]; a.row_end = lay->lvl_ptr[s.l0 + 1];
       a.ldx = xs; a.ldy = xs; a.ldb = ldb;
       RC_TRY(sor ? launch_gs_level<M_SOR>(a, s.rows, st, ncolv) : launch_gs_level<M_GS>(a, s.rows, st, ncolv));
+      if (il) RC_TRY(il_copy_rows(ncolv, xp, xs, g->xil, a.row_begin, a.row_end - a.row_begin, st));
     }
   }
   if (last && !no_scatter) {
