@@ -466,6 +466,35 @@ int pcg_dev(amgh_t* h, const real* b, real* x, int cyc, int use_precond, int max
   const real one = 1.0;
   HIP_TRY(hipMemcpyAsync(h->scal + 1, &one, sizeof(real), hipMemcpyHostToDevice, h->stream));  // rho = 1
   int it = 0;
+  // the recurrence between two cycles in 8 launches (pcg_scal_kernel / pcg_update_kernel); the same operations in the same
+  // order: bitwise the launch-per-operation loop below (tunable pcg_fused = 0)
+  if (g_pcg_fused) {
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kThreads - 1) / kThreads));
+    if (use_precond) RC_TRY(vec_fill(h, c, n, 0.0));   // (once: every iteration leaves c = 0 behind)
+    while (it < maxiter && residual > tol) {
+      if (use_precond) RC_TRY(apply_cycle(h, c, r, cyc, true));
+      else RC_TRY(vec_copy(h, c, r, n));
+      {
+        hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, h->stream, (const real*)c, (const real*)r, n, h->partial);
+        hipLaunchKernelGGL(pcg_scal_kernel, dim3(1), dim3(kThreads), 0, h->stream, (const real*)h->partial, nb, h->scal, 0);
+        hipLaunchKernelGGL(xpby_dev_kernel, dim3(grid_for(n)), dim3(256), 0, h->stream, u, c, h->scal + 4, n);
+        RC_TRY(fine_spmv(h, u, c));
+        hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kThreads), 0, h->stream, (const real*)u, (const real*)c, n, h->partial);
+        hipLaunchKernelGGL(pcg_scal_kernel, dim3(1), dim3(kThreads), 0, h->stream, (const real*)h->partial, nb, h->scal, 1);
+        hipLaunchKernelGGL(pcg_update_kernel, dim3(nb), dim3(kThreads), 0, h->stream, x, (const real*)u, r, c, (const real*)(h->scal + 3), n, h->partial);
+        hipLaunchKernelGGL(pcg_scal_kernel, dim3(1), dim3(kThreads), 0, h->stream, (const real*)h->partial, nb, h->scal, 2);
+      }
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(&residual, h->scal, sizeof(real), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      ++it;
+      if (hist) hist[it] = residual;
+    }
+    if (iters) *iters = it;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    RC_TRY(prof_flush(h));
+    return bw_err_check();
+  }
   while (it < maxiter && residual > tol) {
     if (use_precond) {
       RC_TRY(vec_fill(h, c, n, 0.0));
@@ -1882,6 +1911,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
   else if (!strcmp(name, "gs_lpr")) g_gs_lpr = value;
   else if (!strcmp(name, "gs_il")) g_gs_il = value;
+  else if (!strcmp(name, "pcg_fused")) g_pcg_fused = value;
   else if (!strcmp(name, "gs_tri_rb")) g_gs_tri_rb = value;
   else if (!strcmp(name, "gs_lean")) g_gs_lean = value;
   else if (!strcmp(name, "gs_sell")) g_gs_sell = value;

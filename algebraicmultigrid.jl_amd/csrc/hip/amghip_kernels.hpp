@@ -1854,6 +1854,44 @@ __global__ void scalar_kernel(real* out, const real* a, const real* b, int op) {
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (op == 0) ? a[0] / b[0] : a[0];
 }
 
+// ---- the device-resident PCG recurrence in fewer launches (round 6) ----------------------------------------------------------
+// Between two V-cycles an iteration of pcg_dev was 15 launches (memset, copy of rho, two-stage dots, scalar divisions, xpby,
+// SpMV, two axpys, two-stage norm).  The same sums, products
+// and quotients in the same order (bitwise the unfused recurrence), fused:
+//   pcg_scal_kernel      the second stage of a dot product + the scalar step that consumes it
+//   pcg_update_kernel    x += alpha u, r -= alpha c, c = 0 (the next cycle's x = 0), first stage of |r|^2
+// 8 launches.  C5: 13 iterations 3.16 -> 3.05 ms; 160^3: 7.18 -> 7.12 ms per iteration.  (Everything between two cycles in ONE
+// workgroup was built for small operators and measured: C5 3.13 ms, 13 824 rows 0.79 instead of 0.55 ms per iteration — the
+// launches of the recurrence queue behind the cycle and cost ~2 us each, a one-workgroup SpMV costs more; removed.)
+// scal: [0] |r|, [1] rho, [2] rho_prev, [3] alpha, [4] beta, [5] u.c
+// which = 0: rho_prev = rho, rho = sum, beta = rho / rho_prev; which = 1: u.c = sum, alpha = rho / u.c; which = 2: |r| = sqrt(sum)
+__global__ __launch_bounds__(kThreads) void pcg_scal_kernel(const real* partial, int np, real* scal, int which) {
+  __shared__ real s_part[kThreads / kWave];
+  real v = 0.0;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) v += partial[i];
+  const real r = block_reduce_sum(v, s_part);
+  if (threadIdx.x == 0) {
+    if (which == 0) { const real rp = scal[1]; scal[2] = rp; scal[1] = r; scal[4] = r / rp; }
+    else if (which == 1) { scal[5] = r; scal[3] = scal[1] / r; }
+    else scal[0] = sqrt(r);
+  }
+}
+__global__ __launch_bounds__(kThreads) void pcg_update_kernel(real* x, const real* u, real* r, real* c, const real* alpha, int64_t n,
+                                                                real* partial) {
+  __shared__ real s_part[kThreads / kWave];
+  const real ap = 1.0 * alpha[0], am = -1.0 * alpha[0];
+  real v = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    x[i] = x[i] + ap * u[i];
+    const real rn = r[i] + am * c[i];
+    r[i] = rn;
+    c[i] = 0.0;
+    v += rn * rn;
+  }
+  const real t = block_reduce_sum(v, s_part);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
 // ---- dense triangular inverse (small operators) -------------------------------------------------------------------
 // X = (D + L)^-1 (upper = 0) or (D + U)^-1 (upper = 1) of a diagonal block of a CSR matrix, dense n x n ROW-major: one thread per column c
 // runs the substitution T X[:, c] = e_c down (up) the rows; a column depends on itself only, and the threads of a

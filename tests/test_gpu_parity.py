@@ -436,6 +436,35 @@ def test_lin_elastic_c5():  # nns_test.jl:213-226
     assert log["iters"] == itp == 13 and rel(xp, xpo) <= 1e-9
 
 
+@pytest.mark.parametrize("case", ["c5", "small", "large"])
+def test_pcg_launch_plans_are_bitwise_the_same_recurrence(case):
+    """amgh_pcg between two cycles: one launch per operation (pcg_fused = 0, 15 launches), or the dot products' second stages
+    fused with the scalar steps and the updates with the norm (1, 8 launches).  The same sums, products and quotients in the
+    same order: identical iterates, residual histories and counts (IterativeSolvers' cg recurrence, runtests.jl:186,204)."""
+    if case == "c5":
+        d = load_npz("lin_elastic_2d")
+        A, b = load_csc("lin_elastic_2d"), d["b"]
+        ml = AMG.smoothed_aggregation(A, B=d["B"])
+    else:
+        A = AMG.poisson((20, 20, 20)) if case == "small" else AMG.poisson((30, 30, 30))
+        b = uniform(A.m, 91) - 0.4
+        ml = AMG.ruge_stuben(A)
+    lib = AMG.hip_lib()
+    out = {}
+    try:
+        for plan in (0, 1):
+            assert lib.amgh_debug_set_tunable(b"pcg_fused", plan) == 0
+            out[plan] = AMG.cg(A, b, Pl=AMG.aspreconditioner(ml), reltol=1e-10, log=True)
+    finally:
+        lib.amgh_debug_set_tunable(b"pcg_fused", 1)
+    for plan in (1,):
+        assert out[plan][1]["iters"] == out[0][1]["iters"]
+        assert np.array_equal(out[plan][1]["resnorm"], out[0][1]["resnorm"])
+        assert np.array_equal(out[plan][0], out[0][0])
+    xo, _, ito = O.OracleHierarchy(ml).pcg(b, reltol=1e-10)
+    assert out[1][1]["iters"] == ito and rel(out[1][0], xo) <= 1e-9
+
+
 def test_degenerate_hierarchies():
     # no levels: every "cycle" is the coarse solve (multilevel.jl:179-180)
     for sz in (10, 5, 2):
