@@ -1911,6 +1911,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
   else if (!strcmp(name, "gs_lpr")) g_gs_lpr = value;
   else if (!strcmp(name, "gs_il")) g_gs_il = value;
+  else if (!strcmp(name, "gs_wave_quad")) g_gs_wave_quad = value;
   else if (!strcmp(name, "pcg_fused")) g_pcg_fused = value;
   else if (!strcmp(name, "gs_tri_rb")) g_gs_tri_rb = value;
   else if (!strcmp(name, "gs_lean")) g_gs_lean = value;

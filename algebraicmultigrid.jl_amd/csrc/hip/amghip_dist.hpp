@@ -1303,20 +1303,44 @@ int dist_pipe_setup(amgh_dist* d) {
     bool protocol = true;
     bool concurrent = true;
     RC_TRY(dist_pipe_probe(d, where, &concurrent));
-    // Two ranks of this process on one hardware queue: the runtime hands queues out round-robin at stream creation, so the ranks
-    // take fresh sweep streams ONE AFTER THE OTHER (rank order, a barrier between them: N consecutive creations land on N
-    // different queues while N <= GPU_MAX_HW_QUEUES) and the probe runs again.  Nothing has been enqueued on the old stream
-    // that a later call depends on (the collapsed levels are bound to the handle's stream after this), so it is simply replaced.
+    // Two ranks of this process on one hardware queue.  The runtime gives a new stream the hardware queue with the FEWEST streams
+    // on it (tools/hwq_probe.hip: 16 streams in a row land 0 1 2 .. 7 7 .. 0 on 8 queues; empty one queue and the next TWO streams
+    // both go there) — in a process that has created and destroyed streams unevenly, consecutive creations need not land on
+    // different queues.  So the first rank of every (process, device) group first creates BALLAST streams, which level the
+    // queues' counts (4 fresh streams behind 16 ballast streams: 4 queues, also after the ballast is gone), then the ranks take
+    // fresh sweep streams ONE AFTER THE OTHER (rank order, a barrier between them), the ballast goes, and the probe runs again —
+    // with 16, 64, 256 ballast streams.  Nothing has been enqueued on the old stream that a later call depends on (the collapsed
+    // levels are bound to the handle's stream after this), so it is simply replaced.
+    bool leader = true;   // the lowest rank of my process on my device
+    if (!concurrent) {
+      std::vector<int64_t> mine{(int64_t)getpid(), where};
+      std::vector<std::vector<int64_t>> all;
+      RC_TRY(tr->allgatherv_host(mine, all));
+      for (int p = 0; p < me && p < (int)all.size(); ++p)
+        if (all[(size_t)p].size() >= 2 && all[(size_t)p][0] == mine[0] && all[(size_t)p][1] == mine[1]) leader = false;
+    }
     for (int attempt = 0; attempt < 3 && !concurrent; ++attempt) {
       double bad_stream = 0.0;
+      std::vector<hipStream_t> ballast;
+      if (leader) {
+        const int nb = 16 << (2 * attempt);
+        for (int k = 0; k < nb; ++k) {
+          hipStream_t bs = nullptr;
+          if (hipStreamCreateWithFlags(&bs, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+          ballast.push_back(bs);
+        }
+      }
+      RC_TRY(tr->barrier());
+      hipStream_t fresh = nullptr;
       for (int p = 0; p < N; ++p) {
-        if (p == me) {
-          hipStream_t fresh = nullptr;
-          if (hipStreamSynchronize(d->stream) != hipSuccess || hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); bad_stream = 1.0; }
-          else { (void)hipStreamDestroy(d->stream); d->stream = fresh; }
+        if (p == me && (hipStreamSynchronize(d->stream) != hipSuccess || hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess)) {
+          (void)hipGetLastError(); bad_stream = 1.0; fresh = nullptr;
         }
         RC_TRY(tr->barrier());
       }
+      // (old streams and ballast go only now: a stream destroyed between two creations would draw the next one onto its queue)
+      if (fresh) { (void)hipStreamDestroy(d->stream); d->stream = fresh; }
+      for (hipStream_t bs : ballast) (void)hipStreamDestroy(bs);
       RC_TRY(tr->allreduce(&bad_stream, 1, true));
       if (bad_stream != 0.0) break;
       RC_TRY(dist_pipe_probe(d, where, &concurrent));

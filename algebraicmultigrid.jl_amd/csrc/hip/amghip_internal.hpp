@@ -241,6 +241,7 @@ struct GsSchedule {
   // the same operator as one record walked by a single wave (gs_wave_kernel): built when it fits (rows of at most
   // kWaveMaxK off-diagonal entries, at most kWaveMaxSteps steps, the LDS budget)
   unsigned char* ww_rec = nullptr; int ww_S = 0, ww_maxk = 0, ww_steps = 0; size_t ww_lds = 0;
+  unsigned char* wq_rec = nullptr; int wq_E = 0, wq_steps = 0; size_t wq_lds = 0;   // ... with four lanes per row (gs_waveq_kernel): 4 n mini-rows of wq_E entries
   i4_t* rowmeta = nullptr;  // per permuted row {start, end, diagonal position, original row}
   i4_t* desc = nullptr;     // per dependency level {first row, end row, first nnz, end nnz}
   real* bp = nullptr;     // right-hand side in dependency-level order (scratch)
@@ -342,6 +343,7 @@ struct GsSchedule {
     hipFree(wcol); hipFree(wval); hipFree(slot_row); hipFree(wmeta); wcol = slot_row = nullptr; wval = nullptr; wmeta = nullptr;
     hipFree(scol); hipFree(sval); hipFree(schunk); scol = nullptr; sval = nullptr; schunk = nullptr;
     hipFree(ww_rec); ww_rec = nullptr;
+    hipFree(wq_rec); wq_rec = nullptr;
     hipFree(xil); xil = nullptr; xil_cap = 0; xil_cols = 0;
     hipFree(bw.blocks); hipFree(bw.rec); hipFree(bw.ext_col);
     hipFree(bw.dep_ptr); hipFree(bw.dep); hipFree(bw.sdep_ptr); hipFree(bw.sdep); hipFree(bw.flags); hipFree(bw.head);
@@ -410,6 +412,7 @@ int g_gs_slots = 1;             // wide levels from the slot layout (0 = CSR str
 int g_jacobi_zero = 1;          // Jacobi on x = 0 as a vector kernel (0 = the full sweep); read at every sweep
 int g_rhs_il = 1;               // blocks of 2 / 4 / 8 / 16 right-hand sides: restriction and prolongation gather an interleaved copy of their input (0 = column by column); read at every cycle
 int g_gs_tiny = 1;              // an operator that fits LDS entirely: 1 = gs_wave_kernel where its record was built, else gs_chain_tiny_kernel; 2 = gs_chain_tiny_kernel; 0 = gs_chain_kernel; read at every sweep
+int g_gs_wave_quad = 1;         // the single-wave walk with four lanes per row where its record was built (gs_waveq_kernel: a row's additions as four interleaved partial sums); 0 = one lane per row (the scalar loop's bits); read at schedule build (0: not built) and at every sweep
 int g_gs_bw = 1;                // wavefront of blocks for single-right-hand-side hierarchies (gs_blocks.hpp): 0 off, 1 where the cost model prefers it, 2 always (tests); read at schedule build
 int g_gs_bw_rows = 512;         // ... rows per block aimed at
 int g_gs_bw_flow = 1;           // the wavefront of blocks as a dataflow (gs_flow.hpp) where the pattern is structurally symmetric: 1 = on, 0 = off (chained / launched sweeps); build: the layout is only built when on; read at every sweep too

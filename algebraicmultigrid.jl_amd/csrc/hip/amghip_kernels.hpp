@@ -846,6 +846,123 @@ __global__ __launch_bounds__(kWaveThreads) void gs_wave_kernel(WaveArgs a) {
   for (int p = tid; p < n; p += kWave) x[p] = xl[p];
 }
 
+// ---- the same walk with FOUR lanes per row (round 6) -----------------------------------------------------------------------
+// What bounds the single wave is its instruction count, and with lane = row that count is the row length: the 18- and 30-entry
+// rows of config C5 (lin_elastic_2d, 208 / 39 rows, ~4 rows per dependency level) cost 0.47 / 0.65 us per step while 60 of the
+// 64 lanes idle — the two symmetric sweeps of its levels are 157 of the V-cycle's 185 us.  Here a row is four MINI-ROWS of the
+// same packed format (entry k of the row = entry k / 4 of mini-row k % 4; each carries the diagonal and its reciprocal), lane =
+// (row, quarter): a quarter of the chunks, gathers and multiply-adds per lane, the four partial sums added by a DPP butterfly
+// inside the quad, then the same quotient in all four lanes, lane 0 of the quad stores.  A step is a piece of at most 16 rows of
+// one level.  Exact Gauss-Seidel / SOR in the scalar loop's row order; a row's additions are reassociated into four
+// interleaved partial sums (deterministic; sweeps <= 1e-14 from the scalar loop, tests/test_gpu_waveq.py); the one-lane walk
+// stays behind the tunable gs_wave_quad = 0 for the tests that pin bits.
+constexpr int kWaveQ = 4;
+template <int E>
+__device__ __forceinline__ void waveq_load(WaveRow<E>& o, int p, bool act, int sub, const unsigned char* rec, const real* bl) {
+  typedef WaveRow<E> O;
+  typedef typename WaveVec16<real>::type V;
+  o.p = act ? p : -1;
+  const int q = act ? p : 0;
+  const unsigned char* row = rec + __umul24((unsigned)(q * kWaveQ + sub), (unsigned)O::RS);
+#pragma unroll
+  for (int k = 0; k < O::NVC; ++k) *(V*)&o.v[k * kWaveVpc] = *(const V*)(row + 16 * k);
+#pragma unroll
+  for (int k = 0; k < O::NCC; ++k) *(uint4*)&o.c[4 * k] = *(const uint4*)(row + 16 * (O::NVC + k));
+  o.bb = bl[q];
+}
+template <int E, bool SOR>
+__device__ __forceinline__ void waveq_row(const WaveRow<E>& o, real* xl, real omega, int sub) {
+  real xv[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const uint32_t w = o.c[k >> 1];
+    xv[k] = *(const real*)((const char*)xl + ((k & 1) ? (w >> 16) : (w & 0xffffu)));
+  }
+  real acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < E; ++k) acc += o.v[k] * xv[k];
+  acc = tree_add<kWaveQ>(acc);
+  const real dg = o.v[E], rc = o.v[E + 1];
+  if (o.p >= 0 && dg != 0.0) {
+    if (SOR) { if (sub == 0) xl[o.p] = (1.0 - omega) * xl[o.p] + (omega / dg) * (o.bb - acc); return; }
+    const real nn = o.bb - acc;
+    real q = nn * rc;
+    const real rem = wave_fma(-dg, q, nn);
+    q = wave_fma(rem, rc, q);
+    const real an = nn < (real)0 ? -nn : nn;
+    const bool safe = sizeof(real) == 8 ? (an > (real)1e-200 && an < (real)1e200) : (an > (real)1e-25 && an < (real)1e25);
+    if (__builtin_amdgcn_ballot_w64(!(rc != 0.0 && safe)) != 0) {
+      asm volatile("; rows outside the normal range: the division itself" ::: "memory");
+      if (!(rc != 0.0 && safe)) q = nn / dg;
+    }
+    if (sub == 0) xl[o.p] = q;
+  }
+}
+template <bool SOR, bool BWD, int E>
+__device__ __forceinline__ void waveq_walk(const unsigned char* rec, const real* bl, real* xl, int ns, int lp0, int lp1, real omega, int tid) {
+#define AMGH_WAVE_SP(i, out)                                                   \
+  {                                                                            \
+    const int i_ = (i);                                                        \
+    const int u0_ = __builtin_amdgcn_readlane(lp0, i_ & 63);                   \
+    const int u1_ = __builtin_amdgcn_readlane(lp1, i_ & 63);                   \
+    out = i_ < 64 ? u0_ : u1_;                                                 \
+  }
+#define AMGH_WAVE_RANGE(k, r0, r1)                                             \
+  {                                                                            \
+    const int k_ = (k);                                                        \
+    const int st_ = BWD ? ns - 1 - k_ : k_;                                    \
+    const bool in_ = k_ < ns;                                                  \
+    int q0_, q1_;                                                              \
+    AMGH_WAVE_SP(in_ ? st_ : 0, q0_);                                          \
+    AMGH_WAVE_SP(in_ ? st_ + 1 : 0, q1_);                                      \
+    r0 = q0_; r1 = in_ ? q1_ : q0_;                                            \
+  }
+  const int rw = tid >> 2, sub = tid & (kWaveQ - 1);
+  WaveRow<E> A, B;
+  int r0, r1;
+  AMGH_WAVE_RANGE(0, r0, r1);
+  waveq_load<E>(A, r0 + rw, r0 + rw < r1, sub, rec, bl);
+  for (int k = 0; k < ns; k += 2) {
+    AMGH_WAVE_RANGE(k + 1, r0, r1);
+    waveq_load<E>(B, r0 + rw, r0 + rw < r1, sub, rec, bl);
+    waveq_row<E, SOR>(A, xl, omega, sub);
+    AMGH_WAVE_RANGE(k + 2, r0, r1);
+    waveq_load<E>(A, r0 + rw, r0 + rw < r1, sub, rec, bl);
+    waveq_row<E, SOR>(B, xl, omega, sub);
+  }
+#undef AMGH_WAVE_RANGE
+#undef AMGH_WAVE_SP
+}
+template <bool SOR, int DIR, int E>
+__global__ __launch_bounds__(kWaveThreads) void gs_waveq_kernel(WaveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wave_lds[];
+  const int tid = threadIdx.x;
+  const real* __restrict__ b = a.bp + (int64_t)blockIdx.x * a.ldb;
+  real* __restrict__ x = a.x + (int64_t)blockIdx.x * a.ldx;
+  const int n = a.n, ns = a.steps;
+  // LDS: x (n + 1 entries, the last one the zero slot) | b | the record (4 n mini-rows, the step pointers) — each padded to 16 bytes
+  const int nxb = (int)(((size_t)(n + 1) * sizeof(real) + 15) & ~(size_t)15), nbb = (int)(((size_t)n * sizeof(real) + 15) & ~(size_t)15);
+  real* xl = (real*)wave_lds;
+  real* bl = (real*)(wave_lds + nxb);
+  unsigned char* rec = wave_lds + nxb + nbb;
+  const int recb = (int)(((size_t)n * kWaveQ * WaveRow<E>::RS + (size_t)(ns + 1) * 2 + 15) & ~(size_t)15);
+  {
+    const uint4* src = (const uint4*)a.rec;
+    uint4* dst = (uint4*)rec;
+    for (int e = tid; e < (recb >> 4); e += kWaveThreads) dst[e] = src[e];
+  }
+  for (int p = tid; p < n; p += kWaveThreads) { bl[p] = b[p]; xl[p] = x[p]; }
+  if (tid == 0) xl[n] = 0.0;
+  __syncthreads();
+  if (tid >= kWave) return;
+  const uint16_t* stp = (const uint16_t*)(rec + (size_t)n * kWaveQ * WaveRow<E>::RS);
+  const int lp0 = tid <= ns ? (int)stp[tid] : n;
+  const int lp1 = tid + 64 <= ns ? (int)stp[tid + 64] : n;
+  if (DIR != 1) waveq_walk<SOR, false, E>(rec, bl, xl, ns, lp0, lp1, a.omega, tid);
+  if (DIR != 0) waveq_walk<SOR, true, E>(rec, bl, xl, ns, lp0, lp1, a.omega, tid);
+  for (int p = tid; p < n; p += kWave) x[p] = xl[p];
+}
+
 // Damped Jacobi on x = 0 (every pre-smoother below the fine level of a cycle, and the fine one of ldiv!): the sweep's
 // matrix pass multiplies zeros — x_new = (1 - w) 0 + w ((b - 0) / d) is the SAME expression the stream kernel evaluates
 // with a row sum of +0 (bitwise the same result), as a vector kernel.  Rows with a zero diagonal keep their x = 0

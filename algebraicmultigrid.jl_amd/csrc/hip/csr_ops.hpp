@@ -238,6 +238,38 @@ int launch_wave(const WaveArgs& a, int maxk, bool sor, int dir, size_t lds, hipS
   }
   return AMGH_EINVAL;
 }
+template <int E, int DIR>
+int launch_waveq_ed(const WaveArgs& a, bool sor, size_t lds, hipStream_t st, int ncolv) {
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  if (lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && !((attr_set.load() >> (dev & 63)) & 1)) {
+    (void)hipFuncSetAttribute((const void*)gs_waveq_kernel<false, DIR, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gs_waveq_kernel<true, DIR, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set.fetch_or((uint64_t)1 << (dev & 63));
+  }
+  if (sor) hipLaunchKernelGGL((gs_waveq_kernel<true, DIR, E>), dim3(ncolv), dim3(kWaveThreads), lds, st, a);
+  else hipLaunchKernelGGL((gs_waveq_kernel<false, DIR, E>), dim3(ncolv), dim3(kWaveThreads), lds, st, a);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+template <int E>
+int launch_waveq_e(const WaveArgs& a, bool sor, int dir, size_t lds, hipStream_t st, int ncolv) {
+  switch (dir) {
+    case 0: return launch_waveq_ed<E, 0>(a, sor, lds, st, ncolv);
+    case 1: return launch_waveq_ed<E, 1>(a, sor, lds, st, ncolv);
+    default: return launch_waveq_ed<E, 2>(a, sor, lds, st, ncolv);
+  }
+}
+// the same walk with four lanes per row (gs_waveq_kernel); e = entries per mini-row
+int launch_waveq(const WaveArgs& a, int e, bool sor, int dir, size_t lds, hipStream_t st, int ncolv) {
+  switch (e) {
+    case 3: return launch_waveq_e<3>(a, sor, dir, lds, st, ncolv);
+    case 5: return launch_waveq_e<5>(a, sor, dir, lds, st, ncolv);
+    case 7: return launch_waveq_e<7>(a, sor, dir, lds, st, ncolv);
+    case 9: return launch_waveq_e<9>(a, sor, dir, lds, st, ncolv);
+  }
+  return AMGH_EINVAL;
+}
 // does a sweep over this operator run as ONE gs_wave_kernel launch?  (then a symmetric sweep may be asked for in one
 // call: csr_gs_sweep(..., sym_pair = true))
 bool gs_wave_path(const GsSchedule* g, bool sor) {
@@ -791,6 +823,11 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
         WaveArgs wa{};   // one record, one wave, no barrier between the levels
         wa.rec = g->ww_rec; wa.bp = rhs; wa.x = xp; wa.ldb = ldb; wa.ldx = xs; wa.omega = omega;
         wa.n = (int32_t)g->n; wa.steps = g->ww_steps;
+        if (g->wq_rec && g_gs_wave_quad) {   // four lanes per row
+          wa.rec = g->wq_rec; wa.steps = g->wq_steps;
+          RC_TRY(launch_waveq(wa, g->wq_E, sor, sym_pair ? 2 : backward ? 1 : 0, g->wq_lds, st, ncolv));
+          continue;
+        }
         RC_TRY(launch_wave(wa, g->ww_maxk, sor, sym_pair ? 2 : backward ? 1 : 0, g->ww_lds, st, ncolv));
         continue;
       }

@@ -545,6 +545,50 @@ int layout_upload(GsSchedule* g, const HostLevelCsr& h, const int32_t* orig, int
         g->bytes += (int64_t)recb;
         g->csr_bytes += (int64_t)recb;
       }
+      // ... and with four lanes per row (gs_waveq_kernel): rows long enough for a quarter to be worth a lane, steps of 16 rows
+      if (g->ww_rec && g_gs_wave_quad && maxlen >= 8) {
+        const int e4 = (maxlen + kWaveQ - 1) / kWaveQ;
+        const int E = e4 <= 3 ? 3 : e4 <= 5 ? 5 : e4 <= 7 ? 7 : 9;
+        std::vector<uint16_t> sq;
+        for (int l2 = 0; l2 < g->nlev; ++l2)
+          for (int32_t q = g->lvl_ptr[l2]; q < g->lvl_ptr[l2 + 1]; q += kWave / kWaveQ) sq.push_back((uint16_t)q);
+        const int qsteps = (int)sq.size();
+        sq.push_back((uint16_t)n);
+        const size_t qrs = (size_t)wave_row_bytes(E);
+        const size_t qrecb = ((size_t)n * kWaveQ * qrs + (size_t)(qsteps + 1) * 2 + 15) & ~(size_t)15;
+        const size_t qlds = (((size_t)(n + 1) * sizeof(real) + 15) & ~(size_t)15) + (((size_t)n * sizeof(real) + 15) & ~(size_t)15) + qrecb;
+        if (e4 <= 9 && qsteps <= kWaveMaxSteps && qlds <= 150 * 1024 && (size_t)n * kWaveQ < (1u << 20)) {
+          std::vector<unsigned char> qrec(qrecb, 0);
+          const int qnvc = wave_nvc(E);
+          const uint16_t zoff = (uint16_t)((size_t)n * sizeof(real));
+          for (int64_t p2 = 0; p2 < n; ++p2) {
+            const real dg = h.pdiag[p2];
+            const double ad = std::fabs((double)dg);
+            const bool safe = sizeof(real) == 8 ? (ad > 1e-100 && ad < 1e100) : (ad > 1e-12 && ad < 1e12);
+            for (int sub = 0; sub < kWaveQ; ++sub) {
+              unsigned char* mr = qrec.data() + ((size_t)p2 * kWaveQ + sub) * qrs;
+              real* v = (real*)mr;
+              uint16_t* cc = (uint16_t*)(mr + (size_t)16 * qnvc);
+              for (int k = 0; k < 8 * wave_ncc(E); ++k) cc[k] = zoff;
+              v[E] = dg;
+              v[E + 1] = safe ? (real)1 / dg : (real)0;
+            }
+            int k = 0;
+            for (int32_t j = prow[p2]; j < prow[p2 + 1]; ++j) {
+              if (j == h.pdpos[p2]) continue;
+              unsigned char* mr = qrec.data() + ((size_t)p2 * kWaveQ + (k % kWaveQ)) * qrs;
+              ((real*)mr)[k / kWaveQ] = h.pval[j];
+              ((uint16_t*)(mr + (size_t)16 * qnvc))[k / kWaveQ] = (uint16_t)((size_t)h.pcol[j] * sizeof(real));
+              ++k;
+            }
+          }
+          std::copy(sq.begin(), sq.end(), (uint16_t*)(qrec.data() + (size_t)n * kWaveQ * qrs));
+          RC_TRY(dev_upload(&g->wq_rec, qrec.data(), (int64_t)qrecb));
+          g->wq_E = E; g->wq_steps = qsteps; g->wq_lds = qlds;
+          g->bytes += (int64_t)qrecb;
+          g->csr_bytes += (int64_t)qrecb;
+        }
+      }
     }
   }
   return AMGH_OK;
