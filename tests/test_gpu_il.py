@@ -77,3 +77,4 @@ def test_interleaved_groups_float32():
     assert rel(Z.astype(np.float64), Zc.astype(np.float64)) <= 5e-5
     oh = O.OracleHierarchy(ml, dtype=np.float32)
     assert rel(Z[:, 7].astype(np.float64), oh.precond(np.ascontiguousarray(B[:, 7])).astype(np.float64)) <= 5e-5
+

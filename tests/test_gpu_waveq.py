@@ -100,3 +100,29 @@ def test_quad_walk_float32(quad):
     z = AMG.aspreconditioner(ml).ldiv(b.astype(np.float32))
     zo = O.OracleHierarchy(ml, dtype=np.float32).precond(b.astype(np.float32))
     assert z.dtype == np.float32 and rel(z.astype(np.float64), zo.astype(np.float64)) <= 5e-5
+
+
+def test_quad_walk_zero_diagonals_and_rows_that_must_divide(quad):
+    """Rows with a zero diagonal keep their value (smoother.jl:87) and rows whose diagonal lies outside the range the record's
+    reciprocal is trusted in take the division itself (the wave-uniform cold branch), with four lanes per row as with one."""
+    import scipy.sparse as sp
+    A0, b, _ = _elastic()
+    M = A0.to_scipy().tolil()
+    n = M.shape[0]
+    for r in (0, 77, n - 1):
+        M[r, r] = 0.0
+    for r in (5, 123):
+        M[r, r] = 6.0e120
+    M[9, 9] = 3.0e-130
+    A = AMG.SparseMatrixCSC.from_scipy(sp.csc_matrix(M.tocsr()))
+    x0 = uniform(n, 61) - 0.5
+    for sm in (AMG.GaussSeidel(AMG.ForwardSweep()), AMG.GaussSeidel(AMG.BackwardSweep()), AMG.GaussSeidel(iter=2), AMG.SOR(1.2)):
+        x = x0.copy()
+        smooth_standalone(sm, A, x, b)
+        xo = O.smooth(sm, A, x0, b)
+        ok = np.isfinite(xo)
+        assert np.array_equal(np.isfinite(x), ok), repr(sm)
+        floor = 1e-3 * np.median(np.abs(xo[ok]))
+        assert np.max(np.abs(x[ok] - xo[ok]) / np.maximum(np.abs(xo[ok]), floor)) <= 1e-12, repr(sm)
+        for r in (0, 77, n - 1):
+            assert x[r] == x0[r]
