@@ -1208,6 +1208,9 @@ __global__ __launch_bounds__(kSlot / EPT) void gs_slot_lpr_kernel(SlotArgs a) {
   int r = tid / LPR;
   i4_t m = i4_t{0, 0, -1, 0};
   real d = 0.0, bb = 0.0;
+  // (row data through the scalar cache — the rows of a wave have wave-uniform addresses, and with LPR >= 8 the lanes fetch the
+  // same 32 bytes 8 or 16 times over — was measured: 2.19 -> 2.43 ms per symmetric sweep of the 1.4 M-row level of the 256^3
+  // hierarchy; 12 scalar loads of distinct lines per wave into a cache that starts every launch cold are slower than 3 vector loads)
   if (r < nrows) { m = a.wmeta[r0 + r]; d = a.diag[r0 + r]; bb = a.bp[r0 + r]; }  // same round trip as the gather
 #pragma unroll
   for (int e = 0; e < EPT; ++e) s_prod[EPT * tid + e] = v[e] * xv[e];
@@ -1370,10 +1373,19 @@ struct SlotIlArgs {
 template <bool SOR, int BS>
 __global__ __launch_bounds__(kSlot) void gs_slot_il_kernel(SlotIlArgs a) {
   static_assert(BS == 2 || BS == 4 || BS == 8 || BS == 16, "columns per block");
-  constexpr int EPW = kWave / BS;   // entries a wave handles per round = lanes per (row, column) sum
+  // Gather phase: a lane takes TWO columns of an entry (one 16-byte load at Float64); what bounds an 8-column launch once the
+  // gathers are sectors is the NUMBER of vector-memory instructions a wave issues (replacing every gather address by one cached
+  // address changed nothing, 12 more wave-uniform loads of row data per thread cost +33 %): 4 gathers + 12 shuffles per thread
+  // instead of 8 + 24, and the row data through the scalar cache (the wave index made uniform).
+  constexpr int LPE = BS / 2;         // lanes per entry in the gather phase
+  constexpr int EPG = kWave / LPE;    // entries a wave gathers per round
+  constexpr int NRG = LPE;            // rounds (64 entries per wave)
+  constexpr int EPW = kWave / BS;     // lanes per (row, column) sum
   constexpr int NW = kSlot / kWave;
-  __shared__ real s_prod[kSlot * BS];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+  typedef real r2_t __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) real s_prod[kSlot * BS];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(tid / kWave);   // (uniform: a wave's row data through the scalar cache — one row per wave here: level 2 of the 256^3 hierarchy at bs = 8 8.69 -> 8.30 ms)
   int lb = blockIdx.x;
   if (a.xcd_map) lb = xcd_block(lb, a.nslots);
   if (lb >= a.nslots) return;
@@ -1382,21 +1394,24 @@ __global__ __launch_bounds__(kSlot) void gs_slot_il_kernel(SlotIlArgs a) {
   const real v = a.wval[base + tid];
   const int c = a.wcol[base + tid];
   const int r0 = a.slot_row[2 * s], nrows = a.slot_row[2 * s + 1] - r0;
-  const int q = lane % BS, sub = lane / BS;
-  real xv[BS], vv[BS];
+  const int qp = lane % LPE, gsub = lane / LPE;
+  r2_t xv[NRG];
+  real vv[NRG];
 #pragma unroll
-  for (int k = 0; k < BS; ++k) {   // round k: entries w * 64 + k * EPW + (0 .. EPW - 1), BS lanes each
-    const int src = k * EPW + sub;
+  for (int k = 0; k < NRG; ++k) {   // round k: entries w * 64 + k * EPG + (0 .. EPG - 1), LPE lanes each
+    const int src = k * EPG + gsub;
     const int ck = __shfl(c, src, kWave);
     vv[k] = __shfl(v, src, kWave);
-    xv[k] = a.xil[(int64_t)ck * BS + q];
+    xv[k] = *(const r2_t*)(a.xil + (int64_t)ck * BS + 2 * qp);
   }
-  // row data of this wave's first row, requested with the gathers
+  const int q = lane % BS, sub = lane / BS;
+  // row data of this wave's first row, requested with the gathers (wave-uniform: scalar loads, but for the right-hand side)
   i4_t m = i4_t{0, 0, -1, 0};
   real d = 0.0, bb = 0.0;
   if (w < nrows) { m = a.wmeta[r0 + w]; d = a.diag[r0 + w]; bb = a.xil[(int64_t)(a.soff + r0 + w) * BS + q]; }
 #pragma unroll
-  for (int k = 0; k < BS; ++k) s_prod[(w * kWave + k * EPW) * BS + lane] = vv[k] * xv[k];   // entry e, column q at e * BS + q
+  for (int k = 0; k < NRG; ++k)     // entry e, column q at e * BS + q: lane's two products side by side
+    *(r2_t*)(s_prod + (w * kWave + k * EPG) * BS + 2 * lane) = r2_t{vv[k] * xv[k].x, vv[k] * xv[k].y};
   __syncthreads();
   for (int r = w; r < nrows; r += NW) {   // a wave per row: EPW lanes per column
     if (r != w) { m = a.wmeta[r0 + r]; d = a.diag[r0 + r]; bb = a.xil[(int64_t)(a.soff + r0 + r) * BS + q]; }
@@ -1416,10 +1431,10 @@ __global__ __launch_bounds__(kSlot) void gs_slot_il_kernel(SlotIlArgs a) {
   }
 }
 
-// The SELL-like copy of a merged group the same way: the wave's 64 entry lanes of a storage iteration are taken EPW at a
-// time, BS column lanes each; BATCH iterations' gathers are in flight together and the next round's (col, val) are
-// requested before them.  Needs K >= EPW and K >= BS (a row's K entry lanes are whole rounds; other shapes keep
-// gs_sell_kernel and have their rows copied over).
+// The SELL-like copy of a merged group the same way: the wave's 64 entry lanes of a storage iteration are taken 2 * 64 / BS at a
+// time, BS / 2 lanes each (a lane gathers two columns); BATCH iterations' gathers are in flight together and the next round's
+// (col, val) are requested before them.  Needs BS >= 4 and K >= 2 * 64 / BS (a row's K entry lanes are whole rounds); other
+// shapes keep gs_sell_kernel and have their rows copied over.
 struct SellIlArgs {
   const int32_t* scol;
   const real* sval;
@@ -1434,11 +1449,13 @@ struct SellIlArgs {
 };
 template <bool SOR, int K, int BS, int BATCH>
 __global__ __launch_bounds__(256) void gs_sell_il_kernel(SellIlArgs a) {
-  constexpr int C = kWave / K;      // rows per chunk
-  constexpr int EPW = kWave / BS;   // entry lanes per round
-  constexpr int NR = BS;            // rounds per storage iteration
-  constexpr int G = K / EPW;        // rounds per row
-  static_assert(K >= EPW && K >= BS && K % EPW == 0, "a row's entry lanes are whole rounds");
+  constexpr int C = kWave / K;        // rows per chunk
+  constexpr int LPE = BS / 2;         // lanes per entry: a lane takes two columns (one 16-byte gather at Float64)
+  constexpr int EPG = kWave / LPE;    // entry lanes per round
+  constexpr int NR = LPE;             // rounds per storage iteration
+  constexpr int G = K / EPG;          // rounds per row
+  static_assert(BS >= 4 && K >= EPG && K >= BS && K % EPG == 0, "a row's entry lanes are whole rounds");
+  typedef real r2_t __attribute__((ext_vector_type(2)));
   const int nwg = (a.nchunks + 3) >> 2;
   int wb = blockIdx.x;
   if (a.xcd_map) wb = xcd_block(wb, nwg);
@@ -1448,14 +1465,15 @@ __global__ __launch_bounds__(256) void gs_sell_il_kernel(SellIlArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const i2_t cd = a.chunk[a.chunk0 + ch];
   const int64_t base = (int64_t)(uint32_t)cd.x * kWave + lane;
-  const int q = lane % BS, sub = lane / BS;
-  const int r = ch * C + sub;   // the row this lane writes (lanes sub < C)
+  const int qp = lane % LPE, sub = lane / LPE;
+  const int r = ch * C + sub;   // the row this lane writes (lanes sub < C), columns 2 qp and 2 qp + 1
   const bool live = sub < C && r < a.nrows;
-  real d = 0.0, bb = 0.0;
-  if (live) { d = a.diag[a.row0 + r]; bb = a.xil[(int64_t)(a.soff + a.row0 + r) * BS + q]; }
-  real acc[NR];
+  real d = 0.0;
+  r2_t bb = r2_t{0.0, 0.0};
+  if (live) { d = a.diag[a.row0 + r]; bb = *(const r2_t*)(a.xil + (int64_t)(a.soff + a.row0 + r) * BS + 2 * qp); }
+  r2_t acc[NR];
 #pragma unroll
-  for (int k = 0; k < NR; ++k) acc[k] = 0.0;
+  for (int k = 0; k < NR; ++k) acc[k] = r2_t{0.0, 0.0};
   const int nit = cd.y;
   int c[BATCH];
   real v[BATCH];
@@ -1473,42 +1491,46 @@ __global__ __launch_bounds__(256) void gs_sell_il_kernel(SellIlArgs a) {
       if (t + BATCH + e < nit) { cn[e] = a.scol[base + (int64_t)(t + BATCH + e) * kWave]; vn[e] = a.sval[base + (int64_t)(t + BATCH + e) * kWave]; }
     }
     int cc[BATCH][NR];
-    real vv[BATCH][NR], xv[BATCH][NR];
+    real vv[BATCH][NR];
+    r2_t xv[BATCH][NR];
 #pragma unroll
     for (int e = 0; e < BATCH; ++e)
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
-        const int src = k * EPW + sub;
+        const int src = k * EPG + sub;
         cc[e][k] = __shfl(c[e], src, kWave);
         vv[e][k] = __shfl(v[e], src, kWave);
-        xv[e][k] = cc[e][k] >= 0 ? a.xil[(int64_t)cc[e][k] * BS + q] : 0.0;
+        xv[e][k] = cc[e][k] >= 0 ? *(const r2_t*)(a.xil + (int64_t)cc[e][k] * BS + 2 * qp) : r2_t{0.0, 0.0};
       }
 #pragma unroll
     for (int e = 0; e < BATCH; ++e)
 #pragma unroll
       for (int k = 0; k < NR; ++k)
-        if (cc[e][k] >= 0) acc[k] += vv[e][k] * xv[e][k];
+        if (cc[e][k] >= 0) { acc[k].x += vv[e][k] * xv[e][k].x; acc[k].y += vv[e][k] * xv[e][k].y; }
 #pragma unroll
     for (int e = 0; e < BATCH; ++e) { c[e] = cn[e]; v[e] = vn[e]; }
   }
-  // entry lane k * EPW + sub belongs to row (k * EPW + sub) / K = k / G of the chunk: the rounds of a row in this lane,
-  // then the EPW lanes of the column
-  real tot = 0.0;
+  // entry lane k * EPG + sub belongs to row (k * EPG + sub) / K = k / G of the chunk: the rounds of a row in this lane,
+  // then the EPG lanes of the column pair
+  r2_t tot = r2_t{0.0, 0.0};
 #pragma unroll
   for (int mrow = 0; mrow < C; ++mrow) {
-    real ra = acc[mrow * G];
+    r2_t ra = acc[mrow * G];
 #pragma unroll
-    for (int g2 = 1; g2 < G; ++g2) ra += acc[mrow * G + g2];
+    for (int g2 = 1; g2 < G; ++g2) { ra.x += acc[mrow * G + g2].x; ra.y += acc[mrow * G + g2].y; }
 #pragma unroll
-    for (int o = BS; o < kWave; o <<= 1) ra += __shfl_xor(ra, o, kWave);
+    for (int o = LPE; o < kWave; o <<= 1) { ra.x += __shfl_xor(ra.x, o, kWave); ra.y += __shfl_xor(ra.y, o, kWave); }
     if (sub == mrow) tot = ra;
   }
   if (live && d != 0.0) {
     const int64_t i = a.row0 + r;
-    real* xi = a.xil + i * BS + q;
-    const real xn = SOR ? (1.0 - a.omega) * *xi + (a.omega / d) * (bb - tot) : (bb - tot) / d;
+    r2_t* xi = (r2_t*)(a.xil + i * BS + 2 * qp);
+    r2_t xn;
+    if (SOR) { const r2_t xo = *xi; xn.x = (1.0 - a.omega) * xo.x + (a.omega / d) * (bb.x - tot.x); xn.y = (1.0 - a.omega) * xo.y + (a.omega / d) * (bb.y - tot.y); }
+    else { xn.x = (bb.x - tot.x) / d; xn.y = (bb.y - tot.y) / d; }
     *xi = xn;
-    a.x[i + q * a.ldx] = xn;
+    a.x[i + (2 * qp) * a.ldx] = xn.x;
+    a.x[i + (2 * qp + 1) * a.ldx] = xn.y;
   }
 }
 

@@ -438,10 +438,10 @@ int launch_slot_il(const SlotIlArgs& a, bool sor, int bs, int grid, hipStream_t 
 #undef AMGH_SLOT_IL
   return AMGH_OK;
 }
-inline bool sell_il_shape(int k, int bs) { return (bs == 8 || bs == 4 || bs == 2) && k >= kWave / bs && k >= bs; }
+inline bool sell_il_shape(int k, int bs) { return (bs == 8 || bs == 4) && k >= 2 * kWave / bs && k >= bs; }   // (a row's K entry lanes are whole gather rounds of 2 * 64 / bs entries)
 template <int K, int BS>
 int launch_sell_il_kb(const SellIlArgs& a, bool sor, int grid, hipStream_t st) {
-  if constexpr (K >= kWave / BS && K >= BS) {
+  if constexpr (BS >= 4 && K >= 2 * kWave / BS && K >= BS) {
     constexpr int BATCH = BS >= 8 ? 2 : 4;   // (storage iterations in flight per lane; at BS = 8: 1: 7.57, 2: 6.13, 4: 6.16 ms on the 228 538-row level of the 256^3 hierarchy)
     if (sor) hipLaunchKernelGGL((gs_sell_il_kernel<true, K, BS, BATCH>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gs_sell_il_kernel<false, K, BS, BATCH>), dim3(grid), dim3(256), 0, st, a);

@@ -42,7 +42,8 @@ def test_interleaved_groups_equal_column_kernels_and_oracle(bs, kind):
     assert np.array_equal(Z, Z2)                      # deterministic
     Zc = _with(lib, b"gs_il", 0, lambda: AMG.aspreconditioner(ml).ldiv(B))
     assert rel(Z, Zc) <= TIGHT
-    assert not np.array_equal(Z, Zc) or bs == 0       # (the interleaved kernels really ran: their sums round differently)
+    if bs >= 4:                                       # (the interleaved kernels really ran: their sums round differently; bs = 2: the
+        assert not np.array_equal(Z, Zc)              #  slot kernel alone is interleaved, the SELL groups of this hierarchy keep the column kernel)
     oh = O.OracleHierarchy(ml)
     for c in (0, bs - 1):
         assert rel(Z[:, c], oh.precond(B[:, c])) <= TOL
