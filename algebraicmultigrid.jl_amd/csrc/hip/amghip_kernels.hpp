@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(256) void gs_sell_kernel(SellArgs a) {
   int wb = blockIdx.x;
   if (a.xcd_map) wb = xcd_block(wb, nwg);
   if (wb >= nwg) return;
-  const int ch = wb * 4 + (threadIdx.x >> 6);
+  const int ch = wb * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: the chunk descriptor — and with K = 64 the row's diagonal and right-hand side — through the scalar cache)
   if (ch >= a.nchunks) return;
   const int lane = threadIdx.x & (kWave - 1);
   const i2_t cd = a.chunk[a.chunk0 + ch];
@@ -1460,7 +1460,7 @@ __global__ __launch_bounds__(256) void gs_sell_il_kernel(SellIlArgs a) {
   int wb = blockIdx.x;
   if (a.xcd_map) wb = xcd_block(wb, nwg);
   if (wb >= nwg) return;
-  const int ch = wb * 4 + (threadIdx.x >> 6);
+  const int ch = wb * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: the chunk descriptor — and with K = 64 the row's diagonal and right-hand side — through the scalar cache)
   if (ch >= a.nchunks) return;
   const int lane = threadIdx.x & (kWave - 1);
   const i2_t cd = a.chunk[a.chunk0 + ch];
