@@ -192,8 +192,8 @@ def secondary_configs(check=True):
         bd = AMG.DeviceBuffer(n, 0, b)
         zd = AMG.DeviceBuffer(n, 0)
         best = 1e9
-        for _ in range(4):   # (tiny cycles: the clocks ramp up under load — best of a few rounds)
-            for _ in range(50 if n < 100000 else 3):
+        for _ in range(5):   # (tiny cycles: the clocks only ramp up under sustained load — best of a few rounds behind 200 warm-up cycles)
+            for _ in range(200 if n < 100000 else 3):
                 lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0)
             lib.amgh_dev_sync(0)
             t0 = time.perf_counter()
