@@ -1029,6 +1029,30 @@ int amgh_finalize(amgh_t* h) {
       }
     }
   }
+  // Trimmed footprint (the default): where an operator the level-ordered cycle streams has value-coded columns, the cycle reads
+  // THEM — 4 bytes per entry — and the 12 bytes of columns and values beside them are a copy nothing in it touches: released
+  // (the restriction and prolongation of the level; its A where the level sweeps the block layout as a dataflow alone, so that
+  // no kernel of the sweep reads the level-ordered CSR either).  256^3: 20.4 -> 15.2 GB.  The stand-alone hooks
+  // (amgh_level_spmv, amgh_bench_op) read the coded columns too (level_lo_op); the run-time tunable stream_code = 0 then has no
+  // plain copy to switch to on these operators (AMGH_LEAN=0 / gs_lean = 0 keeps both).
+  if (gs_trim() && g_stream_code && g_trim_coded) {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (Level* L : h->levels) {
+      for (amgh_csr* M : {&L->Rp, &L->Pp})
+        if (M->cc.ccol && M->col && M->val) {
+          hipFree(M->col); hipFree(M->val); M->col = nullptr; M->val = nullptr;
+          M->bytes -= M->nnz * kEntB;
+        }
+      amgh_csr* S = L->smat();
+      GsSchedule* g = S->gs;
+      if (L->lo_cc.ccol && g && g->bw.on && g->bw.flow.on && !g->bw.rec && g->segs.empty() && !g->mf && !g->mb && g->col && g->val) {
+        hipFree(g->col); hipFree(g->val); g->col = nullptr; g->val = nullptr;
+        int64_t freed = g->nnz * kEntB;
+        if (L->lo_val) { hipFree(L->lo_val); L->lo_val = nullptr; }
+        g->csr_bytes -= freed; g->bytes -= freed; S->bytes -= freed;
+      }
+    }
+  }
   // a level that receives its right-hand side in level order gets it written into its schedule's own vector by the
   // level above: sized for the block of right-hand sides before the first cycle
   for (size_t l = 0; l + 1 < h->levels.size(); ++l)
@@ -1126,8 +1150,11 @@ int amgh_debug_bw_late(const amgh_t* h, int l) {
 int amgh_debug_coded_ops(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
   const Level* L = h->levels[l];
-  if (!g_stream_code) return 0;
-  return (L->lo_cc.ccol ? 1 : 0) | (L->Rp.cc.ccol ? 2 : 0) | (L->Pp.cc.ccol ? 4 : 0);
+  // (what the launches take: the coded columns where they exist and either the tunable says so or no plain copy is left)
+  const GsSchedule* g = (L->has_S ? L->S : L->A).gs;
+  const bool a_on = L->lo_cc.ccol && (g_stream_code || (g && !g->col));
+  const bool r_on = L->Rp.cc.ccol && (g_stream_code || !L->Rp.col), p_on = L->Pp.cc.ccol && (g_stream_code || !L->Pp.col);
+  return (a_on ? 1 : 0) | (r_on ? 2 : 0) | (p_on ? 4 : 0);
 }
 int amgh_gs_num_dependency_levels(const amgh_t* h, int l) {
   if (!h || l < 0 || l >= (int)h->levels.size()) return -1;
@@ -1304,6 +1331,7 @@ struct LoOp {
   const real* val = nullptr;
   int64_t nrows = 0, ncols = 0;
   const int32_t *row_perm = nullptr, *col_perm = nullptr;
+  const CodedCols* cc = nullptr;   // value-coded columns of the same operator (the trimmed footprint keeps only them: col / val nullptr)
 };
 static bool level_lo_op(amgh_t* h, int level, int which, LoOp* o) {
   if (level < 0 || level >= (int)h->levels.size()) return false;
@@ -1320,13 +1348,13 @@ static bool level_lo_op(amgh_t* h, int level, int which, LoOp* o) {
   switch (which) {
     case AMGH_OP_A:
       if ((int64_t)g->ncols != L->n) return false;
-      *o = LoOp{g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, L->n, L->n, g->perm, g->perm};
+      *o = LoOp{g->rowptr, g->col, L->lo_val ? L->lo_val : g->val, L->n, L->n, g->perm, g->perm, &L->lo_cc};
       return g->rowptr != nullptr && !g->compacted;
     case AMGH_OP_P:
-      *o = LoOp{L->Pp.rowptr, L->Pp.col, L->Pp.val, L->n, L->nc, g->perm, coarse_perm};
+      *o = LoOp{L->Pp.rowptr, L->Pp.col, L->Pp.val, L->n, L->nc, g->perm, coarse_perm, &L->Pp.cc};
       return L->Pp.rowptr != nullptr;
     case AMGH_OP_R:
-      *o = LoOp{L->Rp.rowptr, L->Rp.col, L->Rp.val, L->nc, L->n, coarse_perm, g->perm};
+      *o = LoOp{L->Rp.rowptr, L->Rp.col, L->Rp.val, L->nc, L->n, coarse_perm, g->perm, &L->Rp.cc};
       return L->Rp.rowptr != nullptr;
   }
   return false;
@@ -1362,7 +1390,7 @@ static int level_apply(amgh_t* h, int level, int which, int mode, const real* x_
     }
   }
   if (rc == AMGH_OK)
-    rc = raw_apply(mode, o.rowptr, o.col, o.val, o.nrows, xin, o.ncols, bin, o.nrows, o.row_perm ? yo : y_d, o.nrows, h->stream, 1);
+    rc = raw_apply(mode, o.rowptr, o.col, o.val, o.nrows, xin, o.ncols, bin, o.nrows, o.row_perm ? yo : y_d, o.nrows, h->stream, 1, o.cc);
   if (rc == AMGH_OK && o.row_perm)
     hipLaunchKernelGGL(scatter_perm_kernel, dim3(grid_for(o.nrows)), dim3(256), 0, h->stream, (const real*)yo, o.row_perm, y_d,
                        (int)o.nrows, (int64_t)0, (int64_t)0);
@@ -1625,7 +1653,7 @@ int amgh_bench_op(amgh_t* h, int level, int which, int reps, int warmup, double*
     }
     const int mode = (which == 3 || which == 5) ? M_RESID : M_SPMV;
     if (op) return csr_apply(op, mode, x, b, y, h->stream);
-    return raw_apply(mode, lo.rowptr, lo.col, lo.val, lo.nrows, x, lo.ncols, b, lo.nrows, y, lo.nrows, h->stream, 1);
+    return raw_apply(mode, lo.rowptr, lo.col, lo.val, lo.nrows, x, lo.ncols, b, lo.nrows, y, lo.nrows, h->stream, 1, lo.cc);
     if (which == 4) {
       if (level >= (int)h->levels.size()) return AMGH_EINVAL;
       return level_smooth_enqueue(h, level, 0, y, b);
@@ -1911,6 +1939,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_xcd_map")) g_gs_xcd_map = value;
   else if (!strcmp(name, "gs_lpr")) g_gs_lpr = value;
   else if (!strcmp(name, "gs_il")) g_gs_il = value;
+  else if (!strcmp(name, "trim_coded")) g_trim_coded = value;
   else if (!strcmp(name, "gs_wave_quad")) g_gs_wave_quad = value;
   else if (!strcmp(name, "pcg_fused")) g_pcg_fused = value;
   else if (!strcmp(name, "gs_tri_rb")) g_gs_tri_rb = value;

@@ -422,6 +422,7 @@ int g_gs_bw_nc = -1;            // columns of a block of right-hand sides one wo
 int g_gs_bw_nrhs = 1;           // hierarchies built for blocks of right-hand sides get the dataflow layout too (0 = single-column hierarchies only); read at schedule build
 int g_gs_bw_chain = 1;          // the wavefront of blocks as one launch per sweep, blocks chained by flags (0: one launch per depth of the quotient graph)
 int g_stream_code = 1;          // SpMV-type launches (residual, restriction, prolongation of the level-ordered cycle) of operators of >= 2^18 rows stream value-coded columns where the operator has <= 256 distinct values (CodedCols; bitwise the same sums); read at amgh_finalize (0: not built) and at every launch
+int g_trim_coded = 1;           // trimmed / lean footprint: operators of the level-ordered cycle that have value-coded columns keep ONLY them (amgh_finalize releases their 12-byte columns and values); 0 = keep both; read at amgh_finalize
 int g_gs_bw_inorder = 0;        // 1: the relayed single-column sweep sums every row in stored entry order (the scalar loop's bits); 0 (default): where the records allow it (GsSchedule::Bw::FlowDev::late_ok) the products with the sweep's FAR side — x values that cannot change any more — are summed above the hand-over and the near half is added below it: the same Gauss-Seidel iterate, one reassociation per row (<= 1 ulp-level differences), a shorter dependent tail per step; read at every sweep
 int g_gs_bw_dict = 1;           // the relayed single-column sweep reads the dictionary layout where a schedule carries one (bw::FlowDict: half the bytes of a 7-point level's sweep; bitwise the same); read at schedule build (0: not built) and at every sweep
 int g_gs_bw_relay = 3;          // walker waves a single-column dataflow sweep relays a block's walk between (gs_relay.hpp: the one instantiated count, BW_RELAY_W; 0: one walker, gs_bw_flow_kernel — bitwise the same); read at every sweep

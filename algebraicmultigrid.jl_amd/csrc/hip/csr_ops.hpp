@@ -67,7 +67,8 @@ using CodedCfg = StreamCfg<AMGH_CODED_CFG, false, false>;
 template <int MODE>
 int launch_stream_sized(const StreamArgs& a, hipStream_t st, int ncolv) {
   if (a.row_end - a.row_begin < (1 << 18)) return launch_stream<MODE, SmallCfg>(a, st, ncolv);
-  if (a.ccol && g_stream_code) return launch_stream<MODE, CodedCfg, true>(a, st, ncolv);   // value-coded columns: 4 bytes per entry
+  // value-coded columns: 4 bytes per entry (the trimmed footprint keeps ONLY them where an operator has them: a.col == nullptr)
+  if (a.ccol && (g_stream_code || !a.col)) return launch_stream<MODE, CodedCfg, true>(a, st, ncolv);
   return launch_stream<MODE>(a, st, ncolv);
 }
 
@@ -328,7 +329,7 @@ int il_apply_t(bool add, const int32_t* rowptr, const int32_t* col, const real* 
   const int64_t threads = nrows * BS;
   if (threads > 0) {
     const unsigned grid = (unsigned)((threads + 255) / 256);
-    if (cc && cc->ccol && g_stream_code) {   // value-coded columns: the words in place of the columns, the table in place of the values
+    if (cc && cc->ccol && (g_stream_code || !col)) {   // value-coded columns: the words in place of the columns, the table in place of the values
       if (add) hipLaunchKernelGGL((csr_il_kernel<true, BS, true>), dim3(grid), dim3(256), 0, st, rowptr, (const int32_t*)cc->ccol, (const real*)cc->vtab, nrows, (const real*)il, y, ldy, cc->n);
       else hipLaunchKernelGGL((csr_il_kernel<false, BS, true>), dim3(grid), dim3(256), 0, st, rowptr, (const int32_t*)cc->ccol, (const real*)cc->vtab, nrows, (const real*)il, y, ldy, cc->n);
     } else
@@ -354,7 +355,7 @@ template <int BS>
 int resid_cols_t(const int32_t* rowptr, const int32_t* col, const real* val, int64_t nrows, const real* x, int64_t ldx,
                  const real* b, int64_t ldb, real* y, int64_t ldy, hipStream_t st, const CodedCols* cc) {
   const int64_t threads = nrows * BS;
-  if (threads > 0 && cc && cc->ccol && g_stream_code)
+  if (threads > 0 && cc && cc->ccol && (g_stream_code || !col))
     hipLaunchKernelGGL((csr_resid_cols_kernel<BS, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, rowptr, (const int32_t*)cc->ccol,
                        (const real*)cc->vtab, nrows, x, ldx, b, ldb, y, ldy, cc->n);
   else
