@@ -178,10 +178,52 @@ class Pinv(CoarseSolver):
         return "Pinv"
 
 
+def _qr_basic_operator(M):
+    """The operator b -> x of a rank-deficient `qr(A) \\ b` in SuiteSparseQR's sense (what `qr` of a SparseMatrixCSC is in
+    Julia, coarse_solver.jl:69,79): Householder QR in which a column whose remaining part has 2-norm <= tol is DEAD
+    (Heath's rank detection; SPQR's default tol = 20 (m + n) eps max_j ||A[:, j]||_2), and the BASIC solution — the live
+    columns solve R11 y = (Q' b)[:r] by back substitution, the dead ones are zero.  Not the minimum-norm solution of
+    `pinv` / `lstsq`: the two differ by a null-space vector.  SPQR also reorders the columns (COLAMD) before it
+    factorises; that order is not reproduced here (natural order), so WHICH column of a dependent set is dead can differ
+    from Julia's — stated in DESIGN.md section 8 ("unpinned")."""
+    M = np.array(M, dtype=np.float64)
+    m, n = M.shape
+    eps = np.finfo(np.float64).eps
+    tol = 20.0 * (m + n) * eps * max(float(np.sqrt((M * M).sum(axis=0)).max()) if n else 0.0, 0.0)
+    W = M.copy()                 # becomes R (live rows on top)
+    QtI = np.eye(m)              # becomes Q' (reflectors applied to the identity)
+    live = []
+    r = 0
+    for j in range(n):
+        if r >= m:
+            break
+        v = W[r:, j].copy()
+        nv = float(np.linalg.norm(v))
+        if nv <= tol:
+            continue             # dead column: its x stays zero
+        alpha = -nv if v[0] >= 0 else nv
+        v[0] -= alpha
+        vn = float(np.linalg.norm(v))
+        if vn > 0.0:
+            v /= vn
+            W[r:, j:] -= 2.0 * np.outer(v, v @ W[r:, j:])
+            QtI[r:, :] -= 2.0 * np.outer(v, v @ QtI[r:, :])
+        live.append(j)
+        r += 1
+    X = np.zeros((n, m))
+    if r:
+        import scipy.linalg as sla
+        R11 = np.triu(W[:r, live])
+        X[live, :] = sla.solve_triangular(R11, QtI[:r, :])
+    return X
+
+
 class QRSolver(CoarseSolver):
     """qr(A) \\ b (coarse_solver.jl:66-81).  For the full-rank coarse matrices AMG
     produces this is A^-1 b; the dense operator is formed by a Householder-QR
-    solve against the identity (least-squares for rank-deficient input)."""
+    solve against the identity.  Rank-deficient input: the BASIC solution of a rank-revealing
+    Householder QR (`_qr_basic_operator`: SuiteSparseQR's semantics — dead columns get zero), not the
+    minimum-norm one."""
 
     def dense_operator(self):
         if self._op is None:
@@ -193,7 +235,7 @@ class QRSolver(CoarseSolver):
                 Q, R = np.linalg.qr(M)
                 d = np.abs(np.diag(R))
                 if d.min() <= np.finfo(np.float64).eps * n * max(d.max(), 1e-300):
-                    self._op = np.linalg.lstsq(M, np.eye(n), rcond=None)[0]
+                    self._op = _qr_basic_operator(M)
                 else:
                     import scipy.linalg as sla
                     self._op = sla.solve_triangular(R, Q.T)

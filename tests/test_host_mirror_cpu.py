@@ -104,3 +104,35 @@ def test_splitting_on_patterns_equals_rs_splitting(dims):
     assert L.amgs_rs_cf_splitting_patterns(n, sp_.ctypes.data, sj.ctypes.data, tp_.ctypes.data, tj.ctypes.data,
                                            got.ctypes.data) == 0
     assert np.array_equal(got, want)
+
+
+def test_qrsolver_rank_deficient_is_the_basic_solution():
+    """coarse_solver.jl:66-81: `qr(A) \\ b` of a sparse A is SuiteSparseQR — on a rank-deficient coarse matrix the BASIC solution
+    (dead columns zero), not pinv's minimum-norm one.  Checked: consistent right-hand sides are solved, dead columns stay zero,
+    the difference to the minimum-norm solution lies in the null space, full-rank input is the inverse."""
+    import sys
+    H = sys.modules[AMG.QRSolver.__module__]
+    n = 9
+    M = 2 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)
+    M[0, 0] = M[-1, -1] = 1.0                                   # 1-D Neumann Laplacian: null space = constants
+    X = AMG.QRSolver(AMG.SparseMatrixCSC.from_dense(M)).dense_operator()
+    assert np.array_equal(X, H._qr_basic_operator(M))
+    rng = np.random.default_rng(5)
+    b = rng.random(n)
+    b -= b.mean()                                               # consistent
+    x = X @ b
+    assert np.linalg.norm(M @ x - b) <= 1e-13 * np.linalg.norm(b)
+    assert x[-1] == 0.0 and np.all(X[-1] == 0.0)                # the last column depends on the others: dead
+    d = x - np.linalg.lstsq(M, b, rcond=None)[0]
+    assert np.linalg.norm(M @ d) <= 1e-13 and np.ptp(d) <= 1e-13 and abs(d[0]) > 1e-3   # a (non-zero) constant apart
+    # two dependent columns in the middle / at the end
+    A = rng.random((6, 6))
+    A[:, 3] = 2 * A[:, 1]
+    A[:, 5] = A[:, 0] - A[:, 2]
+    X3 = H._qr_basic_operator(A)
+    bb = A @ rng.random(6)
+    x3 = X3 @ bb
+    assert np.linalg.norm(A @ x3 - bb) <= 1e-13 * np.linalg.norm(bb) and x3[3] == 0.0 and x3[5] == 0.0
+    # full rank: the inverse
+    F = M + 0.1 * np.eye(n)
+    assert np.abs(H._qr_basic_operator(F) - np.linalg.inv(F)).max() <= 1e-13
