@@ -120,6 +120,8 @@ def _bind_solve_phase(L, creal, coarse_fn):
     L.amgh_set_coarse_host.argtypes = [vp, i64, vp, vp, vp, coarse_fn, vp]
     L.amgh_finalize.argtypes = [vp]
     L.amgh_num_levels.argtypes = [vp]
+    L.amgh_tail_dense_build.argtypes = [vp, C.c_int]
+    L.amgh_tail_dense_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(C.c_double)]
     L.amgh_level_size.restype = i64
     L.amgh_level_size.argtypes = [vp, C.c_int]
     L.amgh_device_bytes.restype = i64

@@ -90,6 +90,16 @@ struct amgh_handle {
   struct CycleGraph { const real* x; const real* b; int cyc; bool xzero; hipGraphExec_t exec; };
   std::vector<CycleGraph> graphs;
   unsigned long long graph_epoch = 0;  // g_sched_epoch the cached graphs were captured under
+  // The collapsed coarse tail: from level tail_level down the recursion of __solve! (multilevel.jl:214-239) is ONE dense operator
+  // per cycle type — M[cyc]: row-major n x n, between the vectors the level above hands over (natural order, or the level's
+  // schedule order where the level above restricts into / prolongs from it).  level: -1 = not decided, -2 = none.
+  struct TailDense { real* M = nullptr; bool built = false; };
+  int tail_level = -1;
+  int tail_cols = 0;        // columns the workspaces of the tail's levels hold (>= nrhs: the build runs blocks of right-hand sides)
+  bool tail_lo = false;     // the operator maps the level-ordered right-hand side to the level-ordered x
+  bool tail_building = false;
+  TailDense tail[3];
+  double tail_build_ms = 0.0;
 };
 
 namespace {
@@ -206,6 +216,31 @@ int smooth(amgh_t* h, Level* L, const amgh_smoother_t& s, real*& xc, real*& xo, 
 
 int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo_io = false);
 
+// ---- the collapsed coarse tail (see amghip_kernels.hpp: dense_rm_gemv_kernel) ----
+// is level l entered through its dense operator in a cycle of type cyc?
+inline bool tail_here(const amgh_t* h, int l, int cyc) {
+  return g_tail_dense && !h->tail_building && h->tail_level == l && cyc >= 0 && cyc < 3 && h->tail[cyc].built;
+}
+template <int NC, bool ACC>
+int tail_launch(const real* M, int64_t n, real* x, int64_t ldx, const real* b, int64_t ldb, int groups, hipStream_t st) {
+  // (the thread count is a function of n alone: a column's sum is formed the same way whatever the block of right-hand sides)
+  if (n <= 1024) hipLaunchKernelGGL((dense_rm_gemv_kernel<NC, 64, ACC>), dim3((unsigned)n, groups), dim3(64), 0, st, M, b, x, (int)n, ldb, ldx);
+  else hipLaunchKernelGGL((dense_rm_gemv_kernel<NC, 256, ACC>), dim3((unsigned)n, groups), dim3(256), 0, st, M, b, x, (int)n, ldb, ldx);
+  HIP_TRY(hipGetLastError());
+  return AMGH_OK;
+}
+// x = M b (acc: x += M b) for ncolv columns; the row of M is read once for 8 / 4 / 2 / 1 columns
+template <bool ACC>
+int tail_apply_t(amgh_t* h, const real* M, int64_t n, real* x, int64_t ldx, const real* b, int64_t ldb, int ncolv) {
+  if (ncolv % 8 == 0) return tail_launch<8, ACC>(M, n, x, ldx, b, ldb, ncolv / 8, h->stream);
+  if (ncolv % 4 == 0) return tail_launch<4, ACC>(M, n, x, ldx, b, ldb, ncolv / 4, h->stream);
+  if (ncolv % 2 == 0) return tail_launch<2, ACC>(M, n, x, ldx, b, ldb, ncolv / 2, h->stream);
+  return tail_launch<1, ACC>(M, n, x, ldx, b, ldb, ncolv, h->stream);
+}
+int tail_apply(amgh_t* h, const real* M, int64_t n, real* x, int64_t ldx, const real* b, int64_t ldb, int ncolv, bool acc) {
+  return acc ? tail_apply_t<true>(h, M, n, x, ldx, b, ldb, ncolv) : tail_apply_t<false>(h, M, n, x, ldx, b, ldb, ncolv);
+}
+
 // __solve_next! (multilevel.jl:200-212)
 // x is the parent's freshly zeroed coarse_x (multilevel.jl:226) on the first visit, not on the second (W, F)
 // lo_io: b is already in this level's level-ordered right-hand side (the level above restricted into it) and x is to
@@ -270,6 +305,10 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo
     if (l == (int)h->levels.size() - 1) {
       ProfScope p(h, AMGH_T_COARSE, l + 1);
       for (int c = 0; c < bs; ++c) RC_TRY(coarse_solve(h, L->cx + c * nc, L->cb + c * nc));
+    } else if (tail_here(h, l + 1, cyc) && (C != nullptr) == h->tail_lo) {
+      // the levels below as ONE dense operator (built from this very recursion, tail_dense_build): x_c = M b_c
+      ProfScope p(h, AMGH_T_COARSE, l + 1);
+      RC_TRY(tail_apply(h, h->tail[cyc].M, nc, C ? cg->xp : L->cx, C ? cg->xstride : nc, C ? (const real*)cg->bp : (const real*)L->cb, nc, bs, false));
     } else {
       RC_TRY(cycle_next(h, l + 1, L->cx, L->cb, cyc, C != nullptr));
     }
@@ -303,6 +342,9 @@ int cycle(amgh_t* h, int l, real* x, const real* b, int cyc, bool xzero, bool lo
   if (l == (int)h->levels.size() - 1) {
     ProfScope p(h, AMGH_T_COARSE, l + 1);
     for (int c = 0; c < bs; ++c) RC_TRY(coarse_solve(h, L->cx + c * nc, L->cb + c * nc));
+  } else if (tail_here(h, l + 1, cyc) && !h->tail_lo) {
+    ProfScope p(h, AMGH_T_COARSE, l + 1);
+    RC_TRY(tail_apply(h, h->tail[cyc].M, nc, L->cx, nc, L->cb, nc, bs, false));
   } else {
     RC_TRY(cycle_next(h, l + 1, L->cx, L->cb, cyc));
   }
@@ -330,7 +372,69 @@ int apply_once(amgh_t* h, real* x, const real* b, int cyc, bool xzero) {
     for (int c = 0; c < h->nrhs; ++c) RC_TRY(coarse_solve(h, x + c * h->ncoarse, b + c * h->ncoarse));
     return AMGH_OK;
   }
+  if (tail_here(h, 0, cyc) && !h->tail_lo) {
+    // the whole hierarchy is the tail: z = M b; on a non-zero x the same stationary iteration, x += M (b - A x)
+    Level* L = h->levels[0];
+    ProfScope p(h, AMGH_T_COARSE, 0);
+    if (xzero) return tail_apply(h, h->tail[cyc].M, L->n, x, L->n, b, L->n, h->nrhs, false);
+    RC_TRY(csr_apply(&L->A, M_RESID, x, b, L->res, h->stream, h->nrhs));
+    return tail_apply(h, h->tail[cyc].M, L->n, x, L->n, L->res, L->n, h->nrhs, true);
+  }
   return cycle(h, 0, x, b, cyc, xzero);
+}
+
+// The dense operator of the tail for cycles of type cyc: the library's own recursion (cycle_next / cycle: whatever smoothers,
+// cycle type and coarse solver the levels carry) applied to the columns of the identity, tail_cols at a time as a block of
+// right-hand sides — every step of it is linear, so the columns are the operator.  Nothing of the result depends on the
+// handle's own block size.  Called outside graph capture (amgh_tail_dense_build, or the first cycle of a type: apply_cycle).
+int tail_dense_build(amgh_t* h, int cyc) {
+  if (h->tail_level < 0 || cyc < 0 || cyc > 2 || h->tail[cyc].built || h->coarse_fn || h->tail_building) return AMGH_OK;
+  const int l0 = h->tail_level;
+  Level* L0 = h->levels[l0];
+  const int64_t n = L0->n;
+  const int BB = h->tail_cols;
+  if (BB < 1 || BB > 64) return AMGH_ESTATE;
+  HIP_TRY(hipEventRecord(h->t0, h->stream));
+  real *X = nullptr, *B = nullptr, *Mc = nullptr, *M = nullptr;
+  auto cleanup = [&] { hipFree(X); hipFree(B); hipFree(Mc); };
+  int rc = dev_alloc(&X, n * BB);
+  if (rc == AMGH_OK) rc = dev_alloc(&B, n * BB);
+  if (rc == AMGH_OK) rc = dev_alloc(&Mc, n * n);
+  if (rc == AMGH_OK) rc = dev_alloc(&M, n * n);
+  // levels below the entry that take their vectors in schedule order from the level above: sized for the build's block
+  for (size_t l = (size_t)l0; rc == AMGH_OK && l + 1 < h->levels.size(); ++l)
+    if (h->levels[l]->coarse_lo) rc = gs_ensure_cols(h->levels[l + 1]->smat(), BB, h->stream);
+  const int nrhs0 = h->nrhs;
+  const bool prof0 = h->profile;
+  h->nrhs = BB; h->profile = false; h->tail_building = true;
+  for (int64_t j0 = 0; j0 < n && rc == AMGH_OK; j0 += BB) {
+    const int nb = (int)std::min<int64_t>(BB, n - j0);
+    if (hipMemsetAsync(B, 0, sizeof(real) * n * BB, h->stream) != hipSuccess || hipMemsetAsync(X, 0, sizeof(real) * n * BB, h->stream) != hipSuccess) { rc = -1001; break; }
+    hipLaunchKernelGGL(unit_cols_kernel, dim3(1), dim3(64), 0, h->stream, B, n, (int)j0, nb);
+    rc = l0 == 0 ? cycle(h, 0, X, B, cyc, true) : cycle_next(h, l0, X, B, cyc, false);
+    if (rc == AMGH_OK && hipMemcpyAsync(Mc + (size_t)j0 * n, X, sizeof(real) * n * nb, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) rc = -1001;
+  }
+  h->nrhs = nrhs0; h->profile = prof0; h->tail_building = false;
+  if (rc == AMGH_OK) {
+    const GsSchedule* g = L0->smat()->gs;
+    const int32_t* perm = h->tail_lo ? (g ? g->perm : nullptr) : nullptr;
+    if (h->tail_lo && !perm) rc = AMGH_ESTATE;
+    else {
+      const unsigned t = (unsigned)((n + 31) / 32);
+      hipLaunchKernelGGL(tail_transpose_kernel, dim3(t, t), dim3(32, 8), 0, h->stream, (const real*)Mc, perm, M, (int)n);
+      if (hipGetLastError() != hipSuccess) rc = -1001;
+    }
+  }
+  float ms = 0.f;
+  if (rc == AMGH_OK && (hipEventRecord(h->t1, h->stream) != hipSuccess || hipEventSynchronize(h->t1) != hipSuccess ||
+                        hipEventElapsedTime(&ms, h->t0, h->t1) != hipSuccess)) rc = -1001;
+  if (rc != AMGH_OK) { hipStreamSynchronize(h->stream); cleanup(); hipFree(M); (void)hipGetLastError(); return rc; }
+  cleanup();
+  h->tail[cyc].M = M;
+  h->tail[cyc].built = true;
+  h->tail_build_ms += ms;
+  h->ws_bytes += kRealB * n * n;
+  return AMGH_OK;
 }
 
 // apply_once through a captured hipGraph: a cycle is thousands of short,
@@ -339,6 +443,9 @@ int apply_once(amgh_t* h, real* x, const real* b, int cyc, bool xzero) {
 // launches when profiling, with a host coarse solver, or if capture fails.
 // xzero: the caller has just zeroed x (ldiv!, the preconditioner inside PCG)
 int apply_cycle(amgh_t* h, real* x, const real* b, int cyc, bool xzero = false) {
+  // (the first cycle of a type builds the tail's dense operator for it — outside any capture; a build that fails leaves the
+  // per-level cycle in charge: amgh_tail_dense_build reports why)
+  if (g_tail_dense && h->tail_level >= 0 && cyc >= 0 && cyc < 3 && !h->tail[cyc].built && tail_dense_build(h, cyc) != AMGH_OK) h->tail_level = -2;
   if (!h->use_graph || h->profile || h->coarse_fn || h->levels.empty()) return apply_once(h, x, b, cyc, xzero);
   if (h->graph_epoch != g_sched_epoch) {  // a schedule buffer moved: the captured pointers are stale
     for (auto& g : h->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
@@ -606,6 +713,7 @@ void amgh_destroy(amgh_t* h) {
   csr_free(&h->finalA);
   hipFree(h->coarse_op); hipFree(h->res_final); hipFree(h->partial); hipFree(h->scal);
   hipFree(h->x0); hipFree(h->b0); hipFree(h->pc_r); hipFree(h->pc_c); hipFree(h->pc_u);
+  for (auto& t : h->tail) hipFree(t.M);
   for (auto& e : h->pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto& g : h->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
   if (h->t0) hipEventDestroy(h->t0);
@@ -966,18 +1074,33 @@ int amgh_finalize(amgh_t* h) {
   if (h->levels.empty() && !h->has_finalA) return AMGH_ESTATE;
   HIP_TRY(hipSetDevice(h->device));
   int64_t ws = 0;
-  for (Level* L : h->levels) {
-    RC_TRY(dev_alloc(&L->res, L->n * h->nrhs));
-    RC_TRY(dev_alloc(&L->cx, L->nc * h->nrhs));
-    RC_TRY(dev_alloc(&L->cb, L->nc * h->nrhs));
-    ws += kRealB * (L->n + 2 * L->nc) * h->nrhs;
+  // the collapsed coarse tail: the first level of at most tail_dense_rows rows (with a device coarse solver below it); its
+  // operator is built later (tail_dense_build), from blocks of tail_cols right-hand sides — the workspaces of the tail's
+  // levels are sized for them here (a few thousand rows: nothing)
+  h->tail_level = -2;
+  if (g_tail_dense_rows > 0 && !h->coarse_fn)
+    for (size_t l = 0; l < h->levels.size(); ++l)
+      if (h->levels[l]->n <= g_tail_dense_rows) { h->tail_level = (int)l; break; }
+  if (h->tail_level >= 0) {
+    int bb = std::max(1, std::min(g_tail_dense_batch, 64));
+    if (bb == 2 || bb == 4 || bb == 8 || bb == 16) bb += 1;   // (not a block size of the interleaved kernels: their buffers belong to the handle's own block)
+    h->tail_cols = bb;
+    h->tail_lo = h->tail_level >= 1 && h->levels[h->tail_level - 1]->coarse_lo;
+  }
+  for (size_t l = 0; l < h->levels.size(); ++l) {
+    Level* L = h->levels[l];
+    const int64_t wc = (h->tail_level >= 0 && (int)l >= h->tail_level) ? std::max(h->nrhs, h->tail_cols) : h->nrhs;   // workspace columns
+    RC_TRY(dev_alloc(&L->res, L->n * wc));
+    RC_TRY(dev_alloc(&L->cx, L->nc * wc));
+    RC_TRY(dev_alloc(&L->cb, L->nc * wc));
+    ws += kRealB * (L->n + 2 * L->nc) * wc;
     if (h->nrhs == 2 || h->nrhs == 4 || h->nrhs == 8 || h->nrhs == 16) {
       RC_TRY(dev_alloc(&L->il, std::max(L->n, L->nc) * h->nrhs));
       ws += kRealB * std::max(L->n, L->nc) * h->nrhs;
     }
     if (L->pre.kind == AMGH_SMOOTH_JACOBI || L->post.kind == AMGH_SMOOTH_JACOBI) {
-      RC_TRY(dev_alloc(&L->tmp, L->n * h->nrhs));
-      ws += kRealB * L->n * h->nrhs;
+      RC_TRY(dev_alloc(&L->tmp, L->n * wc));
+      ws += kRealB * L->n * wc;
       RC_TRY(csr_ensure_diag(L->smat(), h->stream));
     }
   }
@@ -1081,6 +1204,21 @@ int amgh_finalize(amgh_t* h) {
 }
 
 int amgh_num_levels(const amgh_t* h) { return h ? (int)h->levels.size() : 0; }
+int amgh_tail_dense_build(amgh_t* h, int cycle_) {
+  RC_TRY(check_ready(h));
+  if (cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
+  HIP_TRY(hipSetDevice(h->device));
+  if (!g_tail_dense || h->tail_level < 0) return AMGH_OK;
+  return tail_dense_build(h, cycle_);
+}
+int amgh_tail_dense_info(const amgh_t* h, int cycle_, int* level, int64_t* rows, double* build_ms) {
+  if (!h || cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
+  const bool on = h->finalized && h->tail_level >= 0 && h->tail[cycle_].built;
+  if (level) *level = on ? h->tail_level : -1;
+  if (rows) *rows = on ? h->levels[h->tail_level]->n : 0;
+  if (build_ms) *build_ms = h->tail_build_ms;
+  return AMGH_OK;
+}
 int64_t amgh_level_size(const amgh_t* h, int l) {
   if (!h || l < 0 || l > (int)h->levels.size()) return -1;
   return l == (int)h->levels.size() ? h->ncoarse : h->levels[l]->n;
@@ -1943,6 +2081,9 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_wave_quad")) g_gs_wave_quad = value;
   else if (!strcmp(name, "pcg_fused")) g_pcg_fused = value;
   else if (!strcmp(name, "gs_tri_rb")) g_gs_tri_rb = value;
+  else if (!strcmp(name, "tail_dense_rows")) g_tail_dense_rows = value < 0 ? 0 : value;
+  else if (!strcmp(name, "tail_dense")) { g_tail_dense = value; g_sched_epoch++; }   // (captured cycles hold the path they were captured on)
+  else if (!strcmp(name, "tail_dense_batch")) g_tail_dense_batch = value;
   else if (!strcmp(name, "gs_lean")) g_gs_lean = value;
   else if (!strcmp(name, "gs_sell")) g_gs_sell = value;
   else if (!strcmp(name, "gs_sample")) g_gs_sample = value;

@@ -439,6 +439,9 @@ int g_gs_ept = 0;               // entries per thread of merged slot launches (0
 int g_gs_lpr = 0;               // lanes per row in the row sums of merged slot launches (0 = by row length, 1 = one thread per row)
 int g_gs_il = 1;                // blocks of 2 / 4 / 8 right-hand sides: merged groups gather from an interleaved copy of the sweep's vector (gs_slot_il_kernel, gs_sell_il_kernel; 0 = one gather per column); read at every sweep
 int g_pcg_fused = 1;            // amgh_pcg: 1 = the recurrence between two cycles in 8 launches (second stages of the dot products fused with the scalar steps, the updates with the norm); 0 = one launch per operation (15) — bitwise the same iterates
+int g_tail_dense_rows = 6144;   // the collapsed coarse tail: the first level with at most this many rows and everything below it become ONE dense operator (0 = off); read at amgh_finalize
+int g_tail_dense = 1;           // ... and is applied where it has been built (0 = the per-level cycle: what the operator was built from); read at every cycle
+int g_tail_dense_batch = 64;    // ... built from the library's own cycle on this many columns of the identity at a time (64 = the largest block of right-hand sides: 256^3 174 -> ~140 ms, C1 17.8 -> 12.0 ms against 32; profiles/r06_tail_dense.log); read at amgh_finalize
 int g_gs_tri_rb = 1;            // dense triangle inverses under a block of right-hand sides: 4 rows per workgroup (tri_gemm_kernel; 0 = one row, tri_gemv_kernel — bitwise the same); read at every sweep
 int g_gs_dense_blk = 4096;       // ... rows per dense block above kDenseTriMax rows; read at schedule build
 int g_gs_dense_tri = 1;          // small operators: sweeps through the dense inverse of the whole triangle (0 = block-inverse / exact order); build + sweep

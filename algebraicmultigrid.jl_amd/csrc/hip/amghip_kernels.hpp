@@ -2178,6 +2178,65 @@ __global__ __launch_bounds__(kThreads) void tri_gemm_kernel(const real* X, const
   }
 }
 
+// ---- the collapsed coarse tail (round 6; amghip.hip: tail_dense_build / tail_apply) ----
+// Every step of __solve! (multilevel.jl:214-239) is linear in (x, b): from a level of a few thousand rows down, the
+// whole recursion — smoothers, residual, restriction, the levels below, the coarse solve, prolongation — IS one dense
+// n x n operator, built once by running the library's own cycle on the columns of the identity.  One launch replaces
+// the ~25-60 launches of ~5 us of those levels (the reference walks them for free, multilevel.jl:227-231).
+// B[c * ld + j0 + c] = 1 for the nb columns of a batch (B zeroed before)
+__global__ void unit_cols_kernel(real* B, int64_t ld, int j0, int nb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nb) B[(int64_t)c * ld + j0 + c] = (real)1;
+}
+// M[i][j] (row-major) = Mc[pj * n + pi] (columns of the natural-order operator), pi = perm ? perm[i] : i — the operator between
+// the level-ordered vectors of a level that takes its right-hand side / leaves its x in its schedule's order
+__global__ void tail_transpose_kernel(const real* __restrict__ Mc, const int32_t* __restrict__ perm, real* __restrict__ M, int n) {
+  __shared__ real tile[32][33];
+  const int bj = blockIdx.x * 32, bi = blockIdx.y * 32;
+  // read: rows of Mc (= columns j of the operator), coalesced along i
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int j = bj + r, i = bi + threadIdx.x;
+    if (j < n && i < n) tile[r][threadIdx.x] = Mc[(size_t)(perm ? perm[j] : j) * n + (perm ? perm[i] : i)];
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int i = bi + r, j = bj + threadIdx.x;
+    if (i < n && j < n) M[(size_t)i * n + j] = tile[threadIdx.x][r];
+  }
+}
+// x (+)= M b, M dense n x n ROW-major: one workgroup of T threads per row, threads across the columns (a thread owns every
+// T-th entry: all its loads independent and in flight together), a fixed shuffle tree, the wave partials added in order:
+// deterministic, and per column the same sum whatever NC is (NC right-hand sides share the row's loads).
+template <int NC, int T, bool ACC>
+__global__ __launch_bounds__(T) void dense_rm_gemv_kernel(const real* __restrict__ M, const real* __restrict__ b, real* __restrict__ x, int n,
+                                                          int64_t ldb, int64_t ldx) {
+  __shared__ real s_part[NC][T / kWave];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const real* bv = b + (int64_t)blockIdx.y * NC * ldb;
+  const real* row = M + (size_t)i * n;
+  real acc[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+  for (int j = tid; j < n; j += T) {
+    const real r = row[j];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) acc[q] += r * bv[j + q * ldb];
+  }
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {
+    for (int o = kWave / 2; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, kWave);
+    if (tid % kWave == 0) s_part[q][tid / kWave] = acc[q];
+  }
+  __syncthreads();
+  if (tid < NC) {
+    real t = s_part[tid][0];
+#pragma unroll
+    for (int w = 1; w < T / kWave; ++w) t += s_part[tid][w];
+    real* xo = x + ((int64_t)blockIdx.y * NC + tid) * ldx + i;
+    if (ACC) *xo += t; else *xo = t;
+  }
+}
+
 // x = M * b, M dense n x n column-major (coarse solve, coarse_solver.jl:16).
 // One thread per output row, columns ascending.
 __global__ void dense_gemv_kernel(const real* M, const real* b, real* x, int n) {

@@ -291,7 +291,15 @@ class DeviceHierarchy:
             hip_check(self.lib.amgh_set_coarse_host(self.h, fA.m, _ptr(fr), _ptr(fc), _ptr(fv), self._coarse_cb, None),
                       "set_coarse_host")
         hip_check(self.lib.amgh_finalize(self.h), "finalize")
+        # the collapsed coarse tail's operator for V-cycles now, inside the setup (W / F: at their first cycle)
+        hip_check(self.lib.amgh_tail_dense_build(self.h, 0), "tail_dense_build")
         self.n = ml.levels[0].A.m if ml.levels else fA.m
+
+    def tail_dense_info(self, cycle=0):
+        """(level, rows, build_ms) of the collapsed coarse tail for a cycle type (level -1: none)."""
+        lv, rows, ms = C.c_int(-1), C.c_int64(0), C.c_double(0.0)
+        hip_check(self.lib.amgh_tail_dense_info(self.h, int(cycle), C.byref(lv), C.byref(rows), C.byref(ms)), "tail_dense_info")
+        return lv.value, rows.value, ms.value
 
     def __del__(self):
         try:

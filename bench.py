@@ -177,6 +177,15 @@ def uncompressed_cycle_ms(ml, lib, bd, zd, n, reps=3):
             lib.amgh_debug_set_tunable(name, 1)
 
 
+def tail_info(dev):
+    """The collapsed coarse tail of a device hierarchy (amghip.h: amgh_tail_dense_build): the level from which the V-cycle's
+    recursion is applied as one dense operator, its rows, and what building it cost (inside setup_s)."""
+    lv, rows, ms = dev.tail_dense_info(0)
+    return {"level": lv, "rows": rows, "operator_bytes": 8 * rows * rows if lv >= 0 else 0, "build_ms": ms,
+            "note": "levels >= level: smoothers, residual, restriction, recursion, coarse solve, prolongation as ONE dense operator "
+                    "(the same linear map, built from the per-level recursion on the columns of the identity; tunable tail_dense_rows)"}
+
+
 def secondary_configs(check=True):
     """The smaller BASELINE.json configurations on the same build, a few hundred milliseconds each: C1 (poisson(1000), ruge_stuben,
     symmetric Gauss-Seidel), C2 at full size (poisson((1024,1024)), smoothed_aggregation, Jacobi(2/3)), C5 (lin_elastic_2d,
@@ -215,8 +224,9 @@ def secondary_configs(check=True):
     try:
         A = AMG.poisson(1000)
         ml = AMG.ruge_stuben(A)
-        ms, err, _ = cycles(ml, 1000, 50)
-        out["C1"] = {"workload": "poisson(1000), ruge_stuben defaults", "vcycle_ms": ms, "levels": len(ml), "rel_err_vs_oracle": err}
+        ms, err, dev = cycles(ml, 1000, 50)
+        out["C1"] = {"workload": "poisson(1000), ruge_stuben defaults", "vcycle_ms": ms, "levels": len(ml), "rel_err_vs_oracle": err,
+                     "collapsed_tail": {k: v for k, v in tail_info(dev).items() if k != "note"}}
     except Exception as ex:  # noqa: BLE001
         out["C1"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
     try:
@@ -232,6 +242,7 @@ def secondary_configs(check=True):
         out["C2"] = {"workload": "poisson((1024,1024)), smoothed_aggregation, Jacobi(2/3) pre+post", "unknowns": n, "setup_s": ts,
                      "vcycle_ms": ms, "unknowns_per_s": n / (ms * 1e-3), "levels": len(ml), "rel_err_vs_oracle": err,
                      "fine_spmv_ms": sp, "fine_spmv_GBs": alg / (sp * 1e-3) / 1e9,
+                     "collapsed_tail": {k: v for k, v in tail_info(dev).items() if k != "note"},
                      "note": "the fine operator (%.0f MB) fits the 256 MB Infinity Cache: the SpMV rate is not an HBM figure" % (alg / 1e6)}
     except Exception as ex:  # noqa: BLE001
         out["C2"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
@@ -246,7 +257,7 @@ def secondary_configs(check=True):
             x, log = AMG.cg(A, d["b"], Pl=pl, reltol=1e-10, log=True)
             best = min(best, 1e3 * (time.perf_counter() - t0))
             iters = int(log["iters"])
-        ms, err, _ = cycles(ml, A.m, 50)
+        ms, err, dev = cycles(ml, A.m, 50)
         res = float(np.linalg.norm(d["b"] - A @ x) / np.linalg.norm(d["b"]))
         out["C5"] = {"workload": "lin_elastic_2d (n = %d), smoothed_aggregation with B, aspreconditioner in cg, reltol 1e-10" % A.m,
                      "pcg_ms": best, "pcg_iterations": iters, "final_rel_residual": res, "vcycle_ms": ms, "rel_err_vs_oracle": err}
@@ -527,6 +538,7 @@ def main():
         "upload_s": t_upload, "setup_overlapped_with_upload": bool(overlap),
         **({"overlap_error": overlap_error} if overlap_error else {}),
         "hbm_bytes": dev.device_bytes(), "hbm_bytes_by_category": dev.device_bytes_detail(),
+        "collapsed_tail": tail_info(dev),
     }
     if not args.light and not args.no_block_rhs:
         # secondary (never `value`): the same cycle on a block of 8 right-hand sides (workspace block size 8,

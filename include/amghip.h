@@ -169,6 +169,20 @@ int amgh_set_coarse_host(amgh_t* h, int64_t n, const int32_t* A_rowptr, const in
 int amgh_finalize(amgh_t* h);
 
 int amgh_num_levels(const amgh_t* h);            /* length(ml.levels)            */
+/* The collapsed coarse tail.  The reference recurses through its small levels for free (__solve!, multilevel.jl:214-239, the
+ * recursion at :227-231); on the GPU every level of a few hundred rows still costs ~5 launches of ~5 us.  Every step of that
+ * recursion is linear in (x, b) — smooth! (smoother.jl), the residual, R * res, the coarse solver (coarse_solver.jl:16,75-81),
+ * x += P * coarse_x — so from the first level with at most `tail_dense_rows` rows (tunable, default 6144; 0 = off; read at
+ * amgh_finalize) down, __solve_next! (multilevel.jl:200-212) IS one dense n x n operator per cycle type (V / W / F), and the
+ * cycle applies it in ONE launch.  The operator is built from the library's own recursion on the columns of the identity
+ * (blocks of `tail_dense_batch` right-hand sides, default 64), either by this call or by the first cycle of that type; a hierarchy whose
+ * finest level is that small is one operator altogether (a cycle on a non-zero x: x += M (b - A x), the same iteration).
+ * Results: the per-level cycle's up to the rounding of an n-term sum (tests: <= 1e-12 relative).  Not built with a host coarse
+ * solver (amgh_set_coarse_host).  Tunable "tail_dense" = 0 (read at every cycle) runs the levels one by one again.
+ * amgh_tail_dense_info: level = the level collapsed for that cycle type (-1: none / not built yet), its rows, and the
+ * milliseconds all builds of this handle took (any of the three may be NULL).                                              */
+int amgh_tail_dense_build(amgh_t* h, int cycle);
+int amgh_tail_dense_info(const amgh_t* h, int cycle, int* level, int64_t* rows, double* build_ms);
 int64_t amgh_level_size(const amgh_t* h, int l); /* size(levels[l].A,1); l==L: final */
 int64_t amgh_device_bytes(const amgh_t* h);      /* HBM held by the handle        */
 /* The same by category: out8 = {natural-order A / S / P / R, level-ordered CSR copies (the schedules' A, P, R),

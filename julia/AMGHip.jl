@@ -133,6 +133,8 @@ function hip(::Type{$T}, ml::MultiLevel; device::Integer = 0, bs::Integer = 1, s
                     h[], n, fr, fc, fv, cb, C_NULL))
     end
     check(ccall((:amgh_finalize, $lib), Cint, (Ptr{Cvoid},), h[]))
+    # the collapsed coarse tail's dense operator for V-cycles now (W / F: at their first cycle); multilevel.jl:227-231
+    check(ccall((:amgh_tail_dense_build, $lib), Cint, (Ptr{Cvoid}, Cint), h[], 0))
     MultiLevel(ml.levels, ml.final_A, ml.coarse_solver, ml.presmoother, ml.postsmoother,
                HipWorkspace{$T}(h[], Int(bs), keep))
 end

@@ -45,6 +45,9 @@ def _build_native():
             # (likewise the single-wave walk of small operators: one lane per row = the scalar loop's bits; the shipping
             # default — four lanes per row, gs_waveq_kernel — runs in tests/test_gpu_waveq.py, bench.py and smoke())
             AMG.hip_lib(dt).amgh_debug_set_tunable(b"gs_wave_quad", 0)
+            # (and the collapsed coarse tail — one dense operator for the small levels, the same linear map in another rounding:
+            # the shipping default runs in tests/test_gpu_tail.py, bench.py and smoke())
+            AMG.hip_lib(dt).amgh_debug_set_tunable(b"tail_dense_rows", 0)
         except Exception:  # noqa: BLE001  (no library: the tests that need it fail on their own)
             pass
 
