@@ -2086,7 +2086,9 @@ template <int NC>
 __global__ __launch_bounds__(kThreads) void tri_gemv_kernel(const real* X, const real* s, real* x, int n, int upper, int64_t lds,
                                                               int64_t ldx) {
   __shared__ real s_part[NC][kThreads / kWave];
-  const int i = blockIdx.x, tid = threadIdx.x;
+  // (the longest rows first: workgroups are dispatched in blockIdx order, and a launch that ends on its 32 KB rows ends later than
+  // one that ends on its 8-byte rows — lower triangle: row n - 1 first; upper: row 0 first)
+  const int i = upper ? (int)blockIdx.x : n - 1 - (int)blockIdx.x, tid = threadIdx.x;
   const real* sv = s + (int64_t)blockIdx.y * NC * lds;
   const real* row = X + (size_t)i * n;
   // a thread's entries are a function of the COLUMN alone — lower: j = tid, tid + 256, ... up to the diagonal; upper: j = n - 1 -
@@ -2131,7 +2133,7 @@ template <int NC, int RB>
 __global__ __launch_bounds__(kThreads) void tri_gemm_kernel(const real* X, const real* s, real* x, int n, int upper, int64_t lds,
                                                               int64_t ldx) {
   __shared__ real s_part[RB * NC][kThreads / kWave];
-  const int i0 = blockIdx.x * RB, tid = threadIdx.x;
+  const int i0 = (upper ? (int)blockIdx.x : (int)(gridDim.x - 1 - blockIdx.x)) * RB, tid = threadIdx.x;   // (the longest rows first, as tri_gemv_kernel)
   const real* sv = s + (int64_t)blockIdx.y * NC * lds;
   real acc[RB][NC];
 #pragma unroll

@@ -576,6 +576,10 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       else if (ncolv % 8 == 0) hipLaunchKernelGGL(tri_gemv_kernel<8>, dim3((unsigned)rb, ncolv / 8), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
       else if (ncolv % 4 == 0) hipLaunchKernelGGL(tri_gemv_kernel<4>, dim3((unsigned)rb, ncolv / 4), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
       else if (ncolv % 2 == 0) hipLaunchKernelGGL(tri_gemv_kernel<2>, dim3((unsigned)rb, ncolv / 2), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      // (single columns: several rows per workgroup share the loads of s too — tunable gs_tri_rb1 = 2 / 4 / 8 rows, bitwise the one-row kernel)
+      else if (g_gs_tri_rb1 == 2) hipLaunchKernelGGL((tri_gemm_kernel<1, 2>), dim3((unsigned)((rb + 1) / 2), ncolv), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      else if (g_gs_tri_rb1 == 4) hipLaunchKernelGGL((tri_gemm_kernel<1, 4>), dim3((unsigned)((rb + 3) / 4), ncolv), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
+      else if (g_gs_tri_rb1 == 8) hipLaunchKernelGGL((tri_gemm_kernel<1, 8>), dim3((unsigned)((rb + 7) / 8), ncolv), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
       else hipLaunchKernelGGL(tri_gemv_kernel<1>, dim3((unsigned)rb, ncolv), dim3(kThreads), 0, st, Xk, (const real*)(g->blk_s + r0), x + r0, rb, backward ? 1 : 0, (int64_t)g->n, (int64_t)g->n);
     }
     HIP_TRY(hipGetLastError());
