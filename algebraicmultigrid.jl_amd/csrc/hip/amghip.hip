@@ -446,6 +446,8 @@ int apply_cycle(amgh_t* h, real* x, const real* b, int cyc, bool xzero = false) 
   // (the first cycle of a type builds the tail's dense operator for it — outside any capture; a build that fails leaves the
   // per-level cycle in charge: amgh_tail_dense_build reports why)
   if (g_tail_dense && h->tail_level >= 0 && cyc >= 0 && cyc < 3 && !h->tail[cyc].built && tail_dense_build(h, cyc) != AMGH_OK) h->tail_level = -2;
+  // (an F-cycle's second visit of a level is a V-cycle, multilevel.jl:209-211: the levels above the tail ask for that operator too)
+  if (g_tail_dense && h->tail_level >= 0 && cyc == AMGH_CYCLE_F && !h->tail[AMGH_CYCLE_V].built && tail_dense_build(h, AMGH_CYCLE_V) != AMGH_OK) h->tail_level = -2;
   if (!h->use_graph || h->profile || h->coarse_fn || h->levels.empty()) return apply_once(h, x, b, cyc, xzero);
   if (h->graph_epoch != g_sched_epoch) {  // a schedule buffer moved: the captured pointers are stale
     for (auto& g : h->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
@@ -1209,7 +1211,9 @@ int amgh_tail_dense_build(amgh_t* h, int cycle_) {
   if (cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
   HIP_TRY(hipSetDevice(h->device));
   if (!g_tail_dense || h->tail_level < 0) return AMGH_OK;
-  return tail_dense_build(h, cycle_);
+  RC_TRY(tail_dense_build(h, cycle_));
+  if (cycle_ == AMGH_CYCLE_F) RC_TRY(tail_dense_build(h, AMGH_CYCLE_V));   // (its second visits are V-cycles)
+  return AMGH_OK;
 }
 int amgh_tail_dense_info(const amgh_t* h, int cycle_, int* level, int64_t* rows, double* build_ms) {
   if (!h || cycle_ < 0 || cycle_ > 2) return AMGH_EINVAL;
