@@ -540,6 +540,34 @@ def main():
         "hbm_bytes": dev.device_bytes(), "hbm_bytes_by_category": dev.device_bytes_detail(),
         "collapsed_tail": tail_info(dev),
     }
+    if not args.light:
+        # secondary (never `value`): time to SOLUTION on the same hierarchy — the device-resident preconditioned CG of amgh_pcg_d
+        # (cg(A, b; Pl = aspreconditioner(ml)) as the reference's tests run it, cycle_tests.jl:25), right-hand side and solution in
+        # HBM, to the default reltol sqrt(eps): iterations, milliseconds, the true relative residual computed on the host.
+        try:
+            import ctypes as C
+            xd = AMG.DeviceBuffer(n, 0, np.zeros(n))
+            hist = np.zeros(201)
+            its = C.c_int(0)
+            rtol = float(np.sqrt(np.finfo(np.float64).eps))
+            lib.amgh_pcg_d(dev.h, bd.ptr, xd.ptr, 0, 1, 200, 0.0, rtol, hist.ctypes.data, C.byref(its))   # warm-up (first-use buffers)
+            sync()
+            xd.upload(np.zeros(n))
+            t0 = time.perf_counter()
+            rc = lib.amgh_pcg_d(dev.h, bd.ptr, xd.ptr, 0, 1, 200, 0.0, rtol, hist.ctypes.data, C.byref(its))
+            sync()
+            t_pcg = 1e3 * (time.perf_counter() - t0)
+            if rc != 0:
+                raise RuntimeError(lib.amgh_strerror(rc).decode())
+            xs = xd.download()
+            As = A.to_scipy().tocsr()
+            true_res = float(np.linalg.norm(b - As @ xs) / np.linalg.norm(b))
+            out["pcg_to_solution"] = {"reltol": rtol, "iterations": int(its.value), "ms": t_pcg, "ms_per_iteration": t_pcg / max(1, its.value),
+                                      "true_rel_residual": true_res, "setup_plus_solve_s": t_setup + 1e-3 * t_pcg,
+                                      "what": "amgh_pcg_d: V-cycle-preconditioned CG, b and x resident in HBM (IterativeSolvers.cg semantics)"}
+            del xd, As, xs
+        except Exception as ex:  # noqa: BLE001
+            out["pcg_to_solution"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
     if not args.light and not args.no_block_rhs:
         # secondary (never `value`): the same cycle on a block of 8 right-hand sides (workspace block size 8,
         # multilevel.jl:28-59) — one launch per sweep carries all columns; first column checked bitwise against the timed
