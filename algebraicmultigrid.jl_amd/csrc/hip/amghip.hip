@@ -2086,6 +2086,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "pcg_fused")) g_pcg_fused = value;
   else if (!strcmp(name, "gs_tri_rb")) g_gs_tri_rb = value;
   else if (!strcmp(name, "gs_tri_rb1")) g_gs_tri_rb1 = value;
+  else if (!strcmp(name, "gs_dti_pre")) g_gs_dti_pre = value;
   else if (!strcmp(name, "tail_dense_rows")) g_tail_dense_rows = value < 0 ? 0 : value;
   else if (!strcmp(name, "tail_dense")) { g_tail_dense = value; g_sched_epoch++; }   // (captured cycles hold the path they were captured on)
   else if (!strcmp(name, "tail_dense_batch")) g_tail_dense_batch = value;

@@ -442,6 +442,7 @@ int g_pcg_fused = 1;            // amgh_pcg: 1 = the recurrence between two cycl
 int g_tail_dense_rows = 6144;   // the collapsed coarse tail: the first level with at most this many rows and everything below it become ONE dense operator (0 = off); read at amgh_finalize
 int g_tail_dense = 1;           // ... and is applied where it has been built (0 = the per-level cycle: what the operator was built from); read at every cycle
 int g_tail_dense_batch = 64;    // ... built from the library's own cycle on this many columns of the identity at a time (64 = the largest block of right-hand sides: 256^3 174 -> ~140 ms, C1 17.8 -> 12.0 ms against 32; profiles/r06_tail_dense.log); read at amgh_finalize
+int g_gs_dti_pre = 8;           // pre-pass of a dense-triangle block: rows per workgroup (8; 16 = the shape of rounds 2-5, bitwise the same); read at every sweep
 int g_gs_tri_rb1 = 0;           // ... and under a SINGLE column: rows per workgroup of the dense triangle inverses (0 = one row, tri_gemv_kernel; 2 / 4 / 8: tri_gemm_kernel<1, RB> — bitwise the same); read at every sweep
 int g_gs_tri_rb = 1;            // dense triangle inverses under a block of right-hand sides: 4 rows per workgroup (tri_gemm_kernel; 0 = one row, tri_gemv_kernel — bitwise the same); read at every sweep
 int g_gs_dense_blk = 4096;       // ... rows per dense block above kDenseTriMax rows; read at schedule build

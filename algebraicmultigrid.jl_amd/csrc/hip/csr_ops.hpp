@@ -562,8 +562,11 @@ int csr_gs_sweep(amgh_csr* op, bool backward, bool sor, real omega, real* x, con
       ra.x = x; ra.b = b; ra.y = g->blk_s;
       ra.row_begin = r0; ra.row_end = r0 + rb;
       ra.ldx = g->n; ra.ldy = g->n; ra.ldb = g->n;
-      // (a block's rows are few and long: 16 per workgroup, or the pre-pass of a 4 096-row block runs on 64 CUs)
-      if (nb > 1) RC_TRY((launch_stream<M_RESID, StreamCfg<256, 16, 4096, 2, false, false>>(ra, st, ncolv)));
+      // (a block's rows are few and long: few per workgroup, or the pre-pass of a 4 096-row block runs on 64 CUs)
+      // (8 rows per workgroup since round 6: 512 workgroups for a 4 096-row block — 14.135 -> 14.10 ms per 256^3 V-cycle against 16 rows,
+      // bitwise; 32 rows 14.25, 128 threads with 8 / 4 rows 14.15 / 14.11: profiles/r06_dense_tri_rows.log; tunable gs_dti_pre = 16: the old shape)
+      if (nb > 1 && g_gs_dti_pre != 16) RC_TRY((launch_stream<M_RESID, StreamCfg<256, 8, 4096, 2, false, false>>(ra, st, ncolv)));
+      else if (nb > 1) RC_TRY((launch_stream<M_RESID, StreamCfg<256, 16, 4096, 2, false, false>>(ra, st, ncolv)));
       else RC_TRY((launch_stream<M_RESID, StreamCfg<256, 64, 4096, 2, false, false>>(ra, st, ncolv)));
       const real* Xk = (const real*)((backward ? g->dti_b : g->dti_f) + g->dti_off[k]);
       // columns per workgroup: the largest of 8 / 4 / 2 / 1 that divides the block of right-hand sides

@@ -21,8 +21,10 @@ zd = AMG.DeviceBuffer(n, 0)
 lib.amgh_profile_enable.argtypes = None
 ref = None
 for rep in range(2):
-    for rb in (0, 2, 4, 8):
-        lib.amgh_debug_set_tunable(b"gs_tri_rb1", rb)
+    TUN = sys.argv[2].encode() if len(sys.argv) > 2 else b"gs_tri_rb1"
+    VALS = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else (0, 2, 4, 8)
+    for rb in VALS:
+        lib.amgh_debug_set_tunable(TUN, rb)
         for _ in range(3):
             lib.amgh_precond_apply_d(dev.h, bd.ptr, zd.ptr, 0)
         lib.amgh_dev_sync(0)
@@ -34,5 +36,5 @@ for rep in range(2):
         z = zd.download()
         if ref is None:
             ref = z
-        print(f"gs_tri_rb1 = {rb}: V-cycle {ms:.3f} ms; bitwise the one-row kernel: {bool(np.array_equal(z, ref))}", flush=True)
-lib.amgh_debug_set_tunable(b"gs_tri_rb1", 0)
+        print(f"{TUN.decode()} = {rb}: V-cycle {ms:.3f} ms; bitwise the one-row kernel: {bool(np.array_equal(z, ref))}", flush=True)
+lib.amgh_debug_set_tunable(TUN, 0)
