@@ -1154,6 +1154,29 @@ int amgh_finalize(amgh_t* h) {
       }
     }
   }
+  // The restriction of a big level with the XCD-contiguous mapping of its workgroups where that is faster (a coarse row gathers from a
+  // fine vector several times its own size: which L2 holds the lines matters) — timed here on the level's own buffers, single column.
+  if (h->nrhs == 1 && g_stream_xcd)
+    for (Level* L : h->levels) {
+      if (!L->lo_ok || !L->Rp.rowptr || L->Rp.nrows < (1 << 18)) continue;
+      if (hipMemsetAsync(L->res, 0, sizeof(real) * L->n, h->stream) != hipSuccess) return -1001;
+      double ms[2] = {0, 0};
+      int rc = AMGH_OK;
+      for (int v = 0; v < 2 && rc == AMGH_OK; ++v) {
+        L->Rp.xcd_map = v == 1;
+        rc = csr_apply(&L->Rp, M_SPMV, L->res, nullptr, L->cb, h->stream, 1);
+        if (rc == AMGH_OK && hipEventRecord(h->t0, h->stream) != hipSuccess) rc = -1001;
+        for (int r = 0; r < 4 && rc == AMGH_OK; ++r) rc = csr_apply(&L->Rp, M_SPMV, L->res, nullptr, L->cb, h->stream, 1);
+        float t = 0.f;
+        if (rc == AMGH_OK && (hipEventRecord(h->t1, h->stream) != hipSuccess || hipEventSynchronize(h->t1) != hipSuccess ||
+                              hipEventElapsedTime(&t, h->t0, h->t1) != hipSuccess)) rc = -1001;
+        ms[v] = t;
+      }
+      L->Rp.xcd_map = false;
+      RC_TRY(rc);
+      L->Rp.xcd_map = ms[1] < 0.93 * ms[0];
+      if (getenv("AMGH_VERBOSE")) fprintf(stderr, "[amghip] n=%lld restriction: %.3f ms, XCD-contiguous %.3f ms -> %s\n", (long long)L->n, ms[0] / 4, ms[1] / 4, L->Rp.xcd_map ? "XCD-contiguous" : "plain");
+    }
   // Trimmed footprint (the default): where an operator the level-ordered cycle streams has value-coded columns, the cycle reads
   // THEM — 4 bytes per entry — and the 12 bytes of columns and values beside them are a copy nothing in it touches: released
   // (the restriction and prolongation of the level; its A where the level sweeps the block layout as a dataflow alone, so that
@@ -2087,6 +2110,7 @@ int amgh_debug_set_tunable(const char* name, int value) {
   else if (!strcmp(name, "gs_tri_rb")) g_gs_tri_rb = value;
   else if (!strcmp(name, "gs_tri_rb1")) g_gs_tri_rb1 = value;
   else if (!strcmp(name, "gs_dti_pre")) g_gs_dti_pre = value;
+  else if (!strcmp(name, "stream_xcd")) g_stream_xcd = value;
   else if (!strcmp(name, "tail_dense_rows")) g_tail_dense_rows = value < 0 ? 0 : value;
   else if (!strcmp(name, "tail_dense")) { g_tail_dense = value; g_sched_epoch++; }   // (captured cycles hold the path they were captured on)
   else if (!strcmp(name, "tail_dense_batch")) g_tail_dense_batch = value;

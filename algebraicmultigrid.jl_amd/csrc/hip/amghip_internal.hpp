@@ -372,6 +372,7 @@ struct CodedCols {
 
 struct amgh_csr {
   CodedCols cc;
+  bool xcd_map = false;   // SpMV launches of this operator with the XCD-contiguous mapping of the workgroups (amgh_finalize times both)
   int device = 0;
   int64_t nrows = 0, ncols = 0, nnz = 0;
   int32_t* rowptr = nullptr;
@@ -442,6 +443,7 @@ int g_pcg_fused = 1;            // amgh_pcg: 1 = the recurrence between two cycl
 int g_tail_dense_rows = 6144;   // the collapsed coarse tail: the first level with at most this many rows and everything below it become ONE dense operator (0 = off); read at amgh_finalize
 int g_tail_dense = 1;           // ... and is applied where it has been built (0 = the per-level cycle: what the operator was built from); read at every cycle
 int g_tail_dense_batch = 64;    // ... built from the library's own cycle on this many columns of the identity at a time (64 = the largest block of right-hand sides: 256^3 174 -> ~140 ms, C1 17.8 -> 12.0 ms against 32; profiles/r06_tail_dense.log); read at amgh_finalize
+int g_stream_xcd = 1;           // big SpMV-type operators whose timing at amgh_finalize asked for it run with the XCD-contiguous workgroup mapping (0 = never); read at amgh_finalize and at every launch
 int g_gs_dti_pre = 8;           // pre-pass of a dense-triangle block: rows per workgroup (8; 16 = the shape of rounds 2-5, bitwise the same); read at every sweep
 int g_gs_tri_rb1 = 0;           // ... and under a SINGLE column: rows per workgroup of the dense triangle inverses (0 = one row, tri_gemv_kernel; 2 / 4 / 8: tri_gemm_kernel<1, RB> — bitwise the same); read at every sweep
 int g_gs_tri_rb = 1;            // dense triangle inverses under a block of right-hand sides: 4 rows per workgroup (tri_gemm_kernel; 0 = one row, tri_gemv_kernel — bitwise the same); read at every sweep

@@ -64,9 +64,18 @@ using SmallCfg = StreamCfg<256, 64, 4096, 2, false, false>;
 #define AMGH_CODED_CFG 1024, 1024, 8192, 4
 #endif
 using CodedCfg = StreamCfg<AMGH_CODED_CFG, false, false>;
+// xcd: the operator asked for the XCD-contiguous mapping of its workgroups (amgh_csr::xcd_map, decided by a timing at amgh_finalize:
+// the restriction of the second level of the 256^3 hierarchy — long rows gathering from a vector eight times its own — 0.141 -> 0.108 ms;
+// every other big operator is flat or slower: profiles/r06_stream_xcd.log).  Same rows, same in-order sums.
 template <int MODE>
-int launch_stream_sized(const StreamArgs& a, hipStream_t st, int ncolv) {
+int launch_stream_sized(const StreamArgs& a, hipStream_t st, int ncolv, bool xcd = false) {
   if (a.row_end - a.row_begin < (1 << 18)) return launch_stream<MODE, SmallCfg>(a, st, ncolv);
+  if constexpr (MODE == M_SPMV) {
+    if (xcd && g_stream_xcd && ncolv == 1) {
+      if (a.ccol && (g_stream_code || !a.col)) return launch_stream<MODE, StreamCfg<1024, 1024, 8192, 4, false, true>, true>(a, st, ncolv);
+      return launch_stream<MODE, StreamCfg<1024, 1024, 8192, 4, false, true>>(a, st, ncolv);
+    }
+  }
   // value-coded columns: 4 bytes per entry (the trimmed footprint keeps ONLY them where an operator has them: a.col == nullptr)
   if (a.ccol && (g_stream_code || !a.col)) return launch_stream<MODE, CodedCfg, true>(a, st, ncolv);
   return launch_stream<MODE>(a, st, ncolv);
@@ -166,7 +175,7 @@ int csr_apply(const amgh_csr* op, int mode, const real* x, const real* b, real* 
   a.row_begin = 0; a.row_end = (int32_t)op->nrows;
   a.ldx = op->ncols; a.ldy = op->nrows; a.ldb = op->nrows;
   switch (mode) {
-    case M_SPMV: return launch_stream_sized<M_SPMV>(a, st, ncolv);
+    case M_SPMV: return launch_stream_sized<M_SPMV>(a, st, ncolv, op->xcd_map);
     case M_RESID: return launch_stream_sized<M_RESID>(a, st, ncolv);
     case M_ADD: return launch_stream_sized<M_ADD>(a, st, ncolv);
   }
