@@ -560,7 +560,7 @@ def main():
             if rc != 0:
                 raise RuntimeError(lib.amgh_strerror(rc).decode())
             xs = xd.download()
-            As = A.to_scipy().tocsr()
+            As = A.to_scipy()
             true_res = float(np.linalg.norm(b - As @ xs) / np.linalg.norm(b))
             out["pcg_to_solution"] = {"reltol": rtol, "iterations": int(its.value), "ms": t_pcg, "ms_per_iteration": t_pcg / max(1, its.value),
                                       "true_rel_residual": true_res, "setup_plus_solve_s": t_setup + 1e-3 * t_pcg,
